@@ -1,0 +1,151 @@
+"""Oracle phase tests: invariants the domain offers + agreement with the independent numpy restatement.
+
+reference: src/transfer.cpp:467-569 (P2G), :837-954 (G2P), src/mpm.cpp:277-372 (grid)."""
+import numpy as np
+import pytest
+
+from oracle import np_mpm
+from tests.common import lattice_cube, make_state, rel_l2
+
+RES, DX, DT = 32, 1.0 / 32, 1e-4
+
+
+def _cfg(orc, **kw):
+    kw.setdefault("clean_boundary", True)
+    return orc.make_config(RES, DX, DT, **kw)
+
+
+def test_p2g_conserves_mass_and_momentum(orc):
+    """sum_i m_i = sum_p m_p and sum_i (mv)_i = sum_p m_p v_p (partition of unity; the affine and stress
+    terms cancel because sum_i w_i (x_i - x_p) = 0 for quadratic B-splines)."""
+    x = lattice_cube(RES, 10, 20, DX, jitter=0.2, seed=0)
+    s = make_state(x, "jelly", DX)
+    cfg = _cfg(orc, gravity=(0, 0, 0))
+    grid = orc.p2g(cfg, s)
+    mass = s.gparams[0, 0]
+    assert np.isclose(grid[..., 3].sum(dtype=np.float64), mass * s.n, rtol=1e-5)
+    mom_p = (mass * s.v.astype(np.float64)).sum(0)
+    mom_g = grid[..., :3].reshape(-1, 3).sum(0, dtype=np.float64)
+    scale = mass * np.abs(s.v).sum()
+    assert np.allclose(mom_g, mom_p, atol=2e-6 * scale)
+
+
+def test_g2p_uniform_field(orc):
+    """a uniform grid velocity is returned exactly, with B = 0 and F unchanged (cdg = I)."""
+    x = lattice_cube(RES, 12, 18, DX, jitter=0.2, seed=1)
+    s = make_state(x, "jelly", DX)
+    cfg = _cfg(orc)
+    grid = np.zeros(orc.grid_shape(cfg), np.float32)
+    grid[..., :3] = [0.3, -0.2, 0.1]
+    grid[..., 3] = 1
+    F0, x0 = s.F.copy(), s.x.copy()
+    orc.g2p(cfg, s, grid)
+    assert np.allclose(s.v, [0.3, -0.2, 0.1], atol=1e-6)
+    assert np.abs(s.B).max() < 2e-6
+    assert np.allclose(s.F, F0, atol=1e-5)
+    assert np.allclose(s.x, x0 + DT * np.array([0.3, -0.2, 0.1]), atol=1e-7)
+
+
+def test_g2p_linear_field_gives_velocity_gradient(orc):
+    """v(x) = G x on the grid  =>  -4/dx * B == G*dx... i.e. cdg = I + dt*G (MLS-MPM exactness for affine fields)."""
+    x = lattice_cube(RES, 12, 18, DX, jitter=0.2, seed=2)
+    s = make_state(x, "jelly", DX, perturb_F=0.0)
+    cfg = _cfg(orc)
+    G = np.array([[0.1, 0.5, -0.3], [0.2, -0.4, 0.6], [-0.7, 0.3, 0.25]])
+    nx = RES + 1
+    ii, jj, kk = np.meshgrid(np.arange(nx), np.arange(nx), np.arange(nx), indexing="ij")
+    P = np.stack([ii, jj, kk], -1) * DX
+    grid = np.zeros(orc.grid_shape(cfg), np.float32)
+    grid[..., :3] = P @ G.T
+    grid[..., 3] = 1
+    x0 = s.x.copy()
+    orc.g2p(cfg, s, grid)
+    # apic_b = sum w v (x_p - x_i)/dx ;  C = -4/dx * apic_b * ... => cdg = I + dt*G
+    F_expected = np.eye(3) + DT * G
+    assert np.allclose(s.F.reshape(-1, 3, 3), F_expected, atol=2e-6)
+    assert np.allclose(s.v, x0 @ G.T, atol=2e-5)
+
+
+@pytest.mark.parametrize("mat", ["jelly", "snow", "sand", "water", "linear", "elastic", "von_mises"])
+def test_substep_matches_numpy_restatement(orc, mat):
+    """fp32 C++ oracle vs float64 numpy second opinion on one full substep, with a floor plane."""
+    x = lattice_cube(RES, 9, 15, DX, jitter=0.2, seed=3)
+    kw = dict(E=1e4) if mat in ("jelly", "linear", "elastic") else {}
+    s = make_state(x, mat, DX, perturb_F=0.02, **kw)
+    planes = [(0.0, 1.0, 0.0, -0.3)]
+    cfg = _cfg(orc, planes=planes, friction=0.4)
+    ref = np_mpm.substep((RES,) * 3, DX, DT, (0, -10, 0), s.x, s.v, s.B, s.F, s.aux, s.gid, s.gparams, s.gtype,
+                         planes=planes, friction=0.4, return_grid=True)
+    s2 = s.copy()
+    g_p2g = orc.p2g(cfg, s2)
+    assert rel_l2(g_p2g[..., 3], ref["p2g_grid"][..., 3]) < 1e-6
+    assert rel_l2(g_p2g[..., :3], ref["p2g_grid"][..., :3]) < 2e-5
+    g = orc.grid_update(cfg, g_p2g.copy())
+    assert rel_l2(g[..., :3], ref["grid"][..., :3]) < 2e-5
+    orc.g2p(cfg, s2, g)
+    assert np.abs(s2.x - ref["x"]).max() < 1e-7
+    assert rel_l2(s2.v, ref["v"]) < 2e-5
+    assert rel_l2(s2.B, ref["B"].reshape(-1, 9)) < 1e-4
+    assert rel_l2(s2.F, ref["F"].reshape(-1, 9)) < 2e-5
+    assert np.abs(s2.aux - ref["aux"]).max() < 2e-5
+
+
+def test_boundary_plane_sticky_zeroes_velocity(orc):
+    x = lattice_cube(RES, 9, 13, DX, jitter=0.1, seed=4)
+    s = make_state(x, "jelly", DX)
+    cfg = _cfg(orc, planes=[(0.0, 1.0, 0.0, -0.35)], friction=-1.0)
+    g = orc.grid_update(cfg, orc.p2g(cfg, s))
+    nx = RES + 1
+    jj = np.arange(nx)
+    phi = (jj * DX - 0.35) / DX
+    inside = (phi <= 0) & (phi >= -3)
+    gin = g[:, np.where(inside)[0]]
+    sel = gin[..., 3] > 0
+    assert sel.any()
+    assert np.abs(gin[sel][:, :3]).max() == 0
+    above = g[:, np.where(phi > 0)[0]]
+    assert np.abs(above[above[..., 3] > 0][:, :3]).max() > 0
+
+
+def test_clear_boundary(orc):
+    """src/mpm.h:269-276: deleted when any coordinate < 7 or > res-7 grid cells, or non-finite."""
+    cfg = _cfg(orc)
+    x = np.array([[0.5, 0.5, 0.5], [6.9 * DX, 0.5, 0.5], [0.5, (RES - 6.9) * DX, 0.5], [0.5, 0.5, np.nan],
+                  [7.1 * DX, 7.1 * DX, (RES - 7.1) * DX]], np.float32)
+    s = make_state(x, "jelly", DX)
+    s.v[:] = 0
+    s.v[0, 0] = np.inf
+    keep = orc.clear_boundary(cfg, s)
+    assert keep.tolist() == [False, False, False, False, True]
+    cfg2 = _cfg(orc, clean_boundary=False)
+    s.v[:] = 0
+    assert orc.clear_boundary(cfg2, s).tolist() == [True, True, True, False, True]
+
+
+def test_substep_compacts_and_keeps_ids(orc):
+    cfg = _cfg(orc)
+    x = lattice_cube(RES, 6, 9, DX)  # cells 6.. are inside the 7-cell margin for some particles
+    s = make_state(x, "jelly", DX)
+    n0 = s.n
+    keep = orc.clear_boundary(cfg, s)
+    orc.substep(cfg, s)
+    assert s.n < n0 and s.n <= keep.sum()
+    assert len(np.unique(s.ids)) == s.n
+
+
+def test_blocked_cpu_baseline_matches_plain_oracle(orc):
+    """orc_opt_run (block-sorted, 8-colour, threaded restatement of rasterize_optimized/resample_optimized)
+    produces the plain oracle's result up to fp32 summation order."""
+    x = lattice_cube(RES, 9, 17, DX, jitter=0.2, seed=5)
+    for mat in ("jelly", "sand"):
+        s = make_state(x, mat, DX, perturb_F=0.02)
+        cfg = _cfg(orc, planes=[(0.0, 1.0, 0.0, -0.3)], friction=-1.0)
+        a, b = s.copy(), s.copy()
+        for _ in range(3):
+            orc.substep(cfg, a)
+        t, ph = orc.opt_run(cfg, b, 3, threads=4)
+        assert a.n == b.n == s.n
+        assert np.abs(a.x - b.x).max() < 1e-6
+        assert rel_l2(b.v, a.v) < 1e-4
+        assert rel_l2(b.F, a.F) < 1e-5
+        assert t > 0 and all(p >= 0 for p in ph)
