@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""bench.py — particle-steps/sec of the MLS-MPM substep (sort + P2G + grid + G2P) on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N>1: launched under torch.distributed.run)
+prints ONE JSON line on rank 0.  A "step" is one substep (src/mpm.cpp:452-575) of the workload
+BASELINE.json's metric is quoted on: config C3 = 256^3 grid, 100^3 cells x 8 = 8 000 000 Drucker-Prager sand
+particles, fp32, inputs resident in HBM before the timed region.
+
+Extra objects on the line:
+  roofline      dominant kernel (the slower of k_p2g / k_g2p): algorithmic bytes per launch / its average launch
+                duration, measured with hipEvents recorded on the ctx stream around every phase of every timed
+                substep (mpmhip_set_profiling).  Algorithmic bytes per particle: P2G 100 B particle
+                read + 16 B per touched grid node written; G2P 52 B read + 100 B written + 16 B per touched node read.
+  cpu_baseline  the block-sorted, 8-colour, OpenMP restatement of the reference's optimised CPU path
+                (oracle/mpm_oracle_opt.cpp, kind "port") timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (res, cube cells, material, kwargs)
+    "c3": dict(res=256, cells=100, material="sand", desc="256^3 grid, 100^3 cells x 8 = 8M Drucker-Prager sand particles (BASELINE configs[2])"),
+    "c2": dict(res=128, cells=50, material="jelly", desc="128^3 grid, 50^3 cells x 8 = 1M fixed-corotated jelly particles (BASELINE configs[1])"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def build_sim(tm, cfg, device):
+    res, cells = cfg["res"], cfg["cells"]
+    lo = res // 2 - cells // 2
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(res,) * 3, delta_x=1.0 / res, base_delta_t=1e-4,
+                                                       gravity=(0, -10, 0), device=device))
+    sim.set_levelset(tm.mpm.LevelSet(friction=-1.0).add_plane((0, 1, 0), d=-0.1))  # sticky floor y = 0.1
+    sim.add_particles(dict(type=cfg["material"], cube=(lo, lo + cells)))
+    return sim
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """restated reference algorithm (CPU) on a bounded sample: same grid/material/ppc, a smaller cube."""
+    from oracle import oracle as orc
+    from taichi_mpm_amd.mpm import lattice_cube
+    res = cfg["res"]
+    dx = 1.0 / res
+    cells = 40 if res >= 256 else 32
+    lo = res // 2 - cells // 2
+    x = lattice_cube(lo, lo + cells, dx)
+    vol = dx ** 3 / 8
+    gp, t = orc.group_params(cfg["material"], 400.0 * vol, vol)
+    aux = np.full(len(x), orc.initial_aux(cfg["material"]), np.float32)
+    s = orc.State(x, None, None, None, aux, None, gp[None], np.array([t], np.int32))
+    ocfg = orc.make_config(res, dx, 1e-4, planes=[(0, 1, 0, -0.1)], friction=-1.0)
+    threads = os.cpu_count() or 1
+    orc.opt_run(ocfg, s, 1, threads)  # warm-up (page faults, first sort)
+    steps, total, phases = 0, 0.0, np.zeros(4)
+    t0 = time.time()
+    while total < budget_s and steps < 50 and time.time() - t0 < 3 * budget_s:
+        sec, ph = orc.opt_run(ocfg, s, 2, threads)
+        total += sec; steps += 2; phases += np.array(ph)
+    n = len(x)
+    return {"value": n * steps / total, "unit": "particle-steps/s", "cores": threads, "kind": "port",
+            "sample": "%d^3 cells x 8 = %d %s particles on the %d^3 grid, %d substeps, all %d host threads (OpenMP); "
+                      "block-sorted 8-colour restatement of rasterize_optimized/resample_optimized, not the reference binary"
+                      % (cells, n, cfg["material"], res, steps, threads),
+            "p2g_ns_per_particle": 1e9 * phases[1] / (n * steps), "g2p_ns_per_particle": 1e9 * phases[3] / (n * steps),
+            "sort_ns_per_particle": 1e9 * phases[0] / (n * steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import taichi_mpm_amd as tm
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = CONFIGS[args.config]
+    from taichi_mpm_amd import tiling
+    job = tiling.make_job(tm, cfg, rank, world, local_rank, build_sim)
+    n_local = job.num_particles()
+    job.run(args.warmup)
+    job.synchronize()
+    job.set_profiling(True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    job.run(args.steps)
+    job.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        nt = torch.tensor([n_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(nt, op=dist.ReduceOp.SUM)
+        n_total = int(nt.item())
+    else:
+        n_total = n_local
+    prof = job.profile()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms = {k: v / max(prof["substeps"], 1) for k, v in prof["phases"].items()}
+    n_per_gpu = prof["particles"]
+    nodes = prof["active_blocks"] * 64.0  # touched 4^3 blocks x 64 nodes (upper bound of touched nodes)
+    per_launch = {"p2g": n_per_gpu * 100.0 + nodes * 16.0, "g2p": n_per_gpu * 152.0 + nodes * 16.0}
+    dom = max(("p2g", "g2p"), key=lambda k: ms[k])
+    achieved = per_launch[dom] / (ms[dom] * 1e-3) / 1e9
+    value = n_total * args.steps / elapsed
+    whole_step_bytes = n_per_gpu * 252.0 + nodes * 16.0 * 5
+    out = {
+        "metric": "particle-steps/sec (P2G+grid+G2P), 256^3 grid 8M particles; %HBM roofline",
+        "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": job.scaling,
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": cfg["desc"], "particles": n_total, "dt": 1e-4, "parallelism": job.parallelism,
+                   "timed": "full substep: sort+reorder, P2G, grid normalise+boundary, G2P, boundary cleanup"},
+        "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": per_launch[dom], "avg_launch_ms": ms[dom]},
+        "phases_ms_per_step": ms,
+        "p2g_plus_g2p_particle_steps_per_s": n_per_gpu / ((ms["p2g"] + ms["g2p"]) * 1e-3),
+        "whole_step_hbm_frac_algorithmic": whole_step_bytes / (1e-3 * sum(ms.values())) / 1e9 / HBM_PEAK_GBS,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        except Exception as e:  # the baseline is a reported extra: never lose the GPU line because of it
+            out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,158 @@
+/* include/mpmhip.h — C ABI of the MI355X-native MLS-MPM time-stepping core (libmpmhip.so).
+ *
+ * This is the drop-in boundary for the hot path of yuanming-hu/taichi_mpm: the per-substep
+ * sequence  sort -> P2G -> grid normalise + boundary -> G2P -> boundary cleanup  that the
+ * reference runs on the CPU inside `MPM<3>::substep()` (src/mpm.cpp:452-575).  The reference has
+ * no C ABI (it is a factory-registered C++ class reached through pybind11, src/mpm.cpp:983-988);
+ * each entry point below names the reference interface it replaces, and INTEGRATION.md shows the
+ * binding a maintainer of the reference would add on top of it.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; `void* stream` is a hipStream_t.
+ *   - every function returns 0 on success or a negative MPMHIP_E* code; it never throws.
+ *     `mpmhip_last_error()` returns a human-readable message for the last failure on that ctx
+ *     (reference behaviour: TC_ASSERT/TC_ERROR abort, e.g. src/mpm.cpp:41-42,154,162,775).
+ *   - host buffers are caller-owned; `*_dev` variants take device pointers.
+ *   - one ctx per GPU; calls on one ctx must be serialised by the caller (reference: not
+ *     re-entrant either).
+ *   - 3x3 matrices are row-major float[9]; `B` is the reference's `apic_b` (sign/units of
+ *     src/transfer.cpp:898-903: B = sum_i w_i v_i (x_p - x_i)^T / dx).
+ */
+#ifndef MPMHIP_H
+#define MPMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPMHIP_ABI_VERSION 1
+
+enum {
+  MPMHIP_OK = 0,
+  MPMHIP_EINVAL = -1,    /* bad argument / unsupported configuration */
+  MPMHIP_ENOMEM = -2,    /* device or host allocation failed, or capacity exceeded */
+  MPMHIP_EHIP = -3,      /* a HIP runtime call failed (message in last_error) */
+  MPMHIP_ECAPACITY = -4, /* more particles / active blocks than the ctx was created for */
+  MPMHIP_ENOTIMPL = -5
+};
+
+/* material ids == y component of MPMParticle::get_debug_info() (src/particles.cpp:157..839);
+ * names are the factory aliases of TC_REGISTER_MPM_PARTICLE (src/particles.cpp:849-856). */
+enum {
+  MPMHIP_VISCO = 1, /* not implemented on device yet: add_group returns MPMHIP_ENOTIMPL */
+  MPMHIP_SNOW = 2,
+  MPMHIP_LINEAR = 3,
+  MPMHIP_JELLY = 4,
+  MPMHIP_WATER = 5,
+  MPMHIP_SAND = 6,
+  MPMHIP_VON_MISES = 7,
+  MPMHIP_ELASTIC = 8
+};
+
+#define MPMHIP_NPARAM 16
+/* per-group parameter row float[16] (a "group" = one add_particles() call of the reference,
+ * src/mpm.cpp:77-148: same type, same material constants, mass = vol*density):
+ *   [0] mass [1] vol
+ *   snow      [2] mu_0 [3] lambda_0 [4] hardening [5] theta_c [6] theta_s [7] min_Jp [8] max_Jp ; aux = Jp
+ *   linear    [2] mu   [3] lambda
+ *   jelly     [2] mu   [3] lambda
+ *   water     [2] k    [3] gamma                                                             ; aux = j
+ *   sand      [2] mu_0 [3] lambda_0 [4] alpha [5] cohesion [6] beta                           ; aux = logJp
+ *   von_mises [2] mu_0 [3] lambda_0 [4] yield_stress
+ *   elastic   [2] mu_0 [3] lambda_0
+ */
+
+/* replaces: Config keys read by MPM<dim>::initialize (src/mpm.cpp:26-75) */
+typedef struct {
+  int32_t res[3];           /* "res": cells per axis (nodes = res+1) */
+  float dx;                 /* "delta_x" (python default 1/res[0], scripts/async/async_mpm.py:40-41) */
+  float dt;                 /* "base_delta_t" * "dt_multiplier" */
+  float gravity[3];         /* "gravity" (default (0,-10,0)) */
+  int32_t particle_gravity; /* "particle_gravity" (default 1): gravity added to particles before P2G */
+  float apic_damping;       /* "apic_damping" */
+  float rpic_damping;       /* "rpic_damping" */
+  int32_t clean_boundary;   /* "clean_boundary" (default 1): src/mpm.cpp:563-565 */
+  /* analytic level set (replaces set_levelset(DynamicLevelSet)): up to 8 half-spaces
+   * phi(x) = n.x + d in world units (|n| = 1), combined with min(); phi<0 inside the solid */
+  int32_t n_planes;
+  float planes[8][4];
+  float friction;           /* levelset friction code: -1 sticky, <=-2 slip, >=0 separate (README.md:326-330) */
+  int64_t max_particles;    /* capacity of the SoA pools (reference: < 2^25, src/mpm.cpp:773-775) */
+  int64_t max_blocks;       /* capacity of the active-block table; 0 = choose from max_particles */
+  int32_t device;           /* HIP device ordinal */
+  int32_t reserved[7];
+} mpmhip_config;
+
+typedef struct mpmhip_ctx mpmhip_ctx;
+
+/* particle fields for upload/download; element = one particle's record of `width` scalars */
+enum {
+  MPMHIP_F_X = 0,   /* float[3]  position (world units)                MPMParticle::pos      */
+  MPMHIP_F_V = 1,   /* float[3]  velocity                              get_velocity()        */
+  MPMHIP_F_B = 2,   /* float[9]  apic_b                                MPMParticle::apic_b   */
+  MPMHIP_F_F = 3,   /* float[9]  elastic deformation gradient          MPMParticle::dg_e     */
+  MPMHIP_F_AUX = 4, /* float[1]  Jp | j | logJp (material state)                             */
+  MPMHIP_F_GID = 5, /* int32[1]  group id                                                    */
+  MPMHIP_F_ID = 6   /* int32[1]  creation index (MPMParticle::id semantics for download ordering) */
+};
+
+uint32_t mpmhip_abi_version(void);
+
+/* lifecycle — replaces create_instance<Simulation3D>("mpm") + MPM<3>::initialize (src/mpm.cpp:26-75) */
+int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out);
+void mpmhip_destroy(mpmhip_ctx *ctx);
+const char *mpmhip_last_error(const mpmhip_ctx *ctx); /* ctx may be NULL: last create() failure */
+int mpmhip_set_stream(mpmhip_ctx *ctx, void *hip_stream); /* NULL = the ctx's own stream */
+/* replaces Simulation::set_levelset(DynamicLevelSet) (scripts/async/async_mpm.py:119-127) for analytic half-spaces */
+int mpmhip_set_levelset(mpmhip_ctx *ctx, int32_t n_planes, const float *planes /* [n][4] */, float friction);
+
+/* particles — replaces MPM<3>::add_particles (src/mpm.cpp:77-270) with caller-generated samples.
+ * add_group returns the group id (>=0) or a negative error. F/B/aux may be NULL (identity/0/material default). */
+int mpmhip_add_group(mpmhip_ctx *ctx, int32_t material, const float params[MPMHIP_NPARAM]);
+int mpmhip_add_particles(mpmhip_ctx *ctx, int32_t group, int64_t n, const float *x, const float *v,
+                         const float *F, const float *B, const float *aux);
+int64_t mpmhip_num_particles(mpmhip_ctx *ctx); /* synchronises; <0 on error */
+int mpmhip_download(mpmhip_ctx *ctx, int32_t field, void *dst, int64_t n_capacity); /* returns n written */
+int mpmhip_upload(mpmhip_ctx *ctx, int32_t field, const void *src, int64_t n);
+
+/* time stepping — replaces MPM<3>::step / substep (src/mpm.cpp:428-450, 452-575) */
+int mpmhip_substep(mpmhip_ctx *ctx);                 /* one substep, asynchronous on the ctx stream */
+int mpmhip_run_substeps(mpmhip_ctx *ctx, int32_t n); /* n substeps back to back */
+int mpmhip_step(mpmhip_ctx *ctx, float dt);          /* step(dt): dt<0 => one substep; else while (t + base_dt < request_t) substep */
+double mpmhip_current_time(const mpmhip_ctx *ctx);   /* get_current_time() */
+int mpmhip_synchronize(mpmhip_ctx *ctx);
+
+/* phase-level entry points (parity tests) — each replaces the named reference function */
+int mpmhip_sort(mpmhip_ctx *ctx);        /* sort_particles_and_populate_grid  src/mpm.cpp:770-918 (+ clear_boundary_particles :582-633) */
+int mpmhip_p2g(mpmhip_ctx *ctx);         /* rasterize_optimized               src/transfer.cpp:361-581 */
+int mpmhip_grid_update(mpmhip_ctx *ctx); /* normalize_grid_and_apply_external_force + apply_grid_boundary_conditions  src/mpm.cpp:277-372 */
+int mpmhip_g2p(mpmhip_ctx *ctx);         /* resample_optimized                src/transfer.cpp:702-970 */
+
+/* dense grid views, node-major float[(rx+1)(ry+1)(rz+1)][4], z fastest.
+ *   which=0: (m*v, m) accumulated by P2G;  which=1: (v, m) after grid_update.
+ * upload_grid installs a dense (v, m) field as the input of the next mpmhip_g2p (needs a prior sort). */
+int mpmhip_download_grid(mpmhip_ctx *ctx, int32_t which, float *dst);
+int mpmhip_upload_grid(mpmhip_ctx *ctx, const float *src);
+
+/* profiling — replaces TC_PROFILE / TC_PROFILE_TPE scoped timers (src/mpm.cpp:464-572).
+ * When enabled, hipEvents bracket each phase of every substep on the ctx stream.
+ * mpmhip_profile writes a JSON object: {"substeps":N,"particles":n,"active_blocks":a,
+ *   "phases":{"sort":ms,"p2g":ms,"grid":ms,"g2p":ms}}  (totals since the last reset). */
+int mpmhip_set_profiling(mpmhip_ctx *ctx, int32_t enabled);
+int mpmhip_profile(mpmhip_ctx *ctx, char *json, size_t cap);
+int mpmhip_profile_reset(mpmhip_ctx *ctx);
+
+/* debug/parity helpers running the device math on host arrays (n items each) */
+int mpmhip_debug_svd3(mpmhip_ctx *ctx, int64_t n, const float *F, float *U, float *S, float *V);
+int mpmhip_debug_force(mpmhip_ctx *ctx, int32_t material, const float params[MPMHIP_NPARAM], int64_t n,
+                       const float *F, const float *aux, float *out);
+int mpmhip_debug_plasticity(mpmhip_ctx *ctx, int32_t material, const float params[MPMHIP_NPARAM], int64_t n,
+                            const float *cdg, float *F, float *aux);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPMHIP_H */

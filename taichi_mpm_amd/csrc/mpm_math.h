@@ -1,0 +1,293 @@
+// taichi_mpm_amd/csrc/mpm_math.h — device-side 3x3 math and constitutive models (gfx950, VALU only).
+//
+// The 3x3 tensor work of MLS-MPM stays in vector registers (no MFMA: nothing here is GEMM-shaped).
+// Design note: every constitutive model of the reference (src/particles.cpp) is isotropic, so both
+// `calculate_force()` (= -V0 * P F^T, a function of the LEFT stretch only) and the return-mapping
+// part of `plasticity()` (F <- U f(S) V^T = U diag(f(s_i)/s_i) U^T F) can be written with U and the
+// singular values alone.  U and s_i^2 are the eigen-pairs of the symmetric matrix F F^T, so the
+// device never forms V: one cyclic-Jacobi eigen-solve of a symmetric 3x3 per call instead of a full
+// SVD.  This is mathematically identical to the reference's svd()/polar_decomp() route
+// (src/particles.cpp:76,212,227,394,630,642) and is checked against the CPU oracle in tests/.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/mpmhip.h"
+
+namespace mpm {
+
+struct mat3 {
+  float m[9];  // row-major
+  __device__ __forceinline__ float &operator()(int r, int c) { return m[3 * r + c]; }
+  __device__ __forceinline__ float operator()(int r, int c) const { return m[3 * r + c]; }
+};
+
+__device__ __forceinline__ mat3 mat_identity() {
+  mat3 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.m[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+  return r;
+}
+__device__ __forceinline__ mat3 mat_mul(const mat3 &A, const mat3 &B) {
+  mat3 C;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) C(r, c) = fmaf(A(r, 0), B(0, c), fmaf(A(r, 1), B(1, c), A(r, 2) * B(2, c)));
+  return C;
+}
+// A * B^T
+__device__ __forceinline__ mat3 mat_mul_bt(const mat3 &A, const mat3 &B) {
+  mat3 C;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) C(r, c) = fmaf(A(r, 0), B(c, 0), fmaf(A(r, 1), B(c, 1), A(r, 2) * B(c, 2)));
+  return C;
+}
+__device__ __forceinline__ float mat_det(const mat3 &m) {
+  return m(0, 0) * (m(1, 1) * m(2, 2) - m(1, 2) * m(2, 1)) - m(0, 1) * (m(1, 0) * m(2, 2) - m(1, 2) * m(2, 0)) +
+         m(0, 2) * (m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0));
+}
+
+// One Jacobi rotation annihilating a_pq of the symmetric matrix {app,aqq,arr,apq,apr,aqr};
+// r is the third index.  U's columns p,q are rotated along.  Branch-free: t = 0 when a_pq = 0.
+__device__ __forceinline__ void jacobi_rotate(float &app, float &aqq, float &apq, float &arp, float &arq,
+                                              float &u0p, float &u0q, float &u1p, float &u1q, float &u2p,
+                                              float &u2q) {
+  const float d = aqq - app;
+  // t = tan(phi): root of t^2 + 2 theta t - 1 = 0 with theta = d/(2 a_pq), in the cancellation-free form
+  const float den = fabsf(d) + sqrtf(fmaf(d, d, 4.0f * apq * apq));
+  const float t = (den > 0.0f) ? copysignf(2.0f * apq, d * apq) / den : 0.0f;
+  const float c = rsqrtf(fmaf(t, t, 1.0f));
+  const float s = t * c;
+  app = fmaf(-t, apq, app);
+  aqq = fmaf(t, apq, aqq);
+  apq = 0.0f;
+  const float nrp = c * arp - s * arq, nrq = s * arp + c * arq;
+  arp = nrp; arq = nrq;
+  float n;
+  n = c * u0p - s * u0q; u0q = s * u0p + c * u0q; u0p = n;
+  n = c * u1p - s * u1q; u1q = s * u1p + c * u1q; u1p = n;
+  n = c * u2p - s * u2q; u2q = s * u2p + c * u2q; u2p = n;
+}
+
+constexpr int kJacobiSweeps = 4;
+
+// Eigen-decomposition of the symmetric positive semi-definite A = F F^T:  A = U diag(lam) U^T.
+// U is a proper rotation (product of Givens rotations).  Unsorted.
+__device__ __forceinline__ void sym_eig3_FFt(const mat3 &F, mat3 &U, float lam[3]) {
+  float a00 = fmaf(F(0, 0), F(0, 0), fmaf(F(0, 1), F(0, 1), F(0, 2) * F(0, 2)));
+  float a11 = fmaf(F(1, 0), F(1, 0), fmaf(F(1, 1), F(1, 1), F(1, 2) * F(1, 2)));
+  float a22 = fmaf(F(2, 0), F(2, 0), fmaf(F(2, 1), F(2, 1), F(2, 2) * F(2, 2)));
+  float a01 = fmaf(F(0, 0), F(1, 0), fmaf(F(0, 1), F(1, 1), F(0, 2) * F(1, 2)));
+  float a02 = fmaf(F(0, 0), F(2, 0), fmaf(F(0, 1), F(2, 1), F(0, 2) * F(2, 2)));
+  float a12 = fmaf(F(1, 0), F(2, 0), fmaf(F(1, 1), F(2, 1), F(1, 2) * F(2, 2)));
+  U = mat_identity();
+#pragma unroll
+  for (int sweep = 0; sweep < kJacobiSweeps; sweep++) {
+    jacobi_rotate(a00, a11, a01, a02, a12, U.m[0], U.m[1], U.m[3], U.m[4], U.m[6], U.m[7]);  // (p,q,r)=(0,1,2)
+    jacobi_rotate(a00, a22, a02, a01, a12, U.m[0], U.m[2], U.m[3], U.m[5], U.m[6], U.m[8]);  // (0,2,1)
+    jacobi_rotate(a11, a22, a12, a01, a02, U.m[1], U.m[2], U.m[4], U.m[5], U.m[7], U.m[8]);  // (1,2,0)
+  }
+  lam[0] = a00; lam[1] = a11; lam[2] = a22;
+}
+
+// Signed singular values in U's (unsorted) column order: s_i = sqrt(lam_i); if det F < 0 the sign goes
+// on the smallest one (the oracle's / taichi's convention: U,V rotations, sign on the last sigma).
+__device__ __forceinline__ void signed_sigma(const float lam[3], float detF, float s[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) s[i] = sqrtf(fmaxf(lam[i], 0.0f));
+  if (detF < 0.0f) {
+    int k = (s[0] <= s[1]) ? ((s[0] <= s[2]) ? 0 : 2) : ((s[1] <= s[2]) ? 1 : 2);
+    if (k == 0) s[0] = -s[0];
+    else if (k == 1) s[1] = -s[1];
+    else s[2] = -s[2];
+  }
+}
+
+// U diag(d) U^T
+__device__ __forceinline__ mat3 sandwich(const mat3 &U, const float d[3]) {
+  mat3 R;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = r; c < 3; c++) {
+      float v = fmaf(U(r, 0) * d[0], U(c, 0), fmaf(U(r, 1) * d[1], U(c, 1), U(r, 2) * d[2] * U(c, 2)));
+      R(r, c) = v;
+      R(c, r) = v;
+    }
+  return R;
+}
+
+struct GroupParams {
+  float p[MPMHIP_NPARAM];
+  int32_t type;
+  int32_t pad[3];
+};
+
+// calculate_force(): returns -vol * P(F) * F^T  (src/particles.h:134-137; bodies in src/particles.cpp)
+__device__ __forceinline__ mat3 calculate_force(const GroupParams &g, const mat3 &F, float aux) {
+  const float vol = g.p[1];
+  mat3 out;
+  switch (g.type) {
+    case MPMHIP_JELLY:   // src/particles.cpp:391-411  P = 2mu(F-R) + lambda (J-1) J F^-T
+    case MPMHIP_SNOW: {  // src/particles.cpp:207-220, 244-252 (mu,lambda scaled by exp(h(1-Jp)))
+      float mu = g.p[2], la = g.p[3];
+      if (g.type == MPMHIP_SNOW) {
+        const float e = expf(g.p[4] * (1.0f - aux));
+        mu *= e; la *= e;
+      }
+      mat3 U; float lam[3], s[3];
+      sym_eig3_FFt(F, U, lam);
+      const float J = mat_det(F);
+      signed_sigma(lam, J, s);
+      // (F-R)F^T = U (S^2 - S) U^T ;  lambda (J-1) J F^-T F^T = lambda (J-1) J I
+      const float vol_l = la * (J - 1.0f) * J;
+      float d[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) d[i] = -vol * fmaf(2.0f * mu, lam[i] - s[i], vol_l);
+      out = sandwich(U, d);
+      break;
+    }
+    case MPMHIP_LINEAR: {  // src/particles.cpp:329-336
+      const float mu = g.p[2], la = g.p[3];
+      const float tr = la * (F(0, 0) + F(1, 1) + F(2, 2) - 3.0f);
+      mat3 P;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) P(r, c) = mu * (F(r, c) + F(c, r) - ((r == c) ? 2.0f : 0.0f)) + ((r == c) ? tr : 0.0f);
+      out = mat_mul_bt(P, F);
+#pragma unroll
+      for (int i = 0; i < 9; i++) out.m[i] *= -vol;
+      break;
+    }
+    case MPMHIP_WATER: {  // src/particles.cpp:463-467: -vol * j * (-p I), p = k (j^-gamma - 1)
+      const float j = aux;
+      const float p = g.p[2] * (powf(j, -g.p[3]) - 1.0f);
+      const float dd = vol * j * p;
+#pragma unroll
+      for (int i = 0; i < 9; i++) out.m[i] = (i % 4 == 0) ? dd : 0.0f;
+      break;
+    }
+    case MPMHIP_SAND:       // src/particles.cpp:628-637
+    case MPMHIP_VON_MISES:  // :701-711
+    case MPMHIP_ELASTIC: {  // :798-807   P F^T = U (2 mu ln S + lambda tr(ln S) I) U^T
+      const float mu = g.p[2], la = g.p[3];
+      mat3 U; float lam[3], s[3];
+      sym_eig3_FFt(F, U, lam);
+      signed_sigma(lam, mat_det(F), s);
+      float ls[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) ls[i] = logf(s[i]);  // log of a negative sigma is NaN, as in the reference (:631)
+      const float tr = ls[0] + ls[1] + ls[2];
+      float d[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) d[i] = -vol * fmaf(2.0f * mu, ls[i], la * tr);
+      out = sandwich(U, d);
+      break;
+    }
+    default:
+#pragma unroll
+      for (int i = 0; i < 9; i++) out.m[i] = 0.0f;
+  }
+  return out;
+}
+
+// plasticity(cdg): F <- cdg F, then the material's return mapping (src/particles.h:139-141).
+__device__ __forceinline__ void plasticity(const GroupParams &g, const mat3 &cdg, mat3 &F, float &aux) {
+  if (g.type == MPMHIP_WATER) {  // src/particles.cpp:469-478 (dg_e is never touched for water)
+    float j = aux * (cdg(0, 0) + cdg(1, 1) + cdg(2, 2) - 2.0f);
+    aux = (j < 0.1f) ? 0.1f : j;
+    return;
+  }
+  F = mat_mul(cdg, F);
+  if (g.type == MPMHIP_JELLY || g.type == MPMHIP_LINEAR || g.type == MPMHIP_ELASTIC) return;  // :413-416,:338-341,:809-812
+  mat3 U; float lam[3], s[3];
+  sym_eig3_FFt(F, U, lam);
+  signed_sigma(lam, mat_det(F), s);
+  float ratio[3];  // f(s_i) / s_i
+  if (g.type == MPMHIP_SNOW) {  // src/particles.cpp:222-242
+    const float lo = 1.0f - g.p[5], hi = 1.0f + g.p[6];
+    float det_o = 1.0f, det_n = 1.0f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const float c = fminf(fmaxf(s[i], lo), hi);
+      det_o *= s[i];
+      det_n *= c;
+      ratio[i] = c / s[i];
+    }
+    float Jp = aux * det_o / det_n;
+    if (!(Jp <= g.p[8])) Jp = g.p[8];
+    if (!(Jp >= g.p[7])) Jp = g.p[7];
+    aux = Jp;
+  } else if (g.type == MPMHIP_SAND) {  // src/particles.cpp:599-626, 639-647
+    const float mu = g.p[2], la = g.p[3], alpha = g.p[4], coh = g.p[5], beta = g.p[6];
+    float eps[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) eps[i] = logf(fmaxf(fabsf(s[i]), 1e-4f)) - coh;
+    const float sum = eps[0] + eps[1] + eps[2];
+    const float tr = sum + aux;
+    float eh[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) eh[i] = eps[i] - tr * (1.0f / 3.0f);
+    const float ehn = sqrtf(fmaf(eh[0], eh[0], fmaf(eh[1], eh[1], eh[2] * eh[2])));
+    float ns[3];
+    if (tr >= 0.0f) {
+      const float e = expf(coh);
+      ns[0] = e; ns[1] = e; ns[2] = e;
+      aux = fmaf(beta, sum, aux);
+    } else {
+      aux = 0.0f;
+      const float dg = ehn + (3.0f * la + 2.0f * mu) / (2.0f * mu) * tr * alpha;
+      const float k = (dg <= 0.0f) ? 0.0f : dg / ehn;
+#pragma unroll
+      for (int i = 0; i < 3; i++) ns[i] = expf(eps[i] - k * eh[i] + coh);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) ratio[i] = ns[i] / s[i];
+  } else if (g.type == MPMHIP_VON_MISES) {  // src/particles.cpp:713-732
+    float e[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) e[i] = logf(s[i]);
+    const float tr = e[0] + e[1] + e[2];
+    float eh[3] = {e[0] - tr * (1.0f / 3.0f), e[1] - tr * (1.0f / 3.0f), e[2] - tr * (1.0f / 3.0f)};
+    const float n2 = fmaf(eh[0], eh[0], fmaf(eh[1], eh[1], eh[2] * eh[2]));  // frobenius_norm2 (squared, as in the reference)
+    const float dg = n2 - g.p[4] / (2.0f * g.p[2]);
+    if (dg <= 0.0f) return;
+#pragma unroll
+    for (int i = 0; i < 3; i++) ratio[i] = expf(e[i] - (dg / n2) * eh[i]) / s[i];
+  } else {
+    return;
+  }
+  // F <- U diag(ratio) U^T F
+  F = mat_mul(sandwich(U, ratio), F);
+}
+
+// friction_project — src/mpm_fwd.h:25-57
+__device__ __forceinline__ void friction_project(float v[3], const float vb[3], const float n[3], float friction) {
+  if (friction == -1.0f) { v[0] = vb[0]; v[1] = vb[1]; v[2] = vb[2]; return; }
+  const bool slip = friction <= -2.0f;
+  if (slip) friction = -friction - 2.0f;
+  const float r0 = v[0] - vb[0], r1 = v[1] - vb[1], r2 = v[2] - vb[2];
+  const float nn = n[0] * r0 + n[1] * r1 + n[2] * r2;
+  const float t0 = r0 - nn * n[0], t1 = r1 - nn * n[1], t2 = r2 - nn * n[2];
+  const float tn = sqrtf(t0 * t0 + t1 * t1 + t2 * t2);
+  const float ts = fmaxf(tn + fminf(nn, 0.0f) * friction, 0.0f) / fmaxf(1e-30f, tn);
+  const float keep = slip ? 0.0f : fmaxf(0.0f, nn);
+  v[0] = ts * t0 + keep * n[0] + vb[0];
+  v[1] = ts * t1 + keep * n[1] + vb[1];
+  v[2] = ts * t2 + keep * n[2] + vb[2];
+}
+
+// quadratic B-spline weights of MLSMPMFastKernel32 (src/transfer.cpp:168-186; src/kernel.h:126-130):
+// p = rel_pos - 0.5 in [0,1);  t = p - (-0.5, 0.5, 1.5);  w = fma(c2, t*t, fma(c1, t, c0))
+__device__ __forceinline__ void bspline_weights(float rel, float w[3]) {
+  const float p = rel - 0.5f;
+  const float t0 = p + 0.5f, t1 = p - 0.5f, t2 = p - 1.5f;
+  w[0] = fmaf(0.5f, t0 * t0, fmaf(-1.5f, t0, 1.125f));
+  w[1] = fmaf(-1.0f, t1 * t1, 0.75f);
+  w[2] = fmaf(0.5f, t2 * t2, fmaf(1.5f, t2, 1.125f));
+}
+
+}  // namespace mpm

@@ -1,0 +1,458 @@
+"""Host-side mirror of the reference's MPM plugin surface, on top of the C ABI (include/mpmhip.h).
+
+Two layers, as in the reference:
+  * `Simulation3D` == the object `tc_core.create_simulation3('mpm')` returns (class MPM<3>, src/mpm.h:56-489):
+    `initialize(config)`, `add_particles(config) -> str`, `set_levelset(ls)`, `step(dt)`,
+    `get_current_time()`, `general_action(config) -> str`, `test()`, `get_debug_information()`,
+    `visualize()`, `get_mpi_world_rank()`, attribute `frame`  (scripts/async/async_mpm.py:25-32,76-287).
+  * `MPM` == the Python driver class scene scripts instantiate (`tc.dynamics.MPM(**kwargs)`; the twin that IS in
+    the reference tree is AsyncMPM, scripts/async/async_mpm.py:17-300): kwargs config, `add_particles(**kw)`,
+    `set_levelset`, `step`, `simulate`.
+
+Configs are flat dicts (reference: taichi `Config`, string->string; `P(**kwargs)`).  Errors raise `MPMError`
+(reference: TC_ASSERT / TC_ERROR abort).  Scene tooling the hot path does not need (textures, meshes, Poisson-disk
+sampling, rigid bodies, rendering) is out of scope: `add_particles` takes explicit `positions=` or the built-in
+`benchmark=` generator (src/mpm.cpp:149-186) or a `cube=(lo, hi)` lattice.
+"""
+import ctypes as C
+import json
+
+import numpy as np
+
+from . import _lib
+from .materials import MATERIAL_IDS, group_params, initial_aux
+
+F_X, F_V, F_B, F_F, F_AUX, F_GID, F_ID = range(7)
+_WIDTH = {F_X: 3, F_V: 3, F_B: 9, F_F: 9, F_AUX: 1, F_GID: 1, F_ID: 1}
+
+
+class MPMError(RuntimeError):
+    pass
+
+
+class LevelSet:
+    """Analytic stand-in for taichi's LevelSet (scripts/async/async_mpm.py:129-137 `create_levelset`):
+    a union of half-space solids with one friction code (README.md:326-330)."""
+
+    def __init__(self, friction=-1.0):
+        self.friction = float(friction)
+        self.planes = []
+
+    def set_friction(self, f):
+        self.friction = float(f)
+
+    def add_plane(self, normal, d=None, point=None):
+        """free space is { x : n.x + d > 0 }.  Either `d` or a `point` on the plane."""
+        n = np.asarray(normal, np.float64)
+        n = n / np.linalg.norm(n)
+        if d is None:
+            d = -float(np.dot(n, np.asarray(point, np.float64)))
+        if len(self.planes) >= 8:
+            raise MPMError("at most 8 planes are supported")
+        self.planes.append((float(n[0]), float(n[1]), float(n[2]), float(d)))
+        return self
+
+
+def _vec3(v, default):
+    if v is None:
+        v = default
+    if np.isscalar(v):
+        return (float(v),) * 3
+    v = tuple(float(a) for a in v)
+    if len(v) != 3:
+        raise MPMError("expected a 3-vector, got %r" % (v,))
+    return v
+
+
+class Simulation3D:
+    """MPM<3> (src/mpm.h:56-489) backed by libmpmhip."""
+
+    def __init__(self):
+        self._L = _lib.load()
+        self._ctx = None
+        self._cfg = None
+        self._staged = []  # (group params, material, arrays) before the ctx exists
+        self._groups = []  # (material id, params) in ctx order
+        self._levelset = None
+        self.frame = 0
+        self.config = {}
+        self._n_added = 0
+
+    # ---------------------------------------------------------------- lifecycle
+    def initialize(self, config):
+        """MPM<dim>::initialize, src/mpm.cpp:26-75 (keys: README.md:234-256)."""
+        cfg = dict(config)
+        if "delta_t" in cfg:  # src/mpm.cpp:41-42
+            raise MPMError("Please use 'base_delta_t' instead of 'delta_t'")
+        if "res" not in cfg:
+            raise MPMError("config key 'res' is required")
+        res = cfg["res"]
+        res = (int(res),) * 3 if np.isscalar(res) else tuple(int(r) for r in res)
+        if len(res) != 3:
+            raise MPMError("this build implements the 3D path (MPM<3>); res must have 3 entries")
+        self.res = res
+        self.delta_x = float(cfg.get("delta_x", 1.0 / res[0]))  # python default, async_mpm.py:40-41
+        self.base_delta_t = float(cfg.get("base_delta_t", 1e-4)) * float(cfg.get("dt_multiplier", 1.0))
+        self.gravity = _vec3(cfg.get("gravity"), (0.0, -10.0, 0.0))
+        self.particle_gravity = bool(cfg.get("particle_gravity", True))
+        self.apic_damping = float(cfg.get("apic_damping", 0.0))
+        self.rpic_damping = float(cfg.get("rpic_damping", 0.0))
+        self.clean_boundary = bool(cfg.get("clean_boundary", True))
+        self.max_particles = int(cfg.get("max_particles", 0))
+        self.max_blocks = int(cfg.get("max_blocks", 0))
+        self.device = int(cfg.get("device", 0))
+        self.config = cfg
+        return self
+
+    def _create(self, capacity):
+        c = _lib.Config()
+        c.res[:] = self.res
+        c.dx, c.dt = self.delta_x, self.base_delta_t
+        c.gravity[:] = self.gravity
+        c.particle_gravity = int(self.particle_gravity)
+        c.apic_damping, c.rpic_damping = self.apic_damping, self.rpic_damping
+        c.clean_boundary = int(self.clean_boundary)
+        ls = self._levelset
+        c.n_planes = len(ls.planes) if ls else 0
+        if ls:
+            for i, p in enumerate(ls.planes):
+                c.planes[i][:] = p
+            c.friction = ls.friction
+        c.max_particles = int(capacity)
+        c.max_blocks = self.max_blocks
+        c.device = self.device
+        ctx = C.c_void_p()
+        rc = self._L.mpmhip_create(C.byref(c), C.byref(ctx))
+        if rc != 0:
+            raise MPMError("mpmhip_create failed (%d): %s" % (rc, self._L.mpmhip_last_error(None).decode()))
+        self._ctx, self._cfg, self._capacity = ctx, c, int(capacity)
+        for mat, params in self._groups:
+            self._check(self._L.mpmhip_add_group(self._ctx, mat, params.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def _check(self, rc):
+        if rc < 0:
+            raise MPMError("libmpmhip error %d: %s" % (rc, self._L.mpmhip_last_error(self._ctx).decode()))
+        return rc
+
+    def _ensure_ctx(self, extra=0):
+        """create the device context on first use; grow it (download, recreate, re-upload) when full."""
+        need = self._n_added + extra
+        if self._ctx is None:
+            cap = max(self.max_particles, need) if self.max_particles > 0 else max(need, 1024)
+            self._create(cap)
+            for gi, arrs in self._staged:
+                self._upload_new(gi, *arrs)
+            self._staged = []
+        elif need > self._capacity:
+            state = self.get_particles()
+            t, frame = self.get_current_time(), self.frame
+            self._L.mpmhip_destroy(self._ctx)
+            self._ctx = None
+            self._create(max(int(need * 1.25), self.max_particles))
+            order = np.argsort(state["gid"], kind="stable")
+            state = {k: v[order] for k, v in state.items()}
+            for gi in range(len(self._groups)):
+                m = state["gid"] == gi
+                if m.any():
+                    self._upload_new(gi, state["x"][m], state["v"][m], state["F"][m], state["B"][m], state["aux"][m])
+            ids = np.ascontiguousarray(state["id"], np.int32)  # keep creation ids across the re-allocation
+            if len(ids):
+                self._check(self._L.mpmhip_upload(self._ctx, F_ID, ids.ctypes.data_as(C.c_void_p), len(ids)))
+            self._time_offset = getattr(self, "_time_offset", 0.0) + t
+            self.frame = frame
+
+    def __del__(self):
+        try:
+            if self._ctx is not None:
+                self._L.mpmhip_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    close = __del__
+
+    # ---------------------------------------------------------------- particles
+    def _near_boundary(self, x):  # src/mpm.h:269-276 (applied at creation: src/mpm.cpp:129-132)
+        X = x / self.delta_x
+        return (X.min(1) < 7.0) | ((X - np.asarray(self.res)).max(1) > -7.0)
+
+    def _upload_new(self, gi, x, v, F, B, aux):
+        fp = C.POINTER(C.c_float)
+
+        def ptr(a, w):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, np.float32).reshape(len(x), w)
+            keep.append(a)
+            return a.ctypes.data_as(fp)
+        keep = []
+        self._check(self._L.mpmhip_add_particles(self._ctx, gi, len(x), ptr(x, 3), ptr(v, 3), ptr(F, 9), ptr(B, 9),
+                                                 ptr(aux, 1)))
+
+    def add_particles(self, config):
+        """MPM<dim>::add_particles, src/mpm.cpp:77-270.  Returns "" (rigid bodies, which return an id, are out
+        of scope)."""
+        cfg = dict(config)
+        ptype = cfg.get("type")
+        if ptype == "rigid":
+            raise MPMError("type='rigid' (CPIC rigid coupling) is outside the scope of this build")
+        if ptype not in MATERIAL_IDS:
+            raise MPMError("unknown particle type %r" % (ptype,))
+        dx = self.delta_x
+        maximum = float(cfg.get("ppc", cfg.get("maximum", 8)))
+        if cfg.get("benchmark", 0):  # src/mpm.cpp:149-186
+            b = int(cfg["benchmark"])
+            if len(set(self.res)) != 1:
+                raise MPMError("benchmark particles need a cubic grid")
+            if b == 125:
+                s = 0.1
+            elif b == 8000:
+                s = 0.4
+            else:
+                raise MPMError("s must be 125 or 8000")
+            lower = int(round(self.res[0] * (0.5 - s)))
+            higher = lower + int(round(self.res[0] * 2 * s))
+            x = lattice_cube(lower, higher, dx)
+            maximum = 1.0  # create_particle(..., 1, config): vol = dx^3 (src/mpm.cpp:178)
+        elif "cube" in cfg:
+            lo, hi = cfg["cube"]
+            x = lattice_cube(int(lo), int(hi), dx)
+        elif "positions" in cfg:
+            x = np.ascontiguousarray(cfg["positions"], np.float32).reshape(-1, 3)
+        else:
+            raise MPMError("add_particles needs one of: benchmark=, cube=(lo,hi), positions= "
+                           "(density_tex / point_cloud sampling is scene tooling outside this build)")
+        keep = ~self._near_boundary(x.astype(np.float64))  # "particle out of box or near boundary. Ignored."
+        x = x[keep]
+        n = len(x)
+        vol = dx ** 3 / maximum  # src/mpm.cpp:134-135
+        mass = vol * float(cfg.get("density", 400.0))
+        params, mat = group_params(ptype, mass, vol, **{k: v for k, v in cfg.items() if isinstance(v, (int, float))})
+        if "params" in cfg:  # explicit float[16] row (include/mpmhip.h), e.g. to share one row with a checker
+            params = np.ascontiguousarray(cfg["params"], np.float32).reshape(16).copy()
+        if mat == MATERIAL_IDS["visco"]:
+            raise MPMError("material 'visco' is not implemented on the device path yet")
+        v0 = np.tile(np.asarray(_vec3(cfg.get("initial_velocity"), (0, 0, 0)), np.float32), (n, 1))
+        if "velocities" in cfg:
+            v0 = np.ascontiguousarray(cfg["velocities"], np.float32).reshape(-1, 3)[keep]
+        dg = float(cfg.get("initial_dg", 1.0))  # src/particles.h:120
+        F = np.tile((np.eye(3, dtype=np.float32) * dg).reshape(1, 9), (n, 1))
+        if "F" in cfg:
+            F = np.ascontiguousarray(cfg["F"], np.float32).reshape(-1, 9)[keep]
+        B = np.zeros((n, 9), np.float32)
+        if "B" in cfg:
+            B = np.ascontiguousarray(cfg["B"], np.float32).reshape(-1, 9)[keep]
+        aux = np.full(n, initial_aux(ptype, **cfg), np.float32)
+        if "aux" in cfg:
+            aux = np.ascontiguousarray(cfg["aux"], np.float32).reshape(-1)[keep]
+        gi = len(self._groups)
+        self._groups.append((mat, params))
+        if self._ctx is not None:
+            self._ensure_ctx(extra=n)
+            self._check(self._L.mpmhip_add_group(self._ctx, mat, params.ctypes.data_as(C.POINTER(C.c_float))))
+            self._upload_new(gi, x, v0, F, B, aux)
+        else:
+            self._staged.append((gi, (x, v0, F, B, aux)))
+        self._n_added += n
+        return ""
+
+    def get_num_particles(self):
+        if self._ctx is None:
+            return self._n_added
+        return int(self._check(self._L.mpmhip_num_particles(self._ctx)))
+
+    def get_particles(self, sort_by_id=True):
+        """dict of numpy arrays (x, v, B, F, aux, gid, id) — the serialised particle fields of
+        src/particles.h:52-66 that the hot path owns."""
+        self._ensure_ctx()
+        n = self.get_num_particles()
+        out = {}
+        for name, f in (("x", F_X), ("v", F_V), ("B", F_B), ("F", F_F), ("aux", F_AUX), ("gid", F_GID), ("id", F_ID)):
+            dt = np.int32 if f in (F_GID, F_ID) else np.float32
+            a = np.zeros((n, _WIDTH[f]), dt)
+            got = self._check(self._L.mpmhip_download(self._ctx, f, a.ctypes.data_as(C.c_void_p), n))
+            a = a[:got]
+            out[name] = a[:, 0] if _WIDTH[f] == 1 else a
+        if sort_by_id:
+            order = np.argsort(out["id"], kind="stable")
+            out = {k: v[order] for k, v in out.items()}
+        return out
+
+    # ---------------------------------------------------------------- level set
+    def set_levelset(self, levelset, is_dynamic=False):
+        if is_dynamic:
+            raise MPMError("dynamic level sets are outside the scope of this build")
+        self._levelset = levelset
+        if self._ctx is not None:
+            pl = np.asarray(levelset.planes, np.float32).reshape(-1, 4)
+            self._check(self._L.mpmhip_set_levelset(self._ctx, len(pl), pl.ctypes.data_as(C.POINTER(C.c_float)),
+                                                    levelset.friction))
+
+    # ---------------------------------------------------------------- stepping
+    def step(self, dt):
+        """MPM<dim>::step, src/mpm.cpp:428-439: dt<0 => exactly one substep."""
+        self._ensure_ctx()
+        self._check(self._L.mpmhip_step(self._ctx, float(dt)))
+
+    def substep(self):
+        self._ensure_ctx()
+        self._check(self._L.mpmhip_substep(self._ctx))
+
+    def run_substeps(self, n):
+        self._ensure_ctx()
+        self._check(self._L.mpmhip_run_substeps(self._ctx, int(n)))
+
+    def synchronize(self):
+        self._ensure_ctx()
+        self._check(self._L.mpmhip_synchronize(self._ctx))
+
+    def get_current_time(self):
+        t0 = getattr(self, "_time_offset", 0.0)
+        return t0 + (self._L.mpmhip_current_time(self._ctx) if self._ctx is not None else 0.0)
+
+    # phase-level (names of the reference's member functions)
+    def sort_particles_and_populate_grid(self):
+        self._ensure_ctx(); self._check(self._L.mpmhip_sort(self._ctx))
+
+    def rasterize_optimized(self):
+        self._ensure_ctx(); self._check(self._L.mpmhip_p2g(self._ctx))
+
+    def normalize_grid_and_apply_boundary_conditions(self):
+        self._ensure_ctx(); self._check(self._L.mpmhip_grid_update(self._ctx))
+
+    def resample_optimized(self):
+        self._ensure_ctx(); self._check(self._L.mpmhip_g2p(self._ctx))
+
+    def get_grid(self, which=1):
+        self._ensure_ctx()
+        g = np.zeros((self.res[0] + 1, self.res[1] + 1, self.res[2] + 1, 4), np.float32)
+        self._check(self._L.mpmhip_download_grid(self._ctx, int(which), g.ctypes.data_as(C.POINTER(C.c_float))))
+        return g
+
+    def set_grid(self, grid):
+        self._ensure_ctx()
+        g = np.ascontiguousarray(grid, np.float32)
+        assert g.shape == (self.res[0] + 1, self.res[1] + 1, self.res[2] + 1, 4)
+        self._check(self._L.mpmhip_upload_grid(self._ctx, g.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def upload(self, field, array):
+        self._ensure_ctx()
+        a = np.ascontiguousarray(array, np.float32)
+        self._check(self._L.mpmhip_upload(self._ctx, field, a.ctypes.data_as(C.c_void_p), len(a)))
+
+    # ---------------------------------------------------------------- profiling (TC_PROFILE, src/mpm.cpp:464-572)
+    def set_profiling(self, on=True):
+        self._ensure_ctx(); self._check(self._L.mpmhip_set_profiling(self._ctx, int(on)))
+
+    def profile(self, reset=False):
+        self._ensure_ctx()
+        buf = C.create_string_buffer(1024)
+        self._check(self._L.mpmhip_profile(self._ctx, buf, len(buf)))
+        out = json.loads(buf.value.decode())
+        if reset:
+            self._check(self._L.mpmhip_profile_reset(self._ctx))
+        return out
+
+    # ---------------------------------------------------------------- misc surface
+    def general_action(self, config):
+        """MPM<dim>::general_action, src/mpm.cpp:920-978."""
+        action = config.get("action")
+        if action == "calculate_energy":  # kinetic part of src/mpm.cpp:1078-1110
+            p = self.get_particles(sort_by_id=False)
+            mass = np.array([g[1][0] for g in self._groups], np.float64)[p["gid"]]
+            return str(float(0.5 * (mass * (p["v"].astype(np.float64) ** 2).sum(1)).sum()))
+        if action == "save":
+            p = self.get_particles()
+            np.savez(config["file_name"], t=self.get_current_time(), frame=self.frame, **p)
+            return ""
+        raise MPMError("general_action(action=%r) is outside the scope of this build" % (action,))
+
+    def test(self):  # src/mpm.cpp:577-580
+        return True
+
+    def get_debug_information(self):  # src/mpm.cpp:635-639
+        return ""
+
+    def visualize(self):  # src/visualize.cpp:156-164 — .bgeo output is out of scope
+        return None
+
+    def get_mpi_world_rank(self):  # scripts/async/async_mpm.py:198-199
+        return 0
+
+    def get_name(self):  # src/mpm.h:486-488
+        return "mpm"
+
+
+def create_simulation3(name):
+    """tc_core.create_simulation3 (scripts/async/async_mpm.py:25-32); only 'mpm' is registered here
+    (TC_IMPLEMENTATION(Simulation3D, MPM3D, "mpm"), src/mpm.cpp:986-988)."""
+    if name != "mpm":
+        raise MPMError("no Simulation3D implementation named %r (registered: 'mpm')" % (name,))
+    return Simulation3D()
+
+
+def lattice_cube(lower, higher, dx):
+    """8 particles per cell at cell centre +- 0.25 dx (src/mpm.cpp:164-180)."""
+    r = np.arange(lower, higher, dtype=np.float64)
+    ii, jj, kk = np.meshgrid(r, r, r, indexing="ij")
+    cells = np.stack([ii, jj, kk], -1).reshape(-1, 1, 3) + 0.5
+    signs = np.array([[1 if (i % 2) else -1, 1 if (i // 2 % 2) else -1, 1 if (i // 4 % 2) else -1] for i in range(8)],
+                     np.float64)
+    x = (cells + 0.25 * signs[None]) * dx
+    return x.reshape(-1, 3).astype(np.float32)
+
+
+class MPM:
+    """Scene-script driver: `tc.dynamics.MPM(**kwargs)` shape (scripts/benchmark/benchmark_3d.py:9-27;
+    in-tree twin: AsyncMPM, scripts/async/async_mpm.py:17-300)."""
+
+    def __init__(self, **kwargs):
+        res = kwargs["res"]
+        self.frame_dt = kwargs.get("frame_dt", 0.01)
+        kwargs.setdefault("frame_dt", self.frame_dt)
+        self.num_frames = kwargs.get("num_frames", 1000)
+        if len(res) != 3:
+            raise MPMError("only the 3D simulation is implemented (create_simulation3)")
+        self.c = create_simulation3("mpm")
+        if "delta_x" not in kwargs:
+            kwargs["delta_x"] = 1.0 / res[0]  # async_mpm.py:40-41
+        self.c.initialize(kwargs)
+        self.res = tuple(res)
+        self.c.frame = 0
+        self.levelset_generator = None
+        self.simulation_total_time = 0.0
+
+    def add_particles(self, **kwargs):
+        return self.c.add_particles(kwargs)
+
+    def create_levelset(self):
+        return LevelSet()
+
+    def set_levelset(self, levelset, is_dynamic_levelset=False):
+        self.c.set_levelset(levelset, is_dynamic_levelset)
+
+    def get_current_time(self):
+        return self.c.get_current_time()
+
+    def step(self, step_t):
+        import time
+        T = time.time()
+        self.c.step(step_t)
+        self.c.synchronize()
+        self.simulation_total_time += time.time() - T
+        self.c.frame += 1
+
+    def general_action(self, **kwargs):
+        return self.c.general_action(kwargs)
+
+    def simulate(self, num_frames=None, print_profile_info=False, frame_update=None, **_ignored):
+        """python frame loop (scripts/async/async_mpm.py:217-248): per frame step(frame_dt) [+ profile print]."""
+        if print_profile_info:
+            self.c.set_profiling(True)
+        n = self.num_frames if num_frames is None else num_frames
+        for i in range(n):
+            if frame_update:
+                frame_update(self.get_current_time(), self.frame_dt)
+            self.step(self.frame_dt)
+            if print_profile_info:
+                print(json.dumps(self.c.profile(reset=True)))

@@ -1,0 +1,400 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the CPU
+oracle on identical seeded inputs, against the committed golden fixtures, and — at BASELINE.json's full sizes —
+through size-independent invariants.
+
+Tolerances (fp32): after one P2G grid mass rel-L2 <= 1e-6, momentum <= 1e-5 (LDS-atomic order);
+after one G2P from an identical grid: x abs <= 1e-7 * L (L=1), v/B rel <= 1e-5, F rel <= 1e-5 (snow/sand 1e-4
+near the clamp); after several steps: statistical.
+"""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from tests.common import lattice_cube, make_state, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+RES, DX, DT = 32, 1.0 / 32, 1e-4
+PLANES = [(0.0, 1.0, 0.0, -0.3)]
+MATS = ["jelly", "snow", "sand", "water", "linear", "elastic", "von_mises"]
+F_TOL = {"snow": 1e-4, "sand": 1e-4, "von_mises": 1e-4}
+
+
+@pytest.fixture(scope="module")
+def tm():
+    import taichi_mpm_amd as tm
+    tm.load()
+    return tm
+
+
+def make_sim(tm, state, planes=PLANES, friction=0.4, res=RES, dx=DX, dt=DT, **cfg):
+    sim = tm.create_simulation3("mpm")
+    sim.initialize(dict(res=(res,) * 3, delta_x=dx, base_delta_t=dt, **cfg))
+    if planes:
+        ls = tm.mpm.LevelSet(friction=friction)
+        for p in planes:
+            ls.add_plane(p[:3], d=p[3])
+        sim.set_levelset(ls)
+    names = {v: k for k, v in tm.MATERIAL_IDS.items()}
+    for gi in range(len(state.gtype)):
+        m = state.gid == gi
+        sim.add_particles(dict(type=names[int(state.gtype[gi])], positions=state.x[m], velocities=state.v[m],
+                               F=state.F[m], B=state.B[m], aux=state.aux[m], params=state.gparams[gi]))
+    return sim
+
+
+def ocfg(orc, planes=PLANES, friction=0.4, res=RES, dx=DX, dt=DT, **kw):
+    return orc.make_config(res, dx, dt, planes=planes, friction=friction, **kw)
+
+
+# ------------------------------------------------------------------------------------------ device math
+def test_device_svd_matches_oracle(tm, orc):
+    """device route (eigen-decomposition of F F^T) vs the oracle's svd convention."""
+    rng = np.random.default_rng(0)
+    n = 4096
+    F = (np.eye(3) + rng.normal(0, 0.3, (n, 3, 3))).astype(np.float32)
+    F[:8] = np.eye(3)
+    F[8:16] = np.diag([1.0, 1.0, -1.0])  # reflections: the sign goes on the smallest sigma
+    sim = make_sim(tm, make_state(lattice_cube(RES, 10, 12, DX), "jelly", DX))
+    sim._ensure_ctx()
+    U = np.zeros((n, 9), np.float32); S = np.zeros((n, 3), np.float32); V = np.zeros((n, 9), np.float32)
+    fp = C.POINTER(C.c_float)
+    Fc = np.ascontiguousarray(F.reshape(n, 9))
+    sim._check(sim._L.mpmhip_debug_svd3(sim._ctx, n, Fc.ctypes.data_as(fp), U.ctypes.data_as(fp), S.ctypes.data_as(fp),
+                                        V.ctypes.data_as(fp)))
+    U = U.reshape(n, 3, 3); V = V.reshape(n, 3, 3)
+    rec = np.einsum("nij,nj,nkj->nik", U, S, V)
+    assert np.abs(rec - F).max() < 2e-5
+    assert np.abs(np.einsum("nji,njk->nik", U, U) - np.eye(3)).max() < 1e-5
+    assert np.all(np.linalg.det(U) > 0.99)
+    for i in list(range(32)) + list(range(100, 400)):
+        _, So, _ = orc.svd3(F[i])
+        assert np.allclose(np.sort(np.abs(S[i]))[::-1], np.abs(So), atol=2e-5), (i, S[i], So)
+        assert np.isclose(np.prod(S[i]), np.prod(So), atol=5e-5 * max(1, abs(np.prod(So))))
+    sim.close()
+
+
+@pytest.mark.parametrize("mat", MATS)
+def test_device_constitutive_models_match_oracle(tm, orc, mat):
+    rng = np.random.default_rng(1)
+    n = 2048
+    gp, t = orc.group_params(mat, 400 * DX ** 3 / 8, DX ** 3 / 8)
+    F = (np.eye(3) + rng.normal(0, 0.05, (n, 3, 3))).astype(np.float32).reshape(n, 9)
+    cdg = (np.eye(3) + rng.normal(0, 0.02, (n, 3, 3))).astype(np.float32).reshape(n, 9)
+    aux = {"snow": 1.0 + rng.normal(0, 0.02, n), "water": 1.0 + rng.normal(0, 0.02, n),
+           "sand": np.abs(rng.normal(0, 0.01, n))}.get(mat, np.zeros(n)).astype(np.float32)
+    sim = make_sim(tm, make_state(lattice_cube(RES, 10, 12, DX), "jelly", DX))
+    sim._ensure_ctx()
+    fp = C.POINTER(C.c_float)
+    out = np.zeros((n, 9), np.float32)
+    sim._check(sim._L.mpmhip_debug_force(sim._ctx, t, gp.ctypes.data_as(fp), n, F.ctypes.data_as(fp),
+                                         aux.ctypes.data_as(fp), out.ctypes.data_as(fp)))
+    ref = np.stack([orc.calculate_force(t, gp, F[i], float(aux[i])).reshape(9) for i in range(n)])
+    scale = np.abs(ref).max()
+    # stress carries an absolute error ~ 2 mu vol eps_fp32 on both sides (F - R cancellation): compare on that scale
+    assert np.abs(out - ref).max() < 3e-5 * scale + 2 * gp[2] * gp[1] * 4e-6, mat
+    Fd, auxd = F.copy(), aux.copy()
+    sim._check(sim._L.mpmhip_debug_plasticity(sim._ctx, t, gp.ctypes.data_as(fp), n, cdg.ctypes.data_as(fp),
+                                              Fd.ctypes.data_as(fp), auxd.ctypes.data_as(fp)))
+    Fo = np.zeros_like(F); auxo = np.zeros_like(aux)
+    for i in range(n):
+        f, a = orc.plasticity(t, gp, cdg[i], F[i], float(aux[i]))
+        Fo[i], auxo[i] = f.reshape(9), a
+    if mat == "water":
+        Fd = F  # water never updates dg_e (src/particles.cpp:469-478); the kernel does not store it either
+    assert np.abs(Fd - Fo).max() < 2e-5, mat
+    assert np.abs(auxd - auxo).max() < 2e-5, mat
+    sim.close()
+
+
+# ------------------------------------------------------------------------------------------ sort
+def test_sort_is_a_permutation_in_key_order_and_drops_dead(tm, orc):
+    x = lattice_cube(RES, 5, 12, DX, jitter=0.3, seed=2)  # cells 5,6 lie inside the 7-cell deletion margin
+    rng = np.random.default_rng(3)
+    x = x[rng.permutation(len(x))]
+    s = make_state(x, "jelly", DX)
+    s.v[5] = np.nan
+    s.x[9, 1] = np.inf
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(RES,) * 3, delta_x=DX, base_delta_t=DT))
+    sim._ensure_ctx(extra=len(x))
+    sim._groups.append((tm.MATERIAL_IDS["jelly"], s.gparams[0]))
+    sim._check(sim._L.mpmhip_add_group(sim._ctx, tm.MATERIAL_IDS["jelly"], s.gparams[0].ctypes.data_as(C.POINTER(C.c_float))))
+    sim._upload_new(0, s.x, s.v, s.F, s.B, s.aux)  # bypasses the Python-side near-boundary filter on purpose
+    sim._n_added = len(x)
+    keep = orc.clear_boundary(ocfg(orc), s)
+    assert 0 < keep.sum() < len(x)
+    sim.sort_particles_and_populate_grid()
+    got = sim.get_particles(sort_by_id=False)
+    assert len(got["id"]) == keep.sum()
+    assert sorted(got["id"].tolist()) == np.nonzero(keep)[0].tolist()
+    assert np.array_equal(got["x"], s.x[got["id"]]) and np.array_equal(got["F"], s.F[got["id"]])
+    # key order: Morton(block) then cell-in-block
+    base = np.floor(got["x"].astype(np.float32) * np.float32(1 / DX) - np.float32(0.5)).astype(np.int64)
+
+    def spread(v):
+        r = np.zeros_like(v)
+        for b in range(10):
+            r |= ((v >> b) & 1) << (3 * b)
+        return r
+    blk = base >> 2
+    key = ((spread(blk[:, 0]) << 2 | spread(blk[:, 1]) << 1 | spread(blk[:, 2])) << 6) | ((base[:, 0] & 3) << 4) | \
+        ((base[:, 1] & 3) << 2) | (base[:, 2] & 3)
+    assert np.all(np.diff(key) >= 0)
+    sim.close()
+
+
+# ------------------------------------------------------------------------------------------ phases
+@pytest.mark.parametrize("mat", MATS)
+def test_p2g_and_grid_update_match_oracle(tm, orc, mat):
+    x = lattice_cube(RES, 9, 17, DX, jitter=0.2, seed=4)
+    s = make_state(x, mat, DX, perturb_F=0.02, seed=5)
+    sim = make_sim(tm, s)
+    sim.sort_particles_and_populate_grid()
+    sim.rasterize_optimized()
+    g0 = sim.get_grid(0)
+    cfg = ocfg(orc)
+    ref = orc.p2g(cfg, s.copy())
+    assert rel_l2(g0[..., 3], ref[..., 3]) <= 1e-6
+    assert rel_l2(g0[..., :3], ref[..., :3]) <= 1e-5
+    assert np.array_equal(g0[..., 3] != 0, ref[..., 3] != 0)
+    sim.normalize_grid_and_apply_boundary_conditions()
+    g1 = sim.get_grid(1)
+    ref1 = orc.grid_update(cfg, ref.copy())
+    assert rel_l2(g1[..., :3], ref1[..., :3]) <= 1e-5
+    assert rel_l2(g1[..., 3], ref1[..., 3]) <= 1e-6
+    sim.close()
+
+
+@pytest.mark.parametrize("mat", MATS)
+def test_g2p_from_identical_grid_matches_oracle(tm, orc, mat):
+    x = lattice_cube(RES, 9, 17, DX, jitter=0.2, seed=6)
+    s = make_state(x, mat, DX, perturb_F=0.02, seed=7)
+    cfg = ocfg(orc)
+    ref = s.copy()
+    grid = orc.grid_update(cfg, orc.p2g(cfg, ref))
+    sim = make_sim(tm, s)
+    sim.sort_particles_and_populate_grid()
+    sim.rasterize_optimized()                       # builds the tile / owner structure
+    sim.normalize_grid_and_apply_boundary_conditions()
+    sim.set_grid(grid)                              # identical grid on both sides
+    sim.resample_optimized()
+    got = sim.get_particles()
+    orc.g2p(cfg, ref, grid)
+    assert np.abs(got["x"] - ref.x).max() <= 1e-7
+    assert rel_l2(got["v"], ref.v) <= 1e-5
+    assert rel_l2(got["B"], ref.B) <= 1e-5
+    assert rel_l2(got["F"], ref.F) <= F_TOL.get(mat, 1e-5)
+    assert np.abs(got["aux"] - ref.aux).max() <= 2e-5
+    sim.close()
+
+
+@pytest.mark.parametrize("mat", MATS)
+def test_full_substep_matches_oracle(tm, orc, mat):
+    x = lattice_cube(RES, 9, 17, DX, jitter=0.2, seed=8)
+    s = make_state(x, mat, DX, perturb_F=0.02, seed=9)
+    sim = make_sim(tm, s)
+    sim.substep()
+    sim.synchronize()
+    got = sim.get_particles()
+    ref = s.copy()
+    orc.substep(ocfg(orc), ref)
+    assert len(got["x"]) == ref.n
+    assert np.array_equal(got["id"], ref.ids)
+    assert np.abs(got["x"] - ref.x).max() <= 2e-7
+    assert rel_l2(got["v"], ref.v) <= 2e-5
+    assert rel_l2(got["F"], ref.F) <= F_TOL.get(mat, 2e-5)
+    sim.close()
+
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "substep_*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_against_committed_golden_fixture(tm, path):
+    """no oracle involved: committed vectors (tests/golden/make_golden.py)."""
+    g = np.load(path)
+    names = {v: k for k, v in tm.MATERIAL_IDS.items()}
+    mat = names[int(g["gtype"][0])]
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(int(g["res"]),) * 3, delta_x=float(g["dx"]),
+                                                       base_delta_t=float(g["dt"])))
+    ls = tm.mpm.LevelSet(friction=float(g["friction"]))
+    for p in g["planes"]:
+        ls.add_plane(p[:3], d=float(p[3]))
+    sim.set_levelset(ls)
+    sim.add_particles(dict(type=mat, positions=g["in_x"], velocities=g["in_v"], F=g["in_F"], B=g["in_B"],
+                           aux=g["in_aux"], params=g["gparams"][0]))
+    sim.sort_particles_and_populate_grid()
+    sim.rasterize_optimized()
+    g0 = sim.get_grid(0)
+    nz = g["nz"].astype(int)
+    sel = g0[nz[:, 0], nz[:, 1], nz[:, 2]]
+    assert rel_l2(sel[:, 3], g["p2g_nz"][:, 3]) <= 1e-6 and rel_l2(sel[:, :3], g["p2g_nz"][:, :3]) <= 1e-5
+    assert np.count_nonzero(g0[..., 3]) == len(nz)
+    sim.normalize_grid_and_apply_boundary_conditions()
+    sim.resample_optimized()
+    got = sim.get_particles()
+    assert np.abs(got["x"] - g["out_x"]).max() <= 2e-7
+    assert rel_l2(got["v"], g["out_v"]) <= 2e-5
+    assert rel_l2(got["F"], g["out_F"]) <= F_TOL.get(mat, 2e-5)
+    for _ in range(4):
+        sim.substep()
+    sim.synchronize()
+    got5 = sim.get_particles()
+    assert np.array_equal(got5["id"], g["out5_ids"])
+    assert np.abs(got5["x"] - g["out5_x"]).max() <= 1e-6
+    assert rel_l2(got5["v"], g["out5_v"]) <= 1e-3
+    sim.close()
+
+
+# ------------------------------------------------------------------------------------------ multi-step / mixed
+def test_twenty_steps_statistics_two_materials(tm, orc):
+    """chaotic divergence is expected over many steps: compare statistics."""
+    xa = lattice_cube(RES, 9, 14, DX, jitter=0.2, seed=10)
+    xb = lattice_cube(RES, 15, 20, DX, jitter=0.2, seed=11)
+    sa = make_state(xa, "jelly", DX, E=1e4, perturb_F=0.0, vel_scale=0.3)
+    sb = make_state(xb, "sand", DX, perturb_F=0.0, vel_scale=0.3)
+    s = orc.State(np.concatenate([sa.x, sb.x]), np.concatenate([sa.v, sb.v]), np.concatenate([sa.B, sb.B]),
+                  np.concatenate([sa.F, sb.F]), np.concatenate([sa.aux, sb.aux]),
+                  np.concatenate([np.zeros(sa.n, np.int32), np.ones(sb.n, np.int32)]),
+                  np.stack([sa.gparams[0], sb.gparams[0]]), np.array([sa.gtype[0], sb.gtype[0]], np.int32))
+    sim = make_sim(tm, s, friction=-1.0)
+    cfg = ocfg(orc, friction=-1.0)
+    ref = s.copy()
+    for _ in range(20):
+        orc.substep(cfg, ref)
+    sim.run_substeps(20)
+    sim.synchronize()
+    got = sim.get_particles()
+    assert len(got["x"]) == ref.n and np.array_equal(got["id"], ref.ids)
+    assert np.isclose(sim.get_current_time(), 20 * DT, rtol=1e-5)
+    assert np.abs(got["x"] - ref.x).max() < 2e-5
+    assert np.allclose(got["x"].mean(0), ref.x.mean(0), atol=1e-6)
+    mass = s.gparams[ref.gid, 0].astype(np.float64)
+    mom_g = (mass[:, None] * got["v"]).sum(0); mom_r = (mass[:, None] * ref.v).sum(0)
+    assert np.allclose(mom_g, mom_r, rtol=1e-4, atol=1e-4 * np.abs(mass[:, None] * ref.v).sum())
+    ke_g = 0.5 * (mass * (got["v"].astype(np.float64) ** 2).sum(1)).sum()
+    ke_r = 0.5 * (mass * (ref.v.astype(np.float64) ** 2).sum(1)).sum()
+    assert np.isclose(ke_g, ke_r, rtol=1e-3)
+    assert np.isclose(float(sim.general_action(dict(action="calculate_energy"))), ke_g, rtol=1e-6)
+    sim.close()
+
+
+def test_step_semantics_match_reference_loop(tm):
+    """MPM::step (src/mpm.cpp:428-439): dt<0 => one substep; else substep while t + base_dt < request_t."""
+    s = make_state(lattice_cube(RES, 12, 14, DX), "jelly", DX)
+    sim = make_sim(tm, s, planes=None)
+    sim.step(-1)
+    assert np.isclose(sim.get_current_time(), DT)
+    t, req, n = np.float32(DT), np.float32(DT) + np.float32(1e-3), 0
+    while t + np.float32(DT) < req:
+        t += np.float32(DT); n += 1
+    sim.step(1e-3)
+    assert np.isclose(sim.get_current_time(), float(t), rtol=1e-6) and n in (9, 10)
+    sim.close()
+
+
+# ------------------------------------------------------------------------------------------ edge cases
+def test_edge_cases_empty_single_ragged_and_capacity(tm, orc):
+    # empty simulation: substeps are no-ops
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(RES,) * 3, delta_x=DX, base_delta_t=DT, max_particles=64))
+    sim.run_substeps(3)
+    sim.synchronize()
+    assert sim.get_num_particles() == 0
+    # a single particle, then a ragged add (n not a multiple of the wave size) on the same ctx (forces a grow)
+    one = make_state(np.array([[0.5, 0.5, 0.5]], np.float32), "snow", DX, perturb_F=0.0)
+    sim.add_particles(dict(type="snow", positions=one.x, velocities=one.v, params=one.gparams[0]))
+    sim.substep(); sim.synchronize()
+    assert sim.get_num_particles() == 1
+    x = lattice_cube(RES, 10, 13, DX, jitter=0.2, seed=12)[:197]
+    rag = make_state(x, "jelly", DX)
+    sim.add_particles(dict(type="jelly", positions=rag.x, velocities=rag.v, F=rag.F, params=rag.gparams[0]))
+    sim.substep(); sim.synchronize()
+    assert sim.get_num_particles() == 198
+    p = sim.get_particles()
+    assert np.all(np.isfinite(p["x"])) and set(p["gid"].tolist()) == {0, 1}
+    sim.close()
+    # raw C ABI: capacity overflow and bad group are reported, not crashed
+    sim2 = tm.create_simulation3("mpm").initialize(dict(res=(RES,) * 3, delta_x=DX, base_delta_t=DT, max_particles=100))
+    sim2._ensure_ctx()
+    fp = C.POINTER(C.c_float)
+    rc = sim2._L.mpmhip_add_particles(sim2._ctx, 3, 10, rag.x.ctypes.data_as(fp), None, None, None, None)
+    assert rc == -1 and b"unknown group" in sim2._L.mpmhip_last_error(sim2._ctx)
+    gi = sim2._L.mpmhip_add_group(sim2._ctx, tm.MATERIAL_IDS["jelly"], rag.gparams[0].ctypes.data_as(fp))
+    assert gi == 0
+    big = np.tile(rag.x, (8, 1))
+    rc = sim2._L.mpmhip_add_particles(sim2._ctx, 0, len(big), big.ctypes.data_as(fp), None, None, None, None)
+    assert rc == -4 and b"capacity" in sim2._L.mpmhip_last_error(sim2._ctx)
+    assert sim2._L.mpmhip_add_group(sim2._ctx, tm.MATERIAL_IDS["visco"], rag.gparams[0].ctypes.data_as(fp)) == -5
+    assert sim2._L.mpmhip_p2g(sim2._ctx) == -1  # needs a sort first
+    sim2.close()
+
+
+def test_particles_leaving_the_domain_are_deleted_like_the_reference(tm, orc):
+    """clear_boundary_particles (src/mpm.cpp:582-633): near-wall particles vanish; clean_boundary=False keeps them."""
+    x = lattice_cube(RES, 8, 11, DX, jitter=0.1, seed=13)
+    s = make_state(x, "jelly", DX, perturb_F=0.0, vel_scale=0.0)
+    s.v[:] = (-30.0, 0.0, 0.0)  # moves 0.1 cells per step towards the x=0 wall
+    s.B[:] = 0
+    for clean in (True, False):
+        sim = make_sim(tm, s, planes=None, gravity=(0, 0, 0), clean_boundary=clean)
+        cfg = ocfg(orc, planes=[], gravity=(0, 0, 0), clean_boundary=clean)
+        ref = s.copy()
+        for _ in range(15):
+            orc.substep(cfg, ref)
+        sim.run_substeps(15)
+        sim.synchronize()
+        got = sim.get_particles()
+        assert len(got["x"]) == ref.n
+        assert np.array_equal(got["id"], ref.ids)
+        if clean:
+            assert ref.n < s.n
+        else:
+            assert ref.n == s.n
+        sim.close()
+
+
+# ------------------------------------------------------------------------------------------ BASELINE sizes
+def _config_run(tm, res, cells, mat, steps, **matkw):
+    dx = 1.0 / res
+    lo = res // 2 - cells // 2
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(res,) * 3, delta_x=dx, base_delta_t=1e-4))
+    sim.set_levelset(tm.mpm.LevelSet(friction=-1.0).add_plane((0, 1, 0), d=-0.1))
+    sim.add_particles(dict(type=mat, cube=(lo, lo + cells), **matkw))
+    n = sim.get_num_particles()
+    sim.sort_particles_and_populate_grid()
+    sim.rasterize_optimized()
+    g0 = sim.get_grid(0)
+    mass = 400.0 * dx ** 3 / 8
+    # P2G conserves mass and momentum: sum_i m_i = N m ; sum_i (m v)_i = N m g dt (particles at rest + gravity)
+    assert np.isclose(g0[..., 3].sum(dtype=np.float64), n * mass, rtol=1e-6)
+    mom = g0[..., :3].reshape(-1, 3).sum(0, dtype=np.float64)
+    assert np.allclose(mom, [0, n * mass * -10.0 * 1e-4, 0], atol=1e-5 * n * mass * 1e-3)
+    # undeformed lattice at rest: every touched node gets exactly v = g dt after normalisation
+    sim.normalize_grid_and_apply_boundary_conditions()
+    g1 = sim.get_grid(1)
+    act = g1[..., 3] > 0
+    assert np.allclose(g1[act][:, 1], -1e-3, rtol=1e-4) and np.abs(g1[act][:, [0, 2]]).max() < 1e-7
+    sim.resample_optimized()
+    sim.run_substeps(steps)
+    sim.synchronize()
+    p = sim.get_particles(sort_by_id=False)
+    assert len(p["x"]) == n and len(np.unique(p["id"])) == n
+    assert np.all(np.isfinite(p["x"])) and np.all(np.isfinite(p["F"]))
+    t = (steps + 1) * 1e-4
+    assert np.allclose(p["v"][:, 1].mean(), -10.0 * t, rtol=2e-3)         # free fall of the centre of mass
+    assert np.abs(np.linalg.det(p["F"].reshape(-1, 3, 3)) - 1).max() < 1e-2
+    sim.close()
+    return n
+
+
+def test_config2_128cubed_1M_jelly_invariants(tm):
+    """BASELINE config C2: 128^3 grid, 50^3 cells x 8 = 1 000 000 fixed-corotated particles."""
+    assert _config_run(tm, 128, 50, "jelly", 5) == 1000000
+
+
+def test_config3_256cubed_8M_sand_invariants(tm):
+    """BASELINE config C3: 256^3 grid, 100^3 cells x 8 = 8 000 000 Drucker-Prager sand particles."""
+    assert _config_run(tm, 256, 100, "sand", 3) == 8000000
