@@ -2,12 +2,13 @@
 //
 // One substep (reference: MPM<3>::substep, src/mpm.cpp:452-575) is
 //
-//   sort      k_build_keys -> k_bitmap_prefix -> k_emit_active -> k_rank -> k_block_totals ->
-//             k_scan_totals -> k_cell_start -> k_reorder -> k_sort_cleanup
+//   sort      k_build_keys -> k_scan_*<0> (bitmap prefix) -> k_emit_active -> k_rank -> k_block_totals ->
+//             k_scan_*<1> (block offsets) -> k_cell_start -> k_reorder -> k_sort_cleanup
 //             (replaces sort_particles_and_populate_grid src/mpm.cpp:770-918, sort_allocator :752-768
 //              and clear_boundary_particles :582-633: dead particles simply get no slot)
-//   P2G       k_p2g        one workgroup per active 4x4x4-cell block, 6^3-node tile in LDS,
-//                          DS float atomics, tile written out non-atomically   (src/transfer.cpp:467-569)
+//   P2G       k_p2g        one wavefront per active 4x4x4-cell block, one lane per cell: register
+//                          accumulation over the cell's particles, then DS float atomics into the 6^3-node
+//                          LDS tile, tile written out non-atomically                (src/transfer.cpp:467-569)
 //   grid      k_grid       sums the <=8 overlapping block tiles of every touched grid block, normalises,
 //                          applies gravity + level-set boundary                  (src/mpm.cpp:277-372)
 //   G2P       k_g2p        6^3 velocity tile in LDS, 27-tap gather, F update + plasticity, advection
@@ -116,12 +117,16 @@ __device__ __forceinline__ uint32_t block_slot(const uint32_t *__restrict__ bits
 __global__ __launch_bounds__(256) void k_build_keys(Params P, SoA s, const Counters *__restrict__ cnt,
                                                     uint32_t *__restrict__ key, uint32_t *__restrict__ bits) {
   const uint32_t n = cnt->n;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t nloop = (n + stride - 1) / stride;
+  for (uint32_t it = 0; it < nloop; it++) {  // uniform trip count: all lanes take part in the shuffle
+    const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
     float X[3];
-    bool alive = true;
+    bool alive = i < n;
+    const uint32_t ii = alive ? i : 0;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      const float x = s.f[FX + k][i], v = s.f[FV + k][i];
+      const float x = s.f[FX + k][ii], v = s.f[FV + k][ii];
       alive = alive && isfinite(x) && isfinite(v);
       X[k] = x * P.idx;
     }
@@ -137,44 +142,110 @@ __global__ __launch_bounds__(256) void k_build_keys(Params P, SoA s, const Count
       b[k] = alive ? (int)(X[k] - 0.5f) : 0;  // MPMKernel<dim,2>::get_stencil_start, src/kernel.h:119-121
       alive = alive && (b[k] + 2 <= P.res[k]);
     }
-    uint32_t kk = INVALID;
+    uint32_t kk = INVALID, bkey = INVALID;
     if (alive) {
-      const uint32_t bkey = morton3(b[0] >> 2, b[1] >> 2, b[2] >> 2);
+      bkey = morton3(b[0] >> 2, b[1] >> 2, b[2] >> 2);
       kk = (bkey << 6) | ((b[0] & 3) << 4) | ((b[1] & 3) << 2) | (b[2] & 3);
-      const uint32_t bit = 1u << (bkey & 31);
-      if (!(bits[bkey >> 5] & bit)) atomicOr(&bits[bkey >> 5], bit);
     }
-    key[i] = kk;
+    // mark the block active: one atomic per run of equal blocks in the wave (particles are nearly sorted, so
+    // a wave usually spans one or two blocks) and only if the bit is not visibly set yet
+    const uint32_t prev = __shfl_up(bkey, 1);
+    if (alive && ((threadIdx.x & 63) == 0 || prev != bkey)) {
+      const uint32_t bit = 1u << (bkey & 31);
+      if (!(__hip_atomic_load(&bits[bkey >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit))
+        atomicOr(&bits[bkey >> 5], bit);
+    }
+    if (i < n) key[i] = kk;
   }
 }
 
-// popcount prefix over the active-block bitmap (single workgroup; the bitmap is 8^k/8 bytes: 256 KiB for a
-// 256^3 grid).  word_prefix[w] = number of active blocks with Morton key < 32*w.
-__global__ __launch_bounds__(1024) void k_bitmap_prefix(Params P, const uint32_t *__restrict__ bits,
-                                                        uint32_t *__restrict__ wprefix, Counters *cnt) {
-  __shared__ uint32_t part[1024];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t per = (P.nbw + 1023u) / 1024u;
-  const uint32_t w0 = tid * per, w1 = min(w0 + per, P.nbw);
-  uint32_t sum = 0;
-  for (uint32_t w = w0; w < w1; w++) sum += __popc(bits[w]);
-  part[tid] = sum;
+// ---- multi-workgroup exclusive scan of a uint32 sequence, two launches:
+//   k_scan_partials: workgroup i reduces chunk i (SCAN_CHUNK elements) -> partials[i]
+//   k_scan_apply   : workgroup i adds the partials before it to a local scan of its chunk
+// MODE 0: element w = popcount(bits[w]) (active-block bitmap; 8^k/8 bytes, 256 KiB for a 256^3 grid),
+//         out = word_prefix (number of active blocks with Morton key < 32 w), total -> cnt->n_active
+// MODE 1: element a = particles in active block a, out = act_start[0..n_active], total -> cnt->n_next
+constexpr int SCAN_CHUNK = 2048;  // 256 threads x 8
+
+__device__ __forceinline__ uint32_t wg_exclusive_scan_256(uint32_t v, uint32_t *lds /*>=5*/, uint32_t &total) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = __shfl_up(inc, off);
+    if ((int)lane >= off) inc += u;
+  }
+  if (lane == 63) lds[wave] = inc;
   __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-    uint32_t v = (tid >= off) ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
+  uint32_t base = 0;
+  for (uint32_t w = 0; w < wave; w++) base += lds[w];
+  total = lds[0] + lds[1] + lds[2] + lds[3];
+  __syncthreads();
+  return base + inc - v;
+}
+
+template <int MODE>
+__device__ __forceinline__ uint32_t scan_count(const Params &P, const Counters *cnt) {
+  return MODE == 0 ? P.nbw : min(cnt->n_active, P.max_blocks);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_scan_partials(Params P, const Counters *__restrict__ cnt,
+                                                       const uint32_t *__restrict__ in,
+                                                       uint32_t *__restrict__ partials) {
+  __shared__ uint32_t lds[8];
+  const uint32_t n = scan_count<MODE>(P, cnt);
+  const uint32_t base = blockIdx.x * SCAN_CHUNK;
+  if (base >= n) return;
+  uint32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t i = base + k * 256 + threadIdx.x;
+    if (i < n) sum += (MODE == 0) ? (uint32_t)__popc(in[i]) : in[i];
   }
-  uint32_t run = part[tid] - sum;
-  for (uint32_t w = w0; w < w1; w++) {
-    wprefix[w] = run;
-    run += __popc(bits[w]);
+  uint32_t total;
+  wg_exclusive_scan_256(sum, lds, total);
+  if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_scan_apply(Params P, Counters *cnt, const uint32_t *__restrict__ in,
+                                                    const uint32_t *__restrict__ partials,
+                                                    uint32_t *__restrict__ out) {
+  __shared__ uint32_t lds[8];
+  const uint32_t n = scan_count<MODE>(P, cnt);
+  const uint32_t base = blockIdx.x * SCAN_CHUNK;
+  if (base >= n && !(n == 0 && blockIdx.x == 0)) return;
+  // sum of the partials of the chunks before this one
+  uint32_t pre = 0;
+  for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256) pre += partials[j];
+  uint32_t chunk_base;
+  wg_exclusive_scan_256(pre, lds, chunk_base);
+  // thread t owns 8 consecutive elements
+  uint32_t v[8], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t i = base + threadIdx.x * 8 + k;
+    v[k] = (i < n) ? ((MODE == 0) ? (uint32_t)__popc(in[i]) : in[i]) : 0u;
+    sum += v[k];
   }
-  if (tid == 1023) {
-    uint32_t na = part[1023];
-    if (na > P.max_blocks) { cnt->error |= 1u; }
-    cnt->n_active = na;
+  uint32_t total;
+  uint32_t run = chunk_base + wg_exclusive_scan_256(sum, lds, total);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t i = base + threadIdx.x * 8 + k;
+    if (i < n) out[i] = run;
+    run += v[k];
+  }
+  if (base + SCAN_CHUNK >= n && threadIdx.x == 255) {  // last chunk: publish the grand total
+    const uint32_t grand = chunk_base + total;
+    if (MODE == 0) {
+      if (grand > P.max_blocks) cnt->error |= 1u;
+      cnt->n_active = grand;
+    } else {
+      out[n] = grand;
+      cnt->n_next = grand;
+    }
   }
 }
 
@@ -242,42 +313,12 @@ __global__ __launch_bounds__(256) void k_block_totals(const Counters *__restrict
   }
 }
 
-// exclusive scan of the per-block totals -> act_start[0..n_active]; single workgroup (tens of thousands
-// of entries).  Also publishes the particle count after compaction.
-__global__ __launch_bounds__(1024) void k_scan_totals(Params P, Counters *cnt, const uint32_t *__restrict__ totals,
-                                                      uint32_t *__restrict__ act_start) {
-  __shared__ uint32_t part[1024];
-  __shared__ uint32_t carry;
-  const uint32_t tid = threadIdx.x;
-  const uint32_t na = min(cnt->n_active, P.max_blocks);
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  for (uint32_t base = 0; base < na; base += 1024) {
-    const uint32_t i = base + tid;
-    const uint32_t v = (i < na) ? totals[i] : 0;
-    part[tid] = v;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-      uint32_t u = (tid >= off) ? part[tid - off] : 0;
-      __syncthreads();
-      part[tid] += u;
-      __syncthreads();
-    }
-    if (i < na) act_start[i] = carry + part[tid] - v;
-    __syncthreads();
-    if (tid == 1023) carry += part[1023];
-    __syncthreads();
-  }
-  if (tid == 0) {
-    act_start[na] = carry;
-    cnt->n_next = carry;
-  }
-}
-
-// cell_cnt (counts) -> global start offset of every cell, in place
+// per-cell counts -> global start offset of every cell: cell_start[slot*64 + c], plus a sentinel at
+// [n_active*64] so that the particles of cell i are always [cell_start[i], cell_start[i+1])
 __global__ __launch_bounds__(256) void k_cell_start(Params P, const Counters *__restrict__ cnt,
-                                                    uint32_t *__restrict__ cell_cnt,
-                                                    const uint32_t *__restrict__ act_start) {
+                                                    const uint32_t *__restrict__ cell_cnt,
+                                                    const uint32_t *__restrict__ act_start,
+                                                    uint32_t *__restrict__ cell_start) {
   const uint32_t na = min(cnt->n_active, P.max_blocks);
   const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -289,8 +330,10 @@ __global__ __launch_bounds__(256) void k_cell_start(Params P, const Counters *__
       const uint32_t u = __shfl_up(v, off);
       if ((int)lane >= off) v += u;
     }
-    cell_cnt[a * BC + lane] = act_start[a] + v - c;
+    cell_start[a * BC + lane] = act_start[a] + v - c;
+    if (a == na - 1 && lane == 63) cell_start[na * BC] = act_start[a] + v;
   }
+  if (na == 0 && wave == 0 && lane == 0) cell_start[0] = 0;
 }
 
 // physical reorder: scatter every live particle to its sorted slot (sort_allocator, src/mpm.cpp:752-768,
@@ -318,24 +361,35 @@ __global__ __launch_bounds__(256) void k_sort_cleanup(Params P, Counters *cnt, u
 }
 
 // ------------------------------------------------------------------------------------------------ P2G
-// rasterize_optimized / block_op_normal (src/transfer.cpp:467-569) for one 4^3-cell block per workgroup.
-template <int NT>
-__global__ __launch_bounds__(NT) void k_p2g(Params P, SoA s, const Counters *__restrict__ cnt,
+// rasterize_optimized / block_op_normal (src/transfer.cpp:467-569).
+// Mapping: one wavefront per active 4^3-cell block, ONE LANE PER CELL.  Particles are sorted by cell, so lane c
+// walks the particles of its cell sequentially and accumulates their 27x4 node contributions in registers
+// (the reference walks cells sequentially inside a block and accumulates into its scratch tile the same
+// way, :474-483).  Write conflicts between particles of one cell therefore never reach memory; the 27x4
+// per-cell sums are then merged into the block's 6^3-node LDS tile with DS float atomics (ds_add_f32), where
+// every instruction touches 64 distinct addresses (same stencil offset, different cells).  The tile is
+// written out non-atomically; conflicts between blocks are resolved by k_grid.
+__global__ __launch_bounds__(64) void k_p2g(Params P, SoA s, const Counters *__restrict__ cnt,
                                             const uint32_t *__restrict__ act_blk,
-                                            const uint32_t *__restrict__ act_start,
+                                            const uint32_t *__restrict__ cell_start,
                                             const GroupParams *__restrict__ groups, float4 *__restrict__ tiles) {
   __shared__ float tile[4 * TN];  // planes: m*vx, m*vy, m*vz, m
   const uint32_t na = min(cnt->n_active, P.max_blocks);
-  const int tid = threadIdx.x;
+  const int lane = threadIdx.x;
+  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
+  const int nbase = (cx * TS + cy) * TS + cz;
   const float S = -4.0f * P.idx * P.dt;  // src/transfer.cpp:465
   for (uint32_t a = blockIdx.x; a < na; a += gridDim.x) {
-    for (int t = tid; t < 4 * TN; t += NT) tile[t] = 0.0f;
+    for (int t = lane; t < 4 * TN; t += 64) tile[t] = 0.0f;
     __syncthreads();
     int bx, by, bz;
     demorton3(act_blk[a], bx, by, bz);
-    const float ox = (float)(bx * BS), oy = (float)(by * BS), oz = (float)(bz * BS);
-    const uint32_t p0 = act_start[a], p1 = act_start[a + 1];
-    for (uint32_t p = p0 + tid; p < p1; p += NT) {
+    const float ox = (float)(bx * BS + cx), oy = (float)(by * BS + cy), oz = (float)(bz * BS + cz);
+    const uint32_t p0 = cell_start[a * BC + lane], p1 = cell_start[a * BC + lane + 1];
+    float acc[27][4];
+#pragma unroll
+    for (int n = 0; n < 27; n++) { acc[n][0] = 0.0f; acc[n][1] = 0.0f; acc[n][2] = 0.0f; acc[n][3] = 0.0f; }
+    for (uint32_t p = p0; p < p1; p++) {
       const GroupParams g = groups[s.gid[p]];
       const float mass = g.p[0];
       float v[3] = {s.f[FV][p], s.f[FV + 1][p], s.f[FV + 2][p]};
@@ -343,10 +397,8 @@ __global__ __launch_bounds__(NT) void k_p2g(Params P, SoA s, const Counters *__r
 #pragma unroll
         for (int k = 0; k < 3; k++) v[k] = fmaf(P.g[k], P.dt, v[k]);
       }
-      // position relative to the block origin in grid units, base cell, fractional part (:490,518)
-      const float X0 = s.f[FX][p] * P.idx - ox, X1 = s.f[FX + 1][p] * P.idx - oy, X2 = s.f[FX + 2][p] * P.idx - oz;
-      const int c0 = (int)(X0 - 0.5f), c1 = (int)(X1 - 0.5f), c2 = (int)(X2 - 0.5f);
-      const float r0 = X0 - (float)c0, r1 = X1 - (float)c1, r2 = X2 - (float)c2;
+      // position relative to the base cell, in grid units: in [0.5, 1.5)^3  (:490,518)
+      const float r0 = s.f[FX][p] * P.idx - ox, r1 = s.f[FX + 1][p] * P.idx - oy, r2 = s.f[FX + 2][p] * P.idx - oz;
       float w0[3], w1[3], w2[3];
       bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
       mat3 F, B;
@@ -358,7 +410,6 @@ __global__ __launch_bounds__(NT) void k_p2g(Params P, SoA s, const Counters *__r
 #pragma unroll
       for (int k = 0; k < 9; k++) A.m[k] = fmaf(stress.m[k], S, B.m[k] * m4);  // :521-522
       const float mv0 = mass * v[0], mv1 = mass * v[1], mv2 = mass * v[2];
-      const int nbase = (c0 * TS + c1) * TS + c2;
 #pragma unroll
       for (int i = 0; i < 3; i++) {
         const float d0 = r0 - (float)i;
@@ -370,21 +421,36 @@ __global__ __launch_bounds__(NT) void k_p2g(Params P, SoA s, const Counters *__r
           for (int k = 0; k < 3; k++) {
             const float d2 = r2 - (float)k;
             const float w = wij * w2[k];
-            const int node = nbase + (i * TS + j) * TS + k;
+            const int n = (i * 3 + j) * 3 + k;
             // :535-541  contrib = (affine * dpos + mass*v, mass); g += weight * contrib
             const float q0 = fmaf(A(0, 2), d2, fmaf(A(0, 1), d1, fmaf(A(0, 0), d0, mv0)));
             const float q1 = fmaf(A(1, 2), d2, fmaf(A(1, 1), d1, fmaf(A(1, 0), d0, mv1)));
             const float q2 = fmaf(A(2, 2), d2, fmaf(A(2, 1), d1, fmaf(A(2, 0), d0, mv2)));
-            atomicAdd(&tile[node], w * q0);
-            atomicAdd(&tile[TN + node], w * q1);
-            atomicAdd(&tile[2 * TN + node], w * q2);
-            atomicAdd(&tile[3 * TN + node], w * mass);
+            acc[n][0] = fmaf(w, q0, acc[n][0]);
+            acc[n][1] = fmaf(w, q1, acc[n][1]);
+            acc[n][2] = fmaf(w, q2, acc[n][2]);
+            acc[n][3] = fmaf(w, mass, acc[n][3]);
           }
         }
       }
     }
+    if (p1 > p0) {
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const int n = (i * 3 + j) * 3 + k;
+            const int node = nbase + (i * TS + j) * TS + k;
+            atomicAdd(&tile[node], acc[n][0]);
+            atomicAdd(&tile[TN + node], acc[n][1]);
+            atomicAdd(&tile[2 * TN + node], acc[n][2]);
+            atomicAdd(&tile[3 * TN + node], acc[n][3]);
+          }
+    }
     __syncthreads();
-    for (int t = tid; t < TN; t += NT)
+    for (int t = lane; t < TN; t += 64)
       tiles[(size_t)a * TN + t] = make_float4(tile[t], tile[TN + t], tile[2 * TN + t], tile[3 * TN + t]);
     __syncthreads();
   }
@@ -639,7 +705,7 @@ struct mpmhip_ctx {
   // blocks
   uint32_t NB = 0;
   uint32_t *bits = nullptr, *wprefix = nullptr, *act_blk = nullptr, *act_start = nullptr, *totals = nullptr;
-  uint32_t *cell_cnt = nullptr, *fat_slot = nullptr;
+  uint32_t *cell_cnt = nullptr, *cell_start = nullptr, *partials = nullptr, *fat_slot = nullptr;
   float4 *tiles = nullptr, *gridv = nullptr, *dense = nullptr;
   Counters *cnt = nullptr;
   std::vector<GroupParams> groups;
@@ -776,6 +842,8 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(dmalloc(&c->act_start, (size_t)mb + 2));
   A(dmalloc(&c->totals, (size_t)mb + 1));
   A(dmalloc(&c->cell_cnt, (size_t)mb * BC));
+  A(dmalloc(&c->cell_start, (size_t)mb * BC + 1));
+  A(dmalloc(&c->partials, (size_t)((P.nbw > (uint32_t)mb ? P.nbw : (uint32_t)mb) / SCAN_CHUNK + 2)));
   A(dmalloc(&c->tiles, (size_t)mb * TN));
   A(dmalloc(&c->gridv, (size_t)mb * 8 * BC));
   A(dmalloc(&c->cnt, 1));
@@ -789,6 +857,8 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(hipMemset(c->bits, 0, sizeof(uint32_t) * P.nbw));
   A(hipMemset(c->cell_cnt, 0, sizeof(uint32_t) * (size_t)mb * BC));
   A(hipMemset(c->cnt, 0, sizeof(Counters)));
+  A(hipMemset(c->cell_start, 0, sizeof(uint32_t) * ((size_t)mb * BC + 1)));
+  A(hipMemset(c->act_start, 0, sizeof(uint32_t) * ((size_t)mb + 2)));
   A(hipMemset(c->fat_slot, 0, sizeof(uint32_t) * (size_t)c->NB));
   A(hipDeviceSynchronize());
   if (e != hipSuccess) { fail(c, MPMHIP_EHIP, "device init failed: %s", hipGetErrorString(e)); return bail(MPMHIP_EHIP); }
@@ -804,7 +874,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
     for (int k = 0; k <= PH_COUNT; k++) hipEventDestroy(ev.e[k]);
   for (int s = 0; s < 2; s++) { hipFree(c->pool_f[s]); hipFree(c->pool_g[s]); hipFree(c->pool_i[s]); }
   hipFree(c->key); hipFree(c->rank); hipFree(c->bits); hipFree(c->wprefix); hipFree(c->fat_slot);
-  hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->totals); hipFree(c->cell_cnt);
+  hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->totals); hipFree(c->cell_cnt); hipFree(c->cell_start); hipFree(c->partials);
   hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense); hipFree(c->cnt); hipFree(c->d_groups);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
@@ -975,13 +1045,17 @@ static int do_sort(mpmhip_ctx *c) {
   SoA &src = c->soa[c->cur], &dst = c->soa[c->cur ^ 1];
   HIPCHK(c, hipMemsetAsync(c->bits, 0, sizeof(uint32_t) * P.nbw, st));
   hipLaunchKernelGGL(k_build_keys, dim3(pg), dim3(256), 0, st, P, src, c->cnt, c->key, c->bits);
-  hipLaunchKernelGGL(k_bitmap_prefix, dim3(1), dim3(1024), 0, st, P, c->bits, c->wprefix, c->cnt);
+  const int nb_chunks = (int)((P.nbw + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  const int na_chunks = (int)((P.max_blocks + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  hipLaunchKernelGGL((k_scan_partials<0>), dim3(nb_chunks), dim3(256), 0, st, P, c->cnt, c->bits, c->partials);
+  hipLaunchKernelGGL((k_scan_apply<0>), dim3(nb_chunks), dim3(256), 0, st, P, c->cnt, c->bits, c->partials, c->wprefix);
   hipLaunchKernelGGL(k_emit_active, dim3((P.nbw + 255) / 256), dim3(256), 0, st, P, c->bits, c->wprefix, c->act_blk);
   hipLaunchKernelGGL(k_rank, dim3(pg), dim3(256), 0, st, P, c->cnt, c->key, c->rank, c->cell_cnt, c->bits, c->wprefix);
   hipLaunchKernelGGL(k_block_totals, dim3(1024), dim3(256), 0, st, c->cnt, c->cell_cnt, c->totals);
-  hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, st, P, c->cnt, c->totals, c->act_start);
-  hipLaunchKernelGGL(k_cell_start, dim3(1024), dim3(256), 0, st, P, c->cnt, c->cell_cnt, c->act_start);
-  hipLaunchKernelGGL(k_reorder, dim3(pg), dim3(256), 0, st, c->cnt, src, dst, c->key, c->rank, c->cell_cnt);
+  hipLaunchKernelGGL((k_scan_partials<1>), dim3(na_chunks), dim3(256), 0, st, P, c->cnt, c->totals, c->partials);
+  hipLaunchKernelGGL((k_scan_apply<1>), dim3(na_chunks), dim3(256), 0, st, P, c->cnt, c->totals, c->partials, c->act_start);
+  hipLaunchKernelGGL(k_cell_start, dim3(1024), dim3(256), 0, st, P, c->cnt, c->cell_cnt, c->act_start, c->cell_start);
+  hipLaunchKernelGGL(k_reorder, dim3(pg), dim3(256), 0, st, c->cnt, src, dst, c->key, c->rank, c->cell_start);
   hipLaunchKernelGGL(k_sort_cleanup, dim3(1024), dim3(256), 0, st, P, c->cnt, c->cell_cnt);
   c->cur ^= 1;
   c->sorted = true;
@@ -989,8 +1063,8 @@ static int do_sort(mpmhip_ctx *c) {
 }
 
 static int do_p2g(mpmhip_ctx *c) {
-  hipLaunchKernelGGL((k_p2g<256>), dim3(4096), dim3(256), 0, c->stream, c->P, c->soa[c->cur], c->cnt, c->act_blk,
-                     c->act_start, c->d_groups, c->tiles);
+  hipLaunchKernelGGL(k_p2g, dim3(8192), dim3(64), 0, c->stream, c->P, c->soa[c->cur], c->cnt, c->act_blk,
+                     c->cell_start, c->d_groups, c->tiles);
   return launch_check(c, "p2g");
 }
 static int do_grid(mpmhip_ctx *c, int mode) {
