@@ -32,6 +32,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -115,7 +116,7 @@ __device__ __forceinline__ uint32_t block_slot(const uint32_t *__restrict__ bits
 // (non-finite x/v, near the domain wall when clean_boundary — src/mpm.h:269-276, src/mpm.cpp:592-598 —
 // or with a stencil that would leave the grid, where the reference has undefined behaviour).
 __global__ __launch_bounds__(256) void k_build_keys(Params P, SoA s, const Counters *__restrict__ cnt,
-                                                    uint32_t *__restrict__ key, uint32_t *__restrict__ bits) {
+                                                    uint32_t *__restrict__ key, uint8_t *__restrict__ blk_flag) {
   const uint32_t n = cnt->n;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t nloop = (n + stride - 1) / stride;
@@ -147,15 +148,30 @@ __global__ __launch_bounds__(256) void k_build_keys(Params P, SoA s, const Count
       bkey = morton3(b[0] >> 2, b[1] >> 2, b[2] >> 2);
       kk = (bkey << 6) | ((b[0] & 3) << 4) | ((b[1] & 3) << 2) | (b[2] & 3);
     }
-    // mark the block active: one atomic per run of equal blocks in the wave (particles are nearly sorted, so
-    // a wave usually spans one or two blocks) and only if the bit is not visibly set yet
+    // mark the block active: a plain byte store (all writers store the same value, no atomics, no
+    // serialisation), one per run of equal blocks in the wave; k_pack_flags turns the bytes into the bitmap
     const uint32_t prev = __shfl_up(bkey, 1);
-    if (alive && ((threadIdx.x & 63) == 0 || prev != bkey)) {
-      const uint32_t bit = 1u << (bkey & 31);
-      if (!(__hip_atomic_load(&bits[bkey >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit))
-        atomicOr(&bits[bkey >> 5], bit);
-    }
+    if (alive && ((threadIdx.x & 63) == 0 || prev != bkey)) blk_flag[bkey] = 1;
     if (i < n) key[i] = kk;
+  }
+}
+
+// byte flags -> active-block bitmap (bit b of word w = block with Morton key 32w+b); clears the flags
+__global__ __launch_bounds__(256) void k_pack_flags(Params P, uint8_t *__restrict__ blk_flag,
+                                                    uint32_t *__restrict__ bits) {
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < P.nbw; w += gridDim.x * blockDim.x) {
+    uint4 *src = reinterpret_cast<uint4 *>(blk_flag + (size_t)w * 32);
+    const uint4 lo = src[0], hi = src[1];
+    const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      // bytes are 0/1: gather bit 0 of each of the 4 bytes
+      const uint32_t v = q[k];
+      m |= ((v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u)) << (4 * k);
+    }
+    bits[w] = m;
+    if (m) { src[0] = make_uint4(0, 0, 0, 0); src[1] = make_uint4(0, 0, 0, 0); }
   }
 }
 
@@ -336,16 +352,41 @@ __global__ __launch_bounds__(256) void k_cell_start(Params P, const Counters *__
   if (na == 0 && wave == 0 && lane == 0) cell_start[0] = 0;
 }
 
+// Layout of a block's particles in memory: RANK-MAJOR.  First the 0th particle of every non-empty cell (in cell
+// order), then the 1st particle of every cell that has one, ...  With the one-lane-per-cell mapping of k_p2g,
+// iteration r of the wave then reads 64 (or fewer) CONSECUTIVE particles: fully coalesced SoA loads.
+// dest[cell_start[c] + r] = final slot of the particle with rank r in cell c.  One wave per block.
+__global__ __launch_bounds__(256) void k_layout(Params P, const Counters *__restrict__ cnt,
+                                                const uint32_t *__restrict__ cell_start,
+                                                uint32_t *__restrict__ dest) {
+  const uint32_t na = min(cnt->n_active, P.max_blocks);
+  const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (uint32_t a = wave; a < na; a += nwaves) {
+    const uint32_t s0 = cell_start[a * BC + lane], s1 = cell_start[a * BC + lane + 1];
+    const uint32_t c = s1 - s0;
+    uint32_t run = __shfl(s0, 0);  // block start
+    for (uint32_t r = 0;; r++) {
+      const unsigned long long m = __ballot(c > r);
+      if (!m) break;
+      if (c > r) dest[s0 + r] = run + (uint32_t)__popcll(m & lt);
+      run += (uint32_t)__popcll(m);
+    }
+  }
+}
+
 // physical reorder: scatter every live particle to its sorted slot (sort_allocator, src/mpm.cpp:752-768,
 // done every substep here; dead particles are dropped = clear_boundary_particles, src/mpm.cpp:582-633)
 __global__ __launch_bounds__(256) void k_reorder(const Counters *__restrict__ cnt, SoA src, SoA dst,
                                                  const uint32_t *__restrict__ key, const uint32_t *__restrict__ rank,
-                                                 const uint32_t *__restrict__ cell_start) {
+                                                 const uint32_t *__restrict__ cell_start,
+                                                 const uint32_t *__restrict__ dest) {
   const uint32_t n = cnt->n;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint32_t c = key[i];
     if (c == INVALID) continue;
-    const uint32_t j = cell_start[c] + rank[i];
+    const uint32_t j = dest[cell_start[c] + rank[i]];
 #pragma unroll
     for (int f = 0; f < NF; f++) dst.f[f][j] = src.f[f][i];
     dst.gid[j] = src.gid[i];
@@ -366,30 +407,38 @@ __global__ __launch_bounds__(256) void k_sort_cleanup(Params P, Counters *cnt, u
 // walks the particles of its cell sequentially and accumulates their 27x4 node contributions in registers
 // (the reference walks cells sequentially inside a block and accumulates into its scratch tile the same
 // way, :474-483).  Write conflicts between particles of one cell therefore never reach memory; the 27x4
-// per-cell sums are then merged into the block's 6^3-node LDS tile with DS float atomics (ds_add_f32), where
-// every instruction touches 64 distinct addresses (same stencil offset, different cells).  The tile is
-// written out non-atomically; conflicts between blocks are resolved by k_grid.
+// per-cell sums are then merged into the block's 6^3-node LDS tile by ordered, non-atomic float4
+// read-modify-writes (see below).  The tile is written out non-atomically; conflicts between blocks are
+// resolved by k_grid.  No atomics of any kind on the P2G path.
 __global__ __launch_bounds__(64) void k_p2g(Params P, SoA s, const Counters *__restrict__ cnt,
                                             const uint32_t *__restrict__ act_blk,
                                             const uint32_t *__restrict__ cell_start,
                                             const GroupParams *__restrict__ groups, float4 *__restrict__ tiles) {
-  __shared__ float tile[4 * TN];  // planes: m*vx, m*vy, m*vz, m
+  __shared__ float4 tile[TN];  // (m*vx, m*vy, m*vz, m) per node of the block's 6^3 tile
   const uint32_t na = min(cnt->n_active, P.max_blocks);
   const int lane = threadIdx.x;
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
   const int nbase = (cx * TS + cy) * TS + cz;
   const float S = -4.0f * P.idx * P.dt;  // src/transfer.cpp:465
   for (uint32_t a = blockIdx.x; a < na; a += gridDim.x) {
-    for (int t = lane; t < 4 * TN; t += 64) tile[t] = 0.0f;
+    for (int t = lane; t < TN; t += 64) tile[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();
     int bx, by, bz;
     demorton3(act_blk[a], bx, by, bz);
     const float ox = (float)(bx * BS + cx), oy = (float)(by * BS + cy), oz = (float)(bz * BS + cz);
-    const uint32_t p0 = cell_start[a * BC + lane], p1 = cell_start[a * BC + lane + 1];
+    const uint32_t cs0 = cell_start[a * BC + lane];
+    const uint32_t count = cell_start[a * BC + lane + 1] - cs0;
+    uint32_t run = __shfl(cs0, 0);  // first particle of the block; rank-major layout (k_layout)
+    const unsigned long long lt = (1ull << lane) - 1ull;
     float acc[27][4];
 #pragma unroll
     for (int n = 0; n < 27; n++) { acc[n][0] = 0.0f; acc[n][1] = 0.0f; acc[n][2] = 0.0f; acc[n][3] = 0.0f; }
-    for (uint32_t p = p0; p < p1; p++) {
+    for (uint32_t r = 0;; r++) {
+      const unsigned long long am = __ballot(count > r);
+      if (!am) break;
+      const uint32_t p = run + (uint32_t)__popcll(am & lt);
+      run += (uint32_t)__popcll(am);
+      if (count <= r) continue;
       const GroupParams g = groups[s.gid[p]];
       const float mass = g.p[0];
       float v[3] = {s.f[FV][p], s.f[FV + 1][p], s.f[FV + 2][p]};
@@ -434,24 +483,30 @@ __global__ __launch_bounds__(64) void k_p2g(Params P, SoA s, const Counters *__r
         }
       }
     }
-    if (p1 > p0) {
+    // Merge the per-cell sums into the tile.  The tile belongs to this wavefront alone, and within one
+    // (i,j,k) step all 64 lanes address distinct nodes (same stencil offset, different cells), so a plain
+    // float4 read-modify-write is race-free as long as the 27 steps stay in program order: LDS operations of
+    // one wave execute in order, the wave_barrier keeps the compiler from interleaving them.  (DS float atomics
+    // cost ~2 LDS cycles per LANE on gfx950 even without conflicts: measured 145 cycles per ds_add_f32.)
 #pragma unroll
-      for (int i = 0; i < 3; i++)
+    for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int j = 0; j < 3; j++)
+      for (int j = 0; j < 3; j++)
 #pragma unroll
-          for (int k = 0; k < 3; k++) {
-            const int n = (i * 3 + j) * 3 + k;
-            const int node = nbase + (i * TS + j) * TS + k;
-            atomicAdd(&tile[node], acc[n][0]);
-            atomicAdd(&tile[TN + node], acc[n][1]);
-            atomicAdd(&tile[2 * TN + node], acc[n][2]);
-            atomicAdd(&tile[3 * TN + node], acc[n][3]);
+        for (int k = 0; k < 3; k++) {
+          const int n = (i * 3 + j) * 3 + k;
+          const int node = nbase + (i * TS + j) * TS + k;
+          if (count > 0) {
+            float4 t = tile[node];
+            t.x += acc[n][0]; t.y += acc[n][1]; t.z += acc[n][2]; t.w += acc[n][3];
+            tile[node] = t;
           }
-    }
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("" ::: "memory");
+        }
     __syncthreads();
     for (int t = lane; t < TN; t += 64)
-      tiles[(size_t)a * TN + t] = make_float4(tile[t], tile[TN + t], tile[2 * TN + t], tile[3 * TN + t]);
+      tiles[(size_t)a * TN + t] = tile[t];
     __syncthreads();
   }
 }
@@ -547,8 +602,8 @@ __global__ __launch_bounds__(64) void k_grid(Params P, int mode, const Counters 
 
 // ------------------------------------------------------------------------------------------------ G2P
 // resample_optimized / block_op_normal (src/transfer.cpp:837-954)
-template <int NT>
-__global__ __launch_bounds__(NT) void k_g2p(Params P, SoA s, const Counters *__restrict__ cnt,
+template <int NT, int MINW>
+__global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, SoA s, const Counters *__restrict__ cnt,
                                             const uint32_t *__restrict__ act_blk,
                                             const uint32_t *__restrict__ act_start,
                                             const GroupParams *__restrict__ groups,
@@ -603,6 +658,7 @@ __global__ __launch_bounds__(NT) void k_g2p(Params P, SoA s, const Counters *__r
             b(2, 0) = fmaf(a2, d0, b(2, 0)); b(2, 1) = fmaf(a2, d1, b(2, 1)); b(2, 2) = fmaf(a2, d2, b(2, 2));
           }
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep at most one i-plane (9 float4 LDS reads) in flight: VGPR pressure
       }
       // apic_b = damp_affine_momemtum(b) (src/mpm.h:465-469); the reference's optimised path has a bug
       // here (passes the block index, transfer.cpp:925-926) — we implement the intended damping.
@@ -704,6 +760,8 @@ struct mpmhip_ctx {
   uint32_t *key = nullptr, *rank = nullptr;
   // blocks
   uint32_t NB = 0;
+  uint8_t *blk_flag = nullptr;
+  uint32_t *dest = nullptr;
   uint32_t *bits = nullptr, *wprefix = nullptr, *act_blk = nullptr, *act_start = nullptr, *totals = nullptr;
   uint32_t *cell_cnt = nullptr, *cell_start = nullptr, *partials = nullptr, *fat_slot = nullptr;
   float4 *tiles = nullptr, *gridv = nullptr, *dense = nullptr;
@@ -712,6 +770,7 @@ struct mpmhip_ctx {
   GroupParams *d_groups = nullptr;
   int groups_cap = 256;
   bool sorted = false;
+  int g2p_minw = 2;  // tuning knob (env MPMHIP_G2P_MINW): __launch_bounds__ waves/SIMD of k_g2p
   float t = 0.0f, request_t = 0.0f;  // `real` accumulators, as in the reference (src/mpm.h:99, mpm.cpp:573)
   int64_t substeps = 0;
   // profiling
@@ -794,6 +853,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   if (!c) return fail(nullptr, MPMHIP_ENOMEM, "host allocation failed");
   c->cfg = *cfg;
   c->device = cfg->device;
+  if (const char *e = getenv("MPMHIP_G2P_MINW")) c->g2p_minw = atoi(e);
   auto bail = [&](int code) { g_create_error = c->err; mpmhip_destroy(c); return code; };
   if (hipSetDevice(c->device) != hipSuccess) { fail(c, MPMHIP_EHIP, "hipSetDevice failed"); return bail(MPMHIP_EHIP); }
   Params &P = c->P;
@@ -836,6 +896,8 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(dmalloc(&c->key, (size_t)c->cap));
   A(dmalloc(&c->rank, (size_t)c->cap));
   A(dmalloc(&c->bits, (size_t)P.nbw));
+  A(dmalloc(&c->blk_flag, (size_t)P.nbw * 32));
+  A(dmalloc(&c->dest, (size_t)c->cap));
   A(dmalloc(&c->wprefix, (size_t)P.nbw));
   A(dmalloc(&c->fat_slot, (size_t)c->NB));
   A(dmalloc(&c->act_blk, (size_t)mb + 1));
@@ -855,6 +917,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   }
   bind_soa(c);
   A(hipMemset(c->bits, 0, sizeof(uint32_t) * P.nbw));
+  A(hipMemset(c->blk_flag, 0, (size_t)P.nbw * 32));
   A(hipMemset(c->cell_cnt, 0, sizeof(uint32_t) * (size_t)mb * BC));
   A(hipMemset(c->cnt, 0, sizeof(Counters)));
   A(hipMemset(c->cell_start, 0, sizeof(uint32_t) * ((size_t)mb * BC + 1)));
@@ -873,7 +936,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   for (auto &ev : c->ev_pool)
     for (int k = 0; k <= PH_COUNT; k++) hipEventDestroy(ev.e[k]);
   for (int s = 0; s < 2; s++) { hipFree(c->pool_f[s]); hipFree(c->pool_g[s]); hipFree(c->pool_i[s]); }
-  hipFree(c->key); hipFree(c->rank); hipFree(c->bits); hipFree(c->wprefix); hipFree(c->fat_slot);
+  hipFree(c->key); hipFree(c->rank); hipFree(c->blk_flag); hipFree(c->dest); hipFree(c->bits); hipFree(c->wprefix); hipFree(c->fat_slot);
   hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->totals); hipFree(c->cell_cnt); hipFree(c->cell_start); hipFree(c->partials);
   hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense); hipFree(c->cnt); hipFree(c->d_groups);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -1043,8 +1106,8 @@ static int do_sort(mpmhip_ctx *c) {
   hipStream_t st = c->stream;
   const int pg = particle_grid(c->n_host);
   SoA &src = c->soa[c->cur], &dst = c->soa[c->cur ^ 1];
-  HIPCHK(c, hipMemsetAsync(c->bits, 0, sizeof(uint32_t) * P.nbw, st));
-  hipLaunchKernelGGL(k_build_keys, dim3(pg), dim3(256), 0, st, P, src, c->cnt, c->key, c->bits);
+  hipLaunchKernelGGL(k_build_keys, dim3(pg), dim3(256), 0, st, P, src, c->cnt, c->key, c->blk_flag);
+  hipLaunchKernelGGL(k_pack_flags, dim3((P.nbw + 255) / 256), dim3(256), 0, st, P, c->blk_flag, c->bits);
   const int nb_chunks = (int)((P.nbw + SCAN_CHUNK - 1) / SCAN_CHUNK);
   const int na_chunks = (int)((P.max_blocks + SCAN_CHUNK - 1) / SCAN_CHUNK);
   hipLaunchKernelGGL((k_scan_partials<0>), dim3(nb_chunks), dim3(256), 0, st, P, c->cnt, c->bits, c->partials);
@@ -1055,7 +1118,8 @@ static int do_sort(mpmhip_ctx *c) {
   hipLaunchKernelGGL((k_scan_partials<1>), dim3(na_chunks), dim3(256), 0, st, P, c->cnt, c->totals, c->partials);
   hipLaunchKernelGGL((k_scan_apply<1>), dim3(na_chunks), dim3(256), 0, st, P, c->cnt, c->totals, c->partials, c->act_start);
   hipLaunchKernelGGL(k_cell_start, dim3(1024), dim3(256), 0, st, P, c->cnt, c->cell_cnt, c->act_start, c->cell_start);
-  hipLaunchKernelGGL(k_reorder, dim3(pg), dim3(256), 0, st, c->cnt, src, dst, c->key, c->rank, c->cell_start);
+  hipLaunchKernelGGL(k_layout, dim3(1024), dim3(256), 0, st, P, c->cnt, c->cell_start, c->dest);
+  hipLaunchKernelGGL(k_reorder, dim3(pg), dim3(256), 0, st, c->cnt, src, dst, c->key, c->rank, c->cell_start, c->dest);
   hipLaunchKernelGGL(k_sort_cleanup, dim3(1024), dim3(256), 0, st, P, c->cnt, c->cell_cnt);
   c->cur ^= 1;
   c->sorted = true;
@@ -1073,7 +1137,8 @@ static int do_grid(mpmhip_ctx *c, int mode) {
   return launch_check(c, "grid");
 }
 static int do_g2p(mpmhip_ctx *c) {
-  hipLaunchKernelGGL((k_g2p<256>), dim3(4096), dim3(256), 0, c->stream, c->P, c->soa[c->cur], c->cnt, c->act_blk,
+  auto kern = c->g2p_minw == 4 ? k_g2p<256, 4> : (c->g2p_minw == 3 ? k_g2p<256, 3> : k_g2p<256, 2>);
+  hipLaunchKernelGGL(kern, dim3(4096), dim3(256), 0, c->stream, c->P, c->soa[c->cur], c->cnt, c->act_blk,
                      c->act_start, c->d_groups, c->gridv, c->fat_slot);
   return launch_check(c, "g2p");
 }

@@ -111,7 +111,7 @@ def test_device_constitutive_models_match_oracle(tm, orc, mat):
 
 
 # ------------------------------------------------------------------------------------------ sort
-def test_sort_is_a_permutation_in_key_order_and_drops_dead(tm, orc):
+def test_sort_is_a_permutation_in_block_rank_major_order_and_drops_dead(tm, orc):
     x = lattice_cube(RES, 5, 12, DX, jitter=0.3, seed=2)  # cells 5,6 lie inside the 7-cell deletion margin
     rng = np.random.default_rng(3)
     x = x[rng.permutation(len(x))]
@@ -131,7 +131,8 @@ def test_sort_is_a_permutation_in_key_order_and_drops_dead(tm, orc):
     assert len(got["id"]) == keep.sum()
     assert sorted(got["id"].tolist()) == np.nonzero(keep)[0].tolist()
     assert np.array_equal(got["x"], s.x[got["id"]]) and np.array_equal(got["F"], s.F[got["id"]])
-    # key order: Morton(block) then cell-in-block
+    # order: blocks in Morton order; inside a block RANK-MAJOR (0th particle of every cell in cell order, then
+    # the 1st of every cell that has one, ...) so that the lane-per-cell P2G reads consecutive particles
     base = np.floor(got["x"].astype(np.float32) * np.float32(1 / DX) - np.float32(0.5)).astype(np.int64)
 
     def spread(v):
@@ -140,9 +141,14 @@ def test_sort_is_a_permutation_in_key_order_and_drops_dead(tm, orc):
             r |= ((v >> b) & 1) << (3 * b)
         return r
     blk = base >> 2
-    key = ((spread(blk[:, 0]) << 2 | spread(blk[:, 1]) << 1 | spread(blk[:, 2])) << 6) | ((base[:, 0] & 3) << 4) | \
-        ((base[:, 1] & 3) << 2) | (base[:, 2] & 3)
-    assert np.all(np.diff(key) >= 0)
+    bkey = spread(blk[:, 0]) << 2 | spread(blk[:, 1]) << 1 | spread(blk[:, 2])
+    cell = ((base[:, 0] & 3) << 4) | ((base[:, 1] & 3) << 2) | (base[:, 2] & 3)
+    assert np.all(np.diff(bkey) >= 0)
+    for b in np.unique(bkey):
+        cells = cell[bkey == b]
+        counts = np.bincount(cells, minlength=64)
+        expect = np.concatenate([np.nonzero(counts > r)[0] for r in range(counts.max())])
+        assert np.array_equal(cells, expect)
     sim.close()
 
 
