@@ -83,7 +83,11 @@ typedef struct {
   int64_t max_particles;    /* capacity of the SoA pools (reference: < 2^25, src/mpm.cpp:773-775) */
   int64_t max_blocks;       /* capacity of the active-block table; 0 = choose from max_particles */
   int32_t device;           /* HIP device ordinal */
-  int32_t reserved[7];
+  int32_t reorder_interval; /* "reorder_interval" (src/mpm.cpp:45,811-813): physical reorder of the particle records
+                               into sorted order every this many substeps; 0 = never (the sorted INDEX is rebuilt
+                               every substep regardless) */
+  int32_t discard_apic_b;   /* 1 = do not keep apic_b (it is folded into the P2G affine matrix); download(B) then fails */
+  int32_t reserved[5];
 } mpmhip_config;
 
 typedef struct mpmhip_ctx mpmhip_ctx;
@@ -149,8 +153,9 @@ int mpmhip_profile_reset(mpmhip_ctx *ctx);
 int mpmhip_debug_svd3(mpmhip_ctx *ctx, int64_t n, const float *F, float *U, float *S, float *V);
 int mpmhip_debug_force(mpmhip_ctx *ctx, int32_t material, const float params[MPMHIP_NPARAM], int64_t n,
                        const float *F, const float *aux, float *out);
+/* next_force == NULL: plasticity(cdg) alone; else the fused "plasticity + next substep's calculate_force" of k_g2p */
 int mpmhip_debug_plasticity(mpmhip_ctx *ctx, int32_t material, const float params[MPMHIP_NPARAM], int64_t n,
-                            const float *cdg, float *F, float *aux);
+                            const float *cdg, float *F, float *aux, float *next_force);
 
 #ifdef __cplusplus
 }

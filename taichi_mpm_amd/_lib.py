@@ -23,7 +23,8 @@ class Config(C.Structure):
                 ("particle_gravity", C.c_int32), ("apic_damping", C.c_float), ("rpic_damping", C.c_float),
                 ("clean_boundary", C.c_int32), ("n_planes", C.c_int32), ("planes", (C.c_float * 4) * 8),
                 ("friction", C.c_float), ("max_particles", C.c_int64), ("max_blocks", C.c_int64),
-                ("device", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("device", C.c_int32), ("reorder_interval", C.c_int32), ("discard_apic_b", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
 
 
 def lib_path():
@@ -103,6 +104,6 @@ def load():
     L.mpmhip_profile.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.mpmhip_debug_svd3.argtypes = [vp, C.c_int64, fp, fp, fp, fp]
     L.mpmhip_debug_force.argtypes = [vp, C.c_int32, fp, C.c_int64, fp, fp, fp]
-    L.mpmhip_debug_plasticity.argtypes = [vp, C.c_int32, fp, C.c_int64, fp, fp, fp]
+    L.mpmhip_debug_plasticity.argtypes = [vp, C.c_int32, fp, C.c_int64, fp, fp, fp, fp]
     _lib = L
     return L

@@ -264,6 +264,122 @@ __device__ __forceinline__ void plasticity(const GroupParams &g, const mat3 &cdg
   F = mat_mul(sandwich(U, ratio), F);
 }
 
+// Fused G2P tail: plasticity(cdg) of THIS substep followed by calculate_force() of the NEXT substep's P2G
+// (src/particles.h:134-141).  The reference evaluates them in two separate passes with an svd/polar_decomp
+// each; both are functions of the same U and singular values (F_new = U S' V^T keeps U), so the device does
+// ONE symmetric eigen-solve per particle per substep and derives both from it.  `stress` = -vol P(F_new) F_new^T.
+__device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const mat3 &cdg, mat3 &F, float &aux,
+                                                     mat3 &stress) {
+  const float vol = g.p[1];
+  if (g.type == MPMHIP_WATER) {  // src/particles.cpp:463-478
+    float j = aux * (cdg(0, 0) + cdg(1, 1) + cdg(2, 2) - 2.0f);
+    j = (j < 0.1f) ? 0.1f : j;
+    aux = j;
+    const float p = g.p[2] * (powf(j, -g.p[3]) - 1.0f);
+    const float dd = vol * j * p;
+#pragma unroll
+    for (int i = 0; i < 9; i++) stress.m[i] = (i % 4 == 0) ? dd : 0.0f;
+    return;
+  }
+  F = mat_mul(cdg, F);
+  if (g.type == MPMHIP_LINEAR) {
+    stress = calculate_force(g, F, aux);
+    return;
+  }
+  mat3 U; float lam[3], s[3];
+  sym_eig3_FFt(F, U, lam);
+  const float detF = mat_det(F);
+  signed_sigma(lam, detF, s);
+  const float mu0 = g.p[2], la0 = g.p[3];
+  float d[3];
+  if (g.type == MPMHIP_JELLY) {  // src/particles.cpp:391-416
+    const float vol_l = la0 * (detF - 1.0f) * detF;
+#pragma unroll
+    for (int i = 0; i < 3; i++) d[i] = -vol * fmaf(2.0f * mu0, lam[i] - s[i], vol_l);
+    stress = sandwich(U, d);
+    return;
+  }
+  if (g.type == MPMHIP_ELASTIC) {  // src/particles.cpp:798-812
+    float ls[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) ls[i] = logf(s[i]);
+    const float tr = ls[0] + ls[1] + ls[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) d[i] = -vol * fmaf(2.0f * mu0, ls[i], la0 * tr);
+    stress = sandwich(U, d);
+    return;
+  }
+  float ratio[3];  // s'_i / s_i
+  if (g.type == MPMHIP_SNOW) {  // src/particles.cpp:207-252
+    const float lo = 1.0f - g.p[5], hi = 1.0f + g.p[6];
+    float det_o = 1.0f, det_n = 1.0f, sn[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      sn[i] = fminf(fmaxf(s[i], lo), hi);
+      det_o *= s[i];
+      det_n *= sn[i];
+      ratio[i] = sn[i] / s[i];
+    }
+    float Jp = aux * det_o / det_n;
+    if (!(Jp <= g.p[8])) Jp = g.p[8];
+    if (!(Jp >= g.p[7])) Jp = g.p[7];
+    aux = Jp;
+    const float e = expf(g.p[4] * (1.0f - Jp));
+    const float mu = mu0 * e, la = la0 * e;
+    const float vol_l = la * (det_n - 1.0f) * det_n;
+#pragma unroll
+    for (int i = 0; i < 3; i++) d[i] = -vol * fmaf(2.0f * mu, sn[i] * sn[i] - sn[i], vol_l);
+  } else if (g.type == MPMHIP_SAND) {  // src/particles.cpp:599-647
+    const float alpha = g.p[4], coh = g.p[5], beta = g.p[6];
+    float eps[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) eps[i] = logf(fmaxf(fabsf(s[i]), 1e-4f)) - coh;
+    const float sum = eps[0] + eps[1] + eps[2];
+    const float tr = sum + aux;
+    float eh[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) eh[i] = eps[i] - tr * (1.0f / 3.0f);
+    const float ehn = sqrtf(fmaf(eh[0], eh[0], fmaf(eh[1], eh[1], eh[2] * eh[2])));
+    float h[3];  // log of the projected singular values
+    if (tr >= 0.0f) {
+      h[0] = coh; h[1] = coh; h[2] = coh;
+      aux = fmaf(beta, sum, aux);
+    } else {
+      aux = 0.0f;
+      const float dg = ehn + (3.0f * la0 + 2.0f * mu0) / (2.0f * mu0) * tr * alpha;
+      const float k = (dg <= 0.0f) ? 0.0f : dg / ehn;
+#pragma unroll
+      for (int i = 0; i < 3; i++) h[i] = eps[i] - k * eh[i] + coh;
+    }
+    const float trh = h[0] + h[1] + h[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      ratio[i] = expf(h[i]) / s[i];
+      d[i] = -vol * fmaf(2.0f * mu0, h[i], la0 * trh);
+    }
+  } else {  // MPMHIP_VON_MISES, src/particles.cpp:701-732
+    float e[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) e[i] = logf(s[i]);
+    const float tr = e[0] + e[1] + e[2];
+    float eh[3] = {e[0] - tr * (1.0f / 3.0f), e[1] - tr * (1.0f / 3.0f), e[2] - tr * (1.0f / 3.0f)};
+    const float n2 = fmaf(eh[0], eh[0], fmaf(eh[1], eh[1], eh[2] * eh[2]));
+    const float dg = n2 - g.p[4] / (2.0f * mu0);
+    float h[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      h[i] = (dg <= 0.0f) ? e[i] : e[i] - (dg / n2) * eh[i];
+      ratio[i] = (dg <= 0.0f) ? 1.0f : expf(h[i]) / s[i];
+    }
+    const float trh = h[0] + h[1] + h[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) d[i] = -vol * fmaf(2.0f * mu0, h[i], la0 * trh);
+    if (dg <= 0.0f) { stress = sandwich(U, d); return; }
+  }
+  F = mat_mul(sandwich(U, ratio), F);
+  stress = sandwich(U, d);
+}
+
 // friction_project — src/mpm_fwd.h:25-57
 __device__ __forceinline__ void friction_project(float v[3], const float vb[3], const float n[3], float friction) {
   if (friction == -1.0f) { v[0] = vb[0]; v[1] = vb[1]; v[2] = vb[2]; return; }

@@ -1,31 +1,39 @@
 // taichi_mpm_amd/csrc/mpmhip.hip — MI355X (gfx950) MLS-MPM time-stepping core: HIP kernels + C ABI.
 //
-// One substep (reference: MPM<3>::substep, src/mpm.cpp:452-575) is
+// One substep (reference: MPM<3>::substep, src/mpm.cpp:452-575):
 //
-//   sort      k_build_keys -> k_scan_*<0> (bitmap prefix) -> k_emit_active -> k_rank -> k_block_totals ->
-//             k_scan_*<1> (block offsets) -> k_cell_start -> k_reorder -> k_sort_cleanup
-//             (replaces sort_particles_and_populate_grid src/mpm.cpp:770-918, sort_allocator :752-768
-//              and clear_boundary_particles :582-633: dead particles simply get no slot)
-//   P2G       k_p2g        one wavefront per active 4x4x4-cell block, one lane per cell: register
-//                          accumulation over the cell's particles, then DS float atomics into the 6^3-node
-//                          LDS tile, tile written out non-atomically                (src/transfer.cpp:467-569)
-//   grid      k_grid       sums the <=8 overlapping block tiles of every touched grid block, normalises,
-//                          applies gravity + level-set boundary                  (src/mpm.cpp:277-372)
-//   G2P       k_g2p        6^3 velocity tile in LDS, 27-tap gather, F update + plasticity, advection
-//                                                                                (src/transfer.cpp:837-954)
+//   sort   (index sort; replaces sort_particles_and_populate_grid src/mpm.cpp:770-918 and
+//           clear_boundary_particles :582-633 — dead particles simply drop out of the index)
+//          [k_build_keys]  key = Morton(block) << 6 | cell-in-block per particle (normally produced by the
+//                          previous substep's k_g2p, which knows the new position)
+//          k_pack_flags -> k_scan_*<0>  active-block bitmap + popcount prefix: dense slot of every active block
+//          k_emit_active, k_rank (rank of each particle in its cell, run-aggregated atomics),
+//          k_block_totals -> k_scan_*<1> -> k_cell_start, k_perm (sorted position -> particle slot)
+//   P2G    k_p2g   one wavefront per active 4x4x4-cell block, ONE LANE PER CELL: register accumulation of the
+//                  27x4 node contributions over the cell's particles, ordered non-atomic float4 merge into the
+//                  block's 6^3-node LDS tile, tile written out whole             (src/transfer.cpp:467-569)
+//   grid   k_grid  sums the <=8 overlapping block tiles of every touched grid block, normalises,
+//                  gravity + level-set boundary                                  (src/mpm.cpp:277-372)
+//   G2P    k_g2p   6^3 velocity tile in LDS, 27-tap gather, F update, plasticity AND the next substep's stress
+//                  from one eigen-solve, advection, next key                     (src/transfer.cpp:837-954)
 //
-// Data layout (all fp32, resident in HBM for the life of the ctx):
-//   particles   SoA, 25 float arrays (x3 v3 B9 F9 aux1) + u8 group id + i32 creation id, ping-pong pair;
-//               physically sorted every substep by key = Morton(block) << 6 | cell-in-block, so a
-//               workgroup's particles are one contiguous, coalesced range.
-//   blocks      an "active" block = 4x4x4 cells holding >=1 particle.  A bitmap over the Morton block
-//               space + per-word popcount prefix gives each active block a dense slot (its rank in
-//               Morton order) without any pass over the whole grid.
-//   tiles       float4[216] per active block: the block's private (4+2)^3-node P2G result.
-//   gridv       float4[64] per touched grid block (v.xyz, m) in block-major order; slot = 8*a+o of the
-//               owning (active block a, corner offset o); `fat_slot` maps Morton block -> slot.
-// No global float atomics anywhere: inter-block write conflicts of P2G are resolved by the tile
-// reduction in k_grid, which makes the grid deterministic given the per-tile sums.
+// Data layout (fp32, resident in HBM for the life of the ctx):
+//   particles  two arrays of 64-byte records indexed by a stable particle slot (the reference's
+//              ParticleAllocator pool index, src/particle_allocator.h:36):
+//                RecG {x3, aux, F9, gid, pid, -}   what G2P reads and rewrites
+//                RecP {x3, v3, A9, gid}            what P2G reads;  A = stress*(-4 inv_dx dt) + apic_b*(4 m)
+//              (src/transfer.cpp:521-522) is produced by G2P, so P2G carries no constitutive work, and
+//              apic_b itself goes to a side array (it is only ever consumed through A).
+//              Particles never move in memory between substeps: `perm` (sorted position -> slot) is rebuilt
+//              every substep and both transfer kernels gather whole 64-byte records through it, one record per
+//              lane.  This mirrors the reference's own structure — sorted index array every substep
+//              (mpm.cpp:785-807) + physical reorder only every `reorder_interval` substeps (:811-813).
+//   blocks     an "active" block = 4x4x4 cells holding >=1 particle; bitmap over the Morton block space +
+//              per-word popcount prefix -> dense slot = rank in Morton order, no pass over the whole grid.
+//   tiles      float4[216] per active block: its private (4+2)^3-node P2G result.
+//   gridv      float4[64] per touched grid block (v.xyz, m); slot = 8a+o of the owning (active block a,
+//              corner offset o); `fat_slot` maps Morton block -> slot.
+// No float atomics anywhere (LDS float atomics cost ~2 cycles per lane on gfx950; global ones leave the L2).
 
 #include <hip/hip_runtime.h>
 
@@ -47,19 +55,29 @@ constexpr int BC = 64;   // cells per block
 constexpr int TS = 6;    // tile edge in nodes (BS + 2: quadratic stencil reaches base+2)
 constexpr int TN = 216;  // nodes per tile
 constexpr uint32_t INVALID = 0xFFFFFFFFu;
-constexpr int NF = 25;   // float fields per particle
-enum { FX = 0, FV = 3, FB = 6, FF = 15, FAUX = 24 };
 
-struct SoA {
-  float *f[NF];
-  uint8_t *gid;
-  int32_t *pid;
+// 64-byte particle records (4 x float4)
+struct alignas(16) RecG {  // G2P side
+  float x[3];
+  float aux;
+  float F[9];
+  uint32_t gid;
+  int32_t pid;  // creation id; < 0 marks a deleted slot
+  uint32_t pad;
 };
+struct alignas(16) RecP {  // P2G side
+  float x[3];
+  float v[3];
+  float A[9];
+  uint32_t gid;
+};
+static_assert(sizeof(RecG) == 64 && sizeof(RecP) == 64, "records must be 64 bytes");
+constexpr int BW = 12;  // floats per apic_b record (9 used): three float4
 
 struct Counters {
-  uint32_t n;         // live particles in the current SoA
-  uint32_t n_next;    // live particles after the reorder in flight
+  uint32_t n_sorted;  // live particles in the current sorted index
   uint32_t n_active;  // active blocks
+  uint32_t n_dead;    // slots marked deleted so far
   uint32_t error;     // bit0: active blocks exceeded max_blocks
 };
 
@@ -76,6 +94,8 @@ struct Params {
   int kbits;         // Morton bits per axis
   uint32_t nbw;      // bitmap words = 8^kbits / 32
   uint32_t max_blocks;
+  uint32_t n_slots;  // particle slots in use (host-known)
+  int store_b;       // keep apic_b in the side array
 };
 
 // ------------------------------------------------------------------------------------------------ Morton
@@ -111,48 +131,70 @@ __device__ __forceinline__ uint32_t block_slot(const uint32_t *__restrict__ bits
   return wprefix[bkey >> 5] + __popc(w & ((1u << (bkey & 31)) - 1u));
 }
 
+// key of a particle at position x with velocity v: Morton(block of its base cell) << 6 | cell in block;
+// INVALID if it must be deleted: non-finite x/v or near the domain wall when clean_boundary
+// (src/mpm.h:269-276, src/mpm.cpp:592-598), or a stencil that would leave the grid (reference: UB).
+__device__ __forceinline__ uint32_t particle_key(const Params &P, const float x[3], const float v[3], uint32_t &bkey) {
+  bool alive = true;
+  float X[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    alive = alive && isfinite(x[k]) && isfinite(v[k]);
+    X[k] = x[k] * P.idx;
+  }
+  if (P.clean_boundary) {
+    const float mn = fminf(X[0], fminf(X[1], X[2]));
+    const float mx = fmaxf(X[0] - P.res[0], fmaxf(X[1] - P.res[1], X[2] - P.res[2]));
+    alive = alive && !(mn < 7.0f || mx > -7.0f);
+  }
+  int b[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    alive = alive && (X[k] >= 0.5f);
+    b[k] = alive ? (int)(X[k] - 0.5f) : 0;  // MPMKernel<dim,2>::get_stencil_start, src/kernel.h:119-121
+    alive = alive && (b[k] + 2 <= P.res[k]);
+  }
+  bkey = INVALID;
+  if (!alive) return INVALID;
+  bkey = morton3(b[0] >> 2, b[1] >> 2, b[2] >> 2);
+  return (bkey << 6) | ((b[0] & 3) << 4) | ((b[1] & 3) << 2) | (b[2] & 3);
+}
+
+// mark the block active: a plain byte store (all writers store the same value: no atomics, no serialisation),
+// one per run of equal blocks among consecutive lanes; k_pack_flags turns the bytes into the bitmap.
+// Must be called by all lanes of the wave.
+__device__ __forceinline__ void flag_block(uint8_t *__restrict__ blk_flag, uint32_t bkey) {
+  const uint32_t prev = __shfl_up(bkey, 1);
+  if (bkey != INVALID && ((threadIdx.x & 63) == 0 || prev != bkey)) blk_flag[bkey] = 1;
+}
+
 // ------------------------------------------------------------------------------------------------ sort
-// key of a particle: Morton(block of its base cell) << 6 | cell in block; INVALID for dead particles
-// (non-finite x/v, near the domain wall when clean_boundary — src/mpm.h:269-276, src/mpm.cpp:592-598 —
-// or with a stencil that would leave the grid, where the reference has undefined behaviour).
-__global__ __launch_bounds__(256) void k_build_keys(Params P, SoA s, const Counters *__restrict__ cnt,
-                                                    uint32_t *__restrict__ key, uint8_t *__restrict__ blk_flag) {
-  const uint32_t n = cnt->n;
+// standalone key builder (first substep, after uploads, phase-level API); afterwards k_g2p produces the keys
+__global__ __launch_bounds__(256) void k_build_keys(Params P, RecG *__restrict__ rg, const RecP *__restrict__ rp,
+                                                    Counters *cnt, uint32_t *__restrict__ key,
+                                                    uint8_t *__restrict__ blk_flag) {
+  const uint32_t n = P.n_slots;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t nloop = (n + stride - 1) / stride;
   for (uint32_t it = 0; it < nloop; it++) {  // uniform trip count: all lanes take part in the shuffle
     const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
-    float X[3];
-    bool alive = i < n;
-    const uint32_t ii = alive ? i : 0;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const float x = s.f[FX + k][ii], v = s.f[FV + k][ii];
-      alive = alive && isfinite(x) && isfinite(v);
-      X[k] = x * P.idx;
-    }
-    if (P.clean_boundary) {
-      const float mn = fminf(X[0], fminf(X[1], X[2]));
-      const float mx = fmaxf(X[0] - P.res[0], fmaxf(X[1] - P.res[1], X[2] - P.res[2]));
-      alive = alive && !(mn < 7.0f || mx > -7.0f);
-    }
-    int b[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      alive = alive && (X[k] >= 0.5f);
-      b[k] = alive ? (int)(X[k] - 0.5f) : 0;  // MPMKernel<dim,2>::get_stencil_start, src/kernel.h:119-121
-      alive = alive && (b[k] + 2 <= P.res[k]);
-    }
     uint32_t kk = INVALID, bkey = INVALID;
-    if (alive) {
-      bkey = morton3(b[0] >> 2, b[1] >> 2, b[2] >> 2);
-      kk = (bkey << 6) | ((b[0] & 3) << 4) | ((b[1] & 3) << 2) | (b[2] & 3);
+    if (i < n) {
+      const float4 g0 = reinterpret_cast<const float4 *>(rg + i)[0];
+      const int32_t pid = rg[i].pid;
+      if (pid >= 0) {
+        const float4 p0 = reinterpret_cast<const float4 *>(rp + i)[0];
+        const float4 p1 = reinterpret_cast<const float4 *>(rp + i)[1];
+        const float x[3] = {g0.x, g0.y, g0.z}, v[3] = {p0.w, p1.x, p1.y};
+        kk = particle_key(P, x, v, bkey);
+        if (kk == INVALID) {  // delete for good (clear_boundary_particles)
+          rg[i].pid = -1;
+          atomicAdd(&cnt->n_dead, 1u);
+        }
+      }
+      key[i] = kk;
     }
-    // mark the block active: a plain byte store (all writers store the same value, no atomics, no
-    // serialisation), one per run of equal blocks in the wave; k_pack_flags turns the bytes into the bitmap
-    const uint32_t prev = __shfl_up(bkey, 1);
-    if (alive && ((threadIdx.x & 63) == 0 || prev != bkey)) blk_flag[bkey] = 1;
-    if (i < n) key[i] = kk;
+    flag_block(blk_flag, bkey);
   }
 }
 
@@ -166,8 +208,7 @@ __global__ __launch_bounds__(256) void k_pack_flags(Params P, uint8_t *__restric
     uint32_t m = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      // bytes are 0/1: gather bit 0 of each of the 4 bytes
-      const uint32_t v = q[k];
+      const uint32_t v = q[k];  // four 0/1 bytes -> four bits
       m |= ((v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u)) << (4 * k);
     }
     bits[w] = m;
@@ -180,10 +221,10 @@ __global__ __launch_bounds__(256) void k_pack_flags(Params P, uint8_t *__restric
 //   k_scan_apply   : workgroup i adds the partials before it to a local scan of its chunk
 // MODE 0: element w = popcount(bits[w]) (active-block bitmap; 8^k/8 bytes, 256 KiB for a 256^3 grid),
 //         out = word_prefix (number of active blocks with Morton key < 32 w), total -> cnt->n_active
-// MODE 1: element a = particles in active block a, out = act_start[0..n_active], total -> cnt->n_next
+// MODE 1: element a = particles in active block a, out = act_start[0..n_active], total -> cnt->n_sorted
 constexpr int SCAN_CHUNK = 2048;  // 256 threads x 8
 
-__device__ __forceinline__ uint32_t wg_exclusive_scan_256(uint32_t v, uint32_t *lds /*>=5*/, uint32_t &total) {
+__device__ __forceinline__ uint32_t wg_exclusive_scan_256(uint32_t v, uint32_t *lds /*>=4*/, uint32_t &total) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t inc = v;
 #pragma unroll
@@ -232,13 +273,11 @@ __global__ __launch_bounds__(256) void k_scan_apply(Params P, Counters *cnt, con
   const uint32_t n = scan_count<MODE>(P, cnt);
   const uint32_t base = blockIdx.x * SCAN_CHUNK;
   if (base >= n && !(n == 0 && blockIdx.x == 0)) return;
-  // sum of the partials of the chunks before this one
-  uint32_t pre = 0;
+  uint32_t pre = 0;  // sum of the partials of the chunks before this one
   for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256) pre += partials[j];
   uint32_t chunk_base;
   wg_exclusive_scan_256(pre, lds, chunk_base);
-  // thread t owns 8 consecutive elements
-  uint32_t v[8], sum = 0;
+  uint32_t v[8], sum = 0;  // thread t owns 8 consecutive elements
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const uint32_t i = base + threadIdx.x * 8 + k;
@@ -260,7 +299,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(Params P, Counters *cnt, con
       cnt->n_active = grand;
     } else {
       out[n] = grand;
-      cnt->n_next = grand;
+      cnt->n_sorted = grand;
     }
   }
 }
@@ -280,18 +319,18 @@ __global__ __launch_bounds__(256) void k_emit_active(Params P, const uint32_t *_
   }
 }
 
-// rank of each particle inside its cell.  Runs of equal keys in consecutive lanes (the common case:
-// particles are already nearly sorted) are aggregated into one returning atomic per run.
-__global__ __launch_bounds__(256) void k_rank(Params P, const Counters *__restrict__ cnt, uint32_t *__restrict__ key,
-                                              uint32_t *__restrict__ rank, uint32_t *__restrict__ cell_cnt,
-                                              const uint32_t *__restrict__ bits,
+// rank of each particle inside its cell.  Runs of equal keys in consecutive lanes are aggregated into one
+// returning atomic per run.  Overwrites key[i] with cidx = slot(block)*64 + cell.
+__global__ __launch_bounds__(256) void k_rank(Params P, uint32_t *__restrict__ key, uint32_t *__restrict__ rank,
+                                              uint32_t *__restrict__ cell_cnt, const uint32_t *__restrict__ bits,
                                               const uint32_t *__restrict__ wprefix) {
-  const uint32_t n = cnt->n;
+  const uint32_t n = P.n_slots;
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t nloop = (n + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t nloop = (n + stride - 1) / stride;
   for (uint32_t it = 0; it < nloop; it++) {  // uniform trip count: every lane takes part in the shuffles
-    const uint32_t i = it * gridDim.x * blockDim.x + blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t k = (i < n) ? key[i] : INVALID;
+    const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k = (i < n) ? key[i] : INVALID;
     uint32_t cidx = INVALID;
     if (k != INVALID) {
       const uint32_t slot = block_slot(bits, wprefix, k >> 6);
@@ -308,17 +347,17 @@ __global__ __launch_bounds__(256) void k_rank(Params P, const Counters *__restri
     if ((int)lane == start && cidx != INVALID) base = atomicAdd(&cell_cnt[cidx], (uint32_t)(end - start));
     base = __shfl(base, start);
     if (i < n) {
-      key[i] = cidx;  // from here on `key` holds slot*64 + cell
+      key[i] = cidx;
       rank[i] = base + (lane - start);
     }
   }
 }
 
 // one wave per active block: particles per block
-__global__ __launch_bounds__(256) void k_block_totals(const Counters *__restrict__ cnt,
+__global__ __launch_bounds__(256) void k_block_totals(Params P, const Counters *__restrict__ cnt,
                                                       const uint32_t *__restrict__ cell_cnt,
                                                       uint32_t *__restrict__ totals) {
-  const uint32_t na = min(cnt->n_active, 0x7fffffffu);
+  const uint32_t na = min(cnt->n_active, P.max_blocks);
   const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t a = wave; a < na; a += nwaves) {
@@ -329,10 +368,11 @@ __global__ __launch_bounds__(256) void k_block_totals(const Counters *__restrict
   }
 }
 
-// per-cell counts -> global start offset of every cell: cell_start[slot*64 + c], plus a sentinel at
-// [n_active*64] so that the particles of cell i are always [cell_start[i], cell_start[i+1])
+// per-cell counts -> start of every cell in the sorted index: cell_start[slot*64 + c], plus a sentinel at
+// [n_active*64], so the particles of cell i are always perm[cell_start[i] .. cell_start[i+1]).  Zeroes the
+// counters behind itself (they must be all-zero at the start of the next sort).
 __global__ __launch_bounds__(256) void k_cell_start(Params P, const Counters *__restrict__ cnt,
-                                                    const uint32_t *__restrict__ cell_cnt,
+                                                    uint32_t *__restrict__ cell_cnt,
                                                     const uint32_t *__restrict__ act_start,
                                                     uint32_t *__restrict__ cell_start) {
   const uint32_t na = min(cnt->n_active, P.max_blocks);
@@ -340,6 +380,7 @@ __global__ __launch_bounds__(256) void k_cell_start(Params P, const Counters *__
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t a = wave; a < na; a += nwaves) {
     const uint32_t c = cell_cnt[a * BC + lane];
+    cell_cnt[a * BC + lane] = 0;
     uint32_t v = c;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -352,132 +393,120 @@ __global__ __launch_bounds__(256) void k_cell_start(Params P, const Counters *__
   if (na == 0 && wave == 0 && lane == 0) cell_start[0] = 0;
 }
 
-// Layout of a block's particles in memory: RANK-MAJOR.  First the 0th particle of every non-empty cell (in cell
-// order), then the 1st particle of every cell that has one, ...  With the one-lane-per-cell mapping of k_p2g,
-// iteration r of the wave then reads 64 (or fewer) CONSECUTIVE particles: fully coalesced SoA loads.
-// dest[cell_start[c] + r] = final slot of the particle with rank r in cell c.  One wave per block.
-__global__ __launch_bounds__(256) void k_layout(Params P, const Counters *__restrict__ cnt,
-                                                const uint32_t *__restrict__ cell_start,
-                                                uint32_t *__restrict__ dest) {
-  const uint32_t na = min(cnt->n_active, P.max_blocks);
-  const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  for (uint32_t a = wave; a < na; a += nwaves) {
-    const uint32_t s0 = cell_start[a * BC + lane], s1 = cell_start[a * BC + lane + 1];
-    const uint32_t c = s1 - s0;
-    uint32_t run = __shfl(s0, 0);  // block start
-    for (uint32_t r = 0;; r++) {
-      const unsigned long long m = __ballot(c > r);
-      if (!m) break;
-      if (c > r) dest[s0 + r] = run + (uint32_t)__popcll(m & lt);
-      run += (uint32_t)__popcll(m);
-    }
-  }
-}
-
-// physical reorder: scatter every live particle to its sorted slot (sort_allocator, src/mpm.cpp:752-768,
-// done every substep here; dead particles are dropped = clear_boundary_particles, src/mpm.cpp:582-633)
-__global__ __launch_bounds__(256) void k_reorder(const Counters *__restrict__ cnt, SoA src, SoA dst,
-                                                 const uint32_t *__restrict__ key, const uint32_t *__restrict__ rank,
-                                                 const uint32_t *__restrict__ cell_start,
-                                                 const uint32_t *__restrict__ dest) {
-  const uint32_t n = cnt->n;
+// sorted position -> particle slot (the reference's sorted `particles` index vector, src/mpm.cpp:800-807)
+__global__ __launch_bounds__(256) void k_perm(Params P, const uint32_t *__restrict__ key,
+                                              const uint32_t *__restrict__ rank,
+                                              const uint32_t *__restrict__ cell_start, uint32_t *__restrict__ perm) {
+  const uint32_t n = P.n_slots;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint32_t c = key[i];
-    if (c == INVALID) continue;
-    const uint32_t j = dest[cell_start[c] + rank[i]];
-#pragma unroll
-    for (int f = 0; f < NF; f++) dst.f[f][j] = src.f[f][i];
-    dst.gid[j] = src.gid[i];
-    dst.pid[j] = src.pid[i];
+    if (c != INVALID) perm[cell_start[c] + rank[i]] = i;
   }
 }
 
-__global__ __launch_bounds__(256) void k_sort_cleanup(Params P, Counters *cnt, uint32_t *__restrict__ cell_cnt) {
-  const uint32_t na = min(cnt->n_active, P.max_blocks);
-  const uint32_t total = na * BC;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) cell_cnt[i] = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) cnt->n = cnt->n_next;
+// physical reorder + compaction (sort_allocator, src/mpm.cpp:752-768): records gathered into sorted order
+__global__ __launch_bounds__(256) void k_gather_records(const Counters *__restrict__ cnt,
+                                                        const uint32_t *__restrict__ perm, const float4 *__restrict__ rg,
+                                                        const float4 *__restrict__ rp, const float4 *__restrict__ rb,
+                                                        float4 *__restrict__ rg2, float4 *__restrict__ rp2,
+                                                        float4 *__restrict__ rb2) {
+  const uint32_t n = cnt->n_sorted;
+  // one float4 per thread: 4 threads per 64-byte record
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n * 4u; t += gridDim.x * blockDim.x) {
+    const uint32_t j = t >> 2, q = t & 3;
+    const uint32_t i = perm[j];
+    rg2[(size_t)j * 4 + q] = rg[(size_t)i * 4 + q];
+    rp2[(size_t)j * 4 + q] = rp[(size_t)i * 4 + q];
+    if (q < 3) rb2[(size_t)j * 3 + q] = rb[(size_t)i * 3 + q];
+  }
+}
+__global__ __launch_bounds__(256) void k_identity_perm(const Counters *__restrict__ cnt, uint32_t *__restrict__ perm) {
+  const uint32_t n = cnt->n_sorted;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) perm[i] = i;
+}
+
+// ------------------------------------------------------------------------------------------------ affine
+// A = stress * (-4 inv_dx dt) + apic_b * (4 m)   (src/transfer.cpp:465,507,521-522) for every live particle,
+// from (F, aux, apic_b).  Needed only when the state did not come out of k_g2p (first substep, uploads).
+__global__ __launch_bounds__(256) void k_affine(Params P, const RecG *__restrict__ rg, RecP *__restrict__ rp,
+                                                const float *__restrict__ rb, const GroupParams *__restrict__ groups) {
+  const float S = -4.0f * P.idx * P.dt;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_slots; i += gridDim.x * blockDim.x) {
+    const RecG r = rg[i];
+    if (r.pid < 0) continue;
+    const GroupParams g = groups[r.gid];
+    mat3 F;
+#pragma unroll
+    for (int k = 0; k < 9; k++) F.m[k] = r.F[k];
+    const mat3 stress = calculate_force(g, F, r.aux);
+    const float m4 = 4.0f * g.p[0];
+#pragma unroll
+    for (int k = 0; k < 9; k++) rp[i].A[k] = fmaf(stress.m[k], S, rb[(size_t)i * BW + k] * m4);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ P2G
 // rasterize_optimized / block_op_normal (src/transfer.cpp:467-569).
-// Mapping: one wavefront per active 4^3-cell block, ONE LANE PER CELL.  Particles are sorted by cell, so lane c
-// walks the particles of its cell sequentially and accumulates their 27x4 node contributions in registers
-// (the reference walks cells sequentially inside a block and accumulates into its scratch tile the same
-// way, :474-483).  Write conflicts between particles of one cell therefore never reach memory; the 27x4
-// per-cell sums are then merged into the block's 6^3-node LDS tile by ordered, non-atomic float4
-// read-modify-writes (see below).  The tile is written out non-atomically; conflicts between blocks are
-// resolved by k_grid.  No atomics of any kind on the P2G path.
-__global__ __launch_bounds__(64) void k_p2g(Params P, SoA s, const Counters *__restrict__ cnt,
+// Mapping: one wavefront per active 4^3-cell block, ONE LANE PER CELL.  The sorted index lists the particles
+// of each cell contiguously, so lane c walks its cell's particles and accumulates their 27x4 node contributions
+// in registers (the reference walks cells sequentially inside a block and accumulates into its scratch tile
+// the same way, :474-483).  Write conflicts between particles of one cell therefore never reach memory; the
+// per-cell sums are merged into the block's 6^3-node LDS tile by ordered, non-atomic float4 read-modify-writes,
+// and the tile is written out whole; conflicts between blocks are resolved by k_grid.
+__global__ __launch_bounds__(64, 2) void k_p2g(Params P, const float4 *__restrict__ rp, const Counters *__restrict__ cnt,
                                             const uint32_t *__restrict__ act_blk,
                                             const uint32_t *__restrict__ cell_start,
+                                            const uint32_t *__restrict__ perm,
                                             const GroupParams *__restrict__ groups, float4 *__restrict__ tiles) {
   __shared__ float4 tile[TN];  // (m*vx, m*vy, m*vz, m) per node of the block's 6^3 tile
   const uint32_t na = min(cnt->n_active, P.max_blocks);
   const int lane = threadIdx.x;
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
   const int nbase = (cx * TS + cy) * TS + cz;
-  const float S = -4.0f * P.idx * P.dt;  // src/transfer.cpp:465
   for (uint32_t a = blockIdx.x; a < na; a += gridDim.x) {
     for (int t = lane; t < TN; t += 64) tile[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();
     int bx, by, bz;
     demorton3(act_blk[a], bx, by, bz);
     const float ox = (float)(bx * BS + cx), oy = (float)(by * BS + cy), oz = (float)(bz * BS + cz);
-    const uint32_t cs0 = cell_start[a * BC + lane];
-    const uint32_t count = cell_start[a * BC + lane + 1] - cs0;
-    uint32_t run = __shfl(cs0, 0);  // first particle of the block; rank-major layout (k_layout)
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t p0 = cell_start[a * BC + lane], p1 = cell_start[a * BC + lane + 1];
     float acc[27][4];
 #pragma unroll
     for (int n = 0; n < 27; n++) { acc[n][0] = 0.0f; acc[n][1] = 0.0f; acc[n][2] = 0.0f; acc[n][3] = 0.0f; }
-    for (uint32_t r = 0;; r++) {
-      const unsigned long long am = __ballot(count > r);
-      if (!am) break;
-      const uint32_t p = run + (uint32_t)__popcll(am & lt);
-      run += (uint32_t)__popcll(am);
-      if (count <= r) continue;
-      const GroupParams g = groups[s.gid[p]];
-      const float mass = g.p[0];
-      float v[3] = {s.f[FV][p], s.f[FV + 1][p], s.f[FV + 2][p]};
+    for (uint32_t p = p0; p < p1; p++) {
+      const size_t i = perm[p];
+      const float4 q0 = rp[i * 4 + 0], q1 = rp[i * 4 + 1], q2 = rp[i * 4 + 2], q3 = rp[i * 4 + 3];
+      const float mass = groups[__float_as_uint(q3.w)].p[0];
+      float v0 = q0.w, v1 = q1.x, v2 = q1.y;
       if (P.particle_gravity) {  // src/transfer.cpp:485-487
-#pragma unroll
-        for (int k = 0; k < 3; k++) v[k] = fmaf(P.g[k], P.dt, v[k]);
+        v0 = fmaf(P.g[0], P.dt, v0); v1 = fmaf(P.g[1], P.dt, v1); v2 = fmaf(P.g[2], P.dt, v2);
       }
       // position relative to the base cell, in grid units: in [0.5, 1.5)^3  (:490,518)
-      const float r0 = s.f[FX][p] * P.idx - ox, r1 = s.f[FX + 1][p] * P.idx - oy, r2 = s.f[FX + 2][p] * P.idx - oz;
+      const float r0 = q0.x * P.idx - ox, r1 = q0.y * P.idx - oy, r2 = q0.z * P.idx - oz;
       float w0[3], w1[3], w2[3];
       bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
-      mat3 F, B;
+      const float A00 = q1.z, A01 = q1.w, A02 = q2.x, A10 = q2.y, A11 = q2.z, A12 = q2.w, A20 = q3.x, A21 = q3.y,
+                  A22 = q3.z;
+      const float mv0 = mass * v0, mv1 = mass * v1, mv2 = mass * v2;
 #pragma unroll
-      for (int k = 0; k < 9; k++) { F.m[k] = s.f[FF + k][p]; B.m[k] = s.f[FB + k][p]; }
-      const mat3 stress = calculate_force(g, F, s.f[FAUX][p]);  // :509
-      mat3 A;
-      const float m4 = 4.0f * mass;  // Kernel::inv_D() * mass, :507
-#pragma unroll
-      for (int k = 0; k < 9; k++) A.m[k] = fmaf(stress.m[k], S, B.m[k] * m4);  // :521-522
-      const float mv0 = mass * v[0], mv1 = mass * v[1], mv2 = mass * v[2];
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        const float d0 = r0 - (float)i;
+      for (int i3 = 0; i3 < 3; i3++) {
+        const float d0 = r0 - (float)i3;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
           const float d1 = r1 - (float)j;
-          const float wij = w0[i] * w1[j];
+          const float wij = w0[i3] * w1[j];
 #pragma unroll
           for (int k = 0; k < 3; k++) {
             const float d2 = r2 - (float)k;
             const float w = wij * w2[k];
-            const int n = (i * 3 + j) * 3 + k;
+            const int n = (i3 * 3 + j) * 3 + k;
             // :535-541  contrib = (affine * dpos + mass*v, mass); g += weight * contrib
-            const float q0 = fmaf(A(0, 2), d2, fmaf(A(0, 1), d1, fmaf(A(0, 0), d0, mv0)));
-            const float q1 = fmaf(A(1, 2), d2, fmaf(A(1, 1), d1, fmaf(A(1, 0), d0, mv1)));
-            const float q2 = fmaf(A(2, 2), d2, fmaf(A(2, 1), d1, fmaf(A(2, 0), d0, mv2)));
-            acc[n][0] = fmaf(w, q0, acc[n][0]);
-            acc[n][1] = fmaf(w, q1, acc[n][1]);
-            acc[n][2] = fmaf(w, q2, acc[n][2]);
+            const float c0 = fmaf(A02, d2, fmaf(A01, d1, fmaf(A00, d0, mv0)));
+            const float c1 = fmaf(A12, d2, fmaf(A11, d1, fmaf(A10, d0, mv1)));
+            const float c2 = fmaf(A22, d2, fmaf(A21, d1, fmaf(A20, d0, mv2)));
+            acc[n][0] = fmaf(w, c0, acc[n][0]);
+            acc[n][1] = fmaf(w, c1, acc[n][1]);
+            acc[n][2] = fmaf(w, c2, acc[n][2]);
             acc[n][3] = fmaf(w, mass, acc[n][3]);
           }
         }
@@ -489,14 +518,14 @@ __global__ __launch_bounds__(64) void k_p2g(Params P, SoA s, const Counters *__r
     // one wave execute in order, the wave_barrier keeps the compiler from interleaving them.  (DS float atomics
     // cost ~2 LDS cycles per LANE on gfx950 even without conflicts: measured 145 cycles per ds_add_f32.)
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+    for (int i3 = 0; i3 < 3; i3++)
 #pragma unroll
       for (int j = 0; j < 3; j++)
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-          const int n = (i * 3 + j) * 3 + k;
-          const int node = nbase + (i * TS + j) * TS + k;
-          if (count > 0) {
+          const int n = (i3 * 3 + j) * 3 + k;
+          const int node = nbase + (i3 * TS + j) * TS + k;
+          if (p1 > p0) {
             float4 t = tile[node];
             t.x += acc[n][0]; t.y += acc[n][1]; t.z += acc[n][2]; t.w += acc[n][3];
             tile[node] = t;
@@ -505,8 +534,7 @@ __global__ __launch_bounds__(64) void k_p2g(Params P, SoA s, const Counters *__r
           asm volatile("" ::: "memory");
         }
     __syncthreads();
-    for (int t = lane; t < TN; t += 64)
-      tiles[(size_t)a * TN + t] = tile[t];
+    for (int t = lane; t < TN; t += 64) tiles[(size_t)a * TN + t] = tile[t];
     __syncthreads();
   }
 }
@@ -534,8 +562,7 @@ __global__ __launch_bounds__(64) void k_grid(Params P, int mode, const Counters 
     int bx, by, bz;
     demorton3(act_blk[a], bx, by, bz);
     const int cx = bx + (o >> 2), cy = by + ((o >> 1) & 1), cz = bz + (o & 1);
-    // owner test + gather of contributing tiles (all wave-uniform)
-    bool owner = true;
+    bool owner = true;  // owner test + gather of contributing tiles (all wave-uniform)
     uint32_t src_slot[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) {
@@ -601,14 +628,19 @@ __global__ __launch_bounds__(64) void k_grid(Params P, int mode, const Counters 
 }
 
 // ------------------------------------------------------------------------------------------------ G2P
-// resample_optimized / block_op_normal (src/transfer.cpp:837-954)
-template <int NT, int MINW>
-__global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, SoA s, const Counters *__restrict__ cnt,
-                                            const uint32_t *__restrict__ act_blk,
-                                            const uint32_t *__restrict__ act_start,
-                                            const GroupParams *__restrict__ groups,
-                                            const float4 *__restrict__ gridv,
-                                            const uint32_t *__restrict__ fat_slot) {
+// resample_optimized / block_op_normal (src/transfer.cpp:837-954), one workgroup per active block, one
+// particle per lane through the sorted index.  Also produces, for the NEXT substep: the affine matrix A of
+// P2G (stress of the updated F from the same eigen-solve as the plasticity) and the sort key of the new position.
+template <int NT, int MINW, bool ROLL>
+__global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__ rg, float4 *__restrict__ rp,
+                                                  float4 *__restrict__ rb, const Counters *__restrict__ cnt,
+                                                  const uint32_t *__restrict__ act_blk,
+                                                  const uint32_t *__restrict__ act_start,
+                                                  const uint32_t *__restrict__ perm,
+                                                  const GroupParams *__restrict__ groups,
+                                                  const float4 *__restrict__ gridv,
+                                                  const uint32_t *__restrict__ fat_slot, Counters *cnt_w,
+                                                  uint32_t *__restrict__ key, uint8_t *__restrict__ blk_flag) {
   __shared__ float4 tile[TN];
   const uint32_t na = min(cnt->n_active, P.max_blocks);
   const int tid = threadIdx.x;
@@ -625,75 +657,106 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, SoA s, const Counter
     __syncthreads();
     const float ox = (float)(bx * BS), oy = (float)(by * BS), oz = (float)(bz * BS);
     const uint32_t p0 = act_start[a], p1 = act_start[a + 1];
-    for (uint32_t p = p0 + tid; p < p1; p += NT) {
-      const GroupParams g = groups[s.gid[p]];
-      const float x0 = s.f[FX][p], x1 = s.f[FX + 1][p], x2 = s.f[FX + 2][p];
-      const float X0 = x0 * P.idx - ox, X1 = x1 * P.idx - oy, X2 = x2 * P.idx - oz;
-      const int c0 = (int)(X0 - 0.5f), c1 = (int)(X1 - 0.5f), c2 = (int)(X2 - 0.5f);
-      const float r0 = X0 - (float)c0, r1 = X1 - (float)c1, r2 = X2 - (float)c2;
-      float w0[3], w1[3], w2[3];
-      bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
-      float v0 = 0, v1 = 0, v2 = 0;
-      mat3 b;
+    const uint32_t nloop = (p1 - p0 + NT - 1) / NT;
+    for (uint32_t it = 0; it < nloop; it++) {  // uniform trip count (flag_block shuffles)
+      const uint32_t p = p0 + it * NT + tid;
+      uint32_t bkey = INVALID;
+      if (p < p1) {
+        const size_t i = perm[p];
+        const float4 g0 = rg[i * 4 + 0], g1 = rg[i * 4 + 1], g2 = rg[i * 4 + 2], g3 = rg[i * 4 + 3];
+        const uint32_t gid = __float_as_uint(g3.y);
+        const GroupParams &g = groups[gid];  // read at use (L1-resident table): keeps 20 VGPRs free
+        const float x0 = g0.x, x1 = g0.y, x2 = g0.z;
+        const float X0 = x0 * P.idx - ox, X1 = x1 * P.idx - oy, X2 = x2 * P.idx - oz;
+        const int c0 = (int)(X0 - 0.5f), c1 = (int)(X1 - 0.5f), c2 = (int)(X2 - 0.5f);
+        const float r0 = X0 - (float)c0, r1 = X1 - (float)c1, r2 = X2 - (float)c2;
+        float w0[3], w1[3], w2[3];
+        bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
+        float v0 = 0, v1 = 0, v2 = 0;
+        mat3 b;
 #pragma unroll
-      for (int k = 0; k < 9; k++) b.m[k] = 0.0f;
-      const int nbase = (c0 * TS + c1) * TS + c2;
+        for (int k = 0; k < 9; k++) b.m[k] = 0.0f;
+        const int nbase = (c0 * TS + c1) * TS + c2;
+        auto plane = [&](int i3) __attribute__((always_inline)) {
+          const float d0 = r0 - (float)i3;
 #pragma unroll
-      for (int i = 0; i < 3; i++) {
-        const float d0 = r0 - (float)i;
+          for (int j = 0; j < 3; j++) {
+            const float d1 = r1 - (float)j;
+            const float wij = w0[i3] * w1[j];
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-          const float d1 = r1 - (float)j;
-          const float wij = w0[i] * w1[j];
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            const float d2 = r2 - (float)k;
-            const float w = wij * w2[k];
-            const float4 gv = tile[nbase + (i * TS + j) * TS + k];
-            // :898-903  v_ = fma(grid_vel, w, v_);  b_[r] = fma(w*grid_vel, dpos[r], b_[r])
-            v0 = fmaf(gv.x, w, v0); v1 = fmaf(gv.y, w, v1); v2 = fmaf(gv.z, w, v2);
-            const float a0 = w * gv.x, a1 = w * gv.y, a2 = w * gv.z;
-            b(0, 0) = fmaf(a0, d0, b(0, 0)); b(0, 1) = fmaf(a0, d1, b(0, 1)); b(0, 2) = fmaf(a0, d2, b(0, 2));
-            b(1, 0) = fmaf(a1, d0, b(1, 0)); b(1, 1) = fmaf(a1, d1, b(1, 1)); b(1, 2) = fmaf(a1, d2, b(1, 2));
-            b(2, 0) = fmaf(a2, d0, b(2, 0)); b(2, 1) = fmaf(a2, d1, b(2, 1)); b(2, 2) = fmaf(a2, d2, b(2, 2));
+            for (int k = 0; k < 3; k++) {
+              const float d2 = r2 - (float)k;
+              const float w = wij * w2[k];
+              const float4 gv = tile[nbase + (i3 * TS + j) * TS + k];
+              // :898-903  v_ = fma(grid_vel, w, v_);  b_[r] = fma(w*grid_vel, dpos[r], b_[r])
+              v0 = fmaf(gv.x, w, v0); v1 = fmaf(gv.y, w, v1); v2 = fmaf(gv.z, w, v2);
+              const float a0 = w * gv.x, a1 = w * gv.y, a2 = w * gv.z;
+              b(0, 0) = fmaf(a0, d0, b(0, 0)); b(0, 1) = fmaf(a0, d1, b(0, 1)); b(0, 2) = fmaf(a0, d2, b(0, 2));
+              b(1, 0) = fmaf(a1, d0, b(1, 0)); b(1, 1) = fmaf(a1, d1, b(1, 1)); b(1, 2) = fmaf(a1, d2, b(1, 2));
+              b(2, 0) = fmaf(a2, d0, b(2, 0)); b(2, 1) = fmaf(a2, d1, b(2, 1)); b(2, 2) = fmaf(a2, d2, b(2, 2));
+            }
           }
+        };
+        if constexpr (ROLL) {  // rolled i-loop: 9 LDS reads in flight instead of 27 (VGPR pressure -> occupancy)
+#pragma unroll 1
+          for (int i3 = 0; i3 < 3; i3++) plane(i3);
+        } else {
+          plane(0); plane(1); plane(2);
         }
-        __builtin_amdgcn_sched_barrier(0);  // keep at most one i-plane (9 float4 LDS reads) in flight: VGPR pressure
-      }
-      // apic_b = damp_affine_momemtum(b) (src/mpm.h:465-469); the reference's optimised path has a bug
-      // here (passes the block index, transfer.cpp:925-926) — we implement the intended damping.
-      if (P.rpic_damping != 0.0f || P.apic_damping != 0.0f) {
-        const float ks = 1.0f - P.rpic_damping, ka = 1.0f - P.apic_damping;
+        mat3 cdg;  // :940-942  cdg = I + (-4 inv_dx dt) b   (undamped b, as in the reference)
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
-          for (int c = 0; c < 3; c++) {
-            const float sym = 0.5f * (b(r, c) + b(c, r));
-            s.f[FB + 3 * r + c][p] = ks * sym + ka * (b(r, c) - sym);
-          }
-      } else {
+          for (int c = 0; c < 3; c++) cdg(r, c) = fmaf(scale, b(r, c), (r == c) ? 1.0f : 0.0f);
+        // apic_b = damp_affine_momemtum(b) (src/mpm.h:465-469); the reference's optimised path has a bug
+        // here (passes the block index, transfer.cpp:925-926) — we implement the intended damping.
+        if (P.rpic_damping != 0.0f || P.apic_damping != 0.0f) {
+          const float ks = 1.0f - P.rpic_damping, ka = 1.0f - P.apic_damping;
+          mat3 bd;
 #pragma unroll
-        for (int k = 0; k < 9; k++) s.f[FB + k][p] = b.m[k];
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              const float sym = 0.5f * (b(r, c) + b(c, r));
+              bd(r, c) = ks * sym + ka * (b(r, c) - sym);
+            }
+          b = bd;
+        }
+        mat3 F;
+        F.m[0] = g1.x; F.m[1] = g1.y; F.m[2] = g1.z; F.m[3] = g1.w; F.m[4] = g2.x; F.m[5] = g2.y; F.m[6] = g2.z;
+        F.m[7] = g2.w; F.m[8] = g3.x;
+        float aux = g0.w;
+        mat3 stress;
+        plasticity_and_force(g, cdg, F, aux, stress);  // :950 + next substep's :509
+        const float nx0 = fmaf(v0, P.dt, x0), nx1 = fmaf(v1, P.dt, x1), nx2 = fmaf(v2, P.dt, x2);  // :951
+        const float m4 = 4.0f * g.p[0];
+        float A[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) A[k] = fmaf(stress.m[k], scale, b.m[k] * m4);  // next P2G's :521-522
+        // next substep's key; deleted particles (clear_boundary_particles) are marked for good
+        const float nx[3] = {nx0, nx1, nx2}, nv[3] = {v0, v1, v2};
+        const uint32_t kk = particle_key(P, nx, nv, bkey);
+        int32_t pid = __float_as_int(g3.z);
+        if (kk == INVALID) {
+          pid = -1;
+          atomicAdd(&cnt_w->n_dead, 1u);
+        }
+        key[i] = kk;
+        rg[i * 4 + 0] = make_float4(nx0, nx1, nx2, aux);
+        rg[i * 4 + 1] = make_float4(F.m[0], F.m[1], F.m[2], F.m[3]);
+        rg[i * 4 + 2] = make_float4(F.m[4], F.m[5], F.m[6], F.m[7]);
+        rg[i * 4 + 3] = make_float4(F.m[8], g3.y, __int_as_float(pid), 0.0f);
+        rp[i * 4 + 0] = make_float4(nx0, nx1, nx2, v0);
+        rp[i * 4 + 1] = make_float4(v1, v2, A[0], A[1]);
+        rp[i * 4 + 2] = make_float4(A[2], A[3], A[4], A[5]);
+        rp[i * 4 + 3] = make_float4(A[6], A[7], A[8], g3.y);
+        if (P.store_b) {
+          rb[i * 3 + 0] = make_float4(b.m[0], b.m[1], b.m[2], b.m[3]);
+          rb[i * 3 + 1] = make_float4(b.m[4], b.m[5], b.m[6], b.m[7]);
+          rb[i * 3 + 2] = make_float4(b.m[8], 0.0f, 0.0f, 0.0f);
+        }
       }
-      s.f[FV][p] = v0; s.f[FV + 1][p] = v1; s.f[FV + 2][p] = v2;
-      mat3 cdg;  // :940-942  cdg = I + (-4 inv_dx dt) b
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) cdg(r, c) = fmaf(scale, b(r, c), (r == c) ? 1.0f : 0.0f);
-      mat3 F;
-#pragma unroll
-      for (int k = 0; k < 9; k++) F.m[k] = s.f[FF + k][p];
-      float aux = s.f[FAUX][p];
-      plasticity(g, cdg, F, aux);  // :950
-      if (g.type != MPMHIP_WATER) {
-#pragma unroll
-        for (int k = 0; k < 9; k++) s.f[FF + k][p] = F.m[k];
-      }
-      s.f[FAUX][p] = aux;
-      s.f[FX][p] = fmaf(v0, P.dt, x0);  // :951
-      s.f[FX + 1][p] = fmaf(v1, P.dt, x1);
-      s.f[FX + 2][p] = fmaf(v2, P.dt, x2);
+      flag_block(blk_flag, bkey);
     }
     __syncthreads();
   }
@@ -722,13 +785,21 @@ __global__ void k_debug_force(GroupParams g, int64_t n, const float *F, const fl
     for (int k = 0; k < 9; k++) out[9 * i + k] = r.m[k];
   }
 }
-__global__ void k_debug_plasticity(GroupParams g, int64_t n, const float *cdg, float *F, float *aux) {
+// plasticity alone, or (force_out != nullptr) the fused plasticity + next-step force of k_g2p
+__global__ void k_debug_plasticity(GroupParams g, int64_t n, const float *cdg, float *F, float *aux, float *force_out) {
   for (int64_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     mat3 f, c;
     for (int k = 0; k < 9; k++) { f.m[k] = F[9 * i + k]; c.m[k] = cdg[9 * i + k]; }
     float a = aux[i];
-    plasticity(g, c, f, a);
-    for (int k = 0; k < 9; k++) F[9 * i + k] = f.m[k];
+    if (force_out) {
+      mat3 st;
+      plasticity_and_force(g, c, f, a, st);
+      for (int k = 0; k < 9; k++) force_out[9 * i + k] = st.m[k];
+    } else {
+      plasticity(g, c, f, a);
+    }
+    if (g.type != MPMHIP_WATER)
+      for (int k = 0; k < 9; k++) F[9 * i + k] = f.m[k];
     aux[i] = a;
   }
 }
@@ -750,18 +821,15 @@ struct mpmhip_ctx {
   std::string err;
   // particles
   int64_t cap = 0;
-  int64_t n_host = 0;     // upper bound of live particles (exact until something is deleted)
+  int64_t n_slots = 0;  // slots in use (live + deleted)
   int32_t next_pid = 0;
-  SoA soa[2];
-  int cur = 0;
-  float *pool_f[2] = {nullptr, nullptr};
-  uint8_t *pool_g[2] = {nullptr, nullptr};
-  int32_t *pool_i[2] = {nullptr, nullptr};
-  uint32_t *key = nullptr, *rank = nullptr;
+  RecG *rg = nullptr, *rg2 = nullptr;
+  RecP *rp = nullptr, *rp2 = nullptr;
+  float *rb = nullptr, *rb2 = nullptr;
+  uint32_t *key = nullptr, *rank = nullptr, *perm = nullptr;
   // blocks
   uint32_t NB = 0;
   uint8_t *blk_flag = nullptr;
-  uint32_t *dest = nullptr;
   uint32_t *bits = nullptr, *wprefix = nullptr, *act_blk = nullptr, *act_start = nullptr, *totals = nullptr;
   uint32_t *cell_cnt = nullptr, *cell_start = nullptr, *partials = nullptr, *fat_slot = nullptr;
   float4 *tiles = nullptr, *gridv = nullptr, *dense = nullptr;
@@ -769,8 +837,11 @@ struct mpmhip_ctx {
   std::vector<GroupParams> groups;
   GroupParams *d_groups = nullptr;
   int groups_cap = 256;
-  bool sorted = false;
-  int g2p_minw = 2;  // tuning knob (env MPMHIP_G2P_MINW): __launch_bounds__ waves/SIMD of k_g2p
+  bool sorted = false;        // perm / cell_start describe the current positions
+  bool keys_valid = false;    // key[] + block flags describe the current positions (set by k_g2p)
+  bool affine_valid = false;  // RecP.A matches (F, aux, apic_b)
+  int g2p_minw = 13;          // tuning knob (env MPMHIP_G2P_MINW): __launch_bounds__ waves/SIMD of k_g2p
+  int reorder_interval = 0;   // physical reorder every this many substeps (0 = never); env MPMHIP_REORDER_INTERVAL
   float t = 0.0f, request_t = 0.0f;  // `real` accumulators, as in the reference (src/mpm.h:99, mpm.cpp:573)
   int64_t substeps = 0;
   // profiling
@@ -800,14 +871,6 @@ static int fail(mpmhip_ctx *c, int code, const char *fmt, ...) {
 
 template <typename T>
 static hipError_t dmalloc(T **p, size_t count) { return hipMalloc((void **)p, count * sizeof(T)); }
-
-static void bind_soa(mpmhip_ctx *c) {
-  for (int s = 0; s < 2; s++) {
-    for (int f = 0; f < NF; f++) c->soa[s].f[f] = c->pool_f[s] + (size_t)f * c->cap;
-    c->soa[s].gid = c->pool_g[s];
-    c->soa[s].pid = c->pool_i[s];
-  }
-}
 
 static int particle_grid(int64_t n) {
   int64_t b = (n + 255) / 256;
@@ -854,6 +917,8 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   c->cfg = *cfg;
   c->device = cfg->device;
   if (const char *e = getenv("MPMHIP_G2P_MINW")) c->g2p_minw = atoi(e);
+  c->reorder_interval = cfg->reorder_interval;
+  if (const char *e = getenv("MPMHIP_REORDER_INTERVAL")) c->reorder_interval = atoi(e);
   auto bail = [&](int code) { g_create_error = c->err; mpmhip_destroy(c); return code; };
   if (hipSetDevice(c->device) != hipSuccess) { fail(c, MPMHIP_EHIP, "hipSetDevice failed"); return bail(MPMHIP_EHIP); }
   Params &P = c->P;
@@ -868,6 +933,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   P.dx = cfg->dx; P.idx = 1.0f / cfg->dx; P.dt = cfg->dt;
   P.particle_gravity = cfg->particle_gravity; P.apic_damping = cfg->apic_damping; P.rpic_damping = cfg->rpic_damping;
   P.clean_boundary = cfg->clean_boundary; P.n_planes = cfg->n_planes; P.friction = cfg->friction;
+  P.store_b = cfg->discard_apic_b ? 0 : 1;
   memcpy(P.planes, cfg->planes, sizeof P.planes);
   int kbits = 1;
   while ((1 << kbits) < maxnb) kbits++;
@@ -878,9 +944,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   if (P.nbw == 0) P.nbw = 1;
   c->cap = cfg->max_particles;
   int64_t mb = cfg->max_blocks;
-  if (mb <= 0) {
-    mb = c->cap / 48 + 4096;  // a block of 64 cells at >= ~1 particle/cell on average, plus slack
-  }
+  if (mb <= 0) mb = c->cap / 48 + 4096;  // a block of 64 cells at >= ~1 particle/cell on average, plus slack
   if (mb > (int64_t)c->NB) mb = c->NB;
   P.max_blocks = (uint32_t)mb;
 
@@ -888,16 +952,14 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
   A(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
-  for (int s = 0; s < 2; s++) {
-    A(dmalloc(&c->pool_f[s], (size_t)NF * c->cap));
-    A(dmalloc(&c->pool_g[s], (size_t)c->cap));
-    A(dmalloc(&c->pool_i[s], (size_t)c->cap));
-  }
+  A(dmalloc(&c->rg, (size_t)c->cap));
+  A(dmalloc(&c->rp, (size_t)c->cap));
+  A(dmalloc(&c->rb, (size_t)c->cap * BW));
   A(dmalloc(&c->key, (size_t)c->cap));
   A(dmalloc(&c->rank, (size_t)c->cap));
+  A(dmalloc(&c->perm, (size_t)c->cap));
   A(dmalloc(&c->bits, (size_t)P.nbw));
   A(dmalloc(&c->blk_flag, (size_t)P.nbw * 32));
-  A(dmalloc(&c->dest, (size_t)c->cap));
   A(dmalloc(&c->wprefix, (size_t)P.nbw));
   A(dmalloc(&c->fat_slot, (size_t)c->NB));
   A(dmalloc(&c->act_blk, (size_t)mb + 1));
@@ -915,14 +977,14 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
          (long long)c->cap, (long long)mb);
     return bail(MPMHIP_ENOMEM);
   }
-  bind_soa(c);
   A(hipMemset(c->bits, 0, sizeof(uint32_t) * P.nbw));
   A(hipMemset(c->blk_flag, 0, (size_t)P.nbw * 32));
   A(hipMemset(c->cell_cnt, 0, sizeof(uint32_t) * (size_t)mb * BC));
-  A(hipMemset(c->cnt, 0, sizeof(Counters)));
   A(hipMemset(c->cell_start, 0, sizeof(uint32_t) * ((size_t)mb * BC + 1)));
   A(hipMemset(c->act_start, 0, sizeof(uint32_t) * ((size_t)mb + 2)));
+  A(hipMemset(c->cnt, 0, sizeof(Counters)));
   A(hipMemset(c->fat_slot, 0, sizeof(uint32_t) * (size_t)c->NB));
+  A(hipMemset(c->rb, 0, sizeof(float) * (size_t)c->cap * BW));
   A(hipDeviceSynchronize());
   if (e != hipSuccess) { fail(c, MPMHIP_EHIP, "device init failed: %s", hipGetErrorString(e)); return bail(MPMHIP_EHIP); }
   *out = c;
@@ -935,10 +997,11 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   if (c->own_stream) hipStreamSynchronize(c->own_stream);
   for (auto &ev : c->ev_pool)
     for (int k = 0; k <= PH_COUNT; k++) hipEventDestroy(ev.e[k]);
-  for (int s = 0; s < 2; s++) { hipFree(c->pool_f[s]); hipFree(c->pool_g[s]); hipFree(c->pool_i[s]); }
-  hipFree(c->key); hipFree(c->rank); hipFree(c->blk_flag); hipFree(c->dest); hipFree(c->bits); hipFree(c->wprefix); hipFree(c->fat_slot);
-  hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->totals); hipFree(c->cell_cnt); hipFree(c->cell_start); hipFree(c->partials);
-  hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense); hipFree(c->cnt); hipFree(c->d_groups);
+  hipFree(c->rg); hipFree(c->rp); hipFree(c->rb); hipFree(c->rg2); hipFree(c->rp2); hipFree(c->rb2);
+  hipFree(c->key); hipFree(c->rank); hipFree(c->perm); hipFree(c->blk_flag); hipFree(c->bits); hipFree(c->wprefix);
+  hipFree(c->fat_slot); hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->totals); hipFree(c->cell_cnt);
+  hipFree(c->cell_start); hipFree(c->partials); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
+  hipFree(c->cnt); hipFree(c->d_groups);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -978,14 +1041,13 @@ int mpmhip_add_group(mpmhip_ctx *c, int32_t material, const float params[MPMHIP_
   return (int)c->groups.size() - 1;
 }
 
-static int refresh_count(mpmhip_ctx *c) {
-  Counters h;
+// synchronise and read the device counters; reports the sticky capacity error
+static int read_counters(mpmhip_ctx *c, Counters &h) {
   HIPCHK(c, hipMemcpyAsync(&h, c->cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (h.error & 1u)
     return fail(c, MPMHIP_ECAPACITY, "active blocks (%u) exceed max_blocks (%u): recreate the ctx with a larger max_blocks",
                 h.n_active, c->P.max_blocks);
-  c->n_host = h.n;
   return MPMHIP_OK;
 }
 
@@ -995,140 +1057,193 @@ int mpmhip_add_particles(mpmhip_ctx *c, int32_t group, int64_t n, const float *x
   if (group < 0 || group >= (int)c->groups.size()) return fail(c, MPMHIP_EINVAL, "unknown group %d", group);
   if (n == 0) return MPMHIP_OK;
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = refresh_count(c);
-  if (rc) return rc;
-  if (c->n_host + n > c->cap)
-    return fail(c, MPMHIP_ECAPACITY, "particle capacity exceeded: %lld + %lld > %lld", (long long)c->n_host, (long long)n, (long long)c->cap);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->n_slots + n > c->cap)
+    return fail(c, MPMHIP_ECAPACITY, "particle capacity exceeded: %lld + %lld > %lld", (long long)c->n_slots, (long long)n, (long long)c->cap);
   const int mat = c->groups[group].type;
   const float aux0 = (mat == MPMHIP_SNOW || mat == MPMHIP_WATER) ? 1.0f : 0.0f;  // Jp = 1 (:204), j = 1 (:460), logJp = 0 (:595)
-  std::vector<float> stage((size_t)n);
-  SoA &s = c->soa[c->cur];
-  for (int f = 0; f < NF; f++) {
-    for (int64_t i = 0; i < n; i++) {
-      float val;
-      if (f < FV) val = x[3 * i + f];
-      else if (f < FB) val = v ? v[3 * i + (f - FV)] : 0.0f;
-      else if (f < FF) val = B ? B[9 * i + (f - FB)] : 0.0f;
-      else if (f < FAUX) val = F ? F[9 * i + (f - FF)] : (((f - FF) % 4 == 0) ? 1.0f : 0.0f);
-      else val = aux ? aux[i] : aux0;
-      stage[i] = val;
+  std::vector<RecG> hg((size_t)n);
+  std::vector<RecP> hp((size_t)n);
+  std::vector<float> hb((size_t)n * BW, 0.0f);
+  for (int64_t i = 0; i < n; i++) {
+    RecG &g = hg[i];
+    RecP &p = hp[i];
+    for (int k = 0; k < 3; k++) {
+      g.x[k] = p.x[k] = x[3 * i + k];
+      p.v[k] = v ? v[3 * i + k] : 0.0f;
     }
-    HIPCHK(c, hipMemcpy(s.f[f] + c->n_host, stage.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+    for (int k = 0; k < 9; k++) {
+      g.F[k] = F ? F[9 * i + k] : ((k % 4 == 0) ? 1.0f : 0.0f);
+      p.A[k] = 0.0f;
+      hb[(size_t)i * BW + k] = B ? B[9 * i + k] : 0.0f;
+    }
+    g.aux = aux ? aux[i] : aux0;
+    g.gid = p.gid = (uint32_t)group;
+    g.pid = c->next_pid + (int32_t)i;
+    g.pad = 0;
   }
-  std::vector<uint8_t> gs((size_t)n, (uint8_t)group);
-  std::vector<int32_t> ids((size_t)n);
-  for (int64_t i = 0; i < n; i++) ids[i] = c->next_pid + (int32_t)i;
   c->next_pid += (int32_t)n;
-  HIPCHK(c, hipMemcpy(s.gid + c->n_host, gs.data(), n, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(s.pid + c->n_host, ids.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
-  c->n_host += n;
-  uint32_t nn = (uint32_t)c->n_host;
-  HIPCHK(c, hipMemcpy(&c->cnt->n, &nn, sizeof nn, hipMemcpyHostToDevice));
-  c->sorted = false;
+  HIPCHK(c, hipMemcpy(c->rg + c->n_slots, hg.data(), sizeof(RecG) * n, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->rp + c->n_slots, hp.data(), sizeof(RecP) * n, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->rb + (size_t)c->n_slots * BW, hb.data(), sizeof(float) * n * BW, hipMemcpyHostToDevice));
+  c->n_slots += n;
+  c->P.n_slots = (uint32_t)c->n_slots;
+  c->sorted = c->keys_valid = c->affine_valid = false;
   return MPMHIP_OK;
 }
 
 int64_t mpmhip_num_particles(mpmhip_ctx *c) {
   if (!c) return MPMHIP_EINVAL;
   if (hipSetDevice(c->device) != hipSuccess) return MPMHIP_EHIP;
-  int rc = refresh_count(c);
-  return rc ? rc : c->n_host;
+  Counters h;
+  int rc = read_counters(c, h);
+  return rc ? rc : c->n_slots - (int64_t)h.n_dead;
 }
 
-static int field_info(int32_t field, int &f0, int &width) {
-  switch (field) {
-    case MPMHIP_F_X: f0 = FX; width = 3; return 0;
-    case MPMHIP_F_V: f0 = FV; width = 3; return 0;
-    case MPMHIP_F_B: f0 = FB; width = 9; return 0;
-    case MPMHIP_F_F: f0 = FF; width = 9; return 0;
-    case MPMHIP_F_AUX: f0 = FAUX; width = 1; return 0;
-  }
-  return -1;
+// host mirrors of the record arrays (download / upload are not on the hot path)
+static int fetch_records(mpmhip_ctx *c, std::vector<RecG> &hg, std::vector<RecP> *hp, std::vector<float> *hb) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t n = (size_t)c->n_slots;
+  hg.resize(n);
+  if (n) HIPCHK(c, hipMemcpy(hg.data(), c->rg, sizeof(RecG) * n, hipMemcpyDeviceToHost));
+  if (hp) { hp->resize(n); if (n) HIPCHK(c, hipMemcpy(hp->data(), c->rp, sizeof(RecP) * n, hipMemcpyDeviceToHost)); }
+  if (hb) { hb->resize(n * BW); if (n) HIPCHK(c, hipMemcpy(hb->data(), c->rb, sizeof(float) * n * BW, hipMemcpyDeviceToHost)); }
+  return MPMHIP_OK;
 }
 
 int mpmhip_download(mpmhip_ctx *c, int32_t field, void *dst, int64_t n_capacity) {
   if (!c || !dst) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = refresh_count(c);
+  if (field < MPMHIP_F_X || field > MPMHIP_F_ID) return fail(c, MPMHIP_EINVAL, "unknown field %d", field);
+  if (field == MPMHIP_F_B && !c->P.store_b)
+    return fail(c, MPMHIP_EINVAL, "apic_b is not kept (ctx created with discard_apic_b)");
+  std::vector<RecG> hg;
+  std::vector<RecP> hp;
+  std::vector<float> hb;
+  int rc = fetch_records(c, hg, field == MPMHIP_F_V ? &hp : nullptr, field == MPMHIP_F_B ? &hb : nullptr);
   if (rc) return rc;
-  const int64_t n = c->n_host;
-  if (n > n_capacity) return fail(c, MPMHIP_ECAPACITY, "download buffer holds %lld particles, need %lld", (long long)n_capacity, (long long)n);
-  SoA &s = c->soa[c->cur];
-  if (field == MPMHIP_F_GID) {
-    std::vector<uint8_t> g((size_t)n);
-    HIPCHK(c, hipMemcpy(g.data(), s.gid, n, hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < n; i++) ((int32_t *)dst)[i] = g[i];
-    return (int)n;
+  int64_t m = 0;
+  for (size_t i = 0; i < hg.size(); i++) {  // live slots, in slot order
+    if (hg[i].pid < 0) continue;
+    if (m >= n_capacity) return fail(c, MPMHIP_ECAPACITY, "download buffer holds %lld particles, more are alive", (long long)n_capacity);
+    float *f = (float *)dst;
+    int32_t *q = (int32_t *)dst;
+    switch (field) {
+      case MPMHIP_F_X: for (int k = 0; k < 3; k++) f[3 * m + k] = hg[i].x[k]; break;
+      case MPMHIP_F_V: for (int k = 0; k < 3; k++) f[3 * m + k] = hp[i].v[k]; break;
+      case MPMHIP_F_B: for (int k = 0; k < 9; k++) f[9 * m + k] = hb[i * BW + k]; break;
+      case MPMHIP_F_F: for (int k = 0; k < 9; k++) f[9 * m + k] = hg[i].F[k]; break;
+      case MPMHIP_F_AUX: f[m] = hg[i].aux; break;
+      case MPMHIP_F_GID: q[m] = (int32_t)hg[i].gid; break;
+      case MPMHIP_F_ID: q[m] = hg[i].pid; break;
+    }
+    m++;
   }
-  if (field == MPMHIP_F_ID) {
-    HIPCHK(c, hipMemcpy(dst, s.pid, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-    return (int)n;
-  }
-  int f0, width;
-  if (field_info(field, f0, width)) return fail(c, MPMHIP_EINVAL, "unknown field %d", field);
-  std::vector<float> stage((size_t)n);
-  for (int k = 0; k < width; k++) {
-    HIPCHK(c, hipMemcpy(stage.data(), s.f[f0 + k], sizeof(float) * n, hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < n; i++) ((float *)dst)[i * width + k] = stage[i];
-  }
-  return (int)n;
+  return (int)m;
 }
 
 int mpmhip_upload(mpmhip_ctx *c, int32_t field, const void *src, int64_t n) {
   if (!c || !src) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = refresh_count(c);
+  if (field < MPMHIP_F_X || field > MPMHIP_F_ID || field == MPMHIP_F_GID)
+    return fail(c, MPMHIP_EINVAL, "field %d cannot be uploaded", field);
+  std::vector<RecG> hg;
+  std::vector<RecP> hp;
+  std::vector<float> hb;
+  int rc = fetch_records(c, hg, &hp, &hb);
   if (rc) return rc;
-  if (n != c->n_host) return fail(c, MPMHIP_EINVAL, "upload of %lld records but the ctx holds %lld particles", (long long)n, (long long)c->n_host);
-  SoA &s = c->soa[c->cur];
-  if (field == MPMHIP_F_ID) {  // restores creation ids after a caller-side re-allocation
-    const int32_t *ids = (const int32_t *)src;
-    int32_t mx = -1;
-    for (int64_t i = 0; i < n; i++) mx = ids[i] > mx ? ids[i] : mx;
-    HIPCHK(c, hipMemcpy(s.pid, ids, sizeof(int32_t) * n, hipMemcpyHostToDevice));
-    if (mx + 1 > c->next_pid) c->next_pid = mx + 1;
-    return MPMHIP_OK;
+  int64_t live = 0;
+  for (auto &g : hg) live += g.pid >= 0;
+  if (n != live) return fail(c, MPMHIP_EINVAL, "upload of %lld records but the ctx holds %lld particles", (long long)n, (long long)live);
+  const float *f = (const float *)src;
+  const int32_t *q = (const int32_t *)src;
+  int64_t m = 0;
+  for (size_t i = 0; i < hg.size(); i++) {
+    if (hg[i].pid < 0) continue;
+    switch (field) {
+      case MPMHIP_F_X: for (int k = 0; k < 3; k++) hg[i].x[k] = hp[i].x[k] = f[3 * m + k]; break;
+      case MPMHIP_F_V: for (int k = 0; k < 3; k++) hp[i].v[k] = f[3 * m + k]; break;
+      case MPMHIP_F_B: for (int k = 0; k < 9; k++) hb[i * BW + k] = f[9 * m + k]; break;
+      case MPMHIP_F_F: for (int k = 0; k < 9; k++) hg[i].F[k] = f[9 * m + k]; break;
+      case MPMHIP_F_AUX: hg[i].aux = f[m]; break;
+      case MPMHIP_F_ID:
+        hg[i].pid = q[m] < 0 ? 0 : q[m];
+        if (hg[i].pid + 1 > c->next_pid) c->next_pid = hg[i].pid + 1;
+        break;
+    }
+    m++;
   }
-  int f0, width;
-  if (field_info(field, f0, width)) return fail(c, MPMHIP_EINVAL, "field %d cannot be uploaded", field);
-  std::vector<float> stage((size_t)n);
-  for (int k = 0; k < width; k++) {
-    for (int64_t i = 0; i < n; i++) stage[i] = ((const float *)src)[i * width + k];
-    HIPCHK(c, hipMemcpy(s.f[f0 + k], stage.data(), sizeof(float) * n, hipMemcpyHostToDevice));
-  }
-  if (field == MPMHIP_F_X) c->sorted = false;
+  const size_t ns = hg.size();
+  HIPCHK(c, hipMemcpy(c->rg, hg.data(), sizeof(RecG) * ns, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->rp, hp.data(), sizeof(RecP) * ns, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->rb, hb.data(), sizeof(float) * ns * BW, hipMemcpyHostToDevice));
+  if (field == MPMHIP_F_X || field == MPMHIP_F_V) c->sorted = c->keys_valid = false;
+  if (field == MPMHIP_F_B || field == MPMHIP_F_F || field == MPMHIP_F_AUX) c->affine_valid = false;
   return MPMHIP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ phases
+static int do_reorder(mpmhip_ctx *c);
+
 static int do_sort(mpmhip_ctx *c) {
-  const Params &P = c->P;
+  Params &P = c->P;
   hipStream_t st = c->stream;
-  const int pg = particle_grid(c->n_host);
-  SoA &src = c->soa[c->cur], &dst = c->soa[c->cur ^ 1];
-  hipLaunchKernelGGL(k_build_keys, dim3(pg), dim3(256), 0, st, P, src, c->cnt, c->key, c->blk_flag);
-  hipLaunchKernelGGL(k_pack_flags, dim3((P.nbw + 255) / 256), dim3(256), 0, st, P, c->blk_flag, c->bits);
+  const int pg = particle_grid(c->n_slots);
+  if (!c->keys_valid)
+    hipLaunchKernelGGL(k_build_keys, dim3(pg), dim3(256), 0, st, P, c->rg, c->rp, c->cnt, c->key, c->blk_flag);
   const int nb_chunks = (int)((P.nbw + SCAN_CHUNK - 1) / SCAN_CHUNK);
   const int na_chunks = (int)((P.max_blocks + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  hipLaunchKernelGGL(k_pack_flags, dim3((P.nbw + 255) / 256), dim3(256), 0, st, P, c->blk_flag, c->bits);
   hipLaunchKernelGGL((k_scan_partials<0>), dim3(nb_chunks), dim3(256), 0, st, P, c->cnt, c->bits, c->partials);
   hipLaunchKernelGGL((k_scan_apply<0>), dim3(nb_chunks), dim3(256), 0, st, P, c->cnt, c->bits, c->partials, c->wprefix);
   hipLaunchKernelGGL(k_emit_active, dim3((P.nbw + 255) / 256), dim3(256), 0, st, P, c->bits, c->wprefix, c->act_blk);
-  hipLaunchKernelGGL(k_rank, dim3(pg), dim3(256), 0, st, P, c->cnt, c->key, c->rank, c->cell_cnt, c->bits, c->wprefix);
-  hipLaunchKernelGGL(k_block_totals, dim3(1024), dim3(256), 0, st, c->cnt, c->cell_cnt, c->totals);
+  hipLaunchKernelGGL(k_rank, dim3(pg), dim3(256), 0, st, P, c->key, c->rank, c->cell_cnt, c->bits, c->wprefix);
+  hipLaunchKernelGGL(k_block_totals, dim3(1024), dim3(256), 0, st, P, c->cnt, c->cell_cnt, c->totals);
   hipLaunchKernelGGL((k_scan_partials<1>), dim3(na_chunks), dim3(256), 0, st, P, c->cnt, c->totals, c->partials);
   hipLaunchKernelGGL((k_scan_apply<1>), dim3(na_chunks), dim3(256), 0, st, P, c->cnt, c->totals, c->partials, c->act_start);
   hipLaunchKernelGGL(k_cell_start, dim3(1024), dim3(256), 0, st, P, c->cnt, c->cell_cnt, c->act_start, c->cell_start);
-  hipLaunchKernelGGL(k_layout, dim3(1024), dim3(256), 0, st, P, c->cnt, c->cell_start, c->dest);
-  hipLaunchKernelGGL(k_reorder, dim3(pg), dim3(256), 0, st, c->cnt, src, dst, c->key, c->rank, c->cell_start, c->dest);
-  hipLaunchKernelGGL(k_sort_cleanup, dim3(1024), dim3(256), 0, st, P, c->cnt, c->cell_cnt);
-  c->cur ^= 1;
+  hipLaunchKernelGGL(k_perm, dim3(pg), dim3(256), 0, st, P, c->key, c->rank, c->cell_start, c->perm);
   c->sorted = true;
-  return launch_check(c, "sort");
+  c->keys_valid = false;  // key[] now holds cell indices
+  int rc = launch_check(c, "sort");
+  if (rc) return rc;
+  if (c->reorder_interval > 0 && c->substeps % c->reorder_interval == 0) return do_reorder(c);  // src/mpm.cpp:811-813
+  return MPMHIP_OK;
+}
+
+// physical reorder into sorted order + compaction of deleted slots (sort_allocator, src/mpm.cpp:752-768).
+// Needs the live count on the host, hence one synchronisation: keep reorder_interval large.
+static int do_reorder(mpmhip_ctx *c) {
+  if (!c->rg2) {
+    hipError_t e = dmalloc(&c->rg2, (size_t)c->cap);
+    if (e == hipSuccess) e = dmalloc(&c->rp2, (size_t)c->cap);
+    if (e == hipSuccess) e = dmalloc(&c->rb2, (size_t)c->cap * BW);
+    if (e != hipSuccess) return fail(c, MPMHIP_ENOMEM, "reorder buffers: %s", hipGetErrorString(e));
+  }
+  const int pg = particle_grid(c->n_slots * 4);
+  hipLaunchKernelGGL(k_gather_records, dim3(pg), dim3(256), 0, c->stream, c->cnt, c->perm, (const float4 *)c->rg,
+                     (const float4 *)c->rp, (const float4 *)c->rb, (float4 *)c->rg2, (float4 *)c->rp2, (float4 *)c->rb2);
+  hipLaunchKernelGGL(k_identity_perm, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->cnt, c->perm);
+  int rc = launch_check(c, "reorder");
+  if (rc) return rc;
+  Counters h;
+  if ((rc = read_counters(c, h))) return rc;
+  std::swap(c->rg, c->rg2); std::swap(c->rp, c->rp2); std::swap(c->rb, c->rb2);
+  c->n_slots = h.n_sorted;
+  c->P.n_slots = h.n_sorted;
+  const uint32_t zero = 0;
+  HIPCHK(c, hipMemcpy(&c->cnt->n_dead, &zero, sizeof zero, hipMemcpyHostToDevice));
+  return MPMHIP_OK;
 }
 
 static int do_p2g(mpmhip_ctx *c) {
-  hipLaunchKernelGGL(k_p2g, dim3(8192), dim3(64), 0, c->stream, c->P, c->soa[c->cur], c->cnt, c->act_blk,
-                     c->cell_start, c->d_groups, c->tiles);
+  if (!c->affine_valid) {
+    hipLaunchKernelGGL(k_affine, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, c->rg, c->rp, c->rb,
+                       c->d_groups);
+    c->affine_valid = true;
+  }
+  hipLaunchKernelGGL(k_p2g, dim3(8192), dim3(64), 0, c->stream, c->P, (const float4 *)c->rp, c->cnt, c->act_blk,
+                     c->cell_start, c->perm, c->d_groups, c->tiles);
   return launch_check(c, "p2g");
 }
 static int do_grid(mpmhip_ctx *c, int mode) {
@@ -1137,9 +1252,20 @@ static int do_grid(mpmhip_ctx *c, int mode) {
   return launch_check(c, "grid");
 }
 static int do_g2p(mpmhip_ctx *c) {
-  auto kern = c->g2p_minw == 4 ? k_g2p<256, 4> : (c->g2p_minw == 3 ? k_g2p<256, 3> : k_g2p<256, 2>);
-  hipLaunchKernelGGL(kern, dim3(4096), dim3(256), 0, c->stream, c->P, c->soa[c->cur], c->cnt, c->act_blk,
-                     c->act_start, c->d_groups, c->gridv, c->fat_slot);
+  auto kern = k_g2p<256, 2, false>;
+  switch (c->g2p_minw) {  // tuning knob: waves/SIMD target x (rolled gather loop ? 10 : 0)
+    case 12: kern = k_g2p<256, 2, true>; break;
+    case 3: kern = k_g2p<256, 3, false>; break;
+    case 13: kern = k_g2p<256, 3, true>; break;
+    case 14: kern = k_g2p<256, 4, true>; break;
+    default: break;
+  }
+  hipLaunchKernelGGL(kern, dim3(4096), dim3(256), 0, c->stream, c->P, (float4 *)c->rg, (float4 *)c->rp, (float4 *)c->rb,
+                     c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
+                     c->blk_flag);
+  c->sorted = false;       // positions moved
+  c->keys_valid = true;    // ... and their keys / block flags are ready for the next sort
+  c->affine_valid = true;  // A was produced together with F
   return launch_check(c, "g2p");
 }
 
@@ -1169,10 +1295,7 @@ int mpmhip_g2p(mpmhip_ctx *c) {
   if (!c) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   int rc = need_sorted(c, "g2p");
-  if (rc) return rc;
-  rc = do_g2p(c);
-  c->sorted = false;  // positions moved: the next phase-level p2g needs a new sort
-  return rc;
+  return rc ? rc : do_g2p(c);
 }
 
 static int get_events(mpmhip_ctx *c, mpmhip_ctx::Ev **out) {
@@ -1218,7 +1341,6 @@ int mpmhip_substep(mpmhip_ctx *c) {
   if (ev) HIPCHK(c, hipEventRecord(ev->e[3], c->stream));
   if ((rc = do_g2p(c))) return rc;
   if (ev) HIPCHK(c, hipEventRecord(ev->e[4], c->stream));
-  c->sorted = false;
   c->t += c->P.dt;  // src/mpm.cpp:573
   c->substeps++;
   return MPMHIP_OK;
@@ -1252,12 +1374,8 @@ double mpmhip_current_time(const mpmhip_ctx *c) { return c ? (double)c->t : 0.0;
 int mpmhip_synchronize(mpmhip_ctx *c) {
   if (!c) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   Counters h;
-  HIPCHK(c, hipMemcpy(&h, c->cnt, sizeof h, hipMemcpyDeviceToHost));
-  if (h.error & 1u)
-    return fail(c, MPMHIP_ECAPACITY, "active blocks (%u) exceed max_blocks (%u)", h.n_active, c->P.max_blocks);
-  return MPMHIP_OK;
+  return read_counters(c, h);
 }
 
 static int ensure_dense(mpmhip_ctx *c, size_t &nodes) {
@@ -1288,6 +1406,7 @@ int mpmhip_upload_grid(mpmhip_ctx *c, const float *src) {
   if (rc) return rc;
   size_t nodes;
   if ((rc = ensure_dense(c, nodes))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(c->dense, src, nodes * sizeof(float4), hipMemcpyHostToDevice));
   return do_grid(c, 2);
 }
@@ -1311,11 +1430,12 @@ int mpmhip_profile(mpmhip_ctx *c, char *json, size_t cap) {
   int rc = collect_events(c);
   if (rc) return rc;
   Counters h;
-  HIPCHK(c, hipMemcpy(&h, c->cnt, sizeof h, hipMemcpyDeviceToHost));
+  if ((rc = read_counters(c, h))) return rc;
   int w = snprintf(json, cap,
-                   "{\"substeps\":%lld,\"particles\":%u,\"active_blocks\":%u,\"phases\":{\"sort\":%.6f,\"p2g\":%.6f,"
+                   "{\"substeps\":%lld,\"particles\":%lld,\"active_blocks\":%u,\"phases\":{\"sort\":%.6f,\"p2g\":%.6f,"
                    "\"grid\":%.6f,\"g2p\":%.6f}}",
-                   (long long)c->prof_substeps, h.n, h.n_active, c->phase_ms[0], c->phase_ms[1], c->phase_ms[2], c->phase_ms[3]);
+                   (long long)c->prof_substeps, (long long)(c->n_slots - h.n_dead), h.n_active, c->phase_ms[0],
+                   c->phase_ms[1], c->phase_ms[2], c->phase_ms[3]);
   return (w < 0 || (size_t)w >= cap) ? fail(c, MPMHIP_EINVAL, "profile buffer too small") : MPMHIP_OK;
 }
 
@@ -1362,23 +1482,25 @@ int mpmhip_debug_force(mpmhip_ctx *c, int32_t material, const float params[MPMHI
 }
 
 int mpmhip_debug_plasticity(mpmhip_ctx *c, int32_t material, const float params[MPMHIP_NPARAM], int64_t n,
-                            const float *cdg, float *F, float *aux) {
+                            const float *cdg, float *F, float *aux, float *next_force) {
   if (!c || n <= 0) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   GroupParams g;
   int rc = make_group(c, material, params, g);
   if (rc) return rc;
-  float *dC, *dF, *dA;
+  float *dC, *dF, *dA, *dO = nullptr;
   HIPCHK(c, dmalloc(&dC, 9 * n)); HIPCHK(c, dmalloc(&dF, 9 * n)); HIPCHK(c, dmalloc(&dA, n));
+  if (next_force) HIPCHK(c, dmalloc(&dO, 9 * n));
   HIPCHK(c, hipMemcpy(dC, cdg, sizeof(float) * 9 * n, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(dF, F, sizeof(float) * 9 * n, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(dA, aux, sizeof(float) * n, hipMemcpyHostToDevice));
-  rc = run_debug(c, k_debug_plasticity, g, n, (const float *)dC, dF, dA);
+  rc = run_debug(c, k_debug_plasticity, g, n, (const float *)dC, dF, dA, dO);
   if (!rc) {
     HIPCHK(c, hipMemcpy(F, dF, sizeof(float) * 9 * n, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(aux, dA, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (next_force) HIPCHK(c, hipMemcpy(next_force, dO, sizeof(float) * 9 * n, hipMemcpyDeviceToHost));
   }
-  hipFree(dC); hipFree(dF); hipFree(dA);
+  hipFree(dC); hipFree(dF); hipFree(dA); hipFree(dO);
   return rc;
 }
 

@@ -98,6 +98,8 @@ class Simulation3D:
         self.apic_damping = float(cfg.get("apic_damping", 0.0))
         self.rpic_damping = float(cfg.get("rpic_damping", 0.0))
         self.clean_boundary = bool(cfg.get("clean_boundary", True))
+        self.reorder_interval = int(cfg.get("reorder_interval", 1000))  # src/mpm.cpp:45
+        self.discard_apic_b = bool(cfg.get("discard_apic_b", False))
         self.max_particles = int(cfg.get("max_particles", 0))
         self.max_blocks = int(cfg.get("max_blocks", 0))
         self.device = int(cfg.get("device", 0))
@@ -121,6 +123,8 @@ class Simulation3D:
         c.max_particles = int(capacity)
         c.max_blocks = self.max_blocks
         c.device = self.device
+        c.reorder_interval = self.reorder_interval
+        c.discard_apic_b = int(self.discard_apic_b)
         ctx = C.c_void_p()
         rc = self._L.mpmhip_create(C.byref(c), C.byref(ctx))
         if rc != 0:

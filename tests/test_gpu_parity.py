@@ -98,7 +98,7 @@ def test_device_constitutive_models_match_oracle(tm, orc, mat):
     assert np.abs(out - ref).max() < 3e-5 * scale + 2 * gp[2] * gp[1] * 4e-6, mat
     Fd, auxd = F.copy(), aux.copy()
     sim._check(sim._L.mpmhip_debug_plasticity(sim._ctx, t, gp.ctypes.data_as(fp), n, cdg.ctypes.data_as(fp),
-                                              Fd.ctypes.data_as(fp), auxd.ctypes.data_as(fp)))
+                                              Fd.ctypes.data_as(fp), auxd.ctypes.data_as(fp), None))
     Fo = np.zeros_like(F); auxo = np.zeros_like(aux)
     for i in range(n):
         f, a = orc.plasticity(t, gp, cdg[i], F[i], float(aux[i]))
@@ -107,11 +107,20 @@ def test_device_constitutive_models_match_oracle(tm, orc, mat):
         Fd = F  # water never updates dg_e (src/particles.cpp:469-478); the kernel does not store it either
     assert np.abs(Fd - Fo).max() < 2e-5, mat
     assert np.abs(auxd - auxo).max() < 2e-5, mat
+    # fused kernel path: plasticity + the NEXT substep's calculate_force from one eigen-solve
+    Ff, auxf, nf = F.copy(), aux.copy(), np.zeros((n, 9), np.float32)
+    sim._check(sim._L.mpmhip_debug_plasticity(sim._ctx, t, gp.ctypes.data_as(fp), n, cdg.ctypes.data_as(fp),
+                                              Ff.ctypes.data_as(fp), auxf.ctypes.data_as(fp), nf.ctypes.data_as(fp)))
+    if mat == "water":
+        Ff = F
+    assert np.abs(Ff - Fo).max() < 2e-5 and np.abs(auxf - auxo).max() < 2e-5, mat
+    ref2 = np.stack([orc.calculate_force(t, gp, Fo[i], float(auxo[i])).reshape(9) for i in range(n)])
+    assert np.abs(nf - ref2).max() < 3e-5 * np.abs(ref2).max() + 2 * gp[2] * gp[1] * 4e-6, mat
     sim.close()
 
 
 # ------------------------------------------------------------------------------------------ sort
-def test_sort_is_a_permutation_in_block_rank_major_order_and_drops_dead(tm, orc):
+def test_sort_is_a_permutation_in_key_order_and_drops_dead(tm, orc):
     x = lattice_cube(RES, 5, 12, DX, jitter=0.3, seed=2)  # cells 5,6 lie inside the 7-cell deletion margin
     rng = np.random.default_rng(3)
     x = x[rng.permutation(len(x))]
@@ -131,8 +140,8 @@ def test_sort_is_a_permutation_in_block_rank_major_order_and_drops_dead(tm, orc)
     assert len(got["id"]) == keep.sum()
     assert sorted(got["id"].tolist()) == np.nonzero(keep)[0].tolist()
     assert np.array_equal(got["x"], s.x[got["id"]]) and np.array_equal(got["F"], s.F[got["id"]])
-    # order: blocks in Morton order; inside a block RANK-MAJOR (0th particle of every cell in cell order, then
-    # the 1st of every cell that has one, ...) so that the lane-per-cell P2G reads consecutive particles
+    # the first sort also reorders the records physically (reorder_interval, src/mpm.cpp:811-813): slot order is
+    # now key order = Morton(block) << 6 | cell-in-block
     base = np.floor(got["x"].astype(np.float32) * np.float32(1 / DX) - np.float32(0.5)).astype(np.int64)
 
     def spread(v):
@@ -141,14 +150,9 @@ def test_sort_is_a_permutation_in_block_rank_major_order_and_drops_dead(tm, orc)
             r |= ((v >> b) & 1) << (3 * b)
         return r
     blk = base >> 2
-    bkey = spread(blk[:, 0]) << 2 | spread(blk[:, 1]) << 1 | spread(blk[:, 2])
-    cell = ((base[:, 0] & 3) << 4) | ((base[:, 1] & 3) << 2) | (base[:, 2] & 3)
-    assert np.all(np.diff(bkey) >= 0)
-    for b in np.unique(bkey):
-        cells = cell[bkey == b]
-        counts = np.bincount(cells, minlength=64)
-        expect = np.concatenate([np.nonzero(counts > r)[0] for r in range(counts.max())])
-        assert np.array_equal(cells, expect)
+    key = ((spread(blk[:, 0]) << 2 | spread(blk[:, 1]) << 1 | spread(blk[:, 2])) << 6) | ((base[:, 0] & 3) << 4) | \
+        ((base[:, 1] & 3) << 2) | (base[:, 2] & 3)
+    assert np.all(np.diff(key) >= 0)
     sim.close()
 
 

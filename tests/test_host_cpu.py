@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(built):
 
 
 def test_config_struct_matches_header_layout():
-    # mpmhip_config: 3 i32, 2 f32, 3 f32, i32, 2 f32, i32, i32, 32 f32, f32, (pad) 2 i64, i32, 7 i32
+    # mpmhip_config: 3 i32, 2 f32, 3 f32, i32, 2 f32, i32, i32, 32 f32, f32, (pad) 2 i64, 3 i32, 5 i32
     assert C.sizeof(_lib.Config) == 232
     assert _lib.Config.max_particles.offset % 8 == 0
 
