@@ -15,6 +15,11 @@
 
 namespace mpm {
 
+// 1-ulp hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32): the IEEE-exact expansions hipcc emits for
+// `/` and sqrtf cost ~10 VALU instructions each, and there are ~20 of them per particle in the eigen-solve.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 struct mat3 {
   float m[9];  // row-major
   __device__ __forceinline__ float &operator()(int r, int c) { return m[3 * r + c]; }
@@ -56,8 +61,8 @@ __device__ __forceinline__ void jacobi_rotate(float &app, float &aqq, float &apq
                                               float &u2q) {
   const float d = aqq - app;
   // t = tan(phi): root of t^2 + 2 theta t - 1 = 0 with theta = d/(2 a_pq), in the cancellation-free form
-  const float den = fabsf(d) + sqrtf(fmaf(d, d, 4.0f * apq * apq));
-  const float t = (den > 0.0f) ? copysignf(2.0f * apq, d * apq) / den : 0.0f;
+  const float den = fabsf(d) + fast_sqrt(fmaf(d, d, 4.0f * apq * apq));
+  const float t = (den > 0.0f) ? copysignf(2.0f * apq, d * apq) * fast_rcp(den) : 0.0f;
   const float c = rsqrtf(fmaf(t, t, 1.0f));
   const float s = t * c;
   app = fmaf(-t, apq, app);
@@ -96,7 +101,7 @@ __device__ __forceinline__ void sym_eig3_FFt(const mat3 &F, mat3 &U, float lam[3
 // on the smallest one (the oracle's / taichi's convention: U,V rotations, sign on the last sigma).
 __device__ __forceinline__ void signed_sigma(const float lam[3], float detF, float s[3]) {
 #pragma unroll
-  for (int i = 0; i < 3; i++) s[i] = sqrtf(fmaxf(lam[i], 0.0f));
+  for (int i = 0; i < 3; i++) s[i] = fast_sqrt(fmaxf(lam[i], 0.0f));
   if (detF < 0.0f) {
     int k = (s[0] <= s[1]) ? ((s[0] <= s[2]) ? 0 : 2) : ((s[1] <= s[2]) ? 1 : 2);
     if (k == 0) s[0] = -s[0];
@@ -302,7 +307,7 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
   if (g.type == MPMHIP_ELASTIC) {  // src/particles.cpp:798-812
     float ls[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) ls[i] = logf(s[i]);
+    for (int i = 0; i < 3; i++) ls[i] = __logf(s[i]);
     const float tr = ls[0] + ls[1] + ls[2];
 #pragma unroll
     for (int i = 0; i < 3; i++) d[i] = -vol * fmaf(2.0f * mu0, ls[i], la0 * tr);
@@ -318,13 +323,13 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
       sn[i] = fminf(fmaxf(s[i], lo), hi);
       det_o *= s[i];
       det_n *= sn[i];
-      ratio[i] = sn[i] / s[i];
+      ratio[i] = sn[i] * fast_rcp(s[i]);
     }
     float Jp = aux * det_o / det_n;
     if (!(Jp <= g.p[8])) Jp = g.p[8];
     if (!(Jp >= g.p[7])) Jp = g.p[7];
     aux = Jp;
-    const float e = expf(g.p[4] * (1.0f - Jp));
+    const float e = __expf(g.p[4] * (1.0f - Jp));
     const float mu = mu0 * e, la = la0 * e;
     const float vol_l = la * (det_n - 1.0f) * det_n;
 #pragma unroll
@@ -333,13 +338,13 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
     const float alpha = g.p[4], coh = g.p[5], beta = g.p[6];
     float eps[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) eps[i] = logf(fmaxf(fabsf(s[i]), 1e-4f)) - coh;
+    for (int i = 0; i < 3; i++) eps[i] = __logf(fmaxf(fabsf(s[i]), 1e-4f)) - coh;
     const float sum = eps[0] + eps[1] + eps[2];
     const float tr = sum + aux;
     float eh[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) eh[i] = eps[i] - tr * (1.0f / 3.0f);
-    const float ehn = sqrtf(fmaf(eh[0], eh[0], fmaf(eh[1], eh[1], eh[2] * eh[2])));
+    const float ehn = fast_sqrt(fmaf(eh[0], eh[0], fmaf(eh[1], eh[1], eh[2] * eh[2])));
     float h[3];  // log of the projected singular values
     if (tr >= 0.0f) {
       h[0] = coh; h[1] = coh; h[2] = coh;
@@ -347,20 +352,20 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
     } else {
       aux = 0.0f;
       const float dg = ehn + (3.0f * la0 + 2.0f * mu0) / (2.0f * mu0) * tr * alpha;
-      const float k = (dg <= 0.0f) ? 0.0f : dg / ehn;
+      const float k = (dg <= 0.0f) ? 0.0f : dg * fast_rcp(ehn);
 #pragma unroll
       for (int i = 0; i < 3; i++) h[i] = eps[i] - k * eh[i] + coh;
     }
     const float trh = h[0] + h[1] + h[2];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      ratio[i] = expf(h[i]) / s[i];
+      ratio[i] = __expf(h[i]) * fast_rcp(s[i]);
       d[i] = -vol * fmaf(2.0f * mu0, h[i], la0 * trh);
     }
   } else {  // MPMHIP_VON_MISES, src/particles.cpp:701-732
     float e[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) e[i] = logf(s[i]);
+    for (int i = 0; i < 3; i++) e[i] = __logf(s[i]);
     const float tr = e[0] + e[1] + e[2];
     float eh[3] = {e[0] - tr * (1.0f / 3.0f), e[1] - tr * (1.0f / 3.0f), e[2] - tr * (1.0f / 3.0f)};
     const float n2 = fmaf(eh[0], eh[0], fmaf(eh[1], eh[1], eh[2] * eh[2]));
@@ -369,7 +374,7 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       h[i] = (dg <= 0.0f) ? e[i] : e[i] - (dg / n2) * eh[i];
-      ratio[i] = (dg <= 0.0f) ? 1.0f : expf(h[i]) / s[i];
+      ratio[i] = (dg <= 0.0f) ? 1.0f : __expf(h[i]) * fast_rcp(s[i]);
     }
     const float trh = h[0] + h[1] + h[2];
 #pragma unroll

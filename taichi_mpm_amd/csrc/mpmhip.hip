@@ -447,183 +447,209 @@ __global__ __launch_bounds__(256) void k_affine(Params P, const RecG *__restrict
 
 // ------------------------------------------------------------------------------------------------ P2G
 // rasterize_optimized / block_op_normal (src/transfer.cpp:467-569).
-// Mapping: one wavefront per active 4^3-cell block, ONE LANE PER CELL.  The sorted index lists the particles
-// of each cell contiguously, so lane c walks its cell's particles and accumulates their 27x4 node contributions
-// in registers (the reference walks cells sequentially inside a block and accumulates into its scratch tile
-// the same way, :474-483).  Write conflicts between particles of one cell therefore never reach memory; the
-// per-cell sums are merged into the block's 6^3-node LDS tile by ordered, non-atomic float4 read-modify-writes,
-// and the tile is written out whole; conflicts between blocks are resolved by k_grid.
-__global__ __launch_bounds__(64, 2) void k_p2g(Params P, const float4 *__restrict__ rp, const Counters *__restrict__ cnt,
-                                            const uint32_t *__restrict__ act_blk,
-                                            const uint32_t *__restrict__ cell_start,
-                                            const uint32_t *__restrict__ perm,
-                                            const GroupParams *__restrict__ groups, float4 *__restrict__ tiles) {
-  __shared__ float4 tile[TN];  // (m*vx, m*vy, m*vz, m) per node of the block's 6^3 tile
+// Mapping: one workgroup of two wavefronts per active 4^3-cell block, ONE LANE PER CELL in each wave; wave 0
+// owns stencil nodes 0..13 of every cell, wave 1 nodes 14..26 (halves the accumulator registers, which buys the
+// occupancy and the software prefetch that hide the record-gather latency).  The sorted index lists the
+// particles of each cell contiguously, so lane c walks its cell's particles and accumulates their node
+// contributions in registers (the reference walks cells sequentially inside a block and accumulates into its
+// scratch tile the same way, :474-483).  Write conflicts between particles of one cell therefore never reach
+// memory; each wave merges its per-cell sums into its own 6^3-node LDS tile by ordered, non-atomic float4
+// read-modify-writes, the two tiles are added on the way out and written whole; conflicts between blocks are
+// resolved by k_grid.
+template <int N0, int N1>
+__device__ __forceinline__ void p2g_cell(const Params &P, const float4 *__restrict__ rp,
+                                         const uint32_t *__restrict__ perm,
+                                         const GroupParams *__restrict__ groups, uint32_t p0, uint32_t p1, float ox,
+                                         float oy, float oz, int nbase, float4 *tile) {
+  constexpr int NN = N1 - N0;
+  float acc[NN][4];
+#pragma unroll
+  for (int n = 0; n < NN; n++) { acc[n][0] = 0.0f; acc[n][1] = 0.0f; acc[n][2] = 0.0f; acc[n][3] = 0.0f; }
+  // software pipeline: the index two particles ahead and the record one particle ahead are already in flight
+  float4 n0, n1, n2, n3;
+  uint32_t inext = 0;
+  if (p0 < p1) {
+    const size_t i = perm[p0];
+    n0 = rp[i * 4 + 0]; n1 = rp[i * 4 + 1]; n2 = rp[i * 4 + 2]; n3 = rp[i * 4 + 3];
+    if (p0 + 1 < p1) inext = perm[p0 + 1];
+  }
+  for (uint32_t p = p0; p < p1; p++) {
+    const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
+    if (p + 1 < p1) {
+      const size_t i = inext;
+      n0 = rp[i * 4 + 0]; n1 = rp[i * 4 + 1]; n2 = rp[i * 4 + 2]; n3 = rp[i * 4 + 3];
+      if (p + 2 < p1) inext = perm[p + 2];
+    }
+    const float mass = groups[__float_as_uint(q3.w)].p[0];
+    float v0 = q0.w, v1 = q1.x, v2 = q1.y;
+    if (P.particle_gravity) {  // src/transfer.cpp:485-487
+      v0 = fmaf(P.g[0], P.dt, v0); v1 = fmaf(P.g[1], P.dt, v1); v2 = fmaf(P.g[2], P.dt, v2);
+    }
+    // position relative to the base cell, in grid units: in [0.5, 1.5)^3  (:490,518)
+    const float r0 = q0.x * P.idx - ox, r1 = q0.y * P.idx - oy, r2 = q0.z * P.idx - oz;
+    float w0[3], w1[3], w2[3];
+    bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
+    const float A00 = q1.z, A01 = q1.w, A02 = q2.x, A10 = q2.y, A11 = q2.z, A12 = q2.w, A20 = q3.x, A21 = q3.y,
+                A22 = q3.z;
+    const float mv0 = mass * v0, mv1 = mass * v1, mv2 = mass * v2;
+#pragma unroll
+    for (int n = N0; n < N1; n++) {
+      const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
+      const float d0 = r0 - (float)i3, d1 = r1 - (float)j, d2 = r2 - (float)k;
+      const float w = (w0[i3] * w1[j]) * w2[k];
+      // :535-541  contrib = (affine * dpos + mass*v, mass); g += weight * contrib
+      const float c0 = fmaf(A02, d2, fmaf(A01, d1, fmaf(A00, d0, mv0)));
+      const float c1 = fmaf(A12, d2, fmaf(A11, d1, fmaf(A10, d0, mv1)));
+      const float c2 = fmaf(A22, d2, fmaf(A21, d1, fmaf(A20, d0, mv2)));
+      acc[n - N0][0] = fmaf(w, c0, acc[n - N0][0]);
+      acc[n - N0][1] = fmaf(w, c1, acc[n - N0][1]);
+      acc[n - N0][2] = fmaf(w, c2, acc[n - N0][2]);
+      acc[n - N0][3] = fmaf(w, mass, acc[n - N0][3]);
+    }
+  }
+  // Merge the per-cell sums into this wave's tile.  The tile belongs to this wavefront alone, and within one
+  // stencil-offset step all 64 lanes address distinct nodes (same offset, different cells), so a plain float4
+  // read-modify-write is race-free as long as the steps stay in program order: LDS operations of one wave
+  // execute in order, the wave_barrier keeps the compiler from interleaving them.  (DS float atomics cost
+  // ~2 LDS cycles per LANE on gfx950 even without conflicts: measured 145 cycles per ds_add_f32.)
+#pragma unroll
+  for (int n = N0; n < N1; n++) {
+    const int node = nbase + ((n / 9) * TS + (n / 3) % 3) * TS + n % 3;
+    if (p1 > p0) {
+      float4 t = tile[node];
+      t.x += acc[n - N0][0]; t.y += acc[n - N0][1]; t.z += acc[n - N0][2]; t.w += acc[n - N0][3];
+      tile[node] = t;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+}
+
+__global__ __launch_bounds__(128, 3) void k_p2g(Params P, const float4 *__restrict__ rp,
+                                                const Counters *__restrict__ cnt,
+                                                const uint32_t *__restrict__ act_blk,
+                                                const uint32_t *__restrict__ cell_start,
+                                                const uint32_t *__restrict__ perm,
+                                                const GroupParams *__restrict__ groups, float4 *__restrict__ tiles) {
+  __shared__ float4 tile[2][TN];  // per wave: (m*vx, m*vy, m*vz, m) per node of the block's 6^3 tile
   const uint32_t na = min(cnt->n_active, P.max_blocks);
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
   const int nbase = (cx * TS + cy) * TS + cz;
   for (uint32_t a = blockIdx.x; a < na; a += gridDim.x) {
-    for (int t = lane; t < TN; t += 64) tile[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int t = threadIdx.x; t < 2 * TN; t += 128) (&tile[0][0])[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();
     int bx, by, bz;
     demorton3(act_blk[a], bx, by, bz);
     const float ox = (float)(bx * BS + cx), oy = (float)(by * BS + cy), oz = (float)(bz * BS + cz);
     const uint32_t p0 = cell_start[a * BC + lane], p1 = cell_start[a * BC + lane + 1];
-    float acc[27][4];
-#pragma unroll
-    for (int n = 0; n < 27; n++) { acc[n][0] = 0.0f; acc[n][1] = 0.0f; acc[n][2] = 0.0f; acc[n][3] = 0.0f; }
-    for (uint32_t p = p0; p < p1; p++) {
-      const size_t i = perm[p];
-      const float4 q0 = rp[i * 4 + 0], q1 = rp[i * 4 + 1], q2 = rp[i * 4 + 2], q3 = rp[i * 4 + 3];
-      const float mass = groups[__float_as_uint(q3.w)].p[0];
-      float v0 = q0.w, v1 = q1.x, v2 = q1.y;
-      if (P.particle_gravity) {  // src/transfer.cpp:485-487
-        v0 = fmaf(P.g[0], P.dt, v0); v1 = fmaf(P.g[1], P.dt, v1); v2 = fmaf(P.g[2], P.dt, v2);
-      }
-      // position relative to the base cell, in grid units: in [0.5, 1.5)^3  (:490,518)
-      const float r0 = q0.x * P.idx - ox, r1 = q0.y * P.idx - oy, r2 = q0.z * P.idx - oz;
-      float w0[3], w1[3], w2[3];
-      bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
-      const float A00 = q1.z, A01 = q1.w, A02 = q2.x, A10 = q2.y, A11 = q2.z, A12 = q2.w, A20 = q3.x, A21 = q3.y,
-                  A22 = q3.z;
-      const float mv0 = mass * v0, mv1 = mass * v1, mv2 = mass * v2;
-#pragma unroll
-      for (int i3 = 0; i3 < 3; i3++) {
-        const float d0 = r0 - (float)i3;
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-          const float d1 = r1 - (float)j;
-          const float wij = w0[i3] * w1[j];
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            const float d2 = r2 - (float)k;
-            const float w = wij * w2[k];
-            const int n = (i3 * 3 + j) * 3 + k;
-            // :535-541  contrib = (affine * dpos + mass*v, mass); g += weight * contrib
-            const float c0 = fmaf(A02, d2, fmaf(A01, d1, fmaf(A00, d0, mv0)));
-            const float c1 = fmaf(A12, d2, fmaf(A11, d1, fmaf(A10, d0, mv1)));
-            const float c2 = fmaf(A22, d2, fmaf(A21, d1, fmaf(A20, d0, mv2)));
-            acc[n][0] = fmaf(w, c0, acc[n][0]);
-            acc[n][1] = fmaf(w, c1, acc[n][1]);
-            acc[n][2] = fmaf(w, c2, acc[n][2]);
-            acc[n][3] = fmaf(w, mass, acc[n][3]);
-          }
-        }
-      }
-    }
-    // Merge the per-cell sums into the tile.  The tile belongs to this wavefront alone, and within one
-    // (i,j,k) step all 64 lanes address distinct nodes (same stencil offset, different cells), so a plain
-    // float4 read-modify-write is race-free as long as the 27 steps stay in program order: LDS operations of
-    // one wave execute in order, the wave_barrier keeps the compiler from interleaving them.  (DS float atomics
-    // cost ~2 LDS cycles per LANE on gfx950 even without conflicts: measured 145 cycles per ds_add_f32.)
-#pragma unroll
-    for (int i3 = 0; i3 < 3; i3++)
-#pragma unroll
-      for (int j = 0; j < 3; j++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const int n = (i3 * 3 + j) * 3 + k;
-          const int node = nbase + (i3 * TS + j) * TS + k;
-          if (p1 > p0) {
-            float4 t = tile[node];
-            t.x += acc[n][0]; t.y += acc[n][1]; t.z += acc[n][2]; t.w += acc[n][3];
-            tile[node] = t;
-          }
-          __builtin_amdgcn_wave_barrier();
-          asm volatile("" ::: "memory");
-        }
+    if (wave == 0) p2g_cell<0, 14>(P, rp, perm, groups, p0, p1, ox, oy, oz, nbase, tile[0]);
+    else p2g_cell<14, 27>(P, rp, perm, groups, p0, p1, ox, oy, oz, nbase, tile[1]);
     __syncthreads();
-    for (int t = lane; t < TN; t += 64) tiles[(size_t)a * TN + t] = tile[t];
+    for (int t = threadIdx.x; t < TN; t += 128) {
+      const float4 u = tile[0][t], w = tile[1][t];
+      tiles[(size_t)a * TN + t] = make_float4(u.x + w.x, u.y + w.y, u.z + w.z, u.w + w.w);
+    }
     __syncthreads();
   }
 }
 
 // ------------------------------------------------------------------------------------------------ grid
-// Candidate (a, o): grid block c = block(a) + o, o in {0,1}^3, is one of the 8 grid blocks the tile of
-// active block a overlaps.  c is processed by its "owner": the candidate with the smallest o among the
+// One wavefront per active block a.  The tile of a overlaps the 8 grid blocks c = block(a) + o, o in {0,1}^3
+// ("candidates").  A grid block c is processed by its "owner": the candidate with the smallest o among the
 // active blocks c - o'.  The owner sums the overlapping tiles (<= 8), then
 //   mode 0: normalize_grid_and_apply_external_force + apply_grid_boundary_conditions (src/mpm.cpp:277-372)
 //           -> gridv[slot = 8a+o], fat_slot[morton(c)] = slot
 //   mode 1: raw (m v, m) sums written to a dense node-major array (parity / download only)
 //   mode 2: dense (v, m) array -> gridv (upload_grid)        mode 3: gridv -> dense (download_grid)
-__global__ __launch_bounds__(64) void k_grid(Params P, int mode, const Counters *__restrict__ cnt,
-                                             const uint32_t *__restrict__ act_blk,
-                                             const uint32_t *__restrict__ bits,
-                                             const uint32_t *__restrict__ wprefix,
-                                             const float4 *__restrict__ tiles, float4 *__restrict__ gridv,
-                                             uint32_t *__restrict__ fat_slot, float4 *__restrict__ dense) {
+// All candidate/owner/source lookups of a block involve only its 27 neighbours b + {-1,0,1}^3: lanes 0..26
+// look one neighbour up each (one round trip), the rest is ballots and shuffles.
+__device__ __forceinline__ constexpr int nb27(int dx, int dy, int dz) { return ((dx + 1) * 3 + (dy + 1)) * 3 + (dz + 1); }
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restrict__ cnt,
+                                              const uint32_t *__restrict__ act_blk,
+                                              const uint32_t *__restrict__ bits,
+                                              const uint32_t *__restrict__ wprefix,
+                                              const float4 *__restrict__ tiles, float4 *__restrict__ gridv,
+                                              uint32_t *__restrict__ fat_slot, float4 *__restrict__ dense) {
   const uint32_t na = min(cnt->n_active, P.max_blocks);
-  const int l = threadIdx.x;
+  const int l = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   const int lx = l >> 4, ly = (l >> 2) & 3, lz = l & 3;
-  for (uint32_t cand = blockIdx.x; cand < na * 8u; cand += gridDim.x) {
-    const uint32_t a = cand >> 3;
-    const int o = cand & 7;
+  for (uint32_t a = wave; a < na; a += nwaves) {
     int bx, by, bz;
     demorton3(act_blk[a], bx, by, bz);
-    const int cx = bx + (o >> 2), cy = by + ((o >> 1) & 1), cz = bz + (o & 1);
-    bool owner = true;  // owner test + gather of contributing tiles (all wave-uniform)
-    uint32_t src_slot[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int sx = cx - (q >> 2), sy = cy - ((q >> 1) & 1), sz = cz - (q & 1);
-      src_slot[q] = INVALID;
+    // neighbour table: lane n < 27 holds (active?, slot) of block b + (n/9-1, n/3%3-1, n%3-1)
+    uint32_t nslot = INVALID;
+    if (l < 27) {
+      const int sx = bx + l / 9 - 1, sy = by + (l / 3) % 3 - 1, sz = bz + l % 3 - 1;
       if (sx >= 0 && sy >= 0 && sz >= 0) {
         const uint32_t bk = morton3(sx, sy, sz);
-        if (block_active(bits, bk)) {
-          if (q < o) owner = false;
-          src_slot[q] = block_slot(bits, wprefix, bk);
+        if (block_active(bits, bk)) nslot = block_slot(bits, wprefix, bk);
+      }
+    }
+    const uint32_t amask = (uint32_t)__ballot(nslot != INVALID);
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+      const int ox = o >> 2, oy = (o >> 1) & 1, oz = o & 1;
+      // sources of c = b + o are c - q = b + (o - q), q in {0,1}^3; owner <=> none of them active for q < o
+      uint32_t lower = 0;
+#pragma unroll
+      for (int q = 0; q < o; q++) lower |= 1u << nb27(ox - (q >> 2), oy - ((q >> 1) & 1), oz - (q & 1));
+      if (amask & lower) continue;  // wave-uniform
+      const int cx = bx + ox, cy = by + oy, cz = bz + oz;
+      const uint32_t slot = a * 8u + (uint32_t)o;
+      const int gi = cx * BS + lx, gj = cy * BS + ly, gk = cz * BS + lz;
+      const bool in_grid = gi <= P.res[0] && gj <= P.res[1] && gk <= P.res[2];
+      const size_t dense_idx = ((size_t)gi * (P.res[1] + 1) + gj) * (P.res[2] + 1) + gk;
+      if (MODE == 2) {
+        gridv[(size_t)slot * BC + l] = in_grid ? dense[dense_idx] : make_float4(0, 0, 0, 0);
+        if (l == 0) fat_slot[morton3(cx, cy, cz)] = slot;
+        continue;
+      }
+      if (MODE == 3) {
+        if (in_grid) dense[dense_idx] = gridv[(size_t)slot * BC + l];
+        continue;
+      }
+      float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int qx = q >> 2, qy = (q >> 1) & 1, qz = q & 1;
+        const int nidx = nb27(ox - qx, oy - qy, oz - qz);
+        const uint32_t sslot = __shfl(nslot, nidx);
+        const int tx = lx + 4 * qx, ty = ly + 4 * qy, tz = lz + 4 * qz;
+        if (((amask >> nidx) & 1u) && tx < TS && ty < TS && tz < TS) {
+          const float4 t = tiles[(size_t)sslot * TN + (tx * TS + ty) * TS + tz];
+          acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
         }
       }
-    }
-    if (!owner) continue;
-    const uint32_t slot = a * 8u + (uint32_t)o;
-    const int gi = cx * BS + lx, gj = cy * BS + ly, gk = cz * BS + lz;
-    const bool in_grid = gi <= P.res[0] && gj <= P.res[1] && gk <= P.res[2];
-    const size_t dense_idx = ((size_t)gi * (P.res[1] + 1) + gj) * (P.res[2] + 1) + gk;
-    if (mode == 2) {
-      gridv[(size_t)slot * BC + l] = in_grid ? dense[dense_idx] : make_float4(0, 0, 0, 0);
+      if (MODE == 1) {
+        if (in_grid) dense[dense_idx] = acc;
+        continue;
+      }
+      float v[3] = {acc.x, acc.y, acc.z};
+      const float m = acc.w;
+      if (m > 0.0f) {  // src/mpm.cpp:282-292; increment is gravity*dt only when !particle_gravity (:526-530)
+        const float im = 1.0f / m;
+#pragma unroll
+        for (int k = 0; k < 3; k++) v[k] = fmaf(v[k], im, P.particle_gravity ? 0.0f : P.g[k] * P.dt);
+      }
+      if (m != 0.0f && P.n_planes > 0) {  // src/mpm.cpp:313-368
+        float phi = 1e30f, nrm[3] = {0, 0, 0};
+        for (int p = 0; p < P.n_planes; p++) {
+          const float ph = (P.planes[p][0] * (gi * P.dx) + P.planes[p][1] * (gj * P.dx) + P.planes[p][2] * (gk * P.dx) +
+                            P.planes[p][3]) * P.idx;
+          if (ph < phi) { phi = ph; nrm[0] = P.planes[p][0]; nrm[1] = P.planes[p][1]; nrm[2] = P.planes[p][2]; }
+        }
+        if (!(phi < -3.0f || 0.0f < phi)) {
+          const float vb[3] = {0, 0, 0};
+          friction_project(v, vb, nrm, P.friction);
+        }
+      }
+      gridv[(size_t)slot * BC + l] = make_float4(v[0], v[1], v[2], m);
       if (l == 0) fat_slot[morton3(cx, cy, cz)] = slot;
-      continue;
     }
-    if (mode == 3) {
-      if (in_grid) dense[dense_idx] = gridv[(size_t)slot * BC + l];
-      continue;
-    }
-    float4 acc = make_float4(0, 0, 0, 0);
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int tx = lx + 4 * (q >> 2), ty = ly + 4 * ((q >> 1) & 1), tz = lz + 4 * (q & 1);
-      if (src_slot[q] != INVALID && tx < TS && ty < TS && tz < TS) {
-        const float4 t = tiles[(size_t)src_slot[q] * TN + (tx * TS + ty) * TS + tz];
-        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-      }
-    }
-    if (mode == 1) {
-      if (in_grid) dense[dense_idx] = acc;
-      continue;
-    }
-    float v[3] = {acc.x, acc.y, acc.z};
-    const float m = acc.w;
-    if (m > 0.0f) {  // src/mpm.cpp:282-292; increment is gravity*dt only when !particle_gravity (:526-530)
-      const float im = 1.0f / m;
-#pragma unroll
-      for (int k = 0; k < 3; k++) v[k] = fmaf(v[k], im, P.particle_gravity ? 0.0f : P.g[k] * P.dt);
-    }
-    if (m != 0.0f && P.n_planes > 0) {  // src/mpm.cpp:313-368
-      float phi = 1e30f, nrm[3] = {0, 0, 0};
-      for (int p = 0; p < P.n_planes; p++) {
-        const float ph = (P.planes[p][0] * (gi * P.dx) + P.planes[p][1] * (gj * P.dx) + P.planes[p][2] * (gk * P.dx) +
-                          P.planes[p][3]) * P.idx;
-        if (ph < phi) { phi = ph; nrm[0] = P.planes[p][0]; nrm[1] = P.planes[p][1]; nrm[2] = P.planes[p][2]; }
-      }
-      if (!(phi < -3.0f || 0.0f < phi)) {
-        const float vb[3] = {0, 0, 0};
-        friction_project(v, vb, nrm, P.friction);
-      }
-    }
-    gridv[(size_t)slot * BC + l] = make_float4(v[0], v[1], v[2], m);
-    if (l == 0) fat_slot[morton3(cx, cy, cz)] = slot;
   }
 }
 
@@ -1242,13 +1268,14 @@ static int do_p2g(mpmhip_ctx *c) {
                        c->d_groups);
     c->affine_valid = true;
   }
-  hipLaunchKernelGGL(k_p2g, dim3(8192), dim3(64), 0, c->stream, c->P, (const float4 *)c->rp, c->cnt, c->act_blk,
+  hipLaunchKernelGGL(k_p2g, dim3(8192), dim3(128), 0, c->stream, c->P, (const float4 *)c->rp, c->cnt, c->act_blk,
                      c->cell_start, c->perm, c->d_groups, c->tiles);
   return launch_check(c, "p2g");
 }
 static int do_grid(mpmhip_ctx *c, int mode) {
-  hipLaunchKernelGGL(k_grid, dim3(16384), dim3(64), 0, c->stream, c->P, mode, c->cnt, c->act_blk, c->bits, c->wprefix,
-                     c->tiles, c->gridv, c->fat_slot, c->dense);
+  auto kern = mode == 0 ? k_grid<0> : (mode == 1 ? k_grid<1> : (mode == 2 ? k_grid<2> : k_grid<3>));
+  hipLaunchKernelGGL(kern, dim3(4096), dim3(256), 0, c->stream, c->P, c->cnt, c->act_blk, c->bits, c->wprefix, c->tiles,
+                     c->gridv, c->fat_slot, c->dense);
   return launch_check(c, "grid");
 }
 static int do_g2p(mpmhip_ctx *c) {
