@@ -149,6 +149,53 @@ int mpmhip_set_profiling(mpmhip_ctx *ctx, int32_t enabled);
 int mpmhip_profile(mpmhip_ctx *ctx, char *json, size_t cap);
 int mpmhip_profile_reset(mpmhip_ctx *ctx);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Multi-GPU tiling (one ctx per GPU, each over the WHOLE grid index space but holding only the particles of its
+ * brick).  The reference has no multi-process code; this is the sharding SURVEY §8(e) derives from the stencil
+ * support (base..base+2 nodes, src/kernel.h:119-121, src/transfer.cpp:59-63).  The library never communicates:
+ * the caller moves the device buffers named here with any transport (RCCL, MPI, hipMemcpyPeer).
+ *
+ *   partition : `dims[a]` bricks per axis with cell cut planes `cuts[a][0..dims[a]]` (cuts[a][0] = 0,
+ *               cuts[a][dims[a]] >= res[a]); rank of brick (px,py,pz) = (px*dims[1] + py)*dims[2] + pz.
+ *               A particle belongs to the brick containing its base cell int(x/dx - 0.5) (src/kernel.h:119-121);
+ *               it may sit up to `margin` cells outside its rank's brick between two migrations.
+ *   halo      : node boxes shared with other ranks.  After P2G, mpmhip_halo_pack() writes this rank's partial
+ *               (m v, m) sums on every box to `send`; the caller exchanges send<->recv with rank `peer`;
+ *               grid_update then forms every node total as the sum over contributors IN RANK ORDER (own partial
+ *               at its rank position), so all holders of a node compute bit-identical values.
+ *   migration : mpmhip_leaver_counts -> per-destination counts (synchronises); mpmhip_export_leavers packs the
+ *               MPMHIP_MIGRATE_FLOATS-float records grouped by destination rank (ascending) into a device buffer
+ *               and removes them locally; mpmhip_import_particles appends received records.
+ */
+#define MPMHIP_MAX_PARTS 16       /* bricks per axis */
+#define MPMHIP_MAX_HALO_BOXES 64
+#define MPMHIP_MIGRATE_FLOATS 44  /* RecG(16) + RecP(16) + apic_b(12) : 176 bytes per migrating particle */
+
+typedef struct {
+  int32_t lo[3], hi[3]; /* node box [lo, hi) in global node coordinates */
+  int32_t peer;         /* rank of the other contributor */
+  int32_t reserved;
+  void *send;           /* device float4[volume], x-major (z fastest): written by mpmhip_halo_pack */
+  const void *recv;     /* device float4[volume]: the peer's partial sums, read by grid_update */
+} mpmhip_halo_box;
+
+int mpmhip_set_partition(mpmhip_ctx *ctx, int32_t rank, const int32_t dims[3], const int32_t *cuts_x,
+                         const int32_t *cuts_y, const int32_t *cuts_z, int32_t margin);
+/* boxes must be sorted by ascending peer; n = 0 disables the halo */
+int mpmhip_set_halo(mpmhip_ctx *ctx, int32_t n, const mpmhip_halo_box *boxes);
+int mpmhip_halo_pack(mpmhip_ctx *ctx);
+/* tiled substep = substep_begin (sort, P2G, halo_pack) ; caller exchanges ; substep_end (grid, G2P) */
+int mpmhip_substep_begin(mpmhip_ctx *ctx);
+int mpmhip_substep_end(mpmhip_ctx *ctx);
+/* counts[world]: live particles whose base cell now lies in another rank's brick.  Also raises MPMHIP_ECAPACITY
+ * (sticky) if a particle is more than `margin` cells outside this rank's brick. */
+int mpmhip_leaver_counts(mpmhip_ctx *ctx, int32_t world, int64_t *counts);
+/* packs every leaver (n_total = sum of the counts just returned) into dev_records, grouped by destination */
+int mpmhip_export_leavers(mpmhip_ctx *ctx, int32_t world, const int64_t *counts, void *dev_records);
+int mpmhip_import_particles(mpmhip_ctx *ctx, int64_t n, const void *dev_records);
+int64_t mpmhip_num_slots(mpmhip_ctx *ctx);       /* slots in use (live + dead) — capacity pressure */
+int mpmhip_request_compaction(mpmhip_ctx *ctx);  /* physical reorder + drop of dead slots at the next sort */
+
 /* debug/parity helpers running the device math on host arrays (n items each) */
 int mpmhip_debug_svd3(mpmhip_ctx *ctx, int64_t n, const float *F, float *U, float *S, float *V);
 int mpmhip_debug_force(mpmhip_ctx *ctx, int32_t material, const float params[MPMHIP_NPARAM], int64_t n,

@@ -27,6 +27,17 @@ class Config(C.Structure):
                 ("reserved", C.c_int32 * 5)]
 
 
+class HaloBox(C.Structure):
+    """mirror of mpmhip_halo_box"""
+    _fields_ = [("lo", C.c_int32 * 3), ("hi", C.c_int32 * 3), ("peer", C.c_int32), ("reserved", C.c_int32),
+                ("send", C.c_void_p), ("recv", C.c_void_p)]
+
+
+MAX_PARTS = 16
+MAX_HALO_BOXES = 64
+MIGRATE_FLOATS = 44
+
+
 def lib_path():
     return _LIB
 
@@ -58,7 +69,9 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_las
             "mpmhip_upload", "mpmhip_substep", "mpmhip_run_substeps", "mpmhip_step", "mpmhip_current_time",
             "mpmhip_synchronize", "mpmhip_sort", "mpmhip_p2g", "mpmhip_grid_update", "mpmhip_g2p",
             "mpmhip_download_grid", "mpmhip_upload_grid", "mpmhip_set_profiling", "mpmhip_profile",
-            "mpmhip_profile_reset", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
+            "mpmhip_profile_reset", "mpmhip_set_partition", "mpmhip_set_halo", "mpmhip_halo_pack",
+            "mpmhip_substep_begin", "mpmhip_substep_end", "mpmhip_leaver_counts", "mpmhip_export_leavers",
+            "mpmhip_import_particles", "mpmhip_num_slots", "mpmhip_request_compaction", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
 
 
 def exported_symbols():
@@ -74,6 +87,13 @@ def load():
     if not os.path.exists(_LIB):
         raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(taichi_mpm_amd has no CPU fallback)" % _LIB)
+    # torch bundles its own HIP runtime: if it is going to be used in this process (tiled runs, bench.py) it must
+    # be loaded BEFORE libmpmhip resolves libamdhip64, or the process ends up with two runtimes and torch reports
+    # "No HIP GPUs are available".  torch stays plumbing: nothing below calls into it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_LIB)
     P = C.POINTER
     vp, fp = C.c_void_p, P(C.c_float)
@@ -91,8 +111,17 @@ def load():
     L.mpmhip_num_particles.restype = C.c_int64
     L.mpmhip_download.argtypes = [vp, C.c_int32, vp, C.c_int64]
     L.mpmhip_upload.argtypes = [vp, C.c_int32, vp, C.c_int64]
+    ip = P(C.c_int32)
+    L.mpmhip_set_partition.argtypes = [vp, C.c_int32, ip, ip, ip, ip, C.c_int32]
+    L.mpmhip_set_halo.argtypes = [vp, C.c_int32, P(HaloBox)]
+    L.mpmhip_leaver_counts.argtypes = [vp, C.c_int32, P(C.c_int64)]
+    L.mpmhip_export_leavers.argtypes = [vp, C.c_int32, P(C.c_int64), vp]
+    L.mpmhip_import_particles.argtypes = [vp, C.c_int64, vp]
+    L.mpmhip_num_slots.argtypes = [vp]
+    L.mpmhip_num_slots.restype = C.c_int64
     for name in ("mpmhip_substep", "mpmhip_synchronize", "mpmhip_sort", "mpmhip_p2g", "mpmhip_grid_update",
-                 "mpmhip_g2p", "mpmhip_profile_reset"):
+                 "mpmhip_g2p", "mpmhip_profile_reset", "mpmhip_halo_pack", "mpmhip_substep_begin",
+                 "mpmhip_substep_end", "mpmhip_request_compaction"):
         getattr(L, name).argtypes = [vp]
     L.mpmhip_run_substeps.argtypes = [vp, C.c_int32]
     L.mpmhip_step.argtypes = [vp, C.c_float]

@@ -37,6 +37,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -96,6 +97,25 @@ struct Params {
   uint32_t max_blocks;
   uint32_t n_slots;  // particle slots in use (host-known)
   int store_b;       // keep apic_b in the side array
+};
+
+// multi-GPU tiling (include/mpmhip.h, "Multi-GPU tiling"): partition of the cell space into bricks + halo boxes
+struct Tiling {
+  int enabled, rank;
+  int dims[3];
+  int cuts[3][MPMHIP_MAX_PARTS + 1];
+  int lo[3], hi[3];          // this rank's brick, cells
+  int margin;
+  int n_boxes;
+  uint32_t box_nodes;        // total nodes over all halo boxes
+  int int_lo[3], int_hi[3];  // node box that no halo box intersects (fast path of k_grid)
+};
+struct DevBox {
+  int lo[3], dim[3];
+  int peer;
+  uint32_t off;  // first node of this box in the concatenated (all boxes) node numbering
+  float4 *send;
+  const float4 *recv;
 };
 
 // ------------------------------------------------------------------------------------------------ Morton
@@ -572,7 +592,8 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
                                               const uint32_t *__restrict__ bits,
                                               const uint32_t *__restrict__ wprefix,
                                               const float4 *__restrict__ tiles, float4 *__restrict__ gridv,
-                                              uint32_t *__restrict__ fat_slot, float4 *__restrict__ dense) {
+                                              uint32_t *__restrict__ fat_slot, float4 *__restrict__ dense, Tiling T,
+                                              const DevBox *__restrict__ boxes) {
   const uint32_t na = min(cnt->n_active, P.max_blocks);
   const int l = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -624,6 +645,28 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
           acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
         }
       }
+      if (T.n_boxes > 0) {  // tiled: add the other ranks' partial sums, contributors in rank order
+        const bool interior = gi >= T.int_lo[0] && gi < T.int_hi[0] && gj >= T.int_lo[1] && gj < T.int_hi[1] &&
+                              gk >= T.int_lo[2] && gk < T.int_hi[2];
+        if (__any(!interior)) {
+          float4 tot = make_float4(0, 0, 0, 0);
+          bool own = false;
+          for (int b = 0; b < T.n_boxes; b++) {
+            const DevBox &B = boxes[b];
+            if (!own && B.peer > T.rank) {
+              tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w;
+              own = true;
+            }
+            const int x = gi - B.lo[0], y = gj - B.lo[1], z = gk - B.lo[2];
+            if ((unsigned)x < (unsigned)B.dim[0] && (unsigned)y < (unsigned)B.dim[1] && (unsigned)z < (unsigned)B.dim[2]) {
+              const float4 r = B.recv[((size_t)x * B.dim[1] + y) * B.dim[2] + z];
+              tot.x += r.x; tot.y += r.y; tot.z += r.z; tot.w += r.w;
+            }
+          }
+          if (!own) { tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w; }
+          acc = tot;
+        }
+      }
       if (MODE == 1) {
         if (in_grid) dense[dense_idx] = acc;
         continue;
@@ -650,6 +693,125 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
       gridv[(size_t)slot * BC + l] = make_float4(v[0], v[1], v[2], m);
       if (l == 0) fat_slot[morton3(cx, cy, cz)] = slot;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ tiling
+// This rank's partial (m v, m) sums on every halo box -> the box's send buffer.  One thread per box node: the
+// node's grid block c and the <= 8 active source blocks c - q whose 6^3 tiles overlap it (same sum as k_grid).
+__global__ __launch_bounds__(256) void k_halo_pack(Params P, Tiling T, const DevBox *__restrict__ boxes,
+                                                   const uint32_t *__restrict__ bits,
+                                                   const uint32_t *__restrict__ wprefix,
+                                                   const float4 *__restrict__ tiles) {
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T.box_nodes; t += gridDim.x * blockDim.x) {
+    int b = 0;
+    while (b + 1 < T.n_boxes && t >= boxes[b + 1].off) b++;
+    const DevBox &B = boxes[b];
+    const uint32_t r = t - B.off;
+    const int z = r % B.dim[2], y = (r / B.dim[2]) % B.dim[1], x = r / (B.dim[2] * B.dim[1]);
+    const int gi = B.lo[0] + x, gj = B.lo[1] + y, gk = B.lo[2] + z;
+    const int cx = gi >> 2, cy = gj >> 2, cz = gk >> 2, lx = gi & 3, ly = gj & 3, lz = gk & 3;
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int qx = q >> 2, qy = (q >> 1) & 1, qz = q & 1;
+      const int sx = cx - qx, sy = cy - qy, sz = cz - qz;
+      const int tx = lx + 4 * qx, ty = ly + 4 * qy, tz = lz + 4 * qz;
+      if (sx < 0 || sy < 0 || sz < 0 || tx >= TS || ty >= TS || tz >= TS) continue;
+      const uint32_t bk = morton3(sx, sy, sz);
+      if (bk >= P.nbw * 32u || !block_active(bits, bk)) continue;
+      const uint32_t slot = block_slot(bits, wprefix, bk);
+      if (slot >= P.max_blocks) continue;
+      const float4 v = tiles[(size_t)slot * TN + (tx * TS + ty) * TS + tz];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    B.send[r] = acc;
+  }
+}
+
+__device__ __forceinline__ int part_index(const int *cuts, int n, int c) {
+  int p = 0;
+  while (p + 1 < n && c >= cuts[p + 1]) p++;
+  return p;
+}
+// destination rank of a live particle at x (brick containing its base cell); -1 if it is not representable
+__device__ __forceinline__ int dest_rank(const Params &P, const Tiling &T, float4 g0, bool &beyond_margin) {
+  int b[3];
+  const float X[3] = {g0.x * P.idx, g0.y * P.idx, g0.z * P.idx};
+  beyond_margin = false;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (!isfinite(X[k]) || X[k] < 0.5f) return -1;
+    b[k] = (int)(X[k] - 0.5f);
+    if (b[k] < T.lo[k] - T.margin || b[k] >= T.hi[k] + T.margin) beyond_margin = true;
+  }
+  return (part_index(T.cuts[0], T.dims[0], b[0]) * T.dims[1] + part_index(T.cuts[1], T.dims[1], b[1])) * T.dims[2] +
+         part_index(T.cuts[2], T.dims[2], b[2]);
+}
+
+__global__ __launch_bounds__(256) void k_leaver_count(Params P, Tiling T, const float4 *__restrict__ rg,
+                                                      uint32_t *__restrict__ counts, Counters *cnt) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_slots; i += gridDim.x * blockDim.x) {
+    if (__float_as_int(rg[(size_t)i * 4 + 3].z) < 0) continue;
+    bool beyond;
+    const int d = dest_rank(P, T, rg[(size_t)i * 4], beyond);
+    if (d < 0) continue;
+    if (beyond) atomicOr(&cnt->error, 2u);
+    if (d != T.rank) atomicAdd(&counts[d], 1u);
+  }
+}
+
+// cursor[d] starts at the first record index of destination d; leavers are removed from this rank
+__global__ __launch_bounds__(256) void k_leaver_pack(Params P, Tiling T, float4 *__restrict__ rg,
+                                                     const float4 *__restrict__ rp, const float4 *__restrict__ rb,
+                                                     uint32_t *__restrict__ key, uint32_t *__restrict__ cursor,
+                                                     float4 *__restrict__ out, Counters *cnt) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_slots; i += gridDim.x * blockDim.x) {
+    const float4 g3 = rg[(size_t)i * 4 + 3];
+    if (__float_as_int(g3.z) < 0) continue;
+    bool beyond;
+    const int d = dest_rank(P, T, rg[(size_t)i * 4], beyond);
+    if (d < 0 || d == T.rank) continue;
+    const size_t o = (size_t)atomicAdd(&cursor[d], 1u) * 11;
+#pragma unroll
+    for (int q = 0; q < 4; q++) out[o + q] = rg[(size_t)i * 4 + q];
+#pragma unroll
+    for (int q = 0; q < 4; q++) out[o + 4 + q] = rp[(size_t)i * 4 + q];
+#pragma unroll
+    for (int q = 0; q < 3; q++) out[o + 8 + q] = rb[(size_t)i * 3 + q];
+    rg[(size_t)i * 4 + 3] = make_float4(g3.x, g3.y, __int_as_float(-1), 0.0f);
+    key[i] = INVALID;
+    atomicAdd(&cnt->n_dead, 1u);
+  }
+}
+
+// arrivals appended at slots base .. base+n; their keys and block flags join the ones k_g2p produced
+__global__ __launch_bounds__(256) void k_import(Params P, uint32_t n, uint32_t base, const float4 *__restrict__ in,
+                                                float4 *__restrict__ rg, float4 *__restrict__ rp,
+                                                float4 *__restrict__ rb, uint32_t *__restrict__ key,
+                                                uint8_t *__restrict__ blk_flag, Counters *cnt) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t nloop = (n + stride - 1) / stride;
+  for (uint32_t it = 0; it < nloop; it++) {  // uniform trip count (flag_block shuffles)
+    const uint32_t j = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t bkey = INVALID;
+    if (j < n) {
+      const size_t i = (size_t)base + j, o = (size_t)j * 11;
+      const float4 g0 = in[o], g3 = in[o + 3], p0 = in[o + 4], p1 = in[o + 5];
+      const float x[3] = {g0.x, g0.y, g0.z}, v[3] = {p0.w, p1.x, p1.y};
+      const uint32_t kk = particle_key(P, x, v, bkey);
+      int32_t pid = __float_as_int(g3.z);
+      if (kk == INVALID) {
+        pid = -1;
+        atomicAdd(&cnt->n_dead, 1u);
+      }
+      key[i] = kk;
+      rg[i * 4 + 0] = g0; rg[i * 4 + 1] = in[o + 1]; rg[i * 4 + 2] = in[o + 2];
+      rg[i * 4 + 3] = make_float4(g3.x, g3.y, __int_as_float(pid), 0.0f);
+      rp[i * 4 + 0] = p0; rp[i * 4 + 1] = p1; rp[i * 4 + 2] = in[o + 6]; rp[i * 4 + 3] = in[o + 7];
+      rb[i * 3 + 0] = in[o + 8]; rb[i * 3 + 1] = in[o + 9]; rb[i * 3 + 2] = in[o + 10];
+    }
+    flag_block(blk_flag, bkey);
   }
 }
 
@@ -837,7 +999,7 @@ using namespace mpm;
 
 static thread_local std::string g_create_error;
 
-enum { PH_SORT = 0, PH_P2G = 1, PH_GRID = 2, PH_G2P = 3, PH_COUNT = 4 };
+enum { PH_SORT = 0, PH_P2G = 1, PH_EXCH = 2, PH_GRID = 3, PH_G2P = 4, PH_COUNT = 5 };
 
 struct mpmhip_ctx {
   mpmhip_config cfg;
@@ -875,8 +1037,16 @@ struct mpmhip_ctx {
   struct Ev { hipEvent_t e[PH_COUNT + 1]; };
   std::vector<Ev> ev_pool;
   size_t ev_used = 0;
-  double phase_ms[PH_COUNT] = {0, 0, 0, 0};
+  double phase_ms[PH_COUNT] = {0, 0, 0, 0, 0};
   int64_t prof_substeps = 0;
+  Ev *cur_ev = nullptr;  // events of the substep between substep_begin and substep_end
+  // tiling
+  Tiling T;
+  DevBox *d_boxes = nullptr;
+  uint32_t *d_counts = nullptr;
+  int counts_cap = 0;
+  bool compact_requested = false;
+  bool in_substep = false;
 };
 
 static int fail(mpmhip_ctx *c, int code, const char *fmt, ...) {
@@ -949,6 +1119,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   if (hipSetDevice(c->device) != hipSuccess) { fail(c, MPMHIP_EHIP, "hipSetDevice failed"); return bail(MPMHIP_EHIP); }
   Params &P = c->P;
   memset(&P, 0, sizeof P);
+  memset(&c->T, 0, sizeof c->T);
   int maxnb = 0;
   for (int k = 0; k < 3; k++) {
     P.res[k] = cfg->res[k];
@@ -1027,7 +1198,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   hipFree(c->key); hipFree(c->rank); hipFree(c->perm); hipFree(c->blk_flag); hipFree(c->bits); hipFree(c->wprefix);
   hipFree(c->fat_slot); hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->totals); hipFree(c->cell_cnt);
   hipFree(c->cell_start); hipFree(c->partials); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
-  hipFree(c->cnt); hipFree(c->d_groups);
+  hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_counts);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1074,6 +1245,9 @@ static int read_counters(mpmhip_ctx *c, Counters &h) {
   if (h.error & 1u)
     return fail(c, MPMHIP_ECAPACITY, "active blocks (%u) exceed max_blocks (%u): recreate the ctx with a larger max_blocks",
                 h.n_active, c->P.max_blocks);
+  if (h.error & 2u)
+    return fail(c, MPMHIP_ECAPACITY, "a particle moved more than margin=%d cells outside this rank's brick between "
+                "two migrations: migrate more often or raise the margin", c->T.margin);
   return MPMHIP_OK;
 }
 
@@ -1233,7 +1407,10 @@ static int do_sort(mpmhip_ctx *c) {
   c->keys_valid = false;  // key[] now holds cell indices
   int rc = launch_check(c, "sort");
   if (rc) return rc;
-  if (c->reorder_interval > 0 && c->substeps % c->reorder_interval == 0) return do_reorder(c);  // src/mpm.cpp:811-813
+  if ((c->reorder_interval > 0 && c->substeps % c->reorder_interval == 0) || c->compact_requested) {  // src/mpm.cpp:811-813
+    c->compact_requested = false;
+    return do_reorder(c);
+  }
   return MPMHIP_OK;
 }
 
@@ -1275,7 +1452,7 @@ static int do_p2g(mpmhip_ctx *c) {
 static int do_grid(mpmhip_ctx *c, int mode) {
   auto kern = mode == 0 ? k_grid<0> : (mode == 1 ? k_grid<1> : (mode == 2 ? k_grid<2> : k_grid<3>));
   hipLaunchKernelGGL(kern, dim3(4096), dim3(256), 0, c->stream, c->P, c->cnt, c->act_blk, c->bits, c->wprefix, c->tiles,
-                     c->gridv, c->fat_slot, c->dense);
+                     c->gridv, c->fat_slot, c->dense, c->T, (const DevBox *)c->d_boxes);
   return launch_check(c, "grid");
 }
 static int do_g2p(mpmhip_ctx *c) {
@@ -1350,9 +1527,19 @@ static int collect_events(mpmhip_ctx *c) {
   return MPMHIP_OK;
 }
 
-int mpmhip_substep(mpmhip_ctx *c) {
+static int do_halo_pack(mpmhip_ctx *c) {
+  if (c->T.n_boxes == 0) return MPMHIP_OK;
+  int nb = (int)((c->T.box_nodes + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_halo_pack, dim3(nb), dim3(256), 0, c->stream, c->P, c->T, (const DevBox *)c->d_boxes, c->bits,
+                     c->wprefix, (const float4 *)c->tiles);
+  return launch_check(c, "halo_pack");
+}
+
+int mpmhip_substep_begin(mpmhip_ctx *c) {  // sort, P2G, halo pack
   if (!c) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
+  if (c->cur_ev) return fail(c, MPMHIP_EINVAL, "substep_begin called twice without substep_end");
   int rc;
   mpmhip_ctx::Ev *ev = nullptr;
   if (c->profiling) {
@@ -1363,14 +1550,37 @@ int mpmhip_substep(mpmhip_ctx *c) {
   if ((rc = do_sort(c))) return rc;
   if (ev) HIPCHK(c, hipEventRecord(ev->e[1], c->stream));
   if ((rc = do_p2g(c))) return rc;
+  if ((rc = do_halo_pack(c))) return rc;
   if (ev) HIPCHK(c, hipEventRecord(ev->e[2], c->stream));
-  if ((rc = do_grid(c, 0))) return rc;
+  c->cur_ev = ev;
+  c->in_substep = true;
+  return MPMHIP_OK;
+}
+
+int mpmhip_substep_end(mpmhip_ctx *c) {  // grid (+ halo sum), G2P
+  if (!c) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->in_substep) return fail(c, MPMHIP_EINVAL, "substep_end without substep_begin");
+  int rc;
+  mpmhip_ctx::Ev *ev = c->cur_ev;
+  c->cur_ev = nullptr;
+  c->in_substep = false;
   if (ev) HIPCHK(c, hipEventRecord(ev->e[3], c->stream));
-  if ((rc = do_g2p(c))) return rc;
+  if ((rc = do_grid(c, 0))) return rc;
   if (ev) HIPCHK(c, hipEventRecord(ev->e[4], c->stream));
+  if ((rc = do_g2p(c))) return rc;
+  if (ev) HIPCHK(c, hipEventRecord(ev->e[5], c->stream));
   c->t += c->P.dt;  // src/mpm.cpp:573
   c->substeps++;
   return MPMHIP_OK;
+}
+
+int mpmhip_substep(mpmhip_ctx *c) {
+  if (!c) return MPMHIP_EINVAL;
+  if (c->T.n_boxes > 0)
+    return fail(c, MPMHIP_EINVAL, "this ctx has halo boxes: drive it with substep_begin / exchange / substep_end");
+  int rc = mpmhip_substep_begin(c);
+  return rc ? rc : mpmhip_substep_end(c);
 }
 
 int mpmhip_run_substeps(mpmhip_ctx *c, int32_t n) {
@@ -1460,10 +1670,162 @@ int mpmhip_profile(mpmhip_ctx *c, char *json, size_t cap) {
   if ((rc = read_counters(c, h))) return rc;
   int w = snprintf(json, cap,
                    "{\"substeps\":%lld,\"particles\":%lld,\"active_blocks\":%u,\"phases\":{\"sort\":%.6f,\"p2g\":%.6f,"
-                   "\"grid\":%.6f,\"g2p\":%.6f}}",
-                   (long long)c->prof_substeps, (long long)(c->n_slots - h.n_dead), h.n_active, c->phase_ms[0],
-                   c->phase_ms[1], c->phase_ms[2], c->phase_ms[3]);
+                   "\"exchange\":%.6f,\"grid\":%.6f,\"g2p\":%.6f}}",
+                   (long long)c->prof_substeps, (long long)(c->n_slots - h.n_dead), h.n_active, c->phase_ms[PH_SORT],
+                   c->phase_ms[PH_P2G], c->phase_ms[PH_EXCH], c->phase_ms[PH_GRID], c->phase_ms[PH_G2P]);
   return (w < 0 || (size_t)w >= cap) ? fail(c, MPMHIP_EINVAL, "profile buffer too small") : MPMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ tiling (host)
+int mpmhip_set_partition(mpmhip_ctx *c, int32_t rank, const int32_t dims[3], const int32_t *cuts_x,
+                         const int32_t *cuts_y, const int32_t *cuts_z, int32_t margin) {
+  if (!c || !dims || !cuts_x || !cuts_y || !cuts_z) return MPMHIP_EINVAL;
+  const int32_t *cuts[3] = {cuts_x, cuts_y, cuts_z};
+  Tiling T;
+  memset(&T, 0, sizeof T);
+  int world = 1;
+  for (int a = 0; a < 3; a++) {
+    if (dims[a] < 1 || dims[a] > MPMHIP_MAX_PARTS) return fail(c, MPMHIP_EINVAL, "dims[%d]=%d outside [1,%d]", a, dims[a], MPMHIP_MAX_PARTS);
+    T.dims[a] = dims[a];
+    world *= dims[a];
+    for (int k = 0; k <= dims[a]; k++) {
+      T.cuts[a][k] = cuts[a][k];
+      if (k > 0 && cuts[a][k] <= cuts[a][k - 1]) return fail(c, MPMHIP_EINVAL, "cuts of axis %d are not increasing", a);
+    }
+    if (cuts[a][0] != 0 || cuts[a][dims[a]] < c->P.res[a]) return fail(c, MPMHIP_EINVAL, "cuts of axis %d do not cover [0,res)", a);
+  }
+  if (rank < 0 || rank >= world) return fail(c, MPMHIP_EINVAL, "rank %d of %d", rank, world);
+  if (margin < 1) return fail(c, MPMHIP_EINVAL, "margin must be >= 1 cell");
+  const int pc[3] = {rank / (dims[1] * dims[2]), (rank / dims[2]) % dims[1], rank % dims[2]};
+  for (int a = 0; a < 3; a++) { T.lo[a] = T.cuts[a][pc[a]]; T.hi[a] = T.cuts[a][pc[a] + 1]; }
+  T.enabled = 1; T.rank = rank; T.margin = margin;
+  c->T = T;  // halo boxes (if any) must be set again
+  return MPMHIP_OK;
+}
+
+int mpmhip_set_halo(mpmhip_ctx *c, int32_t n, const mpmhip_halo_box *boxes) {
+  if (!c || n < 0 || n > MPMHIP_MAX_HALO_BOXES || (n > 0 && !boxes)) return MPMHIP_EINVAL;
+  if (n > 0 && !c->T.enabled) return fail(c, MPMHIP_EINVAL, "set_halo needs set_partition first");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  Tiling &T = c->T;
+  T.n_boxes = 0; T.box_nodes = 0;
+  if (n == 0) return MPMHIP_OK;
+  // node box this rank's particles can touch: base cells in [lo-margin, hi+margin), stencil base..base+2
+  int nlo[3], nhi[3];
+  for (int a = 0; a < 3; a++) {
+    nlo[a] = std::max(0, T.lo[a] - T.margin);
+    nhi[a] = std::min(c->P.res[a] + 1, T.hi[a] + T.margin + 2);
+    T.int_lo[a] = nlo[a]; T.int_hi[a] = nhi[a];
+  }
+  std::vector<DevBox> hb((size_t)n);
+  uint64_t off = 0;
+  bool empty_interior = false;
+  for (int i = 0; i < n; i++) {
+    const mpmhip_halo_box &b = boxes[i];
+    if (i > 0 && b.peer < boxes[i - 1].peer) return fail(c, MPMHIP_EINVAL, "halo boxes must be sorted by peer rank");
+    if (b.peer == T.rank || !b.send || !b.recv) return fail(c, MPMHIP_EINVAL, "halo box %d: bad peer or null buffer", i);
+    bool proper = false;
+    for (int a = 0; a < 3; a++) {
+      if (b.lo[a] < 0 || b.hi[a] <= b.lo[a] || b.hi[a] > c->P.res[a] + 1) return fail(c, MPMHIP_EINVAL, "halo box %d: bad extent on axis %d", i, a);
+      hb[i].lo[a] = b.lo[a]; hb[i].dim[a] = b.hi[a] - b.lo[a];
+      // shrink the overlap-free interior along every axis where the box is a proper sub-range of the node box
+      if (b.lo[a] <= nlo[a] && b.hi[a] >= nhi[a]) continue;
+      proper = true;
+      if (b.lo[a] <= nlo[a]) T.int_lo[a] = std::max(T.int_lo[a], b.hi[a]);
+      else if (b.hi[a] >= nhi[a]) T.int_hi[a] = std::min(T.int_hi[a], b.lo[a]);
+      else empty_interior = true;
+    }
+    if (!proper) empty_interior = true;
+    hb[i].peer = b.peer; hb[i].off = (uint32_t)off;
+    hb[i].send = (float4 *)b.send; hb[i].recv = (const float4 *)b.recv;
+    off += (uint64_t)hb[i].dim[0] * hb[i].dim[1] * hb[i].dim[2];
+    if (off >= (1ull << 31)) return fail(c, MPMHIP_EINVAL, "halo boxes too large");
+  }
+  if (empty_interior) for (int a = 0; a < 3; a++) T.int_hi[a] = T.int_lo[a];
+  if (!c->d_boxes) HIPCHK(c, dmalloc(&c->d_boxes, (size_t)MPMHIP_MAX_HALO_BOXES));
+  HIPCHK(c, hipMemcpy(c->d_boxes, hb.data(), sizeof(DevBox) * n, hipMemcpyHostToDevice));
+  T.n_boxes = n; T.box_nodes = (uint32_t)off;
+  return MPMHIP_OK;
+}
+
+int mpmhip_halo_pack(mpmhip_ctx *c) {
+  if (!c) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = need_sorted(c, "halo_pack");
+  return rc ? rc : do_halo_pack(c);
+}
+
+static int ensure_counts(mpmhip_ctx *c, int world) {
+  if (!c->T.enabled) return fail(c, MPMHIP_EINVAL, "no partition set");
+  if (world != c->T.dims[0] * c->T.dims[1] * c->T.dims[2]) return fail(c, MPMHIP_EINVAL, "world=%d does not match the partition", world);
+  if (c->counts_cap < world) {
+    hipFree(c->d_counts);
+    c->d_counts = nullptr;
+    HIPCHK(c, dmalloc(&c->d_counts, (size_t)world));
+    c->counts_cap = world;
+  }
+  return MPMHIP_OK;
+}
+
+int mpmhip_leaver_counts(mpmhip_ctx *c, int32_t world, int64_t *counts) {
+  if (!c || !counts) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = ensure_counts(c, world);
+  if (rc) return rc;
+  if (c->in_substep) return fail(c, MPMHIP_EINVAL, "migration inside a substep");
+  HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * world, c->stream));
+  hipLaunchKernelGGL(k_leaver_count, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, c->T,
+                     (const float4 *)c->rg, c->d_counts, c->cnt);
+  if ((rc = launch_check(c, "leaver_count"))) return rc;
+  std::vector<uint32_t> h((size_t)world);
+  HIPCHK(c, hipMemcpyAsync(h.data(), c->d_counts, sizeof(uint32_t) * world, hipMemcpyDeviceToHost, c->stream));
+  Counters hc;
+  if ((rc = read_counters(c, hc))) return rc;  // synchronises; reports the margin violation
+  for (int i = 0; i < world; i++) counts[i] = h[i];
+  return MPMHIP_OK;
+}
+
+int mpmhip_export_leavers(mpmhip_ctx *c, int32_t world, const int64_t *counts, void *dev_records) {
+  if (!c || !counts) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = ensure_counts(c, world);
+  if (rc) return rc;
+  if (c->in_substep) return fail(c, MPMHIP_EINVAL, "migration inside a substep");
+  std::vector<uint32_t> cur((size_t)world);
+  uint64_t off = 0;
+  for (int i = 0; i < world; i++) { cur[i] = (uint32_t)off; off += (uint64_t)counts[i]; }
+  if (off == 0) return MPMHIP_OK;
+  if (!dev_records) return MPMHIP_EINVAL;
+  HIPCHK(c, hipMemcpyAsync(c->d_counts, cur.data(), sizeof(uint32_t) * world, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // `cur` is a stack-owned staging buffer
+  hipLaunchKernelGGL(k_leaver_pack, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, c->T, (float4 *)c->rg,
+                     (const float4 *)c->rp, (const float4 *)c->rb, c->key, c->d_counts, (float4 *)dev_records, c->cnt);
+  return launch_check(c, "leaver_pack");
+}
+
+int mpmhip_import_particles(mpmhip_ctx *c, int64_t n, const void *dev_records) {
+  if (!c || n < 0 || (n > 0 && !dev_records)) return MPMHIP_EINVAL;
+  if (n == 0) return MPMHIP_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->in_substep || c->sorted) return fail(c, MPMHIP_EINVAL, "import_particles between sort and G2P");
+  if (c->n_slots + n > c->cap)
+    return fail(c, MPMHIP_ECAPACITY, "particle capacity exceeded on import: %lld + %lld > %lld (request_compaction or a larger max_particles)",
+                (long long)c->n_slots, (long long)n, (long long)c->cap);
+  hipLaunchKernelGGL(k_import, dim3(particle_grid(n)), dim3(256), 0, c->stream, c->P, (uint32_t)n, (uint32_t)c->n_slots,
+                     (const float4 *)dev_records, (float4 *)c->rg, (float4 *)c->rp, (float4 *)c->rb, c->key, c->blk_flag,
+                     c->cnt);
+  c->n_slots += n;
+  c->P.n_slots = (uint32_t)c->n_slots;
+  return launch_check(c, "import");
+}
+
+int64_t mpmhip_num_slots(mpmhip_ctx *c) { return c ? c->n_slots : MPMHIP_EINVAL; }
+
+int mpmhip_request_compaction(mpmhip_ctx *c) {
+  if (!c) return MPMHIP_EINVAL;
+  c->compact_requested = true;
+  return MPMHIP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ debug math

@@ -310,6 +310,11 @@ class Simulation3D:
         self._ensure_ctx()
         self._check(self._L.mpmhip_synchronize(self._ctx))
 
+    def set_stream(self, hip_stream):
+        """run the ctx on an existing hipStream_t (int handle; 0/None = the ctx's own stream)"""
+        self._ensure_ctx()
+        self._check(self._L.mpmhip_set_stream(self._ctx, C.c_void_p(hip_stream or None)))
+
     def get_current_time(self):
         t0 = getattr(self, "_time_offset", 0.0)
         return t0 + (self._L.mpmhip_current_time(self._ctx) if self._ctx is not None else 0.0)
@@ -341,7 +346,7 @@ class Simulation3D:
 
     def upload(self, field, array):
         self._ensure_ctx()
-        a = np.ascontiguousarray(array, np.float32)
+        a = np.ascontiguousarray(array, np.int32 if field in (F_GID, F_ID) else np.float32)
         self._check(self._L.mpmhip_upload(self._ctx, field, a.ctypes.data_as(C.c_void_p), len(a)))
 
     # ---------------------------------------------------------------- profiling (TC_PROFILE, src/mpm.cpp:464-572)

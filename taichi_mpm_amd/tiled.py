@@ -1,0 +1,372 @@
+"""The grid tiled across the GPUs of one node: one process per GPU, each with its own libmpmhip ctx holding the
+particles of one brick.  The reference has no multi-process code; the decomposition
+follows from its stencil support (base..base+2 nodes, src/kernel.h:119-121, src/transfer.cpp:59-63).
+
+Per substep:   begin (sort, P2G, pack partial sums on the halo boxes)
+               ONE all_to_all of the halo boxes (RCCL over xGMI; box R∩S is the same on both sides)
+               end (grid: contributors summed in rank order => bit-identical on every holder; G2P)
+Every `migrate_interval` substeps: particles whose base cell left the brick move to their new owner.
+
+The module is engine-agnostic: `HipEngine` drives a libmpmhip ctx; the CPU tests plug a checker engine in
+(tests/fake_engine.py) to run the exchange/migration logic under gloo with world_size 2.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+MIGRATE_FLOATS = _lib.MIGRATE_FLOATS
+
+
+def brick_dims(world):
+    """2 -> 2x1x1, 4 -> 2x2x1, 8 -> 2x2x2; otherwise the most cubic factorisation."""
+    dims = [1, 1, 1]
+    n, a = world, 0
+    f = 2
+    factors = []
+    while n > 1:
+        while n % f == 0:
+            factors.append(f)
+            n //= f
+        f += 1
+    for f in sorted(factors, reverse=True):
+        a = int(np.argmin(dims))
+        dims[a] *= f
+    return tuple(sorted(dims, reverse=True))
+
+
+def base_cells(x, dx):
+    """base cell of the quadratic stencil, int(x/dx - 0.5) (src/kernel.h:119-121), in fp32 like the device"""
+    X = np.asarray(x, np.float32) * np.float32(1.0 / dx)
+    return (X - np.float32(0.5)).astype(np.int32)
+
+
+def balanced_cuts(cells, res, parts):
+    """cell cut planes [0, c1, .., res] along one axis so that every part holds about the same number of
+    particles (marginal histogram of base cells)."""
+    cuts = [0]
+    if parts > 1:
+        hist = np.bincount(np.clip(cells, 0, res - 1), minlength=res).astype(np.int64)
+        cum = np.cumsum(hist)
+        total = int(cum[-1])
+        for k in range(1, parts):
+            c = int(np.searchsorted(cum, total * k / parts, side="left")) + 1 if total else (res * k) // parts
+            c = max(c, cuts[-1] + 1)
+            c = min(c, res - (parts - k))
+            cuts.append(c)
+    cuts.append(int(res))
+    return cuts
+
+
+class Partition:
+    """`dims` bricks with cell cut planes `cuts[a]`; rank = (px*dims[1] + py)*dims[2] + pz."""
+
+    def __init__(self, res, dims, cuts, margin):
+        self.res = tuple(int(r) for r in res)
+        self.dims = tuple(int(d) for d in dims)
+        self.cuts = [list(map(int, c)) for c in cuts]
+        self.margin = int(margin)
+        self.world = self.dims[0] * self.dims[1] * self.dims[2]
+        for a in range(3):
+            assert len(self.cuts[a]) == self.dims[a] + 1 and self.cuts[a][0] == 0 and self.cuts[a][-1] >= self.res[a]
+            assert all(self.cuts[a][k] < self.cuts[a][k + 1] for k in range(self.dims[a]))
+            assert self.dims[a] <= _lib.MAX_PARTS
+
+    @classmethod
+    def balanced(cls, res, world, x, dx, margin, dims=None):
+        dims = dims or brick_dims(world)
+        b = base_cells(x, dx)
+        return cls(res, dims, [balanced_cuts(b[:, a], res[a], dims[a]) for a in range(3)], margin)
+
+    def coords(self, rank):
+        return (rank // (self.dims[1] * self.dims[2]), (rank // self.dims[2]) % self.dims[1], rank % self.dims[2])
+
+    def brick(self, rank):
+        pc = self.coords(rank)
+        return ([self.cuts[a][pc[a]] for a in range(3)], [self.cuts[a][pc[a] + 1] for a in range(3)])
+
+    def node_box(self, rank):
+        """nodes the rank's particles can touch: base cells in [lo-margin, hi+margin), stencil base..base+2"""
+        lo, hi = self.brick(rank)
+        return ([max(0, lo[a] - self.margin) for a in range(3)],
+                [min(self.res[a] + 1, hi[a] + self.margin + 2) for a in range(3)])
+
+    def overlap(self, r, s):
+        (alo, ahi), (blo, bhi) = self.node_box(r), self.node_box(s)
+        lo = [max(alo[a], blo[a]) for a in range(3)]
+        hi = [min(ahi[a], bhi[a]) for a in range(3)]
+        return (lo, hi) if all(lo[a] < hi[a] for a in range(3)) else None
+
+    def boxes(self, rank):
+        """[(peer, lo, hi)] sorted by peer: the halo boxes of `rank`"""
+        out = []
+        for s in range(self.world):
+            if s != rank:
+                o = self.overlap(rank, s)
+                if o:
+                    out.append((s, o[0], o[1]))
+        return out
+
+    def rank_of_cells(self, b):
+        idx = [np.searchsorted(np.asarray(self.cuts[a][1:-1]), b[:, a], side="right") for a in range(3)]
+        return (idx[0] * self.dims[1] + idx[1]) * self.dims[2] + idx[2]
+
+
+class HaloPlan:
+    """send/recv buffers of one rank, laid out by peer rank so ONE all_to_all moves every box."""
+
+    def __init__(self, part, rank, alloc):
+        self.boxes = part.boxes(rank)
+        if len(self.boxes) > _lib.MAX_HALO_BOXES:
+            raise ValueError("too many halo boxes (%d)" % len(self.boxes))
+        self.vol = [int(np.prod([hi[a] - lo[a] for a in range(3)])) for _, lo, hi in self.boxes]
+        self.splits = [0] * part.world  # floats per peer; symmetric (box R∩S is the same on both sides)
+        self.offsets = []
+        off = 0
+        for (peer, _, _), v in zip(self.boxes, self.vol):
+            self.offsets.append(off)
+            self.splits[peer] = 4 * v
+            off += 4 * v
+        self.total = off
+        self.send = alloc(max(off, 4))
+        self.recv = alloc(max(off, 4))
+        self.send.zero_()
+        self.recv.zero_()
+
+
+# ---------------------------------------------------------------------------------------------------- engines
+class HipEngine:
+    """drives one libmpmhip ctx (the product path)"""
+
+    def __init__(self, sim, device):
+        import torch
+        self.torch = torch
+        self.sim = sim
+        self.device = torch.device("cuda", device)
+        sim._ensure_ctx()
+        self.L, self.ctx = sim._L, sim._ctx
+        # everything (kernels, RCCL collectives, buffer copies) on ONE stream: ordering by construction.  The legacy
+        # default stream has handle 0, which the C ABI reads as "the ctx's own stream" — and a non-blocking stream
+        # does not order against it — so make a real stream torch's current one first.
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream == 0:
+            cur = torch.cuda.Stream(self.device)
+            torch.cuda.set_stream(cur)
+        self.stream = cur
+        sim.set_stream(cur.cuda_stream)
+
+    def alloc(self, nfloats):
+        return self.torch.empty(int(nfloats), dtype=self.torch.float32, device=self.device)
+
+    def configure(self, part, rank, plan):
+        ip = C.POINTER(C.c_int32)
+        arrs = [np.asarray(c, np.int32) for c in part.cuts]
+        dims = np.asarray(part.dims, np.int32)
+        self.sim._check(self.L.mpmhip_set_partition(self.ctx, rank, dims.ctypes.data_as(ip), arrs[0].ctypes.data_as(ip),
+                                                    arrs[1].ctypes.data_as(ip), arrs[2].ctypes.data_as(ip), part.margin))
+        n = len(plan.boxes)
+        hb = (_lib.HaloBox * max(n, 1))()
+        for i, ((peer, lo, hi), off) in enumerate(zip(plan.boxes, plan.offsets)):
+            hb[i].lo[:] = lo
+            hb[i].hi[:] = hi
+            hb[i].peer = peer
+            hb[i].send = plan.send.data_ptr() + 4 * off
+            hb[i].recv = plan.recv.data_ptr() + 4 * off
+        self.sim._check(self.L.mpmhip_set_halo(self.ctx, n, hb))
+        self.world = part.world
+
+    def begin(self):
+        self.sim._check(self.L.mpmhip_substep_begin(self.ctx))
+
+    def end(self):
+        self.sim._check(self.L.mpmhip_substep_end(self.ctx))
+
+    def leaver_counts(self):
+        out = np.zeros(self.world, np.int64)
+        self.sim._check(self.L.mpmhip_leaver_counts(self.ctx, self.world, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
+    def export_leavers(self, counts, buf):
+        counts = np.ascontiguousarray(counts, np.int64)
+        self.sim._check(self.L.mpmhip_export_leavers(self.ctx, self.world, counts.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                     C.c_void_p(buf.data_ptr())))
+
+    def import_particles(self, buf, n):
+        if n:
+            self.sim._check(self.L.mpmhip_import_particles(self.ctx, int(n), C.c_void_p(buf.data_ptr())))
+        cap, slots = self.sim._capacity, int(self.L.mpmhip_num_slots(self.ctx))
+        if slots > 0.85 * cap:  # dead slots (leavers) pile up: compact at the next sort
+            self.sim._check(self.L.mpmhip_request_compaction(self.ctx))
+
+    def num_particles(self):
+        return self.sim.get_num_particles()
+
+    def synchronize(self):
+        self.sim.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------------- comms
+class DistComm:
+    """torch.distributed: backend nccl (= RCCL over xGMI) with device tensors, gloo with CPU tensors in tests"""
+
+    def __init__(self, dist, device):
+        import torch
+        self.torch, self.dist, self.device = torch, dist, device
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def all_to_all(self, out, inp, out_splits, in_splits):
+        out_splits, in_splits = list(map(int, out_splits)), list(map(int, in_splits))
+        self.dist.all_to_all_single(out[:sum(out_splits)], inp[:sum(in_splits)], out_splits, in_splits)
+
+    def exchange_counts(self, counts):
+        t = self.torch.as_tensor(np.asarray(counts, np.int64)).to(self.device)
+        o = self.torch.empty_like(t)
+        self.dist.all_to_all_single(o, t)
+        return o.cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------------- one rank
+class TiledRank:
+    """one rank's substep / migration, split into phases so that a distributed job (one rank per process) and a
+    virtual job (several ranks in one process, tests) run the very same code between the exchanges"""
+
+    def __init__(self, engine, part, rank, migrate_interval=None):
+        self.e, self.part, self.rank = engine, part, rank
+        self.plan = HaloPlan(part, rank, engine.alloc)
+        engine.configure(part, rank, self.plan)
+        # CFL: a particle moves < 1 cell per substep, so it stays inside the margin for `margin` substeps
+        self.migrate_interval = int(migrate_interval or part.margin)
+        assert 1 <= self.migrate_interval <= part.margin
+        self.k = 0
+        self.migrated_out = 0
+
+    # --- migration phases
+    def mig_counts(self):
+        self._counts = self.e.leaver_counts()
+        return self._counts
+
+    def mig_export(self, incoming):
+        self._incoming = np.asarray(incoming, np.int64)
+        ns, nr = int(self._counts.sum()), int(self._incoming.sum())
+        self._sendrec = self.e.alloc(max(ns, 1) * MIGRATE_FLOATS)
+        self._recvrec = self.e.alloc(max(nr, 1) * MIGRATE_FLOATS)
+        self.e.export_leavers(self._counts, self._sendrec)
+        self.migrated_out += ns
+        return self._sendrec, self._recvrec
+
+    def mig_import(self):
+        self.e.import_particles(self._recvrec, int(self._incoming.sum()))
+        self._sendrec = self._recvrec = None
+
+
+class TiledJob:
+    """bench.py job: this process's rank of the tiled run (torch.distributed)"""
+    scaling = "strong"
+
+    def __init__(self, engine, part, comm, migrate_interval=None):
+        self.r = TiledRank(engine, part, comm.rank, migrate_interval)
+        self.comm, self.e = comm, engine
+        self.parallelism = "%dx%dx%d bricks, one rank per GPU, halo all-sum + migration over RCCL" % part.dims
+
+    def substep(self):
+        r, p = self.r, self.r.plan
+        r.e.begin()
+        if p.total:
+            self.comm.all_to_all(p.recv, p.send, p.splits, p.splits)
+        r.e.end()
+        r.k += 1
+        if r.k % r.migrate_interval == 0:
+            self.migrate()
+
+    def migrate(self):
+        r = self.r
+        counts = r.mig_counts()
+        incoming = self.comm.exchange_counts(counts)
+        send, recv = r.mig_export(incoming)
+        self.comm.all_to_all(recv, send, incoming * MIGRATE_FLOATS, counts * MIGRATE_FLOATS)
+        r.mig_import()
+
+    def run(self, n):
+        for _ in range(n):
+            self.substep()
+
+    def num_particles(self):
+        return self.e.num_particles()
+
+    def synchronize(self):
+        self.e.synchronize()
+
+    def set_profiling(self, on):
+        self.e.sim.set_profiling(on)
+        self.e.sim.profile(reset=True)
+
+    def profile(self):
+        return self.e.sim.profile()
+
+
+class VirtualTiledJob:
+    """all ranks of a partition in ONE process (several ctx on one GPU, or checker engines on the CPU): the
+    exchanges become local copies.  Used by the tests to check K-tile == 1-tile on a single device."""
+
+    def __init__(self, engines, part, migrate_interval=None):
+        assert len(engines) == part.world
+        self.part = part
+        self.ranks = [TiledRank(e, part, i, migrate_interval) for i, e in enumerate(engines)]
+
+    @staticmethod
+    def _a2a(recvs, sends, splits):
+        """recvs[r] gets, for every peer s, the slice sends[s] addressed to r.  splits[r][s] = floats r sends to s."""
+        w = len(sends)
+        soff = [np.concatenate([[0], np.cumsum(splits[r])]) for r in range(w)]
+        for r in range(w):
+            o = 0
+            for s in range(w):
+                n = int(splits[s][r])
+                if n:
+                    recvs[r][o:o + n].copy_(sends[s][int(soff[s][r]):int(soff[s][r]) + n])
+                o += n
+
+    def substep(self):
+        for r in self.ranks:
+            r.e.begin()
+        self._a2a([r.plan.recv for r in self.ranks], [r.plan.send for r in self.ranks], [r.plan.splits for r in self.ranks])
+        for r in self.ranks:
+            r.e.end()
+            r.k += 1
+        if self.ranks[0].k % self.ranks[0].migrate_interval == 0:
+            self.migrate()
+
+    def migrate(self):
+        counts = np.stack([r.mig_counts() for r in self.ranks])  # counts[r][s]: r -> s
+        bufs = [r.mig_export(counts[:, i]) for i, r in enumerate(self.ranks)]
+        self._a2a([b[1] for b in bufs], [b[0] for b in bufs], counts * MIGRATE_FLOATS)
+        for r in self.ranks:
+            r.mig_import()
+
+    def run(self, n):
+        for _ in range(n):
+            self.substep()
+
+
+# ---------------------------------------------------------------------------------------------------- bench glue
+def make_tiled_job(tm, cfg, rank, world, local_rank, margin=4, migrate_interval=None):
+    """bench.py, N > 1: every rank generates the same synthetic lattice, keeps its brick's particles."""
+    import torch
+    import torch.distributed as dist
+
+    from .mpm import F_ID, lattice_cube
+    res, cells = cfg["res"], cfg["cells"]
+    dx = 1.0 / res
+    lo = res // 2 - cells // 2
+    x = lattice_cube(lo, lo + cells, dx)
+    part = Partition.balanced((res,) * 3, world, x, dx, margin)
+    mine = np.nonzero(part.rank_of_cells(base_cells(x, dx)) == rank)[0]
+    sim = tm.create_simulation3("mpm").initialize(dict(
+        res=(res,) * 3, delta_x=dx, base_delta_t=1e-4, gravity=(0, -10, 0), device=local_rank,
+        max_particles=int(len(mine) * 1.5) + (1 << 16), reorder_interval=0))
+    sim.set_levelset(tm.mpm.LevelSet(friction=-1.0).add_plane((0, 1, 0), d=-0.1))
+    sim.add_particles(dict(type=cfg["material"], positions=x[mine]))
+    sim.upload(F_ID, mine.astype(np.int32))  # creation ids are global
+    engine = HipEngine(sim, local_rank)
+    return TiledJob(engine, part, DistComm(dist, torch.device("cuda", local_rank)), migrate_interval)

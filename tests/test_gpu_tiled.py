@@ -1,0 +1,157 @@
+"""GPU tests of the tiled (multi-GPU) path on ONE device: K "virtual ranks" = K libmpmhip ctx, each holding one
+brick's particles, exchanges done as local copies (taichi_mpm_amd.tiled.VirtualTiledJob).  The kernels, halo boxes,
+rank-ordered sums and the migration are exactly what a real multi-GPU run executes; only the transport differs
+(RCCL all_to_all there).  The K-tile run must reproduce the 1-ctx run (SURVEY §8e "Test constraint").
+"""
+import numpy as np
+import pytest
+
+from tests.common import lattice_cube, make_state, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+RES, DX, DT = 32, 1.0 / 32, 1e-4
+PLANES = [(0.0, 1.0, 0.0, -0.3)]
+
+
+@pytest.fixture(scope="module")
+def tm():
+    import taichi_mpm_amd as tm
+    tm.load()
+    return tm
+
+
+def _sim(tm, s, sel, ids, cap):
+    from taichi_mpm_amd.mpm import F_ID
+    sim = tm.create_simulation3("mpm")
+    sim.initialize(dict(res=(RES,) * 3, delta_x=DX, base_delta_t=DT, max_particles=cap, reorder_interval=0))
+    ls = tm.mpm.LevelSet(friction=0.4)
+    for p in PLANES:
+        ls.add_plane(p[:3], d=p[3])
+    sim.set_levelset(ls)
+    names = {v: k for k, v in tm.MATERIAL_IDS.items()}
+    # every rank registers every group in the same order (group ids travel with migrating particles)
+    for gi in range(len(s.gtype)):
+        m = sel & (s.gid == gi)
+        sim.add_particles(dict(type=names[int(s.gtype[gi])], positions=s.x[m], velocities=s.v[m], F=s.F[m], B=s.B[m],
+                               aux=s.aux[m], params=s.gparams[gi]))
+    order = np.concatenate([np.nonzero(sel & (s.gid == gi))[0] for gi in range(len(s.gtype))])
+    if len(order):
+        sim.upload(F_ID, ids[order].astype(np.int32))
+    else:
+        sim._ensure_ctx()
+    return sim
+
+
+def _two_material_state():
+    x = lattice_cube(RES, 9, 21, DX, jitter=0.2, seed=21)
+    a = make_state(x, "jelly", DX, perturb_F=0.02, seed=22, vel_scale=8.0)
+    b = make_state(x, "sand", DX, perturb_F=0.02, seed=23, vel_scale=8.0)
+    half = x[:, 0] < x[:, 0].mean()
+    s = a.copy()
+    s.gparams = np.concatenate([a.gparams, b.gparams])
+    s.gtype = np.concatenate([a.gtype, b.gtype])
+    s.gid = np.where(half, 0, 1).astype(np.int32)
+    s.F[~half] = b.F[~half]
+    s.aux[~half] = b.aux[~half]
+    return s
+
+
+def _gather(sims):
+    parts = [sim.get_particles(sort_by_id=False) for sim in sims]
+    out = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    order = np.argsort(out["id"], kind="stable")
+    return {k: v[order] for k, v in out.items()}
+
+
+@pytest.mark.parametrize("world,dims", [(2, None), (4, None), (8, None), (3, (1, 3, 1))])
+def test_k_tiles_reproduce_one_tile(tm, world, dims):
+    from taichi_mpm_amd import tiled
+    s = _two_material_state()
+    n = s.n
+    ids = np.arange(n)
+    one = _sim(tm, s, np.ones(n, bool), ids, n + 1024)
+    part = tiled.Partition.balanced((RES,) * 3, world, s.x, DX, margin=2, dims=dims)
+    owner = part.rank_of_cells(tiled.base_cells(s.x, DX))
+    counts = np.bincount(owner, minlength=world)
+    assert counts.min() > 0.6 * n / world, counts  # balanced cuts
+    sims = [_sim(tm, s, owner == r, ids, n + 1024) for r in range(world)]
+    job = tiled.VirtualTiledJob([tiled.HipEngine(sim, 0) for sim in sims], part, migrate_interval=2)
+
+    # one P2G: every rank's node totals equal the single-ctx totals wherever the rank has mass of its own
+    one.sort_particles_and_populate_grid()
+    one.rasterize_optimized()
+    g1 = one.get_grid(0)
+    for r in job.ranks:
+        r.e.begin()
+    job._a2a([r.plan.recv for r in job.ranks], [r.plan.send for r in job.ranks], [r.plan.splits for r in job.ranks])
+    for rank, sim in enumerate(sims):
+        gr = sim.get_grid(0)
+        (nlo, nhi) = part.node_box(rank)
+        touched = gr[..., 3] > 0
+        assert touched.any()
+        idx = np.argwhere(touched)
+        assert (idx >= np.array(nlo)).all() and (idx < np.array(nhi)).all()
+        assert rel_l2(gr[touched][:, 3], g1[touched][:, 3]) <= 1e-6
+        assert rel_l2(gr[touched][:, :3], g1[touched][:, :3]) <= 1e-5
+    # ranks sharing a node hold the bit-identical total (rank-ordered sums)
+    for a in range(world):
+        for b in range(a + 1, world):
+            ga, gb = sims[a].get_grid(0), sims[b].get_grid(0)
+            both = (ga[..., 3] > 0) & (gb[..., 3] > 0)
+            assert np.array_equal(ga[both], gb[both])
+    for r in job.ranks:
+        r.e.end()
+        r.k += 1
+    one.normalize_grid_and_apply_boundary_conditions()
+    one.resample_optimized()
+
+    steps = 11
+    job.run(steps)  # migrations at k = 2, 4, ...
+    one.run_substeps(steps)
+    ref = one.get_particles()
+    got = _gather(sims)
+    assert sum(r.migrated_out for r in job.ranks) > 0, "the scene must exercise migration"
+    assert len(got["id"]) == len(ref["id"]) == n
+    assert np.array_equal(got["id"], ref["id"])
+    assert np.array_equal(got["gid"], ref["gid"])
+    # every particle sits on the rank that owns its base cell, or within the margin of it
+    for rank, sim in enumerate(sims):
+        p = sim.get_particles(sort_by_id=False)
+        b = tiled.base_cells(p["x"], DX)
+        lo, hi = part.brick(rank)
+        assert (b >= np.array(lo) - part.margin).all() and (b < np.array(hi) + part.margin).all()
+    assert np.abs(got["x"] - ref["x"]).max() <= 1e-6
+    assert rel_l2(got["v"], ref["v"]) <= 1e-4
+    assert rel_l2(got["F"], ref["F"]) <= 1e-4
+    assert rel_l2(got["B"], ref["B"]) <= 1e-3
+    for sim in sims + [one]:
+        sim.close()
+
+
+def test_migration_compacts_when_slots_run_out(tm):
+    """leavers leave dead slots behind; a rank that keeps receiving and losing particles compacts its records at
+    a later sort instead of running out of slots"""
+    from taichi_mpm_amd import tiled
+    x = lattice_cube(RES, 8, 20, DX, jitter=0.2, seed=31)
+    s = make_state(x, "jelly", DX, perturb_F=0.0, seed=32, vel_scale=0.0)
+    s.v[:] = (25.0, 0.0, 0.0)  # 0.08 cells per substep along x: a steady stream across both cuts
+    s.B[:] = 0
+    n = s.n
+    part = tiled.Partition.balanced((RES,) * 3, 3, s.x, DX, margin=2, dims=(3, 1, 1))
+    owner = part.rank_of_cells(tiled.base_cells(s.x, DX))
+    own = [int((owner == r).sum()) for r in range(3)]
+    caps = [own[0] + 64, int(own[1] * 1.3), n]
+    sims = [_sim(tm, s, owner == r, np.arange(n), caps[r]) for r in range(3)]
+    for sim in sims:
+        sim.set_levelset(tm.mpm.LevelSet())
+    job = tiled.VirtualTiledJob([tiled.HipEngine(sim, 0) for sim in sims], part, migrate_interval=2)
+    job.run(50)
+    got = _gather(sims)
+    assert len(got["id"]) == n and np.array_equal(got["id"], np.arange(n))
+    through = job.ranks[1].migrated_out
+    assert through > 0.5 * own[1], (through, own)  # far more slots were used than the 30 % of slack
+    assert int(sims[1]._L.mpmhip_num_slots(sims[1]._ctx)) <= caps[1]
+    assert np.allclose(got["v"][:, 0], 25.0, rtol=1e-3)
+    for sim in sims:
+        sim.close()
