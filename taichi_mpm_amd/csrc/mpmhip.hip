@@ -10,8 +10,9 @@
 //          k_emit_active, k_rank (rank of each particle in its cell, run-aggregated atomics),
 //          k_block_totals -> k_scan_*<1> -> k_cell_start, k_perm (sorted position -> particle slot)
 //   P2G    k_p2g   one wavefront per active 4x4x4-cell block, ONE LANE PER CELL: register accumulation of the
-//                  27x4 node contributions over the cell's particles, ordered non-atomic float4 merge into the
-//                  block's 6^3-node LDS tile, tile written out whole             (src/transfer.cpp:467-569)
+//                  27x4 node contributions over the cell's particles (records prefetched two particles ahead),
+//                  ordered non-atomic float4 merge into the block's 6^3-node LDS tile, tile written out whole
+//                                                                                (src/transfer.cpp:467-569)
 //   grid   k_grid  sums the <=8 overlapping block tiles of every touched grid block, normalises,
 //                  gravity + level-set boundary                                  (src/mpm.cpp:277-372)
 //   G2P    k_g2p   6^3 velocity tile in LDS, 27-tap gather, F update, plasticity AND the next substep's stress
@@ -21,7 +22,7 @@
 //   particles  two arrays of 64-byte records indexed by a stable particle slot (the reference's
 //              ParticleAllocator pool index, src/particle_allocator.h:36):
 //                RecG {x3, aux, F9, gid, pid, -}   what G2P reads and rewrites
-//                RecP {x3, v3, A9, gid}            what P2G reads;  A = stress*(-4 inv_dx dt) + apic_b*(4 m)
+//                RecP {x3, v3, A9, mass}           what P2G reads;  A = stress*(-4 inv_dx dt) + apic_b*(4 m)
 //              (src/transfer.cpp:521-522) is produced by G2P, so P2G carries no constitutive work, and
 //              apic_b itself goes to a side array (it is only ever consumed through A).
 //              Particles never move in memory between substeps: `perm` (sorted position -> slot) is rebuilt
@@ -70,7 +71,7 @@ struct alignas(16) RecP {  // P2G side
   float x[3];
   float v[3];
   float A[9];
-  uint32_t gid;
+  float mass;  // group mass (get_mass()), so P2G needs no group-table lookup
 };
 static_assert(sizeof(RecG) == 64 && sizeof(RecP) == 64, "records must be 64 bytes");
 constexpr int BW = 12;  // floats per apic_b record (9 used): three float4
@@ -97,6 +98,8 @@ struct Params {
   uint32_t max_blocks;
   uint32_t n_slots;  // particle slots in use (host-known)
   int store_b;       // keep apic_b in the side array
+  int ablate;        // PROFILING ONLY (env MPMHIP_ABLATE, results invalid): 1 no G2P stores, 2 no constitutive
+                     // update, 4 no 27-tap gather
 };
 
 // multi-GPU tiling (include/mpmhip.h, "Multi-GPU tiling"): partition of the cell space into bricks + halo boxes
@@ -467,15 +470,14 @@ __global__ __launch_bounds__(256) void k_affine(Params P, const RecG *__restrict
 
 // ------------------------------------------------------------------------------------------------ P2G
 // rasterize_optimized / block_op_normal (src/transfer.cpp:467-569).
-// Mapping: one workgroup of two wavefronts per active 4^3-cell block, ONE LANE PER CELL in each wave; wave 0
-// owns stencil nodes 0..13 of every cell, wave 1 nodes 14..26 (halves the accumulator registers, which buys the
-// occupancy and the software prefetch that hide the record-gather latency).  The sorted index lists the
-// particles of each cell contiguously, so lane c walks its cell's particles and accumulates their node
-// contributions in registers (the reference walks cells sequentially inside a block and accumulates into its
-// scratch tile the same way, :474-483).  Write conflicts between particles of one cell therefore never reach
-// memory; each wave merges its per-cell sums into its own 6^3-node LDS tile by ordered, non-atomic float4
-// read-modify-writes, the two tiles are added on the way out and written whole; conflicts between blocks are
-// resolved by k_grid.
+// Mapping: ONE LANE PER CELL of an active 4^3-cell block.  The sorted index lists the particles of each cell
+// contiguously, so lane c walks its cell's particles and accumulates their node contributions in registers (the
+// reference walks cells sequentially inside a block and accumulates into its scratch tile the same way,
+// :474-483).  Write conflicts between particles of one cell therefore never reach memory; a wave merges its
+// per-cell sums into its own 6^3-node LDS tile by ordered, non-atomic float4 read-modify-writes and the tile is
+// written out whole; conflicts between blocks are resolved by k_grid.  p2g_cell<N0,N1> handles stencil nodes
+// N0..N1-1 of the particles [p0,p1) of the lane's cell, so a block can be one wave (default) or several waves
+// splitting the nodes and/or the particles (k_p2g<NS,PS>).
 template <int N0, int N1>
 __device__ __forceinline__ void p2g_cell(const Params &P, const float4 *__restrict__ rp,
                                          const uint32_t *__restrict__ perm,
@@ -485,22 +487,28 @@ __device__ __forceinline__ void p2g_cell(const Params &P, const float4 *__restri
   float acc[NN][4];
 #pragma unroll
   for (int n = 0; n < NN; n++) { acc[n][0] = 0.0f; acc[n][1] = 0.0f; acc[n][2] = 0.0f; acc[n][3] = 0.0f; }
-  // software pipeline: the index two particles ahead and the record one particle ahead are already in flight
-  float4 n0, n1, n2, n3;
+  // software pipeline: the records of the next TWO particles and the index of the third are in flight while
+  // one particle is computed (one particle's arithmetic is shorter than the loaded HBM latency)
+  float4 n0, n1, n2, n3, m0, m1, m2, m3;
   uint32_t inext = 0;
   if (p0 < p1) {
     const size_t i = perm[p0];
     n0 = rp[i * 4 + 0]; n1 = rp[i * 4 + 1]; n2 = rp[i * 4 + 2]; n3 = rp[i * 4 + 3];
-    if (p0 + 1 < p1) inext = perm[p0 + 1];
+    if (p0 + 1 < p1) {
+      const size_t j = perm[p0 + 1];
+      m0 = rp[j * 4 + 0]; m1 = rp[j * 4 + 1]; m2 = rp[j * 4 + 2]; m3 = rp[j * 4 + 3];
+      if (p0 + 2 < p1) inext = perm[p0 + 2];
+    }
   }
   for (uint32_t p = p0; p < p1; p++) {
     const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
-    if (p + 1 < p1) {
+    n0 = m0; n1 = m1; n2 = m2; n3 = m3;
+    if (p + 2 < p1) {
       const size_t i = inext;
-      n0 = rp[i * 4 + 0]; n1 = rp[i * 4 + 1]; n2 = rp[i * 4 + 2]; n3 = rp[i * 4 + 3];
-      if (p + 2 < p1) inext = perm[p + 2];
+      m0 = rp[i * 4 + 0]; m1 = rp[i * 4 + 1]; m2 = rp[i * 4 + 2]; m3 = rp[i * 4 + 3];
+      if (p + 3 < p1) inext = perm[p + 3];
     }
-    const float mass = groups[__float_as_uint(q3.w)].p[0];
+    const float mass = q3.w;  // the particle mass travels in the record: no dependent table lookup
     float v0 = q0.w, v1 = q1.x, v2 = q1.y;
     if (P.particle_gravity) {  // src/transfer.cpp:485-487
       v0 = fmaf(P.g[0], P.dt, v0); v1 = fmaf(P.g[1], P.dt, v1); v2 = fmaf(P.g[2], P.dt, v2);
@@ -535,6 +543,7 @@ __device__ __forceinline__ void p2g_cell(const Params &P, const float4 *__restri
 #pragma unroll
   for (int n = N0; n < N1; n++) {
     const int node = nbase + ((n / 9) * TS + (n / 3) % 3) * TS + n % 3;
+    if ((P.ablate & 8) && acc[n - N0][3] != 1.2345e-30f) continue;
     if (p1 > p0) {
       float4 t = tile[node];
       t.x += acc[n - N0][0]; t.y += acc[n - N0][1]; t.z += acc[n - N0][2]; t.w += acc[n - N0][3];
@@ -545,30 +554,48 @@ __device__ __forceinline__ void p2g_cell(const Params &P, const float4 *__restri
   }
 }
 
-__global__ __launch_bounds__(128, 3) void k_p2g(Params P, const float4 *__restrict__ rp,
-                                                const Counters *__restrict__ cnt,
-                                                const uint32_t *__restrict__ act_blk,
-                                                const uint32_t *__restrict__ cell_start,
-                                                const uint32_t *__restrict__ perm,
-                                                const GroupParams *__restrict__ groups, float4 *__restrict__ tiles) {
-  __shared__ float4 tile[2][TN];  // per wave: (m*vx, m*vy, m*vz, m) per node of the block's 6^3 tile
+// NS = waves splitting the 27 stencil nodes (1 or 2), PS = waves splitting every cell's particles (1, 2 or 4):
+// NS*PS wavefronts per block, each with its own LDS tile.  Node splitting halves the accumulator registers
+// (occupancy) but both halves load the same records; particle splitting keeps every record load unique.
+template <int NS, int PS, int MINW>
+__global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const float4 *__restrict__ rp,
+                                                            const Counters *__restrict__ cnt,
+                                                            const uint32_t *__restrict__ act_blk,
+                                                            const uint32_t *__restrict__ cell_start,
+                                                            const uint32_t *__restrict__ perm,
+                                                            const GroupParams *__restrict__ groups,
+                                                            float4 *__restrict__ tiles) {
+  constexpr int NW = NS * PS, NT = 64 * NW;
+  __shared__ float4 tile[NW][TN];  // per wave: (m*vx, m*vy, m*vz, m) per node of the block's 6^3 tile
   const uint32_t na = min(cnt->n_active, P.max_blocks);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int npart = wave % NS, ppart = wave / NS;
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
   const int nbase = (cx * TS + cy) * TS + cz;
   for (uint32_t a = blockIdx.x; a < na; a += gridDim.x) {
-    for (int t = threadIdx.x; t < 2 * TN; t += 128) (&tile[0][0])[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int t = threadIdx.x; t < NW * TN; t += NT) (&tile[0][0])[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();
     int bx, by, bz;
     demorton3(act_blk[a], bx, by, bz);
     const float ox = (float)(bx * BS + cx), oy = (float)(by * BS + cy), oz = (float)(bz * BS + cz);
-    const uint32_t p0 = cell_start[a * BC + lane], p1 = cell_start[a * BC + lane + 1];
-    if (wave == 0) p2g_cell<0, 14>(P, rp, perm, groups, p0, p1, ox, oy, oz, nbase, tile[0]);
-    else p2g_cell<14, 27>(P, rp, perm, groups, p0, p1, ox, oy, oz, nbase, tile[1]);
+    const uint32_t c0 = cell_start[a * BC + lane], c1 = cell_start[a * BC + lane + 1];
+    const uint32_t n = c1 - c0;
+    const uint32_t p0 = c0 + (n * ppart + PS - 1) / PS, p1 = c0 + (n * (ppart + 1) + PS - 1) / PS;
+    if constexpr (NS == 1) {
+      p2g_cell<0, 27>(P, rp, perm, groups, p0, p1, ox, oy, oz, nbase, tile[wave]);
+    } else {
+      if (npart == 0) p2g_cell<0, 14>(P, rp, perm, groups, p0, p1, ox, oy, oz, nbase, tile[wave]);
+      else p2g_cell<14, 27>(P, rp, perm, groups, p0, p1, ox, oy, oz, nbase, tile[wave]);
+    }
     __syncthreads();
-    for (int t = threadIdx.x; t < TN; t += 128) {
-      const float4 u = tile[0][t], w = tile[1][t];
-      tiles[(size_t)a * TN + t] = make_float4(u.x + w.x, u.y + w.y, u.z + w.z, u.w + w.w);
+    for (int t = threadIdx.x; t < TN; t += NT) {
+      float4 u = tile[0][t];
+#pragma unroll
+      for (int w = 1; w < NW; w++) {
+        const float4 q = tile[w][t];
+        u.x += q.x; u.y += q.y; u.z += q.z; u.w += q.w;
+      }
+      tiles[(size_t)a * TN + t] = u;
     }
     __syncthreads();
   }
@@ -830,123 +857,213 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
                                                   const uint32_t *__restrict__ fat_slot, Counters *cnt_w,
                                                   uint32_t *__restrict__ key, uint8_t *__restrict__ blk_flag) {
   __shared__ float4 tile[TN];
+  // Store staging, one slab per wavefront.  A lane holds its particle's whole record, so a direct store would
+  // issue 16-byte pieces at a 64-byte stride: 64 partial-line write requests per instruction (measured: the
+  // stores alone cost 0.28 of 0.61 ms).  Records are written row-wise to LDS (80-byte stride: conflict-free
+  // b128) and read back transposed, so 4 consecutive lanes store the 4 float4 of one record: full 64-byte
+  // segments, 4x fewer write requests.
+  __shared__ float4 xpose[NT / 64][64 * 5];
+  __shared__ uint32_t xslot[NT / 64][64];
   const uint32_t na = min(cnt->n_active, P.max_blocks);
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  float4 *xp = xpose[wave];
+  uint32_t *xs = xslot[wave];
   const float scale = -4.0f * P.idx * P.dt;  // :938
-  for (uint32_t a = blockIdx.x; a < na; a += gridDim.x) {
-    int bx, by, bz;
-    demorton3(act_blk[a], bx, by, bz);
-    for (int t = tid; t < TN; t += NT) {
-      const int tx = t / (TS * TS), ty = (t / TS) % TS, tz = t % TS;
-      const int qx = tx >> 2, qy = ty >> 2, qz = tz >> 2;
-      const uint32_t fs = fat_slot[morton3(bx + qx, by + qy, bz + qz)];
-      tile[t] = gridv[(size_t)fs * BC + (((tx & 3) << 4) | ((ty & 3) << 2) | (tz & 3))];
+  // The workgroup walks "chunks": NT consecutive entries of the sorted index inside one active block.  The
+  // record gather of chunk k+1 and the index load of chunk k+2 are issued before the arithmetic of chunk k
+  // (also across block boundaries), so every wave keeps 4 KiB of loads in flight while it computes.
+  struct Chunk { uint32_t a, p, p1; };
+  auto first = [&](uint32_t a) {
+    Chunk c;
+    c.a = a; c.p = 0; c.p1 = 0;
+    while (c.a < na) {
+      c.p = act_start[c.a]; c.p1 = act_start[c.a + 1];
+      if (c.p < c.p1) break;
+      c.a += gridDim.x;  // empty block (all its particles migrated away)
     }
-    __syncthreads();
-    const float ox = (float)(bx * BS), oy = (float)(by * BS), oz = (float)(bz * BS);
-    const uint32_t p0 = act_start[a], p1 = act_start[a + 1];
-    const uint32_t nloop = (p1 - p0 + NT - 1) / NT;
-    for (uint32_t it = 0; it < nloop; it++) {  // uniform trip count (flag_block shuffles)
-      const uint32_t p = p0 + it * NT + tid;
-      uint32_t bkey = INVALID;
-      if (p < p1) {
-        const size_t i = perm[p];
-        const float4 g0 = rg[i * 4 + 0], g1 = rg[i * 4 + 1], g2 = rg[i * 4 + 2], g3 = rg[i * 4 + 3];
-        const uint32_t gid = __float_as_uint(g3.y);
-        const GroupParams &g = groups[gid];  // read at use (L1-resident table): keeps 20 VGPRs free
-        const float x0 = g0.x, x1 = g0.y, x2 = g0.z;
-        const float X0 = x0 * P.idx - ox, X1 = x1 * P.idx - oy, X2 = x2 * P.idx - oz;
-        const int c0 = (int)(X0 - 0.5f), c1 = (int)(X1 - 0.5f), c2 = (int)(X2 - 0.5f);
-        const float r0 = X0 - (float)c0, r1 = X1 - (float)c1, r2 = X2 - (float)c2;
-        float w0[3], w1[3], w2[3];
-        bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
-        float v0 = 0, v1 = 0, v2 = 0;
-        mat3 b;
+    return c;
+  };
+  auto next = [&](Chunk c) {
+    if (c.a >= na) return c;
+    c.p += NT;
+    if (c.p >= c.p1) c = first(c.a + gridDim.x);
+    return c;
+  };
+  auto lane_slot = [&](const Chunk &c) -> uint32_t {
+    return (c.a < na && c.p + tid < c.p1) ? perm[c.p + tid] : INVALID;
+  };
+  Chunk cur = first(blockIdx.x);
+  Chunk nx = next(cur);
+  uint32_t i_cur = lane_slot(cur);
+  float4 g0, g1, g2, g3;
+  if (i_cur != INVALID) {
+    const size_t i = i_cur;
+    g0 = rg[i * 4 + 0]; g1 = rg[i * 4 + 1]; g2 = rg[i * 4 + 2]; g3 = rg[i * 4 + 3];
+  }
+  uint32_t i_nx = lane_slot(nx);
+  uint32_t tile_a = INVALID;
+  float ox = 0, oy = 0, oz = 0;
+  while (cur.a < na) {
+    if (cur.a != tile_a) {
+      __syncthreads();  // everyone is done with the previous tile
+      int bx, by, bz;
+      demorton3(act_blk[cur.a], bx, by, bz);
+      for (int t = tid; t < TN; t += NT) {
+        const int tx = t / (TS * TS), ty = (t / TS) % TS, tz = t % TS;
+        const int qx = tx >> 2, qy = ty >> 2, qz = tz >> 2;
+        const uint32_t fs = fat_slot[morton3(bx + qx, by + qy, bz + qz)];
+        tile[t] = gridv[(size_t)fs * BC + (((tx & 3) << 4) | ((ty & 3) << 2) | (tz & 3))];
+      }
+      __syncthreads();
+      ox = (float)(bx * BS); oy = (float)(by * BS); oz = (float)(bz * BS);
+      tile_a = cur.a;
+    }
+    // prefetch: records of the next chunk, index of the one after
+    const Chunk nn = next(nx);
+    float4 n0, n1, n2, n3;
+    if (i_nx != INVALID) {
+      const size_t i = i_nx;
+      n0 = rg[i * 4 + 0]; n1 = rg[i * 4 + 1]; n2 = rg[i * 4 + 2]; n3 = rg[i * 4 + 3];
+    }
+    const uint32_t i_nn = lane_slot(nn);
+    uint32_t bkey = INVALID, out_slot = INVALID;
+    float4 G0, G1, G2, G3, Q0, Q1, Q2, Q3, B0, B1, B2;
+    G0 = G1 = G2 = G3 = Q0 = Q1 = Q2 = Q3 = B0 = B1 = B2 = make_float4(0, 0, 0, 0);
+    if (i_cur != INVALID) {
+      const size_t i = i_cur;
+      const uint32_t gid = __float_as_uint(g3.y);
+      const GroupParams &g = groups[gid];  // read at use (L1-resident table): keeps 20 VGPRs free
+      const float x0 = g0.x, x1 = g0.y, x2 = g0.z;
+      const float X0 = x0 * P.idx - ox, X1 = x1 * P.idx - oy, X2 = x2 * P.idx - oz;
+      const int c0 = (int)(X0 - 0.5f), c1 = (int)(X1 - 0.5f), c2 = (int)(X2 - 0.5f);
+      const float r0 = X0 - (float)c0, r1 = X1 - (float)c1, r2 = X2 - (float)c2;
+      float w0[3], w1[3], w2[3];
+      bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
+      float v0 = 0, v1 = 0, v2 = 0;
+      mat3 b;
 #pragma unroll
-        for (int k = 0; k < 9; k++) b.m[k] = 0.0f;
-        const int nbase = (c0 * TS + c1) * TS + c2;
-        auto plane = [&](int i3) __attribute__((always_inline)) {
-          const float d0 = r0 - (float)i3;
+      for (int k = 0; k < 9; k++) b.m[k] = 0.0f;
+      const int nbase = (c0 * TS + c1) * TS + c2;
+      auto plane = [&](int i3) __attribute__((always_inline)) {
+        const float d0 = r0 - (float)i3;
 #pragma unroll
-          for (int j = 0; j < 3; j++) {
-            const float d1 = r1 - (float)j;
-            const float wij = w0[i3] * w1[j];
+        for (int j = 0; j < 3; j++) {
+          const float d1 = r1 - (float)j;
+          const float wij = w0[i3] * w1[j];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-              const float d2 = r2 - (float)k;
-              const float w = wij * w2[k];
-              const float4 gv = tile[nbase + (i3 * TS + j) * TS + k];
-              // :898-903  v_ = fma(grid_vel, w, v_);  b_[r] = fma(w*grid_vel, dpos[r], b_[r])
-              v0 = fmaf(gv.x, w, v0); v1 = fmaf(gv.y, w, v1); v2 = fmaf(gv.z, w, v2);
-              const float a0 = w * gv.x, a1 = w * gv.y, a2 = w * gv.z;
-              b(0, 0) = fmaf(a0, d0, b(0, 0)); b(0, 1) = fmaf(a0, d1, b(0, 1)); b(0, 2) = fmaf(a0, d2, b(0, 2));
-              b(1, 0) = fmaf(a1, d0, b(1, 0)); b(1, 1) = fmaf(a1, d1, b(1, 1)); b(1, 2) = fmaf(a1, d2, b(1, 2));
-              b(2, 0) = fmaf(a2, d0, b(2, 0)); b(2, 1) = fmaf(a2, d1, b(2, 1)); b(2, 2) = fmaf(a2, d2, b(2, 2));
-            }
+          for (int k = 0; k < 3; k++) {
+            const float d2 = r2 - (float)k;
+            const float w = wij * w2[k];
+            const float4 gv = tile[nbase + (i3 * TS + j) * TS + k];
+            // :898-903  v_ = fma(grid_vel, w, v_);  b_[r] = fma(w*grid_vel, dpos[r], b_[r])
+            v0 = fmaf(gv.x, w, v0); v1 = fmaf(gv.y, w, v1); v2 = fmaf(gv.z, w, v2);
+            const float a0 = w * gv.x, a1 = w * gv.y, a2 = w * gv.z;
+            b(0, 0) = fmaf(a0, d0, b(0, 0)); b(0, 1) = fmaf(a0, d1, b(0, 1)); b(0, 2) = fmaf(a0, d2, b(0, 2));
+            b(1, 0) = fmaf(a1, d0, b(1, 0)); b(1, 1) = fmaf(a1, d1, b(1, 1)); b(1, 2) = fmaf(a1, d2, b(1, 2));
+            b(2, 0) = fmaf(a2, d0, b(2, 0)); b(2, 1) = fmaf(a2, d1, b(2, 1)); b(2, 2) = fmaf(a2, d2, b(2, 2));
           }
-        };
+        }
+      };
+      if (!(P.ablate & 4)) {
         if constexpr (ROLL) {  // rolled i-loop: 9 LDS reads in flight instead of 27 (VGPR pressure -> occupancy)
 #pragma unroll 1
           for (int i3 = 0; i3 < 3; i3++) plane(i3);
         } else {
           plane(0); plane(1); plane(2);
         }
-        mat3 cdg;  // :940-942  cdg = I + (-4 inv_dx dt) b   (undamped b, as in the reference)
+      }
+      mat3 cdg;  // :940-942  cdg = I + (-4 inv_dx dt) b   (undamped b, as in the reference)
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) cdg(r, c) = fmaf(scale, b(r, c), (r == c) ? 1.0f : 0.0f);
+      // apic_b = damp_affine_momemtum(b) (src/mpm.h:465-469); the reference's optimised path has a bug
+      // here (passes the block index, transfer.cpp:925-926) — we implement the intended damping.
+      if (P.rpic_damping != 0.0f || P.apic_damping != 0.0f) {
+        const float ks = 1.0f - P.rpic_damping, ka = 1.0f - P.apic_damping;
+        mat3 bd;
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
-          for (int c = 0; c < 3; c++) cdg(r, c) = fmaf(scale, b(r, c), (r == c) ? 1.0f : 0.0f);
-        // apic_b = damp_affine_momemtum(b) (src/mpm.h:465-469); the reference's optimised path has a bug
-        // here (passes the block index, transfer.cpp:925-926) — we implement the intended damping.
-        if (P.rpic_damping != 0.0f || P.apic_damping != 0.0f) {
-          const float ks = 1.0f - P.rpic_damping, ka = 1.0f - P.apic_damping;
-          mat3 bd;
-#pragma unroll
-          for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-              const float sym = 0.5f * (b(r, c) + b(c, r));
-              bd(r, c) = ks * sym + ka * (b(r, c) - sym);
-            }
-          b = bd;
-        }
-        mat3 F;
-        F.m[0] = g1.x; F.m[1] = g1.y; F.m[2] = g1.z; F.m[3] = g1.w; F.m[4] = g2.x; F.m[5] = g2.y; F.m[6] = g2.z;
-        F.m[7] = g2.w; F.m[8] = g3.x;
-        float aux = g0.w;
-        mat3 stress;
-        plasticity_and_force(g, cdg, F, aux, stress);  // :950 + next substep's :509
-        const float nx0 = fmaf(v0, P.dt, x0), nx1 = fmaf(v1, P.dt, x1), nx2 = fmaf(v2, P.dt, x2);  // :951
-        const float m4 = 4.0f * g.p[0];
-        float A[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) A[k] = fmaf(stress.m[k], scale, b.m[k] * m4);  // next P2G's :521-522
-        // next substep's key; deleted particles (clear_boundary_particles) are marked for good
-        const float nx[3] = {nx0, nx1, nx2}, nv[3] = {v0, v1, v2};
-        const uint32_t kk = particle_key(P, nx, nv, bkey);
-        int32_t pid = __float_as_int(g3.z);
-        if (kk == INVALID) {
-          pid = -1;
-          atomicAdd(&cnt_w->n_dead, 1u);
-        }
-        key[i] = kk;
-        rg[i * 4 + 0] = make_float4(nx0, nx1, nx2, aux);
-        rg[i * 4 + 1] = make_float4(F.m[0], F.m[1], F.m[2], F.m[3]);
-        rg[i * 4 + 2] = make_float4(F.m[4], F.m[5], F.m[6], F.m[7]);
-        rg[i * 4 + 3] = make_float4(F.m[8], g3.y, __int_as_float(pid), 0.0f);
-        rp[i * 4 + 0] = make_float4(nx0, nx1, nx2, v0);
-        rp[i * 4 + 1] = make_float4(v1, v2, A[0], A[1]);
-        rp[i * 4 + 2] = make_float4(A[2], A[3], A[4], A[5]);
-        rp[i * 4 + 3] = make_float4(A[6], A[7], A[8], g3.y);
-        if (P.store_b) {
-          rb[i * 3 + 0] = make_float4(b.m[0], b.m[1], b.m[2], b.m[3]);
-          rb[i * 3 + 1] = make_float4(b.m[4], b.m[5], b.m[6], b.m[7]);
-          rb[i * 3 + 2] = make_float4(b.m[8], 0.0f, 0.0f, 0.0f);
-        }
+          for (int c = 0; c < 3; c++) {
+            const float sym = 0.5f * (b(r, c) + b(c, r));
+            bd(r, c) = ks * sym + ka * (b(r, c) - sym);
+          }
+        b = bd;
       }
-      flag_block(blk_flag, bkey);
+      mat3 F;
+      F.m[0] = g1.x; F.m[1] = g1.y; F.m[2] = g1.z; F.m[3] = g1.w; F.m[4] = g2.x; F.m[5] = g2.y; F.m[6] = g2.z;
+      F.m[7] = g2.w; F.m[8] = g3.x;
+      float aux = g0.w;
+      mat3 stress;
+      if (!(P.ablate & 2)) plasticity_and_force(g, cdg, F, aux, stress);  // :950 + next substep's :509
+      else stress = cdg;
+      const float nx0 = fmaf(v0, P.dt, x0), nx1 = fmaf(v1, P.dt, x1), nx2 = fmaf(v2, P.dt, x2);  // :951
+      const float m4 = 4.0f * g.p[0];
+      float A[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) A[k] = fmaf(stress.m[k], scale, b.m[k] * m4);  // next P2G's :521-522
+      // next substep's key; deleted particles (clear_boundary_particles) are marked for good
+      const float nxp[3] = {nx0, nx1, nx2}, nv[3] = {v0, v1, v2};
+      const uint32_t kk = particle_key(P, nxp, nv, bkey);
+      int32_t pid = __float_as_int(g3.z);
+      if (kk == INVALID) {
+        pid = -1;
+        atomicAdd(&cnt_w->n_dead, 1u);
+      }
+      key[i] = kk;
+      G0 = make_float4(nx0, nx1, nx2, aux);
+      G1 = make_float4(F.m[0], F.m[1], F.m[2], F.m[3]);
+      G2 = make_float4(F.m[4], F.m[5], F.m[6], F.m[7]);
+      G3 = make_float4(F.m[8], g3.y, __int_as_float(pid), 0.0f);
+      Q0 = make_float4(nx0, nx1, nx2, v0);
+      Q1 = make_float4(v1, v2, A[0], A[1]);
+      Q2 = make_float4(A[2], A[3], A[4], A[5]);
+      Q3 = make_float4(A[6], A[7], A[8], g.p[0]);
+      B0 = make_float4(b.m[0], b.m[1], b.m[2], b.m[3]);
+      B1 = make_float4(b.m[4], b.m[5], b.m[6], b.m[7]);
+      B2 = make_float4(b.m[8], 0.0f, 0.0f, 0.0f);
+      out_slot = (P.ablate & 1) ? INVALID : i_cur;
     }
-    __syncthreads();
+    // transposed stores through this wave's LDS slab (DS operations of one wave execute in program order)
+    xs[lane] = out_slot;
+    xp[lane * 5 + 0] = G0; xp[lane * 5 + 1] = G1; xp[lane * 5 + 2] = G2; xp[lane * 5 + 3] = G3;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int src = 16 * k + (lane >> 2), q = lane & 3;
+      const uint32_t sl = xs[src];
+      const float4 val = xp[src * 5 + q];
+      if (sl != INVALID) rg[(size_t)sl * 4 + q] = val;
+    }
+    __builtin_amdgcn_wave_barrier();
+    xp[lane * 5 + 0] = Q0; xp[lane * 5 + 1] = Q1; xp[lane * 5 + 2] = Q2; xp[lane * 5 + 3] = Q3;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int src = 16 * k + (lane >> 2), q = lane & 3;
+      const uint32_t sl = xs[src];
+      const float4 val = xp[src * 5 + q];
+      if (sl != INVALID) rp[(size_t)sl * 4 + q] = val;
+    }
+    if (P.store_b) {
+      __builtin_amdgcn_wave_barrier();
+      xp[lane * 5 + 0] = B0; xp[lane * 5 + 1] = B1; xp[lane * 5 + 2] = B2;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int e = 64 * k + lane, src = e / 3, q = e - 3 * src;
+        const uint32_t sl = xs[src];
+        const float4 val = xp[src * 5 + q];
+        if (sl != INVALID) rb[(size_t)sl * 3 + q] = val;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    flag_block(blk_flag, bkey);
+    cur = nx; nx = nn;
+    i_cur = i_nx; i_nx = i_nn;
+    g0 = n0; g1 = n1; g2 = n2; g3 = n3;
   }
 }
 
@@ -1028,6 +1145,8 @@ struct mpmhip_ctx {
   bool sorted = false;        // perm / cell_start describe the current positions
   bool keys_valid = false;    // key[] + block flags describe the current positions (set by k_g2p)
   bool affine_valid = false;  // RecP.A matches (F, aux, apic_b)
+  int p2g_wgs = 16384;        // workgroups of k_p2g (env MPMHIP_P2G_WGS)
+  int p2g_split = 11;         // tuning knob (env MPMHIP_P2G_SPLIT): 10*NS + PS, see do_p2g
   int g2p_minw = 13;          // tuning knob (env MPMHIP_G2P_MINW): __launch_bounds__ waves/SIMD of k_g2p
   int reorder_interval = 0;   // physical reorder every this many substeps (0 = never); env MPMHIP_REORDER_INTERVAL
   float t = 0.0f, request_t = 0.0f;  // `real` accumulators, as in the reference (src/mpm.h:99, mpm.cpp:573)
@@ -1113,8 +1232,11 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   c->cfg = *cfg;
   c->device = cfg->device;
   if (const char *e = getenv("MPMHIP_G2P_MINW")) c->g2p_minw = atoi(e);
+  if (const char *e = getenv("MPMHIP_P2G_SPLIT")) c->p2g_split = atoi(e);
+  if (const char *e = getenv("MPMHIP_P2G_WGS")) c->p2g_wgs = atoi(e) > 0 ? atoi(e) : 16384;
   c->reorder_interval = cfg->reorder_interval;
   if (const char *e = getenv("MPMHIP_REORDER_INTERVAL")) c->reorder_interval = atoi(e);
+  const int ablate = getenv("MPMHIP_ABLATE") ? atoi(getenv("MPMHIP_ABLATE")) : 0;
   auto bail = [&](int code) { g_create_error = c->err; mpmhip_destroy(c); return code; };
   if (hipSetDevice(c->device) != hipSuccess) { fail(c, MPMHIP_EHIP, "hipSetDevice failed"); return bail(MPMHIP_EHIP); }
   Params &P = c->P;
@@ -1131,6 +1253,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   P.particle_gravity = cfg->particle_gravity; P.apic_damping = cfg->apic_damping; P.rpic_damping = cfg->rpic_damping;
   P.clean_boundary = cfg->clean_boundary; P.n_planes = cfg->n_planes; P.friction = cfg->friction;
   P.store_b = cfg->discard_apic_b ? 0 : 1;
+  P.ablate = ablate;
   memcpy(P.planes, cfg->planes, sizeof P.planes);
   int kbits = 1;
   while ((1 << kbits) < maxnb) kbits++;
@@ -1278,7 +1401,8 @@ int mpmhip_add_particles(mpmhip_ctx *c, int32_t group, int64_t n, const float *x
       hb[(size_t)i * BW + k] = B ? B[9 * i + k] : 0.0f;
     }
     g.aux = aux ? aux[i] : aux0;
-    g.gid = p.gid = (uint32_t)group;
+    g.gid = (uint32_t)group;
+    p.mass = c->groups[group].p[0];
     g.pid = c->next_pid + (int32_t)i;
     g.pad = 0;
   }
@@ -1445,8 +1569,17 @@ static int do_p2g(mpmhip_ctx *c) {
                        c->d_groups);
     c->affine_valid = true;
   }
-  hipLaunchKernelGGL(k_p2g, dim3(8192), dim3(128), 0, c->stream, c->P, (const float4 *)c->rp, c->cnt, c->act_blk,
-                     c->cell_start, c->perm, c->d_groups, c->tiles);
+  // one wavefront per block (all 27 nodes, all particles) measured fastest at 256^3 / 8 M: 0.187 ms against
+  // 0.237 (two waves splitting the nodes) and 0.225 (two waves splitting the particles); knob: 10*NS + PS
+  auto kern = k_p2g<1, 1, 2>;
+  int nt = 64;
+  switch (c->p2g_split) {
+    case 21: kern = k_p2g<2, 1, 3>; nt = 128; break;
+    case 12: kern = k_p2g<1, 2, 2>; nt = 128; break;
+    default: break;
+  }
+  hipLaunchKernelGGL(kern, dim3(c->p2g_wgs), dim3(nt), 0, c->stream, c->P,
+                     (const float4 *)c->rp, c->cnt, c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles);
   return launch_check(c, "p2g");
 }
 static int do_grid(mpmhip_ctx *c, int mode) {
