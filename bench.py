@@ -6,11 +6,17 @@ prints ONE JSON line on rank 0.  A "step" is one substep (src/mpm.cpp:452-575) o
 BASELINE.json's metric is quoted on: config C3 = 256^3 grid, 100^3 cells x 8 = 8 000 000 Drucker-Prager sand
 particles, fp32, inputs resident in HBM before the timed region.
 
+Sequence:  W warm-up substeps (untimed) | a short untimed pass with every phase bracketed by hipEvents (phase
+table, picks the dominant kernel) | barrier | K timed substeps, only the dominant kernel bracketed (two event
+records per substep; bracketing all phases would add ~20 us of idle GPU per substep) | barrier.
+
 Extra objects on the line:
   roofline      dominant kernel (the slower of k_p2g / k_g2p): algorithmic bytes per launch / its average launch
-                duration, measured with hipEvents recorded on the ctx stream around every phase of every timed
-                substep (mpmhip_set_profiling).  Algorithmic bytes per particle: P2G 100 B particle
-                read + 16 B per touched grid node written; G2P 52 B read + 100 B written + 16 B per touched node read.
+                duration over the K timed substeps, hipEvents recorded on the ctx stream (mpmhip_set_profiling).
+                Algorithmic bytes per particle: P2G 100 B particle read + 16 B per touched grid node
+                written; G2P 52 B read + 100 B written + 16 B per touched node read.  `traffic` = HBM bytes per
+                launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE, see
+                DESIGN.md §6) / the same launch duration, or null when no PMC summary matches the workload.
   cpu_baseline  the block-sorted, 8-colour, OpenMP restatement of the reference's optimised CPU path
                 (oracle/mpm_oracle_opt.cpp, kind "port") timed on this box's host cores on a bounded sample.
 """
@@ -45,12 +51,14 @@ def build_sim(tm, cfg, device):
 
 
 def cpu_baseline(cfg, budget_s=20.0):
-    """restated reference algorithm (CPU) on a bounded sample: same grid/material/ppc, a smaller cube."""
+    """restated reference algorithm (CPU) on a bounded sample: same grid/material/ppc, a smaller cube.
+    OpenMP thread count: the best of a short sweep (oversubscribing a 512k-particle sample with every hardware
+    thread of a 256-thread host is several times SLOWER than 32 threads); `cores` is the count actually used."""
     from oracle import oracle as orc
     from taichi_mpm_amd.mpm import lattice_cube
     res = cfg["res"]
     dx = 1.0 / res
-    cells = 40 if res >= 256 else 32
+    cells = 48 if res >= 256 else 32
     lo = res // 2 - cells // 2
     x = lattice_cube(lo, lo + cells, dx)
     vol = dx ** 3 / 8
@@ -58,20 +66,41 @@ def cpu_baseline(cfg, budget_s=20.0):
     aux = np.full(len(x), orc.initial_aux(cfg["material"]), np.float32)
     s = orc.State(x, None, None, None, aux, None, gp[None], np.array([t], np.int32))
     ocfg = orc.make_config(res, dx, 1e-4, planes=[(0, 1, 0, -0.1)], friction=-1.0)
-    threads = os.cpu_count() or 1
-    orc.opt_run(ocfg, s, 1, threads)  # warm-up (page faults, first sort)
+    n = len(x)
+    hw = os.cpu_count() or 1
+    orc.opt_run(ocfg, s, 1, min(hw, 16))  # warm-up (page faults, first sort)
+    sweep = {}
+    for th in sorted({1, 8, 16, 32, 64, hw}):
+        if th > hw:
+            continue
+        sec, _ = orc.opt_run(ocfg, s, 1, th)
+        sweep[th] = n / sec
+        if sec > budget_s / 4:
+            break
+    threads = max(sweep, key=sweep.get)
     steps, total, phases = 0, 0.0, np.zeros(4)
     t0 = time.time()
-    while total < budget_s and steps < 50 and time.time() - t0 < 3 * budget_s:
+    while total < budget_s / 2 and steps < 40 and time.time() - t0 < 2 * budget_s:
         sec, ph = orc.opt_run(ocfg, s, 2, threads)
         total += sec; steps += 2; phases += np.array(ph)
-    n = len(x)
     return {"value": n * steps / total, "unit": "particle-steps/s", "cores": threads, "kind": "port",
-            "sample": "%d^3 cells x 8 = %d %s particles on the %d^3 grid, %d substeps, all %d host threads (OpenMP); "
-                      "block-sorted 8-colour restatement of rasterize_optimized/resample_optimized, not the reference binary"
-                      % (cells, n, cfg["material"], res, steps, threads),
+            "sample": "%d^3 cells x 8 = %d %s particles on the %d^3 grid, %d substeps, %d OpenMP threads (best of a "
+                      "sweep on a %d-thread host); block-sorted 8-colour restatement of rasterize_optimized/"
+                      "resample_optimized, not the reference binary" % (cells, n, cfg["material"], res, steps, threads, hw),
+            "thread_sweep_particle_steps_per_s": {str(k): v for k, v in sweep.items()},
             "p2g_ns_per_particle": 1e9 * phases[1] / (n * steps), "g2p_ns_per_particle": 1e9 * phases[3] / (n * steps),
             "sort_ns_per_particle": 1e9 * phases[0] / (n * steps)}
+
+
+def pmc_traffic(config_name, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary of this workload (profiles/), or None"""
+    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % config_name)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return float(d["kernels"][kernel]["hbm_bytes_per_launch"]), d.get("source")
+    except Exception:
+        return None, None
 
 
 def main():
@@ -106,7 +135,13 @@ def main():
     n_local = job.num_particles()
     job.run(args.warmup)
     job.synchronize()
-    job.set_profiling(True)
+    # untimed pass, every phase bracketed: phase table + which transfer kernel dominates
+    job.set_profiling(1)
+    job.run(min(10, max(args.steps, 1)))
+    phase_prof = job.profile()
+    pms = {k: v / max(phase_prof["substeps"], 1) for k, v in phase_prof["phases"].items()}
+    dom = "g2p" if pms["g2p"] >= pms["p2g"] else "p2g"
+    job.set_profiling(2 if dom == "g2p" else 3)  # timed region: only the dominant kernel is bracketed
 
     def barrier():
         if world > 1:
@@ -134,14 +169,15 @@ def main():
             dist.destroy_process_group()
         return
 
-    ms = {k: v / max(prof["substeps"], 1) for k, v in prof["phases"].items()}
+    ms = dict(pms)  # phase table from the untimed pass ...
+    ms[dom] = prof["phases"][dom] / max(prof["substeps"], 1)  # ... dominant kernel from the timed region itself
     n_per_gpu = prof["particles"]
     nodes = prof["active_blocks"] * 64.0  # touched 4^3 blocks x 64 nodes (upper bound of touched nodes)
     per_launch = {"p2g": n_per_gpu * 100.0 + nodes * 16.0, "g2p": n_per_gpu * 152.0 + nodes * 16.0}
-    dom = max(("p2g", "g2p"), key=lambda k: ms[k])
     achieved = per_launch[dom] / (ms[dom] * 1e-3) / 1e9
     value = n_total * args.steps / elapsed
     whole_step_bytes = n_per_gpu * 252.0 + nodes * 16.0 * 5
+    tbytes, tsrc = pmc_traffic(args.config, "k_" + dom) if world == 1 else (None, None)
     out = {
         "metric": "particle-steps/sec (P2G+grid+G2P), 256^3 grid 8M particles; %HBM roofline",
         "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -150,11 +186,14 @@ def main():
         "config": {"workload": cfg["desc"], "particles": n_total, "dt": 1e-4, "parallelism": job.parallelism,
                    "timed": "full substep: sort+reorder, P2G, grid normalise+boundary, G2P, boundary cleanup"},
         "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": (tbytes / (ms[dom] * 1e-3) / 1e9) if tbytes else None,
+                     "traffic_bytes_per_launch": tbytes, "traffic_source": tsrc,
                      "algorithmic_bytes_per_launch": per_launch[dom], "avg_launch_ms": ms[dom]},
         "phases_ms_per_step": ms,
         "p2g_plus_g2p_particle_steps_per_s": n_per_gpu / ((ms["p2g"] + ms["g2p"]) * 1e-3),
-        "whole_step_hbm_frac_algorithmic": whole_step_bytes / (1e-3 * sum(ms.values())) / 1e9 / HBM_PEAK_GBS,
+        "p2g_plus_g2p_hbm_frac_algorithmic": (per_launch["p2g"] + per_launch["g2p"]) / ((ms["p2g"] + ms["g2p"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "whole_step_hbm_frac_algorithmic": whole_step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
     }
     if world == 1 and not args.no_cpu_baseline:
         try:

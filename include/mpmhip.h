@@ -86,7 +86,10 @@ typedef struct {
   int32_t reorder_interval; /* "reorder_interval" (src/mpm.cpp:45,811-813): physical reorder of the particle records
                                into sorted order every this many substeps; 0 = never (the sorted INDEX is rebuilt
                                every substep regardless) */
-  int32_t discard_apic_b;   /* 1 = do not keep apic_b (it is folded into the P2G affine matrix); download(B) then fails */
+  int32_t discard_apic_b;   /* 1 = G2P does not store apic_b: it lives on folded into the P2G affine matrix
+                               A = stress*(-4 inv_dx dt) + apic_b*(4 m) (src/transfer.cpp:521-522), which is the state
+                               the next substep consumes (-48 of 180 stored bytes per particle-step).  download(B)
+                               then recovers apic_b = (A - stress(F) S)/(4 m) on demand, to ~1e-5..1e-4 relative */
   int32_t reserved[5];
 } mpmhip_config;
 
@@ -142,10 +145,13 @@ int mpmhip_download_grid(mpmhip_ctx *ctx, int32_t which, float *dst);
 int mpmhip_upload_grid(mpmhip_ctx *ctx, const float *src);
 
 /* profiling — replaces TC_PROFILE / TC_PROFILE_TPE scoped timers (src/mpm.cpp:464-572).
- * When enabled, hipEvents bracket each phase of every substep on the ctx stream.
+ * level 0: off.  level 1: hipEvents bracket each phase of every substep on the ctx stream (six records per
+ * substep; each record costs ~5 us of idle GPU).  level 2 / 3: only k_g2p / only k_p2g is bracketed (two records),
+ * for timing the dominant kernel inside a throughput measurement.
  * mpmhip_profile writes a JSON object: {"substeps":N,"particles":n,"active_blocks":a,
- *   "phases":{"sort":ms,"p2g":ms,"grid":ms,"g2p":ms}}  (totals since the last reset). */
-int mpmhip_set_profiling(mpmhip_ctx *ctx, int32_t enabled);
+ *   "phases":{"sort":ms,"p2g":ms,"exchange":ms,"grid":ms,"g2p":ms}}  (totals since the last reset; "exchange" is
+ *   the gap between substep_begin and substep_end of a tiled run; phases not bracketed at the level stay 0). */
+int mpmhip_set_profiling(mpmhip_ctx *ctx, int32_t level);
 int mpmhip_profile(mpmhip_ctx *ctx, char *json, size_t cap);
 int mpmhip_profile_reset(mpmhip_ctx *ctx);
 

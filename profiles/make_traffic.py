@@ -1,0 +1,34 @@
+"""HBM traffic per launch of the transfer kernels from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE).
+
+    python profiles/make_traffic.py <pmc_fetch>/p_counter_collection.csv <pmc_write>/p_counter_collection.csv > traffic_c3.json
+
+Units and gfx950 correction (MI355X_MICROARCH.md, "HBM"): both counters are in KiB; on gfx950 FETCH_SIZE reports
+half of the bytes of wide (16 B/lane) reads, so reads = FETCH_SIZE * 1024 * 2; WRITE_SIZE is taken as is
+(for k_g2p it matches the bytes the kernel stores: 180 B per particle)."""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def means(path, counter):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"].split("(")[0].replace("void ", "").replace("mpm::", "").split("<")[0]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def main(fetch_csv, write_csv):
+    f, w = means(fetch_csv, "FETCH_SIZE"), means(write_csv, "WRITE_SIZE")
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean over dispatches; "
+                     "reads = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), writes = WRITE_SIZE KiB x 1024",
+           "kernels": {}}
+    for k in sorted(set(f) & set(w)):
+        rd, wr = f[k] * 1024 * 2, w[k] * 1024
+        out["kernels"][k] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:3])

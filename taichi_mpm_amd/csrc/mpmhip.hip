@@ -468,6 +468,27 @@ __global__ __launch_bounds__(256) void k_affine(Params P, const RecG *__restrict
   }
 }
 
+// inverse of k_affine for ctxs that fold apic_b into A (discard_apic_b): apic_b = (A - stress * S) / (4 m),
+// written to the side array.  Runs only when somebody asks for apic_b (download, upload of F/aux, new particles).
+// Accuracy: the stress is re-evaluated from the stored (F, aux) by calculate_force(), not by the fused G2P path
+// that produced A, so apic_b comes back to ~1e-6 * |stress S| / (4 m) absolute — 1e-5..1e-4 relative in practice.
+__global__ __launch_bounds__(256) void k_recover_b(Params P, const RecG *__restrict__ rg, const RecP *__restrict__ rp,
+                                                   float *__restrict__ rb, const GroupParams *__restrict__ groups) {
+  const float S = -4.0f * P.idx * P.dt;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_slots; i += gridDim.x * blockDim.x) {
+    const RecG r = rg[i];
+    if (r.pid < 0) continue;
+    const GroupParams g = groups[r.gid];
+    mat3 F;
+#pragma unroll
+    for (int k = 0; k < 9; k++) F.m[k] = r.F[k];
+    const mat3 stress = calculate_force(g, F, r.aux);
+    const float im4 = 1.0f / (4.0f * g.p[0]);
+#pragma unroll
+    for (int k = 0; k < 9; k++) rb[(size_t)i * BW + k] = fmaf(-stress.m[k], S, rp[i].A[k]) * im4;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ P2G
 // rasterize_optimized / block_op_normal (src/transfer.cpp:467-569).
 // Mapping: ONE LANE PER CELL of an active 4^3-cell block.  The sorted index lists the particles of each cell
@@ -1145,6 +1166,7 @@ struct mpmhip_ctx {
   bool sorted = false;        // perm / cell_start describe the current positions
   bool keys_valid = false;    // key[] + block flags describe the current positions (set by k_g2p)
   bool affine_valid = false;  // RecP.A matches (F, aux, apic_b)
+  bool b_stale = false;       // discard_apic_b: the side array is behind RecP.A (k_g2p did not write it)
   int p2g_wgs = 16384;        // workgroups of k_p2g (env MPMHIP_P2G_WGS)
   int p2g_split = 11;         // tuning knob (env MPMHIP_P2G_SPLIT): 10*NS + PS, see do_p2g
   int g2p_minw = 13;          // tuning knob (env MPMHIP_G2P_MINW): __launch_bounds__ waves/SIMD of k_g2p
@@ -1152,12 +1174,13 @@ struct mpmhip_ctx {
   float t = 0.0f, request_t = 0.0f;  // `real` accumulators, as in the reference (src/mpm.h:99, mpm.cpp:573)
   int64_t substeps = 0;
   // profiling
-  bool profiling = false;
+  int profiling = 0;  // 0 off, 1 every phase, 2 only G2P, 3 only P2G (two events per substep instead of six)
   struct Ev { hipEvent_t e[PH_COUNT + 1]; };
   std::vector<Ev> ev_pool;
   size_t ev_used = 0;
   double phase_ms[PH_COUNT] = {0, 0, 0, 0, 0};
   int64_t prof_substeps = 0;
+  int ev_level = 0;  // level the pooled events were recorded with
   Ev *cur_ev = nullptr;  // events of the substep between substep_begin and substep_end
   // tiling
   Tiling T;
@@ -1374,6 +1397,19 @@ static int read_counters(mpmhip_ctx *c, Counters &h) {
   return MPMHIP_OK;
 }
 
+// discard_apic_b: bring the apic_b side array up to date from RecP.A before anybody reads it or invalidates A
+static int ensure_b_current(mpmhip_ctx *c) {
+  if (!c->b_stale) return MPMHIP_OK;
+  if (!c->affine_valid) return fail(c, MPMHIP_EINVAL, "internal: apic_b is stale and the affine matrices are invalid");
+  hipLaunchKernelGGL(k_recover_b, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, (const RecG *)c->rg,
+                     (const RecP *)c->rp, c->rb, (const GroupParams *)c->d_groups);
+  int rc = launch_check(c, "recover_b");
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->b_stale = false;
+  return MPMHIP_OK;
+}
+
 int mpmhip_add_particles(mpmhip_ctx *c, int32_t group, int64_t n, const float *x, const float *v, const float *F,
                          const float *B, const float *aux) {
   if (!c || n < 0 || (n > 0 && !x)) return MPMHIP_EINVAL;
@@ -1383,6 +1419,7 @@ int mpmhip_add_particles(mpmhip_ctx *c, int32_t group, int64_t n, const float *x
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->n_slots + n > c->cap)
     return fail(c, MPMHIP_ECAPACITY, "particle capacity exceeded: %lld + %lld > %lld", (long long)c->n_slots, (long long)n, (long long)c->cap);
+  if (int rc = ensure_b_current(c)) return rc;  // A of every particle is recomputed from apic_b below
   const int mat = c->groups[group].type;
   const float aux0 = (mat == MPMHIP_SNOW || mat == MPMHIP_WATER) ? 1.0f : 0.0f;  // Jp = 1 (:204), j = 1 (:460), logJp = 0 (:595)
   std::vector<RecG> hg((size_t)n);
@@ -1439,8 +1476,8 @@ int mpmhip_download(mpmhip_ctx *c, int32_t field, void *dst, int64_t n_capacity)
   if (!c || !dst) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   if (field < MPMHIP_F_X || field > MPMHIP_F_ID) return fail(c, MPMHIP_EINVAL, "unknown field %d", field);
-  if (field == MPMHIP_F_B && !c->P.store_b)
-    return fail(c, MPMHIP_EINVAL, "apic_b is not kept (ctx created with discard_apic_b)");
+  if (field == MPMHIP_F_B)
+    if (int rc = ensure_b_current(c)) return rc;
   std::vector<RecG> hg;
   std::vector<RecP> hp;
   std::vector<float> hb;
@@ -1474,8 +1511,9 @@ int mpmhip_upload(mpmhip_ctx *c, int32_t field, const void *src, int64_t n) {
   std::vector<RecG> hg;
   std::vector<RecP> hp;
   std::vector<float> hb;
-  int rc = fetch_records(c, hg, &hp, &hb);
+  int rc = ensure_b_current(c);
   if (rc) return rc;
+  if ((rc = fetch_records(c, hg, &hp, &hb))) return rc;
   int64_t live = 0;
   for (auto &g : hg) live += g.pid >= 0;
   if (n != live) return fail(c, MPMHIP_EINVAL, "upload of %lld records but the ctx holds %lld particles", (long long)n, (long long)live);
@@ -1603,6 +1641,7 @@ static int do_g2p(mpmhip_ctx *c) {
   c->sorted = false;       // positions moved
   c->keys_valid = true;    // ... and their keys / block flags are ready for the next sort
   c->affine_valid = true;  // A was produced together with F
+  if (!c->P.store_b) c->b_stale = true;
   return launch_check(c, "g2p");
 }
 
@@ -1650,6 +1689,7 @@ static int collect_events(mpmhip_ctx *c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (size_t i = 0; i < c->ev_used; i++) {
     for (int k = 0; k < PH_COUNT; k++) {
+      if ((c->ev_level == 2 && k != PH_G2P) || (c->ev_level == 3 && k != PH_P2G)) continue;
       float ms = 0;
       HIPCHK(c, hipEventElapsedTime(&ms, c->ev_pool[i].e[k], c->ev_pool[i].e[k + 1]));
       c->phase_ms[k] += ms;
@@ -1675,16 +1715,18 @@ int mpmhip_substep_begin(mpmhip_ctx *c) {  // sort, P2G, halo pack
   if (c->cur_ev) return fail(c, MPMHIP_EINVAL, "substep_begin called twice without substep_end");
   int rc;
   mpmhip_ctx::Ev *ev = nullptr;
-  if (c->profiling) {
+  const int lvl = c->profiling;
+  if (lvl) {
     if (c->ev_used >= 4096 && (rc = collect_events(c))) return rc;
     if ((rc = get_events(c, &ev))) return rc;
-    HIPCHK(c, hipEventRecord(ev->e[0], c->stream));
+    if (lvl == 1) HIPCHK(c, hipEventRecord(ev->e[0], c->stream));
   }
   if ((rc = do_sort(c))) return rc;
-  if (ev) HIPCHK(c, hipEventRecord(ev->e[1], c->stream));
+  if (ev && (lvl == 1 || lvl == 3)) HIPCHK(c, hipEventRecord(ev->e[1], c->stream));
   if ((rc = do_p2g(c))) return rc;
+  if (ev && lvl == 3) HIPCHK(c, hipEventRecord(ev->e[2], c->stream));
   if ((rc = do_halo_pack(c))) return rc;
-  if (ev) HIPCHK(c, hipEventRecord(ev->e[2], c->stream));
+  if (ev && lvl == 1) HIPCHK(c, hipEventRecord(ev->e[2], c->stream));
   c->cur_ev = ev;
   c->in_substep = true;
   return MPMHIP_OK;
@@ -1698,11 +1740,12 @@ int mpmhip_substep_end(mpmhip_ctx *c) {  // grid (+ halo sum), G2P
   mpmhip_ctx::Ev *ev = c->cur_ev;
   c->cur_ev = nullptr;
   c->in_substep = false;
-  if (ev) HIPCHK(c, hipEventRecord(ev->e[3], c->stream));
+  const int lvl = c->profiling;
+  if (ev && lvl == 1) HIPCHK(c, hipEventRecord(ev->e[3], c->stream));
   if ((rc = do_grid(c, 0))) return rc;
-  if (ev) HIPCHK(c, hipEventRecord(ev->e[4], c->stream));
+  if (ev && (lvl == 1 || lvl == 2)) HIPCHK(c, hipEventRecord(ev->e[4], c->stream));
   if ((rc = do_g2p(c))) return rc;
-  if (ev) HIPCHK(c, hipEventRecord(ev->e[5], c->stream));
+  if (ev && (lvl == 1 || lvl == 2)) HIPCHK(c, hipEventRecord(ev->e[5], c->stream));
   c->t += c->P.dt;  // src/mpm.cpp:573
   c->substeps++;
   return MPMHIP_OK;
@@ -1781,10 +1824,14 @@ int mpmhip_upload_grid(mpmhip_ctx *c, const float *src) {
   return do_grid(c, 2);
 }
 
-int mpmhip_set_profiling(mpmhip_ctx *c, int32_t enabled) {
-  if (!c) return MPMHIP_EINVAL;
-  c->profiling = enabled != 0;
-  return MPMHIP_OK;
+int mpmhip_set_profiling(mpmhip_ctx *c, int32_t level) {
+  if (!c || level < 0 || level > 3) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->in_substep) return fail(c, MPMHIP_EINVAL, "set_profiling inside a substep");
+  int rc = collect_events(c);  // pending events belong to the old level
+  c->profiling = level;
+  c->ev_level = level;
+  return rc;
 }
 int mpmhip_profile_reset(mpmhip_ctx *c) {
   if (!c) return MPMHIP_EINVAL;

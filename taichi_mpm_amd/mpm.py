@@ -99,7 +99,10 @@ class Simulation3D:
         self.rpic_damping = float(cfg.get("rpic_damping", 0.0))
         self.clean_boundary = bool(cfg.get("clean_boundary", True))
         self.reorder_interval = int(cfg.get("reorder_interval", 1000))  # src/mpm.cpp:45
-        self.discard_apic_b = bool(cfg.get("discard_apic_b", False))
+        # apic_b is only ever consumed through the P2G affine matrix A, which is stored; keeping a separate copy
+        # costs 48 of the 180 bytes G2P writes per particle.  keep_apic_b=True stores it (exact downloads of B);
+        # otherwise download recovers it from A on demand (include/mpmhip.h: discard_apic_b).
+        self.discard_apic_b = not bool(cfg.get("keep_apic_b", False))
         self.max_particles = int(cfg.get("max_particles", 0))
         self.max_blocks = int(cfg.get("max_blocks", 0))
         self.device = int(cfg.get("device", 0))
@@ -350,8 +353,9 @@ class Simulation3D:
         self._check(self._L.mpmhip_upload(self._ctx, field, a.ctypes.data_as(C.c_void_p), len(a)))
 
     # ---------------------------------------------------------------- profiling (TC_PROFILE, src/mpm.cpp:464-572)
-    def set_profiling(self, on=True):
-        self._ensure_ctx(); self._check(self._L.mpmhip_set_profiling(self._ctx, int(on)))
+    def set_profiling(self, level=1):
+        """0 off, 1 every phase, 2 only G2P, 3 only P2G (include/mpmhip.h)"""
+        self._ensure_ctx(); self._check(self._L.mpmhip_set_profiling(self._ctx, int(level)))
 
     def profile(self, reset=False):
         self._ensure_ctx()

@@ -297,8 +297,8 @@ class TiledJob:
     def synchronize(self):
         self.e.synchronize()
 
-    def set_profiling(self, on):
-        self.e.sim.set_profiling(on)
+    def set_profiling(self, level):
+        self.e.sim.set_profiling(level)
         self.e.sim.profile(reset=True)
 
     def profile(self):

@@ -21,8 +21,8 @@ class SingleJob:
     def synchronize(self):
         self.sim.synchronize()
 
-    def set_profiling(self, on):
-        self.sim.set_profiling(on)
+    def set_profiling(self, level):
+        self.sim.set_profiling(level)
         self.sim.profile(reset=True)
 
     def profile(self):

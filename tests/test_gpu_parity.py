@@ -31,6 +31,7 @@ def tm():
 
 
 def make_sim(tm, state, planes=PLANES, friction=0.4, res=RES, dx=DX, dt=DT, **cfg):
+    """default ctx mode: apic_b folded into the P2G affine matrix (keep_apic_b=True stores it exactly)"""
     sim = tm.create_simulation3("mpm")
     sim.initialize(dict(res=(res,) * 3, delta_x=dx, base_delta_t=dt, **cfg))
     if planes:
@@ -178,14 +179,17 @@ def test_p2g_and_grid_update_match_oracle(tm, orc, mat):
     sim.close()
 
 
+@pytest.mark.parametrize("keep", [True, False], ids=["apic_b_stored", "apic_b_folded"])
 @pytest.mark.parametrize("mat", MATS)
-def test_g2p_from_identical_grid_matches_oracle(tm, orc, mat):
+def test_g2p_from_identical_grid_matches_oracle(tm, orc, mat, keep):
+    """keep=False is the default ctx mode: G2P does not store apic_b; the download recovers it from the P2G affine
+    matrix (A - stress S)/(4 m), hence the looser bound on B in that mode."""
     x = lattice_cube(RES, 9, 17, DX, jitter=0.2, seed=6)
     s = make_state(x, mat, DX, perturb_F=0.02, seed=7)
     cfg = ocfg(orc)
     ref = s.copy()
     grid = orc.grid_update(cfg, orc.p2g(cfg, ref))
-    sim = make_sim(tm, s)
+    sim = make_sim(tm, s, keep_apic_b=keep)
     sim.sort_particles_and_populate_grid()
     sim.rasterize_optimized()                       # builds the tile / owner structure
     sim.normalize_grid_and_apply_boundary_conditions()
@@ -195,7 +199,7 @@ def test_g2p_from_identical_grid_matches_oracle(tm, orc, mat):
     orc.g2p(cfg, ref, grid)
     assert np.abs(got["x"] - ref.x).max() <= 1e-7
     assert rel_l2(got["v"], ref.v) <= 1e-5
-    assert rel_l2(got["B"], ref.B) <= 1e-5
+    assert rel_l2(got["B"], ref.B) <= (1e-5 if keep else 3e-4)
     assert rel_l2(got["F"], ref.F) <= F_TOL.get(mat, 1e-5)
     assert np.abs(got["aux"] - ref.aux).max() <= 2e-5
     sim.close()
