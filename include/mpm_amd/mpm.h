@@ -1,0 +1,218 @@
+// include/mpm_amd/mpm.h — `MPM<3>`: the reference's simulation class (src/mpm.h:56-489, src/mpm.cpp) as a thin
+// C++ host layer over the C ABI of libmpmhip (include/mpmhip.h).  Same method names and semantics as the
+// reference's `Simulation3D` implementation registered as "mpm" (src/mpm.cpp:983-988):
+//   initialize(Config)            src/mpm.cpp:26-75     add_particles(Config) -> std::string   :77-270
+//   step(real dt)                 :428-439              substep()                                :452-575
+//   get_current_time()            src/mpm.h:99          general_action(Config) -> std::string   :920-978
+//   sort_particles_and_populate_grid / rasterize_optimized / normalize_grid_and_apply_external_force +
+//   apply_grid_boundary_conditions / resample_optimized: the phase functions, one C-ABI call each.
+// All device work happens in the HIP kernels behind the ABI; this header holds no numerics.  Errors throw
+// std::runtime_error with the library's message (reference: TC_ASSERT / TC_ERROR abort).
+// Out of scope, as in DESIGN.md §7: rigid bodies, textures/meshes in add_particles, dynamic level sets, rendering.
+#pragma once
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../mpmhip.h"
+#include "kernel.h"
+#include "particles.h"
+
+namespace mpm_amd {
+
+struct RenderParticle {  // what get_render_particles() hands to a renderer (src/visualize.cpp:102-154)
+  Vector3 position, velocity;
+  int32_t id;
+};
+
+template <int dim>
+class MPM;
+
+template <>
+class MPM<3> {
+ public:
+  static constexpr int D = 3;
+  using Vector = Vector3;
+  using VectorI = Vector3i;
+
+  MPM() = default;
+  MPM(const MPM &) = delete;
+  MPM &operator=(const MPM &) = delete;
+  ~MPM() { if (ctx_) mpmhip_destroy(ctx_); }
+
+  // --- MPM<dim>::initialize (src/mpm.cpp:26-75; config keys README.md:234-256)
+  void initialize(const Config &config) {
+    if (config.has_key("delta_t")) throw std::runtime_error("Please use 'base_delta_t' instead of 'delta_t'");  // :41-42
+    res = config.get_vec("res", VectorI(0, 0, 0));
+    if (res[0] <= 0) throw std::runtime_error("config key 'res' is required");
+    delta_x = config.get("delta_x", 1.0f / res[0]);
+    base_delta_t = config.get("base_delta_t", 1e-4f) * config.get("dt_multiplier", 1.0f);
+    cfg_ = mpmhip_config{};
+    for (int k = 0; k < 3; k++) cfg_.res[k] = res[k];
+    cfg_.dx = delta_x;
+    cfg_.dt = base_delta_t;
+    const Vector g = config.get_vec("gravity", Vector(0.0f, -10.0f, 0.0f));
+    for (int k = 0; k < 3; k++) cfg_.gravity[k] = g[k];
+    cfg_.particle_gravity = config.get("particle_gravity", true);  // :47
+    cfg_.apic_damping = config.get("apic_damping", 0.0f);
+    cfg_.rpic_damping = config.get("rpic_damping", 0.0f);
+    cfg_.clean_boundary = config.get("clean_boundary", true);
+    cfg_.reorder_interval = config.get("reorder_interval", 1000);  // :45
+    cfg_.max_particles = (int64_t)config.get("max_particles", (double)(1 << 25));  // :773-775
+    cfg_.max_blocks = (int64_t)config.get("max_blocks", 0.0);
+    cfg_.device = config.get("device", 0);
+    cfg_.discard_apic_b = !config.get("keep_apic_b", false);
+    check(mpmhip_create(&cfg_, &ctx_), nullptr);
+    frame = 0;
+  }
+
+  // --- analytic level set (set_levelset(DynamicLevelSet) of the reference, for half-spaces): phi = n.x + d
+  void set_levelset(const std::vector<Vector4> &planes, real friction) {
+    std::vector<float> flat;
+    for (auto &p : planes) flat.insert(flat.end(), p.begin(), p.end());
+    check(mpmhip_set_levelset(ctx_, (int32_t)planes.size(), flat.data(), friction), ctx_);
+  }
+
+  // --- MPM<dim>::add_particles (src/mpm.cpp:77-270).  Sampling: the built-in benchmark generator
+  // ("benchmark" = 125 | 8000, :149-186), a lattice "cube_lo"/"cube_hi" in cells, or explicit arrays through
+  // the overload below.  Returns "" (the reference returns a rigid-body id only for type "rigid").
+  std::string add_particles(const Config &config) {
+    std::vector<float> x;
+    float maximum = config.get("ppc", config.get("maximum", 8.0f));
+    if (config.get("benchmark", 0)) {
+      const int b = config.get("benchmark", 0);
+      float s;
+      if (b == 125) s = 0.1f;
+      else if (b == 8000) s = 0.4f;
+      else throw std::runtime_error("s must be 125 or 8000");  // :162
+      const int lower = (int)std::lround(res[0] * (0.5f - s)), higher = lower + (int)std::lround(res[0] * 2 * s);
+      lattice(lower, higher, x);
+      maximum = 1.0f;  // create_particle(..., 1, config): vol = dx^3 (:178)
+    } else if (config.has_key("cube_lo")) {
+      lattice(config.get("cube_lo", 0), config.get("cube_hi", 0), x);
+    } else {
+      throw std::runtime_error("add_particles(Config) needs 'benchmark' or 'cube_lo'/'cube_hi'; pass sampled positions "
+                               "to add_particles(config, n, x, v)");
+    }
+    return add_particles(config, (int64_t)x.size() / 3, x.data(), nullptr, maximum);
+  }
+
+  std::string add_particles(const Config &config, int64_t n, const float *x, const float *v, float maximum = 0) {
+    const std::string type = config.get("type", "");
+    if (type == "rigid") throw std::runtime_error("type='rigid' (CPIC rigid coupling) is outside the scope of this build");
+    if (maximum <= 0) maximum = config.get("ppc", config.get("maximum", 8.0f));
+    const float vol = delta_x * delta_x * delta_x / maximum;  // :134-135
+    const float mass = vol * config.get("density", 400.0f);
+    const ParticleType t = create_particle_type(type, config, mass, vol);
+    const int gid = mpmhip_add_group(ctx_, t.material, t.params);
+    check(gid, ctx_);
+    // "particle out of box or near boundary. Ignored." (:129-132, src/mpm.h:269-276)
+    std::vector<float> xs, vs, Fs, auxs;
+    const Vector v0 = config.get_vec("initial_velocity", Vector(0.0f, 0.0f, 0.0f));
+    for (int64_t i = 0; i < n; i++) {
+      bool near = false;
+      for (int k = 0; k < 3; k++) {
+        const float X = x[3 * i + k] / delta_x;
+        near = near || X < 7.0f || X - res[k] > -7.0f;
+      }
+      if (near) continue;
+      for (int k = 0; k < 3; k++) {
+        xs.push_back(x[3 * i + k]);
+        vs.push_back(v ? v[3 * i + k] : v0[k]);
+      }
+      for (int k = 0; k < 9; k++) Fs.push_back(k % 4 == 0 ? t.initial_dg : 0.0f);
+      auxs.push_back(t.initial_aux);
+    }
+    const int64_t m = (int64_t)auxs.size();
+    if (m) check(mpmhip_add_particles(ctx_, gid, m, xs.data(), vs.data(), Fs.data(), nullptr, auxs.data()), ctx_);
+    types_.push_back(t);
+    return "";
+  }
+
+  // --- time stepping
+  void step(real dt) { check(mpmhip_step(ctx_, dt), ctx_); frame++; }  // src/mpm.cpp:428-439 (dt < 0: one substep)
+  void substep() { check(mpmhip_substep(ctx_), ctx_); }              // :452-575
+  real get_current_time() const { return (real)mpmhip_current_time(ctx_); }
+  void synchronize() { check(mpmhip_synchronize(ctx_), ctx_); }
+
+  // --- the phases of substep(), under the reference's names
+  void sort_particles_and_populate_grid() { check(mpmhip_sort(ctx_), ctx_); }        // src/mpm.cpp:770-918
+  void rasterize_optimized() { check(mpmhip_p2g(ctx_), ctx_); }                      // src/transfer.cpp:361-581
+  void normalize_grid_and_apply_external_force() { check(mpmhip_grid_update(ctx_), ctx_); }  // src/mpm.cpp:277-294 (+ :296-372)
+  void apply_grid_boundary_conditions() {}  // fused into the grid kernel above (src/mpm.cpp:296-372)
+  void resample_optimized() { check(mpmhip_g2p(ctx_), ctx_); }                       // src/transfer.cpp:702-970
+
+  int64_t get_num_particles() const { const int64_t n = mpmhip_num_particles(ctx_); check((int)std::min<int64_t>(n, 0), ctx_); return n; }
+
+  std::vector<RenderParticle> get_render_particles() const {
+    const int64_t n = get_num_particles();
+    std::vector<float> x(3 * n), v(3 * n);
+    std::vector<int32_t> id(n);
+    check(mpmhip_download(ctx_, MPMHIP_F_X, x.data(), n), ctx_);
+    check(mpmhip_download(ctx_, MPMHIP_F_V, v.data(), n), ctx_);
+    check(mpmhip_download(ctx_, MPMHIP_F_ID, id.data(), n), ctx_);
+    std::vector<RenderParticle> out(n);
+    for (int64_t i = 0; i < n; i++) {
+      out[i].position = Vector(x[3 * i], x[3 * i + 1], x[3 * i + 2]);
+      out[i].velocity = Vector(v[3 * i], v[3 * i + 1], v[3 * i + 2]);
+      out[i].id = id[i];
+    }
+    return out;
+  }
+
+  // --- MPM<dim>::general_action (src/mpm.cpp:920-978): the actions that only need the hot path's state
+  std::string general_action(const Config &config) {
+    const std::string action = config.get("action", "");
+    if (action == "calculate_energy") {  // kinetic part of :1078-1110
+      const int64_t n = get_num_particles();
+      std::vector<float> v(3 * n);
+      std::vector<int32_t> gid(n);
+      check(mpmhip_download(ctx_, MPMHIP_F_V, v.data(), n), ctx_);
+      check(mpmhip_download(ctx_, MPMHIP_F_GID, gid.data(), n), ctx_);
+      double e = 0;
+      for (int64_t i = 0; i < n; i++)
+        e += 0.5 * types_[gid[i]].params[0] * ((double)v[3 * i] * v[3 * i] + (double)v[3 * i + 1] * v[3 * i + 1] + (double)v[3 * i + 2] * v[3 * i + 2]);
+      return std::to_string(e);
+    }
+    throw std::runtime_error("general_action(action='" + action + "') is outside the scope of this build");
+  }
+
+  bool test() const { return true; }                          // src/mpm.cpp:577-580
+  std::string get_debug_information() const { return ""; }    // :635-639
+  std::string get_name() const { return "mpm"; }              // src/mpm.h:486-488
+  mpmhip_ctx *ctx() const { return ctx_; }
+
+  VectorI res;
+  real delta_x = 0, base_delta_t = 0;
+  int frame = 0;
+
+ private:
+  void lattice(int lower, int higher, std::vector<float> &x) const {  // src/mpm.cpp:164-180: cell centre +- 0.25 dx
+    for (int i = lower; i < higher; i++)
+      for (int j = lower; j < higher; j++)
+        for (int k = lower; k < higher; k++)
+          for (int s = 0; s < 8; s++) {
+            x.push_back((i + 0.5f + ((s & 1) ? 0.25f : -0.25f)) * delta_x);
+            x.push_back((j + 0.5f + ((s & 2) ? 0.25f : -0.25f)) * delta_x);
+            x.push_back((k + 0.5f + ((s & 4) ? 0.25f : -0.25f)) * delta_x);
+          }
+  }
+  static void check(int rc, const mpmhip_ctx *c) {
+    if (rc < 0) throw std::runtime_error(std::string("libmpmhip error ") + std::to_string(rc) + ": " + mpmhip_last_error(c));
+  }
+  mpmhip_ctx *ctx_ = nullptr;
+  mpmhip_config cfg_{};
+  std::vector<ParticleType> types_;
+};
+
+using MPM3D = MPM<3>;
+
+// the factory the reference reaches through `create_instance<Simulation3D>("mpm")` (src/mpm.cpp:983-988)
+inline std::unique_ptr<MPM3D> create_simulation3(const std::string &name) {
+  if (name != "mpm") throw std::runtime_error("no Simulation3D implementation named '" + name + "' (registered: 'mpm')");
+  return std::make_unique<MPM3D>();
+}
+
+}  // namespace mpm_amd

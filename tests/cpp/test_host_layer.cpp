@@ -1,0 +1,155 @@
+// tests/cpp/test_host_layer.cpp — the C++ host layer (include/mpm_amd/{kernel,particles,mpm}.h) over libmpmhip.
+//   ./test_host_layer cpu   kernel known-answer tests of the reference (src/tests.cpp:13-51: sum w = 1, sum dw = 0,
+//                           fast == slow kernel to 1e-6; src/transfer.cpp:975-989), Config, the particle registry,
+//                           and "no GPU => initialize() throws" (no CPU fallback)
+//   ./test_host_layer gpu   MPM<3> end to end on a device: benchmark particles, step(), phases, energy, device
+//                           constitutive calls through MPMParticle
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+
+#include "mpm_amd/mpm.h"
+
+using namespace mpm_amd;
+
+static int failures = 0;
+#define CHECK(cond)                                                             \
+  do {                                                                          \
+    if (!(cond)) { std::printf("CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond); failures++; } \
+  } while (0)
+
+template <int dim, int order>
+static void test_kernel(std::mt19937 &rng) {  // src/tests.cpp:13-26
+  std::uniform_real_distribution<float> U(0.0f, 10.0f);
+  for (int l = 0; l < 100; l++) {
+    VectorND<dim, real> pos;
+    for (int a = 0; a < dim; a++) pos[a] = U(rng);
+    MPMKernel<dim, order> kernel(pos, 1.0f);
+    for (int j = 0; j < dim; j++) {
+      CHECK(std::fabs(kernel.w_cache[j].sum() - 1.0f) < 1e-5f);
+      CHECK(std::fabs(kernel.dw_cache[j].sum()) < 1e-5f);
+    }
+  }
+}
+
+static void cpu_tests() {
+  std::mt19937 rng(88);
+  test_kernel<2, 3>(rng); test_kernel<2, 2>(rng); test_kernel<3, 3>(rng); test_kernel<3, 2>(rng); test_kernel<3, 1>(rng);
+  std::uniform_real_distribution<float> U(0.5f, 10.0f);  // x < 0.5 has no valid quadratic stencil (int() truncates)
+  for (int l = 0; l < 100; l++) {  // src/tests.cpp:35-51, src/transfer.cpp:975-989
+    Vector3 pos(U(rng), U(rng), U(rng));
+    MPMKernel<3, 2> slow(pos, 3.0f);
+    MPMFastKernel32 fast(pos, 3.0f);
+    Vector3 rel;
+    for (int a = 0; a < 3; a++) rel[a] = pos[a] - (float)MPMKernel<3, 2>::get_stencil_start(pos[a]);
+    MLSMPMFastKernel32 mls(rel);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+        for (int k = 0; k < 3; k++) {
+          const Vector4 a = slow.get_dw_w(Vector3i(i, j, k)), b = fast.get_dw_w(Vector3i(i, j, k));
+          float d = 0;
+          for (int c = 0; c < 4; c++) d += (a[c] - b[c]) * (a[c] - b[c]);
+          CHECK(std::sqrt(d) < 1e-6f);
+          CHECK(std::fabs(mls.kernels[i][j][k] - slow.get_w(Vector3i(i, j, k))) < 1e-6f);
+          CHECK(rel[0] >= 0.5f && rel[0] < 1.5f);
+        }
+  }
+  {  // closed form at fx = 1 (node-centred particle): (1/8, 3/4, 1/8), src/kernel.h:126-130
+    MPMKernel<3, 2> k(Vector3(4.0f, 4.0f, 4.0f), 1.0f);
+    CHECK(std::fabs(k.w_cache[0][0] - 0.125f) < 1e-7f && std::fabs(k.w_cache[0][1] - 0.75f) < 1e-7f && std::fabs(k.w_cache[0][2] - 0.125f) < 1e-7f);
+    CHECK((MPMKernel<3, 2>::get_stencil_start(4.0f) == 3));
+    CHECK((MPMKernel<3, 2>::get_stencil_start(4.6f) == 4));
+    CHECK((MPMKernel<3, 1>::get_stencil_start(4.6f) == 4));
+    CHECK((MPMKernel<3, 3>::get_stencil_start(4.6f) == 3));
+    CHECK((MPMKernel<3, 2>::inv_D() == 4.0f) && (MPMKernel<3, 3>::inv_D() == 3.0f));
+  }
+  {  // Config + particle registry defaults (src/particles.cpp initialize() bodies)
+    Config c;
+    c.set("res", Vector3i(64, 64, 64)).set("gravity", Vector3(0, -9.8f, 0)).set("E", 2e5).set("flag", true);
+    CHECK((c.get_vec("res", Vector3i(0, 0, 0))[2] == 64));
+    CHECK(std::fabs(c.get_vec("gravity", Vector3(0, 0, 0))[1] + 9.8f) < 1e-6f);
+    CHECK(c.get("missing", 7) == 7 && c.get("flag", false));
+    const ParticleType jelly = create_particle_type("jelly", c, 1.0f, 2.0f);
+    CHECK(jelly.material == MPMHIP_JELLY && std::fabs(jelly.params[2] - 2e5f / 2.6f) < 1.0f);
+    const ParticleType sand = create_particle_type("sand", Config(), 1.0f, 1.0f);
+    CHECK(sand.material == MPMHIP_SAND && sand.params[2] == 136038.0f && sand.params[3] == 204057.0f);
+    CHECK(std::fabs(sand.params[4] - std::sqrt(2.0 / 3.0) * 2.0 * 0.5 / 2.5) < 1e-6);  // friction angle 30 deg
+    const ParticleType snow = create_particle_type("snow", Config(), 1.0f, 1.0f);
+    CHECK(snow.initial_aux == 1.0f && snow.params[4] == 10.0f && std::fabs(snow.params[5] - 2.5e-2f) < 1e-9f);
+    bool threw = false;
+    try { create_particle_type("custard", Config(), 1, 1); } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw);
+    threw = false;
+    try { create_particle_type("jelly", Config().set("compressibility", 1.0), 1, 1); } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw);
+  }
+  {  // no device: initialize() must fail loudly (the library has no CPU path); "delta_t" is rejected as in :41-42
+    MPM<3> sim;
+    bool threw = false;
+    try { sim.initialize(Config().set("res", Vector3i(32, 32, 32)).set("delta_t", 1e-3)); } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw);
+    if (!std::getenv("MPMHIP_TEST_HAS_GPU")) {
+      threw = false;
+      std::string msg;
+      try { sim.initialize(Config().set("res", Vector3i(32, 32, 32))); } catch (const std::runtime_error &e) { threw = true; msg = e.what(); }
+      CHECK(threw);
+      CHECK(msg.find("HIP") != std::string::npos);
+    }
+  }
+}
+
+static void gpu_tests() {
+  auto sim = create_simulation3("mpm");
+  sim->initialize(Config().set("res", Vector3i(64, 64, 64)).set("base_delta_t", 1e-4).set("gravity", Vector3(0, -10, 0)));
+  sim->set_levelset({Vector4(0.0f, 1.0f, 0.0f, -0.15f)}, -1.0f);
+  CHECK(sim->add_particles(Config().set("type", "jelly").set("benchmark", 125)) == "");
+  const int64_t n = sim->get_num_particles();
+  CHECK(n == 13 * 13 * 13 * 8);  // round(64*0.4)=26..39: 13^3 cells x 8 (src/mpm.cpp:149-186)
+  sim->add_particles(Config().set("type", "sand").set("cube_lo", 40).set("cube_hi", 44).set("initial_velocity", Vector3(0, -1, 0)));
+  CHECK(sim->get_num_particles() == n + 4 * 4 * 4 * 8);
+  sim->step(-1.0f);  // exactly one substep
+  CHECK(std::fabs(sim->get_current_time() - 1e-4f) < 1e-9f);
+  sim->step(1e-3f);
+  CHECK(sim->get_current_time() > 0.9e-3f && sim->get_current_time() <= 1.1e-3f + 1e-4f);
+  // the phases, under the reference's names
+  sim->sort_particles_and_populate_grid();
+  sim->rasterize_optimized();
+  sim->normalize_grid_and_apply_external_force();
+  sim->apply_grid_boundary_conditions();
+  sim->resample_optimized();
+  sim->synchronize();
+  const auto rp = sim->get_render_particles();
+  CHECK((int64_t)rp.size() == sim->get_num_particles());
+  double vy = 0;
+  for (auto &p : rp) vy += p.velocity[1];
+  vy /= rp.size();
+  CHECK(vy < -5e-3 && vy > -0.2);  // ~12 substeps of free fall (+ the sand block's -1 m/s)
+  const double e = std::stod(sim->general_action(Config().set("action", "calculate_energy")));
+  CHECK(e > 0 && std::isfinite(e));
+  // device constitutive code through the particle surface: F = I => zero force; plasticity(cdg) = F <- cdg F for jelly
+  MPMParticle p;
+  p.type = create_particle_type("jelly", Config(), 1.0f, 1e-6f);
+  const Matrix3 f0 = p.calculate_force(sim->ctx());
+  for (float v : f0) CHECK(std::fabs(v) < 1e-9f);
+  Matrix3 cdg{{1.01f, 0, 0, 0, 1, 0, 0, 0, 0.99f}};
+  p.plasticity(sim->ctx(), cdg);
+  CHECK(std::fabs(p.dg_e[0] - 1.01f) < 1e-6f && std::fabs(p.dg_e[8] - 0.99f) < 1e-6f);
+  const Matrix3 f1 = p.calculate_force(sim->ctx());
+  CHECK(f1[0] < 0 && f1[8] > 0);  // -vol P F^T: stretched axis pulls back, compressed axis pushes
+  CHECK(p.get_allowed_dt(1.0f / 64) > 0);
+}
+
+int main(int argc, char **argv) {
+  const std::string mode = argc > 1 ? argv[1] : "cpu";
+  try {
+    if (mode == "cpu") cpu_tests();
+    else gpu_tests();
+  } catch (const std::exception &e) {
+    std::printf("unexpected exception: %s\n", e.what());
+    return 2;
+  }
+  std::printf("%s: %d failure(s)\n", mode.c_str(), failures);
+  return failures ? 1 : 0;
+}
