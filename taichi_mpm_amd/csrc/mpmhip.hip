@@ -6,9 +6,11 @@
 //           clear_boundary_particles :582-633 — dead particles simply drop out of the index)
 //          [k_build_keys]  key = Morton(block) << 6 | cell-in-block per particle (normally produced by the
 //                          previous substep's k_g2p, which knows the new position)
-//          k_pack_flags -> k_scan_*<0>  active-block bitmap + popcount prefix: dense slot of every active block
-//          k_emit_active, k_rank (rank of each particle in its cell, run-aggregated atomics),
-//          k_block_totals -> k_scan_*<1> -> k_cell_start, k_perm (sorted position -> particle slot)
+//          k_block_table  byte flags -> active-block bitmap + popcount prefix (dense slot of every active block)
+//                         + active-block list, one single-pass chained-scan launch
+//          k_rank         rank of each particle in its cell (run-aggregated atomics)
+//          k_cell_table   per-cell counts -> start of every cell / block in the sorted index (single pass)
+//          k_perm         sorted position -> particle slot
 //   P2G    k_p2g   one wavefront per active 4x4x4-cell block, ONE LANE PER CELL: register accumulation of the
 //                  27x4 node contributions over the cell's particles (records prefetched two particles ahead),
 //                  ordered non-atomic float4 merge into the block's 6^3-node LDS tile, tile written out whole
@@ -221,32 +223,13 @@ __global__ __launch_bounds__(256) void k_build_keys(Params P, RecG *__restrict__
   }
 }
 
-// byte flags -> active-block bitmap (bit b of word w = block with Morton key 32w+b); clears the flags
-__global__ __launch_bounds__(256) void k_pack_flags(Params P, uint8_t *__restrict__ blk_flag,
-                                                    uint32_t *__restrict__ bits) {
-  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < P.nbw; w += gridDim.x * blockDim.x) {
-    uint4 *src = reinterpret_cast<uint4 *>(blk_flag + (size_t)w * 32);
-    const uint4 lo = src[0], hi = src[1];
-    const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    uint32_t m = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const uint32_t v = q[k];  // four 0/1 bytes -> four bits
-      m |= ((v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u)) << (4 * k);
-    }
-    bits[w] = m;
-    if (m) { src[0] = make_uint4(0, 0, 0, 0); src[1] = make_uint4(0, 0, 0, 0); }
-  }
-}
-
-// ---- multi-workgroup exclusive scan of a uint32 sequence, two launches:
-//   k_scan_partials: workgroup i reduces chunk i (SCAN_CHUNK elements) -> partials[i]
-//   k_scan_apply   : workgroup i adds the partials before it to a local scan of its chunk
-// MODE 0: element w = popcount(bits[w]) (active-block bitmap; 8^k/8 bytes, 256 KiB for a 256^3 grid),
-//         out = word_prefix (number of active blocks with Morton key < 32 w), total -> cnt->n_active
-// MODE 1: element a = particles in active block a, out = act_start[0..n_active], total -> cnt->n_sorted
-constexpr int SCAN_CHUNK = 2048;  // 256 threads x 8
-
+// ---- single-pass chained scans.  Both tables below are prefix sums over data produced by the previous kernel.
+// Instead of the classic three launches (partials, scan of partials, apply) a workgroup publishes the sum of its
+// chunk as ONE 64-bit word {epoch, value} (agent-scope atomic: the 8 XCDs' L2s are not coherent for plain
+// accesses; the word is self-contained, so relaxed ordering suffices), sums the words of the chunks before it
+// (spinning until their epoch matches) and finishes its chunk.  Chunks are handed out by a ticket counter, so a
+// chunk's predecessors have always started and never wait on it: no deadlock, no co-residency assumption.  The
+// epoch changes with every sort and each kernel zeroes the OTHER kernel's ticket: nothing is cleared by memsets.
 __device__ __forceinline__ uint32_t wg_exclusive_scan_256(uint32_t v, uint32_t *lds /*>=4*/, uint32_t &total) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t inc = v;
@@ -264,80 +247,78 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan_256(uint32_t v, uint32_t *
   return base + inc - v;
 }
 
-template <int MODE>
-__device__ __forceinline__ uint32_t scan_count(const Params &P, const Counters *cnt) {
-  return MODE == 0 ? P.nbw : min(cnt->n_active, P.max_blocks);
+__device__ __forceinline__ void publish(unsigned long long *slot, uint32_t epoch, uint32_t value) {
+  __hip_atomic_store(slot, ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
-template <int MODE>
-__global__ __launch_bounds__(256) void k_scan_partials(Params P, const Counters *__restrict__ cnt,
-                                                       const uint32_t *__restrict__ in,
-                                                       uint32_t *__restrict__ partials) {
-  __shared__ uint32_t lds[8];
-  const uint32_t n = scan_count<MODE>(P, cnt);
-  const uint32_t base = blockIdx.x * SCAN_CHUNK;
-  if (base >= n) return;
-  uint32_t sum = 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const uint32_t i = base + k * 256 + threadIdx.x;
-    if (i < n) sum += (MODE == 0) ? (uint32_t)__popc(in[i]) : in[i];
+// sum of the published values of chunks [0, chunk): every thread of the 256-thread workgroup gets the result
+__device__ __forceinline__ uint32_t sum_predecessors(const unsigned long long *slots, uint32_t chunk, uint32_t epoch,
+                                                     uint32_t *lds) {
+  uint32_t pre = 0;
+  for (uint32_t j = threadIdx.x; j < chunk; j += 256) {
+    unsigned long long w;
+    while ((uint32_t)((w = __hip_atomic_load(slots + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch)
+      __builtin_amdgcn_s_sleep(1);
+    pre += (uint32_t)w;
   }
   uint32_t total;
-  wg_exclusive_scan_256(sum, lds, total);
-  if (threadIdx.x == 0) partials[blockIdx.x] = total;
+  wg_exclusive_scan_256(pre, lds, total);
+  return total;
+}
+__device__ __forceinline__ uint32_t take_ticket(uint32_t *ticket, uint32_t *s_chunk) {
+  __syncthreads();  // the previous chunk's readers of *s_chunk are done
+  if (threadIdx.x == 0) *s_chunk = atomicAdd(ticket, 1u);
+  __syncthreads();
+  return *s_chunk;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_scan_apply(Params P, Counters *cnt, const uint32_t *__restrict__ in,
-                                                    const uint32_t *__restrict__ partials,
-                                                    uint32_t *__restrict__ out) {
+// Active-block table, one launch: byte flags -> bitmap `bits` (bit b of word w = block with Morton key 32w+b;
+// the flags are cleared behind), per-word prefix `wprefix` (active blocks with key < 32w) = dense slot of every
+// active block, the list act_blk[slot] = key, and cnt->n_active.  Chunk = 256 bitmap words, one per thread.
+__global__ __launch_bounds__(256) void k_block_table(Params P, uint8_t *__restrict__ blk_flag,
+                                                     uint32_t *__restrict__ bits, uint32_t *__restrict__ wprefix,
+                                                     uint32_t *__restrict__ act_blk, Counters *cnt,
+                                                     unsigned long long *__restrict__ slots, uint32_t *ticket,
+                                                     uint32_t epoch) {
   __shared__ uint32_t lds[8];
-  const uint32_t n = scan_count<MODE>(P, cnt);
-  const uint32_t base = blockIdx.x * SCAN_CHUNK;
-  if (base >= n && !(n == 0 && blockIdx.x == 0)) return;
-  uint32_t pre = 0;  // sum of the partials of the chunks before this one
-  for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256) pre += partials[j];
-  uint32_t chunk_base;
-  wg_exclusive_scan_256(pre, lds, chunk_base);
-  uint32_t v[8], sum = 0;  // thread t owns 8 consecutive elements
+  __shared__ uint32_t s_chunk;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ticket[1] = 0;  // k_cell_table's counter (it is not running now)
+  const uint32_t nchunks = (P.nbw + 255) / 256;
+  while (true) {
+    const uint32_t chunk = take_ticket(ticket, &s_chunk);
+    if (chunk >= nchunks) return;
+    const uint32_t w = chunk * 256 + threadIdx.x;
+    uint32_t m = 0;
+    if (w < P.nbw) {
+      uint4 *src = reinterpret_cast<uint4 *>(blk_flag + (size_t)w * 32);
+      const uint4 lo = src[0], hi = src[1];
+      const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const uint32_t i = base + threadIdx.x * 8 + k;
-    v[k] = (i < n) ? ((MODE == 0) ? (uint32_t)__popc(in[i]) : in[i]) : 0u;
-    sum += v[k];
-  }
-  uint32_t total;
-  uint32_t run = chunk_base + wg_exclusive_scan_256(sum, lds, total);
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const uint32_t i = base + threadIdx.x * 8 + k;
-    if (i < n) out[i] = run;
-    run += v[k];
-  }
-  if (base + SCAN_CHUNK >= n && threadIdx.x == 255) {  // last chunk: publish the grand total
-    const uint32_t grand = chunk_base + total;
-    if (MODE == 0) {
+      for (int i = 0; i < 8; i++) {
+        const uint32_t v = q[i];  // four 0/1 bytes -> four bits
+        m |= ((v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u)) << (4 * i);
+      }
+      if (m) { src[0] = make_uint4(0, 0, 0, 0); src[1] = make_uint4(0, 0, 0, 0); }
+    }
+    uint32_t total;
+    const uint32_t excl = wg_exclusive_scan_256(__popc(m), lds, total);
+    if (threadIdx.x == 0) publish(slots + chunk, epoch, total);
+    const uint32_t chunk_base = sum_predecessors(slots, chunk, epoch, lds);
+    uint32_t run = chunk_base + excl;
+    if (w < P.nbw) {
+      bits[w] = m;
+      wprefix[w] = run;
+      uint32_t mm = m;
+      while (mm) {
+        const int b = __ffs(mm) - 1;
+        mm &= mm - 1;
+        if (run < P.max_blocks) act_blk[run] = (w << 5) | (uint32_t)b;
+        run++;
+      }
+    }
+    if (chunk == nchunks - 1 && threadIdx.x == 255) {
+      const uint32_t grand = chunk_base + total;
       if (grand > P.max_blocks) cnt->error |= 1u;
       cnt->n_active = grand;
-    } else {
-      out[n] = grand;
-      cnt->n_sorted = grand;
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void k_emit_active(Params P, const uint32_t *__restrict__ bits,
-                                                     const uint32_t *__restrict__ wprefix,
-                                                     uint32_t *__restrict__ act_blk) {
-  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < P.nbw; w += gridDim.x * blockDim.x) {
-    uint32_t m = bits[w];
-    uint32_t slot = wprefix[w];
-    while (m) {
-      const int b = __ffs(m) - 1;
-      m &= m - 1;
-      if (slot < P.max_blocks) act_blk[slot] = (w << 5) | (uint32_t)b;
-      slot++;
     }
   }
 }
@@ -376,44 +357,69 @@ __global__ __launch_bounds__(256) void k_rank(Params P, uint32_t *__restrict__ k
   }
 }
 
-// one wave per active block: particles per block
-__global__ __launch_bounds__(256) void k_block_totals(Params P, const Counters *__restrict__ cnt,
-                                                      const uint32_t *__restrict__ cell_cnt,
-                                                      uint32_t *__restrict__ totals) {
+// Cell table, one launch: per-cell counts (k_rank) -> act_start[a] (first sorted position of active block a,
+// sentinel at [n_active]) and cell_start[a*64 + c] (sentinel at [n_active*64]): the particles of cell i are
+// perm[cell_start[i] .. cell_start[i+1]).  Zeroes the counters behind itself.  Chunk = the 64 blocks
+// [64 t, 64 t + 64): wave w takes the 16 blocks [64 t + 16 w, +16), one lane per cell.
+constexpr int CT_BLOCKS = 64;
+__global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uint32_t *__restrict__ cell_cnt,
+                                                    uint32_t *__restrict__ act_start,
+                                                    uint32_t *__restrict__ cell_start,
+                                                    unsigned long long *__restrict__ slots, uint32_t *ticket,
+                                                    uint32_t epoch) {
+  __shared__ uint32_t lds[8];
+  __shared__ uint32_t s_chunk;
+  __shared__ uint32_t blk_tot[CT_BLOCKS];
+  if (blockIdx.x == 0 && threadIdx.x == 0) ticket[0] = 0;  // k_block_table's counter (it is not running now)
   const uint32_t na = min(cnt->n_active, P.max_blocks);
-  const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (uint32_t a = wave; a < na; a += nwaves) {
-    uint32_t v = cell_cnt[a * BC + lane];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  while (true) {
+    const uint32_t chunk = take_ticket(ticket + 1, &s_chunk);
+    const uint32_t a0 = chunk * CT_BLOCKS;
+    if (a0 >= na && !(na == 0 && chunk == 0)) return;
+    uint32_t excl[16];  // exclusive in-block prefix of this lane's cell, for the wave's 16 blocks
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (lane == 0) totals[a] = v;
-  }
-}
-
-// per-cell counts -> start of every cell in the sorted index: cell_start[slot*64 + c], plus a sentinel at
-// [n_active*64], so the particles of cell i are always perm[cell_start[i] .. cell_start[i+1]).  Zeroes the
-// counters behind itself (they must be all-zero at the start of the next sort).
-__global__ __launch_bounds__(256) void k_cell_start(Params P, const Counters *__restrict__ cnt,
-                                                    uint32_t *__restrict__ cell_cnt,
-                                                    const uint32_t *__restrict__ act_start,
-                                                    uint32_t *__restrict__ cell_start) {
-  const uint32_t na = min(cnt->n_active, P.max_blocks);
-  const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (uint32_t a = wave; a < na; a += nwaves) {
-    const uint32_t c = cell_cnt[a * BC + lane];
-    cell_cnt[a * BC + lane] = 0;
-    uint32_t v = c;
+    for (int i = 0; i < 16; i++) {
+      const uint32_t a = a0 + wave * 16 + i;
+      uint32_t c = 0;
+      if (a < na) {
+        c = cell_cnt[(size_t)a * BC + lane];
+        cell_cnt[(size_t)a * BC + lane] = 0;
+      }
+      uint32_t v = c;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t u = __shfl_up(v, off);
-      if ((int)lane >= off) v += u;
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(v, off);
+        if ((int)lane >= off) v += u;
+      }
+      excl[i] = v - c;
+      if (lane == 63) blk_tot[wave * 16 + i] = v;
     }
-    cell_start[a * BC + lane] = act_start[a] + v - c;
-    if (a == na - 1 && lane == 63) cell_start[na * BC] = act_start[a] + v;
+    __syncthreads();
+    // exclusive scan of the 64 block totals (threads 0..63 hold one block each; other threads contribute 0)
+    const uint32_t mine = threadIdx.x < CT_BLOCKS ? blk_tot[threadIdx.x] : 0u;
+    uint32_t total;
+    const uint32_t boff = wg_exclusive_scan_256(mine, lds, total);
+    if (threadIdx.x == 0) publish(slots + chunk, epoch, total);
+    if (threadIdx.x < CT_BLOCKS) blk_tot[threadIdx.x] = boff;
+    const uint32_t chunk_base = sum_predecessors(slots, chunk, epoch, lds);  // its barriers also cover blk_tot
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const uint32_t a = a0 + wave * 16 + i;
+      if (a < na) {
+        const uint32_t start = chunk_base + blk_tot[wave * 16 + i];
+        cell_start[(size_t)a * BC + lane] = start + excl[i];
+        if (lane == 0) act_start[a] = start;
+      }
+    }
+    if (a0 + CT_BLOCKS >= na && threadIdx.x == 0) {  // last chunk: sentinels + live count
+      const uint32_t grand = chunk_base + total;
+      act_start[na] = grand;
+      cell_start[(size_t)na * BC] = grand;
+      cnt->n_sorted = grand;
+    }
+    if (na == 0) return;
   }
-  if (na == 0 && wave == 0 && lane == 0) cell_start[0] = 0;
 }
 
 // sorted position -> particle slot (the reference's sorted `particles` index vector, src/mpm.cpp:800-807)
@@ -1156,8 +1162,10 @@ struct mpmhip_ctx {
   // blocks
   uint32_t NB = 0;
   uint8_t *blk_flag = nullptr;
-  uint32_t *bits = nullptr, *wprefix = nullptr, *act_blk = nullptr, *act_start = nullptr, *totals = nullptr;
-  uint32_t *cell_cnt = nullptr, *cell_start = nullptr, *partials = nullptr, *fat_slot = nullptr;
+  uint32_t *bits = nullptr, *wprefix = nullptr, *act_blk = nullptr, *act_start = nullptr;
+  uint32_t *cell_cnt = nullptr, *cell_start = nullptr, *fat_slot = nullptr, *ticket = nullptr;
+  unsigned long long *scan_slots = nullptr;  // [256] k_block_table + [ct_grid] k_cell_table: {epoch, chunk sum}
+  uint32_t sort_epoch = 0, bt_slots = 0;
   float4 *tiles = nullptr, *gridv = nullptr, *dense = nullptr;
   Counters *cnt = nullptr;
   std::vector<GroupParams> groups;
@@ -1307,10 +1315,12 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(dmalloc(&c->fat_slot, (size_t)c->NB));
   A(dmalloc(&c->act_blk, (size_t)mb + 1));
   A(dmalloc(&c->act_start, (size_t)mb + 2));
-  A(dmalloc(&c->totals, (size_t)mb + 1));
   A(dmalloc(&c->cell_cnt, (size_t)mb * BC));
   A(dmalloc(&c->cell_start, (size_t)mb * BC + 1));
-  A(dmalloc(&c->partials, (size_t)((P.nbw > (uint32_t)mb ? P.nbw : (uint32_t)mb) / SCAN_CHUNK + 2)));
+  c->bt_slots = (P.nbw + 255) / 256;
+  const size_t n_slots64 = c->bt_slots + ((size_t)mb + CT_BLOCKS - 1) / CT_BLOCKS + 1;
+  A(dmalloc(&c->scan_slots, n_slots64));
+  A(dmalloc(&c->ticket, 2));
   A(dmalloc(&c->tiles, (size_t)mb * TN));
   A(dmalloc(&c->gridv, (size_t)mb * 8 * BC));
   A(dmalloc(&c->cnt, 1));
@@ -1326,6 +1336,8 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(hipMemset(c->cell_start, 0, sizeof(uint32_t) * ((size_t)mb * BC + 1)));
   A(hipMemset(c->act_start, 0, sizeof(uint32_t) * ((size_t)mb + 2)));
   A(hipMemset(c->cnt, 0, sizeof(Counters)));
+  A(hipMemset(c->scan_slots, 0, sizeof(unsigned long long) * n_slots64));  // epoch 0 is never used
+  A(hipMemset(c->ticket, 0, 2 * sizeof(uint32_t)));
   A(hipMemset(c->fat_slot, 0, sizeof(uint32_t) * (size_t)c->NB));
   A(hipMemset(c->rb, 0, sizeof(float) * (size_t)c->cap * BW));
   A(hipDeviceSynchronize());
@@ -1342,8 +1354,8 @@ void mpmhip_destroy(mpmhip_ctx *c) {
     for (int k = 0; k <= PH_COUNT; k++) hipEventDestroy(ev.e[k]);
   hipFree(c->rg); hipFree(c->rp); hipFree(c->rb); hipFree(c->rg2); hipFree(c->rp2); hipFree(c->rb2);
   hipFree(c->key); hipFree(c->rank); hipFree(c->perm); hipFree(c->blk_flag); hipFree(c->bits); hipFree(c->wprefix);
-  hipFree(c->fat_slot); hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->totals); hipFree(c->cell_cnt);
-  hipFree(c->cell_start); hipFree(c->partials); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
+  hipFree(c->fat_slot); hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->cell_cnt);
+  hipFree(c->cell_start); hipFree(c->scan_slots); hipFree(c->ticket); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
   hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_counts);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
@@ -1553,17 +1565,13 @@ static int do_sort(mpmhip_ctx *c) {
   const int pg = particle_grid(c->n_slots);
   if (!c->keys_valid)
     hipLaunchKernelGGL(k_build_keys, dim3(pg), dim3(256), 0, st, P, c->rg, c->rp, c->cnt, c->key, c->blk_flag);
-  const int nb_chunks = (int)((P.nbw + SCAN_CHUNK - 1) / SCAN_CHUNK);
-  const int na_chunks = (int)((P.max_blocks + SCAN_CHUNK - 1) / SCAN_CHUNK);
-  hipLaunchKernelGGL(k_pack_flags, dim3((P.nbw + 255) / 256), dim3(256), 0, st, P, c->blk_flag, c->bits);
-  hipLaunchKernelGGL((k_scan_partials<0>), dim3(nb_chunks), dim3(256), 0, st, P, c->cnt, c->bits, c->partials);
-  hipLaunchKernelGGL((k_scan_apply<0>), dim3(nb_chunks), dim3(256), 0, st, P, c->cnt, c->bits, c->partials, c->wprefix);
-  hipLaunchKernelGGL(k_emit_active, dim3((P.nbw + 255) / 256), dim3(256), 0, st, P, c->bits, c->wprefix, c->act_blk);
+  const uint32_t bt_chunks = (P.nbw + 255) / 256, ct_chunks = (P.max_blocks + CT_BLOCKS - 1) / CT_BLOCKS;
+  const uint32_t epoch = ++c->sort_epoch;
+  hipLaunchKernelGGL(k_block_table, dim3(std::min(bt_chunks, 512u)), dim3(256), 0, st, P, c->blk_flag, c->bits,
+                     c->wprefix, c->act_blk, c->cnt, c->scan_slots, c->ticket, epoch);
   hipLaunchKernelGGL(k_rank, dim3(pg), dim3(256), 0, st, P, c->key, c->rank, c->cell_cnt, c->bits, c->wprefix);
-  hipLaunchKernelGGL(k_block_totals, dim3(1024), dim3(256), 0, st, P, c->cnt, c->cell_cnt, c->totals);
-  hipLaunchKernelGGL((k_scan_partials<1>), dim3(na_chunks), dim3(256), 0, st, P, c->cnt, c->totals, c->partials);
-  hipLaunchKernelGGL((k_scan_apply<1>), dim3(na_chunks), dim3(256), 0, st, P, c->cnt, c->totals, c->partials, c->act_start);
-  hipLaunchKernelGGL(k_cell_start, dim3(1024), dim3(256), 0, st, P, c->cnt, c->cell_cnt, c->act_start, c->cell_start);
+  hipLaunchKernelGGL(k_cell_table, dim3(std::min(ct_chunks, 512u)), dim3(256), 0, st, P, c->cnt, c->cell_cnt,
+                     c->act_start, c->cell_start, c->scan_slots + c->bt_slots, c->ticket, epoch);
   hipLaunchKernelGGL(k_perm, dim3(pg), dim3(256), 0, st, P, c->key, c->rank, c->cell_start, c->perm);
   c->sorted = true;
   c->keys_valid = false;  // key[] now holds cell indices
