@@ -103,6 +103,47 @@ def pmc_traffic(config_name, kernel):
         return None, None
 
 
+def virtual_run(tm, cfg, args):
+    import torch
+
+    from taichi_mpm_amd import tiled
+    from taichi_mpm_amd.mpm import F_ID, lattice_cube
+    K = args.virtual
+    res, cells = cfg["res"], cfg["cells"]
+    dx = 1.0 / res
+    lo = res // 2 - cells // 2
+    x = lattice_cube(lo, lo + cells, dx)
+    part = tiled.Partition.balanced((res,) * 3, K, x, dx, margin=4)
+    owner = part.rank_of_cells(tiled.base_cells(x, dx))
+    engines = []
+    for r in range(K):
+        mine = np.nonzero(owner == r)[0]
+        sim = tm.create_simulation3("mpm").initialize(dict(res=(res,) * 3, delta_x=dx, base_delta_t=1e-4, gravity=(0, -10, 0),
+                                                           max_particles=int(len(mine) * 1.5) + (1 << 16)))
+        sim.set_levelset(tm.mpm.LevelSet(friction=-1.0).add_plane((0, 1, 0), d=-0.1))
+        sim.add_particles(dict(type=cfg["material"], positions=x[mine]))
+        sim.upload(F_ID, mine.astype(np.int32))
+        engines.append(tiled.HipEngine(sim, 0))
+    job = tiled.VirtualTiledJob(engines, part)
+    job.run(args.warmup)
+    for e in engines:
+        e.sim.set_profiling(1)
+        e.sim.profile(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    job.run(args.steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    profs = [e.sim.profile() for e in engines]
+    per_rank = [{k: v / max(p["substeps"], 1) for k, v in p["phases"].items()} for p in profs]
+    print(json.dumps({"diagnostic": "virtual ranks on one GPU", "K": K, "dims": part.dims, "cuts": part.cuts,
+                      "particles_per_rank": [p["particles"] for p in profs], "active_blocks": [p["active_blocks"] for p in profs],
+                      "halo_floats_per_rank": [r.plan.total for r in job.ranks],
+                      "ms_per_step_all_ranks_serial": 1e3 * el / args.steps,
+                      "per_rank_compute_ms": [sum(v for k, v in pr.items() if k != "exchange") for pr in per_rank],
+                      "rank0_phases_ms": per_rank[0], "migrated": [r.migrated_out for r in job.ranks]}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +151,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--virtual", type=int, default=0, metavar="K",
+                    help="diagnostic, not the metric: run the K-brick tiled job as K ctx on ONE GPU (exchanges are local "
+                         "copies) and print per-rank phase times = the per-GPU compute of a K-GPU run without the wire")
     args = ap.parse_args()
 
     import torch
@@ -131,7 +175,17 @@ def main():
 
     cfg = CONFIGS[args.config]
     from taichi_mpm_amd import tiling
-    job = tiling.make_job(tm, cfg, rank, world, local_rank, build_sim)
+    if args.virtual > 1:
+        return virtual_run(tm, cfg, args)
+    force_tiled = world == 1 and os.environ.get("MPMHIP_FORCE_TILED") == "1"  # test hook: TiledJob over RCCL, 1 rank
+    if force_tiled:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        from taichi_mpm_amd import tiled
+        job = tiled.make_tiled_job(tm, cfg, 0, 1, local_rank)
+    else:
+        job = tiling.make_job(tm, cfg, rank, world, local_rank, build_sim)
     n_local = job.num_particles()
     job.run(args.warmup)
     job.synchronize()

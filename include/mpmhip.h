@@ -199,6 +199,9 @@ int mpmhip_leaver_counts(mpmhip_ctx *ctx, int32_t world, int64_t *counts);
 /* packs every leaver (n_total = sum of the counts just returned) into dev_records, grouped by destination */
 int mpmhip_export_leavers(mpmhip_ctx *ctx, int32_t world, const int64_t *counts, void *dev_records);
 int mpmhip_import_particles(mpmhip_ctx *ctx, int64_t n, const void *dev_records);
+/* cell bounding box [lo, hi) of the active 4^3-cell blocks of the last sort (lo > hi when there are none);
+ * synchronises.  Lets the caller clip the halo boxes to the occupied part of the grid. */
+int mpmhip_active_bounds(mpmhip_ctx *ctx, int32_t lo[3], int32_t hi[3]);
 int64_t mpmhip_num_slots(mpmhip_ctx *ctx);       /* slots in use (live + dead) — capacity pressure */
 int mpmhip_request_compaction(mpmhip_ctx *ctx);  /* physical reorder + drop of dead slots at the next sort */
 

@@ -71,7 +71,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_las
             "mpmhip_download_grid", "mpmhip_upload_grid", "mpmhip_set_profiling", "mpmhip_profile",
             "mpmhip_profile_reset", "mpmhip_set_partition", "mpmhip_set_halo", "mpmhip_halo_pack",
             "mpmhip_substep_begin", "mpmhip_substep_end", "mpmhip_leaver_counts", "mpmhip_export_leavers",
-            "mpmhip_import_particles", "mpmhip_num_slots", "mpmhip_request_compaction", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
+            "mpmhip_import_particles", "mpmhip_active_bounds", "mpmhip_num_slots", "mpmhip_request_compaction", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
 
 
 def exported_symbols():
@@ -117,6 +117,7 @@ def load():
     L.mpmhip_leaver_counts.argtypes = [vp, C.c_int32, P(C.c_int64)]
     L.mpmhip_export_leavers.argtypes = [vp, C.c_int32, P(C.c_int64), vp]
     L.mpmhip_import_particles.argtypes = [vp, C.c_int64, vp]
+    L.mpmhip_active_bounds.argtypes = [vp, ip, ip]
     L.mpmhip_num_slots.argtypes = [vp]
     L.mpmhip_num_slots.restype = C.c_int64
     for name in ("mpmhip_substep", "mpmhip_synchronize", "mpmhip_sort", "mpmhip_p2g", "mpmhip_grid_update",

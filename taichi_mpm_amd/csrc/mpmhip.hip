@@ -629,7 +629,7 @@ __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const floa
 }
 
 // ------------------------------------------------------------------------------------------------ grid
-// One wavefront per active block a.  The tile of a overlaps the 8 grid blocks c = block(a) + o, o in {0,1}^3
+// One wavefront per (active block a, o).  The tile of a overlaps the 8 grid blocks c = block(a) + o, o in {0,1}^3
 // ("candidates").  A grid block c is processed by its "owner": the candidate with the smallest o among the
 // active blocks c - o'.  The owner sums the overlapping tiles (<= 8), then
 //   mode 0: normalize_grid_and_apply_external_force + apply_grid_boundary_conditions (src/mpm.cpp:277-372)
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const floa
 // look one neighbour up each (one round trip), the rest is ballots and shuffles.
 __device__ __forceinline__ constexpr int nb27(int dx, int dy, int dz) { return ((dx + 1) * 3 + (dy + 1)) * 3 + (dz + 1); }
 
-template <int MODE>
+template <int MODE, bool PER_CAND>
 __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restrict__ cnt,
                                               const uint32_t *__restrict__ act_blk,
                                               const uint32_t *__restrict__ bits,
@@ -652,7 +652,15 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
   const int l = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   const int lx = l >> 4, ly = (l >> 2) & 3, lz = l & 3;
-  for (uint32_t a = wave; a < na; a += nwaves) {
+  // The kernel is a chain of dependent lookups (block list -> bitmap/prefix -> tiles -> halo -> store).
+  // PER_CAND = false: one wavefront per active block walks its 8 candidates (lookups shared; best when there are
+  // more blocks than resident waves).  PER_CAND = true: one wavefront per (block, candidate) — 8x the lookups but
+  // an 8x shorter chain for the boundary blocks that own many candidates (best for small per-GPU problems, i.e.
+  // the tiled multi-GPU runs: 32 -> 19 us at 1 M particles; 33 -> 88 us at 8 M, hence the switch in do_grid).
+  const uint32_t nwork = PER_CAND ? na * 8u : na;
+  for (uint32_t work = wave; work < nwork; work += nwaves) {
+    const uint32_t a = PER_CAND ? work >> 3 : work;
+    const int o_mine = PER_CAND ? (int)(work & 7u) : -1;
     int bx, by, bz;
     demorton3(act_blk[a], bx, by, bz);
     // neighbour table: lane n < 27 holds (active?, slot) of block b + (n/9-1, n/3%3-1, n%3-1)
@@ -667,6 +675,7 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
     const uint32_t amask = (uint32_t)__ballot(nslot != INVALID);
 #pragma unroll
     for (int o = 0; o < 8; o++) {
+      if (PER_CAND && o != o_mine) continue;  // wave-uniform (the loop stays unrolled: compile-time masks)
       const int ox = o >> 2, oy = (o >> 1) & 1, oz = o & 1;
       // sources of c = b + o are c - q = b + (o - q), q in {0,1}^3; owner <=> none of them active for q < o
       uint32_t lower = 0;
@@ -703,18 +712,31 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
         const bool interior = gi >= T.int_lo[0] && gi < T.int_hi[0] && gj >= T.int_lo[1] && gj < T.int_hi[1] &&
                               gk >= T.int_lo[2] && gk < T.int_hi[2];
         if (__any(!interior)) {
+          // contributors in rank order; the peers' values are fetched eight boxes at a time (independent loads,
+          // one round trip) and then added in order
           float4 tot = make_float4(0, 0, 0, 0);
           bool own = false;
-          for (int b = 0; b < T.n_boxes; b++) {
-            const DevBox &B = boxes[b];
-            if (!own && B.peer > T.rank) {
-              tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w;
-              own = true;
+          for (int b0 = 0; b0 < T.n_boxes; b0 += 8) {
+            float4 r[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              r[u] = make_float4(0, 0, 0, 0);
+              if (b0 + u < T.n_boxes) {
+                const DevBox &B = boxes[b0 + u];
+                const int x = gi - B.lo[0], y = gj - B.lo[1], z = gk - B.lo[2];
+                if ((unsigned)x < (unsigned)B.dim[0] && (unsigned)y < (unsigned)B.dim[1] && (unsigned)z < (unsigned)B.dim[2])
+                  r[u] = B.recv[((size_t)x * B.dim[1] + y) * B.dim[2] + z];
+              }
             }
-            const int x = gi - B.lo[0], y = gj - B.lo[1], z = gk - B.lo[2];
-            if ((unsigned)x < (unsigned)B.dim[0] && (unsigned)y < (unsigned)B.dim[1] && (unsigned)z < (unsigned)B.dim[2]) {
-              const float4 r = B.recv[((size_t)x * B.dim[1] + y) * B.dim[2] + z];
-              tot.x += r.x; tot.y += r.y; tot.z += r.z; tot.w += r.w;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              if (b0 + u < T.n_boxes) {
+                if (!own && boxes[b0 + u].peer > T.rank) {
+                  tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w;
+                  own = true;
+                }
+                tot.x += r[u].x; tot.y += r[u].y; tot.z += r[u].z; tot.w += r[u].w;
+              }
             }
           }
           if (!own) { tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w; }
@@ -780,6 +802,28 @@ __global__ __launch_bounds__(256) void k_halo_pack(Params P, Tiling T, const Dev
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     B.send[r] = acc;
+  }
+}
+
+// bounding box (cells) of the active blocks of the last sort: out[0..2] = min, out[3..5] = max (exclusive)
+__global__ __launch_bounds__(256) void k_active_bounds(Params P, const Counters *__restrict__ cnt,
+                                                       const uint32_t *__restrict__ act_blk, int *__restrict__ out) {
+  const uint32_t na = min(cnt->n_active, P.max_blocks);
+  int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
+  for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < na; a += gridDim.x * blockDim.x) {
+    int b[3];
+    demorton3(act_blk[a], b[0], b[1], b[2]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { lo[k] = min(lo[k], b[k] * BS); hi[k] = max(hi[k], b[k] * BS + BS); }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[k] = min(lo[k], __shfl_xor(lo[k], off));
+      hi[k] = max(hi[k], __shfl_xor(hi[k], off));
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&out[k], lo[k]); atomicMax(&out[3 + k], hi[k]); }
   }
 }
 
@@ -1194,6 +1238,7 @@ struct mpmhip_ctx {
   Tiling T;
   DevBox *d_boxes = nullptr;
   uint32_t *d_counts = nullptr;
+  int *d_bounds = nullptr;
   int counts_cap = 0;
   bool compact_requested = false;
   bool in_substep = false;
@@ -1356,7 +1401,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   hipFree(c->key); hipFree(c->rank); hipFree(c->perm); hipFree(c->blk_flag); hipFree(c->bits); hipFree(c->wprefix);
   hipFree(c->fat_slot); hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->cell_cnt);
   hipFree(c->cell_start); hipFree(c->scan_slots); hipFree(c->ticket); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
-  hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_counts);
+  hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_counts); hipFree(c->d_bounds);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1629,8 +1674,10 @@ static int do_p2g(mpmhip_ctx *c) {
   return launch_check(c, "p2g");
 }
 static int do_grid(mpmhip_ctx *c, int mode) {
-  auto kern = mode == 0 ? k_grid<0> : (mode == 1 ? k_grid<1> : (mode == 2 ? k_grid<2> : k_grid<3>));
-  hipLaunchKernelGGL(kern, dim3(4096), dim3(256), 0, c->stream, c->P, c->cnt, c->act_blk, c->bits, c->wprefix, c->tiles,
+  const bool per_cand = mode == 0 && c->n_slots < (2 << 20);  // small per-GPU problem: latency-bound, see k_grid
+  auto kern = mode == 0 ? (per_cand ? k_grid<0, true> : k_grid<0, false>)
+                        : (mode == 1 ? k_grid<1, false> : (mode == 2 ? k_grid<2, false> : k_grid<3, false>));
+  hipLaunchKernelGGL(kern, dim3(per_cand ? 16384 : 4096), dim3(256), 0, c->stream, c->P, c->cnt, c->act_blk, c->bits, c->wprefix, c->tiles,
                      c->gridv, c->fat_slot, c->dense, c->T, (const DevBox *)c->d_boxes);
   return launch_check(c, "grid");
 }
@@ -2006,6 +2053,24 @@ int mpmhip_import_particles(mpmhip_ctx *c, int64_t n, const void *dev_records) {
   c->n_slots += n;
   c->P.n_slots = (uint32_t)c->n_slots;
   return launch_check(c, "import");
+}
+
+int mpmhip_active_bounds(mpmhip_ctx *c, int32_t lo[3], int32_t hi[3]) {
+  if (!c || !lo || !hi) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->d_bounds) HIPCHK(c, dmalloc(&c->d_bounds, 6));
+  const int init[6] = {1 << 30, 1 << 30, 1 << 30, -1, -1, -1};
+  int h[6];
+  HIPCHK(c, hipMemcpyAsync(c->d_bounds, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // `init` lives on this stack frame
+  hipLaunchKernelGGL(k_active_bounds, dim3(64), dim3(256), 0, c->stream, c->P, (const Counters *)c->cnt,
+                     (const uint32_t *)c->act_blk, c->d_bounds);
+  int rc = launch_check(c, "active_bounds");
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(h, c->d_bounds, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 3; k++) { lo[k] = h[k]; hi[k] = h[3 + k]; }
+  return MPMHIP_OK;
 }
 
 int64_t mpmhip_num_slots(mpmhip_ctx *c) { return c ? c->n_slots : MPMHIP_EINVAL; }

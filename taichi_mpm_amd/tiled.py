@@ -68,16 +68,21 @@ class Partition:
         self.cuts = [list(map(int, c)) for c in cuts]
         self.margin = int(margin)
         self.world = self.dims[0] * self.dims[1] * self.dims[2]
+        # halo boxes are clipped to this node box (the occupied part of the grid + slack, the same on all ranks)
+        self.clip = ([0, 0, 0], [r + 1 for r in self.res])
         for a in range(3):
             assert len(self.cuts[a]) == self.dims[a] + 1 and self.cuts[a][0] == 0 and self.cuts[a][-1] >= self.res[a]
             assert all(self.cuts[a][k] < self.cuts[a][k + 1] for k in range(self.dims[a]))
             assert self.dims[a] <= _lib.MAX_PARTS
 
     @classmethod
-    def balanced(cls, res, world, x, dx, margin, dims=None):
+    def balanced(cls, res, world, x, dx, margin, dims=None, clip=True):
         dims = dims or brick_dims(world)
         b = base_cells(x, dx)
-        return cls(res, dims, [balanced_cuts(b[:, a], res[a], dims[a]) for a in range(3)], margin)
+        part = cls(res, dims, [balanced_cuts(b[:, a], res[a], dims[a]) for a in range(3)], margin)
+        if clip and len(b):
+            part.set_clip_from_bounds(b.min(0), b.max(0) + 1)
+        return part
 
     def coords(self, rank):
         return (rank // (self.dims[1] * self.dims[2]), (rank // self.dims[2]) % self.dims[1], rank % self.dims[2])
@@ -89,8 +94,22 @@ class Partition:
     def node_box(self, rank):
         """nodes the rank's particles can touch: base cells in [lo-margin, hi+margin), stencil base..base+2"""
         lo, hi = self.brick(rank)
-        return ([max(0, lo[a] - self.margin) for a in range(3)],
-                [min(self.res[a] + 1, hi[a] + self.margin + 2) for a in range(3)])
+        return ([max(self.clip[0][a], lo[a] - self.margin) for a in range(3)],
+                [min(self.clip[1][a], hi[a] + self.margin + 2) for a in range(3)])
+
+    def clip_slack(self):
+        return max(8, 2 * self.margin + 4)
+
+    def clip_covers(self, cell_lo, cell_hi):
+        """does the current clip box hold every node the particles (base cells in [cell_lo, cell_hi)) can touch
+        before the next check, i.e. after drifting up to `margin` cells?"""
+        return all(cell_lo[a] - self.margin - 1 >= self.clip[0][a] or self.clip[0][a] == 0 for a in range(3)) and \
+            all(cell_hi[a] + self.margin + 3 <= self.clip[1][a] or self.clip[1][a] == self.res[a] + 1 for a in range(3))
+
+    def set_clip_from_bounds(self, cell_lo, cell_hi):
+        s = self.clip_slack()
+        self.clip = ([max(0, int(cell_lo[a]) - s) for a in range(3)],
+                     [min(self.res[a] + 1, int(cell_hi[a]) + s + 2) for a in range(3)])
 
     def overlap(self, r, s):
         (alo, ahi), (blo, bhi) = self.node_box(r), self.node_box(s)
@@ -199,6 +218,12 @@ class HipEngine:
         if slots > 0.85 * cap:  # dead slots (leavers) pile up: compact at the next sort
             self.sim._check(self.L.mpmhip_request_compaction(self.ctx))
 
+    def active_bounds(self):
+        lo, hi = np.zeros(3, np.int32), np.zeros(3, np.int32)
+        ip = C.POINTER(C.c_int32)
+        self.sim._check(self.L.mpmhip_active_bounds(self.ctx, lo.ctypes.data_as(ip), hi.ctypes.data_as(ip)))
+        return lo, hi
+
     def num_particles(self):
         return self.sim.get_num_particles()
 
@@ -224,6 +249,12 @@ class DistComm:
         o = self.torch.empty_like(t)
         self.dist.all_to_all_single(o, t)
         return o.cpu().numpy()
+
+    def global_bounds(self, lo, hi):
+        t = self.torch.as_tensor(np.concatenate([-np.asarray(lo, np.int64), np.asarray(hi, np.int64)])).to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        t = t.cpu().numpy()
+        return -t[:3], t[3:]
 
 
 # ---------------------------------------------------------------------------------------------------- one rank
@@ -259,6 +290,12 @@ class TiledRank:
         self.e.import_particles(self._recvrec, int(self._incoming.sum()))
         self._sendrec = self._recvrec = None
 
+    def replan(self):
+        """the partition's clip box changed: new halo boxes and buffers"""
+        self.plan = HaloPlan(self.part, self.rank, self.e.alloc)
+        self.e.configure(self.part, self.rank, self.plan)
+        self.replans = getattr(self, "replans", 0) + 1
+
 
 class TiledJob:
     """bench.py job: this process's rank of the tiled run (torch.distributed)"""
@@ -286,6 +323,11 @@ class TiledJob:
         send, recv = r.mig_export(incoming)
         self.comm.all_to_all(recv, send, incoming * MIGRATE_FLOATS, counts * MIGRATE_FLOATS)
         r.mig_import()
+        # keep the halo boxes wrapped around the occupied part of the grid (same decision on every rank)
+        lo, hi = self.comm.global_bounds(*r.e.active_bounds())
+        if (lo <= hi).all() and not r.part.clip_covers(lo, hi):
+            r.part.set_clip_from_bounds(lo, hi)
+            r.replan()
 
     def run(self, n):
         for _ in range(n):
@@ -343,6 +385,14 @@ class VirtualTiledJob:
         self._a2a([b[1] for b in bufs], [b[0] for b in bufs], counts * MIGRATE_FLOATS)
         for r in self.ranks:
             r.mig_import()
+        bounds = [r.e.active_bounds() for r in self.ranks]
+        bounds = [b for b in bounds if (b[0] <= b[1]).all()]
+        if bounds:
+            lo, hi = np.min([b[0] for b in bounds], 0), np.max([b[1] for b in bounds], 0)
+            if not self.part.clip_covers(lo, hi):
+                self.part.set_clip_from_bounds(lo, hi)
+                for r in self.ranks:
+                    r.replan()
 
     def run(self, n):
         for _ in range(n):
@@ -364,7 +414,7 @@ def make_tiled_job(tm, cfg, rank, world, local_rank, margin=4, migrate_interval=
     mine = np.nonzero(part.rank_of_cells(base_cells(x, dx)) == rank)[0]
     sim = tm.create_simulation3("mpm").initialize(dict(
         res=(res,) * 3, delta_x=dx, base_delta_t=1e-4, gravity=(0, -10, 0), device=local_rank,
-        max_particles=int(len(mine) * 1.5) + (1 << 16), reorder_interval=0))
+        max_particles=int(len(mine) * 1.5) + (1 << 16)))
     sim.set_levelset(tm.mpm.LevelSet(friction=-1.0).add_plane((0, 1, 0), d=-0.1))
     sim.add_particles(dict(type=cfg["material"], positions=x[mine]))
     sim.upload(F_ID, mine.astype(np.int32))  # creation ids are global

@@ -95,6 +95,12 @@ class OracleEngine:
         for k in ("x", "v", "B", "F", "aux", "gid", "ids"):
             setattr(s, k, np.ascontiguousarray(getattr(s, k)))
 
+    def active_bounds(self):
+        if self.s.n == 0:
+            return np.full(3, 1 << 30, np.int32), np.full(3, -1, np.int32)
+        b = tiled.base_cells(self.s.x, self.dx)
+        return (b.min(0) // 4 * 4).astype(np.int32), ((b.max(0) // 4 + 1) * 4).astype(np.int32)
+
     def num_particles(self):
         return self.s.n
 

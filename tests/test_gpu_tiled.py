@@ -146,8 +146,13 @@ def test_migration_compacts_when_slots_run_out(tm):
     for sim in sims:
         sim.set_levelset(tm.mpm.LevelSet())
     job = tiled.VirtualTiledJob([tiled.HipEngine(sim, 0) for sim in sims], part, migrate_interval=2)
+    b = tiled.base_cells(s.x, DX)
+    part.clip = (list(map(int, b.min(0) - 3)), list(map(int, b.max(0) + 6)))  # tight: the moving blob forces replans
+    for r in job.ranks:
+        r.replan()
     job.run(50)
     got = _gather(sims)
+    assert all(r.replans >= 2 for r in job.ranks)  # the halo boxes followed the particles
     assert len(got["id"]) == n and np.array_equal(got["id"], np.arange(n))
     through = job.ranks[1].migrated_out
     assert through > 0.5 * own[1], (through, own)  # far more slots were used than the 30 % of slack

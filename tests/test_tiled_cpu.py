@@ -117,6 +117,26 @@ def test_virtual_ranks_match_single_oracle(orc, world, dims):
     _compare(_collect([e.s for e in engines]), ref)
 
 
+def test_halo_boxes_follow_the_particles(orc):
+    """halo boxes are clipped to the occupied part of the grid; when the particles approach the clip box the
+    plan is rebuilt (same decision on all ranks) and the result is unchanged"""
+    s = _state()
+    steps = 6
+    ref = _reference_run(orc, s, steps)
+    part = tiled.Partition.balanced((RES,) * 3, 2, s.x, DX, margin=2)
+    b = tiled.base_cells(s.x, DX)
+    full = tiled.Partition((RES,) * 3, part.dims, part.cuts, 2)
+    part.clip = (list(map(int, b.min(0))), list(map(int, b.max(0) + 3)))  # no slack at all: must replan at once
+    assert sum(tiled.HaloPlan(part, 0, lambda n: torch.empty(int(n))).vol) < \
+        sum(tiled.HaloPlan(full, 0, lambda n: torch.empty(int(n))).vol)  # clipped boxes are smaller
+    owner = part.rank_of_cells(b)
+    engines = [OracleEngine(_cfg(orc), subset(s, owner == r), DX) for r in range(2)]
+    job = tiled.VirtualTiledJob(engines, part, migrate_interval=1)
+    job.run(steps)
+    assert all(getattr(r, "replans", 0) >= 1 for r in job.ranks)
+    _compare(_collect([e.s for e in engines]), ref)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
