@@ -79,7 +79,9 @@ __device__ __forceinline__ void jacobi_rotate(float &app, float &aqq, float &apq
 constexpr int kJacobiSweeps = 4;
 
 // Eigen-decomposition of the symmetric positive semi-definite A = F F^T:  A = U diag(lam) U^T.
-// U is a proper rotation (product of Givens rotations).  Unsorted.
+// U is a proper rotation (product of Givens rotations).  Unsorted.  Cyclic Jacobi converges quadratically; from
+// the third sweep on the wavefront stops as soon as every lane's off-diagonal is below 1e-7 * trace (all users
+// are isotropic functions U f(lam) U^T, whose error is ~f' * |off-diagonal|, also for near-equal eigenvalues).
 __device__ __forceinline__ void sym_eig3_FFt(const mat3 &F, mat3 &U, float lam[3]) {
   float a00 = fmaf(F(0, 0), F(0, 0), fmaf(F(0, 1), F(0, 1), F(0, 2) * F(0, 2)));
   float a11 = fmaf(F(1, 0), F(1, 0), fmaf(F(1, 1), F(1, 1), F(1, 2) * F(1, 2)));
@@ -88,8 +90,10 @@ __device__ __forceinline__ void sym_eig3_FFt(const mat3 &F, mat3 &U, float lam[3
   float a02 = fmaf(F(0, 0), F(2, 0), fmaf(F(0, 1), F(2, 1), F(0, 2) * F(2, 2)));
   float a12 = fmaf(F(1, 0), F(2, 0), fmaf(F(1, 1), F(2, 1), F(1, 2) * F(2, 2)));
   U = mat_identity();
+  const float tol = 1e-7f * (a00 + a11 + a22);
 #pragma unroll
   for (int sweep = 0; sweep < kJacobiSweeps; sweep++) {
+    if (sweep >= 2 && !__any(fmaxf(fabsf(a01), fmaxf(fabsf(a02), fabsf(a12))) > tol)) break;
     jacobi_rotate(a00, a11, a01, a02, a12, U.m[0], U.m[1], U.m[3], U.m[4], U.m[6], U.m[7]);  // (p,q,r)=(0,1,2)
     jacobi_rotate(a00, a22, a02, a01, a12, U.m[0], U.m[2], U.m[3], U.m[5], U.m[6], U.m[8]);  // (0,2,1)
     jacobi_rotate(a11, a22, a12, a01, a02, U.m[1], U.m[2], U.m[4], U.m[5], U.m[7], U.m[8]);  // (1,2,0)

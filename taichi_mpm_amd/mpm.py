@@ -224,6 +224,8 @@ class Simulation3D:
         elif "cube" in cfg:
             lo, hi = cfg["cube"]
             x = lattice_cube(int(lo), int(hi), dx)
+        elif "cube_lo" in cfg:  # cube of `cube_cells`^3 cells with its lower corner at cell cube_lo = (i, j, k)
+            x = lattice_cube(0, int(cfg["cube_cells"]), dx) + (np.asarray(cfg["cube_lo"], np.float64) * dx).astype(np.float32)
         elif "positions" in cfg:
             x = np.ascontiguousarray(cfg["positions"], np.float32).reshape(-1, 3)
         else:

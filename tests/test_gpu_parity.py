@@ -412,3 +412,53 @@ def test_config2_128cubed_1M_jelly_invariants(tm):
 def test_config3_256cubed_8M_sand_invariants(tm):
     """BASELINE config C3: 256^3 grid, 100^3 cells x 8 = 8 000 000 Drucker-Prager sand particles."""
     assert _config_run(tm, 256, 100, "sand", 3) == 8000000
+
+
+def test_config5_512cubed_64M_water_and_elastic_invariants(tm):
+    """BASELINE config C5 on ONE GPU: 512^3 sparse blocked grid, 8 clusters of 100^3 cells x 8 = 64 000 000 particles
+    (4 water, 4 Hencky-elastic).  Size-independent properties: particle count, P2G mass/momentum conservation on the
+    sparse block structure, finite state after stepping, free fall of the centre of mass."""
+    import ctypes as C
+
+    import psutil
+    if psutil.virtual_memory().available < 48 << 30:
+        pytest.skip("needs ~48 GB of host memory for the 64 M-particle staging buffers")
+    from taichi_mpm_amd.mpm import F_AUX, F_V
+    res, cells = 512, 100
+    dx = 1.0 / res
+    n_expected = 8 * cells ** 3 * 8
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(res,) * 3, delta_x=dx, base_delta_t=1e-4,
+                                                       max_particles=n_expected + 1024, reorder_interval=0))
+    k = 0
+    for ox in (78, 334):
+        for oy in (78, 334):
+            for oz in (78, 334):
+                sim.add_particles(dict(type="water" if k % 2 == 0 else "elastic", cube_lo=(ox, oy, oz), cube_cells=cells))
+                k += 1
+    n = sim.get_num_particles()
+    assert n == n_expected
+    sim.sort_particles_and_populate_grid()
+    sim.rasterize_optimized()
+    g0 = sim.get_grid(0)
+    mass = 400.0 * dx ** 3 / 8
+    assert np.isclose(g0[..., 3].sum(dtype=np.float64), n * mass, rtol=1e-6)
+    mom = g0[..., :3].reshape(-1, 3).sum(0, dtype=np.float64)
+    assert np.allclose(mom, [0, n * mass * -10.0 * 1e-4, 0], atol=1e-5 * n * mass * 1e-3)
+    assert int((g0[..., 3] > 0).sum()) == 8 * 103 ** 3  # base cells 77..177 per axis -> nodes 77..179
+    del g0
+    sim.normalize_grid_and_apply_boundary_conditions()
+    sim.resample_optimized()
+    steps = 3
+    sim.run_substeps(steps)
+    sim.synchronize()
+    prof = sim.profile()
+    assert prof["particles"] == n and prof["active_blocks"] == 8 * 26 ** 3  # cells 78..177 -> base 77..177: 26 blocks
+    v = np.zeros((n, 3), np.float32)
+    assert sim._check(sim._L.mpmhip_download(sim._ctx, F_V, v.ctypes.data_as(C.c_void_p), n)) == n
+    assert np.all(np.isfinite(v))
+    assert np.allclose(v[:, 1].mean(dtype=np.float64), -10.0 * (steps + 1) * 1e-4, rtol=2e-3)
+    del v
+    aux = np.zeros(n, np.float32)
+    assert sim._check(sim._L.mpmhip_download(sim._ctx, F_AUX, aux.ctypes.data_as(C.c_void_p), n)) == n
+    assert np.all(np.isfinite(aux)) and aux.max() <= 1.001  # water j stays ~1 in free fall; elastic aux = 0
+    sim.close()
