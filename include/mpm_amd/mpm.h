@@ -64,6 +64,7 @@ class MPM<3> {
     cfg_.max_blocks = (int64_t)config.get("max_blocks", 0.0);
     cfg_.device = config.get("device", 0);
     cfg_.discard_apic_b = !config.get("keep_apic_b", false);
+    cfg_.particle_collision = config.get("particle_collision", false);  // src/mpm.cpp:566-569
     check(mpmhip_create(&cfg_, &ctx_), nullptr);
     frame = 0;
   }
@@ -73,6 +74,11 @@ class MPM<3> {
     std::vector<float> flat;
     for (auto &p : planes) flat.insert(flat.end(), p.begin(), p.end());
     check(mpmhip_set_levelset(ctx_, (int32_t)planes.size(), flat.data(), friction), ctx_);
+  }
+
+  // general form: planes, spheres, axis-aligned cuboids (taichi LevelSet::add_plane / add_sphere / add_cuboid)
+  void set_levelset(const std::vector<mpmhip_shape> &shapes, real friction) {
+    check(mpmhip_set_levelset_shapes(ctx_, (int32_t)shapes.size(), shapes.data(), friction), ctx_);
   }
 
   // --- MPM<dim>::add_particles (src/mpm.cpp:77-270).  Sampling: the built-in benchmark generator

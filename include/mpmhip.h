@@ -86,11 +86,12 @@ typedef struct {
   int32_t reorder_interval; /* "reorder_interval" (src/mpm.cpp:45,811-813): physical reorder of the particle records
                                into sorted order every this many substeps; 0 = never (the sorted INDEX is rebuilt
                                every substep regardless) */
+  int32_t particle_collision; /* "particle_collision" (default 0): particle_collision_resolution after G2P, src/mpm.cpp:414-426,566-569 */
   int32_t discard_apic_b;   /* 1 = G2P does not store apic_b: it lives on folded into the P2G affine matrix
                                A = stress*(-4 inv_dx dt) + apic_b*(4 m) (src/transfer.cpp:521-522), which is the state
                                the next substep consumes (-48 of 180 stored bytes per particle-step).  download(B)
                                then recovers apic_b = (A - stress(F) S)/(4 m) on demand, to ~1e-5..1e-4 relative */
-  int32_t reserved[5];
+  int32_t reserved[4];
 } mpmhip_config;
 
 typedef struct mpmhip_ctx mpmhip_ctx;
@@ -115,6 +116,19 @@ const char *mpmhip_last_error(const mpmhip_ctx *ctx); /* ctx may be NULL: last c
 int mpmhip_set_stream(mpmhip_ctx *ctx, void *hip_stream); /* NULL = the ctx's own stream */
 /* replaces Simulation::set_levelset(DynamicLevelSet) (scripts/async/async_mpm.py:119-127) for analytic half-spaces */
 int mpmhip_set_levelset(mpmhip_ctx *ctx, int32_t n_planes, const float *planes /* [n][4] */, float friction);
+
+/* general analytic level set: union of up to MPMHIP_MAX_SHAPES solids, phi = min over shapes, negative inside a
+ * solid; replaces the LevelSet the scene scripts build with add_plane / add_sphere / add_cuboid
+ * (e.g. scripts/mls-cpic/goo_blocks.py:17-20, scripts/async/sand.py:34-37).  World units.
+ *   type 0 plane  p = {nx, ny, nz, d}            phi = n.x + d            (|n| = 1)
+ *   type 1 sphere p = {cx, cy, cz, r}            solid ball;  inside_out = 1: the ball is the FREE space
+ *   type 2 cuboid p = {lo x,y,z, hi x,y,z}       solid box;   inside_out = 1: the box is a container */
+#define MPMHIP_MAX_SHAPES 16
+typedef struct {
+  int32_t type, inside_out;
+  float p[6];
+} mpmhip_shape;
+int mpmhip_set_levelset_shapes(mpmhip_ctx *ctx, int32_t n, const mpmhip_shape *shapes, float friction);
 
 /* particles — replaces MPM<3>::add_particles (src/mpm.cpp:77-270) with caller-generated samples.
  * add_group returns the group id (>=0) or a negative error. F/B/aux may be NULL (identity/0/material default). */

@@ -288,6 +288,21 @@ void orc_g2p(const orc_config *c, int64_t n, float *x, float *v, float *B, float
   }
 }
 
+// MPM<dim>::particle_collision_resolution — src/mpm.cpp:414-426: a particle inside the level set (phi < 0) is
+// moved back to the surface along the gradient and loses the normal component of its velocity.
+void orc_particle_collision(const orc_config *c, int64_t n, float *x, float *v) {
+  const real idx = 1.0f / c->dx;
+  for (int64_t p = 0; p < n; p++) {
+    real pos[3] = {x[3 * p] * idx, x[3 * p + 1] * idx, x[3 * p + 2] * idx}, phi, g[3] = {0, 0, 0};
+    if (!levelset_eval(c, pos, phi, g) || !(phi < 0)) continue;
+    real vn = g[0] * v[3 * p] + g[1] * v[3 * p + 1] + g[2] * v[3 * p + 2];
+    for (int k = 0; k < 3; k++) {
+      x[3 * p + k] -= g[k] * phi * c->dx;
+      v[3 * p + k] -= vn * g[k];
+    }
+  }
+}
+
 int64_t orc_clear_boundary(const orc_config *c, int64_t n, const float *x, const float *v, uint8_t *keep) {
   int64_t cnt = 0;
   for (int64_t p = 0; p < n; p++) {
@@ -315,6 +330,7 @@ int64_t orc_substep(const orc_config *c, int64_t n, float *x, float *v, float *B
     }
     m++;
   }
+  if (c->particle_collision) orc_particle_collision(c, m, x, v);  // src/mpm.cpp:566-569 (after the clean-up)
   return m;
 }
 

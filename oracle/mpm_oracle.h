@@ -65,6 +65,13 @@ typedef struct {
   int32_t n_planes;
   float planes[8][4];
   float friction;          /* levelset0->friction: -1 sticky, <=-2 slip, >=0 separate */
+  /* further analytic solids, also combined by min (taichi LevelSet::add_sphere / add_cuboid as the scene
+   * scripts use them, e.g. scripts/mls-cpic; the sampled implementation itself is in the un-vendored
+   * taichi core): type 1 sphere {cx,cy,cz,r}; type 2 axis-aligned cuboid {lo xyz, hi xyz}; world units.
+   * inside_out = 1: the FREE space is the inside of the shape (a container). */
+  int32_t n_shapes;
+  struct { int32_t type, inside_out; float p[6]; } shapes[8];
+  int32_t particle_collision; /* src/mpm.cpp:566-569, :414-426: push particles out of the level set after G2P */
 } orc_config;
 
 /* --- kernel weights (src/kernel.h:103-135,168-210; src/transfer.cpp:162-191) */
@@ -108,6 +115,8 @@ void orc_g2p(const orc_config* c, int64_t n, float* x, float* v, float* B, float
 /* clear_boundary_particles: src/mpm.cpp:582-633, src/mpm.h:269-276. keep[i]=1 if the particle survives.
  * (also drops particles whose stencil would leave the grid — the reference has UB there) */
 int64_t orc_clear_boundary(const orc_config* c, int64_t n, const float* x, const float* v, uint8_t* keep);
+/* particle_collision_resolution: src/mpm.cpp:414-426 */
+void orc_particle_collision(const orc_config* c, int64_t n, float* x, float* v);
 /* one full substep on SoA arrays; particles are compacted in place (stable); returns new n.
  * ids (may be NULL) is permuted along. grid is scratch of the dense size. */
 int64_t orc_substep(const orc_config* c, int64_t n, float* x, float* v, float* B, float* F, float* aux,

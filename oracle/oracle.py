@@ -18,12 +18,17 @@ TYPE_IDS = {"visco": VISCO, "snow": SNOW, "linear": LINEAR, "jelly": JELLY, "wat
             "sand": SAND, "von_mises": VON_MISES, "elastic": ELASTIC}
 
 
+class Shape(C.Structure):
+    _fields_ = [("type", C.c_int32), ("inside_out", C.c_int32), ("p", C.c_float * 6)]
+
+
 class Config(C.Structure):
     _fields_ = [("res", C.c_int32 * 3), ("dx", C.c_float), ("dt", C.c_float),
                 ("gravity", C.c_float * 3), ("particle_gravity", C.c_int32),
                 ("apic_damping", C.c_float), ("rpic_damping", C.c_float),
                 ("clean_boundary", C.c_int32), ("n_planes", C.c_int32),
-                ("planes", (C.c_float * 4) * 8), ("friction", C.c_float)]
+                ("planes", (C.c_float * 4) * 8), ("friction", C.c_float), ("n_shapes", C.c_int32),
+                ("shapes", Shape * 8), ("particle_collision", C.c_int32)]
 
 
 def build():
@@ -47,7 +52,8 @@ def lib():
 
 
 def make_config(res, dx, dt, gravity=(0, -10, 0), particle_gravity=True, apic_damping=0.0,
-                rpic_damping=0.0, clean_boundary=True, planes=(), friction=-1.0):
+                rpic_damping=0.0, clean_boundary=True, planes=(), friction=-1.0, shapes=(), particle_collision=False):
+    """shapes: [(type, inside_out, params...)] with type 1 = sphere (cx, cy, cz, r), 2 = cuboid (lo xyz, hi xyz)"""
     c = Config()
     if np.isscalar(res):
         res = (res,) * 3
@@ -63,6 +69,12 @@ def make_config(res, dx, dt, gravity=(0, -10, 0), particle_gravity=True, apic_da
     for i, p in enumerate(planes):
         c.planes[i][:] = [float(v) for v in p]
     c.friction = friction
+    c.n_shapes = len(shapes)
+    for i, sh in enumerate(shapes):
+        c.shapes[i].type, c.shapes[i].inside_out = int(sh[0]), int(bool(sh[1]))
+        vals = [float(v) for v in sh[2:]]
+        c.shapes[i].p[:] = vals + [0.0] * (6 - len(vals))
+    c.particle_collision = int(bool(particle_collision))
     return c
 
 
@@ -272,6 +284,10 @@ def g2p(cfg, s, grid):
     grid = np.ascontiguousarray(grid, np.float32)
     lib().orc_g2p(C.byref(cfg), C.c_int64(s.n), _pf(s.x), _pf(s.v), _pf(s.B), _pf(s.F), _pf(s.aux),
                   _pi(s.gid), _pf(s.gparams), _pi(s.gtype), _pf(grid))
+
+
+def particle_collision(cfg, s):
+    lib().orc_particle_collision(C.byref(cfg), C.c_int64(s.n), _pf(s.x), _pf(s.v))
 
 
 def clear_boundary(cfg, s):

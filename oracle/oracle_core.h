@@ -396,14 +396,53 @@ inline int64_t node_index(const orc_config *c, int i, int j, int k) {
   return ((int64_t)i * (c->res[1] + 1) + j) * (c->res[2] + 1) + k;
 }
 
-// level set in grid units at a node (reference: levelset.sample(pos,t) / get_spatial_gradient, src/mpm.cpp:323-326)
+// level set in grid units at a grid-unit position: phi and its (unit) spatial gradient
+// (reference: levelset.sample(pos,t) / get_spatial_gradient(pos,t), src/mpm.cpp:323-326,416-421)
 inline bool levelset_eval(const orc_config *c, const real pos_grid[3], real &phi, real n[3]) {
-  if (c->n_planes <= 0) return false;
+  if (c->n_planes <= 0 && c->n_shapes <= 0) return false;
+  const real idx = 1.0f / c->dx;
+  const real x[3] = {pos_grid[0] * c->dx, pos_grid[1] * c->dx, pos_grid[2] * c->dx};
   phi = 1e30f;
   for (int p = 0; p < c->n_planes; p++) {
     const float *pl = c->planes[p];
-    real ph = (pl[0] * pos_grid[0] * c->dx + pl[1] * pos_grid[1] * c->dx + pl[2] * pos_grid[2] * c->dx + pl[3]) / c->dx;
+    real ph = (pl[0] * x[0] + pl[1] * x[1] + pl[2] * x[2] + pl[3]) * idx;
     if (ph < phi) { phi = ph; n[0] = pl[0]; n[1] = pl[1]; n[2] = pl[2]; }
+  }
+  for (int s = 0; s < c->n_shapes; s++) {
+    const float *q = c->shapes[s].p;
+    real ph, g[3];
+    if (c->shapes[s].type == 1) {  // sphere: distance to the surface, negative inside the ball
+      real d[3] = {x[0] - q[0], x[1] - q[1], x[2] - q[2]};
+      real len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      real inv = len > 0 ? 1.0f / len : 0.0f;
+      ph = len - q[3];
+      for (int k = 0; k < 3; k++) g[k] = d[k] * inv;
+    } else {  // cuboid: negative inside the box (distance to the nearest face), Euclidean distance outside
+      bool inside = true;
+      real near[3];
+      for (int k = 0; k < 3; k++) {
+        inside = inside && q[k] <= x[k] && x[k] <= q[3 + k];
+        near[k] = std::min(std::max(x[k], q[k]), q[3 + k]);
+      }
+      g[0] = g[1] = g[2] = 0;
+      if (inside) {
+        real best = 1e30f;
+        for (int k = 0; k < 3; k++) {
+          real dlo = x[k] - q[k], dhi = q[3 + k] - x[k];
+          if (dlo < best) { best = dlo; g[0] = g[1] = g[2] = 0; g[k] = -1; }
+          if (dhi < best) { best = dhi; g[0] = g[1] = g[2] = 0; g[k] = 1; }
+        }
+        ph = -best;
+      } else {
+        real d[3] = {x[0] - near[0], x[1] - near[1], x[2] - near[2]};
+        real len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        ph = len;
+        for (int k = 0; k < 3; k++) g[k] = d[k] / len;
+      }
+    }
+    if (c->shapes[s].inside_out) { ph = -ph; g[0] = -g[0]; g[1] = -g[1]; g[2] = -g[2]; }
+    ph *= idx;
+    if (ph < phi) { phi = ph; n[0] = g[0]; n[1] = g[1]; n[2] = g[2]; }
   }
   return true;
 }

@@ -23,8 +23,16 @@ class Config(C.Structure):
                 ("particle_gravity", C.c_int32), ("apic_damping", C.c_float), ("rpic_damping", C.c_float),
                 ("clean_boundary", C.c_int32), ("n_planes", C.c_int32), ("planes", (C.c_float * 4) * 8),
                 ("friction", C.c_float), ("max_particles", C.c_int64), ("max_blocks", C.c_int64),
-                ("device", C.c_int32), ("reorder_interval", C.c_int32), ("discard_apic_b", C.c_int32),
-                ("reserved", C.c_int32 * 5)]
+                ("device", C.c_int32), ("reorder_interval", C.c_int32), ("particle_collision", C.c_int32),
+                ("discard_apic_b", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+class Shape(C.Structure):
+    """mirror of mpmhip_shape"""
+    _fields_ = [("type", C.c_int32), ("inside_out", C.c_int32), ("p", C.c_float * 6)]
+
+
+MAX_SHAPES = 16
 
 
 class HaloBox(C.Structure):
@@ -64,7 +72,7 @@ def build(force=False, verbose=False):
 
 _lib = None
 
-_SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_last_error", "mpmhip_set_stream", "mpmhip_set_levelset",
+_SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_last_error", "mpmhip_set_stream", "mpmhip_set_levelset", "mpmhip_set_levelset_shapes",
             "mpmhip_add_group", "mpmhip_add_particles", "mpmhip_num_particles", "mpmhip_download",
             "mpmhip_upload", "mpmhip_substep", "mpmhip_run_substeps", "mpmhip_step", "mpmhip_current_time",
             "mpmhip_synchronize", "mpmhip_sort", "mpmhip_p2g", "mpmhip_grid_update", "mpmhip_g2p",
@@ -105,6 +113,7 @@ def load():
     L.mpmhip_last_error.restype = C.c_char_p
     L.mpmhip_set_stream.argtypes = [vp, vp]
     L.mpmhip_set_levelset.argtypes = [vp, C.c_int32, fp, C.c_float]
+    L.mpmhip_set_levelset_shapes.argtypes = [vp, C.c_int32, P(Shape), C.c_float]
     L.mpmhip_add_group.argtypes = [vp, C.c_int32, fp]
     L.mpmhip_add_particles.argtypes = [vp, C.c_int32, C.c_int64, fp, fp, fp, fp, fp]
     L.mpmhip_num_particles.argtypes = [vp]

@@ -405,6 +405,65 @@ __device__ __forceinline__ void friction_project(float v[3], const float vb[3], 
   v[2] = ts * t2 + keep * n[2] + vb[2];
 }
 
+// Analytic level set: union of solids, phi = min over primitives, negative inside a solid (reference: taichi's
+// sampled LevelSet built by add_plane / add_sphere / add_cuboid in the scene scripts; sample() and
+// get_spatial_gradient() as used in src/mpm.cpp:323-326 and :416-421).  Returns phi in grid units and the unit
+// gradient of the active primitive.
+struct LevelSetDev {
+  int n;
+  float friction;
+  int particle_collision;
+  int pad;
+  struct { int type, inside_out; float p[6]; } s[MPMHIP_MAX_SHAPES];  // type 0 plane {n, d}, 1 sphere, 2 cuboid
+};
+
+__device__ __forceinline__ bool levelset_eval(const LevelSetDev &L, const float x[3], float idx, float &phi, float n[3]) {
+  if (L.n <= 0) return false;
+  phi = 1e30f;
+  for (int i = 0; i < L.n; i++) {
+    const float *q = L.s[i].p;
+    float ph, g[3];
+    if (L.s[i].type == 0) {
+      ph = q[0] * x[0] + q[1] * x[1] + q[2] * x[2] + q[3];
+      g[0] = q[0]; g[1] = q[1]; g[2] = q[2];
+    } else if (L.s[i].type == 1) {
+      const float d0 = x[0] - q[0], d1 = x[1] - q[1], d2 = x[2] - q[2];
+      const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+      const float inv = len > 0.0f ? 1.0f / len : 0.0f;
+      ph = len - q[3];
+      g[0] = d0 * inv; g[1] = d1 * inv; g[2] = d2 * inv;
+    } else {
+      bool inside = true;
+      float near[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        inside = inside && q[k] <= x[k] && x[k] <= q[3 + k];
+        near[k] = fminf(fmaxf(x[k], q[k]), q[3 + k]);
+      }
+      g[0] = g[1] = g[2] = 0.0f;
+      if (inside) {
+        float best = 1e30f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const float dlo = x[k] - q[k], dhi = q[3 + k] - x[k];
+          if (dlo < best) { best = dlo; g[0] = g[1] = g[2] = 0.0f; g[k] = -1.0f; }
+          if (dhi < best) { best = dhi; g[0] = g[1] = g[2] = 0.0f; g[k] = 1.0f; }
+        }
+        ph = -best;
+      } else {
+        const float d0 = x[0] - near[0], d1 = x[1] - near[1], d2 = x[2] - near[2];
+        const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+        ph = len;
+        g[0] = d0 / len; g[1] = d1 / len; g[2] = d2 / len;
+      }
+    }
+    if (L.s[i].type != 0 && L.s[i].inside_out) { ph = -ph; g[0] = -g[0]; g[1] = -g[1]; g[2] = -g[2]; }
+    ph *= idx;
+    if (ph < phi) { phi = ph; n[0] = g[0]; n[1] = g[1]; n[2] = g[2]; }
+  }
+  return true;
+}
+
 // quadratic B-spline weights of MLSMPMFastKernel32 (src/transfer.cpp:168-186; src/kernel.h:126-130):
 // p = rel_pos - 0.5 in [0,1);  t = p - (-0.5, 0.5, 1.5);  w = fma(c2, t*t, fma(c1, t, c0))
 __device__ __forceinline__ void bspline_weights(float rel, float w[3]) {

@@ -92,9 +92,6 @@ struct Params {
   int particle_gravity;
   float apic_damping, rpic_damping;
   int clean_boundary;
-  int n_planes;
-  float planes[8][4];
-  float friction;
   int kbits;         // Morton bits per axis
   uint32_t nbw;      // bitmap words = 8^kbits / 32
   uint32_t max_blocks;
@@ -647,7 +644,7 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
                                               const uint32_t *__restrict__ wprefix,
                                               const float4 *__restrict__ tiles, float4 *__restrict__ gridv,
                                               uint32_t *__restrict__ fat_slot, float4 *__restrict__ dense, Tiling T,
-                                              const DevBox *__restrict__ boxes) {
+                                              const DevBox *__restrict__ boxes, LevelSetDev LS) {
   const uint32_t na = min(cnt->n_active, P.max_blocks);
   const int l = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -754,16 +751,13 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
 #pragma unroll
         for (int k = 0; k < 3; k++) v[k] = fmaf(v[k], im, P.particle_gravity ? 0.0f : P.g[k] * P.dt);
       }
-      if (m != 0.0f && P.n_planes > 0) {  // src/mpm.cpp:313-368
-        float phi = 1e30f, nrm[3] = {0, 0, 0};
-        for (int p = 0; p < P.n_planes; p++) {
-          const float ph = (P.planes[p][0] * (gi * P.dx) + P.planes[p][1] * (gj * P.dx) + P.planes[p][2] * (gk * P.dx) +
-                            P.planes[p][3]) * P.idx;
-          if (ph < phi) { phi = ph; nrm[0] = P.planes[p][0]; nrm[1] = P.planes[p][1]; nrm[2] = P.planes[p][2]; }
-        }
+      if (m != 0.0f && LS.n > 0) {  // src/mpm.cpp:313-368
+        const float xw[3] = {gi * P.dx, gj * P.dx, gk * P.dx};
+        float phi, nrm[3] = {0, 0, 0};
+        levelset_eval(LS, xw, P.idx, phi, nrm);
         if (!(phi < -3.0f || 0.0f < phi)) {
           const float vb[3] = {0, 0, 0};
-          friction_project(v, vb, nrm, P.friction);
+          friction_project(v, vb, nrm, LS.friction);
         }
       }
       gridv[(size_t)slot * BC + l] = make_float4(v[0], v[1], v[2], m);
@@ -926,7 +920,8 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
                                                   const GroupParams *__restrict__ groups,
                                                   const float4 *__restrict__ gridv,
                                                   const uint32_t *__restrict__ fat_slot, Counters *cnt_w,
-                                                  uint32_t *__restrict__ key, uint8_t *__restrict__ blk_flag) {
+                                                  uint32_t *__restrict__ key, uint8_t *__restrict__ blk_flag,
+                                                  LevelSetDev LS) {
   __shared__ float4 tile[TN];
   // Store staging, one slab per wavefront.  A lane holds its particle's whole record, so a direct store would
   // issue 16-byte pieces at a 64-byte stride: 64 partial-line write requests per instruction (measured: the
@@ -1070,7 +1065,16 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
       mat3 stress;
       if (!(P.ablate & 2)) plasticity_and_force(g, cdg, F, aux, stress);  // :950 + next substep's :509
       else stress = cdg;
-      const float nx0 = fmaf(v0, P.dt, x0), nx1 = fmaf(v1, P.dt, x1), nx2 = fmaf(v2, P.dt, x2);  // :951
+      float nx0 = fmaf(v0, P.dt, x0), nx1 = fmaf(v1, P.dt, x1), nx2 = fmaf(v2, P.dt, x2);  // :951
+      if (LS.particle_collision) {  // particle_collision_resolution, src/mpm.cpp:414-426 (runs after G2P, :566-569)
+        const float xw[3] = {nx0, nx1, nx2};
+        float phi, gr[3] = {0, 0, 0};
+        if (levelset_eval(LS, xw, P.idx, phi, gr) && phi < 0.0f) {
+          const float vn = gr[0] * v0 + gr[1] * v1 + gr[2] * v2;
+          nx0 -= gr[0] * phi * P.dx; nx1 -= gr[1] * phi * P.dx; nx2 -= gr[2] * phi * P.dx;
+          v0 -= vn * gr[0]; v1 -= vn * gr[1]; v2 -= vn * gr[2];
+        }
+      }
       const float m4 = 4.0f * g.p[0];
       float A[9];
 #pragma unroll
@@ -1235,6 +1239,7 @@ struct mpmhip_ctx {
   int ev_level = 0;  // level the pooled events were recorded with
   Ev *cur_ev = nullptr;  // events of the substep between substep_begin and substep_end
   // tiling
+  LevelSetDev LS;
   Tiling T;
   DevBox *d_boxes = nullptr;
   uint32_t *d_counts = nullptr;
@@ -1327,10 +1332,12 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   }
   P.dx = cfg->dx; P.idx = 1.0f / cfg->dx; P.dt = cfg->dt;
   P.particle_gravity = cfg->particle_gravity; P.apic_damping = cfg->apic_damping; P.rpic_damping = cfg->rpic_damping;
-  P.clean_boundary = cfg->clean_boundary; P.n_planes = cfg->n_planes; P.friction = cfg->friction;
+  P.clean_boundary = cfg->clean_boundary;
   P.store_b = cfg->discard_apic_b ? 0 : 1;
   P.ablate = ablate;
-  memcpy(P.planes, cfg->planes, sizeof P.planes);
+  memset(&c->LS, 0, sizeof c->LS);
+  c->LS.particle_collision = cfg->particle_collision;
+  if (mpmhip_set_levelset(c, cfg->n_planes, &cfg->planes[0][0], cfg->friction) != MPMHIP_OK) return bail(MPMHIP_EINVAL);
   int kbits = 1;
   while ((1 << kbits) < maxnb) kbits++;
   if (kbits > 8) { fail(c, MPMHIP_EINVAL, "grid too large for 32-bit keys"); return bail(MPMHIP_EINVAL); }
@@ -1414,14 +1421,32 @@ int mpmhip_set_stream(mpmhip_ctx *c, void *s) {
   return MPMHIP_OK;
 }
 
+int mpmhip_set_levelset_shapes(mpmhip_ctx *c, int32_t n, const mpmhip_shape *shapes, float friction) {
+  if (!c || n < 0 || n > MPMHIP_MAX_SHAPES || (n > 0 && !shapes)) return MPMHIP_EINVAL;
+  for (int i = 0; i < n; i++) {
+    if (shapes[i].type < 0 || shapes[i].type > 2) return fail(c, MPMHIP_EINVAL, "shape %d: unknown type %d", i, shapes[i].type);
+    if (shapes[i].type == 1 && !(shapes[i].p[3] > 0)) return fail(c, MPMHIP_EINVAL, "shape %d: sphere radius must be > 0", i);
+    if (shapes[i].type == 2)
+      for (int k = 0; k < 3; k++)
+        if (!(shapes[i].p[k] < shapes[i].p[3 + k])) return fail(c, MPMHIP_EINVAL, "shape %d: cuboid needs lo < hi", i);
+  }
+  c->LS.n = n;
+  c->LS.friction = friction;
+  for (int i = 0; i < n; i++) {
+    c->LS.s[i].type = shapes[i].type;
+    c->LS.s[i].inside_out = shapes[i].inside_out;
+    for (int k = 0; k < 6; k++) c->LS.s[i].p[k] = shapes[i].p[k];
+  }
+  return MPMHIP_OK;
+}
+
 int mpmhip_set_levelset(mpmhip_ctx *c, int32_t n_planes, const float *planes, float friction) {
   if (!c || n_planes < 0 || n_planes > 8 || (n_planes > 0 && !planes)) return MPMHIP_EINVAL;
-  c->P.n_planes = n_planes;
-  c->cfg.n_planes = n_planes;
+  mpmhip_shape sh[8];
+  memset(sh, 0, sizeof sh);
   for (int i = 0; i < n_planes; i++)
-    for (int k = 0; k < 4; k++) c->P.planes[i][k] = c->cfg.planes[i][k] = planes[4 * i + k];
-  c->P.friction = c->cfg.friction = friction;
-  return MPMHIP_OK;
+    for (int k = 0; k < 4; k++) sh[i].p[k] = planes[4 * i + k];
+  return mpmhip_set_levelset_shapes(c, n_planes, sh, friction);
 }
 
 int mpmhip_add_group(mpmhip_ctx *c, int32_t material, const float params[MPMHIP_NPARAM]) {
@@ -1678,7 +1703,7 @@ static int do_grid(mpmhip_ctx *c, int mode) {
   auto kern = mode == 0 ? (per_cand ? k_grid<0, true> : k_grid<0, false>)
                         : (mode == 1 ? k_grid<1, false> : (mode == 2 ? k_grid<2, false> : k_grid<3, false>));
   hipLaunchKernelGGL(kern, dim3(per_cand ? 16384 : 4096), dim3(256), 0, c->stream, c->P, c->cnt, c->act_blk, c->bits, c->wprefix, c->tiles,
-                     c->gridv, c->fat_slot, c->dense, c->T, (const DevBox *)c->d_boxes);
+                     c->gridv, c->fat_slot, c->dense, c->T, (const DevBox *)c->d_boxes, c->LS);
   return launch_check(c, "grid");
 }
 static int do_g2p(mpmhip_ctx *c) {
@@ -1692,7 +1717,7 @@ static int do_g2p(mpmhip_ctx *c) {
   }
   hipLaunchKernelGGL(kern, dim3(4096), dim3(256), 0, c->stream, c->P, (float4 *)c->rg, (float4 *)c->rp, (float4 *)c->rb,
                      c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
-                     c->blk_flag);
+                     c->blk_flag, c->LS);
   c->sorted = false;       // positions moved
   c->keys_valid = true;    // ... and their keys / block flags are ready for the next sort
   c->affine_valid = true;  // A was produced together with F

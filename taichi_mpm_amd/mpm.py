@@ -31,15 +31,25 @@ class MPMError(RuntimeError):
 
 
 class LevelSet:
-    """Analytic stand-in for taichi's LevelSet (scripts/async/async_mpm.py:129-137 `create_levelset`):
-    a union of half-space solids with one friction code (README.md:326-330)."""
+    """Analytic stand-in for taichi's LevelSet (scripts/async/async_mpm.py:129-137 `create_levelset`): a union of
+    solids — half-spaces, spheres, axis-aligned cuboids — with one friction code (README.md:326-330).  Method names
+    and argument order follow the calls the scene scripts make (`add_plane(normal, d)`, `add_sphere(center, radius,
+    inside_out)`, `add_cuboid(lower, upper, inside_out)`, `set_friction(f)`)."""
 
     def __init__(self, friction=-1.0):
         self.friction = float(friction)
-        self.planes = []
+        self.shapes = []  # (type, inside_out, p[6]) — include/mpmhip.h: mpmhip_shape
 
     def set_friction(self, f):
         self.friction = float(f)
+        return self
+
+    def _add(self, type_, inside_out, p):
+        if len(self.shapes) >= _lib.MAX_SHAPES:
+            raise MPMError("at most %d level-set shapes are supported" % _lib.MAX_SHAPES)
+        p = [float(v) for v in p]
+        self.shapes.append((int(type_), int(bool(inside_out)), p + [0.0] * (6 - len(p))))
+        return self
 
     def add_plane(self, normal, d=None, point=None):
         """free space is { x : n.x + d > 0 }.  Either `d` or a `point` on the plane."""
@@ -47,10 +57,26 @@ class LevelSet:
         n = n / np.linalg.norm(n)
         if d is None:
             d = -float(np.dot(n, np.asarray(point, np.float64)))
-        if len(self.planes) >= 8:
-            raise MPMError("at most 8 planes are supported")
-        self.planes.append((float(n[0]), float(n[1]), float(n[2]), float(d)))
-        return self
+        return self._add(0, 0, [n[0], n[1], n[2], d])
+
+    def add_sphere(self, center, radius, inside_out=False):
+        """solid ball; inside_out=True: the ball is the free space (e.g. scripts/mls-cpic: add_sphere(c, 0.3, True))"""
+        c = _vec3(center, None)
+        return self._add(1, inside_out, [c[0], c[1], c[2], radius])
+
+    def add_cuboid(self, lower, upper, inside_out=False):
+        """solid box; inside_out=True: the box is a container (e.g. add_cuboid((0,.2,.05), (.95,.95,.95), True))"""
+        lo, hi = _vec3(lower, None), _vec3(upper, None)
+        return self._add(2, inside_out, list(lo) + list(hi))
+
+    @property
+    def planes(self):
+        return [tuple(p[:4]) for t_, _, p in self.shapes if t_ == 0]
+
+    @property
+    def non_planes(self):
+        """(type, inside_out, params...) rows in the form oracle.make_config(shapes=...) takes"""
+        return [(t_, io) + tuple(p[:4] if t_ == 1 else p) for t_, io, p in self.shapes if t_ != 0]
 
 
 def _vec3(v, default):
@@ -98,6 +124,7 @@ class Simulation3D:
         self.apic_damping = float(cfg.get("apic_damping", 0.0))
         self.rpic_damping = float(cfg.get("rpic_damping", 0.0))
         self.clean_boundary = bool(cfg.get("clean_boundary", True))
+        self.particle_collision = bool(cfg.get("particle_collision", False))  # src/mpm.cpp:566-569
         self.reorder_interval = int(cfg.get("reorder_interval", 1000))  # src/mpm.cpp:45
         # apic_b is only ever consumed through the P2G affine matrix A, which is stored; keeping a separate copy
         # costs 48 of the 180 bytes G2P writes per particle.  keep_apic_b=True stores it (exact downloads of B);
@@ -117,12 +144,8 @@ class Simulation3D:
         c.particle_gravity = int(self.particle_gravity)
         c.apic_damping, c.rpic_damping = self.apic_damping, self.rpic_damping
         c.clean_boundary = int(self.clean_boundary)
-        ls = self._levelset
-        c.n_planes = len(ls.planes) if ls else 0
-        if ls:
-            for i, p in enumerate(ls.planes):
-                c.planes[i][:] = p
-            c.friction = ls.friction
+        c.n_planes = 0  # the level set (any mix of shapes) is installed right after creation
+        c.particle_collision = int(self.particle_collision)
         c.max_particles = int(capacity)
         c.max_blocks = self.max_blocks
         c.device = self.device
@@ -133,6 +156,7 @@ class Simulation3D:
         if rc != 0:
             raise MPMError("mpmhip_create failed (%d): %s" % (rc, self._L.mpmhip_last_error(None).decode()))
         self._ctx, self._cfg, self._capacity = ctx, c, int(capacity)
+        self._apply_levelset()
         for mat, params in self._groups:
             self._check(self._L.mpmhip_add_group(self._ctx, mat, params.ctypes.data_as(C.POINTER(C.c_float))))
 
@@ -293,9 +317,17 @@ class Simulation3D:
             raise MPMError("dynamic level sets are outside the scope of this build")
         self._levelset = levelset
         if self._ctx is not None:
-            pl = np.asarray(levelset.planes, np.float32).reshape(-1, 4)
-            self._check(self._L.mpmhip_set_levelset(self._ctx, len(pl), pl.ctypes.data_as(C.POINTER(C.c_float)),
-                                                    levelset.friction))
+            self._apply_levelset()
+
+    def _apply_levelset(self):
+        ls = self._levelset
+        if ls is None:
+            return
+        arr = (_lib.Shape * max(len(ls.shapes), 1))()
+        for i, (t_, io, p) in enumerate(ls.shapes):
+            arr[i].type, arr[i].inside_out = t_, io
+            arr[i].p[:] = p
+        self._check(self._L.mpmhip_set_levelset_shapes(self._ctx, len(ls.shapes), arr, ls.friction))
 
     # ---------------------------------------------------------------- stepping
     def step(self, dt):

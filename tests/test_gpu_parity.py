@@ -462,3 +462,51 @@ def test_config5_512cubed_64M_water_and_elastic_invariants(tm):
     assert sim._check(sim._L.mpmhip_download(sim._ctx, F_AUX, aux.ctypes.data_as(C.c_void_p), n)) == n
     assert np.all(np.isfinite(aux)) and aux.max() <= 1.001  # water j stays ~1 in free fall; elastic aux = 0
     sim.close()
+
+
+# ------------------------------------------------------------------------------------------ level-set shapes
+SHAPE_SCENES = {
+    "ball": dict(shapes=[(1, 0, 0.45, 0.2, 0.45, 0.12)], friction=0.3),
+    "box": dict(shapes=[(2, 0, 0.2, 0.1, 0.2, 0.5, 0.31, 0.5)], friction=-1.0),
+    "container": dict(shapes=[(2, 1, 0.27, 0.27, 0.27, 0.56, 0.56, 0.56)], friction=-2.0),
+    "plane+ball": dict(planes=[(0.0, 1.0, 0.0, -0.3)], shapes=[(1, 1, 0.4, 0.4, 0.4, 0.2)], friction=0.5),
+}
+
+
+def _levelset(tm, planes=(), shapes=(), friction=-1.0):
+    ls = tm.mpm.LevelSet(friction=friction)
+    for p in planes:
+        ls.add_plane(p[:3], d=p[3])
+    for sh in shapes:
+        if sh[0] == 1:
+            ls.add_sphere(sh[2:5], sh[5], bool(sh[1]))
+        else:
+            ls.add_cuboid(sh[2:5], sh[5:8], bool(sh[1]))
+    return ls
+
+
+@pytest.mark.parametrize("collide", [False, True], ids=["grid_bc", "grid_bc+particle_collision"])
+@pytest.mark.parametrize("scene", sorted(SHAPE_SCENES))
+def test_levelset_shapes_and_particle_collision_match_oracle(tm, orc, scene, collide):
+    """spheres / cuboids / containers as grid boundary (src/mpm.cpp:296-372) and particle_collision_resolution
+    (:414-426) against the oracle, five substeps"""
+    sc = SHAPE_SCENES[scene]
+    x = lattice_cube(RES, 9, 17, DX, jitter=0.2, seed=51)
+    s = make_state(x, "jelly", DX, perturb_F=0.02, seed=52, vel_scale=2.0)
+    sim = make_sim(tm, s, planes=None, particle_collision=collide)
+    ls = _levelset(tm, sc.get("planes", ()), sc["shapes"], sc["friction"])
+    sim.set_levelset(ls)
+    cfg = orc.make_config(RES, DX, DT, planes=ls.planes, friction=sc["friction"], shapes=ls.non_planes,
+                          particle_collision=collide)
+    ref = s.copy()
+    for _ in range(5):
+        sim.substep()
+        orc.substep(cfg, ref)
+    got = sim.get_particles()
+    assert len(got["x"]) == ref.n and np.array_equal(got["id"], ref.ids)
+    assert np.abs(got["x"] - ref.x).max() <= 1e-6
+    assert rel_l2(got["v"], ref.v) <= 1e-4
+    assert rel_l2(got["F"], ref.F) <= 1e-4
+    moved = np.abs(ref.v - s.v).max()
+    assert moved > 1e-3  # the boundary did something in this scene
+    sim.close()
