@@ -120,8 +120,11 @@ inline ParticleType create_particle_type(const std::string &alias, const Config 
   } else if (alias == "elastic") {  // :777-783
     t.material = MPMHIP_ELASTIC;
     lame(c.get("E", 5e3), c.get("nu", 0.4), p[2], p[3]);
-  } else if (alias == "visco") {
-    throw std::runtime_error("particle type 'visco' is not implemented on the device path yet");
+  } else if (alias == "visco") {  // :57-70
+    t.material = MPMHIP_VISCO;
+    lame(c.get("youngs_modulus", 4e4), c.get("poisson_ratio", 0.4), p[2], p[3]);
+    p[4] = c.get("nu", 10000.0f); p[5] = c.get("kappa", 0.0f); p[6] = c.get("base_delta_t", 1e-4f);
+    t.initial_aux = c.get("tau", 1000.0f);
   } else {
     throw std::runtime_error("unknown particle type '" + alias + "'");
   }

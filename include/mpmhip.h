@@ -42,7 +42,7 @@ enum {
 /* material ids == y component of MPMParticle::get_debug_info() (src/particles.cpp:157..839);
  * names are the factory aliases of TC_REGISTER_MPM_PARTICLE (src/particles.cpp:849-856). */
 enum {
-  MPMHIP_VISCO = 1, /* not implemented on device yet: add_group returns MPMHIP_ENOTIMPL */
+  MPMHIP_VISCO = 1,
   MPMHIP_SNOW = 2,
   MPMHIP_LINEAR = 3,
   MPMHIP_JELLY = 4,
@@ -63,6 +63,7 @@ enum {
  *   sand      [2] mu_0 [3] lambda_0 [4] alpha [5] cohesion [6] beta                           ; aux = logJp
  *   von_mises [2] mu_0 [3] lambda_0 [4] yield_stress
  *   elastic   [2] mu_0 [3] lambda_0
+ *   visco     [2] mu_0 [3] lambda_0 [4] visco_nu [5] visco_kappa [6] base_delta_t                ; aux = visco_tau
  */
 
 /* replaces: Config keys read by MPM<dim>::initialize (src/mpm.cpp:26-75) */

@@ -139,6 +139,7 @@ __device__ __forceinline__ mat3 calculate_force(const GroupParams &g, const mat3
   const float vol = g.p[1];
   mat3 out;
   switch (g.type) {
+    case MPMHIP_VISCO:   // src/particles.cpp:72-85 (same fixed-corotated energy)
     case MPMHIP_JELLY:   // src/particles.cpp:391-411  P = 2mu(F-R) + lambda (J-1) J F^-T
     case MPMHIP_SNOW: {  // src/particles.cpp:207-220, 244-252 (mu,lambda scaled by exp(h(1-Jp)))
       float mu = g.p[2], la = g.p[3];
@@ -203,11 +204,76 @@ __device__ __forceinline__ mat3 calculate_force(const GroupParams &g, const mat3
   return out;
 }
 
+// ViscoParticle::plasticity (src/particles.cpp:87-134): F_hat = approximate_exponent(cdg - I) F; the Frobenius
+// norm of the first Piola-Kirchhoff stress of the OLD F drives gamma; sigma_d <- clamp(sigma_d / (sigma_d *
+// det^-1/3)^gamma, 0.1, 10); tau += kappa gamma |P|.  Both SVDs of the reference share U and V, so one
+// eigen-solve of F_hat F_hat^T gives everything (plus one of the old F for |P|, which is rotation invariant).
+// On return F = F_hat, U/s = its left singular vectors/values, sn = the new singular values.
+__device__ __forceinline__ void visco_return(const GroupParams &g, const mat3 &cdg, mat3 &F, float &aux, mat3 &U,
+                                             float s[3], float sn[3]) {
+  const float mu = g.p[2], la = g.p[3], vnu = g.p[4], kappa = g.p[5], dt = g.p[6];
+  float pnorm;
+  {
+    mat3 U0; float lam0[3], s0[3];
+    sym_eig3_FFt(F, U0, lam0);
+    const float J0 = mat_det(F);
+    signed_sigma(lam0, J0, s0);
+    float acc = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const float pd = fmaf(2.0f * mu, s0[d] - 1.0f, la * (J0 - 1.0f) * J0 / s0[d]);
+      acc = fmaf(pd, pd, acc);
+    }
+    pnorm = sqrtf(acc);
+  }
+  mat3 sm;  // approximate_exponent(dt, (cdg - I)/dt): r = I + s + s^2/2 with s halved until det r > 0, then squared back
+#pragma unroll
+  for (int i = 0; i < 9; i++) sm.m[i] = cdg.m[i] - ((i % 4 == 0) ? 1.0f : 0.0f);
+  mat3 r;
+  int halvings = 0;
+  for (;;) {
+    mat3 h = sm;
+#pragma unroll
+    for (int i = 0; i < 9; i++) h.m[i] = 0.5f * sm.m[i] + ((i % 4 == 0) ? 1.0f : 0.0f);
+    r = mat_mul(h, sm);
+#pragma unroll
+    for (int i = 0; i < 3; i++) r.m[4 * i] += 1.0f;
+    if (mat_det(r) > 0.0f || halvings > 20) break;
+#pragma unroll
+    for (int i = 0; i < 9; i++) sm.m[i] *= 0.5f;
+    halvings++;
+  }
+  for (int i = 0; i < halvings; i++) r = mat_mul(r, r);
+  F = mat_mul(r, F);
+  float lam[3];
+  sym_eig3_FFt(F, U, lam);
+  signed_sigma(lam, mat_det(F), s);
+  float gamma = 0.0f;
+  if (pnorm > 1e-5f) gamma = fminf(fmaxf(dt * vnu * (pnorm - aux) / pnorm, 0.0f), 1.0f);
+  const float dets = s[0] * s[1] * s[2];
+  const float scale = fabsf(dets) > 1e-5f ? 1.0f / powf(dets, 1.0f / 3.0f) : 1.0f;
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const float md = powf(s[d] * scale, gamma);
+    const float inv = fabsf(md) > 1e-5f ? 1.0f / md : 1.0f;
+    sn[d] = fminf(fmaxf(s[d] * inv, 0.1f), 10.0f);
+  }
+  aux = fmaf(kappa * gamma, pnorm, aux);
+}
+
 // plasticity(cdg): F <- cdg F, then the material's return mapping (src/particles.h:139-141).
 __device__ __forceinline__ void plasticity(const GroupParams &g, const mat3 &cdg, mat3 &F, float &aux) {
   if (g.type == MPMHIP_WATER) {  // src/particles.cpp:469-478 (dg_e is never touched for water)
     float j = aux * (cdg(0, 0) + cdg(1, 1) + cdg(2, 2) - 2.0f);
     aux = (j < 0.1f) ? 0.1f : j;
+    return;
+  }
+  if (g.type == MPMHIP_VISCO) {
+    mat3 U; float s[3], sn[3], ratio[3];
+    visco_return(g, cdg, F, aux, U, s, sn);
+#pragma unroll
+    for (int i = 0; i < 3; i++) ratio[i] = sn[i] / s[i];
+    F = mat_mul(sandwich(U, ratio), F);
     return;
   }
   F = mat_mul(cdg, F);
@@ -288,6 +354,20 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
     const float dd = vol * j * p;
 #pragma unroll
     for (int i = 0; i < 9; i++) stress.m[i] = (i % 4 == 0) ? dd : 0.0f;
+    return;
+  }
+  if (g.type == MPMHIP_VISCO) {  // src/particles.cpp:72-134
+    mat3 U; float s[3], sn[3], ratio[3], d[3];
+    visco_return(g, cdg, F, aux, U, s, sn);
+    const float Jn = sn[0] * sn[1] * sn[2];
+    const float vol_l = g.p[3] * (Jn - 1.0f) * Jn;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      ratio[i] = sn[i] / s[i];
+      d[i] = -vol * fmaf(2.0f * g.p[2], sn[i] * sn[i] - sn[i], vol_l);
+    }
+    F = mat_mul(sandwich(U, ratio), F);
+    stress = sandwich(U, d);
     return;
   }
   F = mat_mul(cdg, F);

@@ -1451,8 +1451,7 @@ int mpmhip_set_levelset(mpmhip_ctx *c, int32_t n_planes, const float *planes, fl
 
 int mpmhip_add_group(mpmhip_ctx *c, int32_t material, const float params[MPMHIP_NPARAM]) {
   if (!c || !params) return MPMHIP_EINVAL;
-  if (material == MPMHIP_VISCO) return fail(c, MPMHIP_ENOTIMPL, "material 'visco' is not implemented on the device path yet");
-  if (material < MPMHIP_SNOW || material > MPMHIP_ELASTIC) return fail(c, MPMHIP_EINVAL, "unknown material id %d", material);
+  if (material < MPMHIP_VISCO || material > MPMHIP_ELASTIC) return fail(c, MPMHIP_EINVAL, "unknown material id %d", material);
   if ((int)c->groups.size() >= c->groups_cap) return fail(c, MPMHIP_ECAPACITY, "too many particle groups (max %d)", c->groups_cap);
   if (!(params[0] > 0) || !(params[1] > 0)) return fail(c, MPMHIP_EINVAL, "group mass and vol must be > 0");
   GroupParams g;
@@ -1503,7 +1502,8 @@ int mpmhip_add_particles(mpmhip_ctx *c, int32_t group, int64_t n, const float *x
     return fail(c, MPMHIP_ECAPACITY, "particle capacity exceeded: %lld + %lld > %lld", (long long)c->n_slots, (long long)n, (long long)c->cap);
   if (int rc = ensure_b_current(c)) return rc;  // A of every particle is recomputed from apic_b below
   const int mat = c->groups[group].type;
-  const float aux0 = (mat == MPMHIP_SNOW || mat == MPMHIP_WATER) ? 1.0f : 0.0f;  // Jp = 1 (:204), j = 1 (:460), logJp = 0 (:595)
+  // Jp = 1 (:204), j = 1 (:460), logJp = 0 (:595), visco_tau = 1000 (:65)
+  const float aux0 = (mat == MPMHIP_SNOW || mat == MPMHIP_WATER) ? 1.0f : (mat == MPMHIP_VISCO ? 1000.0f : 0.0f);
   std::vector<RecG> hg((size_t)n);
   std::vector<RecP> hp((size_t)n);
   std::vector<float> hb((size_t)n * BW, 0.0f);
@@ -2124,7 +2124,7 @@ int mpmhip_debug_svd3(mpmhip_ctx *c, int64_t n, const float *F, float *U, float 
 }
 
 static int make_group(mpmhip_ctx *c, int32_t material, const float *params, GroupParams &g) {
-  if (material < MPMHIP_SNOW || material > MPMHIP_ELASTIC) return fail(c, MPMHIP_EINVAL, "unknown material id %d", material);
+  if (material < MPMHIP_VISCO || material > MPMHIP_ELASTIC) return fail(c, MPMHIP_EINVAL, "unknown material id %d", material);
   memset(&g, 0, sizeof g);
   memcpy(g.p, params, sizeof g.p);
   g.type = material;

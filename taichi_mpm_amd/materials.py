@@ -47,6 +47,7 @@ def group_params(type_name, mass, vol, **kw):
         p[2], p[3] = _lame(kw.get("E", 5e3), kw.get("nu", 0.4))
     elif type_name == "visco":  # :57-70
         p[2], p[3] = _lame(kw.get("youngs_modulus", 4e4), kw.get("poisson_ratio", 0.4))
+        # src/particles.cpp:57-70: the particle reads "base_delta_t" from ITS config (default 1e-4)
         p[4], p[5], p[6] = kw.get("nu", 10000.0), kw.get("kappa", 0.0), kw.get("base_delta_t", 1e-4)
     return p, t
 

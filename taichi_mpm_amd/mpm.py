@@ -263,8 +263,6 @@ class Simulation3D:
         params, mat = group_params(ptype, mass, vol, **{k: v for k, v in cfg.items() if isinstance(v, (int, float))})
         if "params" in cfg:  # explicit float[16] row (include/mpmhip.h), e.g. to share one row with a checker
             params = np.ascontiguousarray(cfg["params"], np.float32).reshape(16).copy()
-        if mat == MATERIAL_IDS["visco"]:
-            raise MPMError("material 'visco' is not implemented on the device path yet")
         v0 = np.tile(np.asarray(_vec3(cfg.get("initial_velocity"), (0, 0, 0)), np.float32), (n, 1))
         if "velocities" in cfg:
             v0 = np.ascontiguousarray(cfg["velocities"], np.float32).reshape(-1, 3)[keep]

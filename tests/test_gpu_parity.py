@@ -19,8 +19,8 @@ pytestmark = pytest.mark.gpu
 
 RES, DX, DT = 32, 1.0 / 32, 1e-4
 PLANES = [(0.0, 1.0, 0.0, -0.3)]
-MATS = ["jelly", "snow", "sand", "water", "linear", "elastic", "von_mises"]
-F_TOL = {"snow": 1e-4, "sand": 1e-4, "von_mises": 1e-4}
+MATS = ["jelly", "snow", "sand", "water", "linear", "elastic", "von_mises", "visco"]
+F_TOL = {"snow": 1e-4, "sand": 1e-4, "von_mises": 1e-4, "visco": 1e-4}
 
 
 @pytest.fixture(scope="module")
@@ -341,7 +341,7 @@ def test_edge_cases_empty_single_ragged_and_capacity(tm, orc):
     big = np.tile(rag.x, (8, 1))
     rc = sim2._L.mpmhip_add_particles(sim2._ctx, 0, len(big), big.ctypes.data_as(fp), None, None, None, None)
     assert rc == -4 and b"capacity" in sim2._L.mpmhip_last_error(sim2._ctx)
-    assert sim2._L.mpmhip_add_group(sim2._ctx, tm.MATERIAL_IDS["visco"], rag.gparams[0].ctypes.data_as(fp)) == -5
+    assert sim2._L.mpmhip_add_group(sim2._ctx, 9, rag.gparams[0].ctypes.data_as(fp)) == -1  # unknown material id
     assert sim2._L.mpmhip_p2g(sim2._ctx) == -1  # needs a sort first
     sim2.close()
 
