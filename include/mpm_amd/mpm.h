@@ -171,16 +171,30 @@ class MPM<3> {
   // --- MPM<dim>::general_action (src/mpm.cpp:920-978): the actions that only need the hot path's state
   std::string general_action(const Config &config) {
     const std::string action = config.get("action", "");
-    if (action == "calculate_energy") {  // kinetic part of :1078-1110
-      const int64_t n = get_num_particles();
-      std::vector<float> v(3 * n);
-      std::vector<int32_t> gid(n);
-      check(mpmhip_download(ctx_, MPMHIP_F_V, v.data(), n), ctx_);
-      check(mpmhip_download(ctx_, MPMHIP_F_GID, gid.data(), n), ctx_);
-      double e = 0;
-      for (int64_t i = 0; i < n; i++)
-        e += 0.5 * types_[gid[i]].params[0] * ((double)v[3 * i] * v[3 * i] + (double)v[3 * i + 1] * v[3 * i + 1] + (double)v[3 * i + 2] * v[3 * i + 2]);
-      return std::to_string(e);
+    if (action == "calculate_energy") {  // :936-938 -> calculate_energy(), :1078-1110
+      double kinetic = 0, potential = 0;
+      check(mpmhip_calculate_energy(ctx_, &kinetic, &potential), ctx_);
+      return std::to_string(kinetic + potential);
+    }
+    if (action == "save" || action == "load") {  // :940-960: whole-state snapshot to / from "file_name"
+      const std::string fn = config.get("file_name", "");
+      if (action == "save") {
+        std::vector<char> buf((size_t)mpmhip_snapshot_size(ctx_));
+        check(mpmhip_snapshot_save(ctx_, buf.data(), buf.size()), ctx_);
+        FILE *f = std::fopen(fn.c_str(), "wb");
+        if (!f || std::fwrite(buf.data(), 1, buf.size(), f) != buf.size()) throw std::runtime_error("cannot write " + fn);
+        std::fclose(f);
+      } else {
+        FILE *f = std::fopen(fn.c_str(), "rb");
+        if (!f) throw std::runtime_error("cannot read " + fn);
+        std::fseek(f, 0, SEEK_END);
+        std::vector<char> buf((size_t)std::ftell(f));
+        std::fseek(f, 0, SEEK_SET);
+        if (std::fread(buf.data(), 1, buf.size(), f) != buf.size()) throw std::runtime_error("cannot read " + fn);
+        std::fclose(f);
+        check(mpmhip_snapshot_load(ctx_, buf.data(), buf.size()), ctx_);
+      }
+      return "";
     }
     throw std::runtime_error("general_action(action='" + action + "') is outside the scope of this build");
   }

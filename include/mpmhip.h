@@ -159,6 +159,21 @@ int mpmhip_g2p(mpmhip_ctx *ctx);         /* resample_optimized                sr
 int mpmhip_download_grid(mpmhip_ctx *ctx, int32_t which, float *dst);
 int mpmhip_upload_grid(mpmhip_ctx *ctx, const float *src);
 
+/* whole-state snapshots — replaces the TC_IO serialization behind general_action "save" / "load"
+ * (src/mpm.cpp:940-960, src/mpm.h:38-54,134-169).  The blob holds the raw particle records (with the P2G affine
+ * matrices), the group table and the clocks; it loads into a ctx of the same grid with enough capacity, which then
+ * continues exactly where the saved run stopped.  Level set and config are NOT part of it (the reference re-reads
+ * them from the scene script too). */
+int64_t mpmhip_snapshot_size(mpmhip_ctx *ctx);
+int mpmhip_snapshot_save(mpmhip_ctx *ctx, void *dst, size_t capacity);
+int mpmhip_snapshot_load(mpmhip_ctx *ctx, const void *src, size_t size);
+
+/* replaces MPM<3>::calculate_energy (src/mpm.cpp:1078-1110; general_action "calculate_energy", :936-938): sorts and
+ * rasterizes, then kinetic = sum over grid nodes of 1/2 m |v|^2, potential = sum of MPMParticle::potential_energy()
+ * (defined for linear, jelly, elastic: src/particles.cpp:323-327,400-407,785-796).  Returns MPMHIP_ENOTIMPL (with a
+ * valid *kinetic) if a live particle is of another type, as the reference aborts there.  Synchronises. */
+int mpmhip_calculate_energy(mpmhip_ctx *ctx, double *kinetic, double *potential);
+
 /* profiling — replaces TC_PROFILE / TC_PROFILE_TPE scoped timers (src/mpm.cpp:464-572).
  * level 0: off.  level 1: hipEvents bracket each phase of every substep on the ctx stream (six records per
  * substep; each record costs ~5 us of idle GPU).  level 2 / 3: only k_g2p / only k_p2g is bracketed (two records),

@@ -492,6 +492,56 @@ __global__ __launch_bounds__(256) void k_recover_b(Params P, const RecG *__restr
   }
 }
 
+// sum of MPMParticle::potential_energy() (src/particles.cpp:323-327 linear, :400-407 jelly, :785-796 elastic;
+// the other types do not define it in the reference: TC_NOT_IMPLEMENTED) -> out[0]; out[1] counts particles of
+// types without a potential energy
+__global__ __launch_bounds__(256) void k_potential_energy(Params P, const RecG *__restrict__ rg,
+                                                          const GroupParams *__restrict__ groups, double *out) {
+  double e = 0.0, bad = 0.0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_slots; i += gridDim.x * blockDim.x) {
+    const RecG r = rg[i];
+    if (r.pid < 0) continue;
+    const GroupParams g = groups[r.gid];
+    mat3 F;
+#pragma unroll
+    for (int k = 0; k < 9; k++) F.m[k] = r.F[k];
+    const float mu = g.p[2], la = g.p[3], vol = g.p[1];
+    if (g.type == MPMHIP_LINEAR) {
+      float n2 = 0.0f, tr = 0.0f;
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+          const float eab = 0.5f * (F(a, b) + F(b, a)) - (a == b ? 1.0f : 0.0f);
+          n2 = fmaf(eab, eab, n2);
+          if (a == b) tr += eab;
+        }
+      e += vol * (mu * n2 + 0.5f * la * tr * tr);
+    } else if (g.type == MPMHIP_JELLY || g.type == MPMHIP_ELASTIC) {
+      mat3 U; float lam[3], s[3];
+      sym_eig3_FFt(F, U, lam);
+      const float J = mat_det(F);
+      signed_sigma(lam, J, s);
+      if (g.type == MPMHIP_JELLY) {  // |F - R|_F^2 = sum (sigma - 1)^2
+        const float n2 = (s[0] - 1) * (s[0] - 1) + (s[1] - 1) * (s[1] - 1) + (s[2] - 1) * (s[2] - 1);
+        e += vol * (mu * n2 + 0.5f * la * (J - 1.0f) * (J - 1.0f));
+      } else {
+        const float l0 = logf(fabsf(s[0])), l1 = logf(fabsf(s[1])), l2 = logf(fabsf(s[2]));
+        const float sum = l0 + l1 + l2;
+        e += vol * (mu * (l0 * l0 + l1 * l1 + l2 * l2) + 0.5f * la * sum * sum);
+      }
+    } else {
+      bad += 1.0;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { e += __shfl_xor(e, off); bad += __shfl_xor(bad, off); }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[0], e);
+    if (bad != 0.0) atomicAdd(&out[1], bad);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ P2G
 // rasterize_optimized / block_op_normal (src/transfer.cpp:467-569).
 // Mapping: ONE LANE PER CELL of an active 4^3-cell block.  The sorted index lists the particles of each cell
@@ -742,6 +792,13 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
       }
       if (MODE == 1) {
         if (in_grid) dense[dense_idx] = acc;
+        continue;
+      }
+      if (MODE == 4) {  // grid kinetic energy sum 1/2 m |v|^2 with v = (m v)/m (calculate_energy, src/mpm.cpp:1078-1096)
+        double e = (acc.w != 0.0f) ? 0.5 * ((double)acc.x * acc.x + (double)acc.y * acc.y + (double)acc.z * acc.z) / acc.w : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
+        if (l == 0) atomicAdd(reinterpret_cast<double *>(dense), e);
         continue;
       }
       float v[3] = {acc.x, acc.y, acc.z};
@@ -1244,6 +1301,7 @@ struct mpmhip_ctx {
   DevBox *d_boxes = nullptr;
   uint32_t *d_counts = nullptr;
   int *d_bounds = nullptr;
+  double *d_energy = nullptr;
   int counts_cap = 0;
   bool compact_requested = false;
   bool in_substep = false;
@@ -1408,7 +1466,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   hipFree(c->key); hipFree(c->rank); hipFree(c->perm); hipFree(c->blk_flag); hipFree(c->bits); hipFree(c->wprefix);
   hipFree(c->fat_slot); hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->cell_cnt);
   hipFree(c->cell_start); hipFree(c->scan_slots); hipFree(c->ticket); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
-  hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_counts); hipFree(c->d_bounds);
+  hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_counts); hipFree(c->d_bounds); hipFree(c->d_energy);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1701,7 +1759,8 @@ static int do_p2g(mpmhip_ctx *c) {
 static int do_grid(mpmhip_ctx *c, int mode) {
   const bool per_cand = mode == 0 && c->n_slots < (2 << 20);  // small per-GPU problem: latency-bound, see k_grid
   auto kern = mode == 0 ? (per_cand ? k_grid<0, true> : k_grid<0, false>)
-                        : (mode == 1 ? k_grid<1, false> : (mode == 2 ? k_grid<2, false> : k_grid<3, false>));
+                        : (mode == 1 ? k_grid<1, false>
+                                     : (mode == 2 ? k_grid<2, false> : (mode == 3 ? k_grid<3, false> : k_grid<4, false>)));
   hipLaunchKernelGGL(kern, dim3(per_cand ? 16384 : 4096), dim3(256), 0, c->stream, c->P, c->cnt, c->act_blk, c->bits, c->wprefix, c->tiles,
                      c->gridv, c->fat_slot, c->dense, c->T, (const DevBox *)c->d_boxes, c->LS);
   return launch_check(c, "grid");
@@ -1902,6 +1961,132 @@ int mpmhip_upload_grid(mpmhip_ctx *c, const float *src) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(c->dense, src, nodes * sizeof(float4), hipMemcpyHostToDevice));
   return do_grid(c, 2);
+}
+
+// ------------------------------------------------------------------------------------------------ snapshots
+// Whole-state save / load (reference: TC_IO serialization of MPM<dim> + ParticleAllocator, src/mpm.h:38-54,134-169,
+// general_action "save"/"load" src/mpm.cpp:940-960).  The blob holds the raw records — including the P2G affine
+// matrices — so a restart continues exactly where the run stopped (up to the in-cell summation order).
+struct SnapHeader {
+  char magic[8];  // "MPMHIP01"
+  uint32_t abi, n_groups;
+  int64_t n_slots, substeps;
+  int32_t next_pid, b_stale, store_b, res[3];
+  float t, request_t, dx, dt;
+  uint32_t n_dead, pad;
+};
+
+static size_t snapshot_bytes(const mpmhip_ctx *c) {
+  return sizeof(SnapHeader) + sizeof(GroupParams) * c->groups.size() +
+         (size_t)c->n_slots * (sizeof(RecG) + sizeof(RecP) + sizeof(float) * BW);
+}
+
+int64_t mpmhip_snapshot_size(mpmhip_ctx *c) { return c ? (int64_t)snapshot_bytes(c) : MPMHIP_EINVAL; }
+
+int mpmhip_snapshot_save(mpmhip_ctx *c, void *dst, size_t cap) {
+  if (!c || !dst) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->in_substep) return fail(c, MPMHIP_EINVAL, "snapshot inside a substep");
+  if (cap < snapshot_bytes(c)) return fail(c, MPMHIP_ECAPACITY, "snapshot buffer too small: %zu < %zu", cap, snapshot_bytes(c));
+  Counters hc;
+  int rc = read_counters(c, hc);
+  if (rc) return rc;
+  if (!c->affine_valid) {  // make A current first (fresh uploads), so that the blob is self-consistent
+    hipLaunchKernelGGL(k_affine, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, c->rg, c->rp, c->rb, c->d_groups);
+    c->affine_valid = true;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  SnapHeader h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, "MPMHIP01", 8);
+  h.abi = MPMHIP_ABI_VERSION; h.n_groups = (uint32_t)c->groups.size();
+  h.n_slots = c->n_slots; h.substeps = c->substeps; h.next_pid = c->next_pid;
+  h.b_stale = c->b_stale; h.store_b = c->P.store_b;
+  for (int k = 0; k < 3; k++) h.res[k] = c->P.res[k];
+  h.t = c->t; h.request_t = c->request_t; h.dx = c->P.dx; h.dt = c->P.dt; h.n_dead = hc.n_dead;
+  char *p = (char *)dst;
+  memcpy(p, &h, sizeof h); p += sizeof h;
+  memcpy(p, c->groups.data(), sizeof(GroupParams) * c->groups.size()); p += sizeof(GroupParams) * c->groups.size();
+  const size_t n = (size_t)c->n_slots;
+  if (n) {
+    HIPCHK(c, hipMemcpy(p, c->rg, sizeof(RecG) * n, hipMemcpyDeviceToHost)); p += sizeof(RecG) * n;
+    HIPCHK(c, hipMemcpy(p, c->rp, sizeof(RecP) * n, hipMemcpyDeviceToHost)); p += sizeof(RecP) * n;
+    HIPCHK(c, hipMemcpy(p, c->rb, sizeof(float) * BW * n, hipMemcpyDeviceToHost));
+  }
+  return MPMHIP_OK;
+}
+
+int mpmhip_snapshot_load(mpmhip_ctx *c, const void *src, size_t size) {
+  if (!c || !src || size < sizeof(SnapHeader)) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  SnapHeader h;
+  memcpy(&h, src, sizeof h);
+  if (memcmp(h.magic, "MPMHIP01", 8) != 0 || h.abi != MPMHIP_ABI_VERSION) return fail(c, MPMHIP_EINVAL, "not a libmpmhip snapshot of this ABI version");
+  for (int k = 0; k < 3; k++)
+    if (h.res[k] != c->P.res[k]) return fail(c, MPMHIP_EINVAL, "snapshot is of a %dx%dx%d grid", h.res[0], h.res[1], h.res[2]);
+  if (h.dx != c->P.dx) return fail(c, MPMHIP_EINVAL, "snapshot has delta_x = %g, the ctx %g", h.dx, c->P.dx);
+  if (h.n_slots < 0 || h.n_slots > c->cap) return fail(c, MPMHIP_ECAPACITY, "snapshot holds %lld particle slots, capacity is %lld", (long long)h.n_slots, (long long)c->cap);
+  if ((int)h.n_groups > c->groups_cap) return fail(c, MPMHIP_ECAPACITY, "snapshot holds %u groups", h.n_groups);
+  const size_t n = (size_t)h.n_slots;
+  if (size < sizeof h + sizeof(GroupParams) * h.n_groups + n * (sizeof(RecG) + sizeof(RecP) + sizeof(float) * BW))
+    return fail(c, MPMHIP_EINVAL, "snapshot is truncated");
+  const char *p = (const char *)src + sizeof h;
+  c->groups.assign((const GroupParams *)p, (const GroupParams *)p + h.n_groups); p += sizeof(GroupParams) * h.n_groups;
+  if (h.n_groups) HIPCHK(c, hipMemcpy(c->d_groups, c->groups.data(), sizeof(GroupParams) * h.n_groups, hipMemcpyHostToDevice));
+  if (n) {
+    HIPCHK(c, hipMemcpy(c->rg, p, sizeof(RecG) * n, hipMemcpyHostToDevice)); p += sizeof(RecG) * n;
+    HIPCHK(c, hipMemcpy(c->rp, p, sizeof(RecP) * n, hipMemcpyHostToDevice)); p += sizeof(RecP) * n;
+    HIPCHK(c, hipMemcpy(c->rb, p, sizeof(float) * BW * n, hipMemcpyHostToDevice));
+  }
+  c->n_slots = h.n_slots; c->P.n_slots = (uint32_t)h.n_slots;
+  c->substeps = h.substeps; c->next_pid = h.next_pid;
+  c->t = h.t; c->request_t = h.request_t;
+  // A travels in the records; apic_b is current only if the saving ctx kept it up to date
+  c->affine_valid = true;
+  c->b_stale = h.b_stale != 0 || (h.store_b == 0);
+  if (c->P.store_b && c->b_stale) {  // this ctx keeps apic_b: rebuild it from A once
+    int rc = ensure_b_current(c);
+    if (rc) return rc;
+  }
+  c->sorted = c->keys_valid = false;  // keys and block flags are rebuilt by the next sort
+  HIPCHK(c, hipMemset(c->blk_flag, 0, (size_t)c->P.nbw * 32));
+  Counters hc;
+  memset(&hc, 0, sizeof hc);
+  hc.n_dead = h.n_dead;
+  HIPCHK(c, hipMemcpy(c->cnt, &hc, sizeof hc, hipMemcpyHostToDevice));
+  return MPMHIP_OK;
+}
+
+// MPM<dim>::calculate_energy (src/mpm.cpp:1078-1110): sort + P2G, kinetic energy of the grid, potential energy
+// of the particles.  Leaves the ctx sorted with fresh P2G tiles (like the reference, which leaves its grid rasterized).
+int mpmhip_calculate_energy(mpmhip_ctx *c, double *kinetic, double *potential) {
+  if (!c || !kinetic || !potential) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->T.n_boxes > 0) return fail(c, MPMHIP_ENOTIMPL, "calculate_energy on a tiled ctx (sum the ranks' shares on the caller side)");
+  int rc;
+  if ((rc = do_sort(c))) return rc;
+  if ((rc = do_p2g(c))) return rc;
+  if (!c->d_energy) HIPCHK(c, dmalloc(&c->d_energy, 4));
+  HIPCHK(c, hipMemsetAsync(c->d_energy, 0, 4 * sizeof(double), c->stream));
+  float4 *const dense_saved = c->dense;
+  c->dense = reinterpret_cast<float4 *>(c->d_energy);  // k_grid<4> accumulates into its `dense` argument
+  rc = do_grid(c, 4);
+  c->dense = dense_saved;
+  if (rc) return rc;
+  double *acc = c->d_energy;
+  hipLaunchKernelGGL(k_potential_energy, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, (const RecG *)c->rg,
+                     (const GroupParams *)c->d_groups, acc + 1);
+  if ((rc = launch_check(c, "potential_energy"))) return rc;
+  double h[3];
+  HIPCHK(c, hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *kinetic = h[0];
+  *potential = h[1];
+  if (h[2] != 0.0)
+    return fail(c, MPMHIP_ENOTIMPL, "%.0f particles are of a type without potential_energy() (reference: TC_NOT_IMPLEMENTED); "
+                "kinetic energy is valid", h[2]);
+  return MPMHIP_OK;
 }
 
 int mpmhip_set_profiling(mpmhip_ctx *c, int32_t level) {

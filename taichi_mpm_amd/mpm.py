@@ -402,15 +402,58 @@ class Simulation3D:
     def general_action(self, config):
         """MPM<dim>::general_action, src/mpm.cpp:920-978."""
         action = config.get("action")
-        if action == "calculate_energy":  # kinetic part of src/mpm.cpp:1078-1110
-            p = self.get_particles(sort_by_id=False)
-            mass = np.array([g[1][0] for g in self._groups], np.float64)[p["gid"]]
-            return str(float(0.5 * (mass * (p["v"].astype(np.float64) ** 2).sum(1)).sum()))
-        if action == "save":
+        if action == "calculate_energy":  # src/mpm.cpp:936-938 -> :1078-1110
+            k, p = self.calculate_energy()
+            return str(k + p)
+        if action == "save":  # src/mpm.cpp:940-949: whole-state snapshot
+            self.save_snapshot(config["file_name"])
+            return ""
+        if action == "load":  # src/mpm.cpp:950-960
+            self.load_snapshot(config["file_name"])
+            return ""
+        if action == "export":  # particle fields as .npz (not a reference action; handy for post-processing)
             p = self.get_particles()
             np.savez(config["file_name"], t=self.get_current_time(), frame=self.frame, **p)
             return ""
         raise MPMError("general_action(action=%r) is outside the scope of this build" % (action,))
+
+    def save_snapshot(self, path):
+        """raw records + group table + clocks (include/mpmhip.h: mpmhip_snapshot_save)"""
+        self._ensure_ctx()
+        n = int(self._check(self._L.mpmhip_snapshot_size(self._ctx)))
+        buf = np.empty(n, np.uint8)
+        self._check(self._L.mpmhip_snapshot_save(self._ctx, buf.ctypes.data_as(C.c_void_p), n))
+        with open(path, "wb") as f:
+            f.write(np.array([self.frame], np.int64).tobytes())
+            f.write(buf.tobytes())
+
+    def load_snapshot(self, path):
+        """into a simulation initialised with the same grid; level set and config come from the script, as in the
+        reference.  Replaces all particles and groups."""
+        raw = np.fromfile(path, np.uint8)
+        self.frame = int(raw[:8].view(np.int64)[0])
+        blob = np.ascontiguousarray(raw[8:])
+        n_groups = int(blob[12:16].view(np.uint32)[0])
+        n_slots = int(blob[16:24].view(np.int64)[0])
+        if self._ctx is None or n_slots > self._capacity:
+            if self._ctx is not None:
+                self._L.mpmhip_destroy(self._ctx)
+                self._ctx = None
+            self._staged, self._groups = [], []
+            self._create(max(self.max_particles, int(n_slots * 1.25) + 1024))
+        self._check(self._L.mpmhip_snapshot_load(self._ctx, blob.ctypes.data_as(C.c_void_p), len(blob)))
+        rows = blob[80:80 + 80 * n_groups].view(np.float32).reshape(n_groups, 20)
+        self._groups = [(int(r[16:17].view(np.int32)[0]), r[:16].copy()) for r in rows]
+        self._n_added = n_slots
+        self._time_offset = 0.0
+
+    def calculate_energy(self):
+        """(kinetic, potential): grid kinetic energy after a fresh P2G + sum of the particles' potential energies
+        (src/mpm.cpp:1078-1110).  Types without potential_energy() raise, as the reference aborts."""
+        self._ensure_ctx()
+        k, p = C.c_double(), C.c_double()
+        self._check(self._L.mpmhip_calculate_energy(self._ctx, C.byref(k), C.byref(p)))
+        return k.value, p.value
 
     def test(self):  # src/mpm.cpp:577-580
         return True

@@ -103,10 +103,14 @@ static void cpu_tests() {
 static void gpu_tests() {
   auto sim = create_simulation3("mpm");
   sim->initialize(Config().set("res", Vector3i(64, 64, 64)).set("base_delta_t", 1e-4).set("gravity", Vector3(0, -10, 0)));
-  sim->set_levelset({Vector4(0.0f, 1.0f, 0.0f, -0.15f)}, -1.0f);
+  sim->set_levelset(std::vector<Vector4>{Vector4(0.0f, 1.0f, 0.0f, -0.15f)}, -1.0f);
   CHECK(sim->add_particles(Config().set("type", "jelly").set("benchmark", 125)) == "");
   const int64_t n = sim->get_num_particles();
   CHECK(n == 13 * 13 * 13 * 8);  // round(64*0.4)=26..39: 13^3 cells x 8 (src/mpm.cpp:149-186)
+  {  // all-jelly scene: mechanical energy is defined (potential_energy exists for jelly, src/particles.cpp:400-407)
+    const double e0 = std::stod(sim->general_action(Config().set("action", "calculate_energy")));
+    CHECK(e0 >= 0 && e0 < 1e-3 && std::isfinite(e0));  // at rest, undeformed: only the first substep's gravity impulse
+  }
   sim->add_particles(Config().set("type", "sand").set("cube_lo", 40).set("cube_hi", 44).set("initial_velocity", Vector3(0, -1, 0)));
   CHECK(sim->get_num_particles() == n + 4 * 4 * 4 * 8);
   sim->step(-1.0f);  // exactly one substep
@@ -126,8 +130,28 @@ static void gpu_tests() {
   for (auto &p : rp) vy += p.velocity[1];
   vy /= rp.size();
   CHECK(vy < -5e-3 && vy > -0.2);  // ~12 substeps of free fall (+ the sand block's -1 m/s)
-  const double e = std::stod(sim->general_action(Config().set("action", "calculate_energy")));
-  CHECK(e > 0 && std::isfinite(e));
+  {  // sand has no potential_energy() in the reference (TC_NOT_IMPLEMENTED): the action must fail loudly
+    bool threw = false;
+    try { sim->general_action(Config().set("action", "calculate_energy")); } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw);
+  }
+  {  // save / load (src/mpm.cpp:940-960): a second simulation continues from the blob
+    const std::string fn = "/tmp/mpm_amd_host_layer_snapshot.bin";
+    sim->general_action(Config().set("action", "save").set("file_name", fn));
+    auto sim2 = create_simulation3("mpm");
+    sim2->initialize(Config().set("res", Vector3i(64, 64, 64)).set("base_delta_t", 1e-4).set("gravity", Vector3(0, -10, 0)));
+    sim2->set_levelset(std::vector<Vector4>{Vector4(0.0f, 1.0f, 0.0f, -0.15f)}, -1.0f);
+    sim2->general_action(Config().set("action", "load").set("file_name", fn));
+    CHECK(sim2->get_num_particles() == sim->get_num_particles());
+    CHECK(std::fabs(sim2->get_current_time() - sim->get_current_time()) < 1e-9f);
+    sim->step(-1.0f); sim2->step(-1.0f);
+    const auto a = sim->get_render_particles(), b = sim2->get_render_particles();
+    double dmax = 0;
+    for (size_t i = 0; i < a.size(); i++)
+      for (int k = 0; k < 3; k++) dmax = std::max(dmax, (double)std::fabs(a[i].position[k] - b[i].position[k]));
+    CHECK(a.size() == b.size() && dmax < 1e-6);
+    std::remove(fn.c_str());
+  }
   // device constitutive code through the particle surface: F = I => zero force; plasticity(cdg) = F <- cdg F for jelly
   MPMParticle p;
   p.type = create_particle_type("jelly", Config(), 1.0f, 1e-6f);

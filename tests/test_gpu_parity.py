@@ -510,3 +510,80 @@ def test_levelset_shapes_and_particle_collision_match_oracle(tm, orc, scene, col
     moved = np.abs(ref.v - s.v).max()
     assert moved > 1e-3  # the boundary did something in this scene
     sim.close()
+
+
+# ------------------------------------------------------------------------------------------ calculate_energy
+def test_calculate_energy_matches_numpy(tm, orc):
+    """MPM<dim>::calculate_energy (src/mpm.cpp:1078-1110): grid kinetic energy after P2G + particle potential energy
+    (linear :323-327, jelly :400-407, elastic :785-796); other types have no potential_energy() in the reference."""
+    x = lattice_cube(RES, 9, 17, DX, jitter=0.2, seed=61)
+    parts = [make_state(x[i::3], m, DX, perturb_F=0.05, seed=62 + i) for i, m in enumerate(("jelly", "linear", "elastic"))]
+    s = orc.State(np.concatenate([p.x for p in parts]), np.concatenate([p.v for p in parts]),
+                  np.concatenate([p.B for p in parts]), np.concatenate([p.F for p in parts]),
+                  np.concatenate([p.aux for p in parts]), np.concatenate([np.full(p.n, i, np.int32) for i, p in enumerate(parts)]),
+                  np.concatenate([p.gparams for p in parts]), np.concatenate([p.gtype for p in parts]))
+    sim = make_sim(tm, s, planes=None, particle_gravity=False)
+    kin, pot = sim.calculate_energy()
+    g = orc.p2g(ocfg(orc, planes=(), particle_gravity=False), s.copy()).astype(np.float64)
+    m = g[..., 3]
+    ref_kin = (0.5 * (g[..., :3] ** 2).sum(-1)[m > 0] / m[m > 0]).sum()
+    F = s.F.reshape(-1, 3, 3).astype(np.float64)
+    U, sig, Vt = np.linalg.svd(F)
+    R = U @ Vt
+    J = np.linalg.det(F)
+    gp = s.gparams[s.gid].astype(np.float64)
+    vol, mu, la = gp[:, 1], gp[:, 2], gp[:, 3]
+    e_j = vol * (mu * ((F - R) ** 2).sum((1, 2)) + 0.5 * la * (J - 1) ** 2)
+    eps = 0.5 * (F + F.transpose(0, 2, 1)) - np.eye(3)
+    e_l = vol * (mu * (eps ** 2).sum((1, 2)) + 0.5 * la * np.trace(eps, axis1=1, axis2=2) ** 2)
+    ls = np.log(sig)
+    e_e = vol * (mu * (ls ** 2).sum(1) + 0.5 * la * ls.sum(1) ** 2)
+    ref_pot = np.where(s.gid == 0, e_j, np.where(s.gid == 1, e_l, e_e)).sum()
+    assert np.isclose(kin, ref_kin, rtol=1e-5)
+    assert np.isclose(pot, ref_pot, rtol=1e-4)
+    assert np.isclose(float(sim.general_action(dict(action="calculate_energy"))), kin + pot)
+    sim.close()
+    sand = make_state(x[:64], "sand", DX)
+    sim = make_sim(tm, sand, planes=None)
+    with pytest.raises(tm.mpm.MPMError, match="potential_energy"):
+        sim.calculate_energy()
+    sim.close()
+
+
+# ------------------------------------------------------------------------------------------ snapshots
+def test_snapshot_restart_continues_the_run(tm, orc, tmp_path):
+    """general_action save / load (src/mpm.cpp:940-960): a restarted run continues where the saved one stopped —
+    the blob carries the raw records incl. the P2G affine matrices, so the restart does not go through the apic_b
+    recovery and differs only by the in-cell summation order."""
+    x = lattice_cube(RES, 9, 17, DX, jitter=0.2, seed=71)
+    sa, sb = make_state(x[::2], "snow", DX, seed=72), make_state(x[1::2], "sand", DX, seed=73)
+    s = orc.State(np.concatenate([sa.x, sb.x]), np.concatenate([sa.v, sb.v]), np.concatenate([sa.B, sb.B]),
+                  np.concatenate([sa.F, sb.F]), np.concatenate([sa.aux, sb.aux]),
+                  np.concatenate([np.zeros(sa.n, np.int32), np.ones(sb.n, np.int32)]),
+                  np.concatenate([sa.gparams, sb.gparams]), np.concatenate([sa.gtype, sb.gtype]))
+    a = make_sim(tm, s)
+    a.run_substeps(6)
+    path = str(tmp_path / "snap.bin")
+    a.frame = 3
+    assert a.general_action(dict(action="save", file_name=path)) == ""
+    a.run_substeps(6)
+    ref = a.get_particles()
+    b = tm.create_simulation3("mpm").initialize(dict(res=(RES,) * 3, delta_x=DX, base_delta_t=DT))
+    ls = tm.mpm.LevelSet(friction=0.4)
+    for p in PLANES:
+        ls.add_plane(p[:3], d=p[3])
+    b.set_levelset(ls)
+    assert b.general_action(dict(action="load", file_name=path)) == ""
+    assert b.frame == 3 and b.get_num_particles() == s.n
+    assert np.isclose(b.get_current_time(), 6 * DT, rtol=1e-5)
+    b.run_substeps(6)
+    got = b.get_particles()
+    assert np.array_equal(got["id"], ref["id"]) and np.array_equal(got["gid"], ref["gid"])
+    assert np.abs(got["x"] - ref["x"]).max() <= 1e-6
+    assert rel_l2(got["v"], ref["v"]) <= 1e-5 and rel_l2(got["F"], ref["F"]) <= 1e-4
+    assert np.isclose(b.get_current_time(), a.get_current_time(), rtol=1e-6)
+    with open(path, "r+b") as f:  # a corrupted blob is rejected, not loaded
+        f.seek(8); f.write(b"XXXX")
+    with pytest.raises(tm.mpm.MPMError, match="snapshot"):
+        b.general_action(dict(action="load", file_name=path))
+    a.close(); b.close()
