@@ -136,12 +136,12 @@ def virtual_run(tm, cfg, args):
     el = time.perf_counter() - t0
     profs = [e.sim.profile() for e in engines]
     per_rank = [{k: v / max(p["substeps"], 1) for k, v in p["phases"].items()} for p in profs]
-    print(json.dumps({"diagnostic": "virtual ranks on one GPU", "K": K, "dims": part.dims, "cuts": part.cuts,
+    return ({"diagnostic": "virtual ranks on one GPU", "K": K, "dims": part.dims, "cuts": part.cuts,
                       "particles_per_rank": [p["particles"] for p in profs], "active_blocks": [p["active_blocks"] for p in profs],
                       "halo_floats_per_rank": [r.plan.total for r in job.ranks],
                       "ms_per_step_all_ranks_serial": 1e3 * el / args.steps,
                       "per_rank_compute_ms": [sum(v for k, v in pr.items() if k != "exchange") for pr in per_rank],
-                      "rank0_phases_ms": per_rank[0], "migrated": [r.migrated_out for r in job.ranks]}))
+                      "rank0_phases_ms": per_rank[0], "migrated": [r.migrated_out for r in job.ranks]})
 
 
 def main():
@@ -155,6 +155,16 @@ def main():
                     help="diagnostic, not the metric: run the K-brick tiled job as K ctx on ONE GPU (exchanges are local "
                          "copies) and print per-rank phase times = the per-GPU compute of a K-GPU run without the wire")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line (the JSON): native libraries print banners to fd 1 (RCCL prints its version
+    # block when the first communicator is created), so fd 1 points at stderr until the result is ready
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(obj) + "\n").encode())
 
     import torch
     import torch.distributed as dist
@@ -176,7 +186,7 @@ def main():
     cfg = CONFIGS[args.config]
     from taichi_mpm_amd import tiling
     if args.virtual > 1:
-        return virtual_run(tm, cfg, args)
+        return emit(virtual_run(tm, cfg, args))
     force_tiled = world == 1 and os.environ.get("MPMHIP_FORCE_TILED") == "1"  # test hook: TiledJob over RCCL, 1 rank
     if force_tiled:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -254,8 +264,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg)
         except Exception as e:  # the baseline is a reported extra: never lose the GPU line because of it
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
-    print(json.dumps(out))
-    if world > 1:
+    emit(out)
+    if world > 1 or force_tiled:
         dist.destroy_process_group()
 
 

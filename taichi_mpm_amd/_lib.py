@@ -78,7 +78,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_las
             "mpmhip_synchronize", "mpmhip_sort", "mpmhip_p2g", "mpmhip_grid_update", "mpmhip_g2p",
             "mpmhip_download_grid", "mpmhip_upload_grid", "mpmhip_calculate_energy", "mpmhip_snapshot_size", "mpmhip_snapshot_save", "mpmhip_snapshot_load", "mpmhip_set_profiling", "mpmhip_profile",
             "mpmhip_profile_reset", "mpmhip_set_partition", "mpmhip_set_halo", "mpmhip_halo_pack",
-            "mpmhip_substep_begin", "mpmhip_substep_end", "mpmhip_leaver_counts", "mpmhip_export_leavers",
+            "mpmhip_substep_begin", "mpmhip_substep_end", "mpmhip_leaver_counts", "mpmhip_migration_scan", "mpmhip_export_leavers",
             "mpmhip_import_particles", "mpmhip_active_bounds", "mpmhip_num_slots", "mpmhip_request_compaction", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
 
 
@@ -124,6 +124,7 @@ def load():
     L.mpmhip_set_partition.argtypes = [vp, C.c_int32, ip, ip, ip, ip, C.c_int32]
     L.mpmhip_set_halo.argtypes = [vp, C.c_int32, P(HaloBox)]
     L.mpmhip_leaver_counts.argtypes = [vp, C.c_int32, P(C.c_int64)]
+    L.mpmhip_migration_scan.argtypes = [vp, C.c_int32, P(C.c_int64), ip, ip]
     L.mpmhip_export_leavers.argtypes = [vp, C.c_int32, P(C.c_int64), vp]
     L.mpmhip_import_particles.argtypes = [vp, C.c_int64, vp]
     L.mpmhip_active_bounds.argtypes = [vp, ip, ip]

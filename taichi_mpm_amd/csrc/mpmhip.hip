@@ -898,15 +898,32 @@ __device__ __forceinline__ int dest_rank(const Params &P, const Tiling &T, float
          part_index(T.cuts[2], T.dims[2], b[2]);
 }
 
+// counts[d] = live particles whose base cell belongs to rank d != this rank; bounds[0..2] / [3..5] = min / max+1 of
+// the base cells of all live particles (one pass, one wave-reduced atomic set per wave)
 __global__ __launch_bounds__(256) void k_leaver_count(Params P, Tiling T, const float4 *__restrict__ rg,
-                                                      uint32_t *__restrict__ counts, Counters *cnt) {
+                                                      uint32_t *__restrict__ counts, int *__restrict__ bounds,
+                                                      Counters *cnt) {
+  int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_slots; i += gridDim.x * blockDim.x) {
     if (__float_as_int(rg[(size_t)i * 4 + 3].z) < 0) continue;
+    const float4 g0 = rg[(size_t)i * 4];
     bool beyond;
-    const int d = dest_rank(P, T, rg[(size_t)i * 4], beyond);
+    const int d = dest_rank(P, T, g0, beyond);
     if (d < 0) continue;
     if (beyond) atomicOr(&cnt->error, 2u);
     if (d != T.rank) atomicAdd(&counts[d], 1u);
+    const int b[3] = {(int)(g0.x * P.idx - 0.5f), (int)(g0.y * P.idx - 0.5f), (int)(g0.z * P.idx - 0.5f)};
+#pragma unroll
+    for (int k = 0; k < 3; k++) { lo[k] = min(lo[k], b[k]); hi[k] = max(hi[k], b[k] + 1); }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[k] = min(lo[k], __shfl_xor(lo[k], off));
+      hi[k] = max(hi[k], __shfl_xor(hi[k], off));
+    }
+    if ((threadIdx.x & 63) == 0 && hi[k] >= 0) { atomicMin(&bounds[k], lo[k]); atomicMax(&bounds[3 + k], hi[k]); }
   }
 }
 
@@ -2207,28 +2224,41 @@ static int ensure_counts(mpmhip_ctx *c, int world) {
   if (c->counts_cap < world) {
     hipFree(c->d_counts);
     c->d_counts = nullptr;
-    HIPCHK(c, dmalloc(&c->d_counts, (size_t)world));
+    HIPCHK(c, dmalloc(&c->d_counts, (size_t)world + 6));  // + the 6 bounds of mpmhip_migration_scan
     c->counts_cap = world;
   }
   return MPMHIP_OK;
 }
 
-int mpmhip_leaver_counts(mpmhip_ctx *c, int32_t world, int64_t *counts) {
+// one pass over the particles, one synchronisation: leaver counts per destination + bounding box of the base cells
+int mpmhip_migration_scan(mpmhip_ctx *c, int32_t world, int64_t *counts, int32_t lo[3], int32_t hi[3]) {
   if (!c || !counts) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   int rc = ensure_counts(c, world);
   if (rc) return rc;
   if (c->in_substep) return fail(c, MPMHIP_EINVAL, "migration inside a substep");
-  HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * world, c->stream));
-  hipLaunchKernelGGL(k_leaver_count, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, c->T,
-                     (const float4 *)c->rg, c->d_counts, c->cnt);
+  std::vector<uint32_t> h((size_t)world + 6, 0u);
+  for (int k = 0; k < 3; k++) { h[world + k] = (uint32_t)(1 << 30); h[world + 3 + k] = (uint32_t)-1; }
+  HIPCHK(c, hipMemcpyAsync(c->d_counts, h.data(), sizeof(uint32_t) * h.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // `h` is reused as the download target below
+  int grid = particle_grid(c->n_slots);
+  if (grid > 512) grid = 512;  // few waves: 6 atomics per wave for the bounds
+  hipLaunchKernelGGL(k_leaver_count, dim3(grid), dim3(256), 0, c->stream, c->P, c->T, (const float4 *)c->rg, c->d_counts,
+                     reinterpret_cast<int *>(c->d_counts + world), c->cnt);
   if ((rc = launch_check(c, "leaver_count"))) return rc;
-  std::vector<uint32_t> h((size_t)world);
-  HIPCHK(c, hipMemcpyAsync(h.data(), c->d_counts, sizeof(uint32_t) * world, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h.data(), c->d_counts, sizeof(uint32_t) * h.size(), hipMemcpyDeviceToHost, c->stream));
   Counters hc;
   if ((rc = read_counters(c, hc))) return rc;  // synchronises; reports the margin violation
   for (int i = 0; i < world; i++) counts[i] = h[i];
+  for (int k = 0; k < 3; k++) {
+    if (lo) lo[k] = (int32_t)h[world + k];
+    if (hi) hi[k] = (int32_t)h[world + 3 + k];
+  }
   return MPMHIP_OK;
+}
+
+int mpmhip_leaver_counts(mpmhip_ctx *c, int32_t world, int64_t *counts) {
+  return mpmhip_migration_scan(c, world, counts, nullptr, nullptr);
 }
 
 int mpmhip_export_leavers(mpmhip_ctx *c, int32_t world, const int64_t *counts, void *dev_records) {

@@ -201,10 +201,13 @@ class HipEngine:
     def end(self):
         self.sim._check(self.L.mpmhip_substep_end(self.ctx))
 
-    def leaver_counts(self):
-        out = np.zeros(self.world, np.int64)
-        self.sim._check(self.L.mpmhip_leaver_counts(self.ctx, self.world, out.ctypes.data_as(C.POINTER(C.c_int64))))
-        return out
+    def migration_scan(self):
+        """(leavers per destination rank, base-cell bounds lo, hi) — one pass, one synchronisation"""
+        out, lo, hi = np.zeros(self.world, np.int64), np.zeros(3, np.int32), np.zeros(3, np.int32)
+        ip = C.POINTER(C.c_int32)
+        self.sim._check(self.L.mpmhip_migration_scan(self.ctx, self.world, out.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                     lo.ctypes.data_as(ip), hi.ctypes.data_as(ip)))
+        return out, lo, hi
 
     def export_leavers(self, counts, buf):
         counts = np.ascontiguousarray(counts, np.int64)
@@ -217,12 +220,6 @@ class HipEngine:
         cap, slots = self.sim._capacity, int(self.L.mpmhip_num_slots(self.ctx))
         if slots > 0.85 * cap:  # dead slots (leavers) pile up: compact at the next sort
             self.sim._check(self.L.mpmhip_request_compaction(self.ctx))
-
-    def active_bounds(self):
-        lo, hi = np.zeros(3, np.int32), np.zeros(3, np.int32)
-        ip = C.POINTER(C.c_int32)
-        self.sim._check(self.L.mpmhip_active_bounds(self.ctx, lo.ctypes.data_as(ip), hi.ctypes.data_as(ip)))
-        return lo, hi
 
     def num_particles(self):
         return self.sim.get_num_particles()
@@ -244,17 +241,12 @@ class DistComm:
         out_splits, in_splits = list(map(int, out_splits)), list(map(int, in_splits))
         self.dist.all_to_all_single(out[:sum(out_splits)], inp[:sum(in_splits)], out_splits, in_splits)
 
-    def exchange_counts(self, counts):
-        t = self.torch.as_tensor(np.asarray(counts, np.int64)).to(self.device)
-        o = self.torch.empty_like(t)
-        self.dist.all_to_all_single(o, t)
-        return o.cpu().numpy()
-
-    def global_bounds(self, lo, hi):
-        t = self.torch.as_tensor(np.concatenate([-np.asarray(lo, np.int64), np.asarray(hi, np.int64)])).to(self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        t = t.cpu().numpy()
-        return -t[:3], t[3:]
+    def all_gather_ints(self, row):
+        """every rank's int64 row -> (world, len(row)) on every rank: ONE small collective per migration"""
+        t = self.torch.as_tensor(np.asarray(row, np.int64)).to(self.device)
+        o = self.torch.empty(self.world * t.numel(), dtype=t.dtype, device=self.device)
+        self.dist.all_gather_into_tensor(o, t)
+        return o.cpu().numpy().reshape(self.world, -1)
 
 
 # ---------------------------------------------------------------------------------------------------- one rank
@@ -273,9 +265,12 @@ class TiledRank:
         self.migrated_out = 0
 
     # --- migration phases
-    def mig_counts(self):
-        self._counts = self.e.leaver_counts()
-        return self._counts
+    def mig_scan(self):
+        """this rank's row of the migration table: [leavers per destination | -lo | hi] of its particles"""
+        self._counts, lo, hi = self.e.migration_scan()
+        if not (lo <= hi).all():  # no particles here
+            lo, hi = np.full(3, 1 << 30), np.full(3, -(1 << 30))
+        return np.concatenate([self._counts, -lo.astype(np.int64), hi.astype(np.int64)])
 
     def mig_export(self, incoming):
         self._incoming = np.asarray(incoming, np.int64)
@@ -295,6 +290,26 @@ class TiledRank:
         self.plan = HaloPlan(self.part, self.rank, self.e.alloc)
         self.e.configure(self.part, self.rank, self.plan)
         self.replans = getattr(self, "replans", 0) + 1
+
+
+def _finish_migration(table, world, ranks, exchange):
+    """second half of a migration, identical on every rank because it only looks at the all-gathered table
+    [counts r -> s | -lo | hi]: move the records (skipped when nobody moves), keep the halo boxes wrapped around
+    the particles.  `ranks` are the TiledRank objects of this process (one, or all of them for a virtual job)."""
+    counts = table[:, :world]  # counts[r][s]: r -> s
+    if counts.sum() > 0:
+        bufs = [r.mig_export(counts[:, r.rank]) for r in ranks]
+        exchange([b[1] for b in bufs], [b[0] for b in bufs], counts)
+        for r in ranks:
+            r.mig_import()
+    lo, hi = -table[:, world:world + 3].max(0), table[:, world + 3:world + 6].max(0)
+    part = ranks[0].part
+    if (lo <= hi).all() and not part.clip_covers(lo, hi):
+        part.set_clip_from_bounds(lo, hi)  # (a virtual job shares ONE Partition object between its ranks)
+        for r in ranks:
+            if r.part is not part:
+                r.part.set_clip_from_bounds(lo, hi)
+            r.replan()
 
 
 class TiledJob:
@@ -317,17 +332,10 @@ class TiledJob:
             self.migrate()
 
     def migrate(self):
-        r = self.r
-        counts = r.mig_counts()
-        incoming = self.comm.exchange_counts(counts)
-        send, recv = r.mig_export(incoming)
-        self.comm.all_to_all(recv, send, incoming * MIGRATE_FLOATS, counts * MIGRATE_FLOATS)
-        r.mig_import()
-        # keep the halo boxes wrapped around the occupied part of the grid (same decision on every rank)
-        lo, hi = self.comm.global_bounds(*r.e.active_bounds())
-        if (lo <= hi).all() and not r.part.clip_covers(lo, hi):
-            r.part.set_clip_from_bounds(lo, hi)
-            r.replan()
+        r, w = self.r, self.comm.world
+        table = self.comm.all_gather_ints(r.mig_scan())  # one pass over the particles, one small collective
+        _finish_migration(table, w, [r], lambda recvs, sends, cnt: self.comm.all_to_all(
+            recvs[0], sends[0], cnt[:, r.rank] * MIGRATE_FLOATS, cnt[r.rank] * MIGRATE_FLOATS))
 
     def run(self, n):
         for _ in range(n):
@@ -380,19 +388,9 @@ class VirtualTiledJob:
             self.migrate()
 
     def migrate(self):
-        counts = np.stack([r.mig_counts() for r in self.ranks])  # counts[r][s]: r -> s
-        bufs = [r.mig_export(counts[:, i]) for i, r in enumerate(self.ranks)]
-        self._a2a([b[1] for b in bufs], [b[0] for b in bufs], counts * MIGRATE_FLOATS)
-        for r in self.ranks:
-            r.mig_import()
-        bounds = [r.e.active_bounds() for r in self.ranks]
-        bounds = [b for b in bounds if (b[0] <= b[1]).all()]
-        if bounds:
-            lo, hi = np.min([b[0] for b in bounds], 0), np.max([b[1] for b in bounds], 0)
-            if not self.part.clip_covers(lo, hi):
-                self.part.set_clip_from_bounds(lo, hi)
-                for r in self.ranks:
-                    r.replan()
+        table = np.stack([r.mig_scan() for r in self.ranks])
+        _finish_migration(table, len(self.ranks), self.ranks,
+                          lambda recvs, sends, cnt: self._a2a(recvs, sends, cnt * MIGRATE_FLOATS))
 
     def run(self, n):
         for _ in range(n):

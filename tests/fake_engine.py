@@ -58,6 +58,10 @@ class OracleEngine:
     def _dest(self):
         return self.part.rank_of_cells(tiled.base_cells(self.s.x, self.dx))
 
+    def migration_scan(self):
+        lo, hi = self.active_bounds()
+        return self.leaver_counts(), lo, hi
+
     def leaver_counts(self):
         d = self._dest()
         b = tiled.base_cells(self.s.x, self.dx)
@@ -99,7 +103,7 @@ class OracleEngine:
         if self.s.n == 0:
             return np.full(3, 1 << 30, np.int32), np.full(3, -1, np.int32)
         b = tiled.base_cells(self.s.x, self.dx)
-        return (b.min(0) // 4 * 4).astype(np.int32), ((b.max(0) // 4 + 1) * 4).astype(np.int32)
+        return b.min(0).astype(np.int32), (b.max(0) + 1).astype(np.int32)
 
     def num_particles(self):
         return self.s.n
