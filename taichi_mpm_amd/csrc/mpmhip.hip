@@ -898,6 +898,12 @@ __device__ __forceinline__ int dest_rank(const Params &P, const Tiling &T, float
          part_index(T.cuts[2], T.dims[2], b[2]);
 }
 
+__global__ void k_scan_init(uint32_t *__restrict__ counts, int world) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < world) counts[t] = 0;
+  else if (t < world + 3) counts[t] = (uint32_t)(1 << 30);
+  else if (t < world + 6) counts[t] = (uint32_t)-1;
+}
 // counts[d] = live particles whose base cell belongs to rank d != this rank; bounds[0..2] / [3..5] = min / max+1 of
 // the base cells of all live particles (one pass, one wave-reduced atomic set per wave)
 __global__ __launch_bounds__(256) void k_leaver_count(Params P, Tiling T, const float4 *__restrict__ rg,
@@ -916,6 +922,8 @@ __global__ __launch_bounds__(256) void k_leaver_count(Params P, Tiling T, const 
 #pragma unroll
     for (int k = 0; k < 3; k++) { lo[k] = min(lo[k], b[k]); hi[k] = max(hi[k], b[k] + 1); }
   }
+  // wave reduce -> workgroup reduce -> 6 atomics per WORKGROUP (same-address atomics serialise at ~13 ns each)
+  __shared__ int red[4][6];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
 #pragma unroll
@@ -923,7 +931,14 @@ __global__ __launch_bounds__(256) void k_leaver_count(Params P, Tiling T, const 
       lo[k] = min(lo[k], __shfl_xor(lo[k], off));
       hi[k] = max(hi[k], __shfl_xor(hi[k], off));
     }
-    if ((threadIdx.x & 63) == 0 && hi[k] >= 0) { atomicMin(&bounds[k], lo[k]); atomicMax(&bounds[3 + k], hi[k]); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][k] = lo[k]; red[threadIdx.x >> 6][3 + k] = hi[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    const int l = min(min(red[0][k], red[1][k]), min(red[2][k], red[3][k]));
+    const int h = max(max(red[0][3 + k], red[1][3 + k]), max(red[2][3 + k], red[3][3 + k]));
+    if (h >= 0) { atomicMin(&bounds[k], l); atomicMax(&bounds[3 + k], h); }
   }
 }
 
@@ -1318,6 +1333,7 @@ struct mpmhip_ctx {
   DevBox *d_boxes = nullptr;
   uint32_t *d_counts = nullptr;
   int *d_bounds = nullptr;
+  uint32_t *h_pinned = nullptr;  // 64 KiB of pinned host memory for small readbacks (counters, migration table)
   double *d_energy = nullptr;
   int counts_cap = 0;
   bool compact_requested = false;
@@ -1451,6 +1467,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(dmalloc(&c->tiles, (size_t)mb * TN));
   A(dmalloc(&c->gridv, (size_t)mb * 8 * BC));
   A(dmalloc(&c->cnt, 1));
+  A(hipHostMalloc((void **)&c->h_pinned, 65536, hipHostMallocDefault));
   A(dmalloc(&c->d_groups, (size_t)c->groups_cap));
   if (e != hipSuccess) {
     fail(c, MPMHIP_ENOMEM, "device allocation failed: %s (max_particles=%lld, max_blocks=%lld)", hipGetErrorString(e),
@@ -1483,7 +1500,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   hipFree(c->key); hipFree(c->rank); hipFree(c->perm); hipFree(c->blk_flag); hipFree(c->bits); hipFree(c->wprefix);
   hipFree(c->fat_slot); hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->cell_cnt);
   hipFree(c->cell_start); hipFree(c->scan_slots); hipFree(c->ticket); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
-  hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_counts); hipFree(c->d_bounds); hipFree(c->d_energy);
+  hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_counts); hipFree(c->d_bounds); if (c->h_pinned) hipHostFree(c->h_pinned); hipFree(c->d_energy);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1542,8 +1559,11 @@ int mpmhip_add_group(mpmhip_ctx *c, int32_t material, const float params[MPMHIP_
 
 // synchronise and read the device counters; reports the sticky capacity error
 static int read_counters(mpmhip_ctx *c, Counters &h) {
-  HIPCHK(c, hipMemcpyAsync(&h, c->cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  // through the ctx's pinned page: an "async" copy into pageable memory is staged and costs ~50 us more
+  Counters *pin = reinterpret_cast<Counters *>(c->h_pinned);
+  HIPCHK(c, hipMemcpyAsync(pin, c->cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  h = *pin;
   if (h.error & 1u)
     return fail(c, MPMHIP_ECAPACITY, "active blocks (%u) exceed max_blocks (%u): recreate the ctx with a larger max_blocks",
                 h.n_active, c->P.max_blocks);
@@ -2237,18 +2257,17 @@ int mpmhip_migration_scan(mpmhip_ctx *c, int32_t world, int64_t *counts, int32_t
   int rc = ensure_counts(c, world);
   if (rc) return rc;
   if (c->in_substep) return fail(c, MPMHIP_EINVAL, "migration inside a substep");
-  std::vector<uint32_t> h((size_t)world + 6, 0u);
-  for (int k = 0; k < 3; k++) { h[world + k] = (uint32_t)(1 << 30); h[world + 3 + k] = (uint32_t)-1; }
-  HIPCHK(c, hipMemcpyAsync(c->d_counts, h.data(), sizeof(uint32_t) * h.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // `h` is reused as the download target below
+  if ((size_t)world + 6 + sizeof(Counters) / 4 > 65536 / 4) return fail(c, MPMHIP_EINVAL, "world too large");
+  hipLaunchKernelGGL(k_scan_init, dim3((world + 6 + 255) / 256), dim3(256), 0, c->stream, c->d_counts, world);
   int grid = particle_grid(c->n_slots);
-  if (grid > 512) grid = 512;  // few waves: 6 atomics per wave for the bounds
+  if (grid > 128) grid = 128;  // few workgroups: 6 same-address atomics each for the bounds
   hipLaunchKernelGGL(k_leaver_count, dim3(grid), dim3(256), 0, c->stream, c->P, c->T, (const float4 *)c->rg, c->d_counts,
                      reinterpret_cast<int *>(c->d_counts + world), c->cnt);
   if ((rc = launch_check(c, "leaver_count"))) return rc;
-  HIPCHK(c, hipMemcpyAsync(h.data(), c->d_counts, sizeof(uint32_t) * h.size(), hipMemcpyDeviceToHost, c->stream));
+  uint32_t *h = c->h_pinned + sizeof(Counters) / 4;  // behind the counters read_counters() fetches
+  HIPCHK(c, hipMemcpyAsync(h, c->d_counts, sizeof(uint32_t) * ((size_t)world + 6), hipMemcpyDeviceToHost, c->stream));
   Counters hc;
-  if ((rc = read_counters(c, hc))) return rc;  // synchronises; reports the margin violation
+  if ((rc = read_counters(c, hc))) return rc;  // the ONE synchronisation; reports the margin violation
   for (int i = 0; i < world; i++) counts[i] = h[i];
   for (int k = 0; k < 3; k++) {
     if (lo) lo[k] = (int32_t)h[world + k];
@@ -2272,8 +2291,9 @@ int mpmhip_export_leavers(mpmhip_ctx *c, int32_t world, const int64_t *counts, v
   for (int i = 0; i < world; i++) { cur[i] = (uint32_t)off; off += (uint64_t)counts[i]; }
   if (off == 0) return MPMHIP_OK;
   if (!dev_records) return MPMHIP_EINVAL;
-  HIPCHK(c, hipMemcpyAsync(c->d_counts, cur.data(), sizeof(uint32_t) * world, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // `cur` is a stack-owned staging buffer
+  uint32_t *pin = c->h_pinned + 1024;  // stays untouched until the next migration: no synchronisation needed
+  memcpy(pin, cur.data(), sizeof(uint32_t) * world);
+  HIPCHK(c, hipMemcpyAsync(c->d_counts, pin, sizeof(uint32_t) * world, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_leaver_pack, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, c->T, (float4 *)c->rg,
                      (const float4 *)c->rp, (const float4 *)c->rb, c->key, c->d_counts, (float4 *)dev_records, c->cnt);
   return launch_check(c, "leaver_pack");

@@ -400,7 +400,10 @@ class VirtualTiledJob:
 # ---------------------------------------------------------------------------------------------------- bench glue
 def make_tiled_job(tm, cfg, rank, world, local_rank, margin=4, migrate_interval=None):
     """bench.py, N > 1: every rank generates the same synthetic lattice, keeps its brick's particles."""
+    import os
+
     import torch
+    margin = int(os.environ.get("MPMHIP_TILE_MARGIN", margin))
     import torch.distributed as dist
 
     from .mpm import F_ID, lattice_cube
