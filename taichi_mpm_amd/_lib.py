@@ -7,7 +7,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _SRC = os.path.join(_HERE, "csrc", "mpmhip.hip")
-_DEPS = [_SRC, os.path.join(_HERE, "csrc", "mpm_math.h"), os.path.join(_ROOT, "include", "mpmhip.h")]
+_DEPS = [_SRC, os.path.join(_ROOT, "include", "mpmhip.h")] + sorted(
+    os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith(".h"))
 _LIBDIR = os.path.join(_HERE, "lib")
 _LIB = os.path.join(_LIBDIR, "libmpmhip.so")
 

@@ -1,0 +1,51 @@
+// taichi_mpm_amd/csrc/k_debug.h — device math exposed for parity tests (mpmhip_debug_*)
+// Part of libmpmhip (see mpmhip.hip for the substep overview and the data layout).
+#pragma once
+#include "mpm_common.h"
+
+namespace mpm {
+
+// ------------------------------------------------------------------------------------------------ debug math
+__global__ void k_debug_svd(int64_t n, const float *F, float *U, float *S, float *V) {
+  for (int64_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    mat3 f, u;
+    for (int k = 0; k < 9; k++) f.m[k] = F[9 * i + k];
+    float lam[3], s[3];
+    sym_eig3_FFt(f, u, lam);
+    signed_sigma(lam, mat_det(f), s);
+    for (int k = 0; k < 9; k++) U[9 * i + k] = u.m[k];
+    for (int k = 0; k < 3; k++) S[3 * i + k] = s[k];
+    // V = F^T U S^-1 (never needed by the product path; provided for the parity test)
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) V[9 * i + 3 * r + c] = (f(0, r) * u(0, c) + f(1, r) * u(1, c) + f(2, r) * u(2, c)) / s[c];
+  }
+}
+__global__ void k_debug_force(GroupParams g, int64_t n, const float *F, const float *aux, float *out) {
+  for (int64_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    mat3 f;
+    for (int k = 0; k < 9; k++) f.m[k] = F[9 * i + k];
+    mat3 r = calculate_force(g, f, aux[i]);
+    for (int k = 0; k < 9; k++) out[9 * i + k] = r.m[k];
+  }
+}
+// plasticity alone, or (force_out != nullptr) the fused plasticity + next-step force of k_g2p
+__global__ void k_debug_plasticity(GroupParams g, int64_t n, const float *cdg, float *F, float *aux, float *force_out) {
+  for (int64_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    mat3 f, c;
+    for (int k = 0; k < 9; k++) { f.m[k] = F[9 * i + k]; c.m[k] = cdg[9 * i + k]; }
+    float a = aux[i];
+    if (force_out) {
+      mat3 st;
+      plasticity_and_force(g, c, f, a, st);
+      for (int k = 0; k < 9; k++) force_out[9 * i + k] = st.m[k];
+    } else {
+      plasticity(g, c, f, a);
+    }
+    if (g.type != MPMHIP_WATER)
+      for (int k = 0; k < 9; k++) F[9 * i + k] = f.m[k];
+    aux[i] = a;
+  }
+}
+
+
+}  // namespace mpm

@@ -1,0 +1,244 @@
+// taichi_mpm_amd/csrc/k_g2p.h — G2P (resample_optimized, src/transfer.cpp:837-954) with the fused constitutive update
+// Part of libmpmhip (see mpmhip.hip for the substep overview and the data layout).
+#pragma once
+#include "mpm_common.h"
+
+namespace mpm {
+
+// ------------------------------------------------------------------------------------------------ G2P
+// resample_optimized / block_op_normal (src/transfer.cpp:837-954), one workgroup per active block, one
+// particle per lane through the sorted index.  Also produces, for the NEXT substep: the affine matrix A of
+// P2G (stress of the updated F from the same eigen-solve as the plasticity) and the sort key of the new position.
+template <int NT, int MINW, bool ROLL>
+__global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__ rg, float4 *__restrict__ rp,
+                                                  float4 *__restrict__ rb, const Counters *__restrict__ cnt,
+                                                  const uint32_t *__restrict__ act_blk,
+                                                  const uint32_t *__restrict__ act_start,
+                                                  const uint32_t *__restrict__ perm,
+                                                  const GroupParams *__restrict__ groups,
+                                                  const float4 *__restrict__ gridv,
+                                                  const uint32_t *__restrict__ fat_slot, Counters *cnt_w,
+                                                  uint32_t *__restrict__ key, uint8_t *__restrict__ blk_flag,
+                                                  LevelSetDev LS) {
+  __shared__ float4 tile[TN];
+  // Store staging, one slab per wavefront.  A lane holds its particle's whole record, so a direct store would
+  // issue 16-byte pieces at a 64-byte stride: 64 partial-line write requests per instruction (measured: the
+  // stores alone cost 0.28 of 0.61 ms).  Records are written row-wise to LDS (80-byte stride: conflict-free
+  // b128) and read back transposed, so 4 consecutive lanes store the 4 float4 of one record: full 64-byte
+  // segments, 4x fewer write requests.
+  __shared__ float4 xpose[NT / 64][64 * 5];
+  __shared__ uint32_t xslot[NT / 64][64];
+  const uint32_t na = min(cnt->n_active, P.max_blocks);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  float4 *xp = xpose[wave];
+  uint32_t *xs = xslot[wave];
+  const float scale = -4.0f * P.idx * P.dt;  // :938
+  // The workgroup walks "chunks": NT consecutive entries of the sorted index inside one active block.  The
+  // record gather of chunk k+1 and the index load of chunk k+2 are issued before the arithmetic of chunk k
+  // (also across block boundaries), so every wave keeps 4 KiB of loads in flight while it computes.
+  struct Chunk { uint32_t a, p, p1; };
+  auto first = [&](uint32_t a) {
+    Chunk c;
+    c.a = a; c.p = 0; c.p1 = 0;
+    while (c.a < na) {
+      c.p = act_start[c.a]; c.p1 = act_start[c.a + 1];
+      if (c.p < c.p1) break;
+      c.a += gridDim.x;  // empty block (all its particles migrated away)
+    }
+    return c;
+  };
+  auto next = [&](Chunk c) {
+    if (c.a >= na) return c;
+    c.p += NT;
+    if (c.p >= c.p1) c = first(c.a + gridDim.x);
+    return c;
+  };
+  auto lane_slot = [&](const Chunk &c) -> uint32_t {
+    return (c.a < na && c.p + tid < c.p1) ? perm[c.p + tid] : INVALID;
+  };
+  Chunk cur = first(blockIdx.x);
+  Chunk nx = next(cur);
+  uint32_t i_cur = lane_slot(cur);
+  float4 g0, g1, g2, g3;
+  if (i_cur != INVALID) {
+    const size_t i = i_cur;
+    g0 = rg[i * 4 + 0]; g1 = rg[i * 4 + 1]; g2 = rg[i * 4 + 2]; g3 = rg[i * 4 + 3];
+  }
+  uint32_t i_nx = lane_slot(nx);
+  uint32_t tile_a = INVALID;
+  float ox = 0, oy = 0, oz = 0;
+  while (cur.a < na) {
+    if (cur.a != tile_a) {
+      __syncthreads();  // everyone is done with the previous tile
+      int bx, by, bz;
+      demorton3(act_blk[cur.a], bx, by, bz);
+      for (int t = tid; t < TN; t += NT) {
+        const int tx = t / (TS * TS), ty = (t / TS) % TS, tz = t % TS;
+        const int qx = tx >> 2, qy = ty >> 2, qz = tz >> 2;
+        const uint32_t fs = fat_slot[morton3(bx + qx, by + qy, bz + qz)];
+        tile[t] = gridv[(size_t)fs * BC + (((tx & 3) << 4) | ((ty & 3) << 2) | (tz & 3))];
+      }
+      __syncthreads();
+      ox = (float)(bx * BS); oy = (float)(by * BS); oz = (float)(bz * BS);
+      tile_a = cur.a;
+    }
+    // prefetch: records of the next chunk, index of the one after
+    const Chunk nn = next(nx);
+    float4 n0, n1, n2, n3;
+    if (i_nx != INVALID) {
+      const size_t i = i_nx;
+      n0 = rg[i * 4 + 0]; n1 = rg[i * 4 + 1]; n2 = rg[i * 4 + 2]; n3 = rg[i * 4 + 3];
+    }
+    const uint32_t i_nn = lane_slot(nn);
+    uint32_t bkey = INVALID, out_slot = INVALID;
+    float4 G0, G1, G2, G3, Q0, Q1, Q2, Q3, B0, B1, B2;
+    G0 = G1 = G2 = G3 = Q0 = Q1 = Q2 = Q3 = B0 = B1 = B2 = make_float4(0, 0, 0, 0);
+    if (i_cur != INVALID) {
+      const size_t i = i_cur;
+      const uint32_t gid = __float_as_uint(g3.y);
+      const GroupParams &g = groups[gid];  // read at use (L1-resident table): keeps 20 VGPRs free
+      const float x0 = g0.x, x1 = g0.y, x2 = g0.z;
+      const float X0 = x0 * P.idx - ox, X1 = x1 * P.idx - oy, X2 = x2 * P.idx - oz;
+      const int c0 = (int)(X0 - 0.5f), c1 = (int)(X1 - 0.5f), c2 = (int)(X2 - 0.5f);
+      const float r0 = X0 - (float)c0, r1 = X1 - (float)c1, r2 = X2 - (float)c2;
+      float w0[3], w1[3], w2[3];
+      bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
+      float v0 = 0, v1 = 0, v2 = 0;
+      mat3 b;
+#pragma unroll
+      for (int k = 0; k < 9; k++) b.m[k] = 0.0f;
+      const int nbase = (c0 * TS + c1) * TS + c2;
+      auto plane = [&](int i3) __attribute__((always_inline)) {
+        const float d0 = r0 - (float)i3;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const float d1 = r1 - (float)j;
+          const float wij = w0[i3] * w1[j];
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const float d2 = r2 - (float)k;
+            const float w = wij * w2[k];
+            const float4 gv = tile[nbase + (i3 * TS + j) * TS + k];
+            // :898-903  v_ = fma(grid_vel, w, v_);  b_[r] = fma(w*grid_vel, dpos[r], b_[r])
+            v0 = fmaf(gv.x, w, v0); v1 = fmaf(gv.y, w, v1); v2 = fmaf(gv.z, w, v2);
+            const float a0 = w * gv.x, a1 = w * gv.y, a2 = w * gv.z;
+            b(0, 0) = fmaf(a0, d0, b(0, 0)); b(0, 1) = fmaf(a0, d1, b(0, 1)); b(0, 2) = fmaf(a0, d2, b(0, 2));
+            b(1, 0) = fmaf(a1, d0, b(1, 0)); b(1, 1) = fmaf(a1, d1, b(1, 1)); b(1, 2) = fmaf(a1, d2, b(1, 2));
+            b(2, 0) = fmaf(a2, d0, b(2, 0)); b(2, 1) = fmaf(a2, d1, b(2, 1)); b(2, 2) = fmaf(a2, d2, b(2, 2));
+          }
+        }
+      };
+      if (!(P.ablate & 4)) {
+        if constexpr (ROLL) {  // rolled i-loop: 9 LDS reads in flight instead of 27 (VGPR pressure -> occupancy)
+#pragma unroll 1
+          for (int i3 = 0; i3 < 3; i3++) plane(i3);
+        } else {
+          plane(0); plane(1); plane(2);
+        }
+      }
+      mat3 cdg;  // :940-942  cdg = I + (-4 inv_dx dt) b   (undamped b, as in the reference)
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) cdg(r, c) = fmaf(scale, b(r, c), (r == c) ? 1.0f : 0.0f);
+      // apic_b = damp_affine_momemtum(b) (src/mpm.h:465-469); the reference's optimised path has a bug
+      // here (passes the block index, transfer.cpp:925-926) — we implement the intended damping.
+      if (P.rpic_damping != 0.0f || P.apic_damping != 0.0f) {
+        const float ks = 1.0f - P.rpic_damping, ka = 1.0f - P.apic_damping;
+        mat3 bd;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const float sym = 0.5f * (b(r, c) + b(c, r));
+            bd(r, c) = ks * sym + ka * (b(r, c) - sym);
+          }
+        b = bd;
+      }
+      mat3 F;
+      F.m[0] = g1.x; F.m[1] = g1.y; F.m[2] = g1.z; F.m[3] = g1.w; F.m[4] = g2.x; F.m[5] = g2.y; F.m[6] = g2.z;
+      F.m[7] = g2.w; F.m[8] = g3.x;
+      float aux = g0.w;
+      mat3 stress;
+      if (!(P.ablate & 2)) plasticity_and_force(g, cdg, F, aux, stress);  // :950 + next substep's :509
+      else stress = cdg;
+      float nx0 = fmaf(v0, P.dt, x0), nx1 = fmaf(v1, P.dt, x1), nx2 = fmaf(v2, P.dt, x2);  // :951
+      if (LS.particle_collision) {  // particle_collision_resolution, src/mpm.cpp:414-426 (runs after G2P, :566-569)
+        const float xw[3] = {nx0, nx1, nx2};
+        float phi, gr[3] = {0, 0, 0};
+        if (levelset_eval(LS, xw, P.idx, phi, gr) && phi < 0.0f) {
+          const float vn = gr[0] * v0 + gr[1] * v1 + gr[2] * v2;
+          nx0 -= gr[0] * phi * P.dx; nx1 -= gr[1] * phi * P.dx; nx2 -= gr[2] * phi * P.dx;
+          v0 -= vn * gr[0]; v1 -= vn * gr[1]; v2 -= vn * gr[2];
+        }
+      }
+      const float m4 = 4.0f * g.p[0];
+      float A[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) A[k] = fmaf(stress.m[k], scale, b.m[k] * m4);  // next P2G's :521-522
+      // next substep's key; deleted particles (clear_boundary_particles) are marked for good
+      const float nxp[3] = {nx0, nx1, nx2}, nv[3] = {v0, v1, v2};
+      const uint32_t kk = particle_key(P, nxp, nv, bkey);
+      int32_t pid = __float_as_int(g3.z);
+      if (kk == INVALID) {
+        pid = -1;
+        atomicAdd(&cnt_w->n_dead, 1u);
+      }
+      key[i] = kk;
+      G0 = make_float4(nx0, nx1, nx2, aux);
+      G1 = make_float4(F.m[0], F.m[1], F.m[2], F.m[3]);
+      G2 = make_float4(F.m[4], F.m[5], F.m[6], F.m[7]);
+      G3 = make_float4(F.m[8], g3.y, __int_as_float(pid), 0.0f);
+      Q0 = make_float4(nx0, nx1, nx2, v0);
+      Q1 = make_float4(v1, v2, A[0], A[1]);
+      Q2 = make_float4(A[2], A[3], A[4], A[5]);
+      Q3 = make_float4(A[6], A[7], A[8], g.p[0]);
+      B0 = make_float4(b.m[0], b.m[1], b.m[2], b.m[3]);
+      B1 = make_float4(b.m[4], b.m[5], b.m[6], b.m[7]);
+      B2 = make_float4(b.m[8], 0.0f, 0.0f, 0.0f);
+      out_slot = (P.ablate & 1) ? INVALID : i_cur;
+    }
+    // transposed stores through this wave's LDS slab (DS operations of one wave execute in program order)
+    xs[lane] = out_slot;
+    xp[lane * 5 + 0] = G0; xp[lane * 5 + 1] = G1; xp[lane * 5 + 2] = G2; xp[lane * 5 + 3] = G3;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int src = 16 * k + (lane >> 2), q = lane & 3;
+      const uint32_t sl = xs[src];
+      const float4 val = xp[src * 5 + q];
+      if (sl != INVALID) rg[(size_t)sl * 4 + q] = val;
+    }
+    __builtin_amdgcn_wave_barrier();
+    xp[lane * 5 + 0] = Q0; xp[lane * 5 + 1] = Q1; xp[lane * 5 + 2] = Q2; xp[lane * 5 + 3] = Q3;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int src = 16 * k + (lane >> 2), q = lane & 3;
+      const uint32_t sl = xs[src];
+      const float4 val = xp[src * 5 + q];
+      if (sl != INVALID) rp[(size_t)sl * 4 + q] = val;
+    }
+    if (P.store_b) {
+      __builtin_amdgcn_wave_barrier();
+      xp[lane * 5 + 0] = B0; xp[lane * 5 + 1] = B1; xp[lane * 5 + 2] = B2;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int e = 64 * k + lane, src = e / 3, q = e - 3 * src;
+        const uint32_t sl = xs[src];
+        const float4 val = xp[src * 5 + q];
+        if (sl != INVALID) rb[(size_t)sl * 3 + q] = val;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    flag_block(blk_flag, bkey);
+    cur = nx; nx = nn;
+    i_cur = i_nx; i_nx = i_nn;
+    g0 = n0; g1 = n1; g2 = n2; g3 = n3;
+  }
+}
+
+
+}  // namespace mpm

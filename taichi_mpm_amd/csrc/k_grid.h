@@ -1,0 +1,157 @@
+// taichi_mpm_amd/csrc/k_grid.h — grid normalise + gravity + level-set boundary (+ halo sums, dense views, kinetic energy)
+// Part of libmpmhip (see mpmhip.hip for the substep overview and the data layout).
+#pragma once
+#include "mpm_common.h"
+
+namespace mpm {
+
+// ------------------------------------------------------------------------------------------------ grid
+// One wavefront per (active block a, o).  The tile of a overlaps the 8 grid blocks c = block(a) + o, o in {0,1}^3
+// ("candidates").  A grid block c is processed by its "owner": the candidate with the smallest o among the
+// active blocks c - o'.  The owner sums the overlapping tiles (<= 8), then
+//   mode 0: normalize_grid_and_apply_external_force + apply_grid_boundary_conditions (src/mpm.cpp:277-372)
+//           -> gridv[slot = 8a+o], fat_slot[morton(c)] = slot
+//   mode 1: raw (m v, m) sums written to a dense node-major array (parity / download only)
+//   mode 2: dense (v, m) array -> gridv (upload_grid)        mode 3: gridv -> dense (download_grid)
+// All candidate/owner/source lookups of a block involve only its 27 neighbours b + {-1,0,1}^3: lanes 0..26
+// look one neighbour up each (one round trip), the rest is ballots and shuffles.
+__device__ __forceinline__ constexpr int nb27(int dx, int dy, int dz) { return ((dx + 1) * 3 + (dy + 1)) * 3 + (dz + 1); }
+
+template <int MODE, bool PER_CAND>
+__global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restrict__ cnt,
+                                              const uint32_t *__restrict__ act_blk,
+                                              const uint32_t *__restrict__ bits,
+                                              const uint32_t *__restrict__ wprefix,
+                                              const float4 *__restrict__ tiles, float4 *__restrict__ gridv,
+                                              uint32_t *__restrict__ fat_slot, float4 *__restrict__ dense, Tiling T,
+                                              const DevBox *__restrict__ boxes, LevelSetDev LS) {
+  const uint32_t na = min(cnt->n_active, P.max_blocks);
+  const int l = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int lx = l >> 4, ly = (l >> 2) & 3, lz = l & 3;
+  // The kernel is a chain of dependent lookups (block list -> bitmap/prefix -> tiles -> halo -> store).
+  // PER_CAND = false: one wavefront per active block walks its 8 candidates (lookups shared; best when there are
+  // more blocks than resident waves).  PER_CAND = true: one wavefront per (block, candidate) — 8x the lookups but
+  // an 8x shorter chain for the boundary blocks that own many candidates (best for small per-GPU problems, i.e.
+  // the tiled multi-GPU runs: 32 -> 19 us at 1 M particles; 33 -> 88 us at 8 M, hence the switch in do_grid).
+  const uint32_t nwork = PER_CAND ? na * 8u : na;
+  for (uint32_t work = wave; work < nwork; work += nwaves) {
+    const uint32_t a = PER_CAND ? work >> 3 : work;
+    const int o_mine = PER_CAND ? (int)(work & 7u) : -1;
+    int bx, by, bz;
+    demorton3(act_blk[a], bx, by, bz);
+    // neighbour table: lane n < 27 holds (active?, slot) of block b + (n/9-1, n/3%3-1, n%3-1)
+    uint32_t nslot = INVALID;
+    if (l < 27) {
+      const int sx = bx + l / 9 - 1, sy = by + (l / 3) % 3 - 1, sz = bz + l % 3 - 1;
+      if (sx >= 0 && sy >= 0 && sz >= 0) {
+        const uint32_t bk = morton3(sx, sy, sz);
+        if (block_active(bits, bk)) nslot = block_slot(bits, wprefix, bk);
+      }
+    }
+    const uint32_t amask = (uint32_t)__ballot(nslot != INVALID);
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+      if (PER_CAND && o != o_mine) continue;  // wave-uniform (the loop stays unrolled: compile-time masks)
+      const int ox = o >> 2, oy = (o >> 1) & 1, oz = o & 1;
+      // sources of c = b + o are c - q = b + (o - q), q in {0,1}^3; owner <=> none of them active for q < o
+      uint32_t lower = 0;
+#pragma unroll
+      for (int q = 0; q < o; q++) lower |= 1u << nb27(ox - (q >> 2), oy - ((q >> 1) & 1), oz - (q & 1));
+      if (amask & lower) continue;  // wave-uniform
+      const int cx = bx + ox, cy = by + oy, cz = bz + oz;
+      const uint32_t slot = a * 8u + (uint32_t)o;
+      const int gi = cx * BS + lx, gj = cy * BS + ly, gk = cz * BS + lz;
+      const bool in_grid = gi <= P.res[0] && gj <= P.res[1] && gk <= P.res[2];
+      const size_t dense_idx = ((size_t)gi * (P.res[1] + 1) + gj) * (P.res[2] + 1) + gk;
+      if (MODE == 2) {
+        gridv[(size_t)slot * BC + l] = in_grid ? dense[dense_idx] : make_float4(0, 0, 0, 0);
+        if (l == 0) fat_slot[morton3(cx, cy, cz)] = slot;
+        continue;
+      }
+      if (MODE == 3) {
+        if (in_grid) dense[dense_idx] = gridv[(size_t)slot * BC + l];
+        continue;
+      }
+      float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int qx = q >> 2, qy = (q >> 1) & 1, qz = q & 1;
+        const int nidx = nb27(ox - qx, oy - qy, oz - qz);
+        const uint32_t sslot = __shfl(nslot, nidx);
+        const int tx = lx + 4 * qx, ty = ly + 4 * qy, tz = lz + 4 * qz;
+        if (((amask >> nidx) & 1u) && tx < TS && ty < TS && tz < TS) {
+          const float4 t = tiles[(size_t)sslot * TN + (tx * TS + ty) * TS + tz];
+          acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+      }
+      if (T.n_boxes > 0) {  // tiled: add the other ranks' partial sums, contributors in rank order
+        const bool interior = gi >= T.int_lo[0] && gi < T.int_hi[0] && gj >= T.int_lo[1] && gj < T.int_hi[1] &&
+                              gk >= T.int_lo[2] && gk < T.int_hi[2];
+        if (__any(!interior)) {
+          // contributors in rank order; the peers' values are fetched eight boxes at a time (independent loads,
+          // one round trip) and then added in order
+          float4 tot = make_float4(0, 0, 0, 0);
+          bool own = false;
+          for (int b0 = 0; b0 < T.n_boxes; b0 += 8) {
+            float4 r[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              r[u] = make_float4(0, 0, 0, 0);
+              if (b0 + u < T.n_boxes) {
+                const DevBox &B = boxes[b0 + u];
+                const int x = gi - B.lo[0], y = gj - B.lo[1], z = gk - B.lo[2];
+                if ((unsigned)x < (unsigned)B.dim[0] && (unsigned)y < (unsigned)B.dim[1] && (unsigned)z < (unsigned)B.dim[2])
+                  r[u] = B.recv[((size_t)x * B.dim[1] + y) * B.dim[2] + z];
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              if (b0 + u < T.n_boxes) {
+                if (!own && boxes[b0 + u].peer > T.rank) {
+                  tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w;
+                  own = true;
+                }
+                tot.x += r[u].x; tot.y += r[u].y; tot.z += r[u].z; tot.w += r[u].w;
+              }
+            }
+          }
+          if (!own) { tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w; }
+          acc = tot;
+        }
+      }
+      if (MODE == 1) {
+        if (in_grid) dense[dense_idx] = acc;
+        continue;
+      }
+      if (MODE == 4) {  // grid kinetic energy sum 1/2 m |v|^2 with v = (m v)/m (calculate_energy, src/mpm.cpp:1078-1096)
+        double e = (acc.w != 0.0f) ? 0.5 * ((double)acc.x * acc.x + (double)acc.y * acc.y + (double)acc.z * acc.z) / acc.w : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
+        if (l == 0) atomicAdd(reinterpret_cast<double *>(dense), e);
+        continue;
+      }
+      float v[3] = {acc.x, acc.y, acc.z};
+      const float m = acc.w;
+      if (m > 0.0f) {  // src/mpm.cpp:282-292; increment is gravity*dt only when !particle_gravity (:526-530)
+        const float im = 1.0f / m;
+#pragma unroll
+        for (int k = 0; k < 3; k++) v[k] = fmaf(v[k], im, P.particle_gravity ? 0.0f : P.g[k] * P.dt);
+      }
+      if (m != 0.0f && LS.n > 0) {  // src/mpm.cpp:313-368
+        const float xw[3] = {gi * P.dx, gj * P.dx, gk * P.dx};
+        float phi, nrm[3] = {0, 0, 0};
+        levelset_eval(LS, xw, P.idx, phi, nrm);
+        if (!(phi < -3.0f || 0.0f < phi)) {
+          const float vb[3] = {0, 0, 0};
+          friction_project(v, vb, nrm, LS.friction);
+        }
+      }
+      gridv[(size_t)slot * BC + l] = make_float4(v[0], v[1], v[2], m);
+      if (l == 0) fat_slot[morton3(cx, cy, cz)] = slot;
+    }
+  }
+}
+
+
+}  // namespace mpm

@@ -1,0 +1,142 @@
+// taichi_mpm_amd/csrc/k_p2g.h — P2G (rasterize_optimized, src/transfer.cpp:467-569)
+// Part of libmpmhip (see mpmhip.hip for the substep overview and the data layout).
+#pragma once
+#include "mpm_common.h"
+
+namespace mpm {
+
+// ------------------------------------------------------------------------------------------------ P2G
+// rasterize_optimized / block_op_normal (src/transfer.cpp:467-569).
+// Mapping: ONE LANE PER CELL of an active 4^3-cell block.  The sorted index lists the particles of each cell
+// contiguously, so lane c walks its cell's particles and accumulates their node contributions in registers (the
+// reference walks cells sequentially inside a block and accumulates into its scratch tile the same way,
+// :474-483).  Write conflicts between particles of one cell therefore never reach memory; a wave merges its
+// per-cell sums into its own 6^3-node LDS tile by ordered, non-atomic float4 read-modify-writes and the tile is
+// written out whole; conflicts between blocks are resolved by k_grid.  p2g_cell<N0,N1> handles stencil nodes
+// N0..N1-1 of the particles [p0,p1) of the lane's cell, so a block can be one wave (default) or several waves
+// splitting the nodes and/or the particles (k_p2g<NS,PS>).
+template <int N0, int N1>
+__device__ __forceinline__ void p2g_cell(const Params &P, const float4 *__restrict__ rp,
+                                         const uint32_t *__restrict__ perm,
+                                         const GroupParams *__restrict__ groups, uint32_t p0, uint32_t p1, float ox,
+                                         float oy, float oz, int nbase, float4 *tile) {
+  constexpr int NN = N1 - N0;
+  float acc[NN][4];
+#pragma unroll
+  for (int n = 0; n < NN; n++) { acc[n][0] = 0.0f; acc[n][1] = 0.0f; acc[n][2] = 0.0f; acc[n][3] = 0.0f; }
+  // software pipeline: the records of the next TWO particles and the index of the third are in flight while
+  // one particle is computed (one particle's arithmetic is shorter than the loaded HBM latency)
+  float4 n0, n1, n2, n3, m0, m1, m2, m3;
+  uint32_t inext = 0;
+  if (p0 < p1) {
+    const size_t i = perm[p0];
+    n0 = rp[i * 4 + 0]; n1 = rp[i * 4 + 1]; n2 = rp[i * 4 + 2]; n3 = rp[i * 4 + 3];
+    if (p0 + 1 < p1) {
+      const size_t j = perm[p0 + 1];
+      m0 = rp[j * 4 + 0]; m1 = rp[j * 4 + 1]; m2 = rp[j * 4 + 2]; m3 = rp[j * 4 + 3];
+      if (p0 + 2 < p1) inext = perm[p0 + 2];
+    }
+  }
+  for (uint32_t p = p0; p < p1; p++) {
+    const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
+    n0 = m0; n1 = m1; n2 = m2; n3 = m3;
+    if (p + 2 < p1) {
+      const size_t i = inext;
+      m0 = rp[i * 4 + 0]; m1 = rp[i * 4 + 1]; m2 = rp[i * 4 + 2]; m3 = rp[i * 4 + 3];
+      if (p + 3 < p1) inext = perm[p + 3];
+    }
+    const float mass = q3.w;  // the particle mass travels in the record: no dependent table lookup
+    float v0 = q0.w, v1 = q1.x, v2 = q1.y;
+    if (P.particle_gravity) {  // src/transfer.cpp:485-487
+      v0 = fmaf(P.g[0], P.dt, v0); v1 = fmaf(P.g[1], P.dt, v1); v2 = fmaf(P.g[2], P.dt, v2);
+    }
+    // position relative to the base cell, in grid units: in [0.5, 1.5)^3  (:490,518)
+    const float r0 = q0.x * P.idx - ox, r1 = q0.y * P.idx - oy, r2 = q0.z * P.idx - oz;
+    float w0[3], w1[3], w2[3];
+    bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
+    const float A00 = q1.z, A01 = q1.w, A02 = q2.x, A10 = q2.y, A11 = q2.z, A12 = q2.w, A20 = q3.x, A21 = q3.y,
+                A22 = q3.z;
+    const float mv0 = mass * v0, mv1 = mass * v1, mv2 = mass * v2;
+#pragma unroll
+    for (int n = N0; n < N1; n++) {
+      const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
+      const float d0 = r0 - (float)i3, d1 = r1 - (float)j, d2 = r2 - (float)k;
+      const float w = (w0[i3] * w1[j]) * w2[k];
+      // :535-541  contrib = (affine * dpos + mass*v, mass); g += weight * contrib
+      const float c0 = fmaf(A02, d2, fmaf(A01, d1, fmaf(A00, d0, mv0)));
+      const float c1 = fmaf(A12, d2, fmaf(A11, d1, fmaf(A10, d0, mv1)));
+      const float c2 = fmaf(A22, d2, fmaf(A21, d1, fmaf(A20, d0, mv2)));
+      acc[n - N0][0] = fmaf(w, c0, acc[n - N0][0]);
+      acc[n - N0][1] = fmaf(w, c1, acc[n - N0][1]);
+      acc[n - N0][2] = fmaf(w, c2, acc[n - N0][2]);
+      acc[n - N0][3] = fmaf(w, mass, acc[n - N0][3]);
+    }
+  }
+  // Merge the per-cell sums into this wave's tile.  The tile belongs to this wavefront alone, and within one
+  // stencil-offset step all 64 lanes address distinct nodes (same offset, different cells), so a plain float4
+  // read-modify-write is race-free as long as the steps stay in program order: LDS operations of one wave
+  // execute in order, the wave_barrier keeps the compiler from interleaving them.  (DS float atomics cost
+  // ~2 LDS cycles per LANE on gfx950 even without conflicts: measured 145 cycles per ds_add_f32.)
+#pragma unroll
+  for (int n = N0; n < N1; n++) {
+    const int node = nbase + ((n / 9) * TS + (n / 3) % 3) * TS + n % 3;
+    if ((P.ablate & 8) && acc[n - N0][3] != 1.2345e-30f) continue;
+    if (p1 > p0) {
+      float4 t = tile[node];
+      t.x += acc[n - N0][0]; t.y += acc[n - N0][1]; t.z += acc[n - N0][2]; t.w += acc[n - N0][3];
+      tile[node] = t;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+}
+
+// NS = waves splitting the 27 stencil nodes (1 or 2), PS = waves splitting every cell's particles (1, 2 or 4):
+// NS*PS wavefronts per block, each with its own LDS tile.  Node splitting halves the accumulator registers
+// (occupancy) but both halves load the same records; particle splitting keeps every record load unique.
+template <int NS, int PS, int MINW>
+__global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const float4 *__restrict__ rp,
+                                                            const Counters *__restrict__ cnt,
+                                                            const uint32_t *__restrict__ act_blk,
+                                                            const uint32_t *__restrict__ cell_start,
+                                                            const uint32_t *__restrict__ perm,
+                                                            const GroupParams *__restrict__ groups,
+                                                            float4 *__restrict__ tiles) {
+  constexpr int NW = NS * PS, NT = 64 * NW;
+  __shared__ float4 tile[NW][TN];  // per wave: (m*vx, m*vy, m*vz, m) per node of the block's 6^3 tile
+  const uint32_t na = min(cnt->n_active, P.max_blocks);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int npart = wave % NS, ppart = wave / NS;
+  const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
+  const int nbase = (cx * TS + cy) * TS + cz;
+  for (uint32_t a = blockIdx.x; a < na; a += gridDim.x) {
+    for (int t = threadIdx.x; t < NW * TN; t += NT) (&tile[0][0])[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    __syncthreads();
+    int bx, by, bz;
+    demorton3(act_blk[a], bx, by, bz);
+    const float ox = (float)(bx * BS + cx), oy = (float)(by * BS + cy), oz = (float)(bz * BS + cz);
+    const uint32_t c0 = cell_start[a * BC + lane], c1 = cell_start[a * BC + lane + 1];
+    const uint32_t n = c1 - c0;
+    const uint32_t p0 = c0 + (n * ppart + PS - 1) / PS, p1 = c0 + (n * (ppart + 1) + PS - 1) / PS;
+    if constexpr (NS == 1) {
+      p2g_cell<0, 27>(P, rp, perm, groups, p0, p1, ox, oy, oz, nbase, tile[wave]);
+    } else {
+      if (npart == 0) p2g_cell<0, 14>(P, rp, perm, groups, p0, p1, ox, oy, oz, nbase, tile[wave]);
+      else p2g_cell<14, 27>(P, rp, perm, groups, p0, p1, ox, oy, oz, nbase, tile[wave]);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < TN; t += NT) {
+      float4 u = tile[0][t];
+#pragma unroll
+      for (int w = 1; w < NW; w++) {
+        const float4 q = tile[w][t];
+        u.x += q.x; u.y += q.y; u.z += q.z; u.w += q.w;
+      }
+      tiles[(size_t)a * TN + t] = u;
+    }
+    __syncthreads();
+  }
+}
+
+
+}  // namespace mpm

@@ -1,0 +1,100 @@
+// taichi_mpm_amd/csrc/k_particles.h — per-particle state kernels off the hot path: affine matrix (re)build, apic_b recovery, potential energy
+// Part of libmpmhip (see mpmhip.hip for the substep overview and the data layout).
+#pragma once
+#include "mpm_common.h"
+
+namespace mpm {
+
+// ------------------------------------------------------------------------------------------------ affine
+// A = stress * (-4 inv_dx dt) + apic_b * (4 m)   (src/transfer.cpp:465,507,521-522) for every live particle,
+// from (F, aux, apic_b).  Needed only when the state did not come out of k_g2p (first substep, uploads).
+__global__ __launch_bounds__(256) void k_affine(Params P, const RecG *__restrict__ rg, RecP *__restrict__ rp,
+                                                const float *__restrict__ rb, const GroupParams *__restrict__ groups) {
+  const float S = -4.0f * P.idx * P.dt;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_slots; i += gridDim.x * blockDim.x) {
+    const RecG r = rg[i];
+    if (r.pid < 0) continue;
+    const GroupParams g = groups[r.gid];
+    mat3 F;
+#pragma unroll
+    for (int k = 0; k < 9; k++) F.m[k] = r.F[k];
+    const mat3 stress = calculate_force(g, F, r.aux);
+    const float m4 = 4.0f * g.p[0];
+#pragma unroll
+    for (int k = 0; k < 9; k++) rp[i].A[k] = fmaf(stress.m[k], S, rb[(size_t)i * BW + k] * m4);
+  }
+}
+
+// inverse of k_affine for ctxs that fold apic_b into A (discard_apic_b): apic_b = (A - stress * S) / (4 m),
+// written to the side array.  Runs only when somebody asks for apic_b (download, upload of F/aux, new particles).
+// Accuracy: the stress is re-evaluated from the stored (F, aux) by calculate_force(), not by the fused G2P path
+// that produced A, so apic_b comes back to ~1e-6 * |stress S| / (4 m) absolute — 1e-5..1e-4 relative in practice.
+__global__ __launch_bounds__(256) void k_recover_b(Params P, const RecG *__restrict__ rg, const RecP *__restrict__ rp,
+                                                   float *__restrict__ rb, const GroupParams *__restrict__ groups) {
+  const float S = -4.0f * P.idx * P.dt;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_slots; i += gridDim.x * blockDim.x) {
+    const RecG r = rg[i];
+    if (r.pid < 0) continue;
+    const GroupParams g = groups[r.gid];
+    mat3 F;
+#pragma unroll
+    for (int k = 0; k < 9; k++) F.m[k] = r.F[k];
+    const mat3 stress = calculate_force(g, F, r.aux);
+    const float im4 = 1.0f / (4.0f * g.p[0]);
+#pragma unroll
+    for (int k = 0; k < 9; k++) rb[(size_t)i * BW + k] = fmaf(-stress.m[k], S, rp[i].A[k]) * im4;
+  }
+}
+
+// sum of MPMParticle::potential_energy() (src/particles.cpp:323-327 linear, :400-407 jelly, :785-796 elastic;
+// the other types do not define it in the reference: TC_NOT_IMPLEMENTED) -> out[0]; out[1] counts particles of
+// types without a potential energy
+__global__ __launch_bounds__(256) void k_potential_energy(Params P, const RecG *__restrict__ rg,
+                                                          const GroupParams *__restrict__ groups, double *out) {
+  double e = 0.0, bad = 0.0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_slots; i += gridDim.x * blockDim.x) {
+    const RecG r = rg[i];
+    if (r.pid < 0) continue;
+    const GroupParams g = groups[r.gid];
+    mat3 F;
+#pragma unroll
+    for (int k = 0; k < 9; k++) F.m[k] = r.F[k];
+    const float mu = g.p[2], la = g.p[3], vol = g.p[1];
+    if (g.type == MPMHIP_LINEAR) {
+      float n2 = 0.0f, tr = 0.0f;
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+          const float eab = 0.5f * (F(a, b) + F(b, a)) - (a == b ? 1.0f : 0.0f);
+          n2 = fmaf(eab, eab, n2);
+          if (a == b) tr += eab;
+        }
+      e += vol * (mu * n2 + 0.5f * la * tr * tr);
+    } else if (g.type == MPMHIP_JELLY || g.type == MPMHIP_ELASTIC) {
+      mat3 U; float lam[3], s[3];
+      sym_eig3_FFt(F, U, lam);
+      const float J = mat_det(F);
+      signed_sigma(lam, J, s);
+      if (g.type == MPMHIP_JELLY) {  // |F - R|_F^2 = sum (sigma - 1)^2
+        const float n2 = (s[0] - 1) * (s[0] - 1) + (s[1] - 1) * (s[1] - 1) + (s[2] - 1) * (s[2] - 1);
+        e += vol * (mu * n2 + 0.5f * la * (J - 1.0f) * (J - 1.0f));
+      } else {
+        const float l0 = logf(fabsf(s[0])), l1 = logf(fabsf(s[1])), l2 = logf(fabsf(s[2]));
+        const float sum = l0 + l1 + l2;
+        e += vol * (mu * (l0 * l0 + l1 * l1 + l2 * l2) + 0.5f * la * sum * sum);
+      }
+    } else {
+      bad += 1.0;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { e += __shfl_xor(e, off); bad += __shfl_xor(bad, off); }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[0], e);
+    if (bad != 0.0) atomicAdd(&out[1], bad);
+  }
+}
+
+
+}  // namespace mpm

@@ -1,0 +1,182 @@
+// taichi_mpm_amd/csrc/k_tiling.h — multi-GPU tiling kernels: halo pack, migration scan / pack / import
+// Part of libmpmhip (see mpmhip.hip for the substep overview and the data layout).
+#pragma once
+#include "mpm_common.h"
+
+namespace mpm {
+
+// ------------------------------------------------------------------------------------------------ tiling
+// This rank's partial (m v, m) sums on every halo box -> the box's send buffer.  One thread per box node: the
+// node's grid block c and the <= 8 active source blocks c - q whose 6^3 tiles overlap it (same sum as k_grid).
+__global__ __launch_bounds__(256) void k_halo_pack(Params P, Tiling T, const DevBox *__restrict__ boxes,
+                                                   const uint32_t *__restrict__ bits,
+                                                   const uint32_t *__restrict__ wprefix,
+                                                   const float4 *__restrict__ tiles) {
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T.box_nodes; t += gridDim.x * blockDim.x) {
+    int b = 0;
+    while (b + 1 < T.n_boxes && t >= boxes[b + 1].off) b++;
+    const DevBox &B = boxes[b];
+    const uint32_t r = t - B.off;
+    const int z = r % B.dim[2], y = (r / B.dim[2]) % B.dim[1], x = r / (B.dim[2] * B.dim[1]);
+    const int gi = B.lo[0] + x, gj = B.lo[1] + y, gk = B.lo[2] + z;
+    const int cx = gi >> 2, cy = gj >> 2, cz = gk >> 2, lx = gi & 3, ly = gj & 3, lz = gk & 3;
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int qx = q >> 2, qy = (q >> 1) & 1, qz = q & 1;
+      const int sx = cx - qx, sy = cy - qy, sz = cz - qz;
+      const int tx = lx + 4 * qx, ty = ly + 4 * qy, tz = lz + 4 * qz;
+      if (sx < 0 || sy < 0 || sz < 0 || tx >= TS || ty >= TS || tz >= TS) continue;
+      const uint32_t bk = morton3(sx, sy, sz);
+      if (bk >= P.nbw * 32u || !block_active(bits, bk)) continue;
+      const uint32_t slot = block_slot(bits, wprefix, bk);
+      if (slot >= P.max_blocks) continue;
+      const float4 v = tiles[(size_t)slot * TN + (tx * TS + ty) * TS + tz];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    B.send[r] = acc;
+  }
+}
+
+// bounding box (cells) of the active blocks of the last sort: out[0..2] = min, out[3..5] = max (exclusive)
+__global__ __launch_bounds__(256) void k_active_bounds(Params P, const Counters *__restrict__ cnt,
+                                                       const uint32_t *__restrict__ act_blk, int *__restrict__ out) {
+  const uint32_t na = min(cnt->n_active, P.max_blocks);
+  int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
+  for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < na; a += gridDim.x * blockDim.x) {
+    int b[3];
+    demorton3(act_blk[a], b[0], b[1], b[2]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { lo[k] = min(lo[k], b[k] * BS); hi[k] = max(hi[k], b[k] * BS + BS); }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[k] = min(lo[k], __shfl_xor(lo[k], off));
+      hi[k] = max(hi[k], __shfl_xor(hi[k], off));
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&out[k], lo[k]); atomicMax(&out[3 + k], hi[k]); }
+  }
+}
+
+__device__ __forceinline__ int part_index(const int *cuts, int n, int c) {
+  int p = 0;
+  while (p + 1 < n && c >= cuts[p + 1]) p++;
+  return p;
+}
+// destination rank of a live particle at x (brick containing its base cell); -1 if it is not representable
+__device__ __forceinline__ int dest_rank(const Params &P, const Tiling &T, float4 g0, bool &beyond_margin) {
+  int b[3];
+  const float X[3] = {g0.x * P.idx, g0.y * P.idx, g0.z * P.idx};
+  beyond_margin = false;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (!isfinite(X[k]) || X[k] < 0.5f) return -1;
+    b[k] = (int)(X[k] - 0.5f);
+    if (b[k] < T.lo[k] - T.margin || b[k] >= T.hi[k] + T.margin) beyond_margin = true;
+  }
+  return (part_index(T.cuts[0], T.dims[0], b[0]) * T.dims[1] + part_index(T.cuts[1], T.dims[1], b[1])) * T.dims[2] +
+         part_index(T.cuts[2], T.dims[2], b[2]);
+}
+
+__global__ void k_scan_init(uint32_t *__restrict__ counts, int world) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < world) counts[t] = 0;
+  else if (t < world + 3) counts[t] = (uint32_t)(1 << 30);
+  else if (t < world + 6) counts[t] = (uint32_t)-1;
+}
+// counts[d] = live particles whose base cell belongs to rank d != this rank; bounds[0..2] / [3..5] = min / max+1 of
+// the base cells of all live particles (one pass, one wave-reduced atomic set per wave)
+__global__ __launch_bounds__(256) void k_leaver_count(Params P, Tiling T, const float4 *__restrict__ rg,
+                                                      uint32_t *__restrict__ counts, int *__restrict__ bounds,
+                                                      Counters *cnt) {
+  int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_slots; i += gridDim.x * blockDim.x) {
+    if (__float_as_int(rg[(size_t)i * 4 + 3].z) < 0) continue;
+    const float4 g0 = rg[(size_t)i * 4];
+    bool beyond;
+    const int d = dest_rank(P, T, g0, beyond);
+    if (d < 0) continue;
+    if (beyond) atomicOr(&cnt->error, 2u);
+    if (d != T.rank) atomicAdd(&counts[d], 1u);
+    const int b[3] = {(int)(g0.x * P.idx - 0.5f), (int)(g0.y * P.idx - 0.5f), (int)(g0.z * P.idx - 0.5f)};
+#pragma unroll
+    for (int k = 0; k < 3; k++) { lo[k] = min(lo[k], b[k]); hi[k] = max(hi[k], b[k] + 1); }
+  }
+  // wave reduce -> workgroup reduce -> 6 atomics per WORKGROUP (same-address atomics serialise at ~13 ns each)
+  __shared__ int red[4][6];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[k] = min(lo[k], __shfl_xor(lo[k], off));
+      hi[k] = max(hi[k], __shfl_xor(hi[k], off));
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][k] = lo[k]; red[threadIdx.x >> 6][3 + k] = hi[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    const int l = min(min(red[0][k], red[1][k]), min(red[2][k], red[3][k]));
+    const int h = max(max(red[0][3 + k], red[1][3 + k]), max(red[2][3 + k], red[3][3 + k]));
+    if (h >= 0) { atomicMin(&bounds[k], l); atomicMax(&bounds[3 + k], h); }
+  }
+}
+
+// cursor[d] starts at the first record index of destination d; leavers are removed from this rank
+__global__ __launch_bounds__(256) void k_leaver_pack(Params P, Tiling T, float4 *__restrict__ rg,
+                                                     const float4 *__restrict__ rp, const float4 *__restrict__ rb,
+                                                     uint32_t *__restrict__ key, uint32_t *__restrict__ cursor,
+                                                     float4 *__restrict__ out, Counters *cnt) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_slots; i += gridDim.x * blockDim.x) {
+    const float4 g3 = rg[(size_t)i * 4 + 3];
+    if (__float_as_int(g3.z) < 0) continue;
+    bool beyond;
+    const int d = dest_rank(P, T, rg[(size_t)i * 4], beyond);
+    if (d < 0 || d == T.rank) continue;
+    const size_t o = (size_t)atomicAdd(&cursor[d], 1u) * 11;
+#pragma unroll
+    for (int q = 0; q < 4; q++) out[o + q] = rg[(size_t)i * 4 + q];
+#pragma unroll
+    for (int q = 0; q < 4; q++) out[o + 4 + q] = rp[(size_t)i * 4 + q];
+#pragma unroll
+    for (int q = 0; q < 3; q++) out[o + 8 + q] = rb[(size_t)i * 3 + q];
+    rg[(size_t)i * 4 + 3] = make_float4(g3.x, g3.y, __int_as_float(-1), 0.0f);
+    key[i] = INVALID;
+    atomicAdd(&cnt->n_dead, 1u);
+  }
+}
+
+// arrivals appended at slots base .. base+n; their keys and block flags join the ones k_g2p produced
+__global__ __launch_bounds__(256) void k_import(Params P, uint32_t n, uint32_t base, const float4 *__restrict__ in,
+                                                float4 *__restrict__ rg, float4 *__restrict__ rp,
+                                                float4 *__restrict__ rb, uint32_t *__restrict__ key,
+                                                uint8_t *__restrict__ blk_flag, Counters *cnt) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t nloop = (n + stride - 1) / stride;
+  for (uint32_t it = 0; it < nloop; it++) {  // uniform trip count (flag_block shuffles)
+    const uint32_t j = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t bkey = INVALID;
+    if (j < n) {
+      const size_t i = (size_t)base + j, o = (size_t)j * 11;
+      const float4 g0 = in[o], g3 = in[o + 3], p0 = in[o + 4], p1 = in[o + 5];
+      const float x[3] = {g0.x, g0.y, g0.z}, v[3] = {p0.w, p1.x, p1.y};
+      const uint32_t kk = particle_key(P, x, v, bkey);
+      int32_t pid = __float_as_int(g3.z);
+      if (kk == INVALID) {
+        pid = -1;
+        atomicAdd(&cnt->n_dead, 1u);
+      }
+      key[i] = kk;
+      rg[i * 4 + 0] = g0; rg[i * 4 + 1] = in[o + 1]; rg[i * 4 + 2] = in[o + 2];
+      rg[i * 4 + 3] = make_float4(g3.x, g3.y, __int_as_float(pid), 0.0f);
+      rp[i * 4 + 0] = p0; rp[i * 4 + 1] = p1; rp[i * 4 + 2] = in[o + 6]; rp[i * 4 + 3] = in[o + 7];
+      rb[i * 3 + 0] = in[o + 8]; rb[i * 3 + 1] = in[o + 9]; rb[i * 3 + 2] = in[o + 10];
+    }
+    flag_block(blk_flag, bkey);
+  }
+}
+
+
+}  // namespace mpm

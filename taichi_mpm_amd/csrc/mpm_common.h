@@ -1,0 +1,150 @@
+// taichi_mpm_amd/csrc/mpm_common.h — constants, particle records, kernel parameter blocks, Morton keys, block bitmap helpers
+// Part of libmpmhip (see mpmhip.hip for the substep overview and the data layout).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "mpm_math.h"
+
+namespace mpm {
+
+
+constexpr int BS = 4;    // cells per block edge
+constexpr int BC = 64;   // cells per block
+constexpr int TS = 6;    // tile edge in nodes (BS + 2: quadratic stencil reaches base+2)
+constexpr int TN = 216;  // nodes per tile
+constexpr uint32_t INVALID = 0xFFFFFFFFu;
+
+// 64-byte particle records (4 x float4)
+struct alignas(16) RecG {  // G2P side
+  float x[3];
+  float aux;
+  float F[9];
+  uint32_t gid;
+  int32_t pid;  // creation id; < 0 marks a deleted slot
+  uint32_t pad;
+};
+struct alignas(16) RecP {  // P2G side
+  float x[3];
+  float v[3];
+  float A[9];
+  float mass;  // group mass (get_mass()), so P2G needs no group-table lookup
+};
+static_assert(sizeof(RecG) == 64 && sizeof(RecP) == 64, "records must be 64 bytes");
+constexpr int BW = 12;  // floats per apic_b record (9 used): three float4
+
+struct Counters {
+  uint32_t n_sorted;  // live particles in the current sorted index
+  uint32_t n_active;  // active blocks
+  uint32_t n_dead;    // slots marked deleted so far
+  uint32_t error;     // bit0: active blocks exceeded max_blocks
+};
+
+struct Params {
+  int res[3];
+  float dx, idx, dt;
+  float g[3];
+  int particle_gravity;
+  float apic_damping, rpic_damping;
+  int clean_boundary;
+  int kbits;         // Morton bits per axis
+  uint32_t nbw;      // bitmap words = 8^kbits / 32
+  uint32_t max_blocks;
+  uint32_t n_slots;  // particle slots in use (host-known)
+  int store_b;       // keep apic_b in the side array
+  int ablate;        // PROFILING ONLY (env MPMHIP_ABLATE, results invalid): 1 no G2P stores, 2 no constitutive
+                     // update, 4 no 27-tap gather
+};
+
+// multi-GPU tiling (include/mpmhip.h, "Multi-GPU tiling"): partition of the cell space into bricks + halo boxes
+struct Tiling {
+  int enabled, rank;
+  int dims[3];
+  int cuts[3][MPMHIP_MAX_PARTS + 1];
+  int lo[3], hi[3];          // this rank's brick, cells
+  int margin;
+  int n_boxes;
+  uint32_t box_nodes;        // total nodes over all halo boxes
+  int int_lo[3], int_hi[3];  // node box that no halo box intersects (fast path of k_grid)
+};
+struct DevBox {
+  int lo[3], dim[3];
+  int peer;
+  uint32_t off;  // first node of this box in the concatenated (all boxes) node numbering
+  float4 *send;
+  const float4 *recv;
+};
+
+// ------------------------------------------------------------------------------------------------ Morton
+__host__ __device__ __forceinline__ uint32_t spread3(uint32_t v) {
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+__host__ __device__ __forceinline__ uint32_t compact3(uint32_t v) {
+  v &= 0x09249249u;
+  v = (v | (v >> 2)) & 0x030c30c3u;
+  v = (v | (v >> 4)) & 0x0300f00fu;
+  v = (v | (v >> 8)) & 0x030000ffu;
+  v = (v | (v >> 16)) & 0x3ffu;
+  return v;
+}
+__host__ __device__ __forceinline__ uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {
+  return (spread3(x) << 2) | (spread3(y) << 1) | spread3(z);
+}
+__host__ __device__ __forceinline__ void demorton3(uint32_t m, int &x, int &y, int &z) {
+  x = (int)compact3(m >> 2); y = (int)compact3(m >> 1); z = (int)compact3(m);
+}
+
+__device__ __forceinline__ bool block_active(const uint32_t *__restrict__ bits, uint32_t bkey) {
+  return (bits[bkey >> 5] >> (bkey & 31)) & 1u;
+}
+__device__ __forceinline__ uint32_t block_slot(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ wprefix,
+                                               uint32_t bkey) {
+  const uint32_t w = bits[bkey >> 5];
+  return wprefix[bkey >> 5] + __popc(w & ((1u << (bkey & 31)) - 1u));
+}
+
+// key of a particle at position x with velocity v: Morton(block of its base cell) << 6 | cell in block;
+// INVALID if it must be deleted: non-finite x/v or near the domain wall when clean_boundary
+// (src/mpm.h:269-276, src/mpm.cpp:592-598), or a stencil that would leave the grid (reference: UB).
+__device__ __forceinline__ uint32_t particle_key(const Params &P, const float x[3], const float v[3], uint32_t &bkey) {
+  bool alive = true;
+  float X[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    alive = alive && isfinite(x[k]) && isfinite(v[k]);
+    X[k] = x[k] * P.idx;
+  }
+  if (P.clean_boundary) {
+    const float mn = fminf(X[0], fminf(X[1], X[2]));
+    const float mx = fmaxf(X[0] - P.res[0], fmaxf(X[1] - P.res[1], X[2] - P.res[2]));
+    alive = alive && !(mn < 7.0f || mx > -7.0f);
+  }
+  int b[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    alive = alive && (X[k] >= 0.5f);
+    b[k] = alive ? (int)(X[k] - 0.5f) : 0;  // MPMKernel<dim,2>::get_stencil_start, src/kernel.h:119-121
+    alive = alive && (b[k] + 2 <= P.res[k]);
+  }
+  bkey = INVALID;
+  if (!alive) return INVALID;
+  bkey = morton3(b[0] >> 2, b[1] >> 2, b[2] >> 2);
+  return (bkey << 6) | ((b[0] & 3) << 4) | ((b[1] & 3) << 2) | (b[2] & 3);
+}
+
+// mark the block active: a plain byte store (all writers store the same value: no atomics, no serialisation),
+// one per run of equal blocks among consecutive lanes; k_pack_flags turns the bytes into the bitmap.
+// Must be called by all lanes of the wave.
+__device__ __forceinline__ void flag_block(uint8_t *__restrict__ blk_flag, uint32_t bkey) {
+  const uint32_t prev = __shfl_up(bkey, 1);
+  if (bkey != INVALID && ((threadIdx.x & 63) == 0 || prev != bkey)) blk_flag[bkey] = 1;
+}
+
+
+}  // namespace mpm
