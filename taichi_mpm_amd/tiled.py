@@ -249,6 +249,22 @@ class DistComm:
         return o.cpu().numpy().reshape(self.world, -1)
 
 
+class StagedDistComm(DistComm):
+    """device buffers moved by a CPU-only backend (gloo): device -> host, collective, host -> device.  Lets several
+    ranks share ONE GPU (RCCL refuses that), which is how the multi-process path is tested on a single-GPU box."""
+
+    def __init__(self, dist):
+        import torch
+        super().__init__(dist, torch.device("cpu"))
+
+    def all_to_all(self, out, inp, out_splits, in_splits):
+        out_splits, in_splits = list(map(int, out_splits)), list(map(int, in_splits))
+        h_in = inp[:sum(in_splits)].cpu()  # synchronises the stream the ctx runs on
+        h_out = self.torch.empty(sum(out_splits), dtype=inp.dtype)
+        self.dist.all_to_all_single(h_out, h_in, out_splits, in_splits)
+        out[:sum(out_splits)].copy_(h_out)
+
+
 # ---------------------------------------------------------------------------------------------------- one rank
 class TiledRank:
     """one rank's substep / migration, split into phases so that a distributed job (one rank per process) and a

@@ -160,3 +160,64 @@ def test_migration_compacts_when_slots_run_out(tm):
     assert np.allclose(got["v"][:, 0], 25.0, rtol=1e-3)
     for sim in sims:
         sim.close()
+
+
+# ------------------------------------------------------------------------------------------ two processes, one GPU
+def _proc_worker(rank, world, port, steps, q):
+    import os
+
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import taichi_mpm_amd as tm
+        from taichi_mpm_amd import tiled
+        tm.load()
+        s = _two_material_state()
+        ids = np.arange(s.n)
+        part = tiled.Partition.balanced((RES,) * 3, world, s.x, DX, margin=2)
+        owner = part.rank_of_cells(tiled.base_cells(s.x, DX))
+        sim = _sim(tm, s, owner == rank, ids, s.n + 1024)
+        job = tiled.TiledJob(tiled.HipEngine(sim, 0), part, tiled.StagedDistComm(dist), migrate_interval=2)
+        job.run(steps)
+        job.synchronize()
+        p = sim.get_particles(sort_by_id=False)
+        q.put((rank, job.r.migrated_out, {k: p[k] for k in ("x", "v", "F", "id", "gid")}))
+        sim.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_on_one_gpu_match_one_ctx(tm):
+    """the distributed TiledJob (one process per rank, torch.distributed) with the HIP engine: two ranks share this
+    GPU, device buffers staged through gloo — everything but the wire is what `bench.py --gpus 2` runs"""
+    import socket
+
+    import torch.multiprocessing as mp
+    s = _two_material_state()
+    steps = 12
+    one = _sim(tm, s, np.ones(s.n, bool), np.arange(s.n), s.n + 1024)
+    one.run_substeps(steps)
+    ref = one.get_particles()
+    one.close()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_proc_worker, args=(r, 2, port, steps, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] + res[1][1] > 0  # migration happened
+    got = {k: np.concatenate([r[2][k] for r in res]) for k in res[0][2]}
+    order = np.argsort(got["id"], kind="stable")
+    got = {k: v[order] for k, v in got.items()}
+    assert np.array_equal(got["id"], ref["id"]) and np.array_equal(got["gid"], ref["gid"])
+    assert np.abs(got["x"] - ref["x"]).max() <= 1e-6
+    assert rel_l2(got["v"], ref["v"]) <= 1e-4 and rel_l2(got["F"], ref["F"]) <= 1e-4
