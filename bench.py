@@ -124,10 +124,10 @@ def virtual_run(tm, cfg, args):
         sim.add_particles(dict(type=cfg["material"], positions=x[mine]))
         sim.upload(F_ID, mine.astype(np.int32))
         engines.append(tiled.HipEngine(sim, 0))
-    job = tiled.VirtualTiledJob(engines, part)
+    job = tiled.VirtualTiledJob(engines, part, overlap=os.environ.get("MPMHIP_TILE_OVERLAP", "1") != "0")
     job.run(args.warmup)
-    for e in engines:
-        e.sim.set_profiling(1)
+    for e in engines:  # level 1 = full phase table (substeps then run unsplit); 2 = only G2P bracketed
+        e.sim.set_profiling(int(os.environ.get("MPMHIP_VIRTUAL_PROFILE", "1")))
         e.sim.profile(reset=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

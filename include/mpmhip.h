@@ -223,6 +223,12 @@ int mpmhip_halo_pack(mpmhip_ctx *ctx);
 /* tiled substep = substep_begin (sort, P2G, halo_pack) ; caller exchanges ; substep_end (grid, G2P) */
 int mpmhip_substep_begin(mpmhip_ctx *ctx);
 int mpmhip_substep_end(mpmhip_ctx *ctx);
+/* exchange/compute overlap: with set_overlap(1), substep_begin only rasterizes the blocks that touch a halo box (then
+ * packs); the caller starts the exchange asynchronously and calls substep_interior (P2G, grid and G2P of everything
+ * that cannot touch a halo node) while it is on the wire, waits for it, and calls substep_end (the boundary part).
+ * substep_interior is a no-op when the overlap is off; substep_end runs it if the caller skipped it. */
+int mpmhip_set_overlap(mpmhip_ctx *ctx, int32_t enabled);
+int mpmhip_substep_interior(mpmhip_ctx *ctx);
 /* counts[world]: live particles whose base cell now lies in another rank's brick.  Also raises MPMHIP_ECAPACITY
  * (sticky) if a particle is more than `margin` cells outside this rank's brick. */
 int mpmhip_leaver_counts(mpmhip_ctx *ctx, int32_t world, int64_t *counts);

@@ -79,7 +79,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_las
             "mpmhip_synchronize", "mpmhip_sort", "mpmhip_p2g", "mpmhip_grid_update", "mpmhip_g2p",
             "mpmhip_download_grid", "mpmhip_upload_grid", "mpmhip_calculate_energy", "mpmhip_snapshot_size", "mpmhip_snapshot_save", "mpmhip_snapshot_load", "mpmhip_set_profiling", "mpmhip_profile",
             "mpmhip_profile_reset", "mpmhip_set_partition", "mpmhip_set_halo", "mpmhip_halo_pack",
-            "mpmhip_substep_begin", "mpmhip_substep_end", "mpmhip_leaver_counts", "mpmhip_migration_scan", "mpmhip_export_leavers",
+            "mpmhip_substep_begin", "mpmhip_substep_end", "mpmhip_substep_interior", "mpmhip_set_overlap", "mpmhip_leaver_counts", "mpmhip_migration_scan", "mpmhip_export_leavers",
             "mpmhip_import_particles", "mpmhip_active_bounds", "mpmhip_num_slots", "mpmhip_request_compaction", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
 
 
@@ -129,11 +129,12 @@ def load():
     L.mpmhip_export_leavers.argtypes = [vp, C.c_int32, P(C.c_int64), vp]
     L.mpmhip_import_particles.argtypes = [vp, C.c_int64, vp]
     L.mpmhip_active_bounds.argtypes = [vp, ip, ip]
+    L.mpmhip_set_overlap.argtypes = [vp, C.c_int32]
     L.mpmhip_num_slots.argtypes = [vp]
     L.mpmhip_num_slots.restype = C.c_int64
     for name in ("mpmhip_substep", "mpmhip_synchronize", "mpmhip_sort", "mpmhip_p2g", "mpmhip_grid_update",
                  "mpmhip_g2p", "mpmhip_profile_reset", "mpmhip_halo_pack", "mpmhip_substep_begin",
-                 "mpmhip_substep_end", "mpmhip_request_compaction"):
+                 "mpmhip_substep_end", "mpmhip_substep_interior", "mpmhip_request_compaction"):
         getattr(L, name).argtypes = [vp]
     L.mpmhip_run_substeps.argtypes = [vp, C.c_int32]
     L.mpmhip_step.argtypes = [vp, C.c_float]

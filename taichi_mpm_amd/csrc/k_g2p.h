@@ -19,7 +19,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
                                                   const float4 *__restrict__ gridv,
                                                   const uint32_t *__restrict__ fat_slot, Counters *cnt_w,
                                                   uint32_t *__restrict__ key, uint8_t *__restrict__ blk_flag,
-                                                  LevelSetDev LS) {
+                                                  LevelSetDev LS, Tiling T, int phase) {
   __shared__ float4 tile[TN];
   // Store staging, one slab per wavefront.  A lane holds its particle's whole record, so a direct store would
   // issue 16-byte pieces at a 64-byte stride: 64 partial-line write requests per instruction (measured: the
@@ -43,8 +43,14 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
     c.a = a; c.p = 0; c.p1 = 0;
     while (c.a < na) {
       c.p = act_start[c.a]; c.p1 = act_start[c.a + 1];
-      if (c.p < c.p1) break;
-      c.a += gridDim.x;  // empty block (all its particles migrated away)
+      bool mine = c.p < c.p1;  // (empty block: all its particles migrated away)
+      if (mine && phase != 0) {
+        int bx, by, bz;
+        demorton3(act_blk[c.a], bx, by, bz);
+        mine = in_phase(T, phase, bx * BS, by * BS, bz * BS, 2 * BS);
+      }
+      if (mine) break;
+      c.a += gridDim.x;
     }
     return c;
   };

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
                                               const uint32_t *__restrict__ wprefix,
                                               const float4 *__restrict__ tiles, float4 *__restrict__ gridv,
                                               uint32_t *__restrict__ fat_slot, float4 *__restrict__ dense, Tiling T,
-                                              const DevBox *__restrict__ boxes, LevelSetDev LS) {
+                                              const DevBox *__restrict__ boxes, LevelSetDev LS, int phase) {
   const uint32_t na = min(cnt->n_active, P.max_blocks);
   const int l = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
       for (int q = 0; q < o; q++) lower |= 1u << nb27(ox - (q >> 2), oy - ((q >> 1) & 1), oz - (q & 1));
       if (amask & lower) continue;  // wave-uniform
       const int cx = bx + ox, cy = by + oy, cz = bz + oz;
+      if (!in_phase(T, phase, cx * BS, cy * BS, cz * BS, BS)) continue;  // wave-uniform
       const uint32_t slot = a * 8u + (uint32_t)o;
       const int gi = cx * BS + lx, gj = cy * BS + ly, gk = cz * BS + lz;
       const bool in_grid = gi <= P.res[0] && gj <= P.res[1] && gk <= P.res[2];

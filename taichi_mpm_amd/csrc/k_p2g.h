@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const floa
                                                             const uint32_t *__restrict__ cell_start,
                                                             const uint32_t *__restrict__ perm,
                                                             const GroupParams *__restrict__ groups,
-                                                            float4 *__restrict__ tiles) {
+                                                            float4 *__restrict__ tiles, Tiling T, int phase) {
   constexpr int NW = NS * PS, NT = 64 * NW;
   __shared__ float4 tile[NW][TN];  // per wave: (m*vx, m*vy, m*vz, m) per node of the block's 6^3 tile
   const uint32_t na = min(cnt->n_active, P.max_blocks);
@@ -110,10 +110,11 @@ __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const floa
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
   const int nbase = (cx * TS + cy) * TS + cz;
   for (uint32_t a = blockIdx.x; a < na; a += gridDim.x) {
-    for (int t = threadIdx.x; t < NW * TN; t += NT) (&tile[0][0])[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    __syncthreads();
     int bx, by, bz;
     demorton3(act_blk[a], bx, by, bz);
+    if (!in_phase(T, phase, bx * BS, by * BS, bz * BS, TS)) continue;  // workgroup-uniform
+    for (int t = threadIdx.x; t < NW * TN; t += NT) (&tile[0][0])[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    __syncthreads();
     const float ox = (float)(bx * BS + cx), oy = (float)(by * BS + cy), oz = (float)(bz * BS + cz);
     const uint32_t c0 = cell_start[a * BC + lane], c1 = cell_start[a * BC + lane + 1];
     const uint32_t n = c1 - c0;

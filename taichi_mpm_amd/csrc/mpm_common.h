@@ -68,6 +68,20 @@ struct Tiling {
   uint32_t box_nodes;        // total nodes over all halo boxes
   int int_lo[3], int_hi[3];  // node box that no halo box intersects (fast path of k_grid)
 };
+// Exchange/compute overlap of a tiled substep: work is split by whether it can touch a halo node.
+//   phase 0: everything (untiled ctx, or overlap off)     phase 1: only work that touches a halo box ("boundary")
+//   phase 2: only work that cannot ("interior": its node box [lo, lo+extent)^3 lies inside the overlap-free box)
+// Boundary P2G + halo pack run first, the exchange then overlaps interior P2G / grid / G2P, boundary grid / G2P run
+// when the peers' sums have arrived.  Extents: P2G tile 6 nodes, grid candidate 4, G2P 8 (all 8 grid blocks its
+// tile reads must be interior).
+__device__ __forceinline__ bool in_phase(const Tiling &T, int phase, int lo0, int lo1, int lo2, int extent) {
+  if (phase == 0) return true;
+  const bool interior = T.n_boxes == 0 ||
+                        (lo0 >= T.int_lo[0] && lo0 + extent <= T.int_hi[0] && lo1 >= T.int_lo[1] &&
+                         lo1 + extent <= T.int_hi[1] && lo2 >= T.int_lo[2] && lo2 + extent <= T.int_hi[2]);
+  return (phase == 2) == interior;
+}
+
 struct DevBox {
   int lo[3], dim[3];
   int peer;

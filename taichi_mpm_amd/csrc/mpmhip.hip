@@ -109,7 +109,7 @@ struct mpmhip_ctx {
   int64_t substeps = 0;
   // profiling
   int profiling = 0;  // 0 off, 1 every phase, 2 only G2P, 3 only P2G (two events per substep instead of six)
-  struct Ev { hipEvent_t e[PH_COUNT + 1]; };
+  struct Ev { hipEvent_t e[PH_COUNT + 1]; bool ov; };  // ov: the substep ran split (boundary / interior)
   std::vector<Ev> ev_pool;
   size_t ev_used = 0;
   double phase_ms[PH_COUNT] = {0, 0, 0, 0, 0};
@@ -127,6 +127,8 @@ struct mpmhip_ctx {
   int counts_cap = 0;
   bool compact_requested = false;
   bool in_substep = false;
+  bool overlap = false;        // mpmhip_set_overlap: split tiled substeps into boundary / interior work
+  bool ov_active = false, interior_done = false;  // state of the substep in flight
 };
 
 static int fail(mpmhip_ctx *c, int code, const char *fmt, ...) {
@@ -563,7 +565,7 @@ static int do_reorder(mpmhip_ctx *c) {
   return MPMHIP_OK;
 }
 
-static int do_p2g(mpmhip_ctx *c) {
+static int do_p2g(mpmhip_ctx *c, int phase = 0) {
   if (!c->affine_valid) {
     hipLaunchKernelGGL(k_affine, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, c->rg, c->rp, c->rb,
                        c->d_groups);
@@ -579,19 +581,19 @@ static int do_p2g(mpmhip_ctx *c) {
     default: break;
   }
   hipLaunchKernelGGL(kern, dim3(c->p2g_wgs), dim3(nt), 0, c->stream, c->P,
-                     (const float4 *)c->rp, c->cnt, c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles);
+                     (const float4 *)c->rp, c->cnt, c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles, c->T, phase);
   return launch_check(c, "p2g");
 }
-static int do_grid(mpmhip_ctx *c, int mode) {
+static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
   const bool per_cand = mode == 0 && c->n_slots < (2 << 20);  // small per-GPU problem: latency-bound, see k_grid
   auto kern = mode == 0 ? (per_cand ? k_grid<0, true> : k_grid<0, false>)
                         : (mode == 1 ? k_grid<1, false>
                                      : (mode == 2 ? k_grid<2, false> : (mode == 3 ? k_grid<3, false> : k_grid<4, false>)));
   hipLaunchKernelGGL(kern, dim3(per_cand ? 16384 : 4096), dim3(256), 0, c->stream, c->P, c->cnt, c->act_blk, c->bits, c->wprefix, c->tiles,
-                     c->gridv, c->fat_slot, c->dense, c->T, (const DevBox *)c->d_boxes, c->LS);
+                     c->gridv, c->fat_slot, c->dense, c->T, (const DevBox *)c->d_boxes, c->LS, phase);
   return launch_check(c, "grid");
 }
-static int do_g2p(mpmhip_ctx *c) {
+static int do_g2p(mpmhip_ctx *c, int phase = 0) {
   auto kern = k_g2p<256, 2, false>;
   switch (c->g2p_minw) {  // tuning knob: waves/SIMD target x (rolled gather loop ? 10 : 0)
     case 12: kern = k_g2p<256, 2, true>; break;
@@ -602,7 +604,7 @@ static int do_g2p(mpmhip_ctx *c) {
   }
   hipLaunchKernelGGL(kern, dim3(4096), dim3(256), 0, c->stream, c->P, (float4 *)c->rg, (float4 *)c->rp, (float4 *)c->rb,
                      c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
-                     c->blk_flag, c->LS);
+                     c->blk_flag, c->LS, c->T, phase);
   c->sorted = false;       // positions moved
   c->keys_valid = true;    // ... and their keys / block flags are ready for the next sort
   c->affine_valid = true;  // A was produced together with F
@@ -653,6 +655,12 @@ static int collect_events(mpmhip_ctx *c) {
   if (c->ev_used == 0) return MPMHIP_OK;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (size_t i = 0; i < c->ev_used; i++) {
+    if (c->ev_pool[i].ov && c->ev_level >= 2) {  // split substep: the interior launch was bracketed separately
+      float ms = 0;
+      const int a = c->ev_level == 2 ? 0 : 3;
+      HIPCHK(c, hipEventElapsedTime(&ms, c->ev_pool[i].e[a], c->ev_pool[i].e[a + 1]));
+      c->phase_ms[c->ev_level == 2 ? PH_G2P : PH_P2G] += ms;
+    }
     for (int k = 0; k < PH_COUNT; k++) {
       if ((c->ev_level == 2 && k != PH_G2P) || (c->ev_level == 3 && k != PH_P2G)) continue;
       float ms = 0;
@@ -674,21 +682,28 @@ static int do_halo_pack(mpmhip_ctx *c) {
   return launch_check(c, "halo_pack");
 }
 
-int mpmhip_substep_begin(mpmhip_ctx *c) {  // sort, P2G, halo pack
+// A tiled substep is begin [exchange] end, or — with mpmhip_set_overlap — begin [exchange starts] interior
+// [exchange done] end: begin runs the sort, the P2G of the blocks that touch a halo box and the halo pack; interior
+// runs everything that cannot touch a halo node (P2G, grid, G2P) while the boxes are on the wire; end finishes the
+// boundary part with the peers' sums.  With level-1 profiling the split is off so the phase table stays clean.
+int mpmhip_substep_begin(mpmhip_ctx *c) {
   if (!c) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
-  if (c->cur_ev) return fail(c, MPMHIP_EINVAL, "substep_begin called twice without substep_end");
+  if (c->in_substep) return fail(c, MPMHIP_EINVAL, "substep_begin called twice without substep_end");
   int rc;
   mpmhip_ctx::Ev *ev = nullptr;
   const int lvl = c->profiling;
+  c->ov_active = c->overlap && c->T.n_boxes > 0 && lvl != 1;
+  c->interior_done = false;
   if (lvl) {
     if (c->ev_used >= 4096 && (rc = collect_events(c))) return rc;
     if ((rc = get_events(c, &ev))) return rc;
+    ev->ov = c->ov_active;
     if (lvl == 1) HIPCHK(c, hipEventRecord(ev->e[0], c->stream));
   }
   if ((rc = do_sort(c))) return rc;
   if (ev && (lvl == 1 || lvl == 3)) HIPCHK(c, hipEventRecord(ev->e[1], c->stream));
-  if ((rc = do_p2g(c))) return rc;
+  if ((rc = do_p2g(c, c->ov_active ? 1 : 0))) return rc;
   if (ev && lvl == 3) HIPCHK(c, hipEventRecord(ev->e[2], c->stream));
   if ((rc = do_halo_pack(c))) return rc;
   if (ev && lvl == 1) HIPCHK(c, hipEventRecord(ev->e[2], c->stream));
@@ -697,22 +712,49 @@ int mpmhip_substep_begin(mpmhip_ctx *c) {  // sort, P2G, halo pack
   return MPMHIP_OK;
 }
 
+int mpmhip_substep_interior(mpmhip_ctx *c) {
+  if (!c) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->in_substep) return fail(c, MPMHIP_EINVAL, "substep_interior without substep_begin");
+  if (!c->ov_active || c->interior_done) return MPMHIP_OK;
+  int rc;
+  mpmhip_ctx::Ev *ev = c->cur_ev;
+  const int lvl = c->profiling;
+  if (ev && lvl == 3) HIPCHK(c, hipEventRecord(ev->e[3], c->stream));
+  if ((rc = do_p2g(c, 2))) return rc;
+  if (ev && lvl == 3) HIPCHK(c, hipEventRecord(ev->e[4], c->stream));
+  if ((rc = do_grid(c, 0, 2))) return rc;
+  if (ev && lvl == 2) HIPCHK(c, hipEventRecord(ev->e[0], c->stream));
+  if ((rc = do_g2p(c, 2))) return rc;
+  if (ev && lvl == 2) HIPCHK(c, hipEventRecord(ev->e[1], c->stream));
+  c->interior_done = true;
+  return MPMHIP_OK;
+}
+
 int mpmhip_substep_end(mpmhip_ctx *c) {  // grid (+ halo sum), G2P
   if (!c) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   if (!c->in_substep) return fail(c, MPMHIP_EINVAL, "substep_end without substep_begin");
   int rc;
+  if (c->ov_active && !c->interior_done && (rc = mpmhip_substep_interior(c))) return rc;  // caller skipped it
   mpmhip_ctx::Ev *ev = c->cur_ev;
   c->cur_ev = nullptr;
   c->in_substep = false;
-  const int lvl = c->profiling;
+  const int lvl = c->profiling, ph = c->ov_active ? 1 : 0;
   if (ev && lvl == 1) HIPCHK(c, hipEventRecord(ev->e[3], c->stream));
-  if ((rc = do_grid(c, 0))) return rc;
+  if ((rc = do_grid(c, 0, ph))) return rc;
   if (ev && (lvl == 1 || lvl == 2)) HIPCHK(c, hipEventRecord(ev->e[4], c->stream));
-  if ((rc = do_g2p(c))) return rc;
+  if ((rc = do_g2p(c, ph))) return rc;
   if (ev && (lvl == 1 || lvl == 2)) HIPCHK(c, hipEventRecord(ev->e[5], c->stream));
   c->t += c->P.dt;  // src/mpm.cpp:573
   c->substeps++;
+  return MPMHIP_OK;
+}
+
+int mpmhip_set_overlap(mpmhip_ctx *c, int32_t enabled) {
+  if (!c) return MPMHIP_EINVAL;
+  if (c->in_substep) return fail(c, MPMHIP_EINVAL, "set_overlap inside a substep");
+  c->overlap = enabled != 0;
   return MPMHIP_OK;
 }
 

@@ -198,8 +198,15 @@ class HipEngine:
     def begin(self):
         self.sim._check(self.L.mpmhip_substep_begin(self.ctx))
 
+    def interior(self):
+        self.sim._check(self.L.mpmhip_substep_interior(self.ctx))
+
     def end(self):
         self.sim._check(self.L.mpmhip_substep_end(self.ctx))
+
+    def set_overlap(self, on):
+        """split substeps into boundary / interior work so that the halo exchange overlaps the interior part"""
+        self.sim._check(self.L.mpmhip_set_overlap(self.ctx, int(bool(on))))
 
     def migration_scan(self):
         """(leavers per destination rank, base-cell bounds lo, hi) — one pass, one synchronisation"""
@@ -241,6 +248,22 @@ class DistComm:
         out_splits, in_splits = list(map(int, out_splits)), list(map(int, in_splits))
         self.dist.all_to_all_single(out[:sum(out_splits)], inp[:sum(in_splits)], out_splits, in_splits)
 
+    def all_to_all_async(self, out, inp, out_splits, in_splits):
+        """start the exchange behind everything enqueued so far and return a handle; handle.wait() makes the
+        CURRENT stream wait for it (no host block with nccl), so kernels launched in between overlap the wire"""
+        out_splits, in_splits = list(map(int, out_splits)), list(map(int, in_splits))
+        if self.device.type != "cuda":
+            return self.dist.all_to_all_single(out[:sum(out_splits)], inp[:sum(in_splits)], out_splits, in_splits,
+                                               async_op=True)
+        tc = self.torch.cuda
+        if getattr(self, "_side", None) is None:
+            self._side, self._ev = tc.Stream(self.device), tc.Event()
+        self._ev.record(tc.current_stream(self.device))
+        with tc.stream(self._side):
+            self._side.wait_event(self._ev)
+            return self.dist.all_to_all_single(out[:sum(out_splits)], inp[:sum(in_splits)], out_splits, in_splits,
+                                               async_op=True)
+
     def all_gather_ints(self, row):
         """every rank's int64 row -> (world, len(row)) on every rank: ONE small collective per migration"""
         t = self.torch.as_tensor(np.asarray(row, np.int64)).to(self.device)
@@ -263,6 +286,14 @@ class StagedDistComm(DistComm):
         h_out = self.torch.empty(sum(out_splits), dtype=inp.dtype)
         self.dist.all_to_all_single(h_out, h_in, out_splits, in_splits)
         out[:sum(out_splits)].copy_(h_out)
+
+    def all_to_all_async(self, out, inp, out_splits, in_splits):
+        self.all_to_all(out, inp, out_splits, in_splits)  # staged transport: nothing to overlap with
+
+        class _Done:
+            def wait(self):
+                return True
+        return _Done()
 
 
 # ---------------------------------------------------------------------------------------------------- one rank
@@ -332,15 +363,31 @@ class TiledJob:
     """bench.py job: this process's rank of the tiled run (torch.distributed)"""
     scaling = "strong"
 
-    def __init__(self, engine, part, comm, migrate_interval=None):
+    def __init__(self, engine, part, comm, migrate_interval=None, overlap=True):
         self.r = TiledRank(engine, part, comm.rank, migrate_interval)
         self.comm, self.e = comm, engine
+        self.overlap = bool(overlap) and hasattr(engine, "set_overlap")
+        if self.overlap:
+            engine.set_overlap(True)
         self.parallelism = "%dx%dx%d bricks, one rank per GPU, halo all-sum + migration over RCCL" % part.dims
 
     def substep(self):
         r, p = self.r, self.r.plan
-        r.e.begin()
-        if p.total:
+        r.e.begin()  # sort, P2G (only the blocks touching a halo box when overlapping), halo pack
+        if p.total and self.overlap:
+            try:
+                work = self.comm.all_to_all_async(p.recv, p.send, p.splits, p.splits)
+            except Exception as exc:  # a transport without async collectives: fall back to the serial exchange
+                import sys
+                print("tiled: async exchange unavailable (%r); continuing without overlap" % (exc,), file=sys.stderr)
+                self.overlap = False
+                self.e.set_overlap(False)  # (the substep in flight stays split: substep_end runs its interior part)
+                self.comm.all_to_all(p.recv, p.send, p.splits, p.splits)
+                work = None
+            if work is not None:
+                r.e.interior()  # everything that cannot touch a halo node runs while the boxes are on the wire
+                work.wait()
+        elif p.total:
             self.comm.all_to_all(p.recv, p.send, p.splits, p.splits)
         r.e.end()
         r.k += 1
@@ -375,10 +422,14 @@ class VirtualTiledJob:
     """all ranks of a partition in ONE process (several ctx on one GPU, or checker engines on the CPU): the
     exchanges become local copies.  Used by the tests to check K-tile == 1-tile on a single device."""
 
-    def __init__(self, engines, part, migrate_interval=None):
+    def __init__(self, engines, part, migrate_interval=None, overlap=False):
         assert len(engines) == part.world
         self.part = part
         self.ranks = [TiledRank(e, part, i, migrate_interval) for i, e in enumerate(engines)]
+        self.overlap = bool(overlap)
+        if self.overlap:
+            for e in engines:
+                e.set_overlap(True)
 
     @staticmethod
     def _a2a(recvs, sends, splits):
@@ -397,6 +448,9 @@ class VirtualTiledJob:
         for r in self.ranks:
             r.e.begin()
         self._a2a([r.plan.recv for r in self.ranks], [r.plan.send for r in self.ranks], [r.plan.splits for r in self.ranks])
+        if self.overlap:
+            for r in self.ranks:
+                r.e.interior()
         for r in self.ranks:
             r.e.end()
             r.k += 1
@@ -436,4 +490,5 @@ def make_tiled_job(tm, cfg, rank, world, local_rank, margin=4, migrate_interval=
     sim.add_particles(dict(type=cfg["material"], positions=x[mine]))
     sim.upload(F_ID, mine.astype(np.int32))  # creation ids are global
     engine = HipEngine(sim, local_rank)
-    return TiledJob(engine, part, DistComm(dist, torch.device("cuda", local_rank)), migrate_interval)
+    overlap = os.environ.get("MPMHIP_TILE_OVERLAP", "1") != "0"
+    return TiledJob(engine, part, DistComm(dist, torch.device("cuda", local_rank)), migrate_interval, overlap=overlap)

@@ -64,8 +64,9 @@ def _gather(sims):
     return {k: v[order] for k, v in out.items()}
 
 
+@pytest.mark.parametrize("overlap", [False, True], ids=["serial", "overlap_split"])
 @pytest.mark.parametrize("world,dims", [(2, None), (4, None), (8, None), (3, (1, 3, 1))])
-def test_k_tiles_reproduce_one_tile(tm, world, dims):
+def test_k_tiles_reproduce_one_tile(tm, world, dims, overlap):
     from taichi_mpm_amd import tiled
     s = _two_material_state()
     n = s.n
@@ -76,7 +77,7 @@ def test_k_tiles_reproduce_one_tile(tm, world, dims):
     counts = np.bincount(owner, minlength=world)
     assert counts.min() > 0.6 * n / world, counts  # balanced cuts
     sims = [_sim(tm, s, owner == r, ids, n + 1024) for r in range(world)]
-    job = tiled.VirtualTiledJob([tiled.HipEngine(sim, 0) for sim in sims], part, migrate_interval=2)
+    job = tiled.VirtualTiledJob([tiled.HipEngine(sim, 0) for sim in sims], part, migrate_interval=2, overlap=overlap)
 
     # one P2G: every rank's node totals equal the single-ctx totals wherever the rank has mass of its own
     one.sort_particles_and_populate_grid()
@@ -85,6 +86,8 @@ def test_k_tiles_reproduce_one_tile(tm, world, dims):
     for r in job.ranks:
         r.e.begin()
     job._a2a([r.plan.recv for r in job.ranks], [r.plan.send for r in job.ranks], [r.plan.splits for r in job.ranks])
+    for r in job.ranks:
+        r.e.interior()  # (no-op unless the substep is split: then the interior blocks are rasterized here)
     for rank, sim in enumerate(sims):
         gr = sim.get_grid(0)
         (nlo, nhi) = part.node_box(rank)
