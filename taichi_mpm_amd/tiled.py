@@ -380,9 +380,8 @@ class TiledJob:
             except Exception as exc:  # a transport without async collectives: fall back to the serial exchange
                 import sys
                 print("tiled: async exchange unavailable (%r); continuing without overlap" % (exc,), file=sys.stderr)
-                self.overlap = False
-                self.e.set_overlap(False)  # (the substep in flight stays split: substep_end runs its interior part)
-                self.comm.all_to_all(p.recv, p.send, p.splits, p.splits)
+                self.overlap, self._unsplit_after = False, True  # the substep in flight stays split:
+                self.comm.all_to_all(p.recv, p.send, p.splits, p.splits)  # substep_end runs its interior part
                 work = None
             if work is not None:
                 r.e.interior()  # everything that cannot touch a halo node runs while the boxes are on the wire
@@ -390,6 +389,9 @@ class TiledJob:
         elif p.total:
             self.comm.all_to_all(p.recv, p.send, p.splits, p.splits)
         r.e.end()
+        if getattr(self, "_unsplit_after", False):
+            self._unsplit_after = False
+            self.e.set_overlap(False)
         r.k += 1
         if r.k % r.migrate_interval == 0:
             self.migrate()
