@@ -103,6 +103,7 @@ struct mpmhip_ctx {
   bool b_stale = false;       // discard_apic_b: the side array is behind RecP.A (k_g2p did not write it)
   int p2g_wgs = 16384;        // workgroups of k_p2g (env MPMHIP_P2G_WGS)
   int p2g_split = 11;         // tuning knob (env MPMHIP_P2G_SPLIT): 10*NS + PS, see do_p2g
+  int g2p_wgs = 4096;         // workgroups of k_g2p (env MPMHIP_G2P_WGS)
   int g2p_minw = 13;          // tuning knob (env MPMHIP_G2P_MINW): __launch_bounds__ waves/SIMD of k_g2p
   int reorder_interval = 0;   // physical reorder every this many substeps (0 = never); env MPMHIP_REORDER_INTERVAL
   float t = 0.0f, request_t = 0.0f;  // `real` accumulators, as in the reference (src/mpm.h:99, mpm.cpp:573)
@@ -195,6 +196,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   c->cfg = *cfg;
   c->device = cfg->device;
   if (const char *e = getenv("MPMHIP_G2P_MINW")) c->g2p_minw = atoi(e);
+  if (const char *e = getenv("MPMHIP_G2P_WGS")) c->g2p_wgs = atoi(e) > 0 ? atoi(e) : 4096;
   if (const char *e = getenv("MPMHIP_P2G_SPLIT")) c->p2g_split = atoi(e);
   if (const char *e = getenv("MPMHIP_P2G_WGS")) c->p2g_wgs = atoi(e) > 0 ? atoi(e) : 16384;
   c->reorder_interval = cfg->reorder_interval;
@@ -595,14 +597,17 @@ static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
 }
 static int do_g2p(mpmhip_ctx *c, int phase = 0) {
   auto kern = k_g2p<256, 2, false>;
+  int nt = 256;
   switch (c->g2p_minw) {  // tuning knob: waves/SIMD target x (rolled gather loop ? 10 : 0)
     case 12: kern = k_g2p<256, 2, true>; break;
     case 3: kern = k_g2p<256, 3, false>; break;
     case 13: kern = k_g2p<256, 3, true>; break;
     case 14: kern = k_g2p<256, 4, true>; break;
+    case 23: kern = k_g2p<128, 3, true>; nt = 128; break;
+    case 53: kern = k_g2p<512, 3, true>; nt = 512; break;
     default: break;
   }
-  hipLaunchKernelGGL(kern, dim3(4096), dim3(256), 0, c->stream, c->P, (float4 *)c->rg, (float4 *)c->rp, (float4 *)c->rb,
+  hipLaunchKernelGGL(kern, dim3(c->g2p_wgs), dim3(nt), 0, c->stream, c->P, (float4 *)c->rg, (float4 *)c->rp, (float4 *)c->rb,
                      c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
                      c->blk_flag, c->LS, c->T, phase);
   c->sorted = false;       // positions moved
