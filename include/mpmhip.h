@@ -131,6 +131,8 @@ typedef struct {
 } mpmhip_shape;
 int mpmhip_set_levelset_shapes(mpmhip_ctx *ctx, int32_t n, const mpmhip_shape *shapes, float friction);
 
+/* A ctx holds at most MPMHIP_MAX_GROUPS groups (k_g2p mirrors the whole group table in LDS). */
+#define MPMHIP_MAX_GROUPS 64
 /* particles — replaces MPM<3>::add_particles (src/mpm.cpp:77-270) with caller-generated samples.
  * add_group returns the group id (>=0) or a negative error. F/B/aux may be NULL (identity/0/material default). */
 int mpmhip_add_group(mpmhip_ctx *ctx, int32_t material, const float params[MPMHIP_NPARAM]);

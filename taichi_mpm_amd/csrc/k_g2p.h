@@ -9,6 +9,7 @@ namespace mpm {
 // resample_optimized / block_op_normal (src/transfer.cpp:837-954), one workgroup per active block, one
 // particle per lane through the sorted index.  Also produces, for the NEXT substep: the affine matrix A of
 // P2G (stress of the updated F from the same eigen-solve as the plasticity) and the sort key of the new position.
+constexpr int G2P_LDS_GROUPS = MPMHIP_MAX_GROUPS;  // the ctx's group capacity: the whole table is mirrored in LDS (5 KiB)
 template <int NT, int MINW, bool ROLL>
 __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__ rg, float4 *__restrict__ rp,
                                                   float4 *__restrict__ rb, const Counters *__restrict__ cnt,
@@ -19,8 +20,12 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
                                                   const float4 *__restrict__ gridv,
                                                   const uint32_t *__restrict__ fat_slot, Counters *cnt_w,
                                                   uint32_t *__restrict__ key, uint8_t *__restrict__ blk_flag,
-                                                  LevelSetDev LS, Tiling T, int phase) {
+                                                  const LevelSetDev *__restrict__ ls, PhaseBox T, int phase) {
   __shared__ float4 tile[TN];
+  __shared__ GroupParams sgroups[G2P_LDS_GROUPS];
+  for (int t = threadIdx.x; t < G2P_LDS_GROUPS * (int)(sizeof(GroupParams) / 4); t += NT)
+    reinterpret_cast<uint32_t *>(sgroups)[t] = reinterpret_cast<const uint32_t *>(groups)[t];  // (the table holds >= 256 rows)
+  __syncthreads();
   // Store staging, one slab per wavefront.  A lane holds its particle's whole record, so a direct store would
   // issue 16-byte pieces at a 64-byte stride: 64 partial-line write requests per instruction (measured: the
   // stores alone cost 0.28 of 0.61 ms).  Records are written row-wise to LDS (80-byte stride: conflict-free
@@ -100,10 +105,8 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
     uint32_t bkey = INVALID, out_slot = INVALID;
     float4 G0, G1, G2, G3, Q0, Q1, Q2, Q3, B0, B1, B2;
     G0 = G1 = G2 = G3 = Q0 = Q1 = Q2 = Q3 = B0 = B1 = B2 = make_float4(0, 0, 0, 0);
-    if (i_cur != INVALID) {
+    auto particle = [&](const GroupParams &g) __attribute__((always_inline)) {
       const size_t i = i_cur;
-      const uint32_t gid = __float_as_uint(g3.y);
-      const GroupParams &g = groups[gid];  // read at use (L1-resident table): keeps 20 VGPRs free
       const float x0 = g0.x, x1 = g0.y, x2 = g0.z;
       const float X0 = x0 * P.idx - ox, X1 = x1 * P.idx - oy, X2 = x2 * P.idx - oz;
       const int c0 = (int)(X0 - 0.5f), c1 = (int)(X1 - 0.5f), c2 = (int)(X2 - 0.5f);
@@ -170,7 +173,8 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
       if (!(P.ablate & 2)) plasticity_and_force(g, cdg, F, aux, stress);  // :950 + next substep's :509
       else stress = cdg;
       float nx0 = fmaf(v0, P.dt, x0), nx1 = fmaf(v1, P.dt, x1), nx2 = fmaf(v2, P.dt, x2);  // :951
-      if (LS.particle_collision) {  // particle_collision_resolution, src/mpm.cpp:414-426 (runs after G2P, :566-569)
+      if (P.particle_collision) {  // particle_collision_resolution, src/mpm.cpp:414-426 (runs after G2P, :566-569)
+        const LevelSetDev &LS = *ls;  // in device memory: by value it would sit in ~130 SGPRs for a rarely used path
         const float xw[3] = {nx0, nx1, nx2};
         float phi, gr[3] = {0, 0, 0};
         if (levelset_eval(LS, xw, P.idx, phi, gr) && phi < 0.0f) {
@@ -204,7 +208,11 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
       B1 = make_float4(b.m[4], b.m[5], b.m[6], b.m[7]);
       B2 = make_float4(b.m[8], 0.0f, 0.0f, 0.0f);
       out_slot = (P.ablate & 1) ? INVALID : i_cur;
-    }
+    };
+    // Group parameters are read at use (keeps ~20 VGPRs free) from the workgroup's LDS copy of the table: DS reads
+    // wait on lgkmcnt, whereas vector loads in the middle of the arithmetic wait on vmcnt and with it on the
+    // prefetched records of the next chunk (the counter is in-order), which would undo the prefetch.
+    if (i_cur != INVALID) particle(sgroups[__float_as_uint(g3.y) & (G2P_LDS_GROUPS - 1)]);
     // transposed stores through this wave's LDS slab (DS operations of one wave execute in program order)
     xs[lane] = out_slot;
     xp[lane * 5 + 0] = G0; xp[lane * 5 + 1] = G1; xp[lane * 5 + 2] = G2; xp[lane * 5 + 3] = G3;

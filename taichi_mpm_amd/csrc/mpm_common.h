@@ -53,6 +53,7 @@ struct Params {
   uint32_t max_blocks;
   uint32_t n_slots;  // particle slots in use (host-known)
   int store_b;       // keep apic_b in the side array
+  int particle_collision;  // particle_collision_resolution after G2P (src/mpm.cpp:566-569)
   int ablate;        // PROFILING ONLY (env MPMHIP_ABLATE, results invalid): 1 no G2P stores, 2 no constitutive
                      // update, 4 no 27-tap gather
 };
@@ -74,7 +75,19 @@ struct Tiling {
 // Boundary P2G + halo pack run first, the exchange then overlaps interior P2G / grid / G2P, boundary grid / G2P run
 // when the peers' sums have arrived.  Extents: P2G tile 6 nodes, grid candidate 4, G2P 8 (all 8 grid blocks its
 // tile reads must be interior).
-__device__ __forceinline__ bool in_phase(const Tiling &T, int phase, int lo0, int lo1, int lo2, int extent) {
+// the part of Tiling the transfer kernels need (kernel arguments live in SGPRs: the full struct costs ~80 of them)
+struct PhaseBox {
+  int n_boxes;
+  int int_lo[3], int_hi[3];
+};
+__host__ __device__ __forceinline__ PhaseBox phase_box(const Tiling &T) {
+  PhaseBox b;
+  b.n_boxes = T.n_boxes;
+  for (int k = 0; k < 3; k++) { b.int_lo[k] = T.int_lo[k]; b.int_hi[k] = T.int_hi[k]; }
+  return b;
+}
+template <typename TB>
+__device__ __forceinline__ bool in_phase(const TB &T, int phase, int lo0, int lo1, int lo2, int extent) {
   if (phase == 0) return true;
   const bool interior = T.n_boxes == 0 ||
                         (lo0 >= T.int_lo[0] && lo0 + extent <= T.int_hi[0] && lo1 >= T.int_lo[1] &&

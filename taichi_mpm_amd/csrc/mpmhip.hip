@@ -96,7 +96,7 @@ struct mpmhip_ctx {
   Counters *cnt = nullptr;
   std::vector<GroupParams> groups;
   GroupParams *d_groups = nullptr;
-  int groups_cap = 256;
+  int groups_cap = G2P_LDS_GROUPS;  // k_g2p mirrors the whole table in LDS
   bool sorted = false;        // perm / cell_start describe the current positions
   bool keys_valid = false;    // key[] + block flags describe the current positions (set by k_g2p)
   bool affine_valid = false;  // RecP.A matches (F, aux, apic_b)
@@ -119,6 +119,7 @@ struct mpmhip_ctx {
   Ev *cur_ev = nullptr;  // events of the substep between substep_begin and substep_end
   // tiling
   LevelSetDev LS;
+  LevelSetDev *d_LS = nullptr;  // device copy for k_g2p (k_grid takes it by value)
   Tiling T;
   DevBox *d_boxes = nullptr;
   uint32_t *d_counts = nullptr;
@@ -221,6 +222,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   P.ablate = ablate;
   memset(&c->LS, 0, sizeof c->LS);
   c->LS.particle_collision = cfg->particle_collision;
+  P.particle_collision = cfg->particle_collision;
   if (mpmhip_set_levelset(c, cfg->n_planes, &cfg->planes[0][0], cfg->friction) != MPMHIP_OK) return bail(MPMHIP_EINVAL);
   int kbits = 1;
   while ((1 << kbits) < maxnb) kbits++;
@@ -260,6 +262,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(dmalloc(&c->tiles, (size_t)mb * TN));
   A(dmalloc(&c->gridv, (size_t)mb * 8 * BC));
   A(dmalloc(&c->cnt, 1));
+  A(dmalloc(&c->d_LS, 1));
   A(hipHostMalloc((void **)&c->h_pinned, 65536, hipHostMallocDefault));
   A(dmalloc(&c->d_groups, (size_t)c->groups_cap));
   if (e != hipSuccess) {
@@ -273,6 +276,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(hipMemset(c->cell_start, 0, sizeof(uint32_t) * ((size_t)mb * BC + 1)));
   A(hipMemset(c->act_start, 0, sizeof(uint32_t) * ((size_t)mb + 2)));
   A(hipMemset(c->cnt, 0, sizeof(Counters)));
+  A(hipMemcpy(c->d_LS, &c->LS, sizeof c->LS, hipMemcpyHostToDevice));
   A(hipMemset(c->scan_slots, 0, sizeof(unsigned long long) * n_slots64));  // epoch 0 is never used
   A(hipMemset(c->ticket, 0, 2 * sizeof(uint32_t)));
   A(hipMemset(c->fat_slot, 0, sizeof(uint32_t) * (size_t)c->NB));
@@ -293,7 +297,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   hipFree(c->key); hipFree(c->rank); hipFree(c->perm); hipFree(c->blk_flag); hipFree(c->bits); hipFree(c->wprefix);
   hipFree(c->fat_slot); hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->cell_cnt);
   hipFree(c->cell_start); hipFree(c->scan_slots); hipFree(c->ticket); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
-  hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_counts); hipFree(c->d_bounds); if (c->h_pinned) hipHostFree(c->h_pinned); hipFree(c->d_energy);
+  hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_LS); hipFree(c->d_counts); hipFree(c->d_bounds); if (c->h_pinned) hipHostFree(c->h_pinned); hipFree(c->d_energy);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -321,6 +325,11 @@ int mpmhip_set_levelset_shapes(mpmhip_ctx *c, int32_t n, const mpmhip_shape *sha
     c->LS.s[i].type = shapes[i].type;
     c->LS.s[i].inside_out = shapes[i].inside_out;
     for (int k = 0; k < 6; k++) c->LS.s[i].p[k] = shapes[i].p[k];
+  }
+  if (c->d_LS) {  // (not yet allocated while mpmhip_create installs the config's planes: create uploads it)
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->d_LS, &c->LS, sizeof c->LS, hipMemcpyHostToDevice));
   }
   return MPMHIP_OK;
 }
@@ -583,7 +592,8 @@ static int do_p2g(mpmhip_ctx *c, int phase = 0) {
     default: break;
   }
   hipLaunchKernelGGL(kern, dim3(c->p2g_wgs), dim3(nt), 0, c->stream, c->P,
-                     (const float4 *)c->rp, c->cnt, c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles, c->T, phase);
+                     (const float4 *)c->rp, c->cnt, c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles,
+                     phase_box(c->T), phase);
   return launch_check(c, "p2g");
 }
 static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
@@ -609,7 +619,7 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0) {
   }
   hipLaunchKernelGGL(kern, dim3(c->g2p_wgs), dim3(nt), 0, c->stream, c->P, (float4 *)c->rg, (float4 *)c->rp, (float4 *)c->rb,
                      c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
-                     c->blk_flag, c->LS, c->T, phase);
+                     c->blk_flag, (const LevelSetDev *)c->d_LS, phase_box(c->T), phase);
   c->sorted = false;       // positions moved
   c->keys_valid = true;    // ... and their keys / block flags are ready for the next sort
   c->affine_valid = true;  // A was produced together with F
