@@ -10,7 +10,7 @@ namespace mpm {
 // particle per lane through the sorted index.  Also produces, for the NEXT substep: the affine matrix A of
 // P2G (stress of the updated F from the same eigen-solve as the plasticity) and the sort key of the new position.
 constexpr int G2P_LDS_GROUPS = MPMHIP_MAX_GROUPS;  // the ctx's group capacity: the whole table is mirrored in LDS (5 KiB)
-template <int NT, int MINW, bool ROLL>
+template <int NT, int MINW, bool ROLL, bool STORE_B>
 __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__ rg, float4 *__restrict__ rp,
                                                   float4 *__restrict__ rb, const Counters *__restrict__ cnt,
                                                   const uint32_t *__restrict__ act_blk,
@@ -204,9 +204,11 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
       Q1 = make_float4(v1, v2, A[0], A[1]);
       Q2 = make_float4(A[2], A[3], A[4], A[5]);
       Q3 = make_float4(A[6], A[7], A[8], g.p[0]);
-      B0 = make_float4(b.m[0], b.m[1], b.m[2], b.m[3]);
-      B1 = make_float4(b.m[4], b.m[5], b.m[6], b.m[7]);
-      B2 = make_float4(b.m[8], 0.0f, 0.0f, 0.0f);
+      if constexpr (STORE_B) {
+        B0 = make_float4(b.m[0], b.m[1], b.m[2], b.m[3]);
+        B1 = make_float4(b.m[4], b.m[5], b.m[6], b.m[7]);
+        B2 = make_float4(b.m[8], 0.0f, 0.0f, 0.0f);
+      }
       out_slot = (P.ablate & 1) ? INVALID : i_cur;
     };
     // Group parameters are read at use (keeps ~20 VGPRs free) from the workgroup's LDS copy of the table: DS reads
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
       const float4 val = xp[src * 5 + q];
       if (sl != INVALID) rp[(size_t)sl * 4 + q] = val;
     }
-    if (P.store_b) {
+    if constexpr (STORE_B) {  // (compile-time: in the default folded mode the apic_b registers do not exist)
       __builtin_amdgcn_wave_barrier();
       xp[lane * 5 + 0] = B0; xp[lane * 5 + 1] = B1; xp[lane * 5 + 2] = B2;
       __builtin_amdgcn_wave_barrier();

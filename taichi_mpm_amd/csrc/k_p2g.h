@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const floa
                                                             const uint32_t *__restrict__ cell_start,
                                                             const uint32_t *__restrict__ perm,
                                                             const GroupParams *__restrict__ groups,
-                                                            float4 *__restrict__ tiles, PhaseBox T, int phase) {
+                                                            float4 *__restrict__ tiles, Tiling T, int phase) {
   constexpr int NW = NS * PS, NT = 64 * NW;
   __shared__ float4 tile[NW][TN];  // per wave: (m*vx, m*vy, m*vz, m) per node of the block's 6^3 tile
   const uint32_t na = min(cnt->n_active, P.max_blocks);

@@ -592,8 +592,7 @@ static int do_p2g(mpmhip_ctx *c, int phase = 0) {
     default: break;
   }
   hipLaunchKernelGGL(kern, dim3(c->p2g_wgs), dim3(nt), 0, c->stream, c->P,
-                     (const float4 *)c->rp, c->cnt, c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles,
-                     phase_box(c->T), phase);
+                     (const float4 *)c->rp, c->cnt, c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles, c->T, phase);
   return launch_check(c, "p2g");
 }
 static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
@@ -606,15 +605,13 @@ static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
   return launch_check(c, "grid");
 }
 static int do_g2p(mpmhip_ctx *c, int phase = 0) {
-  auto kern = k_g2p<256, 2, false>;
+  const bool sb = c->P.store_b != 0;
+  auto kern = sb ? k_g2p<256, 3, true, true> : k_g2p<256, 3, true, false>;  // 3 waves/SIMD, rolled gather: fastest
   int nt = 256;
-  switch (c->g2p_minw) {  // tuning knob: waves/SIMD target x (rolled gather loop ? 10 : 0)
-    case 12: kern = k_g2p<256, 2, true>; break;
-    case 3: kern = k_g2p<256, 3, false>; break;
-    case 13: kern = k_g2p<256, 3, true>; break;
-    case 14: kern = k_g2p<256, 4, true>; break;
-    case 23: kern = k_g2p<128, 3, true>; nt = 128; break;
-    case 53: kern = k_g2p<512, 3, true>; nt = 512; break;
+  switch (c->g2p_minw) {  // tuning knob: waves/SIMD target + 10 (rolled gather loop) | plain
+    case 12: kern = sb ? k_g2p<256, 2, true, true> : k_g2p<256, 2, true, false>; break;
+    case 3: kern = sb ? k_g2p<256, 3, false, true> : k_g2p<256, 3, false, false>; break;
+    case 14: kern = sb ? k_g2p<256, 4, true, true> : k_g2p<256, 4, true, false>; break;
     default: break;
   }
   hipLaunchKernelGGL(kern, dim3(c->g2p_wgs), dim3(nt), 0, c->stream, c->P, (float4 *)c->rg, (float4 *)c->rp, (float4 *)c->rb,
