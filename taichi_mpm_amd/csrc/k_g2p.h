@@ -81,7 +81,10 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
   float ox = 0, oy = 0, oz = 0;
   while (cur.a < na) {
     if (cur.a != tile_a) {
-      __syncthreads();  // everyone is done with the previous tile
+      // LDS-only barriers (lgkmcnt(0) + s_barrier): __syncthreads() would also wait on vmcnt, i.e. on the
+      // acknowledgements of the previous chunk's record stores
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();  // everyone is done with the previous tile
       int bx, by, bz;
       demorton3(act_blk[cur.a], bx, by, bz);
       for (int t = tid; t < TN; t += NT) {
@@ -90,7 +93,8 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
         const uint32_t fs = fat_slot[morton3(bx + qx, by + qy, bz + qz)];
         tile[t] = gridv[(size_t)fs * BC + (((tx & 3) << 4) | ((ty & 3) << 2) | (tz & 3))];
       }
-      __syncthreads();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
       ox = (float)(bx * BS); oy = (float)(by * BS); oz = (float)(bz * BS);
       tile_a = cur.a;
     }
@@ -215,6 +219,11 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
     // wait on lgkmcnt, whereas vector loads in the middle of the arithmetic wait on vmcnt and with it on the
     // prefetched records of the next chunk (the counter is in-order), which would undo the prefetch.
     if (i_cur != INVALID) particle(sgroups[__float_as_uint(g3.y) & (G2P_LDS_GROUPS - 1)]);
+    // Let the prefetched records of the next chunk land BEFORE this chunk's stores go out: on gfx9-family parts
+    // loads and stores share one in-order-per-type counter (vmcnt), so a later wait for those loads would be a
+    // vmcnt(0) that also waits for the stores' acknowledgements — here the loads have had the whole arithmetic to
+    // arrive, and the stores then drain behind the next chunk's arithmetic.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
     // transposed stores through this wave's LDS slab (DS operations of one wave execute in program order)
     xs[lane] = out_slot;
     xp[lane * 5 + 0] = G0; xp[lane * 5 + 1] = G1; xp[lane * 5 + 2] = G2; xp[lane * 5 + 3] = G3;
