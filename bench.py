@@ -178,10 +178,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # test hook: MPMHIP_BENCH_BACKEND=gloo runs the N > 1 path with all ranks sharing the visible GPU(s) and the
+    # device buffers staged through gloo (RCCL refuses two ranks on one GPU) — everything but the wire
+    staged = world > 1 and os.environ.get("MPMHIP_BENCH_BACKEND", "nccl") == "gloo"
+    if staged:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    red_dev = "cpu" if staged else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if staged:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = CONFIGS[args.config]
     from taichi_mpm_amd import tiling
@@ -194,6 +203,9 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         from taichi_mpm_amd import tiled
         job = tiled.make_tiled_job(tm, cfg, 0, 1, local_rank)
+    elif staged:
+        from taichi_mpm_amd import tiled
+        job = tiled.make_tiled_job(tm, cfg, rank, world, local_rank, comm=tiled.StagedDistComm(dist))
     else:
         job = tiling.make_job(tm, cfg, rank, world, local_rank, build_sim)
     n_local = job.num_particles()
@@ -219,10 +231,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        nt = torch.tensor([n_local], dtype=torch.float64, device="cuda")
+        nt = torch.tensor([n_local], dtype=torch.float64, device=red_dev)
         dist.all_reduce(nt, op=dist.ReduceOp.SUM)
         n_total = int(nt.item())
     else:

@@ -470,7 +470,7 @@ class VirtualTiledJob:
 
 
 # ---------------------------------------------------------------------------------------------------- bench glue
-def make_tiled_job(tm, cfg, rank, world, local_rank, margin=4, migrate_interval=None):
+def make_tiled_job(tm, cfg, rank, world, local_rank, margin=4, migrate_interval=None, comm=None):
     """bench.py, N > 1: every rank generates the same synthetic lattice, keeps its brick's particles."""
     import os
 
@@ -493,4 +493,5 @@ def make_tiled_job(tm, cfg, rank, world, local_rank, margin=4, migrate_interval=
     sim.upload(F_ID, mine.astype(np.int32))  # creation ids are global
     engine = HipEngine(sim, local_rank)
     overlap = os.environ.get("MPMHIP_TILE_OVERLAP", "1") != "0"
-    return TiledJob(engine, part, DistComm(dist, torch.device("cuda", local_rank)), migrate_interval, overlap=overlap)
+    comm = comm or DistComm(dist, torch.device("cuda", local_rank))
+    return TiledJob(engine, part, comm, migrate_interval, overlap=overlap)

@@ -224,3 +224,32 @@ def test_two_processes_on_one_gpu_match_one_ctx(tm):
     assert np.array_equal(got["id"], ref["id"]) and np.array_equal(got["gid"], ref["gid"])
     assert np.abs(got["x"] - ref["x"]).max() <= 1e-6
     assert rel_l2(got["v"], ref["v"]) <= 1e-4 and rel_l2(got["F"], ref["F"]) <= 1e-4
+
+
+@pytest.mark.parametrize("nproc,bricks", [(2, "2x1x1"), (8, "2x2x2")])
+def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks):
+    """`bench.py --gpus N` exactly as the driver launches it (torch.distributed.run, one process per rank), with
+    the MPMHIP_BENCH_BACKEND=gloo hook: both ranks share this GPU and the buffers are staged through gloo.  Checks
+    the ONE-JSON-line contract and the whole-job aggregation of the N > 1 path."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MPMHIP_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--config", "c2",
+           "--steps", "8", "--warmup", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == nproc and d["steps"] == 8 and d["warmup"] == 4 and d["scaling"] == "strong"
+    assert d["config"]["particles"] == 1000000  # both ranks' particles: whole-job aggregate
+    assert d["value"] > 0 and d["unit"] == "particle-steps/s" and d["roofline"]["kernel"] in ("k_g2p", "k_p2g")
+    assert bricks + " bricks" in d["config"]["parallelism"]
