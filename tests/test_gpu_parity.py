@@ -586,3 +586,47 @@ def test_snapshot_restart_continues_the_run(tm, orc, tmp_path):
     with pytest.raises(tm.mpm.MPMError, match="snapshot"):
         b.general_action(dict(action="load", file_name=path))
     a.close(); b.close()
+
+
+# ------------------------------------------------------------------------------------------ long runs / reorder
+def test_physical_reorder_does_not_change_the_run(tm, orc):
+    """sort_allocator (src/mpm.cpp:752-768, every reorder_interval substeps): moving the records into sorted order
+    mid-run must not change the simulation (only the in-cell summation order)."""
+    x = lattice_cube(RES, 9, 17, DX, jitter=0.2, seed=81)
+    s = make_state(x, "snow", DX, perturb_F=0.02, seed=82, vel_scale=4.0)
+    outs = []
+    for interval in (0, 1, 3):
+        sim = make_sim(tm, s, reorder_interval=interval)
+        sim.run_substeps(10)
+        outs.append(sim.get_particles())
+        sim.close()
+    for o in outs[1:]:
+        assert np.array_equal(o["id"], outs[0]["id"])
+        assert np.abs(o["x"] - outs[0]["x"]).max() <= 1e-6
+        assert rel_l2(o["v"], outs[0]["v"]) <= 1e-5 and rel_l2(o["F"], outs[0]["F"]) <= 1e-4
+
+
+@pytest.mark.parametrize("mat", ["sand", "water", "snow", "visco"])
+def test_column_collapse_stays_sane_for_400_substeps(tm, mat):
+    """a block dropped on a frictional floor inside a container: after 400 substeps every particle is still there,
+    finite, inside the container and above the floor, nothing moves faster than free fall + sound, and the centre
+    of mass has gone down"""
+    x = lattice_cube(RES, 10, 18, DX, jitter=0.15, seed=91)
+    s = make_state(x, mat, DX, perturb_F=0.0, vel_scale=0.0)
+    s.v[:] = 0
+    s.B[:] = 0
+    sim = make_sim(tm, s, planes=None, particle_collision=True)
+    ls = tm.mpm.LevelSet(friction=0.3).add_plane((0, 1, 0), d=-0.28).add_cuboid((0.24, 0.2, 0.24), (0.76, 0.9, 0.76), True)
+    sim.set_levelset(ls)
+    y0 = s.x[:, 1].mean()
+    sim.run_substeps(400)
+    sim.synchronize()
+    p = sim.get_particles()
+    assert len(p["x"]) == s.n
+    for k in ("x", "v", "F", "aux"):
+        assert np.all(np.isfinite(p[k])), k
+    assert p["x"][:, 1].min() >= 0.28 - 1e-4
+    assert (p["x"][:, [0, 2]] >= 0.24 - 1e-4).all() and (p["x"][:, [0, 2]] <= 0.76 + 1e-4).all()
+    assert np.abs(p["v"]).max() < 20.0
+    assert p["x"][:, 1].mean() < y0 - 1e-3
+    sim.close()
