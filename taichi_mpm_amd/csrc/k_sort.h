@@ -172,8 +172,9 @@ __global__ __launch_bounds__(256) void k_rank(Params P, uint32_t *__restrict__ k
 // Cell table, one launch: per-cell counts (k_rank) -> act_start[a] (first sorted position of active block a,
 // sentinel at [n_active]) and cell_start[a*64 + c] (sentinel at [n_active*64]): the particles of cell i are
 // perm[cell_start[i] .. cell_start[i+1]).  Zeroes the counters behind itself.  Chunk = the 64 blocks
-// [64 t, 64 t + 64): wave w takes the 16 blocks [64 t + 16 w, +16), one lane per cell.
-constexpr int CT_BLOCKS = 64;
+// [CT_BLOCKS t, CT_BLOCKS (t + 1)): each of the 4 waves takes CT_BLOCKS / 4 of them, one lane per cell.
+template <int CT_BLOCKS>  // blocks per chunk: 64 for large problems, 16 when there are few blocks (shorter chains,
+                           // more workgroups: 35 -> 31 us of sort at 1 M particles, but 90 -> 100 us at 8 M)
 __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uint32_t *__restrict__ cell_cnt,
                                                     uint32_t *__restrict__ act_start,
                                                     uint32_t *__restrict__ cell_start,
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
                                                     uint32_t epoch) {
   __shared__ uint32_t lds[8];
   __shared__ uint32_t s_chunk;
+  constexpr int CT_BPW = CT_BLOCKS / 4;  // blocks per wave
   __shared__ uint32_t blk_tot[CT_BLOCKS];
   if (blockIdx.x == 0 && threadIdx.x == 0) ticket[0] = 0;  // k_block_table's counter (it is not running now)
   const uint32_t na = min(cnt->n_active, P.max_blocks);
@@ -189,10 +191,10 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
     const uint32_t chunk = take_ticket(ticket + 1, &s_chunk);
     const uint32_t a0 = chunk * CT_BLOCKS;
     if (a0 >= na && !(na == 0 && chunk == 0)) return;
-    uint32_t excl[16];  // exclusive in-block prefix of this lane's cell, for the wave's 16 blocks
+    uint32_t excl[CT_BPW];  // exclusive in-block prefix of this lane's cell, for the wave's blocks
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const uint32_t a = a0 + wave * 16 + i;
+    for (int i = 0; i < CT_BPW; i++) {
+      const uint32_t a = a0 + wave * CT_BPW + i;
       uint32_t c = 0;
       if (a < na) {
         c = cell_cnt[(size_t)a * BC + lane];
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
         if ((int)lane >= off) v += u;
       }
       excl[i] = v - c;
-      if (lane == 63) blk_tot[wave * 16 + i] = v;
+      if (lane == 63) blk_tot[wave * CT_BPW + i] = v;
     }
     __syncthreads();
     // exclusive scan of the 64 block totals (threads 0..63 hold one block each; other threads contribute 0)
@@ -216,10 +218,10 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
     if (threadIdx.x < CT_BLOCKS) blk_tot[threadIdx.x] = boff;
     const uint32_t chunk_base = sum_predecessors(slots, chunk, epoch, lds);  // its barriers also cover blk_tot
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const uint32_t a = a0 + wave * 16 + i;
+    for (int i = 0; i < CT_BPW; i++) {
+      const uint32_t a = a0 + wave * CT_BPW + i;
       if (a < na) {
-        const uint32_t start = chunk_base + blk_tot[wave * 16 + i];
+        const uint32_t start = chunk_base + blk_tot[wave * CT_BPW + i];
         cell_start[(size_t)a * BC + lane] = start + excl[i];
         if (lane == 0) act_start[a] = start;
       }

@@ -256,7 +256,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(dmalloc(&c->cell_cnt, (size_t)mb * BC));
   A(dmalloc(&c->cell_start, (size_t)mb * BC + 1));
   c->bt_slots = (P.nbw + 255) / 256;
-  const size_t n_slots64 = c->bt_slots + ((size_t)mb + CT_BLOCKS - 1) / CT_BLOCKS + 1;
+  const size_t n_slots64 = c->bt_slots + ((size_t)mb + 15) / 16 + 1;  // k_cell_table chunks are >= 16 blocks
   A(dmalloc(&c->scan_slots, n_slots64));
   A(dmalloc(&c->ticket, 2));
   A(dmalloc(&c->tiles, (size_t)mb * TN));
@@ -532,13 +532,14 @@ static int do_sort(mpmhip_ctx *c) {
   const int pg = particle_grid(c->n_slots);
   if (!c->keys_valid)
     hipLaunchKernelGGL(k_build_keys, dim3(pg), dim3(256), 0, st, P, c->rg, c->rp, c->cnt, c->key, c->blk_flag);
-  const uint32_t bt_chunks = (P.nbw + 255) / 256, ct_chunks = (P.max_blocks + CT_BLOCKS - 1) / CT_BLOCKS;
+  const bool small = c->n_slots < (2 << 20);  // few blocks: finer chunks in k_cell_table
+  const uint32_t bt_chunks = (P.nbw + 255) / 256, ct_chunks = (P.max_blocks + (small ? 16 : 64) - 1) / (small ? 16 : 64);
   const uint32_t epoch = ++c->sort_epoch;
   hipLaunchKernelGGL(k_block_table, dim3(std::min(bt_chunks, 512u)), dim3(256), 0, st, P, c->blk_flag, c->bits,
                      c->wprefix, c->act_blk, c->cnt, c->scan_slots, c->ticket, epoch);
   hipLaunchKernelGGL(k_rank, dim3(pg), dim3(256), 0, st, P, c->key, c->rank, c->cell_cnt, c->bits, c->wprefix);
-  hipLaunchKernelGGL(k_cell_table, dim3(std::min(ct_chunks, 512u)), dim3(256), 0, st, P, c->cnt, c->cell_cnt,
-                     c->act_start, c->cell_start, c->scan_slots + c->bt_slots, c->ticket, epoch);
+  hipLaunchKernelGGL(small ? k_cell_table<16> : k_cell_table<64>, dim3(std::min(ct_chunks, 512u)), dim3(256), 0, st, P,
+                     c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots, c->ticket, epoch);
   hipLaunchKernelGGL(k_perm, dim3(pg), dim3(256), 0, st, P, c->key, c->rank, c->cell_start, c->perm);
   c->sorted = true;
   c->keys_valid = false;  // key[] now holds cell indices
