@@ -181,31 +181,54 @@ def main():
     # test hook: MPMHIP_BENCH_BACKEND=gloo runs the N > 1 path with all ranks sharing the visible GPU(s) and the
     # device buffers staged through gloo (RCCL refuses two ranks on one GPU) — everything but the wire
     staged = world > 1 and os.environ.get("MPMHIP_BENCH_BACKEND", "nccl") == "gloo"
-    if staged:
-        local_rank = local_rank % torch.cuda.device_count()
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    red_dev = "cpu" if staged else "cuda"
-    if world > 1:
+    force_tiled = world == 1 and os.environ.get("MPMHIP_FORCE_TILED") == "1"  # test hook: TiledJob over RCCL, 1 rank
+    data_group, wire = None, None
+    if world > 1 or force_tiled:
+        # control plane (barriers, the two scalar reductions below, agreement on the transport) = gloo, the default
+        # group; data plane (halo all-sum, migration) = an RCCL group over xGMI with device buffers
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if staged:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        wire = "gloo, staged through host memory (test hook)"
+        if not staged:
+            # probe the transport with the two collectives the job uses; every rank must see it work, else all ranks
+            # stage the same buffers through gloo (slower wire, same kernels, same results) rather than abort
+            ok, why = 1, ""
+            try:
+                data_group = dist.new_group(backend="nccl")
+                dev = torch.device("cuda", local_rank)
+                a = torch.full((world,), float(rank), device=dev)
+                b = torch.empty_like(a)
+                dist.all_to_all_single(b, a, [1] * world, [1] * world, group=data_group)
+                g = torch.empty(world, device=dev)
+                dist.all_gather_into_tensor(g, a[:1], group=data_group)
+                torch.cuda.synchronize()
+                ok = int(bool((b.cpu() == torch.arange(world, dtype=b.dtype)).all())
+                         and bool((g.cpu() == torch.arange(world, dtype=g.dtype)).all()))
+                why = "" if ok else "RCCL probe returned wrong data"
+            except Exception as e:
+                ok, why = 0, repr(e)
+            flag = torch.tensor([ok])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()):
+                wire = "RCCL (nccl backend), device buffers"
+            else:
+                print("bench.py[rank %d]: RCCL transport unavailable (%s); staging the exchange through gloo" % (rank, why or "failed on another rank"),
+                      file=sys.stderr)
+                staged, data_group = True, None
+                wire = "gloo, staged through host memory (RCCL probe failed)"
 
     cfg = CONFIGS[args.config]
     from taichi_mpm_amd import tiling
     if args.virtual > 1:
         return emit(virtual_run(tm, cfg, args))
-    force_tiled = world == 1 and os.environ.get("MPMHIP_FORCE_TILED") == "1"  # test hook: TiledJob over RCCL, 1 rank
-    if force_tiled:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    if world > 1 or force_tiled:
         from taichi_mpm_amd import tiled
-        job = tiled.make_tiled_job(tm, cfg, 0, 1, local_rank)
-    elif staged:
-        from taichi_mpm_amd import tiled
-        job = tiled.make_tiled_job(tm, cfg, rank, world, local_rank, comm=tiled.StagedDistComm(dist))
+        comm = (tiled.StagedDistComm(dist) if staged else
+                tiled.DistComm(dist, torch.device("cuda", local_rank), data_group))
+        job = tiled.make_tiled_job(tm, cfg, rank, world, local_rank, comm=comm)
     else:
         job = tiling.make_job(tm, cfg, rank, world, local_rank, build_sim)
     n_local = job.num_particles()
@@ -231,10 +254,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        nt = torch.tensor([n_local], dtype=torch.float64, device=red_dev)
+        nt = torch.tensor([n_local], dtype=torch.float64)
         dist.all_reduce(nt, op=dist.ReduceOp.SUM)
         n_total = int(nt.item())
     else:
@@ -259,7 +282,7 @@ def main():
         "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": job.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": cfg["desc"], "particles": n_total, "dt": 1e-4, "parallelism": job.parallelism,
+        "config": {"workload": cfg["desc"], "particles": n_total, "dt": 1e-4, "parallelism": job.parallelism, "wire": wire,
                    "timed": "full substep: sort+reorder, P2G, grid normalise+boundary, G2P, boundary cleanup"},
         "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,

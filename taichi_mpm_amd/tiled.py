@@ -239,14 +239,15 @@ class HipEngine:
 class DistComm:
     """torch.distributed: backend nccl (= RCCL over xGMI) with device tensors, gloo with CPU tensors in tests"""
 
-    def __init__(self, dist, device):
+    def __init__(self, dist, device, group=None):
         import torch
-        self.torch, self.dist, self.device = torch, dist, device
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.torch, self.dist, self.device, self.group = torch, dist, device, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
 
     def all_to_all(self, out, inp, out_splits, in_splits):
         out_splits, in_splits = list(map(int, out_splits)), list(map(int, in_splits))
-        self.dist.all_to_all_single(out[:sum(out_splits)], inp[:sum(in_splits)], out_splits, in_splits)
+        self.dist.all_to_all_single(out[:sum(out_splits)], inp[:sum(in_splits)], out_splits, in_splits,
+                                    group=self.group)
 
     def all_to_all_async(self, out, inp, out_splits, in_splits):
         """start the exchange behind everything enqueued so far and return a handle; handle.wait() makes the
@@ -254,7 +255,7 @@ class DistComm:
         out_splits, in_splits = list(map(int, out_splits)), list(map(int, in_splits))
         if self.device.type != "cuda":
             return self.dist.all_to_all_single(out[:sum(out_splits)], inp[:sum(in_splits)], out_splits, in_splits,
-                                               async_op=True)
+                                               group=self.group, async_op=True)
         tc = self.torch.cuda
         if getattr(self, "_side", None) is None:
             self._side, self._ev = tc.Stream(self.device), tc.Event()
@@ -262,13 +263,13 @@ class DistComm:
         with tc.stream(self._side):
             self._side.wait_event(self._ev)
             return self.dist.all_to_all_single(out[:sum(out_splits)], inp[:sum(in_splits)], out_splits, in_splits,
-                                               async_op=True)
+                                               group=self.group, async_op=True)
 
     def all_gather_ints(self, row):
         """every rank's int64 row -> (world, len(row)) on every rank: ONE small collective per migration"""
         t = self.torch.as_tensor(np.asarray(row, np.int64)).to(self.device)
         o = self.torch.empty(self.world * t.numel(), dtype=t.dtype, device=self.device)
-        self.dist.all_gather_into_tensor(o, t)
+        self.dist.all_gather_into_tensor(o, t, group=self.group)
         return o.cpu().numpy().reshape(self.world, -1)
 
 
@@ -276,15 +277,15 @@ class StagedDistComm(DistComm):
     """device buffers moved by a CPU-only backend (gloo): device -> host, collective, host -> device.  Lets several
     ranks share ONE GPU (RCCL refuses that), which is how the multi-process path is tested on a single-GPU box."""
 
-    def __init__(self, dist):
+    def __init__(self, dist, group=None):
         import torch
-        super().__init__(dist, torch.device("cpu"))
+        super().__init__(dist, torch.device("cpu"), group)
 
     def all_to_all(self, out, inp, out_splits, in_splits):
         out_splits, in_splits = list(map(int, out_splits)), list(map(int, in_splits))
         h_in = inp[:sum(in_splits)].cpu()  # synchronises the stream the ctx runs on
         h_out = self.torch.empty(sum(out_splits), dtype=inp.dtype)
-        self.dist.all_to_all_single(h_out, h_in, out_splits, in_splits)
+        self.dist.all_to_all_single(h_out, h_in, out_splits, in_splits, group=self.group)
         out[:sum(out_splits)].copy_(h_out)
 
     def all_to_all_async(self, out, inp, out_splits, in_splits):

@@ -226,11 +226,13 @@ def test_two_processes_on_one_gpu_match_one_ctx(tm):
     assert rel_l2(got["v"], ref["v"]) <= 1e-4 and rel_l2(got["F"], ref["F"]) <= 1e-4
 
 
-@pytest.mark.parametrize("nproc,bricks", [(2, "2x1x1"), (8, "2x2x2")])
-def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks):
+@pytest.mark.parametrize("nproc,bricks,hook", [(2, "2x1x1", True), (8, "2x2x2", True), (2, "2x1x1", False)])
+def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks, hook):
     """`bench.py --gpus N` exactly as the driver launches it (torch.distributed.run, one process per rank), with
     the MPMHIP_BENCH_BACKEND=gloo hook: both ranks share this GPU and the buffers are staged through gloo.  Checks
-    the ONE-JSON-line contract and the whole-job aggregation of the N > 1 path."""
+    the ONE-JSON-line contract and the whole-job aggregation of the N > 1 path.  hook=False is the launch without
+    any hook on a box with fewer GPUs than ranks: the RCCL probe fails (two ranks on one device) on every rank and
+    the job must carry on over the staged transport instead of aborting."""
     import json
     import os
     import socket
@@ -240,7 +242,10 @@ def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, MPMHIP_BENCH_BACKEND="gloo")
+    env = dict(os.environ)
+    env.pop("MPMHIP_BENCH_BACKEND", None)
+    if hook:
+        env["MPMHIP_BENCH_BACKEND"] = "gloo"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--config", "c2",
            "--steps", "8", "--warmup", "4"]
@@ -253,3 +258,26 @@ def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks):
     assert d["config"]["particles"] == 1000000  # both ranks' particles: whole-job aggregate
     assert d["value"] > 0 and d["unit"] == "particle-steps/s" and d["roofline"]["kernel"] in ("k_g2p", "k_p2g")
     assert bricks + " bricks" in d["config"]["parallelism"]
+    assert d["config"]["wire"].startswith("gloo") and ("probe failed" in d["config"]["wire"]) == (not hook)
+
+
+def test_bench_tiled_job_over_rccl_single_rank(tm):
+    """MPMHIP_FORCE_TILED=1: the tiled job (halo plan, migration scan, all_to_all / all_gather on DEVICE buffers) over a
+    real RCCL communicator — with the one rank a 1-GPU box allows.  The transport probe must pick RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MPMHIP_FORCE_TILED="1")
+    env.pop("MPMHIP_BENCH_BACKEND", None)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c2", "--steps", "8", "--warmup", "4",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["particles"] == 1000000 and d["value"] > 0
+    assert d["config"]["wire"].startswith("RCCL"), d["config"]["wire"]
