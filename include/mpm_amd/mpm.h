@@ -65,8 +65,11 @@ class MPM<3> {
     cfg_.device = config.get("device", 0);
     cfg_.discard_apic_b = !config.get("keep_apic_b", false);
     cfg_.particle_collision = config.get("particle_collision", false);  // src/mpm.cpp:566-569
+    verbose_bgeo = config.get("verbose_bgeo", false);   // src/visualize.cpp:22
+    frame_directory = config.get("frame_directory", "");  // injected by the python driver, async_mpm.py:49
     check(mpmhip_create(&cfg_, &ctx_), nullptr);
     frame = 0;
+    frame_count = 0;
   }
 
   // --- analytic level set (set_levelset(DynamicLevelSet) of the reference, for half-spaces): phi = n.x + d
@@ -168,6 +171,19 @@ class MPM<3> {
     return out;
   }
 
+  // --- frame output: visualize() -> write_bgeo() -> write_partio(file) (src/visualize.cpp:156-159, src/mpm.h:333-337,
+  // src/visualize.cpp:17-100).  The Houdini .bgeo bytes equal the reference's (rows assembled on the device).
+  void write_partio(const std::string &file_name) const { check(mpmhip_write_bgeo(ctx_, file_name.c_str(), verbose_bgeo), ctx_); }
+  std::string write_bgeo() {
+    if (frame_directory.empty()) throw std::runtime_error("write_bgeo() needs the config key 'frame_directory'");
+    char name[32];
+    std::snprintf(name, sizeof name, "/%04d.bgeo", ++frame_count);  // frames start at 1 (src/mpm.h:334-336)
+    const std::string file_name = frame_directory + name;
+    write_partio(file_name);
+    return file_name;
+  }
+  void visualize() { write_bgeo(); }
+
   // --- MPM<dim>::general_action (src/mpm.cpp:920-978): the actions that only need the hot path's state
   std::string general_action(const Config &config) {
     const std::string action = config.get("action", "");
@@ -206,7 +222,9 @@ class MPM<3> {
 
   VectorI res;
   real delta_x = 0, base_delta_t = 0;
-  int frame = 0;
+  int frame = 0, frame_count = 0;
+  bool verbose_bgeo = false;
+  std::string frame_directory;
 
  private:
   void lattice(int lower, int higher, std::vector<float> &x) const {  // src/mpm.cpp:164-180: cell centre +- 0.25 dx

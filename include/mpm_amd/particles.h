@@ -120,6 +120,7 @@ inline ParticleType create_particle_type(const std::string &alias, const Config 
   } else if (alias == "elastic") {  // :777-783
     t.material = MPMHIP_ELASTIC;
     lame(c.get("E", 5e3), c.get("nu", 0.4), p[2], p[3]);
+    p[4] = c.get("E", 5e3f);  // only reported back by get_debug_info() (verbose .bgeo), :838-840
   } else if (alias == "visco") {  // :57-70
     t.material = MPMHIP_VISCO;
     lame(c.get("youngs_modulus", 4e4), c.get("poisson_ratio", 0.4), p[2], p[3]);

@@ -62,7 +62,7 @@ enum {
  *   water     [2] k    [3] gamma                                                             ; aux = j
  *   sand      [2] mu_0 [3] lambda_0 [4] alpha [5] cohesion [6] beta                           ; aux = logJp
  *   von_mises [2] mu_0 [3] lambda_0 [4] yield_stress
- *   elastic   [2] mu_0 [3] lambda_0
+ *   elastic   [2] mu_0 [3] lambda_0 [4] E (reported by get_debug_info() only, src/particles.cpp:838-840)
  *   visco     [2] mu_0 [3] lambda_0 [4] visco_nu [5] visco_kappa [6] base_delta_t                ; aux = visco_tau
  */
 
@@ -175,6 +175,21 @@ int mpmhip_snapshot_load(mpmhip_ctx *ctx, const void *src, size_t size);
  * (defined for linear, jelly, elastic: src/particles.cpp:323-327,400-407,785-796).  Returns MPMHIP_ENOTIMPL (with a
  * valid *kinetic) if a live particle is of another type, as the reference aborts there.  Synchronises. */
 int mpmhip_calculate_energy(mpmhip_ctx *ctx, double *kinetic, double *potential);
+
+/* frame output — replaces MPM<dim>::write_bgeo / write_partio (src/mpm.h:333-337, src/visualize.cpp:17-100; called
+ * by visualize(), src/visualize.cpp:156-164) including the Partio encoder behind it (external/partio/src/io/BGEO.cpp:
+ * 57-194, Houdini .bgeo version 5, big-endian).  Byte-identical to the reference's file for the same particle state:
+ * attributes position, type, index, limit[3], v and — verbose (config "verbose_bgeo") — m, boundary_normal[3], debug[3],
+ * states, boundary_distance, near_boundary, apic_frobenius_norm; particles in ascending id.  The rows are gathered,
+ * interleaved and byte-swapped on the device; the host adds header and trailer.  Fields this library does not track
+ * (no rigid bodies, no async stepping) hold the reference's constructor values (src/particles.h:92-99).
+ * mpmhip_bgeo_size: bytes of the file for the current state.  mpmhip_bgeo_encode: the file image into caller memory
+ * (*written = bytes; MPMHIP_ECAPACITY if `capacity` is too small).  mpmhip_write_bgeo: the same to `path` (plain
+ * .bgeo as the reference writes; a ".gz" suffix is MPMHIP_ENOTIMPL).  A tiled ctx encodes its own rank's particles.
+ * All three synchronise. */
+int mpmhip_bgeo_size(mpmhip_ctx *ctx, int32_t verbose, size_t *bytes);
+int mpmhip_bgeo_encode(mpmhip_ctx *ctx, int32_t verbose, void *dst, size_t capacity, size_t *written);
+int mpmhip_write_bgeo(mpmhip_ctx *ctx, const char *path, int32_t verbose);
 
 /* profiling — replaces TC_PROFILE / TC_PROFILE_TPE scoped timers (src/mpm.cpp:464-572).
  * level 0: off.  level 1: hipEvents bracket each phase of every substep on the ctx stream (six records per

@@ -119,6 +119,7 @@ def group_params(type_name, mass, vol, **kw):
         p[4] = kw.get("yield_stress", 1.0)
     elif t == ELASTIC:  # :777-783
         p[2], p[3] = lame(kw.get("E", 5e3), kw.get("nu", 0.4))
+        p[4] = kw.get("E", 5e3)  # `E` member, read back only by get_debug_info() (:838-840)
     elif t == VISCO:  # :57-70
         p[2], p[3] = lame(kw.get("youngs_modulus", 4e4), kw.get("poisson_ratio", 0.4))
         p[4], p[5], p[6] = kw.get("nu", 10000.0), kw.get("kappa", 0.0), kw.get("base_delta_t", 1e-4)

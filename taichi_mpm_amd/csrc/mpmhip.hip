@@ -44,6 +44,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -62,6 +63,7 @@
 #include "k_tiling.h"
 #include "k_g2p.h"
 #include "k_debug.h"
+#include "k_bgeo.h"
 
 
 // ================================================================================================ host side
@@ -171,6 +173,91 @@ static int run_debug(mpmhip_ctx *c, K kernel, Args... args) {
   int rc = launch_check(c, "debug kernel");
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MPMHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- .bgeo frames
+// Houdini .bgeo v5 as Partio writes it (external/partio/src/io/BGEO.cpp:57-194) with write_partio's attribute table
+// (src/visualize.cpp:24-38).  Big-endian throughout.
+namespace {
+struct BgeoAttr { const char *name; uint16_t count; int32_t houdini_type; };  // 0 float, 1 int, 5 vector
+const BgeoAttr BGEO_PLAIN[] = {{"type", 1, 1}, {"index", 1, 1}, {"limit", 3, 1}, {"v", 3, 5}};
+const BgeoAttr BGEO_VERBOSE[] = {{"m", 1, 5}, {"boundary_normal", 3, 5}, {"debug", 3, 5}, {"states", 1, 1},
+                                 {"boundary_distance", 1, 0}, {"near_boundary", 1, 1}, {"apic_frobenius_norm", 1, 0}};
+void put32(std::vector<uint8_t> &o, uint32_t v) { for (int s = 24; s >= 0; s -= 8) o.push_back((uint8_t)(v >> s)); }
+void put16(std::vector<uint8_t> &o, uint16_t v) { o.push_back((uint8_t)(v >> 8)); o.push_back((uint8_t)v); }
+void put_str(std::vector<uint8_t> &o, const char *s) {
+  const size_t n = std::strlen(s);
+  put16(o, (uint16_t)n);
+  o.insert(o.end(), s, s + n);
+}
+std::vector<uint8_t> bgeo_header(uint32_t n, bool verbose) {
+  std::vector<uint8_t> o;
+  put32(o, 0x4267656fu);  // "Bgeo"
+  o.push_back('V');
+  put32(o, 5);
+  put32(o, n); put32(o, 1); put32(o, 0);  // points, one primitive, point groups
+  put32(o, 0); put32(o, verbose ? 11 : 4); put32(o, 0); put32(o, 1); put32(o, 0);  // prim groups, point / vertex / prim / detail attributes
+  auto table = [&](const BgeoAttr *a, int m) {
+    for (int i = 0; i < m; i++) {
+      put_str(o, a[i].name);
+      put16(o, a[i].count);
+      put32(o, (uint32_t)a[i].houdini_type);
+      for (int k = 0; k < a[i].count; k++) put32(o, 0);  // defaults
+    }
+  };
+  table(BGEO_PLAIN, 4);
+  if (verbose) table(BGEO_VERBOSE, 7);
+  return o;
+}
+std::vector<uint8_t> bgeo_prim_attr() {  // the "generator" = "papi" primitive attribute and the primitive's head
+  std::vector<uint8_t> o;
+  put_str(o, "generator");
+  put16(o, 1); put32(o, 4); put32(o, 1);
+  put_str(o, "papi");
+  put32(o, 0x8000);
+  return o;
+}
+size_t bgeo_bytes(uint32_t n, bool verbose) {
+  const size_t w = verbose ? BGEO_W_VERBOSE : BGEO_W_PLAIN;
+  return bgeo_header(n, verbose).size() + (size_t)n * w * 4 + bgeo_prim_attr().size() + 4 +
+         (size_t)n * (n > (1u << 16) ? 4 : 2) + 4 + 2;
+}
+}  // namespace
+
+// live particles in ascending creation id (write_partio sorts by id, src/visualize.cpp:39-43) -> slot list
+static int bgeo_order(mpmhip_ctx *c, std::vector<uint32_t> &order) {
+  order.clear();
+  const size_t ns = (size_t)c->n_slots;
+  if (!ns) return MPMHIP_OK;
+  int32_t *d_ids = nullptr;
+  HIPCHK(c, dmalloc(&d_ids, ns));
+  hipLaunchKernelGGL(k_bgeo_ids, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, (const RecG *)c->rg, d_ids);
+  std::vector<int32_t> ids(ns);
+  hipError_t e = hipMemcpyAsync(ids.data(), d_ids, ns * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_ids);
+  HIPCHK(c, e);
+  order.reserve(ns);
+  bool ascending = true;
+  int32_t last = -1, max_id = -1;
+  for (size_t s = 0; s < ns; s++) {
+    if (ids[s] < 0) continue;
+    order.push_back((uint32_t)s);
+    ascending = ascending && ids[s] > last;
+    last = ids[s];
+    max_id = std::max(max_id, ids[s]);
+  }
+  if (ascending) return MPMHIP_OK;  // slots are handed out in creation order: true until the first physical reorder
+  if ((size_t)max_id < 16 * order.size() + 1024) {  // ids are unique: a direct table, swept in id order
+    std::vector<uint32_t> slot_of(max_id + 1, 0xFFFFFFFFu);
+    for (uint32_t s : order) slot_of[ids[s]] = s;
+    size_t m = 0;
+    for (uint32_t s : slot_of)
+      if (s != 0xFFFFFFFFu) order[m++] = s;
+  } else {
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
+  }
   return MPMHIP_OK;
 }
 
@@ -936,6 +1023,89 @@ int mpmhip_snapshot_load(mpmhip_ctx *c, const void *src, size_t size) {
   memset(&hc, 0, sizeof hc);
   hc.n_dead = h.n_dead;
   HIPCHK(c, hipMemcpy(c->cnt, &hc, sizeof hc, hipMemcpyHostToDevice));
+  return MPMHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- .bgeo frames
+int mpmhip_bgeo_size(mpmhip_ctx *c, int32_t verbose, size_t *bytes) {
+  if (!c || !bytes) return MPMHIP_EINVAL;
+  const int64_t n = mpmhip_num_particles(c);
+  if (n < 0) return (int)n;
+  *bytes = bgeo_bytes((uint32_t)n, verbose != 0);
+  return MPMHIP_OK;
+}
+
+int mpmhip_bgeo_encode(mpmhip_ctx *c, int32_t verbose, void *dst, size_t capacity, size_t *written) {
+  if (!c || !dst || !written) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (verbose)
+    if (int rc = ensure_b_current(c)) return rc;
+  std::vector<uint32_t> order;
+  if (int rc = bgeo_order(c, order)) return rc;
+  const uint32_t n = (uint32_t)order.size();
+  const size_t total = bgeo_bytes(n, verbose != 0);
+  if (total > capacity)
+    return fail(c, MPMHIP_ECAPACITY, "bgeo image needs %zu bytes, the buffer holds %zu", total, capacity);
+  uint8_t *out = static_cast<uint8_t *>(dst);
+  const std::vector<uint8_t> head = bgeo_header(n, verbose != 0);
+  std::memcpy(out, head.data(), head.size());
+  out += head.size();
+  const size_t row_bytes = (size_t)n * (verbose ? BGEO_W_VERBOSE : BGEO_W_PLAIN) * 4;
+  if (n) {
+    uint32_t *d_order = nullptr, *d_rows = nullptr;
+    hipError_t e = dmalloc(&d_order, (size_t)n);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_rows, row_bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+      const dim3 grid(particle_grid(n)), wg(256);
+      if (verbose)
+        hipLaunchKernelGGL(k_bgeo_rows<true>, grid, wg, 0, c->stream, n, (const uint32_t *)d_order, (const RecG *)c->rg,
+                           (const RecP *)c->rp, (const float *)c->rb, (const GroupParams *)c->d_groups, d_rows);
+      else
+        hipLaunchKernelGGL(k_bgeo_rows<false>, grid, wg, 0, c->stream, n, (const uint32_t *)d_order, (const RecG *)c->rg,
+                           (const RecP *)c->rp, (const float *)c->rb, (const GroupParams *)c->d_groups, d_rows);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_rows, row_bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_order);
+    (void)hipFree(d_rows);
+    HIPCHK(c, e);
+  }
+  out += row_bytes;
+  const std::vector<uint8_t> prim = bgeo_prim_attr();
+  std::memcpy(out, prim.data(), prim.size());
+  out += prim.size();
+  auto w32 = [&](uint32_t v) { for (int s = 24; s >= 0; s -= 8) *out++ = (uint8_t)(v >> s); };
+  w32(n);
+  if (n > (1u << 16)) {  // BGEO.cpp:175-180: point numbers as int32 above 65536 points, uint16 otherwise
+    for (uint32_t i = 0; i < n; i++) w32(i);
+  } else {
+    for (uint32_t i = 0; i < n; i++) { *out++ = (uint8_t)(i >> 8); *out++ = (uint8_t)i; }
+  }
+  w32(0);
+  *out++ = 0x00;
+  *out++ = 0xff;
+  *written = (size_t)(out - static_cast<uint8_t *>(dst));
+  if (*written != total) return fail(c, MPMHIP_EINVAL, "internal: bgeo image is %zu bytes, expected %zu", *written, total);
+  return MPMHIP_OK;
+}
+
+int mpmhip_write_bgeo(mpmhip_ctx *c, const char *path, int32_t verbose) {
+  if (!c || !path) return MPMHIP_EINVAL;
+  const size_t len = std::strlen(path);
+  if (len >= 3 && std::strcmp(path + len - 3, ".gz") == 0)
+    return fail(c, MPMHIP_ENOTIMPL, "gzip-compressed .bgeo (the reference writes plain %%04d.bgeo, src/mpm.h:336)");
+  size_t bytes = 0, written = 0;
+  if (int rc = mpmhip_bgeo_size(c, verbose, &bytes)) return rc;
+  std::vector<uint8_t> img;
+  try { img.resize(bytes); } catch (const std::bad_alloc &) { return fail(c, MPMHIP_ENOMEM, "host allocation of %zu bytes failed", bytes); }
+  if (int rc = mpmhip_bgeo_encode(c, verbose, img.data(), img.size(), &written)) return rc;
+  FILE *f = std::fopen(path, "wb");
+  if (!f) return fail(c, MPMHIP_EINVAL, "cannot open '%s' for writing: %s", path, std::strerror(errno));
+  const size_t ok = std::fwrite(img.data(), 1, written, f);
+  const int cl = std::fclose(f);
+  if (ok != written || cl != 0) return fail(c, MPMHIP_EINVAL, "short write to '%s': %s", path, std::strerror(errno));
   return MPMHIP_OK;
 }
 

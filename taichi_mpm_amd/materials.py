@@ -45,6 +45,7 @@ def group_params(type_name, mass, vol, **kw):
         p[4] = kw.get("yield_stress", 1.0)
     elif type_name == "elastic":  # :777-783
         p[2], p[3] = _lame(kw.get("E", 5e3), kw.get("nu", 0.4))
+        p[4] = kw.get("E", 5e3)  # only reported back by get_debug_info() (verbose .bgeo), :838-840
     elif type_name == "visco":  # :57-70
         p[2], p[3] = _lame(kw.get("youngs_modulus", 4e4), kw.get("poisson_ratio", 0.4))
         # src/particles.cpp:57-70: the particle reads "base_delta_t" from ITS config (default 1e-4)

@@ -16,6 +16,7 @@ sampling, rigid bodies, rendering) is out of scope: `add_particles` takes explic
 """
 import ctypes as C
 import json
+import os
 
 import numpy as np
 
@@ -133,6 +134,9 @@ class Simulation3D:
         self.max_particles = int(cfg.get("max_particles", 0))
         self.max_blocks = int(cfg.get("max_blocks", 0))
         self.device = int(cfg.get("device", 0))
+        self.verbose_bgeo = bool(cfg.get("verbose_bgeo", False))  # src/visualize.cpp:22
+        self.frame_directory = cfg.get("frame_directory")  # injected by the python driver, async_mpm.py:49
+        self.frame_count = 0  # src/mpm.h:334
         self.config = cfg
         return self
 
@@ -461,8 +465,33 @@ class Simulation3D:
     def get_debug_information(self):  # src/mpm.cpp:635-639
         return ""
 
-    def visualize(self):  # src/visualize.cpp:156-164 — .bgeo output is out of scope
-        return None
+    def visualize(self):
+        """MPM<3>::visualize -> write_bgeo (src/visualize.cpp:156-159, src/mpm.h:333-337): the next
+        `frame_directory/%04d.bgeo`, frame numbers starting at 1."""
+        if not self.frame_directory:
+            raise MPMError("visualize() needs the config key 'frame_directory'")
+        self.frame_count += 1
+        os.makedirs(self.frame_directory, exist_ok=True)
+        path = os.path.join(self.frame_directory, "%04d.bgeo" % self.frame_count)
+        self.write_partio(path)
+        return path
+
+    def write_partio(self, file_name):
+        """MPM<dim>::write_partio (src/visualize.cpp:17-100): Houdini .bgeo v5 with the reference's attributes, rows
+        assembled on the device (include/mpmhip.h: mpmhip_write_bgeo)."""
+        self._ensure_ctx()
+        self._check(self._L.mpmhip_write_bgeo(self._ctx, os.fsencode(file_name), int(self.verbose_bgeo)))
+
+    def bgeo_bytes(self, verbose=None):
+        """the .bgeo image of the current state as bytes (no file)"""
+        self._ensure_ctx()
+        verbose = int(self.verbose_bgeo if verbose is None else verbose)
+        n = C.c_size_t()
+        self._check(self._L.mpmhip_bgeo_size(self._ctx, verbose, C.byref(n)))
+        buf = np.empty(n.value, np.uint8)
+        w = C.c_size_t()
+        self._check(self._L.mpmhip_bgeo_encode(self._ctx, verbose, buf.ctypes.data_as(C.c_void_p), n.value, C.byref(w)))
+        return buf[:w.value].tobytes()
 
     def get_mpi_world_rank(self):  # scripts/async/async_mpm.py:198-199
         return 0
@@ -533,6 +562,9 @@ class MPM:
     def general_action(self, **kwargs):
         return self.c.general_action(kwargs)
 
+    def visualize(self):  # scripts/async/async_mpm.py:201-202
+        return self.c.visualize()
+
     def simulate(self, num_frames=None, print_profile_info=False, frame_update=None, **_ignored):
         """python frame loop (scripts/async/async_mpm.py:217-248): per frame step(frame_dt) [+ profile print]."""
         if print_profile_info:
@@ -542,5 +574,7 @@ class MPM:
             if frame_update:
                 frame_update(self.get_current_time(), self.frame_dt)
             self.step(self.frame_dt)
+            if self.c.frame_directory:  # one .bgeo per frame, as async_mpm.py:243
+                self.visualize()
             if print_profile_info:
                 print(json.dumps(self.c.profile(reset=True)))

@@ -152,6 +152,30 @@ static void gpu_tests() {
     CHECK(a.size() == b.size() && dmax < 1e-6);
     std::remove(fn.c_str());
   }
+  {  // visualize() -> frame_directory/0001.bgeo, 0002.bgeo (src/mpm.h:333-337); header and size as Partio writes them
+    auto sim3 = create_simulation3("mpm");
+    sim3->initialize(Config().set("res", Vector3i(64, 64, 64)).set("frame_directory", "/tmp").set("verbose_bgeo", true));
+    sim3->add_particles(Config().set("type", "water").set("cube_lo", 30).set("cube_hi", 33));
+    sim3->step(-1.0f);
+    sim3->visualize();
+    const std::string fn = sim3->write_bgeo();
+    CHECK(fn == "/tmp/0002.bgeo" && sim3->frame_count == 2);
+    FILE *f = std::fopen(fn.c_str(), "rb");
+    CHECK(f != nullptr);
+    if (f) {
+      unsigned char h[17] = {0};
+      CHECK(std::fread(h, 1, 17, f) == 17);
+      CHECK(h[0] == 'B' && h[1] == 'g' && h[2] == 'e' && h[3] == 'o' && h[4] == 'V' && h[8] == 5);
+      const uint32_t n_points = (uint32_t)h[9] << 24 | (uint32_t)h[10] << 16 | (uint32_t)h[11] << 8 | h[12];
+      CHECK(n_points == 3 * 3 * 3 * 8);
+      std::fseek(f, 0, SEEK_END);
+      size_t want = 0;
+      CHECK(mpmhip_bgeo_size(sim3->ctx(), 1, &want) == 0 && (size_t)std::ftell(f) == want);
+      std::fclose(f);
+    }
+    std::remove("/tmp/0001.bgeo");
+    std::remove("/tmp/0002.bgeo");
+  }
   // device constitutive code through the particle surface: F = I => zero force; plasticity(cdg) = F <- cdg F for jelly
   MPMParticle p;
   p.type = create_particle_type("jelly", Config(), 1.0f, 1e-6f);
