@@ -7,7 +7,7 @@
 //   normalize_grid + boundary           src/mpm.cpp:277-372
 //   resample_optimized/block_op_normal  src/transfer.cpp:837-954
 // Block shape = SPGrid's 4x4x8 nodes (external/SPGrid/Core/SPGrid_Mask.h:29-35 with
-// sizeof(GridState<3>)=32 B), blocks ordered by a Morton (bit-interleaved) key, cells inside a
+// sizeof(GridState<3>)=32 B), blocks ordered by SPGrid's Morton (bit-interleaved, z-x-y) key, cells inside a
 // block lexicographic with z fastest — the order `Linear_Offset` produces (SPGrid_Mask.h:141-148).
 // Particles are AoS records reached through a sorted index array, physically reordered every
 // `reorder_interval`(=1000) substeps like sort_allocator (src/mpm.cpp:752-768,811-813).
@@ -45,7 +45,13 @@ inline uint32_t spread3(uint32_t v) {  // bit-interleave helper (pdep equivalent
   for (int b = 0; b < 10; b++) r |= ((v >> b) & 1u) << (3 * b);
   return r;
 }
-inline uint32_t morton_block(int bx, int by, int bz) { return (spread3(bx) << 2) | (spread3(by) << 1) | spread3(bz); }
+// block index = the page bits of SparseMask::Linear_Offset: per level z is the most significant bit, then x, then y
+// (page_zmask / page_xmask / page_ymask of SPGrid_Mask.h:29-35 for block_bits = 7).  PINNED against the reference's own
+// header through oracle/_ref/spgrid_keys (tests/golden/spgrid_keys.txt, tests/test_oracle_kernel.py).
+inline uint32_t morton_block(int bx, int by, int bz) { return (spread3(bz) << 2) | (spread3(bx) << 1) | spread3(by); }
+inline uint64_t spgrid_key(int i, int j, int k) {  // Linear_Offset(i, j, k) >> data_bits  (src/mpm.cpp:785-790)
+  return ((uint64_t)morton_block(i / BX, j / BY, k / BZ) << 7) | (uint64_t)(((i % BX) * BY + (j % BY)) * BZ + (k % BZ));
+}
 
 struct Opt {
   const orc_config *c;
@@ -58,6 +64,8 @@ struct Opt {
 };
 
 }  // namespace
+
+extern "C" uint64_t orc_spgrid_key(int i, int j, int k) { return spgrid_key(i, j, k); }
 
 extern "C" double orc_opt_run(const orc_config *c, int64_t n, float *x, float *v, float *B, float *F, float *aux,
                               const int32_t *gid, const float *gparams, const int32_t *gtype, int steps,
@@ -106,8 +114,7 @@ extern "C" double orc_opt_run(const orc_config *c, int64_t n, float *x, float *v
       const PRec &r = pool[particles[i]];
       int b[3];
       for (int k = 0; k < 3; k++) b[k] = stencil_start(r.pos[k] * idx);
-      uint64_t key = ((uint64_t)morton_block(b[0] / BX, b[1] / BY, b[2] / BZ) << 7) |
-                     (uint64_t)(((b[0] % BX) * BY + (b[1] % BY)) * BZ + (b[2] % BZ));
+      uint64_t key = spgrid_key(b[0], b[1], b[2]);
       sorter[i] = (key << index_bits) + (uint64_t)i;
     }
 #ifdef _OPENMP

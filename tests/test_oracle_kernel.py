@@ -72,3 +72,18 @@ def test_inv_D_and_stencil_start():
     assert 6.0 - 2 == 4.0
     for x in (0.5, 0.99, 1.49, 1.5, 7.3, 100.51):
         assert int(np.float32(x) - np.float32(0.5)) == int(np.floor(np.float32(x) - np.float32(0.5)))
+
+
+def test_block_sort_key_equals_the_reference_spgrid_offset(orc):
+    """the key the CPU baseline sorts by == SparseMask::Linear_Offset >> data_bits of the reference's own SPGrid header
+    (tests/golden/spgrid_keys.txt, produced by oracle/_ref/spgrid_keys; src/mpm.cpp:785-790)"""
+    import ctypes as C
+    import os
+    L = orc.lib()
+    L.orc_spgrid_key.restype = C.c_uint64
+    L.orc_spgrid_key.argtypes = [C.c_int] * 3
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spgrid_keys.txt")
+    rows = [tuple(int(t) for t in ln.split()) for ln in open(path)]
+    assert len(rows) > 500
+    for i, j, k, key in rows:
+        assert L.orc_spgrid_key(i, j, k) == key, (i, j, k)
