@@ -212,6 +212,11 @@ class MPM<3> {
       }
       return "";
     }
+    if (action == "delete_particles_inside_level_set") {  // :962-974
+      int64_t deleted = 0;
+      check(mpmhip_delete_particles_inside_level_set(ctx_, &deleted), ctx_);
+      return "";
+    }
     throw std::runtime_error("general_action(action='" + action + "') is outside the scope of this build");
   }
 

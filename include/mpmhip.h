@@ -176,6 +176,11 @@ int mpmhip_snapshot_load(mpmhip_ctx *ctx, const void *src, size_t size);
  * valid *kinetic) if a live particle is of another type, as the reference aborts there.  Synchronises. */
 int mpmhip_calculate_energy(mpmhip_ctx *ctx, double *kinetic, double *potential);
 
+/* replaces general_action "delete_particles_inside_level_set" (src/mpm.cpp:962-974): deletes every particle whose
+ * level-set value at its position is negative (the level set last given to mpmhip_set_levelset[_shapes]);
+ * *deleted = how many.  The next sort rebuilds the keys.  Synchronises. */
+int mpmhip_delete_particles_inside_level_set(mpmhip_ctx *ctx, int64_t *deleted);
+
 /* frame output — replaces MPM<dim>::write_bgeo / write_partio (src/mpm.h:333-337, src/visualize.cpp:17-100; called
  * by visualize(), src/visualize.cpp:156-164) including the Partio encoder behind it (external/partio/src/io/BGEO.cpp:
  * 57-194, Houdini .bgeo version 5, big-endian).  Byte-identical to the reference's file for the same particle state:

@@ -303,6 +303,20 @@ void orc_particle_collision(const orc_config *c, int64_t n, float *x, float *v) 
   }
 }
 
+// general_action "delete_particles_inside_level_set" — src/mpm.cpp:962-974: a particle whose level-set sample at its
+// position is negative is dropped.  keep[p] = 0 for those; returns the number deleted.
+int64_t orc_delete_inside_levelset(const orc_config *c, int64_t n, const float *x, uint8_t *keep) {
+  const real idx = 1.0f / c->dx;
+  int64_t deleted = 0;
+  for (int64_t p = 0; p < n; p++) {
+    real pos[3] = {x[3 * p] * idx, x[3 * p + 1] * idx, x[3 * p + 2] * idx}, phi, g[3] = {0, 0, 0};
+    const bool inside = levelset_eval(c, pos, phi, g) && phi < 0;
+    keep[p] = inside ? 0 : 1;
+    deleted += inside;
+  }
+  return deleted;
+}
+
 int64_t orc_clear_boundary(const orc_config *c, int64_t n, const float *x, const float *v, uint8_t *keep) {
   int64_t cnt = 0;
   for (int64_t p = 0; p < n; p++) {

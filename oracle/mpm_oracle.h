@@ -115,6 +115,8 @@ void orc_g2p(const orc_config* c, int64_t n, float* x, float* v, float* B, float
 /* clear_boundary_particles: src/mpm.cpp:582-633, src/mpm.h:269-276. keep[i]=1 if the particle survives.
  * (also drops particles whose stencil would leave the grid — the reference has UB there) */
 int64_t orc_clear_boundary(const orc_config* c, int64_t n, const float* x, const float* v, uint8_t* keep);
+/* general_action "delete_particles_inside_level_set" (src/mpm.cpp:962-974): keep[p] = 0 where phi(x_p) < 0 */
+int64_t orc_delete_inside_levelset(const orc_config* c, int64_t n, const float* x, uint8_t* keep);
 /* particle_collision_resolution: src/mpm.cpp:414-426 */
 void orc_particle_collision(const orc_config* c, int64_t n, float* x, float* v);
 /* one full substep on SoA arrays; particles are compacted in place (stable); returns new n.

@@ -252,6 +252,11 @@ class State:
     def copy(self):
         return State(self.x, self.v, self.B, self.F, self.aux, self.gid, self.gparams, self.gtype, self.ids)
 
+    def select(self, mask):
+        """the particles where mask is True, as a new State (same group table)"""
+        m = np.asarray(mask, bool)
+        return State(self.x[m], self.v[m], self.B[m], self.F[m], self.aux[m], self.gid[m], self.gparams, self.gtype, self.ids[m])
+
     def truncate(self, n):
         for k in ("x", "v", "B", "F", "aux", "gid", "ids"):
             setattr(self, k, getattr(self, k)[:n].copy())
@@ -289,6 +294,14 @@ def g2p(cfg, s, grid):
 
 def particle_collision(cfg, s):
     lib().orc_particle_collision(C.byref(cfg), C.c_int64(s.n), _pf(s.x), _pf(s.v))
+
+
+def delete_inside_levelset(cfg, s):
+    """-> keep mask (bool) of general_action 'delete_particles_inside_level_set' (src/mpm.cpp:962-974)"""
+    keep = np.zeros(s.n, np.uint8)
+    lib().orc_delete_inside_levelset.restype = C.c_int64
+    lib().orc_delete_inside_levelset(C.byref(cfg), C.c_int64(s.n), _pf(s.x), keep.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return keep.astype(bool)
 
 
 def clear_boundary(cfg, s):

@@ -46,6 +46,21 @@ __global__ __launch_bounds__(256) void k_recover_b(Params P, const RecG *__restr
   }
 }
 
+// general_action "delete_particles_inside_level_set" (src/mpm.cpp:962-974): every live particle whose level-set
+// value at its position is negative is deleted for good (pid = -1, like clear_boundary_particles does in k_g2p)
+__global__ __launch_bounds__(256) void k_delete_inside_levelset(Params P, RecG *__restrict__ rg, LevelSetDev LS,
+                                                                Counters *cnt) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_slots; i += gridDim.x * blockDim.x) {
+    if (rg[i].pid < 0) continue;
+    const float xw[3] = {rg[i].x[0], rg[i].x[1], rg[i].x[2]};
+    float phi, nrm[3];
+    if (levelset_eval(LS, xw, P.idx, phi, nrm) && phi < 0.0f) {
+      rg[i].pid = -1;
+      atomicAdd(&cnt->n_dead, 1u);
+    }
+  }
+}
+
 // sum of MPMParticle::potential_energy() (src/particles.cpp:323-327 linear, :400-407 jelly, :785-796 elastic;
 // the other types do not define it in the reference: TC_NOT_IMPLEMENTED) -> out[0]; out[1] counts particles of
 // types without a potential energy

@@ -1026,6 +1026,23 @@ int mpmhip_snapshot_load(mpmhip_ctx *c, const void *src, size_t size) {
   return MPMHIP_OK;
 }
 
+int mpmhip_delete_particles_inside_level_set(mpmhip_ctx *c, int64_t *deleted) {
+  if (!c || !deleted) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  *deleted = 0;
+  if (c->LS.n <= 0 || c->n_slots == 0) return MPMHIP_OK;
+  if (int rc = ensure_b_current(c)) return rc;  // the recovery reads every live record: do it before some die
+  Counters before, after;
+  if (int rc = read_counters(c, before)) return rc;
+  hipLaunchKernelGGL(k_delete_inside_levelset, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, (RecG *)c->rg,
+                     c->LS, c->cnt);
+  if (int rc = launch_check(c, "delete_inside_levelset")) return rc;
+  if (int rc = read_counters(c, after)) return rc;
+  *deleted = (int64_t)after.n_dead - (int64_t)before.n_dead;
+  if (*deleted) c->sorted = c->keys_valid = false;  // key[] still lists the deleted ones: rebuild
+  return MPMHIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- .bgeo frames
 int mpmhip_bgeo_size(mpmhip_ctx *c, int32_t verbose, size_t *bytes) {
   if (!c || !bytes) return MPMHIP_EINVAL;

@@ -415,6 +415,11 @@ class Simulation3D:
         if action == "load":  # src/mpm.cpp:950-960
             self.load_snapshot(config["file_name"])
             return ""
+        if action == "delete_particles_inside_level_set":  # src/mpm.cpp:962-974
+            self._ensure_ctx()
+            n = C.c_int64()
+            self._check(self._L.mpmhip_delete_particles_inside_level_set(self._ctx, C.byref(n)))
+            return ""
         if action == "export":  # particle fields as .npz (not a reference action; handy for post-processing)
             p = self.get_particles()
             np.savez(config["file_name"], t=self.get_current_time(), frame=self.frame, **p)

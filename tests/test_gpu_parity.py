@@ -511,6 +511,43 @@ def test_levelset_shapes_and_particle_collision_match_oracle(tm, orc, scene, col
     sim.close()
 
 
+@pytest.mark.parametrize("scene", sorted(SHAPE_SCENES))
+def test_delete_particles_inside_level_set_matches_oracle(tm, orc, scene):
+    """general_action 'delete_particles_inside_level_set' (src/mpm.cpp:962-974): exactly the particles with phi < 0 go,
+    before the first substep and again in the middle of a run (keys are rebuilt), and the run continues like the
+    oracle's on the survivors"""
+    sc = SHAPE_SCENES[scene]
+    x = lattice_cube(RES, 9, 17, DX, jitter=0.2, seed=71)
+    s = make_state(x, "jelly", DX, perturb_F=0.02, seed=72, vel_scale=2.0)
+    sim = make_sim(tm, s, planes=None)
+    ls = _levelset(tm, sc.get("planes", ()), sc["shapes"], sc["friction"])
+    sim.set_levelset(ls)
+    cfg = orc.make_config(RES, DX, DT, planes=ls.planes, friction=sc["friction"], shapes=ls.non_planes)
+    ref = s.copy()
+    total = 0
+    for rounds in range(2):
+        keep = orc.delete_inside_levelset(cfg, ref)
+        n_before = sim.get_num_particles()
+        assert sim.general_action(dict(action="delete_particles_inside_level_set")) == ""
+        assert n_before - sim.get_num_particles() == int((~keep).sum())
+        total += int((~keep).sum())
+        ref = ref.select(keep)
+        for _ in range(3):
+            sim.substep()
+            orc.substep(cfg, ref)
+        if rounds == 0:  # push everything 1.5 cells towards the solid so that the second call has work to do
+            shift = np.array([0.0, -1.5 * DX, 0.0], np.float32) if scene != "container" else np.array([1.5 * DX, 0, 0], np.float32)
+            got = sim.get_particles(sort_by_id=False)
+            sim.upload(tm.mpm.F_X, got["x"] + shift)
+            order = np.argsort(got["id"])
+            assert np.array_equal(got["id"][order], ref.ids)
+            ref.x = (got["x"] + shift).astype(np.float32)[order]  # bit-identical positions for the second decision
+    got = sim.get_particles()
+    assert total > 0 and len(got["x"]) == ref.n and np.array_equal(got["id"], ref.ids)
+    assert np.abs(got["x"] - ref.x).max() <= 1e-6 and rel_l2(got["v"], ref.v) <= 1e-4
+    sim.close()
+
+
 # ------------------------------------------------------------------------------------------ calculate_energy
 def test_calculate_energy_matches_numpy(tm, orc):
     """MPM<dim>::calculate_energy (src/mpm.cpp:1078-1110): grid kinetic energy after P2G + particle potential energy
