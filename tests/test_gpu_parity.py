@@ -223,6 +223,43 @@ def test_full_substep_matches_oracle(tm, orc, mat):
     sim.close()
 
 
+CONFIG_VARIANTS = {
+    "apic_damping": dict(apic_damping=0.3),  # scene scripts set one of them, e.g. scripts/mls-cpic/goo_blocks.py:14
+    "rpic_damping": dict(rpic_damping=0.2),
+    "both_dampings": dict(apic_damping=0.3, rpic_damping=0.1),
+    "grid_gravity": dict(particle_gravity=False),  # gravity applied at the grid nodes (src/mpm.cpp:281-293,526-530)
+    "skew_gravity+no_clean": dict(gravity=(1.5, -9.0, 0.5), clean_boundary=False),
+}
+
+
+@pytest.mark.parametrize("keep", [True, False], ids=["keep_b", "fold_b"])
+@pytest.mark.parametrize("variant", sorted(CONFIG_VARIANTS))
+def test_config_variants_match_oracle_over_three_substeps(tm, orc, variant, keep):
+    """the config keys of MPM::initialize (src/mpm.cpp:26-75) that change the substep's arithmetic: APIC / RPIC damping
+    (the intended damp_affine_momemtum, src/mpm.h:465-469 — SURVEY quirk 3), grid-side gravity, a general gravity
+    vector; damping acts on apic_b, so both storage modes of apic_b are covered"""
+    kw = CONFIG_VARIANTS[variant]
+    x = lattice_cube(RES, 9, 17, DX, jitter=0.2, seed=81)
+    s = make_state(x, "jelly", DX, perturb_F=0.02, seed=82, vel_scale=2.0)
+    sim = make_sim(tm, s, keep_apic_b=keep, **kw)
+    cfg = ocfg(orc, **kw)
+    ref = s.copy()
+    for _ in range(3):
+        sim.substep()
+        orc.substep(cfg, ref)
+    got = sim.get_particles()
+    assert len(got["x"]) == ref.n and np.array_equal(got["id"], ref.ids)
+    assert np.abs(got["x"] - ref.x).max() <= 5e-7
+    assert rel_l2(got["v"], ref.v) <= 5e-5 and rel_l2(got["F"], ref.F) <= 5e-5
+    assert rel_l2(got["B"], ref.B) <= (5e-5 if keep else 2e-3)
+    if "damping" in variant:  # the damping did something: an undamped run differs
+        plain = s.copy()
+        for _ in range(3):
+            orc.substep(ocfg(orc), plain)
+        assert rel_l2(plain.B, ref.B) > 1e-2
+    sim.close()
+
+
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "substep_*.npz")))
 
 
