@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
       const int src = 16 * k + (lane >> 2), q = lane & 3;
       const uint32_t sl = xs[src];
       const float4 val = xp[src * 5 + q];
-      if (sl != INVALID) rg[(size_t)sl * 4 + q] = val;
+      if (sl != INVALID) st_rec(rg + (size_t)sl * 4 + q, val);
     }
     __builtin_amdgcn_wave_barrier();
     xp[lane * 5 + 0] = Q0; xp[lane * 5 + 1] = Q1; xp[lane * 5 + 2] = Q2; xp[lane * 5 + 3] = Q3;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
       const int src = 16 * k + (lane >> 2), q = lane & 3;
       const uint32_t sl = xs[src];
       const float4 val = xp[src * 5 + q];
-      if (sl != INVALID) rp[(size_t)sl * 4 + q] = val;
+      if (sl != INVALID) st_rec(rp + (size_t)sl * 4 + q, val);
     }
     if constexpr (STORE_B) {  // (compile-time: in the default folded mode the apic_b registers do not exist)
       __builtin_amdgcn_wave_barrier();
