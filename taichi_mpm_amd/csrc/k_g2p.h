@@ -68,6 +68,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
   auto lane_slot = [&](const Chunk &c) -> uint32_t {
     return (c.a < na && c.p + tid < c.p1) ? perm[c.p + tid] : INVALID;
   };
+  const bool nt_store = P.n_slots >= NT_STORE_MIN_SLOTS;  // see st_rec
   Chunk cur = first(blockIdx.x);
   Chunk nx = next(cur);
   uint32_t i_cur = lane_slot(cur);
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
       const int src = 16 * k + (lane >> 2), q = lane & 3;
       const uint32_t sl = xs[src];
       const float4 val = xp[src * 5 + q];
-      if (sl != INVALID) st_rec(rg + (size_t)sl * 4 + q, val);
+      if (sl != INVALID) st_rec(rg + (size_t)sl * 4 + q, val, nt_store);
     }
     __builtin_amdgcn_wave_barrier();
     xp[lane * 5 + 0] = Q0; xp[lane * 5 + 1] = Q1; xp[lane * 5 + 2] = Q2; xp[lane * 5 + 3] = Q3;
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
       const int src = 16 * k + (lane >> 2), q = lane & 3;
       const uint32_t sl = xs[src];
       const float4 val = xp[src * 5 + q];
-      if (sl != INVALID) st_rec(rp + (size_t)sl * 4 + q, val);
+      if (sl != INVALID) st_rec(rp + (size_t)sl * 4 + q, val, nt_store);
     }
     if constexpr (STORE_B) {  // (compile-time: in the default folded mode the apic_b registers do not exist)
       __builtin_amdgcn_wave_barrier();

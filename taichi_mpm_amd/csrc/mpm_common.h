@@ -9,16 +9,22 @@
 
 namespace mpm {
 
-// The 64-byte particle records G2P writes are not touched again before the next substep's P2G / G2P and are far
-// larger than the caches: stored with the non-temporal hint they stop evicting the tiles and index arrays the
-// following kernels read (C3: 0.682 -> 0.669 ms per substep, most of it in k_p2g).  The same hint on the record
-// LOADS is harmful (k_p2g 0.18 -> 0.32 ms): a lane fetches its record with four 16-byte loads, and the line has to
-// survive between them.
+// The 64-byte particle records G2P writes are not touched again before the next substep's P2G / G2P.  When they
+// are far larger than the caches (128 B per particle against the 256 MB of infinity cache), storing them with the
+// non-temporal hint stops them evicting the tiles and index arrays the following kernels read (C3, 8 M particles:
+// 0.682 -> 0.669 ms per substep, most of it in k_p2g); when they fit (C2, 1 M particles: the next P2G finds them
+// in cache) the hint costs 5 %, hence the size switch.  The same hint on the record LOADS is harmful at any size
+// (k_p2g 0.18 -> 0.32 ms): a lane fetches its record with four 16-byte loads, and the line has to survive between them.
+constexpr uint32_t NT_STORE_MIN_SLOTS = 2u << 20;
 typedef float nt_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st_rec(float4 *p, const float4 &v) {
-  nt_f4 t;
-  t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-  __builtin_nontemporal_store(t, reinterpret_cast<nt_f4 *>(p));
+__device__ __forceinline__ void st_rec(float4 *p, const float4 &v, bool nt) {
+  if (nt) {  // wave-uniform
+    nt_f4 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<nt_f4 *>(p));
+  } else {
+    *p = v;
+  }
 }
 
 
