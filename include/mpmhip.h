@@ -254,9 +254,12 @@ int mpmhip_substep_interior(mpmhip_ctx *ctx);
 /* counts[world]: live particles whose base cell now lies in another rank's brick.  Also raises MPMHIP_ECAPACITY
  * (sticky) if a particle is more than `margin` cells outside this rank's brick. */
 int mpmhip_leaver_counts(mpmhip_ctx *ctx, int32_t world, int64_t *counts);
-/* the same pass also yields the bounding box [lo, hi) of the base cells of all live particles (lo > hi: none), so
- * one synchronisation per migration serves both the counts and the halo-box clipping */
-int mpmhip_migration_scan(mpmhip_ctx *ctx, int32_t world, int64_t *counts, int32_t lo[3], int32_t hi[3]);
+/* the same pass also yields the bounding box [lo, hi) of the base cells of all live particles (lo > hi: none) and
+ * the speed of the fastest one in cells per substep (max |v|_inf dt / dx; may be NULL), so one synchronisation per
+ * migration serves the counts, the halo-box clipping and the schedule of the next migration (a particle needs
+ * margin / speed substeps to cross the margin) */
+int mpmhip_migration_scan(mpmhip_ctx *ctx, int32_t world, int64_t *counts, int32_t lo[3], int32_t hi[3],
+                          float *max_cells_per_substep);
 /* packs every leaver (n_total = sum of the counts just returned) into dev_records, grouped by destination */
 int mpmhip_export_leavers(mpmhip_ctx *ctx, int32_t world, const int64_t *counts, void *dev_records);
 int mpmhip_import_particles(mpmhip_ctx *ctx, int64_t n, const void *dev_records);

@@ -125,7 +125,7 @@ def load():
     L.mpmhip_set_partition.argtypes = [vp, C.c_int32, ip, ip, ip, ip, C.c_int32]
     L.mpmhip_set_halo.argtypes = [vp, C.c_int32, P(HaloBox)]
     L.mpmhip_leaver_counts.argtypes = [vp, C.c_int32, P(C.c_int64)]
-    L.mpmhip_migration_scan.argtypes = [vp, C.c_int32, P(C.c_int64), ip, ip]
+    L.mpmhip_migration_scan.argtypes = [vp, C.c_int32, P(C.c_int64), ip, ip, P(C.c_float)]
     L.mpmhip_export_leavers.argtypes = [vp, C.c_int32, P(C.c_int64), vp]
     L.mpmhip_import_particles.argtypes = [vp, C.c_int64, vp]
     L.mpmhip_active_bounds.argtypes = [vp, ip, ip]

@@ -85,13 +85,16 @@ __global__ void k_scan_init(uint32_t *__restrict__ counts, int world) {
   if (t < world) counts[t] = 0;
   else if (t < world + 3) counts[t] = (uint32_t)(1 << 30);
   else if (t < world + 6) counts[t] = (uint32_t)-1;
+  else if (t < world + 7) counts[t] = 0;  // max speed (bits of a non-negative float)
 }
 // counts[d] = live particles whose base cell belongs to rank d != this rank; bounds[0..2] / [3..5] = min / max+1 of
-// the base cells of all live particles (one pass, one wave-reduced atomic set per wave)
+// the base cells of all live particles; bounds[6] = bits of the largest |v|_inf dt / dx (cells per substep) among them
+// (one pass, one wave-reduced atomic set per wave)
 __global__ __launch_bounds__(256) void k_leaver_count(Params P, Tiling T, const float4 *__restrict__ rg,
-                                                      uint32_t *__restrict__ counts, int *__restrict__ bounds,
-                                                      Counters *cnt) {
+                                                      const float4 *__restrict__ rp, uint32_t *__restrict__ counts,
+                                                      int *__restrict__ bounds, Counters *cnt) {
   int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
+  float speed = 0.0f;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_slots; i += gridDim.x * blockDim.x) {
     if (__float_as_int(rg[(size_t)i * 4 + 3].z) < 0) continue;
     const float4 g0 = rg[(size_t)i * 4];
@@ -103,9 +106,15 @@ __global__ __launch_bounds__(256) void k_leaver_count(Params P, Tiling T, const 
     const int b[3] = {(int)(g0.x * P.idx - 0.5f), (int)(g0.y * P.idx - 0.5f), (int)(g0.z * P.idx - 0.5f)};
 #pragma unroll
     for (int k = 0; k < 3; k++) { lo[k] = min(lo[k], b[k]); hi[k] = max(hi[k], b[k] + 1); }
+    const float4 p0 = rp[(size_t)i * 4], p1 = rp[(size_t)i * 4 + 1];  // v = (p0.w, p1.x, p1.y)
+    speed = fmaxf(speed, fmaxf(fabsf(p0.w), fmaxf(fabsf(p1.x), fabsf(p1.y))));
   }
   // wave reduce -> workgroup reduce -> 6 atomics per WORKGROUP (same-address atomics serialise at ~13 ns each)
   __shared__ int red[4][6];
+  __shared__ float sred[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) speed = fmaxf(speed, __shfl_xor(speed, off));
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = speed;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
 #pragma unroll
@@ -121,6 +130,10 @@ __global__ __launch_bounds__(256) void k_leaver_count(Params P, Tiling T, const 
     const int l = min(min(red[0][k], red[1][k]), min(red[2][k], red[3][k]));
     const int h = max(max(red[0][3 + k], red[1][3 + k]), max(red[2][3 + k], red[3][3 + k]));
     if (h >= 0) { atomicMin(&bounds[k], l); atomicMax(&bounds[3 + k], h); }
+  }
+  if (threadIdx.x == 3) {
+    const float s = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3])) * P.dt * P.idx;
+    if (s > 0.0f) atomicMax(reinterpret_cast<uint32_t *>(&bounds[6]), __float_as_uint(s));  // NaN speeds are deleted by G2P
   }
 }
 

@@ -1275,28 +1275,30 @@ static int ensure_counts(mpmhip_ctx *c, int world) {
   if (c->counts_cap < world) {
     hipFree(c->d_counts);
     c->d_counts = nullptr;
-    HIPCHK(c, dmalloc(&c->d_counts, (size_t)world + 6));  // + the 6 bounds of mpmhip_migration_scan
+    HIPCHK(c, dmalloc(&c->d_counts, (size_t)world + 7));  // + the 6 bounds and the speed of mpmhip_migration_scan
     c->counts_cap = world;
   }
   return MPMHIP_OK;
 }
 
 // one pass over the particles, one synchronisation: leaver counts per destination + bounding box of the base cells
-int mpmhip_migration_scan(mpmhip_ctx *c, int32_t world, int64_t *counts, int32_t lo[3], int32_t hi[3]) {
+// + the fastest particle (cells per substep)
+int mpmhip_migration_scan(mpmhip_ctx *c, int32_t world, int64_t *counts, int32_t lo[3], int32_t hi[3],
+                          float *max_cells_per_substep) {
   if (!c || !counts) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   int rc = ensure_counts(c, world);
   if (rc) return rc;
   if (c->in_substep) return fail(c, MPMHIP_EINVAL, "migration inside a substep");
-  if ((size_t)world + 6 + sizeof(Counters) / 4 > 65536 / 4) return fail(c, MPMHIP_EINVAL, "world too large");
-  hipLaunchKernelGGL(k_scan_init, dim3((world + 6 + 255) / 256), dim3(256), 0, c->stream, c->d_counts, world);
+  if ((size_t)world + 7 + sizeof(Counters) / 4 > 65536 / 4) return fail(c, MPMHIP_EINVAL, "world too large");
+  hipLaunchKernelGGL(k_scan_init, dim3((world + 7 + 255) / 256), dim3(256), 0, c->stream, c->d_counts, world);
   int grid = particle_grid(c->n_slots);
   if (grid > 128) grid = 128;  // few workgroups: 6 same-address atomics each for the bounds
-  hipLaunchKernelGGL(k_leaver_count, dim3(grid), dim3(256), 0, c->stream, c->P, c->T, (const float4 *)c->rg, c->d_counts,
-                     reinterpret_cast<int *>(c->d_counts + world), c->cnt);
+  hipLaunchKernelGGL(k_leaver_count, dim3(grid), dim3(256), 0, c->stream, c->P, c->T, (const float4 *)c->rg,
+                     (const float4 *)c->rp, c->d_counts, reinterpret_cast<int *>(c->d_counts + world), c->cnt);
   if ((rc = launch_check(c, "leaver_count"))) return rc;
   uint32_t *h = c->h_pinned + sizeof(Counters) / 4;  // behind the counters read_counters() fetches
-  HIPCHK(c, hipMemcpyAsync(h, c->d_counts, sizeof(uint32_t) * ((size_t)world + 6), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h, c->d_counts, sizeof(uint32_t) * ((size_t)world + 7), hipMemcpyDeviceToHost, c->stream));
   Counters hc;
   if ((rc = read_counters(c, hc))) return rc;  // the ONE synchronisation; reports the margin violation
   for (int i = 0; i < world; i++) counts[i] = h[i];
@@ -1304,11 +1306,12 @@ int mpmhip_migration_scan(mpmhip_ctx *c, int32_t world, int64_t *counts, int32_t
     if (lo) lo[k] = (int32_t)h[world + k];
     if (hi) hi[k] = (int32_t)h[world + 3 + k];
   }
+  if (max_cells_per_substep) std::memcpy(max_cells_per_substep, &h[world + 6], sizeof(float));
   return MPMHIP_OK;
 }
 
 int mpmhip_leaver_counts(mpmhip_ctx *c, int32_t world, int64_t *counts) {
-  return mpmhip_migration_scan(c, world, counts, nullptr, nullptr);
+  return mpmhip_migration_scan(c, world, counts, nullptr, nullptr, nullptr);
 }
 
 int mpmhip_export_leavers(mpmhip_ctx *c, int32_t world, const int64_t *counts, void *dev_records) {

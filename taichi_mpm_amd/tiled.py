@@ -11,6 +11,7 @@ The module is engine-agnostic: `HipEngine` drives a libmpmhip ctx; the CPU tests
 (tests/fake_engine.py) to run the exchange/migration logic under gloo with world_size 2.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -209,12 +210,13 @@ class HipEngine:
         self.sim._check(self.L.mpmhip_set_overlap(self.ctx, int(bool(on))))
 
     def migration_scan(self):
-        """(leavers per destination rank, base-cell bounds lo, hi) — one pass, one synchronisation"""
+        """(leavers per destination rank, base-cell bounds lo, hi, fastest particle in cells per substep) — one pass,
+        one synchronisation"""
         out, lo, hi = np.zeros(self.world, np.int64), np.zeros(3, np.int32), np.zeros(3, np.int32)
-        ip = C.POINTER(C.c_int32)
+        ip, speed = C.POINTER(C.c_int32), C.c_float()
         self.sim._check(self.L.mpmhip_migration_scan(self.ctx, self.world, out.ctypes.data_as(C.POINTER(C.c_int64)),
-                                                     lo.ctypes.data_as(ip), hi.ctypes.data_as(ip)))
-        return out, lo, hi
+                                                     lo.ctypes.data_as(ip), hi.ctypes.data_as(ip), C.byref(speed)))
+        return out, lo, hi, float(speed.value)
 
     def export_leavers(self, counts, buf):
         counts = np.ascontiguousarray(counts, np.int64)
@@ -306,19 +308,35 @@ class TiledRank:
         self.e, self.part, self.rank = engine, part, rank
         self.plan = HaloPlan(part, rank, engine.alloc)
         engine.configure(part, rank, self.plan)
-        # CFL: a particle moves < 1 cell per substep, so it stays inside the margin for `margin` substeps
+        # CFL: a particle moves < 1 cell per substep, so it stays inside the margin for `margin` substeps.  That is
+        # the worst case; the scan also measures the fastest particle, and when it is slow the next migration is
+        # scheduled later (see schedule()).  An explicit migrate_interval fixes the schedule (tests).
         self.migrate_interval = int(migrate_interval or part.margin)
         assert 1 <= self.migrate_interval <= part.margin
+        self.adaptive_cap = 0 if migrate_interval else int(os.environ.get("MPMHIP_TILE_MIGRATE_CAP", 64))
         self.k = 0
+        self.next_migration = self.migrate_interval
         self.migrated_out = 0
+
+    def schedule(self, speed):
+        """next migration, from the globally fastest particle (cells per substep, identical on every rank): after a
+        migration every particle is inside its brick and needs margin / speed substeps to cross the margin; half of
+        that leaves room for the speed to double in between (gravity adds g dt^2 / dx ~ 1e-5 cells per substep^2),
+        never sooner than the CFL schedule and never later than the cap"""
+        n = self.migrate_interval
+        if self.adaptive_cap > n and np.isfinite(speed):
+            n = max(n, min(self.adaptive_cap, int(0.5 * self.part.margin / max(speed, 1e-9))))
+        self.next_migration = self.k + n
 
     # --- migration phases
     def mig_scan(self):
-        """this rank's row of the migration table: [leavers per destination | -lo | hi] of its particles"""
-        self._counts, lo, hi = self.e.migration_scan()
+        """this rank's row of the migration table: [leavers per destination | -lo | hi | speed] of its particles
+        (speed = fastest particle in 2^-20 cells per substep, rounded up)"""
+        self._counts, lo, hi, speed = self.e.migration_scan()
         if not (lo <= hi).all():  # no particles here
             lo, hi = np.full(3, 1 << 30), np.full(3, -(1 << 30))
-        return np.concatenate([self._counts, -lo.astype(np.int64), hi.astype(np.int64)])
+        q = int(np.ceil(min(max(speed, 0.0), 1e6) * (1 << 20))) if np.isfinite(speed) else (1 << 40)
+        return np.concatenate([self._counts, -lo.astype(np.int64), hi.astype(np.int64), [q]])
 
     def mig_export(self, incoming):
         self._incoming = np.asarray(incoming, np.int64)
@@ -342,7 +360,7 @@ class TiledRank:
 
 def _finish_migration(table, world, ranks, exchange):
     """second half of a migration, identical on every rank because it only looks at the all-gathered table
-    [counts r -> s | -lo | hi]: move the records (skipped when nobody moves), keep the halo boxes wrapped around
+    [counts r -> s | -lo | hi | speed]: move the records (skipped when nobody moves), keep the halo boxes wrapped around
     the particles.  `ranks` are the TiledRank objects of this process (one, or all of them for a virtual job)."""
     counts = table[:, :world]  # counts[r][s]: r -> s
     if counts.sum() > 0:
@@ -358,6 +376,9 @@ def _finish_migration(table, world, ranks, exchange):
             if r.part is not part:
                 r.part.set_clip_from_bounds(lo, hi)
             r.replan()
+    speed = float(table[:, world + 6].max()) / (1 << 20)
+    for r in ranks:
+        r.schedule(speed)
 
 
 class TiledJob:
@@ -394,7 +415,7 @@ class TiledJob:
             self._unsplit_after = False
             self.e.set_overlap(False)
         r.k += 1
-        if r.k % r.migrate_interval == 0:
+        if r.k >= r.next_migration:
             self.migrate()
 
     def migrate(self):
@@ -457,7 +478,7 @@ class VirtualTiledJob:
         for r in self.ranks:
             r.e.end()
             r.k += 1
-        if self.ranks[0].k % self.ranks[0].migrate_interval == 0:
+        if self.ranks[0].k >= self.ranks[0].next_migration:
             self.migrate()
 
     def migrate(self):

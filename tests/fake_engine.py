@@ -60,7 +60,8 @@ class OracleEngine:
 
     def migration_scan(self):
         lo, hi = self.active_bounds()
-        return self.leaver_counts(), lo, hi
+        speed = float(np.abs(self.s.v).max() * self.cfg.dt / self.dx) if self.s.n else 0.0
+        return self.leaver_counts(), lo, hi, speed
 
     def leaver_counts(self):
         d = self._dest()

@@ -132,6 +132,45 @@ def test_k_tiles_reproduce_one_tile(tm, world, dims, overlap):
         sim.close()
 
 
+def test_adaptive_migration_schedule_on_the_device(tm):
+    """no explicit interval: the scan's measured top speed (max |v|_inf dt / dx over the live particles) schedules
+    the next migration; checked against numpy on the downloaded velocities, and the 4-brick run still reproduces the
+    single-ctx run with far fewer scans than the CFL schedule would make"""
+    from taichi_mpm_amd import tiled
+    s = _two_material_state()
+    n, world, steps = s.n, 4, 60
+    ids = np.arange(n)
+    one = _sim(tm, s, np.ones(n, bool), ids, n + 1024)
+    part = tiled.Partition.balanced((RES,) * 3, world, s.x, DX, margin=2)
+    owner = part.rank_of_cells(tiled.base_cells(s.x, DX))
+    sims = [_sim(tm, s, owner == r, ids, n + 1024) for r in range(world)]
+    engines = [tiled.HipEngine(sim, 0) for sim in sims]
+    job = tiled.VirtualTiledJob(engines, part, overlap=True)
+    _, _, _, sp = engines[0].migration_scan()
+    v0 = sims[0].get_particles(sort_by_id=False)["v"]
+    assert abs(sp - np.abs(v0).max() * DT / DX) <= 1e-6 * sp and 0 < sp < 0.5
+    scans = []
+    plain = engines[0].migration_scan
+
+    def counting_scan():
+        scans.append(job.ranks[0].k)
+        return plain()
+    engines[0].migration_scan = counting_scan
+    job.run(steps)
+    one.run_substeps(steps)
+    assert scans[0] == 2 and 2 <= len(scans) <= steps // 6, scans
+    assert sum(r.migrated_out for r in job.ranks) > 0
+    for rank, sim in enumerate(sims):  # nobody is beyond the margin of its brick (the library would have raised)
+        b = tiled.base_cells(sim.get_particles(sort_by_id=False)["x"], DX)
+        lo, hi = part.brick(rank)
+        assert (b >= np.array(lo) - part.margin).all() and (b < np.array(hi) + part.margin).all()
+    ref, got = one.get_particles(), _gather(sims)
+    assert np.array_equal(got["id"], ref["id"]) and np.abs(got["x"] - ref["x"]).max() <= 2e-6
+    assert rel_l2(got["v"], ref["v"]) <= 2e-4 and rel_l2(got["F"], ref["F"]) <= 2e-4
+    for sim in sims + [one]:
+        sim.close()
+
+
 def test_migration_compacts_when_slots_run_out(tm):
     """leavers leave dead slots behind; a rank that keeps receiving and losing particles compacts its records at
     a later sort instead of running out of slots"""

@@ -117,6 +117,53 @@ def test_virtual_ranks_match_single_oracle(orc, world, dims):
     _compare(_collect([e.s for e in engines]), ref)
 
 
+def test_adaptive_migration_schedule_follows_the_fastest_particle(orc):
+    """without an explicit interval the next migration is scheduled from the measured top speed (cells per substep):
+    half the time the fastest particle needs to cross the margin, never sooner than the CFL schedule (= margin
+    substeps), never later than the cap — and the run still equals the single-domain run (the engines assert that
+    no particle ever leaves the margin)"""
+    s = _state()
+    steps = 80
+    ref = _reference_run(orc, s, steps)
+    part = tiled.Partition.balanced((RES,) * 3, 2, s.x, DX, margin=2)
+    owner = part.rank_of_cells(tiled.base_cells(s.x, DX))
+    engines = [OracleEngine(_cfg(orc), subset(s, owner == r), DX) for r in range(2)]
+    job = tiled.VirtualTiledJob(engines, part)
+    seen = {}
+
+    def counting(e):
+        plain = e.migration_scan
+
+        def scan():
+            out = plain()
+            k = job.ranks[0].k
+            seen[k] = max(seen.get(k, 0.0), out[3])  # the schedule uses the fastest particle of ALL ranks
+            return out
+        return scan
+    for e in engines:
+        e.migration_scan = counting(e)
+    job.run(steps)
+    scans = sorted(seen.items())
+    ks = [k for k, _ in scans]
+    assert ks[0] == 2 and len(ks) < steps // 4, ks  # first scan on the CFL schedule, then far fewer than every 2
+    for (k0, sp), k1 in zip(scans, ks[1:]):  # every gap = what the speed measured at its start allows
+        q = np.ceil(sp * (1 << 20)) / (1 << 20)
+        assert k1 - k0 == max(2, min(64, int(0.5 * 2 / q))), (k0, k1, sp)
+    assert sum(r.migrated_out for r in job.ranks) > 0
+    _compare(_collect([e.s for e in engines]), ref)
+    # fast particles: back to the CFL schedule; an explicit interval or cap 0 switches the adaptation off
+    r = job.ranks[0]
+    r.k = 100
+    r.schedule(0.7)
+    assert r.next_migration == 102
+    r.schedule(1e-9)
+    assert r.next_migration == 164
+    fixed = tiled.VirtualTiledJob([OracleEngine(_cfg(orc), subset(s, owner == q), DX) for q in range(2)], part,
+                                  migrate_interval=2).ranks[0]
+    fixed.schedule(1e-9)
+    assert fixed.next_migration == 2
+
+
 def test_halo_boxes_follow_the_particles(orc):
     """halo boxes are clipped to the occupied part of the grid; when the particles approach the clip box the
     plan is rebuilt (same decision on all ranks) and the result is unchanged"""
