@@ -1,97 +1,97 @@
 // oracle/partio_ref_driver.cpp — TEST INFRASTRUCTURE (only tests/ and the golden-fixture script run it).
 //
-// Drives the REFERENCE's own vendored Partio (external/partio, compiled in place by `make -C oracle ref_partio`,
-// output oracle/_ref/partio_write) through the attribute sequence of MPM<dim>::write_partio
-// (src/visualize.cpp:17-100): position VECTOR3, type INT1, index INT1, limit INT3, v VECTOR3 and, with
-// verbose_bgeo, m VECTOR1, boundary_normal VECTOR3, debug VECTOR3, states INT1, boundary_distance FLOAT1,
-// near_boundary INT1, apic_frobenius_norm FLOAT1; particles in ascending id (:39-43).  The bytes it writes are the
-// reference's bytes for that particle state: they pin the .bgeo encoder of libmpmhip (tests/golden/bgeo_*).
+// Feeds a particle state through the REFERENCE's own vendored Partio (external/partio, compiled in place by
+// `make -C oracle ref_partio` -> oracle/_ref/partio_write) with the attribute set, attribute order and particle order
+// that MPM<dim>::write_partio uses (src/visualize.cpp:17-100): position, type, index, limit[3], v and — verbose_bgeo —
+// m, boundary_normal[3], debug[3], states, boundary_distance, near_boundary, apic_frobenius_norm; ascending id.
+// The bytes Partio then writes are the reference's bytes for that state: they pin libmpmhip's .bgeo encoder
+// (tests/golden/bgeo_*).
 //
 // usage: partio_write <in.raw> <out.bgeo>
-// in.raw: int32 n, int32 verbose, then per particle (native little-endian, in FILE order, any id order):
+// in.raw: int32 n, int32 verbose, then one record per particle (native little-endian, any id order):
 //   float pos[3], float v[3], int32 id, int32 is_rigid, int32 limit[3]
-//   and if verbose: float mass, float boundary_normal[3], float debug[3], int32 states,
-//                   float boundary_distance_in_cells, int32 near_boundary, float apic_b[9] (row-major)
+//   verbose only: float mass, float boundary_normal[3], float debug[3], int32 states,
+//                 float boundary_distance_in_cells, int32 near_boundary, float apic_b[9] (row-major)
 #include <Partio.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
+#include <numeric>
 #include <vector>
 
-struct Row {
-  float pos[3], v[3];
-  int32_t id, is_rigid, limit[3];
-  float mass, bn[3], debug[3];
-  int32_t states;
-  float bdist;
-  int32_t near_boundary;
-  float b[9];
+namespace {
+
+// one output attribute: where its words sit inside the input record (in 4-byte words; -1 = computed)
+struct Column {
+  const char *name;
+  Partio::ParticleAttributeType type;
+  int count;
+  int word;  // offset into the record
 };
+// record words: 0 pos, 3 v, 6 id, 7 is_rigid, 8 limit | 11 mass, 12 normal, 15 debug, 18 states, 19 distance, 20 near, 21 apic_b
+constexpr int PLAIN_WORDS = 11, VERBOSE_WORDS = 30;
+const Column PLAIN[] = {{"position", Partio::VECTOR, 3, 0}, {"type", Partio::INT, 1, 7}, {"index", Partio::INT, 1, 6},
+                        {"limit", Partio::INT, 3, 8},        {"v", Partio::VECTOR, 3, 3}};
+const Column VERBOSE[] = {{"m", Partio::VECTOR, 1, 11},       {"boundary_normal", Partio::VECTOR, 3, 12},
+                          {"debug", Partio::VECTOR, 3, 15},   {"states", Partio::INT, 1, 18},
+                          {"boundary_distance", Partio::FLOAT, 1, 19}, {"near_boundary", Partio::INT, 1, 20},
+                          {"apic_frobenius_norm", Partio::FLOAT, 1, -1}};
+
+float skew_norm(const uint32_t *rec) {  // || 0.5 (B - B^T) ||_F of the apic_b at words 21..29
+  float b[9];
+  std::memcpy(b, rec + 21, sizeof b);
+  float acc = 0;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      const float h = 0.5f * (b[3 * r + c] - b[3 * c + r]);
+      acc += h * h;
+    }
+  return std::sqrt(acc);
+}
+
+}  // namespace
 
 int main(int argc, char **argv) {
   if (argc != 3) return 2;
-  FILE *f = std::fopen(argv[1], "rb");
-  if (!f) return 3;
-  int32_t n = 0, verbose = 0;
-  if (std::fread(&n, 4, 1, f) != 1 || std::fread(&verbose, 4, 1, f) != 1) return 4;
-  std::vector<Row> rows(n);
-  for (auto &r : rows) {
-    r = Row{};
-    size_t ok = std::fread(r.pos, 4, 3, f) + std::fread(r.v, 4, 3, f) + std::fread(&r.id, 4, 1, f) +
-                std::fread(&r.is_rigid, 4, 1, f) + std::fread(r.limit, 4, 3, f);
-    if (ok != 11) return 5;
-    if (verbose) {
-      ok = std::fread(&r.mass, 4, 1, f) + std::fread(r.bn, 4, 3, f) + std::fread(r.debug, 4, 3, f) +
-           std::fread(&r.states, 4, 1, f) + std::fread(&r.bdist, 4, 1, f) + std::fread(&r.near_boundary, 4, 1, f) +
-           std::fread(r.b, 4, 9, f);
-      if (ok != 19) return 6;
-    }
-  }
-  std::fclose(f);
-  std::sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) { return a.id < b.id; });  // visualize.cpp:39-43
+  FILE *in = std::fopen(argv[1], "rb");
+  if (!in) return 3;
+  int32_t head[2];
+  if (std::fread(head, 4, 2, in) != 2) return 4;
+  const int n = head[0];
+  const bool verbose = head[1] != 0;
+  const int words = verbose ? VERBOSE_WORDS : PLAIN_WORDS;
+  std::vector<uint32_t> recs((size_t)n * words);
+  if (n && std::fread(recs.data(), 4, recs.size(), in) != recs.size()) return 5;
+  std::fclose(in);
 
-  Partio::ParticlesDataMutable *parts = Partio::create();
-  Partio::ParticleAttribute posH, vH, mH, typeH, normH, statH, boundH, distH, debugH, indexH, limitH, apicH;
-  posH = parts->addAttribute("position", Partio::VECTOR, 3);
-  typeH = parts->addAttribute("type", Partio::INT, 1);
-  indexH = parts->addAttribute("index", Partio::INT, 1);
-  limitH = parts->addAttribute("limit", Partio::INT, 3);
-  vH = parts->addAttribute("v", Partio::VECTOR, 3);
-  if (verbose) {
-    mH = parts->addAttribute("m", Partio::VECTOR, 1);
-    normH = parts->addAttribute("boundary_normal", Partio::VECTOR, 3);
-    debugH = parts->addAttribute("debug", Partio::VECTOR, 3);
-    statH = parts->addAttribute("states", Partio::INT, 1);
-    distH = parts->addAttribute("boundary_distance", Partio::FLOAT, 1);
-    boundH = parts->addAttribute("near_boundary", Partio::INT, 1);
-    apicH = parts->addAttribute("apic_frobenius_norm", Partio::FLOAT, 1);
-  }
-  for (const Row &r : rows) {
-    const int idx = parts->addParticle();
-    if (verbose) {
-      parts->dataWrite<float>(mH, idx)[0] = r.mass;
-      for (int k = 0; k < 3; k++) parts->dataWrite<float>(normH, idx)[k] = r.bn[k];
-      for (int k = 0; k < 3; k++) parts->dataWrite<float>(debugH, idx)[k] = r.debug[k];
-      parts->dataWrite<int>(statH, idx)[0] = r.states;
-      parts->dataWrite<int>(boundH, idx)[0] = r.near_boundary;
-      parts->dataWrite<float>(distH, idx)[0] = r.bdist;
-      float s = 0;  // || 0.5 (B - B^T) ||_F  (visualize.cpp:70-71)
-      for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) {
-          const float a = 0.5f * (r.b[i * 3 + j] - r.b[j * 3 + i]);
-          s += a * a;
-        }
-      parts->dataWrite<float>(apicH, idx)[0] = std::sqrt(s);
+  std::vector<int> by_id(n);
+  std::iota(by_id.begin(), by_id.end(), 0);
+  auto id_of = [&](int p) { int32_t v; std::memcpy(&v, &recs[(size_t)p * words + 6], 4); return v; };
+  std::sort(by_id.begin(), by_id.end(), [&](int a, int b) { return id_of(a) < id_of(b); });
+
+  std::vector<Column> cols(PLAIN, PLAIN + 5);
+  if (verbose) cols.insert(cols.end(), VERBOSE, VERBOSE + 7);
+  Partio::ParticlesDataMutable *out = Partio::create();
+  std::vector<Partio::ParticleAttribute> handles;
+  for (const Column &c : cols) handles.push_back(out->addAttribute(c.name, c.type, c.count));
+  for (int p : by_id) {
+    const uint32_t *rec = &recs[(size_t)p * words];
+    const int row = out->addParticle();
+    for (size_t a = 0; a < cols.size(); a++) {
+      // FLOAT / VECTOR / INT are all 4-byte words in Partio: copy the bits
+      uint32_t *dst = reinterpret_cast<uint32_t *>(out->dataWrite<float>(handles[a], row));
+      if (cols[a].word < 0) {
+        const float s = skew_norm(rec);
+        std::memcpy(dst, &s, 4);
+      } else {
+        std::memcpy(dst, rec + cols[a].word, 4 * (size_t)cols[a].count);
+      }
     }
-    for (int k = 0; k < 3; k++) parts->dataWrite<float>(vH, idx)[k] = r.v[k];
-    parts->dataWrite<int>(typeH, idx)[0] = r.is_rigid;
-    parts->dataWrite<int>(indexH, idx)[0] = r.id;
-    for (int k = 0; k < 3; k++) parts->dataWrite<int>(limitH, idx)[k] = r.limit[k];
-    for (int k = 0; k < 3; k++) parts->dataWrite<float>(posH, idx)[k] = r.pos[k];
   }
-  Partio::write(argv[2], *parts);
-  parts->release();
+  Partio::write(argv[2], *out);
+  out->release();
   return 0;
 }
