@@ -17,6 +17,8 @@ Extra objects on the line:
                 written; G2P 52 B read + 100 B written + 16 B per touched node read.  `traffic` = HBM bytes per
                 launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE, see
                 DESIGN.md §6) / the same launch duration, or null when no PMC summary matches the workload.
+                `measured_copy_GBs` = a plain float4 copy kernel of the library on this box (1 GiB, best of 5, bytes
+                read + written), run after the timed region: the practical ceiling next to the nominal `peak`.
   cpu_baseline  the block-sorted, 8-colour, OpenMP restatement of the reference's optimised CPU path
                 (oracle/mpm_oracle_opt.cpp, kind "port") timed on this box's host cores on a bounded sample.
 """
@@ -263,6 +265,12 @@ def main():
     else:
         n_total = n_local
     prof = job.profile()
+    copy_gbs = None
+    if world == 1 and not force_tiled:  # what a plain streaming copy reaches on THIS box, measured after the timed region
+        try:
+            copy_gbs = job.sim.copy_bandwidth(1 << 30, 5)
+        except Exception as e:
+            print("bench.py: copy bandwidth probe failed: %r" % (e,), file=sys.stderr)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -286,6 +294,8 @@ def main():
                    "timed": "full substep: sort+reorder, P2G, grid normalise+boundary, G2P, boundary cleanup"},
         "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
+                     "measured_copy_GBs": copy_gbs,  # plain float4 copy kernel on this box (read + written bytes)
+                     "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
                      "traffic": (tbytes / (ms[dom] * 1e-3) / 1e9) if tbytes else None,
                      "traffic_bytes_per_launch": tbytes, "traffic_source": tsrc,
                      "algorithmic_bytes_per_launch": per_launch[dom], "avg_launch_ms": ms[dom]},

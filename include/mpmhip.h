@@ -269,6 +269,11 @@ int mpmhip_active_bounds(mpmhip_ctx *ctx, int32_t lo[3], int32_t hi[3]);
 int64_t mpmhip_num_slots(mpmhip_ctx *ctx);       /* slots in use (live + dead) — capacity pressure */
 int mpmhip_request_compaction(mpmhip_ctx *ctx);  /* physical reorder + drop of dead slots at the next sort */
 
+/* measurement helper: streams `bytes` (rounded down to 16; two scratch buffers of that size are allocated and freed)
+ * through a plain copy kernel `iters` times on the ctx stream and returns the best rate in GB/s, counting the bytes
+ * read plus the bytes written.  bench.py reports it next to the nominal HBM peak.  Synchronises. */
+int mpmhip_debug_copy_bandwidth(mpmhip_ctx *ctx, size_t bytes, int32_t iters, double *gb_per_s);
+
 /* debug/parity helpers running the device math on host arrays (n items each) */
 int mpmhip_debug_svd3(mpmhip_ctx *ctx, int64_t n, const float *F, float *U, float *S, float *V);
 int mpmhip_debug_force(mpmhip_ctx *ctx, int32_t material, const float params[MPMHIP_NPARAM], int64_t n,

@@ -5,6 +5,24 @@
 
 namespace mpm {
 
+// ------------------------------------------------------------------------------------------------ bandwidth probe
+// plain streaming copy (16 bytes per lane, grid-stride): what this box's HBM delivers to the simplest possible
+// kernel — the yardstick bench.py reports next to the nominal 8 TB/s
+// UNROLL independent 16-byte loads per lane are in flight before the first store; NT = non-temporal stores
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void k_stream_copy(float4 *__restrict__ dst, const float4 *__restrict__ src, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
+    float4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) v[u] = src[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) st_rec(dst + i + u * stride, v[u], NT);
+  }
+  for (; i < n; i += stride) dst[i] = src[i];
+}
+
 // ------------------------------------------------------------------------------------------------ debug math
 __global__ void k_debug_svd(int64_t n, const float *F, float *U, float *S, float *V) {
   for (int64_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {

@@ -1375,6 +1375,43 @@ int mpmhip_request_compaction(mpmhip_ctx *c) {
   return MPMHIP_OK;
 }
 
+int mpmhip_debug_copy_bandwidth(mpmhip_ctx *c, size_t bytes, int32_t iters, double *gb_per_s) {
+  if (!c || !gb_per_s || iters <= 0 || bytes < 16) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = bytes / 16;
+  float4 *a = nullptr, *b = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = dmalloc(&a, n);
+  if (e == hipSuccess) e = dmalloc(&b, n);
+  if (e == hipSuccess) e = hipMemsetAsync(a, 0, n * 16, c->stream);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  double best = 0.0;
+  // best over a few shapes of the same copy (loads in flight per lane, workgroups per CU, store hint): the
+  // yardstick should be the best a plain kernel does, not one arbitrary launch shape
+  using Kern = void (*)(float4 *, const float4 *, size_t);
+  const Kern kerns[] = {k_stream_copy<1, false>, k_stream_copy<4, false>, k_stream_copy<4, true>, k_stream_copy<8, true>};
+  const int grids[] = {256 * 4, 256 * 16, 256 * 64};
+  for (Kern k : kerns)
+    for (int g : grids)
+      for (int it = 0; e == hipSuccess && it < iters + 1; it++) {  // the first pass of a shape is a warm-up
+        hipEventRecord(e0, c->stream);
+        hipLaunchKernelGGL(k, dim3(g), dim3(256), 0, c->stream, b, (const float4 *)a, n);
+        hipEventRecord(e1, c->stream);
+        e = hipEventSynchronize(e1);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && it > 0 && ms > 0.0f) best = std::max(best, 2.0 * (double)n * 16.0 / (ms * 1e-3) / 1e9);
+      }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  HIPCHK(c, e);
+  *gb_per_s = best;
+  return MPMHIP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ debug math
 int mpmhip_debug_svd3(mpmhip_ctx *c, int64_t n, const float *F, float *U, float *S, float *V) {
   if (!c || n <= 0) return MPMHIP_EINVAL;

@@ -393,6 +393,13 @@ class Simulation3D:
         """0 off, 1 every phase, 2 only G2P, 3 only P2G (include/mpmhip.h)"""
         self._ensure_ctx(); self._check(self._L.mpmhip_set_profiling(self._ctx, int(level)))
 
+    def copy_bandwidth(self, nbytes=1 << 30, iters=5):
+        """GB/s (read + written) of a plain streaming copy on this GPU: the measured yardstick next to the nominal peak"""
+        self._ensure_ctx()
+        out = C.c_double()
+        self._check(self._L.mpmhip_debug_copy_bandwidth(self._ctx, int(nbytes), int(iters), C.byref(out)))
+        return out.value
+
     def profile(self, reset=False):
         self._ensure_ctx()
         buf = C.create_string_buffer(1024)
