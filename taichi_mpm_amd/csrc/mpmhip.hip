@@ -1392,7 +1392,7 @@ int mpmhip_debug_copy_bandwidth(mpmhip_ctx *c, size_t bytes, int32_t iters, doub
   using Kern = void (*)(float4 *, const float4 *, size_t);
   const Kern kerns[] = {k_stream_copy<1, false>, k_stream_copy<4, false>, k_stream_copy<4, true>, k_stream_copy<8, true>};
   const int grids[] = {256 * 4, 256 * 16, 256 * 64};
-  for (Kern k : kerns)
+  for (const Kern &k : kerns)
     for (int g : grids)
       for (int it = 0; e == hipSuccess && it < iters + 1; it++) {  // the first pass of a shape is a warm-up
         hipEventRecord(e0, c->stream);
@@ -1402,6 +1402,8 @@ int mpmhip_debug_copy_bandwidth(mpmhip_ctx *c, size_t bytes, int32_t iters, doub
         float ms = 0.0f;
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
         if (e == hipSuccess && it > 0 && ms > 0.0f) best = std::max(best, 2.0 * (double)n * 16.0 / (ms * 1e-3) / 1e9);
+        if (it == iters && getenv("MPMHIP_BW_VERBOSE"))
+          std::fprintf(stderr, "copy variant %d grid %d: %.0f GB/s\n", (int)(&k - kerns), g, 2.0 * (double)n * 16.0 / (ms * 1e-3) / 1e9);
       }
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
