@@ -200,8 +200,9 @@ int mpmhip_write_bgeo(mpmhip_ctx *ctx, const char *path, int32_t verbose);
  * level 0: off.  level 1: hipEvents bracket each phase of every substep on the ctx stream (six records per
  * substep; each record costs ~5 us of idle GPU).  level 2 / 3: only k_g2p / only k_p2g is bracketed (two records),
  * for timing the dominant kernel inside a throughput measurement.
- * mpmhip_profile writes a JSON object: {"substeps":N,"particles":n,"active_blocks":a,
- *   "phases":{"sort":ms,"p2g":ms,"exchange":ms,"grid":ms,"g2p":ms}}  (totals since the last reset; "exchange" is
+ * mpmhip_profile writes a JSON object: {"substeps":N,"particles":n,"active_blocks":a,"rank_mode":m,
+ *   "phases":{"sort":ms,"p2g":ms,"exchange":ms,"grid":ms,"g2p":ms}}  (totals since the last reset; rank_mode = the
+ *   in-cell ranking path the next sort will take: 0 per-run atomics, 1 per-batch LDS hash; "exchange" is
  *   the gap between substep_begin and substep_end of a tiled run; phases not bracketed at the level stay 0). */
 int mpmhip_set_profiling(mpmhip_ctx *ctx, int32_t level);
 int mpmhip_profile(mpmhip_ctx *ctx, char *json, size_t cap);

@@ -135,37 +135,115 @@ __global__ __launch_bounds__(256) void k_block_table(Params P, uint8_t *__restri
   }
 }
 
-// rank of each particle inside its cell.  Runs of equal keys in consecutive lanes are aggregated into one
-// returning atomic per run.  Overwrites key[i] with cidx = slot(block)*64 + cell.
+// rank of each particle inside its cell; overwrites key[i] with cidx = slot(block)*64 + cell.  Two paths, chosen
+// per sort from the statistics of the previous one (cnt->rank_mode, set by k_cell_table):
+//  mode 0  runs of equal keys in adjacent lanes (the slots are in the order of the last physical reorder, i.e. cell by
+//          cell) are aggregated into ONE returning global atomic per run.  Cheapest while the runs are long: 39 us
+//          at 8 M particles on the freshly seeded lattice (8 per cell), but 162 us in the impact phase of C3, when the
+//          particle order has decayed and the cells are hit from many waves at once.
+//  mode 1  a workgroup takes 1024 consecutive slots, counts them per cell in an LDS hash table (open addressing on
+//          cidx; nothing is assumed about which cells a batch holds), reserves each cell's range with ONE global
+//          atomic per distinct cell of the batch and hands the local ranks out from LDS: ~70 us whatever the order.
+// Both count the runs they see (cnt->run_heads); more than one run per 3 slots selects mode 1 for the next sort.
+constexpr int RANK_PER_THREAD = 4, RANK_BATCH = 256 * RANK_PER_THREAD, RANK_TAB = 2048;
+
+// cidx of slot i (INVALID: dead / out of range / block table overflow)
+__device__ __forceinline__ uint32_t rank_cidx(const Params &P, const uint32_t *__restrict__ key,
+                                              const uint32_t *__restrict__ bits, const uint32_t *__restrict__ wprefix,
+                                              uint32_t i, uint32_t n) {
+  if (i >= n) return INVALID;
+  const uint32_t k = key[i];
+  if (k == INVALID) return INVALID;
+  const uint32_t slot = block_slot(bits, wprefix, k >> 6);
+  return (slot < P.max_blocks) ? slot * BC + (k & 63u) : INVALID;
+}
+// the run of equal values around this lane: [start, end) in lane numbers; heads = mask of the first lanes of all runs
+__device__ __forceinline__ void lane_run(uint32_t c, uint32_t lane, int &start, int &end, unsigned long long &heads) {
+  const uint32_t prev = __shfl_up(c, 1);
+  heads = __ballot((lane == 0) || (c != prev));
+  const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+  start = 63 - __clzll(heads & le);
+  const unsigned long long above = heads & ~le;
+  end = above ? (__ffsll((long long)above) - 1) : 64;
+}
+
 __global__ __launch_bounds__(256) void k_rank(Params P, uint32_t *__restrict__ key, uint32_t *__restrict__ rank,
                                               uint32_t *__restrict__ cell_cnt, const uint32_t *__restrict__ bits,
-                                              const uint32_t *__restrict__ wprefix) {
+                                              const uint32_t *__restrict__ wprefix, Counters *cnt) {
+  __shared__ uint32_t tkey[RANK_TAB], tcnt[RANK_TAB];  // mode 1.  tcnt: particles of the batch in that cell, then their global base
+  __shared__ uint32_t s_heads;
   const uint32_t n = P.n_slots;
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t nloop = (n + stride - 1) / stride;
-  for (uint32_t it = 0; it < nloop; it++) {  // uniform trip count: every lane takes part in the shuffles
-    const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t k = (i < n) ? key[i] : INVALID;
-    uint32_t cidx = INVALID;
-    if (k != INVALID) {
-      const uint32_t slot = block_slot(bits, wprefix, k >> 6);
-      cidx = (slot < P.max_blocks) ? slot * BC + (k & 63u) : INVALID;
+  const uint32_t mode = cnt->rank_mode;  // uniform over the grid
+  if (threadIdx.x == 0) s_heads = 0u;
+  uint32_t my_heads = 0u;  // lane 0 of each wave counts its wave's runs
+  if (mode == 0u) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t nloop = (n + stride - 1) / stride;
+    for (uint32_t it = 0; it < nloop; it++) {  // uniform trip count: every lane takes part in the shuffles
+      const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+      const uint32_t c = rank_cidx(P, key, bits, wprefix, i, n);
+      int start, end;
+      unsigned long long H;
+      lane_run(c, lane, start, end, H);
+      my_heads += (uint32_t)__popcll(H);
+      uint32_t base = 0;
+      if ((int)lane == start && c != INVALID) base = atomicAdd(&cell_cnt[c], (uint32_t)(end - start));
+      base = __shfl(base, start);
+      if (i < n) {
+        key[i] = c;
+        rank[i] = base + (lane - (uint32_t)start);
+      }
     }
-    const uint32_t prev = __shfl_up(cidx, 1);
-    const bool head = (lane == 0) || (cidx != prev);
-    const unsigned long long H = __ballot(head);
-    const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-    const int start = 63 - __clzll(H & le);
-    const unsigned long long above = H & ~le;
-    const int end = above ? (__ffsll((long long)above) - 1) : 64;
-    uint32_t base = 0;
-    if ((int)lane == start && cidx != INVALID) base = atomicAdd(&cell_cnt[cidx], (uint32_t)(end - start));
-    base = __shfl(base, start);
-    if (i < n) {
-      key[i] = cidx;
-      rank[i] = base + (lane - start);
+    __syncthreads();
+  } else {
+    const uint32_t nbatch = (n + RANK_BATCH - 1) / RANK_BATCH;
+    for (uint32_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
+      for (int t = threadIdx.x; t < RANK_TAB; t += 256) { tkey[t] = INVALID; tcnt[t] = 0u; }
+      __syncthreads();
+      uint32_t cidx[RANK_PER_THREAD], ent[RANK_PER_THREAD], loc[RANK_PER_THREAD];
+#pragma unroll
+      for (int u = 0; u < RANK_PER_THREAD; u++) {
+        const uint32_t i = b * RANK_BATCH + u * 256 + threadIdx.x;
+        const uint32_t c = rank_cidx(P, key, bits, wprefix, i, n);
+        cidx[u] = c;
+        int start, end;
+        unsigned long long H;
+        lane_run(c, lane, start, end, H);  // a run enters the table once, with its length
+        my_heads += (uint32_t)__popcll(H);
+        uint32_t h = 0u, first = 0u;
+        if ((int)lane == start && c != INVALID) {
+          h = (c * 2654435761u) >> 21;  // 11 bits: RANK_TAB entries, at most half of them used
+          for (;;) {
+            const uint32_t seen = atomicCAS(&tkey[h], INVALID, c);
+            if (seen == INVALID || seen == c) break;
+            h = (h + 1u) & (RANK_TAB - 1);
+          }
+          first = atomicAdd(&tcnt[h], (uint32_t)(end - start));
+        }
+        ent[u] = __shfl(h, start);
+        loc[u] = __shfl(first, start) + (lane - (uint32_t)start);
+      }
+      __syncthreads();
+      for (int t = threadIdx.x; t < RANK_TAB; t += 256)
+        if (tkey[t] != INVALID) tcnt[t] = atomicAdd(&cell_cnt[tkey[t]], tcnt[t]);
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < RANK_PER_THREAD; u++) {
+        const uint32_t i = b * RANK_BATCH + u * 256 + threadIdx.x;
+        if (i < n) {
+          key[i] = cidx[u];
+          rank[i] = (cidx[u] != INVALID) ? tcnt[ent[u]] + loc[u] : 0u;
+        }
+      }
+      __syncthreads();
     }
+  }
+  // statistics from every 16th workgroup only (scaled): thousands of atomics on ONE address serialise at ~13 ns each
+  if ((blockIdx.x & 15u) == 0u) {
+    if (lane == 0 && my_heads) atomicAdd(&s_heads, my_heads);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_heads) atomicAdd(&cnt->run_heads, s_heads * 16u);
   }
 }
 
@@ -184,7 +262,12 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
   __shared__ uint32_t s_chunk;
   constexpr int CT_BPW = CT_BLOCKS / 4;  // blocks per wave
   __shared__ uint32_t blk_tot[CT_BLOCKS];
-  if (blockIdx.x == 0 && threadIdx.x == 0) ticket[0] = 0;  // k_block_table's counter (it is not running now)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ticket[0] = 0;  // k_block_table's counter (it is not running now)
+    // k_rank of this sort is complete: its run statistics choose the path of the next one (see k_rank)
+    cnt->rank_mode = (cnt->run_heads * 3u > P.n_slots) ? 1u : 0u;
+    cnt->run_heads = 0u;
+  }
   const uint32_t na = min(cnt->n_active, P.max_blocks);
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   while (true) {

@@ -11,7 +11,8 @@
 //                          previous substep's k_g2p, which knows the new position)
 //          k_block_table  byte flags -> active-block bitmap + popcount prefix (dense slot of every active block)
 //                         + active-block list, one single-pass chained-scan launch
-//          k_rank         rank of each particle in its cell (run-aggregated atomics)
+//          k_rank         rank of each particle in its cell (one global atomic per run of equal keys, or — when the
+//                         particle order has decayed — an LDS hash per 1024 slots and one atomic per distinct cell)
 //          k_cell_table   per-cell counts -> start of every cell / block in the sorted index (single pass)
 //          k_perm         sorted position -> particle slot
 //   P2G    k_p2g   one wavefront per active 4x4x4-cell block, ONE LANE PER CELL: register accumulation of the
@@ -624,7 +625,9 @@ static int do_sort(mpmhip_ctx *c) {
   const uint32_t epoch = ++c->sort_epoch;
   hipLaunchKernelGGL(k_block_table, dim3(std::min(bt_chunks, 512u)), dim3(256), 0, st, P, c->blk_flag, c->bits,
                      c->wprefix, c->act_blk, c->cnt, c->scan_slots, c->ticket, epoch);
-  hipLaunchKernelGGL(k_rank, dim3(pg), dim3(256), 0, st, P, c->key, c->rank, c->cell_cnt, c->bits, c->wprefix);
+  const uint32_t rank_wgs = std::min<uint32_t>((P.n_slots + RANK_BATCH - 1) / RANK_BATCH, 8192u);
+  hipLaunchKernelGGL(k_rank, dim3(std::max(rank_wgs, 1u)), dim3(256), 0, st, P, c->key, c->rank, c->cell_cnt, c->bits, c->wprefix,
+                     c->cnt);
   hipLaunchKernelGGL(small ? k_cell_table<16> : k_cell_table<64>, dim3(std::min(ct_chunks, 512u)), dim3(256), 0, st, P,
                      c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots, c->ticket, epoch);
   hipLaunchKernelGGL(k_perm, dim3(pg), dim3(256), 0, st, P, c->key, c->rank, c->cell_start, c->perm);
@@ -1182,9 +1185,9 @@ int mpmhip_profile(mpmhip_ctx *c, char *json, size_t cap) {
   Counters h;
   if ((rc = read_counters(c, h))) return rc;
   int w = snprintf(json, cap,
-                   "{\"substeps\":%lld,\"particles\":%lld,\"active_blocks\":%u,\"phases\":{\"sort\":%.6f,\"p2g\":%.6f,"
+                   "{\"substeps\":%lld,\"particles\":%lld,\"active_blocks\":%u,\"rank_mode\":%u,\"phases\":{\"sort\":%.6f,\"p2g\":%.6f,"
                    "\"exchange\":%.6f,\"grid\":%.6f,\"g2p\":%.6f}}",
-                   (long long)c->prof_substeps, (long long)(c->n_slots - h.n_dead), h.n_active, c->phase_ms[PH_SORT],
+                   (long long)c->prof_substeps, (long long)(c->n_slots - h.n_dead), h.n_active, h.rank_mode, c->phase_ms[PH_SORT],
                    c->phase_ms[PH_P2G], c->phase_ms[PH_EXCH], c->phase_ms[PH_GRID], c->phase_ms[PH_G2P]);
   return (w < 0 || (size_t)w >= cap) ? fail(c, MPMHIP_EINVAL, "profile buffer too small") : MPMHIP_OK;
 }
