@@ -703,6 +703,7 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0) {
     case 12: kern = sb ? k_g2p<256, 2, true, true> : k_g2p<256, 2, true, false>; break;
     case 3: kern = sb ? k_g2p<256, 3, false, true> : k_g2p<256, 3, false, false>; break;
     case 14: kern = sb ? k_g2p<256, 4, true, true> : k_g2p<256, 4, true, false>; break;
+    case 23: kern = sb ? k_g2p<128, 3, true, true> : k_g2p<128, 3, true, false>; nt = 128; break;  // 128-entry chunks
     default: break;
   }
   hipLaunchKernelGGL(kern, dim3(c->g2p_wgs), dim3(nt), 0, c->stream, c->P, (float4 *)c->rg, (float4 *)c->rp, (float4 *)c->rb,
