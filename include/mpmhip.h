@@ -270,6 +270,22 @@ int mpmhip_active_bounds(mpmhip_ctx *ctx, int32_t lo[3], int32_t hi[3]);
 int64_t mpmhip_num_slots(mpmhip_ctx *ctx);       /* slots in use (live + dead) — capacity pressure */
 int mpmhip_request_compaction(mpmhip_ctx *ctx);  /* physical reorder + drop of dead slots at the next sort */
 
+/* ---- the 2D dense-grid demo (BASELINE configs[0]) — replaces advance(dt) of mls-mpm88.cpp:16-69 (annotated twin
+ * mls-mpm88-explained.cpp:64-197): (n+1)^2 grid, snow model inline (E = 1e4, nu = 0.2, hardening 10, sigma clamp
+ * [0.975, 1.0075], Jp in [0.6, 20]), gravity -200 on the grid, sticky side/top walls and a separating floor at 0.05.
+ * Particle state as the demo's `Particle` (:11-13): x[2], v[2], F[4] row-major, C[4], Jp.  NULL inputs of
+ * mpmhip_mpm88_add take the demo's constructor values (v = 0, F = I, C = 0, Jp = 1); NULL outputs of download are
+ * skipped.  `plastic` = the demo's `plastic` flag (:10).  Its own small object: no mpmhip_ctx involved. */
+typedef struct mpmhip_mpm88 mpmhip_mpm88;
+int mpmhip_mpm88_create(int32_t n_grid, float dt, int32_t plastic, int32_t device, mpmhip_mpm88 **out);
+void mpmhip_mpm88_destroy(mpmhip_mpm88 *m);
+const char *mpmhip_mpm88_last_error(const mpmhip_mpm88 *m);
+int mpmhip_mpm88_add(mpmhip_mpm88 *m, int64_t n, const float *x, const float *v, const float *F, const float *C, const float *Jp);
+int64_t mpmhip_mpm88_num_particles(const mpmhip_mpm88 *m);
+int mpmhip_mpm88_advance(mpmhip_mpm88 *m, int32_t steps);  /* `steps` x advance(dt); asynchronous */
+int mpmhip_mpm88_download(mpmhip_mpm88 *m, float *x, float *v, float *F, float *C, float *Jp);  /* synchronises */
+int mpmhip_mpm88_download_grid(mpmhip_mpm88 *m, float *grid /* [(n+1)^2][3] = (v.x, v.y, m>0 ? 1 : 0) after advance */);
+
 /* measurement helper: streams `bytes` (rounded down to 16; two scratch buffers of that size are allocated and freed)
  * through a plain copy kernel `iters` times on the ctx stream and returns the best rate in GB/s, counting the bytes
  * read plus the bytes written.  bench.py reports it next to the nominal HBM peak.  Synchronises. */

@@ -80,7 +80,9 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_las
             "mpmhip_download_grid", "mpmhip_upload_grid", "mpmhip_calculate_energy", "mpmhip_snapshot_size", "mpmhip_snapshot_save", "mpmhip_snapshot_load", "mpmhip_delete_particles_inside_level_set", "mpmhip_bgeo_size", "mpmhip_bgeo_encode", "mpmhip_write_bgeo", "mpmhip_set_profiling", "mpmhip_profile",
             "mpmhip_profile_reset", "mpmhip_set_partition", "mpmhip_set_halo", "mpmhip_halo_pack",
             "mpmhip_substep_begin", "mpmhip_substep_end", "mpmhip_substep_interior", "mpmhip_set_overlap", "mpmhip_leaver_counts", "mpmhip_migration_scan", "mpmhip_export_leavers",
-            "mpmhip_import_particles", "mpmhip_active_bounds", "mpmhip_num_slots", "mpmhip_request_compaction", "mpmhip_debug_copy_bandwidth", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
+            "mpmhip_import_particles", "mpmhip_active_bounds", "mpmhip_num_slots", "mpmhip_request_compaction", "mpmhip_mpm88_create", "mpmhip_mpm88_destroy", "mpmhip_mpm88_last_error", "mpmhip_mpm88_add",
+            "mpmhip_mpm88_num_particles", "mpmhip_mpm88_advance", "mpmhip_mpm88_download", "mpmhip_mpm88_download_grid",
+            "mpmhip_debug_copy_bandwidth", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
 
 
 def exported_symbols():
@@ -144,6 +146,18 @@ def load():
     L.mpmhip_upload_grid.argtypes = [vp, fp]
     L.mpmhip_calculate_energy.argtypes = [vp, P(C.c_double), P(C.c_double)]
     L.mpmhip_delete_particles_inside_level_set.argtypes = [vp, P(C.c_int64)]
+    fp = P(C.c_float)
+    L.mpmhip_mpm88_create.argtypes = [C.c_int32, C.c_float, C.c_int32, C.c_int32, P(C.c_void_p)]
+    L.mpmhip_mpm88_destroy.argtypes = [vp]
+    L.mpmhip_mpm88_destroy.restype = None
+    L.mpmhip_mpm88_last_error.argtypes = [vp]
+    L.mpmhip_mpm88_last_error.restype = C.c_char_p
+    L.mpmhip_mpm88_add.argtypes = [vp, C.c_int64, fp, fp, fp, fp, fp]
+    L.mpmhip_mpm88_num_particles.argtypes = [vp]
+    L.mpmhip_mpm88_num_particles.restype = C.c_int64
+    L.mpmhip_mpm88_advance.argtypes = [vp, C.c_int32]
+    L.mpmhip_mpm88_download.argtypes = [vp, fp, fp, fp, fp, fp]
+    L.mpmhip_mpm88_download_grid.argtypes = [vp, fp]
     L.mpmhip_debug_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int32, P(C.c_double)]
     L.mpmhip_bgeo_size.argtypes = [vp, C.c_int32, P(C.c_size_t)]
     L.mpmhip_bgeo_encode.argtypes = [vp, C.c_int32, C.c_void_p, C.c_size_t, P(C.c_size_t)]

@@ -65,6 +65,7 @@
 #include "k_g2p.h"
 #include "k_debug.h"
 #include "k_bgeo.h"
+#include "k_mpm88.h"
 
 
 // ================================================================================================ host side
@@ -1415,6 +1416,141 @@ int mpmhip_debug_copy_bandwidth(mpmhip_ctx *c, size_t bytes, int32_t iters, doub
   (void)hipFree(b);
   HIPCHK(c, e);
   *gb_per_s = best;
+  return MPMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ 2D demo (configs[0])
+struct mpmhip_mpm88 {
+  mpm88::Params P{};
+  int device = 0;
+  int64_t n = 0, cap = 0;
+  float *x = nullptr, *v = nullptr, *F = nullptr, *C = nullptr, *Jp = nullptr, *grid = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+};
+static thread_local std::string g_mpm88_create_error;
+static int fail88(mpmhip_mpm88 *m, int code, const std::string &msg) {
+  (m ? m->err : g_mpm88_create_error) = msg;
+  return code;
+}
+#define HIPCHK88(m, call)                                                                                      \
+  do {                                                                                                         \
+    hipError_t e_ = (call);                                                                                    \
+    if (e_ != hipSuccess) return fail88((m), MPMHIP_EHIP, std::string(#call " failed: ") + hipGetErrorString(e_)); \
+  } while (0)
+
+const char *mpmhip_mpm88_last_error(const mpmhip_mpm88 *m) { return m ? m->err.c_str() : g_mpm88_create_error.c_str(); }
+
+int mpmhip_mpm88_create(int32_t n_grid, float dt, int32_t plastic, int32_t device, mpmhip_mpm88 **out) {
+  if (!out || n_grid < 4 || n_grid > 8192 || !(dt > 0.0f)) return fail88(nullptr, MPMHIP_EINVAL, "mpm88: bad n_grid / dt");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail88(nullptr, MPMHIP_EHIP, "no HIP device available: libmpmhip has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail88(nullptr, MPMHIP_EINVAL, "mpm88: no such device");
+  mpmhip_mpm88 *m = new (std::nothrow) mpmhip_mpm88;
+  if (!m) return fail88(nullptr, MPMHIP_ENOMEM, "host allocation failed");
+  m->device = device;
+  const float E = 1e4f, nu = 0.2f;  // mls-mpm88.cpp:8-9
+  m->P.n = n_grid; m->P.dt = dt; m->P.dx = 1.0f / n_grid; m->P.inv_dx = 1.0f / m->P.dx;
+  m->P.mu_0 = E / (2 * (1 + nu)); m->P.lambda_0 = E * nu / ((1 + nu) * (1 - 2 * nu)); m->P.hardening = 10.0f;
+  m->P.mass = 1.0f; m->P.vol = 1.0f; m->P.plastic = plastic ? 1 : 0;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = dmalloc(&m->grid, (size_t)3 * (n_grid + 1) * (n_grid + 1));
+  if (e != hipSuccess) {
+    const int rc = fail88(nullptr, MPMHIP_EHIP, std::string("mpm88 create: ") + hipGetErrorString(e));
+    mpmhip_mpm88_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return MPMHIP_OK;
+}
+
+void mpmhip_mpm88_destroy(mpmhip_mpm88 *m) {
+  if (!m) return;
+  hipSetDevice(m->device);
+  if (m->stream) { hipStreamSynchronize(m->stream); hipStreamDestroy(m->stream); }
+  hipFree(m->x); hipFree(m->v); hipFree(m->F); hipFree(m->C); hipFree(m->Jp); hipFree(m->grid);
+  delete m;
+}
+
+int64_t mpmhip_mpm88_num_particles(const mpmhip_mpm88 *m) { return m ? m->n : MPMHIP_EINVAL; }
+
+int mpmhip_mpm88_add(mpmhip_mpm88 *m, int64_t n, const float *x, const float *v, const float *F, const float *C, const float *Jp) {
+  if (!m || n < 0 || (n > 0 && !x)) return MPMHIP_EINVAL;
+  if (n == 0) return MPMHIP_OK;
+  HIPCHK88(m, hipSetDevice(m->device));
+  HIPCHK88(m, hipStreamSynchronize(m->stream));
+  const int64_t total = m->n + n;
+  if (total > m->cap) {  // grow: new arrays, old contents copied over
+    const int64_t cap = std::max<int64_t>(total, 2 * m->cap);
+    float **arrs[5] = {&m->x, &m->v, &m->F, &m->C, &m->Jp};
+    const int width[5] = {2, 2, 4, 4, 1};
+    for (int a = 0; a < 5; a++) {
+      float *fresh = nullptr;
+      HIPCHK88(m, dmalloc(&fresh, (size_t)cap * width[a]));
+      if (m->n) HIPCHK88(m, hipMemcpy(fresh, *arrs[a], sizeof(float) * m->n * width[a], hipMemcpyDeviceToDevice));
+      (void)hipFree(*arrs[a]);
+      *arrs[a] = fresh;
+    }
+    m->cap = cap;
+  }
+  std::vector<float> h;
+  auto put = [&](float *dst, const float *src, int width, const float *dflt) -> hipError_t {
+    if (!src) {
+      h.resize((size_t)n * width);
+      for (int64_t i = 0; i < n; i++)
+        for (int k = 0; k < width; k++) h[(size_t)i * width + k] = dflt[k];
+      src = h.data();
+    }
+    return hipMemcpy(dst + m->n * width, src, sizeof(float) * n * width, hipMemcpyHostToDevice);
+  };
+  const float zero4[4] = {0, 0, 0, 0}, eye[4] = {1, 0, 0, 1}, one[1] = {1};
+  HIPCHK88(m, put(m->x, x, 2, zero4));
+  HIPCHK88(m, put(m->v, v, 2, zero4));   // Particle(x, c, v = Vec(0)): F(1), C(0), Jp(1)  (mls-mpm88.cpp:12-13)
+  HIPCHK88(m, put(m->F, F, 4, eye));
+  HIPCHK88(m, put(m->C, C, 4, zero4));
+  HIPCHK88(m, put(m->Jp, Jp, 1, one));
+  m->n = total;
+  return MPMHIP_OK;
+}
+
+int mpmhip_mpm88_advance(mpmhip_mpm88 *m, int32_t steps) {
+  if (!m || steps < 0) return MPMHIP_EINVAL;
+  HIPCHK88(m, hipSetDevice(m->device));
+  const int nn = m->P.n + 1;
+  const dim3 pg((unsigned)std::max<int64_t>((m->n + 255) / 256, 1)), gg((unsigned)((nn * nn + 255) / 256)), wg(256);
+  for (int s = 0; s < steps; s++) {
+    HIPCHK88(m, hipMemsetAsync(m->grid, 0, sizeof(float) * 3 * nn * nn, m->stream));  // :17
+    if (m->n)
+      hipLaunchKernelGGL(mpm88::k_p2g, pg, wg, 0, m->stream, m->P, m->n, (const float *)m->x, (const float *)m->v,
+                         (const float *)m->F, (const float *)m->C, (const float *)m->Jp, m->grid);
+    hipLaunchKernelGGL(mpm88::k_grid, gg, wg, 0, m->stream, m->P, m->grid);
+    if (m->n)
+      hipLaunchKernelGGL(mpm88::k_g2p, pg, wg, 0, m->stream, m->P, m->n, m->x, m->v, m->F, m->C, m->Jp, (const float *)m->grid);
+    HIPCHK88(m, hipGetLastError());
+  }
+  return MPMHIP_OK;
+}
+
+int mpmhip_mpm88_download(mpmhip_mpm88 *m, float *x, float *v, float *F, float *C, float *Jp) {
+  if (!m) return MPMHIP_EINVAL;
+  HIPCHK88(m, hipSetDevice(m->device));
+  HIPCHK88(m, hipStreamSynchronize(m->stream));
+  float *dst[5] = {x, v, F, C, Jp};
+  const float *src[5] = {m->x, m->v, m->F, m->C, m->Jp};
+  const int width[5] = {2, 2, 4, 4, 1};
+  for (int a = 0; a < 5; a++)
+    if (dst[a] && m->n) HIPCHK88(m, hipMemcpy(dst[a], src[a], sizeof(float) * m->n * width[a], hipMemcpyDeviceToHost));
+  return MPMHIP_OK;
+}
+
+int mpmhip_mpm88_download_grid(mpmhip_mpm88 *m, float *grid) {
+  if (!m || !grid) return MPMHIP_EINVAL;
+  HIPCHK88(m, hipSetDevice(m->device));
+  HIPCHK88(m, hipStreamSynchronize(m->stream));
+  const int nn = m->P.n + 1;
+  HIPCHK88(m, hipMemcpy(grid, m->grid, sizeof(float) * 3 * nn * nn, hipMemcpyDeviceToHost));
   return MPMHIP_OK;
 }
 

@@ -11,6 +11,7 @@
 #include <random>
 
 #include "mpm_amd/mpm.h"
+#include "mpm_amd/mpm88.h"
 
 using namespace mpm_amd;
 
@@ -175,6 +176,21 @@ static void gpu_tests() {
     }
     std::remove("/tmp/0001.bgeo");
     std::remove("/tmp/0002.bgeo");
+  }
+  {  // the 2D demo (mls-mpm88.cpp): three squares, first step from rest = free fall with v.y = -200 dt
+    MLSMPM88 demo;
+    demo.add_object(0.55f, 0.45f, 0xED553B);
+    demo.add_object(0.45f, 0.65f, 0xF2B134);
+    demo.add_object(0.55f, 0.85f, 0x068587);
+    CHECK(demo.num_particles() == 3000);
+    demo.advance(1);
+    const auto ps = demo.particles();
+    double vy = 0, vx = 0;
+    for (auto &q : ps) { vy += q.v[1]; vx += std::fabs(q.v[0]); }
+    CHECK(std::fabs(vy / ps.size() + 200.0 * 1e-4) < 1e-6 && vx / ps.size() < 1e-6);
+    CHECK(ps[0].c == 0xED553B && ps[2999].c == 0x068587 && std::fabs(ps[5].F[0] - 1.0f) < 1e-5f);
+    demo.advance(200);
+    CHECK(demo.particles()[1500].x[1] < 0.65f + 0.08f);
   }
   // device constitutive code through the particle surface: F = I => zero force; plasticity(cdg) = F <- cdg F for jelly
   MPMParticle p;
