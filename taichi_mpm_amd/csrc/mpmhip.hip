@@ -2,6 +2,7 @@
 // the host side of the ctx.  The kernels live next to this file, one header per phase:
 //   mpm_common.h (records, parameter blocks, Morton keys)   mpm_math.h (3x3 math, constitutive models, level set)
 //   k_sort.h  k_p2g.h  k_grid.h  k_g2p.h  k_tiling.h  k_particles.h  k_debug.h
+//   k_bgeo.h (.bgeo frame rows)   k_mpm88.h (the 2D dense-grid demo, its own small object)
 //
 // One substep (reference: MPM<3>::substep, src/mpm.cpp:452-575):
 //
