@@ -20,7 +20,8 @@ FRICTION = 0.4
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
-    for mat in ("jelly", "snow", "sand", "water"):
+    # default: every registered particle type.  `python tests/golden/make_golden.py visco linear` regenerates a subset
+    for mat in (sys.argv[1:] or ("jelly", "snow", "sand", "water", "linear", "elastic", "von_mises", "visco")):
         x = lattice_cube(RES, 9, 15, DX, jitter=0.2, seed=11)
         s = make_state(x, mat, DX, perturb_F=0.02, seed=12)
         cfg = orc.make_config(RES, DX, DT, planes=PLANES, friction=FRICTION)
