@@ -83,13 +83,53 @@ def kirchhoff_like_force(types, gp, F, aux):
     return out
 
 
+def _approx_exp(dt, M):
+    """ViscoParticle::approximate_exponent (src/particles.cpp:88-100): 1 + s + s^2/2 with s = M dt, halving dt and
+    squaring while the determinant is not positive"""
+    s = M * dt
+    r = (s * 0.5 + np.eye(3)) @ s + np.eye(3)
+    if np.linalg.det(r) > 0:
+        return r
+    h = _approx_exp(dt / 2, M)
+    return h @ h
+
+
+def _visco_plasticity(g, cdg, F_old, tau):
+    """ViscoParticle::plasticity (src/particles.cpp:102-134), one particle, float64.  g = parameter row
+    (mu, lambda at [2], [3]; nu, kappa, dt at [4..6]); F_old = dg_e BEFORE the update (drives the flow)."""
+    mu, lam, vnu, kappa, dt = g[2], g[3], g[4], g[5], g[6]
+    Fh = _approx_exp(dt, (cdg - np.eye(3)) / dt) @ F_old
+    U, s, V = _svd_rot(Fh[None])
+    U, s, V = U[0], s[0], V[0]
+    Uo, so, Vo = _svd_rot(F_old[None])
+    R = Uo[0] @ Vo[0].T
+    J = np.linalg.det(F_old)
+    P = 2 * mu * (F_old - R) + lam * (J - 1) * J * np.linalg.inv(F_old.T)  # first_piola_kirchhoff, :72-80
+    pnorm = np.linalg.norm(P)
+    gamma = min(max(dt * vnu * (pnorm - tau) / pnorm, 0.0), 1.0) if pnorm > 1e-5 else 0.0
+    det = s.prod()
+    scale = 1.0 / det ** (1.0 / 3.0) if abs(det) > 1e-5 else 1.0
+    mid = (s * scale) ** gamma
+    inv = np.where(np.abs(mid) > 1e-5, 1.0 / mid, 1.0)
+    Fn = U @ np.diag(s * inv) @ V.T
+    U2, s2, V2 = _svd_rot(Fn[None])
+    Fn = U2[0] @ np.diag(np.clip(s2[0], 0.1, 10.0)) @ V2[0].T
+    return Fn, tau + kappa * gamma * pnorm
+
+
 def plasticity(types, gp, cdg, F, aux):
+    F_old = F
     F = cdg @ F
     aux = aux.copy()
     for t in np.unique(types):
         m = types == t
         g = gp[m]
         if t in (JELLY, LINEAR, ELASTIC):
+            continue
+        if t == VISCO:
+            idx = np.nonzero(m)[0]
+            for k, i in enumerate(idx):
+                F[i], aux[i] = _visco_plasticity(g[k], cdg[i], F_old[i], aux[i])
             continue
         if t == WATER:
             j = aux[m] * (np.trace(cdg[m], axis1=1, axis2=2) - 2.0)

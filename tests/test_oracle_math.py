@@ -59,7 +59,7 @@ def test_svd2_polar2(orc):
         assert np.allclose(np.sort(np.abs(s))[::-1], np.linalg.svd(F, compute_uv=False), atol=3e-6)
 
 
-MATS = ["jelly", "snow", "linear", "water", "sand", "von_mises", "elastic"]
+MATS = ["jelly", "snow", "linear", "water", "sand", "von_mises", "elastic", "visco"]
 
 
 @pytest.mark.parametrize("mat", MATS)
@@ -82,7 +82,7 @@ def test_plasticity_vs_numpy(orc, mat):
     for _ in range(100):
         F = _rand_F(rng, 0.04)[0]
         cdg = np.eye(3) + rng.normal(0, 0.02, (3, 3))
-        aux = {"snow": 1.0, "water": 1.0, "sand": 0.005}.get(mat, 0.0)
+        aux = {"snow": 1.0, "water": 1.0, "sand": 0.005, "visco": 1000.0}.get(mat, 0.0)
         Fa, auxa = orc.plasticity(t, gp, cdg, F, aux)
         F32 = F.astype(np.float32).astype(np.float64)
         c32 = cdg.astype(np.float32).astype(np.float64)
@@ -155,3 +155,24 @@ def test_friction_project(orc):
     assert np.isclose(out[1], 0)
     vb2 = np.array([0.3, 0.1, 0.0])
     assert np.allclose(orc.friction_project(v, vb2, n, -1), vb2)
+
+
+@pytest.mark.parametrize("tau,kappa", [(10.0, 0.0), (3000.0, 0.4), (1e6, 0.4)])
+def test_visco_flow_branch_vs_numpy(orc, tau, kappa):
+    """ViscoParticle::plasticity (src/particles.cpp:102-134) with the flow active (|P| > tau, 0 < gamma <= 1), with
+    hardening of tau (kappa) and with the flow off (tau above |P|): C++ oracle == numpy restatement"""
+    rng = np.random.default_rng(14)
+    gp, t = orc.group_params("visco", 400 * 1e-6, 1e-6, kappa=kappa)
+    flowed = 0
+    for _ in range(100):
+        F = _rand_F(rng, 0.04)[0]
+        cdg = np.eye(3) + rng.normal(0, 0.02, (3, 3))
+        Fa, auxa = orc.plasticity(t, gp, cdg, F, tau)
+        F32 = F.astype(np.float32).astype(np.float64)
+        c32 = cdg.astype(np.float32).astype(np.float64)
+        Fb, auxb = np_mpm.plasticity(np.array([t]), gp[None].astype(np.float64), c32[None], F32[None], np.array([tau]))
+        assert np.allclose(Fa, Fb[0], atol=2e-5), (Fa, Fb[0])
+        assert abs(auxa - auxb[0]) <= 1e-4 * max(1.0, abs(auxb[0]))
+        still, _ = np_mpm.plasticity(np.array([t]), gp[None].astype(np.float64), c32[None], F32[None], np.array([1e9]))
+        flowed += not np.allclose(Fb[0], still[0], atol=1e-6)  # differs from the same update with the flow switched off
+    assert (flowed > 50) == (tau < 1e5), flowed
