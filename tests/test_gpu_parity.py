@@ -223,6 +223,49 @@ def test_full_substep_matches_oracle(tm, orc, mat):
     sim.close()
 
 
+def _angular_momentum(x, v, B, mass, dx):
+    """sum_p x_p x m v_p + m eps : B_conv^T with B_conv = -dx * apic_b (tests/test_oracle_substep.py has the derivation)"""
+    Bc = -dx * B.reshape(-1, 3, 3).astype(np.float64)
+    eps = np.zeros((3, 3, 3))
+    eps[0, 1, 2] = eps[1, 2, 0] = eps[2, 0, 1] = 1
+    eps[0, 2, 1] = eps[2, 1, 0] = eps[1, 0, 2] = -1
+    return np.cross(x.astype(np.float64), mass * v.astype(np.float64)).sum(0) + mass * np.einsum("ijk,pkj->i", eps, Bc)
+
+
+@pytest.mark.parametrize("spin_only", [False, True], ids=["stirred", "spin_only"])
+def test_apic_transfers_conserve_angular_momentum_on_the_device(tm, spin_only):
+    """no oracle involved: the HIP P2G and G2P against the conservation law that defines APIC transfers — particles ->
+    grid -> particles keeps the total angular momentum including the affine part (F = I: no stress; no gravity, no
+    boundary).  The spin-only state (v = 0, one skew apic_b for all) makes the affine term the whole signal."""
+    x = lattice_cube(RES, 10, 20, DX, jitter=0.3, seed=5)
+    s = make_state(x, "jelly", DX, perturb_F=0.0, vel_scale=3.0)
+    mass = float(s.gparams[0, 0])
+    if spin_only:
+        w = np.array([0.4, -1.1, 0.7])
+        Wx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        s.v[:] = 0
+        s.B[:] = (-(DX / 4.0) * Wx).reshape(1, 9).astype(np.float32)  # apic_b = -B_conv / dx, B_conv = (dx^2 / 4) [w]_x
+    sim = make_sim(tm, s, planes=None, gravity=(0, 0, 0), clean_boundary=False, keep_apic_b=True)
+    L_p = _angular_momentum(s.x, s.v, s.B, mass, DX)
+    if spin_only:
+        assert np.allclose(L_p, s.n * mass * (DX * DX / 4.0) * 2.0 * w, rtol=1e-6)
+    sim.sort_particles_and_populate_grid()
+    sim.rasterize_optimized()
+    g = sim.get_grid(0)  # raw (m v, m) sums
+    nx = RES + 1
+    ii, jj, kk = np.meshgrid(np.arange(nx), np.arange(nx), np.arange(nx), indexing="ij")
+    X = np.stack([ii, jj, kk], -1).reshape(-1, 3) * DX
+    L_g = np.cross(X, g[..., :3].reshape(-1, 3).astype(np.float64)).sum(0)
+    scale = max(np.abs(np.cross(s.x.astype(np.float64), mass * s.v.astype(np.float64))).sum(), np.abs(L_p).sum())
+    assert np.allclose(L_g, L_p, atol=1e-5 * scale), (L_g, L_p)
+    sim.normalize_grid_and_apply_boundary_conditions()
+    sim.resample_optimized()
+    got = sim.get_particles()  # ids = creation order = the order of s
+    L_back = _angular_momentum(s.x, got["v"], got["B"], mass, DX)  # at the positions the transfer used
+    assert np.allclose(L_back, L_g, atol=1e-5 * scale), (L_back, L_g)
+    sim.close()
+
+
 CONFIG_VARIANTS = {
     "apic_damping": dict(apic_damping=0.3),  # scene scripts set one of them, e.g. scripts/mls-cpic/goo_blocks.py:14
     "rpic_damping": dict(rpic_damping=0.2),

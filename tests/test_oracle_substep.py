@@ -149,3 +149,62 @@ def test_blocked_cpu_baseline_matches_plain_oracle(orc):
         assert rel_l2(b.v, a.v) < 1e-4
         assert rel_l2(b.F, a.F) < 1e-5
         assert t > 0 and all(p >= 0 for p in ph)
+
+
+def _angular_momentum_of_particles(x, v, B, mass, dx):
+    """sum_p x_p x m v_p + m eps : B_conv^T with the conventional APIC matrix B_conv = sum_i w v (x_i - x_p)^T in world
+    units = -dx * apic_b (the reference accumulates apic_b with x_p - x_i in grid units)."""
+    Bc = -dx * B.reshape(-1, 3, 3).astype(np.float64)
+    L = np.cross(x.astype(np.float64), mass * v.astype(np.float64)).sum(0)
+    eps = np.zeros((3, 3, 3))
+    eps[0, 1, 2] = eps[1, 2, 0] = eps[2, 0, 1] = 1
+    eps[0, 2, 1] = eps[2, 1, 0] = eps[1, 0, 2] = -1
+    return L + mass * np.einsum("ijk,pkj->i", eps, Bc)  # (eps : B^T)_i = eps_ijk B_kj
+
+
+def test_apic_transfers_conserve_angular_momentum(orc):
+    """the defining property of APIC transfers (Jiang et al. 2015), exact for the quadratic B-spline with D = dx^2/4:
+    particles -> grid -> particles conserves the total angular momentum INCLUDING the affine part.  With F = I (no
+    stress), no gravity and no boundary this pins the sign and the units of apic_b in both transfers by a physical
+    law instead of a second restatement: a flipped sign or a missing factor in either transfer breaks it."""
+    x = lattice_cube(RES, 10, 20, DX, jitter=0.3, seed=5)
+    s = make_state(x, "jelly", DX, perturb_F=0.0, vel_scale=3.0)
+    assert np.abs(s.B).max() > 1e-3  # the affine part matters in this state
+    mass = float(s.gparams[0, 0])
+    cfg = _cfg(orc, gravity=(0, 0, 0), clean_boundary=False)
+    L_p = _angular_momentum_of_particles(s.x, s.v, s.B, mass, DX)
+    grid = orc.p2g(cfg, s)
+    nx = RES + 1
+    ii, jj, kk = np.meshgrid(np.arange(nx), np.arange(nx), np.arange(nx), indexing="ij")
+    X = np.stack([ii, jj, kk], -1).reshape(-1, 3) * DX
+    L_g = np.cross(X, grid[..., :3].reshape(-1, 3).astype(np.float64)).sum(0)
+    scale = np.abs(np.cross(s.x.astype(np.float64), mass * s.v.astype(np.float64))).sum()
+    assert np.allclose(L_g, L_p, atol=3e-6 * scale), (L_g, L_p)
+    x0 = s.x.copy()
+    orc.grid_update(cfg, grid)
+    orc.g2p(cfg, s, grid)
+    L_back = _angular_momentum_of_particles(x0, s.v, s.B, mass, DX)  # at the positions the transfer used
+    assert np.allclose(L_back, L_g, atol=3e-6 * scale), (L_back, L_g)
+
+
+def test_apic_spin_only_state_carries_its_angular_momentum_to_the_grid(orc):
+    """particles at rest that only SPIN (v = 0, apic_b = the same skew matrix for all): every bit of the grid's angular
+    momentum comes from the affine term, so a wrong sign gives -L and a wrong unit a wrong magnitude"""
+    x = lattice_cube(RES, 12, 18, DX, jitter=0.3, seed=6)
+    s = make_state(x, "jelly", DX, perturb_F=0.0)
+    s.v[:] = 0
+    w = np.array([0.4, -1.1, 0.7])  # conventional B_conv = D [w]_x  <=>  rigid spin w of every particle's neighbourhood
+    Wx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    s.B[:] = (-(DX * DX / 4.0) * Wx / DX).reshape(1, 9).astype(np.float32)  # apic_b = -B_conv / dx, B_conv = C D, C = [w]_x
+    mass = float(s.gparams[0, 0])
+    cfg = _cfg(orc, gravity=(0, 0, 0), clean_boundary=False)
+    grid = orc.p2g(cfg, s)
+    nx = RES + 1
+    ii, jj, kk = np.meshgrid(np.arange(nx), np.arange(nx), np.arange(nx), indexing="ij")
+    X = np.stack([ii, jj, kk], -1).reshape(-1, 3) * DX
+    mv = grid[..., :3].reshape(-1, 3).astype(np.float64)
+    assert np.abs(mv.sum(0)).max() <= 1e-6 * np.abs(mv).sum()  # no net linear momentum
+    L_g = np.cross(X, mv).sum(0)
+    L_expected = s.n * mass * (DX * DX / 4.0) * 2.0 * w  # sum_p m eps:(D [w]_x)^T = m (dx^2/4) 2 w per particle
+    assert np.allclose(L_g, L_expected, rtol=1e-4), (L_g, L_expected)
+    assert np.allclose(_angular_momentum_of_particles(s.x, s.v, s.B, mass, DX), L_expected, rtol=1e-6)
