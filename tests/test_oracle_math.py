@@ -176,3 +176,106 @@ def test_visco_flow_branch_vs_numpy(orc, tau, kappa):
         still, _ = np_mpm.plasticity(np.array([t]), gp[None].astype(np.float64), c32[None], F32[None], np.array([1e9]))
         flowed += not np.allclose(Fb[0], still[0], atol=1e-6)  # differs from the same update with the flow switched off
     assert (flowed > 50) == (tau < 1e5), flowed
+
+
+def _energy_density(mat, mu, lam, F):
+    """strain energy densities the models derive from: fixed-corotated (jelly / snow / visco, src/particles.cpp:400-407),
+    small-strain linear (:323-327), Hencky / quadratic-log (elastic :785-796; sand and von_mises use the same elastic law)"""
+    U, s, Vt = np.linalg.svd(F)
+    if mat in ("jelly", "snow", "visco"):
+        R = U @ Vt
+        J = np.linalg.det(F)
+        return mu * ((F - R) ** 2).sum() + 0.5 * lam * (J - 1) ** 2
+    if mat == "linear":
+        e = 0.5 * (F + F.T) - np.eye(3)
+        return mu * (e ** 2).sum() + 0.5 * lam * np.trace(e) ** 2
+    ls = np.log(s)
+    return mu * (ls ** 2).sum() + 0.5 * lam * ls.sum() ** 2
+
+
+@pytest.mark.parametrize("mat", ["jelly", "snow", "visco", "linear", "elastic", "sand", "von_mises"])
+def test_stress_is_the_derivative_of_the_strain_energy(orc, mat):
+    """hyperelasticity ties the stress to an energy: P = d Psi / d F.  A central difference of Psi (numpy, float64)
+    against the oracle's calculate_force() = -vol P F^T checks every elastic law without a second restatement of the
+    stress formula."""
+    rng = np.random.default_rng(31)
+    vol = 1e-6
+    gp, t = orc.group_params(mat, 400 * vol, vol)
+    mu, lam = float(gp[2]), float(gp[3])
+    aux = {"snow": 1.0, "visco": 1000.0}.get(mat, 0.0)  # Jp = 1: no hardening factor
+    h = 1e-5
+    for F in _rand_F(rng, 0.03, 40):
+        F = F.astype(np.float32).astype(np.float64)
+        P = np.zeros((3, 3))
+        for i in range(3):
+            for j in range(3):
+                d = np.zeros((3, 3))
+                d[i, j] = h
+                P[i, j] = (_energy_density(mat, mu, lam, F + d) - _energy_density(mat, mu, lam, F - d)) / (2 * h)
+        want = -vol * P @ F.T
+        got = orc.calculate_force(t, gp, F, aux)
+        assert np.allclose(got, want, rtol=2e-3, atol=2e-4 * np.abs(want).max()), (mat, got, want)
+
+
+def test_sand_return_map_lands_on_or_inside_the_drucker_prager_cone(orc):
+    """after plasticity() the Hencky strain of a sand particle satisfies the yield condition of the projection
+    (src/particles.cpp:599-626): y = |dev eps| + (3 lambda + 2 mu) / (2 mu) * tr(eps) * alpha <= 0 under compression
+    (on the cone, y = 0, whenever the trial state was outside), and the state sits at the tip (eps = 0) under
+    expansion; an idempotent map: projecting again changes nothing"""
+    rng = np.random.default_rng(41)
+    gp, t = orc.group_params("sand", 1.0, 1.0)
+    mu, lam, alpha = float(gp[2]), float(gp[3]), float(gp[4])
+    on_cone = tip = inside = 0
+    for _ in range(300):
+        F0 = np.eye(3) + rng.normal(0, 0.03, (3, 3))
+        cdg = np.eye(3) + rng.normal(0, 0.05, (3, 3))
+        F, logJp = orc.plasticity(t, gp, cdg, F0, 0.0)
+        eps = np.log(np.linalg.svd(F, compute_uv=False))
+        tr = eps.sum()
+        dev = eps - tr / 3
+        y = np.linalg.norm(dev) + (3 * lam + 2 * mu) / (2 * mu) * tr * alpha
+        trial = np.log(np.linalg.svd(cdg.astype(np.float32).astype(np.float64) @ F0.astype(np.float32).astype(np.float64),
+                                     compute_uv=False))
+        if np.abs(eps).max() < 1e-5:
+            tip += 1  # expansion: projected to sigma = 1
+            assert trial.sum() >= -1e-5
+        else:
+            assert y <= 2e-5, (y, eps)
+            y_trial = np.linalg.norm(trial - trial.sum() / 3) + (3 * lam + 2 * mu) / (2 * mu) * trial.sum() * alpha
+            if y_trial > 1e-4:
+                on_cone += 1
+                assert abs(y) <= 2e-5  # returned exactly onto the cone
+                assert abs(tr - trial.sum()) <= 2e-5  # along the deviator: the volumetric strain is kept
+            else:
+                inside += 1
+                assert np.allclose(np.sort(eps), np.sort(trial), atol=2e-5)  # elastic step: untouched
+        F2, _ = orc.plasticity(t, gp, np.eye(3), F, logJp)
+        assert np.allclose(F2, F, atol=2e-5)
+    assert on_cone > 30 and tip > 30 and inside > 5, (on_cone, tip, inside)
+
+
+def test_von_mises_return_map_bounds_the_deviator(orc):
+    """src/particles.cpp:713-732: the squared norm of the deviatoric Hencky strain is capped at yield_stress / (2 mu)...
+    as the reference writes it (dg = |dev|^2 - yield / (2 mu) > 0  =>  eps -= (dg / |dev|^2) dev), i.e. after the map
+    |dev| = |dev_trial| * yield / (2 mu |dev_trial|^2); volume untouched; elastic below the threshold"""
+    rng = np.random.default_rng(42)
+    gp, t = orc.group_params("von_mises", 1.0, 1.0, yield_stress=20.0)
+    mu, ys = float(gp[2]), float(gp[4])
+    plastic = 0
+    for _ in range(200):
+        F0 = np.eye(3) + rng.normal(0, 0.02, (3, 3))
+        cdg = np.eye(3) + rng.normal(0, 0.06, (3, 3))
+        F, _ = orc.plasticity(t, gp, cdg, F0, 0.0)
+        trial = np.log(np.linalg.svd(cdg.astype(np.float32).astype(np.float64) @ F0.astype(np.float32).astype(np.float64),
+                                     compute_uv=False))
+        eps = np.log(np.linalg.svd(F, compute_uv=False))
+        d_t = trial - trial.sum() / 3
+        n2 = (d_t ** 2).sum()
+        assert abs(eps.sum() - trial.sum()) <= 2e-5
+        if n2 - ys / (2 * mu) > 1e-6:
+            plastic += 1
+            want = trial - ((n2 - ys / (2 * mu)) / n2) * d_t
+            assert np.allclose(np.sort(eps), np.sort(want), atol=3e-5)
+        else:
+            assert np.allclose(np.sort(eps), np.sort(trial), atol=3e-5)
+    assert 20 < plastic < 200
