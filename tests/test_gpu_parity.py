@@ -266,6 +266,57 @@ def test_apic_transfers_conserve_angular_momentum_on_the_device(tm, spin_only):
     sim.close()
 
 
+def test_free_rotation_on_the_device_keeps_momentum_angular_momentum_and_energy(tm):
+    """oracle-free: a jelly block spinning in free space for 150 substeps of the HIP path — linear momentum, total angular
+    momentum (with the affine part), kinetic energy and the turning angle (tests/test_oracle_substep.py runs the same
+    scene through the oracle)"""
+    x = lattice_cube(RES, 10, 22, DX)
+    c = x.mean(0).astype(np.float64)
+    s = make_state(x, "jelly", DX, perturb_F=0.0)
+    w = np.array([0.0, 0.0, 5.0])
+    s.v[:] = np.cross(w, x.astype(np.float64) - c).astype(np.float32)
+    Wx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    s.B[:] = (-(DX / 4.0) * Wx).reshape(1, 9).astype(np.float32)
+    mass = float(s.gparams[0, 0])
+    sim = make_sim(tm, s, planes=None, gravity=(0, 0, 0), clean_boundary=False, keep_apic_b=True)
+
+    def state(p):
+        L = _angular_momentum(p["x"] - c.astype(np.float32), p["v"], p["B"], mass, DX)
+        return (mass * p["v"].astype(np.float64)).sum(0), L, 0.5 * mass * (p["v"].astype(np.float64) ** 2).sum()
+    p0, L0, k0 = state(dict(x=s.x, v=s.v, B=s.B))
+    sim.run_substeps(150)
+    got = sim.get_particles()
+    p1, L1, k1 = state(got)
+    assert len(got["x"]) == s.n and np.abs(p1 - p0).max() <= 1e-5 * mass * np.abs(s.v).sum()
+    assert np.allclose(L1, L0, rtol=1e-4, atol=1e-6 * np.abs(L0).max())
+    assert abs(k1 - k0) <= 0.02 * k0
+    assert np.abs(got["x"].astype(np.float64).mean(0) - c).max() <= 1e-5
+    r0, r1 = x[0].astype(np.float64) - c, got["x"][0].astype(np.float64) - c
+    ang = 150 * DT * w[2]
+    assert abs((np.arctan2(r1[1], r1[0]) - np.arctan2(r0[1], r0[0])) - ang) <= 0.03 * ang
+    sim.close()
+
+
+@pytest.mark.parametrize("mat", ["jelly", "elastic", "snow", "linear"])
+def test_compressed_block_expands_and_stretched_block_contracts_on_the_device(tm, mat):
+    """oracle-free sign check of the stress term in the HIP P2G by its physical effect"""
+    x = lattice_cube(RES, 11, 21, DX)
+    c = x.mean(0)
+    for stretch, sign in ((0.97, +1.0), (1.03, -1.0)):
+        s = make_state(x, mat, DX, perturb_F=0.0)
+        s.v[:] = 0
+        s.B[:] = 0
+        s.F[:] = (np.eye(3) * stretch).reshape(1, 9)
+        sim = make_sim(tm, s, planes=None, gravity=(0, 0, 0), clean_boundary=False)
+        sim.run_substeps(3)
+        got = sim.get_particles()
+        radial = ((got["x"] - c) * got["v"]).sum(1)
+        far = np.linalg.norm(got["x"] - c, axis=1) > 0.1
+        r = sign * radial[far].astype(np.float64)
+        assert r.mean() > 0 and (r > 0).mean() > 0.8 and -r[r < 0].sum() < 0.05 * r[r > 0].sum(), (mat, stretch)
+        sim.close()
+
+
 CONFIG_VARIANTS = {
     "apic_damping": dict(apic_damping=0.3),  # scene scripts set one of them, e.g. scripts/mls-cpic/goo_blocks.py:14
     "rpic_damping": dict(rpic_damping=0.2),
