@@ -115,3 +115,19 @@ def test_add_particles_staging_drops_near_boundary():
     with pytest.raises(tm.MPMError):
         sim.add_particles(dict(type="jelly"))
     assert sim.test() and sim.get_name() == "mpm" and sim.get_mpi_world_rank() == 0
+
+
+def test_bench_and_examples_are_importable_without_a_gpu():
+    """bench.py's workload table and traffic lookup, and the example scripts' syntax (nothing here touches a device)"""
+    import importlib.util
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert {"c2", "c3", "c5"} <= set(bench.CONFIGS) and bench.CONFIGS["c3"]["res"] == 256 and bench.CONFIGS["c3"]["cells"] == 100
+    tbytes, src = bench.pmc_traffic("c3", "k_g2p")
+    assert tbytes and 1.0e9 < tbytes < 3.0e9 and "rocprofv3" in src  # the committed PMC passes (profiles/traffic_c3.json)
+    assert bench.pmc_traffic("c2", "k_g2p") == (None, None)
+    for f in ("benchmark_3d.py", "sand_column.py"):
+        py_compile.compile(os.path.join(root, "examples", f), doraise=True)
