@@ -1,0 +1,444 @@
+// oracle/ref_mpm_driver.cpp — TEST INFRASTRUCTURE (never shipped, never on the product path).
+//
+// C-ABI driver around the REFERENCE's own solver, compiled from its sources where they lie
+// (/root/reference/src/{mpm,transfer,visualize}.cpp as separate objects, particles.cpp included below because the
+// material classes are defined in that .cpp) against oracle/taichi_shim — see the header of
+// oracle/taichi_shim/taichi/common/util.h for what that stand-in provides and what it cannot pin (svd/polar_decomp
+// and the sampled level set of the absent taichi core).  Built by `make -C oracle ref_mpm` into
+// oracle/_ref/libmpm_ref.so.  Used (i) to check the restated oracle (oracle/mpm_oracle.cpp) and the HIP library
+// against the reference's real arithmetic, (ii) to generate tests/golden/ref_*.npz, (iii) as the `cpu_baseline` of
+// bench.py (kind "reference").
+//
+// Everything here only moves data in and out of the reference's own objects (MPM<dim>, MPMParticle<dim>):
+// no arithmetic of the path is written in this file.  Matrices cross this ABI row-major (m[dim*r + c]); the
+// reference stores columns (Matrix[i] = column i).
+#include <taichi/common/util.h>
+
+#include "particles.cpp"  // the reference's constitutive models (class definitions live in the .cpp)
+
+#include "kernel.h"
+#include "mpm.h"
+
+TC_NAMESPACE_BEGIN
+
+// CPIC rigid coupling (src/mpm_rigid_body.cpp, src/rigid_transfer.cpp) is outside this build: with only the
+// background body present (has_rigid_body() == false) substep() never reaches these.
+#define SHIM_RIGID_STUBS(D)                                                           \
+  template <> void MPM<D>::gather_cdf() { TC_NOT_IMPLEMENTED }                        \
+  template <> void MPM<D>::add_rigid_particle(Config) { TC_NOT_IMPLEMENTED }          \
+  template <> void MPM<D>::advect_rigid_bodies(real) { TC_NOT_IMPLEMENTED }           \
+  template <> void MPM<D>::rasterize_rigid_boundary() { TC_NOT_IMPLEMENTED }          \
+  template <> void MPM<D>::rigid_body_levelset_collision(real, real) { TC_NOT_IMPLEMENTED } \
+  template <> void MPM<D>::rigidify(real) { TC_NOT_IMPLEMENTED }
+SHIM_RIGID_STUBS(2)
+SHIM_RIGID_STUBS(3)
+
+namespace {
+
+thread_local std::string g_err;
+
+template <int dim>
+MatrixND<dim, real> mat_in(const float *m) {
+  MatrixND<dim, real> M;
+  for (int r = 0; r < dim; r++)
+    for (int c = 0; c < dim; c++) M[c][r] = m[dim * r + c];
+  return M;
+}
+template <int dim>
+void mat_out(const MatrixND<dim, real> &M, float *m) {
+  for (int r = 0; r < dim; r++)
+    for (int c = 0; c < dim; c++) m[dim * r + c] = M[c][r];
+}
+
+// the one scalar of material state outside dg_e: Jp (snow), j (water), logJp (sand), visco_tau (visco)
+template <int dim>
+real *aux_ptr(MPMParticle<dim> *p) {
+  if (auto q = dynamic_cast<SnowParticle<dim> *>(p)) return &q->Jp;
+  if (auto q = dynamic_cast<WaterParticle<dim> *>(p)) return &q->j;
+  if (auto q = dynamic_cast<SandParticle<dim> *>(p)) return &q->logJp;
+  if (auto q = dynamic_cast<ViscoParticle<dim> *>(p)) return &q->visco_tau;
+  return nullptr;
+}
+
+struct Handle {
+  int dim = 3;
+  std::unique_ptr<MPM<2>> m2;
+  std::unique_ptr<MPM<3>> m3;
+};
+
+template <int dim> MPM<dim> &sim(Handle *h);
+template <> MPM<2> &sim<2>(Handle *h) { return *h->m2; }
+template <> MPM<3> &sim<3>(Handle *h) { return *h->m3; }
+
+template <int dim>
+int add_particles(Handle *h, const Config &cfg, int64_t n, const float *x, const float *v, const float *F, const float *B,
+                  const float *aux) {
+  MPM<dim> &m = sim<dim>(h);
+  const std::string type = cfg.get<std::string>("type");
+  const real vol = cfg.get<real>("vol"), mass = cfg.get<real>("mass");
+  for (int64_t i = 0; i < n; i++) {  // = create_particle, src/mpm.cpp:101-147, with explicit state
+    auto alloc = m.allocator.allocate_particle(type);
+    MPMParticle<dim> *p = alloc.second;
+    p->initialize(cfg);
+    VectorND<dim, real> pos, vel(0.0f);
+    for (int k = 0; k < dim; k++) { pos[k] = x[dim * i + k]; if (v) vel[k] = v[dim * i + k]; }
+    p->pos = pos;
+    p->vol = vol;
+    p->set_mass(mass);
+    p->set_velocity(vel);
+    if (F) p->dg_e = mat_in<dim>(F + dim * dim * i);
+    if (B) p->apic_b = mat_in<dim>(B + dim * dim * i);
+    if (aux) if (real *a = aux_ptr<dim>(p)) *a = aux[i];
+    m.particles.push_back(alloc.first);
+  }
+  return 0;
+}
+
+template <int dim>
+int64_t download(Handle *h, float *x, float *v, float *F, float *B, float *aux, int32_t *id) {
+  MPM<dim> &m = sim<dim>(h);
+  int64_t i = 0;
+  for (auto pi : m.particles) {
+    MPMParticle<dim> *p = m.allocator[pi];
+    auto vel = p->get_velocity();
+    for (int k = 0; k < dim; k++) { if (x) x[dim * i + k] = p->pos[k]; if (v) v[dim * i + k] = vel[k]; }
+    if (F) mat_out<dim>(p->dg_e, F + dim * dim * i);
+    if (B) mat_out<dim>(p->apic_b, B + dim * dim * i);
+    if (aux) { real *a = aux_ptr<dim>(p); aux[i] = a ? *a : 0.0f; }
+    if (id) id[i] = p->id;
+    i++;
+  }
+  return i;
+}
+
+// dense (res+1)^dim x (dim+1) view of the reference's sparse grid: velocity_and_mass of every allocated node
+template <int dim>
+int grid_io(Handle *h, float *dense, bool upload) {
+  MPM<dim> &m = sim<dim>(h);
+  using Mask = typename MPM<dim>::SparseMask;
+  auto blocks = m.fat_page_map->Get_Blocks();
+  auto bs = m.grid_block_size();
+  for (unsigned b = 0; b < blocks.second; b++) {
+    VectorND<dim, int> base(Mask::LinearToCoord(blocks.first[b]));
+    for (auto &ind : RegionND<dim>(VectorND<dim, int>(0), bs)) {
+      VectorND<dim, int> g = base + ind.get_ipos();
+      bool in = true;
+      size_t lin = 0;
+      for (int k = 0; k < dim; k++) { in = in && g[k] <= m.res[k]; lin = lin * (m.res[k] + 1) + g[k]; }
+      if (!in) continue;
+      auto &node = m.get_grid(g).velocity_and_mass;
+      for (int k = 0; k <= dim; k++) {
+        if (upload) node[k] = dense[lin * (dim + 1) + k];
+        else dense[lin * (dim + 1) + k] = node[k];
+      }
+    }
+  }
+  return 0;
+}
+
+template <int dim>
+void set_levelset(Handle *h, int n, const float *shapes, float friction) {
+  MPM<dim> &m = sim<dim>(h);
+  auto L = std::make_shared<LevelSet<dim>>();
+  L->friction = friction;
+  L->delta_x = m.delta_x;
+  for (int i = 0; i < n; i++) {  // rows of 11 floats: type, inside_out, p[6], vel[3]
+    const float *r = shapes + 11 * i;
+    ShimShape s;
+    s.type = (int)r[0]; s.inside_out = (int)r[1];
+    for (int k = 0; k < 6; k++) s.p[k] = r[2 + k];
+    for (int k = 0; k < 3; k++) s.vel[k] = r[8 + k];
+    L->shapes.push_back(s);
+  }
+  m.levelset.levelset0 = L;
+}
+
+template <int dim>
+int phase(Handle *h, int which, int optimized) {
+  MPM<dim> &m = sim<dim>(h);
+  const real dt = m.base_delta_t;
+  switch (which) {
+    case 0: m.sort_particles_and_populate_grid(); break;                      // src/mpm.cpp:770-918
+    case 1: if (optimized) m.rasterize_optimized(dt); else m.rasterize(dt); break;  // src/transfer.cpp:193-283,361-581
+    case 2:                                                                    // src/mpm.cpp:524-533
+      m.normalize_grid_and_apply_external_force(m.particle_gravity ? VectorND<dim, real>(0.0f) : m.gravity * dt);
+      m.apply_grid_boundary_conditions(m.levelset, m.current_t);
+      break;
+    case 3: if (optimized) m.resample_optimized(); else m.resample(); break;  // src/transfer.cpp:585-700,702-970
+    case 4: m.clear_boundary_particles(); break;                              // src/mpm.cpp:582-633
+    case 5: m.particle_collision_resolution(m.current_t); break;              // src/mpm.cpp:414-426
+    case 6: m.normalize_grid_and_apply_external_force(m.particle_gravity ? VectorND<dim, real>(0.0f) : m.gravity * dt); break;
+    default: return -1;
+  }
+  return 0;
+}
+
+template <int dim>
+MPMParticle<dim> *scratch_particle(const Config &cfg, std::vector<uint8> &buf) {
+  buf.assign(get_particle_size_upper_bound<dim>(), 0);
+  MPMParticle<dim> *p = create_instance_placement<MPMParticle<dim>>(cfg.get<std::string>("type"), buf.data());
+  p->initialize(cfg);
+  p->vol = cfg.get<real>("vol");
+  p->set_mass(cfg.get<real>("mass"));
+  return p;
+}
+
+template <typename F>
+int guarded(const F &f) {
+  try {
+    return f();
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+}  // namespace
+
+TC_NAMESPACE_END
+
+using namespace taichi;
+
+#define DISPATCH(h, expr2, expr3) ((h)->dim == 2 ? (expr2) : (expr3))
+
+extern "C" {
+
+const char *ref_last_error() { return g_err.c_str(); }
+
+int ref_set_threads(int n) {
+  ShimRuntime::get().threads = n > 0 ? n : omp_get_max_threads();
+  return ShimRuntime::get().threads;
+}
+
+// cfg: "res=(32,32,32);delta_x=0.03125;base_delta_t=1e-4;gravity=(0,-10,0);..." — the keys of MPM<dim>::initialize
+void *ref_create(int dim, const char *cfg) {
+  Handle *h = nullptr;
+  const int rc = guarded([&] {
+    h = new Handle();
+    h->dim = dim;
+    Config c = Config::from_string(cfg);
+    if (!c.has_key("num_threads")) c.set("num_threads", ShimRuntime::get().threads);
+    if (dim == 2) { h->m2 = std::make_unique<MPM<2>>(); h->m2->initialize(c); set_levelset<2>(h, 0, nullptr, 1.0f); }
+    else if (dim == 3) { h->m3 = std::make_unique<MPM<3>>(); h->m3->initialize(c); set_levelset<3>(h, 0, nullptr, 1.0f); }
+    else TC_ERROR("dim must be 2 or 3");
+    return 0;
+  });
+  if (rc) { delete h; return nullptr; }
+  return h;
+}
+void ref_destroy(void *h) { delete (Handle *)h; }
+
+int ref_set_levelset(void *hh, int n, const float *shapes, float friction) {
+  Handle *h = (Handle *)hh;
+  return guarded([&] { DISPATCH(h, set_levelset<2>(h, n, shapes, friction), set_levelset<3>(h, n, shapes, friction)); return 0; });
+}
+
+// type_cfg: "type=sand;mass=..;vol=..;<the material's own config keys>"
+int ref_add_particles(void *hh, const char *type_cfg, int64_t n, const float *x, const float *v, const float *F, const float *B,
+                      const float *aux) {
+  Handle *h = (Handle *)hh;
+  return guarded([&] {
+    Config c = Config::from_string(type_cfg);
+    return DISPATCH(h, add_particles<2>(h, c, n, x, v, F, B, aux), add_particles<3>(h, c, n, x, v, F, B, aux));
+  });
+}
+// the reference's own generator (src/mpm.cpp:149-186): cfg "type=..;benchmark=125|8000;<material keys>"
+int ref_add_particles_cfg(void *hh, const char *cfg) {
+  Handle *h = (Handle *)hh;
+  return guarded([&] {
+    Config c = Config::from_string(cfg);
+    DISPATCH(h, h->m2->add_particles(c), h->m3->add_particles(c));
+    return 0;
+  });
+}
+int64_t ref_num_particles(void *hh) {
+  Handle *h = (Handle *)hh;
+  return DISPATCH(h, (int64_t)h->m2->particles.size(), (int64_t)h->m3->particles.size());
+}
+int64_t ref_download(void *hh, float *x, float *v, float *F, float *B, float *aux, int32_t *id) {
+  Handle *h = (Handle *)hh;
+  int64_t n = -1;
+  guarded([&] { n = DISPATCH(h, download<2>(h, x, v, F, B, aux, id), download<3>(h, x, v, F, B, aux, id)); return 0; });
+  return n;
+}
+int ref_download_grid(void *hh, float *dense) {
+  Handle *h = (Handle *)hh;
+  return guarded([&] { return DISPATCH(h, grid_io<2>(h, dense, false), grid_io<3>(h, dense, false)); });
+}
+int ref_upload_grid(void *hh, const float *dense) {
+  Handle *h = (Handle *)hh;
+  return guarded([&] { return DISPATCH(h, grid_io<2>(h, const_cast<float *>(dense), true), grid_io<3>(h, const_cast<float *>(dense), true)); });
+}
+int ref_substep(void *hh, int n) {
+  Handle *h = (Handle *)hh;
+  return guarded([&] {
+    for (int i = 0; i < n; i++) DISPATCH(h, h->m2->substep(), h->m3->substep());
+    return 0;
+  });
+}
+int ref_step(void *hh, float dt) {
+  Handle *h = (Handle *)hh;
+  return guarded([&] { DISPATCH(h, h->m2->step(dt), h->m3->step(dt)); return 0; });
+}
+// which: 0 sort+populate, 1 P2G, 2 grid normalise + boundary, 3 G2P, 4 clear_boundary_particles, 5 particle collision,
+// 6 grid normalise only
+int ref_phase(void *hh, int which, int optimized) {
+  Handle *h = (Handle *)hh;
+  return guarded([&] { return DISPATCH(h, phase<2>(h, which, optimized), phase<3>(h, which, optimized)); });
+}
+double ref_time(void *hh) {
+  Handle *h = (Handle *)hh;
+  return DISPATCH(h, (double)h->m2->current_t, (double)h->m3->current_t);
+}
+int ref_set_time(void *hh, double t) {
+  Handle *h = (Handle *)hh;
+  DISPATCH(h, h->m2->current_t = (real)t, h->m3->current_t = (real)t);
+  return 0;
+}
+double ref_calculate_energy(void *hh) {
+  Handle *h = (Handle *)hh;
+  double e = std::nan("");
+  guarded([&] { e = DISPATCH(h, (double)h->m2->calculate_energy(), (double)h->m3->calculate_energy()); return 0; });
+  return e;
+}
+int ref_write_bgeo(void *hh, const char *path) {  // MPM<dim>::write_partio, src/visualize.cpp:17-100
+  Handle *h = (Handle *)hh;
+  return guarded([&] { DISPATCH(h, h->m2->write_partio(path), h->m3->write_partio(path)); return 0; });
+}
+int ref_general_action(void *hh, const char *cfg, char *out, size_t cap) {
+  Handle *h = (Handle *)hh;
+  return guarded([&] {
+    Config c = Config::from_string(cfg);
+    std::string r = DISPATCH(h, h->m2->general_action(c), h->m3->general_action(c));
+    if (out && cap) { std::snprintf(out, cap, "%s", r.c_str()); }
+    return 0;
+  });
+}
+
+// seconds per TC_PROFILE name since the last reset, as "name=seconds;..."
+int ref_profile(char *out, size_t cap, int reset) {
+  auto &r = ShimRuntime::get();
+  std::string s;
+  for (auto &kv : r.seconds) { char b[256]; std::snprintf(b, sizeof b, "%s=%.9g;", kv.first.c_str(), kv.second); s += b; }
+  if (out && cap) std::snprintf(out, cap, "%s", s.c_str());
+  if (reset) r.seconds.clear();
+  return 0;
+}
+
+// ---- single-particle entry points (materials, kernels, friction) ------------------------------------------------
+int ref_calculate_force(int dim, const char *type_cfg, int64_t n, const float *F, const float *aux, float *out) {
+  return guarded([&] {
+    Config c = Config::from_string(type_cfg);
+    std::vector<uint8> buf;
+    for (int64_t i = 0; i < n; i++) {
+      if (dim == 3) {
+        auto *p = scratch_particle<3>(c, buf);
+        p->dg_e = mat_in<3>(F + 9 * i);
+        if (real *a = aux_ptr<3>(p)) *a = aux[i];
+        mat_out<3>(p->calculate_force(), out + 9 * i);
+      } else {
+        auto *p = scratch_particle<2>(c, buf);
+        p->dg_e = mat_in<2>(F + 4 * i);
+        if (real *a = aux_ptr<2>(p)) *a = aux[i];
+        mat_out<2>(p->calculate_force(), out + 4 * i);
+      }
+    }
+    return 0;
+  });
+}
+int ref_plasticity(int dim, const char *type_cfg, int64_t n, const float *cdg, float *F, float *aux) {
+  return guarded([&] {
+    Config c = Config::from_string(type_cfg);
+    std::vector<uint8> buf;
+    for (int64_t i = 0; i < n; i++) {
+      if (dim == 3) {
+        auto *p = scratch_particle<3>(c, buf);
+        p->dg_e = mat_in<3>(F + 9 * i);
+        real *a = aux_ptr<3>(p);
+        if (a) *a = aux[i];
+        p->plasticity(mat_in<3>(cdg + 9 * i));
+        mat_out<3>(p->dg_e, F + 9 * i);
+        if (a) aux[i] = *a;
+      } else {
+        auto *p = scratch_particle<2>(c, buf);
+        p->dg_e = mat_in<2>(F + 4 * i);
+        real *a = aux_ptr<2>(p);
+        if (a) *a = aux[i];
+        p->plasticity(mat_in<2>(cdg + 4 * i));
+        mat_out<2>(p->dg_e, F + 4 * i);
+        if (a) aux[i] = *a;
+      }
+    }
+    return 0;
+  });
+}
+// get_allowed_dt(dx) and potential_energy() of one particle state (3D)
+int ref_particle_scalars(const char *type_cfg, int64_t n, const float *F, const float *aux, const float *v, float dx,
+                         float *allowed_dt, float *potential) {
+  return guarded([&] {
+    Config c = Config::from_string(type_cfg);
+    std::vector<uint8> buf;
+    for (int64_t i = 0; i < n; i++) {
+      auto *p = scratch_particle<3>(c, buf);
+      p->dg_e = mat_in<3>(F + 9 * i);
+      if (real *a = aux_ptr<3>(p)) *a = aux[i];
+      p->set_velocity(Vector3(v[3 * i], v[3 * i + 1], v[3 * i + 2]));
+      if (allowed_dt) allowed_dt[i] = p->get_allowed_dt(dx);
+      if (potential) {
+        try { potential[i] = p->potential_energy(); } catch (const ShimError &) { potential[i] = std::nanf(""); }
+      }
+    }
+    return 0;
+  });
+}
+// MPMKernel<3,2> (kind 0), MPMFastKernel32 (kind 1): get_dw_w of the 27 stencil nodes -> out[27][4]
+int ref_kernel3(int kind, const float *pos, float inv_dx, float *out) {
+  return guarded([&] {
+    const Vector3 p(pos[0], pos[1], pos[2]);
+    int n = 0;
+    if (kind == 0) {
+      MPMKernel<3, 2> k(p, inv_dx);
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int l = 0; l < 3; l++, n++) {
+        const Vector4 w = k.get_dw_w(Vector3i(i, j, l));
+        for (int q = 0; q < 4; q++) out[4 * n + q] = w[q];
+      }
+    } else {
+      MPMFastKernel32 k(p, inv_dx);
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int l = 0; l < 3; l++, n++) {
+        const Vector4 w = k.get_dw_w(Vector3i(i, j, l));
+        for (int q = 0; q < 4; q++) out[4 * n + q] = w[q];
+      }
+    }
+    return 0;
+  });
+}
+int ref_kernel2(const float *pos, float inv_dx, float *out) {  // MPMKernel<2,2>: out[9][3]
+  return guarded([&] {
+    MPMKernel<2, 2> k(Vector2(pos[0], pos[1]), inv_dx);
+    int n = 0;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++, n++) {
+      const Vector3 w = k.get_dw_w(Vector2i(i, j));
+      for (int q = 0; q < 3; q++) out[3 * n + q] = w[q];
+    }
+    return 0;
+  });
+}
+int ref_stencil_start(float x) { return MPMKernel<3, 2>::get_stencil_start(x); }
+int ref_friction_project(const float *v, const float *vb, const float *n, float mu, float *out) {
+  return guarded([&] {
+    const Vector3 r = friction_project<3>(Vector3(v[0], v[1], v[2]), Vector3(vb[0], vb[1], vb[2]), Vector3(n[0], n[1], n[2]), mu);
+    for (int k = 0; k < 3; k++) out[k] = r[k];
+    return 0;
+  });
+}
+// the shim's own svd / polar_decomp (NOT reference code): exposed so the tests can state how far the restated oracle's
+// fp32 routines are from an exact decomposition
+int ref_shim_svd3(const float *F, float *U, float *S, float *V) {
+  Matrix3 u, s, v;
+  svd(mat_in<3>(F), u, s, v);
+  mat_out<3>(u, U); mat_out<3>(v, V);
+  for (int i = 0; i < 3; i++) S[i] = s[i][i];
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,303 @@
+"""ctypes binding of oracle/_ref/libmpm_ref.so (TEST INFRASTRUCTURE ONLY).
+
+libmpm_ref.so is the REFERENCE's own solver: /root/reference/src/{mpm,transfer,visualize,particles}.cpp compiled from the
+sources where they lie (oracle/Makefile: ref_mpm) against oracle/taichi_shim, our stand-in for the un-vendored legacy
+taichi core.  What that pins and what it cannot (svd / polar_decomp, the sampled level set) is stated in the header
+of oracle/taichi_shim/taichi/common/util.h and in DESIGN.md §2.
+
+The binding mirrors oracle/oracle.py (same State, same matrix layout: row-major float[9]) so a test can run the same
+scene through the restated oracle, the reference and the HIP library.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_ref", "libmpm_ref.so")
+_lib = None
+
+P_F = C.POINTER(C.c_float)
+P_I = C.POINTER(C.c_int32)
+
+
+def available():
+    return os.path.exists(_LIB)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "ref_mpm"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not available():
+            raise RuntimeError("oracle/_ref/libmpm_ref.so is missing: run `make -C oracle ref_mpm` where /root/reference exists")
+        L = C.CDLL(_LIB)
+        L.ref_last_error.restype = C.c_char_p
+        L.ref_create.restype = C.c_void_p
+        L.ref_create.argtypes = [C.c_int, C.c_char_p]
+        L.ref_destroy.argtypes = [C.c_void_p]
+        L.ref_num_particles.restype = C.c_int64
+        L.ref_num_particles.argtypes = [C.c_void_p]
+        L.ref_download.restype = C.c_int64
+        L.ref_download.argtypes = [C.c_void_p, P_F, P_F, P_F, P_F, P_F, P_I]
+        L.ref_add_particles.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, P_F, P_F, P_F, P_F, P_F]
+        L.ref_add_particles_cfg.argtypes = [C.c_void_p, C.c_char_p]
+        L.ref_set_levelset.argtypes = [C.c_void_p, C.c_int, P_F, C.c_float]
+        L.ref_download_grid.argtypes = [C.c_void_p, P_F]
+        L.ref_upload_grid.argtypes = [C.c_void_p, P_F]
+        L.ref_substep.argtypes = [C.c_void_p, C.c_int]
+        L.ref_step.argtypes = [C.c_void_p, C.c_float]
+        L.ref_phase.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ref_time.restype = C.c_double
+        L.ref_time.argtypes = [C.c_void_p]
+        L.ref_set_time.argtypes = [C.c_void_p, C.c_double]
+        L.ref_calculate_energy.restype = C.c_double
+        L.ref_calculate_energy.argtypes = [C.c_void_p]
+        L.ref_write_bgeo.argtypes = [C.c_void_p, C.c_char_p]
+        L.ref_general_action.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.ref_profile.argtypes = [C.c_char_p, C.c_size_t, C.c_int]
+        L.ref_calculate_force.argtypes = [C.c_int, C.c_char_p, C.c_int64, P_F, P_F, P_F]
+        L.ref_plasticity.argtypes = [C.c_int, C.c_char_p, C.c_int64, P_F, P_F, P_F]
+        L.ref_particle_scalars.argtypes = [C.c_char_p, C.c_int64, P_F, P_F, P_F, C.c_float, P_F, P_F]
+        L.ref_kernel3.argtypes = [C.c_int, P_F, C.c_float, P_F]
+        L.ref_kernel2.argtypes = [P_F, C.c_float, P_F]
+        L.ref_stencil_start.argtypes = [C.c_float]
+        L.ref_friction_project.argtypes = [P_F, P_F, P_F, C.c_float, P_F]
+        L.ref_shim_svd3.argtypes = [P_F, P_F, P_F, P_F]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise RuntimeError("reference: " + lib().ref_last_error().decode())
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(P_F)
+
+
+def _fmt(v):
+    if isinstance(v, bool):
+        return "true" if v else "false"
+    if isinstance(v, (tuple, list, np.ndarray)):
+        return "(" + ",".join(_fmt(x) for x in v) + ")"
+    if isinstance(v, (float, np.floating)):
+        return "%.9g" % float(v)
+    return str(v)
+
+
+def cfg_string(**kw):
+    return ";".join("%s=%s" % (k, _fmt(v)) for k, v in kw.items()).encode()
+
+
+def set_threads(n):
+    return lib().ref_set_threads(int(n))
+
+
+def type_config(type_name, mass, vol, **mat_kw):
+    """the material's own Config keys (MPMParticle subclasses' initialize(), src/particles.cpp) + mass / vol"""
+    return cfg_string(type=type_name, mass=mass, vol=vol, **mat_kw)
+
+
+class Sim:
+    """MPM<dim> of the reference (create_simulation3('mpm') / create_simulation2('mpm'))"""
+
+    def __init__(self, res, dx, dt, dim=3, gravity=None, shapes=(), friction=1.0, **cfg):
+        self.dim = dim
+        if np.isscalar(res):
+            res = (int(res),) * dim
+        self.res = tuple(int(r) for r in res)
+        if gravity is None:
+            gravity = (0, -10, 0)[:dim]
+        s = cfg_string(res=self.res, delta_x=dx, base_delta_t=dt, gravity=tuple(gravity), **cfg)
+        self.h = lib().ref_create(dim, s)
+        if not self.h:
+            raise RuntimeError("reference: " + lib().ref_last_error().decode())
+        self.set_levelset(shapes, friction)
+
+    def close(self):
+        if self.h:
+            lib().ref_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_levelset(self, shapes=(), friction=1.0):
+        """shapes: rows (type, inside_out, p0..p5[, vx, vy, vz]) in WORLD units: type 0 plane (n, d), 1 sphere
+        (c, r), 2 cuboid (lo, hi); an optional constant velocity moves the shape rigidly."""
+        rows = np.zeros((len(shapes), 11), np.float32)
+        for i, sh in enumerate(shapes):
+            sh = [float(v) for v in sh]
+            rows[i, :len(sh)] = sh
+        _chk(lib().ref_set_levelset(self.h, len(shapes), rows.ctypes.data_as(P_F), C.c_float(friction)))
+
+    def add_particles(self, type_name, mass, vol, x, v=None, F=None, B=None, aux=None, **mat_kw):
+        d = self.dim
+        x, xp = _f(np.asarray(x).reshape(-1, d))
+        n = len(x)
+
+        def opt(a, w):
+            if a is None:
+                return None, None
+            a, p = _f(np.asarray(a).reshape(n, w) if w > 1 else np.asarray(a).reshape(n))
+            return a, p
+        v, vp = opt(v, d); F, Fp = opt(F, d * d); B, Bp = opt(B, d * d); aux, ap = opt(aux, 1)
+        _chk(lib().ref_add_particles(self.h, type_config(type_name, mass, vol, **mat_kw), n, xp, vp, Fp, Bp, ap))
+
+    def add_benchmark(self, type_name, benchmark, **mat_kw):
+        """the reference's own lattice generator, src/mpm.cpp:149-186 (benchmark = 125 or 8000)"""
+        _chk(lib().ref_add_particles_cfg(self.h, cfg_string(type=type_name, benchmark=benchmark, **mat_kw)))
+
+    def num_particles(self):
+        return int(lib().ref_num_particles(self.h))
+
+    def download(self, by_id=True):
+        n, d = self.num_particles(), self.dim
+        out = dict(x=np.zeros((n, d), np.float32), v=np.zeros((n, d), np.float32), F=np.zeros((n, d * d), np.float32),
+                   B=np.zeros((n, d * d), np.float32), aux=np.zeros(n, np.float32), id=np.zeros(n, np.int32))
+        m = lib().ref_download(self.h, *(out[k].ctypes.data_as(P_F) for k in ("x", "v", "F", "B", "aux")),
+                               out["id"].ctypes.data_as(P_I))
+        if m != n:
+            raise RuntimeError("reference: " + lib().ref_last_error().decode())
+        if by_id:
+            o = np.argsort(out["id"], kind="stable")
+            out = {k: a[o] for k, a in out.items()}
+        return out
+
+    def grid_shape(self):
+        return tuple(r + 1 for r in self.res) + (self.dim + 1,)
+
+    def download_grid(self):
+        g = np.zeros(self.grid_shape(), np.float32)
+        _chk(lib().ref_download_grid(self.h, g.ctypes.data_as(P_F)))
+        return g
+
+    def upload_grid(self, g):
+        g, gp = _f(np.asarray(g).reshape(self.grid_shape()))
+        _chk(lib().ref_upload_grid(self.h, gp))
+
+    def substep(self, n=1):
+        _chk(lib().ref_substep(self.h, int(n)))
+
+    def step(self, dt):
+        _chk(lib().ref_step(self.h, C.c_float(dt)))
+
+    def sort(self):
+        _chk(lib().ref_phase(self.h, 0, 1))
+
+    def p2g(self, optimized=True):
+        _chk(lib().ref_phase(self.h, 1, int(optimized)))
+
+    def grid_update(self):
+        _chk(lib().ref_phase(self.h, 2, 1))
+
+    def g2p(self, optimized=True):
+        _chk(lib().ref_phase(self.h, 3, int(optimized)))
+
+    def clear_boundary_particles(self):
+        _chk(lib().ref_phase(self.h, 4, 1))
+
+    def particle_collision(self):
+        _chk(lib().ref_phase(self.h, 5, 1))
+
+    def time(self):
+        return lib().ref_time(self.h)
+
+    def set_time(self, t):
+        lib().ref_set_time(self.h, float(t))
+
+    def calculate_energy(self):
+        return lib().ref_calculate_energy(self.h)
+
+    def write_bgeo(self, path):
+        _chk(lib().ref_write_bgeo(self.h, os.fsencode(path)))
+
+    def general_action(self, **kw):
+        buf = C.create_string_buffer(4096)
+        _chk(lib().ref_general_action(self.h, cfg_string(**kw), buf, 4096))
+        return buf.value.decode()
+
+
+def profile(reset=False):
+    """seconds per TC_PROFILE name of the reference ('P2G optimized', 'G2P optimized', 'parallel_sort', ...)"""
+    buf = C.create_string_buffer(1 << 16)
+    lib().ref_profile(buf, 1 << 16, int(reset))
+    out = {}
+    for kv in buf.value.decode().split(";"):
+        if "=" in kv:
+            k, v = kv.rsplit("=", 1)
+            out[k] = float(v)
+    return out
+
+
+# ----------------------------------------------------------------------------- single-particle entry points
+def calculate_force(type_name, mass, vol, F, aux=None, dim=3, **mat_kw):
+    F, fp = _f(np.asarray(F).reshape(-1, dim * dim))
+    n = len(F)
+    aux, ap = _f(np.zeros(n) if aux is None else np.broadcast_to(np.asarray(aux, np.float32), (n,)))
+    out = np.zeros_like(F)
+    _chk(lib().ref_calculate_force(dim, type_config(type_name, mass, vol, **mat_kw), n, fp, ap, out.ctypes.data_as(P_F)))
+    return out
+
+
+def plasticity(type_name, mass, vol, cdg, F, aux=None, dim=3, **mat_kw):
+    F = np.array(F, np.float32).reshape(-1, dim * dim).copy()
+    n = len(F)
+    cdg, cp = _f(np.asarray(cdg).reshape(n, dim * dim))
+    aux = np.array(np.zeros(n) if aux is None else np.broadcast_to(np.asarray(aux, np.float32), (n,)), np.float32).copy()
+    _chk(lib().ref_plasticity(dim, type_config(type_name, mass, vol, **mat_kw), n, cp, F.ctypes.data_as(P_F), aux.ctypes.data_as(P_F)))
+    return F, aux
+
+
+def particle_scalars(type_name, mass, vol, F, aux, v, dx, **mat_kw):
+    """(get_allowed_dt(dx), potential_energy()) per particle state; NaN where the type has no potential_energy()"""
+    F, fp = _f(np.asarray(F).reshape(-1, 9))
+    n = len(F)
+    aux, ap = _f(np.broadcast_to(np.asarray(aux, np.float32), (n,)))
+    v, vp = _f(np.asarray(v).reshape(n, 3))
+    adt = np.zeros(n, np.float32); pot = np.zeros(n, np.float32)
+    _chk(lib().ref_particle_scalars(type_config(type_name, mass, vol, **mat_kw), n, fp, ap, vp, C.c_float(dx),
+                                    adt.ctypes.data_as(P_F), pot.ctypes.data_as(P_F)))
+    return adt, pot
+
+
+def kernel3_dw_w(pos, inv_dx=1.0, fast=False):
+    p, pp = _f(pos)
+    out = np.zeros((27, 4), np.float32)
+    _chk(lib().ref_kernel3(int(fast), pp, C.c_float(inv_dx), out.ctypes.data_as(P_F)))
+    return out
+
+
+def kernel2_dw_w(pos, inv_dx=1.0):
+    p, pp = _f(pos)
+    out = np.zeros((9, 3), np.float32)
+    _chk(lib().ref_kernel2(pp, C.c_float(inv_dx), out.ctypes.data_as(P_F)))
+    return out
+
+
+def stencil_start(x):
+    return int(lib().ref_stencil_start(C.c_float(x)))
+
+
+def friction_project(v, vb, n, mu):
+    v, vp = _f(v); vb, vbp = _f(vb); n, np_ = _f(n)
+    out = np.zeros(3, np.float32)
+    _chk(lib().ref_friction_project(vp, vbp, np_, C.c_float(mu), out.ctypes.data_as(P_F)))
+    return out
+
+
+def shim_svd3(F):
+    F, fp = _f(np.asarray(F).reshape(9))
+    U = np.zeros(9, np.float32); S = np.zeros(3, np.float32); V = np.zeros(9, np.float32)
+    lib().ref_shim_svd3(fp, U.ctypes.data_as(P_F), S.ctypes.data_as(P_F), V.ctypes.data_as(P_F))
+    return U.reshape(3, 3), S, V.reshape(3, 3)
