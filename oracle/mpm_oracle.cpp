@@ -221,9 +221,11 @@ void orc_grid_update(const orc_config *c, float *grid) {
         }
         if (g[3] == 0.0f) continue;  // src/mpm.cpp:313-315
         real pos[3] = {(real)i, (real)j, (real)k}, phi, nrm[3] = {0, 0, 0};
-        if (!levelset_eval(c, pos, phi, nrm)) continue;
+        real dphidt;
+        if (!levelset_eval(c, pos, phi, nrm, &dphidt)) continue;
         if (phi < -3 || 0 < phi) continue;  // src/mpm.cpp:324-325
-        real vb[3] = {0, 0, 0}, out[3];
+        // boundary_velocity = -levelset.get_temporal_derivative(pos, t) * n * delta_x   (src/mpm.cpp:340-342)
+        real vb[3] = {-dphidt * nrm[0] * c->dx, -dphidt * nrm[1] * c->dx, -dphidt * nrm[2] * c->dx}, out[3];
         real vel[3] = {g[0], g[1], g[2]};
         friction_project(vel, vb, nrm, c->friction, out);
         g[0] = out[0]; g[1] = out[1]; g[2] = out[2];

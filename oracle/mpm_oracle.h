@@ -72,6 +72,16 @@ typedef struct {
   int32_t n_shapes;
   struct { int32_t type, inside_out; float p[6]; } shapes[8];
   int32_t particle_collision; /* src/mpm.cpp:566-569, :414-426: push particles out of the level set after G2P */
+  /* DynamicLevelSet (scripts/async/async_mpm.py:119-127: levelset(t0), levelset(t1) blended linearly in time): when
+   * `dynamic` != 0 the fields above are the key frame at t0 and these the key frame at t1; `t` = current_t of the
+   * substep.  phi = lerp, gradient = normalised lerp of the two gradients, boundary velocity =
+   * -(phi1 - phi0)/(t1 - t0) n dx (src/mpm.cpp:340-342). */
+  int32_t dynamic;
+  float t0, t1, t;
+  int32_t n_planes1;
+  float planes1[8][4];
+  int32_t n_shapes1;
+  struct { int32_t type, inside_out; float p[6]; } shapes1[8];
 } orc_config;
 
 /* --- kernel weights (src/kernel.h:103-135,168-210; src/transfer.cpp:162-191) */

@@ -28,7 +28,9 @@ class Config(C.Structure):
                 ("apic_damping", C.c_float), ("rpic_damping", C.c_float),
                 ("clean_boundary", C.c_int32), ("n_planes", C.c_int32),
                 ("planes", (C.c_float * 4) * 8), ("friction", C.c_float), ("n_shapes", C.c_int32),
-                ("shapes", Shape * 8), ("particle_collision", C.c_int32)]
+                ("shapes", Shape * 8), ("particle_collision", C.c_int32),
+                ("dynamic", C.c_int32), ("t0", C.c_float), ("t1", C.c_float), ("t", C.c_float),
+                ("n_planes1", C.c_int32), ("planes1", (C.c_float * 4) * 8), ("n_shapes1", C.c_int32), ("shapes1", Shape * 8)]
 
 
 def build():
@@ -52,8 +54,11 @@ def lib():
 
 
 def make_config(res, dx, dt, gravity=(0, -10, 0), particle_gravity=True, apic_damping=0.0,
-                rpic_damping=0.0, clean_boundary=True, planes=(), friction=-1.0, shapes=(), particle_collision=False):
-    """shapes: [(type, inside_out, params...)] with type 1 = sphere (cx, cy, cz, r), 2 = cuboid (lo xyz, hi xyz)"""
+                rpic_damping=0.0, clean_boundary=True, planes=(), friction=-1.0, shapes=(), particle_collision=False,
+                planes1=None, shapes1=None, t0=0.0, t1=1.0, t=0.0):
+    """shapes: [(type, inside_out, params...)] with type 1 = sphere (cx, cy, cz, r), 2 = cuboid (lo xyz, hi xyz).
+    planes1 / shapes1 (either not None): the level set at time t1 — a DynamicLevelSet(t0, t1, ...) blended linearly in
+    time; `t` is the current time, advanced by substep()."""
     c = Config()
     if np.isscalar(res):
         res = (res,) * 3
@@ -75,6 +80,16 @@ def make_config(res, dx, dt, gravity=(0, -10, 0), particle_gravity=True, apic_da
         vals = [float(v) for v in sh[2:]]
         c.shapes[i].p[:] = vals + [0.0] * (6 - len(vals))
     c.particle_collision = int(bool(particle_collision))
+    c.dynamic = int(planes1 is not None or shapes1 is not None)
+    c.t0, c.t1, c.t = t0, t1, t
+    c.n_planes1 = len(planes1 or ())
+    for i, p in enumerate(planes1 or ()):
+        c.planes1[i][:] = [float(v) for v in p]
+    c.n_shapes1 = len(shapes1 or ())
+    for i, sh in enumerate(shapes1 or ()):
+        c.shapes1[i].type, c.shapes1[i].inside_out = int(sh[0]), int(bool(sh[1]))
+        vals = [float(v) for v in sh[2:]]
+        c.shapes1[i].p[:] = vals + [0.0] * (6 - len(vals))
     return c
 
 
@@ -318,6 +333,7 @@ def substep(cfg, s, grid=None):
                           _pi(s.gid), _pi(s.ids), _pf(s.gparams), _pi(s.gtype), _pf(grid))
     if n != s.n:
         s.truncate(n)
+    cfg.t = float(np.float32(cfg.t) + np.float32(cfg.dt))  # this->current_t += delta_t, src/mpm.cpp:573
     return grid
 
 

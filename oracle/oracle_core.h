@@ -396,22 +396,24 @@ inline int64_t node_index(const orc_config *c, int i, int j, int k) {
   return ((int64_t)i * (c->res[1] + 1) + j) * (c->res[2] + 1) + k;
 }
 
-// level set in grid units at a grid-unit position: phi and its (unit) spatial gradient
+// one key frame of the level set, in grid units at a grid-unit position: phi and its (unit) spatial gradient
 // (reference: levelset.sample(pos,t) / get_spatial_gradient(pos,t), src/mpm.cpp:323-326,416-421)
-inline bool levelset_eval(const orc_config *c, const real pos_grid[3], real &phi, real n[3]) {
-  if (c->n_planes <= 0 && c->n_shapes <= 0) return false;
+template <typename ShapeT>
+inline bool levelset_eval_key(const orc_config *c, int n_planes, const float (*planes)[4], int n_shapes, const ShapeT *shapes,
+                              const real pos_grid[3], real &phi, real n[3]) {
+  if (n_planes <= 0 && n_shapes <= 0) return false;
   const real idx = 1.0f / c->dx;
   const real x[3] = {pos_grid[0] * c->dx, pos_grid[1] * c->dx, pos_grid[2] * c->dx};
   phi = 1e30f;
-  for (int p = 0; p < c->n_planes; p++) {
-    const float *pl = c->planes[p];
+  for (int p = 0; p < n_planes; p++) {
+    const float *pl = planes[p];
     real ph = (pl[0] * x[0] + pl[1] * x[1] + pl[2] * x[2] + pl[3]) * idx;
     if (ph < phi) { phi = ph; n[0] = pl[0]; n[1] = pl[1]; n[2] = pl[2]; }
   }
-  for (int s = 0; s < c->n_shapes; s++) {
-    const float *q = c->shapes[s].p;
+  for (int s = 0; s < n_shapes; s++) {
+    const float *q = shapes[s].p;
     real ph, g[3];
-    if (c->shapes[s].type == 1) {  // sphere: distance to the surface, negative inside the ball
+    if (shapes[s].type == 1) {  // sphere: distance to the surface, negative inside the ball
       real d[3] = {x[0] - q[0], x[1] - q[1], x[2] - q[2]};
       real len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
       real inv = len > 0 ? 1.0f / len : 0.0f;
@@ -440,10 +442,29 @@ inline bool levelset_eval(const orc_config *c, const real pos_grid[3], real &phi
         for (int k = 0; k < 3; k++) g[k] = d[k] / len;
       }
     }
-    if (c->shapes[s].inside_out) { ph = -ph; g[0] = -g[0]; g[1] = -g[1]; g[2] = -g[2]; }
+    if (shapes[s].inside_out) { ph = -ph; g[0] = -g[0]; g[1] = -g[1]; g[2] = -g[2]; }
     ph *= idx;
     if (ph < phi) { phi = ph; n[0] = g[0]; n[1] = g[1]; n[2] = g[2]; }
   }
+  return true;
+}
+
+// the level set at time c->t.  Static: key frame 0.  Dynamic (DynamicLevelSet of the taichi core, as the python driver
+// builds it per frame, scripts/async/async_mpm.py:119-127): the two key frames blended linearly in time; *dphidt =
+// get_temporal_derivative in grid units per second (0 when static).
+inline bool levelset_eval(const orc_config *c, const real pos_grid[3], real &phi, real n[3], real *dphidt = nullptr) {
+  if (dphidt) *dphidt = 0.0f;
+  if (!levelset_eval_key(c, c->n_planes, c->planes, c->n_shapes, c->shapes, pos_grid, phi, n)) return false;
+  if (!c->dynamic) return true;
+  real phi1, n1[3] = {0, 0, 0};
+  if (!levelset_eval_key(c, c->n_planes1, c->planes1, c->n_shapes1, c->shapes1, pos_grid, phi1, n1)) return true;
+  const real a = (c->t - c->t0) / (c->t1 - c->t0);
+  if (dphidt) *dphidt = (phi1 - phi) / (c->t1 - c->t0);
+  phi = (1.0f - a) * phi + a * phi1;
+  real g[3], len2 = 0;
+  for (int k = 0; k < 3; k++) { g[k] = n[k] * (1.0f - a) + n1[k] * a; len2 += g[k] * g[k]; }
+  const real len = std::sqrt(len2);
+  for (int k = 0; k < 3; k++) n[k] = len < 1e-10f ? 0.0f : g[k] / len;
   return true;
 }
 

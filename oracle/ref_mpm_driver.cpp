@@ -137,20 +137,27 @@ int grid_io(Handle *h, float *dense, bool upload) {
 }
 
 template <int dim>
-void set_levelset(Handle *h, int n, const float *shapes, float friction) {
-  MPM<dim> &m = sim<dim>(h);
+std::shared_ptr<LevelSet<dim>> make_levelset(MPM<dim> &m, int n, const float *shapes, float friction) {
   auto L = std::make_shared<LevelSet<dim>>();
   L->friction = friction;
   L->delta_x = m.delta_x;
-  for (int i = 0; i < n; i++) {  // rows of 11 floats: type, inside_out, p[6], vel[3]
-    const float *r = shapes + 11 * i;
+  for (int i = 0; i < n; i++) {  // rows of 8 floats: type, inside_out, p[6]
+    const float *r = shapes + 8 * i;
     ShimShape s;
     s.type = (int)r[0]; s.inside_out = (int)r[1];
     for (int k = 0; k < 6; k++) s.p[k] = r[2 + k];
-    for (int k = 0; k < 3; k++) s.vel[k] = r[8 + k];
     L->shapes.push_back(s);
   }
-  m.levelset.levelset0 = L;
+  return L;
+}
+// static level set (n1 < 0) or DynamicLevelSet::initialize(t0, t1, levelset(t0), levelset(t1)) as
+// scripts/async/async_mpm.py:119-127 update_levelset builds it every frame
+template <int dim>
+void set_levelset(Handle *h, int n0, const float *shapes0, int n1, const float *shapes1, float t0, float t1, float friction) {
+  MPM<dim> &m = sim<dim>(h);
+  DynamicLevelSet<dim> D;
+  D.initialize(t0, t1, make_levelset<dim>(m, n0, shapes0, friction), n1 >= 0 ? make_levelset<dim>(m, n1, shapes1, friction) : nullptr);
+  m.set_levelset(D);
 }
 
 template <int dim>
@@ -218,8 +225,8 @@ void *ref_create(int dim, const char *cfg) {
     h->dim = dim;
     Config c = Config::from_string(cfg);
     if (!c.has_key("num_threads")) c.set("num_threads", ShimRuntime::get().threads);
-    if (dim == 2) { h->m2 = std::make_unique<MPM<2>>(); h->m2->initialize(c); set_levelset<2>(h, 0, nullptr, 1.0f); }
-    else if (dim == 3) { h->m3 = std::make_unique<MPM<3>>(); h->m3->initialize(c); set_levelset<3>(h, 0, nullptr, 1.0f); }
+    if (dim == 2) { h->m2 = std::make_unique<MPM<2>>(); h->m2->initialize(c); set_levelset<2>(h, 0, nullptr, -1, nullptr, 0, 1, 1.0f); }
+    else if (dim == 3) { h->m3 = std::make_unique<MPM<3>>(); h->m3->initialize(c); set_levelset<3>(h, 0, nullptr, -1, nullptr, 0, 1, 1.0f); }
     else TC_ERROR("dim must be 2 or 3");
     return 0;
   });
@@ -228,9 +235,12 @@ void *ref_create(int dim, const char *cfg) {
 }
 void ref_destroy(void *h) { delete (Handle *)h; }
 
-int ref_set_levelset(void *hh, int n, const float *shapes, float friction) {
+int ref_set_levelset(void *hh, int n0, const float *shapes0, int n1, const float *shapes1, float t0, float t1, float friction) {
   Handle *h = (Handle *)hh;
-  return guarded([&] { DISPATCH(h, set_levelset<2>(h, n, shapes, friction), set_levelset<3>(h, n, shapes, friction)); return 0; });
+  return guarded([&] {
+    DISPATCH(h, set_levelset<2>(h, n0, shapes0, n1, shapes1, t0, t1, friction), set_levelset<3>(h, n0, shapes0, n1, shapes1, t0, t1, friction));
+    return 0;
+  });
 }
 
 // type_cfg: "type=sand;mass=..;vol=..;<the material's own config keys>"

@@ -46,7 +46,7 @@ def lib():
         L.ref_download.argtypes = [C.c_void_p, P_F, P_F, P_F, P_F, P_F, P_I]
         L.ref_add_particles.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, P_F, P_F, P_F, P_F, P_F]
         L.ref_add_particles_cfg.argtypes = [C.c_void_p, C.c_char_p]
-        L.ref_set_levelset.argtypes = [C.c_void_p, C.c_int, P_F, C.c_float]
+        L.ref_set_levelset.argtypes = [C.c_void_p, C.c_int, P_F, C.c_int, P_F, C.c_float, C.c_float, C.c_float]
         L.ref_download_grid.argtypes = [C.c_void_p, P_F]
         L.ref_upload_grid.argtypes = [C.c_void_p, P_F]
         L.ref_substep.argtypes = [C.c_void_p, C.c_int]
@@ -132,14 +132,20 @@ class Sim:
         except Exception:
             pass
 
-    def set_levelset(self, shapes=(), friction=1.0):
-        """shapes: rows (type, inside_out, p0..p5[, vx, vy, vz]) in WORLD units: type 0 plane (n, d), 1 sphere
-        (c, r), 2 cuboid (lo, hi); an optional constant velocity moves the shape rigidly."""
-        rows = np.zeros((len(shapes), 11), np.float32)
-        for i, sh in enumerate(shapes):
-            sh = [float(v) for v in sh]
-            rows[i, :len(sh)] = sh
-        _chk(lib().ref_set_levelset(self.h, len(shapes), rows.ctypes.data_as(P_F), C.c_float(friction)))
+    def set_levelset(self, shapes=(), friction=1.0, shapes1=None, t0=0.0, t1=1.0):
+        """shapes: rows (type, inside_out, p0..p5) in WORLD units: type 0 plane (n, d), 1 sphere (c, r), 2 cuboid
+        (lo, hi).  shapes1 (with t0 < t1): the level set at time t1 — DynamicLevelSet(t0, t1, shapes, shapes1), blended
+        linearly in time like the reference's (scripts/async/async_mpm.py:119-127)."""
+        def rows(sh):
+            r = np.zeros((len(sh), 8), np.float32)
+            for i, row in enumerate(sh):
+                row = [float(v) for v in row]
+                r[i, :len(row)] = row
+            return r
+        r0 = rows(shapes)
+        r1 = rows(shapes1) if shapes1 is not None else np.zeros((0, 8), np.float32)
+        _chk(lib().ref_set_levelset(self.h, len(r0), r0.ctypes.data_as(P_F), len(r1) if shapes1 is not None else -1,
+                                    r1.ctypes.data_as(P_F), C.c_float(t0), C.c_float(t1), C.c_float(friction)))
 
     def add_particles(self, type_name, mass, vol, x, v=None, F=None, B=None, aux=None, **mat_kw):
         d = self.dim

@@ -677,31 +677,28 @@ inline VectorND<dim, real> transform(const MatrixND<dim + 1, real> &m, const Vec
   return VectorND<dim, real>(m * VectorND<dim + 1, real>(v, 1.0f));
 }
 
-// analytic level set (taichi core: a SAMPLED signed-distance array built by add_plane / add_sphere / add_cuboid and
-// interpolated in space and time).  Arguments of sample() etc. are in GRID units like the reference's call sites
-// (src/mpm.cpp:323-342,416-421); shapes are kept in world units; phi is returned in grid units.  A shape may move
-// rigidly with a constant velocity `vel` (world units / s): x(t) = x0 + vel * t.
-struct ShimShape { int type = 0, inside_out = 0; float p[6] = {0, 0, 0, 0, 0, 0}; float vel[3] = {0, 0, 0}; };
+// analytic level set (taichi core: a SAMPLED signed-distance array built by add_plane / add_sphere / add_cuboid,
+// and DynamicLevelSet = two such arrays at times t0 < t1 blended linearly in time — scripts/async/async_mpm.py:119-127
+// builds one per frame from levelset_generator(t0), levelset_generator(t1)).  Here each key frame is a list of exact
+// shapes; the time blending follows the same model: phi = lerp(phi0, phi1), gradient = normalised lerp of the two
+// gradients, d phi / dt = (phi1 - phi0) / (t1 - t0)   [our reading of the absent core: a design choice, not a
+// reference fact].  Arguments of sample() etc. are in GRID units like the reference's call sites
+// (src/mpm.cpp:323-342,416-421); shapes are kept in world units; phi is returned in grid units.
+struct ShimShape { int type = 0, inside_out = 0; float p[6] = {0, 0, 0, 0, 0, 0}; };
 template <int dim>
 struct LevelSet {
+  using Vector = VectorND<dim, real>;
   real friction = 1.0f;
   std::vector<ShimShape> shapes;
   real delta_x = 1.0f;
-};
-template <int dim>
-struct DynamicLevelSet {
-  using Vector = VectorND<dim, real>;
-  std::shared_ptr<LevelSet<dim>> levelset0, levelset1;
-  // phi (grid units) and unit gradient of the nearest shape at grid position pos, time t
-  real eval(const Vector &pos, real t, Vector *grad, real *dphidt) const {
-    const LevelSet<dim> &L = *levelset0;
-    const real dx = L.delta_x, idx = 1.0f / dx;
+  // phi (grid units) and unit gradient of the nearest shape at grid position pos
+  real eval(const Vector &pos, Vector *grad) const {
+    const real dx = delta_x, idx = 1.0f / dx;
     real best = 1e30f;
     Vector g(0.0f);
-    real dt_best = 0;
-    for (const ShimShape &s : L.shapes) {
+    for (const ShimShape &s : shapes) {
       real x[3] = {0, 0, 0};
-      for (int k = 0; k < dim; k++) x[k] = pos[k] * dx - s.vel[k] * t;  // into the shape's rest frame
+      for (int k = 0; k < dim; k++) x[k] = pos[k] * dx;
       real ph, gr[3] = {0, 0, 0};
       if (s.type == 0) {
         ph = s.p[0] * x[0] + s.p[1] * x[1] + s.p[2] * x[2] + s.p[3];
@@ -731,20 +728,41 @@ struct DynamicLevelSet {
       }
       if (s.type != 0 && s.inside_out) { ph = -ph; for (int k = 0; k < 3; k++) gr[k] = -gr[k]; }
       ph *= idx;
-      if (ph < best) {
-        best = ph;
-        for (int k = 0; k < dim; k++) g[k] = gr[k];
-        // d phi / dt at a fixed point = -grad . velocity  (grid units per second)
-        dt_best = -(gr[0] * s.vel[0] + gr[1] * s.vel[1] + gr[2] * s.vel[2]) * idx;
-      }
+      if (ph < best) { best = ph; for (int k = 0; k < dim; k++) g[k] = gr[k]; }
     }
     if (grad) *grad = g;
-    if (dphidt) *dphidt = dt_best;
     return best;
   }
-  real sample(const Vector &pos, real t) const { return eval(pos, t, nullptr, nullptr); }
-  Vector get_spatial_gradient(const Vector &pos, real t) const { Vector g; eval(pos, t, &g, nullptr); return g; }
-  real get_temporal_derivative(const Vector &pos, real t) const { real d; eval(pos, t, nullptr, &d); return d; }
+};
+template <int dim>
+struct DynamicLevelSet {
+  using Vector = VectorND<dim, real>;
+  std::shared_ptr<LevelSet<dim>> levelset0, levelset1;  // levelset1 == nullptr: static
+  real t0 = 0.0f, t1 = 1.0f;
+  void initialize(real t0_, real t1_, const std::shared_ptr<LevelSet<dim>> &l0, const std::shared_ptr<LevelSet<dim>> &l1) {
+    t0 = t0_; t1 = t1_; levelset0 = l0; levelset1 = l1;
+  }
+  real sample(const Vector &pos, real t) const {
+    const real p0 = levelset0->eval(pos, nullptr);
+    if (!levelset1) return p0;
+    const real a = (t - t0) / (t1 - t0);
+    return (1.0f - a) * p0 + a * levelset1->eval(pos, nullptr);
+  }
+  Vector get_spatial_gradient(const Vector &pos, real t) const {
+    Vector g0;
+    levelset0->eval(pos, &g0);
+    if (!levelset1) return g0;
+    Vector g1;
+    levelset1->eval(pos, &g1);
+    const real a = (t - t0) / (t1 - t0);
+    Vector g = g0 * (1.0f - a) + g1 * a;
+    const real len = g.length();
+    return len < 1e-10f ? Vector(0.0f) : g / len;
+  }
+  real get_temporal_derivative(const Vector &pos, real t) const {
+    if (!levelset1) return 0.0f;
+    return (levelset1->eval(pos, nullptr) - levelset0->eval(pos, nullptr)) / (t1 - t0);
+  }
   bool inside(const Vector &) const { return true; }
 };
 

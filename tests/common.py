@@ -4,6 +4,10 @@ import numpy as np
 from oracle import oracle as orc
 
 
+# per-material Config keys used by the seeded scenes (empty = the reference's defaults, src/particles.cpp initialize())
+MAT_KW = {}
+
+
 def lattice_cube(res, lo_cell, hi_cell, dx, jitter=0.0, seed=0):
     """8 particles per cell at the +-0.25*dx lattice of the reference's benchmark generator
     (src/mpm.cpp:164-180), optionally jittered."""

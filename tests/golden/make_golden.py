@@ -1,8 +1,12 @@
-"""Generates tests/golden/*.npz from the CPU oracle (seeded).  Run from the repo root:
-    python tests/golden/make_golden.py
-The reference holds no golden vectors for P2G/G2P ("parity unpinned") and cannot be built or
-imported here, so these fixtures pin the ORACLE's output; they let the GPU parity tests run on a box
-without depending on the oracle's floating-point environment, and they detect accidental oracle drift."""
+"""Generates tests/golden/substep_*.npz, ref_materials.npz, ref_kernels.npz and ref_shapes.npz from the REFERENCE's own
+solver (oracle/_ref/libmpm_ref.so = /root/reference/src/{mpm,transfer,particles}.cpp compiled where they lie, see
+oracle/Makefile: ref_mpm).  Run in the container that has /root/reference, from the repo root:
+    make -C oracle ref_mpm && python tests/golden/make_golden.py
+Round 1 wrote these fixtures from the restated oracle ("parity unpinned"); since round 2 they hold REFERENCE output, so
+that the restated oracle (tests/test_golden_cpu.py) and the HIP library (tests/test_gpu_parity.py,
+tests/test_gpu_ref.py) are both checked against the reference's arithmetic on any box, without the reference tree.
+What the compiled reference cannot pin is stated in oracle/taichi_shim/taichi/common/util.h (svd / polar_decomp are
+the shim's, in double precision; the level set is analytic)."""
 import os
 import sys
 
@@ -10,38 +14,174 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from oracle import oracle as orc  # noqa: E402
-from tests.common import lattice_cube, make_state  # noqa: E402
+from oracle import oracle as orc  # noqa: E402  (only for the parameter rows / type ids the fixtures carry)
+from oracle import refmpm as ref  # noqa: E402
+from tests.common import MAT_KW, lattice_cube, make_state  # noqa: E402
 
 RES, DX, DT = 32, 1.0 / 32, 1e-4
 PLANES = [(0.0, 1.0, 0.0, -0.3)]
 FRICTION = 0.4
+MATS = ("jelly", "snow", "sand", "water", "linear", "elastic", "von_mises", "visco")
+
+
+def ref_sim(s, mat, shapes, friction, shapes1=None, t1=1.0, **cfg):
+    sim = ref.Sim(RES, DX, DT, shapes=shapes, friction=friction, **cfg)
+    if shapes1 is not None:
+        sim.set_levelset(shapes, friction, shapes1=shapes1, t0=0.0, t1=t1)
+    gp = s.gparams[0]
+    sim.add_particles(mat, gp[0], gp[1], s.x, s.v, s.F, s.B, s.aux, **MAT_KW.get(mat, {}))
+    return sim
+
+
+def substep_fixture(here, mat):
+    x = lattice_cube(RES, 9, 15, DX, jitter=0.2, seed=11)
+    s = make_state(x, mat, DX, perturb_F=0.02, seed=12, **MAT_KW.get(mat, {}))
+    shapes = [(0, 0) + tuple(p) for p in PLANES]
+    sim = ref_sim(s, mat, shapes, FRICTION)
+    sim.sort()
+    sim.p2g(optimized=True)       # rasterize_optimized -> block_op_normal, src/transfer.cpp:467-569
+    g_p2g = sim.download_grid()
+    sim.grid_update()             # src/mpm.cpp:277-372
+    g_upd = sim.download_grid()
+    sim.g2p(optimized=True)       # resample_optimized -> block_op_normal, src/transfer.cpp:837-954
+    a = sim.download()
+    sim.close()
+    nz = np.argwhere(g_p2g[..., 3] != 0)
+    # the generic (optimized=False) path on the same input: src/transfer.cpp:193-278, :585-687
+    gen = ref_sim(s, mat, shapes, FRICTION, optimized=False)
+    gen.sort(); gen.p2g(optimized=False)
+    gg = gen.download_grid()
+    gen.grid_update(); gen.g2p(optimized=False)
+    ga = gen.download()
+    gen.close()
+    b = ref_sim(s, mat, shapes, FRICTION)
+    b.substep(5)                  # MPM<3>::substep, src/mpm.cpp:452-575
+    b5 = b.download()
+    b.close()
+    np.savez_compressed(
+        os.path.join(here, "substep_%s.npz" % mat), res=RES, dx=DX, dt=DT, planes=np.array(PLANES, np.float32),
+        friction=FRICTION, gparams=s.gparams, gtype=s.gtype, source="reference (oracle/_ref/libmpm_ref.so)",
+        in_x=s.x, in_v=s.v, in_B=s.B, in_F=s.F, in_aux=s.aux,
+        nz=nz.astype(np.int16), p2g_nz=g_p2g[nz[:, 0], nz[:, 1], nz[:, 2]], upd_nz=g_upd[nz[:, 0], nz[:, 1], nz[:, 2]],
+        out_x=a["x"], out_v=a["v"], out_B=a["B"], out_F=a["F"], out_aux=a["aux"],
+        gen_p2g_nz=gg[nz[:, 0], nz[:, 1], nz[:, 2]], gen_x=ga["x"], gen_v=ga["v"], gen_B=ga["B"], gen_F=ga["F"],
+        out5_x=b5["x"], out5_v=b5["v"], out5_F=b5["F"], out5_aux=b5["aux"], out5_ids=b5["id"])
+    print(mat, s.n, "particles,", len(nz), "nodes")
+
+
+def materials_fixture(here):
+    """calculate_force / plasticity / get_allowed_dt / potential_energy of every registered particle type
+    (src/particles.cpp) on seeded deformation gradients: small strains, large strains, and states past the yield
+    surfaces / clamps"""
+    rng = np.random.default_rng(2024)
+    n = 384
+    out = {}
+    vol = DX ** 3 / 8
+    mass = 400.0 * vol
+    for mat in MATS:
+        kw = MAT_KW.get(mat, {})
+        amp = np.repeat([0.01, 0.05, 0.2], n // 3)[:, None, None]
+        F = (np.eye(3) + rng.normal(0, 1, (n, 3, 3)) * amp).astype(np.float32).reshape(n, 9)
+        cdg = (np.eye(3) + rng.normal(0, 1, (n, 3, 3)) * amp * 0.3).astype(np.float32).reshape(n, 9)
+        aux = {"snow": 1.0 + rng.normal(0, 0.05, n), "water": 1.0 + rng.normal(0, 0.05, n),
+               "sand": np.abs(rng.normal(0, 0.02, n)), "visco": np.full(n, 1000.0)}.get(mat, np.zeros(n)).astype(np.float32)
+        if mat in ("sand", "elastic", "von_mises"):  # Hencky models take log(sigma): keep det F > 0 (reference: NaN otherwise)
+            bad = np.linalg.det(F.reshape(n, 3, 3)) <= 0.05
+            F[bad] = np.eye(3, dtype=np.float32).reshape(9)
+        v = rng.normal(0, 1, (n, 3)).astype(np.float32)
+        force = ref.calculate_force(mat, mass, vol, F, aux, **kw)
+        F2, aux2 = ref.plasticity(mat, mass, vol, cdg, F, aux, **kw)
+        force2 = ref.calculate_force(mat, mass, vol, F2, aux2, **kw)
+        adt, pot = ref.particle_scalars(mat, mass, vol, F, aux, v, DX, **kw)
+        gp, t = orc.group_params(mat, mass, vol, **kw)
+        out.update({mat + "_F": F, mat + "_cdg": cdg, mat + "_aux": aux, mat + "_v": v, mat + "_force": force,
+                    mat + "_F2": F2, mat + "_aux2": aux2, mat + "_force2": force2, mat + "_allowed_dt": adt,
+                    mat + "_potential": pot, mat + "_gp": gp, mat + "_type": t})
+    np.savez_compressed(os.path.join(here, "ref_materials.npz"), mass=mass, vol=vol, dx=DX, **out)
+    print("materials:", n, "states x", len(MATS), "types")
+
+
+def kernels_fixture(here):
+    """MPMKernel<3,2>, MPMFastKernel32, MPMKernel<2,2> (src/kernel.h) and friction_project (src/mpm_fwd.h:25-57)"""
+    rng = np.random.default_rng(7)
+    pos = (rng.uniform(3, 20, (64, 3))).astype(np.float32)
+    inv_dx = 32.0
+    slow = np.stack([ref.kernel3_dw_w(p, inv_dx, fast=False) for p in pos])
+    fast = np.stack([ref.kernel3_dw_w(p, inv_dx, fast=True) for p in pos])
+    k2 = np.stack([ref.kernel2_dw_w(p[:2], inv_dx) for p in pos])
+    start = np.array([ref.stencil_start(float(p[0])) for p in pos], np.int32)
+    fr_in, fr_out = [], []
+    for mu in (-1.0, -2.0, -2.4, 0.0, 0.3, 1.5):
+        for _ in range(12):
+            v, vb = rng.normal(0, 1, 3).astype(np.float32), rng.normal(0, 0.3, 3).astype(np.float32)
+            n = rng.normal(0, 1, 3); n = (n / np.linalg.norm(n)).astype(np.float32)
+            fr_in.append(np.concatenate([v, vb, n, [mu]]).astype(np.float32))
+            fr_out.append(ref.friction_project(v, vb, n, mu))
+    np.savez_compressed(os.path.join(here, "ref_kernels.npz"), pos=pos, inv_dx=inv_dx, slow=slow, fast=fast, k2=k2, start=start,
+                        friction_in=np.stack(fr_in), friction_out=np.stack(fr_out))
+    print("kernels:", len(pos), "positions;", len(fr_in), "friction cases")
+
+
+def shapes_fixture(here):
+    """level-set shapes (plane + sphere + inside-out cuboid container), a MOVING plane and sphere
+    (boundary_velocity = -dphi/dt n dx, src/mpm.cpp:323-342), particle_collision (src/mpm.cpp:414-426,566-569)
+    and the config variants of MPM::initialize; three substeps each"""
+    cases = {
+        "static_shapes": dict(shapes=[(0, 0, 0, 1, 0, -0.3), (1, 0, 0.5, 0.3, 0.5, 0.12), (2, 1, 0.2, 0.2, 0.2, 0.8, 0.8, 0.8)],
+                              friction=0.3, cfg={}),
+        "slip_sphere": dict(shapes=[(1, 0, 0.5, 0.33, 0.5, 0.1)], friction=-2.3, cfg={}),
+        # DynamicLevelSet(t0 = 0, t1, levelset(t0), levelset(t1)): a floor rising at 0.8 m/s, a ball moving at
+        # (0.3, 1.0, -0.2) m/s, and the shrinking container of scripts/async/balls.py:38-49
+        "moving_plane": dict(shapes=[(0, 0, 0, 1, 0, -0.3)], shapes1=[(0, 0, 0, 1, 0, -0.308)], t1=0.01, friction=0.4, cfg={}),
+        "moving_sphere": dict(shapes=[(1, 0, 0.5, 0.25, 0.5, 0.1)], shapes1=[(1, 0, 0.503, 0.26, 0.498, 0.1)], t1=0.01,
+                              friction=-1.0, cfg={}),
+        "shrinking_box": dict(shapes=[(2, 1, 0.26, 0.26, 0.26, 0.50, 0.50, 0.50)], shapes1=[(2, 1, 0.28, 0.26, 0.28, 0.48, 0.50, 0.48)],
+                              t1=0.01, friction=-2.0, cfg={}),
+        "particle_collision": dict(shapes=[(0, 0, 0, 1, 0, -0.32), (1, 0, 0.5, 0.3, 0.5, 0.1)], friction=0.2,
+                                   cfg=dict(particle_collision=True)),
+        "grid_gravity": dict(shapes=[(0, 0, 0, 1, 0, -0.3)], friction=0.4, cfg=dict(particle_gravity=False)),
+        "apic_damping_only": dict(shapes=[(0, 0, 0, 1, 0, -0.3)], friction=0.4, cfg=dict(apic_damping=0.3)),
+        "both_dampings": dict(shapes=[(0, 0, 0, 1, 0, -0.3)], friction=0.4, cfg=dict(apic_damping=0.3, rpic_damping=0.1)),
+    }
+    out = {}
+    x = lattice_cube(RES, 10, 15, DX, jitter=0.2, seed=21)
+    for mat in ("jelly", "sand"):
+        s = make_state(x, mat, DX, perturb_F=0.02, seed=22, vel_scale=2.0)
+        out["in_" + mat] = np.concatenate([s.x, s.v, s.B, s.F, s.aux[:, None]], 1)
+        out["gp_" + mat] = s.gparams[0]
+        for name, c in cases.items():
+            for optimized in (True, False):
+                if not optimized and name not in ("static_shapes", "moving_sphere", "apic_damping_only", "both_dampings"):
+                    continue  # (the generic path repeats the same boundary code: two cases keep the fixture small)
+                sim = ref_sim(s, mat, c["shapes"], c["friction"], shapes1=c.get("shapes1"), t1=c.get("t1", 1.0),
+                              optimized=optimized, **c["cfg"])
+                sim.substep(3)
+                d = sim.download()
+                sim.close()
+                key = "%s_%s_%s" % (name, mat, "opt" if optimized else "gen")
+                out[key] = np.concatenate([d["x"], d["v"], d["F"], d["aux"][:, None]], 1)
+                out[key + "_ids"] = d["id"]
+    import json
+    np.savez_compressed(os.path.join(here, "ref_shapes.npz"), res=RES, dx=DX, dt=DT, cases=json.dumps(
+        {k: dict(shapes=[list(map(float, sh)) for sh in c["shapes"]], friction=c["friction"], cfg=c["cfg"],
+                 shapes1=[list(map(float, sh)) for sh in c["shapes1"]] if "shapes1" in c else None, t1=c.get("t1", 1.0))
+         for k, c in cases.items()}), **out)
+    print("shapes:", len(cases), "cases x 2 materials x 2 paths")
 
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
-    # default: every registered particle type.  `python tests/golden/make_golden.py visco linear` regenerates a subset
-    for mat in (sys.argv[1:] or ("jelly", "snow", "sand", "water", "linear", "elastic", "von_mises", "visco")):
-        x = lattice_cube(RES, 9, 15, DX, jitter=0.2, seed=11)
-        s = make_state(x, mat, DX, perturb_F=0.02, seed=12)
-        cfg = orc.make_config(RES, DX, DT, planes=PLANES, friction=FRICTION)
-        inp = s.copy()
-        a = s.copy()
-        g_p2g = orc.p2g(cfg, a)
-        g_upd = orc.grid_update(cfg, g_p2g.copy())
-        orc.g2p(cfg, a, g_upd)
-        nz = np.argwhere(g_p2g[..., 3] != 0)
-        b = s.copy()
-        for _ in range(5):
-            orc.substep(cfg, b)
-        np.savez_compressed(
-            os.path.join(here, "substep_%s.npz" % mat), res=RES, dx=DX, dt=DT, planes=np.array(PLANES, np.float32),
-            friction=FRICTION, gparams=inp.gparams, gtype=inp.gtype,
-            in_x=inp.x, in_v=inp.v, in_B=inp.B, in_F=inp.F, in_aux=inp.aux,
-            nz=nz.astype(np.int16), p2g_nz=g_p2g[nz[:, 0], nz[:, 1], nz[:, 2]], upd_nz=g_upd[nz[:, 0], nz[:, 1], nz[:, 2]],
-            out_x=a.x, out_v=a.v, out_B=a.B, out_F=a.F, out_aux=a.aux,
-            out5_x=b.x, out5_v=b.v, out5_F=b.F, out5_aux=b.aux, out5_ids=b.ids)
-        print(mat, s.n, "particles,", len(nz), "nodes")
+    ref.set_threads(1)  # the generic P2G of the reference is racy with more than one thread (SURVEY quirk 5)
+    what = sys.argv[1:] or (list(MATS) + ["materials", "kernels", "shapes"])
+    for w in what:
+        if w in MATS:
+            substep_fixture(here, w)
+        elif w == "materials":
+            materials_fixture(here)
+        elif w == "kernels":
+            kernels_fixture(here)
+        elif w == "shapes":
+            shapes_fixture(here)
 
 
 if __name__ == "__main__":
