@@ -49,7 +49,8 @@ def build_sim(tm, cfg, device):
     res, cells = cfg["res"], cfg["cells"]
     lo = res // 2 - cells // 2
     sim = tm.create_simulation3("mpm").initialize(dict(res=(res,) * 3, delta_x=1.0 / res, base_delta_t=1e-4,
-                                                       gravity=(0, -10, 0), device=device))
+                                                       gravity=(0, -10, 0), device=device,
+                                                       keep_apic_b=bool(cfg.get("keep_apic_b", False))))
     sim.set_levelset(tm.mpm.LevelSet(friction=-1.0).add_plane((0, 1, 0), d=-0.1))  # sticky floor y = 0.1
     if "clusters" in cfg:  # C5: one cube per corner of a 2x2x2 arrangement, materials alternating
         k = 0
@@ -63,8 +64,135 @@ def build_sim(tm, cfg, device):
     return sim
 
 
+def substeps_to_impact(cfg, dt=1e-4, g=10.0, floor=0.1):
+    """substeps of free fall until the seeded cube touches the floor plane y = 0.1"""
+    res, cells = cfg["res"], cfg["cells"]
+    lo = cfg["clusters"][0] if "clusters" in cfg else res // 2 - cells // 2
+    h = (lo + 0.25) / res - floor
+    return int(np.sqrt(2.0 * h / g) / dt)
+
+
+EVOLVE_AFTER_IMPACT = 400  # substeps run after the block has touched the floor before the `evolved` state is timed
+
+
+def evolve_to_impact(sim, cfg):
+    """run the scene on the device until EVOLVE_AFTER_IMPACT substeps after the block hit the floor: uneven cells, decayed
+    slot order, active return map — the state the `evolved` object of the JSON line is timed on.  Returns the number of
+    substeps run after the impact."""
+    n = substeps_to_impact(cfg) + EVOLVE_AFTER_IMPACT
+    sim.run_substeps(n)
+    sim.synchronize()
+    return EVOLVE_AFTER_IMPACT
+
+
+def cpu_baseline_reference(cfg, budget_s=25.0):
+    """the REFERENCE's own solver (oracle/_ref/libmpm_ref.so: /root/reference/src/{mpm,transfer,particles}.cpp compiled
+    where they lie against oracle/taichi_shim) on this box's host cores.  Sample: the reference's own benchmark
+    generator (src/mpm.cpp:149-186, benchmark=125: ~1 M particles) on the workload's grid and material for the thread
+    sweep and the threads=1 row (what scripts/benchmark/benchmark_3d.py:17 uses), then the full workload (8 M) at the
+    best thread count when the budget allows.  svd / polar_decomp are the shim's (double-precision Jacobi), slower
+    than the legacy taichi core's fp32 routines: the stress-bound phases are pessimistic."""
+    from oracle import refmpm as ref
+    from taichi_mpm_amd.mpm import lattice_cube
+    res = cfg["res"]
+    dx = 1.0 / res
+    mat = cfg.get("cpu_material", cfg["material"])
+    hw = os.cpu_count() or 1
+
+    def run(sim, steps):
+        ref.profile(reset=True)
+        t0 = time.perf_counter()
+        sim.substep(steps)
+        sec = time.perf_counter() - t0
+        return sec, ref.profile()
+
+    def small(threads):
+        ref.set_threads(threads)
+        sim = ref.Sim(res, dx, 1e-4, shapes=[(0, 0, 0, 1, 0, -0.1)], friction=-1.0)
+        sim.add_benchmark(mat, 125)
+        return sim
+    sweep, n_small = {}, 0
+    t_start = time.time()
+    for th in sorted({1, 8, 16, 32, 64, 128} | {hw}):
+        if th > hw:
+            continue
+        sim = small(th)
+        n_small = sim.num_particles()
+        sim.substep(1)  # warm-up: first sort + physical reorder, page faults
+        sec, prof = run(sim, 3)
+        sim.close()
+        sweep[th] = dict(value=n_small * 3 / sec, p2g_ns=1e9 * prof.get("P2G optimized", 0) / (3 * n_small),
+                         g2p_ns=1e9 * prof.get("G2P optimized", 0) / (3 * n_small),
+                         sort_ns=1e9 * prof.get("sort_particles_and_populate_grid", 0) / (3 * n_small))
+        if time.time() - t_start > budget_s * 0.5:
+            break
+    best = max(sweep, key=lambda k: sweep[k]["value"])
+    out = {"value": sweep[best]["value"], "unit": "particle-steps/s", "cores": best, "kind": "reference",
+           "sample": "%d %s particles (the reference's benchmark=125 generator, src/mpm.cpp:149-186) on the %d^3 grid, "
+                     "3 substeps after a warm-up, %d OpenMP threads = best of the sweep on a %d-thread host; the reference's "
+                     "own sources (mpm.cpp, transfer.cpp, particles.cpp) built against oracle/taichi_shim: svd / polar_decomp "
+                     "are the shim's double-precision Jacobi" % (n_small, mat, res, best, hw),
+           "threads_1_particle_steps_per_s": sweep.get(1, {}).get("value"),
+           "thread_sweep": {str(k): v for k, v in sweep.items()},
+           "p2g_ns_per_particle": sweep[best]["p2g_ns"], "g2p_ns_per_particle": sweep[best]["g2p_ns"],
+           "sort_ns_per_particle": sweep[best]["sort_ns"]}
+    # the full workload at the best thread count, if ~5 substeps fit the rest of the budget
+    n_full = cfg["cells"] ** 3 * 8 * (8 if "clusters" in cfg else 1)
+    est = n_full / sweep[best]["value"]
+    if "clusters" not in cfg and 5 * est < budget_s:
+        try:
+            ref.set_threads(best)
+            lo = res // 2 - cfg["cells"] // 2
+            x = lattice_cube(lo, lo + cfg["cells"], dx)
+            vol = dx ** 3 / 8
+            sim = ref.Sim(res, dx, 1e-4, shapes=[(0, 0, 0, 1, 0, -0.1)], friction=-1.0)
+            sim.add_particles(mat, 400.0 * vol, vol, x)
+            sim.substep(1)
+            sec, prof = run(sim, 3)
+            sim.close()
+            out.update({"value": len(x) * 3 / sec, "full_workload": True,
+                        "sample": "the full workload: %d %s particles on the %d^3 grid, 3 substeps after a warm-up, %d OpenMP "
+                                  "threads (best of a sweep on a %d-thread host); the reference's own sources built against "
+                                  "oracle/taichi_shim: svd / polar_decomp are the shim's double-precision Jacobi"
+                                  % (len(x), mat, res, best, hw),
+                        "p2g_ns_per_particle": 1e9 * prof.get("P2G optimized", 0) / (3 * len(x)),
+                        "g2p_ns_per_particle": 1e9 * prof.get("G2P optimized", 0) / (3 * len(x)),
+                        "sort_ns_per_particle": 1e9 * prof.get("sort_particles_and_populate_grid", 0) / (3 * len(x))})
+        except Exception as e:
+            out["full_workload_error"] = repr(e)
+    return out
+
+
+class SingleJob:
+    """the one-GPU job: the whole problem in one ctx"""
+    scaling = "strong"
+    parallelism = "1 GPU"
+
+    def __init__(self, sim):
+        self.sim = sim
+        self.substeps = 0
+        sim._ensure_ctx()
+
+    def num_particles(self):
+        return self.sim.get_num_particles()
+
+    def run(self, n):
+        self.sim.run_substeps(n)
+        self.substeps += n
+
+    def synchronize(self):
+        self.sim.synchronize()
+
+    def set_profiling(self, level):
+        self.sim.set_profiling(level)
+        self.sim.profile(reset=True)
+
+    def profile(self):
+        return self.sim.profile()
+
+
 def cpu_baseline(cfg, budget_s=20.0):
-    """restated reference algorithm (CPU) on a bounded sample: same grid/material/ppc, a smaller cube.
+    """(fallback when oracle/_ref/libmpm_ref.so is absent) restated reference algorithm (CPU) on a bounded sample: same grid/material/ppc, a smaller cube.
     OpenMP thread count: the best of a short sweep (oversubscribing a 512k-particle sample with every hardware
     thread of a 256-thread host is several times SLOWER than 32 threads); `cores` is the count actually used."""
     from oracle import oracle as orc
@@ -164,6 +292,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-evolved", action="store_true", help="skip the second measurement on the evolved state")
+    ap.add_argument("--state", default="lattice", choices=["lattice", "evolved"],
+                    help="state the main measurement is taken on: the freshly seeded lattice (the metric's configuration) or "
+                         "the same scene %d substeps after the block hit the floor (for profiling runs)" % EVOLVE_AFTER_IMPACT)
     ap.add_argument("--virtual", type=int, default=0, metavar="K",
                     help="diagnostic, not the metric: run the K-brick tiled job as K ctx on ONE GPU (exchanges are local "
                          "copies) and print per-rank phase times = the per-GPU compute of a K-GPU run without the wire")
@@ -236,7 +368,6 @@ def main():
     cfg = CONFIGS[args.config]
     if "clusters" in cfg and (world > 1 or args.virtual > 1):
         raise SystemExit("--config %s is a single-GPU workload in this build" % args.config)
-    from taichi_mpm_amd import tiling
     if args.virtual > 1:
         return emit(virtual_run(tm, cfg, args))
     if world > 1 or force_tiled:
@@ -245,29 +376,57 @@ def main():
                 tiled.DistComm(dist, torch.device("cuda", local_rank), data_group))
         job = tiled.make_tiled_job(tm, cfg, rank, world, local_rank, comm=comm)
     else:
-        job = tiling.make_job(tm, cfg, rank, world, local_rank, build_sim)
+        job = SingleJob(build_sim(tm, cfg, local_rank))
     n_local = job.num_particles()
-    job.run(args.warmup)
-    job.synchronize()
-    # untimed pass, every phase bracketed: phase table + which transfer kernel dominates
-    job.set_profiling(1)
-    job.run(min(10, max(args.steps, 1)))
-    phase_prof = job.profile()
-    pms = {k: v / max(phase_prof["substeps"], 1) for k, v in phase_prof["phases"].items()}
-    dom = "g2p" if pms["g2p"] >= pms["p2g"] else "p2g"
-    job.set_profiling(2 if dom == "g2p" else 3)  # timed region: only the dominant kernel is bracketed
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    job.run(args.steps)
-    job.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def measure(warmup, steps):
+        """W untimed warm-up substeps | a short untimed pass with every phase bracketed (phase table, picks the
+        dominant transfer kernel) | barrier | K timed substeps with only the dominant kernel bracketed | barrier.
+        Returns (seconds, phase table in ms per substep with the dominant kernel taken from the timed region, which
+        kernel dominates, profile of the timed region)."""
+        job.run(warmup)
+        job.synchronize()
+        job.set_profiling(1)
+        job.run(min(10, max(steps, 1)))
+        phase_prof = job.profile()
+        pms = {k: v / max(phase_prof["substeps"], 1) for k, v in phase_prof["phases"].items()}
+        dom = "g2p" if pms["g2p"] >= pms["p2g"] else "p2g"
+        job.set_profiling(2 if dom == "g2p" else 3)  # timed region: only the dominant kernel is bracketed
+        barrier()
+        t0 = time.perf_counter()
+        job.run(steps)
+        job.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prof = job.profile()
+        job.set_profiling(0)
+        ms = dict(pms)
+        ms[dom] = prof["phases"][dom] / max(prof["substeps"], 1)
+        return elapsed, ms, dom, prof
+
+    def roofline_of(ms, dom, prof, traffic_tag):
+        n_per_gpu = prof["particles"]
+        nodes = prof["active_blocks"] * 64.0  # touched 4^3 blocks x 64 nodes (upper bound of touched nodes)
+        per_launch = {"p2g": n_per_gpu * 100.0 + nodes * 16.0, "g2p": n_per_gpu * 152.0 + nodes * 16.0}
+        achieved = per_launch[dom] / (ms[dom] * 1e-3) / 1e9
+        tbytes, tsrc = pmc_traffic(traffic_tag, "k_" + dom) if world == 1 else (None, None)
+        roof = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": (tbytes / (ms[dom] * 1e-3) / 1e9) if tbytes else None,
+                "traffic_bytes_per_launch": tbytes, "traffic_source": tsrc,
+                "algorithmic_bytes_per_launch": per_launch[dom], "avg_launch_ms": ms[dom]}
+        both = (per_launch["p2g"] + per_launch["g2p"]) / ((ms["p2g"] + ms["g2p"]) * 1e-3) / 1e9 / HBM_PEAK_GBS
+        return roof, both, n_per_gpu, nodes
+
+    if args.state == "evolved":  # make the evolved state the one that is measured (profiling runs)
+        evolve_to_impact(job.sim, cfg)
+        job.substeps += substeps_to_impact(cfg) + EVOLVE_AFTER_IMPACT
+    elapsed, ms, dom, prof = measure(args.warmup, args.steps)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -277,7 +436,6 @@ def main():
         n_total = int(nt.item())
     else:
         n_total = n_local
-    prof = job.profile()
     copy_gbs = None
     if world == 1 and not force_tiled:  # what a plain streaming copy reaches on THIS box, measured after the timed region
         try:
@@ -289,37 +447,49 @@ def main():
             dist.destroy_process_group()
         return
 
-    ms = dict(pms)  # phase table from the untimed pass ...
-    ms[dom] = prof["phases"][dom] / max(prof["substeps"], 1)  # ... dominant kernel from the timed region itself
-    n_per_gpu = prof["particles"]
-    nodes = prof["active_blocks"] * 64.0  # touched 4^3 blocks x 64 nodes (upper bound of touched nodes)
-    per_launch = {"p2g": n_per_gpu * 100.0 + nodes * 16.0, "g2p": n_per_gpu * 152.0 + nodes * 16.0}
-    achieved = per_launch[dom] / (ms[dom] * 1e-3) / 1e9
+    tag = args.config + ("_evolved" if args.state == "evolved" else "")
+    roof, both_frac, n_per_gpu, nodes = roofline_of(ms, dom, prof, tag)
+    roof["measured_copy_GBs"] = copy_gbs  # plain float4 copy kernel on this box (read + written bytes)
+    roof["frac_of_measured_copy"] = (roof["achieved"] / copy_gbs) if copy_gbs else None
     value = n_total * args.steps / elapsed
     whole_step_bytes = n_per_gpu * 252.0 + nodes * 16.0 * 5
-    tbytes, tsrc = pmc_traffic(args.config, "k_" + dom) if world == 1 else (None, None)
+    state_desc = ("the lattice the reference's benchmark seeds (8 particles per cell, F = I, slots in sorted order): the best "
+                  "case; see `evolved` for the same scene after the block has hit the floor")
+    if args.state == "evolved":
+        state_desc = "%d substeps after the block hit the floor (--state evolved)" % EVOLVE_AFTER_IMPACT
     out = {
         "metric": "particle-steps/sec (P2G+grid+G2P), 256^3 grid 8M particles; %HBM roofline",
         "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": job.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["desc"], "particles": n_total, "dt": 1e-4, "parallelism": job.parallelism, "wire": wire,
-                   "timed": "full substep: sort+reorder, P2G, grid normalise+boundary, G2P, boundary cleanup"},
-        "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS,
-                     "measured_copy_GBs": copy_gbs,  # plain float4 copy kernel on this box (read + written bytes)
-                     "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
-                     "traffic": (tbytes / (ms[dom] * 1e-3) / 1e9) if tbytes else None,
-                     "traffic_bytes_per_launch": tbytes, "traffic_source": tsrc,
-                     "algorithmic_bytes_per_launch": per_launch[dom], "avg_launch_ms": ms[dom]},
+                   "timed": "full substep: sort+reorder, P2G, grid normalise+boundary, G2P, boundary cleanup",
+                   "state": state_desc},
+        "roofline": roof,
         "phases_ms_per_step": ms,
         "p2g_plus_g2p_particle_steps_per_s": n_per_gpu / ((ms["p2g"] + ms["g2p"]) * 1e-3),
-        "p2g_plus_g2p_hbm_frac_algorithmic": (per_launch["p2g"] + per_launch["g2p"]) / ((ms["p2g"] + ms["g2p"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "p2g_plus_g2p_hbm_frac_algorithmic": both_frac,
         "whole_step_hbm_frac_algorithmic": whole_step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
     }
+    if world == 1 and not force_tiled and args.state == "lattice" and not args.no_evolved:
+        # the same scene after impact, on the same ctx: the state the lattice number flatters
+        try:
+            after = evolve_to_impact(job.sim, cfg)
+            job.substeps += substeps_to_impact(cfg) + after
+            e_el, e_ms, e_dom, e_prof = measure(5, args.steps)
+            e_roof, e_both, e_n, e_nodes = roofline_of(e_ms, e_dom, e_prof, args.config + "_evolved")
+            out["evolved"] = {
+                "substeps_before": job.substeps - args.steps,  # run on this ctx before the timed region of this object
+                "substeps_after_impact": after, "particles": e_n, "active_blocks": e_prof["active_blocks"],
+                "value": e_n * args.steps / e_el, "ms_per_step": 1e3 * e_el / args.steps, "phases_ms_per_step": e_ms,
+                "roofline": e_roof, "p2g_plus_g2p_hbm_frac_algorithmic": e_both,
+                "whole_step_hbm_frac_algorithmic": (e_n * 252.0 + e_nodes * 80.0) / (e_el / args.steps) / 1e9 / HBM_PEAK_GBS}
+        except Exception as e:
+            out["evolved"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            from oracle import refmpm
+            out["cpu_baseline"] = cpu_baseline_reference(cfg) if refmpm.available() else cpu_baseline(cfg)
         except Exception as e:  # the baseline is a reported extra: never lose the GPU line because of it
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     emit(out)

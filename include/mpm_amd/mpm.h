@@ -84,6 +84,14 @@ class MPM<3> {
     check(mpmhip_set_levelset_shapes(ctx_, (int32_t)shapes.size(), shapes.data(), friction), ctx_);
   }
 
+  // DynamicLevelSet(t0, t1, levelset(t0), levelset(t1)) as the python driver installs before every frame
+  // (scripts/async/async_mpm.py:119-127): two key frames blended linearly in time, boundary velocity included
+  void set_levelset(real t0, real t1, const std::vector<mpmhip_shape> &shapes0, const std::vector<mpmhip_shape> &shapes1,
+                    real friction) {
+    check(mpmhip_set_levelset_keyframes(ctx_, t0, t1, (int32_t)shapes0.size(), shapes0.data(), (int32_t)shapes1.size(),
+                                        shapes1.data(), friction), ctx_);
+  }
+
   // --- MPM<dim>::add_particles (src/mpm.cpp:77-270).  Sampling: the built-in benchmark generator
   // ("benchmark" = 125 | 8000, :149-186), a lattice "cube_lo"/"cube_hi" in cells, or explicit arrays through
   // the overload below.  Returns "" (the reference returns a rigid-body id only for type "rigid").

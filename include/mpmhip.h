@@ -130,6 +130,13 @@ typedef struct {
   float p[6];
 } mpmhip_shape;
 int mpmhip_set_levelset_shapes(mpmhip_ctx *ctx, int32_t n, const mpmhip_shape *shapes, float friction);
+/* time-dependent level set — replaces DynamicLevelSet::initialize(t0, t1, levelset(t0), levelset(t1)) +
+ * Simulation::set_levelset as the python driver calls them before every frame (scripts/async/async_mpm.py:119-127,
+ * e.g. the shrinking container of scripts/async/balls.py:38-49): two key frames blended linearly in time; at time t
+ * phi = lerp(phi0, phi1), the normal is the normalised lerp of the two gradients, and the grid boundary condition
+ * uses boundary_velocity = -(phi1 - phi0)/(t1 - t0) n delta_x (src/mpm.cpp:323-342).  t = the ctx's current time. */
+int mpmhip_set_levelset_keyframes(mpmhip_ctx *ctx, float t0, float t1, int32_t n0, const mpmhip_shape *shapes0,
+                                  int32_t n1, const mpmhip_shape *shapes1, float friction);
 
 /* A ctx holds at most MPMHIP_MAX_GROUPS groups (k_g2p mirrors the whole group table in LDS). */
 #define MPMHIP_MAX_GROUPS 64

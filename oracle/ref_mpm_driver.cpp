@@ -76,15 +76,27 @@ int add_particles(Handle *h, const Config &cfg, int64_t n, const float *x, const
   MPM<dim> &m = sim<dim>(h);
   const std::string type = cfg.get<std::string>("type");
   const real vol = cfg.get<real>("vol"), mass = cfg.get<real>("mass");
+  // one prototype goes through initialize(config) (string lookups); the others are byte copies of its container with
+  // their own id — the reference itself moves particles as container bytes (ParticleContainer's copy constructor,
+  // sort_allocator src/mpm.cpp:752-768)
+  ParticleContainer<dim> proto;
+  {
+    MPMParticle<dim> *pp = create_instance_placement<MPMParticle<dim>>(type, &proto);
+    pp->initialize(cfg);
+    pp->vol = vol;
+    pp->set_mass(mass);
+  }
+  m.allocator.pool.reserve(m.allocator.pool.size() + (size_t)n);
+  m.particles.reserve(m.particles.size() + (size_t)n);
   for (int64_t i = 0; i < n; i++) {  // = create_particle, src/mpm.cpp:101-147, with explicit state
     auto alloc = m.allocator.allocate_particle(type);
     MPMParticle<dim> *p = alloc.second;
-    p->initialize(cfg);
+    const int32 id = p->id;
+    memcpy(&m.allocator.pool[alloc.first], &proto, sizeof proto);
+    p->id = id;
     VectorND<dim, real> pos, vel(0.0f);
     for (int k = 0; k < dim; k++) { pos[k] = x[dim * i + k]; if (v) vel[k] = v[dim * i + k]; }
     p->pos = pos;
-    p->vol = vol;
-    p->set_mass(mass);
     p->set_velocity(vel);
     if (F) p->dg_e = mat_in<dim>(F + dim * dim * i);
     if (B) p->apic_b = mat_in<dim>(B + dim * dim * i);

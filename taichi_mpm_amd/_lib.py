@@ -14,6 +14,7 @@ _LIB = os.path.join(_LIBDIR, "libmpmhip.so")
 
 NPARAM = 16
 
+# (-munsafe-fp-atomics only matters to the 2D demo's global float atomics, k_mpm88.h: the 3D path has no float atomics)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics",
                "-Wno-unused-value"]
 
@@ -73,7 +74,7 @@ def build(force=False, verbose=False):
 
 _lib = None
 
-_SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_last_error", "mpmhip_set_stream", "mpmhip_set_levelset", "mpmhip_set_levelset_shapes",
+_SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_last_error", "mpmhip_set_stream", "mpmhip_set_levelset", "mpmhip_set_levelset_shapes", "mpmhip_set_levelset_keyframes",
             "mpmhip_add_group", "mpmhip_add_particles", "mpmhip_num_particles", "mpmhip_download",
             "mpmhip_upload", "mpmhip_substep", "mpmhip_run_substeps", "mpmhip_step", "mpmhip_current_time",
             "mpmhip_synchronize", "mpmhip_sort", "mpmhip_p2g", "mpmhip_grid_update", "mpmhip_g2p",
@@ -117,6 +118,7 @@ def load():
     L.mpmhip_set_stream.argtypes = [vp, vp]
     L.mpmhip_set_levelset.argtypes = [vp, C.c_int32, fp, C.c_float]
     L.mpmhip_set_levelset_shapes.argtypes = [vp, C.c_int32, P(Shape), C.c_float]
+    L.mpmhip_set_levelset_keyframes.argtypes = [vp, C.c_float, C.c_float, C.c_int32, P(Shape), C.c_int32, P(Shape), C.c_float]
     L.mpmhip_add_group.argtypes = [vp, C.c_int32, fp]
     L.mpmhip_add_particles.argtypes = [vp, C.c_int32, C.c_int64, fp, fp, fp, fp, fp]
     L.mpmhip_num_particles.argtypes = [vp]

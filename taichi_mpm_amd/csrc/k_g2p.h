@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
         const LevelSetDev &LS = *ls;  // in device memory: by value it would sit in ~130 SGPRs for a rarely used path
         const float xw[3] = {nx0, nx1, nx2};
         float phi, gr[3] = {0, 0, 0};
-        if (levelset_eval(LS, xw, P.idx, phi, gr) && phi < 0.0f) {
+        if (levelset_eval(LS, P.t, xw, P.idx, phi, gr) && phi < 0.0f) {
           const float vn = gr[0] * v0 + gr[1] * v1 + gr[2] * v2;
           nx0 -= gr[0] * phi * P.dx; nx1 -= gr[1] * phi * P.dx; nx2 -= gr[2] * phi * P.dx;
           v0 -= vn * gr[0]; v1 -= vn * gr[1]; v2 -= vn * gr[2];

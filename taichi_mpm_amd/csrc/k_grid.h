@@ -46,7 +46,11 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
       const int sx = bx + l / 9 - 1, sy = by + (l / 3) % 3 - 1, sz = bz + l % 3 - 1;
       if (sx >= 0 && sy >= 0 && sz >= 0) {
         const uint32_t bk = morton3(sx, sy, sz);
-        if (block_active(bits, bk)) nslot = block_slot(bits, wprefix, bk);
+        if (block_active(bits, bk)) {
+          // (a slot beyond max_blocks has no tile: the block table overflowed, the sticky capacity error is set)
+          const uint32_t ns = block_slot(bits, wprefix, bk);
+          if (ns < P.max_blocks) nslot = ns;
+        }
       }
     }
     const uint32_t amask = (uint32_t)__ballot(nslot != INVALID);
@@ -141,10 +145,11 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
       }
       if (m != 0.0f && LS.n > 0) {  // src/mpm.cpp:313-368
         const float xw[3] = {gi * P.dx, gj * P.dx, gk * P.dx};
-        float phi, nrm[3] = {0, 0, 0};
-        levelset_eval(LS, xw, P.idx, phi, nrm);
+        float phi, dphidt, nrm[3] = {0, 0, 0};
+        levelset_eval(LS, P.t, xw, P.idx, phi, nrm, &dphidt);
         if (!(phi < -3.0f || 0.0f < phi)) {
-          const float vb[3] = {0, 0, 0};
+          // boundary_velocity = -levelset.get_temporal_derivative(pos, t) * n * delta_x   (src/mpm.cpp:340-342)
+          const float vb[3] = {-dphidt * nrm[0] * P.dx, -dphidt * nrm[1] * P.dx, -dphidt * nrm[2] * P.dx};
           friction_project(v, vb, nrm, LS.friction);
         }
       }

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_delete_inside_levelset(Params P, RecG *
     if (rg[i].pid < 0) continue;
     const float xw[3] = {rg[i].x[0], rg[i].x[1], rg[i].x[2]};
     float phi, nrm[3];
-    if (levelset_eval(LS, xw, P.idx, phi, nrm) && phi < 0.0f) {
+    if (levelset_eval(LS, P.t, xw, P.idx, phi, nrm) && phi < 0.0f) {
       rg[i].pid = -1;
       atomicAdd(&cnt->n_dead, 1u);
     }

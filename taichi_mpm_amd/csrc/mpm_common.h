@@ -65,6 +65,7 @@ struct Counters {
 struct Params {
   int res[3];
   float dx, idx, dt;
+  float t;            // current_t of the substep in flight (dynamic level sets sample at this time)
   float g[3];
   int particle_gravity;
   float apic_damping, rpic_damping;

@@ -488,25 +488,33 @@ __device__ __forceinline__ void friction_project(float v[3], const float vb[3], 
 // Analytic level set: union of solids, phi = min over primitives, negative inside a solid (reference: taichi's
 // sampled LevelSet built by add_plane / add_sphere / add_cuboid in the scene scripts; sample() and
 // get_spatial_gradient() as used in src/mpm.cpp:323-326 and :416-421).  Returns phi in grid units and the unit
-// gradient of the active primitive.
+// gradient of the active primitive.  A DYNAMIC level set (taichi's DynamicLevelSet, which the python driver rebuilds
+// every frame from levelset_generator(t0), levelset_generator(t1): scripts/async/async_mpm.py:119-127) is two key
+// frames blended linearly in time: phi = lerp, gradient = normalised lerp of the two gradients,
+// d phi / dt = (phi1 - phi0) / (t1 - t0), which gives the boundary velocity of src/mpm.cpp:340-342.
+struct ShapeDev { int type, inside_out; float p[6]; };  // type 0 plane {n, d}, 1 sphere, 2 cuboid
 struct LevelSetDev {
   int n;
   float friction;
   int particle_collision;
-  int pad;
-  struct { int type, inside_out; float p[6]; } s[MPMHIP_MAX_SHAPES];  // type 0 plane {n, d}, 1 sphere, 2 cuboid
+  int dynamic;  // 1: s1 / n1 hold the key frame at t1, s / n the one at t0
+  int n1;
+  float t0, t1, pad;
+  ShapeDev s[MPMHIP_MAX_SHAPES];
+  ShapeDev s1[MPMHIP_MAX_SHAPES];
 };
 
-__device__ __forceinline__ bool levelset_eval(const LevelSetDev &L, const float x[3], float idx, float &phi, float n[3]) {
-  if (L.n <= 0) return false;
+__device__ __forceinline__ bool levelset_eval_key(const ShapeDev *S, int count, const float x[3], float idx, float &phi,
+                                                  float n[3]) {
+  if (count <= 0) return false;
   phi = 1e30f;
-  for (int i = 0; i < L.n; i++) {
-    const float *q = L.s[i].p;
+  for (int i = 0; i < count; i++) {
+    const float *q = S[i].p;
     float ph, g[3];
-    if (L.s[i].type == 0) {
+    if (S[i].type == 0) {
       ph = q[0] * x[0] + q[1] * x[1] + q[2] * x[2] + q[3];
       g[0] = q[0]; g[1] = q[1]; g[2] = q[2];
-    } else if (L.s[i].type == 1) {
+    } else if (S[i].type == 1) {
       const float d0 = x[0] - q[0], d1 = x[1] - q[1], d2 = x[2] - q[2];
       const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
       const float inv = len > 0.0f ? 1.0f / len : 0.0f;
@@ -537,10 +545,28 @@ __device__ __forceinline__ bool levelset_eval(const LevelSetDev &L, const float 
         g[0] = d0 / len; g[1] = d1 / len; g[2] = d2 / len;
       }
     }
-    if (L.s[i].type != 0 && L.s[i].inside_out) { ph = -ph; g[0] = -g[0]; g[1] = -g[1]; g[2] = -g[2]; }
+    if (S[i].type != 0 && S[i].inside_out) { ph = -ph; g[0] = -g[0]; g[1] = -g[1]; g[2] = -g[2]; }
     ph *= idx;
     if (ph < phi) { phi = ph; n[0] = g[0]; n[1] = g[1]; n[2] = g[2]; }
   }
+  return true;
+}
+
+// the level set at time t: phi (grid units), unit gradient, and — when asked — d phi / dt in grid units per second
+__device__ __forceinline__ bool levelset_eval(const LevelSetDev &L, float t, const float x[3], float idx, float &phi,
+                                              float n[3], float *dphidt = nullptr) {
+  if (dphidt) *dphidt = 0.0f;
+  if (!levelset_eval_key(L.s, L.n, x, idx, phi, n)) return false;
+  if (!L.dynamic) return true;
+  float phi1, n1[3] = {0.0f, 0.0f, 0.0f};
+  if (!levelset_eval_key(L.s1, L.n1, x, idx, phi1, n1)) return true;
+  const float a = (t - L.t0) / (L.t1 - L.t0);
+  if (dphidt) *dphidt = (phi1 - phi) / (L.t1 - L.t0);
+  phi = (1.0f - a) * phi + a * phi1;
+  const float g0 = n[0] * (1.0f - a) + n1[0] * a, g1 = n[1] * (1.0f - a) + n1[1] * a, g2 = n[2] * (1.0f - a) + n1[2] * a;
+  const float len = sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+  const float inv = len < 1e-10f ? 0.0f : 1.0f / len;
+  n[0] = g0 * inv; n[1] = g1 * inv; n[2] = g2 * inv;
   return true;
 }
 

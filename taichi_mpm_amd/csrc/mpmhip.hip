@@ -411,6 +411,7 @@ int mpmhip_set_levelset_shapes(mpmhip_ctx *c, int32_t n, const mpmhip_shape *sha
   }
   c->LS.n = n;
   c->LS.friction = friction;
+  c->LS.dynamic = 0; c->LS.n1 = 0;
   for (int i = 0; i < n; i++) {
     c->LS.s[i].type = shapes[i].type;
     c->LS.s[i].inside_out = shapes[i].inside_out;
@@ -421,6 +422,35 @@ int mpmhip_set_levelset_shapes(mpmhip_ctx *c, int32_t n, const mpmhip_shape *sha
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(c->d_LS, &c->LS, sizeof c->LS, hipMemcpyHostToDevice));
   }
+  return MPMHIP_OK;
+}
+
+static int check_shapes(mpmhip_ctx *c, int32_t n, const mpmhip_shape *shapes) {
+  if (n < 0 || n > MPMHIP_MAX_SHAPES || (n > 0 && !shapes)) return fail(c, MPMHIP_EINVAL, "between 0 and %d level-set shapes", MPMHIP_MAX_SHAPES);
+  for (int i = 0; i < n; i++) {
+    if (shapes[i].type < 0 || shapes[i].type > 2) return fail(c, MPMHIP_EINVAL, "shape %d: unknown type %d", i, shapes[i].type);
+    if (shapes[i].type == 1 && !(shapes[i].p[3] > 0)) return fail(c, MPMHIP_EINVAL, "shape %d: sphere radius must be > 0", i);
+    if (shapes[i].type == 2)
+      for (int k = 0; k < 3; k++)
+        if (!(shapes[i].p[k] < shapes[i].p[3 + k])) return fail(c, MPMHIP_EINVAL, "shape %d: cuboid needs lo < hi", i);
+  }
+  return MPMHIP_OK;
+}
+
+int mpmhip_set_levelset_keyframes(mpmhip_ctx *c, float t0, float t1, int32_t n0, const mpmhip_shape *shapes0, int32_t n1,
+                                  const mpmhip_shape *shapes1, float friction) {
+  if (!c) return MPMHIP_EINVAL;
+  if (!(t1 > t0)) return fail(c, MPMHIP_EINVAL, "key frame times must satisfy t0 < t1");
+  if (int rc = check_shapes(c, n0, shapes0)) return rc;
+  if (int rc = check_shapes(c, n1, shapes1)) return rc;
+  if (int rc = mpmhip_set_levelset_shapes(c, n0, shapes0, friction)) return rc;
+  c->LS.dynamic = 1; c->LS.n1 = n1; c->LS.t0 = t0; c->LS.t1 = t1;
+  for (int i = 0; i < n1; i++) {
+    c->LS.s1[i].type = shapes1[i].type;
+    c->LS.s1[i].inside_out = shapes1[i].inside_out;
+    for (int k = 0; k < 6; k++) c->LS.s1[i].p[k] = shapes1[i].p[k];
+  }
+  HIPCHK(c, hipMemcpy(c->d_LS, &c->LS, sizeof c->LS, hipMemcpyHostToDevice));
   return MPMHIP_OK;
 }
 
@@ -447,6 +477,18 @@ int mpmhip_add_group(mpmhip_ctx *c, int32_t material, const float params[MPMHIP_
   HIPCHK(c, hipMemcpyAsync(c->d_groups, c->groups.data(), sizeof(GroupParams) * c->groups.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return (int)c->groups.size() - 1;
+}
+
+// The particle positions changed behind k_g2p's back (uploads, new particles, deletions): key[] and the block flags
+// G2P wrote for the OLD positions must not leak into the next sort — k_build_keys only ORs new flags on top, so stale
+// ones would turn into phantom active blocks (empty tiles, inflated n_active, spurious capacity errors).
+static int invalidate_keys(mpmhip_ctx *c) {
+  c->sorted = false;
+  if (c->keys_valid) {
+    c->keys_valid = false;
+    HIPCHK(c, hipMemsetAsync(c->blk_flag, 0, (size_t)c->P.nbw * 32, c->stream));
+  }
+  return MPMHIP_OK;
 }
 
 // synchronise and read the device counters; reports the sticky capacity error
@@ -518,8 +560,8 @@ int mpmhip_add_particles(mpmhip_ctx *c, int32_t group, int64_t n, const float *x
   HIPCHK(c, hipMemcpy(c->rb + (size_t)c->n_slots * BW, hb.data(), sizeof(float) * n * BW, hipMemcpyHostToDevice));
   c->n_slots += n;
   c->P.n_slots = (uint32_t)c->n_slots;
-  c->sorted = c->keys_valid = c->affine_valid = false;
-  return MPMHIP_OK;
+  c->affine_valid = false;
+  return invalidate_keys(c);
 }
 
 int64_t mpmhip_num_particles(mpmhip_ctx *c) {
@@ -608,7 +650,8 @@ int mpmhip_upload(mpmhip_ctx *c, int32_t field, const void *src, int64_t n) {
   HIPCHK(c, hipMemcpy(c->rg, hg.data(), sizeof(RecG) * ns, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->rp, hp.data(), sizeof(RecP) * ns, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->rb, hb.data(), sizeof(float) * ns * BW, hipMemcpyHostToDevice));
-  if (field == MPMHIP_F_X || field == MPMHIP_F_V) c->sorted = c->keys_valid = false;
+  if (field == MPMHIP_F_X || field == MPMHIP_F_V)
+    if (int rc = invalidate_keys(c)) return rc;
   if (field == MPMHIP_F_B || field == MPMHIP_F_F || field == MPMHIP_F_AUX) c->affine_valid = false;
   return MPMHIP_OK;
 }
@@ -689,6 +732,7 @@ static int do_p2g(mpmhip_ctx *c, int phase = 0) {
   return launch_check(c, "p2g");
 }
 static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
+  c->P.t = c->t;  // this->current_t of the substep in flight (src/mpm.cpp:532-533)
   const bool per_cand = mode == 0 && c->n_slots < (2 << 20);  // small per-GPU problem: latency-bound, see k_grid
   auto kern = mode == 0 ? (per_cand ? k_grid<0, true> : k_grid<0, false>)
                         : (mode == 1 ? k_grid<1, false>
@@ -698,6 +742,7 @@ static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
   return launch_check(c, "grid");
 }
 static int do_g2p(mpmhip_ctx *c, int phase = 0) {
+  c->P.t = c->t;
   const bool sb = c->P.store_b != 0;
   auto kern = sb ? k_g2p<256, 3, true, true> : k_g2p<256, 3, true, false>;  // 3 waves/SIMD, rolled gather: fastest
   int nt = 256;
@@ -1000,11 +1045,19 @@ int mpmhip_snapshot_load(mpmhip_ctx *c, const void *src, size_t size) {
   for (int k = 0; k < 3; k++)
     if (h.res[k] != c->P.res[k]) return fail(c, MPMHIP_EINVAL, "snapshot is of a %dx%dx%d grid", h.res[0], h.res[1], h.res[2]);
   if (h.dx != c->P.dx) return fail(c, MPMHIP_EINVAL, "snapshot has delta_x = %g, the ctx %g", h.dx, c->P.dx);
+  // the stored P2G affine matrices carry the factor -4 inv_dx dt of the saving ctx (and apic_b is recovered with it)
+  if (h.dt != c->P.dt) return fail(c, MPMHIP_EINVAL, "snapshot has base_delta_t = %g, the ctx %g", h.dt, c->P.dt);
   if (h.n_slots < 0 || h.n_slots > c->cap) return fail(c, MPMHIP_ECAPACITY, "snapshot holds %lld particle slots, capacity is %lld", (long long)h.n_slots, (long long)c->cap);
   if ((int)h.n_groups > c->groups_cap) return fail(c, MPMHIP_ECAPACITY, "snapshot holds %u groups", h.n_groups);
   const size_t n = (size_t)h.n_slots;
   if (size < sizeof h + sizeof(GroupParams) * h.n_groups + n * (sizeof(RecG) + sizeof(RecP) + sizeof(float) * BW))
     return fail(c, MPMHIP_EINVAL, "snapshot is truncated");
+  {
+    const RecG *srg = reinterpret_cast<const RecG *>((const char *)src + sizeof h + sizeof(GroupParams) * h.n_groups);
+    for (size_t i = 0; i < n; i++)
+      if (srg[i].pid >= 0 && srg[i].gid >= h.n_groups)
+        return fail(c, MPMHIP_EINVAL, "snapshot record %zu refers to group %u of %u", i, srg[i].gid, h.n_groups);
+  }
   const char *p = (const char *)src + sizeof h;
   c->groups.assign((const GroupParams *)p, (const GroupParams *)p + h.n_groups); p += sizeof(GroupParams) * h.n_groups;
   if (h.n_groups) HIPCHK(c, hipMemcpy(c->d_groups, c->groups.data(), sizeof(GroupParams) * h.n_groups, hipMemcpyHostToDevice));
@@ -1040,12 +1093,13 @@ int mpmhip_delete_particles_inside_level_set(mpmhip_ctx *c, int64_t *deleted) {
   if (int rc = ensure_b_current(c)) return rc;  // the recovery reads every live record: do it before some die
   Counters before, after;
   if (int rc = read_counters(c, before)) return rc;
+  c->P.t = c->t;
   hipLaunchKernelGGL(k_delete_inside_levelset, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, (RecG *)c->rg,
                      c->LS, c->cnt);
   if (int rc = launch_check(c, "delete_inside_levelset")) return rc;
   if (int rc = read_counters(c, after)) return rc;
   *deleted = (int64_t)after.n_dead - (int64_t)before.n_dead;
-  if (*deleted) c->sorted = c->keys_valid = false;  // key[] still lists the deleted ones: rebuild
+  if (*deleted) return invalidate_keys(c);  // key[] still lists the deleted ones: rebuild
   return MPMHIP_OK;
 }
 

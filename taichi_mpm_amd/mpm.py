@@ -80,6 +80,21 @@ class LevelSet:
         return [(t_, io) + tuple(p[:4] if t_ == 1 else p) for t_, io, p in self.shapes if t_ != 0]
 
 
+class DynamicLevelSet:
+    """taichi's DynamicLevelSet as the python driver builds it every frame (scripts/async/async_mpm.py:119-127):
+    `initialize(t0, t1, levelset(t0), levelset(t1))`; the two key frames are blended linearly in time on the device
+    (include/mpmhip.h: mpmhip_set_levelset_keyframes)."""
+
+    def __init__(self):
+        self.t0, self.t1, self.levelset0, self.levelset1 = 0.0, 1.0, None, None
+
+    def initialize(self, t0, t1, levelset0, levelset1):
+        if not float(t1) > float(t0):
+            raise MPMError("DynamicLevelSet needs t0 < t1")
+        self.t0, self.t1, self.levelset0, self.levelset1 = float(t0), float(t1), levelset0, levelset1
+        return self
+
+
 def _vec3(v, default):
     if v is None:
         v = default
@@ -314,22 +329,32 @@ class Simulation3D:
         return out
 
     # ---------------------------------------------------------------- level set
-    def set_levelset(self, levelset, is_dynamic=False):
-        if is_dynamic:
-            raise MPMError("dynamic level sets are outside the scope of this build")
+    def set_levelset(self, levelset):
+        """Simulation::set_levelset: a LevelSet (static) or a DynamicLevelSet (two key frames)"""
         self._levelset = levelset
         if self._ctx is not None:
             self._apply_levelset()
+
+    @staticmethod
+    def _shape_array(ls):
+        arr = (_lib.Shape * max(len(ls.shapes), 1))()
+        for i, (t_, io, p) in enumerate(ls.shapes):
+            arr[i].type, arr[i].inside_out = t_, io
+            arr[i].p[:] = p
+        return arr
 
     def _apply_levelset(self):
         ls = self._levelset
         if ls is None:
             return
-        arr = (_lib.Shape * max(len(ls.shapes), 1))()
-        for i, (t_, io, p) in enumerate(ls.shapes):
-            arr[i].type, arr[i].inside_out = t_, io
-            arr[i].p[:] = p
-        self._check(self._L.mpmhip_set_levelset_shapes(self._ctx, len(ls.shapes), arr, ls.friction))
+        if isinstance(ls, DynamicLevelSet):
+            l0, l1 = ls.levelset0, ls.levelset1
+            # key frame times are relative to the ctx clock (a re-created ctx restarts it at 0)
+            off = getattr(self, "_time_offset", 0.0)
+            self._check(self._L.mpmhip_set_levelset_keyframes(self._ctx, ls.t0 - off, ls.t1 - off, len(l0.shapes), self._shape_array(l0),
+                                                              len(l1.shapes), self._shape_array(l1), l0.friction))
+            return
+        self._check(self._L.mpmhip_set_levelset_shapes(self._ctx, len(ls.shapes), self._shape_array(ls), ls.friction))
 
     # ---------------------------------------------------------------- stepping
     def step(self, dt):
@@ -557,14 +582,25 @@ class MPM:
     def create_levelset(self):
         return LevelSet()
 
-    def set_levelset(self, levelset, is_dynamic_levelset=False):
-        self.c.set_levelset(levelset, is_dynamic_levelset)
+    def update_levelset(self, t0, t1):  # scripts/async/async_mpm.py:119-127
+        if self.levelset_generator is None:
+            return
+        self.c.set_levelset(DynamicLevelSet().initialize(t0, t1, self.levelset_generator(t0), self.levelset_generator(t1)))
+
+    def set_levelset(self, levelset, is_dynamic_levelset=False):  # scripts/async/async_mpm.py:129-137
+        if is_dynamic_levelset:
+            self.levelset_generator = levelset  # a function t -> LevelSet, sampled at both ends of every frame
+        else:
+            self.levelset_generator = None
+            self.c.set_levelset(levelset)
 
     def get_current_time(self):
         return self.c.get_current_time()
 
     def step(self, step_t):
         import time
+        t = self.c.get_current_time()
+        self.update_levelset(t, t + step_t)
         T = time.time()
         self.c.step(step_t)
         self.c.synchronize()
