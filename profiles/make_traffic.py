@@ -11,11 +11,15 @@ import sys
 from collections import defaultdict
 
 
+LAST = None
+
+
 def means(path, counter):
     acc = defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
             acc[r["Kernel_Name"].split("(")[0].replace("void ", "").replace("mpm::", "").split("<")[0]].append(float(r["Counter_Value"]))
+    acc = {k: (v[-LAST:] if LAST else v) for k, v in acc.items()}
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
@@ -31,4 +35,8 @@ def main(fetch_csv, write_csv):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:3])
+    args = sys.argv[1:]
+    if args and args[0] == "--last":  # only the last N dispatches of every kernel
+        LAST = int(args[1])
+        args = args[2:]
+    main(*args[:2])

@@ -5,6 +5,10 @@ from collections import defaultdict
 
 
 def main(paths):
+    last = None
+    if paths and paths[0] == "--last":  # only the last N dispatches of every kernel (the end of an evolving run)
+        last = int(paths[1])
+        paths = paths[2:]
     acc = defaultdict(lambda: defaultdict(list))
     for path in paths:
         for r in csv.DictReader(open(path)):
@@ -17,7 +21,7 @@ def main(paths):
         print(name)
         for c in counters:
             if c in d:
-                v = d[c]
+                v = d[c][-last:] if last else d[c]
                 print("   %-22s %14.4g   (n=%d)" % (c, sum(v) / len(v), len(v)))
 
 

@@ -10,7 +10,10 @@ _SRC = os.path.join(_HERE, "csrc", "mpmhip.hip")
 _DEPS = [_SRC, os.path.join(_ROOT, "include", "mpmhip.h")] + sorted(
     os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith(".h"))
 _LIBDIR = os.path.join(_HERE, "lib")
-_LIB = os.path.join(_LIBDIR, "libmpmhip.so")
+# MPMHIP_LIB_VARIANT=<name> loads lib/libmpmhip_<name>.so: an A/B build of the same sources with extra -D flags
+# (build_variant below; tuning experiments only — the default library is the product)
+_VARIANT = os.environ.get("MPMHIP_LIB_VARIANT", "")
+_LIB = os.path.join(_LIBDIR, "libmpmhip%s.so" % (("_" + _VARIANT) if _VARIANT else ""))
 
 NPARAM = 16
 
@@ -72,6 +75,14 @@ def build(force=False, verbose=False):
     return _LIB
 
 
+def build_variant(name, extra_flags):
+    """lib/libmpmhip_<name>.so from the same sources with extra compiler flags (A/B timing on one box)"""
+    os.makedirs(_LIBDIR, exist_ok=True)
+    out = os.path.join(_LIBDIR, "libmpmhip_%s.so" % name)
+    subprocess.check_call([_hipcc()] + HIPCC_FLAGS + list(extra_flags) + [_SRC, "-o", out])
+    return out
+
+
 _lib = None
 
 _SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_last_error", "mpmhip_set_stream", "mpmhip_set_levelset", "mpmhip_set_levelset_shapes", "mpmhip_set_levelset_keyframes",
@@ -83,7 +94,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_las
             "mpmhip_substep_begin", "mpmhip_substep_end", "mpmhip_substep_interior", "mpmhip_set_overlap", "mpmhip_leaver_counts", "mpmhip_migration_scan", "mpmhip_export_leavers",
             "mpmhip_import_particles", "mpmhip_active_bounds", "mpmhip_num_slots", "mpmhip_request_compaction", "mpmhip_mpm88_create", "mpmhip_mpm88_destroy", "mpmhip_mpm88_last_error", "mpmhip_mpm88_add",
             "mpmhip_mpm88_num_particles", "mpmhip_mpm88_advance", "mpmhip_mpm88_download", "mpmhip_mpm88_download_grid",
-            "mpmhip_debug_copy_bandwidth", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
+            "mpmhip_debug_copy_bandwidth", "mpmhip_debug_gather_bandwidth", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
 
 
 def exported_symbols():
@@ -107,6 +118,17 @@ def load():
     except ImportError:
         pass
     L = C.CDLL(_LIB)
+    if _VARIANT:  # an A/B build may predate the newest entry points: give those inert stand-ins
+        class _Tolerant:
+            def __init__(self, lib):
+                object.__setattr__(self, "_lib", lib)
+
+            def __getattr__(self, name):
+                try:
+                    return getattr(self._lib, name)
+                except AttributeError:
+                    return C.CFUNCTYPE(C.c_int)(lambda *a: -38)
+        L = _Tolerant(L)
     P = C.POINTER
     vp, fp = C.c_void_p, P(C.c_float)
     L.mpmhip_abi_version.restype = C.c_uint32
@@ -161,6 +183,7 @@ def load():
     L.mpmhip_mpm88_download.argtypes = [vp, fp, fp, fp, fp, fp]
     L.mpmhip_mpm88_download_grid.argtypes = [vp, fp]
     L.mpmhip_debug_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int32, P(C.c_double)]
+    L.mpmhip_debug_gather_bandwidth.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, P(C.c_double)]
     L.mpmhip_bgeo_size.argtypes = [vp, C.c_int32, P(C.c_size_t)]
     L.mpmhip_bgeo_encode.argtypes = [vp, C.c_int32, C.c_void_p, C.c_size_t, P(C.c_size_t)]
     L.mpmhip_write_bgeo.argtypes = [vp, C.c_char_p, C.c_int32]

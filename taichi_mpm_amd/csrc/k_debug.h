@@ -23,6 +23,34 @@ __global__ __launch_bounds__(256) void k_stream_copy(float4 *__restrict__ dst, c
   for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// 64-byte record gather with a KNOWN byte count: the access pattern of the transfer kernels (one lane fetches one
+// whole record with four 16-byte loads through an index), used to calibrate rocprofv3's FETCH_SIZE for this width
+// (profiles/calibrate_fetch.py): n records of 64 B + n indices of 4 B read, 16 B per workgroup written.
+__global__ __launch_bounds__(256) void k_gather_records_probe(const float4 *__restrict__ rec, const uint32_t *__restrict__ idx,
+                                                              uint32_t n, float4 *__restrict__ out) {
+  float4 acc = make_float4(0, 0, 0, 0);
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const size_t i = idx[p];
+    const float4 a = rec[i * 4 + 0], b = rec[i * 4 + 1], c = rec[i * 4 + 2], d = rec[i * 4 + 3];
+    acc.x += a.x + b.x; acc.y += a.y + c.y; acc.z += b.z + d.z; acc.w += c.w + d.w;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off); acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+  }
+  if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = acc;
+}
+// index patterns for the probe: 0 identity, 1 blocks of 8 consecutive records in shuffled order (the decayed order of an
+// evolved scene: cell-sized runs), 2 fully shuffled (multiplicative hash bijection on a power-of-two range)
+__global__ __launch_bounds__(256) void k_probe_indices(uint32_t *__restrict__ idx, uint32_t n, int mode) {
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    uint32_t i = p;
+    if (mode == 1) i = ((((p >> 3) * 2654435761u) & ((n >> 3) - 1u)) << 3) | (p & 7u);   // n: power of two
+    else if (mode == 2) i = (p * 2654435761u) & (n - 1u);
+    idx[p] = i;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ debug math
 __global__ void k_debug_svd(int64_t n, const float *F, float *U, float *S, float *V) {
   for (int64_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {

@@ -80,6 +80,9 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
   uint32_t i_nx = lane_slot(nx);
   uint32_t tile_a = INVALID;
   float ox = 0, oy = 0, oz = 0;
+  // the outgoing records of a lane (lanes without a particle leave stale values here: they are never stored)
+  float4 G0, G1, G2, G3, Q0, Q1, Q2, Q3, B0, B1, B2;
+  G0 = G1 = G2 = G3 = Q0 = Q1 = Q2 = Q3 = B0 = B1 = B2 = make_float4(0, 0, 0, 0);
   while (cur.a < na) {
     if (cur.a != tile_a) {
       // LDS-only barriers (lgkmcnt(0) + s_barrier): __syncthreads() would also wait on vmcnt, i.e. on the
@@ -108,8 +111,6 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
     }
     const uint32_t i_nn = lane_slot(nn);
     uint32_t bkey = INVALID, out_slot = INVALID;
-    float4 G0, G1, G2, G3, Q0, Q1, Q2, Q3, B0, B1, B2;
-    G0 = G1 = G2 = G3 = Q0 = Q1 = Q2 = Q3 = B0 = B1 = B2 = make_float4(0, 0, 0, 0);
     auto particle = [&](const GroupParams &g) __attribute__((always_inline)) {
       const size_t i = i_cur;
       const float x0 = g0.x, x1 = g0.y, x2 = g0.z;
@@ -118,39 +119,47 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
       const float r0 = X0 - (float)c0, r1 = X1 - (float)c1, r2 = X2 - (float)c2;
       float w0[3], w1[3], w2[3];
       bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
-      float v0 = 0, v1 = 0, v2 = 0;
-      mat3 b;
-#pragma unroll
-      for (int k = 0; k < 9; k++) b.m[k] = 0.0f;
+      // 27-tap gather, :888-904:  v = sum w g,  b[:, c] = sum (w d_c) g  with  w = w0[i] w1[j] w2[k],  d = r - (i, j, k).
+      // The weights factor along the axes, so the sums are taken axis by axis — 4 multiply-adds per node on the (x, y) and
+      // (z, m) register pairs of the tile's float4 (packed fp32: v_pk_fma_f32) instead of 15 scalar ones per node:
+      //   S0 = sum_k w2[k] g,  S1 = sum_k (w2 d2)[k] g;   T0 = sum_j w1[j] S0,  T1 = sum_j (w1 d1)[j] S0,  T2 = sum_j w1[j] S1;
+      //   v = sum_i w0[i] T0,  b[:,0] = sum_i (w0 d0)[i] T0,  b[:,1] = sum_i w0[i] T1,  b[:,2] = sum_i w0[i] T2
+      // (the m lanes ride along unused).  Same terms as the reference's loop, summed in a different order.
+      const float e0[3] = {w0[0] * r0, w0[1] * (r0 - 1.0f), w0[2] * (r0 - 2.0f)};
+      const float e1[3] = {w1[0] * r1, w1[1] * (r1 - 1.0f), w1[2] * (r1 - 2.0f)};
+      const float e2[3] = {w2[0] * r2, w2[1] * (r2 - 1.0f), w2[2] * (r2 - 2.0f)};
+      const f2 z2 = {0.0f, 0.0f};
+      f2 vxy = z2, vzw = z2, b0xy = z2, b0zw = z2, b1xy = z2, b1zw = z2, b2xy = z2, b2zw = z2;
       const int nbase = (c0 * TS + c1) * TS + c2;
-      auto plane = [&](int i3) __attribute__((always_inline)) {
-        const float d0 = r0 - (float)i3;
+      auto plane = [&](int i3, float w0i, float e0i) __attribute__((always_inline)) {
+        f2 T0xy = z2, T0zw = z2, T1xy = z2, T1zw = z2, T2xy = z2, T2zw = z2;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-          const float d1 = r1 - (float)j;
-          const float wij = w0[i3] * w1[j];
+          f2 S0xy = z2, S0zw = z2, S1xy = z2, S1zw = z2;
 #pragma unroll
           for (int k = 0; k < 3; k++) {
-            const float d2 = r2 - (float)k;
-            const float w = wij * w2[k];
             const float4 gv = tile[nbase + (i3 * TS + j) * TS + k];
-            // :898-903  v_ = fma(grid_vel, w, v_);  b_[r] = fma(w*grid_vel, dpos[r], b_[r])
-            v0 = fmaf(gv.x, w, v0); v1 = fmaf(gv.y, w, v1); v2 = fmaf(gv.z, w, v2);
-            const float a0 = w * gv.x, a1 = w * gv.y, a2 = w * gv.z;
-            b(0, 0) = fmaf(a0, d0, b(0, 0)); b(0, 1) = fmaf(a0, d1, b(0, 1)); b(0, 2) = fmaf(a0, d2, b(0, 2));
-            b(1, 0) = fmaf(a1, d0, b(1, 0)); b(1, 1) = fmaf(a1, d1, b(1, 1)); b(1, 2) = fmaf(a1, d2, b(1, 2));
-            b(2, 0) = fmaf(a2, d0, b(2, 0)); b(2, 1) = fmaf(a2, d1, b(2, 1)); b(2, 2) = fmaf(a2, d2, b(2, 2));
+            const f2 gxy = {gv.x, gv.y}, gzw = {gv.z, gv.w};
+            S0xy = fma2(splat2(w2[k]), gxy, S0xy); S0zw = fma2(splat2(w2[k]), gzw, S0zw);
+            S1xy = fma2(splat2(e2[k]), gxy, S1xy); S1zw = fma2(splat2(e2[k]), gzw, S1zw);
           }
+          T0xy = fma2(splat2(w1[j]), S0xy, T0xy); T0zw = fma2(splat2(w1[j]), S0zw, T0zw);
+          T1xy = fma2(splat2(e1[j]), S0xy, T1xy); T1zw = fma2(splat2(e1[j]), S0zw, T1zw);
+          T2xy = fma2(splat2(w1[j]), S1xy, T2xy); T2zw = fma2(splat2(w1[j]), S1zw, T2zw);
         }
+        vxy = fma2(splat2(w0i), T0xy, vxy); vzw = fma2(splat2(w0i), T0zw, vzw);
+        b0xy = fma2(splat2(e0i), T0xy, b0xy); b0zw = fma2(splat2(e0i), T0zw, b0zw);
+        b1xy = fma2(splat2(w0i), T1xy, b1xy); b1zw = fma2(splat2(w0i), T1zw, b1zw);
+        b2xy = fma2(splat2(w0i), T2xy, b2xy); b2zw = fma2(splat2(w0i), T2zw, b2zw);
       };
       if (!(P.ablate & 4)) {
-        if constexpr (ROLL) {  // rolled i-loop: 9 LDS reads in flight instead of 27 (VGPR pressure -> occupancy)
-#pragma unroll 1
-          for (int i3 = 0; i3 < 3; i3++) plane(i3);
-        } else {
-          plane(0); plane(1); plane(2);
-        }
+        plane(0, w0[0], e0[0]); plane(1, w0[1], e0[1]); plane(2, w0[2], e0[2]);
       }
+      float v0 = vxy.x, v1 = vxy.y, v2 = vzw.x;
+      mat3 b;
+      b(0, 0) = b0xy.x; b(1, 0) = b0xy.y; b(2, 0) = b0zw.x;
+      b(0, 1) = b1xy.x; b(1, 1) = b1xy.y; b(2, 1) = b1zw.x;
+      b(0, 2) = b2xy.x; b(1, 2) = b2xy.y; b(2, 2) = b2zw.x;
       mat3 cdg;  // :940-942  cdg = I + (-4 inv_dx dt) b   (undamped b, as in the reference)
 #pragma unroll
       for (int r = 0; r < 3; r++)

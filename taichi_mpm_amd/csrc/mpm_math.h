@@ -20,6 +20,11 @@ namespace mpm {
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
+// packed fp32: two lanes of a 64-bit register pair per instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on gfx950)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat2(float a) { return (f2){a, a}; }
+
 struct mat3 {
   float m[9];  // row-major
   __device__ __forceinline__ float &operator()(int r, int c) { return m[3 * r + c]; }
@@ -33,11 +38,14 @@ __device__ __forceinline__ mat3 mat_identity() {
   return r;
 }
 __device__ __forceinline__ mat3 mat_mul(const mat3 &A, const mat3 &B) {
-  mat3 C;
+  mat3 C;  // row r of C = sum_k A(r,k) * row k of B: the (c0, c1) pair of every row goes through packed fp32
+  const f2 b0 = {B(0, 0), B(0, 1)}, b1 = {B(1, 0), B(1, 1)}, b2 = {B(2, 0), B(2, 1)};
 #pragma unroll
-  for (int r = 0; r < 3; r++)
-#pragma unroll
-    for (int c = 0; c < 3; c++) C(r, c) = fmaf(A(r, 0), B(0, c), fmaf(A(r, 1), B(1, c), A(r, 2) * B(2, c)));
+  for (int r = 0; r < 3; r++) {
+    const f2 c01 = fma2(splat2(A(r, 0)), b0, fma2(splat2(A(r, 1)), b1, splat2(A(r, 2)) * b2));
+    C(r, 0) = c01.x; C(r, 1) = c01.y;
+    C(r, 2) = fmaf(A(r, 0), B(0, 2), fmaf(A(r, 1), B(1, 2), A(r, 2) * B(2, 2)));
+  }
   return C;
 }
 // A * B^T
@@ -54,34 +62,47 @@ __device__ __forceinline__ float mat_det(const mat3 &m) {
          m(0, 2) * (m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0));
 }
 
-// One Jacobi rotation annihilating a_pq of the symmetric matrix {app,aqq,arr,apq,apr,aqr};
-// r is the third index.  U's columns p,q are rotated along.  Branch-free: t = 0 when a_pq = 0.
-__device__ __forceinline__ void jacobi_rotate(float &app, float &aqq, float &apq, float &arp, float &arq,
-                                              float &u0p, float &u0q, float &u1p, float &u1q, float &u2p,
-                                              float &u2q) {
-  const float d = aqq - app;
-  // t = tan(phi): root of t^2 + 2 theta t - 1 = 0 with theta = d/(2 a_pq), in the cancellation-free form
-  const float den = fabsf(d) + fast_sqrt(fmaf(d, d, 4.0f * apq * apq));
-  const float t = (den > 0.0f) ? copysignf(2.0f * apq, d * apq) * fast_rcp(den) : 0.0f;
-  const float c = rsqrtf(fmaf(t, t, 1.0f));
-  const float s = t * c;
-  app = fmaf(-t, apq, app);
-  aqq = fmaf(t, apq, aqq);
+// One Jacobi rotation annihilating a_pq of the symmetric matrix {app,aqq,arr,apq,arp,arq}; r is the third index.
+// Columns p,q of U are rotated along (U is kept by columns: (U0k, U1k) as a register pair + U2k, so that the three rows
+// of a rotation go through packed fp32).  With d = aqq - app, x = 2 a_pq, h = sqrt(d^2 + x^2) and den = |d| + h the
+// classical small-angle root is t = tan(phi) = sgn(d) x / den, hence
+//     (cos, sin) = (den, sgn(d) x) / sqrt(den^2 + x^2),        {app', aqq'} = (app + aqq -+ sgn(d) h) / 2
+// (the rotated diagonal is the eigenvalue pair of the 2x2 block): one v_sqrt and one v_rsq per rotation, no division.
+// d = x = 0 (to within 1e-15 of nothing) leaves everything unchanged.
+__device__ __forceinline__ void jacobi_rotate(float &app, float &aqq, float &apq, float &arp, float &arq, f2 &up01,
+                                              float &up2, f2 &uq01, float &uq2) {
+  const float d = aqq - app, x = apq + apq;
+  const float xx = x * x;
+  const float h = fast_sqrt(fmaf(d, d, xx));
+  const float den = fabsf(d) + h;
+  const float n2 = fmaf(den, den, xx);
+  const float r = __builtin_amdgcn_rsqf(n2);
+  const bool live = n2 > 1e-30f;  // (below: d = x = 0 up to denormals, which v_rsq_f32 does not take — nothing to rotate)
+  const uint32_t sd = __float_as_uint(d) & 0x80000000u;  // sgn(d), +1 at d = 0
+  const float c = live ? den * r : 1.0f;
+  const float sn = live ? __uint_as_float(__float_as_uint(x * r) ^ sd) : 0.0f;
+  const float sum = app + aqq, hs = __uint_as_float(__float_as_uint(h) | sd);
+  app = 0.5f * (sum - hs);
+  aqq = 0.5f * (sum + hs);
   apq = 0.0f;
-  const float nrp = c * arp - s * arq, nrq = s * arp + c * arq;
+  const float nrp = c * arp - sn * arq, nrq = sn * arp + c * arq;
   arp = nrp; arq = nrq;
-  float n;
-  n = c * u0p - s * u0q; u0q = s * u0p + c * u0q; u0p = n;
-  n = c * u1p - s * u1q; u1q = s * u1p + c * u1q; u1p = n;
-  n = c * u2p - s * u2q; u2q = s * u2p + c * u2q; u2p = n;
+  const f2 c2 = splat2(c), s2 = splat2(sn);
+  const f2 np01 = fma2(c2, up01, -(s2 * uq01));
+  uq01 = fma2(s2, up01, c2 * uq01);
+  up01 = np01;
+  const float np2 = c * up2 - sn * uq2;
+  uq2 = sn * up2 + c * uq2;
+  up2 = np2;
 }
 
 constexpr int kJacobiSweeps = 4;
 
 // Eigen-decomposition of the symmetric positive semi-definite A = F F^T:  A = U diag(lam) U^T.
-// U is a proper rotation (product of Givens rotations).  Unsorted.  Cyclic Jacobi converges quadratically; from
-// the third sweep on the wavefront stops as soon as every lane's off-diagonal is below 1e-7 * trace (all users
-// are isotropic functions U f(lam) U^T, whose error is ~f' * |off-diagonal|, also for near-equal eigenvalues).
+// U is a proper rotation (product of Givens rotations).  Unsorted.  Cyclic Jacobi converges quadratically; the
+// wavefront stops as soon as every lane's off-diagonal is below 1e-7 * trace (all users are isotropic functions
+// U f(lam) U^T, whose error is ~f' * |off-diagonal|, also for near-equal eigenvalues).  The test runs before every
+// sweep: material at rest or in free fall (F F^T diagonal to rounding) costs no sweep at all.
 __device__ __forceinline__ void sym_eig3_FFt(const mat3 &F, mat3 &U, float lam[3]) {
   float a00 = fmaf(F(0, 0), F(0, 0), fmaf(F(0, 1), F(0, 1), F(0, 2) * F(0, 2)));
   float a11 = fmaf(F(1, 0), F(1, 0), fmaf(F(1, 1), F(1, 1), F(1, 2) * F(1, 2)));
@@ -89,15 +110,19 @@ __device__ __forceinline__ void sym_eig3_FFt(const mat3 &F, mat3 &U, float lam[3
   float a01 = fmaf(F(0, 0), F(1, 0), fmaf(F(0, 1), F(1, 1), F(0, 2) * F(1, 2)));
   float a02 = fmaf(F(0, 0), F(2, 0), fmaf(F(0, 1), F(2, 1), F(0, 2) * F(2, 2)));
   float a12 = fmaf(F(1, 0), F(2, 0), fmaf(F(1, 1), F(2, 1), F(1, 2) * F(2, 2)));
-  U = mat_identity();
+  f2 u0 = {1.0f, 0.0f}, u1 = {0.0f, 1.0f}, u2 = {0.0f, 0.0f};  // columns of U: rows 0,1
+  float w0 = 0.0f, w1 = 0.0f, w2 = 1.0f;                        //               row 2
   const float tol = 1e-7f * (a00 + a11 + a22);
 #pragma unroll
   for (int sweep = 0; sweep < kJacobiSweeps; sweep++) {
-    if (sweep >= 2 && !__any(fmaxf(fabsf(a01), fmaxf(fabsf(a02), fabsf(a12))) > tol)) break;
-    jacobi_rotate(a00, a11, a01, a02, a12, U.m[0], U.m[1], U.m[3], U.m[4], U.m[6], U.m[7]);  // (p,q,r)=(0,1,2)
-    jacobi_rotate(a00, a22, a02, a01, a12, U.m[0], U.m[2], U.m[3], U.m[5], U.m[6], U.m[8]);  // (0,2,1)
-    jacobi_rotate(a11, a22, a12, a01, a02, U.m[1], U.m[2], U.m[4], U.m[5], U.m[7], U.m[8]);  // (1,2,0)
+    if (!__any(fmaxf(fabsf(a01), fmaxf(fabsf(a02), fabsf(a12))) > tol)) break;
+    jacobi_rotate(a00, a11, a01, a02, a12, u0, w0, u1, w1);  // (p,q,r)=(0,1,2)
+    jacobi_rotate(a00, a22, a02, a01, a12, u0, w0, u2, w2);  // (0,2,1)
+    jacobi_rotate(a11, a22, a12, a01, a02, u1, w1, u2, w2);  // (1,2,0)
   }
+  U(0, 0) = u0.x; U(1, 0) = u0.y; U(2, 0) = w0;
+  U(0, 1) = u1.x; U(1, 1) = u1.y; U(2, 1) = w1;
+  U(0, 2) = u2.x; U(1, 2) = u2.y; U(2, 2) = w2;
   lam[0] = a00; lam[1] = a11; lam[2] = a22;
 }
 
@@ -126,6 +151,19 @@ __device__ __forceinline__ mat3 sandwich(const mat3 &U, const float d[3]) {
       R(c, r) = v;
     }
   return R;
+}
+// (U diag(d1) U^T, U diag(d2) U^T) together: the dyads U(r,k) U(c,k) are formed once and each entry pair goes through
+// packed fp32
+__device__ __forceinline__ void sandwich2(const mat3 &U, const float d1[3], const float d2[3], mat3 &R1, mat3 &R2) {
+  const f2 e0 = {d1[0], d2[0]}, e1 = {d1[1], d2[1]}, e2 = {d1[2], d2[2]};
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = r; c < 3; c++) {
+      const f2 v = fma2(splat2(U(r, 0) * U(c, 0)), e0, fma2(splat2(U(r, 1) * U(c, 1)), e1, splat2(U(r, 2) * U(c, 2)) * e2));
+      R1(r, c) = v.x; R1(c, r) = v.x;
+      R2(r, c) = v.y; R2(c, r) = v.y;
+    }
 }
 
 struct GroupParams {
@@ -366,8 +404,9 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
       ratio[i] = sn[i] / s[i];
       d[i] = -vol * fmaf(2.0f * g.p[2], sn[i] * sn[i] - sn[i], vol_l);
     }
-    F = mat_mul(sandwich(U, ratio), F);
-    stress = sandwich(U, d);
+    mat3 Rr;
+    sandwich2(U, ratio, d, Rr, stress);
+    F = mat_mul(Rr, F);
     return;
   }
   F = mat_mul(cdg, F);
@@ -465,8 +504,9 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
     for (int i = 0; i < 3; i++) d[i] = -vol * fmaf(2.0f * mu0, h[i], la0 * trh);
     if (dg <= 0.0f) { stress = sandwich(U, d); return; }
   }
-  F = mat_mul(sandwich(U, ratio), F);
-  stress = sandwich(U, d);
+  mat3 Rr;
+  sandwich2(U, ratio, d, Rr, stress);
+  F = mat_mul(Rr, F);
 }
 
 // friction_project — src/mpm_fwd.h:25-57

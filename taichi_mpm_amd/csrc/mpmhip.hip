@@ -109,7 +109,7 @@ struct mpmhip_ctx {
   int p2g_wgs = 16384;        // workgroups of k_p2g (env MPMHIP_P2G_WGS)
   int p2g_split = 11;         // tuning knob (env MPMHIP_P2G_SPLIT): 10*NS + PS, see do_p2g
   int g2p_wgs = 4096;         // workgroups of k_g2p (env MPMHIP_G2P_WGS)
-  int g2p_minw = 13;          // tuning knob (env MPMHIP_G2P_MINW): __launch_bounds__ waves/SIMD of k_g2p
+  int g2p_minw = 12;          // tuning knob (env MPMHIP_G2P_MINW): 10 + __launch_bounds__ waves/SIMD of k_g2p
   int reorder_interval = 0;   // physical reorder every this many substeps (0 = never); env MPMHIP_REORDER_INTERVAL
   float t = 0.0f, request_t = 0.0f;  // `real` accumulators, as in the reference (src/mpm.h:99, mpm.cpp:573)
   int64_t substeps = 0;
@@ -744,13 +744,15 @@ static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
 static int do_g2p(mpmhip_ctx *c, int phase = 0) {
   c->P.t = c->t;
   const bool sb = c->P.store_b != 0;
-  auto kern = sb ? k_g2p<256, 3, true, true> : k_g2p<256, 3, true, false>;  // 3 waves/SIMD, rolled gather: fastest
+  // 2 waves/SIMD (up to 256 VGPRs): the kernel is bound by vector-ALU issue, not by latency — with the registers of a
+  // third wave the compiler shuffles less (C3: 0.308 -> 0.293 ms on the lattice, 0.443 -> 0.422 ms after impact); a fourth
+  // wave spills (0.41 ms)
+  auto kern = sb ? k_g2p<256, 2, true, true> : k_g2p<256, 2, true, false>;
   int nt = 256;
-  switch (c->g2p_minw) {  // tuning knob: waves/SIMD target + 10 (rolled gather loop) | plain
-    case 12: kern = sb ? k_g2p<256, 2, true, true> : k_g2p<256, 2, true, false>; break;
-    case 3: kern = sb ? k_g2p<256, 3, false, true> : k_g2p<256, 3, false, false>; break;
+  switch (c->g2p_minw) {  // tuning knob: 10 + waves/SIMD target; 23: 128-entry chunks
+    case 13: kern = sb ? k_g2p<256, 3, true, true> : k_g2p<256, 3, true, false>; break;
     case 14: kern = sb ? k_g2p<256, 4, true, true> : k_g2p<256, 4, true, false>; break;
-    case 23: kern = sb ? k_g2p<128, 3, true, true> : k_g2p<128, 3, true, false>; nt = 128; break;  // 128-entry chunks
+    case 23: kern = sb ? k_g2p<128, 3, true, true> : k_g2p<128, 3, true, false>; nt = 128; break;
     default: break;
   }
   hipLaunchKernelGGL(kern, dim3(c->g2p_wgs), dim3(nt), 0, c->stream, c->P, (float4 *)c->rg, (float4 *)c->rp, (float4 *)c->rb,
@@ -1469,6 +1471,43 @@ int mpmhip_debug_copy_bandwidth(mpmhip_ctx *c, size_t bytes, int32_t iters, doub
   if (e1) (void)hipEventDestroy(e1);
   (void)hipFree(a);
   (void)hipFree(b);
+  HIPCHK(c, e);
+  *gb_per_s = best;
+  return MPMHIP_OK;
+}
+
+// 64-byte record gather of known size (calibration of the FETCH_SIZE counter, profiles/calibrate_fetch.py): n (a power
+// of two) records read through an index of the given pattern, `iters` launches; *gb_per_s = (64 + 4) n / best time
+int mpmhip_debug_gather_bandwidth(mpmhip_ctx *c, int64_t n, int32_t mode, int32_t iters, double *gb_per_s) {
+  if (!c || !gb_per_s || iters <= 0 || n < 1024 || (n & (n - 1)) || n > (1ll << 30) || mode < 0 || mode > 2) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  float4 *rec = nullptr, *out = nullptr;
+  uint32_t *idx = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const int grid = 256 * 16;
+  hipError_t e = dmalloc(&rec, (size_t)n * 4);
+  if (e == hipSuccess) e = dmalloc(&idx, (size_t)n);
+  if (e == hipSuccess) e = dmalloc(&out, (size_t)grid * 4);
+  if (e == hipSuccess) e = hipMemsetAsync(rec, 0, (size_t)n * 64, c->stream);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  double best = 0.0;
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_probe_indices, dim3(4096), dim3(256), 0, c->stream, idx, (uint32_t)n, (int)mode);
+    for (int it = 0; e == hipSuccess && it < iters + 1; it++) {
+      hipEventRecord(e0, c->stream);
+      hipLaunchKernelGGL(k_gather_records_probe, dim3(grid), dim3(256), 0, c->stream, (const float4 *)rec, (const uint32_t *)idx,
+                         (uint32_t)n, out);
+      hipEventRecord(e1, c->stream);
+      e = hipEventSynchronize(e1);
+      float ms = 0.0f;
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+      if (e == hipSuccess && it > 0 && ms > 0.0f) best = std::max(best, 68.0 * (double)n / (ms * 1e-3) / 1e9);
+    }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(rec); (void)hipFree(idx); (void)hipFree(out);
   HIPCHK(c, e);
   *gb_per_s = best;
   return MPMHIP_OK;
