@@ -52,15 +52,9 @@ def build_sim(tm, cfg, device):
                                                        gravity=(0, -10, 0), device=device,
                                                        keep_apic_b=bool(cfg.get("keep_apic_b", False))))
     sim.set_levelset(tm.mpm.LevelSet(friction=-1.0).add_plane((0, 1, 0), d=-0.1))  # sticky floor y = 0.1
-    if "clusters" in cfg:  # C5: one cube per corner of a 2x2x2 arrangement, materials alternating
-        k = 0
-        for ox in cfg["clusters"]:
-            for oy in cfg["clusters"]:
-                for oz in cfg["clusters"]:
-                    sim.add_particles(dict(type="water" if k % 2 == 0 else "elastic", cube_lo=(ox, oy, oz), cube_cells=cells))
-                    k += 1
-        return sim
-    sim.add_particles(dict(type=cfg["material"], cube=(lo, lo + cells)))
+    from taichi_mpm_amd.tiled import scene_groups
+    for typ, lo, n in scene_groups(cfg):  # C5: one cube per corner of a 2x2x2 arrangement, materials alternating
+        sim.add_particles(dict(type=typ, cube_lo=lo, cube_cells=n))
     return sim
 
 
@@ -248,22 +242,11 @@ def virtual_run(tm, cfg, args):
     import torch
 
     from taichi_mpm_amd import tiled
-    from taichi_mpm_amd.mpm import F_ID, lattice_cube
     K = args.virtual
-    res, cells = cfg["res"], cfg["cells"]
-    dx = 1.0 / res
-    lo = res // 2 - cells // 2
-    x = lattice_cube(lo, lo + cells, dx)
-    part = tiled.Partition.balanced((res,) * 3, K, x, dx, margin=4)
-    owner = part.rank_of_cells(tiled.base_cells(x, dx))
+    part = tiled.scene_partition(cfg, K, margin=4)
     engines = []
     for r in range(K):
-        mine = np.nonzero(owner == r)[0]
-        sim = tm.create_simulation3("mpm").initialize(dict(res=(res,) * 3, delta_x=dx, base_delta_t=1e-4, gravity=(0, -10, 0),
-                                                           max_particles=int(len(mine) * 1.5) + (1 << 16)))
-        sim.set_levelset(tm.mpm.LevelSet(friction=-1.0).add_plane((0, 1, 0), d=-0.1))
-        sim.add_particles(dict(type=cfg["material"], positions=x[mine]))
-        sim.upload(F_ID, mine.astype(np.int32))
+        sim, _ = tiled.build_rank_sim(tm, cfg, part, r, 0)
         engines.append(tiled.HipEngine(sim, 0))
     job = tiled.VirtualTiledJob(engines, part, overlap=os.environ.get("MPMHIP_TILE_OVERLAP", "1") != "0")
     job.run(args.warmup)
@@ -292,6 +275,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cells", type=int, default=0, help="override the cube / cluster edge in cells (reduced runs for tests)")
     ap.add_argument("--no-evolved", action="store_true", help="skip the second measurement on the evolved state")
     ap.add_argument("--state", default="lattice", choices=["lattice", "evolved"],
                     help="state the main measurement is taken on: the freshly seeded lattice (the metric's configuration) or "
@@ -365,9 +349,10 @@ def main():
                 staged, data_group = True, None
                 wire = "gloo, staged through host memory (RCCL probe failed)"
 
-    cfg = CONFIGS[args.config]
-    if "clusters" in cfg and (world > 1 or args.virtual > 1):
-        raise SystemExit("--config %s is a single-GPU workload in this build" % args.config)
+    cfg = dict(CONFIGS[args.config])
+    if args.cells:  # reduced problem (tests, smoke runs): NOT the metric's configuration — the line says so
+        cfg["cells"] = args.cells
+        cfg["desc"] += " [REDUCED: cube edge %d cells]" % args.cells
     if args.virtual > 1:
         return emit(virtual_run(tm, cfg, args))
     if world > 1 or force_tiled:

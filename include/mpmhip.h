@@ -92,7 +92,11 @@ typedef struct {
                                A = stress*(-4 inv_dx dt) + apic_b*(4 m) (src/transfer.cpp:521-522), which is the state
                                the next substep consumes (-48 of 180 stored bytes per particle-step).  download(B)
                                then recovers apic_b = (A - stress(F) S)/(4 m) on demand, to ~1e-5..1e-4 relative */
-  int32_t reserved[4];
+  int32_t generic_path;     /* config "optimized" = false: the reference's generic transfer path (src/transfer.cpp:193-278,
+                             * 585-687).  Same arithmetic as the optimised path here (both go through the same kernels); what
+                             * differs in the reference is the position clamp into [0, res - eps] after the advection
+                             * (:668-670), which this flag turns on */
+  int32_t reserved[3];
 } mpmhip_config;
 
 typedef struct mpmhip_ctx mpmhip_ctx;
@@ -276,6 +280,40 @@ int mpmhip_import_particles(mpmhip_ctx *ctx, int64_t n, const void *dev_records)
 int mpmhip_active_bounds(mpmhip_ctx *ctx, int32_t lo[3], int32_t hi[3]);
 int64_t mpmhip_num_slots(mpmhip_ctx *ctx);       /* slots in use (live + dead) — capacity pressure */
 int mpmhip_request_compaction(mpmhip_ctx *ctx);  /* physical reorder + drop of dead slots at the next sort */
+
+/* ---- MPM<2>: the reference's 2D simulation — replaces the object tc_core.create_simulation2('mpm') returns
+ * (TC_IMPLEMENTATION(Simulation2D, MPM2D, "mpm"), src/mpm.cpp:983-986).  MPM<2> runs the GENERIC transfer path
+ * (rasterize_optimized = rasterize, resample_optimized = resample: src/transfer.cpp:280-283,697-700; bodies :193-278,
+ * :585-687, including the position clamp of :668-670) with all eight particle types in their dim = 2 form.  Its own small
+ * object: SoA particles, dense (res+1)^2 grid (2D scenes are the reference's small cases).  Matrices row-major float[4].
+ * Level-set shapes are mpmhip_shape read in the plane (z ignored); n1 >= 0 adds the key frame at t1 (DynamicLevelSet). */
+typedef struct mpmhip2d_ctx mpmhip2d_ctx;
+typedef struct {
+  int32_t res[2];
+  float dx, dt;
+  float gravity[2];
+  int32_t particle_gravity;
+  float apic_damping, rpic_damping;
+  int32_t clean_boundary, particle_collision;
+  int64_t max_particles;
+  int32_t device;
+  int32_t reserved[3];
+} mpmhip2d_config;
+int mpmhip2d_create(const mpmhip2d_config *cfg, mpmhip2d_ctx **out);
+void mpmhip2d_destroy(mpmhip2d_ctx *ctx);
+const char *mpmhip2d_last_error(const mpmhip2d_ctx *ctx);
+int mpmhip2d_set_levelset(mpmhip2d_ctx *ctx, int32_t n0, const mpmhip_shape *shapes0, int32_t n1, const mpmhip_shape *shapes1,
+                          float t0, float t1, float friction);
+int mpmhip2d_add_group(mpmhip2d_ctx *ctx, int32_t material, const float params[MPMHIP_NPARAM]);
+int mpmhip2d_add_particles(mpmhip2d_ctx *ctx, int32_t group, int64_t n, const float *x, const float *v, const float *F,
+                           const float *B, const float *aux);
+int mpmhip2d_substep(mpmhip2d_ctx *ctx);          /* MPM<2>::substep, src/mpm.cpp:452-575; asynchronous */
+int mpmhip2d_step(mpmhip2d_ctx *ctx, float dt);   /* MPM<dim>::step, src/mpm.cpp:428-439 (dt < 0: one substep) */
+double mpmhip2d_current_time(const mpmhip2d_ctx *ctx);
+int64_t mpmhip2d_num_particles(mpmhip2d_ctx *ctx); /* synchronises */
+int64_t mpmhip2d_download(mpmhip2d_ctx *ctx, int64_t capacity, float *x, float *v, float *F, float *B, float *aux, int32_t *gid,
+                          int32_t *id);            /* live particles in slot order; NULL outputs are skipped; returns n */
+int mpmhip2d_download_grid(mpmhip2d_ctx *ctx, float *grid /* [(res0+1)(res1+1)][3] = (v.x, v.y, m) */);
 
 /* ---- the 2D dense-grid demo (BASELINE configs[0]) — replaces advance(dt) of mls-mpm88.cpp:16-69 (annotated twin
  * mls-mpm88-explained.cpp:64-197): (n+1)^2 grid, snow model inline (E = 1e4, nu = 0.2, hardening 10, sigma clamp

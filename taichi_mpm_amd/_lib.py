@@ -29,7 +29,7 @@ class Config(C.Structure):
                 ("clean_boundary", C.c_int32), ("n_planes", C.c_int32), ("planes", (C.c_float * 4) * 8),
                 ("friction", C.c_float), ("max_particles", C.c_int64), ("max_blocks", C.c_int64),
                 ("device", C.c_int32), ("reorder_interval", C.c_int32), ("particle_collision", C.c_int32),
-                ("discard_apic_b", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("discard_apic_b", C.c_int32), ("generic_path", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class Shape(C.Structure):
@@ -38,6 +38,14 @@ class Shape(C.Structure):
 
 
 MAX_SHAPES = 16
+
+
+class Config2D(C.Structure):
+    """mirror of mpmhip2d_config"""
+    _fields_ = [("res", C.c_int32 * 2), ("dx", C.c_float), ("dt", C.c_float), ("gravity", C.c_float * 2),
+                ("particle_gravity", C.c_int32), ("apic_damping", C.c_float), ("rpic_damping", C.c_float),
+                ("clean_boundary", C.c_int32), ("particle_collision", C.c_int32), ("max_particles", C.c_int64),
+                ("device", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class HaloBox(C.Structure):
@@ -94,6 +102,8 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_las
             "mpmhip_substep_begin", "mpmhip_substep_end", "mpmhip_substep_interior", "mpmhip_set_overlap", "mpmhip_leaver_counts", "mpmhip_migration_scan", "mpmhip_export_leavers",
             "mpmhip_import_particles", "mpmhip_active_bounds", "mpmhip_num_slots", "mpmhip_request_compaction", "mpmhip_mpm88_create", "mpmhip_mpm88_destroy", "mpmhip_mpm88_last_error", "mpmhip_mpm88_add",
             "mpmhip_mpm88_num_particles", "mpmhip_mpm88_advance", "mpmhip_mpm88_download", "mpmhip_mpm88_download_grid",
+            "mpmhip2d_create", "mpmhip2d_destroy", "mpmhip2d_last_error", "mpmhip2d_set_levelset", "mpmhip2d_add_group", "mpmhip2d_add_particles",
+            "mpmhip2d_substep", "mpmhip2d_step", "mpmhip2d_current_time", "mpmhip2d_num_particles", "mpmhip2d_download", "mpmhip2d_download_grid",
             "mpmhip_debug_copy_bandwidth", "mpmhip_debug_gather_bandwidth", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
 
 
@@ -182,6 +192,23 @@ def load():
     L.mpmhip_mpm88_advance.argtypes = [vp, C.c_int32]
     L.mpmhip_mpm88_download.argtypes = [vp, fp, fp, fp, fp, fp]
     L.mpmhip_mpm88_download_grid.argtypes = [vp, fp]
+    L.mpmhip2d_create.argtypes = [P(Config2D), P(vp)]
+    L.mpmhip2d_destroy.argtypes = [vp]
+    L.mpmhip2d_destroy.restype = None
+    L.mpmhip2d_last_error.argtypes = [vp]
+    L.mpmhip2d_last_error.restype = C.c_char_p
+    L.mpmhip2d_set_levelset.argtypes = [vp, C.c_int32, P(Shape), C.c_int32, P(Shape), C.c_float, C.c_float, C.c_float]
+    L.mpmhip2d_add_group.argtypes = [vp, C.c_int32, fp]
+    L.mpmhip2d_add_particles.argtypes = [vp, C.c_int32, C.c_int64, fp, fp, fp, fp, fp]
+    L.mpmhip2d_substep.argtypes = [vp]
+    L.mpmhip2d_step.argtypes = [vp, C.c_float]
+    L.mpmhip2d_current_time.argtypes = [vp]
+    L.mpmhip2d_current_time.restype = C.c_double
+    L.mpmhip2d_num_particles.argtypes = [vp]
+    L.mpmhip2d_num_particles.restype = C.c_int64
+    L.mpmhip2d_download.argtypes = [vp, C.c_int64, fp, fp, fp, fp, fp, ip, ip]
+    L.mpmhip2d_download.restype = C.c_int64
+    L.mpmhip2d_download_grid.argtypes = [vp, fp]
     L.mpmhip_debug_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int32, P(C.c_double)]
     L.mpmhip_debug_gather_bandwidth.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, P(C.c_double)]
     L.mpmhip_bgeo_size.argtypes = [vp, C.c_int32, P(C.c_size_t)]

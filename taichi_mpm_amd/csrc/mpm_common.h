@@ -76,6 +76,7 @@ struct Params {
   uint32_t n_slots;  // particle slots in use (host-known)
   int store_b;       // keep apic_b in the side array
   int particle_collision;  // particle_collision_resolution after G2P (src/mpm.cpp:566-569)
+  int clamp_pos;     // generic transfer path (optimized = false): positions clamped into [0, res - eps] (src/transfer.cpp:668-670)
   int ablate;        // PROFILING ONLY (env MPMHIP_ABLATE, results invalid): 1 no G2P stores, 2 no constitutive
                      // update, 4 no 27-tap gather
 };

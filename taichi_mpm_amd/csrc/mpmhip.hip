@@ -67,6 +67,7 @@
 #include "k_debug.h"
 #include "k_bgeo.h"
 #include "k_mpm88.h"
+#include "k_mpm2d.h"
 
 
 // ================================================================================================ host side
@@ -309,6 +310,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   P.particle_gravity = cfg->particle_gravity; P.apic_damping = cfg->apic_damping; P.rpic_damping = cfg->rpic_damping;
   P.clean_boundary = cfg->clean_boundary;
   P.store_b = cfg->discard_apic_b ? 0 : 1;
+  P.clamp_pos = cfg->generic_path ? 1 : 0;
   P.ablate = ablate;
   memset(&c->LS, 0, sizeof c->LS);
   c->LS.particle_collision = cfg->particle_collision;
@@ -1645,6 +1647,239 @@ int mpmhip_mpm88_download_grid(mpmhip_mpm88 *m, float *grid) {
   HIPCHK88(m, hipStreamSynchronize(m->stream));
   const int nn = m->P.n + 1;
   HIPCHK88(m, hipMemcpy(grid, m->grid, sizeof(float) * 3 * nn * nn, hipMemcpyDeviceToHost));
+  return MPMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ MPM<2>
+// The reference's 2D simulation (create_simulation2('mpm') -> MPM<2>, which runs the generic transfer path): its own small
+// object — SoA particle arrays, dense (res+1)^2 grid — see k_mpm2d.h.
+struct mpmhip2d_ctx {
+  mpm2d::Params P{};
+  LevelSetDev LS{};
+  int device = 0;
+  int64_t n = 0, cap = 0;
+  float *x = nullptr, *v = nullptr, *F = nullptr, *B = nullptr, *aux = nullptr, *grid = nullptr;
+  int32_t *gid = nullptr, *pid = nullptr;
+  unsigned int *n_dead = nullptr;
+  GroupParams *d_groups = nullptr;
+  std::vector<GroupParams> groups;
+  int32_t next_pid = 0;
+  float t = 0.0f, request_t = 0.0f;
+  hipStream_t stream = nullptr;
+  std::string err;
+};
+static thread_local std::string g_2d_create_error;
+static int fail2d(mpmhip2d_ctx *m, int code, const std::string &msg) {
+  (m ? m->err : g_2d_create_error) = msg;
+  return code;
+}
+#define HIPCHK2D(m, call)                                                                                      \
+  do {                                                                                                         \
+    hipError_t e_ = (call);                                                                                    \
+    if (e_ != hipSuccess) return fail2d((m), MPMHIP_EHIP, std::string(#call " failed: ") + hipGetErrorString(e_)); \
+  } while (0)
+
+const char *mpmhip2d_last_error(const mpmhip2d_ctx *m) { return m ? m->err.c_str() : g_2d_create_error.c_str(); }
+
+int mpmhip2d_create(const mpmhip2d_config *cfg, mpmhip2d_ctx **out) {
+  if (!cfg || !out) return fail2d(nullptr, MPMHIP_EINVAL, "null argument");
+  *out = nullptr;
+  for (int k = 0; k < 2; k++)
+    if (cfg->res[k] < 8 || cfg->res[k] > 16384) return fail2d(nullptr, MPMHIP_EINVAL, "res outside [8,16384]");
+  if (!(cfg->dx > 0) || !(cfg->dt >= 0) || cfg->max_particles <= 0) return fail2d(nullptr, MPMHIP_EINVAL, "dx > 0, dt >= 0, max_particles > 0 required");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail2d(nullptr, MPMHIP_EHIP, "no HIP device available (libmpmhip has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail2d(nullptr, MPMHIP_EINVAL, "no such device");
+  mpmhip2d_ctx *m = new (std::nothrow) mpmhip2d_ctx;
+  if (!m) return fail2d(nullptr, MPMHIP_ENOMEM, "host allocation failed");
+  m->device = cfg->device;
+  mpm2d::Params &P = m->P;
+  P.res[0] = cfg->res[0]; P.res[1] = cfg->res[1];
+  P.dx = cfg->dx; P.idx = 1.0f / cfg->dx; P.dt = cfg->dt; P.t = 0.0f;
+  P.g[0] = cfg->gravity[0]; P.g[1] = cfg->gravity[1];
+  P.particle_gravity = cfg->particle_gravity; P.apic_damping = cfg->apic_damping; P.rpic_damping = cfg->rpic_damping;
+  P.clean_boundary = cfg->clean_boundary; P.particle_collision = cfg->particle_collision; P.clamp_pos = 1;
+  memset(&m->LS, 0, sizeof m->LS);
+  m->cap = cfg->max_particles;
+  const size_t c = (size_t)m->cap, nodes = (size_t)(P.res[0] + 1) * (P.res[1] + 1);
+  hipError_t e = hipSetDevice(m->device);
+  auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  A(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  A(dmalloc(&m->x, 2 * c)); A(dmalloc(&m->v, 2 * c)); A(dmalloc(&m->F, 4 * c)); A(dmalloc(&m->B, 4 * c)); A(dmalloc(&m->aux, c));
+  A(dmalloc(&m->gid, c)); A(dmalloc(&m->pid, c)); A(dmalloc(&m->grid, 3 * nodes)); A(dmalloc(&m->n_dead, 1));
+  A(dmalloc(&m->d_groups, (size_t)MPMHIP_MAX_GROUPS));
+  if (e == hipSuccess) e = hipMemset(m->n_dead, 0, sizeof(unsigned int));
+  if (e != hipSuccess) {
+    const int rc = fail2d(nullptr, MPMHIP_ENOMEM, std::string("mpmhip2d_create: ") + hipGetErrorString(e));
+    mpmhip2d_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return MPMHIP_OK;
+}
+
+void mpmhip2d_destroy(mpmhip2d_ctx *m) {
+  if (!m) return;
+  hipSetDevice(m->device);
+  if (m->stream) { hipStreamSynchronize(m->stream); hipStreamDestroy(m->stream); }
+  hipFree(m->x); hipFree(m->v); hipFree(m->F); hipFree(m->B); hipFree(m->aux); hipFree(m->gid); hipFree(m->pid); hipFree(m->grid);
+  hipFree(m->n_dead); hipFree(m->d_groups);
+  delete m;
+}
+
+// level set in the plane: the shapes of mpmhip_shape with z ignored (plane = line n.x + d, sphere = disc, cuboid = box with
+// p[2], p[5] spanning z = 0); two key frames like mpmhip_set_levelset_keyframes when n1 >= 0
+int mpmhip2d_set_levelset(mpmhip2d_ctx *m, int32_t n0, const mpmhip_shape *shapes0, int32_t n1, const mpmhip_shape *shapes1,
+                          float t0, float t1, float friction) {
+  if (!m || n0 < 0 || n0 > MPMHIP_MAX_SHAPES || n1 > MPMHIP_MAX_SHAPES || (n0 > 0 && !shapes0) || (n1 > 0 && !shapes1)) return MPMHIP_EINVAL;
+  if (n1 >= 0 && !(t1 > t0)) return fail2d(m, MPMHIP_EINVAL, "key frame times must satisfy t0 < t1");
+  HIPCHK2D(m, hipSetDevice(m->device));
+  HIPCHK2D(m, hipStreamSynchronize(m->stream));
+  LevelSetDev &L = m->LS;
+  memset(&L, 0, sizeof L);
+  L.n = n0; L.friction = friction; L.dynamic = n1 >= 0; L.n1 = n1 >= 0 ? n1 : 0; L.t0 = t0; L.t1 = t1;
+  auto put = [](ShapeDev &d, const mpmhip_shape &s) {
+    d.type = s.type; d.inside_out = s.inside_out;
+    for (int k = 0; k < 6; k++) d.p[k] = s.p[k];
+    if (s.type == 2) { d.p[2] = -1e30f; d.p[5] = 1e30f; }  // a box in the plane: unbounded along z
+    if (s.type == 1) d.p[2] = 0.0f;
+    if (s.type == 0) d.p[2] = 0.0f;
+  };
+  for (int i = 0; i < n0; i++) put(L.s[i], shapes0[i]);
+  for (int i = 0; i < L.n1; i++) put(L.s1[i], shapes1[i]);
+  return MPMHIP_OK;
+}
+
+int mpmhip2d_add_group(mpmhip2d_ctx *m, int32_t material, const float params[MPMHIP_NPARAM]) {
+  if (!m || !params) return MPMHIP_EINVAL;
+  if (material < MPMHIP_VISCO || material > MPMHIP_ELASTIC) return fail2d(m, MPMHIP_EINVAL, "unknown material id");
+  if ((int)m->groups.size() >= MPMHIP_MAX_GROUPS) return fail2d(m, MPMHIP_ECAPACITY, "too many particle groups");
+  if (!(params[0] > 0) || !(params[1] > 0)) return fail2d(m, MPMHIP_EINVAL, "group mass and vol must be > 0");
+  GroupParams g;
+  memset(&g, 0, sizeof g);
+  memcpy(g.p, params, sizeof g.p);
+  g.type = material;
+  m->groups.push_back(g);
+  HIPCHK2D(m, hipSetDevice(m->device));
+  HIPCHK2D(m, hipStreamSynchronize(m->stream));
+  HIPCHK2D(m, hipMemcpy(m->d_groups, m->groups.data(), sizeof(GroupParams) * m->groups.size(), hipMemcpyHostToDevice));
+  return (int)m->groups.size() - 1;
+}
+
+int mpmhip2d_add_particles(mpmhip2d_ctx *m, int32_t group, int64_t n, const float *x, const float *v, const float *F, const float *B,
+                           const float *aux) {
+  if (!m || n < 0 || (n > 0 && !x)) return MPMHIP_EINVAL;
+  if (group < 0 || group >= (int)m->groups.size()) return fail2d(m, MPMHIP_EINVAL, "unknown group");
+  if (n == 0) return MPMHIP_OK;
+  if (m->n + n > m->cap) return fail2d(m, MPMHIP_ECAPACITY, "particle capacity exceeded");
+  HIPCHK2D(m, hipSetDevice(m->device));
+  HIPCHK2D(m, hipStreamSynchronize(m->stream));
+  const int mat = m->groups[group].type;
+  const float aux0 = (mat == MPMHIP_SNOW || mat == MPMHIP_WATER) ? 1.0f : (mat == MPMHIP_VISCO ? 1000.0f : 0.0f);
+  std::vector<float> h;
+  auto put = [&](float *dst, const float *src, int width, const float *dflt) -> hipError_t {
+    if (!src) {
+      h.resize((size_t)n * width);
+      for (int64_t i = 0; i < n; i++)
+        for (int k = 0; k < width; k++) h[(size_t)i * width + k] = dflt[k];
+      src = h.data();
+    }
+    return hipMemcpy(dst + m->n * width, src, sizeof(float) * n * width, hipMemcpyHostToDevice);
+  };
+  const float zero4[4] = {0, 0, 0, 0}, eye[4] = {1, 0, 0, 1}, a0[1] = {aux0};
+  HIPCHK2D(m, put(m->x, x, 2, zero4));
+  HIPCHK2D(m, put(m->v, v, 2, zero4));
+  HIPCHK2D(m, put(m->F, F, 4, eye));
+  HIPCHK2D(m, put(m->B, B, 4, zero4));
+  HIPCHK2D(m, put(m->aux, aux, 1, a0));
+  std::vector<int32_t> ids((size_t)n), gs((size_t)n, group);
+  for (int64_t i = 0; i < n; i++) ids[i] = m->next_pid + (int32_t)i;
+  m->next_pid += (int32_t)n;
+  HIPCHK2D(m, hipMemcpy(m->pid + m->n, ids.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  HIPCHK2D(m, hipMemcpy(m->gid + m->n, gs.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  m->n += n;
+  return MPMHIP_OK;
+}
+
+int mpmhip2d_substep(mpmhip2d_ctx *m) {  // MPM<2>::substep, src/mpm.cpp:452-575
+  if (!m) return MPMHIP_EINVAL;
+  HIPCHK2D(m, hipSetDevice(m->device));
+  const size_t nodes = (size_t)(m->P.res[0] + 1) * (m->P.res[1] + 1);
+  m->P.t = m->t;
+  const dim3 pg((unsigned)std::max<int64_t>((m->n + 255) / 256, 1)), gg((unsigned)((nodes + 255) / 256)), wg(256);
+  HIPCHK2D(m, hipMemsetAsync(m->grid, 0, sizeof(float) * 3 * nodes, m->stream));
+  if (m->n)
+    hipLaunchKernelGGL(mpm2d::k_p2g, pg, wg, 0, m->stream, m->P, m->n, (const float *)m->x, m->v, (const float *)m->F,
+                       (const float *)m->B, (const float *)m->aux, (const int32_t *)m->gid, (const int32_t *)m->pid,
+                       (const GroupParams *)m->d_groups, m->grid);
+  hipLaunchKernelGGL(mpm2d::k_grid, gg, wg, 0, m->stream, m->P, m->LS, m->grid);
+  if (m->n)
+    hipLaunchKernelGGL(mpm2d::k_g2p, pg, wg, 0, m->stream, m->P, m->LS, m->n, m->x, m->v, m->F, m->B, m->aux, (const int32_t *)m->gid,
+                       m->pid, (const GroupParams *)m->d_groups, (const float *)m->grid, m->n_dead);
+  HIPCHK2D(m, hipGetLastError());
+  m->t += m->P.dt;
+  return MPMHIP_OK;
+}
+
+int mpmhip2d_step(mpmhip2d_ctx *m, float dt) {  // MPM<dim>::step, src/mpm.cpp:428-439
+  if (!m) return MPMHIP_EINVAL;
+  if (dt < 0) {
+    const int rc = mpmhip2d_substep(m);
+    m->request_t = m->t;
+    return rc;
+  }
+  m->request_t += dt;
+  while (m->t + m->P.dt < m->request_t)
+    if (int rc = mpmhip2d_substep(m)) return rc;
+  return MPMHIP_OK;
+}
+
+double mpmhip2d_current_time(const mpmhip2d_ctx *m) { return m ? (double)m->t : 0.0; }
+
+int64_t mpmhip2d_num_particles(mpmhip2d_ctx *m) {
+  if (!m) return MPMHIP_EINVAL;
+  if (hipSetDevice(m->device) != hipSuccess || hipStreamSynchronize(m->stream) != hipSuccess) return MPMHIP_EHIP;
+  unsigned int dead = 0;
+  if (hipMemcpy(&dead, m->n_dead, sizeof dead, hipMemcpyDeviceToHost) != hipSuccess) return MPMHIP_EHIP;
+  return m->n - (int64_t)dead;
+}
+
+// live particles in slot order; any output may be NULL.  Returns the number written or a negative error.
+int64_t mpmhip2d_download(mpmhip2d_ctx *m, int64_t capacity, float *x, float *v, float *F, float *B, float *aux, int32_t *gid,
+                          int32_t *id) {
+  if (!m) return MPMHIP_EINVAL;
+  if (hipSetDevice(m->device) != hipSuccess || hipStreamSynchronize(m->stream) != hipSuccess) return fail2d(m, MPMHIP_EHIP, "synchronise failed");
+  const size_t n = (size_t)m->n;
+  std::vector<float> hx(2 * n), hv(2 * n), hF(4 * n), hB(4 * n), ha(n);
+  std::vector<int32_t> hg(n), hp(n);
+  if (n) {
+    HIPCHK2D(m, hipMemcpy(hx.data(), m->x, 8 * n, hipMemcpyDeviceToHost)); HIPCHK2D(m, hipMemcpy(hv.data(), m->v, 8 * n, hipMemcpyDeviceToHost));
+    HIPCHK2D(m, hipMemcpy(hF.data(), m->F, 16 * n, hipMemcpyDeviceToHost)); HIPCHK2D(m, hipMemcpy(hB.data(), m->B, 16 * n, hipMemcpyDeviceToHost));
+    HIPCHK2D(m, hipMemcpy(ha.data(), m->aux, 4 * n, hipMemcpyDeviceToHost)); HIPCHK2D(m, hipMemcpy(hg.data(), m->gid, 4 * n, hipMemcpyDeviceToHost));
+    HIPCHK2D(m, hipMemcpy(hp.data(), m->pid, 4 * n, hipMemcpyDeviceToHost));
+  }
+  int64_t k = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (hp[i] < 0) continue;
+    if (k >= capacity) return fail2d(m, MPMHIP_ECAPACITY, "download buffer too small");
+    if (x) { x[2 * k] = hx[2 * i]; x[2 * k + 1] = hx[2 * i + 1]; }
+    if (v) { v[2 * k] = hv[2 * i]; v[2 * k + 1] = hv[2 * i + 1]; }
+    if (F) for (int q = 0; q < 4; q++) F[4 * k + q] = hF[4 * i + q];
+    if (B) for (int q = 0; q < 4; q++) B[4 * k + q] = hB[4 * i + q];
+    if (aux) aux[k] = ha[i];
+    if (gid) gid[k] = hg[i];
+    if (id) id[k] = hp[i];
+    k++;
+  }
+  return k;
+}
+
+int mpmhip2d_download_grid(mpmhip2d_ctx *m, float *grid) {  // (v.x, v.y, m) per node of the (res+1)^2 grid after the last substep
+  if (!m || !grid) return MPMHIP_EINVAL;
+  HIPCHK2D(m, hipSetDevice(m->device));
+  HIPCHK2D(m, hipStreamSynchronize(m->stream));
+  HIPCHK2D(m, hipMemcpy(grid, m->grid, sizeof(float) * 3 * (size_t)(m->P.res[0] + 1) * (m->P.res[1] + 1), hipMemcpyDeviceToHost));
   return MPMHIP_OK;
 }
 

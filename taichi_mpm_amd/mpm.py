@@ -146,6 +146,9 @@ class Simulation3D:
         # costs 48 of the 180 bytes G2P writes per particle.  keep_apic_b=True stores it (exact downloads of B);
         # otherwise download recovers it from A on demand (include/mpmhip.h: discard_apic_b).
         self.discard_apic_b = not bool(cfg.get("keep_apic_b", False))
+        # optimized=False: the reference's generic transfer path (src/mpm.cpp:508-515,546-552).  Same kernels here; the
+        # one arithmetic difference of that path, the position clamp of src/transfer.cpp:668-670, is switched on
+        self.optimized = bool(cfg.get("optimized", True))
         self.max_particles = int(cfg.get("max_particles", 0))
         self.max_blocks = int(cfg.get("max_blocks", 0))
         self.device = int(cfg.get("device", 0))
@@ -170,6 +173,7 @@ class Simulation3D:
         c.device = self.device
         c.reorder_interval = self.reorder_interval
         c.discard_apic_b = int(self.discard_apic_b)
+        c.generic_path = int(not self.optimized)
         ctx = C.c_void_p()
         rc = self._L.mpmhip_create(C.byref(c), C.byref(ctx))
         if rc != 0:
@@ -537,6 +541,15 @@ class Simulation3D:
         return "mpm"
 
 
+def create_simulation2(name):
+    """tc_core.create_simulation2 (scripts/async/async_mpm.py:25-32): MPM<2>
+    (TC_IMPLEMENTATION(Simulation2D, MPM2D, "mpm"), src/mpm.cpp:983-986)"""
+    if name != "mpm":
+        raise MPMError("no Simulation2D implementation named %r (registered: 'mpm')" % (name,))
+    from .mpm2d import Simulation2D
+    return Simulation2D()
+
+
 def create_simulation3(name):
     """tc_core.create_simulation3 (scripts/async/async_mpm.py:25-32); only 'mpm' is registered here
     (TC_IMPLEMENTATION(Simulation3D, MPM3D, "mpm"), src/mpm.cpp:986-988)."""
@@ -565,9 +578,9 @@ class MPM:
         self.frame_dt = kwargs.get("frame_dt", 0.01)
         kwargs.setdefault("frame_dt", self.frame_dt)
         self.num_frames = kwargs.get("num_frames", 1000)
-        if len(res) != 3:
-            raise MPMError("only the 3D simulation is implemented (create_simulation3)")
-        self.c = create_simulation3("mpm")
+        if len(res) not in (2, 3):
+            raise MPMError("res must have 2 or 3 entries")
+        self.c = create_simulation3("mpm") if len(res) == 3 else create_simulation2("mpm")  # async_mpm.py:25-32
         if "delta_x" not in kwargs:
             kwargs["delta_x"] = 1.0 / res[0]  # async_mpm.py:40-41
         self.c.initialize(kwargs)

@@ -1,0 +1,229 @@
+"""MPM<2> — the reference's 2D simulation (`tc_core.create_simulation2('mpm')`, src/mpm.cpp:983-986) on top of the
+mpmhip2d_* entry points of the C ABI (include/mpmhip.h).  Same surface as Simulation3D (taichi_mpm_amd/mpm.py) where it
+applies: `initialize`, `add_particles`, `set_levelset`, `step`, `get_current_time`, `get_particles`.  MPM<2> runs the
+generic transfer path (src/transfer.cpp:280-283,697-700)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .materials import MATERIAL_IDS, group_params, initial_aux
+from .mpm import DynamicLevelSet, LevelSet, MPMError
+
+
+def lattice_square(lower, higher, dx):
+    """4 particles per cell at cell centre +- 0.25 dx (the 2D analogue of the 3D benchmark lattice)"""
+    r = np.arange(lower, higher, dtype=np.float64)
+    ii, jj = np.meshgrid(r, r, indexing="ij")
+    cells = np.stack([ii, jj], -1).reshape(-1, 1, 2) + 0.5
+    signs = np.array([[-1, -1], [1, -1], [-1, 1], [1, 1]], np.float64)
+    return ((cells + 0.25 * signs[None]) * dx).reshape(-1, 2).astype(np.float32)
+
+
+class Simulation2D:
+    def __init__(self):
+        self._L = _lib.load()
+        self._ctx = None
+        self._staged = []
+        self._groups = []
+        self._levelset = None
+        self._n_added = 0
+        self.frame = 0
+
+    def initialize(self, config):
+        cfg = dict(config)
+        if "delta_t" in cfg:  # src/mpm.cpp:41-42
+            raise MPMError("Please use 'base_delta_t' instead of 'delta_t'")
+        res = cfg["res"]
+        res = (int(res),) * 2 if np.isscalar(res) else tuple(int(r) for r in res)
+        if len(res) != 2:
+            raise MPMError("Simulation2D needs a 2-entry res")
+        self.res = res
+        self.delta_x = float(cfg.get("delta_x", 1.0 / res[0]))
+        self.base_delta_t = float(cfg.get("base_delta_t", 1e-4)) * float(cfg.get("dt_multiplier", 1.0))
+        g = cfg.get("gravity", (0.0, -10.0))
+        self.gravity = (float(g[0]), float(g[1]))
+        self.config = cfg
+        self.max_particles = int(cfg.get("max_particles", 0))
+        return self
+
+    def _check(self, rc):
+        if rc < 0:
+            raise MPMError("libmpmhip error %d: %s" % (rc, self._L.mpmhip2d_last_error(self._ctx).decode()))
+        return rc
+
+    def _ensure_ctx(self, extra=0):
+        if self._ctx is not None:
+            if self._n_added + extra > self._capacity:
+                raise MPMError("2D particle capacity exceeded: pass max_particles to initialize()")
+            return
+        cfg = self.config
+        c = _lib.Config2D()
+        c.res[:] = self.res
+        c.dx, c.dt = self.delta_x, self.base_delta_t
+        c.gravity[:] = self.gravity
+        c.particle_gravity = int(bool(cfg.get("particle_gravity", True)))
+        c.apic_damping, c.rpic_damping = float(cfg.get("apic_damping", 0.0)), float(cfg.get("rpic_damping", 0.0))
+        c.clean_boundary = int(bool(cfg.get("clean_boundary", True)))
+        c.particle_collision = int(bool(cfg.get("particle_collision", False)))
+        self._capacity = max(self.max_particles, int((self._n_added + extra) * 1.5) + 1024)
+        c.max_particles = self._capacity
+        c.device = int(cfg.get("device", 0))
+        ctx = C.c_void_p()
+        rc = self._L.mpmhip2d_create(C.byref(c), C.byref(ctx))
+        if rc != 0:
+            raise MPMError("mpmhip2d_create failed (%d): %s" % (rc, self._L.mpmhip2d_last_error(None).decode()))
+        self._ctx = ctx
+        self._apply_levelset()
+        for gi, (mat, params, arrs) in enumerate(self._staged):
+            self._add(mat, params, *arrs)
+        self._staged = []
+
+    def close(self):
+        if self._ctx is not None:
+            self._L.mpmhip2d_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _add(self, mat, params, x, v, F, B, aux):
+        fp = C.POINTER(C.c_float)
+        gi = self._check(self._L.mpmhip2d_add_group(self._ctx, mat, params.ctypes.data_as(fp)))
+        keep = []
+
+        def ptr(a, w):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, np.float32).reshape(len(x), w) if w > 1 else np.ascontiguousarray(a, np.float32).reshape(len(x))
+            keep.append(a)
+            return a.ctypes.data_as(fp)
+        self._check(self._L.mpmhip2d_add_particles(self._ctx, gi, len(x), ptr(x, 2), ptr(v, 2), ptr(F, 4), ptr(B, 4), ptr(aux, 1)))
+
+    def add_particles(self, config):
+        """MPM<2>::add_particles (src/mpm.cpp:77-270) with explicit `positions=` (n, 2) or a `square=(lo, hi)` lattice"""
+        cfg = dict(config)
+        ptype = cfg.get("type")
+        if ptype not in MATERIAL_IDS:
+            raise MPMError("unknown particle type %r" % (ptype,))
+        dx = self.delta_x
+        maximum = float(cfg.get("ppc", cfg.get("maximum", 4)))
+        if "square" in cfg:
+            x = lattice_square(int(cfg["square"][0]), int(cfg["square"][1]), dx)
+        elif "positions" in cfg:
+            x = np.ascontiguousarray(cfg["positions"], np.float32).reshape(-1, 2)
+        else:
+            raise MPMError("add_particles needs positions= or square=(lo, hi)")
+        X = x.astype(np.float64) / dx
+        keep = ~((X.min(1) < 7.0) | ((X - np.asarray(self.res)).max(1) > -7.0))  # src/mpm.cpp:129-132
+        x = x[keep]
+        n = len(x)
+        vol = dx ** 2 / maximum  # pow<dim>(delta_x) / maximum, src/mpm.cpp:134
+        mass = vol * float(cfg.get("density", 400.0))
+        params, mat = group_params(ptype, mass, vol, **{k: v for k, v in cfg.items() if isinstance(v, (int, float))})
+        if "params" in cfg:
+            params = np.ascontiguousarray(cfg["params"], np.float32).reshape(16).copy()
+
+        def sel(key, w, default):
+            if key in cfg:
+                a = np.ascontiguousarray(cfg[key], np.float32)
+                return (a.reshape(-1, w) if w > 1 else a.reshape(-1))[keep]
+            return default
+        v = sel("velocities", 2, None)
+        F = sel("F", 4, None)
+        B = sel("B", 4, None)
+        aux = sel("aux", 1, np.full(n, initial_aux(ptype, **cfg), np.float32))
+        if self._ctx is None:
+            self._staged.append((mat, params, (x, v, F, B, aux)))
+        else:
+            self._ensure_ctx(extra=n)
+            self._add(mat, params, x, v, F, B, aux)
+        self._groups.append((mat, params))
+        self._n_added += n
+        return ""
+
+    def set_levelset(self, levelset):
+        self._levelset = levelset
+        if self._ctx is not None:
+            self._apply_levelset()
+
+    @staticmethod
+    def _shapes(ls):
+        arr = (_lib.Shape * max(len(ls.shapes), 1))()
+        for i, (t_, io, p) in enumerate(ls.shapes):
+            arr[i].type, arr[i].inside_out = t_, io
+            arr[i].p[:] = p
+        return arr
+
+    def _apply_levelset(self):
+        ls = self._levelset
+        if ls is None:
+            return
+        if isinstance(ls, DynamicLevelSet):
+            l0, l1 = ls.levelset0, ls.levelset1
+            self._check(self._L.mpmhip2d_set_levelset(self._ctx, len(l0.shapes), self._shapes(l0), len(l1.shapes), self._shapes(l1),
+                                                      ls.t0, ls.t1, l0.friction))
+        else:
+            self._check(self._L.mpmhip2d_set_levelset(self._ctx, len(ls.shapes), self._shapes(ls), -1, None, 0.0, 1.0, ls.friction))
+
+    def step(self, dt):
+        self._ensure_ctx()
+        self._check(self._L.mpmhip2d_step(self._ctx, float(dt)))
+
+    def substep(self):
+        self._ensure_ctx()
+        self._check(self._L.mpmhip2d_substep(self._ctx))
+
+    def run_substeps(self, n):
+        for _ in range(int(n)):
+            self.substep()
+
+    def synchronize(self):
+        self.get_num_particles()
+
+    def get_current_time(self):
+        return self._L.mpmhip2d_current_time(self._ctx) if self._ctx is not None else 0.0
+
+    def get_num_particles(self):
+        if self._ctx is None:
+            return self._n_added
+        return int(self._check(self._L.mpmhip2d_num_particles(self._ctx)))
+
+    def get_particles(self, sort_by_id=True):
+        self._ensure_ctx()
+        n = self.get_num_particles()
+        out = dict(x=np.zeros((n, 2), np.float32), v=np.zeros((n, 2), np.float32), F=np.zeros((n, 4), np.float32),
+                   B=np.zeros((n, 4), np.float32), aux=np.zeros(n, np.float32), gid=np.zeros(n, np.int32), id=np.zeros(n, np.int32))
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        got = self._check(self._L.mpmhip2d_download(self._ctx, n, out["x"].ctypes.data_as(fp), out["v"].ctypes.data_as(fp),
+                                                    out["F"].ctypes.data_as(fp), out["B"].ctypes.data_as(fp), out["aux"].ctypes.data_as(fp),
+                                                    out["gid"].ctypes.data_as(ip), out["id"].ctypes.data_as(ip)))
+        out = {k: a[:got] for k, a in out.items()}
+        if sort_by_id:
+            o = np.argsort(out["id"], kind="stable")
+            out = {k: a[o] for k, a in out.items()}
+        return out
+
+    def get_grid(self):
+        self._ensure_ctx()
+        g = np.zeros((self.res[0] + 1, self.res[1] + 1, 3), np.float32)
+        self._check(self._L.mpmhip2d_download_grid(self._ctx, g.ctypes.data_as(C.POINTER(C.c_float))))
+        return g
+
+    def test(self):
+        return True
+
+    def get_name(self):
+        return "mpm"
+
+    def get_mpi_world_rank(self):
+        return 0
+
+    def general_action(self, config):
+        raise MPMError("general_action(%r) is not part of the 2D build" % (config.get("action"),))
+
+    def visualize(self):
+        raise MPMError("frame output is implemented for the 3D simulation")

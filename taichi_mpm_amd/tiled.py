@@ -43,13 +43,14 @@ def base_cells(x, dx):
     return (X - np.float32(0.5)).astype(np.int32)
 
 
-def balanced_cuts(cells, res, parts):
+def balanced_cuts(cells, res, parts, hist=None):
     """cell cut planes [0, c1, .., res] along one axis so that every part holds about the same number of
-    particles (marginal histogram of base cells)."""
+    particles (marginal histogram of base cells; `hist` = that histogram when it was accumulated by the caller)."""
     cuts = [0]
     if parts > 1:
-        hist = np.bincount(np.clip(cells, 0, res - 1), minlength=res).astype(np.int64)
-        cum = np.cumsum(hist)
+        if hist is None:
+            hist = np.bincount(np.clip(cells, 0, res - 1), minlength=res)
+        cum = np.cumsum(np.asarray(hist, np.int64))
         total = int(cum[-1])
         for k in range(1, parts):
             c = int(np.searchsorted(cum, total * k / parts, side="left")) + 1 if total else (res * k) // parts
@@ -83,6 +84,15 @@ class Partition:
         part = cls(res, dims, [balanced_cuts(b[:, a], res[a], dims[a]) for a in range(3)], margin)
         if clip and len(b):
             part.set_clip_from_bounds(b.min(0), b.max(0) + 1)
+        return part
+
+    @classmethod
+    def from_histograms(cls, res, world, hists, cell_lo, cell_hi, margin, dims=None):
+        """as `balanced`, from the per-axis histograms of the base cells and their bounds (a scene made of several
+        clusters is histogrammed cluster by cluster, without ever holding all positions at once)"""
+        dims = dims or brick_dims(world)
+        part = cls(res, dims, [balanced_cuts(None, res[a], dims[a], hist=hists[a]) for a in range(3)], margin)
+        part.set_clip_from_bounds(cell_lo, cell_hi)
         return part
 
     def coords(self, rank):
@@ -492,27 +502,81 @@ class VirtualTiledJob:
 
 
 # ---------------------------------------------------------------------------------------------------- bench glue
+def scene_groups(cfg):
+    """the synthetic workload of a bench config as [(particle type, lower corner in cells (3,), cube edge in cells)]:
+    one cube (C2 / C3), or the 2x2x2 arrangement of clusters with alternating materials (C5).  Every group is one
+    `add_particles` call; bench.py's single-GPU builder and the tiled builder below both go through this list."""
+    res, cells = cfg["res"], cfg["cells"]
+    if "clusters" in cfg:
+        out, k = [], 0
+        for ox in cfg["clusters"]:
+            for oy in cfg["clusters"]:
+                for oz in cfg["clusters"]:
+                    out.append(("water" if k % 2 == 0 else "elastic", (ox, oy, oz), cells))
+                    k += 1
+        return out
+    lo = res // 2 - cells // 2
+    return [(cfg["material"], (lo, lo, lo), cells)]
+
+
+def group_positions(group, dx):
+    from .mpm import lattice_cube
+    _, lo, cells = group
+    return lattice_cube(0, cells, dx) + (np.asarray(lo, np.float64) * dx).astype(np.float32)
+
+
+def scene_partition(cfg, world, margin, dims=None):
+    """balanced bricks over ALL groups of the scene (union of the clusters' histograms)"""
+    res = cfg["res"]
+    dx = 1.0 / res
+    hists = [np.zeros(res, np.int64) for _ in range(3)]
+    lo, hi = np.full(3, 1 << 30), np.full(3, -1)
+    for g in scene_groups(cfg):
+        b = base_cells(group_positions(g, dx), dx)
+        for a in range(3):
+            hists[a] += np.bincount(np.clip(b[:, a], 0, res - 1), minlength=res)
+        lo, hi = np.minimum(lo, b.min(0)), np.maximum(hi, b.max(0) + 1)
+    return Partition.from_histograms((res,) * 3, world, hists, lo, hi, margin, dims=dims)
+
+
+def build_rank_sim(tm, cfg, part, rank, device, extra_cfg=None):
+    """the ctx of one rank: EVERY rank registers EVERY group in the same order (group ids travel with migrating
+    particles), holds the particles whose base cell lies in its brick, with global creation ids"""
+    from .mpm import F_ID
+    res = cfg["res"]
+    dx = 1.0 / res
+    groups = scene_groups(cfg)
+    mine, ids, offset = [], [], 0
+    for g in groups:
+        x = group_positions(g, dx)
+        m = np.nonzero(part.rank_of_cells(base_cells(x, dx)) == rank)[0]
+        mine.append(x[m])
+        ids.append((offset + m).astype(np.int32))
+        offset += len(x)
+    n_mine = sum(len(x) for x in mine)
+    sim = tm.create_simulation3("mpm").initialize(dict(
+        res=(res,) * 3, delta_x=dx, base_delta_t=1e-4, gravity=(0, -10, 0), device=device,
+        max_particles=int(n_mine * 1.5) + (1 << 16), **(extra_cfg or {})))
+    sim.set_levelset(tm.mpm.LevelSet(friction=-1.0).add_plane((0, 1, 0), d=-0.1))
+    for g, x in zip(groups, mine):
+        sim.add_particles(dict(type=g[0], positions=x))
+    sim._ensure_ctx()
+    if n_mine:
+        sim.upload(F_ID, np.concatenate(ids))  # creation ids are global
+    return sim, offset
+
+
 def make_tiled_job(tm, cfg, rank, world, local_rank, margin=4, migrate_interval=None, comm=None):
-    """bench.py, N > 1: every rank generates the same synthetic lattice, keeps its brick's particles."""
+    """bench.py, N > 1: every rank generates the same synthetic scene (one cube, or the C5 clusters with their two
+    materials), keeps its brick's particles."""
     import os
 
     import torch
     margin = int(os.environ.get("MPMHIP_TILE_MARGIN", margin))
     import torch.distributed as dist
 
-    from .mpm import F_ID, lattice_cube
-    res, cells = cfg["res"], cfg["cells"]
-    dx = 1.0 / res
-    lo = res // 2 - cells // 2
-    x = lattice_cube(lo, lo + cells, dx)
-    part = Partition.balanced((res,) * 3, world, x, dx, margin)
-    mine = np.nonzero(part.rank_of_cells(base_cells(x, dx)) == rank)[0]
-    sim = tm.create_simulation3("mpm").initialize(dict(
-        res=(res,) * 3, delta_x=dx, base_delta_t=1e-4, gravity=(0, -10, 0), device=local_rank,
-        max_particles=int(len(mine) * 1.5) + (1 << 16)))
-    sim.set_levelset(tm.mpm.LevelSet(friction=-1.0).add_plane((0, 1, 0), d=-0.1))
-    sim.add_particles(dict(type=cfg["material"], positions=x[mine]))
-    sim.upload(F_ID, mine.astype(np.int32))  # creation ids are global
+    part = scene_partition(cfg, world, margin)
+    sim, _ = build_rank_sim(tm, cfg, part, rank, local_rank)
     engine = HipEngine(sim, local_rank)
     overlap = os.environ.get("MPMHIP_TILE_OVERLAP", "1") != "0"
     comm = comm or DistComm(dist, torch.device("cuda", local_rank))

@@ -169,10 +169,64 @@ def shapes_fixture(here):
     print("shapes:", len(cases), "cases x 2 materials x 2 paths")
 
 
+def mpm2d_state(res=64, lo=(20, 25), cells=20, seed=5):
+    """seeded 2D scene shared by the generator and the tests: 4 particles per cell, stirred velocities, perturbed F"""
+    rng = np.random.default_rng(seed)
+    dx = 1.0 / res
+    cc = np.stack(np.meshgrid(np.arange(lo[0], lo[0] + cells), np.arange(lo[1], lo[1] + cells), indexing="ij"), -1).reshape(-1, 2)
+    off = 0.25 * np.array([[-1, -1], [1, -1], [-1, 1], [1, 1]])
+    x = ((cc[:, None, :] + 0.5 + off[None]) * dx).reshape(-1, 2) + rng.uniform(-0.1, 0.1, (len(cc) * 4, 2)) * dx
+    n = len(x)
+    c = x.mean(0)
+    v = 3.0 * np.stack([-(x[:, 1] - c[1]), x[:, 0] - c[0]], 1) + rng.normal(0, 0.1, (n, 2))
+    F = np.eye(2).reshape(1, 4) + rng.normal(0, 0.02, (n, 4))
+    B = rng.normal(0, 0.01, (n, 4))
+    return x.astype(np.float32), v.astype(np.float32), F.astype(np.float32), B.astype(np.float32)
+
+
+MPM2D_CASES = {
+    "floor": dict(shapes=[(0, 0, 0, 1, 0, -0.37)], friction=0.4, cfg={}),
+    "disc+rising_floor": dict(shapes=[(0, 0, 0, 1, 0, -0.37), (1, 0, 0.5, 0.33, 0, 0.08)],
+                              shapes1=[(0, 0, 0, 1, 0, -0.375), (1, 0, 0.5, 0.33, 0, 0.08)], t1=0.01, friction=-1.0, cfg={}),
+    "damped+grid_gravity": dict(shapes=[(2, 1, 0.2, 0.2, 0, 0.8, 0.8, 0)], friction=-2.5,
+                                cfg=dict(apic_damping=0.2, rpic_damping=0.1, particle_gravity=False)),
+}
+
+
+def mpm2d_fixture(here):
+    """MPM<2> of the reference (create_simulation2('mpm'): the generic rasterize / resample, src/transfer.cpp:193-278,585-687)
+    for every particle type, three substeps"""
+    import json
+    res, dt = 64, 1e-4
+    dx = 1.0 / res
+    x, v, F, B = mpm2d_state(res)
+    vol = dx ** 2 / 4
+    out = dict(x=x, v=v, F=F, B=B)
+    for mat in MATS:
+        aux0 = {"snow": 1.0, "water": 1.0, "visco": 1000.0}.get(mat, 0.0)
+        aux = np.full(len(x), aux0, np.float32)
+        gp, t = orc.group_params(mat, 400.0 * vol, vol, **MAT_KW.get(mat, {}))
+        out["gp_" + mat] = gp
+        for name, c in MPM2D_CASES.items():
+            if name != "floor" and mat not in ("jelly", "sand", "water"):
+                continue
+            sim = ref.Sim(res, dx, dt, dim=2, shapes=c["shapes"], friction=c["friction"], **c["cfg"])
+            if "shapes1" in c:
+                sim.set_levelset(c["shapes"], c["friction"], shapes1=c["shapes1"], t0=0.0, t1=c["t1"])
+            sim.add_particles(mat, 400.0 * vol, vol, x, v, F, B, aux, **MAT_KW.get(mat, {}))
+            sim.substep(3)
+            d = sim.download()
+            sim.close()
+            out["%s_%s" % (name, mat)] = np.concatenate([d["x"], d["v"], d["F"], d["B"], d["aux"][:, None]], 1)
+            out["%s_%s_ids" % (name, mat)] = d["id"]
+    np.savez_compressed(os.path.join(here, "ref_mpm2d.npz"), res=res, dx=dx, dt=dt, cases=json.dumps(MPM2D_CASES), **out)
+    print("mpm2d:", len(x), "particles")
+
+
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     ref.set_threads(1)  # the generic P2G of the reference is racy with more than one thread (SURVEY quirk 5)
-    what = sys.argv[1:] or (list(MATS) + ["materials", "kernels", "shapes"])
+    what = sys.argv[1:] or (list(MATS) + ["materials", "kernels", "shapes", "mpm2d"])
     for w in what:
         if w in MATS:
             substep_fixture(here, w)
@@ -182,6 +236,8 @@ def main():
             kernels_fixture(here)
         elif w == "shapes":
             shapes_fixture(here)
+        elif w == "mpm2d":
+            mpm2d_fixture(here)
 
 
 if __name__ == "__main__":

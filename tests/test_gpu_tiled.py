@@ -132,6 +132,40 @@ def test_k_tiles_reproduce_one_tile(tm, world, dims, overlap):
         sim.close()
 
 
+def test_c5_clusters_over_8_virtual_ranks_reproduce_one_ctx(tm):
+    """BASELINE configs[4] on more than one GPU (reduced: 64^3 grid, 8 clusters of 12^3 cells x 8, water / Hencky-elastic
+    alternating): the builders bench.py uses for `--config c5 --gpus 8` — every rank registers all 8 groups, balanced
+    bricks over the union of the clusters — against the single-ctx builder, 11 substeps, K = 8 bricks"""
+    import bench
+    from taichi_mpm_amd import tiled
+    cfg = dict(res=64, cells=12, material="water+elastic", clusters=(10, 38), desc="reduced c5")
+    one = bench.build_sim(tm, cfg, 0)
+    groups = tiled.scene_groups(cfg)
+    assert len(groups) == 8 and {g[0] for g in groups} == {"water", "elastic"}
+    part = tiled.scene_partition(cfg, 8, margin=2)
+    assert part.dims == (2, 2, 2)
+    engines, total = [], 0
+    for r in range(8):
+        sim, total = tiled.build_rank_sim(tm, cfg, part, r, 0, extra_cfg=dict(reorder_interval=0))
+        assert sim.get_num_particles() > 0.5 * total / 8  # the cuts fall between the clusters
+        engines.append(tiled.HipEngine(sim, 0))
+    assert total == 8 * 12 ** 3 * 8 == one.get_num_particles()
+    job = tiled.VirtualTiledJob(engines, part, migrate_interval=2, overlap=True)
+    steps = 11
+    job.run(steps)
+    one.run_substeps(steps)
+    ref, got = one.get_particles(), _gather([e.sim for e in engines])
+    assert np.array_equal(got["id"], ref["id"]) and np.array_equal(got["gid"], ref["gid"])
+    assert set(np.unique(got["gid"])) == set(range(8))
+    assert np.abs(got["x"] - ref["x"]).max() <= 1e-6
+    assert rel_l2(got["v"], ref["v"]) <= 1e-4
+    el = ref["gid"] % 2 == 1  # water never updates F
+    assert rel_l2(got["F"][el], ref["F"][el]) <= 1e-4 and np.abs(got["aux"] - ref["aux"]).max() <= 1e-4
+    for e in engines:
+        e.sim.close()
+    one.close()
+
+
 def test_adaptive_migration_schedule_on_the_device(tm):
     """no explicit interval: the scan's measured top speed (max |v|_inf dt / dx over the live particles) schedules
     the next migration; checked against numpy on the downloaded velocities, and the 4-brick run still reproduces the
@@ -265,13 +299,15 @@ def test_two_processes_on_one_gpu_match_one_ctx(tm):
     assert rel_l2(got["v"], ref["v"]) <= 1e-4 and rel_l2(got["F"], ref["F"]) <= 1e-4
 
 
-@pytest.mark.parametrize("nproc,bricks,hook", [(2, "2x1x1", True), (8, "2x2x2", True), (2, "2x1x1", False)])
-def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks, hook):
+@pytest.mark.parametrize("nproc,bricks,hook,config", [(2, "2x1x1", True, "c2"), (8, "2x2x2", True, "c2"), (2, "2x1x1", False, "c2"),
+                                                       (8, "2x2x2", True, "c5")])
+def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks, hook, config):
     """`bench.py --gpus N` exactly as the driver launches it (torch.distributed.run, one process per rank), with
     the MPMHIP_BENCH_BACKEND=gloo hook: both ranks share this GPU and the buffers are staged through gloo.  Checks
     the ONE-JSON-line contract and the whole-job aggregation of the N > 1 path.  hook=False is the launch without
     any hook on a box with fewer GPUs than ranks: the RCCL probe fails (two ranks on one device) on every rank and
-    the job must carry on over the staged transport instead of aborting."""
+    the job must carry on over the staged transport instead of aborting.  config c5 = BASELINE configs[4] (512^3 grid,
+    8 clusters, two materials) tiled over 8 ranks, at a reduced cluster size (--cells 16)."""
     import json
     import os
     import socket
@@ -286,15 +322,16 @@ def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks, hook):
     if hook:
         env["MPMHIP_BENCH_BACKEND"] = "gloo"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--config", "c2",
-           "--steps", "8", "--warmup", "4"]
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--config", config,
+           "--steps", "8", "--warmup", "4"] + (["--cells", "16"] if config == "c5" else [])
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == nproc and d["steps"] == 8 and d["warmup"] == 4 and d["scaling"] == "strong"
-    assert d["config"]["particles"] == 1000000  # both ranks' particles: whole-job aggregate
+    assert d["config"]["particles"] == (1000000 if config == "c2" else 8 * 16 ** 3 * 8)  # all ranks' particles: whole-job aggregate
+    assert ("REDUCED" in d["config"]["workload"]) == (config == "c5")
     assert d["value"] > 0 and d["unit"] == "particle-steps/s" and d["roofline"]["kernel"] in ("k_g2p", "k_p2g")
     assert bricks + " bricks" in d["config"]["parallelism"]
     assert d["config"]["wire"].startswith("gloo") and ("probe failed" in d["config"]["wire"]) == (not hook)

@@ -24,7 +24,7 @@ def built():
 def test_library_exports_every_declared_symbol(built):
     hdr = open(os.path.join(ROOT, "include", "mpmhip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(mpmhip_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(mpmhip(?:2d)?_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     for sym in sorted(declared):
         assert hasattr(built, sym), "libmpmhip.so does not export %s" % sym

@@ -45,6 +45,28 @@ def test_brick_dims_and_balanced_cuts():
     assert counts.max() / counts.min() < 1.05, counts
 
 
+def test_scene_partition_balances_the_c5_clusters_over_8_ranks():
+    """BASELINE configs[4] on 8 GPUs: the scene is a list of groups (8 clusters, two materials); the bricks are balanced
+    over the union of the clusters' histograms and every particle has exactly one owner (no GPU needed)"""
+    cfg = dict(res=128, cells=20, material="water+elastic", clusters=(20, 84))
+    groups = tiled.scene_groups(cfg)
+    assert [g[0] for g in groups] == ["water", "elastic"] * 4 and len({g[1] for g in groups}) == 8
+    part = tiled.scene_partition(cfg, 8, margin=4)
+    assert part.dims == (2, 2, 2)
+    counts = np.zeros(8, np.int64)
+    for g in groups:
+        x = tiled.group_positions(g, 1.0 / 128)
+        assert len(x) == 20 ** 3 * 8
+        counts += np.bincount(part.rank_of_cells(tiled.base_cells(x, 1.0 / 128)), minlength=8)
+    assert counts.sum() == 8 * 20 ** 3 * 8 and counts.min() == counts.max()  # one cluster per brick
+    # a single cube (C3) goes through the same builders
+    c3 = dict(res=256, cells=100, material="sand")
+    assert tiled.scene_groups(c3) == [("sand", (78, 78, 78), 100)]
+    # the clip box wraps the occupied part of the grid
+    lo, hi = part.clip
+    assert all(lo[a] <= 20 - 4 and hi[a] >= 84 + 20 + 4 for a in range(3))
+
+
 def test_halo_boxes_are_symmetric_and_cover_every_shared_node():
     x = _state().x
     for world, dims in ((2, None), (8, None), (4, (4, 1, 1)), (6, None)):
