@@ -159,11 +159,39 @@ struct MPMParticle {
     const int rc = mpmhip_debug_plasticity(ctx, type.material, type.params, 1, cdg.data(), dg_e.data(), &aux, nullptr);
     if (rc < 0) throw std::runtime_error(mpmhip_last_error(ctx));
   }
-  // explicit-integration bound used by the reference's async stepper: dx / sqrt((lambda + 2 mu) / density)
+  // MPMParticle::get_allowed_dt(dx): dx / (c + |v|) with the material's own sound speed c — what the reference's async
+  // stepper turns into a block's strength_dt_limit (src/async/async_mpm.cpp:105-111).  Per type (src/particles.cpp):
+  //   visco / sand / von_mises / elastic (:136-155,649-665,734-750,814-830)
+  //        J = det F, rho = rho0 / J, K = 2 mu / 3 + lambda, c^2 = max(4 mu / (3 rho) + K (1 - log J) / rho0, 1e-20)
+  //   snow (:254-278)   J = det F * Jp, (mu, lambda) hardened by exp(h (1 - Jp)), c = sqrt((lambda + 2 mu) / rho)
+  //   water (:480-490)  c^2 = k gamma / j^(gamma - 1)
+  //   linear / jelly (:343-345,418-420)  0 (no bound: the async stepper stops on them)
+  // The device evaluates the same expression per particle (mpmhip_debug_allowed_dt, mpmhip_async_update_dt_limits).
   float get_allowed_dt(float dx) const {
-    const float rho = get_mass() / get_vol();
-    const float stiff = (type.material == MPMHIP_WATER) ? type.params[2] * type.params[3] : type.params[3] + 2 * type.params[2];
-    return dx / std::sqrt(stiff / rho);
+    const float *p = type.params;
+    const float u = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float rho0 = get_mass() / get_vol();
+    const float *F = dg_e.data();
+    const float det = F[0] * (F[4] * F[8] - F[5] * F[7]) - F[1] * (F[3] * F[8] - F[5] * F[6]) + F[2] * (F[3] * F[7] - F[4] * F[6]);
+    float c;
+    switch (type.material) {
+      case MPMHIP_LINEAR:
+      case MPMHIP_JELLY:
+        return 0.0f;
+      case MPMHIP_WATER:
+        c = std::sqrt(p[2] * p[3] / std::pow(aux, p[3] - 1.0f));
+        break;
+      case MPMHIP_SNOW: {
+        const float J = det * aux, rho = rho0 / J, e = std::exp(p[4] * (1.0f - aux));
+        c = std::sqrt((p[3] * e + 2.0f * p[2] * e) / rho);
+        break;
+      }
+      default: {
+        const float rho = rho0 / det, K = 2.0f * p[2] / 3.0f + p[3];
+        c = std::sqrt(std::max(4.0f * p[2] / (3.0f * rho) + K * (1.0f - std::log(det)) / rho0, 1e-20f));
+      }
+    }
+    return dx / (c + u);
   }
 };
 

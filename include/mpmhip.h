@@ -281,6 +281,30 @@ int mpmhip_active_bounds(mpmhip_ctx *ctx, int32_t lo[3], int32_t hi[3]);
 int64_t mpmhip_num_slots(mpmhip_ctx *ctx);       /* slots in use (live + dead) — capacity pressure */
 int mpmhip_request_compaction(mpmhip_ctx *ctx);  /* physical reorder + drop of dead slots at the next sort */
 
+/* ---- AsyncMPM, first half — replaces AsyncMPM<dim>::update_dt_limits (src/async/async_mpm.cpp:90-164) and the limit
+ * attributes AsyncMPM<dim>::visualize writes (src/async/async_visualize.cpp:17-26).  A scheduler block is the reference's
+ * SPGrid block of 4 x 4 x 8 nodes holding the particle's base node.  Per block: strength_dt_limit =
+ * int(strength_dt_mul * min get_allowed_dt(dx) / unit_delta_t) (per-material sound-speed bound, src/particles.cpp),
+ * cfl_dt_limit = int(cfl_dt_mul * dx / unit_delta_t / sqrt(max |v|^2)), continuous_dt_limit = the power of two that
+ * tracks min(cfl, strength, max_units) under the reference's halving / doubling rule.  The per-block reduction runs on
+ * the device, the block state machine on the host.  After mpmhip_async_update_dt_limits the `limit` attribute of
+ * mpmhip_write_bgeo carries (continuous, strength, cfl) of each particle's block instead of (1, 1, 1).
+ * NOT built: the stepping itself (AsyncMPM<dim>::advance / step: block subsets advancing with their own dt). */
+typedef struct {
+  float unit_delta_t;     /* config "unit_delta_t", default 1e-6 (src/async/async_mpm.cpp:24) */
+  int64_t max_units;      /* "max_units", default 8192 */
+  float cfl_dt_mul;       /* "cfl_dt_mul", default 1 */
+  float strength_dt_mul;  /* "strength_dt_mul", default 1 */
+} mpmhip_async_config;
+int mpmhip_async_enable(mpmhip_ctx *ctx, const mpmhip_async_config *cfg);
+int mpmhip_async_update_dt_limits(mpmhip_ctx *ctx);
+int64_t mpmhip_async_blocks(mpmhip_ctx *ctx, int64_t capacity, int32_t *corner_node /* [n][3] */, int64_t *strength,
+                            int64_t *cfl, int64_t *continuous, int64_t *count, int64_t min_max_delta_t_int[2]);
+int mpmhip_async_set_time_int(mpmhip_ctx *ctx, int64_t current_t_int);
+/* MPMParticle::get_allowed_dt(dx) of n particle states of one material (src/particles.cpp:136-155,254-278,480-490,...) */
+int mpmhip_debug_allowed_dt(mpmhip_ctx *ctx, int32_t material, const float params[MPMHIP_NPARAM], int64_t n, const float *F,
+                            const float *aux, const float *v, float dx, float *out);
+
 /* ---- MPM<2>: the reference's 2D simulation — replaces the object tc_core.create_simulation2('mpm') returns
  * (TC_IMPLEMENTATION(Simulation2D, MPM2D, "mpm"), src/mpm.cpp:983-986).  MPM<2> runs the GENERIC transfer path
  * (rasterize_optimized = rasterize, resample_optimized = resample: src/transfer.cpp:280-283,697-700; bodies :193-278,

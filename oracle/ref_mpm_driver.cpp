@@ -18,6 +18,8 @@
 
 #include "kernel.h"
 #include "mpm.h"
+#include "async/async_mpm.h"  // AsyncMPM<dim>: this TU is compiled with -fno-access-control so that the checker can read
+                              // the block table (`blocks`, `particle_pool`), which the class keeps private
 
 TC_NAMESPACE_BEGIN
 
@@ -64,6 +66,7 @@ struct Handle {
   int dim = 3;
   std::unique_ptr<MPM<2>> m2;
   std::unique_ptr<MPM<3>> m3;
+  AsyncMPM<3> *async3 = nullptr;  // == m3.get() when the simulation is the "async_mpm" one
 };
 
 template <int dim> MPM<dim> &sim(Handle *h);
@@ -102,6 +105,19 @@ int add_particles(Handle *h, const Config &cfg, int64_t n, const float *x, const
     if (B) p->apic_b = mat_in<dim>(B + dim * dim * i);
     if (aux) if (real *a = aux_ptr<dim>(p)) *a = aux[i];
     m.particles.push_back(alloc.first);
+  }
+  if (dim == 3 && h->async3) {
+    // the tail of AsyncMPM<dim>::add_particles (src/async/async_mpm.cpp:62-75): the new particles move from the
+    // flat list into the pool of the scheduler block of their base node
+    AsyncMPM<3> &a = *h->async3;
+    using Mask = typename MPM<3>::SparseMask;
+    for (auto p : a.particles) {
+      uint64 grid_offset = Mask::Linear_Offset(a.MPM<3>::get_grid_base_pos(
+          (reinterpret_cast<MPMParticle<3> *>(&a.allocator.pool[p]))->pos * a.inv_delta_x));
+      uint64 offset = (grid_offset >> Mask::data_bits >> Mask::block_bits) & a.scheduler_mask;
+      a.particle_pool[offset].push_back(a.allocator.pool[p]);
+    }
+    a.particles.clear();
   }
   return 0;
 }
@@ -238,6 +254,12 @@ void *ref_create(int dim, const char *cfg) {
     Config c = Config::from_string(cfg);
     if (!c.has_key("num_threads")) c.set("num_threads", ShimRuntime::get().threads);
     if (dim == 2) { h->m2 = std::make_unique<MPM<2>>(); h->m2->initialize(c); set_levelset<2>(h, 0, nullptr, -1, nullptr, 0, 1, 1.0f); }
+    else if (dim == 3 && c.get("async", false)) {  // create_simulation3('async_mpm'), src/async/async_mpm.cpp:423-427
+      h->async3 = new AsyncMPM<3>();
+      h->m3.reset(h->async3);
+      h->m3->initialize(c);
+      set_levelset<3>(h, 0, nullptr, -1, nullptr, 0, 1, 1.0f);
+    }
     else if (dim == 3) { h->m3 = std::make_unique<MPM<3>>(); h->m3->initialize(c); set_levelset<3>(h, 0, nullptr, -1, nullptr, 0, 1, 1.0f); }
     else TC_ERROR("dim must be 2 or 3");
     return 0;
@@ -336,6 +358,74 @@ int ref_general_action(void *hh, const char *cfg, char *out, size_t cap) {
     return 0;
   });
 }
+
+// ---- AsyncMPM (src/async/async_mpm.{h,cpp}) ----------------------------------------------------------------------
+int ref_async_update_dt_limits(void *hh) {
+  Handle *h = (Handle *)hh;
+  return guarded([&] { if (!h->async3) TC_ERROR("not an async_mpm simulation"); h->async3->update_dt_limits(); return 0; });
+}
+// non-empty scheduler blocks after update_dt_limits(): node coordinates of the block's corner + its three limits +
+// the number of particles in its pool.  Returns the number of blocks (-1 on error); min / max_delta_t_int in mm[2].
+int64_t ref_async_blocks(void *hh, int64_t cap, int32_t *coord, int64_t *strength, int64_t *cfl, int64_t *continuous, int64_t *count,
+                         int64_t *mm) {
+  Handle *h = (Handle *)hh;
+  int64_t n = 0;
+  const int rc = guarded([&] {
+    if (!h->async3) TC_ERROR("not an async_mpm simulation");
+    AsyncMPM<3> &a = *h->async3;
+    using Mask = typename MPM<3>::SparseMask;
+    for (uint64 offset = 0; offset < a.scheduler_size; ++offset) {
+      if (a.particle_pool[offset].empty()) continue;
+      if (n >= cap) TC_ERROR("block buffer too small");
+      auto c = Mask::LinearToCoord(uint64(offset) << Mask::data_bits << Mask::block_bits);
+      for (int k = 0; k < 3; k++) coord[3 * n + k] = c[k];
+      strength[n] = a.blocks[offset].strength_dt_limit;
+      cfl[n] = a.blocks[offset].cfl_dt_limit;
+      continuous[n] = a.blocks[offset].continuous_dt_limit;
+      count[n] = (int64_t)a.particle_pool[offset].size();
+      n++;
+    }
+    if (mm) { mm[0] = a.min_delta_t_int; mm[1] = a.max_delta_t_int; }
+    return 0;
+  });
+  return rc ? -1 : n;
+}
+// every particle of every pool (state at its block's particle_t) with its block's limits
+int64_t ref_async_download(void *hh, int64_t cap, float *x, float *v, float *F, float *B, float *aux, int32_t *id, int64_t *limits) {
+  Handle *h = (Handle *)hh;
+  int64_t n = 0;
+  const int rc = guarded([&] {
+    if (!h->async3) TC_ERROR("not an async_mpm simulation");
+    AsyncMPM<3> &a = *h->async3;
+    for (uint64 offset = 0; offset < a.scheduler_size; ++offset)
+      for (auto &container : a.particle_pool[offset]) {
+        if (n >= cap) TC_ERROR("particle buffer too small");
+        MPMParticle<3> *p = const_cast<MPMParticle<3> *>(reinterpret_cast<const MPMParticle<3> *>(&container));
+        auto vel = p->get_velocity();
+        for (int k = 0; k < 3; k++) { x[3 * n + k] = p->pos[k]; v[3 * n + k] = vel[k]; }
+        if (F) mat_out<3>(p->dg_e, F + 9 * n);
+        if (B) mat_out<3>(p->apic_b, B + 9 * n);
+        if (aux) { real *q = aux_ptr<3>(p); aux[n] = q ? *q : 0.0f; }
+        id[n] = p->id;
+        if (limits) {
+          limits[4 * n + 0] = a.blocks[offset].continuous_dt_limit; limits[4 * n + 1] = a.blocks[offset].strength_dt_limit;
+          limits[4 * n + 2] = a.blocks[offset].cfl_dt_limit; limits[4 * n + 3] = a.blocks[offset].particle_t;
+        }
+        n++;
+      }
+    return 0;
+  });
+  return rc ? -1 : n;
+}
+int64_t ref_async_num_particles(void *hh) {
+  Handle *h = (Handle *)hh;
+  if (!h->async3) return -1;
+  int64_t n = 0;
+  for (uint64 offset = 0; offset < h->async3->scheduler_size; ++offset) n += (int64_t)h->async3->particle_pool[offset].size();
+  return n;
+}
+int64_t ref_async_time_int(void *hh) { Handle *h = (Handle *)hh; return h->async3 ? h->async3->current_t_int : -1; }
+int64_t ref_async_update_counter(void *hh) { Handle *h = (Handle *)hh; return h->async3 ? (int64_t)h->async3->update_counter : -1; }
 
 // seconds per TC_PROFILE name since the last reset, as "name=seconds;..."
 int ref_profile(char *out, size_t cap, int reset) {

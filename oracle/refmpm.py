@@ -68,6 +68,18 @@ def lib():
         L.ref_stencil_start.argtypes = [C.c_float]
         L.ref_friction_project.argtypes = [P_F, P_F, P_F, C.c_float, P_F]
         L.ref_shim_svd3.argtypes = [P_F, P_F, P_F, P_F]
+        P_L = C.POINTER(C.c_int64)
+        L.ref_async_update_dt_limits.argtypes = [C.c_void_p]
+        L.ref_async_blocks.restype = C.c_int64
+        L.ref_async_blocks.argtypes = [C.c_void_p, C.c_int64, P_I, P_L, P_L, P_L, P_L, P_L]
+        L.ref_async_download.restype = C.c_int64
+        L.ref_async_download.argtypes = [C.c_void_p, C.c_int64, P_F, P_F, P_F, P_F, P_F, P_I, P_L]
+        L.ref_async_num_particles.restype = C.c_int64
+        L.ref_async_num_particles.argtypes = [C.c_void_p]
+        L.ref_async_time_int.restype = C.c_int64
+        L.ref_async_time_int.argtypes = [C.c_void_p]
+        L.ref_async_update_counter.restype = C.c_int64
+        L.ref_async_update_counter.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -232,6 +244,52 @@ class Sim:
         buf = C.create_string_buffer(4096)
         _chk(lib().ref_general_action(self.h, cfg_string(**kw), buf, 4096))
         return buf.value.decode()
+
+
+class AsyncSim(Sim):
+    """AsyncMPM<3> of the reference (create_simulation3('async_mpm'), src/async/async_mpm.{h,cpp}): block-local time steps.
+    Config keys: unit_delta_t, max_units, cfl_dt_mul, strength_dt_mul (src/async/async_mpm.cpp:24-27)."""
+
+    def __init__(self, res, dx, dt=1e-4, **cfg):
+        super().__init__(res, dx, dt, dim=3, **{"async": True, **cfg})
+
+    def update_dt_limits(self):
+        _chk(lib().ref_async_update_dt_limits(self.h))
+
+    def blocks(self):
+        """non-empty scheduler blocks: dict(coord (n,3) node coordinates of the block corner, strength, cfl, continuous,
+        count) + (min_delta_t_int, max_delta_t_int)"""
+        cap = 1 << 20
+        coord = np.zeros((cap, 3), np.int32)
+        arrs = [np.zeros(cap, np.int64) for _ in range(4)]
+        mm = np.zeros(2, np.int64)
+        P_L = C.POINTER(C.c_int64)
+        n = lib().ref_async_blocks(self.h, cap, coord.ctypes.data_as(P_I), *(a.ctypes.data_as(P_L) for a in arrs), mm.ctypes.data_as(P_L))
+        if n < 0:
+            raise RuntimeError("reference: " + lib().ref_last_error().decode())
+        return dict(coord=coord[:n], strength=arrs[0][:n], cfl=arrs[1][:n], continuous=arrs[2][:n], count=arrs[3][:n]), tuple(mm)
+
+    def num_particles(self):
+        return int(lib().ref_async_num_particles(self.h))
+
+    def download(self, by_id=True):
+        n = self.num_particles()
+        out = dict(x=np.zeros((n, 3), np.float32), v=np.zeros((n, 3), np.float32), F=np.zeros((n, 9), np.float32),
+                   B=np.zeros((n, 9), np.float32), aux=np.zeros(n, np.float32), id=np.zeros(n, np.int32), limits=np.zeros((n, 4), np.int64))
+        m = lib().ref_async_download(self.h, n, *(out[k].ctypes.data_as(P_F) for k in ("x", "v", "F", "B", "aux")),
+                                     out["id"].ctypes.data_as(P_I), out["limits"].ctypes.data_as(C.POINTER(C.c_int64)))
+        if m != n:
+            raise RuntimeError("reference: " + lib().ref_last_error().decode())
+        if by_id:
+            o = np.argsort(out["id"], kind="stable")
+            out = {k: a[o] for k, a in out.items()}
+        return out
+
+    def time_int(self):
+        return int(lib().ref_async_time_int(self.h))
+
+    def update_counter(self):
+        return int(lib().ref_async_update_counter(self.h))
 
 
 def profile(reset=False):

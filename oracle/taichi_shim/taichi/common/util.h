@@ -131,6 +131,7 @@ struct ShimError : std::runtime_error {
 #define TC_REPEAT27(F) \
   F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15) F(16) F(17) F(18) F(19) F(20) F(21) F(22) F(23) F(24) F(25) F(26)
 #define TC_LOAD_CONFIG(name, dflt) name = config.get(#name, dflt)
+#define TC_ERROR_IF(cond, ...) do { if (cond) ::taichi::shim_fail("TC_ERROR_IF: " #cond, __FILE__, __LINE__); } while (0)
 
 // serialization: not part of the path; the declarations only have to parse
 struct BinaryOutputSerializer {
@@ -150,13 +151,14 @@ struct BinaryInputSerializer {
 #define TC_IO_DEF_WITH_BASE(...)
 #define TC_IO_DECL template <typename TC_SERIALIZER_> void io(TC_SERIALIZER_ &serializer) const
 #define TC_IO_DECL_VIRT template <typename TC_SERIALIZER_> void io_virt_(TC_SERIALIZER_ &serializer) const
-#define TC_SERIALIZER_IS(T) (std::is_same<TC_SERIALIZER_, T>::value)
+#define TC_SERIALIZER_IS(T) (std::is_same<std::decay_t<decltype(serializer)>, T>::value)
 template <typename T> void write_to_binary_file(const T &, const std::string &) {}
 template <typename T> void read_from_binary_file(T &, const std::string &) {}
 template <int dim> struct Element {};
 
 namespace bit {
-constexpr bool is_power_of_two(int x) { return x > 0 && (x & (x - 1)) == 0; }
+constexpr bool is_power_of_two(long long x) { return x > 0 && (x & (x - 1)) == 0; }
+inline int log2int(unsigned long long x) { int r = 0; while (x > 1) { x >>= 1; r++; } return r; }
 }  // namespace bit
 namespace math {
 inline real radians(real deg) { return deg * (real)(M_PI / 180.0); }
@@ -536,7 +538,8 @@ class Unit {
   virtual bool test() const { return true; }
   virtual std::string get_name() const { return "unit"; }
   virtual ~Unit() {}
-  template <typename S> void binary_io(S &) const {}
+  virtual void binary_io(BinaryOutputSerializer &) const {}
+  virtual void binary_io(BinaryInputSerializer &) const {}
 };
 template <typename T>
 struct InterfaceHolder {
@@ -796,6 +799,7 @@ class Profiler {
   static void disable() {}
   static void enable() {}
 };
+#define TC_PROFILER(name) ::taichi::Profiler TC_SHIM_CAT(shim_profiler_scope_, __LINE__)(name);
 #define TC_PROFILE(name, stmt) { ::taichi::Profiler shim_profiler_(name); stmt; }
 #define TC_PROFILE_TPE(name, stmt, n) { ::taichi::Profiler shim_profiler_(name); stmt; }
 namespace Time {
@@ -834,6 +838,29 @@ using Simulation3D = Simulation<3>;
 }  // namespace taichi
 
 namespace tbb {
+// the containers src/async/async_mpm.{h,cpp} uses.  The reference runs its block loops on TBB threads; here every tbb
+// construct with a blocked_range runs serially (AsyncMPM is a checker in this build, not a timed path), so plain vectors do.
+template <typename T>
+class concurrent_vector : public std::vector<T> {
+ public:
+  using std::vector<T>::vector;
+};
+template <typename T>
+struct blocked_range {
+  T b, e;
+  blocked_range(T b_, T e_) : b(b_), e(e_) {}
+  T begin() const { return b; }
+  T end() const { return e; }
+};
+template <typename T>
+class enumerable_thread_specific {
+  std::vector<T> v = std::vector<T>(1);
+ public:
+  T &local() { return v[0]; }
+  typename std::vector<T>::iterator begin() { return v.begin(); }
+  typename std::vector<T>::iterator end() { return v.end(); }
+};
+template <typename T, typename F> inline void parallel_for(const blocked_range<T> &r, const F &f) { f(r); }
 template <typename F> inline void parallel_for(int b, int e, const F &f) {
   const int th = ::taichi::ShimRuntime::get().threads;
   if (th <= 1) { for (int i = b; i < e; i++) f(i); return; }

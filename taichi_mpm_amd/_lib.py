@@ -40,6 +40,11 @@ class Shape(C.Structure):
 MAX_SHAPES = 16
 
 
+class AsyncConfig(C.Structure):
+    """mirror of mpmhip_async_config"""
+    _fields_ = [("unit_delta_t", C.c_float), ("max_units", C.c_int64), ("cfl_dt_mul", C.c_float), ("strength_dt_mul", C.c_float)]
+
+
 class Config2D(C.Structure):
     """mirror of mpmhip2d_config"""
     _fields_ = [("res", C.c_int32 * 2), ("dx", C.c_float), ("dt", C.c_float), ("gravity", C.c_float * 2),
@@ -102,6 +107,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_las
             "mpmhip_substep_begin", "mpmhip_substep_end", "mpmhip_substep_interior", "mpmhip_set_overlap", "mpmhip_leaver_counts", "mpmhip_migration_scan", "mpmhip_export_leavers",
             "mpmhip_import_particles", "mpmhip_active_bounds", "mpmhip_num_slots", "mpmhip_request_compaction", "mpmhip_mpm88_create", "mpmhip_mpm88_destroy", "mpmhip_mpm88_last_error", "mpmhip_mpm88_add",
             "mpmhip_mpm88_num_particles", "mpmhip_mpm88_advance", "mpmhip_mpm88_download", "mpmhip_mpm88_download_grid",
+            "mpmhip_async_enable", "mpmhip_async_update_dt_limits", "mpmhip_async_blocks", "mpmhip_async_set_time_int", "mpmhip_debug_allowed_dt",
             "mpmhip2d_create", "mpmhip2d_destroy", "mpmhip2d_last_error", "mpmhip2d_set_levelset", "mpmhip2d_add_group", "mpmhip2d_add_particles",
             "mpmhip2d_substep", "mpmhip2d_step", "mpmhip2d_current_time", "mpmhip2d_num_particles", "mpmhip2d_download", "mpmhip2d_download_grid",
             "mpmhip_debug_copy_bandwidth", "mpmhip_debug_gather_bandwidth", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
@@ -192,6 +198,13 @@ def load():
     L.mpmhip_mpm88_advance.argtypes = [vp, C.c_int32]
     L.mpmhip_mpm88_download.argtypes = [vp, fp, fp, fp, fp, fp]
     L.mpmhip_mpm88_download_grid.argtypes = [vp, fp]
+    lp = P(C.c_int64)
+    L.mpmhip_async_enable.argtypes = [vp, P(AsyncConfig)]
+    L.mpmhip_async_update_dt_limits.argtypes = [vp]
+    L.mpmhip_async_blocks.argtypes = [vp, C.c_int64, ip, lp, lp, lp, lp, lp]
+    L.mpmhip_async_blocks.restype = C.c_int64
+    L.mpmhip_async_set_time_int.argtypes = [vp, C.c_int64]
+    L.mpmhip_debug_allowed_dt.argtypes = [vp, C.c_int32, fp, C.c_int64, fp, fp, fp, C.c_float, fp]
     L.mpmhip2d_create.argtypes = [P(Config2D), P(vp)]
     L.mpmhip2d_destroy.argtypes = [vp]
     L.mpmhip2d_destroy.restype = None

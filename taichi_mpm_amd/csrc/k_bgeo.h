@@ -18,13 +18,15 @@ __global__ __launch_bounds__(256) void k_bgeo_ids(Params P, const RecG *__restri
 __device__ __forceinline__ uint32_t be(float f) { return __builtin_bswap32(__float_as_uint(f)); }
 __device__ __forceinline__ uint32_t be(int32_t i) { return __builtin_bswap32((uint32_t)i); }
 
-// row j <- particle in slot order[j].  Without rigid bodies and async stepping the reference's remaining per-particle
-// fields keep their constructor values (src/particles.h:92-99): type = is_rigid = 0, limit = (1, 1, 1),
+// row j <- particle in slot order[j].  Without rigid bodies the reference's remaining per-particle fields keep their
+// constructor values (src/particles.h:92-99): type = is_rigid = 0, limit = (1, 1, 1) unless async stepping is on,
 // boundary_normal = 0, states = 0, boundary_distance = 0, near_boundary = 0.
 template <bool VERBOSE>
 __global__ __launch_bounds__(256) void k_bgeo_rows(uint32_t n, const uint32_t *__restrict__ order, const RecG *__restrict__ rg,
                                                    const RecP *__restrict__ rp, const float *__restrict__ rb,
-                                                   const GroupParams *__restrict__ groups, uint32_t *__restrict__ rows) {
+                                                   const GroupParams *__restrict__ groups,
+                                                   const int32_t *__restrict__ limits /* [slot][3] or nullptr */,
+                                                   uint32_t *__restrict__ rows) {
   constexpr int W = VERBOSE ? BGEO_W_VERBOSE : BGEO_W_PLAIN;
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
     const uint32_t s = order[j];
@@ -35,6 +37,9 @@ __global__ __launch_bounds__(256) void k_bgeo_rows(uint32_t n, const uint32_t *_
     w[4] = be(0);                                                                // type = int(is_rigid())
     w[5] = be(g.pid);                                                            // index = id
     w[6] = w[7] = w[8] = be(1);                                                  // dt_limit, stiffness_limit, cfl_limit
+    if (limits) {  // async stepping: the limits of the particle's scheduler block (src/async/async_visualize.cpp:17-26)
+      w[6] = be(limits[3 * (size_t)s]); w[7] = be(limits[3 * (size_t)s + 1]); w[8] = be(limits[3 * (size_t)s + 2]);
+    }
     w[9] = be(p.v[0]); w[10] = be(p.v[1]); w[11] = be(p.v[2]);
     if constexpr (VERBOSE) {
       const GroupParams gp = groups[g.gid];

@@ -61,6 +61,56 @@ __global__ __launch_bounds__(256) void k_delete_inside_levelset(Params P, RecG *
   }
 }
 
+// AsyncMPM, first half of update_dt_limits (src/async/async_mpm.cpp:91-111): per SCHEDULER block — the reference's SPGrid
+// block of 4 x 4 x 8 nodes holding the particle's base node — the smallest get_allowed_dt(dx) and the largest |v|^2 of
+// its particles, and their number.  tab[3 b + {0, 1, 2}] = (bits of min allowed dt, bits of max |v|^2, count); positive
+// floats order like their bit patterns, so integer atomics do.  Also writes the block id of every particle.
+__global__ __launch_bounds__(256) void k_async_block_reduce(Params P, const RecG *__restrict__ rg, const RecP *__restrict__ rp,
+                                                            const GroupParams *__restrict__ groups, int nbx, int nby, int nbz,
+                                                            uint32_t *__restrict__ tab, uint32_t *__restrict__ blk_of) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_slots; i += gridDim.x * blockDim.x) {
+    const RecG r = rg[i];
+    if (r.pid < 0) { blk_of[i] = INVALID; continue; }
+    const RecP q = rp[i];
+    int b[3];
+    bool in = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      b[k] = (int)(r.x[k] * P.idx - 0.5f);  // get_grid_base_pos, src/mpm.h:252-255
+      in = in && r.x[k] * P.idx >= 0.5f;
+    }
+    const int bx = b[0] >> 2, by = b[1] >> 2, bz = b[2] >> 3;
+    if (!in || bx >= nbx || by >= nby || bz >= nbz) { blk_of[i] = INVALID; continue; }
+    const uint32_t blk = ((uint32_t)bx * nby + by) * nbz + bz;
+    blk_of[i] = blk;
+    mat3 F;
+#pragma unroll
+    for (int k = 0; k < 9; k++) F.m[k] = r.F[k];
+    const float adt = allowed_dt(groups[r.gid], F, r.aux, q.v, P.dx);
+    const float v2 = q.v[0] * q.v[0] + q.v[1] * q.v[1] + q.v[2] * q.v[2];
+    atomicMin(&tab[3 * blk + 0], __float_as_uint(fmaxf(adt, 0.0f)));
+    atomicMax(&tab[3 * blk + 1], __float_as_uint(v2));
+    atomicAdd(&tab[3 * blk + 2], 1u);
+  }
+}
+// per-particle (dt_limit, stiffness_limit, cfl_limit) = its block's (AsyncMPM::visualize, src/async/async_visualize.cpp:17-26)
+__global__ __launch_bounds__(256) void k_async_particle_limits(Params P, const uint32_t *__restrict__ blk_of,
+                                                               const int32_t *__restrict__ blk_limits, int32_t *__restrict__ out) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_slots; i += gridDim.x * blockDim.x) {
+    const uint32_t b = blk_of[i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) out[3 * (size_t)i + k] = b == INVALID ? 1 : blk_limits[3 * (size_t)b + k];
+  }
+}
+__global__ void k_debug_allowed_dt(GroupParams g, int64_t n, const float *F, const float *aux, const float *v, float dx, float *out) {
+  for (int64_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    mat3 f;
+    for (int k = 0; k < 9; k++) f.m[k] = F[9 * i + k];
+    const float vv[3] = {v[3 * i], v[3 * i + 1], v[3 * i + 2]};
+    out[i] = allowed_dt(g, f, aux[i], vv, dx);
+  }
+}
+
 // sum of MPMParticle::potential_energy() (src/particles.cpp:323-327 linear, :400-407 jelly, :785-796 elastic;
 // the other types do not define it in the reference: TC_NOT_IMPLEMENTED) -> out[0]; out[1] counts particles of
 // types without a potential energy

@@ -509,6 +509,37 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
   F = mat_mul(Rr, F);
 }
 
+// MPMParticle::get_allowed_dt(dx) per material — the explicit-integration bound the async stepper turns into the block's
+// strength_dt_limit (src/async/async_mpm.cpp:105-111): dx / (c + |v|) with the material's sound speed c
+//   visco / sand / von_mises / elastic (src/particles.cpp:136-155,649-665,734-750,814-830):
+//        J = det F, rho = rho0 / J, K = 2 mu / 3 + lambda, c^2 = max(4 mu / (3 rho) + K (1 - log J) / rho0, 1e-20)
+//   snow (:254-278):  J = det F * Jp, (mu, lambda) hardened by exp(h (1 - Jp)), c = sqrt((lambda + 2 mu) / rho)
+//   water (:480-490): c^2 = k gamma / j^(gamma - 1)
+//   linear / jelly (:343-345,418-420): 0 — the reference's async stepper stops on them (tmp_limit < 1)
+__device__ __forceinline__ float allowed_dt(const GroupParams &g, const mat3 &F, float aux, const float v[3], float dx) {
+  const float u = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  const float rho0 = g.p[0] / g.p[1];
+  float c;
+  switch (g.type) {
+    case MPMHIP_LINEAR:
+    case MPMHIP_JELLY:
+      return 0.0f;
+    case MPMHIP_WATER:
+      c = sqrtf(g.p[2] * g.p[3] / powf(aux, g.p[3] - 1.0f));
+      break;
+    case MPMHIP_SNOW: {
+      const float J = mat_det(F) * aux, rho = rho0 / J, e = expf(g.p[4] * (1.0f - aux));
+      c = sqrtf((g.p[3] * e + 2.0f * g.p[2] * e) / rho);
+      break;
+    }
+    default: {
+      const float J = mat_det(F), rho = rho0 / J, K = 2.0f * g.p[2] / 3.0f + g.p[3];
+      c = sqrtf(fmaxf(4.0f * g.p[2] / (3.0f * rho) + K * (1.0f - logf(J)) / rho0, 1e-20f));
+    }
+  }
+  return dx / (c + u);
+}
+
 // friction_project — src/mpm_fwd.h:25-57
 __device__ __forceinline__ void friction_project(float v[3], const float vb[3], const float n[3], float friction) {
   if (friction == -1.0f) { v[0] = vb[0]; v[1] = vb[1]; v[2] = vb[2]; return; }

@@ -45,6 +45,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <immintrin.h>
+
 #include <algorithm>
 #include <cerrno>
 #include <cmath>
@@ -135,6 +137,17 @@ struct mpmhip_ctx {
   int counts_cap = 0;
   bool compact_requested = false;
   bool in_substep = false;
+  struct AsyncState {  // AsyncMPM block table (src/async/async_mpm.h:93-110), one entry per scheduler block of 4x4x8 nodes
+    bool enabled = false, limits_valid = false;
+    mpmhip_async_config cfg{};
+    int nb[3] = {0, 0, 0};
+    int64_t current_t_int = 0, min_delta_t_int = 1, max_delta_t_int = 1;
+    std::vector<int64_t> strength, cfl, continuous;  // strength_dt_limit, cfl_dt_limit, continuous_dt_limit
+    std::vector<uint32_t> count;
+    uint32_t *d_tab = nullptr, *d_blk_of = nullptr;
+    int32_t *d_blk_limits = nullptr, *d_particle_limits = nullptr;
+    int64_t blk_of_cap = 0;
+  } async;
   bool overlap = false;        // mpmhip_set_overlap: split tiled substeps into boundary / interior work
   bool ov_active = false, interior_done = false;  // state of the substep in flight
 };
@@ -389,6 +402,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   hipFree(c->key); hipFree(c->rank); hipFree(c->perm); hipFree(c->blk_flag); hipFree(c->bits); hipFree(c->wprefix);
   hipFree(c->fat_slot); hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->cell_cnt);
   hipFree(c->cell_start); hipFree(c->scan_slots); hipFree(c->ticket); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
+  hipFree(c->async.d_tab); hipFree(c->async.d_blk_of); hipFree(c->async.d_blk_limits); hipFree(c->async.d_particle_limits);
   hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_LS); hipFree(c->d_counts); hipFree(c->d_bounds); if (c->h_pinned) hipHostFree(c->h_pinned); hipFree(c->d_energy);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
@@ -1125,6 +1139,8 @@ int mpmhip_bgeo_encode(mpmhip_ctx *c, int32_t verbose, void *dst, size_t capacit
   if (int rc = bgeo_order(c, order)) return rc;
   const uint32_t n = (uint32_t)order.size();
   const size_t total = bgeo_bytes(n, verbose != 0);
+  int32_t *limits = nullptr;  // async stepping: per-slot (dt_limit, stiffness_limit, cfl_limit) of the particle's block
+  if (c->async.enabled && c->async.limits_valid) limits = c->async.d_particle_limits;
   if (total > capacity)
     return fail(c, MPMHIP_ECAPACITY, "bgeo image needs %zu bytes, the buffer holds %zu", total, capacity);
   uint8_t *out = static_cast<uint8_t *>(dst);
@@ -1141,10 +1157,10 @@ int mpmhip_bgeo_encode(mpmhip_ctx *c, int32_t verbose, void *dst, size_t capacit
       const dim3 grid(particle_grid(n)), wg(256);
       if (verbose)
         hipLaunchKernelGGL(k_bgeo_rows<true>, grid, wg, 0, c->stream, n, (const uint32_t *)d_order, (const RecG *)c->rg,
-                           (const RecP *)c->rp, (const float *)c->rb, (const GroupParams *)c->d_groups, d_rows);
+                           (const RecP *)c->rp, (const float *)c->rb, (const GroupParams *)c->d_groups, (const int32_t *)limits, d_rows);
       else
         hipLaunchKernelGGL(k_bgeo_rows<false>, grid, wg, 0, c->stream, n, (const uint32_t *)d_order, (const RecG *)c->rg,
-                           (const RecP *)c->rp, (const float *)c->rb, (const GroupParams *)c->d_groups, d_rows);
+                           (const RecP *)c->rp, (const float *)c->rb, (const GroupParams *)c->d_groups, (const int32_t *)limits, d_rows);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_rows, row_bytes, hipMemcpyDeviceToHost, c->stream);
@@ -1648,6 +1664,153 @@ int mpmhip_mpm88_download_grid(mpmhip_mpm88 *m, float *grid) {
   const int nn = m->P.n + 1;
   HIPCHK88(m, hipMemcpy(grid, m->grid, sizeof(float) * 3 * nn * nn, hipMemcpyDeviceToHost));
   return MPMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ AsyncMPM (first half)
+// Block-local time-step limits of the reference's asynchronous stepper (src/async/async_mpm.{h,cpp}): the per-block
+// reduction over the particles runs on the device, the block state machine (power-of-two limits, :112-164) on the host.
+int mpmhip_async_enable(mpmhip_ctx *c, const mpmhip_async_config *cfg) {
+  if (!c || !cfg) return MPMHIP_EINVAL;
+  if (!(cfg->unit_delta_t > 0) || cfg->max_units < 1) return fail(c, MPMHIP_EINVAL, "unit_delta_t > 0 and max_units >= 1 required");
+  HIPCHK(c, hipSetDevice(c->device));
+  auto &A = c->async;
+  A.cfg = *cfg;
+  A.nb[0] = (c->P.res[0] >> 2) + 1; A.nb[1] = (c->P.res[1] >> 2) + 1; A.nb[2] = (c->P.res[2] >> 3) + 1;
+  const size_t nblk = (size_t)A.nb[0] * A.nb[1] * A.nb[2];
+  // src/async/async_mpm.cpp:32-37: strength = cfl = 2^31, continuous = 1
+  A.strength.assign(nblk, 1ll << 31); A.cfl.assign(nblk, 1ll << 31); A.continuous.assign(nblk, 1);
+  A.count.assign(nblk, 0);
+  A.current_t_int = 0; A.min_delta_t_int = 1; A.max_delta_t_int = 1;
+  hipFree(A.d_tab); hipFree(A.d_blk_limits);
+  A.d_tab = nullptr; A.d_blk_limits = nullptr;
+  HIPCHK(c, dmalloc(&A.d_tab, 3 * nblk));
+  HIPCHK(c, dmalloc(&A.d_blk_limits, 3 * nblk));
+  A.enabled = true; A.limits_valid = false;
+  return MPMHIP_OK;
+}
+
+static inline float async_inv_sqrt(float v) {  // src/async/async_mpm.cpp:77-80: the SSE reciprocal-square-root estimate
+  return _mm_cvtss_f32(_mm_rsqrt_ss(_mm_set1_ps(v)));
+}
+
+int mpmhip_async_update_dt_limits(mpmhip_ctx *c) {  // AsyncMPM<dim>::update_dt_limits, src/async/async_mpm.cpp:90-164
+  if (!c) return MPMHIP_EINVAL;
+  auto &A = c->async;
+  if (!A.enabled) return fail(c, MPMHIP_EINVAL, "mpmhip_async_enable first");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nblk = A.strength.size();
+  if (A.blk_of_cap < c->cap) {
+    hipFree(A.d_blk_of); hipFree(A.d_particle_limits);
+    A.d_blk_of = nullptr; A.d_particle_limits = nullptr;
+    HIPCHK(c, dmalloc(&A.d_blk_of, (size_t)c->cap));
+    HIPCHK(c, dmalloc(&A.d_particle_limits, 3 * (size_t)c->cap));
+    A.blk_of_cap = c->cap;
+  }
+  // (min allowed dt, max |v|^2, count) per block: min starts at the bits of 0.1f (":104 min_allowed_dt = 0.1"), max at 1e-16f
+  std::vector<uint32_t> init(3 * nblk);
+  const float f01 = 0.1f, fv = 1e-16f;
+  uint32_t b01, bv;
+  memcpy(&b01, &f01, 4); memcpy(&bv, &fv, 4);
+  for (size_t b = 0; b < nblk; b++) { init[3 * b] = b01; init[3 * b + 1] = bv; init[3 * b + 2] = 0; }
+  HIPCHK(c, hipMemcpyAsync(A.d_tab, init.data(), sizeof(uint32_t) * 3 * nblk, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_async_block_reduce, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, (const RecG *)c->rg,
+                     (const RecP *)c->rp, (const GroupParams *)c->d_groups, A.nb[0], A.nb[1], A.nb[2], A.d_tab, A.d_blk_of);
+  if (int rc = launch_check(c, "async_block_reduce")) return rc;
+  std::vector<uint32_t> tab(3 * nblk);
+  HIPCHK(c, hipMemcpyAsync(tab.data(), A.d_tab, sizeof(uint32_t) * 3 * nblk, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const float inv_unit = 1.0f / A.cfg.unit_delta_t;
+  const int64_t t = A.current_t_int;
+  // non-empty blocks (:93-134)
+  for (size_t b = 0; b < nblk; b++) {
+    A.count[b] = tab[3 * b + 2];
+    if (!A.count[b] || (t & (A.continuous[b] - 1)) != 0) continue;
+    float min_dt, max_v2;
+    memcpy(&min_dt, &tab[3 * b], 4); memcpy(&max_v2, &tab[3 * b + 1], 4);
+    A.strength[b] = (int64_t)(A.cfg.strength_dt_mul * min_dt * inv_unit);
+    A.cfl[b] = (int64_t)(A.cfg.cfl_dt_mul * c->P.dx * inv_unit * async_inv_sqrt(max_v2));
+    const int64_t tmp = std::min(std::min(A.cfl[b], A.strength[b]), (int64_t)A.cfg.max_units);
+    if (tmp < 1)
+      return fail(c, MPMHIP_EINVAL, "async stepping: a block's allowed time step is below unit_delta_t (particle types without a "
+                                    "sound-speed bound, e.g. linear / jelly, return 0: the reference stops here too, src/async/async_mpm.cpp:118-125)");
+    int64_t &limit = A.continuous[b];
+    while (tmp < limit) limit >>= 1;
+    while (tmp >= (limit << 1) && (t & ((limit << 1) - 1)) == 0) limit <<= 1;
+  }
+  auto boundary = [&](bool non_empty) {  // update_dt_limit_boundary, src/async/async_mpm.h:178-189
+    A.min_delta_t_int = 1ll << 31; A.max_delta_t_int = 1;
+    for (size_t b = 0; b < nblk; b++) {
+      if (non_empty && !A.count[b]) continue;
+      A.min_delta_t_int = std::min(A.min_delta_t_int, A.continuous[b]);
+      A.max_delta_t_int = std::max(A.max_delta_t_int, A.continuous[b]);
+    }
+  };
+  boundary(true);
+  for (size_t b = 0; b < nblk; b++) {  // empty blocks follow the largest step in use (:137-152)
+    if (A.count[b] || (t & (A.continuous[b] - 1)) != 0) continue;
+    int64_t &limit = A.continuous[b];
+    while (A.max_delta_t_int < limit) limit >>= 1;
+    while (A.max_delta_t_int >= (limit << 1) && (t & ((limit << 1) - 1)) == 0) limit <<= 1;
+  }
+  boundary(false);
+  // what the frame output shows per particle (src/async/async_visualize.cpp:17-26)
+  std::vector<int32_t> lim(3 * nblk);
+  for (size_t b = 0; b < nblk; b++) { lim[3 * b] = (int32_t)A.continuous[b]; lim[3 * b + 1] = (int32_t)A.strength[b]; lim[3 * b + 2] = (int32_t)A.cfl[b]; }
+  HIPCHK(c, hipMemcpy(A.d_blk_limits, lim.data(), sizeof(int32_t) * 3 * nblk, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_async_particle_limits, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P,
+                     (const uint32_t *)A.d_blk_of, (const int32_t *)A.d_blk_limits, A.d_particle_limits);
+  if (int rc = launch_check(c, "async_particle_limits")) return rc;
+  A.limits_valid = true;
+  return MPMHIP_OK;
+}
+
+// non-empty scheduler blocks: corner node (3 ints), strength / cfl / continuous limits, particle count.  Returns the number.
+int64_t mpmhip_async_blocks(mpmhip_ctx *c, int64_t capacity, int32_t *coord, int64_t *strength, int64_t *cfl, int64_t *continuous,
+                            int64_t *count, int64_t min_max[2]) {
+  if (!c || !c->async.enabled) return MPMHIP_EINVAL;
+  auto &A = c->async;
+  int64_t n = 0;
+  for (int bx = 0; bx < A.nb[0]; bx++)
+    for (int by = 0; by < A.nb[1]; by++)
+      for (int bz = 0; bz < A.nb[2]; bz++) {
+        const size_t b = ((size_t)bx * A.nb[1] + by) * A.nb[2] + bz;
+        if (!A.count[b]) continue;
+        if (n >= capacity) return fail(c, MPMHIP_ECAPACITY, "block buffer too small");
+        if (coord) { coord[3 * n] = bx * 4; coord[3 * n + 1] = by * 4; coord[3 * n + 2] = bz * 8; }
+        if (strength) strength[n] = A.strength[b];
+        if (cfl) cfl[n] = A.cfl[b];
+        if (continuous) continuous[n] = A.continuous[b];
+        if (count) count[n] = A.count[b];
+        n++;
+      }
+  if (min_max) { min_max[0] = A.min_delta_t_int; min_max[1] = A.max_delta_t_int; }
+  return n;
+}
+
+int mpmhip_async_set_time_int(mpmhip_ctx *c, int64_t t_int) {
+  if (!c || !c->async.enabled || t_int < 0) return MPMHIP_EINVAL;
+  c->async.current_t_int = t_int;
+  return MPMHIP_OK;
+}
+
+int mpmhip_debug_allowed_dt(mpmhip_ctx *c, int32_t material, const float params[MPMHIP_NPARAM], int64_t n, const float *F,
+                            const float *aux, const float *v, float dx, float *out) {
+  if (!c || n <= 0) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  GroupParams g;
+  if (material < MPMHIP_VISCO || material > MPMHIP_ELASTIC) return fail(c, MPMHIP_EINVAL, "unknown material id %d", material);
+  memset(&g, 0, sizeof g);
+  memcpy(g.p, params, sizeof g.p);
+  g.type = material;
+  float *dF, *dA, *dV, *dO;
+  HIPCHK(c, dmalloc(&dF, 9 * n)); HIPCHK(c, dmalloc(&dA, n)); HIPCHK(c, dmalloc(&dV, 3 * n)); HIPCHK(c, dmalloc(&dO, n));
+  HIPCHK(c, hipMemcpy(dF, F, sizeof(float) * 9 * n, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(dA, aux, sizeof(float) * n, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(dV, v, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
+  int rc = run_debug(c, k_debug_allowed_dt, g, n, (const float *)dF, (const float *)dA, (const float *)dV, dx, dO);
+  if (!rc) HIPCHK(c, hipMemcpy(out, dO, sizeof(float) * n, hipMemcpyDeviceToHost));
+  hipFree(dF); hipFree(dA); hipFree(dV); hipFree(dO);
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------ MPM<2>

@@ -438,6 +438,29 @@ class Simulation3D:
             self._check(self._L.mpmhip_profile_reset(self._ctx))
         return out
 
+    # ---------------------------------------------------------------- async limits (AsyncMPM, first half)
+    def enable_async(self, unit_delta_t=1e-6, max_units=8192, cfl_dt_mul=1.0, strength_dt_mul=1.0):
+        """config keys of AsyncMPM<dim>::initialize (src/async/async_mpm.cpp:24-27).  Builds the scheduler-block table; the
+        stepping itself (AsyncMPM::advance) is not part of this build — see include/mpmhip.h."""
+        self._ensure_ctx()
+        a = _lib.AsyncConfig(float(unit_delta_t), int(max_units), float(cfl_dt_mul), float(strength_dt_mul))
+        self._check(self._L.mpmhip_async_enable(self._ctx, C.byref(a)))
+
+    def update_dt_limits(self):
+        """AsyncMPM<dim>::update_dt_limits (src/async/async_mpm.cpp:90-164): per-block strength / CFL / power-of-two limits"""
+        self._check(self._L.mpmhip_async_update_dt_limits(self._ctx))
+
+    def async_blocks(self):
+        """(dict(coord, strength, cfl, continuous, count) of the non-empty scheduler blocks, (min_delta_t_int, max_delta_t_int))"""
+        cap = 1 << 20
+        coord = np.zeros((cap, 3), np.int32)
+        arrs = [np.zeros(cap, np.int64) for _ in range(4)]
+        mm = np.zeros(2, np.int64)
+        lp, ip = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+        n = self._check(self._L.mpmhip_async_blocks(self._ctx, cap, coord.ctypes.data_as(ip), *(a.ctypes.data_as(lp) for a in arrs),
+                                                    mm.ctypes.data_as(lp)))
+        return dict(coord=coord[:n], strength=arrs[0][:n], cfl=arrs[1][:n], continuous=arrs[2][:n], count=arrs[3][:n]), tuple(int(v) for v in mm)
+
     # ---------------------------------------------------------------- misc surface
     def general_action(self, config):
         """MPM<dim>::general_action, src/mpm.cpp:920-978."""

@@ -202,7 +202,20 @@ static void gpu_tests() {
   CHECK(std::fabs(p.dg_e[0] - 1.01f) < 1e-6f && std::fabs(p.dg_e[8] - 0.99f) < 1e-6f);
   const Matrix3 f1 = p.calculate_force(sim->ctx());
   CHECK(f1[0] < 0 && f1[8] > 0);  // -vol P F^T: stretched axis pulls back, compressed axis pushes
-  CHECK(p.get_allowed_dt(1.0f / 64) > 0);
+  CHECK(p.get_allowed_dt(1.0f / 64) == 0.0f);  // JellyParticle::get_allowed_dt returns 0 (src/particles.cpp:418-420)
+  // per-material get_allowed_dt: the host expression equals what the device evaluates (mpmhip_debug_allowed_dt)
+  for (const char *name : {"sand", "snow", "water", "elastic", "von_mises", "visco"}) {
+    MPMParticle q;
+    q.type = create_particle_type(name, Config(), 400.0f * 1e-6f, 1e-6f);
+    q.aux = q.type.initial_aux;
+    q.dg_e = Matrix3{{1.02f, 0.01f, 0, -0.01f, 0.98f, 0.02f, 0, 0.01f, 1.01f}};
+    q.v = Vector3(0.3f, -0.2f, 0.1f);
+    const float host = q.get_allowed_dt(1.0f / 64);
+    float dev = 0;
+    const int rc = mpmhip_debug_allowed_dt(sim->ctx(), q.type.material, q.type.params, 1, q.dg_e.data(), &q.aux, q.v.data(), 1.0f / 64, &dev);
+    CHECK(rc == 0);
+    CHECK(host > 0 && std::fabs(host - dev) <= 2e-5f * host);
+  }
 }
 
 int main(int argc, char **argv) {
