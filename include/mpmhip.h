@@ -289,7 +289,8 @@ int mpmhip_request_compaction(mpmhip_ctx *ctx);  /* physical reorder + drop of d
  * tracks min(cfl, strength, max_units) under the reference's halving / doubling rule.  The per-block reduction runs on
  * the device, the block state machine on the host.  After mpmhip_async_update_dt_limits the `limit` attribute of
  * mpmhip_write_bgeo carries (continuous, strength, cfl) of each particle's block instead of (1, 1, 1).
- * NOT built: the stepping itself (AsyncMPM<dim>::advance / step: block subsets advancing with their own dt). */
+ * The stepping itself (AsyncMPM<dim>::advance / step: block subsets advancing with their own dt, backup pools as frozen
+ * neighbours) is host orchestration around substeps of gathered working sets, like the reference's: taichi_mpm_amd/async_mpm.py. */
 typedef struct {
   float unit_delta_t;     /* config "unit_delta_t", default 1e-6 (src/async/async_mpm.cpp:24) */
   int64_t max_units;      /* "max_units", default 8192 */
@@ -301,6 +302,16 @@ int mpmhip_async_update_dt_limits(mpmhip_ctx *ctx);
 int64_t mpmhip_async_blocks(mpmhip_ctx *ctx, int64_t capacity, int32_t *corner_node /* [n][3] */, int64_t *strength,
                             int64_t *cfl, int64_t *continuous, int64_t *count, int64_t min_max_delta_t_int[2]);
 int mpmhip_async_set_time_int(mpmhip_ctx *ctx, int64_t current_t_int);
+/* dense block table: nb[3] = blocks per axis, block b = (bx nb[1] + by) nb[2] + bz; returns the number of blocks (with
+ * capacity < that number nothing is written: size query) */
+int64_t mpmhip_async_table(mpmhip_ctx *ctx, int32_t nb[3], int64_t capacity, int64_t *strength, int64_t *cfl,
+                           int64_t *continuous, int64_t *count);
+/* working-set plumbing of the asynchronous stepper (taichi_mpm_amd/async_mpm.py): drop all particles but keep groups /
+ * level set / config; change base_delta_t (the P2G matrices are rebuilt) and the clock — AsyncMPM<dim>::advance / step set
+ * both before every MPM<dim>::substep (src/async/async_mpm.cpp:405-408) */
+int mpmhip_clear_particles(mpmhip_ctx *ctx);
+int mpmhip_set_dt(mpmhip_ctx *ctx, float base_delta_t);
+int mpmhip_set_time(mpmhip_ctx *ctx, double current_t);
 /* MPMParticle::get_allowed_dt(dx) of n particle states of one material (src/particles.cpp:136-155,254-278,480-490,...) */
 int mpmhip_debug_allowed_dt(mpmhip_ctx *ctx, int32_t material, const float params[MPMHIP_NPARAM], int64_t n, const float *F,
                             const float *aux, const float *v, float dx, float *out);

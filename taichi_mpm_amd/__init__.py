@@ -7,9 +7,9 @@ classes without the built library, or creating a simulation without a GPU, fails
 """
 from ._lib import build, lib_path, load  # noqa: F401
 from .materials import MATERIAL_IDS, group_params, initial_aux  # noqa: F401
-from .mpm import MPM, MPMError, Simulation3D, create_simulation2, create_simulation3  # noqa: F401
+from .mpm import MPM, AsyncMPM, MPMError, Simulation3D, create_simulation2, create_simulation3  # noqa: F401
 from .mpm2d import Simulation2D  # noqa: F401
 from .mpm88 import MPM88  # noqa: F401
 
-__all__ = ["MPM", "MPM88", "MPMError", "Simulation2D", "Simulation3D", "create_simulation2", "create_simulation3", "build", "load", "lib_path",
+__all__ = ["MPM", "AsyncMPM", "MPM88", "MPMError", "Simulation2D", "Simulation3D", "create_simulation2", "create_simulation3", "build", "load", "lib_path",
            "group_params", "initial_aux", "MATERIAL_IDS"]

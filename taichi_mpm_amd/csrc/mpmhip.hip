@@ -580,6 +580,35 @@ int mpmhip_add_particles(mpmhip_ctx *c, int32_t group, int64_t n, const float *x
   return invalidate_keys(c);
 }
 
+// drop every particle (groups, level set and configuration stay): the asynchronous stepper reloads the working set of
+// every advance (AsyncMPM<dim>::advance gathers block pools into `particles`, src/async/async_mpm.cpp:255-318)
+int mpmhip_clear_particles(mpmhip_ctx *c) {
+  if (!c) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->in_substep) return fail(c, MPMHIP_EINVAL, "clear_particles inside a substep");
+  c->n_slots = 0; c->P.n_slots = 0; c->next_pid = 0;
+  c->affine_valid = false; c->b_stale = false;
+  const uint32_t zero = 0;
+  HIPCHK(c, hipMemcpy(&c->cnt->n_dead, &zero, sizeof zero, hipMemcpyHostToDevice));
+  c->keys_valid = true;  // force the flag array to be cleared
+  return invalidate_keys(c);
+}
+// base_delta_t / current_t of the next substeps (AsyncMPM<dim>::step sets both per advance, src/async/async_mpm.cpp:405-408)
+int mpmhip_set_dt(mpmhip_ctx *c, float dt) {
+  if (!c || !(dt >= 0)) return MPMHIP_EINVAL;
+  if (c->in_substep) return fail(c, MPMHIP_EINVAL, "set_dt inside a substep");
+  if (int rc = ensure_b_current(c)) return rc;  // the stored P2G matrices carry the old dt: they are rebuilt from apic_b
+  c->P.dt = dt;
+  c->affine_valid = false;
+  return MPMHIP_OK;
+}
+int mpmhip_set_time(mpmhip_ctx *c, double t) {
+  if (!c) return MPMHIP_EINVAL;
+  c->t = (float)t; c->request_t = (float)t;
+  return MPMHIP_OK;
+}
+
 int64_t mpmhip_num_particles(mpmhip_ctx *c) {
   if (!c) return MPMHIP_EINVAL;
   if (hipSetDevice(c->device) != hipSuccess) return MPMHIP_EHIP;
@@ -1784,6 +1813,23 @@ int64_t mpmhip_async_blocks(mpmhip_ctx *c, int64_t capacity, int32_t *coord, int
         n++;
       }
   if (min_max) { min_max[0] = A.min_delta_t_int; min_max[1] = A.max_delta_t_int; }
+  return n;
+}
+
+// dense view of the block table: nb[3] blocks per axis (block b = (bx nb[1] + by) nb[2] + bz), limits of EVERY block
+int64_t mpmhip_async_table(mpmhip_ctx *c, int32_t nb[3], int64_t capacity, int64_t *strength, int64_t *cfl, int64_t *continuous,
+                           int64_t *count) {
+  if (!c || !c->async.enabled || !nb) return MPMHIP_EINVAL;
+  auto &A = c->async;
+  for (int k = 0; k < 3; k++) nb[k] = A.nb[k];
+  const int64_t n = (int64_t)A.continuous.size();
+  if (capacity < n) return n;  // (query of the size)
+  for (int64_t b = 0; b < n; b++) {
+    if (strength) strength[b] = A.strength[b];
+    if (cfl) cfl[b] = A.cfl[b];
+    if (continuous) continuous[b] = A.continuous[b];
+    if (count) count[b] = A.count[b];
+  }
   return n;
 }
 

@@ -576,8 +576,11 @@ def create_simulation2(name):
 def create_simulation3(name):
     """tc_core.create_simulation3 (scripts/async/async_mpm.py:25-32); only 'mpm' is registered here
     (TC_IMPLEMENTATION(Simulation3D, MPM3D, "mpm"), src/mpm.cpp:986-988)."""
+    if name == "async_mpm":  # TC_IMPLEMENTATION(Simulation3D, AsyncMPM3D, "async_mpm"), src/async/async_mpm.cpp:423-427
+        from .async_mpm import AsyncSimulation3D
+        return AsyncSimulation3D()
     if name != "mpm":
-        raise MPMError("no Simulation3D implementation named %r (registered: 'mpm')" % (name,))
+        raise MPMError("no Simulation3D implementation named %r (registered: 'mpm', 'async_mpm')" % (name,))
     return Simulation3D()
 
 
@@ -595,6 +598,7 @@ def lattice_cube(lower, higher, dx):
 class MPM:
     """Scene-script driver: `tc.dynamics.MPM(**kwargs)` shape (scripts/benchmark/benchmark_3d.py:9-27;
     in-tree twin: AsyncMPM, scripts/async/async_mpm.py:17-300)."""
+    simulation_name = "mpm"
 
     def __init__(self, **kwargs):
         res = kwargs["res"]
@@ -603,7 +607,9 @@ class MPM:
         self.num_frames = kwargs.get("num_frames", 1000)
         if len(res) not in (2, 3):
             raise MPMError("res must have 2 or 3 entries")
-        self.c = create_simulation3("mpm") if len(res) == 3 else create_simulation2("mpm")  # async_mpm.py:25-32
+        if len(res) == 2 and self.simulation_name != "mpm":
+            raise MPMError("create_simulation2(%r) is not part of this build" % self.simulation_name)
+        self.c = create_simulation3(self.simulation_name) if len(res) == 3 else create_simulation2("mpm")  # async_mpm.py:25-32
         if "delta_x" not in kwargs:
             kwargs["delta_x"] = 1.0 / res[0]  # async_mpm.py:40-41
         self.c.initialize(kwargs)
@@ -662,3 +668,9 @@ class MPM:
                 self.visualize()
             if print_profile_info:
                 print(json.dumps(self.c.profile(reset=True)))
+
+
+class AsyncMPM(MPM):
+    """scripts/async/async_mpm.py:17-300 `AsyncMPM(**kwargs)`: the same driver over create_simulation3('async_mpm')
+    (block-local time steps; config keys unit_delta_t, max_units, cfl_dt_mul, strength_dt_mul)"""
+    simulation_name = "async_mpm"

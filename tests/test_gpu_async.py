@@ -90,3 +90,37 @@ def test_block_dt_limits_match_the_reference_async_stepper_on_a_two_stiffness_sc
     assert np.array_equal(lim[:, 0], d["limits"][:, 0])
     assert np.abs(lim[:, 1] - d["limits"][:, 1]).max() <= 1 and np.allclose(lim[:, 2], d["limits"][:, 2], rtol=1e-5, atol=1)
     sim.close(); r.close()
+
+
+def test_async_stepping_matches_the_reference_async_stepper(tm):
+    """create_simulation3('async_mpm').step(dt): blocks advancing with their own power-of-two multiples of unit_delta_t
+    (AsyncMPM<dim>::step / advance, src/async/async_mpm.cpp:255-421) against the reference's own stepper on the
+    two-stiffness scene: same pools (every container of every block, at its block's time), same number of particle
+    updates, particle states to fp32 tolerance"""
+    from oracle import refmpm as ref
+    if not ref.available():
+        pytest.skip("oracle/_ref/libmpm_ref.so did not travel to this box")
+    ref.set_threads(1)
+    res, dx, sa, sb = _two_stiffness_scene()
+    kw = dict(unit_delta_t=2e-6, max_units=1024)  # sand blocks step with 256 units, the soft elastic ones with 1024
+    r = ref.AsyncSim(res, dx, shapes=[(0, 0, 0, 1, 0, -0.2)], friction=0.4, **kw)
+    sim = tm.create_simulation3("async_mpm").initialize(dict(res=(res,) * 3, delta_x=dx, **kw))
+    sim.set_levelset(tm.mpm.LevelSet(friction=0.4).add_plane((0, 1, 0), d=-0.2))
+    for s, mat in ((sa, "elastic"), (sb, "sand")):
+        r.add_particles(mat, s.gparams[0][0], s.gparams[0][1], s.x, s.v, s.F, s.B, s.aux)
+        sim.add_particles(dict(type=mat, positions=s.x, velocities=s.v, F=s.F, B=s.B, aux=s.aux, params=s.gparams[0]))
+    for _ in range(2):
+        r.step(2.5e-3)
+        sim.step(2.5e-3)
+    assert sim.current_t_int == r.time_int()
+    assert sim.update_counter == r.update_counter()
+    a, b = sim.get_pool_particles(), r.download()
+    assert np.array_equal(a["id"], b["id"])
+    assert len(np.unique(b["limits"][:, 0])) >= 2, "the scene must step with at least two block step sizes"
+    assert np.array_equal(a["continuous"], b["limits"][:, 0]) and np.array_equal(a["particle_t"], b["limits"][:, 3])
+    from tests.common import rel_l2
+    assert np.abs(a["x"] - b["x"]).max() <= 1e-6
+    # the stiff blocks have taken 12 substeps, their frozen neighbours were re-advanced as often: rounding differences have
+    # had a dozen stiff steps to grow (the synchronous multi-step tests allow 1e-3 after 5)
+    assert rel_l2(a["v"], b["v"]) <= 5e-4 and rel_l2(a["F"], b["F"]) <= 1e-4
+    sim.close(); r.close()
