@@ -312,6 +312,10 @@ int64_t mpmhip_async_table(mpmhip_ctx *ctx, int32_t nb[3], int64_t capacity, int
 int mpmhip_clear_particles(mpmhip_ctx *ctx);
 int mpmhip_set_dt(mpmhip_ctx *ctx, float base_delta_t);
 int mpmhip_set_time(mpmhip_ctx *ctx, double current_t);
+/* the three clocks of a ctx — current_t, the request_t accumulator of step() (src/mpm.cpp:428-439), the substep counter
+ * that phases the physical reorder (src/mpm.cpp:811-813): read / restored by a host layer that re-creates a ctx */
+int mpmhip_get_clock(const mpmhip_ctx *ctx, double *current_t, double *request_t, int64_t *substeps);
+int mpmhip_set_clock(mpmhip_ctx *ctx, double current_t, double request_t, int64_t substeps);
 /* MPMParticle::get_allowed_dt(dx) of n particle states of one material (src/particles.cpp:136-155,254-278,480-490,...) */
 int mpmhip_debug_allowed_dt(mpmhip_ctx *ctx, int32_t material, const float params[MPMHIP_NPARAM], int64_t n, const float *F,
                             const float *aux, const float *v, float dx, float *out);

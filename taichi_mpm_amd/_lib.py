@@ -107,7 +107,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_las
             "mpmhip_substep_begin", "mpmhip_substep_end", "mpmhip_substep_interior", "mpmhip_set_overlap", "mpmhip_leaver_counts", "mpmhip_migration_scan", "mpmhip_export_leavers",
             "mpmhip_import_particles", "mpmhip_active_bounds", "mpmhip_num_slots", "mpmhip_request_compaction", "mpmhip_mpm88_create", "mpmhip_mpm88_destroy", "mpmhip_mpm88_last_error", "mpmhip_mpm88_add",
             "mpmhip_mpm88_num_particles", "mpmhip_mpm88_advance", "mpmhip_mpm88_download", "mpmhip_mpm88_download_grid",
-            "mpmhip_async_enable", "mpmhip_async_update_dt_limits", "mpmhip_async_blocks", "mpmhip_async_set_time_int", "mpmhip_async_table", "mpmhip_clear_particles", "mpmhip_set_dt", "mpmhip_set_time", "mpmhip_debug_allowed_dt",
+            "mpmhip_async_enable", "mpmhip_async_update_dt_limits", "mpmhip_async_blocks", "mpmhip_async_set_time_int", "mpmhip_async_table", "mpmhip_clear_particles", "mpmhip_set_dt", "mpmhip_set_time", "mpmhip_get_clock", "mpmhip_set_clock", "mpmhip_debug_allowed_dt",
             "mpmhip2d_create", "mpmhip2d_destroy", "mpmhip2d_last_error", "mpmhip2d_set_levelset", "mpmhip2d_add_group", "mpmhip2d_add_particles",
             "mpmhip2d_substep", "mpmhip2d_step", "mpmhip2d_current_time", "mpmhip2d_num_particles", "mpmhip2d_download", "mpmhip2d_download_grid",
             "mpmhip_debug_copy_bandwidth", "mpmhip_debug_gather_bandwidth", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
@@ -209,6 +209,8 @@ def load():
     L.mpmhip_clear_particles.argtypes = [vp]
     L.mpmhip_set_dt.argtypes = [vp, C.c_float]
     L.mpmhip_set_time.argtypes = [vp, C.c_double]
+    L.mpmhip_get_clock.argtypes = [vp, P(C.c_double), P(C.c_double), lp]
+    L.mpmhip_set_clock.argtypes = [vp, C.c_double, C.c_double, C.c_int64]
     L.mpmhip_debug_allowed_dt.argtypes = [vp, C.c_int32, fp, C.c_int64, fp, fp, fp, C.c_float, fp]
     L.mpmhip2d_create.argtypes = [P(Config2D), P(vp)]
     L.mpmhip2d_destroy.argtypes = [vp]

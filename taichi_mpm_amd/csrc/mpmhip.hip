@@ -608,6 +608,20 @@ int mpmhip_set_time(mpmhip_ctx *c, double t) {
   c->t = (float)t; c->request_t = (float)t;
   return MPMHIP_OK;
 }
+// the three clocks of a ctx (current_t, the request_t accumulator of step(), the substep counter that phases the physical
+// reorder): read / restored when a host layer re-creates a ctx (e.g. to grow it) so that the run continues unchanged
+int mpmhip_get_clock(const mpmhip_ctx *c, double *t, double *request_t, int64_t *substeps) {
+  if (!c) return MPMHIP_EINVAL;
+  if (t) *t = c->t;
+  if (request_t) *request_t = c->request_t;
+  if (substeps) *substeps = c->substeps;
+  return MPMHIP_OK;
+}
+int mpmhip_set_clock(mpmhip_ctx *c, double t, double request_t, int64_t substeps) {
+  if (!c || substeps < 0) return MPMHIP_EINVAL;
+  c->t = (float)t; c->request_t = (float)request_t; c->substeps = substeps;
+  return MPMHIP_OK;
+}
 
 int64_t mpmhip_num_particles(mpmhip_ctx *c) {
   if (!c) return MPMHIP_EINVAL;

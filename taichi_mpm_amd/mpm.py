@@ -198,8 +198,13 @@ class Simulation3D:
                 self._upload_new(gi, *arrs)
             self._staged = []
         elif need > self._capacity:
+            if getattr(self, "_pinned_by", None):
+                # a tiled engine holds this ctx (pointer, partition, halo buffers, stream): growing would re-create it
+                raise MPMError("cannot grow a ctx that is driven by %s: pass max_particles to initialize()" % self._pinned_by)
             state = self.get_particles()
-            t, frame = self.get_current_time(), self.frame
+            frame = self.frame
+            t, rt, ns = C.c_double(), C.c_double(), C.c_int64()
+            self._check(self._L.mpmhip_get_clock(self._ctx, C.byref(t), C.byref(rt), C.byref(ns)))
             self._L.mpmhip_destroy(self._ctx)
             self._ctx = None
             self._create(max(int(need * 1.25), self.max_particles))
@@ -212,7 +217,11 @@ class Simulation3D:
             ids = np.ascontiguousarray(state["id"], np.int32)  # keep creation ids across the re-allocation
             if len(ids):
                 self._check(self._L.mpmhip_upload(self._ctx, F_ID, ids.ctypes.data_as(C.c_void_p), len(ids)))
-            self._time_offset = getattr(self, "_time_offset", 0.0) + t
+            # the run continues where it was: current_t, the residual of step()'s request_t, the phase of the physical
+            # reorder, and the stream the caller had installed
+            self._check(self._L.mpmhip_set_clock(self._ctx, t.value, rt.value, ns.value))
+            if getattr(self, "_stream", None):
+                self._check(self._L.mpmhip_set_stream(self._ctx, C.c_void_p(self._stream)))
             self.frame = frame
 
     def __del__(self):
@@ -381,6 +390,7 @@ class Simulation3D:
     def set_stream(self, hip_stream):
         """run the ctx on an existing hipStream_t (int handle; 0/None = the ctx's own stream)"""
         self._ensure_ctx()
+        self._stream = hip_stream or None
         self._check(self._L.mpmhip_set_stream(self._ctx, C.c_void_p(hip_stream or None)))
 
     def get_current_time(self):

@@ -798,3 +798,28 @@ def test_column_collapse_stays_sane_for_400_substeps(tm, mat):
     assert np.abs(p["v"]).max() < 20.0
     assert p["x"][:, 1].mean() < y0 - 1e-3
     sim.close()
+
+
+def test_growing_the_ctx_keeps_clocks_and_results(tm, orc):
+    """adding particles beyond the capacity re-creates the ctx: current_t, the residual of step()'s request_t and the
+    particle state carry over, so the run equals one that had the capacity from the start"""
+    xa = lattice_cube(RES, 9, 13, DX, jitter=0.2, seed=91)
+    xb = lattice_cube(RES, 14, 18, DX, jitter=0.2, seed=92)
+    sa, sb = make_state(xa, "jelly", DX, seed=93), make_state(xb, "sand", DX, seed=94)
+
+    def run(cap):
+        sim = tm.create_simulation3("mpm").initialize(dict(res=(RES,) * 3, delta_x=DX, base_delta_t=DT, max_particles=cap, keep_apic_b=True))
+        sim.add_particles(dict(type="jelly", positions=sa.x, velocities=sa.v, F=sa.F, B=sa.B, aux=sa.aux, params=sa.gparams[0]))
+        sim.step(3.5 * DT)  # 3 substeps, residual 0.5 dt stays in request_t
+        sim.add_particles(dict(type="sand", positions=sb.x, velocities=sb.v, F=sb.F, B=sb.B, aux=sb.aux, params=sb.gparams[0]))
+        sim.step(1.6 * DT)  # request_t = 5.1 dt -> two more substeps
+        out = sim.get_particles()
+        t = sim.get_current_time()
+        sim.close()
+        return out, t
+    small, t_small = run(sa.n + 8)      # must grow at the second add_particles
+    big, t_big = run(sa.n + sb.n + 64)  # never grows
+    assert np.isclose(t_small, 5 * DT, rtol=1e-6) and t_small == t_big
+    assert np.array_equal(small["id"], big["id"]) and np.array_equal(small["gid"], big["gid"])
+    assert np.abs(small["x"] - big["x"]).max() <= 1e-7 and rel_l2(small["v"], big["v"]) <= 1e-5
+    assert rel_l2(small["F"], big["F"]) <= 1e-5
