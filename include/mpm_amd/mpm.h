@@ -10,6 +10,7 @@
 // std::runtime_error with the library's message (reference: TC_ASSERT / TC_ERROR abort).
 // Out of scope, as in DESIGN.md §7: rigid bodies, textures/meshes in add_particles, dynamic level sets, rendering.
 #pragma once
+#include <algorithm>
 #include <cstdio>
 #include <memory>
 #include <stdexcept>
@@ -177,6 +178,8 @@ class MPM<3> {
       out[i].velocity = Vector(v[3 * i], v[3 * i + 1], v[3 * i + 2]);
       out[i].id = id[i];
     }
+    // slots are the order of the last sort, not a stable handle: a particle is identified by its creation id
+    std::sort(out.begin(), out.end(), [](const RenderParticle &a, const RenderParticle &b) { return a.id < b.id; });
     return out;
   }
 

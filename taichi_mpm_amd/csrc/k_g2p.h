@@ -9,10 +9,16 @@ namespace mpm {
 // resample_optimized / block_op_normal (src/transfer.cpp:837-954), one workgroup per active block, one
 // particle per lane through the sorted index.  Also produces, for the NEXT substep: the affine matrix A of
 // P2G (stress of the updated F from the same eigen-solve as the plasticity) and the sort key of the new position.
+// The updated records are written to the OTHER record buffers at the particle's SORTED POSITION (the host swaps the
+// buffers behind the launch): every substep leaves the records in the order of its own sort, i.e. one substep stale —
+// the physical reorder of the reference's sort_allocator (src/mpm.cpp:752-768) for free, every substep instead of every
+// reorder_interval, with fully sequential record stores; particles deleted by an earlier substep drop out, so the live
+// records always occupy the slots [0, n_sorted).
 constexpr int G2P_LDS_GROUPS = MPMHIP_MAX_GROUPS;  // the ctx's group capacity: the whole table is mirrored in LDS (5 KiB)
 template <int NT, int MINW, bool ROLL, bool STORE_B>
-__global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__ rg, float4 *__restrict__ rp,
-                                                  float4 *__restrict__ rb, const Counters *__restrict__ cnt,
+__global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__restrict__ rg, float4 *__restrict__ rg_out,
+                                                  float4 *__restrict__ rp_out, float4 *__restrict__ rb_out,
+                                                  const Counters *__restrict__ cnt,
                                                   const uint32_t *__restrict__ act_blk,
                                                   const uint32_t *__restrict__ act_start,
                                                   const uint32_t *__restrict__ perm,
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
         pid = -1;
         atomicAdd(&cnt_w->n_dead, 1u);
       }
-      key[i] = kk;
+      key[cur.p + tid] = kk;
       G0 = make_float4(nx0, nx1, nx2, aux);
       G1 = make_float4(F.m[0], F.m[1], F.m[2], F.m[3]);
       G2 = make_float4(F.m[4], F.m[5], F.m[6], F.m[7]);
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
         B1 = make_float4(b.m[4], b.m[5], b.m[6], b.m[7]);
         B2 = make_float4(b.m[8], 0.0f, 0.0f, 0.0f);
       }
-      out_slot = (P.ablate & 1) ? INVALID : i_cur;
+      out_slot = (P.ablate & 1) ? INVALID : cur.p + tid;
     };
     // Group parameters are read at use (keeps ~20 VGPRs free) from the workgroup's LDS copy of the table: DS reads
     // wait on lgkmcnt, whereas vector loads in the middle of the arithmetic wait on vmcnt and with it on the
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
       const int src = 16 * k + (lane >> 2), q = lane & 3;
       const uint32_t sl = xs[src];
       const float4 val = xp[src * 5 + q];
-      if (sl != INVALID) st_rec(rg + (size_t)sl * 4 + q, val, nt_store);
+      if (sl != INVALID) st_rec(rg_out + (size_t)sl * 4 + q, val, nt_store);
     }
     __builtin_amdgcn_wave_barrier();
     xp[lane * 5 + 0] = Q0; xp[lane * 5 + 1] = Q1; xp[lane * 5 + 2] = Q2; xp[lane * 5 + 3] = Q3;
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
       const int src = 16 * k + (lane >> 2), q = lane & 3;
       const uint32_t sl = xs[src];
       const float4 val = xp[src * 5 + q];
-      if (sl != INVALID) st_rec(rp + (size_t)sl * 4 + q, val, nt_store);
+      if (sl != INVALID) st_rec(rp_out + (size_t)sl * 4 + q, val, nt_store);
     }
     if constexpr (STORE_B) {  // (compile-time: in the default folded mode the apic_b registers do not exist)
       __builtin_amdgcn_wave_barrier();
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
         const int e = 64 * k + lane, src = e / 3, q = e - 3 * src;
         const uint32_t sl = xs[src];
         const float4 val = xp[src * 5 + q];
-        if (sl != INVALID) rb[(size_t)sl * 3 + q] = val;
+        if (sl != INVALID) rb_out[(size_t)sl * 3 + q] = val;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -277,6 +283,11 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, float4 *__restrict__
     cur = nx; nx = nn;
     i_cur = i_nx; i_nx = i_nn;
     g0 = n0; g1 = n1; g2 = n2; g3 = n3;
+  }
+  // slots behind the live range (particles deleted by earlier substeps have dropped out): dead for every consumer
+  for (uint32_t t = cnt->n_sorted + blockIdx.x * NT + tid; t < P.n_slots; t += gridDim.x * NT) {
+    key[t] = INVALID;
+    rg_out[(size_t)t * 4 + 3] = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);  // pid = -1
   }
 }
 

@@ -109,6 +109,8 @@ struct mpmhip_ctx {
   bool keys_valid = false;    // key[] + block flags describe the current positions (set by k_g2p)
   bool affine_valid = false;  // RecP.A matches (F, aux, apic_b)
   bool b_stale = false;       // discard_apic_b: the side array is behind RecP.A (k_g2p did not write it)
+  bool ordered = false;       // the records lie in the order of the last sort (k_g2p wrote them at their sorted positions)
+  bool compact = false;       // ... and the live ones occupy exactly [0, cnt->n_sorted): n_slots may shrink to that
   int p2g_wgs = 16384;        // workgroups of k_p2g (env MPMHIP_P2G_WGS)
   int p2g_split = 11;         // tuning knob (env MPMHIP_P2G_SPLIT): 10*NS + PS, see do_p2g
   int g2p_wgs = 4096;         // workgroups of k_g2p (env MPMHIP_G2P_WGS)
@@ -349,6 +351,9 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(dmalloc(&c->rg, (size_t)c->cap));
   A(dmalloc(&c->rp, (size_t)c->cap));
   A(dmalloc(&c->rb, (size_t)c->cap * BW));
+  A(dmalloc(&c->rg2, (size_t)c->cap));  // k_g2p writes the updated records here, at their sorted positions; the two sets swap
+  A(dmalloc(&c->rp2, (size_t)c->cap));
+  A(dmalloc(&c->rb2, (size_t)c->cap * BW));
   A(dmalloc(&c->key, (size_t)c->cap));
   A(dmalloc(&c->rank, (size_t)c->cap));
   A(dmalloc(&c->perm, (size_t)c->cap));
@@ -500,6 +505,7 @@ int mpmhip_add_group(mpmhip_ctx *c, int32_t material, const float params[MPMHIP_
 // ones would turn into phantom active blocks (empty tiles, inflated n_active, spurious capacity errors).
 static int invalidate_keys(mpmhip_ctx *c) {
   c->sorted = false;
+  c->ordered = c->compact = false;
   if (c->keys_valid) {
     c->keys_valid = false;
     HIPCHK(c, hipMemsetAsync(c->blk_flag, 0, (size_t)c->P.nbw * 32, c->stream));
@@ -514,6 +520,14 @@ static int read_counters(mpmhip_ctx *c, Counters &h) {
   HIPCHK(c, hipMemcpyAsync(pin, c->cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   h = *pin;
+  if (c->compact && !c->sorted && !c->in_substep && (int64_t)h.n_sorted < c->n_slots) {
+    // k_g2p left the live records in [0, n_sorted): the slots behind are all dead (particles deleted in earlier substeps)
+    const uint32_t tail = (uint32_t)(c->n_slots - (int64_t)h.n_sorted);
+    h.n_dead = h.n_dead >= tail ? h.n_dead - tail : 0u;
+    c->n_slots = h.n_sorted;
+    c->P.n_slots = h.n_sorted;
+    HIPCHK(c, hipMemcpy(&c->cnt->n_dead, &h.n_dead, sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   if (h.error & 1u)
     return fail(c, MPMHIP_ECAPACITY, "active blocks (%u) exceed max_blocks (%u): recreate the ctx with a larger max_blocks",
                 h.n_active, c->P.max_blocks);
@@ -739,7 +753,10 @@ static int do_sort(mpmhip_ctx *c) {
   c->keys_valid = false;  // key[] now holds cell indices
   int rc = launch_check(c, "sort");
   if (rc) return rc;
-  if ((c->reorder_interval > 0 && c->substeps % c->reorder_interval == 0) || c->compact_requested) {  // src/mpm.cpp:811-813
+  // sort_allocator (src/mpm.cpp:752-768, every reorder_interval substeps :811-813): needed here only for records that
+  // did not come out of k_g2p (fresh uploads, arrivals of a migration) — k_g2p itself leaves the records in sorted order
+  // every substep, so a running simulation never pays for a separate reorder (nor for its host synchronisation)
+  if ((c->reorder_interval > 0 && !c->ordered) || c->compact_requested) {
     c->compact_requested = false;
     return do_reorder(c);
   }
@@ -749,12 +766,6 @@ static int do_sort(mpmhip_ctx *c) {
 // physical reorder into sorted order + compaction of deleted slots (sort_allocator, src/mpm.cpp:752-768).
 // Needs the live count on the host, hence one synchronisation: keep reorder_interval large.
 static int do_reorder(mpmhip_ctx *c) {
-  if (!c->rg2) {
-    hipError_t e = dmalloc(&c->rg2, (size_t)c->cap);
-    if (e == hipSuccess) e = dmalloc(&c->rp2, (size_t)c->cap);
-    if (e == hipSuccess) e = dmalloc(&c->rb2, (size_t)c->cap * BW);
-    if (e != hipSuccess) return fail(c, MPMHIP_ENOMEM, "reorder buffers: %s", hipGetErrorString(e));
-  }
   const int pg = particle_grid(c->n_slots * 4);
   hipLaunchKernelGGL(k_gather_records, dim3(pg), dim3(256), 0, c->stream, c->cnt, c->perm, (const float4 *)c->rg,
                      (const float4 *)c->rp, (const float4 *)c->rb, (float4 *)c->rg2, (float4 *)c->rp2, (float4 *)c->rb2);
@@ -764,6 +775,7 @@ static int do_reorder(mpmhip_ctx *c) {
   Counters h;
   if ((rc = read_counters(c, h))) return rc;
   std::swap(c->rg, c->rg2); std::swap(c->rp, c->rp2); std::swap(c->rb, c->rb2);
+  c->ordered = true;
   c->n_slots = h.n_sorted;
   c->P.n_slots = h.n_sorted;
   const uint32_t zero = 0;
@@ -814,14 +826,20 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0) {
     case 23: kern = sb ? k_g2p<128, 3, true, true> : k_g2p<128, 3, true, false>; nt = 128; break;
     default: break;
   }
-  hipLaunchKernelGGL(kern, dim3(c->g2p_wgs), dim3(nt), 0, c->stream, c->P, (float4 *)c->rg, (float4 *)c->rp, (float4 *)c->rb,
-                     c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
+  hipLaunchKernelGGL(kern, dim3(c->g2p_wgs), dim3(nt), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
+                     (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
                      c->blk_flag, (const LevelSetDev *)c->d_LS, phase_box(c->T), phase);
   c->sorted = false;       // positions moved
   c->keys_valid = true;    // ... and their keys / block flags are ready for the next sort
   c->affine_valid = true;  // A was produced together with F
   if (!c->P.store_b) c->b_stale = true;
   return launch_check(c, "g2p");
+}
+
+// behind the LAST k_g2p launch of a substep: the buffers it wrote become the current records
+static void swap_records(mpmhip_ctx *c) {
+  std::swap(c->rg, c->rg2); std::swap(c->rp, c->rp2); std::swap(c->rb, c->rb2);
+  c->ordered = c->compact = true;
 }
 
 static int need_sorted(mpmhip_ctx *c, const char *who) {
@@ -850,7 +868,9 @@ int mpmhip_g2p(mpmhip_ctx *c) {
   if (!c) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   int rc = need_sorted(c, "g2p");
-  return rc ? rc : do_g2p(c);
+  if (rc || (rc = do_g2p(c))) return rc;
+  swap_records(c);
+  return MPMHIP_OK;
 }
 
 static int get_events(mpmhip_ctx *c, mpmhip_ctx::Ev **out) {
@@ -958,6 +978,7 @@ int mpmhip_substep_end(mpmhip_ctx *c) {  // grid (+ halo sum), G2P
   if (ev && (lvl == 1 || lvl == 2)) HIPCHK(c, hipEventRecord(ev->e[4], c->stream));
   if ((rc = do_g2p(c, ph))) return rc;
   if (ev && (lvl == 1 || lvl == 2)) HIPCHK(c, hipEventRecord(ev->e[5], c->stream));
+  swap_records(c);
   c->t += c->P.dt;  // src/mpm.cpp:573
   c->substeps++;
   return MPMHIP_OK;
@@ -1138,6 +1159,7 @@ int mpmhip_snapshot_load(mpmhip_ctx *c, const void *src, size_t size) {
     if (rc) return rc;
   }
   c->sorted = c->keys_valid = false;  // keys and block flags are rebuilt by the next sort
+  c->ordered = c->compact = false;
   HIPCHK(c, hipMemset(c->blk_flag, 0, (size_t)c->P.nbw * 32));
   Counters hc;
   memset(&hc, 0, sizeof hc);
@@ -1469,6 +1491,7 @@ int mpmhip_import_particles(mpmhip_ctx *c, int64_t n, const void *dev_records) {
                      c->cnt);
   c->n_slots += n;
   c->P.n_slots = (uint32_t)c->n_slots;
+  c->compact = false;  // live records now also sit behind the range k_g2p compacted
   return launch_check(c, "import");
 }
 
