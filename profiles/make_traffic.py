@@ -12,6 +12,7 @@ from collections import defaultdict
 
 
 LAST = None
+TAG = ""
 
 
 def means(path, counter):
@@ -25,8 +26,10 @@ def means(path, counter):
 
 def main(fetch_csv, write_csv):
     f, w = means(fetch_csv, "FETCH_SIZE"), means(write_csv, "WRITE_SIZE")
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean over dispatches; "
-                     "reads = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), writes = WRITE_SIZE KiB x 1024",
+    out = {"source": "committed profile %s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean over the last "
+                     "dispatches; reads = FETCH_SIZE KiB x 1024 x 2 (the counter reports 128-byte requests as 64: factor 1.98 measured "
+                     "for sequential 64-byte record gathers, 1.0 for fully shuffled ones, profiles/r02_c_calibrate_fetch.json — "
+                     "an upper bound where the particle order has decayed), writes = WRITE_SIZE KiB x 1024" % (TAG or "?"),
            "kernels": {}}
     for k in sorted(set(f) & set(w)):
         rd, wr = f[k] * 1024 * 2, w[k] * 1024
@@ -36,7 +39,10 @@ def main(fetch_csv, write_csv):
 
 if __name__ == "__main__":
     args = sys.argv[1:]
-    if args and args[0] == "--last":  # only the last N dispatches of every kernel
-        LAST = int(args[1])
+    while args and args[0] in ("--last", "--tag"):
+        if args[0] == "--last":  # only the last N dispatches of every kernel
+            LAST = int(args[1])
+        else:
+            TAG = args[1]
         args = args[2:]
     main(*args[:2])

@@ -97,6 +97,9 @@ __device__ __forceinline__ void jacobi_rotate(float &app, float &aqq, float &apq
 }
 
 constexpr int kJacobiSweeps = 4;
+#ifndef MPM_JACOBI_TOL
+#define MPM_JACOBI_TOL 1e-7f
+#endif
 
 // Eigen-decomposition of the symmetric positive semi-definite A = F F^T:  A = U diag(lam) U^T.
 // U is a proper rotation (product of Givens rotations).  Unsorted.  Cyclic Jacobi converges quadratically; the
@@ -112,7 +115,7 @@ __device__ __forceinline__ void sym_eig3_FFt(const mat3 &F, mat3 &U, float lam[3
   float a12 = fmaf(F(1, 0), F(2, 0), fmaf(F(1, 1), F(2, 1), F(1, 2) * F(2, 2)));
   f2 u0 = {1.0f, 0.0f}, u1 = {0.0f, 1.0f}, u2 = {0.0f, 0.0f};  // columns of U: rows 0,1
   float w0 = 0.0f, w1 = 0.0f, w2 = 1.0f;                        //               row 2
-  const float tol = 1e-7f * (a00 + a11 + a22);
+  const float tol = MPM_JACOBI_TOL * (a00 + a11 + a22);
 #pragma unroll
   for (int sweep = 0; sweep < kJacobiSweeps; sweep++) {
     if (!__any(fmaxf(fabsf(a01), fmaxf(fabsf(a02), fabsf(a12))) > tol)) break;
