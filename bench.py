@@ -15,12 +15,20 @@ Extra objects on the line:
                 duration over the K timed substeps, hipEvents recorded on the ctx stream (mpmhip_set_profiling).
                 Algorithmic bytes per particle: P2G 100 B particle read + 16 B per touched grid node
                 written; G2P 52 B read + 100 B written + 16 B per touched node read.  `traffic` = HBM bytes per
-                launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE, see
-                DESIGN.md §6) / the same launch duration, or null when no PMC summary matches the workload.
+                launch from the committed rocprofv3 PMC passes (profiles/traffic_<config>[_evolved].json:
+                FETCH_SIZE x2 + WRITE_SIZE, the factor calibrated for 64-byte gathers) / the same
+                launch duration, or null when no PMC summary matches the workload.
                 `measured_copy_GBs` = a plain float4 copy kernel of the library on this box (1 GiB, best of 5, bytes
                 read + written), run after the timed region: the practical ceiling next to the nominal `peak`.
-  cpu_baseline  the block-sorted, 8-colour, OpenMP restatement of the reference's optimised CPU path
-                (oracle/mpm_oracle_opt.cpp, kind "port") timed on this box's host cores on a bounded sample.
+  evolved       the same measurement (ms_per_step, phases, roofline) on the same ctx after the seeded block has
+                fallen onto the floor and EVOLVE_AFTER_IMPACT further substeps have run: uneven cells, active
+                return map.  `value` stays the lattice the reference's benchmark seeds (config.state says so);
+                --state evolved makes the evolved state the main measurement (profiling runs), --no-evolved skips it.
+  cpu_baseline  kind "reference": the reference's own solver, compiled from its sources in place
+                (oracle/_ref/libmpm_ref.so, built by `make -C oracle ref_mpm` where /root/reference exists; the
+                built library travels), timed on this box's host cores: thread sweep + threads=1 row on the
+                reference's benchmark=125 lattice (~1 M particles), then the full workload at the best thread count.
+                Fallback when that library is absent: the OpenMP restatement (oracle/mpm_oracle_opt.cpp, kind "port").
 """
 import argparse
 import json
