@@ -18,23 +18,15 @@
 
 #include "kernel.h"
 #include "mpm.h"
+#include "boundary_particle.h"
 #include "async/async_mpm.h"  // AsyncMPM<dim>: this TU is compiled with -fno-access-control so that the checker can read
                               // the block table (`blocks`, `particle_pool`), which the class keeps private
 
 TC_NAMESPACE_BEGIN
 
-// CPIC rigid coupling (src/mpm_rigid_body.cpp, src/rigid_transfer.cpp) is outside this build: with only the
-// background body present (has_rigid_body() == false) substep() never reaches these.
-#define SHIM_RIGID_STUBS(D)                                                           \
-  template <> void MPM<D>::gather_cdf() { TC_NOT_IMPLEMENTED }                        \
-  template <> void MPM<D>::add_rigid_particle(Config) { TC_NOT_IMPLEMENTED }          \
-  template <> void MPM<D>::advect_rigid_bodies(real) { TC_NOT_IMPLEMENTED }           \
-  template <> void MPM<D>::rasterize_rigid_boundary() { TC_NOT_IMPLEMENTED }          \
-  template <> void MPM<D>::rigid_body_levelset_collision(real, real) { TC_NOT_IMPLEMENTED } \
-  template <> void MPM<D>::rigidify(real) { TC_NOT_IMPLEMENTED }
-SHIM_RIGID_STUBS(2)
-SHIM_RIGID_STUBS(3)
-
+// CPIC rigid coupling: src/rigid_transfer.cpp (colored distance field), src/mpm_rigid_body.cpp (bodies, boundary
+// particles, advection) and src/boundary_particle.cpp are compiled as separate objects like the other sources; the rigid
+// body itself is the shim's (taichi/dynamics/rigid_body_shim.h).  Joints (src/articulation.cpp) are outside this build.
 namespace {
 
 thread_local std::string g_err;
@@ -67,6 +59,10 @@ struct Handle {
   std::unique_ptr<MPM<2>> m2;
   std::unique_ptr<MPM<3>> m3;
   AsyncMPM<3> *async3 = nullptr;  // == m3.get() when the simulation is the "async_mpm" one
+  // scripted motions of rigid bodies: the reference receives POINTERS to std::function objects through its config
+  // (src/mpm_rigid_body.cpp:79-92) and copies them
+  std::vector<std::unique_ptr<RigidBody<3>::PositionFunctionType>> pos_scripts;
+  std::vector<std::unique_ptr<RigidBody<3>::RotationFunctionType>> rot_scripts;
 };
 
 template <int dim> MPM<dim> &sim(Handle *h);
@@ -128,6 +124,7 @@ int64_t download(Handle *h, float *x, float *v, float *F, float *B, float *aux, 
   int64_t i = 0;
   for (auto pi : m.particles) {
     MPMParticle<dim> *p = m.allocator[pi];
+    if (p->is_rigid()) continue;  // the boundary particles of a rigid body: see ref_rigid_samples
     auto vel = p->get_velocity();
     for (int k = 0; k < dim; k++) { if (x) x[dim * i + k] = p->pos[k]; if (v) v[dim * i + k] = vel[k]; }
     if (F) mat_out<dim>(p->dg_e, F + dim * dim * i);
@@ -203,6 +200,9 @@ int phase(Handle *h, int which, int optimized) {
     case 4: m.clear_boundary_particles(); break;                              // src/mpm.cpp:582-633
     case 5: m.particle_collision_resolution(m.current_t); break;              // src/mpm.cpp:414-426
     case 6: m.normalize_grid_and_apply_external_force(m.particle_gravity ? VectorND<dim, real>(0.0f) : m.gravity * dt); break;
+    case 7: m.rasterize_rigid_boundary(); break;                               // src/rigid_transfer.cpp:17-115
+    case 8: m.gather_cdf(); break;                                             // src/rigid_transfer.cpp:121-275
+    case 9: m.advect_rigid_bodies(dt); break;                                  // src/mpm_rigid_body.cpp:255-286
     default: return -1;
   }
   return 0;
@@ -295,9 +295,12 @@ int ref_add_particles_cfg(void *hh, const char *cfg) {
     return 0;
   });
 }
-int64_t ref_num_particles(void *hh) {
+int64_t ref_num_particles(void *hh) {  // material particles (the boundary particles of rigid bodies are not counted)
   Handle *h = (Handle *)hh;
-  return DISPATCH(h, (int64_t)h->m2->particles.size(), (int64_t)h->m3->particles.size());
+  int64_t n = 0;
+  if (h->dim == 2) { for (auto pi : h->m2->particles) n += !h->m2->allocator[pi]->is_rigid(); }
+  else { for (auto pi : h->m3->particles) n += !h->m3->allocator[pi]->is_rigid(); }
+  return n;
 }
 int64_t ref_download(void *hh, float *x, float *v, float *F, float *B, float *aux, int32_t *id) {
   Handle *h = (Handle *)hh;
@@ -426,6 +429,138 @@ int64_t ref_async_num_particles(void *hh) {
 }
 int64_t ref_async_time_int(void *hh) { Handle *h = (Handle *)hh; return h->async3 ? h->async3->current_t_int : -1; }
 int64_t ref_async_update_counter(void *hh) { Handle *h = (Handle *)hh; return h->async3 ? (int64_t)h->async3->update_counter : -1; }
+
+
+// ---- CPIC rigid coupling (3D) --------------------------------------------------------------------------------------
+// add_particles(type='rigid', ...) (src/mpm.cpp:80-83 -> src/mpm_rigid_body.cpp:130-252) with the mesh handed over as
+// n_tri triangles (9 floats each, mesh space).  cfg: the reference's own keys (codimensional, density, friction |
+// friction0+friction1, restitution, scale, initial_position | initial_rotation | initial_velocity |
+// initial_angular_velocity, rotation_axis, linear_damping, angular_damping, recenter).  script (18 floats, may be null):
+// [has_pos, p0(3), vel(3), amp(3), omega | has_rot, e0(3) deg, rate(3) deg/s]:
+//   scripted_position(t) = p0 + vel t + amp sin(omega t),  scripted_rotation(t) = e0 + rate t   (Euler angles, degrees)
+// Returns the rigid body's index in MPM::rigids (>= 1; 0 is the background body).
+int ref_add_rigid(void *hh, const char *cfg, int n_tri, const float *tri, const float *script) {
+  Handle *h = (Handle *)hh;
+  return guarded([&] {
+    if (h->dim != 3) TC_ERROR("rigid bodies: 3D only in this driver");
+    MPM<3> &m = *h->m3;
+    Config c = Config::from_string(cfg);
+    c.set("type", std::string("rigid"));
+    c.set("shim_mesh_ptr", (unsigned long long)(uintptr_t)tri);
+    c.set("shim_mesh_n", n_tri);
+    if (script && script[0] != 0.0f) {
+      const Vector3 p0(script[1], script[2], script[3]), vel(script[4], script[5], script[6]), amp(script[7], script[8], script[9]);
+      const real omega = script[10];
+      h->pos_scripts.push_back(std::make_unique<RigidBody<3>::PositionFunctionType>(
+          [=](real t) { return p0 + vel * t + amp * std::sin(omega * t); }));
+      c.set("scripted_position", (unsigned long long)(uintptr_t)h->pos_scripts.back().get());
+      c.set("scripted_position_id", (int)h->pos_scripts.size() - 1);
+    }
+    if (script && script[11] != 0.0f) {
+      const Vector3 e0(script[12], script[13], script[14]), rate(script[15], script[16], script[17]);
+      h->rot_scripts.push_back(std::make_unique<RigidBody<3>::RotationFunctionType>([=](real t) { return e0 + rate * t; }));
+      c.set("scripted_rotation", (unsigned long long)(uintptr_t)h->rot_scripts.back().get());
+      c.set("scripted_rotation_id", (int)h->rot_scripts.size() - 1);
+    }
+    m.add_particles(c);
+    m.rigids.back()->id = (int)m.rigids.size() - 1;  // (the legacy core numbered bodies with a process-wide counter)
+    return (int)m.rigids.size() - 1;
+  });
+}
+// out[33]: position 3, quaternion (w, x, y, z) 4, velocity 3, angular velocity 3, mass, inv_mass, inertia 9 (body frame,
+// row-major), inv_inertia 9
+int ref_rigid_state(void *hh, int id, float *out) {
+  Handle *h = (Handle *)hh;
+  return guarded([&] {
+    MPM<3> &m = *h->m3;
+    if (id < 0 || id >= (int)m.rigids.size()) TC_ERROR("no such rigid body");
+    const RigidBody<3> &r = *m.rigids[id];
+    int k = 0;
+    for (int i = 0; i < 3; i++) out[k++] = r.position[i];
+    out[k++] = r.rotation.value.qw; out[k++] = r.rotation.value.qx; out[k++] = r.rotation.value.qy; out[k++] = r.rotation.value.qz;
+    for (int i = 0; i < 3; i++) out[k++] = r.velocity[i];
+    for (int i = 0; i < 3; i++) out[k++] = r.angular_velocity.value[i];
+    out[k++] = r.mass; out[k++] = r.inv_mass;
+    mat_out<3>(r.inertia, out + k); k += 9;
+    mat_out<3>(r.inv_inertia, out + k); k += 9;
+    return 0;
+  });
+}
+int ref_rigid_set_velocity(void *hh, int id, const float *v, const float *w) {
+  Handle *h = (Handle *)hh;
+  return guarded([&] {
+    MPM<3> &m = *h->m3;
+    if (id < 1 || id >= (int)m.rigids.size()) TC_ERROR("no such rigid body");
+    if (v) m.rigids[id]->velocity = Vector3(v[0], v[1], v[2]);
+    if (w) m.rigids[id]->angular_velocity.value = Vector3(w[0], w[1], w[2]);
+    m.advect_rigid_bodies(0.0f);  // boundary particles follow (align_with_rigid_body); a zero step moves nothing
+    return 0;
+  });
+}
+// the boundary particles sampled on the body's triangles: world position, offset from the centre of mass (body frame),
+// the untransformed triangle (9 floats, recentred mesh space).  Returns the count of body `id` (all bodies: id < 0).
+int64_t ref_rigid_samples(void *hh, int id, int64_t cap, float *pos, float *offset, float *element, int32_t *body) {
+  Handle *h = (Handle *)hh;
+  int64_t n = 0;
+  const int rc = guarded([&] {
+    MPM<3> &m = *h->m3;
+    for (auto pi : m.particles) {
+      auto *p = dynamic_cast<RigidBoundaryParticle<3> *>(m.allocator[pi]);
+      if (!p || (id >= 0 && p->rigid->id != id)) continue;
+      if (n < cap) {
+        for (int k = 0; k < 3; k++) { if (pos) pos[3 * n + k] = p->pos[k]; if (offset) offset[3 * n + k] = p->offset[k]; }
+        if (element) for (int q = 0; q < 3; q++) for (int k = 0; k < 3; k++) element[9 * n + 3 * q + k] = p->untransformed_element.v[q][k];
+        if (body) body[n] = p->rigid->id;
+      }
+      n++;
+    }
+    return 0;
+  });
+  return rc ? -1 : n;
+}
+// colored distance field of the grid: dense (res+1)^3 arrays of GridState::states (24 tag bits | rigid id + 1 << 24,
+// src/mpm_fwd.h:69-105) and GridState::distance
+int ref_download_cdf(void *hh, uint32_t *states, float *distance) {
+  Handle *h = (Handle *)hh;
+  return guarded([&] {
+    MPM<3> &m = *h->m3;
+    using Mask = typename MPM<3>::SparseMask;
+    auto blocks = m.fat_page_map->Get_Blocks();
+    auto bs = m.grid_block_size();
+    for (unsigned b = 0; b < blocks.second; b++) {
+      Vector3i base(Mask::LinearToCoord(blocks.first[b]));
+      for (auto &ind : RegionND<3>(Vector3i(0), bs)) {
+        Vector3i g = base + ind.get_ipos();
+        if (g[0] > m.res[0] || g[1] > m.res[1] || g[2] > m.res[2]) continue;
+        const size_t lin = ((size_t)g[0] * (m.res[1] + 1) + g[1]) * (m.res[2] + 1) + g[2];
+        states[lin] = m.get_grid(g).states;
+        distance[lin] = m.get_grid(g).distance;
+      }
+    }
+    return 0;
+  });
+}
+// per material particle, in the order of ref_download: MPMParticle::states, boundary_distance, boundary_normal,
+// near_boundary_  (what gather_cdf leaves, src/rigid_transfer.cpp:121-275); upload = states only
+int64_t ref_particle_cdf(void *hh, uint32_t *states, float *distance, float *normal, int32_t *near, const uint32_t *upload_states) {
+  Handle *h = (Handle *)hh;
+  int64_t n = 0;
+  guarded([&] {
+    MPM<3> &m = *h->m3;
+    for (auto pi : m.particles) {
+      MPMParticle<3> *p = m.allocator[pi];
+      if (p->is_rigid()) continue;
+      if (upload_states) p->states = upload_states[n];
+      if (states) states[n] = p->states;
+      if (distance) distance[n] = p->boundary_distance;
+      if (normal) for (int k = 0; k < 3; k++) normal[3 * n + k] = p->boundary_normal[k];
+      if (near) near[n] = p->near_boundary_;
+      n++;
+    }
+    return 0;
+  });
+  return n;
+}
 
 // seconds per TC_PROFILE name since the last reset, as "name=seconds;..."
 int ref_profile(char *out, size_t cap, int reset) {

@@ -80,6 +80,15 @@ def lib():
         L.ref_async_time_int.argtypes = [C.c_void_p]
         L.ref_async_update_counter.restype = C.c_int64
         L.ref_async_update_counter.argtypes = [C.c_void_p]
+        P_U = C.POINTER(C.c_uint32)
+        L.ref_add_rigid.argtypes = [C.c_void_p, C.c_char_p, C.c_int, P_F, P_F]
+        L.ref_rigid_state.argtypes = [C.c_void_p, C.c_int, P_F]
+        L.ref_rigid_set_velocity.argtypes = [C.c_void_p, C.c_int, P_F, P_F]
+        L.ref_rigid_samples.restype = C.c_int64
+        L.ref_rigid_samples.argtypes = [C.c_void_p, C.c_int, C.c_int64, P_F, P_F, P_F, P_I]
+        L.ref_download_cdf.argtypes = [C.c_void_p, P_U, P_F]
+        L.ref_particle_cdf.restype = C.c_int64
+        L.ref_particle_cdf.argtypes = [C.c_void_p, P_U, P_F, P_F, P_I, P_U]
         _lib = L
     return _lib
 
@@ -106,6 +115,19 @@ def _fmt(v):
 
 def cfg_string(**kw):
     return ";".join("%s=%s" % (k, _fmt(v)) for k, v in kw.items()).encode()
+
+
+def rigid_script(position=None, velocity=(0, 0, 0), amplitude=(0, 0, 0), omega=0.0, rotation=None, rotation_rate=(0, 0, 0)):
+    """the parametric scripts of ref_add_rigid: scripted_position(t) = position + velocity t + amplitude sin(omega t),
+    scripted_rotation(t) = rotation + rotation_rate t (Euler angles in degrees); None = not scripted"""
+    s = np.zeros(18, np.float32)
+    if position is not None:
+        s[0] = 1
+        s[1:4], s[4:7], s[7:10], s[10] = position, velocity, amplitude, omega
+    if rotation is not None:
+        s[11] = 1
+        s[12:15], s[15:18] = rotation, rotation_rate
+    return s
 
 
 def set_threads(n):
@@ -227,6 +249,70 @@ class Sim:
 
     def particle_collision(self):
         _chk(lib().ref_phase(self.h, 5, 1))
+
+    # ---- CPIC rigid coupling (3D): src/rigid_transfer.cpp, src/mpm_rigid_body.cpp, rigid branches of src/transfer.cpp
+    def add_rigid(self, triangles, script=None, **cfg):
+        """add_particles(type='rigid', ...): triangles (n, 3, 3) in mesh space; cfg = the reference's keys (codimensional,
+        density, friction, scale, initial_position, initial_rotation, ...); script = rigid_script(...) or None.
+        Returns the body's index (>= 1)."""
+        tri, tp = _f(np.asarray(triangles, np.float32).reshape(-1, 9))
+        sp = None
+        if script is not None:
+            script, sp = _f(np.asarray(script, np.float32).reshape(18))
+        cfg.setdefault("codimensional", True)
+        rid = lib().ref_add_rigid(self.h, cfg_string(**cfg), len(tri), tp, sp)
+        if rid < 0:
+            raise RuntimeError("reference: " + lib().ref_last_error().decode())
+        return rid
+
+    def rigid_state(self, rid):
+        o = np.zeros(33, np.float32)
+        _chk(lib().ref_rigid_state(self.h, int(rid), o.ctypes.data_as(P_F)))
+        return dict(position=o[0:3], rotation=o[3:7], velocity=o[7:10], angular_velocity=o[10:13], mass=float(o[13]),
+                    inv_mass=float(o[14]), inertia=o[15:24].reshape(3, 3), inv_inertia=o[24:33].reshape(3, 3))
+
+    def rigid_set_velocity(self, rid, v=None, w=None):
+        vp = _f(v)[1] if v is not None else None
+        wp = _f(w)[1] if w is not None else None
+        _chk(lib().ref_rigid_set_velocity(self.h, int(rid), vp, wp))
+
+    def rigid_samples(self, rid=-1):
+        """boundary particles: world position, body-frame offset, untransformed triangle, body index"""
+        n = lib().ref_rigid_samples(self.h, int(rid), 0, None, None, None, None)
+        pos, off, el, body = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 3, 3), np.float32), np.zeros(n, np.int32)
+        m = lib().ref_rigid_samples(self.h, int(rid), n, pos.ctypes.data_as(P_F), off.ctypes.data_as(P_F), el.ctypes.data_as(P_F),
+                                    body.ctypes.data_as(P_I))
+        assert m == n
+        return dict(pos=pos, offset=off, element=el, body=body)
+
+    def rasterize_rigid_boundary(self):
+        _chk(lib().ref_phase(self.h, 7, 1))
+
+    def gather_cdf(self):
+        _chk(lib().ref_phase(self.h, 8, 1))
+
+    def advect_rigid_bodies(self):
+        _chk(lib().ref_phase(self.h, 9, 1))
+
+    def download_cdf(self):
+        """(states, distance) of every grid node, dense (res+1)^3; states = 24 colour-tag bits | (rigid id + 1) << 24"""
+        shp = tuple(r + 1 for r in self.res)
+        st, d = np.zeros(shp, np.uint32), np.zeros(shp, np.float32)
+        _chk(lib().ref_download_cdf(self.h, st.ctypes.data_as(C.POINTER(C.c_uint32)), d.ctypes.data_as(P_F)))
+        return st, d
+
+    def particle_cdf(self, upload_states=None):
+        """per material particle in the order of download(by_id=False): states, boundary_distance, boundary_normal, near_boundary"""
+        n = self.num_particles()
+        st, d, nr, near = np.zeros(n, np.uint32), np.zeros(n, np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.int32)
+        up = None
+        if upload_states is not None:
+            upload_states = np.ascontiguousarray(upload_states, np.uint32)
+            up = upload_states.ctypes.data_as(C.POINTER(C.c_uint32))
+        m = lib().ref_particle_cdf(self.h, st.ctypes.data_as(C.POINTER(C.c_uint32)), d.ctypes.data_as(P_F), nr.ctypes.data_as(P_F),
+                                   near.ctypes.data_as(P_I), up)
+        assert m == n
+        return dict(states=st, distance=d, normal=nr, near=near)
 
     def time(self):
         return lib().ref_time(self.h)

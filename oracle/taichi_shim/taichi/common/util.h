@@ -9,7 +9,7 @@
 //   * small fixed-size vectors / matrices (column-major, Vector3f/Vector4f on SSE registers, as the reference's
 //     SIMD code requires: `p.pos.v`, `reinterpret_cast<Matrix &>(__m128[3])`, src/transfer.cpp:490-545,929)
 //   * Config (string dictionary), the Unit / interface factory macros, serialization macros (no-ops)
-//   * RegionND / IndexND / ArrayND, Simulation<dim> base, analytic DynamicLevelSet, inert RigidBody / Texture / Mesh
+//   * RegionND / IndexND / ArrayND, Simulation<dim> base, analytic DynamicLevelSet, functional RigidBody (rigid_body_shim.h), inert Texture / Mesh
 //   * ThreadedTaskManager / tbb::parallel_* on OpenMP, Profiler (accumulates per-name wall time)
 //   * svd / polar_decomp: OURS (see below) — the one numerical routine of the hot path that lives in the absent
 //     library.  Computed in double precision by a Jacobi eigen-solve of A^T A (3D) / closed form (2D) and rounded to
@@ -123,8 +123,8 @@ struct ShimError : std::runtime_error {
 #define TC_STOP ::taichi::shim_fail("TC_STOP", __FILE__, __LINE__)
 #define TC_ASSERT(x) \
   do { if (!(x)) ::taichi::shim_fail("TC_ASSERT failed: " #x, __FILE__, __LINE__); } while (0)
-#define TC_ASSERT_INFO(x, ...) \
-  do { if (!(x)) ::taichi::shim_fail("TC_ASSERT_INFO failed: " #x, __FILE__, __LINE__); } while (0)
+#define TC_ASSERT_INFO(x, ...) /* a complete statement: src/mpm_rigid_body.cpp:22-23 uses it without a semicolon */ \
+  { if (!(x)) ::taichi::shim_fail("TC_ASSERT_INFO failed: " #x, __FILE__, __LINE__); }
 #define TC_STATIC_IF(x) if constexpr (x)
 #define TC_STATIC_ELSE else
 #define TC_STATIC_END_IF
@@ -251,6 +251,7 @@ struct VectorND : public VecStore<dim, T> {
   TC_FORCE_INLINE T dot(const VectorND &o) const { T r = d[0] * o.d[0]; for (int i = 1; i < dim; i++) r += d[i] * o.d[i]; return r; }
   TC_FORCE_INLINE T length2() const { return dot(*this); }
   TC_FORCE_INLINE T length() const { return std::sqrt(length2()); }
+  TC_FORCE_INLINE T abs_max() const { T r = std::abs(d[0]); for (int i = 1; i < dim; i++) r = std::max(r, std::abs(d[i])); return r; }
   TC_FORCE_INLINE VectorND abs() const { VectorND r; for (int i = 0; i < dim; i++) r.d[i] = std::abs(d[i]); return r; }
   template <typename F> TC_FORCE_INLINE VectorND map(F f) const { VectorND r; for (int i = 0; i < dim; i++) r.d[i] = f(d[i]); return r; }
   TC_FORCE_INLINE VectorND clamp(const VectorND &lo, const VectorND &hi) const {
@@ -301,6 +302,9 @@ struct MatrixND {
   // it where it passes a block index to damp_affine_momemtum (src/transfer.cpp:925-926)
   template <typename S, std::enable_if_t<std::is_arithmetic<S>::value, int> = 0>
   TC_FORCE_INLINE MatrixND(S a) { for (int i = 0; i < dim; i++) d[i][i] = (T)a; }
+  // a smaller matrix into the top-left corner (MatrixP(rotation_matrix), src/rigid_body_solver.h:131)
+  template <int d2, std::enable_if_t<(d2 < dim), int> = 0>
+  TC_FORCE_INLINE explicit MatrixND(const MatrixND<d2, T> &o) { for (int c = 0; c < d2; c++) for (int r = 0; r < d2; r++) d[c][r] = o[c][r]; }
   TC_FORCE_INLINE explicit MatrixND(const Vector &diag) { for (int i = 0; i < dim; i++) d[i][i] = diag[i]; }
   TC_FORCE_INLINE MatrixND(const Vector &c0, const Vector &c1) { static_assert(dim == 2, ""); d[0] = c0; d[1] = c1; }
   TC_FORCE_INLINE MatrixND(const Vector &c0, const Vector &c1, const Vector &c2) { static_assert(dim == 3, ""); d[0] = c0; d[1] = c1; d[2] = c2; }
@@ -353,6 +357,36 @@ template <typename T> inline MatrixND<3, T> inversed(const MatrixND<3, T> &m) {
   o[0][0] = (a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1)) * id; o[1][0] = (a(0, 2) * a(2, 1) - a(0, 1) * a(2, 2)) * id; o[2][0] = (a(0, 1) * a(1, 2) - a(0, 2) * a(1, 1)) * id;
   o[0][1] = (a(1, 2) * a(2, 0) - a(1, 0) * a(2, 2)) * id; o[1][1] = (a(0, 0) * a(2, 2) - a(0, 2) * a(2, 0)) * id; o[2][1] = (a(0, 2) * a(1, 0) - a(0, 0) * a(1, 2)) * id;
   o[0][2] = (a(1, 0) * a(2, 1) - a(1, 1) * a(2, 0)) * id; o[1][2] = (a(0, 1) * a(2, 0) - a(0, 0) * a(2, 1)) * id; o[2][2] = (a(0, 0) * a(1, 1) - a(0, 1) * a(1, 0)) * id;
+  return o;
+}
+// 4x4 (the least-squares fit of src/rigid_transfer.cpp:250-252): OURS like svd — Gauss-Jordan with partial pivoting in
+// double precision, rounded to T
+template <typename T> inline T determinant(const MatrixND<4, T> &m) {
+  double a[4][4], det = 1;
+  for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) a[r][c] = m[c][r];
+  for (int k = 0; k < 4; k++) {
+    int p = k;
+    for (int r = k + 1; r < 4; r++) if (std::abs(a[r][k]) > std::abs(a[p][k])) p = r;
+    if (a[p][k] == 0) return T(0);
+    if (p != k) { for (int c = 0; c < 4; c++) std::swap(a[p][c], a[k][c]); det = -det; }
+    det *= a[k][k];
+    for (int r = k + 1; r < 4; r++) { const double f = a[r][k] / a[k][k]; for (int c = k; c < 4; c++) a[r][c] -= f * a[k][c]; }
+  }
+  return (T)det;
+}
+template <typename T> inline MatrixND<4, T> inversed(const MatrixND<4, T> &m) {
+  double a[4][8];
+  for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { a[r][c] = m[c][r]; a[r][4 + c] = r == c; }
+  for (int k = 0; k < 4; k++) {
+    int p = k;
+    for (int r = k + 1; r < 4; r++) if (std::abs(a[r][k]) > std::abs(a[p][k])) p = r;
+    if (p != k) for (int c = 0; c < 8; c++) std::swap(a[p][c], a[k][c]);
+    const double inv = 1.0 / a[k][k];
+    for (int c = 0; c < 8; c++) a[k][c] *= inv;
+    for (int r = 0; r < 4; r++) if (r != k) { const double f = a[r][k]; for (int c = 0; c < 8; c++) a[r][c] -= f * a[k][c]; }
+  }
+  MatrixND<4, T> o;
+  for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) o[c][r] = (T)a[r][4 + c];
   return o;
 }
 template <int dim, typename T> inline MatrixND<dim, T> inverse(const MatrixND<dim, T> &m) { return inversed(m); }
@@ -639,6 +673,7 @@ struct ArrayND {
   bool inside(const Vectori &i) const { for (int k = 0; k < dim; k++) if (i[k] < 0 || i[k] >= res[k]) return false; return true; }
   RegionND<dim> get_region() const { return RegionND<dim>(Vectori(0), res); }
   void write_as_image(const std::string &) const {}
+  void reset_zero() { std::fill(data.begin(), data.end(), T()); }
 };
 template <typename T> using Array2D = ArrayND<2, T>;
 template <typename T> using Array3D = ArrayND<3, T>;
@@ -653,32 +688,9 @@ template <typename... A> inline std::string format(const std::string &f, A &&...
 template <typename... A> inline void print(FILE *, const char *, A &&...) {}
 }  // namespace fmt
 
-template <int dim>
-struct RigidBody {  // only the background body (no rigid bodies on this path): every hook is inert
-  using Vector = VectorND<dim, real>;
-  using ElementType = int;
-  using PositionFunctionType = std::function<Vector(real)>;
-  using RotationFunctionType = std::function<Vector(real)>;
-  int id = 0;
-  real frictions[2] = {0, 0};
-  int pos_func_id = -1, rot_func_id = -1;
-  PositionFunctionType pos_func;
-  RotationFunctionType rot_func;
-  struct ShimElement { Vector v[dim]; };
-  struct ShimMesh { std::vector<ShimElement> elements; };
-  std::shared_ptr<ShimMesh> mesh = std::make_shared<ShimMesh>();
-  MatrixND<dim + 1, real> get_mesh_to_world() const { return MatrixND<dim + 1, real>(1.0f); }
-  void set_as_background() {}
-  void reset_tmp_velocity() {}
-  void apply_tmp_velocity() {}
-  Vector get_velocity_at(const Vector &) const { return Vector(0.0f); }
-  void apply_tmp_impulse(const Vector &, const Vector &) {}
-};
-
-template <int dim>
-inline VectorND<dim, real> transform(const MatrixND<dim + 1, real> &m, const VectorND<dim, real> &v) {
-  return VectorND<dim, real>(m * VectorND<dim + 1, real>(v, 1.0f));
-}
+}  // namespace taichi
+#include <taichi/dynamics/rigid_body_shim.h>  // RigidBody / mesh elements / rotations for the CPIC coupling (ours)
+namespace taichi {
 
 // analytic level set (taichi core: a SAMPLED signed-distance array built by add_plane / add_sphere / add_cuboid,
 // and DynamicLevelSet = two such arrays at times t0 < t1 blended linearly in time — scripts/async/async_mpm.py:119-127
