@@ -109,7 +109,8 @@ enum {
   MPMHIP_F_F = 3,   /* float[9]  elastic deformation gradient          MPMParticle::dg_e     */
   MPMHIP_F_AUX = 4, /* float[1]  Jp | j | logJp (material state)                             */
   MPMHIP_F_GID = 5, /* int32[1]  group id                                                    */
-  MPMHIP_F_ID = 6   /* int32[1]  creation index (MPMParticle::id semantics for download ordering) */
+  MPMHIP_F_ID = 6,  /* int32[1]  creation index (MPMParticle::id semantics for download ordering) */
+  MPMHIP_F_STATES = 7 /* int32[1] CPIC colour word (MPMParticle::states, src/particles.h): 2 bits per rigid body */
 };
 
 uint32_t mpmhip_abi_version(void);
@@ -387,6 +388,58 @@ int mpmhip_debug_force(mpmhip_ctx *ctx, int32_t material, const float params[MPM
 /* next_force == NULL: plasticity(cdg) alone; else the fused "plasticity + next substep's calculate_force" of k_g2p */
 int mpmhip_debug_plasticity(mpmhip_ctx *ctx, int32_t material, const float params[MPMHIP_NPARAM], int64_t n,
                             const float *cdg, float *F, float *aux, float *next_force);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * CPIC rigid coupling (3D) — replaces add_particles(type='rigid', ...) (src/mpm.cpp:80-83 -> MPM::add_rigid_particle,
+ * src/mpm_rigid_body.cpp:130-252), rasterize_rigid_boundary / gather_cdf (src/rigid_transfer.cpp), the rigid branches of
+ * the transfers (block_op_rigid, src/transfer.cpp:367-463,706-835) and advect_rigid_bodies (src/mpm_rigid_body.cpp:255-286).
+ * Once a body exists, every substep runs: sort | rasterize_rigid_boundary | gather_cdf | P2G | grid | G2P | advect.
+ * Not part of this library: rigid-rigid collisions (rigidify / libccd), joints (articulation.cpp),
+ * rigid_body_levelset_collision.  Rigid bodies cannot be combined with the multi-GPU tiling or asynchronous stepping.
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* scripted_position(t) -> world position; scripted_rotation(t) -> Euler angles in degrees (applied X * Y * Z):
+ * tc.function13 objects in the scene scripts (scripts/mls-cpic/sand_paddles.py:27, src/mpm_rigid_body.cpp:79-92) */
+typedef void (*mpmhip_script_fn)(void *user, float t, float out[3]);
+typedef struct mpmhip_rigid_config {
+  int32_t codimensional;     /* a shell (cuts the material) instead of a solid; mandatory key of the reference */
+  int32_t recenter;          /* 1 (reference default): the mesh is moved so that its centre of mass is the body origin */
+  int32_t reverse_vertices;  /* flip the orientation of every triangle */
+  int32_t reserved0;
+  float density;             /* <= 0: the reference's default, 40 (codimensional) / 400 */
+  float friction[2];         /* friction0 / friction1: the two sides of the surface ('friction' sets both) */
+  float restitution;
+  float scale[3];            /* 0 = 1 */
+  float initial_position[3], initial_rotation[3] /* Euler, degrees */, initial_velocity[3], initial_angular_velocity[3];
+  float rotation_axis[3];    /* angular velocity restricted to this (world) axis when max |axis| > 0.1 */
+  float linear_damping, angular_damping;
+  mpmhip_script_fn scripted_position; void *position_user;  /* null: a free body */
+  mpmhip_script_fn scripted_rotation; void *rotation_user;
+} mpmhip_rigid_config;
+
+/* 'penalty' and 'pushing_force' of MPM::initialize (src/mpm.cpp:35,40); defaults 0 and 20000 */
+int mpmhip_set_rigid_coupling(mpmhip_ctx *ctx, float penalty, float pushing_force);
+/* triangles: n_triangles x 9 floats (mesh space, before `scale`).  Returns the body's index (>= 1; 0 = background) —
+ * the string add_particles returns for type='rigid' (src/mpm.cpp:82) */
+int mpmhip_add_rigid_body(mpmhip_ctx *ctx, const mpmhip_rigid_config *cfg, int64_t n_triangles, const float *triangles);
+int32_t mpmhip_num_rigid_bodies(const mpmhip_ctx *ctx); /* including the background body: rigids.size() */
+/* out[33]: position 3, rotation quaternion (w,x,y,z) 4, velocity 3, angular velocity 3, mass, inv_mass,
+ * inertia 9 (body frame, row-major), inv_inertia 9 */
+int mpmhip_rigid_get_state(mpmhip_ctx *ctx, int32_t id, float *out);
+int mpmhip_rigid_set_velocity(mpmhip_ctx *ctx, int32_t id, const float *velocity, const float *angular_velocity);
+/* the boundary particles sampled on the body's triangles (RigidBoundaryParticle, src/boundary_particle.h): world
+ * position, offset from the centre of mass in the body frame, body index; id < 0: all bodies.  Returns the count. */
+int64_t mpmhip_rigid_get_samples(mpmhip_ctx *ctx, int32_t id, int64_t capacity, float *position, float *offset, int32_t *body);
+/* phases (parity tests; mpmhip_substep runs them itself): rasterize_rigid_boundary, gather_cdf (needs a sort),
+ * advect_rigid_bodies(base_delta_t) */
+int mpmhip_rasterize_rigid_boundary(mpmhip_ctx *ctx);
+int mpmhip_gather_cdf(mpmhip_ctx *ctx);
+int mpmhip_advect_rigid_bodies(mpmhip_ctx *ctx);
+/* dense (res+1)^3 views of the grid's colored distance field: GridState::states (24 colour bits | body id + 1 << 24,
+ * src/mpm_fwd.h:69-105) and GridState::distance */
+int mpmhip_download_cdf(mpmhip_ctx *ctx, uint32_t *states, float *distance);
+/* gather_cdf's per-particle results, live particles in slot order, 5 floats each: boundary_normal 3, boundary_distance,
+ * near_boundary.  Valid between mpmhip_gather_cdf and the next G2P (a G2P moves the records). */
+int64_t mpmhip_download_boundary(mpmhip_ctx *ctx, float *out, int64_t n_capacity);
 
 #ifdef __cplusplus
 }

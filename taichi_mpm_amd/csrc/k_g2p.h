@@ -26,7 +26,8 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
                                                   const float4 *__restrict__ gridv,
                                                   const uint32_t *__restrict__ fat_slot, Counters *cnt_w,
                                                   uint32_t *__restrict__ key, uint8_t *__restrict__ blk_flag,
-                                                  const LevelSetDev *__restrict__ ls, PhaseBox T, int phase) {
+                                                  const LevelSetDev *__restrict__ ls, PhaseBox T, int phase,
+                                                  const uint8_t *__restrict__ blk_rigid) {
   __shared__ float4 tile[TN];
   __shared__ GroupParams sgroups[G2P_LDS_GROUPS];
   for (int t = threadIdx.x; t < G2P_LDS_GROUPS * (int)(sizeof(GroupParams) / 4); t += NT)
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
         demorton3(act_blk[c.a], bx, by, bz);
         mine = in_phase(T, phase, bx * BS, by * BS, bz * BS, 2 * BS);
       }
+      if (mine && blk_rigid) mine = !blk_rigid[c.a];  // near a rigid body: k_g2p_rigid takes the block (CPIC colour test)
       if (mine) break;
       c.a += gridDim.x;
     }
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
       G0 = make_float4(nx0, nx1, nx2, aux);
       G1 = make_float4(F.m[0], F.m[1], F.m[2], F.m[3]);
       G2 = make_float4(F.m[4], F.m[5], F.m[6], F.m[7]);
-      G3 = make_float4(F.m[8], g3.y, __int_as_float(pid), 0.0f);
+      G3 = make_float4(F.m[8], g3.y, __int_as_float(pid), g3.w);  // (.w: the particle's CPIC colour word travels with it)
       Q0 = make_float4(nx0, nx1, nx2, v0);
       Q1 = make_float4(v1, v2, A[0], A[1]);
       Q2 = make_float4(A[2], A[3], A[4], A[5]);

@@ -101,7 +101,8 @@ __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const floa
                                                             const uint32_t *__restrict__ cell_start,
                                                             const uint32_t *__restrict__ perm,
                                                             const GroupParams *__restrict__ groups,
-                                                            float4 *__restrict__ tiles, Tiling T, int phase) {
+                                                            float4 *__restrict__ tiles, Tiling T, int phase,
+                                                            const uint8_t *__restrict__ blk_rigid) {
   constexpr int NW = NS * PS, NT = 64 * NW;
   __shared__ float4 tile[NW][TN];  // per wave: (m*vx, m*vy, m*vz, m) per node of the block's 6^3 tile
   const uint32_t na = min(cnt->n_active, P.max_blocks);
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const floa
     int bx, by, bz;
     demorton3(act_blk[a], bx, by, bz);
     if (!in_phase(T, phase, bx * BS, by * BS, bz * BS, TS)) continue;  // workgroup-uniform
+    if (blk_rigid && blk_rigid[a]) continue;  // near a rigid body: k_p2g_rigid takes the block (CPIC colour test)
     for (int t = threadIdx.x; t < NW * TN; t += NT) (&tile[0][0])[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();
     const float ox = (float)(bx * BS + cx), oy = (float)(by * BS + cy), oz = (float)(bz * BS + cz);

@@ -1,0 +1,472 @@
+// taichi_mpm_amd/csrc/k_rigid.h — CPIC rigid coupling: bodies, the grid's colored distance field, the particles' colours
+// Part of libmpmhip (see mpmhip.hip for the substep overview and the data layout).
+//
+// Reference: src/rigid_transfer.cpp (rasterize_rigid_boundary :17-115, gather_cdf :121-275), the rigid branches of
+// src/transfer.cpp (block_op_rigid :367-463 and :706-835), src/mpm_rigid_body.cpp (boundary particles :130-252,
+// advect_rigid_bodies :255-286), src/mpm_fwd.h:69-105 (GridState::states = 24 colour-tag bits, 2 per body, + body id).
+//
+// Layout.  A body's surface is sampled by "boundary particles" (offset in the body frame + the triangle they sit on);
+// they are NOT material particles here: they live in their own array and never enter the sort.  The colored distance
+// field exists only near those samples, so it is kept in 4^3-node PAGES handed out from a pool on first touch
+// (cdf.slot[morton(block)] -> page, one CAS per new block) and cleared page by page before the next substep — no pass
+// over the grid, no dependence on the particle blocks.  Per node: `mind` = (distance bits << 32 | body id + 1), updated
+// with one 64-bit atomicMin (= the reference's "closer triangle wins" under its per-node spinlock; ties go to the lower
+// body id instead of the first writer), and `tags` = the colour bits, updated with atomicOr.
+// A material particle's colour word travels in the spare word of its RecG record; the per-substep results of
+// gather_cdf (boundary normal / distance / near flag) go to a side array indexed by slot.
+#pragma once
+#include "mpm_common.h"
+
+namespace mpm {
+
+constexpr int MAX_RIGID = 12;                    // GridState::max_num_rigid_bodies (body 0 = background, no surface)
+constexpr uint32_t CDF_TAG_MASK = 0x00FFFFFFu;   // src/mpm_fwd.h:78-82
+constexpr uint32_t CDF_STATE_MASK = 0xAAAAAAAAu; // src/mpm.h:36 (the "has colour" bit of every body)
+constexpr unsigned long long CDF_EMPTY = ~0ull;
+
+struct RigidBodyDev {
+  float pos[3], vel[3], omega[3];
+  float R[9];      // body -> world, row-major
+  float q[4];      // the same rotation as a quaternion (w, x, y, z)
+  float mass, inv_mass;
+  float inv_I[9];  // body frame, row-major
+  float fric[2];
+  float lin_damp, ang_damp;
+  float axis[3];   // rotation_axis (all zero: unrestricted)
+  int scripted;    // bit 0: position follows a script, bit 1: rotation follows a script
+  float tmp_imp[3], tmp_trq[3];  // impulse / torque (about the centre of mass) collected by a transfer (apply_tmp_impulse)
+};
+struct RigidSample { float off[3]; int body; int elem; };  // boundary particle: offset from the centre of mass, body frame
+struct RigidStep {  // what the host knows about a scripted body for one substep: poses at t and t + dt
+  int has_pos, has_rot;
+  float p0[3], p1[3], q0[4], q1[4];
+};
+struct RigidSteps { RigidStep s[MAX_RIGID]; };
+
+struct CdfDev {
+  uint32_t *slot;            // [8^kbits] Morton(block of 4^3 nodes) -> page, INVALID = none
+  uint32_t *page_key;        // [max_pages] page -> Morton key (for the clear pass)
+  unsigned long long *mind;  // [max_pages * 64]
+  uint32_t *tags;            // [max_pages * 64]
+  uint32_t *n_pages;         // pages handed out this substep
+  uint32_t max_pages;
+  uint32_t *rpage;           // bitmap over the REFERENCE's 4x4x8-node blocks: its rigid_page_map (src/mpm.cpp:1026-1076)
+  int rpd[3];
+  uint32_t *error;           // bit 1: page pool exhausted
+};
+struct BndRec { float n[3]; float dist; uint32_t near; float pad[3]; };  // gather_cdf's per-particle output (32 bytes)
+
+__device__ __forceinline__ void rot_apply(const float R[9], const float v[3], float o[3]) {
+#pragma unroll
+  for (int r = 0; r < 3; r++) o[r] = R[3 * r] * v[0] + R[3 * r + 1] * v[1] + R[3 * r + 2] * v[2];
+}
+__device__ __forceinline__ void cross3(const float a[3], const float b[3], float o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+// RigidBody::get_velocity_at
+__device__ __forceinline__ void rigid_velocity_at(const RigidBodyDev &b, const float p[3], float v[3]) {
+  const float r[3] = {p[0] - b.pos[0], p[1] - b.pos[1], p[2] - b.pos[2]};
+  float w[3];
+  cross3(b.omega, r, w);
+  v[0] = b.vel[0] + w[0]; v[1] = b.vel[1] + w[1]; v[2] = b.vel[2] + w[2];
+}
+// RigidBody::apply_tmp_impulse: impulse and torque sums (the conversion to velocities happens once, in k_rigid_apply_tmp)
+__device__ __forceinline__ void rigid_tmp_impulse(RigidBodyDev *b, const float imp[3], const float at[3]) {
+  const float r[3] = {at[0] - b->pos[0], at[1] - b->pos[1], at[2] - b->pos[2]};
+  float t[3];
+  cross3(r, imp, t);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { atomicAdd(&b->tmp_imp[k], imp[k]); atomicAdd(&b->tmp_trq[k], t[k]); }
+}
+
+// node (i, j, k) of the colored distance field: tags (24 bits), body id of the closest triangle (-1: none), distance (world)
+__device__ __forceinline__ void cdf_node(const CdfDev &C, const Params &P, int i, int j, int k, uint32_t &tags, int &rid, float &dist) {
+  tags = 0; rid = -1; dist = 0.0f;
+  if (i < 0 || j < 0 || k < 0) return;
+  const uint32_t pg = C.slot[morton3(i >> 2, j >> 2, k >> 2)];
+  if (pg == INVALID) return;
+  const size_t n = (size_t)pg * 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3));
+  tags = C.tags[n];
+  const unsigned long long m = C.mind[n];
+  if (m != CDF_EMPTY) {
+    rid = (int)(m & 0xFFu) - 1;
+    dist = __uint_as_float((uint32_t)(m >> 32)) * P.dx;  // (the reference rescales by delta_x after the rasterisation, :77-78)
+  }
+}
+// packed node word of the transfer kernels' LDS tiles: tags | (rid + 1) << 24   (= GridState::states)
+__device__ __forceinline__ uint32_t cdf_node_word(const CdfDev &C, int i, int j, int k) {
+  if (i < 0 || j < 0 || k < 0) return 0u;
+  const uint32_t pg = C.slot[morton3(i >> 2, j >> 2, k >> 2)];
+  if (pg == INVALID) return 0u;
+  const size_t n = (size_t)pg * 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3));
+  const unsigned long long m = C.mind[n];
+  return (C.tags[n] & CDF_TAG_MASK) | (m != CDF_EMPTY ? ((uint32_t)(m & 0xFFu) << 24) : 0u);
+}
+// the colour test of the transfers (src/transfer.cpp:419-423): true = the node belongs to the other side of a body
+__device__ __forceinline__ bool cdf_incompatible(uint32_t node_word, uint32_t pstate) {
+  const uint32_t gs = node_word & CDF_TAG_MASK;
+  const uint32_t mask = (gs & pstate & CDF_STATE_MASK) >> 1;
+  return (gs & mask) != (pstate & mask);
+}
+
+// ---------------------------------------------------------------------------------------------- clear
+// pages handed out by the previous substep: unlink and reset them (then the host zeroes the counter and the page bitmap)
+__global__ __launch_bounds__(256) void k_cdf_clear(CdfDev C) {
+  const uint32_t np = min(*C.n_pages, C.max_pages);
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < np * 64u; t += gridDim.x * blockDim.x) {
+    C.mind[t] = CDF_EMPTY;
+    C.tags[t] = 0u;
+    if ((t & 63u) == 0u) C.slot[C.page_key[t >> 6]] = INVALID;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- rasterize
+// rasterize_rigid_boundary (src/rigid_transfer.cpp:17-78), one thread per boundary particle; also marks the reference's
+// rigid pages (blocks of 4x4x8 nodes) from the block of the particle's base node (src/mpm.cpp:1026-1076)
+__global__ __launch_bounds__(256) void k_cdf_rasterize(Params P, CdfDev C, const RigidBodyDev *__restrict__ rb,
+                                                       const RigidSample *__restrict__ smp, const float *__restrict__ elems,
+                                                       uint32_t n) {
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    const RigidSample S = smp[s];
+    const RigidBodyDev &B = rb[S.body];
+    float w[3];
+    rot_apply(B.R, S.off, w);
+    const float x[3] = {w[0] + B.pos[0], w[1] + B.pos[1], w[2] + B.pos[2]};  // get_anchor_point
+    int base[3];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float X = x[k] * P.idx;
+      ok = ok && X >= 0.5f && X < (float)P.res[k] - 1.5f;
+      base[k] = (int)(X - 0.5f);
+    }
+    if (!ok) continue;  // (the reference refuses boundary particles near the domain wall at creation, :241-246)
+    {  // (the reference's loop runs over ind in {-1,0,1}^3 but keeps only 0 <= ind, src/mpm.cpp:1062-1064: the block itself
+       // and its neighbours in the POSITIVE directions)
+      const int bx = base[0] >> 2, by = base[1] >> 2, bz = base[2] >> 3;
+      for (int a = 0; a <= 1; a++)
+        for (int b = 0; b <= 1; b++)
+          for (int c = 0; c <= 1; c++) {
+            const int px = bx + a, py = by + b, pz = bz + c;
+            if (px < 0 || py < 0 || pz < 0 || px >= C.rpd[0] || py >= C.rpd[1] || pz >= C.rpd[2]) continue;
+            const uint32_t bit = ((uint32_t)px * C.rpd[1] + py) * C.rpd[2] + pz;
+            atomicOr(&C.rpage[bit >> 5], 1u << (bit & 31));
+          }
+    }
+    // world-space triangle and the map world -> (edge coordinates, signed distance): inverse of [e1, e2, n]
+    float v[3][3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      float t[3];
+      rot_apply(B.R, elems + (size_t)S.elem * 9 + 3 * q, t);
+#pragma unroll
+      for (int k = 0; k < 3; k++) v[q][k] = t[k] + B.pos[k];
+    }
+    const float e1[3] = {v[1][0] - v[0][0], v[1][1] - v[0][1], v[1][2] - v[0][2]};
+    const float e2[3] = {v[2][0] - v[0][0], v[2][1] - v[0][1], v[2][2] - v[0][2]};
+    float nn[3];
+    cross3(e1, e2, nn);
+    const float nl = sqrtf(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+    nn[0] /= nl; nn[1] /= nl; nn[2] /= nl;
+    // M = [e1 e2 n] (columns); inverse by the adjugate, row r of M^-1 = cross of the other two columns / det
+    float c12[3], c20[3], c01[3];
+    cross3(e2, nn, c12); cross3(nn, e1, c20); cross3(e1, e2, c01);
+    const float det = e1[0] * c12[0] + e1[1] * c12[1] + e1[2] * c12[2], id = 1.0f / det;
+    const uint32_t body_bits = (uint32_t)S.body * 2u;
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++)
+        for (int c = 0; c < 3; c++) {
+          const int gi = base[0] + a, gj = base[1] + b, gk = base[2] + c;
+          const float d[3] = {gi * P.dx - v[0][0], gj * P.dx - v[0][1], gk * P.dx - v[0][2]};
+          const float u0 = (c12[0] * d[0] + c12[1] * d[1] + c12[2] * d[2]) * id;
+          const float u1 = (c20[0] * d[0] + c20[1] * d[1] + c20[2] * d[2]) * id;
+          const float u2 = (c01[0] * d[0] + c01[1] * d[1] + c01[2] * d[2]) * id;
+          if (!(0.0f <= u0 && 0.0f <= u1 && u0 + u1 <= 1.0f)) continue;
+          const bool negative = u2 < 0.0f;
+          const float dist = fabsf(u2) * P.idx;
+          // the node's page (handed out on first touch)
+          const uint32_t bk = morton3(gi >> 2, gj >> 2, gk >> 2);
+          uint32_t pg = __hip_atomic_load(&C.slot[bk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (pg == INVALID) {
+            const uint32_t mine = atomicAdd(C.n_pages, 1u);
+            if (mine >= C.max_pages) { atomicOr(C.error, 2u); continue; }
+            C.page_key[mine] = bk;  // (a page that loses the race below stays unused this substep; it is cleared like the others)
+            const uint32_t prev = atomicCAS(&C.slot[bk], INVALID, mine);
+            pg = prev == INVALID ? mine : prev;
+          }
+          const size_t node = (size_t)pg * 64 + (((gi & 3) << 4) | ((gj & 3) << 2) | (gk & 3));
+          atomicMin(&C.mind[node], ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned long long)(S.body + 1));
+          atomicOr(&C.tags[node], (2u + (negative ? 1u : 0u)) << body_bits);
+        }
+  }
+}
+
+// is the reference's rigid page holding node-block coordinates (bx, by, bz) of OUR 4^3 blocks set?  (its blocks are
+// 4x4x8 nodes: two of ours stacked in z)
+__device__ __forceinline__ bool rigid_page_of_block(const CdfDev &C, int bx, int by, int bz) {
+  const int pz = bz >> 1;
+  if (bx < 0 || by < 0 || pz < 0 || bx >= C.rpd[0] || by >= C.rpd[1] || pz >= C.rpd[2]) return false;
+  const uint32_t bit = ((uint32_t)bx * C.rpd[1] + by) * C.rpd[2] + pz;
+  return (C.rpage[bit >> 5] >> (bit & 31)) & 1u;
+}
+// active blocks the transfers handle with the colour-aware kernels: block_op_switch, src/transfer.cpp:570-576 — the
+// block's page is in rigid_page_map.  (Blocks outside ignore colours altogether, like the reference's block_op_normal.)
+__global__ __launch_bounds__(256) void k_blk_rigid(Params P, const Counters *__restrict__ cnt, const uint32_t *__restrict__ act_blk,
+                                                   CdfDev C, uint8_t *__restrict__ blk_rigid) {
+  const uint32_t na = min(cnt->n_active, P.max_blocks);
+  for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < na; a += gridDim.x * blockDim.x) {
+    int bx, by, bz;
+    demorton3(act_blk[a], bx, by, bz);
+    blk_rigid[a] = rigid_page_of_block(C, bx, by, bz) ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- gather_cdf
+// 4x4 least-squares system in double precision (the host-side reference build solves it in double as well: the taichi
+// core's own routine is not available, see oracle/taichi_shim); returns |det|, solves A r = y when it exceeds the guard
+__device__ __noinline__ double solve4(const float A[4][4], const float y[4], float r[4], double guard) {
+  double a[4][5];
+  for (int i = 0; i < 4; i++) {
+    for (int j = 0; j < 4; j++) a[i][j] = A[i][j];
+    a[i][4] = y[i];
+  }
+  double det = 1.0;
+  for (int k = 0; k < 4; k++) {
+    int p = k;
+    for (int i = k + 1; i < 4; i++) if (fabs(a[i][k]) > fabs(a[p][k])) p = i;
+    if (a[p][k] == 0.0) return 0.0;
+    if (p != k) {
+      for (int j = 0; j < 5; j++) { const double t = a[k][j]; a[k][j] = a[p][j]; a[p][j] = t; }
+      det = -det;
+    }
+    det *= a[k][k];
+    for (int i = k + 1; i < 4; i++) {
+      const double f = a[i][k] / a[k][k];
+      for (int j = k; j < 5; j++) a[i][j] -= f * a[k][j];
+    }
+  }
+  if (!(fabs(det) > guard)) return fabs(det);
+  double x[4];
+  for (int i = 3; i >= 0; i--) {
+    double s = a[i][4];
+    for (int j = i + 1; j < 4; j++) s -= a[i][j] * x[j];
+    x[i] = s / a[i][i];
+  }
+  for (int i = 0; i < 4; i++) r[i] = (float)x[i];
+  return fabs(det);
+}
+
+// gather_cdf (src/rigid_transfer.cpp:121-275), one thread per particle slot: the particle gains colours from the grid
+// (never changes one it has), then fits (normal, distance) of the boundary to the nodes of its own colour
+__global__ __launch_bounds__(256) void k_gather_cdf(Params P, CdfDev C, RecG *__restrict__ rg, BndRec *__restrict__ bnd,
+                                                    uint32_t *__restrict__ cutting_counter) {
+  const uint32_t n = P.n_slots;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    BndRec out;
+    out.n[0] = out.n[1] = out.n[2] = 0.0f; out.dist = 0.0f; out.near = 0u; out.pad[0] = out.pad[1] = out.pad[2] = 0.0f;
+    if (rg[i].pid < 0) { bnd[i] = out; continue; }
+    const float pos[3] = {rg[i].x[0] * P.idx, rg[i].x[1] * P.idx, rg[i].x[2] * P.idx};
+    {  // rigid_page_map->Test_Page(Linear_Offset(pos.cast<int>()))  (:142-146): elsewhere the colours stay as they are
+      const int px = (int)pos[0] >> 2, py = (int)pos[1] >> 2, pz = (int)pos[2] >> 3;
+      bool on = px >= 0 && py >= 0 && pz >= 0 && px < C.rpd[0] && py < C.rpd[1] && pz < C.rpd[2];
+      if (on) {
+        const uint32_t bit = ((uint32_t)px * C.rpd[1] + py) * C.rpd[2] + pz;
+        on = (C.rpage[bit >> 5] >> (bit & 31)) & 1u;
+      }
+      if (!on) { bnd[i] = out; continue; }
+    }
+    uint32_t pstate = rg[i].pad;
+    int base[3];
+    float w[3][3], rel[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      base[k] = (int)(pos[k] - 0.5f);
+      rel[k] = pos[k] - (float)base[k];
+      bspline_weights(rel[k], w[k]);
+    }
+    uint32_t ntag[27];
+    int nrid[27];
+    float nd[27];
+    uint32_t all_b = 0u;
+#pragma unroll
+    for (int t = 0; t < 27; t++) {
+      cdf_node(C, P, base[0] + t / 9, base[1] + (t / 3) % 3, base[2] + t % 3, ntag[t], nrid[t], nd[t]);
+      all_b |= ntag[t] & CDF_STATE_MASK;
+    }
+    pstate &= (all_b + (all_b >> 1));  // unset the colours of bodies the particle no longer touches (:164)
+    uint32_t to_add = all_b & ~pstate;
+    while (to_add) {
+      const uint32_t bit = to_add & (0u - to_add);
+      to_add ^= bit;
+      float wd[2] = {0.0f, 0.0f};
+#pragma unroll
+      for (int t = 0; t < 27; t++) {
+        if (nrid[t] == -1) continue;
+        const float d = nd[t] * P.idx;
+        const float weight = (w[0][t / 9] * w[1][(t / 3) % 3]) * w[2][t % 3];
+        if (ntag[t] & bit) wd[(ntag[t] & (bit >> 1)) != 0u ? 1 : 0] += d * weight;
+      }
+      if (wd[0] + wd[1] > 1e-7f) {
+        pstate |= bit | ((bit >> 1) * (wd[0] < wd[1] ? 1u : 0u));
+        atomicAdd(cutting_counter, 1u);
+      }
+    }
+    rg[i].pad = pstate;
+    if (pstate != 0u) {
+      float XtX[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, XtY[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 27; t++) {
+        if (nrid[t] == -1) continue;
+        const uint32_t gs = ntag[t];
+        if (gs == 0u) continue;
+        const float dp[3] = {rel[0] - (float)(t / 9), rel[1] - (float)((t / 3) % 3), rel[2] - (float)(t % 3)};
+        const float xp[4] = {-dp[0], -dp[1], -dp[2], 1.0f};
+        const float d = nd[t] * P.idx;
+        const float weight = (w[0][t / 9] * w[1][(t / 3) % 3]) * w[2][t % 3];
+        const uint32_t mask = (gs & pstate & CDF_STATE_MASK) >> 1;
+        float sgn = 0.0f;
+        if ((gs & mask) == (pstate & mask)) sgn = 1.0f;  // same colour
+        else {                                           // exactly one colour differs: the node counts with the negative distance
+          const uint32_t diff = (gs & mask) ^ (pstate & mask);
+          if (diff != 0u && (diff & (diff - 1u)) == 0u) sgn = -1.0f;
+        }
+        if (sgn == 0.0f) continue;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int c = 0; c < 4; c++) XtX[r][c] += (xp[r] * xp[c]) * weight;
+        const float yv[4] = {-d * dp[0], -d * dp[1], -d * dp[2], d};
+#pragma unroll
+        for (int r = 0; r < 4; r++) XtY[r] += (sgn * yv[r]) * weight;
+      }
+      float r4[4] = {0, 0, 0, 0};
+      const double det = solve4(XtX, XtY, r4, 1e-4);  // mpm_reconstruction_guard<3>()
+      if (det > 1e-4) {
+        out.near = 1u;
+        out.dist = r4[3] * P.dx;
+        const float l2 = r4[0] * r4[0] + r4[1] * r4[1] + r4[2] * r4[2];
+        if (l2 > 1e-4f) {
+          const float il = 1.0f / sqrtf(l2);
+          out.n[0] = r4[0] * il; out.n[1] = r4[1] * il; out.n[2] = r4[2] * il;
+        }
+      }
+    }
+    bnd[i] = out;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- the bodies
+// RigidBody::apply_tmp_velocity after a transfer: velocity += impulse / m, omega += R I^-1 R^T torque; sums cleared
+__global__ void k_rigid_apply_tmp(RigidBodyDev *rb, int nb) {
+  const int b = threadIdx.x;
+  if (b < 1 || b >= nb) return;
+  RigidBodyDev &B = rb[b];
+  float t[3], u[3], w[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) B.vel[k] += B.tmp_imp[k] * B.inv_mass;
+  // world inverse inertia applied to the torque: R (I^-1 (R^T torque))
+#pragma unroll
+  for (int c = 0; c < 3; c++) t[c] = B.R[c] * B.tmp_trq[0] + B.R[3 + c] * B.tmp_trq[1] + B.R[6 + c] * B.tmp_trq[2];
+  rot_apply(B.inv_I, t, u);
+  rot_apply(B.R, u, w);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { B.omega[k] += w[k]; B.tmp_imp[k] = 0.0f; B.tmp_trq[k] = 0.0f; }
+}
+
+__device__ __forceinline__ void quat_to_R(const float q[4], float R[9]) {
+  const float w = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+}
+__device__ __forceinline__ void quat_mul(const float a[4], const float b[4], float o[4]) {
+  o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+__device__ __forceinline__ void enforce_axis(RigidBodyDev &B) {  // enforce_angular_velocity_parallel_to (world-frame axis)
+  const float am = fmaxf(fabsf(B.axis[0]), fmaxf(fabsf(B.axis[1]), fabsf(B.axis[2])));
+  if (!(am > 0.1f)) return;
+  const float il = 1.0f / sqrtf(B.axis[0] * B.axis[0] + B.axis[1] * B.axis[1] + B.axis[2] * B.axis[2]);
+  const float a[3] = {B.axis[0] * il, B.axis[1] * il, B.axis[2] * il};
+  const float d = a[0] * B.omega[0] + a[1] * B.omega[1] + a[2] * B.omega[2];
+  B.omega[0] = a[0] * d; B.omega[1] = a[1] * d; B.omega[2] = a[2] * d;
+}
+// advect_rigid_bodies (src/mpm_rigid_body.cpp:255-286): RigidBody::advance (scripted: the pose of the script at t + dt and
+// the secant velocity of the step; free: damping, explicit Euler, exponential map — the conventions of the rigid body
+// the reference build uses, oracle/taichi_shim/taichi/dynamics/rigid_body_shim.h), then gravity as an impulse
+__global__ void k_rigid_advect(RigidBodyDev *rb, int nb, RigidSteps steps, float dt, float g0, float g1, float g2) {
+  const int b = threadIdx.x;
+  if (b < 1 || b >= nb) return;
+  RigidBodyDev &B = rb[b];
+  const RigidStep &S = steps.s[b];
+  enforce_axis(B);
+  if (S.has_pos) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { B.vel[k] = (S.p1[k] - S.p0[k]) / dt; B.pos[k] = S.p1[k]; }
+  } else {
+    const float f = expf(-B.lin_damp * dt);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { B.vel[k] *= f; B.pos[k] += B.vel[k] * dt; }
+  }
+  if (S.has_rot) {
+    const float q0c[4] = {S.q0[0], -S.q0[1], -S.q0[2], -S.q0[3]};
+    float dq[4];
+    quat_mul(S.q1, q0c, dq);
+    if (dq[0] < 0.0f) { dq[0] = -dq[0]; dq[1] = -dq[1]; dq[2] = -dq[2]; dq[3] = -dq[3]; }
+    const float s = sqrtf(dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]);
+    const float ang = 2.0f * atan2f(s, dq[0]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) B.omega[k] = s > 1e-12f ? dq[1 + k] * (ang / (s * dt)) : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) B.q[k] = S.q1[k];
+  } else {
+    const float f = expf(-B.ang_damp * dt);
+#pragma unroll
+    for (int k = 0; k < 3; k++) B.omega[k] *= f;
+    const float len = sqrtf(B.omega[0] * B.omega[0] + B.omega[1] * B.omega[1] + B.omega[2] * B.omega[2]);
+    if (len * dt >= 1e-12f) {
+      const float h = 0.5f * len * dt, sn = sinf(h) / len;
+      const float d[4] = {cosf(h), sn * B.omega[0], sn * B.omega[1], sn * B.omega[2]};
+      float o[4];
+      quat_mul(d, B.q, o);
+      const float nl = 1.0f / sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+#pragma unroll
+      for (int k = 0; k < 4; k++) B.q[k] = o[k] * nl;
+    }
+  }
+  quat_to_R(B.q, B.R);
+  // rigid.apply_impulse(gravity * mass * dt, rigid.position): no torque; a scripted translation has inv_mass = 0
+  B.vel[0] += g0 * B.mass * dt * B.inv_mass; B.vel[1] += g1 * B.mass * dt * B.inv_mass; B.vel[2] += g2 * B.mass * dt * B.inv_mass;
+  enforce_axis(B);
+}
+
+// world positions of the boundary particles (download / tests)
+__global__ __launch_bounds__(256) void k_rigid_sample_positions(const RigidBodyDev *__restrict__ rb, const RigidSample *__restrict__ smp,
+                                                                uint32_t n, float *__restrict__ out) {
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    const RigidBodyDev &B = rb[smp[s].body];
+    float w[3];
+    rot_apply(B.R, smp[s].off, w);
+    out[3 * s] = w[0] + B.pos[0]; out[3 * s + 1] = w[1] + B.pos[1]; out[3 * s + 2] = w[2] + B.pos[2];
+  }
+}
+// dense views of the colored distance field (parity / download only): states word and distance of every node
+__global__ __launch_bounds__(256) void k_cdf_dense(Params P, CdfDev C, uint32_t *__restrict__ states, float *__restrict__ dist) {
+  const uint32_t np = min(*C.n_pages, C.max_pages);
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < np * 64u; t += gridDim.x * blockDim.x) {
+    const uint32_t pg = t >> 6, l = t & 63u;
+    int bx, by, bz;
+    demorton3(C.page_key[pg], bx, by, bz);
+    if (C.slot[C.page_key[pg]] != pg) continue;  // a page that lost the allocation race
+    const int gi = bx * 4 + (int)(l >> 4), gj = by * 4 + (int)((l >> 2) & 3), gk = bz * 4 + (int)(l & 3);
+    if (gi > P.res[0] || gj > P.res[1] || gk > P.res[2]) continue;
+    const size_t idx = ((size_t)gi * (P.res[1] + 1) + gj) * (P.res[2] + 1) + gk;
+    const unsigned long long m = C.mind[t];
+    states[idx] = (C.tags[t] & CDF_TAG_MASK) | (m != CDF_EMPTY ? ((uint32_t)(m & 0xFFu) << 24) : 0u);
+    dist[idx] = m != CDF_EMPTY ? __uint_as_float((uint32_t)(m >> 32)) * P.dx : 0.0f;
+  }
+}
+
+}  // namespace mpm

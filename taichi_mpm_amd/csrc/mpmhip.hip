@@ -66,6 +66,7 @@
 #include "k_grid.h"
 #include "k_tiling.h"
 #include "k_g2p.h"
+#include "k_rigid_transfer.h"
 #include "k_debug.h"
 #include "k_bgeo.h"
 #include "k_mpm88.h"
@@ -150,6 +151,29 @@ struct mpmhip_ctx {
     int32_t *d_blk_limits = nullptr, *d_particle_limits = nullptr;
     int64_t blk_of_cap = 0;
   } async;
+  // CPIC rigid coupling (rigid_api.h): bodies 1.. (0 = background), their boundary particles, the colored distance field
+  struct HostRigid {
+    mpmhip_rigid_config cfg{};
+    float mass = 0.0f, inertia[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, inv_inertia[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int first_sample = 0, n_samples = 0;
+  };
+  struct RigidState {
+    bool enabled = false;
+    std::vector<HostRigid> bodies;
+    RigidBodyDev *d_rb = nullptr;
+    RigidSample *d_smp = nullptr;
+    float *d_elems = nullptr;
+    uint32_t n_smp = 0;
+    std::vector<RigidSample> h_smp;
+    std::vector<float> h_elems;
+    CdfDev cdf{};
+    BndRec *d_bnd = nullptr;
+    uint8_t *d_blk_rigid = nullptr;
+    uint32_t *d_counters = nullptr;  // [0] pages handed out, [1] error bits, [2] cutting_counter
+    uint32_t max_pages = 0;
+    size_t rpage_words = 0;
+    float penalty = 0.0f, pushing_force = 20000.0f;  // MPM::initialize defaults, src/mpm.cpp:35,40
+  } rigid;
   bool overlap = false;        // mpmhip_set_overlap: split tiled substeps into boundary / interior work
   bool ov_active = false, interior_done = false;  // state of the substep in flight
 };
@@ -409,6 +433,8 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   hipFree(c->cell_start); hipFree(c->scan_slots); hipFree(c->ticket); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
   hipFree(c->async.d_tab); hipFree(c->async.d_blk_of); hipFree(c->async.d_blk_limits); hipFree(c->async.d_particle_limits);
   hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_LS); hipFree(c->d_counts); hipFree(c->d_bounds); if (c->h_pinned) hipHostFree(c->h_pinned); hipFree(c->d_energy);
+  { auto &R = c->rigid; hipFree(R.d_rb); hipFree(R.d_smp); hipFree(R.d_elems); hipFree(R.cdf.slot); hipFree(R.cdf.page_key); hipFree(R.cdf.mind);
+    hipFree(R.cdf.tags); hipFree(R.cdf.rpage); hipFree(R.d_bnd); hipFree(R.d_blk_rigid); hipFree(R.d_counters); }
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -659,7 +685,7 @@ static int fetch_records(mpmhip_ctx *c, std::vector<RecG> &hg, std::vector<RecP>
 int mpmhip_download(mpmhip_ctx *c, int32_t field, void *dst, int64_t n_capacity) {
   if (!c || !dst) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
-  if (field < MPMHIP_F_X || field > MPMHIP_F_ID) return fail(c, MPMHIP_EINVAL, "unknown field %d", field);
+  if (field < MPMHIP_F_X || field > MPMHIP_F_STATES) return fail(c, MPMHIP_EINVAL, "unknown field %d", field);
   if (field == MPMHIP_F_B)
     if (int rc = ensure_b_current(c)) return rc;
   std::vector<RecG> hg;
@@ -681,6 +707,7 @@ int mpmhip_download(mpmhip_ctx *c, int32_t field, void *dst, int64_t n_capacity)
       case MPMHIP_F_AUX: f[m] = hg[i].aux; break;
       case MPMHIP_F_GID: q[m] = (int32_t)hg[i].gid; break;
       case MPMHIP_F_ID: q[m] = hg[i].pid; break;
+      case MPMHIP_F_STATES: q[m] = (int32_t)hg[i].pad; break;
     }
     m++;
   }
@@ -690,7 +717,7 @@ int mpmhip_download(mpmhip_ctx *c, int32_t field, void *dst, int64_t n_capacity)
 int mpmhip_upload(mpmhip_ctx *c, int32_t field, const void *src, int64_t n) {
   if (!c || !src) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
-  if (field < MPMHIP_F_X || field > MPMHIP_F_ID || field == MPMHIP_F_GID)
+  if (field < MPMHIP_F_X || field > MPMHIP_F_STATES || field == MPMHIP_F_GID)
     return fail(c, MPMHIP_EINVAL, "field %d cannot be uploaded", field);
   std::vector<RecG> hg;
   std::vector<RecP> hp;
@@ -712,6 +739,7 @@ int mpmhip_upload(mpmhip_ctx *c, int32_t field, const void *src, int64_t n) {
       case MPMHIP_F_B: for (int k = 0; k < 9; k++) hb[i * BW + k] = f[9 * m + k]; break;
       case MPMHIP_F_F: for (int k = 0; k < 9; k++) hg[i].F[k] = f[9 * m + k]; break;
       case MPMHIP_F_AUX: hg[i].aux = f[m]; break;
+      case MPMHIP_F_STATES: hg[i].pad = (uint32_t)q[m]; break;
       case MPMHIP_F_ID:
         hg[i].pid = q[m] < 0 ? 0 : q[m];
         if (hg[i].pid + 1 > c->next_pid) c->next_pid = hg[i].pid + 1;
@@ -783,6 +811,10 @@ static int do_reorder(mpmhip_ctx *c) {
   return MPMHIP_OK;
 }
 
+static inline bool rigid_active(const mpmhip_ctx *c);
+static RigidXfer rigid_xfer(mpmhip_ctx *c);
+static int do_rigid_apply_tmp(mpmhip_ctx *c);
+
 static int do_p2g(mpmhip_ctx *c, int phase = 0) {
   if (!c->affine_valid) {
     hipLaunchKernelGGL(k_affine, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, c->rg, c->rp, c->rb,
@@ -798,8 +830,15 @@ static int do_p2g(mpmhip_ctx *c, int phase = 0) {
     case 12: kern = k_p2g<1, 2, 2>; nt = 128; break;
     default: break;
   }
+  const bool rigid = rigid_active(c);
   hipLaunchKernelGGL(kern, dim3(c->p2g_wgs), dim3(nt), 0, c->stream, c->P,
-                     (const float4 *)c->rp, c->cnt, c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles, c->T, phase);
+                     (const float4 *)c->rp, c->cnt, c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles, c->T, phase,
+                     rigid ? (const uint8_t *)c->rigid.d_blk_rigid : (const uint8_t *)nullptr);
+  if (rigid) {  // blocks near a body (block_op_rigid), then RigidBody::apply_tmp_velocity (src/transfer.cpp:578-580)
+    hipLaunchKernelGGL(k_p2g_rigid, dim3(4096), dim3(64), 0, c->stream, c->P, (const float4 *)c->rp, (const float4 *)c->rg, c->cnt,
+                       c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles, rigid_xfer(c));
+    if (int rc = do_rigid_apply_tmp(c)) return rc;
+  }
   return launch_check(c, "p2g");
 }
 static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
@@ -828,7 +867,14 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0) {
   }
   hipLaunchKernelGGL(kern, dim3(c->g2p_wgs), dim3(nt), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
                      (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
-                     c->blk_flag, (const LevelSetDev *)c->d_LS, phase_box(c->T), phase);
+                     c->blk_flag, (const LevelSetDev *)c->d_LS, phase_box(c->T), phase,
+                     rigid_active(c) ? (const uint8_t *)c->rigid.d_blk_rigid : (const uint8_t *)nullptr);
+  if (rigid_active(c)) {
+    hipLaunchKernelGGL(k_g2p_rigid, dim3(2048), dim3(256), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
+                       (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
+                       c->blk_flag, (const LevelSetDev *)c->d_LS, rigid_xfer(c));
+    if (int rc = do_rigid_apply_tmp(c)) return rc;
+  }
   c->sorted = false;       // positions moved
   c->keys_valid = true;    // ... and their keys / block flags are ready for the next sort
   c->affine_valid = true;  // A was produced together with F
@@ -846,6 +892,8 @@ static int need_sorted(mpmhip_ctx *c, const char *who) {
   if (!c->sorted) return fail(c, MPMHIP_EINVAL, "%s needs sorted particles: call mpmhip_sort first", who);
   return MPMHIP_OK;
 }
+
+#include "rigid_api.h"
 
 int mpmhip_sort(mpmhip_ctx *c) {
   if (!c) return MPMHIP_EINVAL;
@@ -934,6 +982,7 @@ int mpmhip_substep_begin(mpmhip_ctx *c) {
     if (lvl == 1) HIPCHK(c, hipEventRecord(ev->e[0], c->stream));
   }
   if ((rc = do_sort(c))) return rc;
+  if (rigid_active(c) && (rc = do_rigid_pre(c))) return rc;  // rasterize_rigid_boundary, gather_cdf (src/mpm.cpp:466-472,506-508)
   if (ev && (lvl == 1 || lvl == 3)) HIPCHK(c, hipEventRecord(ev->e[1], c->stream));
   if ((rc = do_p2g(c, c->ov_active ? 1 : 0))) return rc;
   if (ev && lvl == 3) HIPCHK(c, hipEventRecord(ev->e[2], c->stream));
@@ -979,6 +1028,7 @@ int mpmhip_substep_end(mpmhip_ctx *c) {  // grid (+ halo sum), G2P
   if ((rc = do_g2p(c, ph))) return rc;
   if (ev && (lvl == 1 || lvl == 2)) HIPCHK(c, hipEventRecord(ev->e[5], c->stream));
   swap_records(c);
+  if (rigid_active(c) && (rc = do_rigid_advect(c, c->P.dt))) return rc;  // src/mpm.cpp:570-572
   c->t += c->P.dt;  // src/mpm.cpp:573
   c->substeps++;
   return MPMHIP_OK;
@@ -1338,6 +1388,7 @@ int mpmhip_profile(mpmhip_ctx *c, char *json, size_t cap) {
 int mpmhip_set_partition(mpmhip_ctx *c, int32_t rank, const int32_t dims[3], const int32_t *cuts_x,
                          const int32_t *cuts_y, const int32_t *cuts_z, int32_t margin) {
   if (!c || !dims || !cuts_x || !cuts_y || !cuts_z) return MPMHIP_EINVAL;
+  if (c->rigid.enabled) return fail(c, MPMHIP_EINVAL, "a ctx with rigid bodies cannot be tiled");
   const int32_t *cuts[3] = {cuts_x, cuts_y, cuts_z};
   Tiling T;
   memset(&T, 0, sizeof T);

@@ -23,8 +23,8 @@ import numpy as np
 from . import _lib
 from .materials import MATERIAL_IDS, group_params, initial_aux
 
-F_X, F_V, F_B, F_F, F_AUX, F_GID, F_ID = range(7)
-_WIDTH = {F_X: 3, F_V: 3, F_B: 9, F_F: 9, F_AUX: 1, F_GID: 1, F_ID: 1}
+F_X, F_V, F_B, F_F, F_AUX, F_GID, F_ID, F_STATES = range(8)
+_WIDTH = {F_X: 3, F_V: 3, F_B: 9, F_F: 9, F_AUX: 1, F_GID: 1, F_ID: 1, F_STATES: 1}
 
 
 class MPMError(RuntimeError):
@@ -106,6 +106,27 @@ def _vec3(v, default):
     return v
 
 
+def load_obj_triangles(path):
+    """triangles (n, 3, 3) of a Wavefront .obj file (v / f records; polygons are fanned) — what the reference loads through
+    taichi's Mesh from `mesh_fn`"""
+    verts, tris = [], []
+    with open(path) as fh:
+        for line in fh:
+            t = line.split()
+            if not t:
+                continue
+            if t[0] == "v":
+                verts.append([float(t[1]), float(t[2]), float(t[3])])
+            elif t[0] == "f":
+                idx = [int(w.split("/")[0]) for w in t[1:]]
+                idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
+                for k in range(1, len(idx) - 1):
+                    tris.append([verts[idx[0]], verts[idx[k]], verts[idx[k + 1]]])
+    if not tris:
+        raise MPMError("no faces in %s" % path)
+    return np.asarray(tris, np.float32)
+
+
 class Simulation3D:
     """MPM<3> (src/mpm.h:56-489) backed by libmpmhip."""
 
@@ -119,6 +140,7 @@ class Simulation3D:
         self.frame = 0
         self.config = {}
         self._n_added = 0
+        self._rigids = []  # ctypes keep-alives (config struct, script callbacks) of the rigid bodies, index = body id - 1
 
     # ---------------------------------------------------------------- lifecycle
     def initialize(self, config):
@@ -155,6 +177,8 @@ class Simulation3D:
         self.verbose_bgeo = bool(cfg.get("verbose_bgeo", False))  # src/visualize.cpp:22
         self.frame_directory = cfg.get("frame_directory")  # injected by the python driver, async_mpm.py:49
         self.frame_count = 0  # src/mpm.h:334
+        self.penalty = float(cfg.get("penalty", 0.0))               # CPIC, src/mpm.cpp:35
+        self.pushing_force = float(cfg.get("pushing_force", 20000.0))  # src/mpm.cpp:40
         self.config = cfg
         return self
 
@@ -179,6 +203,7 @@ class Simulation3D:
         if rc != 0:
             raise MPMError("mpmhip_create failed (%d): %s" % (rc, self._L.mpmhip_last_error(None).decode()))
         self._ctx, self._cfg, self._capacity = ctx, c, int(capacity)
+        self._check(self._L.mpmhip_set_rigid_coupling(self._ctx, self.penalty, self.pushing_force))
         self._apply_levelset()
         for mat, params in self._groups:
             self._check(self._L.mpmhip_add_group(self._ctx, mat, params.ctypes.data_as(C.POINTER(C.c_float))))
@@ -257,8 +282,8 @@ class Simulation3D:
         of scope)."""
         cfg = dict(config)
         ptype = cfg.get("type")
-        if ptype == "rigid":
-            raise MPMError("type='rigid' (CPIC rigid coupling) is outside the scope of this build")
+        if ptype == "rigid":  # src/mpm.cpp:80-83: returns the rigid body's index as a string
+            return str(self.add_rigid_body(cfg))
         if ptype not in MATERIAL_IDS:
             raise MPMError("unknown particle type %r" % (ptype,))
         dx = self.delta_x
@@ -319,6 +344,106 @@ class Simulation3D:
         self._n_added += n
         return ""
 
+    # ---------------------------------------------------------------- CPIC rigid bodies
+    def add_rigid_body(self, cfg):
+        """MPM::add_rigid_particle (src/mpm_rigid_body.cpp:130-252) with the keys of the scene scripts
+        (scripts/mls-cpic/*.py): codimensional (mandatory), density, friction | friction0 + friction1, restitution, scale,
+        initial_position | scripted_position, initial_rotation | scripted_rotation (Euler angles, degrees),
+        initial_velocity, initial_angular_velocity, rotation_axis, linear_damping, angular_damping, recenter,
+        reverse_vertices.  The mesh: mesh=(n, 3, 3) triangles or mesh_fn='file.obj'.  Scripts are callables t -> 3-vector
+        (tc.function13 / tc.constant_function13 of the reference's scenes).  Returns the body's index (>= 1)."""
+        # check_scripting_parameters, src/mpm_rigid_body.cpp:15-56
+        for bad, use in (("scripted", None), ("position", "initial_position"), ("rotation", "initial_rotation")):
+            if bad in cfg:
+                raise MPMError("'%s' is deprecated. Please remove." % bad if use is None else "Use '%s' instead of '%s'." % (use, bad))
+        if "codimensional" not in cfg:
+            raise MPMError("rigid bodies need the key 'codimensional'")
+        if "scripted_position" in cfg and ("initial_position" in cfg or "initial_velocity" in cfg):
+            raise MPMError("scripted_position and initial_position / initial_velocity cannot coexist.")
+        if "scripted_position" not in cfg and "initial_position" not in cfg:
+            raise MPMError("Please specify one (and only one) of 'scripted_position' and 'initial_position'.")
+        if "scripted_rotation" in cfg and ("initial_rotation" in cfg or "initial_angular_velocity" in cfg):
+            raise MPMError("scripted_rotation and initial_rotation / initial_angular_velocity cannot coexist!")
+        if "friction" in cfg and ("friction0" in cfg or "friction1" in cfg):
+            raise MPMError("friction and friction0 / friction1 cannot coexist!")
+        if ("friction0" in cfg) != ("friction1" in cfg):
+            raise MPMError("friction0 and friction1 must be specified simultaneuously.")
+        if "mesh" in cfg:
+            tri = np.ascontiguousarray(cfg["mesh"], np.float32).reshape(-1, 9)
+        elif "mesh_fn" in cfg:
+            tri = load_obj_triangles(cfg["mesh_fn"]).reshape(-1, 9)
+        else:
+            raise MPMError("a rigid body needs mesh=(n, 3, 3) triangles or mesh_fn='file.obj'")
+        r = _lib.RigidConfig()
+        r.codimensional = int(bool(cfg["codimensional"]))
+        r.recenter = int(bool(cfg.get("recenter", True)))
+        r.reverse_vertices = int(bool(cfg.get("reverse_vertices", False)))
+        r.density = float(cfg.get("density", 0.0))
+        f0, f1 = (cfg["friction"],) * 2 if "friction" in cfg else (cfg.get("friction0", 0.0), cfg.get("friction1", 0.0))
+        r.friction[:] = (float(f0), float(f1))
+        r.restitution = float(cfg.get("restitution", 0.0))
+        r.scale[:] = _vec3(cfg.get("scale"), (1.0, 1.0, 1.0))
+        r.initial_position[:] = _vec3(cfg.get("initial_position"), (0, 0, 0))
+        r.initial_rotation[:] = _vec3(cfg.get("initial_rotation"), (0, 0, 0))
+        r.initial_velocity[:] = _vec3(cfg.get("initial_velocity"), (0, 0, 0))
+        r.initial_angular_velocity[:] = _vec3(cfg.get("initial_angular_velocity"), (0, 0, 0))
+        r.rotation_axis[:] = _vec3(cfg.get("rotation_axis"), (0, 0, 0))
+        r.linear_damping = float(cfg.get("linear_damping", 0.0))
+        r.angular_damping = float(cfg.get("angular_damping", 0.0))
+
+        def script(fn):
+            def call(_user, t, out):
+                v = fn(float(t))
+                out[0], out[1], out[2] = float(v[0]), float(v[1]), float(v[2])
+            return _lib.SCRIPT_FN(call)
+        if cfg.get("scripted_position") is not None:
+            r.scripted_position = script(cfg["scripted_position"])
+        if cfg.get("scripted_rotation") is not None:
+            r.scripted_rotation = script(cfg["scripted_rotation"])
+        self._ensure_ctx()
+        rid = self._check(self._L.mpmhip_add_rigid_body(self._ctx, C.byref(r), len(tri), tri.ctypes.data_as(C.POINTER(C.c_float))))
+        self._rigids.append(r)  # keeps the callbacks alive for the life of the simulation
+        self._pinned_by = "rigid bodies (their state lives in the ctx)"
+        return rid
+
+    def get_rigid_state(self, rid):
+        o = np.zeros(33, np.float32)
+        self._check(self._L.mpmhip_rigid_get_state(self._ctx, int(rid), o.ctypes.data_as(C.POINTER(C.c_float))))
+        return dict(position=o[0:3], rotation=o[3:7], velocity=o[7:10], angular_velocity=o[10:13], mass=float(o[13]),
+                    inv_mass=float(o[14]), inertia=o[15:24].reshape(3, 3), inv_inertia=o[24:33].reshape(3, 3))
+
+    def set_rigid_velocity(self, rid, velocity=None, angular_velocity=None):
+        fp = C.POINTER(C.c_float)
+        v = np.ascontiguousarray(velocity, np.float32) if velocity is not None else None
+        w = np.ascontiguousarray(angular_velocity, np.float32) if angular_velocity is not None else None
+        self._check(self._L.mpmhip_rigid_set_velocity(self._ctx, int(rid), v.ctypes.data_as(fp) if v is not None else None,
+                                                      w.ctypes.data_as(fp) if w is not None else None))
+
+    def get_rigid_samples(self, rid=-1):
+        """the boundary particles of a body (all bodies: rid < 0): world position, body-frame offset, body index"""
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        n = self._check(self._L.mpmhip_rigid_get_samples(self._ctx, int(rid), 0, None, None, None))
+        pos, off, body = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.int32)
+        if n:
+            self._check(self._L.mpmhip_rigid_get_samples(self._ctx, int(rid), n, pos.ctypes.data_as(fp), off.ctypes.data_as(fp),
+                                                         body.ctypes.data_as(ip)))
+        return dict(pos=pos, offset=off, body=body)
+
+    def download_cdf(self):
+        """(states, distance) of every grid node, dense (res+1)^3: the colored distance field after rasterize_rigid_boundary"""
+        shp = tuple(r + 1 for r in self.res)
+        st, d = np.zeros(shp, np.uint32), np.zeros(shp, np.float32)
+        self._check(self._L.mpmhip_download_cdf(self._ctx, st.ctypes.data_as(C.POINTER(C.c_uint32)), d.ctypes.data_as(C.POINTER(C.c_float))))
+        return st, d
+
+    def download_boundary(self):
+        """gather_cdf's results per live particle in slot order: dict(normal, distance, near) — valid until the next G2P"""
+        n = self.get_num_particles()
+        o = np.zeros((n, 5), np.float32)
+        m = self._check(self._L.mpmhip_download_boundary(self._ctx, o.ctypes.data_as(C.POINTER(C.c_float)), n))
+        o = o[:m]
+        return dict(normal=o[:, 0:3].copy(), distance=o[:, 3].copy(), near=o[:, 4].astype(np.int32))
+
     def get_num_particles(self):
         if self._ctx is None:
             return self._n_added
@@ -330,8 +455,8 @@ class Simulation3D:
         self._ensure_ctx()
         n = self.get_num_particles()
         out = {}
-        for name, f in (("x", F_X), ("v", F_V), ("B", F_B), ("F", F_F), ("aux", F_AUX), ("gid", F_GID), ("id", F_ID)):
-            dt = np.int32 if f in (F_GID, F_ID) else np.float32
+        for name, f in (("x", F_X), ("v", F_V), ("B", F_B), ("F", F_F), ("aux", F_AUX), ("gid", F_GID), ("id", F_ID), ("states", F_STATES)):
+            dt = np.int32 if f in (F_GID, F_ID, F_STATES) else np.float32
             a = np.zeros((n, _WIDTH[f]), dt)
             got = self._check(self._L.mpmhip_download(self._ctx, f, a.ctypes.data_as(C.c_void_p), n))
             a = a[:got]
@@ -410,6 +535,15 @@ class Simulation3D:
     def resample_optimized(self):
         self._ensure_ctx(); self._check(self._L.mpmhip_g2p(self._ctx))
 
+    def rasterize_rigid_boundary(self):  # src/rigid_transfer.cpp:17-115
+        self._ensure_ctx(); self._check(self._L.mpmhip_rasterize_rigid_boundary(self._ctx))
+
+    def gather_cdf(self):  # src/rigid_transfer.cpp:121-275
+        self._ensure_ctx(); self._check(self._L.mpmhip_gather_cdf(self._ctx))
+
+    def advect_rigid_bodies(self):  # src/mpm_rigid_body.cpp:255-286
+        self._ensure_ctx(); self._check(self._L.mpmhip_advect_rigid_bodies(self._ctx))
+
     def get_grid(self, which=1):
         self._ensure_ctx()
         g = np.zeros((self.res[0] + 1, self.res[1] + 1, self.res[2] + 1, 4), np.float32)
@@ -424,7 +558,7 @@ class Simulation3D:
 
     def upload(self, field, array):
         self._ensure_ctx()
-        a = np.ascontiguousarray(array, np.int32 if field in (F_GID, F_ID) else np.float32)
+        a = np.ascontiguousarray(array, np.int32 if field in (F_GID, F_ID, F_STATES) else np.float32)
         self._check(self._L.mpmhip_upload(self._ctx, field, a.ctypes.data_as(C.c_void_p), len(a)))
 
     # ---------------------------------------------------------------- profiling (TC_PROFILE, src/mpm.cpp:464-572)
