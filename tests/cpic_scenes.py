@@ -1,0 +1,99 @@
+"""Seeded CPIC scenes (a rigid body cutting through / pushing a block of particles) shared by the fixture generator
+(tests/golden/make_golden.py -> ref_cpic.npz) and the tests."""
+import numpy as np
+
+from oracle import oracle as orc
+
+RES, DX, DT = 32, 1.0 / 32, 1e-4
+VOL = DX ** 3 / 8
+MASS = VOL * 400.0
+
+
+def plate(half=0.2):
+    """a square plate in the x-z plane: two triangles"""
+    h = half
+    return np.array([[[-h, 0, -h], [h, 0, -h], [h, 0, h]], [[-h, 0, -h], [h, 0, h], [-h, 0, h]]], np.float32)
+
+
+def box(hx=0.1, hy=0.06, hz=0.12):
+    """a closed box, outward-facing triangles"""
+    c = np.array([[x, y, z] for x in (-hx, hx) for y in (-hy, hy) for z in (-hz, hz)], np.float32)
+    q = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    return np.array([[c[a], c[b], c[d]] for a, b, d, e in q] + [[c[a], c[d], c[e]] for a, b, d, e in q], np.float32)
+
+
+def block_of_particles(lo=10, hi=22, seed=0):
+    rng = np.random.default_rng(seed)
+    g = np.arange(lo, hi) + 0.25
+    X = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    X = np.concatenate([X, X + 0.5])
+    X = X + rng.uniform(-0.2, 0.2, X.shape)
+    v = rng.normal(0, 0.3, X.shape)
+    return (X * DX).astype(np.float32), v.astype(np.float32)
+
+
+# free bodies
+BODIES = {
+    "plate": dict(mesh=plate(), codimensional=True, density=40.0, friction=0.3, initial_position=(0.5, 0.5, 0.5),
+                  initial_rotation=(20.0, 0.0, 10.0)),
+    "box": dict(mesh=box(), codimensional=False, density=400.0, friction0=0.2, friction1=-1.0, initial_position=(0.5, 0.52, 0.5),
+                initial_rotation=(0.0, 30.0, 15.0), initial_velocity=(0.3, -0.5, 0.1), initial_angular_velocity=(0.0, 2.0, 1.0)),
+}
+# a scripted plate: position(t) = P0 + VEL t + AMP sin(OMEGA t), Euler angles(t) = E0 + RATE t (degrees)
+SCRIPT = dict(p0=(0.5, 0.55, 0.5), vel=(0.2, -1.0, 0.0), amp=(0.0, 0.0, 0.02), omega=40.0, e0=(10.0, 0.0, 5.0), rate=(0.0, 90.0, 30.0))
+# (case name, body, material, substeps, simulation config)
+CASES = [("plate_jelly", "plate", "jelly", 5, dict(penalty=1e3)), ("box_jelly", "box", "jelly", 5, dict(penalty=1e3)),
+         ("plate_sand", "plate", "sand", 5, dict(penalty=1e3)), ("box_water", "box", "water", 5, dict(penalty=1e3)),
+         ("scripted_plate_jelly", "scripted", "jelly", 8, dict())]
+
+
+def script_functions():
+    """the scripts as float32 python callables (what a scene script hands to add_particles(type='rigid', ...))"""
+    f32 = np.float32
+    s = SCRIPT
+
+    def pos(t):
+        t = f32(t)
+        return [f32(s["p0"][k]) + f32(s["vel"][k]) * t + f32(s["amp"][k]) * f32(np.sin(f32(s["omega"]) * t)) for k in range(3)]
+
+    def rot(t):
+        t = f32(t)
+        return [f32(s["e0"][k]) + f32(s["rate"][k]) * t for k in range(3)]
+    return pos, rot
+
+
+def group_row(material):
+    return orc.group_params(material, MASS, VOL)[0]
+
+
+def build_reference(refmpm, body, material, **cfg):
+    x, v = block_of_particles()
+    ref = refmpm.Sim(RES, DX, DT, gravity=(0, -10, 0), **cfg)
+    if body == "scripted":
+        s = SCRIPT
+        rid = ref.add_rigid(plate(), script=refmpm.rigid_script(s["p0"], s["vel"], s["amp"], s["omega"], s["e0"], s["rate"]),
+                            codimensional=True, friction=0.4)
+    else:
+        b = dict(BODIES[body])
+        rid = ref.add_rigid(b.pop("mesh"), **b)
+    ref.add_particles(material, MASS, VOL, x, v)
+    return ref, rid
+
+
+def build_device(tm, body, material, **cfg):
+    x, v = block_of_particles()
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(RES,) * 3, delta_x=DX, base_delta_t=DT, gravity=(0, -10, 0),
+                                                       max_particles=len(x) + 16, **cfg))
+    if body == "scripted":
+        pos, rot = script_functions()
+        rid = int(sim.add_particles(dict(type="rigid", mesh=plate(), codimensional=True, friction=0.4, scripted_position=pos,
+                                         scripted_rotation=rot)))
+    else:
+        rid = int(sim.add_particles(dict(type="rigid", **BODIES[body])))
+    sim.add_particles(dict(type=material, positions=x, velocities=v, params=group_row(material)))
+    return sim, rid
+
+
+def rigid_vector(state):
+    """position 3, quaternion 4, velocity 3, angular velocity 3, mass"""
+    return np.concatenate([state["position"], state["rotation"], state["velocity"], state["angular_velocity"], [state["mass"]]]).astype(np.float32)

@@ -223,10 +223,42 @@ def mpm2d_fixture(here):
     print("mpm2d:", len(x), "particles")
 
 
+def cpic_fixture(here):
+    """CPIC rigid coupling (src/rigid_transfer.cpp, src/mpm_rigid_body.cpp, rigid branches of src/transfer.cpp): per case
+    the boundary particles, the colored distance field and the particles' colours after sort + rasterize + gather_cdf,
+    then the particles and the body after n whole substeps"""
+    from tests import cpic_scenes as cs
+    out = {}
+    for name, body, material, n, cfg in cs.CASES:
+        sim, rid = cs.build_reference(ref, body, material, **cfg)
+        out[name + "_body0"] = cs.rigid_vector(sim.rigid_state(rid))
+        out[name + "_inertia"] = sim.rigid_state(rid)["inertia"]
+        out[name + "_samples"] = sim.rigid_samples(rid)["pos"]
+        sim.sort(); sim.rasterize_rigid_boundary()
+        st, d = sim.download_cdf()
+        nz = np.flatnonzero(st.reshape(-1))
+        out[name + "_cdf_idx"], out[name + "_cdf_states"], out[name + "_cdf_dist"] = nz.astype(np.int32), st.reshape(-1)[nz], d.reshape(-1)[nz]
+        sim.gather_cdf()
+        pc = sim.particle_cdf()
+        o = np.argsort(sim.download(by_id=False)["id"], kind="stable")
+        out[name + "_p_states"], out[name + "_p_near"] = pc["states"][o], pc["near"][o].astype(np.int8)
+        out[name + "_p_dist"], out[name + "_p_normal"] = pc["distance"][o], pc["normal"][o]
+        # (the phases above are the first third of a substep; start over for the whole-substep run)
+        sim, rid = cs.build_reference(ref, body, material, **cfg)
+        sim.substep(n)
+        p = sim.download(by_id=True)
+        out[name + "_x"], out[name + "_v"], out[name + "_F"] = p["x"], p["v"], p["F"]
+        o = np.argsort(sim.download(by_id=False)["id"], kind="stable")
+        out[name + "_states"] = sim.particle_cdf()["states"][o]
+        out[name + "_body"] = cs.rigid_vector(sim.rigid_state(rid))
+        print("cpic", name, len(p["x"]), "particles,", len(nz), "coloured nodes,", int((out[name + "_states"] != 0).sum()), "coloured particles")
+    np.savez_compressed(os.path.join(here, "ref_cpic.npz"), **out)
+
+
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     ref.set_threads(1)  # the generic P2G of the reference is racy with more than one thread (SURVEY quirk 5)
-    what = sys.argv[1:] or (list(MATS) + ["materials", "kernels", "shapes", "mpm2d"])
+    what = sys.argv[1:] or (list(MATS) + ["materials", "kernels", "shapes", "mpm2d", "cpic"])
     for w in what:
         if w in MATS:
             substep_fixture(here, w)
@@ -238,6 +270,8 @@ def main():
             shapes_fixture(here)
         elif w == "mpm2d":
             mpm2d_fixture(here)
+        elif w == "cpic":
+            cpic_fixture(here)
 
 
 if __name__ == "__main__":

@@ -240,3 +240,45 @@ def test_live_reference_bgeo_bytes_equal_the_restated_writer(tmp_path, verbose):
     fa = np.frombuffer(got[head:head + n * width], ">f4").reshape(n, 23)[:, 22]
     fb = np.frombuffer(want[head:head + n * width], ">f4").reshape(n, 23)[:, 22]
     assert np.abs(fa - fb).max() <= 3e-7 * np.abs(fb).max()
+
+
+# ---------------------------------------------------------------------------------------------- CPIC rigid coupling
+def test_live_reference_reproduces_its_cpic_fixture():
+    """tests/golden/ref_cpic.npz is what the compiled reference (src/rigid_transfer.cpp, src/mpm_rigid_body.cpp, rigid
+    branches of src/transfer.cpp) produces for the seeded scenes of tests/cpic_scenes.py"""
+    from oracle import refmpm
+    if not refmpm.available():
+        pytest.skip("oracle/_ref/libmpm_ref.so is not built")
+    from tests import cpic_scenes as cs
+    refmpm.set_threads(1)
+    g = np.load(os.path.join(HERE, "golden", "ref_cpic.npz"))
+    for name, body, material, n, cfg in cs.CASES[:2] + cs.CASES[-1:]:
+        sim, rid = cs.build_reference(refmpm, body, material, **cfg)
+        np.testing.assert_array_equal(cs.rigid_vector(sim.rigid_state(rid)), g[name + "_body0"])
+        sim.substep(n)
+        p = sim.download(by_id=True)
+        np.testing.assert_array_equal(p["x"], g[name + "_x"])
+        np.testing.assert_array_equal(p["v"], g[name + "_v"])
+        np.testing.assert_array_equal(cs.rigid_vector(sim.rigid_state(rid)), g[name + "_body"])
+
+
+def test_rigid_body_shim_mass_properties_are_the_textbook_ones():
+    """the rigid body under the compiled reference is OURS (oracle/taichi_shim/.../rigid_body_shim.h): a solid box and a
+    square shell must have their closed-form mass and inertia, whatever the mesh's position before recentring"""
+    from oracle import refmpm
+    if not refmpm.available():
+        pytest.skip("oracle/_ref/libmpm_ref.so is not built")
+    from tests import cpic_scenes as cs
+    hx, hy, hz, rho = 0.1, 0.06, 0.12, 400.0
+    sim = refmpm.Sim(cs.RES, cs.DX, cs.DT)
+    rid = sim.add_rigid(cs.box(hx, hy, hz) + np.float32([0.3, -0.2, 0.1]), codimensional=False, density=rho, initial_position=(0.5, 0.5, 0.5))
+    st = sim.rigid_state(rid)
+    m = rho * 8 * hx * hy * hz
+    assert abs(st["mass"] - m) < 1e-5 * m
+    np.testing.assert_allclose(np.diag(st["inertia"]), m / 3 * np.array([hy * hy + hz * hz, hx * hx + hz * hz, hx * hx + hy * hy]), rtol=1e-5)
+    np.testing.assert_allclose(st["position"], (0.5, 0.5, 0.5), atol=1e-7)  # recentred: the body origin is the centre of mass
+    rid = sim.add_rigid(cs.plate(0.2), codimensional=True, density=40.0, initial_position=(0.5, 0.5, 0.5))
+    st = sim.rigid_state(rid)
+    m = 40.0 * 0.16
+    assert abs(st["mass"] - m) < 1e-5 * m
+    np.testing.assert_allclose(np.diag(st["inertia"]), m * 0.16 / 12 * np.array([1, 2, 1]), rtol=1e-5)
