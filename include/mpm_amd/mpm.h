@@ -8,10 +8,13 @@
 //   apply_grid_boundary_conditions / resample_optimized: the phase functions, one C-ABI call each.
 // All device work happens in the HIP kernels behind the ABI; this header holds no numerics.  Errors throw
 // std::runtime_error with the library's message (reference: TC_ASSERT / TC_ERROR abort).
-// Out of scope, as in DESIGN.md §7: rigid bodies, textures/meshes in add_particles, dynamic level sets, rendering.
+// CPIC rigid bodies: add_rigid_body(config, triangles) = add_particles(type='rigid', ...) with the mesh handed over as
+// triangles; scripted motions are std::function<Vector(real)> like the reference's (src/mpm_rigid_body.cpp:79-92).
+// Out of scope, as in DESIGN.md §7: textures/meshes in add_particles (the mesh LOADER), rigid-rigid collisions, joints, rendering.
 #pragma once
 #include <algorithm>
 #include <cstdio>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -70,6 +73,8 @@ class MPM<3> {
     verbose_bgeo = config.get("verbose_bgeo", false);   // src/visualize.cpp:22
     frame_directory = config.get("frame_directory", "");  // injected by the python driver, async_mpm.py:49
     check(mpmhip_create(&cfg_, &ctx_), nullptr);
+    // CPIC coupling constants (src/mpm.cpp:35,40)
+    check(mpmhip_set_rigid_coupling(ctx_, config.get("penalty", 0.0f), config.get("pushing_force", 20000.0f)), ctx_);
     frame = 0;
     frame_count = 0;
   }
@@ -118,9 +123,59 @@ class MPM<3> {
     return add_particles(config, (int64_t)x.size() / 3, x.data(), nullptr, maximum);
   }
 
+  // --- add_particles(type='rigid') (src/mpm.cpp:80-83 -> MPM::add_rigid_particle, src/mpm_rigid_body.cpp:130-252): the
+  // mesh is handed over as n_triangles x 9 floats; config keys as in the scene scripts (codimensional is mandatory;
+  // density, friction | friction0 + friction1, restitution, scale, initial_position, initial_rotation (Euler, degrees),
+  // initial_velocity, initial_angular_velocity, rotation_axis, linear_damping, angular_damping, recenter,
+  // reverse_vertices).  Scripted motions: t -> position, t -> Euler angles in degrees.  Returns the body's index as the
+  // reference does (a string, >= "1").
+  using ScriptFunction = std::function<Vector(real)>;
+  std::string add_rigid_body(const Config &config, int64_t n_triangles, const float *triangles, ScriptFunction scripted_position = nullptr,
+                             ScriptFunction scripted_rotation = nullptr) {
+    if (!config.has_key("codimensional")) throw std::runtime_error("rigid bodies need the key 'codimensional'");
+    if (config.has_key("friction") && (config.has_key("friction0") || config.has_key("friction1")))
+      throw std::runtime_error("friction and friction0 / friction1 cannot coexist!");  // src/mpm_rigid_body.cpp:41-55
+    if (!scripted_position && !config.has_key("initial_position"))
+      throw std::runtime_error("Please specify one (and only one) of 'scripted_position' and 'initial_position'.");
+    mpmhip_rigid_config r{};
+    r.codimensional = config.get("codimensional", true);
+    r.recenter = config.get("recenter", true);
+    r.reverse_vertices = config.get("reverse_vertices", false);
+    r.density = config.get("density", 0.0f);
+    r.friction[0] = config.get("friction0", config.get("friction", 0.0f));
+    r.friction[1] = config.get("friction1", config.get("friction", 0.0f));
+    r.restitution = config.get("restitution", 0.0f);
+    auto vec = [&](const char *key, const Vector &d, float *out) { const Vector v = config.get_vec(key, d); for (int k = 0; k < 3; k++) out[k] = v[k]; };
+    vec("scale", Vector(1.0f, 1.0f, 1.0f), r.scale);
+    vec("initial_position", Vector(0.0f, 0.0f, 0.0f), r.initial_position);
+    vec("initial_rotation", Vector(0.0f, 0.0f, 0.0f), r.initial_rotation);
+    vec("initial_velocity", Vector(0.0f, 0.0f, 0.0f), r.initial_velocity);
+    vec("initial_angular_velocity", Vector(0.0f, 0.0f, 0.0f), r.initial_angular_velocity);
+    vec("rotation_axis", Vector(0.0f, 0.0f, 0.0f), r.rotation_axis);
+    r.linear_damping = config.get("linear_damping", 0.0f);
+    r.angular_damping = config.get("angular_damping", 0.0f);
+    // the library calls back once per scripted body and substep; the std::function objects live as long as this MPM
+    auto trampoline = [](void *user, float t, float out[3]) {
+      const Vector v = (*static_cast<ScriptFunction *>(user))(t);
+      for (int k = 0; k < 3; k++) out[k] = v[k];
+    };
+    if (scripted_position) { scripts_.push_back(std::make_unique<ScriptFunction>(std::move(scripted_position))); r.scripted_position = trampoline; r.position_user = scripts_.back().get(); }
+    if (scripted_rotation) { scripts_.push_back(std::make_unique<ScriptFunction>(std::move(scripted_rotation))); r.scripted_rotation = trampoline; r.rotation_user = scripts_.back().get(); }
+    const int id = mpmhip_add_rigid_body(ctx_, &r, n_triangles, triangles);
+    check(id, ctx_);
+    return std::to_string(id);
+  }
+  bool has_rigid_body() const { return mpmhip_num_rigid_bodies(ctx_) > 1; }  // src/mpm.h:240-242
+  // position 3, rotation quaternion (w,x,y,z) 4, velocity 3, angular velocity 3, mass, inv_mass, inertia 9, inv_inertia 9
+  std::vector<float> get_rigid_state(int id) const {
+    std::vector<float> o(33);
+    check(mpmhip_rigid_get_state(ctx_, id, o.data()), ctx_);
+    return o;
+  }
+
   std::string add_particles(const Config &config, int64_t n, const float *x, const float *v, float maximum = 0) {
     const std::string type = config.get("type", "");
-    if (type == "rigid") throw std::runtime_error("type='rigid' (CPIC rigid coupling) is outside the scope of this build");
+    if (type == "rigid") throw std::runtime_error("type='rigid': hand the mesh over with add_rigid_body(config, n_triangles, triangles)");
     if (maximum <= 0) maximum = config.get("ppc", config.get("maximum", 8.0f));
     const float vol = delta_x * delta_x * delta_x / maximum;  // :134-135
     const float mass = vol * config.get("density", 400.0f);
@@ -260,6 +315,7 @@ class MPM<3> {
   mpmhip_ctx *ctx_ = nullptr;
   mpmhip_config cfg_{};
   std::vector<ParticleType> types_;
+  std::vector<std::unique_ptr<ScriptFunction>> scripts_;  // scripted motions of rigid bodies (called back by the library)
 };
 
 using MPM3D = MPM<3>;

@@ -1138,6 +1138,8 @@ int mpmhip_snapshot_save(mpmhip_ctx *c, void *dst, size_t cap) {
   if (!c || !dst) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   if (c->in_substep) return fail(c, MPMHIP_EINVAL, "snapshot inside a substep");
+  if (c->rigid.enabled && c->rigid.bodies.size() > 1)
+    return fail(c, MPMHIP_ENOTIMPL, "snapshots do not carry rigid bodies (meshes, scripts and poses would have to come from the scene again)");
   if (cap < snapshot_bytes(c)) return fail(c, MPMHIP_ECAPACITY, "snapshot buffer too small: %zu < %zu", cap, snapshot_bytes(c));
   Counters hc;
   int rc = read_counters(c, hc);

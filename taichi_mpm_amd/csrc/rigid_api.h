@@ -248,6 +248,7 @@ int mpmhip_add_rigid_body(mpmhip_ctx *c, const mpmhip_rigid_config *cfg, int64_t
   const float dx = c->P.dx;
   const size_t elem0 = R.h_elems.size() / 9;
   B.first_sample = (int)R.h_smp.size();
+  int32_t allocated = 0;
   for (int64_t e = 0; e < n_triangles; e++) {
     const float *v0 = &tri[9 * e], *v1 = v0 + 3, *v2 = v0 + 6;
     float a[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]}, b[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
@@ -267,9 +268,13 @@ int mpmhip_add_rigid_body(mpmhip_ctx *c, const mpmhip_rigid_config *cfg, int64_t
           w[r] = (D.R[3 * r] * s.off[0] + D.R[3 * r + 1] * s.off[1] + D.R[3 * r + 2] * s.off[2] + D.pos[r]) * c->P.idx;
           near_wall = near_wall || w[r] < 7.0f || w[r] - (float)c->P.res[r] > -7.0f;
         }
+        allocated++;
         if (!near_wall) R.h_smp.push_back(s);
       }
   }
+  // every boundary particle took a creation id from the same counter as the material particles
+  // (allocator.allocate_particle, src/particle_allocator.h:68-74): later material particles are numbered behind them
+  c->next_pid += allocated;
   B.n_samples = (int)R.h_smp.size() - B.first_sample;
   R.h_elems.insert(R.h_elems.end(), tri.begin(), tri.end());
   // (re)upload samples and elements

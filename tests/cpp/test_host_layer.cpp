@@ -192,6 +192,26 @@ static void gpu_tests() {
     demo.advance(200);
     CHECK(demo.particles()[1500].x[1] < 0.65f + 0.08f);
   }
+  {  // CPIC: add_particles(type='rigid') — a scripted plate pushed down through a block of jelly
+    auto sim4 = create_simulation3("mpm");
+    sim4->initialize(Config().set("res", Vector3i(32, 32, 32)).set("base_delta_t", 1e-4).set("gravity", Vector3(0, -10, 0))
+                         .set("max_particles", 100000.0));
+    const float h = 0.2f;
+    const float tri[18] = {-h, 0, -h, h, 0, -h, h, 0, h, -h, 0, -h, h, 0, h, -h, 0, h};
+    const std::string id = sim4->add_rigid_body(Config().set("codimensional", true).set("friction", 0.3), 2, tri,
+                                                [](real t) { return Vector3(0.5f, 0.55f - 1.0f * t, 0.5f); });
+    CHECK(id == "1" && sim4->has_rigid_body());
+    sim4->add_particles(Config().set("type", "jelly").set("cube_lo", 10).set("cube_hi", 22));
+    for (int i = 0; i < 20; i++) sim4->substep();
+    sim4->synchronize();
+    const auto st = sim4->get_rigid_state(1);
+    CHECK(std::fabs(st[1] - (0.55f - 20e-4f)) < 1e-6f);  // on its script
+    CHECK(std::fabs(st[8] + 1.0f) < 1e-3f);              // moving with the script's secant velocity
+    CHECK(st[14] == 0.0f);                               // a scripted translation answers impulses with infinite mass
+    double below = 0, above = 0;  // the plate separates the block: particles under it are pushed down faster than those above
+    for (auto &q : sim4->get_render_particles()) (q.position[1] < st[1] ? below : above) += 1;
+    CHECK(below > 1000 && above > 1000);
+  }
   // device constitutive code through the particle surface: F = I => zero force; plasticity(cdg) = F <- cdg F for jelly
   MPMParticle p;
   p.type = create_particle_type("jelly", Config(), 1.0f, 1e-6f);

@@ -137,6 +137,7 @@ def test_live_reference_agrees_with_the_device_on_a_longer_run(tm):
     sim.run_substeps(40)
     r, h = ref.download(by_id=True), sim.get_particles(sort_by_id=True)
     assert len(r["x"]) == len(h["x"])
+    np.testing.assert_array_equal(h["id"], r["id"])  # creation ids count the boundary particles, as the reference's allocator does
     assert np.abs(h["x"] - r["x"]).max() <= 5e-5
     assert rel_l2(h["v"], r["v"]) <= 2e-3
     a, b = cs.rigid_vector(ref.rigid_state(rid)), cs.rigid_vector(sim.get_rigid_state(rid))
