@@ -17,7 +17,8 @@ _LIB = os.path.join(_LIBDIR, "libmpmhip%s.so" % (("_" + _VARIANT) if _VARIANT el
 
 NPARAM = 16
 
-# (-munsafe-fp-atomics only matters to the 2D demo's global float atomics, k_mpm88.h: the 3D path has no float atomics)
+# (-munsafe-fp-atomics: hardware float atomics for the 2D solvers' grid scatter (k_mpm88.h, k_mpm2d.h) and for the impulses a
+# particle hands to a rigid body (k_rigid.h); the 3D transfers themselves use no float atomics)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics",
                "-Wno-unused-value"]
 

@@ -15,7 +15,10 @@ namespace mpm {
 // reorder_interval, with fully sequential record stores; particles deleted by an earlier substep drop out, so the live
 // records always occupy the slots [0, n_sorted).
 constexpr int G2P_LDS_GROUPS = MPMHIP_MAX_GROUPS;  // the ctx's group capacity: the whole table is mirrored in LDS (5 KiB)
-template <int NT, int MINW, bool ROLL, bool STORE_B>
+// RIGID: CPIC rigid bodies exist — blocks flagged in blk_rigid are left to k_g2p_rigid and the records' spare word (the
+// particle's colour) is carried along.  A compile-time switch: the instantiation without it is the kernel tuned above,
+// instruction for instruction.
+template <int NT, int MINW, bool ROLL, bool STORE_B, bool RIGID = false>
 __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__restrict__ rg, float4 *__restrict__ rg_out,
                                                   float4 *__restrict__ rp_out, float4 *__restrict__ rb_out,
                                                   const Counters *__restrict__ cnt,
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
         demorton3(act_blk[c.a], bx, by, bz);
         mine = in_phase(T, phase, bx * BS, by * BS, bz * BS, 2 * BS);
       }
-      if (mine && blk_rigid) mine = !blk_rigid[c.a];  // near a rigid body: k_g2p_rigid takes the block (CPIC colour test)
+      if constexpr (RIGID) { if (mine) mine = !blk_rigid[c.a]; }  // near a rigid body: k_g2p_rigid takes the block (CPIC colour test)
       if (mine) break;
       c.a += gridDim.x;
     }
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
       G0 = make_float4(nx0, nx1, nx2, aux);
       G1 = make_float4(F.m[0], F.m[1], F.m[2], F.m[3]);
       G2 = make_float4(F.m[4], F.m[5], F.m[6], F.m[7]);
-      G3 = make_float4(F.m[8], g3.y, __int_as_float(pid), g3.w);  // (.w: the particle's CPIC colour word travels with it)
+      G3 = make_float4(F.m[8], g3.y, __int_as_float(pid), RIGID ? g3.w : 0.0f);  // (.w: the particle's CPIC colour word travels with it)
       Q0 = make_float4(nx0, nx1, nx2, v0);
       Q1 = make_float4(v1, v2, A[0], A[1]);
       Q2 = make_float4(A[2], A[3], A[4], A[5]);

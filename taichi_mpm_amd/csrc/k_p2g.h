@@ -94,7 +94,7 @@ __device__ __forceinline__ void p2g_cell(const Params &P, const float4 *__restri
 // NS = waves splitting the 27 stencil nodes (1 or 2), PS = waves splitting every cell's particles (1, 2 or 4):
 // NS*PS wavefronts per block, each with its own LDS tile.  Node splitting halves the accumulator registers
 // (occupancy) but both halves load the same records; particle splitting keeps every record load unique.
-template <int NS, int PS, int MINW>
+template <int NS, int PS, int MINW, bool RIGID = false>  // RIGID: skip the blocks flagged in blk_rigid (k_p2g_rigid takes them)
 __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const float4 *__restrict__ rp,
                                                             const Counters *__restrict__ cnt,
                                                             const uint32_t *__restrict__ act_blk,
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const floa
     int bx, by, bz;
     demorton3(act_blk[a], bx, by, bz);
     if (!in_phase(T, phase, bx * BS, by * BS, bz * BS, TS)) continue;  // workgroup-uniform
-    if (blk_rigid && blk_rigid[a]) continue;  // near a rigid body: k_p2g_rigid takes the block (CPIC colour test)
+    if constexpr (RIGID) { if (blk_rigid[a]) continue; }  // near a rigid body: k_p2g_rigid takes the block (CPIC colour test)
     for (int t = threadIdx.x; t < NW * TN; t += NT) (&tile[0][0])[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();
     const float ox = (float)(bx * BS + cx), oy = (float)(by * BS + cy), oz = (float)(bz * BS + cz);

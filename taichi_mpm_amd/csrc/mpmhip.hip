@@ -831,6 +831,7 @@ static int do_p2g(mpmhip_ctx *c, int phase = 0) {
     default: break;
   }
   const bool rigid = rigid_active(c);
+  if (rigid) { kern = k_p2g<1, 1, 2, true>; nt = 64; }
   hipLaunchKernelGGL(kern, dim3(c->p2g_wgs), dim3(nt), 0, c->stream, c->P,
                      (const float4 *)c->rp, c->cnt, c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles, c->T, phase,
                      rigid ? (const uint8_t *)c->rigid.d_blk_rigid : (const uint8_t *)nullptr);
@@ -865,6 +866,7 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0) {
     case 23: kern = sb ? k_g2p<128, 3, true, true> : k_g2p<128, 3, true, false>; nt = 128; break;
     default: break;
   }
+  if (rigid_active(c)) { kern = sb ? k_g2p<256, 2, true, true, true> : k_g2p<256, 2, true, false, true>; nt = 256; }
   hipLaunchKernelGGL(kern, dim3(c->g2p_wgs), dim3(nt), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
                      (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
                      c->blk_flag, (const LevelSetDev *)c->d_LS, phase_box(c->T), phase,
