@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_bgeo_rows(uint32_t n, const uint32_t *_
       // get_debug_info(): (0, material number, 0); water (j, 5, sticky = 0); elastic (E, 8, 0) (src/particles.cpp:157..839)
       const float d0 = gp.type == MPMHIP_WATER ? g.aux : gp.type == MPMHIP_ELASTIC ? gp.p[4] : 0.0f;
       w[16] = be(d0); w[17] = be((float)gp.type); w[18] = be(0.0f);
-      w[19] = be(0); w[20] = be(0.0f); w[21] = be(0);
+      w[19] = be((int32_t)g.pad); w[20] = be(0.0f); w[21] = be(0);  // states = the CPIC colour word (0 without rigid bodies)
       const float *b = rb + (size_t)s * BW;  // || 0.5 (apic_b - apic_b^T) ||_F   (visualize.cpp:70-71)
       float sum = 0.0f;
 #pragma unroll

@@ -178,21 +178,32 @@ __global__ __launch_bounds__(256) void k_rank(Params P, uint32_t *__restrict__ k
   if (threadIdx.x == 0) s_heads = 0u;
   uint32_t my_heads = 0u;  // lane 0 of each wave counts its wave's runs
   if (mode == 0u) {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t nloop = (n + stride - 1) / stride;
-    for (uint32_t it = 0; it < nloop; it++) {  // uniform trip count: every lane takes part in the shuffles
-      const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
-      const uint32_t c = rank_cidx(P, key, bits, wprefix, i, n);
-      int start, end;
-      unsigned long long H;
-      lane_run(c, lane, start, end, H);
-      my_heads += (uint32_t)__popcll(H);
-      uint32_t base = 0;
-      if ((int)lane == start && c != INVALID) base = atomicAdd(&cell_cnt[c], (uint32_t)(end - start));
-      base = __shfl(base, start);
-      if (i < n) {
-        key[i] = c;
-        rank[i] = base + (lane - (uint32_t)start);
+    // a workgroup takes batches of RANK_BATCH consecutive slots, RANK_PER_THREAD per thread: the keys, the block-table
+    // lookups and the returning atomics of a thread's slots are issued back to back, so their round trips overlap
+    // (C3, 8 M particles: sort 0.092 -> 0.087 ms on the lattice against one dependent chain per slot; A/B on one box)
+    const uint32_t nbatch = (n + RANK_BATCH - 1) / RANK_BATCH;
+    for (uint32_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
+      uint32_t cidx[RANK_PER_THREAD], base[RANK_PER_THREAD];
+      int start[RANK_PER_THREAD];
+#pragma unroll
+      for (int u = 0; u < RANK_PER_THREAD; u++) cidx[u] = rank_cidx(P, key, bits, wprefix, b * RANK_BATCH + u * 256 + threadIdx.x, n);
+#pragma unroll
+      for (int u = 0; u < RANK_PER_THREAD; u++) {
+        int end;
+        unsigned long long H;
+        lane_run(cidx[u], lane, start[u], end, H);
+        my_heads += (uint32_t)__popcll(H);
+        base[u] = 0;
+        if ((int)lane == start[u] && cidx[u] != INVALID) base[u] = atomicAdd(&cell_cnt[cidx[u]], (uint32_t)(end - start[u]));
+      }
+#pragma unroll
+      for (int u = 0; u < RANK_PER_THREAD; u++) {
+        const uint32_t i = b * RANK_BATCH + u * 256 + threadIdx.x;
+        const uint32_t r = __shfl(base[u], start[u]) + (lane - (uint32_t)start[u]);
+        if (i < n) {
+          key[i] = cidx[u];
+          rank[i] = r;
+        }
       }
     }
     __syncthreads();

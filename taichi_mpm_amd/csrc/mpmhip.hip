@@ -165,6 +165,7 @@ struct mpmhip_ctx {
     float *d_elems = nullptr;
     uint32_t n_smp = 0;
     std::vector<RigidSample> h_smp;
+    std::vector<int32_t> h_smp_id;  // creation id of every boundary particle (they share the material particles' counter)
     std::vector<float> h_elems;
     CdfDev cdf{};
     BndRec *d_bnd = nullptr;
@@ -269,7 +270,7 @@ size_t bgeo_bytes(uint32_t n, bool verbose) {
 }  // namespace
 
 // live particles in ascending creation id (write_partio sorts by id, src/visualize.cpp:39-43) -> slot list
-static int bgeo_order(mpmhip_ctx *c, std::vector<uint32_t> &order) {
+static int bgeo_order(mpmhip_ctx *c, std::vector<uint32_t> &order, std::vector<int32_t> *ids_out = nullptr) {
   order.clear();
   const size_t ns = (size_t)c->n_slots;
   if (!ns) return MPMHIP_OK;
@@ -291,7 +292,8 @@ static int bgeo_order(mpmhip_ctx *c, std::vector<uint32_t> &order) {
     last = ids[s];
     max_id = std::max(max_id, ids[s]);
   }
-  if (ascending) return MPMHIP_OK;  // slots are handed out in creation order: true until the first physical reorder
+  auto finish = [&]() { if (ids_out) { ids_out->resize(order.size()); for (size_t j = 0; j < order.size(); j++) (*ids_out)[j] = ids[order[j]]; } return MPMHIP_OK; };
+  if (ascending) return finish();  // slots are handed out in creation order: true until the first physical reorder
   if ((size_t)max_id < 16 * order.size() + 1024) {  // ids are unique: a direct table, swept in id order
     std::vector<uint32_t> slot_of(max_id + 1, 0xFFFFFFFFu);
     for (uint32_t s : order) slot_of[ids[s]] = s;
@@ -301,7 +303,7 @@ static int bgeo_order(mpmhip_ctx *c, std::vector<uint32_t> &order) {
   } else {
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
   }
-  return MPMHIP_OK;
+  return finish();
 }
 
 extern "C" {
@@ -1243,8 +1245,9 @@ int mpmhip_delete_particles_inside_level_set(mpmhip_ctx *c, int64_t *deleted) {
 // ---------------------------------------------------------------------------------------------- .bgeo frames
 int mpmhip_bgeo_size(mpmhip_ctx *c, int32_t verbose, size_t *bytes) {
   if (!c || !bytes) return MPMHIP_EINVAL;
-  const int64_t n = mpmhip_num_particles(c);
+  int64_t n = mpmhip_num_particles(c);
   if (n < 0) return (int)n;
+  if (c->rigid.enabled) n += (int64_t)c->rigid.h_smp.size();  // the boundary particles of rigid bodies are rows too (type = 1)
   *bytes = bgeo_bytes((uint32_t)n, verbose != 0);
   return MPMHIP_OK;
 }
@@ -1255,8 +1258,11 @@ int mpmhip_bgeo_encode(mpmhip_ctx *c, int32_t verbose, void *dst, size_t capacit
   if (verbose)
     if (int rc = ensure_b_current(c)) return rc;
   std::vector<uint32_t> order;
-  if (int rc = bgeo_order(c, order)) return rc;
-  const uint32_t n = (uint32_t)order.size();
+  std::vector<int32_t> ids;
+  const bool with_rigid = c->rigid.enabled && !c->rigid.h_smp.empty();
+  if (int rc = bgeo_order(c, order, with_rigid ? &ids : nullptr)) return rc;
+  const uint32_t nm = (uint32_t)order.size();  // material particles
+  const uint32_t n = nm + (with_rigid ? (uint32_t)c->rigid.h_smp.size() : 0u);
   const size_t total = bgeo_bytes(n, verbose != 0);
   int32_t *limits = nullptr;  // async stepping: per-slot (dt_limit, stiffness_limit, cfl_limit) of the particle's block
   if (c->async.enabled && c->async.limits_valid) limits = c->async.d_particle_limits;
@@ -1266,27 +1272,61 @@ int mpmhip_bgeo_encode(mpmhip_ctx *c, int32_t verbose, void *dst, size_t capacit
   const std::vector<uint8_t> head = bgeo_header(n, verbose != 0);
   std::memcpy(out, head.data(), head.size());
   out += head.size();
-  const size_t row_bytes = (size_t)n * (verbose ? BGEO_W_VERBOSE : BGEO_W_PLAIN) * 4;
-  if (n) {
+  const size_t W = verbose ? BGEO_W_VERBOSE : BGEO_W_PLAIN;
+  const size_t row_bytes = (size_t)n * W * 4, mat_bytes = (size_t)nm * W * 4;
+  std::vector<uint8_t> mat_rows;  // with rigid bodies the material rows are merged with the boundary particles' by creation id
+  uint8_t *mat_dst = out;
+  if (with_rigid) { mat_rows.resize(mat_bytes); mat_dst = mat_rows.data(); }
+  if (nm) {
     uint32_t *d_order = nullptr, *d_rows = nullptr;
-    hipError_t e = dmalloc(&d_order, (size_t)n);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_rows, row_bytes);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    hipError_t e = dmalloc(&d_order, (size_t)nm);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_rows, mat_bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_order, order.data(), (size_t)nm * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-      const dim3 grid(particle_grid(n)), wg(256);
+      const dim3 grid(particle_grid(nm)), wg(256);
       if (verbose)
-        hipLaunchKernelGGL(k_bgeo_rows<true>, grid, wg, 0, c->stream, n, (const uint32_t *)d_order, (const RecG *)c->rg,
+        hipLaunchKernelGGL(k_bgeo_rows<true>, grid, wg, 0, c->stream, nm, (const uint32_t *)d_order, (const RecG *)c->rg,
                            (const RecP *)c->rp, (const float *)c->rb, (const GroupParams *)c->d_groups, (const int32_t *)limits, d_rows);
       else
-        hipLaunchKernelGGL(k_bgeo_rows<false>, grid, wg, 0, c->stream, n, (const uint32_t *)d_order, (const RecG *)c->rg,
+        hipLaunchKernelGGL(k_bgeo_rows<false>, grid, wg, 0, c->stream, nm, (const uint32_t *)d_order, (const RecG *)c->rg,
                            (const RecP *)c->rp, (const float *)c->rb, (const GroupParams *)c->d_groups, (const int32_t *)limits, d_rows);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(out, d_rows, row_bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(mat_dst, d_rows, mat_bytes, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d_order);
     (void)hipFree(d_rows);
     HIPCHK(c, e);
+  }
+  if (with_rigid) {
+    // rows of the boundary particles (RigidBoundaryParticle, src/boundary_particle.h): position = anchor point, type = 1,
+    // v = body velocity at the anchor (align_with_rigid_body); every other field keeps MPMParticle's constructor value
+    auto &R = c->rigid;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<RigidBodyDev> hb(MAX_RIGID);
+    HIPCHK(c, hipMemcpy(hb.data(), R.d_rb, sizeof(RigidBodyDev) * MAX_RIGID, hipMemcpyDeviceToHost));
+    auto be32 = [](uint8_t *p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; };
+    auto bef = [&](uint8_t *p, float f) { uint32_t u; std::memcpy(&u, &f, 4); be32(p, u); };
+    size_t im = 0, ir = 0;
+    uint8_t *row = out;
+    for (uint32_t j = 0; j < n; j++, row += W * 4) {
+      const bool take_rigid = ir < R.h_smp.size() && (im >= nm || R.h_smp_id[ir] < ids[im]);
+      if (!take_rigid) { std::memcpy(row, mat_rows.data() + (im++) * W * 4, W * 4); continue; }
+      const RigidSample &S = R.h_smp[ir];
+      const RigidBodyDev &B = hb[S.body];
+      float ro[3], x[3], v[3];
+      for (int r = 0; r < 3; r++) ro[r] = B.R[3 * r] * S.off[0] + B.R[3 * r + 1] * S.off[1] + B.R[3 * r + 2] * S.off[2];
+      for (int r = 0; r < 3; r++) x[r] = ro[r] + B.pos[r];
+      v[0] = B.vel[0] + (B.omega[1] * ro[2] - B.omega[2] * ro[1]);
+      v[1] = B.vel[1] + (B.omega[2] * ro[0] - B.omega[0] * ro[2]);
+      v[2] = B.vel[2] + (B.omega[0] * ro[1] - B.omega[1] * ro[0]);
+      std::memset(row, 0, W * 4);
+      bef(row, x[0]); bef(row + 4, x[1]); bef(row + 8, x[2]); bef(row + 12, 1.0f);
+      be32(row + 16, 1u); be32(row + 20, (uint32_t)R.h_smp_id[ir]);
+      be32(row + 24, 1u); be32(row + 28, 1u); be32(row + 32, 1u);
+      bef(row + 36, v[0]); bef(row + 40, v[1]); bef(row + 44, v[2]);
+      ir++;
+    }
   }
   out += row_bytes;
   const std::vector<uint8_t> prim = bgeo_prim_attr();

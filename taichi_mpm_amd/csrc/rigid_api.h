@@ -268,8 +268,8 @@ int mpmhip_add_rigid_body(mpmhip_ctx *c, const mpmhip_rigid_config *cfg, int64_t
           w[r] = (D.R[3 * r] * s.off[0] + D.R[3 * r + 1] * s.off[1] + D.R[3 * r + 2] * s.off[2] + D.pos[r]) * c->P.idx;
           near_wall = near_wall || w[r] < 7.0f || w[r] - (float)c->P.res[r] > -7.0f;
         }
+        if (!near_wall) { R.h_smp.push_back(s); R.h_smp_id.push_back(c->next_pid + allocated); }
         allocated++;
-        if (!near_wall) R.h_smp.push_back(s);
       }
   }
   // every boundary particle took a creation id from the same counter as the material particles

@@ -143,3 +143,45 @@ def test_live_reference_agrees_with_the_device_on_a_longer_run(tm):
     a, b = cs.rigid_vector(ref.rigid_state(rid)), cs.rigid_vector(sim.get_rigid_state(rid))
     np.testing.assert_allclose(b[0:7], a[0:7], rtol=0, atol=2e-5)
     np.testing.assert_allclose(b[7:10], a[7:10], rtol=0, atol=2e-3 * np.abs(a[7:10]).max())
+
+
+def read_bgeo_rows(path, verbose=False):
+    """point rows of a Houdini .bgeo v5 file as Partio writes it: (n, W) big-endian words behind the attribute table"""
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"Bgeo" and raw[4:5] == b"V"
+    import struct
+    n = struct.unpack(">I", raw[9:13])[0]
+    n_attr = struct.unpack(">I", raw[25:29])[0]
+    off = 41
+    width = 4
+    for _ in range(n_attr):
+        ln = struct.unpack(">H", raw[off:off + 2])[0]
+        off += 2 + ln
+        cnt = struct.unpack(">H", raw[off:off + 2])[0]
+        off += 2 + 4 + 4 * cnt
+        width += cnt
+    rows = np.frombuffer(raw, dtype=">u4", count=n * width, offset=off).reshape(n, width)
+    return rows
+
+
+def test_bgeo_frame_lists_the_boundary_particles_like_the_reference(tm, tmp_path):
+    """write_partio (src/visualize.cpp:17-100) lists every particle of MPM::particles by creation id: material particles
+    (type 0) and the boundary particles of rigid bodies (type 1, at their anchor points, moving with the body)"""
+    from oracle import refmpm
+    if not refmpm.available():
+        pytest.skip("oracle/_ref/libmpm_ref.so did not travel to this box")
+    refmpm.set_threads(1)
+    ref, rid = cs.build_reference(refmpm, "box", "jelly", penalty=1e3)
+    sim, _ = cs.build_device(tm, "box", "jelly", penalty=1e3)
+    ref.substep(3)
+    sim.run_substeps(3)
+    fr, fh = str(tmp_path / "ref.bgeo"), str(tmp_path / "hip.bgeo")
+    ref.write_bgeo(fr)
+    sim.write_partio(fh)
+    a, b = read_bgeo_rows(fr), read_bgeo_rows(fh)
+    assert a.shape == b.shape and a.shape[1] == 12
+    np.testing.assert_array_equal(a[:, 4:9], b[:, 4:9])  # type, index, limit: bit-identical rows in the same order
+    assert (a[:, 4] == 1).sum() == len(sim.get_rigid_samples(rid)["pos"]) > 50
+    fa, fb = a.astype(">u4").view(">f4"), b.astype(">u4").view(">f4")
+    assert np.abs(fa[:, 0:3] - fb[:, 0:3]).max() <= 5e-6
+    assert np.abs(fa[:, 9:12] - fb[:, 9:12]).max() <= 2e-4 * np.abs(fa[:, 9:12]).max()
