@@ -185,3 +185,55 @@ def test_bgeo_frame_lists_the_boundary_particles_like_the_reference(tm, tmp_path
     fa, fb = a.astype(">u4").view(">f4"), b.astype(">u4").view(">f4")
     assert np.abs(fa[:, 0:3] - fb[:, 0:3]).max() <= 5e-6
     assert np.abs(fa[:, 9:12] - fb[:, 9:12]).max() <= 2e-4 * np.abs(fa[:, 9:12]).max()
+
+
+def paddle(r=0.18, h=0.12):
+    """two crossed rectangular blades (a paddle wheel), four triangles"""
+    a = np.array([[[-r, -h, 0], [r, -h, 0], [r, h, 0]], [[-r, -h, 0], [r, h, 0], [-r, h, 0]]], np.float32)
+    b = a[:, :, [2, 1, 0]].copy()
+    return np.concatenate([a, b])
+
+
+def test_rotating_paddle_in_a_million_particles_matches_the_live_reference(tm):
+    """BASELINE configs[1] size (128^3 grid, 50^3 cells x 8 = 1 M jelly particles) with a scripted paddle wheel turning
+    inside the block (the scene type of scripts/mls-cpic/sand_paddles.py): whole substeps against the compiled reference"""
+    from oracle import refmpm
+    if not refmpm.available():
+        pytest.skip("oracle/_ref/libmpm_ref.so did not travel to this box")
+    from oracle import oracle as orc
+    from tests.common import lattice_cube
+    import os as _os
+    refmpm.set_threads(min(32, _os.cpu_count() or 1))  # a scripted body takes no impulses: the run is thread-safe
+    res, dx, dt, n = 128, 1.0 / 128, 1e-4, 4
+    x = lattice_cube(res, 39, 89, dx, jitter=0.15, seed=3)
+    rng = np.random.default_rng(4)
+    v = rng.normal(0, 0.2, x.shape).astype(np.float32)
+    vol = dx ** 3 / 8
+    mass = vol * 400.0
+    gp, _ = orc.group_params("jelly", mass, vol)
+    centre, rate = (0.5, 0.5, 0.5), (0.0, 0.0, 720.0)
+    ref = refmpm.Sim(res, dx, dt, gravity=(0, -10, 0))
+    rid = ref.add_rigid(paddle(), script=refmpm.rigid_script(centre, (0, 0, 0), (0, 0, 0), 0.0, (0, 0, 0), rate), codimensional=True,
+                        friction=-1.0)
+    ref.add_particles("jelly", mass, vol, x, v)
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(res,) * 3, delta_x=dx, base_delta_t=dt, gravity=(0, -10, 0),
+                                                       max_particles=len(x) + 16))
+    f32 = np.float32
+    assert int(sim.add_particles(dict(type="rigid", mesh=paddle(), codimensional=True, friction=-1.0,
+                                      scripted_position=lambda t: centre,
+                                      scripted_rotation=lambda t: [f32(rate[k]) * f32(t) for k in range(3)]))) == rid
+    sim.add_particles(dict(type="jelly", positions=x, velocities=v, params=gp))
+    assert len(x) == 1_000_000
+    ref.substep(n)
+    sim.run_substeps(n)
+    r, h = ref.download(by_id=True), sim.get_particles(sort_by_id=True)
+    assert len(r["x"]) == len(h["x"]) == len(x)
+    assert np.abs(h["x"] - r["x"]).max() <= 2e-6
+    assert rel_l2(h["v"], r["v"]) <= 2e-4
+    assert rel_l2(h["F"], r["F"]) <= 1e-4
+    o = np.argsort(ref.download(by_id=False)["id"], kind="stable")
+    st = ref.particle_cdf()["states"][o]
+    assert (st != 0).sum() > 50_000
+    assert (st != h["states"].astype(np.uint32)).sum() <= 20  # of a million: particles on the zero level of a blade
+    a, b = cs.rigid_vector(ref.rigid_state(rid)), cs.rigid_vector(sim.get_rigid_state(rid))
+    np.testing.assert_allclose(b[0:13], a[0:13], rtol=0, atol=2e-5)
