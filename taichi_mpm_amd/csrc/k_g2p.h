@@ -15,8 +15,8 @@ namespace mpm {
 // reorder_interval, with fully sequential record stores; particles deleted by an earlier substep drop out, so the live
 // records always occupy the slots [0, n_sorted).
 constexpr int G2P_LDS_GROUPS = MPMHIP_MAX_GROUPS;  // the ctx's group capacity: the whole table is mirrored in LDS (5 KiB)
-// RIGID: CPIC rigid bodies exist — blocks flagged in blk_rigid are left to k_g2p_rigid and the records' spare word (the
-// particle's colour) is carried along.  A compile-time switch: the instantiation without it is the kernel tuned above,
+// RIGID: CPIC rigid bodies exist — blocks flagged by k_blk_rigid (top bit of act_start) are left to k_g2p_rigid and the
+// records' spare word (the particle's colour) is carried along.  A compile-time switch: the instantiation without it is the kernel tuned above,
 // instruction for instruction.
 template <int NT, int MINW, bool ROLL, bool STORE_B, bool RIGID = false>
 __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__restrict__ rg, float4 *__restrict__ rg_out,
@@ -29,8 +29,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
                                                   const float4 *__restrict__ gridv,
                                                   const uint32_t *__restrict__ fat_slot, Counters *cnt_w,
                                                   uint32_t *__restrict__ key, uint8_t *__restrict__ blk_flag,
-                                                  const LevelSetDev *__restrict__ ls, PhaseBox T, int phase,
-                                                  const uint8_t *__restrict__ blk_rigid) {
+                                                  const LevelSetDev *__restrict__ ls, PhaseBox T, int phase) {
   __shared__ float4 tile[TN];
   __shared__ GroupParams sgroups[G2P_LDS_GROUPS];
   for (int t = threadIdx.x; t < G2P_LDS_GROUPS * (int)(sizeof(GroupParams) / 4); t += NT)
@@ -58,13 +57,17 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
     c.a = a; c.p = 0; c.p1 = 0;
     while (c.a < na) {
       c.p = act_start[c.a]; c.p1 = act_start[c.a + 1];
-      bool mine = c.p < c.p1;  // (empty block: all its particles migrated away)
+      bool rigid_block = false;
+      if constexpr (RIGID) {  // the top bit flags a block near a rigid body (k_blk_rigid): k_g2p_rigid takes it
+        rigid_block = (c.p & 0x80000000u) != 0u;
+        c.p &= 0x7FFFFFFFu; c.p1 &= 0x7FFFFFFFu;
+      }
+      bool mine = c.p < c.p1 && !rigid_block;  // (empty block: all its particles migrated away)
       if (mine && phase != 0) {
         int bx, by, bz;
         demorton3(act_blk[c.a], bx, by, bz);
         mine = in_phase(T, phase, bx * BS, by * BS, bz * BS, 2 * BS);
       }
-      if constexpr (RIGID) { if (mine) mine = !blk_rigid[c.a]; }  // near a rigid body: k_g2p_rigid takes the block (CPIC colour test)
       if (mine) break;
       c.a += gridDim.x;
     }

@@ -211,13 +211,20 @@ __device__ __forceinline__ bool rigid_page_of_block(const CdfDev &C, int bx, int
 }
 // active blocks the transfers handle with the colour-aware kernels: block_op_switch, src/transfer.cpp:570-576 — the
 // block's page is in rigid_page_map.  (Blocks outside ignore colours altogether, like the reference's block_op_normal.)
+// The flag goes to blk_rigid[a] (k_p2g / k_p2g_rigid) and into the TOP BIT of act_start[a]: k_g2p's chunk iterator loads
+// act_start anyway, a second array there would put one more load — and with its vmcnt wait the prefetched records — on
+// the iterator's critical path (measured: +20 % on k_g2p).  Only the RIGID variants of the G2P kernels see the bit.
+constexpr uint32_t ACT_RIGID_BIT = 0x80000000u;
 __global__ __launch_bounds__(256) void k_blk_rigid(Params P, const Counters *__restrict__ cnt, const uint32_t *__restrict__ act_blk,
-                                                   CdfDev C, uint8_t *__restrict__ blk_rigid) {
+                                                   CdfDev C, uint8_t *__restrict__ blk_rigid, uint32_t *__restrict__ act_start) {
   const uint32_t na = min(cnt->n_active, P.max_blocks);
   for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < na; a += gridDim.x * blockDim.x) {
     int bx, by, bz;
     demorton3(act_blk[a], bx, by, bz);
-    blk_rigid[a] = rigid_page_of_block(C, bx, by, bz) ? 1 : 0;
+    const bool r = rigid_page_of_block(C, bx, by, bz);
+    blk_rigid[a] = r ? 1 : 0;
+    const uint32_t s = act_start[a] & ~ACT_RIGID_BIT;  // (idempotent: the phase-level API may run this twice per sort)
+    act_start[a] = r ? (s | ACT_RIGID_BIT) : s;
   }
 }
 

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_g2p_rigid(Params P, const float4 *__res
     load_state_tile(X.C, bx, by, bz, stile, tid, 256);
     __syncthreads();
     const float ox = (float)(bx * BS), oy = (float)(by * BS), oz = (float)(bz * BS);
-    const uint32_t q0 = act_start[a], q1 = act_start[a + 1];
+    const uint32_t q0 = act_start[a] & ~ACT_RIGID_BIT, q1 = act_start[a + 1] & ~ACT_RIGID_BIT;
     for (uint32_t pb = q0; pb < q1; pb += 256) {  // uniform trip count: every lane reaches flag_block
       const uint32_t p = pb + tid;
       uint32_t bkey = INVALID;

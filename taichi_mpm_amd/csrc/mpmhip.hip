@@ -850,7 +850,8 @@ static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
   auto kern = mode == 0 ? (per_cand ? k_grid<0, true> : k_grid<0, false>)
                         : (mode == 1 ? k_grid<1, false>
                                      : (mode == 2 ? k_grid<2, false> : (mode == 3 ? k_grid<3, false> : k_grid<4, false>)));
-  hipLaunchKernelGGL(kern, dim3(per_cand ? 16384 : 4096), dim3(256), 0, c->stream, c->P, c->cnt, c->act_blk, c->bits, c->wprefix, c->tiles,
+  static const int grid_wgs_small = getenv("MPMHIP_GRID_WGS") ? atoi(getenv("MPMHIP_GRID_WGS")) : 16384;
+  hipLaunchKernelGGL(kern, dim3(per_cand ? grid_wgs_small : 4096), dim3(256), 0, c->stream, c->P, c->cnt, c->act_blk, c->bits, c->wprefix, c->tiles,
                      c->gridv, c->fat_slot, c->dense, c->T, (const DevBox *)c->d_boxes, c->LS, phase);
   return launch_check(c, "grid");
 }
@@ -871,8 +872,7 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0) {
   if (rigid_active(c)) { kern = sb ? k_g2p<256, 2, true, true, true> : k_g2p<256, 2, true, false, true>; nt = 256; }
   hipLaunchKernelGGL(kern, dim3(c->g2p_wgs), dim3(nt), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
                      (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
-                     c->blk_flag, (const LevelSetDev *)c->d_LS, phase_box(c->T), phase,
-                     rigid_active(c) ? (const uint8_t *)c->rigid.d_blk_rigid : (const uint8_t *)nullptr);
+                     c->blk_flag, (const LevelSetDev *)c->d_LS, phase_box(c->T), phase);
   if (rigid_active(c)) {
     hipLaunchKernelGGL(k_g2p_rigid, dim3(2048), dim3(256), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
                        (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,

@@ -147,7 +147,7 @@ static int do_rigid_gather(mpmhip_ctx *c) {
 static int do_rigid_block_flags(mpmhip_ctx *c) {
   auto &R = c->rigid;
   hipLaunchKernelGGL(k_blk_rigid, dim3(256), dim3(256), 0, c->stream, c->P, (const Counters *)c->cnt, (const uint32_t *)c->act_blk, R.cdf,
-                     R.d_blk_rigid);
+                     R.d_blk_rigid, c->act_start);
   return launch_check(c, "rigid block flags");
 }
 static int do_rigid_apply_tmp(mpmhip_ctx *c) {
