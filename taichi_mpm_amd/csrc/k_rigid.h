@@ -52,7 +52,8 @@ struct CdfDev {
   uint32_t max_pages;
   uint32_t *rpage;           // bitmap over the REFERENCE's 4x4x8-node blocks: its rigid_page_map (src/mpm.cpp:1026-1076)
   int rpd[3];
-  uint32_t *error;           // bit 1: page pool exhausted
+  int nb_axis;               // blocks per axis of the Morton space (1 << kbits): node coordinates beyond it have no page
+  uint32_t *error;           // the ctx's sticky error word (Counters::error); bit 2 (value 4): page pool exhausted
 };
 struct BndRec { float n[3]; float dist; uint32_t near; float pad[3]; };  // gather_cdf's per-particle output (32 bytes)
 
@@ -82,7 +83,7 @@ __device__ __forceinline__ void rigid_tmp_impulse(RigidBodyDev *b, const float i
 // node (i, j, k) of the colored distance field: tags (24 bits), body id of the closest triangle (-1: none), distance (world)
 __device__ __forceinline__ void cdf_node(const CdfDev &C, const Params &P, int i, int j, int k, uint32_t &tags, int &rid, float &dist) {
   tags = 0; rid = -1; dist = 0.0f;
-  if (i < 0 || j < 0 || k < 0) return;
+  if (i < 0 || j < 0 || k < 0 || (i >> 2) >= C.nb_axis || (j >> 2) >= C.nb_axis || (k >> 2) >= C.nb_axis) return;
   const uint32_t pg = C.slot[morton3(i >> 2, j >> 2, k >> 2)];
   if (pg == INVALID) return;
   const size_t n = (size_t)pg * 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3));
@@ -95,7 +96,7 @@ __device__ __forceinline__ void cdf_node(const CdfDev &C, const Params &P, int i
 }
 // packed node word of the transfer kernels' LDS tiles: tags | (rid + 1) << 24   (= GridState::states)
 __device__ __forceinline__ uint32_t cdf_node_word(const CdfDev &C, int i, int j, int k) {
-  if (i < 0 || j < 0 || k < 0) return 0u;
+  if (i < 0 || j < 0 || k < 0 || (i >> 2) >= C.nb_axis || (j >> 2) >= C.nb_axis || (k >> 2) >= C.nb_axis) return 0u;
   const uint32_t pg = C.slot[morton3(i >> 2, j >> 2, k >> 2)];
   if (pg == INVALID) return 0u;
   const size_t n = (size_t)pg * 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3));
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void k_cdf_rasterize(Params P, CdfDev C, const
           uint32_t pg = __hip_atomic_load(&C.slot[bk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (pg == INVALID) {
             const uint32_t mine = atomicAdd(C.n_pages, 1u);
-            if (mine >= C.max_pages) { atomicOr(C.error, 2u); continue; }
+            if (mine >= C.max_pages) { atomicOr(C.error, 4u); continue; }  // sticky: reported by the next synchronising call
             C.page_key[mine] = bk;  // (a page that loses the race below stays unused this substep; it is cleared like the others)
             const uint32_t prev = atomicCAS(&C.slot[bk], INVALID, mine);
             pg = prev == INVALID ? mine : prev;

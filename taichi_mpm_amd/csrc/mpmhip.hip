@@ -170,7 +170,7 @@ struct mpmhip_ctx {
     CdfDev cdf{};
     BndRec *d_bnd = nullptr;
     uint8_t *d_blk_rigid = nullptr;
-    uint32_t *d_counters = nullptr;  // [0] pages handed out, [1] error bits, [2] cutting_counter
+    uint32_t *d_counters = nullptr;  // [0] pages handed out, [2] cutting_counter
     uint32_t max_pages = 0;
     size_t rpage_words = 0;
     float penalty = 0.0f, pushing_force = 20000.0f;  // MPM::initialize defaults, src/mpm.cpp:35,40
@@ -562,6 +562,9 @@ static int read_counters(mpmhip_ctx *c, Counters &h) {
   if (h.error & 2u)
     return fail(c, MPMHIP_ECAPACITY, "a particle moved more than margin=%d cells outside this rank's brick between "
                 "two migrations: migrate more often or raise the margin", c->T.margin);
+  if (h.error & 4u)
+    return fail(c, MPMHIP_ECAPACITY, "the colored distance field of the rigid bodies needs more than %u pages of 4^3 nodes: "
+                "recreate the ctx with a larger max_blocks", c->rigid.max_pages);
   return MPMHIP_OK;
 }
 

@@ -101,7 +101,8 @@ static int rigid_enable(mpmhip_ctx *c) {
   A(dmalloc(&R.d_bnd, (size_t)c->cap));
   A(dmalloc(&R.d_blk_rigid, (size_t)c->P.max_blocks + 1));
   if (e != hipSuccess) return fail(c, MPMHIP_ENOMEM, "rigid coupling: device allocation failed: %s", hipGetErrorString(e));
-  R.cdf.n_pages = R.d_counters; R.cdf.error = R.d_counters + 1;
+  R.cdf.n_pages = R.d_counters; R.cdf.error = &c->cnt->error;
+  R.cdf.nb_axis = 1 << c->P.kbits;
   R.cdf.max_pages = R.max_pages;
   for (int k = 0; k < 3; k++) R.cdf.rpd[k] = rpd[k];
   HIPCHK(c, hipMemset(R.d_rb, 0, sizeof(RigidBodyDev) * MAX_RIGID));
@@ -253,6 +254,7 @@ int mpmhip_add_rigid_body(mpmhip_ctx *c, const mpmhip_rigid_config *cfg, int64_t
     const float *v0 = &tri[9 * e], *v1 = v0 + 3, *v2 = v0 + 6;
     float a[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]}, b[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
     const float xl = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), yl = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+    if (!(xl > 0.0f) || !(yl > 0.0f)) continue;  // a degenerate triangle carries no boundary particles
     for (int k = 0; k < 3; k++) { a[k] /= xl; b[k] /= yl; }
     for (float _x = std::min(xl / 3.0f, dx / 2.0f); _x < xl + dx; _x += dx)
       for (float _y = std::min(yl / 3.0f, dx / 2.0f); _y < yl + dx; _y += dx) {
