@@ -389,6 +389,27 @@ int mpmhip_debug_force(mpmhip_ctx *ctx, int32_t material, const float params[MPM
 int mpmhip_debug_plasticity(mpmhip_ctx *ctx, int32_t material, const float params[MPMHIP_NPARAM], int64_t n,
                             const float *cdg, float *F, float *aux, float *next_force);
 
+/* CPIC rigid coupling of MPM<2> (bodies made of segments; same semantics as the 3D entry points below).  A script
+ * returns the position in out[0..1] resp. the angle in degrees in out[0]. */
+typedef void (*mpmhip_script_fn)(void *user, float t, float out[3]);
+typedef struct mpmhip2d_rigid_config {
+  int32_t codimensional, recenter, reverse_vertices, reserved0;
+  float density;            /* <= 0: 40 (codimensional) / 400 */
+  float friction[2], restitution;
+  float scale[2];
+  float initial_position[2], initial_rotation /* degrees */, initial_velocity[2], initial_angular_velocity;
+  float linear_damping, angular_damping;
+  mpmhip_script_fn scripted_position; void *position_user;
+  mpmhip_script_fn scripted_rotation; void *rotation_user;
+} mpmhip2d_rigid_config;
+int mpmhip2d_set_rigid_coupling(mpmhip2d_ctx *ctx, float penalty, float pushing_force);
+int mpmhip2d_add_rigid_body(mpmhip2d_ctx *ctx, const mpmhip2d_rigid_config *cfg, int64_t n_segments, const float *segments /* n x 4 */);
+int mpmhip2d_rigid_get_state(mpmhip2d_ctx *ctx, int32_t id, float *out /* [10]: pos 2, angle, vel 2, omega, mass, inv_mass, inertia, inv_inertia */);
+int64_t mpmhip2d_rigid_get_samples(mpmhip2d_ctx *ctx, int32_t id, int64_t capacity, float *position);
+int mpmhip2d_cdf_phase(mpmhip2d_ctx *ctx); /* rasterize_rigid_boundary + gather_cdf (parity tests) */
+int mpmhip2d_download_cdf(mpmhip2d_ctx *ctx, uint32_t *states, float *distance); /* dense (res+1)^2 */
+int64_t mpmhip2d_download_colours(mpmhip2d_ctx *ctx, int64_t capacity, uint32_t *states, float *distance, float *normal, int32_t *near);
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * CPIC rigid coupling (3D) — replaces add_particles(type='rigid', ...) (src/mpm.cpp:80-83 -> MPM::add_rigid_particle,
  * src/mpm_rigid_body.cpp:130-252), rasterize_rigid_boundary / gather_cdf (src/rigid_transfer.cpp), the rigid branches of
@@ -399,7 +420,6 @@ int mpmhip_debug_plasticity(mpmhip_ctx *ctx, int32_t material, const float param
  * ------------------------------------------------------------------------------------------------------------------ */
 /* scripted_position(t) -> world position; scripted_rotation(t) -> Euler angles in degrees (applied X * Y * Z):
  * tc.function13 objects in the scene scripts (scripts/mls-cpic/sand_paddles.py:27, src/mpm_rigid_body.cpp:79-92) */
-typedef void (*mpmhip_script_fn)(void *user, float t, float out[3]);
 typedef struct mpmhip_rigid_config {
   int32_t codimensional;     /* a shell (cuts the material) instead of a solid; mandatory key of the reference */
   int32_t recenter;          /* 1 (reference default): the mesh is moved so that its centre of mass is the body origin */

@@ -63,6 +63,8 @@ struct Handle {
   // (src/mpm_rigid_body.cpp:79-92) and copies them
   std::vector<std::unique_ptr<RigidBody<3>::PositionFunctionType>> pos_scripts;
   std::vector<std::unique_ptr<RigidBody<3>::RotationFunctionType>> rot_scripts;
+  std::vector<std::unique_ptr<RigidBody<2>::PositionFunctionType>> pos_scripts2;
+  std::vector<std::unique_ptr<RigidBody<2>::RotationFunctionType>> rot_scripts2;
 };
 
 template <int dim> MPM<dim> &sim(Handle *h);
@@ -554,6 +556,102 @@ int64_t ref_particle_cdf(void *hh, uint32_t *states, float *distance, float *nor
       if (states) states[n] = p->states;
       if (distance) distance[n] = p->boundary_distance;
       if (normal) for (int k = 0; k < 3; k++) normal[3 * n + k] = p->boundary_normal[k];
+      if (near) near[n] = p->near_boundary_;
+      n++;
+    }
+    return 0;
+  });
+  return n;
+}
+
+
+// ---- CPIC in 2D (MPM<2>: generic transfers, src/transfer.cpp:193-278,585-687) -------------------------------------
+// segments: n_seg x 4 floats (two end points each).  script (8 floats, may be null): [has_pos, p0(2), vel(2) | has_rot,
+// a0 deg, rate deg/s]: scripted_position(t) = p0 + vel t, scripted_rotation(t) = a0 + rate t
+int ref2_add_rigid(void *hh, const char *cfg, int n_seg, const float *seg, const float *script) {
+  Handle *h = (Handle *)hh;
+  return guarded([&] {
+    if (h->dim != 2) TC_ERROR("ref2_add_rigid needs a 2D simulation");
+    MPM<2> &m = *h->m2;
+    Config c = Config::from_string(cfg);
+    c.set("type", std::string("rigid"));
+    c.set("shim_mesh_ptr", (unsigned long long)(uintptr_t)seg);
+    c.set("shim_mesh_n", n_seg);
+    if (script && script[0] != 0.0f) {
+      const Vector2 p0(script[1], script[2]), vel(script[3], script[4]);
+      h->pos_scripts2.push_back(std::make_unique<RigidBody<2>::PositionFunctionType>([=](real t) { return p0 + vel * t; }));
+      c.set("scripted_position", (unsigned long long)(uintptr_t)h->pos_scripts2.back().get());
+      c.set("scripted_position_id", (int)h->pos_scripts2.size() - 1);
+    }
+    if (script && script[5] != 0.0f) {
+      const real a0 = script[6], rate = script[7];
+      h->rot_scripts2.push_back(std::make_unique<RigidBody<2>::RotationFunctionType>([=](real t) { return a0 + rate * t; }));
+      c.set("scripted_rotation", (unsigned long long)(uintptr_t)h->rot_scripts2.back().get());
+      c.set("scripted_rotation_id", (int)h->rot_scripts2.size() - 1);
+    }
+    m.add_particles(c);
+    m.rigids.back()->id = (int)m.rigids.size() - 1;
+    return (int)m.rigids.size() - 1;
+  });
+}
+// out[10]: position 2, angle (radians), velocity 2, angular velocity, mass, inv_mass, inertia, inv_inertia
+int ref2_rigid_state(void *hh, int id, float *out) {
+  Handle *h = (Handle *)hh;
+  return guarded([&] {
+    MPM<2> &m = *h->m2;
+    if (id < 0 || id >= (int)m.rigids.size()) TC_ERROR("no such rigid body");
+    const RigidBody<2> &r = *m.rigids[id];
+    out[0] = r.position[0]; out[1] = r.position[1]; out[2] = r.rotation.value; out[3] = r.velocity[0]; out[4] = r.velocity[1];
+    out[5] = r.angular_velocity.value; out[6] = r.mass; out[7] = r.inv_mass; out[8] = r.inertia; out[9] = r.inv_inertia;
+    return 0;
+  });
+}
+int64_t ref2_rigid_samples(void *hh, int id, int64_t cap, float *pos) {
+  Handle *h = (Handle *)hh;
+  int64_t n = 0;
+  const int rc = guarded([&] {
+    MPM<2> &m = *h->m2;
+    for (auto pi : m.particles) {
+      auto *p = dynamic_cast<RigidBoundaryParticle<2> *>(m.allocator[pi]);
+      if (!p || (id >= 0 && p->rigid->id != id)) continue;
+      if (n < cap && pos) { pos[2 * n] = p->pos[0]; pos[2 * n + 1] = p->pos[1]; }
+      n++;
+    }
+    return 0;
+  });
+  return rc ? -1 : n;
+}
+int ref2_download_cdf(void *hh, uint32_t *states, float *distance) {  // dense (res+1)^2
+  Handle *h = (Handle *)hh;
+  return guarded([&] {
+    MPM<2> &m = *h->m2;
+    using Mask = typename MPM<2>::SparseMask;
+    auto blocks = m.fat_page_map->Get_Blocks();
+    auto bs = m.grid_block_size();
+    for (unsigned b = 0; b < blocks.second; b++) {
+      Vector2i base(Mask::LinearToCoord(blocks.first[b]));
+      for (auto &ind : RegionND<2>(Vector2i(0), bs)) {
+        Vector2i g = base + ind.get_ipos();
+        if (g[0] > m.res[0] || g[1] > m.res[1]) continue;
+        const size_t lin = (size_t)g[0] * (m.res[1] + 1) + g[1];
+        states[lin] = m.get_grid(g).states;
+        distance[lin] = m.get_grid(g).distance;
+      }
+    }
+    return 0;
+  });
+}
+int64_t ref2_particle_cdf(void *hh, uint32_t *states, float *distance, float *normal, int32_t *near) {
+  Handle *h = (Handle *)hh;
+  int64_t n = 0;
+  guarded([&] {
+    MPM<2> &m = *h->m2;
+    for (auto pi : m.particles) {
+      MPMParticle<2> *p = m.allocator[pi];
+      if (p->is_rigid()) continue;
+      if (states) states[n] = p->states;
+      if (distance) distance[n] = p->boundary_distance;
+      if (normal) { normal[2 * n] = p->boundary_normal[0]; normal[2 * n + 1] = p->boundary_normal[1]; }
       if (near) near[n] = p->near_boundary_;
       n++;
     }

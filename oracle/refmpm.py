@@ -89,6 +89,13 @@ def lib():
         L.ref_download_cdf.argtypes = [C.c_void_p, P_U, P_F]
         L.ref_particle_cdf.restype = C.c_int64
         L.ref_particle_cdf.argtypes = [C.c_void_p, P_U, P_F, P_F, P_I, P_U]
+        L.ref2_add_rigid.argtypes = [C.c_void_p, C.c_char_p, C.c_int, P_F, P_F]
+        L.ref2_rigid_state.argtypes = [C.c_void_p, C.c_int, P_F]
+        L.ref2_rigid_samples.restype = C.c_int64
+        L.ref2_rigid_samples.argtypes = [C.c_void_p, C.c_int, C.c_int64, P_F]
+        L.ref2_download_cdf.argtypes = [C.c_void_p, P_U, P_F]
+        L.ref2_particle_cdf.restype = C.c_int64
+        L.ref2_particle_cdf.argtypes = [C.c_void_p, P_U, P_F, P_F, P_I]
         _lib = L
     return _lib
 
@@ -284,6 +291,43 @@ class Sim:
                                     body.ctypes.data_as(P_I))
         assert m == n
         return dict(pos=pos, offset=off, element=el, body=body)
+
+    # the same in 2D (MPM<2>)
+    def add_rigid2(self, segments, script=None, **cfg):
+        """segments (n, 2, 2); script = [has_pos, p0(2), vel(2), has_rot, a0 deg, rate deg/s] or None"""
+        seg, sp_ = _f(np.asarray(segments, np.float32).reshape(-1, 4))
+        sp = None
+        if script is not None:
+            script, sp = _f(np.asarray(script, np.float32).reshape(8))
+        cfg.setdefault("codimensional", True)
+        rid = lib().ref2_add_rigid(self.h, cfg_string(**cfg), len(seg), sp_, sp)
+        if rid < 0:
+            raise RuntimeError("reference: " + lib().ref_last_error().decode())
+        return rid
+
+    def rigid_state2(self, rid):
+        o = np.zeros(10, np.float32)
+        _chk(lib().ref2_rigid_state(self.h, int(rid), o.ctypes.data_as(P_F)))
+        return o
+
+    def rigid_samples2(self, rid=-1):
+        n = lib().ref2_rigid_samples(self.h, int(rid), 0, None)
+        pos = np.zeros((n, 2), np.float32)
+        assert lib().ref2_rigid_samples(self.h, int(rid), n, pos.ctypes.data_as(P_F)) == n
+        return pos
+
+    def download_cdf2(self):
+        shp = tuple(r + 1 for r in self.res)
+        st, d = np.zeros(shp, np.uint32), np.zeros(shp, np.float32)
+        _chk(lib().ref2_download_cdf(self.h, st.ctypes.data_as(C.POINTER(C.c_uint32)), d.ctypes.data_as(P_F)))
+        return st, d
+
+    def particle_cdf2(self):
+        n = self.num_particles()
+        st, d, nr, near = np.zeros(n, np.uint32), np.zeros(n, np.float32), np.zeros((n, 2), np.float32), np.zeros(n, np.int32)
+        assert lib().ref2_particle_cdf(self.h, st.ctypes.data_as(C.POINTER(C.c_uint32)), d.ctypes.data_as(P_F), nr.ctypes.data_as(P_F),
+                                       near.ctypes.data_as(P_I)) == n
+        return dict(states=st, distance=d, normal=nr, near=near)
 
     def rasterize_rigid_boundary(self):
         _chk(lib().ref_phase(self.h, 7, 1))

@@ -60,6 +60,16 @@ class RigidConfig(C.Structure):
                 ("scripted_rotation", SCRIPT_FN), ("rotation_user", C.c_void_p)]
 
 
+class RigidConfig2D(C.Structure):
+    """mirror of mpmhip2d_rigid_config"""
+    _fields_ = [("codimensional", C.c_int32), ("recenter", C.c_int32), ("reverse_vertices", C.c_int32), ("reserved0", C.c_int32),
+                ("density", C.c_float), ("friction", C.c_float * 2), ("restitution", C.c_float), ("scale", C.c_float * 2),
+                ("initial_position", C.c_float * 2), ("initial_rotation", C.c_float), ("initial_velocity", C.c_float * 2),
+                ("initial_angular_velocity", C.c_float), ("linear_damping", C.c_float), ("angular_damping", C.c_float),
+                ("scripted_position", SCRIPT_FN), ("position_user", C.c_void_p),
+                ("scripted_rotation", SCRIPT_FN), ("rotation_user", C.c_void_p)]
+
+
 class Config2D(C.Structure):
     """mirror of mpmhip2d_config"""
     _fields_ = [("res", C.c_int32 * 2), ("dx", C.c_float), ("dt", C.c_float), ("gravity", C.c_float * 2),
@@ -125,6 +135,8 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_las
             "mpmhip_async_enable", "mpmhip_async_update_dt_limits", "mpmhip_async_blocks", "mpmhip_async_set_time_int", "mpmhip_async_table", "mpmhip_clear_particles", "mpmhip_set_dt", "mpmhip_set_time", "mpmhip_get_clock", "mpmhip_set_clock", "mpmhip_debug_allowed_dt",
             "mpmhip2d_create", "mpmhip2d_destroy", "mpmhip2d_last_error", "mpmhip2d_set_levelset", "mpmhip2d_add_group", "mpmhip2d_add_particles",
             "mpmhip2d_substep", "mpmhip2d_step", "mpmhip2d_current_time", "mpmhip2d_num_particles", "mpmhip2d_download", "mpmhip2d_download_grid",
+            "mpmhip2d_set_rigid_coupling", "mpmhip2d_add_rigid_body", "mpmhip2d_rigid_get_state", "mpmhip2d_rigid_get_samples", "mpmhip2d_cdf_phase",
+            "mpmhip2d_download_cdf", "mpmhip2d_download_colours",
             "mpmhip_set_rigid_coupling", "mpmhip_add_rigid_body", "mpmhip_num_rigid_bodies", "mpmhip_rigid_get_state", "mpmhip_rigid_set_velocity",
             "mpmhip_rigid_get_samples", "mpmhip_rasterize_rigid_boundary", "mpmhip_gather_cdf", "mpmhip_advect_rigid_bodies", "mpmhip_download_cdf",
             "mpmhip_download_boundary",
@@ -271,6 +283,15 @@ def load():
     L.mpmhip_download_cdf.argtypes = [vp, up, fp]
     L.mpmhip_download_boundary.argtypes = [vp, fp, C.c_int64]
     L.mpmhip_download_boundary.restype = C.c_int64
+    L.mpmhip2d_set_rigid_coupling.argtypes = [vp, C.c_float, C.c_float]
+    L.mpmhip2d_add_rigid_body.argtypes = [vp, P(RigidConfig2D), C.c_int64, fp]
+    L.mpmhip2d_rigid_get_state.argtypes = [vp, C.c_int32, fp]
+    L.mpmhip2d_rigid_get_samples.argtypes = [vp, C.c_int32, C.c_int64, fp]
+    L.mpmhip2d_rigid_get_samples.restype = C.c_int64
+    L.mpmhip2d_cdf_phase.argtypes = [vp]
+    L.mpmhip2d_download_cdf.argtypes = [vp, up, fp]
+    L.mpmhip2d_download_colours.argtypes = [vp, C.c_int64, up, fp, fp, ip]
+    L.mpmhip2d_download_colours.restype = C.c_int64
     L.mpmhip_debug_svd3.argtypes = [vp, C.c_int64, fp, fp, fp, fp]
     L.mpmhip_debug_force.argtypes = [vp, C.c_int32, fp, C.c_int64, fp, fp, fp]
     L.mpmhip_debug_plasticity.argtypes = [vp, C.c_int32, fp, C.c_int64, fp, fp, fp, fp]

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mpm_math.h"
+#include "k_rigid2d.h"
 
 namespace mpm2d {
 
@@ -220,12 +221,14 @@ __device__ __forceinline__ bool alive_pos(const Params &P, const float x[2], con
   return ok;
 }
 
-// rasterize — src/transfer.cpp:193-278 (same-colour branch)
+__device__ __forceinline__ void friction_project2(float v[2], const float vb[2], const float n[2], float friction);
+
+// rasterize — src/transfer.cpp:193-278 (with rigid bodies: the colour test and the impulses to the bodies)
 __global__ __launch_bounds__(256) void k_p2g(Params P, int64_t n, const float *__restrict__ x, float *__restrict__ v,
                                              const float *__restrict__ F, const float *__restrict__ B,
                                              const float *__restrict__ aux, const int32_t *__restrict__ gid,
                                              const int32_t *__restrict__ pid, const GroupParams *__restrict__ groups,
-                                             float *__restrict__ grid) {
+                                             float *__restrict__ grid, RigidArgs2 R) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n || pid[p] < 0) return;
   float vv[2] = {v[2 * p], v[2 * p + 1]};
@@ -246,11 +249,34 @@ __global__ __launch_bounds__(256) void k_p2g(Params P, int64_t n, const float *_
   float w0[3], w1[3];
   weights(r0, w0); weights(r1, w1);
   const int ny = P.res[1] + 1;
+  uint32_t pstate = 0u;
+  Bnd2 bn;
+  bn.n[0] = bn.n[1] = 0.0f; bn.dist = 0.0f; bn.near = 0u;
+  if (R.enabled) { pstate = R.states[p]; bn = R.bnd[p]; }
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const float d0 = r0 - (float)i, d1 = r1 - (float)j, w = w0[i] * w1[j];
+      if (R.enabled) {  // the colour test of the generic rasterize (:227-254): the other side of a body receives nothing
+        const uint32_t word = node_word2(R, (size_t)(b[0] + i) * ny + (b[1] + j));
+        if (incompatible2(word, pstate)) {
+          const int rid = (int)(word >> 24) - 1;
+          if (rid < 0) continue;
+          Rigid2 *Bd = R.rb + rid;
+          const float gpos[2] = {(b[0] + i) * P.dx, (b[1] + j) * P.dx};
+          float rv[2], pv[2] = {vv[0], vv[1]};
+          velocity_at2(*Bd, gpos, rv);
+          friction_project2(pv, rv, bn.n, Bd->fric[(pstate >> (2 * rid)) & 1u]);
+          // gradient of the weight (dw / dx, world units): d/dr of the quadratic B-spline is (r - 1.5, -2 (r - 1), r - 0.5)
+          const float t0[3] = {r0 - 1.5f, -2.0f * (r0 - 1.0f), r0 - 0.5f}, t1[3] = {r1 - 1.5f, -2.0f * (r1 - 1.0f), r1 - 0.5f};
+          const float gr[2] = {t0[i] * P.idx * w1[j], w0[i] * t1[j] * P.idx};
+          const float imp[2] = {mass * w * (vv[0] - pv[0]) + P.dt * (st.a * gr[0] + st.b * gr[1]),
+                                mass * w * (vv[1] - pv[1]) + P.dt * (st.c * gr[0] + st.d * gr[1])};
+          tmp_impulse2(Bd, imp, gpos);
+          continue;
+        }
+      }
       float *gp = grid + 3 * ((size_t)(b[0] + i) * ny + (b[1] + j));
       atomicAdd(gp + 0, w * (mass * vv[0] + A[0] * d0 + A[1] * d1));
       atomicAdd(gp + 1, w * (mass * vv[1] + A[2] * d0 + A[3] * d1));
@@ -303,7 +329,7 @@ __global__ __launch_bounds__(256) void k_g2p(Params P, LevelSetDev LS, int64_t n
                                              float *__restrict__ F, float *__restrict__ B, float *__restrict__ aux,
                                              const int32_t *__restrict__ gid, int32_t *__restrict__ pid,
                                              const GroupParams *__restrict__ groups, const float *__restrict__ grid,
-                                             unsigned int *__restrict__ n_dead) {
+                                             unsigned int *__restrict__ n_dead, RigidArgs2 R) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n || pid[p] < 0) return;
   float xx[2] = {x[2 * p], x[2 * p + 1]}, vv[2] = {v[2 * p], v[2 * p + 1]};
@@ -318,19 +344,46 @@ __global__ __launch_bounds__(256) void k_g2p(Params P, LevelSetDev LS, int64_t n
   weights(r0, w0); weights(r1, w1);
   const int ny = P.res[1] + 1;
   float nv[2] = {0, 0}, bb[4] = {0, 0, 0, 0};
+  uint32_t pstate = 0u;
+  Bnd2 bn;
+  bn.n[0] = bn.n[1] = 0.0f; bn.dist = 0.0f; bn.near = 0u;
+  int rigid_id = -1;
+  if (R.enabled) { pstate = R.states[p]; bn = R.bnd[p]; }
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const float *gp = grid + 3 * ((size_t)(b[0] + i) * ny + (b[1] + j));
       const float d0 = r0 - (float)i, d1 = r1 - (float)j, w = w0[i] * w1[j];
-      const float a0 = w * gp[0], a1 = w * gp[1];
+      float gv[2] = {gp[0], gp[1]};
+      if (R.enabled) {  // :611-642: a node of the other colour contributes the particle's own (projected) velocity
+        const uint32_t word = node_word2(R, (size_t)(b[0] + i) * ny + (b[1] + j));
+        if (incompatible2(word, pstate)) {
+          float fake[2] = {vv[0], vv[1]}, vg[2] = {0, 0}, friction = 0.0f;
+          const int rid = (int)(word >> 24) - 1;
+          if (rid >= 0) {
+            const float gpos[2] = {(b[0] + i) * P.dx, (b[1] + j) * P.dx};
+            velocity_at2(R.rb[rid], gpos, vg);
+            rigid_id = rid;
+            friction = R.rb[rid].fric[(pstate >> (2 * rid)) & 1u];
+          }
+          if (bn.near) {
+            friction_project2(fake, vg, bn.n, friction);
+            const float push = P.dt * P.dx * R.pushing_force;
+            fake[0] += bn.n[0] * push; fake[1] += bn.n[1] * push;
+          }
+          gv[0] = fake[0]; gv[1] = fake[1];
+        }
+      }
+      const float a0 = w * gv[0], a1 = w * gv[1];
       nv[0] += a0; nv[1] += a1;
       bb[0] += a0 * d0; bb[1] += a0 * d1; bb[2] += a1 * d0; bb[3] += a1 * d1;  // b = sum (w g_v) (x) dpos, :644
     }
   const float scale = -4.0f * P.idx * P.dt;
   const m2 cdg = {1.0f + scale * bb[0], scale * bb[1], scale * bb[2], 1.0f + scale * bb[3]};  // :659-661
-  if (P.rpic_damping != 0.0f || P.apic_damping != 0.0f) {  // damp_affine_momemtum, src/mpm.h:465-469 (:654)
+  if (bn.near) {  // p.apic_b = Matrix(0), :649-653
+    bb[0] = bb[1] = bb[2] = bb[3] = 0.0f;
+  } else if (P.rpic_damping != 0.0f || P.apic_damping != 0.0f) {  // damp_affine_momemtum, src/mpm.h:465-469 (:654)
     const float ks = 1.0f - P.rpic_damping, ka = 1.0f - P.apic_damping;
     const float sym = 0.5f * (bb[1] + bb[2]), skew = 0.5f * (bb[1] - bb[2]);
     bb[0] *= ks; bb[3] *= ks;
@@ -344,6 +397,14 @@ __global__ __launch_bounds__(256) void k_g2p(Params P, LevelSetDev LS, int64_t n
   if (P.clamp_pos) {  // :668-670
     xx[0] = fminf(fmaxf(xx[0] * P.idx, 0.0f), (float)P.res[0] - 1e-6f) * P.dx;
     xx[1] = fminf(fmaxf(xx[1] * P.idx, 0.0f), (float)P.res[1] - 1e-6f) * P.dx;
+  }
+  if (bn.near && bn.dist < -0.05f * P.dx && bn.dist > -P.dx * 0.3f) {  // penalty, :671-682
+    const float dv[2] = {bn.dist * bn.n[0] * R.penalty, bn.dist * bn.n[1] * R.penalty};
+    nv[0] -= dv[0]; nv[1] -= dv[1];
+    if (rigid_id != -1) {
+      const float imp[2] = {dv[0] * g.p[0], dv[1] * g.p[0]};
+      tmp_impulse2(R.rb + rigid_id, imp, xx);
+    }
   }
   int nb[2];
   const bool keep = alive_pos(P, xx, nv, nb);  // clear_boundary_particles sees the advected position

@@ -1,0 +1,242 @@
+// taichi_mpm_amd/csrc/k_rigid2d.h — CPIC rigid coupling of MPM<2>: bodies made of segments, dense colored distance field
+// Part of libmpmhip (C ABI: mpmhip2d_*).  The 3D version (k_rigid.h) explains the method; in 2D the reference runs the
+// GENERIC transfers with their colour test (src/transfer.cpp:193-278, 585-687), rasterize_rigid_boundary and gather_cdf in
+// their dim = 2 form (src/rigid_transfer.cpp: segments with a +-2 % end tolerance :43-47, 3x3 least squares, guard 3e-3,
+// no rigid_page_map), and the grid is dense here, so the field is two dense node arrays cleared by a memset.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mpm2d {
+
+constexpr int MAX_RIGID2 = 12;
+constexpr uint32_t TAG_MASK2 = 0x00FFFFFFu, STATE_MASK2 = 0xAAAAAAAAu;
+constexpr unsigned long long CDF2_EMPTY = ~0ull;
+
+struct Rigid2 {
+  float pos[2], vel[2], omega, angle;
+  float mass, inv_mass, inv_I;
+  float fric[2];
+  float lin_damp, ang_damp;
+  int scripted;
+  float tmp_imp[2], tmp_trq;
+};
+struct Sample2 { float off[2]; int body; int elem; };
+struct Step2 { int has_pos, has_rot; float p0[2], p1[2], a0, a1; };  // a0 / a1: radians
+struct Steps2 { Step2 s[MAX_RIGID2]; };
+struct Bnd2 { float n[2]; float dist; uint32_t near; };
+struct RigidArgs2 {
+  int enabled;
+  unsigned long long *mind;  // [(res+1)^2]  distance bits << 32 | body id + 1
+  uint32_t *tags;            // [(res+1)^2]
+  Rigid2 *rb;
+  uint32_t *states;          // per particle: MPMParticle::states
+  Bnd2 *bnd;                 // per particle: gather_cdf's results
+  float penalty, pushing_force;
+};
+
+__device__ __forceinline__ void rot2(float angle, const float v[2], float o[2]) {
+  const float c = cosf(angle), s = sinf(angle);
+  o[0] = c * v[0] - s * v[1]; o[1] = s * v[0] + c * v[1];
+}
+__device__ __forceinline__ void velocity_at2(const Rigid2 &b, const float p[2], float v[2]) {
+  const float r0 = p[0] - b.pos[0], r1 = p[1] - b.pos[1];
+  v[0] = b.vel[0] - b.omega * r1; v[1] = b.vel[1] + b.omega * r0;
+}
+__device__ __forceinline__ void tmp_impulse2(Rigid2 *b, const float imp[2], const float at[2]) {
+  const float r0 = at[0] - b->pos[0], r1 = at[1] - b->pos[1];
+  atomicAdd(&b->tmp_imp[0], imp[0]); atomicAdd(&b->tmp_imp[1], imp[1]);
+  atomicAdd(&b->tmp_trq, r0 * imp[1] - r1 * imp[0]);
+}
+__device__ __forceinline__ uint32_t node_word2(const RigidArgs2 &R, size_t node) {
+  const unsigned long long m = R.mind[node];
+  return (R.tags[node] & TAG_MASK2) | (m != CDF2_EMPTY ? ((uint32_t)(m & 0xFFu) << 24) : 0u);
+}
+__device__ __forceinline__ bool incompatible2(uint32_t word, uint32_t pstate) {
+  const uint32_t gs = word & TAG_MASK2, mask = (gs & pstate & STATE_MASK2) >> 1;
+  return (gs & mask) != (pstate & mask);
+}
+
+// rasterize_rigid_boundary, dim = 2 (src/rigid_transfer.cpp:17-78): one thread per boundary particle
+__global__ __launch_bounds__(256) void k2_cdf_rasterize(int res0, int res1, float dx, float idx, RigidArgs2 R, const Sample2 *__restrict__ smp,
+                                                        const float *__restrict__ elems, uint32_t n) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const Sample2 S = smp[s];
+  const Rigid2 &B = R.rb[S.body];
+  float w[2];
+  rot2(B.angle, S.off, w);
+  const float x[2] = {w[0] + B.pos[0], w[1] + B.pos[1]};
+  const float X0 = x[0] * idx, X1 = x[1] * idx;
+  if (!(X0 >= 0.5f && X1 >= 0.5f && X0 < (float)res0 - 1.5f && X1 < (float)res1 - 1.5f)) return;
+  const int b0 = (int)(X0 - 0.5f), b1 = (int)(X1 - 0.5f);
+  float v0[2], v1[2], t[2];
+  rot2(B.angle, elems + (size_t)S.elem * 4, t); v0[0] = t[0] + B.pos[0]; v0[1] = t[1] + B.pos[1];
+  rot2(B.angle, elems + (size_t)S.elem * 4 + 2, t); v1[0] = t[0] + B.pos[0]; v1[1] = t[1] + B.pos[1];
+  const float e[2] = {v1[0] - v0[0], v1[1] - v0[1]};
+  const float nl = sqrtf(e[0] * e[0] + e[1] * e[1]);
+  const float nn[2] = {e[1] / nl, -e[0] / nl};  // the segment's normal (get_normal of the rigid body's element)
+  const float det = e[0] * nn[1] - nn[0] * e[1], id = 1.0f / det;
+  const int ny = res1 + 1;
+  for (int a = 0; a < 3; a++)
+    for (int c = 0; c < 3; c++) {
+      const int gi = b0 + a, gj = b1 + c;
+      const float d0 = gi * dx - v0[0], d1 = gj * dx - v0[1];
+      const float u0 = (nn[1] * d0 - nn[0] * d1) * id, u1 = (-e[1] * d0 + e[0] * d1) * id;
+      if (!(-0.02f <= u0 && u0 <= 1.02f)) continue;
+      const bool negative = u1 < 0.0f;
+      const float dist = fabsf(u1) * idx;
+      const size_t node = (size_t)gi * ny + gj;
+      atomicMin(&R.mind[node], ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned long long)(S.body + 1));
+      atomicOr(&R.tags[node], (2u + (negative ? 1u : 0u)) << (2u * (uint32_t)S.body));
+    }
+}
+
+// 3x3 solve by the adjugate in float (the reference build's inversed(MatrixND<3>) is the same formula)
+__device__ __forceinline__ float solve3(const float A[3][3], const float y[3], float r[3], float guard) {
+  const float c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1], c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2], c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+  const float det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02;
+  if (!(fabsf(det) > guard)) return fabsf(det);
+  const float id = 1.0f / det;
+  const float c10 = A[0][2] * A[2][1] - A[0][1] * A[2][2], c11 = A[0][0] * A[2][2] - A[0][2] * A[2][0], c12 = A[0][1] * A[2][0] - A[0][0] * A[2][1];
+  const float c20 = A[0][1] * A[1][2] - A[0][2] * A[1][1], c21 = A[0][2] * A[1][0] - A[0][0] * A[1][2], c22 = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+  // inverse = adj / det with adj[r][c] = cofactor[c][r]
+  r[0] = (c00 * y[0] + c10 * y[1] + c20 * y[2]) * id;
+  r[1] = (c01 * y[0] + c11 * y[1] + c21 * y[2]) * id;
+  r[2] = (c02 * y[0] + c12 * y[1] + c22 * y[2]) * id;
+  return fabsf(det);
+}
+
+__device__ __forceinline__ void weights2(float rel, float w[3]) {
+  const float p = rel - 0.5f;
+  const float t0 = p + 0.5f, t1 = p - 0.5f, t2 = p - 1.5f;
+  w[0] = 0.5f * t0 * t0 - 1.5f * t0 + 1.125f;
+  w[1] = -t1 * t1 + 0.75f;
+  w[2] = 0.5f * t2 * t2 + 1.5f * t2 + 1.125f;
+}
+
+// gather_cdf, dim = 2 (src/rigid_transfer.cpp:121-275)
+__global__ __launch_bounds__(256) void k2_gather_cdf(int res0, int res1, float dx, float idx, RigidArgs2 R, int64_t n, const float *__restrict__ x,
+                                                     const int32_t *__restrict__ pid) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  Bnd2 out;
+  out.n[0] = out.n[1] = 0.0f; out.dist = 0.0f; out.near = 0u;
+  const float pos[2] = {x[2 * p] * idx, x[2 * p + 1] * idx};
+  const bool ok = pid[p] >= 0 && pos[0] >= 0.5f && pos[1] >= 0.5f && (int)(pos[0] - 0.5f) + 2 <= res0 && (int)(pos[1] - 0.5f) + 2 <= res1;
+  if (!ok) { R.bnd[p] = out; return; }
+  uint32_t pstate = R.states[p];
+  const int b0 = (int)(pos[0] - 0.5f), b1 = (int)(pos[1] - 0.5f);
+  const float rel[2] = {pos[0] - (float)b0, pos[1] - (float)b1};
+  float w0[3], w1[3];
+  weights2(rel[0], w0); weights2(rel[1], w1);
+  const int ny = res1 + 1;
+  uint32_t ntag[9];
+  int nrid[9];
+  float nd[9];
+  uint32_t all_b = 0u;
+#pragma unroll
+  for (int t = 0; t < 9; t++) {
+    const size_t node = (size_t)(b0 + t / 3) * ny + (b1 + t % 3);
+    const unsigned long long m = R.mind[node];
+    ntag[t] = R.tags[node];
+    nrid[t] = m != CDF2_EMPTY ? (int)(m & 0xFFu) - 1 : -1;
+    nd[t] = m != CDF2_EMPTY ? __uint_as_float((uint32_t)(m >> 32)) * dx : 0.0f;
+    all_b |= ntag[t] & STATE_MASK2;
+  }
+  pstate &= (all_b + (all_b >> 1));
+  uint32_t to_add = all_b & ~pstate;
+  while (to_add) {
+    const uint32_t bit = to_add & (0u - to_add);
+    to_add ^= bit;
+    float wd[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      if (nrid[t] == -1) continue;
+      const float d = nd[t] * idx, weight = w0[t / 3] * w1[t % 3];
+      if (ntag[t] & bit) wd[(ntag[t] & (bit >> 1)) != 0u ? 1 : 0] += d * weight;
+    }
+    if (wd[0] + wd[1] > 1e-7f) pstate |= bit | ((bit >> 1) * (wd[0] < wd[1] ? 1u : 0u));
+  }
+  R.states[p] = pstate;
+  if (pstate != 0u) {
+    float XtX[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, XtY[3] = {0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      if (nrid[t] == -1) continue;
+      const uint32_t gs = ntag[t];
+      if (gs == 0u) continue;
+      const float dp[2] = {rel[0] - (float)(t / 3), rel[1] - (float)(t % 3)};
+      const float xp[3] = {-dp[0], -dp[1], 1.0f};
+      const float d = nd[t] * idx, weight = w0[t / 3] * w1[t % 3];
+      const uint32_t mask = (gs & pstate & STATE_MASK2) >> 1;
+      float sgn = 0.0f;
+      if ((gs & mask) == (pstate & mask)) sgn = 1.0f;
+      else {
+        const uint32_t diff = (gs & mask) ^ (pstate & mask);
+        if (diff != 0u && (diff & (diff - 1u)) == 0u) sgn = -1.0f;
+      }
+      if (sgn == 0.0f) continue;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) XtX[r][c] += (xp[r] * xp[c]) * weight;
+      const float yv[3] = {-d * dp[0], -d * dp[1], d};
+#pragma unroll
+      for (int r = 0; r < 3; r++) XtY[r] += (sgn * yv[r]) * weight;
+    }
+    float r3[3] = {0, 0, 0};
+    if (solve3(XtX, XtY, r3, 3e-3f) > 3e-3f) {  // mpm_reconstruction_guard<2>()
+      out.near = 1u;
+      out.dist = r3[2] * dx;
+      const float l2 = r3[0] * r3[0] + r3[1] * r3[1];
+      if (l2 > 1e-4f) {
+        const float il = 1.0f / sqrtf(l2);
+        out.n[0] = r3[0] * il; out.n[1] = r3[1] * il;
+      }
+    }
+  }
+  R.bnd[p] = out;
+}
+
+__global__ void k2_rigid_apply_tmp(Rigid2 *rb, int nb) {
+  const int b = threadIdx.x;
+  if (b < 1 || b >= nb) return;
+  Rigid2 &B = rb[b];
+  B.vel[0] += B.tmp_imp[0] * B.inv_mass; B.vel[1] += B.tmp_imp[1] * B.inv_mass;
+  B.omega += B.inv_I * B.tmp_trq;
+  B.tmp_imp[0] = B.tmp_imp[1] = B.tmp_trq = 0.0f;
+}
+// advect_rigid_bodies, dim = 2 (same conventions as k_rigid_advect)
+__global__ void k2_rigid_advect(Rigid2 *rb, int nb, Steps2 steps, float dt, float g0, float g1) {
+  const int b = threadIdx.x;
+  if (b < 1 || b >= nb) return;
+  Rigid2 &B = rb[b];
+  const Step2 &S = steps.s[b];
+  if (S.has_pos) {
+    for (int k = 0; k < 2; k++) { B.vel[k] = (S.p1[k] - S.p0[k]) / dt; B.pos[k] = S.p1[k]; }
+  } else {
+    const float f = expf(-B.lin_damp * dt);
+    for (int k = 0; k < 2; k++) { B.vel[k] *= f; B.pos[k] += B.vel[k] * dt; }
+  }
+  if (S.has_rot) {
+    B.omega = (S.a1 - S.a0) / dt;
+    B.angle = S.a1;
+  } else {
+    B.omega *= expf(-B.ang_damp * dt);
+    B.angle += B.omega * dt;
+  }
+  B.vel[0] += g0 * B.mass * dt * B.inv_mass; B.vel[1] += g1 * B.mass * dt * B.inv_mass;
+}
+__global__ __launch_bounds__(256) void k2_sample_positions(const Rigid2 *__restrict__ rb, const Sample2 *__restrict__ smp, uint32_t n,
+                                                           float *__restrict__ out) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const Rigid2 &B = rb[smp[s].body];
+  float w[2];
+  rot2(B.angle, smp[s].off, w);
+  out[2 * s] = w[0] + B.pos[0]; out[2 * s + 1] = w[1] + B.pos[1];
+}
+
+}  // namespace mpm2d

@@ -2011,6 +2011,19 @@ struct mpmhip2d_ctx {
   float t = 0.0f, request_t = 0.0f;
   hipStream_t stream = nullptr;
   std::string err;
+  // CPIC rigid bodies (k_rigid2d.h): segments, boundary particles, dense colored distance field
+  struct HostRigid2 { mpmhip2d_rigid_config cfg{}; float mass = 0, inertia = 0; };
+  bool rigid_enabled = false;
+  std::vector<HostRigid2> bodies;
+  std::vector<mpm2d::Sample2> h_smp;
+  std::vector<float> h_elems;
+  mpm2d::Rigid2 *d_rb = nullptr;
+  mpm2d::Sample2 *d_smp = nullptr;
+  float *d_elems = nullptr;
+  unsigned long long *d_mind = nullptr;
+  uint32_t *d_tags = nullptr, *d_states = nullptr;
+  mpm2d::Bnd2 *d_bnd = nullptr;
+  float penalty = 0.0f, pushing_force = 20000.0f;
 };
 static thread_local std::string g_2d_create_error;
 static int fail2d(mpmhip2d_ctx *m, int code, const std::string &msg) {
@@ -2069,6 +2082,7 @@ void mpmhip2d_destroy(mpmhip2d_ctx *m) {
   if (m->stream) { hipStreamSynchronize(m->stream); hipStreamDestroy(m->stream); }
   hipFree(m->x); hipFree(m->v); hipFree(m->F); hipFree(m->B); hipFree(m->aux); hipFree(m->gid); hipFree(m->pid); hipFree(m->grid);
   hipFree(m->n_dead); hipFree(m->d_groups);
+  hipFree(m->d_rb); hipFree(m->d_smp); hipFree(m->d_elems); hipFree(m->d_mind); hipFree(m->d_tags); hipFree(m->d_states); hipFree(m->d_bnd);
   delete m;
 }
 
@@ -2146,6 +2160,53 @@ int mpmhip2d_add_particles(mpmhip2d_ctx *m, int32_t group, int64_t n, const floa
   return MPMHIP_OK;
 }
 
+static mpm2d::RigidArgs2 rigid_args2(mpmhip2d_ctx *m) {
+  mpm2d::RigidArgs2 R;
+  memset(&R, 0, sizeof R);
+  R.enabled = m->rigid_enabled && m->bodies.size() > 1;  // has_rigid_body()
+  R.mind = m->d_mind; R.tags = m->d_tags; R.rb = m->d_rb; R.states = m->d_states; R.bnd = m->d_bnd;
+  R.penalty = m->penalty; R.pushing_force = m->pushing_force;
+  return R;
+}
+// rasterize_rigid_boundary + gather_cdf (src/mpm.cpp:466-472, 506-508)
+static int rigid2_pre(mpmhip2d_ctx *m) {
+  const size_t nodes = (size_t)(m->P.res[0] + 1) * (m->P.res[1] + 1);
+  HIPCHK2D(m, hipMemsetAsync(m->d_mind, 0xFF, sizeof(unsigned long long) * nodes, m->stream));
+  HIPCHK2D(m, hipMemsetAsync(m->d_tags, 0, sizeof(uint32_t) * nodes, m->stream));
+  const mpm2d::RigidArgs2 R = rigid_args2(m);
+  const uint32_t ns = (uint32_t)m->h_smp.size();
+  if (ns)
+    hipLaunchKernelGGL(mpm2d::k2_cdf_rasterize, dim3((ns + 255) / 256), dim3(256), 0, m->stream, m->P.res[0], m->P.res[1], m->P.dx, m->P.idx, R,
+                       (const mpm2d::Sample2 *)m->d_smp, (const float *)m->d_elems, ns);
+  if (m->n)
+    hipLaunchKernelGGL(mpm2d::k2_gather_cdf, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, m->stream, m->P.res[0], m->P.res[1], m->P.dx,
+                       m->P.idx, R, m->n, (const float *)m->x, (const int32_t *)m->pid);
+  HIPCHK2D(m, hipGetLastError());
+  return MPMHIP_OK;
+}
+static int rigid2_advect(mpmhip2d_ctx *m) {
+  mpm2d::Steps2 st;
+  memset(&st, 0, sizeof st);
+  const float dt = m->P.dt, rad = (float)(M_PI / 180.0);
+  for (size_t b = 1; b < m->bodies.size(); b++) {
+    const auto &cfg = m->bodies[b].cfg;
+    float o[3];
+    if (cfg.scripted_position) {
+      st.s[b].has_pos = 1;
+      cfg.scripted_position(cfg.position_user, m->t, o); st.s[b].p0[0] = o[0]; st.s[b].p0[1] = o[1];
+      cfg.scripted_position(cfg.position_user, m->t + dt, o); st.s[b].p1[0] = o[0]; st.s[b].p1[1] = o[1];
+    }
+    if (cfg.scripted_rotation) {
+      st.s[b].has_rot = 1;
+      cfg.scripted_rotation(cfg.rotation_user, m->t, o); st.s[b].a0 = o[0] * rad;
+      cfg.scripted_rotation(cfg.rotation_user, m->t + dt, o); st.s[b].a1 = o[0] * rad;
+    }
+  }
+  hipLaunchKernelGGL(mpm2d::k2_rigid_advect, dim3(1), dim3(64), 0, m->stream, m->d_rb, (int)m->bodies.size(), st, dt, m->P.g[0], m->P.g[1]);
+  HIPCHK2D(m, hipGetLastError());
+  return MPMHIP_OK;
+}
+
 int mpmhip2d_substep(mpmhip2d_ctx *m) {  // MPM<2>::substep, src/mpm.cpp:452-575
   if (!m) return MPMHIP_EINVAL;
   HIPCHK2D(m, hipSetDevice(m->device));
@@ -2153,17 +2214,215 @@ int mpmhip2d_substep(mpmhip2d_ctx *m) {  // MPM<2>::substep, src/mpm.cpp:452-575
   m->P.t = m->t;
   const dim3 pg((unsigned)std::max<int64_t>((m->n + 255) / 256, 1)), gg((unsigned)((nodes + 255) / 256)), wg(256);
   HIPCHK2D(m, hipMemsetAsync(m->grid, 0, sizeof(float) * 3 * nodes, m->stream));
+  const mpm2d::RigidArgs2 R = rigid_args2(m);
+  if (R.enabled)
+    if (int rc = rigid2_pre(m)) return rc;
   if (m->n)
     hipLaunchKernelGGL(mpm2d::k_p2g, pg, wg, 0, m->stream, m->P, m->n, (const float *)m->x, m->v, (const float *)m->F,
                        (const float *)m->B, (const float *)m->aux, (const int32_t *)m->gid, (const int32_t *)m->pid,
-                       (const GroupParams *)m->d_groups, m->grid);
+                       (const GroupParams *)m->d_groups, m->grid, R);
+  if (R.enabled) hipLaunchKernelGGL(mpm2d::k2_rigid_apply_tmp, dim3(1), dim3(64), 0, m->stream, m->d_rb, (int)m->bodies.size());
   hipLaunchKernelGGL(mpm2d::k_grid, gg, wg, 0, m->stream, m->P, m->LS, m->grid);
   if (m->n)
     hipLaunchKernelGGL(mpm2d::k_g2p, pg, wg, 0, m->stream, m->P, m->LS, m->n, m->x, m->v, m->F, m->B, m->aux, (const int32_t *)m->gid,
-                       m->pid, (const GroupParams *)m->d_groups, (const float *)m->grid, m->n_dead);
+                       m->pid, (const GroupParams *)m->d_groups, (const float *)m->grid, m->n_dead, R);
+  if (R.enabled) {
+    hipLaunchKernelGGL(mpm2d::k2_rigid_apply_tmp, dim3(1), dim3(64), 0, m->stream, m->d_rb, (int)m->bodies.size());
+    if (int rc = rigid2_advect(m)) return rc;
+  }
   HIPCHK2D(m, hipGetLastError());
   m->t += m->P.dt;
   return MPMHIP_OK;
+}
+
+// ---- CPIC rigid bodies in 2D: add_particles(type='rigid') of MPM<2> (src/mpm_rigid_body.cpp:130-252, dim = 2 branches)
+int mpmhip2d_set_rigid_coupling(mpmhip2d_ctx *m, float penalty, float pushing_force) {
+  if (!m) return MPMHIP_EINVAL;
+  m->penalty = penalty; m->pushing_force = pushing_force;
+  return MPMHIP_OK;
+}
+int mpmhip2d_add_rigid_body(mpmhip2d_ctx *m, const mpmhip2d_rigid_config *cfg, int64_t n_segments, const float *segments) {
+  if (!m || !cfg || !segments || n_segments <= 0) return MPMHIP_EINVAL;
+  HIPCHK2D(m, hipSetDevice(m->device));
+  HIPCHK2D(m, hipStreamSynchronize(m->stream));
+  const size_t nodes = (size_t)(m->P.res[0] + 1) * (m->P.res[1] + 1);
+  if (!m->rigid_enabled) {
+    hipError_t e = hipSuccess;
+    auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    A(dmalloc(&m->d_rb, (size_t)mpm2d::MAX_RIGID2)); A(dmalloc(&m->d_mind, nodes)); A(dmalloc(&m->d_tags, nodes));
+    A(dmalloc(&m->d_states, (size_t)m->cap)); A(dmalloc(&m->d_bnd, (size_t)m->cap));
+    if (e != hipSuccess) return fail2d(m, MPMHIP_ENOMEM, std::string("rigid coupling: ") + hipGetErrorString(e));
+    HIPCHK2D(m, hipMemset(m->d_rb, 0, sizeof(mpm2d::Rigid2) * mpm2d::MAX_RIGID2));
+    HIPCHK2D(m, hipMemset(m->d_states, 0, sizeof(uint32_t) * (size_t)m->cap));
+    HIPCHK2D(m, hipMemset(m->d_bnd, 0, sizeof(mpm2d::Bnd2) * (size_t)m->cap));
+    m->bodies.clear();
+    m->bodies.emplace_back();  // the background body
+    m->rigid_enabled = true;
+  }
+  if ((int)m->bodies.size() >= mpm2d::MAX_RIGID2) return fail2d(m, MPMHIP_ECAPACITY, "too many rigid bodies");
+  const bool spos = cfg->scripted_position != nullptr, srot = cfg->scripted_rotation != nullptr;
+  if (!cfg->recenter && !(spos && srot)) return fail2d(m, MPMHIP_EINVAL, "recenter = 0 needs a scripted position and rotation");
+  std::vector<float> seg(segments, segments + 4 * n_segments);
+  const float sc[2] = {cfg->scale[0] != 0 ? cfg->scale[0] : 1.0f, cfg->scale[1] != 0 ? cfg->scale[1] : 1.0f};
+  for (int64_t e = 0; e < n_segments; e++) {
+    if (cfg->reverse_vertices) { std::swap(seg[4 * e], seg[4 * e + 2]); std::swap(seg[4 * e + 1], seg[4 * e + 3]); }
+    for (int q = 0; q < 2; q++) for (int k = 0; k < 2; k++) seg[4 * e + 2 * q + k] *= sc[k];
+  }
+  // mass, centre of mass, inertia: the segments as a shell of line density `density` (the rigid body the reference build
+  // is tested against, oracle/taichi_shim/.../rigid_body_shim.h, treats 2D bodies this way whether codimensional or not)
+  const double density = cfg->density > 0 ? cfg->density : (cfg->codimensional ? 40.0 : 400.0);
+  double M = 0, com[2] = {0, 0}, S00 = 0, S11 = 0;
+  for (int64_t e = 0; e < n_segments; e++) {
+    const double a[2] = {seg[4 * e], seg[4 * e + 1]}, b[2] = {seg[4 * e + 2], seg[4 * e + 3]};
+    const double mm = std::sqrt((b[0] - a[0]) * (b[0] - a[0]) + (b[1] - a[1]) * (b[1] - a[1])) * density;
+    M += mm;
+    for (int k = 0; k < 2; k++) com[k] += mm * 0.5 * (a[k] + b[k]);
+    S00 += mm / 6.0 * (a[0] * a[0] + b[0] * b[0] + (a[0] + b[0]) * (a[0] + b[0]));
+    S11 += mm / 6.0 * (a[1] * a[1] + b[1] * b[1] + (a[1] + b[1]) * (a[1] + b[1]));
+  }
+  if (!(M > 0)) return fail2d(m, MPMHIP_EINVAL, "rigid body without mass");
+  com[0] /= M; com[1] /= M;
+  const double I = (S00 - M * com[0] * com[0]) + (S11 - M * com[1] * com[1]);
+  if (!cfg->recenter) com[0] = com[1] = 0.0;
+  for (int64_t e = 0; e < n_segments; e++)
+    for (int q = 0; q < 2; q++) for (int k = 0; k < 2; k++) seg[4 * e + 2 * q + k] -= (float)com[k];
+  mpm2d::Rigid2 D;
+  memset(&D, 0, sizeof D);
+  float o[3] = {cfg->initial_position[0], cfg->initial_position[1], 0};
+  if (spos) cfg->scripted_position(cfg->position_user, m->t, o);
+  D.pos[0] = o[0]; D.pos[1] = o[1];
+  float ang[3] = {cfg->initial_rotation, 0, 0};
+  if (srot) cfg->scripted_rotation(cfg->rotation_user, m->t, ang);
+  D.angle = ang[0] * (float)(M_PI / 180.0);
+  D.vel[0] = spos ? 0.0f : cfg->initial_velocity[0]; D.vel[1] = spos ? 0.0f : cfg->initial_velocity[1];
+  D.omega = srot ? 0.0f : cfg->initial_angular_velocity;
+  D.mass = (float)M; D.inv_mass = spos ? 0.0f : (float)(1.0 / M); D.inv_I = srot ? 0.0f : (float)(1.0 / I);
+  D.fric[0] = cfg->friction[0]; D.fric[1] = cfg->friction[1];
+  D.lin_damp = cfg->linear_damping; D.ang_damp = cfg->angular_damping;
+  D.scripted = (spos ? 1 : 0) | (srot ? 2 : 0);
+  // boundary particles (src/mpm_rigid_body.cpp:196-207): max(ceil(length / dx), 2) per segment, at the mid points of equal parts
+  const int body = (int)m->bodies.size();
+  const size_t elem0 = m->h_elems.size() / 4;
+  const float cs = std::cos(D.angle), sn = std::sin(D.angle);
+  int32_t allocated = 0;
+  for (int64_t e = 0; e < n_segments; e++) {
+    const float a[2] = {seg[4 * e], seg[4 * e + 1]}, b[2] = {seg[4 * e + 2], seg[4 * e + 3]};
+    const float len = std::sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]));
+    const int ns = std::max((int)std::ceil(len * m->P.idx), 2);
+    for (int j = 0; j < ns; j++) {
+      const float t = (0.5f + j) / ns;
+      mpm2d::Sample2 s;
+      s.off[0] = a[0] * (1.0f - t) + b[0] * t; s.off[1] = a[1] * (1.0f - t) + b[1] * t;
+      s.body = body; s.elem = (int)(elem0 + e);
+      const float w[2] = {(cs * s.off[0] - sn * s.off[1] + D.pos[0]) * m->P.idx, (sn * s.off[0] + cs * s.off[1] + D.pos[1]) * m->P.idx};
+      const bool near_wall = w[0] < 7.0f || w[1] < 7.0f || w[0] - m->P.res[0] > -7.0f || w[1] - m->P.res[1] > -7.0f;
+      if (!near_wall) m->h_smp.push_back(s);
+      allocated++;
+    }
+  }
+  m->next_pid += allocated;  // boundary particles take creation ids from the same counter (src/particle_allocator.h:68-74)
+  m->h_elems.insert(m->h_elems.end(), seg.begin(), seg.end());
+  (void)hipFree(m->d_smp); (void)hipFree(m->d_elems);
+  m->d_smp = nullptr; m->d_elems = nullptr;
+  HIPCHK2D(m, dmalloc(&m->d_smp, std::max<size_t>(m->h_smp.size(), 1)));
+  HIPCHK2D(m, dmalloc(&m->d_elems, std::max<size_t>(m->h_elems.size(), 4)));
+  if (!m->h_smp.empty()) HIPCHK2D(m, hipMemcpy(m->d_smp, m->h_smp.data(), sizeof(mpm2d::Sample2) * m->h_smp.size(), hipMemcpyHostToDevice));
+  HIPCHK2D(m, hipMemcpy(m->d_elems, m->h_elems.data(), sizeof(float) * m->h_elems.size(), hipMemcpyHostToDevice));
+  HIPCHK2D(m, hipMemcpy(m->d_rb + body, &D, sizeof D, hipMemcpyHostToDevice));
+  mpmhip2d_ctx::HostRigid2 H;
+  H.cfg = *cfg; H.mass = (float)M; H.inertia = (float)I;
+  m->bodies.push_back(H);
+  return body;
+}
+// out[10]: position 2, angle (radians), velocity 2, angular velocity, mass, inv_mass, inertia, inv_inertia
+int mpmhip2d_rigid_get_state(mpmhip2d_ctx *m, int32_t id, float *out) {
+  if (!m || !out) return MPMHIP_EINVAL;
+  if (!m->rigid_enabled || id < 1 || id >= (int)m->bodies.size()) return fail2d(m, MPMHIP_EINVAL, "no such rigid body");
+  HIPCHK2D(m, hipSetDevice(m->device));
+  HIPCHK2D(m, hipStreamSynchronize(m->stream));
+  mpm2d::Rigid2 D;
+  HIPCHK2D(m, hipMemcpy(&D, m->d_rb + id, sizeof D, hipMemcpyDeviceToHost));
+  out[0] = D.pos[0]; out[1] = D.pos[1]; out[2] = D.angle; out[3] = D.vel[0]; out[4] = D.vel[1]; out[5] = D.omega;
+  out[6] = D.mass; out[7] = D.inv_mass; out[8] = m->bodies[id].inertia; out[9] = D.inv_I;
+  return MPMHIP_OK;
+}
+// world positions of the boundary particles of body id (id < 0: all); returns the count
+int64_t mpmhip2d_rigid_get_samples(mpmhip2d_ctx *m, int32_t id, int64_t cap, float *pos) {
+  if (!m) return MPMHIP_EINVAL;
+  if (!m->rigid_enabled) return 0;
+  if (hipSetDevice(m->device) != hipSuccess) return MPMHIP_EHIP;
+  const uint32_t ns = (uint32_t)m->h_smp.size();
+  std::vector<float> w((size_t)ns * 2);
+  if (ns && pos) {
+    float *d = nullptr;
+    HIPCHK2D(m, dmalloc(&d, (size_t)ns * 2));
+    hipLaunchKernelGGL(mpm2d::k2_sample_positions, dim3((ns + 255) / 256), dim3(256), 0, m->stream, (const mpm2d::Rigid2 *)m->d_rb,
+                       (const mpm2d::Sample2 *)m->d_smp, ns, d);
+    hipError_t e = hipMemcpyAsync(w.data(), d, sizeof(float) * w.size(), hipMemcpyDeviceToHost, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    (void)hipFree(d);
+    HIPCHK2D(m, e);
+  }
+  int64_t n = 0;
+  for (size_t s = 0; s < m->h_smp.size(); s++) {
+    if (id >= 0 && m->h_smp[s].body != id) continue;
+    if (n < cap && pos) { pos[2 * n] = w[2 * s]; pos[2 * n + 1] = w[2 * s + 1]; }
+    n++;
+  }
+  return n;
+}
+// rasterize_rigid_boundary + gather_cdf as a phase (parity tests), then: dense (res+1)^2 grid states / distances, and per
+// live particle in slot order states, boundary distance, normal (2), near flag
+int mpmhip2d_cdf_phase(mpmhip2d_ctx *m) {
+  if (!m) return MPMHIP_EINVAL;
+  HIPCHK2D(m, hipSetDevice(m->device));
+  if (!(m->rigid_enabled && m->bodies.size() > 1)) return MPMHIP_OK;
+  return rigid2_pre(m);
+}
+int mpmhip2d_download_cdf(mpmhip2d_ctx *m, uint32_t *states, float *distance) {
+  if (!m || !states || !distance) return MPMHIP_EINVAL;
+  const size_t nodes = (size_t)(m->P.res[0] + 1) * (m->P.res[1] + 1);
+  memset(states, 0, nodes * 4); memset(distance, 0, nodes * 4);
+  if (!m->rigid_enabled) return MPMHIP_OK;
+  HIPCHK2D(m, hipSetDevice(m->device));
+  HIPCHK2D(m, hipStreamSynchronize(m->stream));
+  std::vector<unsigned long long> hm(nodes);
+  std::vector<uint32_t> ht(nodes);
+  HIPCHK2D(m, hipMemcpy(hm.data(), m->d_mind, nodes * 8, hipMemcpyDeviceToHost));
+  HIPCHK2D(m, hipMemcpy(ht.data(), m->d_tags, nodes * 4, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < nodes; i++) {
+    const bool has = hm[i] != ~0ull;
+    states[i] = (ht[i] & 0xFFFFFFu) | (has ? ((uint32_t)(hm[i] & 0xFFu) << 24) : 0u);
+    if (has) { const uint32_t bits = (uint32_t)(hm[i] >> 32); float d; memcpy(&d, &bits, 4); distance[i] = d * m->P.dx; }
+  }
+  return MPMHIP_OK;
+}
+int64_t mpmhip2d_download_colours(mpmhip2d_ctx *m, int64_t capacity, uint32_t *states, float *distance, float *normal, int32_t *near) {
+  if (!m) return MPMHIP_EINVAL;
+  if (hipSetDevice(m->device) != hipSuccess || hipStreamSynchronize(m->stream) != hipSuccess) return MPMHIP_EHIP;
+  const size_t n = (size_t)m->n;
+  std::vector<int32_t> hp(n);
+  std::vector<uint32_t> hs(n, 0u);
+  std::vector<mpm2d::Bnd2> hb(n);
+  memset(hb.data(), 0, sizeof(mpm2d::Bnd2) * n);
+  if (n) {
+    HIPCHK2D(m, hipMemcpy(hp.data(), m->pid, n * 4, hipMemcpyDeviceToHost));
+    if (m->rigid_enabled) {
+      HIPCHK2D(m, hipMemcpy(hs.data(), m->d_states, n * 4, hipMemcpyDeviceToHost));
+      HIPCHK2D(m, hipMemcpy(hb.data(), m->d_bnd, sizeof(mpm2d::Bnd2) * n, hipMemcpyDeviceToHost));
+    }
+  }
+  int64_t k = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (hp[i] < 0) continue;
+    if (k >= capacity) return fail2d(m, MPMHIP_ECAPACITY, "download buffer too small");
+    if (states) states[k] = hs[i];
+    if (distance) distance[k] = hb[i].dist;
+    if (normal) { normal[2 * k] = hb[i].n[0]; normal[2 * k + 1] = hb[i].n[1]; }
+    if (near) near[k] = (int32_t)hb[i].near;
+    k++;
+  }
+  return k;
 }
 
 int mpmhip2d_step(mpmhip2d_ctx *m, float dt) {  // MPM<dim>::step, src/mpm.cpp:428-439

@@ -29,6 +29,7 @@ class Simulation2D:
         self._levelset = None
         self._n_added = 0
         self.frame = 0
+        self._rigids = []  # ctypes keep-alives of the rigid bodies' configs / script callbacks
 
     def initialize(self, config):
         cfg = dict(config)
@@ -74,6 +75,7 @@ class Simulation2D:
         if rc != 0:
             raise MPMError("mpmhip2d_create failed (%d): %s" % (rc, self._L.mpmhip2d_last_error(None).decode()))
         self._ctx = ctx
+        self._check(self._L.mpmhip2d_set_rigid_coupling(ctx, float(cfg.get("penalty", 0.0)), float(cfg.get("pushing_force", 20000.0))))
         self._apply_levelset()
         for gi, (mat, params, arrs) in enumerate(self._staged):
             self._add(mat, params, *arrs)
@@ -107,6 +109,8 @@ class Simulation2D:
         """MPM<2>::add_particles (src/mpm.cpp:77-270) with explicit `positions=` (n, 2) or a `square=(lo, hi)` lattice"""
         cfg = dict(config)
         ptype = cfg.get("type")
+        if ptype == "rigid":  # src/mpm.cpp:80-83
+            return str(self.add_rigid_body(cfg))
         if ptype not in MATERIAL_IDS:
             raise MPMError("unknown particle type %r" % (ptype,))
         dx = self.delta_x
@@ -186,6 +190,83 @@ class Simulation2D:
 
     def get_current_time(self):
         return self._L.mpmhip2d_current_time(self._ctx) if self._ctx is not None else 0.0
+
+    # ---------------------------------------------------------------- CPIC rigid bodies (segments)
+    def add_rigid_body(self, cfg):
+        """MPM<2>::add_rigid_particle (src/mpm_rigid_body.cpp:130-252, dim = 2): mesh=(n, 2, 2) segments; keys as in 3D
+        (codimensional is mandatory; initial_rotation / scripted_rotation are one angle in degrees)"""
+        if "codimensional" not in cfg:
+            raise MPMError("rigid bodies need the key 'codimensional'")
+        if "scripted_position" not in cfg and "initial_position" not in cfg:
+            raise MPMError("Please specify one (and only one) of 'scripted_position' and 'initial_position'.")
+        seg = np.ascontiguousarray(cfg["mesh"], np.float32).reshape(-1, 4)
+        r = _lib.RigidConfig2D()
+        r.codimensional = int(bool(cfg["codimensional"]))
+        r.recenter = int(bool(cfg.get("recenter", True)))
+        r.reverse_vertices = int(bool(cfg.get("reverse_vertices", False)))
+        r.density = float(cfg.get("density", 0.0))
+        f0, f1 = (cfg["friction"],) * 2 if "friction" in cfg else (cfg.get("friction0", 0.0), cfg.get("friction1", 0.0))
+        r.friction[:] = (float(f0), float(f1))
+        r.restitution = float(cfg.get("restitution", 0.0))
+        sc = cfg.get("scale", (1.0, 1.0))
+        r.scale[:] = (float(sc[0]), float(sc[1]))
+        p0 = cfg.get("initial_position", (0.0, 0.0))
+        r.initial_position[:] = (float(p0[0]), float(p0[1]))
+        r.initial_rotation = float(cfg.get("initial_rotation", 0.0))
+        v0 = cfg.get("initial_velocity", (0.0, 0.0))
+        r.initial_velocity[:] = (float(v0[0]), float(v0[1]))
+        r.initial_angular_velocity = float(cfg.get("initial_angular_velocity", 0.0))
+        r.linear_damping = float(cfg.get("linear_damping", 0.0))
+        r.angular_damping = float(cfg.get("angular_damping", 0.0))
+        if cfg.get("scripted_position") is not None:
+            fn = cfg["scripted_position"]
+
+            def pos(_u, t, out, fn=fn):
+                v = fn(float(t))
+                out[0], out[1] = float(v[0]), float(v[1])
+            r.scripted_position = _lib.SCRIPT_FN(pos)
+        if cfg.get("scripted_rotation") is not None:
+            gn = cfg["scripted_rotation"]
+
+            def rot(_u, t, out, gn=gn):
+                out[0] = float(gn(float(t)))
+            r.scripted_rotation = _lib.SCRIPT_FN(rot)
+        self._ensure_ctx()
+        rid = self._check(self._L.mpmhip2d_add_rigid_body(self._ctx, C.byref(r), len(seg), seg.ctypes.data_as(C.POINTER(C.c_float))))
+        self._rigids.append(r)
+        return rid
+
+    def get_rigid_state(self, rid):
+        """position 2, angle (radians), velocity 2, angular velocity, mass, inv_mass, inertia, inv_inertia"""
+        o = np.zeros(10, np.float32)
+        self._check(self._L.mpmhip2d_rigid_get_state(self._ctx, int(rid), o.ctypes.data_as(C.POINTER(C.c_float))))
+        return o
+
+    def get_rigid_samples(self, rid=-1):
+        n = self._check(self._L.mpmhip2d_rigid_get_samples(self._ctx, int(rid), 0, None))
+        pos = np.zeros((n, 2), np.float32)
+        if n:
+            self._check(self._L.mpmhip2d_rigid_get_samples(self._ctx, int(rid), n, pos.ctypes.data_as(C.POINTER(C.c_float))))
+        return pos
+
+    def cdf_phase(self):
+        """rasterize_rigid_boundary + gather_cdf as one phase (parity tests; substep() runs them itself)"""
+        self._ensure_ctx(); self._check(self._L.mpmhip2d_cdf_phase(self._ctx))
+
+    def download_cdf(self):
+        shp = tuple(r + 1 for r in self.res)
+        st, d = np.zeros(shp, np.uint32), np.zeros(shp, np.float32)
+        self._check(self._L.mpmhip2d_download_cdf(self._ctx, st.ctypes.data_as(C.POINTER(C.c_uint32)), d.ctypes.data_as(C.POINTER(C.c_float))))
+        return st, d
+
+    def download_colours(self):
+        """per live particle in slot order: states, boundary distance, normal, near flag"""
+        n = self.get_num_particles()
+        st, d, nr, near = np.zeros(n, np.uint32), np.zeros(n, np.float32), np.zeros((n, 2), np.float32), np.zeros(n, np.int32)
+        fp = C.POINTER(C.c_float)
+        got = self._check(self._L.mpmhip2d_download_colours(self._ctx, n, st.ctypes.data_as(C.POINTER(C.c_uint32)), d.ctypes.data_as(fp),
+                                                            nr.ctypes.data_as(fp), near.ctypes.data_as(C.POINTER(C.c_int32))))
+        return dict(states=st[:got], distance=d[:got], normal=nr[:got], near=near[:got])
 
     def get_num_particles(self):
         if self._ctx is None:

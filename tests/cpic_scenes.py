@@ -97,3 +97,67 @@ def build_device(tm, body, material, **cfg):
 def rigid_vector(state):
     """position 3, quaternion 4, velocity 3, angular velocity 3, mass"""
     return np.concatenate([state["position"], state["rotation"], state["velocity"], state["angular_velocity"], [state["mass"]]]).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------- 2D (MPM<2>)
+RES2, DX2 = 64, 1.0 / 64
+VOL2 = DX2 ** 2 / 4
+MASS2 = VOL2 * 400.0
+
+
+def bar2(half=0.15):
+    return np.array([[[-half, 0.0], [half, 0.0]]], np.float32)
+
+
+def box2(hx=0.08, hy=0.05):
+    c = np.array([[-hx, -hy], [hx, -hy], [hx, hy], [-hx, hy]], np.float32)
+    return np.array([[c[i], c[(i + 1) % 4]] for i in range(4)], np.float32)
+
+
+def block2(lo=22, hi=42, seed=0):
+    rng = np.random.default_rng(seed)
+    g = np.arange(lo, hi) + 0.25
+    X = np.stack(np.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)
+    X = np.concatenate([X, X + 0.5]) + rng.uniform(-0.2, 0.2, (2 * len(X), 2))
+    return (X * DX2).astype(np.float32), rng.normal(0, 0.3, X.shape).astype(np.float32)
+
+
+BODIES2 = {
+    "bar": dict(mesh=bar2(), codimensional=True, density=40.0, friction=0.3, initial_position=(0.5, 0.5), initial_rotation=20.0),
+    "box": dict(mesh=box2(), codimensional=False, density=400.0, friction0=0.2, friction1=-1.0, initial_position=(0.5, 0.52),
+                initial_rotation=30.0, initial_velocity=(0.3, -0.5), initial_angular_velocity=2.0),
+}
+SCRIPT2 = dict(p0=(0.5, 0.55), vel=(0.2, -1.0), a0=10.0, rate=180.0)
+CASES2 = [("bar_jelly", "bar", "jelly", 5, dict(penalty=1e3)), ("box_sand", "box", "sand", 5, dict(penalty=1e3)),
+          ("scripted_bar_water", "scripted", "water", 8, dict())]
+
+
+def build_reference2(refmpm, body, material, **cfg):
+    x, v = block2()
+    ref = refmpm.Sim(RES2, DX2, DT, dim=2, gravity=(0, -10), **cfg)
+    if body == "scripted":
+        s = SCRIPT2
+        rid = ref.add_rigid2(bar2(), script=[1, s["p0"][0], s["p0"][1], s["vel"][0], s["vel"][1], 1, s["a0"], s["rate"]],
+                             codimensional=True, friction=0.4)
+    else:
+        b = dict(BODIES2[body])
+        rid = ref.add_rigid2(b.pop("mesh"), **b)
+    ref.add_particles(material, MASS2, VOL2, x, v)
+    return ref, rid
+
+
+def build_device2(tm, body, material, **cfg):
+    x, v = block2()
+    sim = tm.create_simulation2("mpm").initialize(dict(res=(RES2,) * 2, delta_x=DX2, base_delta_t=DT, gravity=(0, -10),
+                                                       max_particles=len(x) + 16, **cfg))
+    f32 = np.float32
+    if body == "scripted":
+        s = SCRIPT2
+        rid = int(sim.add_particles(dict(type="rigid", mesh=bar2(), codimensional=True, friction=0.4,
+                                         scripted_position=lambda t: [f32(s["p0"][k]) + f32(s["vel"][k]) * f32(t) for k in range(2)],
+                                         scripted_rotation=lambda t: f32(s["a0"]) + f32(s["rate"]) * f32(t))))
+    else:
+        rid = int(sim.add_particles(dict(type="rigid", **BODIES2[body])))
+    gp = orc.group_params(material, MASS2, VOL2)[0]
+    sim.add_particles(dict(type=material, positions=x, velocities=v, params=gp))
+    return sim, rid

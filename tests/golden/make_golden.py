@@ -255,10 +255,38 @@ def cpic_fixture(here):
     np.savez_compressed(os.path.join(here, "ref_cpic.npz"), **out)
 
 
+def cpic2d_fixture(here):
+    """the same for MPM<2> (generic transfers with the colour test, segments instead of triangles)"""
+    from tests import cpic_scenes as cs
+    out = {}
+    for name, body, material, n, cfg in cs.CASES2:
+        sim, rid = cs.build_reference2(ref, body, material, **cfg)
+        out[name + "_body0"] = sim.rigid_state2(rid)
+        out[name + "_samples"] = sim.rigid_samples2(rid)
+        sim.sort(); sim.rasterize_rigid_boundary()
+        st, d = sim.download_cdf2()
+        nz = np.flatnonzero(st.reshape(-1))
+        out[name + "_cdf_idx"], out[name + "_cdf_states"], out[name + "_cdf_dist"] = nz.astype(np.int32), st.reshape(-1)[nz], d.reshape(-1)[nz]
+        sim.gather_cdf()
+        pc = sim.particle_cdf2()
+        o = np.argsort(sim.download(by_id=False)["id"], kind="stable")
+        out[name + "_p_states"], out[name + "_p_near"] = pc["states"][o], pc["near"][o].astype(np.int8)
+        out[name + "_p_dist"], out[name + "_p_normal"] = pc["distance"][o], pc["normal"][o]
+        sim, rid = cs.build_reference2(ref, body, material, **cfg)
+        sim.substep(n)
+        p = sim.download(by_id=True)
+        out[name + "_x"], out[name + "_v"], out[name + "_F"] = p["x"], p["v"], p["F"]
+        o = np.argsort(sim.download(by_id=False)["id"], kind="stable")
+        out[name + "_states"] = sim.particle_cdf2()["states"][o]
+        out[name + "_body"] = sim.rigid_state2(rid)
+        print("cpic2d", name, len(p["x"]), "particles,", len(nz), "coloured nodes,", int((out[name + "_states"] != 0).sum()), "coloured particles")
+    np.savez_compressed(os.path.join(here, "ref_cpic2d.npz"), **out)
+
+
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     ref.set_threads(1)  # the generic P2G of the reference is racy with more than one thread (SURVEY quirk 5)
-    what = sys.argv[1:] or (list(MATS) + ["materials", "kernels", "shapes", "mpm2d", "cpic"])
+    what = sys.argv[1:] or (list(MATS) + ["materials", "kernels", "shapes", "mpm2d", "cpic", "cpic2d"])
     for w in what:
         if w in MATS:
             substep_fixture(here, w)
@@ -272,6 +300,8 @@ def main():
             mpm2d_fixture(here)
         elif w == "cpic":
             cpic_fixture(here)
+        elif w == "cpic2d":
+            cpic2d_fixture(here)
 
 
 if __name__ == "__main__":

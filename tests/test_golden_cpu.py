@@ -282,3 +282,19 @@ def test_rigid_body_shim_mass_properties_are_the_textbook_ones():
     m = 40.0 * 0.16
     assert abs(st["mass"] - m) < 1e-5 * m
     np.testing.assert_allclose(np.diag(st["inertia"]), m * 0.16 / 12 * np.array([1, 2, 1]), rtol=1e-5)
+
+
+def test_live_reference_reproduces_its_2d_cpic_fixture():
+    from oracle import refmpm
+    if not refmpm.available():
+        pytest.skip("oracle/_ref/libmpm_ref.so is not built")
+    from tests import cpic_scenes as cs
+    refmpm.set_threads(1)
+    g = np.load(os.path.join(HERE, "golden", "ref_cpic2d.npz"))
+    for name, body, material, n, cfg in cs.CASES2:
+        sim, rid = cs.build_reference2(refmpm, body, material, **cfg)
+        np.testing.assert_array_equal(sim.rigid_state2(rid), g[name + "_body0"])
+        sim.substep(n)
+        p = sim.download(by_id=True)
+        np.testing.assert_array_equal(p["x"], g[name + "_x"])
+        np.testing.assert_array_equal(sim.rigid_state2(rid), g[name + "_body"])

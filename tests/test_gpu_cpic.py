@@ -237,3 +237,64 @@ def test_rotating_paddle_in_a_million_particles_matches_the_live_reference(tm):
     assert (st != h["states"].astype(np.uint32)).sum() <= 20  # of a million: particles on the zero level of a blade
     a, b = cs.rigid_vector(ref.rigid_state(rid)), cs.rigid_vector(sim.get_rigid_state(rid))
     np.testing.assert_allclose(b[0:13], a[0:13], rtol=0, atol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------- 2D (MPM<2>)
+@pytest.fixture(scope="module")
+def gold2():
+    return np.load(os.path.join(HERE, "golden", "ref_cpic2d.npz"))
+
+
+CASE2_IDS = [c[0] for c in cs.CASES2]
+
+
+@pytest.mark.parametrize("case", cs.CASES2, ids=CASE2_IDS)
+def test_2d_colored_distance_field_and_colours_match_the_reference(tm, gold2, case):
+    """MPM<2>: bodies of segments (creation, boundary particles), rasterize_rigid_boundary + gather_cdf in their dim = 2 form"""
+    name, body, material, n, cfg = case
+    sim, rid = cs.build_device2(tm, body, material, **cfg)
+    st0 = sim.get_rigid_state(rid)
+    np.testing.assert_allclose(st0[:6], gold2[name + "_body0"][:6], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(st0[6:], gold2[name + "_body0"][6:], rtol=1e-5)
+    s = sim.get_rigid_samples(rid)
+    assert len(s) == len(gold2[name + "_samples"]) >= 10
+    np.testing.assert_allclose(s, gold2[name + "_samples"], rtol=0, atol=2e-7)
+    sim.cdf_phase()
+    st_h, d_h = sim.download_cdf()
+    st_r, d_r = np.zeros(st_h.size, np.uint32), np.zeros(st_h.size, np.float32)
+    st_r[gold2[name + "_cdf_idx"]], d_r[gold2[name + "_cdf_idx"]] = gold2[name + "_cdf_states"], gold2[name + "_cdf_dist"]
+    st_h, d_h = st_h.reshape(-1), d_h.reshape(-1)
+    differ = st_r != st_h
+    assert differ.sum() <= 2, differ.sum()
+    same = ~differ & (st_r != 0)
+    assert same.sum() > 50
+    np.testing.assert_allclose(d_h[same], d_r[same], rtol=0, atol=2e-7)
+    c = sim.download_colours()
+    o = np.argsort(sim.get_particles(sort_by_id=False)["id"], kind="stable")
+    bad = c["states"][o] != gold2[name + "_p_states"]
+    assert bad.sum() <= 2, bad.sum()
+    near_ref = gold2[name + "_p_near"].astype(np.int32)
+    flips = (c["near"][o] != near_ref) & ~bad
+    assert flips.sum() <= 2
+    near = ~bad & ~flips & (near_ref != 0)
+    assert near.sum() > 50
+    np.testing.assert_allclose(c["distance"][o][near], gold2[name + "_p_dist"][near], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(c["normal"][o][near], gold2[name + "_p_normal"][near], rtol=0, atol=5e-4)
+
+
+@pytest.mark.parametrize("case", cs.CASES2, ids=CASE2_IDS)
+def test_2d_substeps_with_a_rigid_body_match_the_reference(tm, gold2, case):
+    name, body, material, n, cfg = case
+    sim, rid = cs.build_device2(tm, body, material, **cfg)
+    sim.run_substeps(n)
+    h = sim.get_particles(sort_by_id=True)
+    assert len(h["x"]) == len(gold2[name + "_x"])
+    assert np.abs(h["x"] - gold2[name + "_x"]).max() <= 5e-6
+    assert rel_l2(h["v"], gold2[name + "_v"]) <= 2e-4
+    assert rel_l2(h["F"], gold2[name + "_F"]) <= 1e-4
+    o = np.argsort(sim.get_particles(sort_by_id=False)["id"], kind="stable")
+    assert (sim.download_colours()["states"][o] != gold2[name + "_states"]).sum() <= 3
+    a, b = gold2[name + "_body"], sim.get_rigid_state(rid)
+    np.testing.assert_allclose(b[0:3], a[0:3], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(b[3:5], a[3:5], rtol=0, atol=2e-4 * max(np.abs(a[3:5]).max(), 1e-2))
+    np.testing.assert_allclose(b[5], a[5], rtol=0, atol=2e-4 * max(abs(a[5]), 1e-1))
