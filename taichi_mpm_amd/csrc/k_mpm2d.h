@@ -253,6 +253,8 @@ __global__ __launch_bounds__(256) void k_p2g(Params P, int64_t n, const float *_
   Bnd2 bn;
   bn.n[0] = bn.n[1] = 0.0f; bn.dist = 0.0f; bn.near = 0u;
   if (R.enabled) { pstate = R.states[p]; bn = R.bnd[p]; }
+  int ibody = -1;  // the particle's impulses are summed here and handed over once (all impulses of a scene hit the same words)
+  float isum[2] = {0, 0}, itrq = 0.0f;
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -273,7 +275,12 @@ __global__ __launch_bounds__(256) void k_p2g(Params P, int64_t n, const float *_
           const float gr[2] = {t0[i] * P.idx * w1[j], w0[i] * t1[j] * P.idx};
           const float imp[2] = {mass * w * (vv[0] - pv[0]) + P.dt * (st.a * gr[0] + st.b * gr[1]),
                                 mass * w * (vv[1] - pv[1]) + P.dt * (st.c * gr[0] + st.d * gr[1])};
-          tmp_impulse2(Bd, imp, gpos);
+          if (ibody != rid) {
+            if (ibody >= 0) { atomicAdd(&R.rb[ibody].tmp_imp[0], isum[0]); atomicAdd(&R.rb[ibody].tmp_imp[1], isum[1]); atomicAdd(&R.rb[ibody].tmp_trq, itrq); }
+            ibody = rid; isum[0] = isum[1] = itrq = 0.0f;
+          }
+          isum[0] += imp[0]; isum[1] += imp[1];
+          itrq += (gpos[0] - Bd->pos[0]) * imp[1] - (gpos[1] - Bd->pos[1]) * imp[0];
           continue;
         }
       }
@@ -282,6 +289,7 @@ __global__ __launch_bounds__(256) void k_p2g(Params P, int64_t n, const float *_
       atomicAdd(gp + 1, w * (mass * vv[1] + A[2] * d0 + A[3] * d1));
       atomicAdd(gp + 2, w * mass);
     }
+  if (ibody >= 0) { atomicAdd(&R.rb[ibody].tmp_imp[0], isum[0]); atomicAdd(&R.rb[ibody].tmp_imp[1], isum[1]); atomicAdd(&R.rb[ibody].tmp_trq, itrq); }
 }
 
 __device__ __forceinline__ void friction_project2(float v[2], const float vb[2], const float n[2], float friction) {

@@ -23,6 +23,8 @@ constexpr int MAX_RIGID = 12;                    // GridState::max_num_rigid_bod
 constexpr uint32_t CDF_TAG_MASK = 0x00FFFFFFu;   // src/mpm_fwd.h:78-82
 constexpr uint32_t CDF_STATE_MASK = 0xAAAAAAAAu; // src/mpm.h:36 (the "has colour" bit of every body)
 constexpr unsigned long long CDF_EMPTY = ~0ull;
+constexpr uint32_t CDF_LOCKED = 0xFFFFFFFEu;  // cdf.slot value while a page is being handed out
+constexpr uint32_t CDF_POOLS = 64;            // sub-pools of the page pool, chosen by the block's Morton key
 
 struct RigidBodyDev {
   float pos[3], vel[3], omega[3];
@@ -48,8 +50,9 @@ struct CdfDev {
   uint32_t *page_key;        // [max_pages] page -> Morton key (for the clear pass)
   unsigned long long *mind;  // [max_pages * 64]
   uint32_t *tags;            // [max_pages * 64]
-  uint32_t *n_pages;         // pages handed out this substep
-  uint32_t max_pages;
+  uint32_t *n_pages;         // [CDF_POOLS] pages handed out this substep, per sub-pool (one counter would serialise every hand-out)
+  uint32_t max_pages;        // CDF_POOLS * pool_cap
+  uint32_t pool_cap;         // pages per sub-pool; sub-pool q owns the pages [q pool_cap, (q + 1) pool_cap)
   uint32_t *rpage;           // bitmap over the REFERENCE's 4x4x8-node blocks: its rigid_page_map (src/mpm.cpp:1026-1076)
   int rpd[3];
   int nb_axis;               // blocks per axis of the Morton space (1 << kbits): node coordinates beyond it have no page
@@ -71,13 +74,53 @@ __device__ __forceinline__ void rigid_velocity_at(const RigidBodyDev &b, const f
   cross3(b.omega, r, w);
   v[0] = b.vel[0] + w[0]; v[1] = b.vel[1] + w[1]; v[2] = b.vel[2] + w[2];
 }
-// RigidBody::apply_tmp_impulse: impulse and torque sums (the conversion to velocities happens once, in k_rigid_apply_tmp)
-__device__ __forceinline__ void rigid_tmp_impulse(RigidBodyDev *b, const float imp[3], const float at[3]) {
-  const float r[3] = {at[0] - b->pos[0], at[1] - b->pos[1], at[2] - b->pos[2]};
+// RigidBody::apply_tmp_impulse.  The reference adds every (particle, node) impulse to the body under a spinlock; here a
+// lane first sums its own impulses (and their torques about the body's centre) in registers, a wave then reduces the sums
+// of its lanes per body, and ONE lane issues the six float atomics: all impulses of a scene land on the same six words of
+// a body, and per-impulse atomics serialise there (measured: 39 ms instead of 0.17 ms per substep with 120 k coloured
+// particles around one body).  The conversion to velocities happens once, in k_rigid_apply_tmp.
+struct ImpulseAcc {
+  float imp[3], trq[3];
+  int body;  // -1: empty
+};
+__device__ __forceinline__ void acc_init(ImpulseAcc &A) { A.body = -1; A.imp[0] = A.imp[1] = A.imp[2] = A.trq[0] = A.trq[1] = A.trq[2] = 0.0f; }
+__device__ __forceinline__ void acc_flush_lane(ImpulseAcc &A, RigidBodyDev *rb) {  // (a lane met a second body: rare)
+  if (A.body >= 0) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { atomicAdd(&rb[A.body].tmp_imp[k], A.imp[k]); atomicAdd(&rb[A.body].tmp_trq[k], A.trq[k]); }
+  }
+  acc_init(A);
+}
+__device__ __forceinline__ void acc_add(ImpulseAcc &A, RigidBodyDev *rb, int body, const float imp[3], const float at[3]) {
+  if (A.body != body) { acc_flush_lane(A, rb); A.body = body; }
+  const RigidBodyDev &B = rb[body];
+  const float r[3] = {at[0] - B.pos[0], at[1] - B.pos[1], at[2] - B.pos[2]};
   float t[3];
   cross3(r, imp, t);
 #pragma unroll
-  for (int k = 0; k < 3; k++) { atomicAdd(&b->tmp_imp[k], imp[k]); atomicAdd(&b->tmp_trq[k], t[k]); }
+  for (int k = 0; k < 3; k++) { A.imp[k] += imp[k]; A.trq[k] += t[k]; }
+}
+// all 64 lanes of the wave must call this together
+__device__ __forceinline__ void acc_flush_wave(ImpulseAcc &A, RigidBodyDev *rb) {
+  unsigned long long pending = __ballot(A.body >= 0);
+  while (pending) {  // wave-uniform: one round per distinct body among the lanes
+    const int leader = __ffsll((long long)pending) - 1;
+    const int body = __shfl(A.body, leader);
+    const bool mine = A.body == body;
+    float v[6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { v[k] = mine ? A.imp[k] : 0.0f; v[3 + k] = mine ? A.trq[k] : 0.0f; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int k = 0; k < 6; k++) v[k] += __shfl_xor(v[k], off);
+    if ((int)(threadIdx.x & 63) == leader) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) { atomicAdd(&rb[body].tmp_imp[k], v[k]); atomicAdd(&rb[body].tmp_trq[k], v[3 + k]); }
+    }
+    if (mine) acc_init(A);
+    pending = __ballot(A.body >= 0);
+  }
 }
 
 // node (i, j, k) of the colored distance field: tags (24 bits), body id of the closest triangle (-1: none), distance (world)
@@ -113,21 +156,27 @@ __device__ __forceinline__ bool cdf_incompatible(uint32_t node_word, uint32_t ps
 // ---------------------------------------------------------------------------------------------- clear
 // pages handed out by the previous substep: unlink and reset them (then the host zeroes the counter and the page bitmap)
 __global__ __launch_bounds__(256) void k_cdf_clear(CdfDev C) {
-  const uint32_t np = min(*C.n_pages, C.max_pages);
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < np * 64u; t += gridDim.x * blockDim.x) {
-    C.mind[t] = CDF_EMPTY;
-    C.tags[t] = 0u;
-    if ((t & 63u) == 0u) C.slot[C.page_key[t >> 6]] = INVALID;
+  for (uint32_t q = blockIdx.y; q < CDF_POOLS; q += gridDim.y) {
+    const uint32_t np = min(C.n_pages[q], C.pool_cap), base = q * C.pool_cap * 64u;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < np * 64u; t += gridDim.x * blockDim.x) {
+      C.mind[base + t] = CDF_EMPTY;
+      C.tags[base + t] = 0u;
+      if ((t & 63u) == 0u) C.slot[C.page_key[(base + t) >> 6]] = INVALID;
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------- rasterize
-// rasterize_rigid_boundary (src/rigid_transfer.cpp:17-78), one thread per boundary particle; also marks the reference's
+// rasterize_rigid_boundary (src/rigid_transfer.cpp:17-78), one thread per (boundary particle, node); also marks the reference's
 // rigid pages (blocks of 4x4x8 nodes) from the block of the particle's base node (src/mpm.cpp:1026-1076)
 __global__ __launch_bounds__(256) void k_cdf_rasterize(Params P, CdfDev C, const RigidBodyDev *__restrict__ rb,
                                                        const RigidSample *__restrict__ smp, const float *__restrict__ elems,
                                                        uint32_t n) {
-  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+  // one thread per (boundary particle, stencil node): 27 threads share a particle and each redoes its small set-up — the
+  // page hand-out and the two atomics per node are a chain of round trips, so a thread per PARTICLE (a few thousand threads
+  // walking 27 nodes each) ran at 125 us where this runs at the latency of one chain
+  for (uint32_t tt = blockIdx.x * blockDim.x + threadIdx.x; tt < n * 27u; tt += gridDim.x * blockDim.x) {
+    const uint32_t s = tt / 27u, node27 = tt - s * 27u;
     const RigidSample S = smp[s];
     const RigidBodyDev &B = rb[S.body];
     float w[3];
@@ -142,7 +191,7 @@ __global__ __launch_bounds__(256) void k_cdf_rasterize(Params P, CdfDev C, const
       base[k] = (int)(X - 0.5f);
     }
     if (!ok) continue;  // (the reference refuses boundary particles near the domain wall at creation, :241-246)
-    {  // (the reference's loop runs over ind in {-1,0,1}^3 but keeps only 0 <= ind, src/mpm.cpp:1062-1064: the block itself
+    if (node27 == 0u) {  // (the reference's loop runs over ind in {-1,0,1}^3 but keeps only 0 <= ind, src/mpm.cpp:1062-1064: the block itself
        // and its neighbours in the POSITIVE directions)
       const int bx = base[0] >> 2, by = base[1] >> 2, bz = base[2] >> 3;
       for (int a = 0; a <= 1; a++)
@@ -151,7 +200,9 @@ __global__ __launch_bounds__(256) void k_cdf_rasterize(Params P, CdfDev C, const
             const int px = bx + a, py = by + b, pz = bz + c;
             if (px < 0 || py < 0 || pz < 0 || px >= C.rpd[0] || py >= C.rpd[1] || pz >= C.rpd[2]) continue;
             const uint32_t bit = ((uint32_t)px * C.rpd[1] + py) * C.rpd[2] + pz;
-            atomicOr(&C.rpage[bit >> 5], 1u << (bit & 31));
+            // (thousands of boundary particles share a page word: set the bit only if it is not there yet)
+            if (!((__hip_atomic_load(&C.rpage[bit >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 31)) & 1u))
+              atomicOr(&C.rpage[bit >> 5], 1u << (bit & 31));
           }
     }
     // world-space triangle and the map world -> (edge coordinates, signed distance): inverse of [e1, e2, n]
@@ -174,9 +225,10 @@ __global__ __launch_bounds__(256) void k_cdf_rasterize(Params P, CdfDev C, const
     cross3(e2, nn, c12); cross3(nn, e1, c20); cross3(e1, e2, c01);
     const float det = e1[0] * c12[0] + e1[1] * c12[1] + e1[2] * c12[2], id = 1.0f / det;
     const uint32_t body_bits = (uint32_t)S.body * 2u;
-    for (int a = 0; a < 3; a++)
-      for (int b = 0; b < 3; b++)
-        for (int c = 0; c < 3; c++) {
+    {
+      {
+        {
+          const int a = (int)(node27 / 9u), b = (int)((node27 / 3u) % 3u), c = (int)(node27 % 3u);
           const int gi = base[0] + a, gj = base[1] + b, gk = base[2] + c;
           const float d[3] = {gi * P.dx - v[0][0], gj * P.dx - v[0][1], gk * P.dx - v[0][2]};
           const float u0 = (c12[0] * d[0] + c12[1] * d[1] + c12[2] * d[2]) * id;
@@ -185,20 +237,37 @@ __global__ __launch_bounds__(256) void k_cdf_rasterize(Params P, CdfDev C, const
           if (!(0.0f <= u0 && 0.0f <= u1 && u0 + u1 <= 1.0f)) continue;
           const bool negative = u2 < 0.0f;
           const float dist = fabsf(u2) * P.idx;
-          // the node's page (handed out on first touch)
+          // the node's page, handed out on first touch: the first thread to turn the slot from INVALID to LOCKED takes a
+          // page from the pool and publishes it; the others wait for the number (the winner's branch completes before the
+          // wait loop starts, also for lanes of the same wave)
           const uint32_t bk = morton3(gi >> 2, gj >> 2, gk >> 2);
           uint32_t pg = __hip_atomic_load(&C.slot[bk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (pg == INVALID) {
-            const uint32_t mine = atomicAdd(C.n_pages, 1u);
-            if (mine >= C.max_pages) { atomicOr(C.error, 4u); continue; }  // sticky: reported by the next synchronising call
-            C.page_key[mine] = bk;  // (a page that loses the race below stays unused this substep; it is cleared like the others)
-            const uint32_t prev = atomicCAS(&C.slot[bk], INVALID, mine);
-            pg = prev == INVALID ? mine : prev;
+            const uint32_t prev = atomicCAS(&C.slot[bk], INVALID, CDF_LOCKED);
+            if (prev == INVALID) {
+              const uint32_t q = bk % CDF_POOLS, mine = atomicAdd(&C.n_pages[q], 1u);
+              if (mine >= C.pool_cap) {  // pool exhausted: sticky error (reported by the next synchronising call), nobody waits
+                atomicOr(C.error, 4u);
+                pg = INVALID;
+              } else {
+                pg = q * C.pool_cap + mine;
+                C.page_key[pg] = bk;
+              }
+              // relaxed is enough: waiters only need the NUMBER (the page's contents were reset by an earlier kernel, page_key is
+              // read by a later one); a release here would write back the whole L2 (buffer_wbl2) once per page
+              __hip_atomic_store(&C.slot[bk], pg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+              pg = prev;
+            }
           }
+          while (pg == CDF_LOCKED) pg = __hip_atomic_load(&C.slot[bk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (pg == INVALID) continue;
           const size_t node = (size_t)pg * 64 + (((gi & 3) << 4) | ((gj & 3) << 2) | (gk & 3));
           atomicMin(&C.mind[node], ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned long long)(S.body + 1));
           atomicOr(&C.tags[node], (2u + (negative ? 1u : 0u)) << body_bits);
         }
+      }
+    }
   }
 }
 
@@ -462,12 +531,12 @@ __global__ __launch_bounds__(256) void k_rigid_sample_positions(const RigidBodyD
 }
 // dense views of the colored distance field (parity / download only): states word and distance of every node
 __global__ __launch_bounds__(256) void k_cdf_dense(Params P, CdfDev C, uint32_t *__restrict__ states, float *__restrict__ dist) {
-  const uint32_t np = min(*C.n_pages, C.max_pages);
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < np * 64u; t += gridDim.x * blockDim.x) {
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < C.max_pages * 64u; t += gridDim.x * blockDim.x) {
     const uint32_t pg = t >> 6, l = t & 63u;
+    if (pg % C.pool_cap >= min(C.n_pages[pg / C.pool_cap], C.pool_cap)) continue;  // not handed out this substep
     int bx, by, bz;
     demorton3(C.page_key[pg], bx, by, bz);
-    if (C.slot[C.page_key[pg]] != pg) continue;  // a page that lost the allocation race
+    if (C.slot[C.page_key[pg]] != pg) continue;
     const int gi = bx * 4 + (int)(l >> 4), gj = by * 4 + (int)((l >> 2) & 3), gk = bz * 4 + (int)(l & 3);
     if (gi > P.res[0] || gj > P.res[1] || gk > P.res[2]) continue;
     const size_t idx = ((size_t)gi * (P.res[1] + 1) + gj) * (P.res[2] + 1) + gk;

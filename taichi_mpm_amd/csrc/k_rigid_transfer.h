@@ -56,6 +56,8 @@ __global__ __launch_bounds__(64) void k_p2g_rigid(Params P, const float4 *__rest
     float acc[27][4];
 #pragma unroll
     for (int n = 0; n < 27; n++) acc[n][0] = acc[n][1] = acc[n][2] = acc[n][3] = 0.0f;
+    ImpulseAcc ia;
+    acc_init(ia);
     for (uint32_t p = p0; p < p1; p++) {
       const size_t i = perm[p];
       const float4 q0 = rp[i * 4 + 0], q1 = rp[i * 4 + 1], q2 = rp[i * 4 + 2], q3 = rp[i * 4 + 3];
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(64) void k_p2g_rigid(Params P, const float4 *__rest
 #pragma unroll
           for (int c = 0; c < 3; c++)
             imp[c] = mass * w * (v[c] - pv[c]) + (dtF(c, 0) * gr[0] + dtF(c, 1) * gr[1] + dtF(c, 2) * gr[2]);
-          rigid_tmp_impulse(B, imp, gp);
+          acc_add(ia, X.rb, rid, imp, gp);
           continue;
         }
         const float d0 = r0 - (float)i3, d1 = r1 - (float)j, d2 = r2 - (float)k;
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(64) void k_p2g_rigid(Params P, const float4 *__rest
         acc[n][2] = fmaf(w, c2, acc[n][2]); acc[n][3] = fmaf(w, mass, acc[n][3]);
       }
     }
+    acc_flush_wave(ia, X.rb);  // the wave's impulses: six atomics per body
     // ordered, race-free merges into the wave's tile (see k_p2g.h)
 #pragma unroll
     for (int n = 0; n < 27; n++) {
@@ -168,6 +171,8 @@ __global__ __launch_bounds__(256) void k_g2p_rigid(Params P, const float4 *__res
     for (uint32_t pb = q0; pb < q1; pb += 256) {  // uniform trip count: every lane reaches flag_block
       const uint32_t p = pb + tid;
       uint32_t bkey = INVALID;
+      ImpulseAcc ia;
+      acc_init(ia);
       if (p < q1) {
         const size_t i = perm[p];
         const float4 g0 = rg[i * 4 + 0], g1 = rg[i * 4 + 1], g2 = rg[i * 4 + 2], g3 = rg[i * 4 + 3];
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(256) void k_g2p_rigid(Params P, const float4 *__res
           v[0] -= dv[0]; v[1] -= dv[1]; v[2] -= dv[2];
           if (rigid_id != -1) {
             const float imp[3] = {dv[0] * g.p[0], dv[1] * g.p[0], dv[2] * g.p[0]}, at[3] = {nx0, nx1, nx2};
-            rigid_tmp_impulse(X.rb + rigid_id, imp, at);
+            acc_add(ia, X.rb, rigid_id, imp, at);
           }
         }
         if (P.clamp_pos) {
@@ -300,6 +305,7 @@ __global__ __launch_bounds__(256) void k_g2p_rigid(Params P, const float4 *__res
           rb_out[o * 3 + 2] = make_float4(b.m[8], 0.0f, 0.0f, 0.0f);
         }
       }
+      acc_flush_wave(ia, X.rb);
       flag_block(blk_flag, bkey);
     }
   }

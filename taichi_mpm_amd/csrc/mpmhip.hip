@@ -170,7 +170,7 @@ struct mpmhip_ctx {
     CdfDev cdf{};
     BndRec *d_bnd = nullptr;
     uint8_t *d_blk_rigid = nullptr;
-    uint32_t *d_counters = nullptr;  // [0] pages handed out, [2] cutting_counter
+    uint32_t *d_counters = nullptr;  // [0, CDF_POOLS) pages handed out per sub-pool, [CDF_POOLS] cutting_counter
     uint32_t max_pages = 0;
     size_t rpage_words = 0;
     float penalty = 0.0f, pushing_force = 20000.0f;  // MPM::initialize defaults, src/mpm.cpp:35,40

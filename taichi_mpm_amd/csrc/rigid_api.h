@@ -88,7 +88,8 @@ static int rigid_enable(mpmhip_ctx *c) {
   if (c->async.enabled) return fail(c, MPMHIP_EINVAL, "rigid bodies are not supported with asynchronous stepping");
   hipError_t e = hipSuccess;
   auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-  R.max_pages = (uint32_t)std::min<int64_t>((int64_t)c->NB, std::max<int64_t>(4096, (int64_t)c->P.max_blocks * 2));
+  R.max_pages = (uint32_t)std::min<int64_t>((int64_t)c->NB, std::max<int64_t>(8192, (int64_t)c->P.max_blocks * 2));
+  R.max_pages = (R.max_pages + CDF_POOLS - 1) / CDF_POOLS * CDF_POOLS;
   const int rpd[3] = {c->P.res[0] / 4 + 2, c->P.res[1] / 4 + 2, c->P.res[2] / 8 + 2};
   R.rpage_words = ((size_t)rpd[0] * rpd[1] * rpd[2] + 31) / 32;
   A(dmalloc(&R.d_rb, (size_t)MAX_RIGID));
@@ -96,7 +97,7 @@ static int rigid_enable(mpmhip_ctx *c) {
   A(dmalloc(&R.cdf.page_key, (size_t)R.max_pages));
   A(dmalloc(&R.cdf.mind, (size_t)R.max_pages * 64));
   A(dmalloc(&R.cdf.tags, (size_t)R.max_pages * 64));
-  A(dmalloc(&R.d_counters, (size_t)4));
+  A(dmalloc(&R.d_counters, (size_t)CDF_POOLS + 4));  // [0, CDF_POOLS) pages handed out per sub-pool, [CDF_POOLS] cutting_counter
   A(dmalloc(&R.cdf.rpage, R.rpage_words));
   A(dmalloc(&R.d_bnd, (size_t)c->cap));
   A(dmalloc(&R.d_blk_rigid, (size_t)c->P.max_blocks + 1));
@@ -104,13 +105,14 @@ static int rigid_enable(mpmhip_ctx *c) {
   R.cdf.n_pages = R.d_counters; R.cdf.error = &c->cnt->error;
   R.cdf.nb_axis = 1 << c->P.kbits;
   R.cdf.max_pages = R.max_pages;
+  R.cdf.pool_cap = R.max_pages / CDF_POOLS;
   for (int k = 0; k < 3; k++) R.cdf.rpd[k] = rpd[k];
   HIPCHK(c, hipMemset(R.d_rb, 0, sizeof(RigidBodyDev) * MAX_RIGID));
   HIPCHK(c, hipMemset(R.cdf.slot, 0xFF, sizeof(uint32_t) * (size_t)c->NB));
   HIPCHK(c, hipMemset(R.cdf.mind, 0xFF, sizeof(unsigned long long) * (size_t)R.max_pages * 64));
   HIPCHK(c, hipMemset(R.cdf.tags, 0, sizeof(uint32_t) * (size_t)R.max_pages * 64));
   HIPCHK(c, hipMemset(R.cdf.page_key, 0, sizeof(uint32_t) * (size_t)R.max_pages));
-  HIPCHK(c, hipMemset(R.d_counters, 0, sizeof(uint32_t) * 4));
+  HIPCHK(c, hipMemset(R.d_counters, 0, sizeof(uint32_t) * (CDF_POOLS + 4)));
   HIPCHK(c, hipMemset(R.cdf.rpage, 0, sizeof(uint32_t) * R.rpage_words));
   HIPCHK(c, hipMemset(R.d_bnd, 0, sizeof(BndRec) * (size_t)c->cap));
   HIPCHK(c, hipMemset(R.d_blk_rigid, 0, (size_t)c->P.max_blocks + 1));
@@ -132,17 +134,17 @@ static inline bool rigid_active(const mpmhip_ctx *c) { return c->rigid.enabled &
 // rasterize_rigid_boundary: clear last substep's pages, then the boundary particles write colours and distances
 static int do_rigid_rasterize(mpmhip_ctx *c) {
   auto &R = c->rigid;
-  hipLaunchKernelGGL(k_cdf_clear, dim3(1024), dim3(256), 0, c->stream, R.cdf);
-  HIPCHK(c, hipMemsetAsync(R.cdf.n_pages, 0, sizeof(uint32_t), c->stream));
+  hipLaunchKernelGGL(k_cdf_clear, dim3(16, CDF_POOLS), dim3(256), 0, c->stream, R.cdf);
+  HIPCHK(c, hipMemsetAsync(R.cdf.n_pages, 0, sizeof(uint32_t) * CDF_POOLS, c->stream));
   HIPCHK(c, hipMemsetAsync(R.cdf.rpage, 0, sizeof(uint32_t) * R.rpage_words, c->stream));
   if (R.n_smp)
-    hipLaunchKernelGGL(k_cdf_rasterize, dim3(particle_grid(R.n_smp)), dim3(256), 0, c->stream, c->P, R.cdf, (const RigidBodyDev *)R.d_rb,
+    hipLaunchKernelGGL(k_cdf_rasterize, dim3(particle_grid((int64_t)R.n_smp * 27)), dim3(256), 0, c->stream, c->P, R.cdf, (const RigidBodyDev *)R.d_rb,
                        (const RigidSample *)R.d_smp, (const float *)R.d_elems, R.n_smp);
   return launch_check(c, "rasterize_rigid_boundary");
 }
 static int do_rigid_gather(mpmhip_ctx *c) {
   auto &R = c->rigid;
-  hipLaunchKernelGGL(k_gather_cdf, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, R.cdf, c->rg, R.d_bnd, R.d_counters + 2);
+  hipLaunchKernelGGL(k_gather_cdf, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, R.cdf, c->rg, R.d_bnd, R.d_counters + CDF_POOLS);
   return launch_check(c, "gather_cdf");
 }
 static int do_rigid_block_flags(mpmhip_ctx *c) {

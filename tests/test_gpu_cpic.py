@@ -298,3 +298,46 @@ def test_2d_substeps_with_a_rigid_body_match_the_reference(tm, gold2, case):
     np.testing.assert_allclose(b[0:3], a[0:3], rtol=0, atol=2e-6)
     np.testing.assert_allclose(b[3:5], a[3:5], rtol=0, atol=2e-4 * max(np.abs(a[3:5]).max(), 1e-2))
     np.testing.assert_allclose(b[5], a[5], rtol=0, atol=2e-4 * max(abs(a[5]), 1e-1))
+
+
+# ---------------------------------------------------------------------------------------------- errors and limits
+def test_rigid_api_refuses_what_it_cannot_do(tm):
+    from taichi_mpm_amd.mpm import MPMError
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(32,) * 3, delta_x=1 / 32, base_delta_t=1e-4, max_particles=4096))
+    with pytest.raises(MPMError, match="codimensional"):
+        sim.add_particles(dict(type="rigid", mesh=cs.plate(), initial_position=(0.5, 0.5, 0.5)))
+    with pytest.raises(MPMError, match="initial_position"):
+        sim.add_particles(dict(type="rigid", mesh=cs.plate(), codimensional=True))
+    with pytest.raises(MPMError, match="cannot coexist"):
+        sim.add_particles(dict(type="rigid", mesh=cs.plate(), codimensional=True, initial_position=(0.5, 0.5, 0.5), friction=0.1, friction0=0.2,
+                               friction1=0.2))
+    rid = int(sim.add_particles(dict(type="rigid", mesh=cs.plate(), codimensional=True, initial_position=(0.5, 0.5, 0.5))))
+    assert rid == 1
+    x, v = cs.block_of_particles()
+    sim.add_particles(dict(type="jelly", positions=x[:1000], velocities=v[:1000]))
+    sim.run_substeps(2)
+    with pytest.raises(MPMError, match="rigid"):  # snapshots do not carry rigid bodies
+        sim.general_action(dict(action="save", file_name="/tmp/never_written.bin"))
+    with pytest.raises(MPMError, match="grow"):  # the bodies' state lives in the ctx: it cannot be re-created to grow
+        sim.add_particles(dict(type="jelly", positions=np.tile(x, (2, 1))))
+    for k in range(10):  # 11 bodies fit the 24 colour bits (2 per body, body 0 = background)
+        sim.add_particles(dict(type="rigid", mesh=cs.plate(0.05), codimensional=True, initial_position=(0.3 + 0.03 * k, 0.3, 0.5)))
+    with pytest.raises(MPMError, match="rigid bodies"):
+        sim.add_particles(dict(type="rigid", mesh=cs.plate(0.05), codimensional=True, initial_position=(0.7, 0.7, 0.5)))
+    sim.run_substeps(2)  # eleven bodies at once still step
+    assert sim.get_num_particles() == 1000
+
+
+def test_a_body_that_touches_nothing_just_falls(tm):
+    """no material near the body: gravity only, the colored distance field stays confined to the body's pages"""
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(64,) * 3, delta_x=1 / 64, base_delta_t=1e-4, max_particles=4096))
+    rid = int(sim.add_particles(dict(type="rigid", mesh=cs.box(), codimensional=False, initial_position=(0.5, 0.7, 0.5),
+                                     initial_angular_velocity=(0.0, 3.0, 0.0))))
+    x = (np.stack(np.meshgrid(*[np.arange(20, 26) + 0.5] * 3, indexing="ij"), -1).reshape(-1, 3) / 64).astype(np.float32)
+    sim.add_particles(dict(type="jelly", positions=x))
+    sim.run_substeps(50)
+    st = sim.get_rigid_state(rid)
+    np.testing.assert_allclose(st["velocity"], (0.0, -10.0 * 50e-4, 0.0), atol=1e-6)
+    np.testing.assert_allclose(st["angular_velocity"], (0.0, 3.0, 0.0), atol=1e-6)
+    assert abs(st["position"][1] - (0.7 - 0.5 * 10 * (50e-4) ** 2 * (49 / 50))) < 2e-6  # explicit Euler, position first: sum_{k<n} k dt^2 g
+    assert (sim.get_particles()["states"] == 0).all()
