@@ -341,3 +341,47 @@ def test_a_body_that_touches_nothing_just_falls(tm):
     np.testing.assert_allclose(st["angular_velocity"], (0.0, 3.0, 0.0), atol=1e-6)
     assert abs(st["position"][1] - (0.7 - 0.5 * 10 * (50e-4) ** 2 * (49 / 50))) < 2e-6  # explicit Euler, position first: sum_{k<n} k dt^2 g
     assert (sim.get_particles()["states"] == 0).all()
+
+
+def test_two_bodies_at_once_match_the_live_reference(tm):
+    """two bodies = two pairs of colour bits: a free box (body 1) and a scripted plate (body 2) in the same block of sand"""
+    from oracle import refmpm
+    if not refmpm.available():
+        pytest.skip("oracle/_ref/libmpm_ref.so did not travel to this box")
+    from oracle import oracle as orc
+    refmpm.set_threads(1)
+    x, v = cs.block_of_particles()
+    gp = orc.group_params("sand", cs.MASS, cs.VOL)[0]
+    s = cs.SCRIPT
+    box_cfg = dict(cs.BODIES["box"])
+    box_mesh = box_cfg.pop("mesh")
+    box_cfg["initial_position"] = (0.42, 0.47, 0.46)
+    ref = refmpm.Sim(cs.RES, cs.DX, cs.DT, gravity=(0, -10, 0), penalty=1e3)
+    r1 = ref.add_rigid(box_mesh, **box_cfg)
+    r2 = ref.add_rigid(cs.plate(0.12), script=refmpm.rigid_script((0.58, 0.56, 0.55), s["vel"], s["amp"], s["omega"], s["e0"], s["rate"]),
+                       codimensional=True, friction=0.4)
+    ref.add_particles("sand", cs.MASS, cs.VOL, x, v)
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(cs.RES,) * 3, delta_x=cs.DX, base_delta_t=cs.DT, gravity=(0, -10, 0),
+                                                       max_particles=len(x) + 16, penalty=1e3))
+    f32 = np.float32
+    p0 = (0.58, 0.56, 0.55)
+    assert int(sim.add_particles(dict(type="rigid", mesh=box_mesh, **box_cfg))) == r1 == 1
+    assert int(sim.add_particles(dict(
+        type="rigid", mesh=cs.plate(0.12), codimensional=True, friction=0.4,
+        scripted_position=lambda t: [f32(p0[k]) + f32(s["vel"][k]) * f32(t) + f32(s["amp"][k]) * f32(np.sin(f32(s["omega"]) * f32(t))) for k in range(3)],
+        scripted_rotation=lambda t: [f32(s["e0"][k]) + f32(s["rate"][k]) * f32(t) for k in range(3)]))) == r2 == 2
+    sim.add_particles(dict(type="sand", positions=x, velocities=v, params=gp))
+    ref.substep(6)
+    sim.run_substeps(6)
+    r, h = ref.download(by_id=True), sim.get_particles(sort_by_id=True)
+    np.testing.assert_array_equal(h["id"], r["id"])
+    assert np.abs(h["x"] - r["x"]).max() <= 5e-6
+    assert rel_l2(h["v"], r["v"]) <= 2e-4
+    o = np.argsort(ref.download(by_id=False)["id"], kind="stable")
+    st = ref.particle_cdf()["states"][o]
+    assert ((st & 0xC) != 0).sum() > 300 and ((st & 0x30) != 0).sum() > 300  # both bodies colour particles
+    assert (st != h["states"].astype(np.uint32)).sum() <= 5
+    for rid in (r1, r2):
+        a, b = cs.rigid_vector(ref.rigid_state(rid)), cs.rigid_vector(sim.get_rigid_state(rid))
+        np.testing.assert_allclose(b[0:7], a[0:7], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(b[7:13], a[7:13], rtol=0, atol=2e-4 * max(np.abs(a[7:13]).max(), 1e-2))
