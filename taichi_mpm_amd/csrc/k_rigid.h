@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void k_cdf_rasterize(Params P, CdfDev C, const
           // page from the pool and publishes it; the others wait for the number (the winner's branch completes before the
           // wait loop starts, also for lanes of the same wave)
           const uint32_t bk = morton3(gi >> 2, gj >> 2, gk >> 2);
-          uint32_t pg = __hip_atomic_load(&C.slot[bk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          uint32_t pg = C.slot[bk];  // (a plain, cacheable load: a stale INVALID only costs the CAS below, which returns the truth)
           if (pg == INVALID) {
             const uint32_t prev = atomicCAS(&C.slot[bk], INVALID, CDF_LOCKED);
             if (prev == INVALID) {
