@@ -385,3 +385,33 @@ def test_two_bodies_at_once_match_the_live_reference(tm):
         a, b = cs.rigid_vector(ref.rigid_state(rid)), cs.rigid_vector(sim.get_rigid_state(rid))
         np.testing.assert_allclose(b[0:7], a[0:7], rtol=0, atol=2e-6)
         np.testing.assert_allclose(b[7:13], a[7:13], rtol=0, atol=2e-4 * max(np.abs(a[7:13]).max(), 1e-2))
+
+
+def test_rotation_axis_and_damping_match_the_live_reference(tm):
+    """rotation_axis (the angular velocity keeps only its component along a world axis: wheels and fans of the scene scripts),
+    linear_damping, angular_damping — a free wheel-like box inside the block of particles"""
+    from oracle import refmpm
+    if not refmpm.available():
+        pytest.skip("oracle/_ref/libmpm_ref.so did not travel to this box")
+    from oracle import oracle as orc
+    refmpm.set_threads(1)
+    x, v = cs.block_of_particles()
+    gp = orc.group_params("jelly", cs.MASS, cs.VOL)[0]
+    body = dict(codimensional=False, density=300.0, friction=0.5, initial_position=(0.51, 0.49, 0.5), initial_rotation=(5.0, 0.0, 12.0),
+                initial_velocity=(0.0, 0.2, 0.0), initial_angular_velocity=(1.0, 2.0, 6.0), rotation_axis=(0.0, 0.0, 1.0), linear_damping=3.0,
+                angular_damping=2.0)
+    ref = refmpm.Sim(cs.RES, cs.DX, cs.DT, gravity=(0, -10, 0))
+    rid = ref.add_rigid(cs.box(), **body)
+    ref.add_particles("jelly", cs.MASS, cs.VOL, x, v)
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(cs.RES,) * 3, delta_x=cs.DX, base_delta_t=cs.DT, gravity=(0, -10, 0),
+                                                       max_particles=len(x) + 16))
+    assert int(sim.add_particles(dict(type="rigid", mesh=cs.box(), **body))) == rid
+    sim.add_particles(dict(type="jelly", positions=x, velocities=v, params=gp))
+    ref.substep(10)
+    sim.run_substeps(10)
+    a, b = cs.rigid_vector(ref.rigid_state(rid)), cs.rigid_vector(sim.get_rigid_state(rid))
+    assert abs(a[10]) < 1e-6 and abs(a[11]) < 1e-6 and abs(a[12]) > 1.0  # the reference's body turns about z only
+    np.testing.assert_allclose(b[0:7], a[0:7], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(b[7:13], a[7:13], rtol=0, atol=2e-4 * np.abs(a[7:13]).max())
+    r, h = ref.download(by_id=True), sim.get_particles(sort_by_id=True)
+    assert np.abs(h["x"] - r["x"]).max() <= 5e-6 and rel_l2(h["v"], r["v"]) <= 2e-4
