@@ -23,7 +23,7 @@ constexpr int MAX_RIGID = 12;                    // GridState::max_num_rigid_bod
 constexpr uint32_t CDF_TAG_MASK = 0x00FFFFFFu;   // src/mpm_fwd.h:78-82
 constexpr uint32_t CDF_STATE_MASK = 0xAAAAAAAAu; // src/mpm.h:36 (the "has colour" bit of every body)
 constexpr unsigned long long CDF_EMPTY = ~0ull;
-constexpr uint32_t CDF_LOCKED = 0xFFFFFFFEu;  // cdf.slot value while a page is being handed out
+constexpr uint32_t CDF_LOCKED = 0xFFFFFFFEu;  // cdf.slot value while a page is being handed out (inside pass 0 of the rasterisation only)
 constexpr uint32_t CDF_POOLS = 64;            // sub-pools of the page pool, chosen by the block's Morton key
 
 struct RigidBodyDev {
@@ -166,45 +166,84 @@ __global__ __launch_bounds__(256) void k_cdf_clear(CdfDev C) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- page hand-out
+// One thread per boundary particle, before the rasterisation: the <= 8 blocks its 3^3 stencil touches get a page (whoever
+// turns a block's slot from INVALID to LOCKED takes one and publishes its number; nobody waits), and the reference's rigid
+// pages are marked: the block (4x4x8 nodes) of the particle's base node and its neighbours in the POSITIVE directions (the
+// reference's loop runs over ind in {-1,0,1}^3 but keeps only 0 <= ind, src/mpm.cpp:1062-1064).
+// Per PARTICLE, not per node, and with an uncached look first: hundreds of threads share a block, and a CAS from each of
+// them on the one slot word serialises (measured: 258 us for 42 k boundary particles when every (particle, node) thread tried).
+__device__ __forceinline__ bool sample_base(const Params &P, const RigidBodyDev *rb, const RigidSample &S, int base[3]) {
+  const RigidBodyDev &B = rb[S.body];
+  float w[3];
+  rot_apply(B.R, S.off, w);
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float X = (w[k] + B.pos[k]) * P.idx;  // get_anchor_point
+    ok = ok && X >= 0.5f && X < (float)P.res[k] - 1.5f;
+    base[k] = (int)(X - 0.5f);
+  }
+  return ok;  // (the reference refuses boundary particles near the domain wall at creation, src/mpm_rigid_body.cpp:241-246)
+}
+__global__ __launch_bounds__(256) void k_cdf_alloc(Params P, CdfDev C, const RigidBodyDev *__restrict__ rb,
+                                                   const RigidSample *__restrict__ smp, uint32_t n) {
+  // Uniform trip count (every lane takes part in the shuffles).  Neighbouring boundary particles sit on the same triangle
+  // row and mostly share pages and blocks: a lane only goes to memory for a page / block its left neighbour lane does not
+  // name too — the rigid-page bitmap of a whole body is a few cache lines, and even LOADS of one line from every thread
+  // of the launch queue up at its L2 bank (measured: 139 us for 42 k particles without this).
+  const uint32_t stride = gridDim.x * blockDim.x, nloop = (n + stride - 1) / stride;
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t it = 0; it < nloop; it++) {
+    const uint32_t s = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    int base[3] = {0, 0, 0};
+    const bool ok = s < n && sample_base(P, rb, smp[s], base);
+    {
+      const int bx = base[0] >> 2, by = base[1] >> 2, bz = base[2] >> 3;
+#pragma unroll
+      for (int o = 0; o < 8; o++) {
+        const int px = bx + (o >> 2), py = by + ((o >> 1) & 1), pz = bz + (o & 1);
+        uint32_t bit = INVALID;
+        if (ok && px >= 0 && py >= 0 && pz >= 0 && px < C.rpd[0] && py < C.rpd[1] && pz < C.rpd[2]) bit = ((uint32_t)px * C.rpd[1] + py) * C.rpd[2] + pz;
+        const uint32_t left = __shfl_up(bit, 1);
+        if (bit != INVALID && (lane == 0u || bit != left) &&
+            !((__hip_atomic_load(&C.rpage[bit >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 31)) & 1u))
+          atomicOr(&C.rpage[bit >> 5], 1u << (bit & 31));
+      }
+    }
+    const int x0 = base[0] >> 2, y0 = base[1] >> 2, z0 = base[2] >> 2;
+    const int nx = ((base[0] + 2) >> 2) - x0, ny = ((base[1] + 2) >> 2) - y0, nz = ((base[2] + 2) >> 2) - z0;  // 0 or 1 more block per axis
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+      const int ax = o >> 2, ay = (o >> 1) & 1, az = o & 1;
+      uint32_t bk = INVALID;
+      if (ok && ax <= nx && ay <= ny && az <= nz) bk = morton3(x0 + ax, y0 + ay, z0 + az);
+      const uint32_t left = __shfl_up(bk, 1);
+      if (bk == INVALID || (lane != 0u && bk == left)) continue;
+      if (__hip_atomic_load(&C.slot[bk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != INVALID) continue;
+      if (atomicCAS(&C.slot[bk], INVALID, CDF_LOCKED) != INVALID) continue;
+      const uint32_t q = bk % CDF_POOLS, mine = atomicAdd(&C.n_pages[q], 1u);
+      uint32_t pg = INVALID;
+      if (mine >= C.pool_cap) atomicOr(C.error, 4u);  // pool exhausted: sticky error, reported by the next synchronising call
+      else { pg = q * C.pool_cap + mine; C.page_key[pg] = bk; }
+      __hip_atomic_store(&C.slot[bk], pg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- rasterize
 // rasterize_rigid_boundary (src/rigid_transfer.cpp:17-78), one thread per (boundary particle, node); also marks the reference's
 // rigid pages (blocks of 4x4x8 nodes) from the block of the particle's base node (src/mpm.cpp:1026-1076)
+// One thread per (boundary particle, stencil node); every page exists (k_cdf_alloc ran before).
 __global__ __launch_bounds__(256) void k_cdf_rasterize(Params P, CdfDev C, const RigidBodyDev *__restrict__ rb,
                                                        const RigidSample *__restrict__ smp, const float *__restrict__ elems,
                                                        uint32_t n) {
-  // one thread per (boundary particle, stencil node): 27 threads share a particle and each redoes its small set-up — the
-  // page hand-out and the two atomics per node are a chain of round trips, so a thread per PARTICLE (a few thousand threads
-  // walking 27 nodes each) ran at 125 us where this runs at the latency of one chain
   for (uint32_t tt = blockIdx.x * blockDim.x + threadIdx.x; tt < n * 27u; tt += gridDim.x * blockDim.x) {
     const uint32_t s = tt / 27u, node27 = tt - s * 27u;
     const RigidSample S = smp[s];
     const RigidBodyDev &B = rb[S.body];
-    float w[3];
-    rot_apply(B.R, S.off, w);
-    const float x[3] = {w[0] + B.pos[0], w[1] + B.pos[1], w[2] + B.pos[2]};  // get_anchor_point
     int base[3];
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const float X = x[k] * P.idx;
-      ok = ok && X >= 0.5f && X < (float)P.res[k] - 1.5f;
-      base[k] = (int)(X - 0.5f);
-    }
-    if (!ok) continue;  // (the reference refuses boundary particles near the domain wall at creation, :241-246)
-    if (node27 == 0u) {  // (the reference's loop runs over ind in {-1,0,1}^3 but keeps only 0 <= ind, src/mpm.cpp:1062-1064: the block itself
-       // and its neighbours in the POSITIVE directions)
-      const int bx = base[0] >> 2, by = base[1] >> 2, bz = base[2] >> 3;
-      for (int a = 0; a <= 1; a++)
-        for (int b = 0; b <= 1; b++)
-          for (int c = 0; c <= 1; c++) {
-            const int px = bx + a, py = by + b, pz = bz + c;
-            if (px < 0 || py < 0 || pz < 0 || px >= C.rpd[0] || py >= C.rpd[1] || pz >= C.rpd[2]) continue;
-            const uint32_t bit = ((uint32_t)px * C.rpd[1] + py) * C.rpd[2] + pz;
-            // (thousands of boundary particles share a page word: set the bit only if it is not there yet)
-            if (!((__hip_atomic_load(&C.rpage[bit >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 31)) & 1u))
-              atomicOr(&C.rpage[bit >> 5], 1u << (bit & 31));
-          }
-    }
+    if (!sample_base(P, rb, S, base)) continue;
     // world-space triangle and the map world -> (edge coordinates, signed distance): inverse of [e1, e2, n]
     float v[3][3];
 #pragma unroll
@@ -237,31 +276,9 @@ __global__ __launch_bounds__(256) void k_cdf_rasterize(Params P, CdfDev C, const
           if (!(0.0f <= u0 && 0.0f <= u1 && u0 + u1 <= 1.0f)) continue;
           const bool negative = u2 < 0.0f;
           const float dist = fabsf(u2) * P.idx;
-          // the node's page, handed out on first touch: the first thread to turn the slot from INVALID to LOCKED takes a
-          // page from the pool and publishes it; the others wait for the number (the winner's branch completes before the
-          // wait loop starts, also for lanes of the same wave)
           const uint32_t bk = morton3(gi >> 2, gj >> 2, gk >> 2);
-          uint32_t pg = C.slot[bk];  // (a plain, cacheable load: a stale INVALID only costs the CAS below, which returns the truth)
-          if (pg == INVALID) {
-            const uint32_t prev = atomicCAS(&C.slot[bk], INVALID, CDF_LOCKED);
-            if (prev == INVALID) {
-              const uint32_t q = bk % CDF_POOLS, mine = atomicAdd(&C.n_pages[q], 1u);
-              if (mine >= C.pool_cap) {  // pool exhausted: sticky error (reported by the next synchronising call), nobody waits
-                atomicOr(C.error, 4u);
-                pg = INVALID;
-              } else {
-                pg = q * C.pool_cap + mine;
-                C.page_key[pg] = bk;
-              }
-              // relaxed is enough: waiters only need the NUMBER (the page's contents were reset by an earlier kernel, page_key is
-              // read by a later one); a release here would write back the whole L2 (buffer_wbl2) once per page
-              __hip_atomic_store(&C.slot[bk], pg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-              pg = prev;
-            }
-          }
-          while (pg == CDF_LOCKED) pg = __hip_atomic_load(&C.slot[bk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (pg == INVALID) continue;
+          const uint32_t pg = C.slot[bk];
+          if (pg == INVALID) continue;  // (pool exhausted)
           const size_t node = (size_t)pg * 64 + (((gi & 3) << 4) | ((gj & 3) << 2) | (gk & 3));
           atomicMin(&C.mind[node], ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned long long)(S.body + 1));
           atomicOr(&C.tags[node], (2u + (negative ? 1u : 0u)) << body_bits);
@@ -301,35 +318,27 @@ __global__ __launch_bounds__(256) void k_blk_rigid(Params P, const Counters *__r
 // ---------------------------------------------------------------------------------------------- gather_cdf
 // 4x4 least-squares system in double precision (the host-side reference build solves it in double as well: the taichi
 // core's own routine is not available, see oracle/taichi_shim); returns |det|, solves A r = y when it exceeds the guard
-__device__ __noinline__ double solve4(const float A[4][4], const float y[4], float r[4], double guard) {
-  double a[4][5];
-  for (int i = 0; i < 4; i++) {
-    for (int j = 0; j < 4; j++) a[i][j] = A[i][j];
-    a[i][4] = y[i];
-  }
-  double det = 1.0;
-  for (int k = 0; k < 4; k++) {
-    int p = k;
-    for (int i = k + 1; i < 4; i++) if (fabs(a[i][k]) > fabs(a[p][k])) p = i;
-    if (a[p][k] == 0.0) return 0.0;
-    if (p != k) {
-      for (int j = 0; j < 5; j++) { const double t = a[k][j]; a[k][j] = a[p][j]; a[p][j] = t; }
-      det = -det;
-    }
-    det *= a[k][k];
-    for (int i = k + 1; i < 4; i++) {
-      const double f = a[i][k] / a[k][k];
-      for (int j = k; j < 5; j++) a[i][j] -= f * a[k][j];
-    }
-  }
+__device__ __forceinline__ double solve4(const float A[4][4], const float y[4], float r[4], double guard) {
+  // A = X^T W X is symmetric positive semi-definite: L D L^T without pivoting, fully unrolled (registers, no scratch);
+  // det A = d0 d1 d2 d3.  Double precision, like the reference build's solve.
+  const double a00 = A[0][0], a10 = A[1][0], a11 = A[1][1], a20 = A[2][0], a21 = A[2][1], a22 = A[2][2], a30 = A[3][0], a31 = A[3][1],
+               a32 = A[3][2], a33 = A[3][3];
+  const double d0 = a00;
+  if (!(d0 > 0.0)) return 0.0;
+  const double l10 = a10 / d0, l20 = a20 / d0, l30 = a30 / d0;
+  const double d1 = a11 - l10 * a10;
+  if (!(d1 > 0.0)) return 0.0;
+  const double l21 = (a21 - l20 * a10) / d1, l31 = (a31 - l30 * a10) / d1;
+  const double d2 = a22 - l20 * a20 - l21 * l21 * d1;
+  if (!(d2 > 0.0)) return 0.0;
+  const double l32 = (a32 - l30 * a20 - l31 * l21 * d1) / d2;
+  const double d3 = a33 - l30 * a30 - l31 * l31 * d1 - l32 * l32 * d2;
+  const double det = d0 * d1 * d2 * d3;
   if (!(fabs(det) > guard)) return fabs(det);
-  double x[4];
-  for (int i = 3; i >= 0; i--) {
-    double s = a[i][4];
-    for (int j = i + 1; j < 4; j++) s -= a[i][j] * x[j];
-    x[i] = s / a[i][i];
-  }
-  for (int i = 0; i < 4; i++) r[i] = (float)x[i];
+  // L z = y, D w = z, L^T x = w
+  const double z0 = y[0], z1 = y[1] - l10 * z0, z2 = y[2] - l20 * z0 - l21 * z1, z3 = y[3] - l30 * z0 - l31 * z1 - l32 * z2;
+  const double x3 = z3 / d3, x2 = z2 / d2 - l32 * x3, x1 = z1 / d1 - l21 * x2 - l31 * x3, x0 = z0 / d0 - l10 * x1 - l20 * x2 - l30 * x3;
+  r[0] = (float)x0; r[1] = (float)x1; r[2] = (float)x2; r[3] = (float)x3;
   return fabs(det);
 }
 

@@ -33,7 +33,7 @@ __device__ __forceinline__ void load_state_tile(const CdfDev &C, int bx, int by,
 // block_op_rigid of rasterize_optimized (src/transfer.cpp:367-463): a node of the other colour receives nothing; the
 // particle's momentum change against the body's surface velocity (friction_project with the particle's boundary
 // normal) and its stress term go to the body as an impulse at the node instead (:425-444).
-__global__ __launch_bounds__(64) void k_p2g_rigid(Params P, const float4 *__restrict__ rp, const float4 *__restrict__ rg,
+__global__ __launch_bounds__(64, 2) void k_p2g_rigid(Params P, const float4 *__restrict__ rp, const float4 *__restrict__ rg,
                                                   const Counters *__restrict__ cnt, const uint32_t *__restrict__ act_blk,
                                                   const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ perm,
                                                   const GroupParams *__restrict__ groups, float4 *__restrict__ tiles,
@@ -58,12 +58,27 @@ __global__ __launch_bounds__(64) void k_p2g_rigid(Params P, const float4 *__rest
     for (int n = 0; n < 27; n++) acc[n][0] = acc[n][1] = acc[n][2] = acc[n][3] = 0.0f;
     ImpulseAcc ia;
     acc_init(ia);
+    // the records of the next particle are in flight while one is computed
+    // (F and aux are only needed for a node of the other colour: fetched then, not prefetched)
+    float4 nq0, nq1, nq2, nq3, nh3, nb0;
+    size_t icur = 0, inext = 0;
+    if (p0 < p1) {
+      inext = perm[p0];
+      nq0 = rp[inext * 4 + 0]; nq1 = rp[inext * 4 + 1]; nq2 = rp[inext * 4 + 2]; nq3 = rp[inext * 4 + 3];
+      nh3 = rg[inext * 4 + 3];
+      nb0 = reinterpret_cast<const float4 *>(X.bnd)[inext * 2];
+    }
     for (uint32_t p = p0; p < p1; p++) {
-      const size_t i = perm[p];
-      const float4 q0 = rp[i * 4 + 0], q1 = rp[i * 4 + 1], q2 = rp[i * 4 + 2], q3 = rp[i * 4 + 3];
-      const float4 h0 = rg[i * 4 + 0], h1 = rg[i * 4 + 1], h2 = rg[i * 4 + 2], h3 = rg[i * 4 + 3];
+      const float4 q0 = nq0, q1 = nq1, q2 = nq2, q3 = nq3, h3 = nh3;
+      const float bnn[3] = {nb0.x, nb0.y, nb0.z};
+      icur = inext;
+      if (p + 1 < p1) {
+        inext = perm[p + 1];
+        nq0 = rp[inext * 4 + 0]; nq1 = rp[inext * 4 + 1]; nq2 = rp[inext * 4 + 2]; nq3 = rp[inext * 4 + 3];
+        nh3 = rg[inext * 4 + 3];
+        nb0 = reinterpret_cast<const float4 *>(X.bnd)[inext * 2];
+      }
       const uint32_t pstate = __float_as_uint(h3.w);
-      const BndRec bn = X.bnd[i];
       const float mass = q3.w;
       float v[3] = {q0.w, q1.x, q1.y};
       if (P.particle_gravity) { v[0] = fmaf(P.g[0], P.dt, v[0]); v[1] = fmaf(P.g[1], P.dt, v[1]); v[2] = fmaf(P.g[2], P.dt, v[2]); }
@@ -76,44 +91,58 @@ __global__ __launch_bounds__(64) void k_p2g_rigid(Params P, const float4 *__rest
                   dw2[3] = {t2[0] - 1.5f, -2.0f * t2[1], t2[2] + 1.5f};
       const float A00 = q1.z, A01 = q1.w, A02 = q2.x, A10 = q2.y, A11 = q2.z, A12 = q2.w, A20 = q3.x, A21 = q3.y, A22 = q3.z;
       const float mv0 = mass * v[0], mv1 = mass * v[1], mv2 = mass * v[2];
-      bool have_force = false;
-      mat3 dtF;  // delta_t * calculate_force(), only needed when a node of the other colour turns up
+      // pass 1: which of the 27 nodes belong to the other side of a body for this particle
+      uint32_t other = 0u;
 #pragma unroll
       for (int n = 0; n < 27; n++) {
         const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
-        const uint32_t word = stile[nbase + (i3 * TS + j) * TS + k];
-        const float w = (w0[i3] * w1[j]) * w2[k];
-        if (cdf_incompatible(word, pstate)) {
-          const int rid = (int)(word >> 24) - 1;
-          if (rid < 0) continue;
-          RigidBodyDev *B = X.rb + rid;
-          const float gp[3] = {(gx + i3) * P.dx, (gy + j) * P.dx, (gz + k) * P.dx};
-          float rv[3];
-          rigid_velocity_at(*B, gp, rv);
-          float pv[3] = {v[0], v[1], v[2]};
-          friction_project(pv, rv, bn.n, B->fric[(pstate >> (2 * rid)) & 1u]);
-          if (!have_force) {
-            mat3 F;
-            F.m[0] = h1.x; F.m[1] = h1.y; F.m[2] = h1.z; F.m[3] = h1.w; F.m[4] = h2.x; F.m[5] = h2.y; F.m[6] = h2.z; F.m[7] = h2.w; F.m[8] = h3.x;
-            dtF = calculate_force(groups[__float_as_uint(h3.y)], F, h0.w);
+        if (cdf_incompatible(stile[nbase + (i3 * TS + j) * TS + k], pstate)) other |= 1u << n;
+      }
+      // pass 2: the ordinary scatter into the lane's registers, skipping those nodes
 #pragma unroll
-            for (int e = 0; e < 9; e++) dtF.m[e] *= P.dt;
-            have_force = true;
-          }
-          const float gr[3] = {dw0[i3] * P.idx * w1[j] * w2[k], w0[i3] * dw1[j] * P.idx * w2[k], w0[i3] * w1[j] * dw2[k] * P.idx};
-          float imp[3];
-#pragma unroll
-          for (int c = 0; c < 3; c++)
-            imp[c] = mass * w * (v[c] - pv[c]) + (dtF(c, 0) * gr[0] + dtF(c, 1) * gr[1] + dtF(c, 2) * gr[2]);
-          acc_add(ia, X.rb, rid, imp, gp);
-          continue;
-        }
+      for (int n = 0; n < 27; n++) {
+        const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
+        const float w = ((other >> n) & 1u) ? 0.0f : (w0[i3] * w1[j]) * w2[k];
         const float d0 = r0 - (float)i3, d1 = r1 - (float)j, d2 = r2 - (float)k;
         const float c0 = fmaf(A02, d2, fmaf(A01, d1, fmaf(A00, d0, mv0)));
         const float c1 = fmaf(A12, d2, fmaf(A11, d1, fmaf(A10, d0, mv1)));
         const float c2 = fmaf(A22, d2, fmaf(A21, d1, fmaf(A20, d0, mv2)));
         acc[n][0] = fmaf(w, c0, acc[n][0]); acc[n][1] = fmaf(w, c1, acc[n][1]);
         acc[n][2] = fmaf(w, c2, acc[n][2]); acc[n][3] = fmaf(w, mass, acc[n][3]);
+      }
+      // pass 3 (particles at a boundary only): momentum change and stress term of the skipped nodes go to the bodies
+      if (other) {
+        const float4 h0 = rg[icur * 4 + 0], h1 = rg[icur * 4 + 1], h2 = rg[icur * 4 + 2];
+        mat3 F;
+        F.m[0] = h1.x; F.m[1] = h1.y; F.m[2] = h1.z; F.m[3] = h1.w; F.m[4] = h2.x; F.m[5] = h2.y; F.m[6] = h2.z; F.m[7] = h2.w; F.m[8] = h3.x;
+        mat3 dtF = calculate_force(groups[__float_as_uint(h3.y)], F, h0.w);  // delta_t * calculate_force()
+#pragma unroll
+        for (int e = 0; e < 9; e++) dtF.m[e] *= P.dt;
+        while (other) {
+          const int n = __ffs(other) - 1;
+          other &= other - 1u;
+          const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
+          const int rid = (int)(stile[nbase + (i3 * TS + j) * TS + k] >> 24) - 1;
+          if (rid < 0) continue;
+          RigidBodyDev *B = X.rb + rid;
+          // weights and their derivatives of node (i3, j, k) without indexing the per-axis arrays dynamically
+          const float wa = i3 == 0 ? w0[0] : (i3 == 1 ? w0[1] : w0[2]), wb = j == 0 ? w1[0] : (j == 1 ? w1[1] : w1[2]),
+                      wc = k == 0 ? w2[0] : (k == 1 ? w2[1] : w2[2]);
+          const float da = i3 == 0 ? dw0[0] : (i3 == 1 ? dw0[1] : dw0[2]), db = j == 0 ? dw1[0] : (j == 1 ? dw1[1] : dw1[2]),
+                      dc = k == 0 ? dw2[0] : (k == 1 ? dw2[1] : dw2[2]);
+          const float w = (wa * wb) * wc;
+          const float gp[3] = {(gx + i3) * P.dx, (gy + j) * P.dx, (gz + k) * P.dx};
+          float rv[3];
+          rigid_velocity_at(*B, gp, rv);
+          float pv[3] = {v[0], v[1], v[2]};
+          friction_project(pv, rv, bnn, B->fric[(pstate >> (2 * rid)) & 1u]);
+          const float gr[3] = {da * P.idx * wb * wc, wa * db * P.idx * wc, wa * wb * dc * P.idx};
+          float imp[3];
+#pragma unroll
+          for (int c = 0; c < 3; c++)
+            imp[c] = mass * w * (v[c] - pv[c]) + (dtF(c, 0) * gr[0] + dtF(c, 1) * gr[1] + dtF(c, 2) * gr[2]);
+          acc_add(ia, X.rb, rid, imp, gp);
+        }
       }
     }
     acc_flush_wave(ia, X.rb);  // the wave's impulses: six atomics per body

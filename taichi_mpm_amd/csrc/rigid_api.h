@@ -137,9 +137,12 @@ static int do_rigid_rasterize(mpmhip_ctx *c) {
   hipLaunchKernelGGL(k_cdf_clear, dim3(16, CDF_POOLS), dim3(256), 0, c->stream, R.cdf);
   HIPCHK(c, hipMemsetAsync(R.cdf.n_pages, 0, sizeof(uint32_t) * CDF_POOLS, c->stream));
   HIPCHK(c, hipMemsetAsync(R.cdf.rpage, 0, sizeof(uint32_t) * R.rpage_words, c->stream));
-  if (R.n_smp)
-    hipLaunchKernelGGL(k_cdf_rasterize, dim3(particle_grid((int64_t)R.n_smp * 27)), dim3(256), 0, c->stream, c->P, R.cdf, (const RigidBodyDev *)R.d_rb,
-                       (const RigidSample *)R.d_smp, (const float *)R.d_elems, R.n_smp);
+  if (R.n_smp) {
+    hipLaunchKernelGGL(k_cdf_alloc, dim3(particle_grid(R.n_smp)), dim3(256), 0, c->stream, c->P, R.cdf, (const RigidBodyDev *)R.d_rb,
+                       (const RigidSample *)R.d_smp, R.n_smp);
+    hipLaunchKernelGGL(k_cdf_rasterize, dim3(particle_grid((int64_t)R.n_smp * 27)), dim3(256), 0, c->stream, c->P, R.cdf,
+                       (const RigidBodyDev *)R.d_rb, (const RigidSample *)R.d_smp, (const float *)R.d_elems, R.n_smp);
+  }
   return launch_check(c, "rasterize_rigid_boundary");
 }
 static int do_rigid_gather(mpmhip_ctx *c) {
