@@ -58,7 +58,8 @@ struct CdfDev {
   int nb_axis;               // blocks per axis of the Morton space (1 << kbits): node coordinates beyond it have no page
   uint32_t *error;           // the ctx's sticky error word (Counters::error); bit 2 (value 4): page pool exhausted
 };
-struct BndRec { float n[3]; float dist; uint32_t near; float pad[3]; };  // gather_cdf's per-particle output (32 bytes)
+struct BndRec { float n[3]; float dist; uint32_t near; uint32_t epoch; float pad[2]; };  // gather_cdf's per-particle output (32 bytes);
+                                                                                        // epoch: the gather that wrote it
 
 __device__ __forceinline__ void rot_apply(const float R[9], const float v[3], float o[3]) {
 #pragma unroll
@@ -344,13 +345,13 @@ __device__ __forceinline__ double solve4(const float A[4][4], const float y[4], 
 
 // gather_cdf (src/rigid_transfer.cpp:121-275), one thread per particle slot: the particle gains colours from the grid
 // (never changes one it has), then fits (normal, distance) of the boundary to the nodes of its own colour
-__global__ __launch_bounds__(256) void k_gather_cdf(Params P, CdfDev C, RecG *__restrict__ rg, BndRec *__restrict__ bnd,
-                                                    uint32_t *__restrict__ cutting_counter) {
-  const uint32_t n = P.n_slots;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+__device__ __forceinline__ void gather_cdf_one(const Params &P, const CdfDev &C, RecG *__restrict__ rg, BndRec *__restrict__ bnd,
+                                               uint32_t *__restrict__ cutting_counter, size_t i, uint32_t epoch, int ox, int oy, int oz,
+                                               const uint32_t *s_tag, const int *s_rid, const float *s_d) {
+  {
     BndRec out;
-    out.n[0] = out.n[1] = out.n[2] = 0.0f; out.dist = 0.0f; out.near = 0u; out.pad[0] = out.pad[1] = out.pad[2] = 0.0f;
-    if (rg[i].pid < 0) { bnd[i] = out; continue; }
+    out.n[0] = out.n[1] = out.n[2] = 0.0f; out.dist = 0.0f; out.near = 0u; out.epoch = epoch; out.pad[0] = out.pad[1] = 0.0f;
+    if (rg[i].pid < 0) { bnd[i] = out; return; }
     const float pos[3] = {rg[i].x[0] * P.idx, rg[i].x[1] * P.idx, rg[i].x[2] * P.idx};
     {  // rigid_page_map->Test_Page(Linear_Offset(pos.cast<int>()))  (:142-146): elsewhere the colours stay as they are
       const int px = (int)pos[0] >> 2, py = (int)pos[1] >> 2, pz = (int)pos[2] >> 3;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(256) void k_gather_cdf(Params P, CdfDev C, RecG *__
         const uint32_t bit = ((uint32_t)px * C.rpd[1] + py) * C.rpd[2] + pz;
         on = (C.rpage[bit >> 5] >> (bit & 31)) & 1u;
       }
-      if (!on) { bnd[i] = out; continue; }
+      if (!on) { bnd[i] = out; return; }
     }
     uint32_t pstate = rg[i].pad;
     int base[3];
@@ -376,7 +377,9 @@ __global__ __launch_bounds__(256) void k_gather_cdf(Params P, CdfDev C, RecG *__
     uint32_t all_b = 0u;
 #pragma unroll
     for (int t = 0; t < 27; t++) {
-      cdf_node(C, P, base[0] + t / 9, base[1] + (t / 3) % 3, base[2] + t % 3, ntag[t], nrid[t], nd[t]);
+      // (the block's 6^3 nodes are staged in LDS by the workgroup: a particle's stencil lies inside its block's tile)
+      const int tn = ((base[0] - ox + t / 9) * TS + (base[1] - oy + (t / 3) % 3)) * TS + (base[2] - oz + t % 3);
+      ntag[t] = s_tag[tn]; nrid[t] = s_rid[tn]; nd[t] = s_d[tn];
       all_b |= ntag[t] & CDF_STATE_MASK;
     }
     pstate &= (all_b + (all_b >> 1));  // unset the colours of bodies the particle no longer touches (:164)
@@ -438,6 +441,34 @@ __global__ __launch_bounds__(256) void k_gather_cdf(Params P, CdfDev C, RecG *__
       }
     }
     bnd[i] = out;
+  }
+}
+// One workgroup per active block that can hold such particles: the page test above uses the TRUNCATED position, the block a
+// particle is sorted into its base node (half a cell lower), so besides the block's own page its neighbours in the positive
+// directions are looked at.  Everything else is skipped without touching its records (the reference leaves those
+// particles' colours alone too); their stale boundary records are told apart by the epoch.
+__global__ __launch_bounds__(256) void k_gather_cdf(Params P, CdfDev C, RecG *__restrict__ rg, BndRec *__restrict__ bnd,
+                                                    uint32_t *__restrict__ cutting_counter, const Counters *__restrict__ cnt,
+                                                    const uint32_t *__restrict__ act_blk, const uint32_t *__restrict__ act_start,
+                                                    const uint32_t *__restrict__ perm, uint32_t epoch) {
+  __shared__ uint32_t s_tag[TN];
+  __shared__ int s_rid[TN];
+  __shared__ float s_d[TN];
+  const uint32_t na = min(cnt->n_active, P.max_blocks);
+  for (uint32_t a = blockIdx.x; a < na; a += gridDim.x) {
+    int bx, by, bz;
+    demorton3(act_blk[a], bx, by, bz);
+    bool cand = false;
+#pragma unroll
+    for (int o = 0; o < 8; o++) cand = cand || rigid_page_of_block(C, bx + (o >> 2), by + ((o >> 1) & 1), bz + 2 * (o & 1));
+    if (!cand) continue;  // workgroup-uniform
+    __syncthreads();
+    for (int t = threadIdx.x; t < TN; t += blockDim.x)
+      cdf_node(C, P, bx * BS + t / (TS * TS), by * BS + (t / TS) % TS, bz * BS + t % TS, s_tag[t], s_rid[t], s_d[t]);
+    __syncthreads();
+    const uint32_t p0 = act_start[a] & 0x7FFFFFFFu, p1 = act_start[a + 1] & 0x7FFFFFFFu;
+    for (uint32_t p = p0 + threadIdx.x; p < p1; p += blockDim.x)
+      gather_cdf_one(P, C, rg, bnd, cutting_counter, perm[p], epoch, bx * BS, by * BS, bz * BS, s_tag, s_rid, s_d);
   }
 }
 

@@ -172,6 +172,7 @@ struct mpmhip_ctx {
     uint8_t *d_blk_rigid = nullptr;
     uint32_t *d_counters = nullptr;  // [0, CDF_POOLS) pages handed out per sub-pool, [CDF_POOLS] cutting_counter
     uint32_t max_pages = 0;
+    uint32_t gather_epoch = 0;  // stamps the boundary records of the particles the last gather_cdf visited
     size_t rpage_words = 0;
     float penalty = 0.0f, pushing_force = 20000.0f;  // MPM::initialize defaults, src/mpm.cpp:35,40
   } rigid;

@@ -147,7 +147,8 @@ static int do_rigid_rasterize(mpmhip_ctx *c) {
 }
 static int do_rigid_gather(mpmhip_ctx *c) {
   auto &R = c->rigid;
-  hipLaunchKernelGGL(k_gather_cdf, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, R.cdf, c->rg, R.d_bnd, R.d_counters + CDF_POOLS);
+  hipLaunchKernelGGL(k_gather_cdf, dim3(8192), dim3(256), 0, c->stream, c->P, R.cdf, c->rg, R.d_bnd, R.d_counters + CDF_POOLS,
+                     (const Counters *)c->cnt, (const uint32_t *)c->act_blk, (const uint32_t *)c->act_start, (const uint32_t *)c->perm, ++R.gather_epoch);
   return launch_check(c, "gather_cdf");
 }
 static int do_rigid_block_flags(mpmhip_ctx *c) {
@@ -418,9 +419,10 @@ int64_t mpmhip_download_boundary(mpmhip_ctx *c, float *out, int64_t n_capacity) 
   for (size_t i = 0; i < hg.size(); i++) {
     if (hg[i].pid < 0) continue;
     if (m >= n_capacity) return fail(c, MPMHIP_ECAPACITY, "download buffer too small");
-    for (int k = 0; k < 3; k++) out[5 * m + k] = hb[i].n[k];
-    out[5 * m + 3] = hb[i].dist;
-    out[5 * m + 4] = (float)hb[i].near;
+    const bool fresh = hb[i].epoch == c->rigid.gather_epoch;  // (particles away from every body are not visited: zeros, as the reference leaves them)
+    for (int k = 0; k < 3; k++) out[5 * m + k] = fresh ? hb[i].n[k] : 0.0f;
+    out[5 * m + 3] = fresh ? hb[i].dist : 0.0f;
+    out[5 * m + 4] = fresh ? (float)hb[i].near : 0.0f;
     m++;
   }
   return m;
