@@ -1,8 +1,9 @@
 """What the CPIC coupling costs: 1 M jelly particles on the 128^3 grid (BASELINE configs[1] size) with and without a scripted
-paddle wheel turning inside the block (120 k coloured particles).  Round 2, one MI355X: 0.138 ms per substep without, 0.75 ms
-with the body (rocprofv3: k_p2g_rigid 0.23, k_cdf_rasterize 0.09-0.12, k_gather_cdf 0.12, k_g2p_rigid 0.10 ms — the
-rigid-block kernels are written for clarity, not speed; before the impulses were reduced per wave the same scene took
-39 ms: every impulse was six float atomics on the same six words of the body).
+paddle wheel turning inside the block (120 k coloured particles).  Round 2, one MI355X: 0.138 ms per substep without, 0.47 ms
+with the body.  The way there (each step measured): 39 ms with one float atomic per impulse on the body's six accumulator
+words -> 0.75 ms with the impulses reduced per wave -> 0.53 ms with the pages handed out per boundary particle and
+neighbouring lanes deduplicated (the rigid-page bitmap and the slot words are a few cache lines: every thread going there
+queued at one L2 bank) -> 0.47 ms with gather_cdf per block from LDS and the transfers near bodies in three passes.
     python profiles/cpic_overhead.py"""
 import time, numpy as np, sys
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))

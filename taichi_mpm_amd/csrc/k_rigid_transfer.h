@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64, 2) void k_p2g_rigid(Params P, const float4 *__r
 // body's surface motion plus a push along the boundary normal (:757-784); a particle near a boundary loses its affine
 // momentum (:800-804) and is pushed back by the penalty term when it is slightly inside (:821-832), the body receiving
 // the opposite impulse.  Everything after the gather is k_g2p's (same record layout, same key / deletion logic).
-__global__ __launch_bounds__(256) void k_g2p_rigid(Params P, const float4 *__restrict__ rg, float4 *__restrict__ rg_out,
+__global__ __launch_bounds__(256, 2) void k_g2p_rigid(Params P, const float4 *__restrict__ rg, float4 *__restrict__ rg_out,
                                                    float4 *__restrict__ rp_out, float4 *__restrict__ rb_out,
                                                    const Counters *__restrict__ cnt, const uint32_t *__restrict__ act_blk,
                                                    const uint32_t *__restrict__ act_start, const uint32_t *__restrict__ perm,
@@ -225,36 +225,53 @@ __global__ __launch_bounds__(256) void k_g2p_rigid(Params P, const float4 *__res
         for (int e = 0; e < 9; e++) b.m[e] = 0.0f;
         int rigid_id = -1;
         const int nbase = (c0 * TS + c1) * TS + c2;
+        // pass 1: the nodes on the other side of a body; pass 2: the ordinary gather without them (small unrolled body);
+        // pass 3 (particles at a boundary only): their share, with the projected velocity the reference substitutes
+        uint32_t other = 0u;
+#pragma unroll
+        for (int n = 0; n < 27; n++)
+          if (cdf_incompatible(stile[nbase + ((n / 9) * TS + (n / 3) % 3) * TS + n % 3], pstate)) other |= 1u << n;
 #pragma unroll
         for (int n = 0; n < 27; n++) {
           const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
           const float4 gv4 = tile[nbase + (i3 * TS + j) * TS + k];
-          float gv[3] = {gv4.x, gv4.y, gv4.z};
-          const uint32_t word = stile[nbase + (i3 * TS + j) * TS + k];
-          if (cdf_incompatible(word, pstate)) {
-            float fake[3] = {pv[0], pv[1], pv[2]};
-            const int rid = (int)(word >> 24) - 1;
-            float vg[3] = {0, 0, 0}, friction = 0.0f;
-            if (rid >= 0) {
-              const float gp[3] = {(bx * BS + c0 + i3) * P.dx, (by * BS + c1 + j) * P.dx, (bz * BS + c2 + k) * P.dx};
-              rigid_velocity_at(X.rb[rid], gp, vg);
-              rigid_id = rid;
-              friction = X.rb[rid].fric[(pstate >> (2 * rid)) & 1u];
-            }
-            if (bn.near) {
-              friction_project(fake, vg, bn.n, friction);
-              const float push = P.dt * P.dx * X.pushing_force;
-              fake[0] += bn.n[0] * push; fake[1] += bn.n[1] * push; fake[2] += bn.n[2] * push;
-            }
-            gv[0] = fake[0]; gv[1] = fake[1]; gv[2] = fake[2];
-          }
-          const float w = (w0[i3] * w1[j]) * w2[k];
-          const float d[3] = {r0 - (float)i3, r1 - (float)j, r2 - (float)k};
+          const float w = ((other >> n) & 1u) ? 0.0f : (w0[i3] * w1[j]) * w2[k];
+          const float d[3] = {r0 - (float)i3, r1 - (float)j, r2 - (float)k}, gv[3] = {gv4.x, gv4.y, gv4.z};
 #pragma unroll
           for (int r = 0; r < 3; r++) {
             v[r] = fmaf(w, gv[r], v[r]);
 #pragma unroll
             for (int c = 0; c < 3; c++) b(r, c) = fmaf(w * gv[r], d[c], b(r, c));
+          }
+        }
+        while (other) {
+          const int n = __ffs(other) - 1;
+          other &= other - 1u;
+          const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
+          const uint32_t word = stile[nbase + (i3 * TS + j) * TS + k];
+          float fake[3] = {pv[0], pv[1], pv[2]};
+          const int rid = (int)(word >> 24) - 1;
+          float vg[3] = {0, 0, 0}, friction = 0.0f;
+          if (rid >= 0) {
+            const float gp[3] = {(bx * BS + c0 + i3) * P.dx, (by * BS + c1 + j) * P.dx, (bz * BS + c2 + k) * P.dx};
+            rigid_velocity_at(X.rb[rid], gp, vg);
+            rigid_id = rid;
+            friction = X.rb[rid].fric[(pstate >> (2 * rid)) & 1u];
+          }
+          if (bn.near) {
+            friction_project(fake, vg, bn.n, friction);
+            const float push = P.dt * P.dx * X.pushing_force;
+            fake[0] += bn.n[0] * push; fake[1] += bn.n[1] * push; fake[2] += bn.n[2] * push;
+          }
+          const float wa = i3 == 0 ? w0[0] : (i3 == 1 ? w0[1] : w0[2]), wb = j == 0 ? w1[0] : (j == 1 ? w1[1] : w1[2]),
+                      wc = k == 0 ? w2[0] : (k == 1 ? w2[1] : w2[2]);
+          const float w = (wa * wb) * wc;
+          const float d[3] = {r0 - (float)i3, r1 - (float)j, r2 - (float)k};
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            v[r] = fmaf(w, fake[r], v[r]);
+#pragma unroll
+            for (int c = 0; c < 3; c++) b(r, c) = fmaf(w * fake[r], d[c], b(r, c));
           }
         }
         mat3 cdg;
