@@ -38,6 +38,44 @@ def test_config_struct_matches_header_layout():
     assert _lib.Config.max_particles.offset % 8 == 0
 
 
+def test_ctypes_mirrors_match_the_c_structs_field_by_field(tmp_path):
+    """every struct that crosses the C ABI by value or pointer: sizeof and the offset of every field, as gcc lays out
+    include/mpmhip.h, against the ctypes mirrors of taichi_mpm_amd/_lib.py"""
+    import subprocess
+    pairs = [("mpmhip_config", _lib.Config), ("mpmhip_shape", _lib.Shape), ("mpmhip_async_config", _lib.AsyncConfig),
+             ("mpmhip2d_config", _lib.Config2D), ("mpmhip_halo_box", _lib.HaloBox), ("mpmhip_rigid_config", _lib.RigidConfig),
+             ("mpmhip2d_rigid_config", _lib.RigidConfig2D)]
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "mpmhip.h"', "int main(void) {"]
+    for cname, mirror in pairs:
+        lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in mirror._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = {}
+    for ln in subprocess.check_output([str(exe)], text=True).splitlines():
+        c, f, v = ln.split()
+        got[(c, f)] = int(v)
+    for cname, mirror in pairs:
+        assert got[(cname, "size")] == C.sizeof(mirror), (cname, got[(cname, "size")], C.sizeof(mirror))
+        for fname, _ in mirror._fields_:
+            assert got[(cname, fname)] == getattr(mirror, fname).offset, (cname, fname)
+
+
+def test_obj_loader_fans_polygons_and_handles_negative_indices(tmp_path):
+    from taichi_mpm_amd.mpm import load_obj_triangles
+    f = tmp_path / "quad.obj"
+    f.write_text("# a quad and a triangle\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\nf 1 2 3 4\nf -1/1/1 1//2 2\n")
+    t = load_obj_triangles(str(f))
+    assert t.shape == (3, 3, 3)
+    np.testing.assert_array_equal(t[0], [[0, 0, 0], [1, 0, 0], [1, 1, 0]])
+    np.testing.assert_array_equal(t[1], [[0, 0, 0], [1, 1, 0], [0, 1, 0]])
+    np.testing.assert_array_equal(t[2], [[0, 0, 1], [0, 0, 0], [1, 0, 0]])
+
+
 def test_create_fails_loudly_without_gpu(built):
     import torch
     if torch.cuda.is_available():
