@@ -406,6 +406,7 @@ int mpmhip2d_set_rigid_coupling(mpmhip2d_ctx *ctx, float penalty, float pushing_
 int mpmhip2d_add_rigid_body(mpmhip2d_ctx *ctx, const mpmhip2d_rigid_config *cfg, int64_t n_segments, const float *segments /* n x 4 */);
 int mpmhip2d_rigid_get_state(mpmhip2d_ctx *ctx, int32_t id, float *out /* [10]: pos 2, angle, vel 2, omega, mass, inv_mass, inertia, inv_inertia */);
 int64_t mpmhip2d_rigid_get_samples(mpmhip2d_ctx *ctx, int32_t id, int64_t capacity, float *position);
+int64_t mpmhip2d_rigid_get_mesh(mpmhip2d_ctx *ctx, int32_t id, int64_t capacity_segments, float *segments /* n x 4, world space */);
 int mpmhip2d_cdf_phase(mpmhip2d_ctx *ctx); /* rasterize_rigid_boundary + gather_cdf (parity tests) */
 int mpmhip2d_download_cdf(mpmhip2d_ctx *ctx, uint32_t *states, float *distance); /* dense (res+1)^2 */
 int64_t mpmhip2d_download_colours(mpmhip2d_ctx *ctx, int64_t capacity, uint32_t *states, float *distance, float *normal, int32_t *near);
@@ -449,6 +450,9 @@ int mpmhip_rigid_set_velocity(mpmhip_ctx *ctx, int32_t id, const float *velocity
 /* the boundary particles sampled on the body's triangles (RigidBoundaryParticle, src/boundary_particle.h): world
  * position, offset from the centre of mass in the body frame, body index; id < 0: all bodies.  Returns the count. */
 int64_t mpmhip_rigid_get_samples(mpmhip_ctx *ctx, int32_t id, int64_t capacity, float *position, float *offset, int32_t *body);
+/* the body's triangles in world space, 9 floats each (write_rigid_body, src/visualize.cpp:102-154: the rigid_%03d_%04d.obj
+ * next to every .bgeo frame).  Returns the triangle count. */
+int64_t mpmhip_rigid_get_mesh(mpmhip_ctx *ctx, int32_t id, int64_t capacity_triangles, float *triangles);
 /* phases (parity tests; mpmhip_substep runs them itself): rasterize_rigid_boundary, gather_cdf (needs a sort),
  * advect_rigid_bodies(base_delta_t) */
 int mpmhip_rasterize_rigid_boundary(mpmhip_ctx *ctx);

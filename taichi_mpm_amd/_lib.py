@@ -138,7 +138,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_las
             "mpmhip2d_set_rigid_coupling", "mpmhip2d_add_rigid_body", "mpmhip2d_rigid_get_state", "mpmhip2d_rigid_get_samples", "mpmhip2d_cdf_phase",
             "mpmhip2d_download_cdf", "mpmhip2d_download_colours",
             "mpmhip_set_rigid_coupling", "mpmhip_add_rigid_body", "mpmhip_num_rigid_bodies", "mpmhip_rigid_get_state", "mpmhip_rigid_set_velocity",
-            "mpmhip_rigid_get_samples", "mpmhip_rasterize_rigid_boundary", "mpmhip_gather_cdf", "mpmhip_advect_rigid_bodies", "mpmhip_download_cdf",
+            "mpmhip_rigid_get_samples", "mpmhip_rigid_get_mesh", "mpmhip2d_rigid_get_mesh", "mpmhip_rasterize_rigid_boundary", "mpmhip_gather_cdf", "mpmhip_advect_rigid_bodies", "mpmhip_download_cdf",
             "mpmhip_download_boundary",
             "mpmhip_debug_copy_bandwidth", "mpmhip_debug_gather_bandwidth", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
 
@@ -278,6 +278,10 @@ def load():
     L.mpmhip_rigid_set_velocity.argtypes = [vp, C.c_int32, fp, fp]
     L.mpmhip_rigid_get_samples.argtypes = [vp, C.c_int32, C.c_int64, fp, fp, ip]
     L.mpmhip_rigid_get_samples.restype = C.c_int64
+    L.mpmhip_rigid_get_mesh.argtypes = [vp, C.c_int32, C.c_int64, fp]
+    L.mpmhip_rigid_get_mesh.restype = C.c_int64
+    L.mpmhip2d_rigid_get_mesh.argtypes = [vp, C.c_int32, C.c_int64, fp]
+    L.mpmhip2d_rigid_get_mesh.restype = C.c_int64
     for name in ("mpmhip_rasterize_rigid_boundary", "mpmhip_gather_cdf", "mpmhip_advect_rigid_bodies"):
         getattr(L, name).argtypes = [vp]
     L.mpmhip_download_cdf.argtypes = [vp, up, fp]

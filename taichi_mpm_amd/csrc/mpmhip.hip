@@ -156,6 +156,7 @@ struct mpmhip_ctx {
     mpmhip_rigid_config cfg{};
     float mass = 0.0f, inertia[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, inv_inertia[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int first_sample = 0, n_samples = 0;
+    int64_t first_elem = 0, n_elems = 0;
   };
   struct RigidState {
     bool enabled = false;
@@ -2013,7 +2014,7 @@ struct mpmhip2d_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   // CPIC rigid bodies (k_rigid2d.h): segments, boundary particles, dense colored distance field
-  struct HostRigid2 { mpmhip2d_rigid_config cfg{}; float mass = 0, inertia = 0; };
+  struct HostRigid2 { mpmhip2d_rigid_config cfg{}; float mass = 0, inertia = 0; int64_t first_elem = 0, n_elems = 0; };
   bool rigid_enabled = false;
   std::vector<HostRigid2> bodies;
   std::vector<mpm2d::Sample2> h_smp;
@@ -2331,7 +2332,7 @@ int mpmhip2d_add_rigid_body(mpmhip2d_ctx *m, const mpmhip2d_rigid_config *cfg, i
   HIPCHK2D(m, hipMemcpy(m->d_elems, m->h_elems.data(), sizeof(float) * m->h_elems.size(), hipMemcpyHostToDevice));
   HIPCHK2D(m, hipMemcpy(m->d_rb + body, &D, sizeof D, hipMemcpyHostToDevice));
   mpmhip2d_ctx::HostRigid2 H;
-  H.cfg = *cfg; H.mass = (float)M; H.inertia = (float)I;
+  H.cfg = *cfg; H.mass = (float)M; H.inertia = (float)I; H.first_elem = (int64_t)elem0; H.n_elems = n_segments;
   m->bodies.push_back(H);
   return body;
 }
@@ -2346,6 +2347,24 @@ int mpmhip2d_rigid_get_state(mpmhip2d_ctx *m, int32_t id, float *out) {
   out[0] = D.pos[0]; out[1] = D.pos[1]; out[2] = D.angle; out[3] = D.vel[0]; out[4] = D.vel[1]; out[5] = D.omega;
   out[6] = D.mass; out[7] = D.inv_mass; out[8] = m->bodies[id].inertia; out[9] = D.inv_I;
   return MPMHIP_OK;
+}
+// the body's segments in world space (write_rigid_body's .poly file, src/visualize.cpp:105-130): 4 floats per segment
+int64_t mpmhip2d_rigid_get_mesh(mpmhip2d_ctx *m, int32_t id, int64_t cap_segments, float *out) {
+  if (!m) return MPMHIP_EINVAL;
+  if (!m->rigid_enabled || id < 1 || id >= (int)m->bodies.size()) return fail2d(m, MPMHIP_EINVAL, "no such rigid body");
+  if (hipSetDevice(m->device) != hipSuccess || hipStreamSynchronize(m->stream) != hipSuccess) return MPMHIP_EHIP;
+  mpm2d::Rigid2 D;
+  HIPCHK2D(m, hipMemcpy(&D, m->d_rb + id, sizeof D, hipMemcpyDeviceToHost));
+  const auto &B = m->bodies[id];
+  const float cs = std::cos(D.angle), sn = std::sin(D.angle);
+  if (out)
+    for (int64_t e = 0; e < std::min<int64_t>(B.n_elems, cap_segments); e++)
+      for (int q = 0; q < 2; q++) {
+        const float *v = &m->h_elems[(size_t)(B.first_elem + e) * 4 + 2 * q];
+        out[4 * e + 2 * q] = cs * v[0] - sn * v[1] + D.pos[0];
+        out[4 * e + 2 * q + 1] = sn * v[0] + cs * v[1] + D.pos[1];
+      }
+  return B.n_elems;
 }
 // world positions of the boundary particles of body id (id < 0: all); returns the count
 int64_t mpmhip2d_rigid_get_samples(mpmhip2d_ctx *m, int32_t id, int64_t cap, float *pos) {

@@ -284,6 +284,7 @@ int mpmhip_add_rigid_body(mpmhip_ctx *c, const mpmhip_rigid_config *cfg, int64_t
   // (allocator.allocate_particle, src/particle_allocator.h:68-74): later material particles are numbered behind them
   c->next_pid += allocated;
   B.n_samples = (int)R.h_smp.size() - B.first_sample;
+  B.first_elem = (int64_t)elem0; B.n_elems = n_triangles;
   R.h_elems.insert(R.h_elems.end(), tri.begin(), tri.end());
   // (re)upload samples and elements
   (void)hipFree(R.d_smp); (void)hipFree(R.d_elems);
@@ -357,6 +358,27 @@ int64_t mpmhip_rigid_get_samples(mpmhip_ctx *c, int32_t id, int64_t cap, float *
     n++;
   }
   return n;
+}
+
+// the body's triangles in world space (get_mesh_to_world applied to mesh->elements): what write_rigid_body puts into
+// frame_directory/rigid_%03d_%04d.obj next to every .bgeo frame (src/visualize.cpp:102-154, src/mpm.h:333-343).
+// out: 9 floats per triangle; returns the body's triangle count.
+int64_t mpmhip_rigid_get_mesh(mpmhip_ctx *c, int32_t id, int64_t cap_triangles, float *out) {
+  if (!c) return MPMHIP_EINVAL;
+  if (!c->rigid.enabled || id < 1 || id >= (int)c->rigid.bodies.size()) return fail(c, MPMHIP_EINVAL, "no rigid body %d", id);
+  if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return MPMHIP_EHIP;
+  auto &R = c->rigid;
+  RigidBodyDev D;
+  HIPCHK(c, hipMemcpy(&D, R.d_rb + id, sizeof D, hipMemcpyDeviceToHost));
+  const auto &B = R.bodies[id];
+  if (out) {
+    for (int64_t e = 0; e < std::min<int64_t>(B.n_elems, cap_triangles); e++)
+      for (int q = 0; q < 3; q++) {
+        const float *v = &R.h_elems[(size_t)(B.first_elem + e) * 9 + 3 * q];
+        for (int r = 0; r < 3; r++) out[9 * e + 3 * q + r] = D.R[3 * r] * v[0] + D.R[3 * r + 1] * v[1] + D.R[3 * r + 2] * v[2] + D.pos[r];
+      }
+  }
+  return B.n_elems;
 }
 
 // phase-level entry points (parity tests; substep() runs them itself)

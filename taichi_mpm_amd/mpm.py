@@ -682,7 +682,35 @@ class Simulation3D:
         os.makedirs(self.frame_directory, exist_ok=True)
         path = os.path.join(self.frame_directory, "%04d.bgeo" % self.frame_count)
         self.write_partio(path)
+        # "Start from 1. (0 is the background rigid body.)": every body's mesh in world space next to the frame (src/mpm.h:338-343)
+        for rid in range(1, self.get_num_rigid_bodies()):
+            self.write_rigid_body(rid, os.path.join(self.frame_directory, "rigid_%03d_%04d" % (rid, self.frame_count)))
         return path
+
+    def get_num_rigid_bodies(self):
+        """rigids.size(): the background body included"""
+        return int(self._L.mpmhip_num_rigid_bodies(self._ctx)) if self._ctx is not None else 1
+
+    def get_rigid_mesh(self, rid):
+        """the body's triangles in world space, (n, 3, 3)"""
+        fp = C.POINTER(C.c_float)
+        n = self._check(self._L.mpmhip_rigid_get_mesh(self._ctx, int(rid), 0, None))
+        tri = np.zeros((n, 3, 3), np.float32)
+        if n:
+            self._check(self._L.mpmhip_rigid_get_mesh(self._ctx, int(rid), n, tri.ctypes.data_as(fp)))
+        return tri
+
+    def write_rigid_body(self, rid, file_name):
+        """MPM<3>::write_rigid_body (src/visualize.cpp:131-153): `file_name`.obj with three `v` records per triangle and one `f`
+        record per triangle (the number format of the reference's fmt build is not pinned: %.9g here)"""
+        tri = self.get_rigid_mesh(rid)
+        with open(file_name + ".obj", "w") as f:
+            for t in tri:
+                for v in t:
+                    f.write("v %.9g %.9g %.9g\n" % (v[0], v[1], v[2]))
+            for k in range(len(tri)):
+                f.write("f %d %d %d\n" % (3 * k + 1, 3 * k + 2, 3 * k + 3))
+        return file_name + ".obj"
 
     def write_partio(self, file_name):
         """MPM<dim>::write_partio (src/visualize.cpp:17-100): Houdini .bgeo v5 with the reference's attributes, rows

@@ -249,6 +249,28 @@ class Simulation2D:
             self._check(self._L.mpmhip2d_rigid_get_samples(self._ctx, int(rid), n, pos.ctypes.data_as(C.POINTER(C.c_float))))
         return pos
 
+    def get_rigid_mesh(self, rid):
+        """the body's segments in world space, (n, 2, 2)"""
+        fp = C.POINTER(C.c_float)
+        n = self._check(self._L.mpmhip2d_rigid_get_mesh(self._ctx, int(rid), 0, None))
+        seg = np.zeros((n, 2, 2), np.float32)
+        if n:
+            self._check(self._L.mpmhip2d_rigid_get_mesh(self._ctx, int(rid), n, seg.ctypes.data_as(fp)))
+        return seg
+
+    def write_rigid_body(self, rid, file_name):
+        """MPM<2>::write_rigid_body (src/visualize.cpp:105-130): `file_name`.poly — POINTS, POLYS (one per segment), END"""
+        seg = self.get_rigid_mesh(rid).reshape(-1, 2)
+        with open(file_name + ".poly", "w") as f:
+            f.write("POINTS\n")
+            for i, v in enumerate(seg):
+                f.write("%d: %.9g %.9g 0.0\n" % (i + 1, v[0], v[1]))
+            f.write("POLYS\n")
+            for i in range(1, len(seg) // 2 + 1):
+                f.write("%d: %d %d\n" % (i, 2 * i - 1, 2 * i))
+            f.write("END\n")
+        return file_name + ".poly"
+
     def cdf_phase(self):
         """rasterize_rigid_boundary + gather_cdf as one phase (parity tests; substep() runs them itself)"""
         self._ensure_ctx(); self._check(self._L.mpmhip2d_cdf_phase(self._ctx))

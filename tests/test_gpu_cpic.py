@@ -415,3 +415,26 @@ def test_rotation_axis_and_damping_match_the_live_reference(tm):
     np.testing.assert_allclose(b[7:13], a[7:13], rtol=0, atol=2e-4 * np.abs(a[7:13]).max())
     r, h = ref.download(by_id=True), sim.get_particles(sort_by_id=True)
     assert np.abs(h["x"] - r["x"]).max() <= 5e-6 and rel_l2(h["v"], r["v"]) <= 2e-4
+
+
+def test_frames_carry_the_rigid_meshes(tm, tmp_path):
+    """visualize() = write_bgeo (src/mpm.h:333-343): %04d.bgeo plus rigid_%03d_%04d.obj per body, the mesh in world space"""
+    sim, rid = cs.build_device(tm, "scripted", "jelly")
+    sim.frame_directory = str(tmp_path)
+    sim.run_substeps(8)
+    path = sim.visualize()
+    assert path.endswith("0001.bgeo") and os.path.exists(path)
+    obj = os.path.join(str(tmp_path), "rigid_001_0001.obj")
+    lines = open(obj).read().split("\n")
+    v = np.array([[float(w) for w in ln.split()[1:]] for ln in lines if ln.startswith("v ")])
+    assert v.shape == (6, 3) and lines[6].startswith("f 1 2 3") and lines[7].startswith("f 4 5 6")
+    st = sim.get_rigid_state(rid)
+    # the plate's corners lie 0.2 * sqrt(2) from its (moving) centre and in a plane through it
+    np.testing.assert_allclose(np.linalg.norm(v - st["position"], axis=1), 0.2 * np.sqrt(2), atol=1e-5)
+    n = np.cross(v[1] - v[0], v[2] - v[0])
+    assert abs(np.dot(n / np.linalg.norm(n), st["position"] - v[0])) < 1e-6
+    # 2D: the .poly file of a bar
+    sim2, rid2 = cs.build_device2(tm, "bar", "jelly")
+    sim2.run_substeps(2)
+    poly = open(sim2.write_rigid_body(rid2, str(tmp_path / "bar"))).read().split("\n")
+    assert poly[0] == "POINTS" and poly[3] == "POLYS" and poly[4] == "1: 1 2" and poly[5] == "END"
