@@ -247,7 +247,24 @@ class MPM<3> {
     std::snprintf(name, sizeof name, "/%04d.bgeo", ++frame_count);  // frames start at 1 (src/mpm.h:334-336)
     const std::string file_name = frame_directory + name;
     write_partio(file_name);
+    // "Start from 1. (0 is the background rigid body.)" — every body's mesh in world space next to the frame (src/mpm.h:338-343)
+    for (int i = 1; i < mpmhip_num_rigid_bodies(ctx_); i++) {
+      std::snprintf(name, sizeof name, "/rigid_%03d_%04d", i, frame_count);
+      write_rigid_body(i, frame_directory + name);
+    }
     return file_name;
+  }
+  // MPM<3>::write_rigid_body (src/visualize.cpp:131-153): file_name.obj, three `v` records and one `f` record per triangle
+  void write_rigid_body(int id, const std::string &file_name) const {
+    const int64_t n = mpmhip_rigid_get_mesh(ctx_, id, 0, nullptr);
+    check((int)n, ctx_);
+    std::vector<float> tri((size_t)n * 9);
+    if (n) check((int)mpmhip_rigid_get_mesh(ctx_, id, n, tri.data()), ctx_);
+    FILE *f = std::fopen((file_name + ".obj").c_str(), "w");
+    if (!f) throw std::runtime_error("cannot write " + file_name + ".obj");
+    for (int64_t k = 0; k < 3 * n; k++) std::fprintf(f, "v %.9g %.9g %.9g\n", tri[3 * k], tri[3 * k + 1], tri[3 * k + 2]);
+    for (int64_t k = 0; k < n; k++) std::fprintf(f, "f %lld %lld %lld\n", (long long)(3 * k + 1), (long long)(3 * k + 2), (long long)(3 * k + 3));
+    std::fclose(f);
   }
   void visualize() { write_bgeo(); }
 
