@@ -49,6 +49,13 @@ class MPM<3> {
   // --- MPM<dim>::initialize (src/mpm.cpp:26-75; config keys README.md:234-256)
   void initialize(const Config &config) {
     if (config.has_key("delta_t")) throw std::runtime_error("Please use 'base_delta_t' instead of 'delta_t'");  // :41-42
+    // physics-changing keys of the reference that this library does not implement: refused, not ignored
+    for (const char *k : {"rigid_body_levelset_collision", "gravity_cutting", "sand_climb", "sand_crawler", "stork_nod", "energy_experiment",
+                          "visualize_cdf", "visualize_particle_cdf", "benchmark_rasterize", "benchmark_resample"})
+      if (config.get(k, false)) throw std::runtime_error(std::string("config key '") + k + "' is not implemented by this library");
+    if (config.get("dirichlet_boundary_radius", 0.0f) > 0 || config.get("expr_leaky_levelset", 0) != 0 || config.get("remove_particles", 0) != 0 ||
+        config.get("coupling_iterations", 1) != 1 || config.get("cdf_expand", 0) != 0)
+      throw std::runtime_error("dirichlet_boundary_radius / expr_leaky_levelset / remove_particles / coupling_iterations / cdf_expand are not implemented");
     res = config.get_vec("res", VectorI(0, 0, 0));
     if (res[0] <= 0) throw std::runtime_error("config key 'res' is required");
     delta_x = config.get("delta_x", 1.0f / res[0]);

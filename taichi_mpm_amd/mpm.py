@@ -127,6 +127,25 @@ def load_obj_triangles(path):
     return np.asarray(tris, np.float32)
 
 
+# config keys of MPM<dim>::initialize / substep that change the physics and are NOT implemented here: a scene that sets them to
+# anything but the inert default is refused instead of being simulated differently (key: inert value, where the reference reads it)
+UNSUPPORTED_KEYS = {
+    "rigid_body_levelset_collision": (False, "src/mpm.cpp:535-538"), "dirichlet_boundary_radius": (0.0, "src/mpm.cpp:541-544"),
+    "expr_leaky_levelset": (0, "src/mpm.cpp:300"), "gravity_cutting": (False, "src/mpm.cpp:347"),
+    "remove_particles": (0, "src/mpm.cpp:586"), "sand_climb": (False, "src/mpm.h:281"), "sand_crawler": (False, "src/mpm.h"),
+    "stork_nod": (False, "src/mpm.h"), "coupling_iterations": (1, "src/mpm.cpp:467"), "cdf_expand": (0, "src/rigid_transfer.cpp:82"),
+    "energy_experiment": (False, "src/mpm.cpp:68"), "visualize_cdf": (False, "src/mpm.cpp:474"),
+    "visualize_particle_cdf": (False, "src/mpm.cpp:488"), "benchmark_rasterize": (False, "src/mpm.cpp:516"),
+    "benchmark_resample": (False, "src/mpm.cpp:554"),
+}
+
+
+def check_unsupported_keys(cfg):
+    for k, (inert, where) in UNSUPPORTED_KEYS.items():
+        if k in cfg and cfg[k] != inert and not (isinstance(inert, bool) and bool(cfg[k]) == inert):
+            raise MPMError("config key %r = %r (%s) is not implemented by this library" % (k, cfg[k], where))
+
+
 class Simulation3D:
     """MPM<3> (src/mpm.h:56-489) backed by libmpmhip."""
 
@@ -148,6 +167,7 @@ class Simulation3D:
         cfg = dict(config)
         if "delta_t" in cfg:  # src/mpm.cpp:41-42
             raise MPMError("Please use 'base_delta_t' instead of 'delta_t'")
+        check_unsupported_keys(cfg)
         if "res" not in cfg:
             raise MPMError("config key 'res' is required")
         res = cfg["res"]

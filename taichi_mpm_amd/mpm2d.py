@@ -8,7 +8,7 @@ import numpy as np
 
 from . import _lib
 from .materials import MATERIAL_IDS, group_params, initial_aux
-from .mpm import DynamicLevelSet, LevelSet, MPMError
+from .mpm import DynamicLevelSet, LevelSet, MPMError, check_unsupported_keys
 
 
 def lattice_square(lower, higher, dx):
@@ -35,6 +35,7 @@ class Simulation2D:
         cfg = dict(config)
         if "delta_t" in cfg:  # src/mpm.cpp:41-42
             raise MPMError("Please use 'base_delta_t' instead of 'delta_t'")
+        check_unsupported_keys(cfg)
         res = cfg["res"]
         res = (int(res),) * 2 if np.isscalar(res) else tuple(int(r) for r in res)
         if len(res) != 2:
