@@ -47,7 +47,10 @@ CONFIGS = {
     "c3": dict(res=256, cells=100, material="sand", desc="256^3 grid, 100^3 cells x 8 = 8M Drucker-Prager sand particles (BASELINE configs[2])"),
     "c2": dict(res=128, cells=50, material="jelly", desc="128^3 grid, 50^3 cells x 8 = 1M fixed-corotated jelly particles (BASELINE configs[1])"),
     # single-GPU only (the whole 64 M-particle problem fits one MI355X: 12 GB); needs ~48 GB of host memory to stage
-    "c5": dict(res=512, cells=100, material="water+elastic", cpu_material="water", clusters=(78, 334),
+    # dt: half of the other configs' — the same Courant number at half the cell size.  (At 1e-4 the water clusters
+    # (k = 1e4, gamma = 7: c = 13 m/s at rest, c dt / dx = 0.68, stiffening under compression) blow up ~420 substeps
+    # after they hit the floor and the run ends with 27 k of 64 M particles: measured, with this build and the one before.)
+    "c5": dict(res=512, cells=100, material="water+elastic", cpu_material="water", clusters=(78, 334), dt=5e-5,
                desc="512^3 sparse blocked grid, 8 clusters of 100^3 cells x 8 = 64M particles, 4 water + 4 Hencky-elastic (BASELINE configs[4])"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
@@ -56,7 +59,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measu
 def build_sim(tm, cfg, device):
     res, cells = cfg["res"], cfg["cells"]
     lo = res // 2 - cells // 2
-    sim = tm.create_simulation3("mpm").initialize(dict(res=(res,) * 3, delta_x=1.0 / res, base_delta_t=1e-4,
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(res,) * 3, delta_x=1.0 / res, base_delta_t=cfg.get("dt", 1e-4),
                                                        gravity=(0, -10, 0), device=device,
                                                        keep_apic_b=bool(cfg.get("keep_apic_b", False))))
     sim.set_levelset(tm.mpm.LevelSet(friction=-1.0).add_plane((0, 1, 0), d=-0.1))  # sticky floor y = 0.1
@@ -66,12 +69,12 @@ def build_sim(tm, cfg, device):
     return sim
 
 
-def substeps_to_impact(cfg, dt=1e-4, g=10.0, floor=0.1):
+def substeps_to_impact(cfg, g=10.0, floor=0.1):
     """substeps of free fall until the seeded cube touches the floor plane y = 0.1"""
     res, cells = cfg["res"], cfg["cells"]
     lo = cfg["clusters"][0] if "clusters" in cfg else res // 2 - cells // 2
     h = (lo + 0.25) / res - floor
-    return int(np.sqrt(2.0 * h / g) / dt)
+    return int(np.sqrt(2.0 * h / g) / cfg.get("dt", 1e-4))
 
 
 EVOLVE_AFTER_IMPACT = 400  # substeps run after the block has touched the floor before the `evolved` state is timed
@@ -110,7 +113,7 @@ def cpu_baseline_reference(cfg, budget_s=25.0):
 
     def small(threads):
         ref.set_threads(threads)
-        sim = ref.Sim(res, dx, 1e-4, shapes=[(0, 0, 0, 1, 0, -0.1)], friction=-1.0)
+        sim = ref.Sim(res, dx, cfg.get("dt", 1e-4), shapes=[(0, 0, 0, 1, 0, -0.1)], friction=-1.0)
         sim.add_benchmark(mat, 125)
         return sim
     sweep, n_small = {}, 0
@@ -147,7 +150,7 @@ def cpu_baseline_reference(cfg, budget_s=25.0):
             lo = res // 2 - cfg["cells"] // 2
             x = lattice_cube(lo, lo + cfg["cells"], dx)
             vol = dx ** 3 / 8
-            sim = ref.Sim(res, dx, 1e-4, shapes=[(0, 0, 0, 1, 0, -0.1)], friction=-1.0)
+            sim = ref.Sim(res, dx, cfg.get("dt", 1e-4), shapes=[(0, 0, 0, 1, 0, -0.1)], friction=-1.0)
             sim.add_particles(mat, 400.0 * vol, vol, x)
             sim.substep(1)
             sec, prof = run(sim, 3)
@@ -208,7 +211,7 @@ def cpu_baseline(cfg, budget_s=20.0):
     gp, t = orc.group_params(cfg.get("cpu_material", cfg["material"]), 400.0 * vol, vol)
     aux = np.full(len(x), orc.initial_aux(cfg.get("cpu_material", cfg["material"])), np.float32)
     s = orc.State(x, None, None, None, aux, None, gp[None], np.array([t], np.int32))
-    ocfg = orc.make_config(res, dx, 1e-4, planes=[(0, 1, 0, -0.1)], friction=-1.0)
+    ocfg = orc.make_config(res, dx, cfg.get("dt", 1e-4), planes=[(0, 1, 0, -0.1)], friction=-1.0)
     n = len(x)
     hw = os.cpu_count() or 1
     orc.opt_run(ocfg, s, 1, min(hw, 16))  # warm-up (page faults, first sort)
@@ -455,7 +458,7 @@ def main():
         "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": job.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": cfg["desc"], "particles": n_total, "dt": 1e-4, "parallelism": job.parallelism, "wire": wire,
+        "config": {"workload": cfg["desc"], "particles": n_total, "dt": cfg.get("dt", 1e-4), "parallelism": job.parallelism, "wire": wire,
                    "timed": "full substep: sort+reorder, P2G, grid normalise+boundary, G2P, boundary cleanup",
                    "state": state_desc},
         "roofline": roof,
@@ -477,6 +480,8 @@ def main():
                 "value": e_n * args.steps / e_el, "ms_per_step": 1e3 * e_el / args.steps, "phases_ms_per_step": e_ms,
                 "roofline": e_roof, "p2g_plus_g2p_hbm_frac_algorithmic": e_both,
                 "whole_step_hbm_frac_algorithmic": (e_n * 252.0 + e_nodes * 80.0) / (e_el / args.steps) / 1e9 / HBM_PEAK_GBS}
+            if e_n < 0.99 * n_per_gpu:  # particles deleted on the way (left the domain / non-finite): not the workload any more
+                out["evolved"]["warning"] = "%d of %d particles were deleted before the timed region" % (n_per_gpu - e_n, n_per_gpu)
         except Exception as e:
             out["evolved"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline:

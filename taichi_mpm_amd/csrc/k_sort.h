@@ -39,9 +39,12 @@ __global__ __launch_bounds__(256) void k_build_keys(Params P, RecG *__restrict__
 // Instead of the classic three launches (partials, scan of partials, apply) a workgroup publishes the sum of its
 // chunk as ONE 64-bit word {epoch, value} (agent-scope atomic: the 8 XCDs' L2s are not coherent for plain
 // accesses; the word is self-contained, so relaxed ordering suffices), sums the words of the chunks before it
-// (spinning until their epoch matches) and finishes its chunk.  Chunks are handed out by a ticket counter, so a
-// chunk's predecessors have always started and never wait on it: no deadlock, no co-residency assumption.  The
-// epoch changes with every sort and each kernel zeroes the OTHER kernel's ticket: nothing is cleared by memsets.
+// (spinning until their epoch matches) and finishes its chunk.  A chunk publishes BEFORE it waits, and the host
+// launches no more workgroups than the device keeps resident at once (scan_grid() in mpmhip.hip, a quarter of the
+// occupancy limit), so every chunk a workgroup waits for has been published or is being computed: no deadlock.
+// (Round 1 handed the chunks out through a ticket counter instead, which needs no co-residency: ~800 returning
+// atomics on ONE address per launch, 6 us of the sort at 8 M particles and 5 us at 1 M.)  The epoch changes with
+// every sort: nothing is cleared by memsets.
 __device__ __forceinline__ uint32_t wg_exclusive_scan_256(uint32_t v, uint32_t *lds /*>=4*/, uint32_t &total) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t inc = v;
@@ -76,11 +79,10 @@ __device__ __forceinline__ uint32_t sum_predecessors(const unsigned long long *s
   wg_exclusive_scan_256(pre, lds, total);
   return total;
 }
-__device__ __forceinline__ uint32_t take_ticket(uint32_t *ticket, uint32_t *s_chunk) {
-  __syncthreads();  // the previous chunk's readers of *s_chunk are done
-  if (threadIdx.x == 0) *s_chunk = atomicAdd(ticket, 1u);
-  __syncthreads();
-  return *s_chunk;
+// chunks are dealt round-robin by workgroup id: chunk = blockIdx.x + round * gridDim.x
+__device__ __forceinline__ uint32_t next_chunk(uint32_t &round) {
+  __syncthreads();  // the previous chunk's LDS readers are done
+  return blockIdx.x + (round++) * gridDim.x;
 }
 
 // Active-block table, one launch: byte flags -> bitmap `bits` (bit b of word w = block with Morton key 32w+b;
@@ -89,14 +91,12 @@ __device__ __forceinline__ uint32_t take_ticket(uint32_t *ticket, uint32_t *s_ch
 __global__ __launch_bounds__(256) void k_block_table(Params P, uint8_t *__restrict__ blk_flag,
                                                      uint32_t *__restrict__ bits, uint32_t *__restrict__ wprefix,
                                                      uint32_t *__restrict__ act_blk, Counters *cnt,
-                                                     unsigned long long *__restrict__ slots, uint32_t *ticket,
-                                                     uint32_t epoch) {
+                                                     unsigned long long *__restrict__ slots, uint32_t epoch) {
   __shared__ uint32_t lds[8];
-  __shared__ uint32_t s_chunk;
-  if (blockIdx.x == 0 && threadIdx.x == 0) ticket[1] = 0;  // k_cell_table's counter (it is not running now)
   const uint32_t nchunks = (P.nbw + 255) / 256;
+  uint32_t round = 0;
   while (true) {
-    const uint32_t chunk = take_ticket(ticket, &s_chunk);
+    const uint32_t chunk = next_chunk(round);
     if (chunk >= nchunks) return;
     const uint32_t w = chunk * 256 + threadIdx.x;
     uint32_t m = 0;
@@ -135,123 +135,197 @@ __global__ __launch_bounds__(256) void k_block_table(Params P, uint8_t *__restri
   }
 }
 
-// rank of each particle inside its cell; overwrites key[i] with cidx = slot(block)*64 + cell.  Two paths, chosen
-// per sort from the statistics of the previous one (cnt->rank_mode, set by k_cell_table):
-//  mode 0  runs of equal keys in adjacent lanes (the slots are in the order of the last physical reorder, i.e. cell by
-//          cell) are aggregated into ONE returning global atomic per run.  Cheapest while the runs are long: 39 us
-//          at 8 M particles on the freshly seeded lattice (8 per cell), but 162 us in the impact phase of C3, when the
-//          particle order has decayed and the cells are hit from many waves at once.
+// rank of each particle inside its cell.  Overwrites key[i] with ONE word per slot, (rank << cb) | cidx, where
+// cidx = slot(block)*64 + cell and cb = the bits cidx needs for THIS sort's number of active blocks (packed_cell_bits):
+// k_perm reads 4 bytes per slot instead of a cell index and a rank.  A rank that does not fit the remaining bits
+// (at C3: 11 bits = 2 047 particles in one cell) is stored as all-ones in the word and in full in rank[i] — a side
+// array nothing touches in an ordinary sort.
+// Two paths, chosen per sort from the statistics of the previous one (cnt->rank_mode, set by k_cell_table):
+//  mode 0  runs of equal cells in adjacent slots (the records lie in the order of the previous sort, i.e. cell by
+//          cell) are aggregated into ONE returning global atomic per run.  Cheapest while the runs are long (the
+//          freshly seeded lattice, 8 per cell), 4x slower in the impact phase of C3, when the order of the slots has
+//          decayed and the cells are hit from many waves at once.
 //  mode 1  a workgroup takes 1024 consecutive slots, counts them per cell in an LDS hash table (open addressing on
 //          cidx; nothing is assumed about which cells a batch holds), reserves each cell's range with ONE global
-//          atomic per distinct cell of the batch and hands the local ranks out from LDS: ~70 us whatever the order.
+//          atomic per distinct cell of the batch and hands the local ranks out from LDS: the same cost whatever the order.
 // Both count the runs they see (cnt->run_heads); more than one run per 3 slots selects mode 1 for the next sort.
-constexpr int RANK_PER_THREAD = 4, RANK_BATCH = 256 * RANK_PER_THREAD, RANK_TAB = 2048;
+// FOUR CONSECUTIVE slots per thread: the keys come in and the packed words go out as 16-byte vectors, the block-table
+// lookup is shared by a thread's slots when they lie in one block (they nearly always do), and a run of equal cells is
+// followed through a thread's registers before it crosses to the next lane — a quarter of the memory instructions of
+// one slot per lane (measured at C3, 8 M particles, one box: sort 0.081 -> 0.072 ms; wider batches per thread were
+// slower).  A wave owns a tile of 256 consecutive slots; element e = 4 lane + j.
+constexpr int RANK_BATCH = 1024, RANK_TAB_BITS = 11, RANK_TAB = 1 << RANK_TAB_BITS;  // 2 table entries per slot of a batch
 
-// cidx of slot i (INVALID: dead / out of range / block table overflow)
-__device__ __forceinline__ uint32_t rank_cidx(const Params &P, const uint32_t *__restrict__ key,
-                                              const uint32_t *__restrict__ bits, const uint32_t *__restrict__ wprefix,
-                                              uint32_t i, uint32_t n) {
-  if (i >= n) return INVALID;
-  const uint32_t k = key[i];
-  if (k == INVALID) return INVALID;
-  const uint32_t slot = block_slot(bits, wprefix, k >> 6);
-  return (slot < P.max_blocks) ? slot * BC + (k & 63u) : INVALID;
+// bits of the cell index in the packed word: n_active*64 < 2^cb strictly, so a valid word never equals INVALID
+__device__ __forceinline__ uint32_t packed_cell_bits(const Params &P, uint32_t n_active) {
+  if (P.ablate & 16) return 29u;  // TEST KNOB: a 3-bit rank field, so that small scenes exercise the side array
+  const uint32_t cb = 32u - (uint32_t)__clz((int)(n_active * (uint32_t)BC));
+  return cb < 6u ? 6u : cb;
 }
-// the run of equal values around this lane: [start, end) in lane numbers; heads = mask of the first lanes of all runs
-__device__ __forceinline__ void lane_run(uint32_t c, uint32_t lane, int &start, int &end, unsigned long long &heads) {
-  const uint32_t prev = __shfl_up(c, 1);
-  heads = __ballot((lane == 0) || (c != prev));
-  const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-  start = 63 - __clzll(heads & le);
-  const unsigned long long above = heads & ~le;
-  end = above ? (__ffsll((long long)above) - 1) : 64;
+struct RunInfo {
+  bool head[4];   // element j starts a run of equal cidx inside the wave's tile
+  int jh[4];      // local index of the head of element j's run, -1: the run came in from an earlier lane
+  int len[4];     // run length (heads only)
+  int s_in;       // tile position of the head of the incoming run (valid when some jh < 0)
+  uint32_t nheads;
+};
+__device__ __forceinline__ RunInfo tile_runs(const uint32_t c[4], int lane) {
+  RunInfo R;
+  const uint32_t prevc = __shfl_up(c[3], 1);
+  R.head[0] = (lane == 0) || (c[0] != prevc);
+#pragma unroll
+  for (int j = 1; j < 4; j++) R.head[j] = c[j] != c[j - 1];
+  int hf = -1, hl = -1;
+#pragma unroll
+  for (int j = 3; j >= 0; j--) if (R.head[j]) hf = j;
+#pragma unroll
+  for (int j = 0; j < 4; j++) if (R.head[j]) hl = j;
+  // last head at or before each lane (inclusive prefix max), first head after it (exclusive suffix min)
+  int pmax = hl >= 0 ? 4 * lane + hl : -1;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int u = __shfl_up(pmax, off);
+    if (lane >= off) pmax = max(pmax, u);
+  }
+  int s_in = __shfl_up(pmax, 1);
+  if (lane == 0) s_in = 0;  // (unused: lane 0 starts with a head)
+  int smin = hf >= 0 ? 4 * lane + hf : 256;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int u = __shfl_down(smin, off);
+    if (lane + off < 64) smin = min(smin, u);
+  }
+  int n_out = __shfl_down(smin, 1);
+  if (lane == 63) n_out = 256;
+  R.s_in = s_in;
+  int cur = -1;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (R.head[j]) cur = j;
+    R.jh[j] = cur;
+  }
+  int nxt = n_out - 4 * lane;  // local index (possibly >= 4) of the next head after element j
+#pragma unroll
+  for (int j = 3; j >= 0; j--) {
+    R.len[j] = nxt - j;
+    if (R.head[j]) nxt = j;
+  }
+  R.nheads = (uint32_t)R.head[0] + (uint32_t)R.head[1] + (uint32_t)R.head[2] + (uint32_t)R.head[3];
+  return R;
+}
+// value of each element's run head: v[j] for runs that start in this thread, the last head's value of the lane the
+// incoming run started in otherwise
+__device__ __forceinline__ void run_broadcast(const RunInfo &R, const uint32_t v[4], uint32_t out[4]) {
+  uint32_t lastv = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) if (R.head[j]) lastv = v[j];
+  const uint32_t vin = __shfl(lastv, R.s_in >> 2);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    uint32_t x = vin;
+#pragma unroll
+    for (int h = 0; h < 4; h++) if (R.jh[j] == h) x = v[h];
+    out[j] = x;
+  }
+}
+__device__ __forceinline__ uint32_t run_offset(const RunInfo &R, int lane, int j) {
+  return (uint32_t)(R.jh[j] >= 0 ? j - R.jh[j] : 4 * lane + j - R.s_in);
 }
 
 __global__ __launch_bounds__(256) void k_rank(Params P, uint32_t *__restrict__ key, uint32_t *__restrict__ rank,
-                                              uint32_t *__restrict__ cell_cnt, const uint32_t *__restrict__ bits,
-                                              const uint32_t *__restrict__ wprefix, Counters *cnt) {
-  __shared__ uint32_t tkey[RANK_TAB], tcnt[RANK_TAB];  // mode 1.  tcnt: particles of the batch in that cell, then their global base
+                                               uint32_t *__restrict__ cell_cnt, const uint32_t *__restrict__ bits,
+                                               const uint32_t *__restrict__ wprefix, Counters *cnt) {
+  __shared__ uint32_t tkey[RANK_TAB], tcnt[RANK_TAB];
   __shared__ uint32_t s_heads;
   const uint32_t n = P.n_slots;
-  const uint32_t lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t mode = cnt->rank_mode;  // uniform over the grid
   if (threadIdx.x == 0) s_heads = 0u;
-  uint32_t my_heads = 0u;  // lane 0 of each wave counts its wave's runs
-  if (mode == 0u) {
-    // a workgroup takes batches of RANK_BATCH consecutive slots, RANK_PER_THREAD per thread: the keys, the block-table
-    // lookups and the returning atomics of a thread's slots are issued back to back, so their round trips overlap
-    // (C3, 8 M particles: sort 0.092 -> 0.087 ms on the lattice against one dependent chain per slot; A/B on one box)
-    const uint32_t nbatch = (n + RANK_BATCH - 1) / RANK_BATCH;
-    for (uint32_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
-      uint32_t cidx[RANK_PER_THREAD], base[RANK_PER_THREAD];
-      int start[RANK_PER_THREAD];
+  uint32_t my_heads = 0u;
+  const uint32_t cb = packed_cell_bits(P, min(cnt->n_active, P.max_blocks)), rmax = (1u << (32u - cb)) - 1u;
+  const uint32_t nbatch = (n + RANK_BATCH - 1) / RANK_BATCH;
+  for (uint32_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
+    const uint32_t i0 = b * RANK_BATCH + (uint32_t)wave * 256u + 4u * (uint32_t)lane;
+    uint32_t k[4] = {INVALID, INVALID, INVALID, INVALID};
+    if (i0 + 4u <= n) {
+      const uint4 kk = *reinterpret_cast<const uint4 *>(key + i0);
+      k[0] = kk.x; k[1] = kk.y; k[2] = kk.z; k[3] = kk.w;
+    } else {
 #pragma unroll
-      for (int u = 0; u < RANK_PER_THREAD; u++) cidx[u] = rank_cidx(P, key, bits, wprefix, b * RANK_BATCH + u * 256 + threadIdx.x, n);
+      for (int j = 0; j < 4; j++) if (i0 + j < n) k[j] = key[i0 + j];
+    }
+    uint32_t c[4];
+    uint32_t last_blk = INVALID, last_slot = INVALID;
 #pragma unroll
-      for (int u = 0; u < RANK_PER_THREAD; u++) {
-        int end;
-        unsigned long long H;
-        lane_run(cidx[u], lane, start[u], end, H);
-        my_heads += (uint32_t)__popcll(H);
-        base[u] = 0;
-        if ((int)lane == start[u] && cidx[u] != INVALID) base[u] = atomicAdd(&cell_cnt[cidx[u]], (uint32_t)(end - start[u]));
-      }
-#pragma unroll
-      for (int u = 0; u < RANK_PER_THREAD; u++) {
-        const uint32_t i = b * RANK_BATCH + u * 256 + threadIdx.x;
-        const uint32_t r = __shfl(base[u], start[u]) + (lane - (uint32_t)start[u]);
-        if (i < n) {
-          key[i] = cidx[u];
-          rank[i] = r;
-        }
+    for (int j = 0; j < 4; j++) {
+      c[j] = INVALID;
+      if (k[j] != INVALID) {
+        const uint32_t blk = k[j] >> 6;
+        if (blk != last_blk) { last_slot = block_slot(bits, wprefix, blk); last_blk = blk; }
+        if (last_slot < P.max_blocks) c[j] = last_slot * BC + (k[j] & 63u);
       }
     }
-    __syncthreads();
-  } else {
-    const uint32_t nbatch = (n + RANK_BATCH - 1) / RANK_BATCH;
-    for (uint32_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
+    const RunInfo R = tile_runs(c, lane);
+    my_heads += R.nheads;
+    uint32_t r[4];
+    if (mode == 0u) {
+      uint32_t base[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (R.head[j] && c[j] != INVALID) base[j] = atomicAdd(&cell_cnt[c[j]], (uint32_t)R.len[j]);
+      uint32_t bb[4];
+      run_broadcast(R, base, bb);
+#pragma unroll
+      for (int j = 0; j < 4; j++) r[j] = bb[j] + run_offset(R, lane, j);
+    } else {
       for (int t = threadIdx.x; t < RANK_TAB; t += 256) { tkey[t] = INVALID; tcnt[t] = 0u; }
       __syncthreads();
-      uint32_t cidx[RANK_PER_THREAD], ent[RANK_PER_THREAD], loc[RANK_PER_THREAD];
+      uint32_t hh[4] = {0u, 0u, 0u, 0u}, ff[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int u = 0; u < RANK_PER_THREAD; u++) {
-        const uint32_t i = b * RANK_BATCH + u * 256 + threadIdx.x;
-        const uint32_t c = rank_cidx(P, key, bits, wprefix, i, n);
-        cidx[u] = c;
-        int start, end;
-        unsigned long long H;
-        lane_run(c, lane, start, end, H);  // a run enters the table once, with its length
-        my_heads += (uint32_t)__popcll(H);
-        uint32_t h = 0u, first = 0u;
-        if ((int)lane == start && c != INVALID) {
-          h = (c * 2654435761u) >> 21;  // 11 bits: RANK_TAB entries, at most half of them used
+      for (int j = 0; j < 4; j++) {
+        if (R.head[j] && c[j] != INVALID) {
+          uint32_t h = (c[j] * 2654435761u) >> (32 - RANK_TAB_BITS);
           for (;;) {
-            const uint32_t seen = atomicCAS(&tkey[h], INVALID, c);
-            if (seen == INVALID || seen == c) break;
+            const uint32_t seen = atomicCAS(&tkey[h], INVALID, c[j]);
+            if (seen == INVALID || seen == c[j]) break;
             h = (h + 1u) & (RANK_TAB - 1);
           }
-          first = atomicAdd(&tcnt[h], (uint32_t)(end - start));
+          hh[j] = h;
+          ff[j] = atomicAdd(&tcnt[h], (uint32_t)R.len[j]);
         }
-        ent[u] = __shfl(h, start);
-        loc[u] = __shfl(first, start) + (lane - (uint32_t)start);
       }
+      uint32_t ent[4], loc[4];
+      run_broadcast(R, hh, ent);
+      run_broadcast(R, ff, loc);
       __syncthreads();
       for (int t = threadIdx.x; t < RANK_TAB; t += 256)
         if (tkey[t] != INVALID) tcnt[t] = atomicAdd(&cell_cnt[tkey[t]], tcnt[t]);
       __syncthreads();
 #pragma unroll
-      for (int u = 0; u < RANK_PER_THREAD; u++) {
-        const uint32_t i = b * RANK_BATCH + u * 256 + threadIdx.x;
-        if (i < n) {
-          key[i] = cidx[u];
-          rank[i] = (cidx[u] != INVALID) ? tcnt[ent[u]] + loc[u] : 0u;
-        }
-      }
+      for (int j = 0; j < 4; j++) r[j] = (c[j] != INVALID) ? tcnt[ent[j]] + loc[j] + run_offset(R, lane, j) : 0u;
       __syncthreads();
     }
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      w[j] = INVALID;
+      if (c[j] != INVALID) {
+        if (r[j] >= rmax) { rank[i0 + j] = r[j]; r[j] = rmax; }  // (crowded cell: the full rank goes to the side array)
+        w[j] = (r[j] << cb) | c[j];
+      }
+    }
+    if (i0 + 4u <= n) {
+      *reinterpret_cast<uint4 *>(key + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (i0 + j < n) key[i0 + j] = w[j];
+    }
   }
-  // statistics from every 16th workgroup only (scaled): thousands of atomics on ONE address serialise at ~13 ns each
+  __syncthreads();
   if ((blockIdx.x & 15u) == 0u) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) my_heads += __shfl_xor(my_heads, off);
     if (lane == 0 && my_heads) atomicAdd(&s_heads, my_heads);
     __syncthreads();
     if (threadIdx.x == 0 && s_heads) atomicAdd(&cnt->run_heads, s_heads * 16u);
@@ -267,22 +341,20 @@ template <int CT_BLOCKS>  // blocks per chunk: 64 for large problems, 16 when th
 __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uint32_t *__restrict__ cell_cnt,
                                                     uint32_t *__restrict__ act_start,
                                                     uint32_t *__restrict__ cell_start,
-                                                    unsigned long long *__restrict__ slots, uint32_t *ticket,
-                                                    uint32_t epoch) {
+                                                    unsigned long long *__restrict__ slots, uint32_t epoch) {
   __shared__ uint32_t lds[8];
-  __shared__ uint32_t s_chunk;
   constexpr int CT_BPW = CT_BLOCKS / 4;  // blocks per wave
   __shared__ uint32_t blk_tot[CT_BLOCKS];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    ticket[0] = 0;  // k_block_table's counter (it is not running now)
     // k_rank of this sort is complete: its run statistics choose the path of the next one (see k_rank)
     cnt->rank_mode = (cnt->run_heads * 3u > P.n_slots) ? 1u : 0u;
     cnt->run_heads = 0u;
   }
   const uint32_t na = min(cnt->n_active, P.max_blocks);
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t round = 0;
   while (true) {
-    const uint32_t chunk = take_ticket(ticket + 1, &s_chunk);
+    const uint32_t chunk = next_chunk(round);
     const uint32_t a0 = chunk * CT_BLOCKS;
     if (a0 >= na && !(na == 0 && chunk == 0)) return;
     uint32_t excl[CT_BPW];  // exclusive in-block prefix of this lane's cell, for the wave's blocks
@@ -330,14 +402,21 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
   }
 }
 
-// sorted position -> particle slot (the reference's sorted `particles` index vector, src/mpm.cpp:800-807)
-__global__ __launch_bounds__(256) void k_perm(Params P, const uint32_t *__restrict__ key,
-                                              const uint32_t *__restrict__ rank,
+// sorted position -> particle slot (the reference's sorted `particles` index vector, src/mpm.cpp:800-807) from the
+// packed words of k_rank.  (Four slots per thread as in k_rank were measured slower here: the scattered 4-byte stores
+// dominate, and one slot per lane keeps them coalesced.)
+__global__ __launch_bounds__(256) void k_perm(Params P, const Counters *__restrict__ cnt,
+                                              const uint32_t *__restrict__ key, const uint32_t *__restrict__ rank,
                                               const uint32_t *__restrict__ cell_start, uint32_t *__restrict__ perm) {
   const uint32_t n = P.n_slots;
+  const uint32_t cb = packed_cell_bits(P, min(cnt->n_active, P.max_blocks)), rmax = (1u << (32u - cb)) - 1u;
+  const uint32_t cmask = (1u << cb) - 1u;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t c = key[i];
-    if (c != INVALID) perm[cell_start[c] + rank[i]] = i;
+    const uint32_t w = key[i];
+    if (w == INVALID) continue;
+    uint32_t r = w >> cb;
+    if (r == rmax) r = rank[i];
+    perm[cell_start[w & cmask] + r] = i;
   }
 }
 

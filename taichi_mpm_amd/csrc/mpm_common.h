@@ -78,7 +78,7 @@ struct Params {
   int particle_collision;  // particle_collision_resolution after G2P (src/mpm.cpp:566-569)
   int clamp_pos;     // generic transfer path (optimized = false): positions clamped into [0, res - eps] (src/transfer.cpp:668-670)
   int ablate;        // PROFILING ONLY (env MPMHIP_ABLATE, results invalid): 1 no G2P stores, 2 no constitutive
-                     // update, 4 no 27-tap gather
+                     // update, 4 no 27-tap gather; 16 (tests, results valid) 3-bit rank field in k_rank's packed words
 };
 
 // multi-GPU tiling (include/mpmhip.h, "Multi-GPU tiling"): partition of the cell space into bricks + halo boxes

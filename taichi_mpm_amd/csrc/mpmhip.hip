@@ -13,7 +13,8 @@
 //          k_block_table  byte flags -> active-block bitmap + popcount prefix (dense slot of every active block)
 //                         + active-block list, one single-pass chained-scan launch
 //          k_rank         rank of each particle in its cell (one global atomic per run of equal keys, or — when the
-//                         particle order has decayed — an LDS hash per 1024 slots and one atomic per distinct cell)
+//                         particle order has decayed — an LDS hash per 1024 slots and one atomic per distinct cell),
+//                         four consecutive slots per thread, one packed (rank, cell) word per slot
 //          k_cell_table   per-cell counts -> start of every cell / block in the sorted index (single pass)
 //          k_perm         sorted position -> particle slot
 //   P2G    k_p2g   one wavefront per active 4x4x4-cell block, ONE LANE PER CELL: register accumulation of the
@@ -98,9 +99,10 @@ struct mpmhip_ctx {
   uint32_t NB = 0;
   uint8_t *blk_flag = nullptr;
   uint32_t *bits = nullptr, *wprefix = nullptr, *act_blk = nullptr, *act_start = nullptr;
-  uint32_t *cell_cnt = nullptr, *cell_start = nullptr, *fat_slot = nullptr, *ticket = nullptr;
+  uint32_t *cell_cnt = nullptr, *cell_start = nullptr, *fat_slot = nullptr;
   unsigned long long *scan_slots = nullptr;  // [256] k_block_table + [ct_grid] k_cell_table: {epoch, chunk sum}
   uint32_t sort_epoch = 0, bt_slots = 0;
+  uint32_t scan_grid = 256;  // workgroups of the single-pass scan kernels: a quarter of what the device keeps resident
   float4 *tiles = nullptr, *gridv = nullptr, *dense = nullptr;
   Counters *cnt = nullptr;
   std::vector<GroupParams> groups;
@@ -396,7 +398,6 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   c->bt_slots = (P.nbw + 255) / 256;
   const size_t n_slots64 = c->bt_slots + ((size_t)mb + 15) / 16 + 1;  // k_cell_table chunks are >= 16 blocks
   A(dmalloc(&c->scan_slots, n_slots64));
-  A(dmalloc(&c->ticket, 2));
   A(dmalloc(&c->tiles, (size_t)mb * TN));
   A(dmalloc(&c->gridv, (size_t)mb * 8 * BC));
   A(dmalloc(&c->cnt, 1));
@@ -416,9 +417,18 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(hipMemset(c->cnt, 0, sizeof(Counters)));
   A(hipMemcpy(c->d_LS, &c->LS, sizeof c->LS, hipMemcpyHostToDevice));
   A(hipMemset(c->scan_slots, 0, sizeof(unsigned long long) * n_slots64));  // epoch 0 is never used
-  A(hipMemset(c->ticket, 0, 2 * sizeof(uint32_t)));
   A(hipMemset(c->fat_slot, 0, sizeof(uint32_t) * (size_t)c->NB));
   A(hipMemset(c->rb, 0, sizeof(float) * (size_t)c->cap * BW));
+  {  // the single-pass scans spin on their predecessors: their grids must fit on the device all at once (k_sort.h)
+    int cus = 0, per_cu = 0, lowest = 1 << 20;
+    A(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    const void *scans[3] = {(const void *)k_block_table, (const void *)k_cell_table<16>, (const void *)k_cell_table<64>};
+    for (const void *k : scans) {
+      A(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, 0));
+      lowest = std::min(lowest, per_cu);
+    }
+    c->scan_grid = (uint32_t)std::max(1, cus * lowest / 4);
+  }
   A(hipDeviceSynchronize());
   if (e != hipSuccess) { fail(c, MPMHIP_EHIP, "device init failed: %s", hipGetErrorString(e)); return bail(MPMHIP_EHIP); }
   *out = c;
@@ -434,7 +444,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   hipFree(c->rg); hipFree(c->rp); hipFree(c->rb); hipFree(c->rg2); hipFree(c->rp2); hipFree(c->rb2);
   hipFree(c->key); hipFree(c->rank); hipFree(c->perm); hipFree(c->blk_flag); hipFree(c->bits); hipFree(c->wprefix);
   hipFree(c->fat_slot); hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->cell_cnt);
-  hipFree(c->cell_start); hipFree(c->scan_slots); hipFree(c->ticket); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
+  hipFree(c->cell_start); hipFree(c->scan_slots); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
   hipFree(c->async.d_tab); hipFree(c->async.d_blk_of); hipFree(c->async.d_blk_limits); hipFree(c->async.d_particle_limits);
   hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_LS); hipFree(c->d_counts); hipFree(c->d_bounds); if (c->h_pinned) hipHostFree(c->h_pinned); hipFree(c->d_energy);
   { auto &R = c->rigid; hipFree(R.d_rb); hipFree(R.d_smp); hipFree(R.d_elems); hipFree(R.cdf.slot); hipFree(R.cdf.page_key); hipFree(R.cdf.mind);
@@ -776,16 +786,17 @@ static int do_sort(mpmhip_ctx *c) {
   const bool small = c->n_slots < (2 << 20);  // few blocks: finer chunks in k_cell_table
   const uint32_t bt_chunks = (P.nbw + 255) / 256, ct_chunks = (P.max_blocks + (small ? 16 : 64) - 1) / (small ? 16 : 64);
   const uint32_t epoch = ++c->sort_epoch;
-  hipLaunchKernelGGL(k_block_table, dim3(std::min(bt_chunks, 512u)), dim3(256), 0, st, P, c->blk_flag, c->bits,
-                     c->wprefix, c->act_blk, c->cnt, c->scan_slots, c->ticket, epoch);
+  // (single-pass scans: never more workgroups than are resident at once, see k_sort.h)
+  hipLaunchKernelGGL(k_block_table, dim3(std::min(bt_chunks, c->scan_grid)), dim3(256), 0, st, P, c->blk_flag, c->bits,
+                     c->wprefix, c->act_blk, c->cnt, c->scan_slots, epoch);
   const uint32_t rank_wgs = std::min<uint32_t>((P.n_slots + RANK_BATCH - 1) / RANK_BATCH, 8192u);
   hipLaunchKernelGGL(k_rank, dim3(std::max(rank_wgs, 1u)), dim3(256), 0, st, P, c->key, c->rank, c->cell_cnt, c->bits, c->wprefix,
                      c->cnt);
-  hipLaunchKernelGGL(small ? k_cell_table<16> : k_cell_table<64>, dim3(std::min(ct_chunks, 512u)), dim3(256), 0, st, P,
-                     c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots, c->ticket, epoch);
-  hipLaunchKernelGGL(k_perm, dim3(pg), dim3(256), 0, st, P, c->key, c->rank, c->cell_start, c->perm);
+  hipLaunchKernelGGL(small ? k_cell_table<16> : k_cell_table<64>, dim3(std::min(ct_chunks, c->scan_grid)), dim3(256), 0, st, P,
+                     c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots, epoch);
+  hipLaunchKernelGGL(k_perm, dim3(pg), dim3(256), 0, st, P, (const Counters *)c->cnt, c->key, c->rank, c->cell_start, c->perm);
   c->sorted = true;
-  c->keys_valid = false;  // key[] now holds cell indices
+  c->keys_valid = false;  // key[] now holds k_rank's packed (rank, cell index) words
   int rc = launch_check(c, "sort");
   if (rc) return rc;
   // sort_allocator (src/mpm.cpp:752-768, every reorder_interval substeps :811-813): needed here only for records that
@@ -829,7 +840,9 @@ static int do_p2g(mpmhip_ctx *c, int phase = 0) {
     c->affine_valid = true;
   }
   // one wavefront per block (all 27 nodes, all particles) measured fastest at 256^3 / 8 M: 0.187 ms against
-  // 0.237 (two waves splitting the nodes) and 0.225 (two waves splitting the particles); knob: 10*NS + PS
+  // 0.237 (two waves splitting the nodes) and 0.225 (two waves splitting the particles); knob: 10*NS + PS.  Splitting
+  // the particles does not help small problems either (128^3 / 1 M, where only 2 448 waves exist: 34 us with one wave per
+  // block, 37 with two, 48 with four)
   auto kern = k_p2g<1, 1, 2>;
   int nt = 64;
   switch (c->p2g_split) {

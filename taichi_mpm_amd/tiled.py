@@ -556,7 +556,7 @@ def build_rank_sim(tm, cfg, part, rank, device, extra_cfg=None):
         offset += len(x)
     n_mine = sum(len(x) for x in mine)
     sim = tm.create_simulation3("mpm").initialize(dict(
-        res=(res,) * 3, delta_x=dx, base_delta_t=1e-4, gravity=(0, -10, 0), device=device,
+        res=(res,) * 3, delta_x=dx, base_delta_t=cfg.get("dt", 1e-4), gravity=(0, -10, 0), device=device,
         max_particles=int(n_mine * 1.5) + (1 << 16), **(extra_cfg or {})))
     sim.set_levelset(tm.mpm.LevelSet(friction=-1.0).add_plane((0, 1, 0), d=-0.1))
     for g, x in zip(groups, mine):

@@ -157,6 +157,33 @@ def test_sort_is_a_permutation_in_key_order_and_drops_dead(tm, orc):
     sim.close()
 
 
+def test_crowded_cells_take_the_side_array_of_the_sort(tm, orc, monkeypatch):
+    """k_rank packs (rank, cell) into one word per slot and spills ranks that do not fit into a side array; with the
+    test knob (a 3-bit rank field) every cell of this scene spills — the substep must come out exactly as without it,
+    in both orders of the slots (long runs -> one atomic per run; shuffled -> the LDS hash path after the first sort)"""
+    x = lattice_cube(RES, 9, 15, DX, jitter=0.3, seed=21)
+    x = np.concatenate([x, x + np.float32(1e-3), x - np.float32(1e-3)])  # 24 particles per cell
+    rng = np.random.default_rng(22)
+    out = {}
+    for order in ("runs", "shuffled"):
+        xs = x if order == "runs" else x[rng.permutation(len(x))]
+        for knob in ("0", "16"):
+            monkeypatch.setenv("MPMHIP_ABLATE", knob)
+            s = make_state(xs, "jelly", DX, perturb_F=0.02, seed=23)
+            sim = make_sim(tm, s)
+            for _ in range(3):
+                sim.substep()
+            got = sim.get_particles()
+            assert len(got["id"]) == len(xs)
+            out[order, knob] = got
+            sim.close()
+        for f in ("x", "v", "F"):
+            a, b = out[order, "0"][f], out[order, "16"][f]
+            # (same sums in a different order inside a cell: ranks are handed out by atomics)
+            assert np.allclose(a, b, rtol=0, atol=2e-6 * max(1.0, float(np.abs(a).max()))), (order, f)
+    monkeypatch.delenv("MPMHIP_ABLATE")
+
+
 # ------------------------------------------------------------------------------------------ phases
 @pytest.mark.parametrize("mat", MATS)
 def test_p2g_and_grid_update_match_oracle(tm, orc, mat):
