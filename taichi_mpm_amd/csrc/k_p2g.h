@@ -15,24 +15,26 @@ namespace mpm {
 // written out whole; conflicts between blocks are resolved by k_grid.  p2g_cell<N0,N1> handles stencil nodes
 // N0..N1-1 of the particles [p0,p1) of the lane's cell, so a block can be one wave (default) or several waves
 // splitting the nodes and/or the particles (k_p2g<NS,PS>).
-template <int N0, int N1>
+template <int N0, int N1, class AfterParticles>
 __device__ __forceinline__ void p2g_cell(const Params &P, const float4 *__restrict__ rp,
                                          const uint32_t *__restrict__ perm,
-                                         const GroupParams *__restrict__ groups, uint32_t p0, uint32_t p1, float ox,
-                                         float oy, float oz, int nbase, float4 *tile) {
+                                         const GroupParams *__restrict__ groups, uint32_t p0, uint32_t p1, uint32_t i0,
+                                         uint32_t i1, float ox, float oy, float oz, int nbase, float4 *tile,
+                                         AfterParticles &&after_particles) {
   constexpr int NN = N1 - N0;
   float acc[NN][4];
 #pragma unroll
   for (int n = 0; n < NN; n++) { acc[n][0] = 0.0f; acc[n][1] = 0.0f; acc[n][2] = 0.0f; acc[n][3] = 0.0f; }
   // software pipeline: the records of the next TWO particles and the index of the third are in flight while
-  // one particle is computed (one particle's arithmetic is shorter than the loaded HBM latency)
+  // one particle is computed (one particle's arithmetic is shorter than the loaded HBM latency; a third record in
+  // flight was measured: no change)
   float4 n0, n1, n2, n3, m0, m1, m2, m3;
   uint32_t inext = 0;
-  if (p0 < p1) {
-    const size_t i = perm[p0];
+  if (p0 < p1) {  // (i0 = perm[p0], i1 = perm[p0 + 1]: loaded by the caller while the previous block was merged)
+    const size_t i = i0;
     n0 = rp[i * 4 + 0]; n1 = rp[i * 4 + 1]; n2 = rp[i * 4 + 2]; n3 = rp[i * 4 + 3];
     if (p0 + 1 < p1) {
-      const size_t j = perm[p0 + 1];
+      const size_t j = i1;
       m0 = rp[j * 4 + 0]; m1 = rp[j * 4 + 1]; m2 = rp[j * 4 + 2]; m3 = rp[j * 4 + 3];
       if (p0 + 2 < p1) inext = perm[p0 + 2];
     }
@@ -57,8 +59,40 @@ __device__ __forceinline__ void p2g_cell(const Params &P, const float4 *__restri
     const float A00 = q1.z, A01 = q1.w, A02 = q2.x, A10 = q2.y, A11 = q2.z, A12 = q2.w, A20 = q3.x, A21 = q3.y,
                 A22 = q3.z;
     const float mv0 = mass * v0, mv1 = mass * v1, mv2 = mass * v2;
+    if constexpr (N0 == 0 && N1 == 27) {
+      // contrib(i, j, k) = affine (r - (i, j, k)) + mass v is affine in the node offset: start from the node (0, 0, 0)
+      // and step by one column of the affine matrix per node — (x, y) and (z, m) as packed fp32 pairs, the mass riding
+      // along with a zero step: 2 packed adds + 2 packed multiply-adds per node instead of 9 + 4 scalar ones (256 -> 212
+      // vector instructions per particle; the kernel is latency-bound, so only 0.171 -> 0.168 ms at C3, 0.206 -> 0.201 after
+      // impact).  Same terms as :535-541, the offsets subtracted column by column instead of before the product.
+      const f2 a0xy = {A00, A10}, a0zw = {A20, 0.0f}, a1xy = {A01, A11}, a1zw = {A21, 0.0f}, a2xy = {A02, A12},
+               a2zw = {A22, 0.0f};
+      f2 cixy = {fmaf(A02, r2, fmaf(A01, r1, fmaf(A00, r0, mv0))), fmaf(A12, r2, fmaf(A11, r1, fmaf(A10, r0, mv1)))};
+      f2 cizw = {fmaf(A22, r2, fmaf(A21, r1, fmaf(A20, r0, mv2))), mass};
 #pragma unroll
-    for (int n = N0; n < N1; n++) {
+      for (int i3 = 0; i3 < 3; i3++) {
+        f2 cjxy = cixy, cjzw = cizw;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const float wij = w0[i3] * w1[j];
+          f2 ckxy = cjxy, ckzw = cjzw;
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const int n = (i3 * 3 + j) * 3 + k;
+            const f2 w = splat2(wij * w2[k]);
+            f2 axy = {acc[n][0], acc[n][1]}, azw = {acc[n][2], acc[n][3]};
+            axy = fma2(w, ckxy, axy); azw = fma2(w, ckzw, azw);
+            acc[n][0] = axy.x; acc[n][1] = axy.y; acc[n][2] = azw.x; acc[n][3] = azw.y;
+            if (k < 2) { ckxy -= a2xy; ckzw -= a2zw; }
+          }
+          if (j < 2) { cjxy -= a1xy; cjzw -= a1zw; }
+        }
+        if (i3 < 2) { cixy -= a0xy; cizw -= a0zw; }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int n = N0; n < N1; n++) {  // (node-split variants: every node from scratch)
       const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
       const float d0 = r0 - (float)i3, d1 = r1 - (float)j, d2 = r2 - (float)k;
       const float w = (w0[i3] * w1[j]) * w2[k];
@@ -72,6 +106,7 @@ __device__ __forceinline__ void p2g_cell(const Params &P, const float4 *__restri
       acc[n - N0][3] = fmaf(w, mass, acc[n - N0][3]);
     }
   }
+  after_particles();  // (the caller's look-ahead loads for the next block: in flight during the merge and the write-out)
   // Merge the per-cell sums into this wave's tile.  The tile belongs to this wavefront alone, and within one
   // stencil-offset step all 64 lanes address distinct nodes (same offset, different cells), so a plain float4
   // read-modify-write is race-free as long as the steps stay in program order: LDS operations of one wave
@@ -110,22 +145,49 @@ __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const floa
   const int npart = wave % NS, ppart = wave / NS;
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
   const int nbase = (cx * TS + cy) * TS + cz;
+  // The start of a block is a chain of dependent loads (block key, cell table, first indices, first records).  The
+  // first three links are taken one block ahead: key and cell range of the NEXT block are requested before this block's
+  // particle loop, its first two indices before this block's tile is merged and written out — a block then starts with
+  // its record loads.
+  struct Ahead { uint32_t key, c0, c1, p0, p1, i0, i1; };
+  auto range_of = [&](Ahead &h) {
+    const uint32_t n = h.c1 - h.c0;
+    h.p0 = h.c0 + (n * ppart + PS - 1) / PS;
+    h.p1 = h.c0 + (n * (ppart + 1) + PS - 1) / PS;
+  };
+  auto load_table = [&](uint32_t a, Ahead &h) {
+    h.key = 0; h.c0 = 0; h.c1 = 0;
+    if (a < na) { h.key = act_blk[a]; h.c0 = cell_start[a * BC + lane]; h.c1 = cell_start[a * BC + lane + 1]; }
+  };
+  auto load_indices = [&](Ahead &h) {
+    range_of(h);
+    h.i0 = 0; h.i1 = 0;
+    if (h.p0 < h.p1) h.i0 = perm[h.p0];
+    if (h.p0 + 1 < h.p1) h.i1 = perm[h.p0 + 1];
+  };
+  Ahead cur, nxt;
+  load_table(blockIdx.x, cur);
+  load_indices(cur);
   for (uint32_t a = blockIdx.x; a < na; a += gridDim.x) {
+    load_table(a + gridDim.x, nxt);
     int bx, by, bz;
-    demorton3(act_blk[a], bx, by, bz);
-    if (!in_phase(T, phase, bx * BS, by * BS, bz * BS, TS)) continue;  // workgroup-uniform
-    if constexpr (RIGID) { if (blk_rigid[a]) continue; }  // near a rigid body: k_p2g_rigid takes the block (CPIC colour test)
+    demorton3(cur.key, bx, by, bz);
+    bool mine = in_phase(T, phase, bx * BS, by * BS, bz * BS, TS);  // workgroup-uniform
+    if constexpr (RIGID) { if (blk_rigid[a]) mine = false; }  // near a rigid body: k_p2g_rigid takes the block (CPIC colour test)
+    if (!mine) {
+      load_indices(nxt);
+      cur = nxt;
+      continue;
+    }
     for (int t = threadIdx.x; t < NW * TN; t += NT) (&tile[0][0])[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();
     const float ox = (float)(bx * BS + cx), oy = (float)(by * BS + cy), oz = (float)(bz * BS + cz);
-    const uint32_t c0 = cell_start[a * BC + lane], c1 = cell_start[a * BC + lane + 1];
-    const uint32_t n = c1 - c0;
-    const uint32_t p0 = c0 + (n * ppart + PS - 1) / PS, p1 = c0 + (n * (ppart + 1) + PS - 1) / PS;
+    auto ahead = [&]() { load_indices(nxt); };
     if constexpr (NS == 1) {
-      p2g_cell<0, 27>(P, rp, perm, groups, p0, p1, ox, oy, oz, nbase, tile[wave]);
+      p2g_cell<0, 27>(P, rp, perm, groups, cur.p0, cur.p1, cur.i0, cur.i1, ox, oy, oz, nbase, tile[wave], ahead);
     } else {
-      if (npart == 0) p2g_cell<0, 14>(P, rp, perm, groups, p0, p1, ox, oy, oz, nbase, tile[wave]);
-      else p2g_cell<14, 27>(P, rp, perm, groups, p0, p1, ox, oy, oz, nbase, tile[wave]);
+      if (npart == 0) p2g_cell<0, 14>(P, rp, perm, groups, cur.p0, cur.p1, cur.i0, cur.i1, ox, oy, oz, nbase, tile[wave], ahead);
+      else p2g_cell<14, 27>(P, rp, perm, groups, cur.p0, cur.p1, cur.i0, cur.i1, ox, oy, oz, nbase, tile[wave], ahead);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < TN; t += NT) {
@@ -138,8 +200,8 @@ __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const floa
       tiles[(size_t)a * TN + t] = u;
     }
     __syncthreads();
+    cur = nxt;
   }
 }
-
 
 }  // namespace mpm
