@@ -458,6 +458,34 @@ int64_t mpmhip_rigid_get_mesh(mpmhip_ctx *ctx, int32_t id, int64_t capacity_tria
 int mpmhip_rasterize_rigid_boundary(mpmhip_ctx *ctx);
 int mpmhip_gather_cdf(mpmhip_ctx *ctx);
 int mpmhip_advect_rigid_bodies(mpmhip_ctx *ctx);
+/* joints between rigid bodies — replaces general_action(action='add_articulation', type=..., obj0=..., obj1=...)
+ * (src/mpm.cpp:923-933; the Articulation classes of src/articulation.cpp; mpm.add_articulation(...) in
+ * scripts/mls-cpic/robot.py:103, water_wheel.py:81).  obj1 = 0 links to the background body.  The joint is set up on the
+ * bodies' poses at the time of the call; MPM::articulate (src/mpm.h:278-319) then runs inside every substep between the
+ * sort and rasterize_rigid_boundary: apply(dt), articulation_iterations (100) Gauss-Seidel sweeps of project(), penalize(dt). */
+enum {
+  MPMHIP_JOINT_ROTATION = 0,  /* 'rotation': both bodies share one angular velocity (their total angular momentum)        */
+  MPMHIP_JOINT_FROZEN = 1,    /* 'frozen': obj0 keeps angular velocity z and velocity x, y only                           */
+  MPMHIP_JOINT_DISTANCE = 2,  /* 'distance': anchors offset0 / offset1 (world-frame offsets from the centres) at target_distance */
+  MPMHIP_JOINT_AXIAL_ROTATION = 3, /* 'axial_rotation': hinge about `axis` through obj0's centre + offset0                */
+  MPMHIP_JOINT_MOTOR = 4,     /* 'motor': hinge + torque `power` about the axis                                           */
+  MPMHIP_JOINT_STEPPER = 5    /* 'stepper': hinge + relative angular velocity about the axis held at `angular_velocity`   */
+};
+typedef struct mpmhip_joint_config {
+  int32_t type, obj0, obj1;
+  int32_t has_offset1;          /* 'offset1' given (mandatory for a distance joint to the background body)        */
+  int32_t has_target_distance;  /* 'target_distance' given; otherwise the anchors' distance at the time of the call */
+  float offset0[3], offset1[3];
+  float target_distance;
+  float penalty;                /* < 0: the reference's default 1e3 */
+  float axis[3];
+  float axis_length;            /* < 0: the reference's default 0.1 */
+  float power, angular_velocity;
+} mpmhip_joint_config;
+int mpmhip_add_articulation(mpmhip_ctx *ctx, const mpmhip_joint_config *cfg);
+int32_t mpmhip_num_articulations(const mpmhip_ctx *ctx);
+int mpmhip_set_articulation_iterations(mpmhip_ctx *ctx, int32_t n); /* config key 'articulation_iterations', default 100 */
+int mpmhip_articulate(mpmhip_ctx *ctx); /* phase (parity tests): MPM::articulate(base_delta_t) */
 /* dense (res+1)^3 views of the grid's colored distance field: GridState::states (24 colour bits | body id + 1 << 24,
  * src/mpm_fwd.h:69-105) and GridState::distance */
 int mpmhip_download_cdf(mpmhip_ctx *ctx, uint32_t *states, float *distance);

@@ -26,7 +26,8 @@ TC_NAMESPACE_BEGIN
 
 // CPIC rigid coupling: src/rigid_transfer.cpp (colored distance field), src/mpm_rigid_body.cpp (bodies, boundary
 // particles, advection) and src/boundary_particle.cpp are compiled as separate objects like the other sources; the rigid
-// body itself is the shim's (taichi/dynamics/rigid_body_shim.h).  Joints (src/articulation.cpp) are outside this build.
+// body itself is the shim's (taichi/dynamics/rigid_body_shim.h).  Joints: src/articulation.cpp, compiled in place as well
+// (ref_general_action with action=add_articulation; phase 10 = MPM::articulate).
 namespace {
 
 thread_local std::string g_err;
@@ -205,6 +206,7 @@ int phase(Handle *h, int which, int optimized) {
     case 7: m.rasterize_rigid_boundary(); break;                               // src/rigid_transfer.cpp:17-115
     case 8: m.gather_cdf(); break;                                             // src/rigid_transfer.cpp:121-275
     case 9: m.advect_rigid_bodies(dt); break;                                  // src/mpm_rigid_body.cpp:255-286
+    case 10: m.articulate(dt); break;                                          // src/mpm.h:278-319 (joints: src/articulation.cpp)
     default: return -1;
   }
   return 0;
@@ -330,7 +332,7 @@ int ref_step(void *hh, float dt) {
   return guarded([&] { DISPATCH(h, h->m2->step(dt), h->m3->step(dt)); return 0; });
 }
 // which: 0 sort+populate, 1 P2G, 2 grid normalise + boundary, 3 G2P, 4 clear_boundary_particles, 5 particle collision,
-// 6 grid normalise only
+// 6 grid normalise only, 7 rasterize_rigid_boundary, 8 gather_cdf, 9 advect_rigid_bodies, 10 articulate
 int ref_phase(void *hh, int which, int optimized) {
   Handle *h = (Handle *)hh;
   return guarded([&] { return DISPATCH(h, phase<2>(h, which, optimized), phase<3>(h, which, optimized)); });

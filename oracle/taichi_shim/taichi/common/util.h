@@ -684,7 +684,15 @@ struct Mesh { std::vector<Vector3> vertices; void initialize(const Config &) { T
 struct AssetManager { template <typename T> static std::shared_ptr<T> get_asset(int) { TC_NOT_IMPLEMENTED } };
 struct RenderParticle {};
 namespace fmt {
-template <typename... A> inline std::string format(const std::string &f, A &&...) { return f; }
+inline void format_into(std::ostringstream &o, const std::string &f, size_t p) { o << f.substr(p); }
+template <typename T, typename... A> inline void format_into(std::ostringstream &o, const std::string &f, size_t p, const T &v, const A &...rest) {
+  const size_t q = f.find("{}", p);
+  if (q == std::string::npos) { o << f.substr(p); return; }
+  o << f.substr(p, q - p) << v;
+  format_into(o, f, q + 2, rest...);
+}
+// "{}" placeholders filled in order (src/articulation.cpp:109 builds the keys offset0 / offset1 this way)
+template <typename... A> inline std::string format(const std::string &f, const A &...a) { std::ostringstream o; format_into(o, f, 0, a...); return o.str(); }
 template <typename... A> inline void print(FILE *, const char *, A &&...) {}
 }  // namespace fmt
 

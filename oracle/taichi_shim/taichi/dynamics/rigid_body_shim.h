@@ -61,10 +61,12 @@ inline real inversed(real x) { return 1.0f / x; }
 using math::radians;
 template <int dim> inline VectorND<dim, real> radians(const VectorND<dim, real> &v) { return v * (real)(M_PI / 180.0); }
 
+// homogeneous transform: w = 1 a point, w = 0 a direction (src/articulation.cpp:111,189,261)
 template <int dim>
-inline VectorND<dim, real> transform(const MatrixND<dim + 1, real> &m, const VectorND<dim, real> &v) {
-  return VectorND<dim, real>(m * VectorND<dim + 1, real>(v, 1.0f));
+inline VectorND<dim, real> transform(const MatrixND<dim + 1, real> &m, const VectorND<dim, real> &v, real w = 1.0f) {
+  return VectorND<dim, real>(m * VectorND<dim + 1, real>(v, w));
 }
+template <int dim> inline MatrixND<dim, real> inverse(const MatrixND<dim, real> &m) { return inversed(m); }
 
 // ---------------------------------------------------------------------------------------------- mesh elements
 // Element<3> = triangle, Element<2> = segment (taichi/geometry/mesh.h)
@@ -275,6 +277,12 @@ struct RigidBody {
     if constexpr (dim == 2) return inv_inertia;
     else { const Matrix R = rotation.get_rotation_matrix(); return R * inv_inertia * transposed(R); }
   }
+  InertiaType get_transformed_inertia() const {
+    if constexpr (dim == 2) return inertia;
+    else { const Matrix R = rotation.get_rotation_matrix(); return R * inertia * transposed(R); }
+  }
+  typename AngularVelocity<dim>::ValueType get_angular_momemtum() const { return get_transformed_inertia() * angular_velocity.value; }
+  void apply_torque(const typename AngularVelocity<dim>::ValueType &t) { angular_velocity.value += get_transformed_inversed_inertia() * t; }
   Vector get_velocity_at(const Vector &p) const { return velocity + angular_velocity.cross(p - position); }
   // change of the velocity at `position + r` along n per unit impulse along n applied there
   real get_impulse_contribution(const Vector &r, const Vector &n) const {

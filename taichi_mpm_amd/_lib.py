@@ -60,6 +60,14 @@ class RigidConfig(C.Structure):
                 ("scripted_rotation", SCRIPT_FN), ("rotation_user", C.c_void_p)]
 
 
+class JointConfig(C.Structure):
+    """mirror of mpmhip_joint_config"""
+    _fields_ = [("type", C.c_int32), ("obj0", C.c_int32), ("obj1", C.c_int32), ("has_offset1", C.c_int32),
+                ("has_target_distance", C.c_int32), ("offset0", C.c_float * 3), ("offset1", C.c_float * 3),
+                ("target_distance", C.c_float), ("penalty", C.c_float), ("axis", C.c_float * 3), ("axis_length", C.c_float),
+                ("power", C.c_float), ("angular_velocity", C.c_float)]
+
+
 class RigidConfig2D(C.Structure):
     """mirror of mpmhip2d_rigid_config"""
     _fields_ = [("codimensional", C.c_int32), ("recenter", C.c_int32), ("reverse_vertices", C.c_int32), ("reserved0", C.c_int32),
@@ -139,6 +147,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_las
             "mpmhip2d_download_cdf", "mpmhip2d_download_colours",
             "mpmhip_set_rigid_coupling", "mpmhip_add_rigid_body", "mpmhip_num_rigid_bodies", "mpmhip_rigid_get_state", "mpmhip_rigid_set_velocity",
             "mpmhip_rigid_get_samples", "mpmhip_rigid_get_mesh", "mpmhip2d_rigid_get_mesh", "mpmhip_rasterize_rigid_boundary", "mpmhip_gather_cdf", "mpmhip_advect_rigid_bodies", "mpmhip_download_cdf",
+            "mpmhip_add_articulation", "mpmhip_num_articulations", "mpmhip_set_articulation_iterations", "mpmhip_articulate",
             "mpmhip_download_boundary",
             "mpmhip_debug_copy_bandwidth", "mpmhip_debug_gather_bandwidth", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
 
@@ -282,7 +291,11 @@ def load():
     L.mpmhip_rigid_get_mesh.restype = C.c_int64
     L.mpmhip2d_rigid_get_mesh.argtypes = [vp, C.c_int32, C.c_int64, fp]
     L.mpmhip2d_rigid_get_mesh.restype = C.c_int64
-    for name in ("mpmhip_rasterize_rigid_boundary", "mpmhip_gather_cdf", "mpmhip_advect_rigid_bodies"):
+    L.mpmhip_add_articulation.argtypes = [vp, P(JointConfig)]
+    L.mpmhip_num_articulations.argtypes = [vp]
+    L.mpmhip_num_articulations.restype = C.c_int32
+    L.mpmhip_set_articulation_iterations.argtypes = [vp, C.c_int32]
+    for name in ("mpmhip_rasterize_rigid_boundary", "mpmhip_gather_cdf", "mpmhip_advect_rigid_bodies", "mpmhip_articulate"):
         getattr(L, name).argtypes = [vp]
     L.mpmhip_download_cdf.argtypes = [vp, up, fp]
     L.mpmhip_download_boundary.argtypes = [vp, fp, C.c_int64]

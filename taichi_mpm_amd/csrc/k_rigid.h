@@ -16,6 +16,7 @@
 // gather_cdf (boundary normal / distance / near flag) go to a side array indexed by slot.
 #pragma once
 #include "mpm_common.h"
+#include "k_joints.h"
 
 namespace mpm {
 
@@ -474,6 +475,27 @@ __global__ __launch_bounds__(256) void k_gather_cdf(Params P, CdfDev C, RecG *__
 
 // ---------------------------------------------------------------------------------------------- the bodies
 // RigidBody::apply_tmp_velocity after a transfer: velocity += impulse / m, omega += R I^-1 R^T torque; sums cleared
+// MPM::articulate (src/mpm.h:278-319): the joints' sequential Gauss-Seidel chain (k_joints.h), one lane; the bodies sit in
+// LDS while it runs
+__global__ __launch_bounds__(64) void k_articulate(RigidBodyDev *rb, int nb, const JointDev *__restrict__ joints, int nj, float dt,
+                                                   int iterations) {
+  __shared__ JointBody sb[MAX_RIGID];
+  const int t = threadIdx.x;
+  if (t < nb) {
+    const RigidBodyDev &B = rb[t];
+    JointBody &J = sb[t];
+    for (int k = 0; k < 3; k++) { J.pos[k] = B.pos[k]; J.vel[k] = B.vel[k]; J.omega[k] = B.omega[k]; }
+    for (int k = 0; k < 9; k++) { J.R[k] = B.R[k]; J.inv_I[k] = B.inv_I[k]; }
+    J.inv_mass = B.inv_mass;
+  }
+  __syncthreads();
+  if (t == 0) articulate(sb, joints, nj, dt, iterations);
+  __syncthreads();
+  if (t < nb) {
+    for (int k = 0; k < 3; k++) { rb[t].vel[k] = sb[t].vel[k]; rb[t].omega[k] = sb[t].omega[k]; }
+  }
+}
+
 __global__ void k_rigid_apply_tmp(RigidBodyDev *rb, int nb) {
   const int b = threadIdx.x;
   if (b < 1 || b >= nb) return;

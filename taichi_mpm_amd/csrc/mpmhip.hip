@@ -178,6 +178,9 @@ struct mpmhip_ctx {
     uint32_t gather_epoch = 0;  // stamps the boundary records of the particles the last gather_cdf visited
     size_t rpage_words = 0;
     float penalty = 0.0f, pushing_force = 20000.0f;  // MPM::initialize defaults, src/mpm.cpp:35,40
+    std::vector<JointDev> joints;    // MPM::articulations, in the order they were added
+    JointDev *d_joints = nullptr;
+    int joint_iterations = 100;      // 'articulation_iterations' (src/mpm.h:279-280)
   } rigid;
   bool overlap = false;        // mpmhip_set_overlap: split tiled substeps into boundary / interior work
   bool ov_active = false, interior_done = false;  // state of the substep in flight
@@ -448,7 +451,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   hipFree(c->async.d_tab); hipFree(c->async.d_blk_of); hipFree(c->async.d_blk_limits); hipFree(c->async.d_particle_limits);
   hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_LS); hipFree(c->d_counts); hipFree(c->d_bounds); if (c->h_pinned) hipHostFree(c->h_pinned); hipFree(c->d_energy);
   { auto &R = c->rigid; hipFree(R.d_rb); hipFree(R.d_smp); hipFree(R.d_elems); hipFree(R.cdf.slot); hipFree(R.cdf.page_key); hipFree(R.cdf.mind);
-    hipFree(R.cdf.tags); hipFree(R.cdf.rpage); hipFree(R.d_bnd); hipFree(R.d_blk_rigid); hipFree(R.d_counters); }
+    hipFree(R.cdf.tags); hipFree(R.cdf.rpage); hipFree(R.d_bnd); hipFree(R.d_blk_rigid); hipFree(R.d_counters); hipFree(R.d_joints); }
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }

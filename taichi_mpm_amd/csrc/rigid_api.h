@@ -93,6 +93,7 @@ static int rigid_enable(mpmhip_ctx *c) {
   const int rpd[3] = {c->P.res[0] / 4 + 2, c->P.res[1] / 4 + 2, c->P.res[2] / 8 + 2};
   R.rpage_words = ((size_t)rpd[0] * rpd[1] * rpd[2] + 31) / 32;
   A(dmalloc(&R.d_rb, (size_t)MAX_RIGID));
+  A(dmalloc(&R.d_joints, (size_t)MAX_JOINTS));
   A(dmalloc(&R.cdf.slot, (size_t)c->NB));
   A(dmalloc(&R.cdf.page_key, (size_t)R.max_pages));
   A(dmalloc(&R.cdf.mind, (size_t)R.max_pages * 64));
@@ -108,6 +109,14 @@ static int rigid_enable(mpmhip_ctx *c) {
   R.cdf.pool_cap = R.max_pages / CDF_POOLS;
   for (int k = 0; k < 3; k++) R.cdf.rpd[k] = rpd[k];
   HIPCHK(c, hipMemset(R.d_rb, 0, sizeof(RigidBodyDev) * MAX_RIGID));
+  {  // body 0, the background (RigidBody::set_as_background): at the origin, unrotated, immovable — joints may link to it
+    RigidBodyDev G;
+    memset(&G, 0, sizeof G);
+    G.R[0] = G.R[4] = G.R[8] = 1.0f;
+    G.q[0] = 1.0f;
+    G.mass = 1.0f;
+    HIPCHK(c, hipMemcpy(R.d_rb, &G, sizeof G, hipMemcpyHostToDevice));
+  }
   HIPCHK(c, hipMemset(R.cdf.slot, 0xFF, sizeof(uint32_t) * (size_t)c->NB));
   HIPCHK(c, hipMemset(R.cdf.mind, 0xFF, sizeof(unsigned long long) * (size_t)R.max_pages * 64));
   HIPCHK(c, hipMemset(R.cdf.tags, 0, sizeof(uint32_t) * (size_t)R.max_pages * 64));
@@ -118,6 +127,9 @@ static int rigid_enable(mpmhip_ctx *c) {
   HIPCHK(c, hipMemset(R.d_blk_rigid, 0, (size_t)c->P.max_blocks + 1));
   R.bodies.clear();
   R.bodies.emplace_back();  // body 0: the background (MPM::initialize, src/mpm.cpp:72-74); it has no surface
+  R.bodies[0].mass = 1.0f;
+  R.bodies[0].inertia[0] = R.bodies[0].inertia[4] = R.bodies[0].inertia[8] = 1.0f;  // set_as_background: inertia 1, inverse 0
+  R.joints.clear();
   R.enabled = true;
   return MPMHIP_OK;
 }
@@ -187,9 +199,19 @@ static int do_rigid_advect(mpmhip_ctx *c, float dt) {
   return launch_check(c, "advect_rigid_bodies");
 }
 // what substep() does with rigid bodies between the sort and P2G (src/mpm.cpp:466-472, 506-508)
+// MPM::articulate (src/mpm.h:278-319): between the sort and rasterize_rigid_boundary (src/mpm.cpp:466-471)
+static int do_rigid_articulate(mpmhip_ctx *c, float dt) {
+  auto &R = c->rigid;
+  if (R.joints.empty()) return MPMHIP_OK;
+  hipLaunchKernelGGL(k_articulate, dim3(1), dim3(64), 0, c->stream, R.d_rb, (int)R.bodies.size(), (const JointDev *)R.d_joints,
+                     (int)R.joints.size(), dt, R.joint_iterations);
+  return launch_check(c, "articulate");
+}
 static int do_rigid_pre(mpmhip_ctx *c) {
   int rc;
-  if ((rc = do_rigid_rasterize(c)) || (rc = do_rigid_gather(c)) || (rc = do_rigid_block_flags(c))) return rc;
+  if ((rc = do_rigid_articulate(c, c->P.dt)) || (rc = do_rigid_rasterize(c)) || (rc = do_rigid_gather(c)) ||
+      (rc = do_rigid_block_flags(c)))
+    return rc;
   return MPMHIP_OK;
 }
 
@@ -395,6 +417,51 @@ int mpmhip_gather_cdf(mpmhip_ctx *c) {
   int rc = need_sorted(c, "gather_cdf");
   if (rc || (rc = do_rigid_gather(c))) return rc;
   return do_rigid_block_flags(c);
+}
+// general_action("add_articulation") (src/mpm.cpp:923-933): the joint's initialize() on the bodies' CURRENT poses
+int mpmhip_add_articulation(mpmhip_ctx *c, const mpmhip_joint_config *cfg) {
+  if (!c || !cfg) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  auto &R = c->rigid;
+  const int nb = R.enabled ? (int)R.bodies.size() : 0;
+  if (cfg->obj0 < 1 || cfg->obj0 >= nb) return fail(c, MPMHIP_EINVAL, "add_articulation: obj0 = %d is not a rigid body of this simulation", cfg->obj0);
+  if (cfg->obj1 < 0 || cfg->obj1 >= nb) return fail(c, MPMHIP_EINVAL, "add_articulation: obj1 = %d is not a rigid body of this simulation", cfg->obj1);
+  if (cfg->type < JOINT_ROTATION || cfg->type > JOINT_STEPPER) return fail(c, MPMHIP_EINVAL, "add_articulation: unknown type %d", cfg->type);
+  if (c->in_substep) return fail(c, MPMHIP_EINVAL, "add_articulation inside a substep");
+  if ((int)R.joints.size() >= MAX_JOINTS) return fail(c, MPMHIP_ECAPACITY, "at most %d articulations", MAX_JOINTS);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  JointBody jb[2];
+  const int ids[2] = {cfg->obj0, cfg->obj1};
+  for (int i = 0; i < 2; i++) {
+    RigidBodyDev D;
+    HIPCHK(c, hipMemcpy(&D, R.d_rb + ids[i], sizeof D, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; k++) { jb[i].pos[k] = D.pos[k]; jb[i].vel[k] = D.vel[k]; jb[i].omega[k] = D.omega[k]; }
+    for (int k = 0; k < 9; k++) { jb[i].R[k] = D.R[k]; jb[i].inv_I[k] = D.inv_I[k]; }
+    jb[i].inv_mass = D.inv_mass;
+  }
+  JointConfig jc;
+  jc.type = cfg->type; jc.obj0 = cfg->obj0; jc.obj1 = cfg->obj1; jc.has_offset1 = cfg->has_offset1; jc.has_target = cfg->has_target_distance;
+  for (int k = 0; k < 3; k++) { jc.offset0[k] = cfg->offset0[k]; jc.offset1[k] = cfg->offset1[k]; jc.axis[k] = cfg->axis[k]; }
+  jc.target_distance = cfg->target_distance; jc.penalty = cfg->penalty; jc.axis_length = cfg->axis_length;
+  jc.power = cfg->power; jc.angular_velocity = cfg->angular_velocity;
+  JointDev J;
+  if (const char *why = joint_init(J, jc, jb[0], jb[1], R.bodies[cfg->obj0].inertia, R.bodies[cfg->obj1].inertia))
+    return fail(c, MPMHIP_EINVAL, "add_articulation: %s", why);
+  R.joints.push_back(J);
+  HIPCHK(c, hipMemcpy(R.d_joints, R.joints.data(), sizeof(JointDev) * R.joints.size(), hipMemcpyHostToDevice));
+  return MPMHIP_OK;
+}
+int32_t mpmhip_num_articulations(const mpmhip_ctx *c) { return c ? (int32_t)c->rigid.joints.size() : 0; }
+int mpmhip_set_articulation_iterations(mpmhip_ctx *c, int32_t n) {
+  if (!c || n < 0) return MPMHIP_EINVAL;
+  c->rigid.joint_iterations = n;
+  return MPMHIP_OK;
+}
+int mpmhip_articulate(mpmhip_ctx *c) {
+  if (!c) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->rigid.enabled) return MPMHIP_OK;
+  return do_rigid_articulate(c, c->P.dt);
 }
 int mpmhip_advect_rigid_bodies(mpmhip_ctx *c) {
   if (!c) return MPMHIP_EINVAL;

@@ -199,6 +199,7 @@ class Simulation3D:
         self.frame_count = 0  # src/mpm.h:334
         self.penalty = float(cfg.get("penalty", 0.0))               # CPIC, src/mpm.cpp:35
         self.pushing_force = float(cfg.get("pushing_force", 20000.0))  # src/mpm.cpp:40
+        self.articulation_iterations = int(cfg.get("articulation_iterations", 100))  # src/mpm.h:279-280
         self.config = cfg
         return self
 
@@ -224,6 +225,7 @@ class Simulation3D:
             raise MPMError("mpmhip_create failed (%d): %s" % (rc, self._L.mpmhip_last_error(None).decode()))
         self._ctx, self._cfg, self._capacity = ctx, c, int(capacity)
         self._check(self._L.mpmhip_set_rigid_coupling(self._ctx, self.penalty, self.pushing_force))
+        self._check(self._L.mpmhip_set_articulation_iterations(self._ctx, self.articulation_iterations))
         self._apply_levelset()
         for mat, params in self._groups:
             self._check(self._L.mpmhip_add_group(self._ctx, mat, params.ctypes.data_as(C.POINTER(C.c_float))))
@@ -561,6 +563,9 @@ class Simulation3D:
     def gather_cdf(self):  # src/rigid_transfer.cpp:121-275
         self._ensure_ctx(); self._check(self._L.mpmhip_gather_cdf(self._ctx))
 
+    def articulate(self):  # src/mpm.h:278-319
+        self._ensure_ctx(); self._check(self._L.mpmhip_articulate(self._ctx))
+
     def advect_rigid_bodies(self):  # src/mpm_rigid_body.cpp:255-286
         self._ensure_ctx(); self._check(self._L.mpmhip_advect_rigid_bodies(self._ctx))
 
@@ -626,9 +631,40 @@ class Simulation3D:
         return dict(coord=coord[:n], strength=arrs[0][:n], cfl=arrs[1][:n], continuous=arrs[2][:n], count=arrs[3][:n]), tuple(int(v) for v in mm)
 
     # ---------------------------------------------------------------- misc surface
+    JOINT_TYPES = {"rotation": 0, "frozen": 1, "distance": 2, "axial_rotation": 3, "motor": 4, "stepper": 5}
+
+    def add_articulation(self, cfg):
+        """general_action(action='add_articulation', ...) (src/mpm.cpp:923-933): a joint between two rigid bodies, with the
+        keys of src/articulation.cpp — type ('rotation', 'frozen', 'distance', 'axial_rotation', 'motor', 'stepper'), obj0,
+        obj1 (body indices as add_particles(type='rigid') returns them; obj1 absent = the background body), offset0,
+        offset1, target_distance, penalty, axis, axis_length, power, angular_velocity."""
+        name = cfg.get("type")
+        if name not in self.JOINT_TYPES:
+            raise MPMError("unknown articulation type %r (registered: %s)" % (name, ", ".join(sorted(self.JOINT_TYPES))))
+        if "obj0" not in cfg:
+            raise MPMError("add_articulation needs 'obj0'")
+        j = _lib.JointConfig()
+        j.type = self.JOINT_TYPES[name]
+        j.obj0, j.obj1 = int(cfg["obj0"]), int(cfg.get("obj1", 0))
+        j.offset0[:] = _vec3(cfg.get("offset0"), (0, 0, 0))
+        j.has_offset1 = int("offset1" in cfg)
+        j.offset1[:] = _vec3(cfg.get("offset1"), (0, 0, 0))
+        j.has_target_distance = int("target_distance" in cfg)
+        j.target_distance = float(cfg.get("target_distance", 0.0))
+        j.penalty = float(cfg.get("penalty", -1.0))
+        j.axis[:] = _vec3(cfg.get("axis"), (0, 0, 0))
+        j.axis_length = float(cfg.get("axis_length", -1.0))
+        j.power = float(cfg.get("power", 0.0))
+        j.angular_velocity = float(cfg.get("angular_velocity", 0.0))
+        self._ensure_ctx()
+        self._check(self._L.mpmhip_add_articulation(self._ctx, C.byref(j)))
+        return ""
+
     def general_action(self, config):
         """MPM<dim>::general_action, src/mpm.cpp:920-978."""
         action = config.get("action")
+        if action == "add_articulation":  # src/mpm.cpp:923-933
+            return self.add_articulation(config)
         if action == "calculate_energy":  # src/mpm.cpp:936-938 -> :1078-1110
             k, p = self.calculate_energy()
             return str(k + p)
@@ -842,6 +878,10 @@ class MPM:
         self.c.frame += 1
 
     def general_action(self, **kwargs):
+        return self.c.general_action(kwargs)
+
+    def add_articulation(self, **kwargs):  # scripts/async/async_mpm.py:277-279
+        kwargs["action"] = "add_articulation"
         return self.c.general_action(kwargs)
 
     def visualize(self):  # scripts/async/async_mpm.py:201-202

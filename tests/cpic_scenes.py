@@ -162,3 +162,30 @@ def build_device2(tm, body, material, **cfg):
     gp = orc.group_params(material, MASS2, VOL2)[0]
     sim.add_particles(dict(type=material, positions=x, velocities=v, params=gp))
     return sim, rid
+
+
+# ---------------------------------------------------------------------------------------------- joints (src/articulation.cpp)
+# three free boxes with sizeable velocities; the joints are set up on these poses, the bodies then drift for JOINT_DRIFT
+# substeps (advect_rigid_bodies only) before MPM::articulate is compared — a joint whose anchors still coincide does nothing
+JOINT_BODIES = [
+    dict(mesh=box(0.10, 0.06, 0.08), codimensional=False, density=40.0, friction=0.3, initial_position=(0.35, 0.50, 0.50),
+         initial_rotation=(10.0, 20.0, 30.0)),
+    dict(mesh=box(0.07, 0.09, 0.05), codimensional=False, density=60.0, friction=0.3, initial_position=(0.60, 0.52, 0.48),
+         initial_rotation=(-15.0, 5.0, 40.0)),
+    dict(mesh=box(0.05, 0.05, 0.09), codimensional=False, density=90.0, friction=0.3, initial_position=(0.50, 0.70, 0.55),
+         initial_rotation=(0.0, -25.0, 12.0)),
+]
+JOINT_VELOCITIES = [((0.3, -0.1, 0.2), (1.0, 2.0, -0.5)), ((-0.2, 0.1, 0.0), (-0.7, 0.4, 1.5)), ((0.05, 0.3, -0.15), (0.6, -1.1, 0.8))]
+JOINT_DRIFT, JOINT_DT = 40, 1e-3
+JOINT_CASES = {
+    "rotation": [dict(type="rotation", obj0=1, obj1=2)],
+    "frozen": [dict(type="frozen", obj0=1, obj1=2)],
+    "distance": [dict(type="distance", obj0=1, obj1=2, offset0=(0.05, 0.0, 0.0), offset1=(-0.03, 0.01, 0.0))],
+    "distance_rod": [dict(type="distance", obj0=2, obj1=3, target_distance=0.2, penalty=5e3)],
+    "distance_background": [dict(type="distance", obj0=3, obj1=0, offset0=(0.0, 0.02, 0.0), offset1=(0.5, 0.8, 0.5))],
+    "axial_rotation": [dict(type="axial_rotation", obj0=1, obj1=2, axis=(0.0, 0.0, 2.0), offset0=(0.1, 0.0, 0.0))],
+    "motor": [dict(type="motor", obj0=1, obj1=2, axis=(0.0, 1.0, 0.0), power=3.0, axis_length=0.05)],
+    "stepper_background": [dict(type="stepper", obj0=1, obj1=0, axis=(0.0, 0.0, 1.0), angular_velocity=2.0)],
+    "chain": [dict(type="rotation", obj0=1, obj1=2), dict(type="axial_rotation", obj0=2, obj1=3, axis=(1.0, 1.0, 0.0)),
+              dict(type="distance", obj0=1, obj1=3, offset0=(0.0, 0.03, 0.0)), dict(type="motor", obj0=3, obj1=0, axis=(0.0, 1.0, 0.0), power=-2.0)],
+}

@@ -283,10 +283,51 @@ def cpic2d_fixture(here):
     np.savez_compressed(os.path.join(here, "ref_cpic2d.npz"), **out)
 
 
+def joints_fixture(here):
+    """the reference's joints (src/articulation.cpp) on free bodies: state the joints are set up on, state after the drift,
+    state after one MPM::articulate (src/mpm.h:278-319), and the bodies after further whole rounds of
+    articulate + advect_rigid_bodies (what a substep does to bodies that touch no particle)"""
+    import json
+    from tests import cpic_scenes as cs
+
+    def states(sim, n):
+        out = np.zeros((n + 1, 33), np.float32)
+        out[0, 3] = 1.0  # the background body: at the origin, unrotated, no inverse mass / inertia
+        for b in range(1, n + 1):
+            st = sim.rigid_state(b)
+            out[b] = np.concatenate([st["position"], st["rotation"], st["velocity"], st["angular_velocity"], [st["mass"], st["inv_mass"]],
+                                     st["inertia"].ravel(), st["inv_inertia"].ravel()])
+        return out
+    out = {}
+    for name, joints in cs.JOINT_CASES.items():
+        sim = ref.Sim(RES, DX, cs.JOINT_DT, gravity=(0, -10, 0))
+        for body in cs.JOINT_BODIES:
+            kw = dict(body)
+            sim.add_rigid(kw.pop("mesh"), **kw)
+        for b, (v, w) in enumerate(cs.JOINT_VELOCITIES):
+            sim.rigid_set_velocity(b + 1, v=v, w=w)
+        nb = len(cs.JOINT_BODIES)
+        out[name + "/setup"] = states(sim, nb)
+        for j in joints:
+            sim.general_action(action="add_articulation", **j)
+        for _ in range(cs.JOINT_DRIFT):
+            sim.advect_rigid_bodies()
+        out[name + "/drifted"] = states(sim, nb)
+        ref._chk(ref.lib().ref_phase(sim.h, 10, 1))
+        out[name + "/articulated"] = states(sim, nb)
+        for _ in range(20):
+            sim.advect_rigid_bodies()
+            ref._chk(ref.lib().ref_phase(sim.h, 10, 1))
+        out[name + "/after20"] = states(sim, nb)
+        sim.close()
+    np.savez_compressed(os.path.join(here, "ref_joints.npz"), cases=json.dumps(cs.JOINT_CASES), dt=cs.JOINT_DT, **out)
+    print("ref_joints.npz:", ", ".join(cs.JOINT_CASES))
+
+
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     ref.set_threads(1)  # the generic P2G of the reference is racy with more than one thread (SURVEY quirk 5)
-    what = sys.argv[1:] or (list(MATS) + ["materials", "kernels", "shapes", "mpm2d", "cpic", "cpic2d"])
+    what = sys.argv[1:] or (list(MATS) + ["materials", "kernels", "shapes", "mpm2d", "cpic", "cpic2d", "joints"])
     for w in what:
         if w in MATS:
             substep_fixture(here, w)
@@ -302,6 +343,8 @@ def main():
             cpic_fixture(here)
         elif w == "cpic2d":
             cpic2d_fixture(here)
+        elif w == "joints":
+            joints_fixture(here)
 
 
 if __name__ == "__main__":

@@ -438,3 +438,109 @@ def test_frames_carry_the_rigid_meshes(tm, tmp_path):
     sim2.run_substeps(2)
     poly = open(sim2.write_rigid_body(rid2, str(tmp_path / "bar"))).read().split("\n")
     assert poly[0] == "POINTS" and poly[3] == "POLYS" and poly[4] == "1: 1 2" and poly[5] == "END"
+
+
+# ---------------------------------------------------------------------------------------------- joints (src/articulation.cpp)
+def _joint_scene(tm, joints, dt=cs.JOINT_DT, **cfg):
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(cs.RES,) * 3, delta_x=cs.DX, base_delta_t=dt, gravity=(0, -10, 0),
+                                                       max_particles=1 << 12, **cfg))
+    for body in cs.JOINT_BODIES:
+        sim.add_particles(dict(type="rigid", **body))
+    for b, (v, w) in enumerate(cs.JOINT_VELOCITIES):
+        sim.set_rigid_velocity(b + 1, v, w)
+    for j in joints:
+        assert sim.general_action(dict(action="add_articulation", **j)) == ""
+    return sim
+
+
+def _body_rows(sim, n):
+    return np.stack([cs.rigid_vector(sim.get_rigid_state(b)) for b in range(1, n + 1)])
+
+
+def _assert_bodies(got, want, name, vtol):
+    """want: fixture rows of the bodies 1.. (position 3, quaternion 4, velocity 3, angular velocity 3, ...)"""
+    for b in range(len(got)):
+        g, w = got[b], want[b]
+        q = g[3:7] if np.dot(g[3:7], w[3:7]) >= 0 else -g[3:7]
+        np.testing.assert_allclose(g[0:3], w[0:3], rtol=0, atol=2e-6, err_msg=name)
+        np.testing.assert_allclose(q, w[3:7], rtol=0, atol=2e-6, err_msg=name)
+        np.testing.assert_allclose(g[7:13], w[7:13], rtol=0, atol=vtol * max(1.0, float(np.abs(want[:, 7:13]).max())), err_msg=name)
+
+
+@pytest.fixture(scope="module")
+def gold_joints():
+    import json
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_joints.npz"))
+    return g, json.loads(str(g["cases"]))
+
+
+def test_joints_match_the_reference(tm, gold_joints):
+    """every Articulation class of src/articulation.cpp on free bodies: set-up, drift (advect_rigid_bodies only), one
+    MPM::articulate, then 20 rounds of advect + articulate — against the reference's compiled joints (ref_joints.npz)"""
+    g, cases = gold_joints
+    nb = len(cs.JOINT_BODIES)
+    for name, joints in cases.items():
+        sim = _joint_scene(tm, joints)
+        _assert_bodies(_body_rows(sim, nb), g[name + "/setup"][1:], name + " setup", 1e-6)
+        for _ in range(cs.JOINT_DRIFT):
+            sim.advect_rigid_bodies()
+        _assert_bodies(_body_rows(sim, nb), g[name + "/drifted"][1:], name + " drifted", 2e-6)
+        sim.articulate()
+        _assert_bodies(_body_rows(sim, nb), g[name + "/articulated"][1:], name + " articulated", 2e-5)
+        for _ in range(20):
+            sim.advect_rigid_bodies()
+            sim.articulate()
+        _assert_bodies(_body_rows(sim, nb), g[name + "/after20"][1:], name + " after20", 2e-4)
+        sim.close()
+
+
+def test_joints_inside_whole_substeps_match_the_live_reference(tm):
+    """a hinged pair of boxes with a motor, one of them pushed through a block of jelly: whole substeps (sort, articulate,
+    CDF, transfers with impulses to the bodies, advection) next to the compiled reference"""
+    from oracle import refmpm
+    if not refmpm.available():
+        pytest.skip("oracle/_ref/libmpm_ref.so did not travel to this box")
+    from oracle import oracle as orc
+    refmpm.set_threads(1)
+    x, v = cs.block_of_particles()
+    gp = orc.group_params("jelly", cs.MASS, cs.VOL)[0]
+    bodies = [dict(mesh=cs.box(0.08, 0.05, 0.07), codimensional=False, density=400.0, friction=0.3, initial_position=(0.43, 0.52, 0.47),
+                   initial_rotation=(5.0, 10.0, -20.0), initial_velocity=(0.2, -0.3, 0.1), initial_angular_velocity=(0.5, 1.0, -2.0)),
+              dict(mesh=cs.box(0.05, 0.07, 0.05), codimensional=False, density=300.0, friction=0.3, initial_position=(0.60, 0.58, 0.52),
+                   initial_rotation=(0.0, 30.0, 15.0), initial_velocity=(-0.1, 0.0, 0.2), initial_angular_velocity=(1.5, -0.5, 0.3))]
+    joints = [dict(type="motor", obj0=1, obj1=2, axis=(0.0, 0.0, 1.0), offset0=(0.08, 0.03, 0.0), power=0.05),
+              dict(type="distance", obj0=2, obj1=0, offset1=(0.6, 0.9, 0.5), penalty=2e3),
+              dict(type="rotation", obj0=1, obj1=2)]
+    ref = refmpm.Sim(cs.RES, cs.DX, cs.DT, gravity=(0, -10, 0))
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(cs.RES,) * 3, delta_x=cs.DX, base_delta_t=cs.DT, gravity=(0, -10, 0),
+                                                       max_particles=len(x) + 16))
+    for b in bodies:
+        kw = dict(b)
+        ref.add_rigid(kw.pop("mesh"), **kw)
+        sim.add_particles(dict(type="rigid", **b))
+    for j in joints:
+        ref.general_action(action="add_articulation", **j)
+        sim.general_action(dict(action="add_articulation", **j))
+    ref.add_particles("jelly", cs.MASS, cs.VOL, x, v)
+    sim.add_particles(dict(type="jelly", positions=x, velocities=v, params=gp))
+    ref.substep(30)
+    sim.run_substeps(30)
+    r, h = ref.download(by_id=True), sim.get_particles(sort_by_id=True)
+    np.testing.assert_array_equal(h["id"], r["id"])
+    assert np.abs(h["x"] - r["x"]).max() <= 5e-6
+    assert rel_l2(h["v"], r["v"]) <= 2e-4
+    for rid in (1, 2):
+        a, b = cs.rigid_vector(ref.rigid_state(rid)), cs.rigid_vector(sim.get_rigid_state(rid))
+        np.testing.assert_allclose(b[0:7], a[0:7], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(b[7:13], a[7:13], rtol=0, atol=2e-4 * max(np.abs(a[7:13]).max(), 1e-2))
+
+
+def test_articulation_api_refuses_what_it_cannot_do(tm):
+    from taichi_mpm_amd.mpm import MPMError
+    sim = _joint_scene(tm, [])
+    for bad, msg in ((dict(type="hinge", obj0=1), "unknown articulation type"), (dict(type="rotation", obj0=7), "not a rigid body"),
+                     (dict(type="rotation", obj0=1, obj1=9), "not a rigid body"), (dict(type="distance", obj0=1), "offset1"),
+                     (dict(type="motor", obj0=1, obj1=2), "axis")):
+        with pytest.raises(MPMError, match=msg):
+            sim.general_action(dict(action="add_articulation", **bad))
+    sim.close()

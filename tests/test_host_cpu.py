@@ -44,7 +44,7 @@ def test_ctypes_mirrors_match_the_c_structs_field_by_field(tmp_path):
     import subprocess
     pairs = [("mpmhip_config", _lib.Config), ("mpmhip_shape", _lib.Shape), ("mpmhip_async_config", _lib.AsyncConfig),
              ("mpmhip2d_config", _lib.Config2D), ("mpmhip_halo_box", _lib.HaloBox), ("mpmhip_rigid_config", _lib.RigidConfig),
-             ("mpmhip2d_rigid_config", _lib.RigidConfig2D)]
+             ("mpmhip2d_rigid_config", _lib.RigidConfig2D), ("mpmhip_joint_config", _lib.JointConfig)]
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "mpmhip.h"', "int main(void) {"]
     for cname, mirror in pairs:
         lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
