@@ -82,6 +82,7 @@ class MPM<3> {
     check(mpmhip_create(&cfg_, &ctx_), nullptr);
     // CPIC coupling constants (src/mpm.cpp:35,40)
     check(mpmhip_set_rigid_coupling(ctx_, config.get("penalty", 0.0f), config.get("pushing_force", 20000.0f)), ctx_);
+    check(mpmhip_set_articulation_iterations(ctx_, config.get("articulation_iterations", 100)), ctx_);  // src/mpm.h:279-280
     frame = 0;
     frame_count = 0;
   }
@@ -173,6 +174,32 @@ class MPM<3> {
     return std::to_string(id);
   }
   bool has_rigid_body() const { return mpmhip_num_rigid_bodies(ctx_) > 1; }  // src/mpm.h:240-242
+  // general_action(action='add_articulation', type=..., obj0=..., obj1=..., ...) (src/mpm.cpp:923-933): a joint between two
+  // rigid bodies with the keys of src/articulation.cpp; obj1 absent = the background body
+  std::string add_articulation(const Config &config) {
+    static const char *names[] = {"rotation", "frozen", "distance", "axial_rotation", "motor", "stepper"};
+    const std::string type = config.get("type", "");
+    mpmhip_joint_config j{};
+    j.type = -1;
+    for (int k = 0; k < 6; k++) if (type == names[k]) j.type = k;
+    if (j.type < 0) throw std::runtime_error("unknown articulation type '" + type + "'");
+    if (!config.has_key("obj0")) throw std::runtime_error("add_articulation needs 'obj0'");
+    j.obj0 = config.get("obj0", 0);
+    j.obj1 = config.get("obj1", 0);
+    auto vec = [&](const char *key, float *out) { const Vector v = config.get_vec(key, Vector(0.0f, 0.0f, 0.0f)); for (int k = 0; k < 3; k++) out[k] = v[k]; };
+    vec("offset0", j.offset0);
+    vec("offset1", j.offset1);
+    vec("axis", j.axis);
+    j.has_offset1 = config.has_key("offset1");
+    j.has_target_distance = config.has_key("target_distance");
+    j.target_distance = config.get("target_distance", 0.0f);
+    j.penalty = config.get("penalty", -1.0f);
+    j.axis_length = config.get("axis_length", -1.0f);
+    j.power = config.get("power", 0.0f);
+    j.angular_velocity = config.get("angular_velocity", 0.0f);
+    check(mpmhip_add_articulation(ctx_, &j), ctx_);
+    return "";
+  }
   // position 3, rotation quaternion (w,x,y,z) 4, velocity 3, angular velocity 3, mass, inv_mass, inertia 9, inv_inertia 9
   std::vector<float> get_rigid_state(int id) const {
     std::vector<float> o(33);
@@ -278,6 +305,7 @@ class MPM<3> {
   // --- MPM<dim>::general_action (src/mpm.cpp:920-978): the actions that only need the hot path's state
   std::string general_action(const Config &config) {
     const std::string action = config.get("action", "");
+    if (action == "add_articulation") return add_articulation(config);  // :923-933
     if (action == "calculate_energy") {  // :936-938 -> calculate_energy(), :1078-1110
       double kinetic = 0, potential = 0;
       check(mpmhip_calculate_energy(ctx_, &kinetic, &potential), ctx_);

@@ -212,6 +212,25 @@ static void gpu_tests() {
     for (auto &q : sim4->get_render_particles()) (q.position[1] < st[1] ? below : above) += 1;
     CHECK(below > 1000 && above > 1000);
   }
+  {  // joints: general_action(action='add_articulation') — a stepper to the background spins a free plate about z
+    auto sim5 = create_simulation3("mpm");
+    sim5->initialize(Config().set("res", Vector3i(32, 32, 32)).set("base_delta_t", 1e-4).set("gravity", Vector3(0, 0, 0))
+                         .set("max_particles", 4096.0));
+    const float h = 0.1f;
+    const float tri[18] = {-h, 0, -h, h, 0, -h, h, 0, h, -h, 0, -h, h, 0, h, -h, 0, h};
+    CHECK(sim5->add_rigid_body(Config().set("codimensional", true).set("friction", 0.3).set("initial_position", Vector3(0.5f, 0.5f, 0.5f)), 2, tri) == "1");
+    CHECK(sim5->general_action(Config().set("action", "add_articulation").set("type", "stepper").set("obj0", 1)
+                                   .set("axis", Vector3(0, 0, 1)).set("angular_velocity", 3.0)) == "");
+    bool threw = false;
+    try { sim5->general_action(Config().set("action", "add_articulation").set("type", "spring").set("obj0", 1)); } catch (const std::exception &) { threw = true; }
+    CHECK(threw);
+    sim5->add_particles(Config().set("type", "jelly").set("cube_lo", 4).set("cube_hi", 6));  // (far from the plate)
+    for (int i = 0; i < 5; i++) sim5->substep();
+    sim5->synchronize();
+    const auto st = sim5->get_rigid_state(1);
+    CHECK(std::fabs(st[12] - 3.0f) < 1e-4f && std::fabs(st[10]) < 1e-5f && std::fabs(st[11]) < 1e-5f);  // angular velocity = (0, 0, 3)
+    CHECK(std::fabs(st[0] - 0.5f) < 1e-5f && std::fabs(st[1] - 0.5f) < 1e-5f);                          // the hinge holds the centre
+  }
   // device constitutive code through the particle surface: F = I => zero force; plasticity(cdg) = F <- cdg F for jelly
   MPMParticle p;
   p.type = create_particle_type("jelly", Config(), 1.0f, 1e-6f);
