@@ -404,6 +404,10 @@ typedef struct mpmhip2d_rigid_config {
 } mpmhip2d_rigid_config;
 int mpmhip2d_set_rigid_coupling(mpmhip2d_ctx *ctx, float penalty, float pushing_force);
 int mpmhip2d_add_rigid_body(mpmhip2d_ctx *ctx, const mpmhip2d_rigid_config *cfg, int64_t n_segments, const float *segments /* n x 4 */);
+/* joints in 2D: type = MPMHIP_JOINT_ROTATION only (scripts/mls-cpic/sand_wheel_2D.py:88); struct below, in the CPIC section */
+struct mpmhip_joint_config;
+int mpmhip2d_add_articulation(mpmhip2d_ctx *ctx, const struct mpmhip_joint_config *cfg);
+int mpmhip2d_set_articulation_iterations(mpmhip2d_ctx *ctx, int32_t n);
 int mpmhip2d_rigid_get_state(mpmhip2d_ctx *ctx, int32_t id, float *out /* [10]: pos 2, angle, vel 2, omega, mass, inv_mass, inertia, inv_inertia */);
 int64_t mpmhip2d_rigid_get_samples(mpmhip2d_ctx *ctx, int32_t id, int64_t capacity, float *position);
 int64_t mpmhip2d_rigid_get_mesh(mpmhip2d_ctx *ctx, int32_t id, int64_t capacity_segments, float *segments /* n x 4, world space */);

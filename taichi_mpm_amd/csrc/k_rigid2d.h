@@ -200,6 +200,21 @@ __global__ __launch_bounds__(256) void k2_gather_cdf(int res0, int res1, float d
   R.bnd[p] = out;
 }
 
+// MPM<2>::articulate (src/mpm.h:278-319) for the joint the reference's 2D scene uses (scripts/mls-cpic/sand_wheel_2D.py:88):
+// RotationArticulation<2>::project (src/articulation.cpp:34-41) — both bodies get the angular velocity (I0 w0 + I1 w1) / (I0 + I1).
+// One lane: the sweeps over the joints are a sequential chain (see k_joints.h).
+struct Joint2 { int obj0, obj1; float I0, I1; };
+constexpr int MAX_JOINTS2 = 16;
+struct Joints2 { int n; Joint2 j[MAX_JOINTS2]; };
+__global__ void k2_articulate(Rigid2 *rb, Joints2 J, int iterations) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int it = 0; it < iterations; it++)
+    for (int i = 0; i < J.n; i++) {
+      Rigid2 &A = rb[J.j[i].obj0], &B = rb[J.j[i].obj1];
+      const float w = (J.j[i].I0 * A.omega + J.j[i].I1 * B.omega) / (J.j[i].I0 + J.j[i].I1);
+      A.omega = w; B.omega = w;
+    }
+}
 __global__ void k2_rigid_apply_tmp(Rigid2 *rb, int nb) {
   const int b = threadIdx.x;
   if (b < 1 || b >= nb) return;

@@ -2042,6 +2042,8 @@ struct mpmhip2d_ctx {
   uint32_t *d_tags = nullptr, *d_states = nullptr;
   mpm2d::Bnd2 *d_bnd = nullptr;
   float penalty = 0.0f, pushing_force = 20000.0f;
+  mpm2d::Joints2 joints{};     // MPM<2>::articulations ('rotation' joints)
+  int joint_iterations = 100;  // 'articulation_iterations'
 };
 static thread_local std::string g_2d_create_error;
 static int fail2d(mpmhip2d_ctx *m, int code, const std::string &msg) {
@@ -2233,8 +2235,11 @@ int mpmhip2d_substep(mpmhip2d_ctx *m) {  // MPM<2>::substep, src/mpm.cpp:452-575
   const dim3 pg((unsigned)std::max<int64_t>((m->n + 255) / 256, 1)), gg((unsigned)((nodes + 255) / 256)), wg(256);
   HIPCHK2D(m, hipMemsetAsync(m->grid, 0, sizeof(float) * 3 * nodes, m->stream));
   const mpm2d::RigidArgs2 R = rigid_args2(m);
-  if (R.enabled)
+  if (R.enabled) {
+    if (m->joints.n)  // articulate, between the sort and rasterize_rigid_boundary (src/mpm.cpp:466-471)
+      hipLaunchKernelGGL(mpm2d::k2_articulate, dim3(1), dim3(64), 0, m->stream, m->d_rb, m->joints, m->joint_iterations);
     if (int rc = rigid2_pre(m)) return rc;
+  }
   if (m->n)
     hipLaunchKernelGGL(mpm2d::k_p2g, pg, wg, 0, m->stream, m->P, m->n, (const float *)m->x, m->v, (const float *)m->F,
                        (const float *)m->B, (const float *)m->aux, (const int32_t *)m->gid, (const int32_t *)m->pid,
@@ -2353,6 +2358,26 @@ int mpmhip2d_add_rigid_body(mpmhip2d_ctx *m, const mpmhip2d_rigid_config *cfg, i
   return body;
 }
 // out[10]: position 2, angle (radians), velocity 2, angular velocity, mass, inv_mass, inertia, inv_inertia
+// general_action("add_articulation") of MPM<2>: the 'rotation' joint (the only one the reference's 2D scenes use; its 'frozen' and
+// 'stepper' are TC_NOT_IMPLEMENTED for dim = 2, src/articulation.cpp:65-67,317)
+int mpmhip2d_add_articulation(mpmhip2d_ctx *m, const mpmhip_joint_config *cfg) {
+  if (!m || !cfg) return MPMHIP_EINVAL;
+  const int nb = m->rigid_enabled ? (int)m->bodies.size() : 0;
+  if (cfg->type != MPMHIP_JOINT_ROTATION) return fail2d(m, MPMHIP_EINVAL, "add_articulation: only type='rotation' is built for 2D simulations");
+  if (cfg->obj0 < 1 || cfg->obj0 >= nb) return fail2d(m, MPMHIP_EINVAL, "add_articulation: obj0 = " + std::to_string(cfg->obj0) + " is not a rigid body of this simulation");
+  if (cfg->obj1 < 0 || cfg->obj1 >= nb) return fail2d(m, MPMHIP_EINVAL, "add_articulation: obj1 = " + std::to_string(cfg->obj1) + " is not a rigid body of this simulation");
+  if (m->joints.n >= mpm2d::MAX_JOINTS2) return fail2d(m, MPMHIP_ECAPACITY, "at most " + std::to_string(mpm2d::MAX_JOINTS2) + " articulations");
+  mpm2d::Joint2 &J = m->joints.j[m->joints.n++];
+  J.obj0 = cfg->obj0; J.obj1 = cfg->obj1;
+  J.I0 = m->bodies[cfg->obj0].inertia;
+  J.I1 = cfg->obj1 == 0 ? 1.0f : m->bodies[cfg->obj1].inertia;  // (the background body: inertia 1, set_as_background)
+  return MPMHIP_OK;
+}
+int mpmhip2d_set_articulation_iterations(mpmhip2d_ctx *m, int32_t n) {
+  if (!m || n < 0) return MPMHIP_EINVAL;
+  m->joint_iterations = n;
+  return MPMHIP_OK;
+}
 int mpmhip2d_rigid_get_state(mpmhip2d_ctx *m, int32_t id, float *out) {
   if (!m || !out) return MPMHIP_EINVAL;
   if (!m->rigid_enabled || id < 1 || id >= (int)m->bodies.size()) return fail2d(m, MPMHIP_EINVAL, "no such rigid body");

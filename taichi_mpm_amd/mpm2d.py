@@ -77,6 +77,7 @@ class Simulation2D:
             raise MPMError("mpmhip2d_create failed (%d): %s" % (rc, self._L.mpmhip2d_last_error(None).decode()))
         self._ctx = ctx
         self._check(self._L.mpmhip2d_set_rigid_coupling(ctx, float(cfg.get("penalty", 0.0)), float(cfg.get("pushing_force", 20000.0))))
+        self._check(self._L.mpmhip2d_set_articulation_iterations(ctx, int(cfg.get("articulation_iterations", 100))))  # src/mpm.h:279-280
         self._apply_levelset()
         for gi, (mat, params, arrs) in enumerate(self._staged):
             self._add(mat, params, *arrs)
@@ -326,7 +327,22 @@ class Simulation2D:
     def get_mpi_world_rank(self):
         return 0
 
+    def add_articulation(self, cfg):
+        """general_action(action='add_articulation', type='rotation', obj0=, obj1=) (src/mpm.cpp:923-933; the joint of
+        scripts/mls-cpic/sand_wheel_2D.py:88): both bodies share one angular velocity.  The other joint types are 3D only."""
+        if cfg.get("type") != "rotation":
+            raise MPMError("add_articulation(type=%r): only 'rotation' is built for 2D simulations" % (cfg.get("type"),))
+        if "obj0" not in cfg:
+            raise MPMError("add_articulation needs 'obj0'")
+        j = _lib.JointConfig()
+        j.type, j.obj0, j.obj1 = 0, int(cfg["obj0"]), int(cfg.get("obj1", 0))
+        self._ensure_ctx()
+        self._check(self._L.mpmhip2d_add_articulation(self._ctx, C.byref(j)))
+        return ""
+
     def general_action(self, config):
+        if config.get("action") == "add_articulation":
+            return self.add_articulation(config)
         raise MPMError("general_action(%r) is not part of the 2D build" % (config.get("action"),))
 
     def visualize(self):

@@ -544,3 +544,44 @@ def test_articulation_api_refuses_what_it_cannot_do(tm):
         with pytest.raises(MPMError, match=msg):
             sim.general_action(dict(action="add_articulation", **bad))
     sim.close()
+
+
+def test_2d_rotation_joint_matches_the_live_reference(tm):
+    """the joint of scripts/mls-cpic/sand_wheel_2D.py:88 — two 2D bodies sharing one angular velocity — over whole
+    substeps in a block of jelly, next to the compiled reference (MPM<2>)"""
+    from oracle import refmpm
+    if not refmpm.available():
+        pytest.skip("oracle/_ref/libmpm_ref.so did not travel to this box")
+    from oracle import oracle as orc
+    refmpm.set_threads(1)
+    x, v = cs.block2()
+    bodies = [dict(mesh=cs.box2(0.07, 0.04), codimensional=False, density=400.0, friction=0.3, initial_position=(0.44, 0.50),
+                   initial_rotation=25.0, initial_velocity=(0.2, -0.3), initial_angular_velocity=3.0),
+              dict(mesh=cs.bar2(0.09), codimensional=True, density=60.0, friction=0.3, initial_position=(0.585, 0.56),
+                   initial_rotation=-40.0, initial_velocity=(-0.1, -0.2), initial_angular_velocity=-1.0)]
+    ref = refmpm.Sim(cs.RES2, cs.DX2, cs.DT, dim=2, gravity=(0, -10), penalty=1e3)
+    sim = tm.create_simulation2("mpm").initialize(dict(res=(cs.RES2,) * 2, delta_x=cs.DX2, base_delta_t=cs.DT, gravity=(0, -10),
+                                                       max_particles=len(x) + 16, penalty=1e3))
+    for b in bodies:
+        kw = dict(b)
+        ref.add_rigid2(kw.pop("mesh"), **kw)
+        sim.add_particles(dict(type="rigid", **b))
+    ref.general_action(action="add_articulation", type="rotation", obj0=1, obj1=2)
+    assert sim.general_action(dict(action="add_articulation", type="rotation", obj0=1, obj1=2)) == ""
+    from taichi_mpm_amd.mpm import MPMError
+    with pytest.raises(MPMError, match="rotation"):
+        sim.general_action(dict(action="add_articulation", type="motor", obj0=1, obj1=2))
+    ref.add_particles("jelly", cs.MASS2, cs.VOL2, x, v)
+    sim.add_particles(dict(type="jelly", positions=x, velocities=v, params=orc.group_params("jelly", cs.MASS2, cs.VOL2)[0]))
+    ref.substep(12)
+    sim.run_substeps(12)
+    r, h = ref.download(by_id=True), sim.get_particles(sort_by_id=True)
+    assert len(h["x"]) == len(r["x"])
+    assert np.abs(h["x"] - r["x"]).max() <= 5e-6
+    assert rel_l2(h["v"], r["v"]) <= 2e-4
+    states = [(ref.rigid_state2(rid), sim.get_rigid_state(rid)) for rid in (1, 2)]
+    for a, b in states:
+        np.testing.assert_allclose(b[0:3], a[0:3], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(b[3:5], a[3:5], rtol=0, atol=2e-4 * max(np.abs(a[3:5]).max(), 1e-2))
+        np.testing.assert_allclose(b[5], a[5], rtol=0, atol=2e-4 * max(abs(a[5]), 1e-1))
+    assert abs(states[1][0][5] + 1.0) > 0.5  # the joint really changed the bar's spin (-1 at the start)
