@@ -37,6 +37,7 @@ struct JointBody {
   float R[9];      // body -> world, row-major
   float inv_mass;
   float inv_I[9];  // body frame, row-major
+  float Iw[9];     // world-frame inverse inertia R inv_I R^T: filled by articulate()
 };
 struct JointDev {
   int type, obj0, obj1, n_dist;  // n_dist: distance constraints in use (distance: 1, axial / motor / stepper: 2)
@@ -72,31 +73,31 @@ MPM_HD void j_inverse3(const float m[9], float o[9]) {
   o[3] = c1 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
   o[6] = c2 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
 }
-// RigidBody::apply_torque / apply_impulse / get_velocity_at / get_impulse_contribution
+// RigidBody::apply_torque / apply_impulse / get_velocity_at / get_impulse_contribution.  The bodies do not move while
+// MPM::articulate runs (only velocities change), so everything that depends on the poses alone is computed ONCE per call:
+// a body's world-frame inverse inertia (JointBody::Iw) and, per joint, the anchors, their connection, the impulse
+// denominators, the world-frame axis and the combined inertias (JointPre).  The sweeps then only move velocities:
+// 264 -> 108 us per hinge and articulate() of 100 sweeps on one lane of an MI355X (profiles/joint_cost.py), same arithmetic.
 MPM_HD void j_apply_torque(JointBody &B, const float t[3]) {
-  float Iw[9], d[3];
-  j_to_world(B.R, B.inv_I, Iw);
-  j_mat_vec(Iw, t, d);
+  float d[3];
+  j_mat_vec(B.Iw, t, d);
   for (int k = 0; k < 3; k++) B.omega[k] += d[k];
 }
-MPM_HD void j_apply_impulse(JointBody &B, const float imp[3], const float at[3]) {
+MPM_HD void j_apply_impulse(JointBody &B, const float imp[3], const float r[3]) {  // r = point of attack - centre of mass
   for (int k = 0; k < 3; k++) B.vel[k] += imp[k] * B.inv_mass;
-  const float r[3] = {at[0] - B.pos[0], at[1] - B.pos[1], at[2] - B.pos[2]};
   float t[3];
   j_cross(r, imp, t);
   j_apply_torque(B, t);
 }
-MPM_HD void j_velocity_at(const JointBody &B, const float p[3], float o[3]) {
-  const float r[3] = {p[0] - B.pos[0], p[1] - B.pos[1], p[2] - B.pos[2]};
+MPM_HD void j_velocity_at(const JointBody &B, const float r[3], float o[3]) {  // r as above
   float c[3];
   j_cross(B.omega, r, c);
   for (int k = 0; k < 3; k++) o[k] = B.vel[k] + c[k];
 }
 MPM_HD float j_impulse_contribution(const JointBody &B, const float r[3], const float n[3]) {
-  float Iw[9], rn[3], t[3], u[3];
-  j_to_world(B.R, B.inv_I, Iw);
+  float rn[3], t[3], u[3];
   j_cross(r, n, rn);
-  j_mat_vec(Iw, rn, t);
+  j_mat_vec(B.Iw, rn, t);
   j_cross(t, r, u);
   return B.inv_mass + j_dot(u, n);
 }
@@ -105,62 +106,78 @@ MPM_HD void j_anchor(const JointBody &B, const float off[3], float p[3]) {  // t
   for (int k = 0; k < 3; k++) p[k] += B.pos[k];
 }
 
-// DistanceArticulation::project (:143-161) / penalize (:124-141) for constraint d of joint J
-MPM_HD bool j_distance_frame(const JointDev &J, int d, const JointBody &A, const JointBody &B, float p0[3], float p1[3], float n[3],
-                             float &dist) {
-  j_anchor(A, J.off[d][0], p0);
-  j_anchor(B, J.off[d][1], p1);
-  for (int k = 0; k < 3; k++) n[k] = p0[k] - p1[k];
-  dist = sqrtf(j_dot(n, n));
-  if (dist < 1e-10f) return false;
-  const float il = 1.0f / dist;
-  for (int k = 0; k < 3; k++) n[k] *= il;
-  return true;
-}
-MPM_HD void j_distance_project(const JointDev &J, int d, JointBody &A, JointBody &B) {
-  float p0[3], p1[3], n[3], dist;
-  if (!j_distance_frame(J, d, A, B, p0, p1, n, dist)) return;
-  float va[3], vb[3];
-  j_velocity_at(A, p0, va);
-  j_velocity_at(B, p1, vb);
-  const float v01[3] = {va[0] - vb[0], va[1] - vb[1], va[2] - vb[2]};
-  const float r0[3] = {p0[0] - A.pos[0], p0[1] - A.pos[1], p0[2] - A.pos[2]};
-  const float r1[3] = {p1[0] - B.pos[0], p1[1] - B.pos[1], p1[2] - B.pos[2]};
-  const float j = j_dot(n, v01) / (j_impulse_contribution(A, r0, n) + j_impulse_contribution(B, r1, n));
-  const float ia[3] = {-j * n[0], -j * n[1], -j * n[2]}, ib[3] = {j * n[0], j * n[1], j * n[2]};
-  j_apply_impulse(A, ia, p0);
-  j_apply_impulse(B, ib, p1);
-}
-MPM_HD void j_distance_penalize(const JointDev &J, int d, JointBody &A, JointBody &B, float dt) {
-  float p0[3], p1[3], n[3], dist;
-  if (!j_distance_frame(J, d, A, B, p0, p1, n, dist)) return;
-  const float j = -dt * J.penalty * (J.target[d] - dist);
-  const float ia[3] = {-j * n[0], -j * n[1], -j * n[2]}, ib[3] = {j * n[0], j * n[1], j * n[2]};
-  j_apply_impulse(A, ia, p0);
-  j_apply_impulse(B, ib, p1);
+// what one articulate() call computes once per joint
+struct DistPre { int active; float n[3], r0[3], r1[3], dist, den; };  // active = 0: the anchors coincide (distance < 1e-10)
+struct JointPre {
+  DistPre d[2];
+  float aw[3];             // motor: the axis in the world frame; stepper: the same, normalised
+  float M0[9], M1[9];      // rotation: the bodies' world-frame inertias
+  float Si[9];             // rotation: (M0 + M1)^-1;  stepper: (Iw0 + Iw1)^-1
+};
+MPM_HD void joint_prepare(const JointDev &J, const JointBody &A, const JointBody &B, JointPre &P) {
+  for (int d = 0; d < J.n_dist; d++) {  // DistanceArticulation::project / penalize up to the velocities (:124-135, :143-155)
+    DistPre &D = P.d[d];
+    float p0[3], p1[3];
+    j_anchor(A, J.off[d][0], p0);
+    j_anchor(B, J.off[d][1], p1);
+    for (int k = 0; k < 3; k++) D.n[k] = p0[k] - p1[k];
+    D.dist = sqrtf(j_dot(D.n, D.n));
+    D.active = !(D.dist < 1e-10f);
+    if (!D.active) continue;
+    const float il = 1.0f / D.dist;
+    for (int k = 0; k < 3; k++) { D.n[k] *= il; D.r0[k] = p0[k] - A.pos[k]; D.r1[k] = p1[k] - B.pos[k]; }
+    D.den = j_impulse_contribution(A, D.r0, D.n) + j_impulse_contribution(B, D.r1, D.n);
+  }
+  if (J.type == JOINT_MOTOR || J.type == JOINT_STEPPER) j_mat_vec(B.R, J.axis, P.aw);  // transform(obj[1]->get_centroid_to_world(), axis, 0)
+  if (J.type == JOINT_STEPPER) {
+    const float il = 1.0f / sqrtf(j_dot(P.aw, P.aw));
+    for (int k = 0; k < 3; k++) P.aw[k] *= il;
+    float S[9];
+    for (int k = 0; k < 9; k++) S[k] = A.Iw[k] + B.Iw[k];
+    j_inverse3(S, P.Si);
+  }
+  if (J.type == JOINT_ROTATION) {
+    float S[9];
+    j_to_world(A.R, J.I[0], P.M0);
+    j_to_world(B.R, J.I[1], P.M1);
+    for (int k = 0; k < 9; k++) S[k] = P.M0[k] + P.M1[k];
+    j_inverse3(S, P.Si);
+  }
 }
 
-MPM_HD void joint_apply(const JointDev &J, JointBody &A, JointBody &B, float dt) {
+MPM_HD void j_distance_project(const DistPre &D, JointBody &A, JointBody &B) {
+  if (!D.active) return;
+  float va[3], vb[3];
+  j_velocity_at(A, D.r0, va);
+  j_velocity_at(B, D.r1, vb);
+  const float v01[3] = {va[0] - vb[0], va[1] - vb[1], va[2] - vb[2]};
+  const float j = j_dot(D.n, v01) / D.den;
+  const float ia[3] = {-j * D.n[0], -j * D.n[1], -j * D.n[2]}, ib[3] = {j * D.n[0], j * D.n[1], j * D.n[2]};
+  j_apply_impulse(A, ia, D.r0);
+  j_apply_impulse(B, ib, D.r1);
+}
+MPM_HD void j_distance_penalize(const JointDev &J, int d, const DistPre &D, JointBody &A, JointBody &B, float dt) {
+  if (!D.active) return;
+  const float j = -dt * J.penalty * (J.target[d] - D.dist);
+  const float ia[3] = {-j * D.n[0], -j * D.n[1], -j * D.n[2]}, ib[3] = {j * D.n[0], j * D.n[1], j * D.n[2]};
+  j_apply_impulse(A, ia, D.r0);
+  j_apply_impulse(B, ib, D.r1);
+}
+
+MPM_HD void joint_apply(const JointDev &J, const JointPre &P, JointBody &A, JointBody &B, float dt) {
   if (J.type != JOINT_MOTOR) return;  // (the stepper forwards to AxialRotationArticulation::apply, which does nothing)
-  float aw[3];
-  j_mat_vec(B.R, J.axis, aw);  // transform(obj[1]->get_centroid_to_world(), axis, 0)
-  const float t[3] = {aw[0] * J.power * dt, aw[1] * J.power * dt, aw[2] * J.power * dt};
+  const float t[3] = {P.aw[0] * J.power * dt, P.aw[1] * J.power * dt, P.aw[2] * J.power * dt};
   const float nt[3] = {-t[0], -t[1], -t[2]};
   j_apply_torque(A, t);
   j_apply_torque(B, nt);
 }
-MPM_HD void joint_project(const JointDev &J, JointBody &A, JointBody &B) {
+MPM_HD void joint_project(const JointDev &J, const JointPre &P, JointBody &A, JointBody &B) {
   if (J.type == JOINT_ROTATION) {
-    float I0[9], I1[9], L0[3], L1[3], S[9], Si[9];
-    j_to_world(A.R, J.I[0], I0);
-    j_to_world(B.R, J.I[1], I1);
-    j_mat_vec(I0, A.omega, L0);
-    j_mat_vec(I1, B.omega, L1);
-    for (int k = 0; k < 9; k++) S[k] = I0[k] + I1[k];
+    float L0[3], L1[3], w[3];
+    j_mat_vec(P.M0, A.omega, L0);
+    j_mat_vec(P.M1, B.omega, L1);
     const float L[3] = {L0[0] + L1[0], L0[1] + L1[1], L0[2] + L1[2]};
-    j_inverse3(S, Si);
-    float w[3];
-    j_mat_vec(Si, L, w);
+    j_mat_vec(P.Si, L, w);
     for (int k = 0; k < 3; k++) A.omega[k] = B.omega[k] = w[k];
     return;
   }
@@ -168,37 +185,31 @@ MPM_HD void joint_project(const JointDev &J, JointBody &A, JointBody &B) {
     A.omega[0] = 0.0f; A.omega[1] = 0.0f; A.vel[2] = 0.0f;
     return;
   }
-  for (int d = 0; d < J.n_dist; d++) j_distance_project(J, d, A, B);
+  for (int d = 0; d < J.n_dist; d++) j_distance_project(P.d[d], A, B);
   if (J.type == JOINT_STEPPER) {
-    float aw[3];
-    j_mat_vec(B.R, J.axis, aw);
-    const float il = 1.0f / sqrtf(j_dot(aw, aw));
-    for (int k = 0; k < 3; k++) aw[k] *= il;
     const float rel[3] = {A.omega[0] - B.omega[0], A.omega[1] - B.omega[1], A.omega[2] - B.omega[2]};
-    const float corr = J.angular_velocity - j_dot(rel, aw);
-    float Ia[9], Ib[9], S[9], Si[9], t[3];
-    j_to_world(A.R, A.inv_I, Ia);
-    j_to_world(B.R, B.inv_I, Ib);
-    for (int k = 0; k < 9; k++) S[k] = Ia[k] + Ib[k];
-    j_inverse3(S, Si);
-    const float ac[3] = {aw[0] * corr, aw[1] * corr, aw[2] * corr};
-    j_mat_vec(Si, ac, t);
+    const float corr = J.angular_velocity - j_dot(rel, P.aw);
+    const float ac[3] = {P.aw[0] * corr, P.aw[1] * corr, P.aw[2] * corr};
+    float t[3];
+    j_mat_vec(P.Si, ac, t);
     const float nt[3] = {-t[0], -t[1], -t[2]};
     j_apply_torque(A, t);
     j_apply_torque(B, nt);
   }
 }
-MPM_HD void joint_penalize(const JointDev &J, JointBody &A, JointBody &B, float dt) {
+MPM_HD void joint_penalize(const JointDev &J, const JointPre &P, JointBody &A, JointBody &B, float dt) {
   if (J.type < JOINT_DISTANCE) return;
-  for (int d = 0; d < J.n_dist; d++) j_distance_penalize(J, d, A, B, dt);
+  for (int d = 0; d < J.n_dist; d++) j_distance_penalize(J, d, P.d[d], A, B, dt);
 }
 
-// MPM::articulate (src/mpm.h:278-319) on the bodies b[0 .. nb): b[0] is the background body
-MPM_HD void articulate(JointBody *b, const JointDev *joints, int nj, float dt, int iterations) {
-  for (int i = 0; i < nj; i++) joint_apply(joints[i], b[joints[i].obj0], b[joints[i].obj1], dt);
+// MPM::articulate (src/mpm.h:278-319) on the bodies b[0 .. nb): b[0] is the background body; pre: scratch, one per joint
+MPM_HD void articulate(JointBody *b, int nb, const JointDev *joints, JointPre *pre, int nj, float dt, int iterations) {
+  for (int i = 0; i < nb; i++) j_to_world(b[i].R, b[i].inv_I, b[i].Iw);
+  for (int i = 0; i < nj; i++) joint_prepare(joints[i], b[joints[i].obj0], b[joints[i].obj1], pre[i]);
+  for (int i = 0; i < nj; i++) joint_apply(joints[i], pre[i], b[joints[i].obj0], b[joints[i].obj1], dt);
   for (int it = 0; it < iterations; it++)
-    for (int i = 0; i < nj; i++) joint_project(joints[i], b[joints[i].obj0], b[joints[i].obj1]);
-  for (int i = 0; i < nj; i++) joint_penalize(joints[i], b[joints[i].obj0], b[joints[i].obj1], dt);
+    for (int i = 0; i < nj; i++) joint_project(joints[i], pre[i], b[joints[i].obj0], b[joints[i].obj1]);
+  for (int i = 0; i < nj; i++) joint_penalize(joints[i], pre[i], b[joints[i].obj0], b[joints[i].obj1], dt);
 }
 
 // ---- joint set-up (the initialize() methods), on the host with the bodies' current poses

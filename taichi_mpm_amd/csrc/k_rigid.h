@@ -480,6 +480,7 @@ __global__ __launch_bounds__(256) void k_gather_cdf(Params P, CdfDev C, RecG *__
 __global__ __launch_bounds__(64) void k_articulate(RigidBodyDev *rb, int nb, const JointDev *__restrict__ joints, int nj, float dt,
                                                    int iterations) {
   __shared__ JointBody sb[MAX_RIGID];
+  __shared__ JointPre pre[MAX_JOINTS];
   const int t = threadIdx.x;
   if (t < nb) {
     const RigidBodyDev &B = rb[t];
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(64) void k_articulate(RigidBodyDev *rb, int nb, con
     J.inv_mass = B.inv_mass;
   }
   __syncthreads();
-  if (t == 0) articulate(sb, joints, nj, dt, iterations);
+  if (t == 0) articulate(sb, nb, joints, pre, nj, dt, iterations);
   __syncthreads();
   if (t < nb) {
     for (int k = 0; k < 3; k++) { rb[t].vel[k] = sb[t].vel[k]; rb[t].omega[k] = sb[t].omega[k]; }

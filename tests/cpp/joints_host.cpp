@@ -20,7 +20,8 @@ int joints_articulate(int nb, const mpm::JointBody *setup, mpm::JointBody *bodie
     if (c.obj0 < 0 || c.obj0 >= nb || c.obj1 < 0 || c.obj1 >= nb) return 1 + i;
     if (mpm::joint_init(joints[i], c, setup[c.obj0], setup[c.obj1], inertia + 9 * c.obj0, inertia + 9 * c.obj1)) return 1 + i;
   }
-  mpm::articulate(bodies, joints.data(), nj, dt, iterations);
+  std::vector<mpm::JointPre> pre(nj);
+  mpm::articulate(bodies, nb, joints.data(), pre.data(), nj, dt, iterations);
   return 0;
 }
 }

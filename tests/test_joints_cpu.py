@@ -19,7 +19,7 @@ JOINT_TYPES = {"rotation": 0, "frozen": 1, "distance": 2, "axial_rotation": 3, "
 
 class JointBody(C.Structure):
     _fields_ = [("pos", C.c_float * 3), ("vel", C.c_float * 3), ("omega", C.c_float * 3), ("R", C.c_float * 9),
-                ("inv_mass", C.c_float), ("inv_I", C.c_float * 9)]
+                ("inv_mass", C.c_float), ("inv_I", C.c_float * 9), ("Iw", C.c_float * 9)]
 
 
 class JointConfig(C.Structure):
