@@ -179,3 +179,16 @@ def test_bench_and_examples_are_importable_without_a_gpu():
     assert bench.pmc_traffic("c2", "k_g2p") == (None, None)
     for f in ("benchmark_3d.py", "sand_column.py"):
         py_compile.compile(os.path.join(root, "examples", f), doraise=True)
+
+
+def test_unknown_articulations_are_refused_before_anything_runs():
+    """general_action(action='add_articulation'): the type is checked like create_instance does for an unregistered alias
+    (src/mpm.cpp:930-932); 2D knows the rotation joint only"""
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(32, 32, 32)))
+    with pytest.raises(tm.MPMError, match="unknown articulation type"):
+        sim.general_action(dict(action="add_articulation", type="hinge", obj0=1))
+    with pytest.raises(tm.MPMError, match="obj0"):
+        sim.general_action(dict(action="add_articulation", type="rotation"))
+    sim2 = tm.create_simulation2("mpm").initialize(dict(res=(32, 32)))
+    with pytest.raises(tm.MPMError, match="only 'rotation'"):
+        sim2.general_action(dict(action="add_articulation", type="motor", obj0=1, obj1=2))
