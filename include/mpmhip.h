@@ -177,7 +177,9 @@ int mpmhip_upload_grid(mpmhip_ctx *ctx, const float *src);
  * (src/mpm.cpp:940-960, src/mpm.h:38-54,134-169).  The blob holds the raw particle records (with the P2G affine
  * matrices), the group table and the clocks; it loads into a ctx of the same grid with enough capacity, which then
  * continues exactly where the saved run stopped.  Level set and config are NOT part of it (the reference re-reads
- * them from the scene script too). */
+ * them from the scene script too). 
+ * A scene with rigid bodies: the blob also carries the bodies' records (pose, velocities, mass properties) and the joints;
+ * meshes, boundary particles and scripts come from the scene again — add the same bodies, in the same order, before loading. */
 int64_t mpmhip_snapshot_size(mpmhip_ctx *ctx);
 int mpmhip_snapshot_save(mpmhip_ctx *ctx, void *dst, size_t capacity);
 int mpmhip_snapshot_load(mpmhip_ctx *ctx, const void *src, size_t size);

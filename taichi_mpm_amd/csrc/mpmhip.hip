@@ -1152,9 +1152,18 @@ struct SnapHeader {
   uint32_t n_dead, pad;
 };
 
+// scenes with rigid bodies append the bodies' records (pose, velocities, mass properties) and the joints: meshes, boundary
+// particles and scripts come from the scene again (the script adds the same bodies before it loads), like the level set
+struct SnapRigid {
+  char magic[8];  // "MPMRIGID"
+  uint32_t n_bodies, n_joints, sizeof_body, sizeof_joint;
+};
+static size_t snapshot_rigid_bytes(const mpmhip_ctx *c) {
+  return rigid_active(c) ? sizeof(SnapRigid) + sizeof(RigidBodyDev) * c->rigid.bodies.size() + sizeof(JointDev) * c->rigid.joints.size() : 0;
+}
 static size_t snapshot_bytes(const mpmhip_ctx *c) {
   return sizeof(SnapHeader) + sizeof(GroupParams) * c->groups.size() +
-         (size_t)c->n_slots * (sizeof(RecG) + sizeof(RecP) + sizeof(float) * BW);
+         (size_t)c->n_slots * (sizeof(RecG) + sizeof(RecP) + sizeof(float) * BW) + snapshot_rigid_bytes(c);
 }
 
 int64_t mpmhip_snapshot_size(mpmhip_ctx *c) { return c ? (int64_t)snapshot_bytes(c) : MPMHIP_EINVAL; }
@@ -1163,8 +1172,6 @@ int mpmhip_snapshot_save(mpmhip_ctx *c, void *dst, size_t cap) {
   if (!c || !dst) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   if (c->in_substep) return fail(c, MPMHIP_EINVAL, "snapshot inside a substep");
-  if (c->rigid.enabled && c->rigid.bodies.size() > 1)
-    return fail(c, MPMHIP_ENOTIMPL, "snapshots do not carry rigid bodies (meshes, scripts and poses would have to come from the scene again)");
   if (cap < snapshot_bytes(c)) return fail(c, MPMHIP_ECAPACITY, "snapshot buffer too small: %zu < %zu", cap, snapshot_bytes(c));
   Counters hc;
   int rc = read_counters(c, hc);
@@ -1189,7 +1196,16 @@ int mpmhip_snapshot_save(mpmhip_ctx *c, void *dst, size_t cap) {
   if (n) {
     HIPCHK(c, hipMemcpy(p, c->rg, sizeof(RecG) * n, hipMemcpyDeviceToHost)); p += sizeof(RecG) * n;
     HIPCHK(c, hipMemcpy(p, c->rp, sizeof(RecP) * n, hipMemcpyDeviceToHost)); p += sizeof(RecP) * n;
-    HIPCHK(c, hipMemcpy(p, c->rb, sizeof(float) * BW * n, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(p, c->rb, sizeof(float) * BW * n, hipMemcpyDeviceToHost)); p += sizeof(float) * BW * n;
+  }
+  if (rigid_active(c)) {
+    SnapRigid r;
+    memcpy(r.magic, "MPMRIGID", 8);
+    r.n_bodies = (uint32_t)c->rigid.bodies.size(); r.n_joints = (uint32_t)c->rigid.joints.size();
+    r.sizeof_body = (uint32_t)sizeof(RigidBodyDev); r.sizeof_joint = (uint32_t)sizeof(JointDev);
+    memcpy(p, &r, sizeof r); p += sizeof r;
+    HIPCHK(c, hipMemcpy(p, c->rigid.d_rb, sizeof(RigidBodyDev) * r.n_bodies, hipMemcpyDeviceToHost)); p += sizeof(RigidBodyDev) * r.n_bodies;
+    if (r.n_joints) memcpy(p, c->rigid.joints.data(), sizeof(JointDev) * r.n_joints);
   }
   return MPMHIP_OK;
 }
@@ -1209,8 +1225,23 @@ int mpmhip_snapshot_load(mpmhip_ctx *c, const void *src, size_t size) {
   if (h.n_slots < 0 || h.n_slots > c->cap) return fail(c, MPMHIP_ECAPACITY, "snapshot holds %lld particle slots, capacity is %lld", (long long)h.n_slots, (long long)c->cap);
   if ((int)h.n_groups > c->groups_cap) return fail(c, MPMHIP_ECAPACITY, "snapshot holds %u groups", h.n_groups);
   const size_t n = (size_t)h.n_slots;
-  if (size < sizeof h + sizeof(GroupParams) * h.n_groups + n * (sizeof(RecG) + sizeof(RecP) + sizeof(float) * BW))
-    return fail(c, MPMHIP_EINVAL, "snapshot is truncated");
+  const size_t base = sizeof h + sizeof(GroupParams) * h.n_groups + n * (sizeof(RecG) + sizeof(RecP) + sizeof(float) * BW);
+  if (size < base) return fail(c, MPMHIP_EINVAL, "snapshot is truncated");
+  // the rigid section: the scene must have added the same bodies (meshes, scripts) before it loads
+  SnapRigid sr;
+  memset(&sr, 0, sizeof sr);
+  const bool has_rigid = size >= base + sizeof sr && memcmp((const char *)src + base, "MPMRIGID", 8) == 0;
+  if (has_rigid) {
+    memcpy(&sr, (const char *)src + base, sizeof sr);
+    if (sr.sizeof_body != sizeof(RigidBodyDev) || sr.sizeof_joint != sizeof(JointDev) || sr.n_joints > (uint32_t)MAX_JOINTS ||
+        size < base + sizeof sr + (size_t)sr.sizeof_body * sr.n_bodies + (size_t)sr.sizeof_joint * sr.n_joints)
+      return fail(c, MPMHIP_EINVAL, "snapshot: the rigid-body section is damaged or of another build");
+    if (!rigid_active(c) || c->rigid.bodies.size() != sr.n_bodies)
+      return fail(c, MPMHIP_EINVAL, "snapshot holds %u rigid bodies: add the scene's bodies (same meshes, same order) before loading",
+                  sr.n_bodies - 1);
+  } else if (rigid_active(c)) {
+    return fail(c, MPMHIP_EINVAL, "snapshot holds no rigid bodies, this simulation has %d", (int)c->rigid.bodies.size() - 1);
+  }
   {
     const RecG *srg = reinterpret_cast<const RecG *>((const char *)src + sizeof h + sizeof(GroupParams) * h.n_groups);
     for (size_t i = 0; i < n; i++)
@@ -1242,6 +1273,12 @@ int mpmhip_snapshot_load(mpmhip_ctx *c, const void *src, size_t size) {
   memset(&hc, 0, sizeof hc);
   hc.n_dead = h.n_dead;
   HIPCHK(c, hipMemcpy(c->cnt, &hc, sizeof hc, hipMemcpyHostToDevice));
+  if (has_rigid) {  // poses, velocities and joints of the saved run; colours travel in the records, the CDF is rebuilt every substep
+    const char *q = (const char *)src + base + sizeof sr;
+    HIPCHK(c, hipMemcpy(c->rigid.d_rb, q, sizeof(RigidBodyDev) * sr.n_bodies, hipMemcpyHostToDevice)); q += sizeof(RigidBodyDev) * sr.n_bodies;
+    c->rigid.joints.assign((const JointDev *)q, (const JointDev *)q + sr.n_joints);
+    if (sr.n_joints) HIPCHK(c, hipMemcpy(c->rigid.d_joints, c->rigid.joints.data(), sizeof(JointDev) * sr.n_joints, hipMemcpyHostToDevice));
+  }
   return MPMHIP_OK;
 }
 

@@ -703,6 +703,9 @@ class Simulation3D:
         blob = np.ascontiguousarray(raw[8:])
         n_groups = int(blob[12:16].view(np.uint32)[0])
         n_slots = int(blob[16:24].view(np.int64)[0])
+        if self._ctx is not None and n_slots > self._capacity and getattr(self, "_pinned_by", None):
+            raise MPMError("the snapshot holds %d particles, this simulation's capacity is %d and cannot grow: it is pinned by %s "
+                           "(set max_particles)" % (n_slots, self._capacity, self._pinned_by))
         if self._ctx is None or n_slots > self._capacity:
             if self._ctx is not None:
                 self._L.mpmhip_destroy(self._ctx)

@@ -316,8 +316,6 @@ def test_rigid_api_refuses_what_it_cannot_do(tm):
     x, v = cs.block_of_particles()
     sim.add_particles(dict(type="jelly", positions=x[:1000], velocities=v[:1000]))
     sim.run_substeps(2)
-    with pytest.raises(MPMError, match="rigid"):  # snapshots do not carry rigid bodies
-        sim.general_action(dict(action="save", file_name="/tmp/never_written.bin"))
     with pytest.raises(MPMError, match="grow"):  # the bodies' state lives in the ctx: it cannot be re-created to grow
         sim.add_particles(dict(type="jelly", positions=np.tile(x, (2, 1))))
     for k in range(10):  # 11 bodies fit the 24 colour bits (2 per body, body 0 = background)
@@ -585,3 +583,51 @@ def test_2d_rotation_joint_matches_the_live_reference(tm):
         np.testing.assert_allclose(b[3:5], a[3:5], rtol=0, atol=2e-4 * max(np.abs(a[3:5]).max(), 1e-2))
         np.testing.assert_allclose(b[5], a[5], rtol=0, atol=2e-4 * max(abs(a[5]), 1e-1))
     assert abs(states[1][0][5] + 1.0) > 0.5  # the joint really changed the bar's spin (-1 at the start)
+
+
+def test_snapshot_restart_with_bodies_and_a_joint_continues_the_run(tm, tmp_path):
+    """general_action save / load (src/mpm.cpp:940-960) in a scene with rigid bodies: the blob carries the bodies' records
+    and the joints; meshes and scripts come from the scene again (it adds the same bodies before it loads)"""
+    from taichi_mpm_amd.mpm import MPMError
+    x, v = cs.block_of_particles()
+    s = cs.SCRIPT
+    f32 = np.float32
+    p0 = (0.58, 0.56, 0.55)
+
+    def scene(with_particles):
+        sim = tm.create_simulation3("mpm").initialize(dict(res=(cs.RES,) * 3, delta_x=cs.DX, base_delta_t=cs.DT, gravity=(0, -10, 0),
+                                                           max_particles=len(x) + 16, penalty=1e3))
+        box_cfg = dict(cs.BODIES["box"])
+        box_cfg["initial_position"] = (0.42, 0.47, 0.46)
+        sim.add_particles(dict(type="rigid", **box_cfg))
+        sim.add_particles(dict(
+            type="rigid", mesh=cs.plate(0.12), codimensional=True, friction=0.4,
+            scripted_position=lambda t: [f32(p0[k]) + f32(s["vel"][k]) * f32(t) + f32(s["amp"][k]) * f32(np.sin(f32(s["omega"]) * f32(t))) for k in range(3)],
+            scripted_rotation=lambda t: [f32(s["e0"][k]) + f32(s["rate"][k]) * f32(t) for k in range(3)]))
+        if with_particles:
+            sim.general_action(dict(action="add_articulation", type="distance", obj0=1, obj1=0, offset1=(0.45, 0.8, 0.5), penalty=2e3))
+            sim.add_particles(dict(type="sand", positions=x, velocities=v))
+        return sim
+    a = scene(True)
+    a.run_substeps(8)
+    path = str(tmp_path / "cpic_snap.bin")
+    assert a.general_action(dict(action="save", file_name=path)) == ""
+    a.run_substeps(8)
+    want, wb = a.get_particles(), [cs.rigid_vector(a.get_rigid_state(r)) for r in (1, 2)]
+    b = scene(False)  # the bodies of the scene, no particles, no joint: both come out of the blob
+    assert b.general_action(dict(action="load", file_name=path)) == ""
+    assert np.isclose(b.get_current_time(), 8 * cs.DT, rtol=1e-5)
+    b.run_substeps(8)
+    got = b.get_particles()
+    assert np.array_equal(got["id"], want["id"])
+    assert np.abs(got["x"] - want["x"]).max() <= 1e-6
+    assert rel_l2(got["v"], want["v"]) <= 1e-5
+    assert (got["states"] != want["states"]).sum() <= 2
+    for r, w in zip((1, 2), wb):
+        g = cs.rigid_vector(b.get_rigid_state(r))
+        np.testing.assert_allclose(g[0:7], w[0:7], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(g[7:13], w[7:13], rtol=0, atol=1e-5 * max(1.0, float(np.abs(w[7:13]).max())))
+    c = tm.create_simulation3("mpm").initialize(dict(res=(cs.RES,) * 3, delta_x=cs.DX, base_delta_t=cs.DT, max_particles=len(x) + 16))
+    with pytest.raises(MPMError, match="rigid bodies"):  # a scene without the bodies cannot take the blob
+        c.general_action(dict(action="load", file_name=path))
+    a.close(); b.close(); c.close()
