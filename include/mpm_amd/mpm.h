@@ -10,7 +10,8 @@
 // std::runtime_error with the library's message (reference: TC_ASSERT / TC_ERROR abort).
 // CPIC rigid bodies: add_rigid_body(config, triangles) = add_particles(type='rigid', ...) with the mesh handed over as
 // triangles; scripted motions are std::function<Vector(real)> like the reference's (src/mpm_rigid_body.cpp:79-92).
-// Out of scope, as in DESIGN.md §7: textures/meshes in add_particles (the mesh LOADER), rigid-rigid collisions, joints, rendering.
+// Joints: add_articulation(config) = general_action(action='add_articulation', ...) (src/mpm.cpp:923-933, src/articulation.cpp).
+// Out of scope, as in DESIGN.md §7: textures/meshes in add_particles (the mesh LOADER), rigid-rigid collisions, rendering.
 #pragma once
 #include <algorithm>
 #include <cstdio>

@@ -10,9 +10,10 @@ Two layers, as in the reference:
     `set_levelset`, `step`, `simulate`.
 
 Configs are flat dicts (reference: taichi `Config`, string->string; `P(**kwargs)`).  Errors raise `MPMError`
-(reference: TC_ASSERT / TC_ERROR abort).  Scene tooling the hot path does not need (textures, meshes, Poisson-disk
-sampling, rigid bodies, rendering) is out of scope: `add_particles` takes explicit `positions=` or the built-in
-`benchmark=` generator (src/mpm.cpp:149-186) or a `cube=(lo, hi)` lattice.
+(reference: TC_ASSERT / TC_ERROR abort).  Scene tooling the hot path does not need (textures, Poisson-disk sampling,
+rendering) is out of scope: `add_particles` takes explicit `positions=` or the built-in `benchmark=` generator
+(src/mpm.cpp:149-186) or a `cube=(lo, hi)` lattice; `type='rigid'` takes `mesh=` triangles or `mesh_fn='file.obj'`
+(CPIC rigid bodies, `add_rigid_body`), joints come through `general_action(action='add_articulation', ...)`.
 """
 import ctypes as C
 import json
