@@ -422,8 +422,8 @@ int64_t mpmhip2d_download_colours(mpmhip2d_ctx *ctx, int64_t capacity, uint32_t 
  * src/mpm_rigid_body.cpp:130-252), rasterize_rigid_boundary / gather_cdf (src/rigid_transfer.cpp), the rigid branches of
  * the transfers (block_op_rigid, src/transfer.cpp:367-463,706-835) and advect_rigid_bodies (src/mpm_rigid_body.cpp:255-286).
  * Once a body exists, every substep runs: sort | rasterize_rigid_boundary | gather_cdf | P2G | grid | G2P | advect.
- * Not part of this library: rigid-rigid collisions (rigidify / libccd), joints (articulation.cpp),
- * rigid_body_levelset_collision.  Rigid bodies cannot be combined with the multi-GPU tiling or asynchronous stepping.
+ * Not part of this library: rigid-rigid collisions (rigidify / libccd), rigid_body_levelset_collision (joints are:
+ * mpmhip_add_articulation below).  Rigid bodies cannot be combined with the multi-GPU tiling or asynchronous stepping.
  * ------------------------------------------------------------------------------------------------------------------ */
 /* scripted_position(t) -> world position; scripted_rotation(t) -> Euler angles in degrees (applied X * Y * Z):
  * tc.function13 objects in the scene scripts (scripts/mls-cpic/sand_paddles.py:27, src/mpm_rigid_body.cpp:79-92) */
