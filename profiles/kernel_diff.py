@@ -1,0 +1,37 @@
+"""Which device kernels differ between two builds of libmpmhip.so?
+    python profiles/kernel_diff.py old/libmpmhip.so new/libmpmhip.so
+Extracts the gfx950 code object of each library (llvm-objdump --offloading), disassembles it and compares every kernel's
+instruction stream.  Used to check that an edit meant to be a no-op for the tuned kernels really is one before spending GPU
+time on it — it is not always: removing ONE unused variable from k_g2p changed its register allocation (5610 -> 5611
+instructions), so the variable stayed (k_g2p.h)."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def kernels(lib):
+    d = tempfile.mkdtemp()
+    try:
+        shutil.copy(lib, os.path.join(d, "lib.so"))
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", "lib.so"], cwd=d, check=True, stdout=subprocess.DEVNULL)
+        co = [f for f in os.listdir(d) if f.endswith("gfx950")][0]
+        txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], cwd=d, check=True, capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(d)
+    parts = re.split(r"^[0-9a-f]+ <([^>]+)>:$", txt, flags=re.M)
+    return {parts[i]: [re.sub(r"\s*//.*$", "", ln.strip()) for ln in parts[i + 1].splitlines() if ln.strip() and not ln.strip().startswith("//")]
+            for i in range(1, len(parts), 2)}
+
+
+if __name__ == "__main__":
+    a, b = kernels(sys.argv[1]), kernels(sys.argv[2])
+    names = sorted(set(a) | set(b))
+    diff = [k for k in names if a.get(k) != b.get(k)]
+    print("%d kernels, %d differ" % (len(names), len(diff)))
+    for k in diff:
+        print("  %-90s %s -> %s instructions" % (k[:90], len(a[k]) if k in a else "-", len(b[k]) if k in b else "-"))
