@@ -96,6 +96,14 @@ def lib():
         L.ref2_download_cdf.argtypes = [C.c_void_p, P_U, P_F]
         L.ref2_particle_cdf.restype = C.c_int64
         L.ref2_particle_cdf.argtypes = [C.c_void_p, P_U, P_F, P_F, P_I]
+        if hasattr(L, "ref88_advance"):  # /root/reference/mls-mpm88.cpp compiled in place (oracle/ref_mpm88_driver.cpp)
+            L.ref88_dt.restype = C.c_double
+            L.ref88_num_particles.restype = C.c_int64
+            L.ref88_reset.argtypes = [C.c_int32]
+            L.ref88_add.argtypes = [C.c_int64, P_F, P_F, P_F, P_F, P_F]
+            L.ref88_advance.argtypes = [C.c_int32]
+            L.ref88_get.argtypes = [P_F, P_F, P_F, P_F, P_F]
+            L.ref88_get_grid.argtypes = [P_F]
         _lib = L
     return _lib
 
@@ -495,3 +503,26 @@ def shim_svd3(F):
     U = np.zeros(9, np.float32); S = np.zeros(3, np.float32); V = np.zeros(9, np.float32)
     lib().ref_shim_svd3(fp, U.ctypes.data_as(P_F), S.ctypes.data_as(P_F), V.ctypes.data_as(P_F))
     return U.reshape(3, 3), S, V.reshape(3, 3)
+
+
+def mpm88_available():
+    return available() and hasattr(lib(), "ref88_advance")
+
+
+def mpm88_advance(x, v, F, Cm, Jp, steps=1, plastic=True):
+    """the reference's 2D demo itself: /root/reference/mls-mpm88.cpp:16-69 advance(dt) with its own constants (n = 80,
+    dt = 1e-4) run `steps` times on the given particles (x, v: n x 2; F, C: n x 4 row-major; Jp: n), updated IN PLACE
+    like oracle.mpm88_advance.  Returns the grid (v.x, v.y, m) of the last step, shape (81, 81, 3).  The state lives
+    in the file's globals: one scene at a time."""
+    L = lib()
+    n = len(x)
+    L.ref88_reset(1 if plastic else 0)
+    L.ref88_add(n, _f(x)[1], _f(v)[1], _f(F)[1], _f(Cm)[1], _f(Jp)[1])
+    L.ref88_advance(int(steps))
+    for a in (x, v, F, Cm, Jp):
+        assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    L.ref88_get(x.ctypes.data_as(P_F), v.ctypes.data_as(P_F), F.ctypes.data_as(P_F), Cm.ctypes.data_as(P_F), Jp.ctypes.data_as(P_F))
+    ng = L.ref88_grid_cells()
+    g = np.zeros((ng + 1, ng + 1, 3), np.float32)
+    L.ref88_get_grid(g.ctypes.data_as(P_F))
+    return g

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
         b1xy = fma2(splat2(w0i), T1xy, b1xy); b1zw = fma2(splat2(w0i), T1zw, b1zw);
         b2xy = fma2(splat2(w0i), T2xy, b2xy); b2zw = fma2(splat2(w0i), T2zw, b2zw);
       };
-      if (!(P.ablate & 4)) {
+      if (!MPM_ABLATE(P, 4)) {
         plane(0, w0[0], e0[0]); plane(1, w0[1], e0[1]); plane(2, w0[2], e0[2]);
       }
       float v0 = vxy.x, v1 = vxy.y, v2 = vzw.x;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
       F.m[7] = g2.w; F.m[8] = g3.x;
       float aux = g0.w;
       mat3 stress;
-      if (!(P.ablate & 2)) plasticity_and_force(g, cdg, F, aux, stress);  // :950 + next substep's :509
+      if (!MPM_ABLATE(P, 2)) plasticity_and_force(g, cdg, F, aux, stress);  // :950 + next substep's :509
       else stress = cdg;
       float nx0 = fmaf(v0, P.dt, x0), nx1 = fmaf(v1, P.dt, x1), nx2 = fmaf(v2, P.dt, x2);  // :951
       if (P.clamp_pos) {  // generic path only (optimized = false): p.pos clamped into [0, res - eps], :668-670
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
         B1 = make_float4(b.m[4], b.m[5], b.m[6], b.m[7]);
         B2 = make_float4(b.m[8], 0.0f, 0.0f, 0.0f);
       }
-      out_slot = (P.ablate & 1) ? INVALID : cur.p + tid;
+      out_slot = MPM_ABLATE(P, 1) ? INVALID : cur.p + tid;
     };
     // Group parameters are read at use (keeps ~20 VGPRs free) from the workgroup's LDS copy of the table: DS reads
     // wait on lgkmcnt, whereas vector loads in the middle of the arithmetic wait on vmcnt and with it on the

@@ -115,7 +115,7 @@ __device__ __forceinline__ void p2g_cell(const Params &P, const float4 *__restri
 #pragma unroll
   for (int n = N0; n < N1; n++) {
     const int node = nbase + ((n / 9) * TS + (n / 3) % 3) * TS + n % 3;
-    if ((P.ablate & 8) && acc[n - N0][3] != 1.2345e-30f) continue;
+    if (MPM_ABLATE(P, 8) && acc[n - N0][3] != 1.2345e-30f) continue;
     if (p1 > p0) {
       float4 t = tile[node];
       t.x += acc[n - N0][0]; t.y += acc[n - N0][1]; t.z += acc[n - N0][2]; t.w += acc[n - N0][3];

@@ -158,7 +158,7 @@ constexpr int RANK_BATCH = 1024, RANK_TAB_BITS = 11, RANK_TAB = 1 << RANK_TAB_BI
 
 // bits of the cell index in the packed word: n_active*64 < 2^cb strictly, so a valid word never equals INVALID
 __device__ __forceinline__ uint32_t packed_cell_bits(const Params &P, uint32_t n_active) {
-  if (P.ablate & 16) return 29u;  // TEST KNOB: a 3-bit rank field, so that small scenes exercise the side array
+  if (P.test_small_rank) return 29u;  // TEST KNOB: a 3-bit rank field, so that small scenes exercise the side array
   const uint32_t cb = 32u - (uint32_t)__clz((int)(n_active * (uint32_t)BC));
   return cb < 6u ? 6u : cb;
 }

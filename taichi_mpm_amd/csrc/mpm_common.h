@@ -77,9 +77,16 @@ struct Params {
   int store_b;       // keep apic_b in the side array
   int particle_collision;  // particle_collision_resolution after G2P (src/mpm.cpp:566-569)
   int clamp_pos;     // generic transfer path (optimized = false): positions clamped into [0, res - eps] (src/transfer.cpp:668-670)
-  int ablate;        // PROFILING ONLY (env MPMHIP_ABLATE, results invalid): 1 no G2P stores, 2 no constitutive
-                     // update, 4 no 27-tap gather; 16 (tests, results valid) 3-bit rank field in k_rank's packed words
+  int test_small_rank;  // TEST KNOB (env MPMHIP_TEST_SMALL_RANK, results valid): a 3-bit rank field in k_rank's packed words
+  int ablate;        // only read by -DMPMHIP_ABLATE_BUILD libraries (profiles/ A/B builds; results invalid): env MPMHIP_ABLATE,
+                     // 1 no G2P stores, 2 no constitutive update, 4 no 27-tap gather, 8 no P2G merge.  The default
+                     // library compiles every use of it away (MPM_ABLATE below is the constant false).
 };
+#ifdef MPMHIP_ABLATE_BUILD
+#define MPM_ABLATE(P, bit) (((P).ablate & (bit)) != 0)
+#else
+#define MPM_ABLATE(P, bit) false
+#endif
 
 // multi-GPU tiling (include/mpmhip.h, "Multi-GPU tiling"): partition of the cell space into bricks + halo boxes
 struct Tiling {

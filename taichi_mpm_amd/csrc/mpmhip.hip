@@ -341,7 +341,11 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   if (const char *e = getenv("MPMHIP_P2G_WGS")) c->p2g_wgs = atoi(e) > 0 ? atoi(e) : 16384;
   c->reorder_interval = cfg->reorder_interval;
   if (const char *e = getenv("MPMHIP_REORDER_INTERVAL")) c->reorder_interval = atoi(e);
+#ifdef MPMHIP_ABLATE_BUILD
   const int ablate = getenv("MPMHIP_ABLATE") ? atoi(getenv("MPMHIP_ABLATE")) : 0;
+#else
+  const int ablate = 0;  // (the default library has no ablation paths: MPM_ABLATE is the constant false)
+#endif
   auto bail = [&](int code) { g_create_error = c->err; mpmhip_destroy(c); return code; };
   if (hipSetDevice(c->device) != hipSuccess) { fail(c, MPMHIP_EHIP, "hipSetDevice failed"); return bail(MPMHIP_EHIP); }
   Params &P = c->P;
@@ -360,6 +364,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   P.store_b = cfg->discard_apic_b ? 0 : 1;
   P.clamp_pos = cfg->generic_path ? 1 : 0;
   P.ablate = ablate;
+  P.test_small_rank = getenv("MPMHIP_TEST_SMALL_RANK") ? atoi(getenv("MPMHIP_TEST_SMALL_RANK")) : 0;
   memset(&c->LS, 0, sizeof c->LS);
   c->LS.particle_collision = cfg->particle_collision;
   P.particle_collision = cfg->particle_collision;

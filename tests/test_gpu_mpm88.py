@@ -94,3 +94,56 @@ def test_empty_and_growing_particle_sets(tm):
     x, v, F, Cm, Jp = sim.particles()
     assert len(x) == 710 and np.all(np.isfinite(x)) and (v[:, 1] < 0).all()
     sim.close()
+
+
+# ------------------------------------------------------------------------------------------ pinned to the reference
+# tests/golden/ref_mpm88.npz = output of /root/reference/mls-mpm88.cpp's own advance() compiled in place
+# (tests/golden/make_mpm88_golden.py).  Tolerances (fp32, float atomics in arbitrary order for the scatter, 2x2 polar / SVD
+# in float on the device against the shim's double): one step 1e-5 relative, x 1.2e-7 absolute; 40 steps x 1e-5.
+import os
+
+GOLD88 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_mpm88.npz")
+
+
+@pytest.mark.parametrize("name,plastic", [("stir_plastic", True), ("stir_elastic", False)])
+def test_one_step_matches_the_reference_file(tm, name, plastic):
+    g = np.load(GOLD88)
+    sim = tm.MPM88(plastic=plastic)
+    sim.add_particles(*[g["%s_in_%s" % (name, k)] for k in "xvFCJ"])
+    sim.advance(1)
+    got = sim.particles()
+    want = [g["%s_out_%s" % (name, k)] for k in "xvFCJ"]
+    assert rel_l2(sim.grid().reshape(81, 81, 3), g[name + "_grid"]) <= 1e-5
+    assert np.abs(got[0] - want[0]).max() <= 1.2e-7
+    for a, b in zip(got[1:], want[1:]):
+        assert rel_l2(a, b) <= 1e-5
+    sim.close()
+
+
+def test_forty_steps_track_the_reference_file(tm):
+    g = np.load(GOLD88)
+    sim = tm.MPM88()
+    sim.add_particles(g["fall_in_x"])
+    sim.advance(40)
+    gx, gv, gF, gC, gJ = sim.particles()
+    assert np.abs(gx - g["fall_out_x"]).max() <= 1e-5
+    assert rel_l2(gv, g["fall_out_v"]) <= 1e-3 and rel_l2(gF, g["fall_out_F"]) <= 1e-4 and rel_l2(gJ, g["fall_out_J"]) <= 1e-4
+    sim.close()
+
+
+def test_live_reference_file_next_to_the_device_on_a_fresh_scene(tm):
+    """the compiled mls-mpm88.cpp itself (oracle/_ref/libmpm_ref.so travels to the GPU box) on a scene no fixture holds"""
+    from oracle import refmpm as ref
+    if not ref.available() or not ref.mpm88_available():
+        pytest.skip("oracle/_ref/libmpm_ref.so (with mls-mpm88.cpp) not built")
+    x, v, F, Cm, Jp = _seed(1500, seed=4242, stir=0.7)
+    sim = tm.MPM88()
+    sim.add_particles(x, v, F, Cm, Jp)
+    sim.advance(3)
+    got = sim.particles()
+    r = [a.copy() for a in (x, v, F, Cm, Jp)]
+    ref.mpm88_advance(*r, steps=3, plastic=True)
+    assert np.abs(got[0] - r[0]).max() <= 3e-7
+    for a, b in zip(got[1:], r[1:]):
+        assert rel_l2(a, b) <= 3e-5
+    sim.close()

@@ -167,8 +167,8 @@ def test_crowded_cells_take_the_side_array_of_the_sort(tm, orc, monkeypatch):
     out = {}
     for order in ("runs", "shuffled"):
         xs = x if order == "runs" else x[rng.permutation(len(x))]
-        for knob in ("0", "16"):
-            monkeypatch.setenv("MPMHIP_ABLATE", knob)
+        for knob in ("0", "1"):
+            monkeypatch.setenv("MPMHIP_TEST_SMALL_RANK", knob)
             s = make_state(xs, "jelly", DX, perturb_F=0.02, seed=23)
             sim = make_sim(tm, s)
             for _ in range(3):
@@ -178,10 +178,10 @@ def test_crowded_cells_take_the_side_array_of_the_sort(tm, orc, monkeypatch):
             out[order, knob] = got
             sim.close()
         for f in ("x", "v", "F"):
-            a, b = out[order, "0"][f], out[order, "16"][f]
+            a, b = out[order, "0"][f], out[order, "1"][f]
             # (same sums in a different order inside a cell: ranks are handed out by atomics)
             assert np.allclose(a, b, rtol=0, atol=2e-6 * max(1.0, float(np.abs(a).max()))), (order, f)
-    monkeypatch.delenv("MPMHIP_ABLATE")
+    monkeypatch.delenv("MPMHIP_TEST_SMALL_RANK")
 
 
 # ------------------------------------------------------------------------------------------ phases
