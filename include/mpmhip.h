@@ -283,6 +283,14 @@ int mpmhip_import_particles(mpmhip_ctx *ctx, int64_t n, const void *dev_records)
 int mpmhip_active_bounds(mpmhip_ctx *ctx, int32_t lo[3], int32_t hi[3]);
 int64_t mpmhip_num_slots(mpmhip_ctx *ctx);       /* slots in use (live + dead) — capacity pressure */
 int mpmhip_request_compaction(mpmhip_ctx *ctx);  /* physical reorder + drop of dead slots at the next sort */
+/* Grows the particle capacity of a live ctx IN PLACE to at least max_particles (never shrinks): the record arrays are
+ * re-allocated and copied, an auto-sized block table (max_blocks = 0 at creation) grows with them.  Everything else
+ * stays — groups, level set, clocks, stream, rigid bodies and joints, the async block table, partition and halo boxes —
+ * so a scene that keeps adding particles (the reference's ParticleAllocator pool grows on demand,
+ * src/particle_allocator.h:36-60) needs no max_particles up front, with or without bodies.  Synchronises; the next
+ * substep sorts from scratch.  Not between substep_begin and substep_end. */
+int mpmhip_reserve(mpmhip_ctx *ctx, int64_t max_particles);
+int64_t mpmhip_capacity(mpmhip_ctx *ctx);
 
 /* ---- AsyncMPM, first half — replaces AsyncMPM<dim>::update_dt_limits (src/async/async_mpm.cpp:90-164) and the limit
  * attributes AsyncMPM<dim>::visualize writes (src/async/async_visualize.cpp:17-26).  A scheduler block is the reference's

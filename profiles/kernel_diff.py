@@ -28,7 +28,42 @@ def kernels(lib):
             for i in range(1, len(parts), 2)}
 
 
+def kernel_stats(lib):
+    """per kernel (mangled name): instruction count of the disassembly + the resource usage the code object's metadata
+    records (vgpr / agpr / sgpr counts, spills, scratch bytes, static LDS bytes)"""
+    d = tempfile.mkdtemp()
+    try:
+        shutil.copy(lib, os.path.join(d, "lib.so"))
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", "lib.so"], cwd=d, check=True, stdout=subprocess.DEVNULL)
+        co = [f for f in os.listdir(d) if f.endswith("gfx950")][0]
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], cwd=d, check=True, capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(d)
+    out, cur = {}, None
+    keys = {".vgpr_count": "vgpr", ".agpr_count": "agpr", ".sgpr_count": "sgpr", ".vgpr_spill_count": "vgpr_spill",
+            ".sgpr_spill_count": "sgpr_spill", ".private_segment_fixed_size": "scratch_bytes", ".group_segment_fixed_size": "lds_bytes"}
+    for blk in re.split(r"^\s+- \.", notes, flags=re.M):  # one metadata map per kernel
+        m = re.search(r"^\s*\.?name:\s+(\S+)$", blk, flags=re.M)
+        sym = re.search(r"\.symbol:\s+(\S+)\.kd", blk)
+        if not sym:
+            continue
+        cur = {}
+        for k, short in keys.items():
+            mm = re.search(r"%s:\s+(\d+)" % re.escape(k), blk)
+            if mm:
+                cur[short] = int(mm.group(1))
+        out[sym.group(1)] = cur
+    for name, ins in kernels(lib).items():
+        if name in out:
+            out[name]["instructions"] = len(ins)
+    return out
+
+
 if __name__ == "__main__":
+    if len(sys.argv) == 3 and sys.argv[1] == "--stats":
+        import json
+        print(json.dumps(kernel_stats(sys.argv[2]), indent=1, sort_keys=True))
+        sys.exit(0)
     a, b = kernels(sys.argv[1]), kernels(sys.argv[2])
     names = sorted(set(a) | set(b))
     diff = [k for k in names if a.get(k) != b.get(k)]

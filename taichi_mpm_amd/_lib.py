@@ -138,7 +138,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_las
             "mpmhip_download_grid", "mpmhip_upload_grid", "mpmhip_calculate_energy", "mpmhip_snapshot_size", "mpmhip_snapshot_save", "mpmhip_snapshot_load", "mpmhip_delete_particles_inside_level_set", "mpmhip_bgeo_size", "mpmhip_bgeo_encode", "mpmhip_write_bgeo", "mpmhip_set_profiling", "mpmhip_profile",
             "mpmhip_profile_reset", "mpmhip_set_partition", "mpmhip_set_halo", "mpmhip_halo_pack",
             "mpmhip_substep_begin", "mpmhip_substep_end", "mpmhip_substep_interior", "mpmhip_set_overlap", "mpmhip_leaver_counts", "mpmhip_migration_scan", "mpmhip_export_leavers",
-            "mpmhip_import_particles", "mpmhip_active_bounds", "mpmhip_num_slots", "mpmhip_request_compaction", "mpmhip_mpm88_create", "mpmhip_mpm88_destroy", "mpmhip_mpm88_last_error", "mpmhip_mpm88_add",
+            "mpmhip_import_particles", "mpmhip_active_bounds", "mpmhip_num_slots", "mpmhip_request_compaction", "mpmhip_reserve", "mpmhip_capacity", "mpmhip_mpm88_create", "mpmhip_mpm88_destroy", "mpmhip_mpm88_last_error", "mpmhip_mpm88_add",
             "mpmhip_mpm88_num_particles", "mpmhip_mpm88_advance", "mpmhip_mpm88_download", "mpmhip_mpm88_download_grid",
             "mpmhip_async_enable", "mpmhip_async_update_dt_limits", "mpmhip_async_blocks", "mpmhip_async_set_time_int", "mpmhip_async_table", "mpmhip_clear_particles", "mpmhip_set_dt", "mpmhip_set_time", "mpmhip_get_clock", "mpmhip_set_clock", "mpmhip_debug_allowed_dt",
             "mpmhip2d_create", "mpmhip2d_destroy", "mpmhip2d_last_error", "mpmhip2d_set_levelset", "mpmhip2d_add_group", "mpmhip2d_add_particles",
@@ -213,6 +213,9 @@ def load():
     L.mpmhip_set_overlap.argtypes = [vp, C.c_int32]
     L.mpmhip_num_slots.argtypes = [vp]
     L.mpmhip_num_slots.restype = C.c_int64
+    L.mpmhip_reserve.argtypes = [vp, C.c_int64]
+    L.mpmhip_capacity.argtypes = [vp]
+    L.mpmhip_capacity.restype = C.c_int64
     for name in ("mpmhip_substep", "mpmhip_synchronize", "mpmhip_sort", "mpmhip_p2g", "mpmhip_grid_update",
                  "mpmhip_g2p", "mpmhip_profile_reset", "mpmhip_halo_pack", "mpmhip_substep_begin",
                  "mpmhip_substep_end", "mpmhip_substep_interior", "mpmhip_request_compaction"):

@@ -126,8 +126,6 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
     const uint32_t i_nn = lane_slot(nn);
     uint32_t bkey = INVALID, out_slot = INVALID;
     auto particle = [&](const GroupParams &g) __attribute__((always_inline)) {
-      const size_t i = i_cur;  // (unused — kept: removing it changes the register allocation of the measured kernel)
-      (void)i;
       const float x0 = g0.x, x1 = g0.y, x2 = g0.z;
       const float X0 = x0 * P.idx - ox, X1 = x1 * P.idx - oy, X2 = x2 * P.idx - oz;
       const int c0 = (int)(X0 - 0.5f), c1 = (int)(X1 - 0.5f), c2 = (int)(X2 - 0.5f);

@@ -205,6 +205,20 @@ static int fail(mpmhip_ctx *c, int code, const char *fmt, ...) {
 template <typename T>
 static hipError_t dmalloc(T **p, size_t count) { return hipMalloc((void **)p, count * sizeof(T)); }
 
+// new array of `count` elements holding the first `keep` elements of *p (the rest zero-filled when `zero`); *p is freed
+template <typename T>
+static hipError_t regrow(T **p, size_t keep, size_t count, bool zero) {
+  T *q = nullptr;
+  hipError_t e = hipMalloc((void **)&q, count * sizeof(T));
+  if (e != hipSuccess) return e;
+  if (zero) e = hipMemset(q, 0, count * sizeof(T));
+  if (e == hipSuccess && keep && *p) e = hipMemcpy(q, *p, keep * sizeof(T), hipMemcpyDeviceToDevice);
+  if (e != hipSuccess) { (void)hipFree(q); return e; }
+  (void)hipFree(*p);
+  *p = q;
+  return hipSuccess;
+}
+
 static int particle_grid(int64_t n) {
   int64_t b = (n + 255) / 256;
   if (b < 1) b = 1;
@@ -853,11 +867,13 @@ static int do_p2g(mpmhip_ctx *c, int phase = 0) {
   // block, 37 with two, 48 with four)
   auto kern = k_p2g<1, 1, 2>;
   int nt = 64;
+#ifdef MPMHIP_TUNING_VARIANTS  // (A/B libraries only, profiles/: the default library carries the one kernel that was kept)
   switch (c->p2g_split) {
     case 21: kern = k_p2g<2, 1, 3>; nt = 128; break;
     case 12: kern = k_p2g<1, 2, 2>; nt = 128; break;
     default: break;
   }
+#endif
   const bool rigid = rigid_active(c);
   if (rigid) { kern = k_p2g<1, 1, 2, true>; nt = 64; }
   hipLaunchKernelGGL(kern, dim3(c->p2g_wgs), dim3(nt), 0, c->stream, c->P,
@@ -889,12 +905,14 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0) {
   // wave spills (0.41 ms)
   auto kern = sb ? k_g2p<256, 2, true, true> : k_g2p<256, 2, true, false>;
   int nt = 256;
+#ifdef MPMHIP_TUNING_VARIANTS  // (A/B libraries only: 3 / 4 waves per SIMD spill, 128-entry chunks measured slower — DESIGN.md §4)
   switch (c->g2p_minw) {  // tuning knob: 10 + waves/SIMD target; 23: 128-entry chunks
     case 13: kern = sb ? k_g2p<256, 3, true, true> : k_g2p<256, 3, true, false>; break;
     case 14: kern = sb ? k_g2p<256, 4, true, true> : k_g2p<256, 4, true, false>; break;
     case 23: kern = sb ? k_g2p<128, 3, true, true> : k_g2p<128, 3, true, false>; nt = 128; break;
     default: break;
   }
+#endif
   if (rigid_active(c)) { kern = sb ? k_g2p<256, 2, true, true, true> : k_g2p<256, 2, true, false, true>; nt = 256; }
   hipLaunchKernelGGL(kern, dim3(c->g2p_wgs), dim3(nt), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
                      (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
@@ -1677,6 +1695,48 @@ int mpmhip_request_compaction(mpmhip_ctx *c) {
   if (!c) return MPMHIP_EINVAL;
   c->compact_requested = true;
   return MPMHIP_OK;
+}
+
+int64_t mpmhip_capacity(mpmhip_ctx *c) { return c ? c->cap : MPMHIP_EINVAL; }
+
+int mpmhip_reserve(mpmhip_ctx *c, int64_t max_particles) {
+  if (!c) return MPMHIP_EINVAL;
+  if (max_particles <= c->cap) return MPMHIP_OK;
+  if (max_particles >= (1ll << 31)) return fail(c, MPMHIP_EINVAL, "max_particles out of range");
+  if (c->in_substep) return fail(c, MPMHIP_EINVAL, "reserve inside a substep");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t n = (size_t)c->n_slots, cap = (size_t)max_particles;
+  hipError_t e = hipSuccess;
+  auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  A(regrow(&c->rg, n, cap, false)); A(regrow(&c->rp, n, cap, false)); A(regrow(&c->rb, n * BW, cap * BW, true));
+  A(regrow(&c->rg2, 0, cap, false)); A(regrow(&c->rp2, 0, cap, false)); A(regrow(&c->rb2, 0, cap * BW, false));
+  A(regrow(&c->key, 0, cap, false)); A(regrow(&c->rank, 0, cap, false)); A(regrow(&c->perm, 0, cap, false));
+  if (c->rigid.d_bnd) A(regrow(&c->rigid.d_bnd, n, cap, true));
+  if (c->async.d_blk_of) {  // (re-allocated at the size of the ctx by the next update_dt_limits)
+    (void)hipFree(c->async.d_blk_of); (void)hipFree(c->async.d_particle_limits);
+    c->async.d_blk_of = nullptr; c->async.d_particle_limits = nullptr; c->async.blk_of_cap = 0; c->async.limits_valid = false;
+  }
+  if (e != hipSuccess) return fail(c, MPMHIP_ENOMEM, "growing the particle arrays to %lld failed: %s", (long long)max_particles, hipGetErrorString(e));
+  c->cap = max_particles;
+  c->cfg.max_particles = max_particles;
+  if (c->cfg.max_blocks <= 0) {  // auto-sized block table: same rule as mpmhip_create
+    int64_t mb = c->cap / 48 + 4096;
+    if (mb > (int64_t)c->NB) mb = c->NB;
+    if ((uint32_t)mb > c->P.max_blocks) {
+      const size_t m = (size_t)mb;
+      A(regrow(&c->act_blk, 0, m + 1, false)); A(regrow(&c->act_start, 0, m + 2, true));
+      A(regrow(&c->cell_cnt, 0, m * BC, true)); A(regrow(&c->cell_start, 0, m * BC + 1, true));
+      A(regrow(&c->scan_slots, 0, c->bt_slots + (m + 15) / 16 + 1, true));  // (epoch 0 is never used)
+      A(regrow(&c->tiles, 0, m * TN, false)); A(regrow(&c->gridv, 0, m * 8 * BC, false));
+      if (c->rigid.d_blk_rigid) A(regrow(&c->rigid.d_blk_rigid, 0, m + 1, true));
+      if (e != hipSuccess) return fail(c, MPMHIP_ENOMEM, "growing the block table to %lld failed: %s", (long long)mb, hipGetErrorString(e));
+      c->P.max_blocks = (uint32_t)mb;
+      HIPCHK(c, hipMemset(c->fat_slot, 0, sizeof(uint32_t) * (size_t)c->NB));  // slots of the old grid array
+    }
+  }
+  c->keys_valid = true;  // (forces invalidate_keys to clear the block flags: the next sort rebuilds keys from the records)
+  return invalidate_keys(c);
 }
 
 int mpmhip_debug_copy_bandwidth(mpmhip_ctx *c, size_t bytes, int32_t iters, double *gb_per_s) {

@@ -6,7 +6,9 @@
 // on every triangle with the reference's own loop, drop samples near the domain wall.  The rigid-body arithmetic itself
 // (what an impulse does, how a script becomes a velocity) belongs to the absent taichi core; the conventions used here
 // are those of the body the reference build is tested against (oracle/taichi_shim/taichi/dynamics/rigid_body_shim.h)
-// and are restated in k_rigid.h.  Rigid-rigid collisions (libccd) and joints are not part of this library.
+// and are restated in k_rigid.h.  Joints between bodies (MPM::articulate) are in k_joints.h; rigid-rigid collisions
+// (MPM::rigidify, src/mpm.cpp:468, libccd) are NOT part of this library — the Python layer warns when a scene has more than
+// one body that could collide.
 
 static void quat_from_euler_deg(const float deg[3], float q[4]) {  // X * Y * Z, src/mpm_rigid_body.cpp:108-114
   const float r = (float)(M_PI / 180.0);

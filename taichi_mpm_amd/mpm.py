@@ -161,6 +161,8 @@ class Simulation3D:
         self.config = {}
         self._n_added = 0
         self._rigids = []  # ctypes keep-alives (config struct, script callbacks) of the rigid bodies, index = body id - 1
+        self._free_bodies = 0  # bodies that move under impulses (not scripted, density > 0)
+        self._script_error = None  # first exception raised by a scripted_position / scripted_rotation callback
 
     # ---------------------------------------------------------------- lifecycle
     def initialize(self, config):
@@ -246,31 +248,11 @@ class Simulation3D:
                 self._upload_new(gi, *arrs)
             self._staged = []
         elif need > self._capacity:
-            if getattr(self, "_pinned_by", None):
-                # a tiled engine holds this ctx (pointer, partition, halo buffers, stream): growing would re-create it
-                raise MPMError("cannot grow a ctx that is driven by %s: pass max_particles to initialize()" % self._pinned_by)
-            state = self.get_particles()
-            frame = self.frame
-            t, rt, ns = C.c_double(), C.c_double(), C.c_int64()
-            self._check(self._L.mpmhip_get_clock(self._ctx, C.byref(t), C.byref(rt), C.byref(ns)))
-            self._L.mpmhip_destroy(self._ctx)
-            self._ctx = None
-            self._create(max(int(need * 1.25), self.max_particles))
-            order = np.argsort(state["gid"], kind="stable")
-            state = {k: v[order] for k, v in state.items()}
-            for gi in range(len(self._groups)):
-                m = state["gid"] == gi
-                if m.any():
-                    self._upload_new(gi, state["x"][m], state["v"][m], state["F"][m], state["B"][m], state["aux"][m])
-            ids = np.ascontiguousarray(state["id"], np.int32)  # keep creation ids across the re-allocation
-            if len(ids):
-                self._check(self._L.mpmhip_upload(self._ctx, F_ID, ids.ctypes.data_as(C.c_void_p), len(ids)))
-            # the run continues where it was: current_t, the residual of step()'s request_t, the phase of the physical
-            # reorder, and the stream the caller had installed
-            self._check(self._L.mpmhip_set_clock(self._ctx, t.value, rt.value, ns.value))
-            if getattr(self, "_stream", None):
-                self._check(self._L.mpmhip_set_stream(self._ctx, C.c_void_p(self._stream)))
-            self.frame = frame
+            # in place (include/mpmhip.h: mpmhip_reserve): clocks, stream, rigid bodies and joints, async table, partition
+            # and halo boxes all stay — scenes that keep adding particles need no max_particles, with or without bodies
+            cap = max(int(need * 1.25), self.max_particles)
+            self._check(self._L.mpmhip_reserve(self._ctx, cap))
+            self._capacity = cap
 
     def __del__(self):
         try:
@@ -416,17 +398,35 @@ class Simulation3D:
 
         def script(fn):
             def call(_user, t, out):
-                v = fn(float(t))
-                out[0], out[1], out[2] = float(v[0]), float(v[1]), float(v[2])
+                # (an exception cannot cross the C frames between here and step(): ctypes would print and drop it and the
+                # body would jump to a zeroed pose — it is stashed, the body keeps a finite pose, and the stepping call
+                # that triggered the script re-raises it)
+                try:
+                    v = fn(float(t))
+                    out[0], out[1], out[2] = float(v[0]), float(v[1]), float(v[2])
+                    last[:] = [out[0], out[1], out[2]]
+                except BaseException as e:  # noqa: BLE001
+                    if self._script_error is None:
+                        self._script_error = e
+                    out[0], out[1], out[2] = last
+            last = [0.0, 0.0, 0.0]
             return _lib.SCRIPT_FN(call)
         if cfg.get("scripted_position") is not None:
             r.scripted_position = script(cfg["scripted_position"])
         if cfg.get("scripted_rotation") is not None:
             r.scripted_rotation = script(cfg["scripted_rotation"])
+        free = cfg.get("scripted_position") is None and float(cfg.get("density", 0.0)) > 0.0
+        if free and self._free_bodies >= 1 or (free or self._free_bodies) and len(self._rigids) >= 1:
+            # MPM::rigidify (src/mpm.cpp:468, libccd) is not part of this library: say so instead of letting bodies
+            # pass through each other silently
+            import warnings
+            warnings.warn("taichi_mpm_amd: rigid-rigid collisions (MPM::rigidify, src/mpm.cpp:468) are not implemented — "
+                          "bodies interact only through the material and through joints", RuntimeWarning, stacklevel=3)
+        self._free_bodies += int(free)
         self._ensure_ctx()
         rid = self._check(self._L.mpmhip_add_rigid_body(self._ctx, C.byref(r), len(tri), tri.ctypes.data_as(C.POINTER(C.c_float))))
+        self._check_script()
         self._rigids.append(r)  # keeps the callbacks alive for the life of the simulation
-        self._pinned_by = "rigid bodies (their state lives in the ctx)"
         return rid
 
     def get_rigid_state(self, rid):
@@ -518,18 +518,29 @@ class Simulation3D:
         self._check(self._L.mpmhip_set_levelset_shapes(self._ctx, len(ls.shapes), self._shape_array(ls), ls.friction))
 
     # ---------------------------------------------------------------- stepping
+    def _check_script(self):
+        if self._script_error is not None:
+            e, self._script_error = self._script_error, None
+            raise MPMError("a scripted_position / scripted_rotation callback raised %r" % (e,)) from e
+
     def step(self, dt):
         """MPM<dim>::step, src/mpm.cpp:428-439: dt<0 => exactly one substep."""
         self._ensure_ctx()
-        self._check(self._L.mpmhip_step(self._ctx, float(dt)))
+        rc = self._L.mpmhip_step(self._ctx, float(dt))
+        self._check_script()
+        self._check(rc)
 
     def substep(self):
         self._ensure_ctx()
-        self._check(self._L.mpmhip_substep(self._ctx))
+        rc = self._L.mpmhip_substep(self._ctx)
+        self._check_script()
+        self._check(rc)
 
     def run_substeps(self, n):
         self._ensure_ctx()
-        self._check(self._L.mpmhip_run_substeps(self._ctx, int(n)))
+        rc = self._L.mpmhip_run_substeps(self._ctx, int(n))
+        self._check_script()
+        self._check(rc)
 
     def synchronize(self):
         self._ensure_ctx()
@@ -704,15 +715,13 @@ class Simulation3D:
         blob = np.ascontiguousarray(raw[8:])
         n_groups = int(blob[12:16].view(np.uint32)[0])
         n_slots = int(blob[16:24].view(np.int64)[0])
-        if self._ctx is not None and n_slots > self._capacity and getattr(self, "_pinned_by", None):
-            raise MPMError("the snapshot holds %d particles, this simulation's capacity is %d and cannot grow: it is pinned by %s "
-                           "(set max_particles)" % (n_slots, self._capacity, self._pinned_by))
-        if self._ctx is None or n_slots > self._capacity:
-            if self._ctx is not None:
-                self._L.mpmhip_destroy(self._ctx)
-                self._ctx = None
+        if self._ctx is None:
             self._staged, self._groups = [], []
             self._create(max(self.max_particles, int(n_slots * 1.25) + 1024))
+        elif n_slots > self._capacity:  # grown in place: bodies added by the scene before the load stay (mpmhip_reserve)
+            cap = max(self.max_particles, int(n_slots * 1.25) + 1024)
+            self._check(self._L.mpmhip_reserve(self._ctx, cap))
+            self._capacity = cap
         self._check(self._L.mpmhip_snapshot_load(self._ctx, blob.ctypes.data_as(C.c_void_p), len(blob)))
         rows = blob[80:80 + 80 * n_groups].view(np.float32).reshape(n_groups, 20)
         self._groups = [(int(r[16:17].view(np.int32)[0]), r[:16].copy()) for r in rows]

@@ -175,7 +175,6 @@ class HipEngine:
         self.sim = sim
         self.device = torch.device("cuda", device)
         sim._ensure_ctx()
-        sim._pinned_by = "a tiled engine (partition, halo buffers and stream are bound to the ctx)"
         self.L, self.ctx = sim._L, sim._ctx
         # everything (kernels, RCCL collectives, buffer copies) on ONE stream: ordering by construction.  The legacy
         # default stream has handle 0, which the C ABI reads as "the ctx's own stream" — and a non-blocking stream

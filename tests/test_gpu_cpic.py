@@ -631,3 +631,56 @@ def test_snapshot_restart_with_bodies_and_a_joint_continues_the_run(tm, tmp_path
     with pytest.raises(MPMError, match="rigid bodies"):  # a scene without the bodies cannot take the blob
         c.general_action(dict(action="load", file_name=path))
     a.close(); b.close(); c.close()
+
+
+def test_a_scene_with_a_body_grows_without_max_particles(tm):
+    """the reference's mls-cpic scenes add the rigid body first and have no max_particles key: the ctx is created small by
+    the body and must grow IN PLACE (mpmhip_reserve) when the material arrives and when more is added mid-run — the run
+    equals one that had the capacity from the start (bodies, their impulses and the clocks carry over)"""
+    xa, va = cs.block_of_particles(10, 16, seed=5)
+    xb, vb = cs.block_of_particles(16, 22, seed=6)
+
+    def run(cap):
+        cfg = dict(res=(cs.RES,) * 3, delta_x=cs.DX, base_delta_t=cs.DT, penalty=1e3)
+        if cap:
+            cfg["max_particles"] = cap
+        sim = tm.create_simulation3("mpm").initialize(cfg)
+        rid = int(sim.add_particles(dict(type="rigid", **cs.BODIES["plate"])))
+        sim.add_particles(dict(type="jelly", positions=xa, velocities=va))  # > the 1024 slots the body-first ctx starts with
+        sim.run_substeps(4)
+        sim.add_particles(dict(type="sand", positions=xb, velocities=vb))
+        sim.run_substeps(4)
+        p, o = by_id(sim)
+        st = sim.get_rigid_state(rid)
+        t = sim.get_current_time()
+        sim.close()
+        return {k: v[o] for k, v in p.items()}, st, t
+    small, st_s, t_s = run(0)
+    big, st_b, t_b = run(len(xa) + len(xb) + 64)
+    assert t_s == t_b and len(small["id"]) == len(xa) + len(xb)
+    assert np.array_equal(small["id"], big["id"]) and np.array_equal(small["gid"], big["gid"])
+    assert np.abs(small["x"] - big["x"]).max() <= 2e-7 and rel_l2(small["v"], big["v"]) <= 2e-5 and rel_l2(small["F"], big["F"]) <= 2e-5
+    for k in ("position", "velocity", "angular_velocity"):
+        np.testing.assert_allclose(st_s[k], st_b[k], rtol=0, atol=2e-6)
+
+
+def test_a_raising_script_surfaces_and_two_free_bodies_warn(tm):
+    """(i) an exception inside a scripted_position callback cannot cross the C frames: it is stashed and re-raised by the
+    stepping call, the body keeps its last finite pose; (ii) rigid-rigid collisions are not implemented: a second body that
+    could collide with the first warns instead of silently passing through"""
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(cs.RES,) * 3, delta_x=cs.DX, base_delta_t=cs.DT, max_particles=4096))
+
+    def pos(t):
+        if t > 2.5 * cs.DT:
+            raise ValueError("script broke at t=%g" % t)
+        return (0.5, 0.5 - t, 0.5)
+    rid = int(sim.add_particles(dict(type="rigid", mesh=cs.plate(0.1), codimensional=True, scripted_position=pos)))
+    x = (np.stack(np.meshgrid(*[np.arange(10, 14) + 0.5] * 3, indexing="ij"), -1).reshape(-1, 3) * cs.DX).astype(np.float32)
+    sim.add_particles(dict(type="jelly", positions=x))
+    sim.run_substeps(2)
+    with pytest.raises(tm.mpm.MPMError, match="script broke"):
+        sim.run_substeps(3)
+    assert np.isfinite(sim.get_rigid_state(rid)["position"]).all() and sim.get_rigid_state(rid)["position"][1] > 0.4
+    with pytest.warns(RuntimeWarning, match="rigid-rigid"):
+        sim.add_particles(dict(type="rigid", mesh=cs.box(), codimensional=False, density=400.0, initial_position=(0.3, 0.7, 0.3)))
+    sim.close()

@@ -1,0 +1,54 @@
+"""Resource budget of the tuned transfer kernels, read from the gfx950 code object of the built library (no GPU needed:
+hipcc cross-compiles).  The measured speed of k_g2p / k_p2g rests on their occupancy class (2 waves per SIMD: <= 256
+VGPRs, k_g2p two workgroups per CU: <= 80 KB of LDS each), on the absence of scratch (a spill turns register traffic
+into memory traffic) and on an instruction count in the range the profiles were taken with — a compiler update or an
+innocent edit that leaves these bands shows up here, before GPU time is spent on it (profiles/kernel_diff.py --stats
+prints the table)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "profiles"))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+@pytest.fixture(scope="module")
+def stats():
+    if not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("llvm-objdump of the ROCm toolchain not found")
+    from taichi_mpm_amd import _lib
+    import kernel_diff
+    return kernel_diff.kernel_stats(_lib.build())
+
+
+def _one(stats, prefix):
+    hits = {k: v for k, v in stats.items() if k.startswith(prefix)}
+    assert len(hits) == 1, (prefix, sorted(hits))
+    return next(iter(hits.values()))
+
+
+# name prefix (mangled, up to the template arguments) -> (max VGPRs, instruction band, max static LDS bytes)
+BUDGET = {
+    "_ZN3mpm5k_g2pILi256ELi2ELb1ELb0ELb0EEE": (256, (4800, 6200), 80 * 1024),   # the default G2P (apic_b folded, no bodies)
+    "_ZN3mpm5k_g2pILi256ELi2ELb1ELb1ELb0EEE": (256, (4900, 6400), 80 * 1024),   # keep_apic_b
+    "_ZN3mpm5k_p2gILi1ELi1ELi2ELb0EEE": (256, (1000, 1450), 16 * 1024),         # the default P2G (one wave per block)
+}
+
+
+@pytest.mark.parametrize("prefix", sorted(BUDGET))
+def test_tuned_kernels_stay_inside_their_budget(stats, prefix):
+    s = _one(stats, prefix)
+    vmax, (ilo, ihi), lds = BUDGET[prefix]
+    assert s["vgpr_spill"] == 0 and s["scratch_bytes"] == 0, s
+    assert 128 < s["vgpr"] + s.get("agpr", 0) <= vmax, s   # the 2-waves-per-SIMD class the kernels were tuned in
+    assert ilo <= s["instructions"] <= ihi, s
+    assert s["lds_bytes"] <= lds, s
+
+
+def test_no_kernel_of_the_library_uses_scratch_unnoticed(stats):
+    """every kernel that spills is listed here on purpose (none of them is on the per-substep path of a scene without bodies)"""
+    allowed = ("k_p2g_rigid", "k_g2p_rigid")  # the CPIC transfers (colour test per node on top of the full kernels)
+    bad = [k for k, v in stats.items() if v.get("scratch_bytes", 0) > 0 and not any(a in k for a in allowed)]
+    assert not bad, bad
