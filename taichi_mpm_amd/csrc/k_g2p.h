@@ -3,6 +3,12 @@
 #pragma once
 #include "mpm_common.h"
 
+#ifndef MPM_FENCE_A
+#define MPM_FENCE_A
+#endif
+#ifndef MPM_FENCE_B
+#define MPM_FENCE_B
+#endif
 namespace mpm {
 
 // ------------------------------------------------------------------------------------------------ G2P
@@ -18,7 +24,8 @@ constexpr int G2P_LDS_GROUPS = MPMHIP_MAX_GROUPS;  // the ctx's group capacity: 
 // RIGID: CPIC rigid bodies exist — blocks flagged by k_blk_rigid (top bit of act_start) are left to k_g2p_rigid and the
 // records' spare word (the particle's colour) is carried along.  A compile-time switch: the instantiation without it is the kernel tuned above,
 // instruction for instruction.
-template <int NT, int MINW, bool ROLL, bool STORE_B, bool RIGID = false>
+// MATS: the set of material types the ctx's groups use (mpm_math.h: plasticity_and_force) — the full set, or one material.
+template <int NT, int MINW, bool ROLL, bool STORE_B, bool RIGID = false, uint32_t MATS = MAT_ALL>
 __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__restrict__ rg, float4 *__restrict__ rg_out,
                                                   float4 *__restrict__ rp_out, float4 *__restrict__ rb_out,
                                                   const Counters *__restrict__ cnt,
@@ -97,6 +104,12 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
   // the outgoing records of a lane (lanes without a particle leave stale values here: they are never stored)
   float4 G0, G1, G2, G3, Q0, Q1, Q2, Q3, B0, B1, B2;
   G0 = G1 = G2 = G3 = Q0 = Q1 = Q2 = Q3 = B0 = B1 = B2 = make_float4(0, 0, 0, 0);
+  // The loop below keeps loads in flight across its back edge, and the compiler's wait-count insertion merges the state of
+  // the entry edge with that of the back edge: a prologue load still pending at entry (the index i_nx) makes it put a
+  // vmcnt(0) in front of the prefetch INSIDE the loop — where it also waits for the previous chunk's record stores (the
+  // counter is shared and in-order): measured 0.305 -> 0.364 ms at C3 when an unrelated edit changed the schedule.  Draining
+  // the prologue's loads here, once per workgroup, makes the entry state empty whatever the schedule.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   while (cur.a < na) {
     if (cur.a != tile_a) {
       // LDS-only barriers (lgkmcnt(0) + s_barrier): __syncthreads() would also wait on vmcnt, i.e. on the
@@ -126,6 +139,10 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
     const uint32_t i_nn = lane_slot(nn);
     uint32_t bkey = INVALID, out_slot = INVALID;
     auto particle = [&](const GroupParams &g) __attribute__((always_inline)) {
+#ifdef MPM_KEEP_UNUSED
+      const size_t i = i_cur;
+      (void)i;
+#endif
       const float x0 = g0.x, x1 = g0.y, x2 = g0.z;
       const float X0 = x0 * P.idx - ox, X1 = x1 * P.idx - oy, X2 = x2 * P.idx - oz;
       const int c0 = (int)(X0 - 0.5f), c1 = (int)(X1 - 0.5f), c2 = (int)(X2 - 0.5f);
@@ -165,9 +182,11 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
         b1xy = fma2(splat2(w0i), T1xy, b1xy); b1zw = fma2(splat2(w0i), T1zw, b1zw);
         b2xy = fma2(splat2(w0i), T2xy, b2xy); b2zw = fma2(splat2(w0i), T2zw, b2zw);
       };
+      MPM_FENCE_A;
       if (!MPM_ABLATE(P, 4)) {
         plane(0, w0[0], e0[0]); plane(1, w0[1], e0[1]); plane(2, w0[2], e0[2]);
       }
+      MPM_FENCE_A;
       float v0 = vxy.x, v1 = vxy.y, v2 = vzw.x;
       mat3 b;
       b(0, 0) = b0xy.x; b(1, 0) = b0xy.y; b(2, 0) = b0zw.x;
@@ -197,8 +216,10 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
       F.m[7] = g2.w; F.m[8] = g3.x;
       float aux = g0.w;
       mat3 stress;
-      if (!MPM_ABLATE(P, 2)) plasticity_and_force(g, cdg, F, aux, stress);  // :950 + next substep's :509
+      MPM_FENCE_B;
+      if (!MPM_ABLATE(P, 2)) plasticity_and_force<MATS>(g, cdg, F, aux, stress);  // :950 + next substep's :509
       else stress = cdg;
+      MPM_FENCE_B;
       float nx0 = fmaf(v0, P.dt, x0), nx1 = fmaf(v1, P.dt, x1), nx2 = fmaf(v2, P.dt, x2);  // :951
       if (P.clamp_pos) {  // generic path only (optimized = false): p.pos clamped into [0, res - eps], :668-670
         nx0 = fminf(fmaxf(nx0 * P.idx, 0.0f), (float)P.res[0] - 1e-6f) * P.dx;

@@ -384,10 +384,23 @@ __device__ __forceinline__ void plasticity(const GroupParams &g, const mat3 &cdg
 // (src/particles.h:134-141).  The reference evaluates them in two separate passes with an svd/polar_decomp
 // each; both are functions of the same U and singular values (F_new = U S' V^T keeps U), so the device does
 // ONE symmetric eigen-solve per particle per substep and derives both from it.  `stress` = -vol P(F_new) F_new^T.
+//
+// MATS: bit t set = material type t can occur (compile time).  k_g2p is instantiated for the full set and for each single
+// material: a scene made of one material (the benchmark configurations, most scene scripts) runs a kernel that carries only
+// that material's code — no type dispatch, a third of the instructions, and a register budget set by the material in use
+// instead of by the hungriest one of the eight (visco: two eigen-solves and a matrix exponential).
+constexpr uint32_t MAT_ALL = 0x1FEu;  // MPMHIP_VISCO (1) .. MPMHIP_ELASTIC (8)
+template <uint32_t MATS>
+__device__ __forceinline__ bool mat_is(const GroupParams &g, int t) {
+  if (!((MATS >> t) & 1u)) return false;       // not in this kernel's set
+  if ((MATS & (MATS - 1u)) == 0u) return true;  // the only one in the set: no run-time test
+  return g.type == t;
+}
+template <uint32_t MATS = MAT_ALL>
 __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const mat3 &cdg, mat3 &F, float &aux,
                                                      mat3 &stress) {
   const float vol = g.p[1];
-  if (g.type == MPMHIP_WATER) {  // src/particles.cpp:463-478
+  if (mat_is<MATS>(g, MPMHIP_WATER)) {  // src/particles.cpp:463-478
     float j = aux * (cdg(0, 0) + cdg(1, 1) + cdg(2, 2) - 2.0f);
     j = (j < 0.1f) ? 0.1f : j;
     aux = j;
@@ -397,7 +410,7 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
     for (int i = 0; i < 9; i++) stress.m[i] = (i % 4 == 0) ? dd : 0.0f;
     return;
   }
-  if (g.type == MPMHIP_VISCO) {  // src/particles.cpp:72-134
+  if (mat_is<MATS>(g, MPMHIP_VISCO)) {  // src/particles.cpp:72-134
     mat3 U; float s[3], sn[3], ratio[3], d[3];
     visco_return(g, cdg, F, aux, U, s, sn);
     const float Jn = sn[0] * sn[1] * sn[2];
@@ -413,8 +426,17 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
     return;
   }
   F = mat_mul(cdg, F);
-  if (g.type == MPMHIP_LINEAR) {
-    stress = calculate_force(g, F, aux);
+  if (mat_is<MATS>(g, MPMHIP_LINEAR)) {  // src/particles.cpp:329-341 (no eigen-solve)
+    const float mu = g.p[2], la = g.p[3];
+    const float tr = la * (F(0, 0) + F(1, 1) + F(2, 2) - 3.0f);
+    mat3 Pk;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) Pk(r, c) = mu * (F(r, c) + F(c, r) - ((r == c) ? 2.0f : 0.0f)) + ((r == c) ? tr : 0.0f);
+    stress = mat_mul_bt(Pk, F);
+#pragma unroll
+    for (int i = 0; i < 9; i++) stress.m[i] *= -vol;
     return;
   }
   mat3 U; float lam[3], s[3];
@@ -423,14 +445,14 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
   signed_sigma(lam, detF, s);
   const float mu0 = g.p[2], la0 = g.p[3];
   float d[3];
-  if (g.type == MPMHIP_JELLY) {  // src/particles.cpp:391-416
+  if (mat_is<MATS>(g, MPMHIP_JELLY)) {  // src/particles.cpp:391-416
     const float vol_l = la0 * (detF - 1.0f) * detF;
 #pragma unroll
     for (int i = 0; i < 3; i++) d[i] = -vol * fmaf(2.0f * mu0, lam[i] - s[i], vol_l);
     stress = sandwich(U, d);
     return;
   }
-  if (g.type == MPMHIP_ELASTIC) {  // src/particles.cpp:798-812
+  if (mat_is<MATS>(g, MPMHIP_ELASTIC)) {  // src/particles.cpp:798-812
     float ls[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) ls[i] = __logf(s[i]);
@@ -441,7 +463,7 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
     return;
   }
   float ratio[3];  // s'_i / s_i
-  if (g.type == MPMHIP_SNOW) {  // src/particles.cpp:207-252
+  if (mat_is<MATS>(g, MPMHIP_SNOW)) {  // src/particles.cpp:207-252
     const float lo = 1.0f - g.p[5], hi = 1.0f + g.p[6];
     float det_o = 1.0f, det_n = 1.0f, sn[3];
 #pragma unroll
@@ -460,7 +482,7 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
     const float vol_l = la * (det_n - 1.0f) * det_n;
 #pragma unroll
     for (int i = 0; i < 3; i++) d[i] = -vol * fmaf(2.0f * mu, sn[i] * sn[i] - sn[i], vol_l);
-  } else if (g.type == MPMHIP_SAND) {  // src/particles.cpp:599-647
+  } else if (mat_is<MATS>(g, MPMHIP_SAND)) {  // src/particles.cpp:599-647
     const float alpha = g.p[4], coh = g.p[5], beta = g.p[6];
     float eps[3];
 #pragma unroll
@@ -488,7 +510,7 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
       ratio[i] = __expf(h[i]) * fast_rcp(s[i]);
       d[i] = -vol * fmaf(2.0f * mu0, h[i], la0 * trh);
     }
-  } else {  // MPMHIP_VON_MISES, src/particles.cpp:701-732
+  } else if (mat_is<MATS>(g, MPMHIP_VON_MISES)) {  // src/particles.cpp:701-732
     float e[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) e[i] = __logf(s[i]);
@@ -506,6 +528,9 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
 #pragma unroll
     for (int i = 0; i < 3; i++) d[i] = -vol * fmaf(2.0f * mu0, h[i], la0 * trh);
     if (dg <= 0.0f) { stress = sandwich(U, d); return; }
+  } else {  // (a type outside this kernel's set, or an unknown type id: nothing to project, no stress)
+#pragma unroll
+    for (int i = 0; i < 3; i++) { ratio[i] = 1.0f; d[i] = 0.0f; }
   }
   mat3 Rr;
   sandwich2(U, ratio, d, Rr, stress);

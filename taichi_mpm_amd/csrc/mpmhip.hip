@@ -60,6 +60,9 @@
 #include <vector>
 
 
+#ifndef MPM_G2P_MINW
+#define MPM_G2P_MINW 2
+#endif
 #include "mpm_common.h"
 #include "k_sort.h"
 #include "k_particles.h"
@@ -900,10 +903,20 @@ static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
 static int do_g2p(mpmhip_ctx *c, int phase = 0) {
   c->P.t = c->t;
   const bool sb = c->P.store_b != 0;
-  // 2 waves/SIMD (up to 256 VGPRs): the kernel is bound by vector-ALU issue, not by latency — with the registers of a
-  // third wave the compiler shuffles less (C3: 0.308 -> 0.293 ms on the lattice, 0.443 -> 0.422 ms after impact); a fourth
-  // wave spills (0.41 ms)
-  auto kern = sb ? k_g2p<256, 2, true, true> : k_g2p<256, 2, true, false>;
+  // __launch_bounds__(256, 2) only PERMITS 256 VGPRs; what decides the speed is whether the allocation stays <= 168, i.e.
+  // whether THREE workgroups fit a CU's register file (512 per SIMD lane): 168 VGPRs 0.303 ms, 180 VGPRs 0.347 ms on the same
+  // box (profiles/r03_b_ab_vgpr.txt).  Forcing the bound (256, 3) makes the all-material kernel spill, and its scratch
+  // reloads wait on the prefetched records (vmcnt is shared and in-order) — so the budget is met by specialising instead:
+  // The kernel is instantiated per material SET (k_g2p.h: MATS): one material in the whole ctx (the benchmark configurations,
+  // most scene scripts) -> the kernel that carries only that material's constitutive code (sand: 2 833 instructions and 153
+  // VGPRs against 5 552 / 180 for all eight); no visco group -> the set without it (161 VGPRs: visco, with two eigen-solves
+  // and a matrix exponential, is what pushes the full kernel over the 168 registers three waves per SIMD can have).
+  constexpr uint32_t NO_VISCO = MAT_ALL & ~(1u << MPMHIP_VISCO);
+  uint32_t mask = 0;
+  for (const GroupParams &g : c->groups) mask |= 1u << (g.type & 31);
+  const bool rigid = rigid_active(c), no_visco = !(mask & (1u << MPMHIP_VISCO));
+  auto kern = sb ? (no_visco ? k_g2p<256, MPM_G2P_MINW, true, true, false, NO_VISCO> : k_g2p<256, MPM_G2P_MINW, true, true>)
+                 : (no_visco ? k_g2p<256, MPM_G2P_MINW, true, false, false, NO_VISCO> : k_g2p<256, MPM_G2P_MINW, true, false>);
   int nt = 256;
 #ifdef MPMHIP_TUNING_VARIANTS  // (A/B libraries only: 3 / 4 waves per SIMD spill, 128-entry chunks measured slower — DESIGN.md §4)
   switch (c->g2p_minw) {  // tuning knob: 10 + waves/SIMD target; 23: 128-entry chunks
@@ -913,11 +926,22 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0) {
     default: break;
   }
 #endif
-  if (rigid_active(c)) { kern = sb ? k_g2p<256, 2, true, true, true> : k_g2p<256, 2, true, false, true>; nt = 256; }
+  if (rigid) {
+    kern = sb ? (no_visco ? k_g2p<256, MPM_G2P_MINW, true, true, true, NO_VISCO> : k_g2p<256, MPM_G2P_MINW, true, true, true>)
+              : (no_visco ? k_g2p<256, MPM_G2P_MINW, true, false, true, NO_VISCO> : k_g2p<256, MPM_G2P_MINW, true, false, true>);
+  } else if (!sb) {
+    switch (mask) {
+#define MPM_ONE_MATERIAL(t) case 1u << (t): kern = k_g2p<256, MPM_G2P_MINW, true, false, false, 1u << (t)>; break;
+      MPM_ONE_MATERIAL(MPMHIP_VISCO) MPM_ONE_MATERIAL(MPMHIP_SNOW) MPM_ONE_MATERIAL(MPMHIP_LINEAR) MPM_ONE_MATERIAL(MPMHIP_JELLY)
+      MPM_ONE_MATERIAL(MPMHIP_WATER) MPM_ONE_MATERIAL(MPMHIP_SAND) MPM_ONE_MATERIAL(MPMHIP_VON_MISES) MPM_ONE_MATERIAL(MPMHIP_ELASTIC)
+#undef MPM_ONE_MATERIAL
+      default: break;
+    }
+  }
   hipLaunchKernelGGL(kern, dim3(c->g2p_wgs), dim3(nt), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
                      (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
                      c->blk_flag, (const LevelSetDev *)c->d_LS, phase_box(c->T), phase);
-  if (rigid_active(c)) {
+  if (rigid) {
     hipLaunchKernelGGL(k_g2p_rigid, dim3(2048), dim3(256), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
                        (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
                        c->blk_flag, (const LevelSetDev *)c->d_LS, rigid_xfer(c));

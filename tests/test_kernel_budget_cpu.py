@@ -1,6 +1,6 @@
 """Resource budget of the tuned transfer kernels, read from the gfx950 code object of the built library (no GPU needed:
-hipcc cross-compiles).  The measured speed of k_g2p / k_p2g rests on their occupancy class (2 waves per SIMD: <= 256
-VGPRs, k_g2p two workgroups per CU: <= 80 KB of LDS each), on the absence of scratch (a spill turns register traffic
+hipcc cross-compiles).  The measured speed of k_g2p / k_p2g rests on their occupancy class (k_g2p: three workgroups per CU, i.e.
+<= 168 VGPRs and <= 53 KB of LDS each; k_p2g: <= 256 VGPRs), on the absence of scratch (a spill turns register traffic
 into memory traffic) and on an instruction count in the range the profiles were taken with — a compiler update or an
 innocent edit that leaves these bands shows up here, before GPU time is spent on it (profiles/kernel_diff.py --stats
 prints the table)."""
@@ -29,11 +29,17 @@ def _one(stats, prefix):
     return next(iter(hits.values()))
 
 
-# name prefix (mangled, up to the template arguments) -> (max VGPRs, instruction band, max static LDS bytes)
+# name prefix (mangled, up to the template arguments) -> (max VGPRs, instruction band, max static LDS bytes).
+# k_g2p: <= 168 VGPRs = THREE workgroups per CU (512 registers per SIMD lane, allocated in eights); at 180 the same code ran
+# 14 % slower on the same box (profiles/r03_b_ab_vgpr.txt) — the all-material kernel (MATS = 510, visco included) is the one
+# instantiation allowed above it.
+G2P = "_ZN3mpm5k_g2pILi256ELi2ELb1ELb0ELb0ELj%dEEE"
 BUDGET = {
-    "_ZN3mpm5k_g2pILi256ELi2ELb1ELb0ELb0EEE": (256, (4800, 6200), 80 * 1024),   # the default G2P (apic_b folded, no bodies)
-    "_ZN3mpm5k_g2pILi256ELi2ELb1ELb1ELb0EEE": (256, (4900, 6400), 80 * 1024),   # keep_apic_b
-    "_ZN3mpm5k_p2gILi1ELi1ELi2ELb0EEE": (256, (1000, 1450), 16 * 1024),         # the default P2G (one wave per block)
+    G2P % 64: (168, (2400, 3300), 53 * 1024),    # sand only (the benchmark configuration C3)
+    G2P % 16: (168, (2200, 3200), 53 * 1024),    # jelly only (C2)
+    G2P % 508: (168, (3000, 4200), 53 * 1024),   # every material but visco (mixed scenes, C5)
+    G2P % 510: (256, (4800, 6200), 80 * 1024),   # all eight
+    "_ZN3mpm5k_p2gILi1ELi1ELi2ELb0EEE": (256, (900, 1450), 16 * 1024),  # the default P2G (one wave per block)
 }
 
 
@@ -42,7 +48,7 @@ def test_tuned_kernels_stay_inside_their_budget(stats, prefix):
     s = _one(stats, prefix)
     vmax, (ilo, ihi), lds = BUDGET[prefix]
     assert s["vgpr_spill"] == 0 and s["scratch_bytes"] == 0, s
-    assert 128 < s["vgpr"] + s.get("agpr", 0) <= vmax, s   # the 2-waves-per-SIMD class the kernels were tuned in
+    assert 128 < s["vgpr"] + s.get("agpr", 0) <= vmax, s
     assert ilo <= s["instructions"] <= ihi, s
     assert s["lds_bytes"] <= lds, s
 
