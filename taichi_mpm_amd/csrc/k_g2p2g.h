@@ -1,0 +1,546 @@
+// taichi_mpm_amd/csrc/k_g2p2g.h — EXPERIMENTAL: k_g2p (k_g2p.h) extended by the next substep's P2G ("G2P2G").
+// Compiled only with -DMPMHIP_WITH_FUSED (lib/libmpmhip_fused.so): it lost its A/B against the two separate kernels
+// (profiles/r03_f_fused.txt) and is kept, with its tests (tests/test_gpu_fused.py), as the record of that
+// measurement.  The G2P part below is k_g2p.h's, statement for statement; the tuned kernel itself is left untouched —
+// edits that are no-ops for its results move its speed by +-3 % (profiles/r03_h_ab_refactor.txt).
+// Part of libmpmhip (see mpmhip.hip for the substep overview and the data layout).
+#pragma once
+#include "k_g2p.h"
+
+namespace mpm {
+
+// ------------------------------------------------------------------------------------------------ G2P
+// resample_optimized / block_op_normal (src/transfer.cpp:837-954), one workgroup per active block, one
+// particle per lane through the sorted index.  Also produces, for the NEXT substep: the affine matrix A of
+// P2G (stress of the updated F from the same eigen-solve as the plasticity) and the sort key of the new position.
+// The updated records are written to the OTHER record buffers at the particle's SORTED POSITION (the host swaps the
+// buffers behind the launch): every substep leaves the records in the order of its own sort, i.e. one substep stale —
+// the physical reorder of the reference's sort_allocator (src/mpm.cpp:752-768) for free, every substep instead of every
+// reorder_interval, with fully sequential record stores; particles deleted by an earlier substep drop out, so the live
+// records always occupy the slots [0, n_sorted).
+// RIGID: CPIC rigid bodies exist — blocks flagged by k_blk_rigid (top bit of act_start) are left to k_g2p_rigid and the
+// records' spare word (the particle's colour) is carried along.  A compile-time switch: the instantiation without it is the kernel tuned above,
+// instruction for instruction.
+// MATS: the set of material types the ctx's groups use (mpm_math.h: plasticity_and_force) — the full set, or one material.
+//
+// FUSED ("G2P2G"): the kernel also performs the NEXT substep's P2G (rasterize_optimized, src/transfer.cpp:467-569) from the
+// state it has just computed, so the P2G-side record (x, v, A, mass: 64 B written here, 64 B + 4 B of index read by k_p2g)
+// never travels through HBM — 132 of the 268 B the two transfers move per particle-step.  The lane-per-cell register
+// accumulation of k_p2g (no float atomics) needs particles grouped by their NEW cell, while a workgroup holds the particles
+// of one block grouped by their OLD one.  A particle moves less than one cell per substep (CFL), so its new base cell lies
+// in the block or in the one-cell shell around it.  Per chunk of 256 particles:
+//   phase A  (four waves)  G2P as before; the P2G inputs of every particle go to an LDS stage and an integer LDS atomic
+//            counts it into its new cell (64 bins) or onto the short list of particles that left the block;
+//   phase B  scan of the 64 counts, per-cell index lists, then THREE waves — one lane per cell each, wave w taking the plane
+//            i = w of the 3x3x3 stencil: nine nodes = 36 accumulator registers instead of k_p2g's 108, which keeps the kernel
+//            inside the 168 VGPRs that three workgroups per CU can have (with all 27 nodes in one wave the kernel needs 256
+//            registers, two workgroups per CU, and three of four waves idle during the scatter: measured 0.59 ms against
+//            0.46 ms for the two separate kernels, profiles/r03_e_fused_v1.txt).  Each wave merges its plane into a private
+//            4x6x6-node slab (its own, idle, store slab) by ordered float4 read-modify-writes as in k_p2g; the fourth wave
+//            meanwhile adds the leavers to the block's 8^3-node tile, 27 lanes (one per stencil node) per particle; finally
+//            all threads add the three slabs to the tile.
+// The 8^3 tiles (tiles8: nodes 4b-1 .. 4b+6 of block b, indexed by THIS sort's block slot) are summed by k_grid_fused after
+// the next sort, which looks the previous block table up through the previous bitmap.  write_p != 0 (the last substep of a
+// batch) also stores the P2G records, so that downloads, snapshots and the unfused path find them current.
+constexpr int T8 = 8, T8N = 512;  // output tile: 8^3 nodes
+constexpr int PSL = 4 * TS * TS;  // nodes of a plane slab: x in [0, 4), y, z in [0, 6)
+// 4 float4 per entry at a 64-byte stride plus one float4 of padding after every 4 entries: 16 lanes writing the same quad
+// of 16 consecutive entries hit 16 different bank groups, and the quad index stays an immediate offset of the entry's
+// address (an XOR swizzle costs one address register per quad, and those live across the whole chunk loop) — stage, and the
+// store slabs of the fused kernel
+__device__ __forceinline__ int stage_at(int idx, int q) { return idx * 4 + (idx >> 2) + q; }
+constexpr int stage_len(int n) { return n * 4 + n / 4; }
+constexpr int G2P_LDS_GROUPS_FUSED = 32;  // (the fused kernel mirrors 32 rows of the group table: 2.5 KB it needs elsewhere)
+
+template <int NT, int MINW, bool ROLL, bool STORE_B, bool RIGID = false, uint32_t MATS = MAT_ALL, bool FUSED = true>
+__global__ __launch_bounds__(NT, MINW) void k_g2p2g(Params P, const float4 *__restrict__ rg, float4 *__restrict__ rg_out,
+                                                  float4 *__restrict__ rp_out, float4 *__restrict__ rb_out,
+                                                  const Counters *__restrict__ cnt,
+                                                  const uint32_t *__restrict__ act_blk,
+                                                  const uint32_t *__restrict__ act_start,
+                                                  const uint32_t *__restrict__ perm,
+                                                  const GroupParams *__restrict__ groups,
+                                                  const float4 *__restrict__ gridv,
+                                                  const uint32_t *__restrict__ fat_slot, Counters *cnt_w,
+                                                  uint32_t *__restrict__ key, uint8_t *__restrict__ blk_flag,
+                                                  const LevelSetDev *__restrict__ ls, PhaseBox T, int phase,
+                                                  float4 *__restrict__ tiles8, int write_p) {
+  static_assert(!FUSED || (NT == 256 && !RIGID && !STORE_B), "the fused kernel exists for the default storage mode only");
+  __shared__ float4 tile[TN];
+  // FUSED state (sizes collapse to one element otherwise)
+  __shared__ float4 stage[FUSED ? stage_len(NT) : 1];        // P2G inputs of the chunk's particles
+  __shared__ uint32_t stag[FUSED ? NT : 1];           // (new cell << 16) | rank in the cell; INVALID: dead or a leaver
+  __shared__ uint16_t slist[FUSED ? NT : 2];          // staged indices grouped by new cell
+  __shared__ uint16_t slv[FUSED ? NT : 2];            // staged indices of the particles that left the block
+  __shared__ uint32_t scnt[FUSED ? BC + 1 : 1];       // particles per new cell; [BC]: leavers
+  __shared__ uint32_t sstart[FUSED ? BC : 1];
+  __shared__ float4 otile[FUSED ? T8N : 1];           // the block's P2G result for the next substep
+  if constexpr (FUSED) {
+    for (int t = threadIdx.x; t < T8N; t += NT) otile[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (threadIdx.x <= BC) scnt[threadIdx.x] = 0u;
+  }
+
+  constexpr int NGROUPS = FUSED ? G2P_LDS_GROUPS_FUSED : G2P_LDS_GROUPS;
+  __shared__ GroupParams sgroups[NGROUPS];
+  for (int t = threadIdx.x; t < NGROUPS * (int)(sizeof(GroupParams) / 4); t += NT)
+    reinterpret_cast<uint32_t *>(sgroups)[t] = reinterpret_cast<const uint32_t *>(groups)[t];  // (the table holds >= 256 rows)
+  __syncthreads();
+  // Store staging, one slab per wavefront.  A lane holds its particle's whole record, so a direct store would
+  // issue 16-byte pieces at a 64-byte stride: 64 partial-line write requests per instruction (measured: the
+  // stores alone cost 0.28 of 0.61 ms).  Records are written row-wise to LDS (80-byte stride: conflict-free
+  // b128) and read back transposed, so 4 consecutive lanes store the 4 float4 of one record: full 64-byte
+  // segments, 4x fewer write requests.
+  __shared__ float4 xpose[NT / 64][FUSED ? stage_len(64) : 64 * 5];  // (FUSED: 64-byte stride, padded: stage_at — 0.7 KB less per wave)
+  __shared__ uint32_t xslot[NT / 64][64];
+  const uint32_t na = min(cnt->n_active, P.max_blocks);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  float4 *xp = xpose[wave];
+  uint32_t *xs = xslot[wave];
+  auto XP = [](int e, int q) { return FUSED ? stage_at(e, q) : e * 5 + q; };  // entry e, quad q of a store slab
+  const float scale = -4.0f * P.idx * P.dt;  // :938
+  // The workgroup walks "chunks": NT consecutive entries of the sorted index inside one active block.  The
+  // record gather of chunk k+1 and the index load of chunk k+2 are issued before the arithmetic of chunk k
+  // (also across block boundaries), so every wave keeps 4 KiB of loads in flight while it computes.
+  struct Chunk { uint32_t a, p, p1; };
+  auto first = [&](uint32_t a) {
+    Chunk c;
+    c.a = a; c.p = 0; c.p1 = 0;
+    while (c.a < na) {
+      c.p = act_start[c.a]; c.p1 = act_start[c.a + 1];
+      bool rigid_block = false;
+      if constexpr (RIGID) {  // the top bit flags a block near a rigid body (k_blk_rigid): k_g2p_rigid takes it
+        rigid_block = (c.p & 0x80000000u) != 0u;
+        c.p &= 0x7FFFFFFFu; c.p1 &= 0x7FFFFFFFu;
+      }
+      bool mine = c.p < c.p1 && !rigid_block;  // (empty block: all its particles migrated away)
+      if (mine && phase != 0) {
+        int bx, by, bz;
+        demorton3(act_blk[c.a], bx, by, bz);
+        mine = in_phase(T, phase, bx * BS, by * BS, bz * BS, 2 * BS);
+      }
+      if (mine) break;
+      c.a += gridDim.x;
+    }
+    return c;
+  };
+  auto next = [&](Chunk c) {
+    if (c.a >= na) return c;
+    c.p += NT;
+    if (c.p >= c.p1) c = first(c.a + gridDim.x);
+    return c;
+  };
+  auto lane_slot = [&](const Chunk &c) -> uint32_t {
+    return (c.a < na && c.p + tid < c.p1) ? perm[c.p + tid] : INVALID;
+  };
+  const bool nt_store = P.n_slots >= NT_STORE_MIN_SLOTS;  // see st_rec
+  Chunk cur = first(blockIdx.x);
+  Chunk nx = next(cur);
+  uint32_t i_cur = lane_slot(cur);
+  float4 g0, g1, g2, g3;
+  if (i_cur != INVALID) {
+    const size_t i = i_cur;
+    g0 = rg[i * 4 + 0]; g1 = rg[i * 4 + 1]; g2 = rg[i * 4 + 2]; g3 = rg[i * 4 + 3];
+  }
+  uint32_t i_nx = lane_slot(nx);
+  uint32_t tile_a = INVALID;
+  float ox = 0, oy = 0, oz = 0;
+  int obx = 0, oby = 0, obz = 0;  // (FUSED) the block's first cell
+  // The loop below keeps loads in flight across its back edge, and the compiler's wait-count insertion merges the state of
+  // the entry edge with that of the back edge: a prologue load still pending at entry (the index i_nx) makes it put a
+  // vmcnt(0) in front of the prefetch INSIDE the loop — where it also waits for the previous chunk's record stores (the
+  // counter is shared and in-order): measured 0.305 -> 0.364 ms at C3 when an unrelated edit changed the schedule.  Draining
+  // the prologue's loads here, once per workgroup, makes the entry state empty whatever the schedule.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  while (cur.a < na) {
+    if (cur.a != tile_a) {
+      // LDS-only barriers (lgkmcnt(0) + s_barrier): __syncthreads() would also wait on vmcnt, i.e. on the
+      // acknowledgements of the previous chunk's record stores
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();  // everyone is done with the previous tile
+      int bx, by, bz;
+      demorton3(act_blk[cur.a], bx, by, bz);
+      // (an opaque copy of the thread index: the node arithmetic below is loop-invariant, and hoisted out of the chunk loop
+      // it would occupy registers through the whole kernel for something that runs once per block)
+      int tT = tid;
+      asm volatile("" : "+v"(tT));
+      for (int t = tT; t < TN; t += NT) {
+        const int tx = t / (TS * TS), ty = (t / TS) % TS, tz = t % TS;
+        const int qx = tx >> 2, qy = ty >> 2, qz = tz >> 2;
+        const uint32_t fs = fat_slot[morton3(bx + qx, by + qy, bz + qz)];
+        tile[t] = gridv[(size_t)fs * BC + (((tx & 3) << 4) | ((ty & 3) << 2) | (tz & 3))];
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      ox = (float)(bx * BS); oy = (float)(by * BS); oz = (float)(bz * BS);
+      if constexpr (FUSED) { obx = bx * BS; oby = by * BS; obz = bz * BS; }
+      tile_a = cur.a;
+    }
+    // prefetch: records of the next chunk, index of the one after
+    const Chunk nn = next(nx);
+    float4 n0, n1, n2, n3;
+    if (i_nx != INVALID) {
+      const size_t i = i_nx;
+      n0 = rg[i * 4 + 0]; n1 = rg[i * 4 + 1]; n2 = rg[i * 4 + 2]; n3 = rg[i * 4 + 3];
+    }
+    const uint32_t i_nn = lane_slot(nn);
+    uint32_t bkey = INVALID, out_slot = INVALID;
+    // the outgoing records of the lane's particle: defined by particle(), dead after the slab writes below (declared out
+    // here, once, they were loop-carried: 32 registers alive through the whole kernel for the sake of lanes without a particle)
+    float4 G0, G1, G2, G3, Q0, Q1, Q2, Q3, B0, B1, B2;
+    uint32_t ftag = INVALID;  // (FUSED) (new cell << 16) | rank
+    bool fleave = false;      // (FUSED) the particle's new base cell is outside this block
+    auto particle = [&](const GroupParams &g) __attribute__((always_inline)) {
+      const float x0 = g0.x, x1 = g0.y, x2 = g0.z;
+      const float X0 = x0 * P.idx - ox, X1 = x1 * P.idx - oy, X2 = x2 * P.idx - oz;
+      const int c0 = (int)(X0 - 0.5f), c1 = (int)(X1 - 0.5f), c2 = (int)(X2 - 0.5f);
+      const float r0 = X0 - (float)c0, r1 = X1 - (float)c1, r2 = X2 - (float)c2;
+      float w0[3], w1[3], w2[3];
+      bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
+      // 27-tap gather, :888-904:  v = sum w g,  b[:, c] = sum (w d_c) g  with  w = w0[i] w1[j] w2[k],  d = r - (i, j, k).
+      // The weights factor along the axes, so the sums are taken axis by axis — 4 multiply-adds per node on the (x, y) and
+      // (z, m) register pairs of the tile's float4 (packed fp32: v_pk_fma_f32) instead of 15 scalar ones per node:
+      //   S0 = sum_k w2[k] g,  S1 = sum_k (w2 d2)[k] g;   T0 = sum_j w1[j] S0,  T1 = sum_j (w1 d1)[j] S0,  T2 = sum_j w1[j] S1;
+      //   v = sum_i w0[i] T0,  b[:,0] = sum_i (w0 d0)[i] T0,  b[:,1] = sum_i w0[i] T1,  b[:,2] = sum_i w0[i] T2
+      // (the m lanes ride along unused).  Same terms as the reference's loop, summed in a different order.
+      const float e0[3] = {w0[0] * r0, w0[1] * (r0 - 1.0f), w0[2] * (r0 - 2.0f)};
+      const float e1[3] = {w1[0] * r1, w1[1] * (r1 - 1.0f), w1[2] * (r1 - 2.0f)};
+      const float e2[3] = {w2[0] * r2, w2[1] * (r2 - 1.0f), w2[2] * (r2 - 2.0f)};
+      const f2 z2 = {0.0f, 0.0f};
+      f2 vxy = z2, vzw = z2, b0xy = z2, b0zw = z2, b1xy = z2, b1zw = z2, b2xy = z2, b2zw = z2;
+      const int nbase = (c0 * TS + c1) * TS + c2;
+      auto plane = [&](int i3, float w0i, float e0i) __attribute__((always_inline)) {
+        f2 T0xy = z2, T0zw = z2, T1xy = z2, T1zw = z2, T2xy = z2, T2zw = z2;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          f2 S0xy = z2, S0zw = z2, S1xy = z2, S1zw = z2;
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const float4 gv = tile[nbase + (i3 * TS + j) * TS + k];
+            const f2 gxy = {gv.x, gv.y}, gzw = {gv.z, gv.w};
+            S0xy = fma2(splat2(w2[k]), gxy, S0xy); S0zw = fma2(splat2(w2[k]), gzw, S0zw);
+            S1xy = fma2(splat2(e2[k]), gxy, S1xy); S1zw = fma2(splat2(e2[k]), gzw, S1zw);
+          }
+          T0xy = fma2(splat2(w1[j]), S0xy, T0xy); T0zw = fma2(splat2(w1[j]), S0zw, T0zw);
+          T1xy = fma2(splat2(e1[j]), S0xy, T1xy); T1zw = fma2(splat2(e1[j]), S0zw, T1zw);
+          T2xy = fma2(splat2(w1[j]), S1xy, T2xy); T2zw = fma2(splat2(w1[j]), S1zw, T2zw);
+        }
+        vxy = fma2(splat2(w0i), T0xy, vxy); vzw = fma2(splat2(w0i), T0zw, vzw);
+        b0xy = fma2(splat2(e0i), T0xy, b0xy); b0zw = fma2(splat2(e0i), T0zw, b0zw);
+        b1xy = fma2(splat2(w0i), T1xy, b1xy); b1zw = fma2(splat2(w0i), T1zw, b1zw);
+        b2xy = fma2(splat2(w0i), T2xy, b2xy); b2zw = fma2(splat2(w0i), T2zw, b2zw);
+      };
+      if (!MPM_ABLATE(P, 4)) {
+        plane(0, w0[0], e0[0]); plane(1, w0[1], e0[1]); plane(2, w0[2], e0[2]);
+      }
+      float v0 = vxy.x, v1 = vxy.y, v2 = vzw.x;
+      mat3 b;
+      b(0, 0) = b0xy.x; b(1, 0) = b0xy.y; b(2, 0) = b0zw.x;
+      b(0, 1) = b1xy.x; b(1, 1) = b1xy.y; b(2, 1) = b1zw.x;
+      b(0, 2) = b2xy.x; b(1, 2) = b2xy.y; b(2, 2) = b2zw.x;
+      mat3 cdg;  // :940-942  cdg = I + (-4 inv_dx dt) b   (undamped b, as in the reference)
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) cdg(r, c) = fmaf(scale, b(r, c), (r == c) ? 1.0f : 0.0f);
+      // apic_b = damp_affine_momemtum(b) (src/mpm.h:465-469); the reference's optimised path has a bug
+      // here (passes the block index, transfer.cpp:925-926) — we implement the intended damping.
+      if (P.rpic_damping != 0.0f || P.apic_damping != 0.0f) {
+        const float ks = 1.0f - P.rpic_damping, ka = 1.0f - P.apic_damping;
+        mat3 bd;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const float sym = 0.5f * (b(r, c) + b(c, r));
+            bd(r, c) = ks * sym + ka * (b(r, c) - sym);
+          }
+        b = bd;
+      }
+      mat3 F;
+      F.m[0] = g1.x; F.m[1] = g1.y; F.m[2] = g1.z; F.m[3] = g1.w; F.m[4] = g2.x; F.m[5] = g2.y; F.m[6] = g2.z;
+      F.m[7] = g2.w; F.m[8] = g3.x;
+      float aux = g0.w;
+      mat3 stress;
+      if (!MPM_ABLATE(P, 2)) plasticity_and_force<MATS>(g, cdg, F, aux, stress);  // :950 + next substep's :509
+      else stress = cdg;
+      float nx0 = fmaf(v0, P.dt, x0), nx1 = fmaf(v1, P.dt, x1), nx2 = fmaf(v2, P.dt, x2);  // :951
+      if (P.clamp_pos) {  // generic path only (optimized = false): p.pos clamped into [0, res - eps], :668-670
+        nx0 = fminf(fmaxf(nx0 * P.idx, 0.0f), (float)P.res[0] - 1e-6f) * P.dx;
+        nx1 = fminf(fmaxf(nx1 * P.idx, 0.0f), (float)P.res[1] - 1e-6f) * P.dx;
+        nx2 = fminf(fmaxf(nx2 * P.idx, 0.0f), (float)P.res[2] - 1e-6f) * P.dx;
+      }
+      if (P.particle_collision) {  // particle_collision_resolution, src/mpm.cpp:414-426 (runs after G2P, :566-569)
+        const LevelSetDev &LS = *ls;  // in device memory: by value it would sit in ~130 SGPRs for a rarely used path
+        const float xw[3] = {nx0, nx1, nx2};
+        float phi, gr[3] = {0, 0, 0};
+        if (levelset_eval(LS, P.t, xw, P.idx, phi, gr) && phi < 0.0f) {
+          const float vn = gr[0] * v0 + gr[1] * v1 + gr[2] * v2;
+          nx0 -= gr[0] * phi * P.dx; nx1 -= gr[1] * phi * P.dx; nx2 -= gr[2] * phi * P.dx;
+          v0 -= vn * gr[0]; v1 -= vn * gr[1]; v2 -= vn * gr[2];
+        }
+      }
+      const float m4 = 4.0f * g.p[0];
+      float A[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) A[k] = fmaf(stress.m[k], scale, b.m[k] * m4);  // next P2G's :521-522
+      // next substep's key; deleted particles (clear_boundary_particles) are marked for good
+      const float nxp[3] = {nx0, nx1, nx2}, nv[3] = {v0, v1, v2};
+      const uint32_t kk = particle_key(P, nxp, nv, bkey);
+      if constexpr (FUSED) {
+        // where the particle goes in the NEXT substep's P2G: its new base cell relative to this block (particle_key's own
+        // arithmetic).  CFL: within one cell of the old one, i.e. in [-1, 4]^3; anything farther is reported (cnt->error bit 3).
+        ftag = INVALID;
+        if (kk != INVALID) {
+          const int r0n = (int)(nx0 * P.idx - 0.5f) - obx, r1n = (int)(nx1 * P.idx - 0.5f) - oby, r2n = (int)(nx2 * P.idx - 0.5f) - obz;
+          const bool inside = (unsigned)r0n < (unsigned)BS && (unsigned)r1n < (unsigned)BS && (unsigned)r2n < (unsigned)BS;
+          if (inside) {
+            const uint32_t cid = (uint32_t)((r0n << 4) | (r1n << 2) | r2n);
+            ftag = (cid << 16) | atomicAdd(&scnt[cid], 1u);
+          } else {
+            if (r0n < -1 || r0n > BS || r1n < -1 || r1n > BS || r2n < -1 || r2n > BS) atomicOr(&cnt_w->error, 8u);
+            else fleave = true;
+          }
+        }
+      }
+      int32_t pid = __float_as_int(g3.z);
+      if (kk == INVALID) {
+        pid = -1;
+        atomicAdd(&cnt_w->n_dead, 1u);
+      }
+      key[cur.p + tid] = kk;
+      G0 = make_float4(nx0, nx1, nx2, aux);
+      G1 = make_float4(F.m[0], F.m[1], F.m[2], F.m[3]);
+      G2 = make_float4(F.m[4], F.m[5], F.m[6], F.m[7]);
+      G3 = make_float4(F.m[8], g3.y, __int_as_float(pid), RIGID ? g3.w : 0.0f);  // (.w: the particle's CPIC colour word travels with it)
+      Q0 = make_float4(nx0, nx1, nx2, v0);
+      Q1 = make_float4(v1, v2, A[0], A[1]);
+      Q2 = make_float4(A[2], A[3], A[4], A[5]);
+      Q3 = make_float4(A[6], A[7], A[8], g.p[0]);
+      if constexpr (STORE_B) {
+        B0 = make_float4(b.m[0], b.m[1], b.m[2], b.m[3]);
+        B1 = make_float4(b.m[4], b.m[5], b.m[6], b.m[7]);
+        B2 = make_float4(b.m[8], 0.0f, 0.0f, 0.0f);
+      }
+      out_slot = MPM_ABLATE(P, 1) ? INVALID : cur.p + tid;
+    };
+    // Group parameters are read at use (keeps ~20 VGPRs free) from the workgroup's LDS copy of the table: DS reads
+    // wait on lgkmcnt, whereas vector loads in the middle of the arithmetic wait on vmcnt and with it on the
+    // prefetched records of the next chunk (the counter is in-order), which would undo the prefetch.
+    if (i_cur != INVALID) particle(sgroups[__float_as_uint(g3.y) & (NGROUPS - 1)]);
+    // Let the prefetched records of the next chunk land BEFORE this chunk's stores go out: on gfx9-family parts
+    // loads and stores share one in-order-per-type counter (vmcnt), so a later wait for those loads would be a
+    // vmcnt(0) that also waits for the stores' acknowledgements — here the loads have had the whole arithmetic to
+    // arrive, and the stores then drain behind the next chunk's arithmetic.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+    // transposed stores through this wave's LDS slab (DS operations of one wave execute in program order)
+    xs[lane] = out_slot;  // (INVALID for a lane without a particle: its slab row is never read out to memory)
+    if (i_cur != INVALID) { xp[XP(lane, 0)] = G0; xp[XP(lane, 1)] = G1; xp[XP(lane, 2)] = G2; xp[XP(lane, 3)] = G3; }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int src = 16 * k + (lane >> 2), q = lane & 3;
+      const uint32_t sl = xs[src];
+      const float4 val = xp[XP(src, q)];
+      if (sl != INVALID) st_rec(rg_out + (size_t)sl * 4 + q, val, nt_store);
+    }
+    if (!FUSED || write_p) {  // (FUSED: the P2G records leave the chip only on the last substep of a batch)
+      __builtin_amdgcn_wave_barrier();
+      if (i_cur != INVALID) { xp[XP(lane, 0)] = Q0; xp[XP(lane, 1)] = Q1; xp[XP(lane, 2)] = Q2; xp[XP(lane, 3)] = Q3; }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int src = 16 * k + (lane >> 2), q = lane & 3;
+        const uint32_t sl = xs[src];
+        const float4 val = xp[XP(src, q)];
+        if (sl != INVALID) st_rec(rp_out + (size_t)sl * 4 + q, val, nt_store);
+      }
+    }
+    if constexpr (STORE_B) {  // (compile-time: in the default folded mode the apic_b registers do not exist)
+      __builtin_amdgcn_wave_barrier();
+      if (i_cur != INVALID) { xp[lane * 5 + 0] = B0; xp[lane * 5 + 1] = B1; xp[lane * 5 + 2] = B2; }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int e = 64 * k + lane, src = e / 3, q = e - 3 * src;
+        const uint32_t sl = xs[src];
+        const float4 val = xp[src * 5 + q];
+        if (sl != INVALID) rb_out[(size_t)sl * 3 + q] = val;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    flag_block(blk_flag, bkey);
+    if constexpr (FUSED) {
+      // (Opaque copies of the thread index: everything phase B derives from it — cell coordinates, a dozen LDS addresses —
+      // is loop-invariant, and hoisted out of the chunk loop those values live in registers through phase A, where the
+      // allocator spills them: 47 spilled VGPRs, reloaded through scratch, i.e. behind vmcnt waits on the prefetched
+      // records.  Recomputing a few integer operations per chunk is free by comparison.)
+      int tB = tid;
+      asm volatile("" : "+v"(tB));
+      const int lB = tB & 63;
+      const int wB = __builtin_amdgcn_readfirstlane(tB >> 6);
+      // ---- phase A, tail: stage this chunk's P2G inputs (entry = thread)
+      if (i_cur != INVALID && (ftag != INVALID || fleave)) {
+        stage[stage_at(tB, 0)] = Q0; stage[stage_at(tB, 1)] = Q1; stage[stage_at(tB, 2)] = Q2; stage[stage_at(tB, 3)] = Q3;
+        if (fleave) slv[atomicAdd(&scnt[BC], 1u)] = (uint16_t)tB;
+      }
+      stag[tB] = (i_cur != INVALID) ? ftag : INVALID;
+      // ---- phase B: the chunk's P2G into the block's 8^3 tile
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();  // stage, tags and counts of the chunk are in; the store slabs are idle
+      if (wB == 0) {  // exclusive scan of the 64 cell counts (ds_bpermute on the opaque lane index: __shfl_up's own lane
+                      // arithmetic would be hoisted, six address registers)
+        const uint32_t v = scnt[lB];
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t u = (uint32_t)__builtin_amdgcn_ds_bpermute((lB - off) << 2, (int)inc);
+          if (lB >= off) inc += u;
+        }
+        sstart[lB] = inc - v;
+      }
+      if (wB < 3) {  // this wave's plane slab (its store slab) starts from zero
+        for (int t = lB; t < PSL; t += 64) xpose[wB][t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      {  // per-cell index lists
+        const uint32_t tg = stag[tB];
+        if (tg != INVALID) slist[sstart[tg >> 16] + (tg & 0xFFFFu)] = (uint16_t)tB;
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      if (wB < 3) {
+        // plane `wave` of the stencil: k_p2g's particle loop (k_p2g.h: p2g_cell, src/transfer.cpp:485-541) for the nodes
+        // (wave, j, k), records from LDS
+        const int cx = lB >> 4, cy = (lB >> 2) & 3, cz = lB & 3;
+        const uint32_t p0 = sstart[lB], p1 = p0 + scnt[lB];
+        const float cox = ox + (float)cx, coy = oy + (float)cy, coz = oz + (float)cz;
+        const float fi = (float)wB;
+        f2 axy[9], azw[9];
+#pragma unroll
+        for (int n = 0; n < 9; n++) { axy[n] = (f2){0.0f, 0.0f}; azw[n] = (f2){0.0f, 0.0f}; }
+        float4 n0q, n1q, n2q, n3q;
+        if (p0 < p1) {
+          const int e = slist[p0];
+          n0q = stage[stage_at(e, 0)]; n1q = stage[stage_at(e, 1)]; n2q = stage[stage_at(e, 2)]; n3q = stage[stage_at(e, 3)];
+        }
+        for (uint32_t p = p0; p < p1; p++) {
+          const float4 q0 = n0q, q1 = n1q, q2 = n2q, q3 = n3q;
+          if (p + 1 < p1) {  // next record on its way from LDS while this one is computed
+            const int e = slist[p + 1];
+            n0q = stage[stage_at(e, 0)]; n1q = stage[stage_at(e, 1)]; n2q = stage[stage_at(e, 2)]; n3q = stage[stage_at(e, 3)];
+          }
+          const float mass = q3.w;
+          float v0 = q0.w, v1 = q1.x, v2 = q1.y;
+          if (P.particle_gravity) { v0 = fmaf(P.g[0], P.dt, v0); v1 = fmaf(P.g[1], P.dt, v1); v2 = fmaf(P.g[2], P.dt, v2); }
+          const float r0 = q0.x * P.idx - cox, r1 = q0.y * P.idx - coy, r2 = q0.z * P.idx - coz;
+          float w0[3], w1[3], w2[3];
+          bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
+          const float w0p = wB == 0 ? w0[0] : (wB == 1 ? w0[1] : w0[2]);  // (wave-uniform selects)
+          const float A00 = q1.z, A01 = q1.w, A02 = q2.x, A10 = q2.y, A11 = q2.z, A12 = q2.w, A20 = q3.x, A21 = q3.y, A22 = q3.z;
+          const float d0 = r0 - fi;  // the plane's node offset along x
+          const f2 a1xy = {A01, A11}, a1zw = {A21, 0.0f}, a2xy = {A02, A12}, a2zw = {A22, 0.0f};
+          f2 cjxy = {fmaf(A02, r2, fmaf(A01, r1, fmaf(A00, d0, mass * v0))), fmaf(A12, r2, fmaf(A11, r1, fmaf(A10, d0, mass * v1)))};
+          f2 cjzw = {fmaf(A22, r2, fmaf(A21, r1, fmaf(A20, d0, mass * v2))), mass};
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            const float wij = w0p * w1[j];
+            f2 ckxy = cjxy, ckzw = cjzw;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              const f2 w = splat2(wij * w2[k]);
+              axy[j * 3 + k] = fma2(w, ckxy, axy[j * 3 + k]); azw[j * 3 + k] = fma2(w, ckzw, azw[j * 3 + k]);
+              if (k < 2) { ckxy -= a2xy; ckzw -= a2zw; }
+            }
+            if (j < 2) { cjxy -= a1xy; cjzw -= a1zw; }
+          }
+        }
+        // merge into the wave's slab: within one (j, k) all 64 cells address distinct nodes, and the LDS operations of a
+        // wave execute in order (k_p2g.h)
+        const int nb = (cx * TS + cy) * TS + cz;
+#pragma unroll
+        for (int n = 0; n < 9; n++) {
+          const int node = nb + (n / 3) * TS + n % 3;
+          if (p1 > p0) {
+            float4 t = xpose[wB][node];
+            t.x += axy[n].x; t.y += axy[n].y; t.z += azw[n].x; t.w += azw[n].y;
+            xpose[wB][node] = t;
+          }
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("" ::: "memory");
+        }
+      } else {
+        // the particles that left the block, one at a time: lane n < 27 adds the contribution to stencil node n of the tile
+        const uint32_t nl = scnt[BC];
+        for (uint32_t u = 0; u < nl; u++) {
+          const int e = slv[u];
+          const float4 q0 = stage[stage_at(e, 0)], q1 = stage[stage_at(e, 1)], q2 = stage[stage_at(e, 2)], q3 = stage[stage_at(e, 3)];
+          const float mass = q3.w;
+          float v0 = q0.w, v1 = q1.x, v2 = q1.y;
+          if (P.particle_gravity) { v0 = fmaf(P.g[0], P.dt, v0); v1 = fmaf(P.g[1], P.dt, v1); v2 = fmaf(P.g[2], P.dt, v2); }
+          const float X0 = q0.x * P.idx, X1 = q0.y * P.idx, X2 = q0.z * P.idx;
+          const int b0 = (int)(X0 - 0.5f), b1 = (int)(X1 - 0.5f), b2 = (int)(X2 - 0.5f);
+          const float r0 = X0 - (float)b0, r1 = X1 - (float)b1, r2 = X2 - (float)b2;
+          float w0[3], w1[3], w2[3];
+          bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
+          const int i3 = lB / 9, j = (lB / 3) % 3, k = lB % 3;
+          if (lB < 27) {
+            const float d0 = r0 - (float)i3, d1 = r1 - (float)j, d2 = r2 - (float)k;
+            const float w = (w0[i3] * w1[j]) * w2[k];
+            const float c0 = fmaf(q2.x, d2, fmaf(q1.w, d1, fmaf(q1.z, d0, mass * v0)));
+            const float c1 = fmaf(q2.w, d2, fmaf(q2.z, d1, fmaf(q2.y, d0, mass * v1)));
+            const float c2 = fmaf(q3.z, d2, fmaf(q3.y, d1, fmaf(q3.x, d0, mass * v2)));
+            const int node = ((b0 - obx + 1 + i3) * T8 + (b1 - oby + 1 + j)) * T8 + (b2 - obz + 1 + k);
+            float4 t = otile[node];
+            t.x = fmaf(w, c0, t.x); t.y = fmaf(w, c1, t.y); t.z = fmaf(w, c2, t.z); t.w = fmaf(w, mass, t.w);
+            otile[node] = t;
+          }
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("" ::: "memory");
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();  // the three slabs and the leavers are in
+      if (tB < TN) {  // node (X, Y, Z) of the tile's interior 6^3: plane w covers X - w in [0, 4)
+        const int X = tB / (TS * TS), rem = tB - X * (TS * TS);
+        float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int w = 0; w < 3; w++) {
+          const int xr = X - w;
+          if (xr >= 0 && xr < 4) {
+            const float4 t = xpose[w][xr * (TS * TS) + rem];
+            sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+          }
+        }
+        const int Y = rem / TS, Z = rem - Y * TS;
+        const int node = ((X + 1) * T8 + (Y + 1)) * T8 + (Z + 1);
+        float4 t = otile[node];
+        t.x += sum.x; t.y += sum.y; t.z += sum.z; t.w += sum.w;
+        otile[node] = t;
+      }
+      if (tB <= BC) scnt[tB] = 0u;
+      if (nx.a != cur.a) {  // (workgroup-uniform) the block is done: its tile goes out
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        for (int t = tB; t < T8N; t += NT) {
+          st_rec(tiles8 + (size_t)cur.a * T8N + t, otile[t], false);
+          otile[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+    }
+    cur = nx; nx = nn;
+    i_cur = i_nx; i_nx = i_nn;
+    g0 = n0; g1 = n1; g2 = n2; g3 = n3;
+  }
+  // slots behind the live range (particles deleted by earlier substeps have dropped out): dead for every consumer
+  for (uint32_t t = cnt->n_sorted + blockIdx.x * NT + tid; t < P.n_slots; t += gridDim.x * NT) {
+    key[t] = INVALID;
+    rg_out[(size_t)t * 4 + 3] = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);  // pid = -1
+  }
+}
+
+
+}  // namespace mpm

@@ -33,12 +33,12 @@ def _one(stats, prefix):
 # k_g2p: <= 168 VGPRs = THREE workgroups per CU (512 registers per SIMD lane, allocated in eights); at 180 the same code ran
 # 14 % slower on the same box (profiles/r03_b_ab_vgpr.txt) — the all-material kernel (MATS = 510, visco included) is the one
 # instantiation allowed above it.
-G2P = "_ZN3mpm5k_g2pILi256ELi2ELb1ELb0ELb0ELj%dEEE"
+G2P = "_ZN3mpm5k_g2pILi256ELi%dELb1ELb0ELb0ELj%dEEE"  # <NT, MINW, ROLL, STORE_B, RIGID, MATS>
 BUDGET = {
-    G2P % 64: (168, (2400, 3300), 53 * 1024),    # sand only (the benchmark configuration C3)
-    G2P % 16: (168, (2200, 3200), 53 * 1024),    # jelly only (C2)
-    G2P % 508: (168, (3000, 4200), 53 * 1024),   # every material but visco (mixed scenes, C5)
-    G2P % 510: (256, (4800, 6200), 80 * 1024),   # all eight
+    G2P % (2, 64): (168, (2400, 3300), 53 * 1024),    # sand only (the benchmark configuration C3)
+    G2P % (2, 16): (168, (2200, 3200), 53 * 1024),    # jelly only (C2)
+    G2P % (2, 508): (168, (3000, 4200), 53 * 1024),   # every material but visco (mixed scenes, C5)
+    G2P % (2, 510): (256, (4800, 6200), 80 * 1024),   # all eight
     "_ZN3mpm5k_p2gILi1ELi1ELi2ELb0EEE": (256, (900, 1450), 16 * 1024),  # the default P2G (one wave per block)
 }
 
