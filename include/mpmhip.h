@@ -300,8 +300,7 @@ int64_t mpmhip_capacity(mpmhip_ctx *ctx);
  * tracks min(cfl, strength, max_units) under the reference's halving / doubling rule.  The per-block reduction runs on
  * the device, the block state machine on the host.  After mpmhip_async_update_dt_limits the `limit` attribute of
  * mpmhip_write_bgeo carries (continuous, strength, cfl) of each particle's block instead of (1, 1, 1).
- * The stepping itself (AsyncMPM<dim>::advance / step: block subsets advancing with their own dt, backup pools as frozen
- * neighbours) is host orchestration around substeps of gathered working sets, like the reference's: taichi_mpm_amd/async_mpm.py. */
+ * The stepping itself (AsyncMPM<dim>::advance / step) is the second half, mpmhip_async_begin / _step below. */
 typedef struct {
   float unit_delta_t;     /* config "unit_delta_t", default 1e-6 (src/async/async_mpm.cpp:24) */
   int64_t max_units;      /* "max_units", default 8192 */
@@ -317,7 +316,41 @@ int mpmhip_async_set_time_int(mpmhip_ctx *ctx, int64_t current_t_int);
  * capacity < that number nothing is written: size query) */
 int64_t mpmhip_async_table(mpmhip_ctx *ctx, int32_t nb[3], int64_t capacity, int64_t *strength, int64_t *cfl,
                            int64_t *continuous, int64_t *count);
-/* working-set plumbing of the asynchronous stepper (taichi_mpm_amd/async_mpm.py): drop all particles but keep groups /
+/* ---- AsyncMPM, second half — replaces AsyncMPM<dim> itself (TC_IMPLEMENTATION(Simulation3D, AsyncMPM3D, "async_mpm"),
+ * src/async/async_mpm.cpp:423-427): initialize (:13-55), add_particles (:57-75), update_dt_limits (:90-253), advance
+ * (:255-373), step (:380-421), and the particle list of visualize (src/async/async_visualize.cpp:86-96).
+ * The particle pools and backup pools of every scheduler block live in a device-resident store of containers; an advance
+ * gathers its working set (first copy of an id wins: smaller-step neighbours' pools, then the pools of the level's blocks,
+ * then larger-step neighbours' backups, each in the reference's block order) into the ctx's records with index kernels,
+ * runs ONE ordinary substep with dt = unit_delta_t * limit, and files the results back.  Block tables and the level walk
+ * are host code as in the reference; no particle data crosses the host boundary during stepping.  The ctx must keep apic_b
+ * (discard_apic_b = 0) and hold neither rigid bodies nor a partition.
+ *   begin            after mpmhip_create; takes the AsyncMPM config keys
+ *   pool_particles   after every mpmhip_add_particles: the new particles move from the ctx's records to their blocks' pools
+ *   step(dt)         AsyncMPM::step; dt < 0 (the synchronous single substep of the base class) is refused
+ *   load_pools       every container of every particle pool becomes the ctx's records (with its pool block's limits for
+ *                    the frame's `limit` attribute), so that mpmhip_write_bgeo / download / calculate_energy / snapshots
+ *                    see the whole state; the next step() ignores the records (the pools are the state)
+ *   state            out = {current_t_int, update_counter, min_delta_t_int, max_delta_t_int, live containers, store size
+ *                    incl. freed containers, compactions so far, step_counter}
+ *   block_times      particle_t / backup_t / local_min_dt_limit of every block of the dense table (size query as above)
+ *   download_pools   rows of 27 floats {x3, v3, F9, apic_b9, aux, gid bits, id bits} + the pool block of every container
+ *                    (an id can occur in more than one pool, as in the reference); rows == NULL: the count */
+int mpmhip_async_begin(mpmhip_ctx *ctx, const mpmhip_async_config *cfg);
+int mpmhip_async_pool_particles(mpmhip_ctx *ctx);
+int mpmhip_async_step(mpmhip_ctx *ctx, float dt);
+int mpmhip_async_load_pools(mpmhip_ctx *ctx);
+int mpmhip_async_state(mpmhip_ctx *ctx, int64_t out[8]);
+double mpmhip_async_current_time(const mpmhip_ctx *ctx);
+int64_t mpmhip_async_block_times(mpmhip_ctx *ctx, int64_t capacity, int64_t *particle_t, int64_t *backup_t, int64_t *local_min);
+int64_t mpmhip_async_download_pools(mpmhip_ctx *ctx, int64_t capacity, float *rows, int32_t *block);
+/* host wall time spent so far, ms: {update_dt_limits, of which the neighbour lists, advance, of which the substep (meaningful
+ * with sync != 0: the stream is then synchronised behind every substep), store compaction, number of advances} */
+int mpmhip_async_profile(mpmhip_ctx *ctx, int32_t sync, double out[6]);
+/* bytes of particle data copied between host and device by this ctx so far (add_particles, download, upload, snapshots,
+ * download_pools): a stepping call must leave it unchanged */
+int64_t mpmhip_host_particle_bytes(const mpmhip_ctx *ctx);
+/* plumbing of a host-driven stepper (the round-2 asynchronous stepper used these): drop all particles but keep groups /
  * level set / config; change base_delta_t (the P2G matrices are rebuilt) and the clock — AsyncMPM<dim>::advance / step set
  * both before every MPM<dim>::substep (src/async/async_mpm.cpp:405-408) */
 int mpmhip_clear_particles(mpmhip_ctx *ctx);

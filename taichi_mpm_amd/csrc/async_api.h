@@ -1,0 +1,487 @@
+// taichi_mpm_amd/csrc/async_api.h — host side of the device-resident asynchronous stepper (included by mpmhip.hip inside
+// extern "C").  Part of libmpmhip.  Device side: k_async.h.
+//
+// AsyncMPM<dim> (src/async/async_mpm.{h,cpp}): per scheduler block a continuous_dt_limit (a power of two of unit_delta_t),
+// a particle pool at the block's own time and a backup pool at an earlier time; step() walks the power-of-two levels and
+// advance(limit) runs ONE ordinary substep, dt = unit_delta_t * limit, on the blocks of that level plus frozen copies of
+// their neighbours.  Here the block tables (a few integers per block) and the level walk are host code, as in the reference;
+// every container stays in HBM (k_async.h: the store), and an advance costs four small kernels around the substep and one
+// two 16-byte read-backs (how many particles the working set has; how many containers were appended / freed).
+
+static inline uint32_t as_spread3(uint32_t v) {  // bits of v three apart
+  uint64_t x = v & 0x3ffu;
+  x = (x | (x << 16)) & 0x030000ffull; x = (x | (x << 8)) & 0x0300f00full;
+  x = (x | (x << 4)) & 0x030c30c3ull;  x = (x | (x << 2)) & 0x09249249ull;
+  return (uint32_t)x;
+}
+
+static int async_store_reserve(mpmhip_ctx *c, uint32_t need) {  // room for `need` containers in total
+  auto &S = c->async.store;
+  if (need <= S.cap) return MPMHIP_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const uint32_t cap = std::max<uint32_t>(need + need / 2, 4096), keep = std::min(S.size_ub, S.cap);
+  hipError_t e = hipSuccess;
+  auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  A(regrow(&S.g, (size_t)keep * 4, (size_t)cap * 4, false)); A(regrow(&S.w, (size_t)keep * 4, (size_t)cap * 4, false));
+  A(regrow(&S.tag, (size_t)keep, (size_t)cap, false)); A(regrow(&S.id, (size_t)keep, (size_t)cap, false));
+  // (kernels walk [0, upper bound of the size): every tag behind the containers in use says FREE)
+  if (e == hipSuccess) A(hipMemset(S.tag + keep, 0xFF, sizeof(uint32_t) * (size_t)(cap - keep)));
+  (void)hipFree(S.g2); (void)hipFree(S.w2); (void)hipFree(S.tag2); (void)hipFree(S.id2);
+  S.g2 = S.w2 = nullptr; S.tag2 = nullptr; S.id2 = nullptr;  // (the compaction targets are re-allocated when a compaction runs)
+  if (e != hipSuccess) return fail(c, MPMHIP_ENOMEM, "async store: growing to %u containers failed: %s", cap, hipGetErrorString(e));
+  S.cap = cap;
+  return MPMHIP_OK;
+}
+static int async_best_reserve(mpmhip_ctx *c) {  // one dedup word per creation id
+  auto &S = c->async.store;
+  if ((int64_t)c->next_pid <= S.best_cap) return MPMHIP_OK;
+  const size_t cap = (size_t)c->next_pid + (size_t)c->next_pid / 2 + 1024;
+  (void)hipFree(S.best); S.best = nullptr;
+  HIPCHK(c, dmalloc(&S.best, cap));
+  HIPCHK(c, hipMemsetAsync(S.best, 0xFF, sizeof(unsigned long long) * cap, c->stream));
+  S.best_cap = (int64_t)cap;
+  return MPMHIP_OK;
+}
+// the ONE read-back of an advance: the transient counters (reset behind the copy) and the append cursor.  Folds what earlier
+// launches appended / freed into the host's view of the store.
+static int async_counters(mpmhip_ctx *c, AsyncCounters &h, bool reset_after) {
+  auto &S = c->async.store;
+  AsyncCounters *pin = reinterpret_cast<AsyncCounters *>(c->h_pinned + 64);  // (the ctx's pinned page; the substep counters sit at its start)
+  HIPCHK(c, hipMemcpyAsync(pin, S.d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  if (reset_after) HIPCHK(c, hipMemsetAsync(S.d_cnt, 0, 16, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  h = *pin;
+  if (reset_after) {
+    S.live += h.n_append; S.live -= std::min(S.live, h.n_freed);
+    S.size = S.size_ub = h.size;
+    c->async.pending_counters = false;
+  }
+  return MPMHIP_OK;
+}
+struct AsTimer {  // wall time of a host-side section, accumulated into c->async.prof_ms[k] (synchronising sections included)
+  double &acc; std::chrono::steady_clock::time_point t0;
+  explicit AsTimer(double &a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+  ~AsTimer() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+static int as_grid(uint32_t n) { return (int)std::min<uint32_t>(std::max<uint32_t>((n + 255) / 256, 1), 4096); }
+
+// (called right behind a read-back: S.size and S.live are exact)
+static int async_compact_if_needed(mpmhip_ctx *c, uint32_t incoming) {
+  auto &S = c->async.store;
+  const uint32_t dead = S.size - std::min(S.size, S.live);
+  // squeeze when the freed containers outnumber the live ones (the passes over the tags then cost twice what they must), or
+  // when that avoids growing the store
+  if (!(dead > S.live + 65536 || (S.size + incoming > S.cap && dead > S.size / 4))) return MPMHIP_OK;
+  AsTimer whole(c->async.prof_ms[4]);
+  if (!S.g2) {
+    hipError_t e = hipSuccess;
+    auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    A(dmalloc(&S.g2, (size_t)S.cap * 4)); A(dmalloc(&S.w2, (size_t)S.cap * 4)); A(dmalloc(&S.tag2, (size_t)S.cap)); A(dmalloc(&S.id2, (size_t)S.cap));
+    if (e != hipSuccess) return fail(c, MPMHIP_ENOMEM, "async store: compaction buffers: %s", hipGetErrorString(e));
+  }
+  HIPCHK(c, hipMemsetAsync(S.tag2, 0xFF, sizeof(uint32_t) * (size_t)S.cap, c->stream));
+  const uint32_t nchunks = (S.size + 1023) / 1024;
+  if (nchunks + 1 > S.scan_cap) {
+    (void)hipFree(S.d_scan); S.d_scan = nullptr;
+    HIPCHK(c, dmalloc(&S.d_scan, (size_t)nchunks + 1024));
+    HIPCHK(c, hipMemsetAsync(S.d_scan, 0, sizeof(unsigned long long) * ((size_t)nchunks + 1024), c->stream));
+    S.scan_cap = nchunks + 1024;
+  }
+  hipLaunchKernelGGL(k_async_compact, dim3(std::min<uint32_t>(nchunks, c->scan_grid)), dim3(256), 0, c->stream, S.size,
+                     (const uint32_t *)S.tag, (const int32_t *)S.id, (const float4 *)S.g, (const float4 *)S.w, S.tag2, S.id2, S.g2, S.w2,
+                     S.d_scan, ++S.scan_epoch, S.d_cnt);
+  if (int rc = launch_check(c, "async_compact")) return rc;
+  std::swap(S.g, S.g2); std::swap(S.w, S.w2); std::swap(S.tag, S.tag2); std::swap(S.id, S.id2);
+  AsyncCounters h;
+  if (int rc = async_counters(c, h, true)) return rc;  // (size = live = what the scan counted)
+  S.live = h.size;
+  S.compactions++;
+  return MPMHIP_OK;
+}
+
+// the ctx's records hold a view of the pools (load_pools): they are copies, dropped before anything else uses the records
+static int async_drop_view(mpmhip_ctx *c) {
+  auto &A = c->async;
+  if (!A.resident || !A.records_are_view) return MPMHIP_OK;
+  A.records_are_view = false;
+  c->n_slots = 0; c->P.n_slots = 0;
+  const uint32_t zero = 0;
+  HIPCHK(c, hipMemcpy(&c->cnt->n_dead, &zero, sizeof zero, hipMemcpyHostToDevice));
+  c->affine_valid = false; c->b_stale = false;
+  c->keys_valid = true;
+  return invalidate_keys(c);
+}
+
+// AsyncMPM<dim>::initialize (src/async/async_mpm.cpp:13-55) on top of mpmhip_async_enable: the pools become device-resident
+int mpmhip_async_begin(mpmhip_ctx *c, const mpmhip_async_config *cfg) {
+  if (!c || !cfg) return MPMHIP_EINVAL;
+  if (rigid_active(c) || c->rigid.enabled) return fail(c, MPMHIP_EINVAL, "asynchronous stepping cannot be combined with rigid bodies");
+  if (c->T.enabled) return fail(c, MPMHIP_EINVAL, "asynchronous stepping cannot be combined with the multi-GPU tiling");
+  if (!c->P.store_b) return fail(c, MPMHIP_EINVAL, "asynchronous stepping needs a ctx that keeps apic_b (discard_apic_b = 0): the "
+                                                   "P2G matrix depends on each advance's dt and is rebuilt from it");
+  if (int rc = mpmhip_async_enable(c, cfg)) return rc;
+  auto &A = c->async;
+  auto &S = A.store;
+  const size_t nblk = A.continuous.size();
+  A.particle_t.assign(nblk, 0); A.backup_t.assign(nblk, 0); A.local_min.assign(nblk, 1);
+  A.has_copied.assign(nblk, 0); A.tbl.assign(nblk, 0);
+  A.larger.assign(64, {}); A.smaller.assign(64, {});
+  A.update_counter = 0; A.step_counter = 0; A.request_t = 0.0f; A.current_t = 0.0f;
+  // the reference's block number: the page bits of SparseMask::Linear_Offset — per level z, then x, then y
+  // (external/SPGrid/Core/SPGrid_Mask.h:29-35); pools are walked in this order
+  std::vector<std::pair<uint64_t, uint32_t>> order(nblk);
+  for (int bx = 0; bx < A.nb[0]; bx++)
+    for (int by = 0; by < A.nb[1]; by++)
+      for (int bz = 0; bz < A.nb[2]; bz++) {
+        const uint32_t b = ((uint32_t)bx * A.nb[1] + by) * A.nb[2] + bz;
+        order[b] = {((uint64_t)as_spread3(bz) << 2) | ((uint64_t)as_spread3(bx) << 1) | as_spread3(by), b};
+      }
+  std::sort(order.begin(), order.end());
+  A.rank_of.assign(nblk, 0);
+  for (size_t r = 0; r < nblk; r++) A.rank_of[order[r].second] = (uint32_t)r;
+  // cached_neighbours (src/async/async_mpm.h:248-301): the blocks around a block, 26 at most
+  A.neigh.assign(nblk * 26, -1);
+  for (int bx = 0; bx < A.nb[0]; bx++)
+    for (int by = 0; by < A.nb[1]; by++)
+      for (int bz = 0; bz < A.nb[2]; bz++) {
+        const size_t b = ((size_t)bx * A.nb[1] + by) * A.nb[2] + bz;
+        int m = 0;
+        for (int i = -1; i < 2; i++)
+          for (int j = -1; j < 2; j++)
+            for (int k = -1; k < 2; k++) {
+              const int x = bx + i, y = by + j, z = bz + k;
+              if ((i || j || k) && x >= 0 && y >= 0 && z >= 0 && x < A.nb[0] && y < A.nb[1] && z < A.nb[2])
+                A.neigh[b * 26 + m++] = (int32_t)(((size_t)x * A.nb[1] + y) * A.nb[2] + z);
+            }
+      }
+  HIPCHK(c, hipSetDevice(c->device));
+  hipFree(S.d_tbl); hipFree(S.d_rank); hipFree(S.d_cnt);
+  S.d_tbl = nullptr; S.d_rank = nullptr; S.d_cnt = nullptr;
+  HIPCHK(c, dmalloc(&S.d_tbl, nblk));
+  HIPCHK(c, dmalloc(&S.d_rank, nblk));
+  HIPCHK(c, dmalloc(&S.d_cnt, 1));
+  HIPCHK(c, hipMemcpy(S.d_rank, A.rank_of.data(), sizeof(uint32_t) * nblk, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemset(S.d_cnt, 0, sizeof(AsyncCounters)));
+  S.size = S.size_ub = S.live = 0;
+  A.limits_version = 0; A.lists_version = ~0ull;
+  A.resident = true;
+  return MPMHIP_OK;
+}
+
+static int async_settle(mpmhip_ctx *c);
+// AsyncMPM<dim>::add_particles (src/async/async_mpm.cpp:57-75): the particles currently in the ctx's records (just added by
+// mpmhip_add_particles) move to the particle pools of their blocks; the ctx's record arrays are empty afterwards.
+int mpmhip_async_pool_particles(mpmhip_ctx *c) {
+  if (!c) return MPMHIP_EINVAL;
+  auto &A = c->async;
+  auto &S = A.store;
+  if (!A.resident) return fail(c, MPMHIP_EINVAL, "mpmhip_async_begin first");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (int rc = async_drop_view(c)) return rc;
+  if (c->n_slots == 0) return MPMHIP_OK;
+  if (int rc = async_settle(c)) return rc;
+  if (int rc = ensure_b_current(c)) return rc;
+  if (int rc = async_store_reserve(c, S.size + (uint32_t)c->n_slots)) return rc;
+  hipLaunchKernelGGL(k_async_file, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, (const float4 *)c->rg,
+                     (const float4 *)c->rp, (const float4 *)c->rb, (const uint8_t *)S.d_tbl, 1, A.nb[0], A.nb[1], A.nb[2], S.cap,
+                     S.g, S.w, S.tag, S.id, S.d_cnt);
+  if (int rc = launch_check(c, "async_file")) return rc;
+  AsyncCounters h;
+  if (int rc = async_counters(c, h, true)) return rc;
+  c->n_slots = 0; c->P.n_slots = 0;  // (creation ids keep counting: next_pid stays)
+  const uint32_t zero = 0;
+  HIPCHK(c, hipMemcpy(&c->cnt->n_dead, &zero, sizeof zero, hipMemcpyHostToDevice));
+  c->affine_valid = false; c->b_stale = false;
+  c->keys_valid = true;
+  return invalidate_keys(c);
+}
+
+// AsyncMPM<dim>::update_dt_limits (src/async/async_mpm.cpp:90-253) over the resident pools
+static int async_update_dt_limits(mpmhip_ctx *c) {
+  auto &A = c->async;
+  auto &S = A.store;
+  const size_t nblk = A.continuous.size();
+  AsTimer whole(A.prof_ms[0]);
+  hipLaunchKernelGGL(k_async_table_reset, dim3(as_grid((uint32_t)nblk)), dim3(256), 0, c->stream, (uint32_t)nblk, A.d_tab);
+  hipLaunchKernelGGL(k_async_store_reduce, dim3(as_grid(S.size_ub)), dim3(256), 0, c->stream, c->P, S.size_ub, (const uint32_t *)S.tag,
+                     (const float4 *)S.g, (const float4 *)S.w, (const GroupParams *)c->d_groups, A.d_tab);
+  if (int rc = launch_check(c, "async_store_reduce")) return rc;
+  A.scratch = A.continuous;
+  if (int rc = async_limits_from_table(c)) return rc;  // the block state machine shared with mpmhip_async_update_dt_limits
+  if (A.scratch != A.continuous) A.limits_version++;
+  AsTimer lists(A.prof_ms[1]);
+  // larger / smaller neighbours per log2(limit) (:183-247), each in the reference's block order — they depend on the
+  // continuous limits alone: rebuilt only when a limit has changed
+  if (A.lists_version != A.limits_version) {
+    for (auto &v : A.larger) v.clear();
+    for (auto &v : A.smaller) v.clear();
+    auto lg = [](int64_t v) { int r = 0; while (v > 1) { v >>= 1; r++; } return r; };
+    for (size_t b = 0; b < nblk; b++) {
+      const int64_t cb = A.continuous[b];
+      for (int k = 0; k < 26; k++) {
+        const int32_t q = A.neigh[b * 26 + k];
+        if (q < 0) break;
+        if (cb < A.continuous[q]) {
+          A.larger[lg(cb)].push_back((uint32_t)q);
+          A.smaller[lg(A.continuous[q])].push_back((uint32_t)b);
+        }
+      }
+    }
+    auto tidy = [&](std::vector<uint32_t> &v) {
+      std::sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return A.rank_of[x] < A.rank_of[y]; });
+      v.erase(std::unique(v.begin(), v.end()), v.end());
+    };
+    for (auto &v : A.larger) tidy(v);
+    for (auto &v : A.smaller) tidy(v);
+    A.lists_version = A.limits_version;
+  }
+  // local_min_dt_limit (:165-182).  advance() reads it only for blocks it has copied with a LARGER limit than the level's,
+  // i.e. for members of the larger-neighbour lists: computed for those (the value of the others is never looked at)
+  for (const auto &v : A.larger)
+    for (uint32_t b : v) {
+      if (A.continuous[b] == A.min_delta_t_int) continue;
+      int64_t m = 1ll << 31;
+      for (int k = 0; k < 26; k++) {
+        const int32_t q = A.neigh[(size_t)b * 26 + k];
+        if (q < 0) break;
+        m = std::min(m, A.particle_t[q] + A.continuous[q]);
+      }
+      A.local_min[b] = m;
+    }
+  return MPMHIP_OK;
+}
+
+// AsyncMPM<dim>::advance (src/async/async_mpm.cpp:255-373)
+static int async_advance(mpmhip_ctx *c, int64_t limit) {
+  auto &A = c->async;
+  auto &S = A.store;
+  const size_t nblk = A.continuous.size();
+  const int64_t t = A.current_t_int;
+  AsTimer whole(A.prof_ms[2]);
+  A.prof_ms[5] += 1.0;  // (advances)
+  int lg = 0;
+  for (int64_t v = limit; v > 1; v >>= 1) lg++;
+  std::fill(A.has_copied.begin(), A.has_copied.end(), 0);
+  std::fill(A.tbl.begin(), A.tbl.end(), 0);
+  for (uint32_t b : A.smaller[lg]) {
+    if (A.particle_t[b] != t) return fail(c, MPMHIP_EINVAL, "async: particle_pool broken 2 (block %u at %lld, now %lld)", b, (long long)A.particle_t[b], (long long)t);
+    A.has_copied[b] = 1; A.tbl[b] |= AT_POOL0;
+  }
+  for (size_t b = 0; b < nblk; b++)
+    if (A.continuous[b] == limit) {
+      if (A.particle_t[b] != t) return fail(c, MPMHIP_EINVAL, "async: particle_pool broken 1 (block %zu)", b);
+      A.tbl[b] |= AT_POOL1 | AT_SWAP;  // (backup_current_dt_limit: same condition, :317-325)
+      A.backup_t[b] = t;
+    }
+  for (uint32_t b : A.larger[lg]) {
+    if (A.backup_t[b] != t) return fail(c, MPMHIP_EINVAL, "async: backup_pool broken (block %u at %lld, now %lld)", b, (long long)A.backup_t[b], (long long)t);
+    A.has_copied[b] = 1; A.tbl[b] |= AT_BACKUP;
+  }
+  if (int rc = async_best_reserve(c)) return rc;
+  HIPCHK(c, hipMemcpyAsync(S.d_tbl, A.tbl.data(), nblk, hipMemcpyHostToDevice, c->stream));
+  // the working set can hold every live container: the ctx's records must have room (the caller sized the ctx for all
+  // particles; duplicates of an id are dropped by the gather)
+  hipLaunchKernelGGL(k_async_mark, dim3(as_grid(S.size_ub)), dim3(256), 0, c->stream, S.size_ub, (const uint32_t *)S.tag,
+                     (const int32_t *)S.id, (const uint8_t *)S.d_tbl, (const uint32_t *)S.d_rank, S.best);
+  hipLaunchKernelGGL(k_async_gather, dim3(as_grid(S.size_ub)), dim3(256), 0, c->stream, S.size_ub, S.tag, (const int32_t *)S.id,
+                     (const uint8_t *)S.d_tbl, (const uint32_t *)S.d_rank, S.best, (const float4 *)S.g, (const float4 *)S.w,
+                     (const GroupParams *)c->d_groups, (float4 *)c->rg, (float4 *)c->rp, (float4 *)c->rb, S.d_cnt);
+  if (int rc = launch_check(c, "async_gather")) return rc;
+  AsyncCounters h;
+  if (int rc = async_counters(c, h, true)) return rc;  // the one read-back of an advance (also settles the previous one's appends)
+  const uint32_t n_work = h.n_work;
+  if ((int64_t)n_work > c->cap) return fail(c, MPMHIP_ECAPACITY, "async: a working set of %u particles exceeds the ctx capacity %lld", n_work, (long long)c->cap);
+  A.update_counter += n_work;
+  // ONE ordinary substep of the working set with this level's dt (:327-329; step() sets base_delta_t / current_t, :405-408)
+  c->n_slots = n_work; c->P.n_slots = n_work;
+  const uint32_t zero = 0;
+  HIPCHK(c, hipMemcpyAsync(&c->cnt->n_dead, &zero, sizeof zero, hipMemcpyHostToDevice, c->stream));
+  c->P.dt = A.cfg.unit_delta_t * (float)limit;
+  c->t = A.cfg.unit_delta_t * (float)t;
+  c->affine_valid = false; c->b_stale = false;
+  c->keys_valid = true;
+  if (int rc = invalidate_keys(c)) return rc;
+  if (n_work) {
+    AsTimer sub(A.prof_ms[3]);
+    if (int rc = mpmhip_substep(c)) return rc;
+    if (A.profile_sync) HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  // update backup_t and particle_t (:331-343)
+  std::fill(A.tbl.begin(), A.tbl.end(), 0);
+  bool any_clear = false;
+  for (size_t b = 0; b < nblk; b++) {
+    if (A.continuous[b] == limit) {
+      A.particle_t[b] = t + limit;
+      A.tbl[b] = AT_DEST_POOL;
+    } else if (A.has_copied[b] && A.continuous[b] > limit && A.local_min[b] == t + limit) {
+      A.backup_t[b] = t + limit;
+      A.tbl[b] = AT_CLEAR | AT_DEST_BACKUP;
+      any_clear = true;
+    }
+  }
+  HIPCHK(c, hipMemcpyAsync(S.d_tbl, A.tbl.data(), nblk, hipMemcpyHostToDevice, c->stream));
+  if (any_clear)
+    hipLaunchKernelGGL(k_async_clear, dim3(as_grid(S.size)), dim3(256), 0, c->stream, S.size, S.tag, (const uint8_t *)S.d_tbl, S.d_cnt);
+  if (n_work) {
+    if (int rc = async_compact_if_needed(c, n_work)) return rc;
+    if (int rc = async_store_reserve(c, S.size + n_work)) return rc;
+    hipLaunchKernelGGL(k_async_file, dim3(particle_grid(n_work)), dim3(256), 0, c->stream, c->P, (const float4 *)c->rg,
+                       (const float4 *)c->rp, (const float4 *)c->rb, (const uint8_t *)S.d_tbl, 0, A.nb[0], A.nb[1], A.nb[2], S.cap,
+                       S.g, S.w, S.tag, S.id, S.d_cnt);
+    S.size_ub = S.size + n_work;  // (the exact size comes with the next read-back)
+  }
+  if (int rc = launch_check(c, "async_file")) return rc;
+  A.pending_counters = true;
+  return MPMHIP_OK;
+}
+
+// counters a previous advance left on the device (appended / freed containers): folded into the host's view of the store
+static int async_settle(mpmhip_ctx *c) {
+  if (!c->async.pending_counters) return MPMHIP_OK;
+  AsyncCounters h;
+  return async_counters(c, h, true);
+}
+
+// AsyncMPM<dim>::step (src/async/async_mpm.cpp:380-421)
+int mpmhip_async_step(mpmhip_ctx *c, float dt) {
+  if (!c) return MPMHIP_EINVAL;
+  auto &A = c->async;
+  if (!A.resident) return fail(c, MPMHIP_EINVAL, "mpmhip_async_begin first");
+  if (dt < 0) return fail(c, MPMHIP_EINVAL, "AsyncMPM::step(dt < 0) is the synchronous substep of the base class");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (int rc = async_drop_view(c)) return rc;
+  if (c->n_slots) {  // (particles added since the last step and not yet pooled)
+    if (int rc = mpmhip_async_pool_particles(c)) return rc;
+  }
+  A.request_t += dt;
+  do {
+    if (int rc = async_update_dt_limits(c)) return rc;
+    for (int64_t d = A.max_delta_t_int; d >= A.min_delta_t_int; d >>= 1)
+      if (A.current_t_int % d == 0) {
+        if (int rc = async_advance(c, d)) return rc;
+      }
+    A.current_t_int += A.min_delta_t_int - A.current_t_int % A.min_delta_t_int;
+    A.current_t = A.cfg.unit_delta_t * (float)A.current_t_int;
+  } while (A.current_t < A.request_t);
+  if (int rc = async_settle(c)) return rc;
+  c->n_slots = 0; c->P.n_slots = 0;  // the records held the last working set: the state is in the pools
+  c->t = A.current_t;
+  A.step_counter++;
+  return MPMHIP_OK;
+}
+
+// {current_t_int, update_counter, pool containers, backup containers + freed (store size - pool), compactions, store size}
+int mpmhip_async_state(mpmhip_ctx *c, int64_t out[8]) {
+  if (!c || !out) return MPMHIP_EINVAL;
+  auto &A = c->async;
+  if (!A.resident) return fail(c, MPMHIP_EINVAL, "mpmhip_async_begin first");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (int rc = async_settle(c)) return rc;
+  out[0] = A.current_t_int; out[1] = A.update_counter; out[2] = A.min_delta_t_int; out[3] = A.max_delta_t_int;
+  out[4] = A.store.live; out[5] = A.store.size; out[6] = A.store.compactions; out[7] = A.step_counter;
+  return MPMHIP_OK;
+}
+// host wall time so far, ms: {update_dt_limits, of which neighbour lists, advance, of which the substep (only meaningful with
+// sync != 0: the stream is then synchronised behind every substep), compaction, number of advances}
+int mpmhip_async_profile(mpmhip_ctx *c, int32_t sync, double out[6]) {
+  if (!c || !out) return MPMHIP_EINVAL;
+  for (int k = 0; k < 6; k++) out[k] = c->async.prof_ms[k];
+  c->async.profile_sync = sync != 0;
+  return MPMHIP_OK;
+}
+double mpmhip_async_current_time(const mpmhip_ctx *c) { return c ? (double)c->async.current_t : 0.0; }
+int64_t mpmhip_host_particle_bytes(const mpmhip_ctx *c) { return c ? c->host_particle_bytes : MPMHIP_EINVAL; }
+
+// per block of the dense table (mpmhip_async_table gives the limits): particle_t, backup_t, local_min_dt_limit
+int64_t mpmhip_async_block_times(mpmhip_ctx *c, int64_t capacity, int64_t *particle_t, int64_t *backup_t, int64_t *local_min) {
+  if (!c || !c->async.resident) return MPMHIP_EINVAL;
+  auto &A = c->async;
+  const int64_t n = (int64_t)A.particle_t.size();
+  if (capacity < n) return n;
+  for (int64_t b = 0; b < n; b++) {
+    if (particle_t) particle_t[b] = A.particle_t[b];
+    if (backup_t) backup_t[b] = A.backup_t[b];
+    if (local_min) local_min[b] = A.local_min[b];
+  }
+  return n;
+}
+
+// Every container of every particle pool (each at its block's particle_t; an id can occur more than once, as in the
+// reference) as rows of 27 floats {x3, v3, F9, apic_b9, aux, gid bits, id bits} + the container's block.  rows == NULL:
+// only the count.  (Tests and host-side inspection: the stepping itself never calls this.)
+int64_t mpmhip_async_download_pools(mpmhip_ctx *c, int64_t capacity, float *rows, int32_t *block) {
+  if (!c) return MPMHIP_EINVAL;
+  auto &A = c->async;
+  auto &S = A.store;
+  if (!A.resident) return fail(c, MPMHIP_EINVAL, "mpmhip_async_begin first");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (int rc = async_settle(c)) return rc;
+  float *d_rows = nullptr;
+  uint32_t *d_blk = nullptr;
+  const size_t m = std::max<size_t>(S.size, 1);
+  HIPCHK(c, dmalloc(&d_rows, m * 27));
+  hipError_t e = dmalloc(&d_blk, m);
+  if (e != hipSuccess) { (void)hipFree(d_rows); return fail(c, MPMHIP_ENOMEM, "async download: %s", hipGetErrorString(e)); }
+  hipLaunchKernelGGL(k_async_export, dim3(as_grid(S.size)), dim3(256), 0, c->stream, S.size, (const uint32_t *)S.tag, (const float4 *)S.g,
+                     (const float4 *)S.w, d_rows, d_blk, S.d_cnt);
+  AsyncCounters h;
+  int rc = launch_check(c, "async_export");
+  if (!rc) rc = async_counters(c, h, true);
+  int64_t n = rc ? rc : (int64_t)h.n_work;
+  if (!rc && rows && block) {
+    if (capacity < n) { rc = fail(c, MPMHIP_ECAPACITY, "async download: %lld containers, room for %lld", (long long)n, (long long)capacity); n = rc; }
+    else if (n) {
+      e = hipMemcpy(rows, d_rows, sizeof(float) * 27 * (size_t)n, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(block, d_blk, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) n = fail(c, MPMHIP_EHIP, "async download: %s", hipGetErrorString(e));
+      c->host_particle_bytes += (int64_t)n * 27 * 4;
+    }
+  }
+  (void)hipFree(d_rows); (void)hipFree(d_blk);
+  return n;
+}
+
+// AsyncMPM<dim>::visualize's particle list (src/async/async_visualize.cpp:17-26,86-96): ALL containers of all particle pools
+// become the ctx's records (so that frame output, downloads, energy and snapshots of the base class see the whole state, not
+// the last working set), each with its pool block's (continuous, strength, cfl) limits for the `limit` attribute.
+int mpmhip_async_load_pools(mpmhip_ctx *c) {
+  if (!c) return MPMHIP_EINVAL;
+  auto &A = c->async;
+  auto &S = A.store;
+  if (!A.resident) return fail(c, MPMHIP_EINVAL, "mpmhip_async_begin first");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (int rc = async_settle(c)) return rc;
+  if (int rc = mpmhip_async_pool_particles(c)) return rc;  // (drops an earlier view; pools particles added since)
+  if ((int64_t)S.live > c->cap) {
+    if (int rc = mpmhip_reserve(c, (int64_t)S.live + 1024)) return rc;
+  }
+  const size_t nblk = A.continuous.size();
+  if (int rc = async_ensure_particle_arrays(c)) return rc;
+  std::fill(A.tbl.begin(), A.tbl.end(), (uint8_t)AT_POOL1);
+  HIPCHK(c, hipMemcpyAsync(S.d_tbl, A.tbl.data(), nblk, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_async_load, dim3(as_grid(S.size)), dim3(256), 0, c->stream, S.size, (const uint32_t *)S.tag, (const float4 *)S.g,
+                     (const float4 *)S.w, (const GroupParams *)c->d_groups, (float4 *)c->rg, (float4 *)c->rp, (float4 *)c->rb,
+                     A.d_blk_of, S.d_cnt);
+  if (int rc = launch_check(c, "async_load")) return rc;
+  AsyncCounters h;
+  if (int rc = async_counters(c, h, true)) return rc;
+  c->n_slots = h.n_work; c->P.n_slots = h.n_work;
+  A.records_are_view = true;
+  const uint32_t zero = 0;
+  HIPCHK(c, hipMemcpy(&c->cnt->n_dead, &zero, sizeof zero, hipMemcpyHostToDevice));
+  c->P.dt = c->cfg.dt;  // (the P2G matrices are rebuilt for the configured base step if anybody runs a synchronous substep)
+  c->affine_valid = false; c->b_stale = false;
+  c->keys_valid = true;
+  if (int rc = invalidate_keys(c)) return rc;
+  // the frame's `limit` attribute: the limits of the container's POOL block
+  if (c->n_slots) {
+    std::vector<int32_t> lim(3 * nblk);
+    for (size_t b = 0; b < nblk; b++) { lim[3 * b] = (int32_t)A.continuous[b]; lim[3 * b + 1] = (int32_t)A.strength[b]; lim[3 * b + 2] = (int32_t)A.cfl[b]; }
+    HIPCHK(c, hipMemcpy(A.d_blk_limits, lim.data(), sizeof(int32_t) * 3 * nblk, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_async_particle_limits, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P,
+                       (const uint32_t *)A.d_blk_of, (const int32_t *)A.d_blk_limits, A.d_particle_limits);
+    if (int rc = launch_check(c, "async_particle_limits")) return rc;
+    A.limits_valid = true;
+  }
+  return MPMHIP_OK;
+}

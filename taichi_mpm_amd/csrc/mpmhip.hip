@@ -50,6 +50,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -77,6 +78,7 @@
 #include "mpm_common.h"
 #include "k_sort.h"
 #include "k_particles.h"
+#include "k_async.h"
 #include "k_p2g.h"
 #include "k_grid.h"
 #include "k_tiling.h"
@@ -172,7 +174,38 @@ struct mpmhip_ctx {
     uint32_t *d_tab = nullptr, *d_blk_of = nullptr;
     int32_t *d_blk_limits = nullptr, *d_particle_limits = nullptr;
     int64_t blk_of_cap = 0;
+    // the resident stepper (async_api.h): block times, neighbour lists, and the device store of pool / backup containers
+    bool resident = false, pending_counters = false;
+    bool records_are_view = false;  // the ctx's records are copies of the pools (mpmhip_async_load_pools), not new particles
+    std::vector<int64_t> particle_t, backup_t, local_min;  // BlockInfo, src/async/async_mpm.h:93-110
+    std::vector<uint8_t> has_copied, tbl;
+    std::vector<int64_t> scratch;
+    uint64_t limits_version = 0, lists_version = ~0ull;  // the neighbour lists are rebuilt only when a continuous limit changed
+    std::vector<uint32_t> rank_of;                         // position of a block in the reference's block order
+    std::vector<int32_t> neigh;                            // cached_neighbours: 26 per block, -1 terminated
+    std::vector<std::vector<uint32_t>> larger, smaller;    // larger_neighbours / smaller_neighbours by log2(limit)
+    int64_t update_counter = 0, step_counter = 0;
+    float request_t = 0.0f, current_t = 0.0f;
+    double prof_ms[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t *h_tab = nullptr;
+    size_t h_tab_cap = 0;
+    bool profile_sync = false;
+    struct Store {
+      uint32_t cap = 0, size = 0, live = 0;   // containers allocated / in use incl. freed ones / not freed (as of the last read-back)
+      uint32_t size_ub = 0;                   // upper bound of the size now (launch bound: tags behind the size say FREE)
+      float4 *g = nullptr, *w = nullptr, *g2 = nullptr, *w2 = nullptr;
+      uint32_t *tag = nullptr, *tag2 = nullptr;
+      int32_t *id = nullptr, *id2 = nullptr;
+      unsigned long long *best = nullptr, *d_scan = nullptr;
+      int64_t best_cap = 0;
+      uint32_t scan_cap = 0, scan_epoch = 0;
+      uint8_t *d_tbl = nullptr;
+      uint32_t *d_rank = nullptr;
+      AsyncCounters *d_cnt = nullptr;
+      int64_t compactions = 0;
+    } store;
   } async;
+  int64_t host_particle_bytes = 0;  // particle data copied between host and device so far (uploads, downloads, snapshots)
   // CPIC rigid coupling (rigid_api.h): bodies 1.. (0 = background), their boundary particles, the colored distance field
   struct HostRigid {
     mpmhip_rigid_config cfg{};
@@ -500,6 +533,9 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   hipFree(c->fat_slot); hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->cell_cnt);
   hipFree(c->cell_start); hipFree(c->scan_slots); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
   hipFree(c->async.d_tab); hipFree(c->async.d_blk_of); hipFree(c->async.d_blk_limits); hipFree(c->async.d_particle_limits);
+  if (c->async.h_tab) hipHostFree(c->async.h_tab);
+  { auto &S = c->async.store; hipFree(S.g); hipFree(S.w); hipFree(S.g2); hipFree(S.w2); hipFree(S.tag); hipFree(S.tag2); hipFree(S.id);
+    hipFree(S.id2); hipFree(S.best); hipFree(S.d_scan); hipFree(S.d_tbl); hipFree(S.d_rank); hipFree(S.d_cnt); }
   hipFree(c->tiles8); hipFree(c->bits_prev); hipFree(c->wprefix_prev);
   hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_LS); hipFree(c->d_counts); hipFree(c->d_bounds); if (c->h_pinned) hipHostFree(c->h_pinned); hipFree(c->d_energy);
   { auto &R = c->rigid; hipFree(R.d_rb); hipFree(R.d_smp); hipFree(R.d_elems); hipFree(R.cdf.slot); hipFree(R.cdf.page_key); hipFree(R.cdf.mind);
@@ -652,6 +688,7 @@ static int ensure_b_current(mpmhip_ctx *c) {
   return MPMHIP_OK;
 }
 
+static int async_drop_view(mpmhip_ctx *c);
 int mpmhip_add_particles(mpmhip_ctx *c, int32_t group, int64_t n, const float *x, const float *v, const float *F,
                          const float *B, const float *aux) {
   if (!c || n < 0 || (n > 0 && !x)) return MPMHIP_EINVAL;
@@ -659,6 +696,7 @@ int mpmhip_add_particles(mpmhip_ctx *c, int32_t group, int64_t n, const float *x
   if (n == 0) return MPMHIP_OK;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int rc = async_drop_view(c)) return rc;  // (resident async stepper: records that only mirror the pools go first)
   if (c->n_slots + n > c->cap)
     return fail(c, MPMHIP_ECAPACITY, "particle capacity exceeded: %lld + %lld > %lld", (long long)c->n_slots, (long long)n, (long long)c->cap);
   if (int rc = ensure_b_current(c)) return rc;  // A of every particle is recomputed from apic_b below
@@ -687,6 +725,7 @@ int mpmhip_add_particles(mpmhip_ctx *c, int32_t group, int64_t n, const float *x
     g.pad = 0;
   }
   c->next_pid += (int32_t)n;
+  c->host_particle_bytes += (int64_t)n * (sizeof(RecG) + sizeof(RecP) + sizeof(float) * BW);
   HIPCHK(c, hipMemcpy(c->rg + c->n_slots, hg.data(), sizeof(RecG) * n, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->rp + c->n_slots, hp.data(), sizeof(RecP) * n, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->rb + (size_t)c->n_slots * BW, hb.data(), sizeof(float) * n * BW, hipMemcpyHostToDevice));
@@ -751,6 +790,7 @@ int64_t mpmhip_num_particles(mpmhip_ctx *c) {
 static int fetch_records(mpmhip_ctx *c, std::vector<RecG> &hg, std::vector<RecP> *hp, std::vector<float> *hb) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const size_t n = (size_t)c->n_slots;
+  c->host_particle_bytes += (int64_t)n * (sizeof(RecG) + (hp ? sizeof(RecP) : 0) + (hb ? sizeof(float) * BW : 0));
   hg.resize(n);
   if (n) HIPCHK(c, hipMemcpy(hg.data(), c->rg, sizeof(RecG) * n, hipMemcpyDeviceToHost));
   if (hp) { hp->resize(n); if (n) HIPCHK(c, hipMemcpy(hp->data(), c->rp, sizeof(RecP) * n, hipMemcpyDeviceToHost)); }
@@ -824,6 +864,7 @@ int mpmhip_upload(mpmhip_ctx *c, int32_t field, const void *src, int64_t n) {
     m++;
   }
   const size_t ns = hg.size();
+  c->host_particle_bytes += (int64_t)ns * (sizeof(RecG) + sizeof(RecP) + sizeof(float) * BW);
   HIPCHK(c, hipMemcpy(c->rg, hg.data(), sizeof(RecG) * ns, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->rp, hp.data(), sizeof(RecP) * ns, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->rb, hb.data(), sizeof(float) * ns * BW, hipMemcpyHostToDevice));
@@ -2079,6 +2120,8 @@ int mpmhip_mpm88_download_grid(mpmhip_mpm88 *m, float *grid) {
 int mpmhip_async_enable(mpmhip_ctx *c, const mpmhip_async_config *cfg) {
   if (!c || !cfg) return MPMHIP_EINVAL;
   if (!(cfg->unit_delta_t > 0) || cfg->max_units < 1) return fail(c, MPMHIP_EINVAL, "unit_delta_t > 0 and max_units >= 1 required");
+  if (rigid_active(c) || c->rigid.enabled) return fail(c, MPMHIP_EINVAL, "asynchronous stepping cannot be combined with rigid bodies");
+  if (c->T.enabled) return fail(c, MPMHIP_EINVAL, "asynchronous stepping cannot be combined with the multi-GPU tiling");
   HIPCHK(c, hipSetDevice(c->device));
   auto &A = c->async;
   A.cfg = *cfg;
@@ -2100,12 +2143,8 @@ static inline float async_inv_sqrt(float v) {  // src/async/async_mpm.cpp:77-80:
   return _mm_cvtss_f32(_mm_rsqrt_ss(_mm_set1_ps(v)));
 }
 
-int mpmhip_async_update_dt_limits(mpmhip_ctx *c) {  // AsyncMPM<dim>::update_dt_limits, src/async/async_mpm.cpp:90-164
-  if (!c) return MPMHIP_EINVAL;
+static int async_ensure_particle_arrays(mpmhip_ctx *c) {
   auto &A = c->async;
-  if (!A.enabled) return fail(c, MPMHIP_EINVAL, "mpmhip_async_enable first");
-  HIPCHK(c, hipSetDevice(c->device));
-  const size_t nblk = A.strength.size();
   if (A.blk_of_cap < c->cap) {
     hipFree(A.d_blk_of); hipFree(A.d_particle_limits);
     A.d_blk_of = nullptr; A.d_particle_limits = nullptr;
@@ -2113,18 +2152,33 @@ int mpmhip_async_update_dt_limits(mpmhip_ctx *c) {  // AsyncMPM<dim>::update_dt_
     HIPCHK(c, dmalloc(&A.d_particle_limits, 3 * (size_t)c->cap));
     A.blk_of_cap = c->cap;
   }
+  return MPMHIP_OK;
+}
+static int async_reset_table(mpmhip_ctx *c) {
   // (min allowed dt, max |v|^2, count) per block: min starts at the bits of 0.1f (":104 min_allowed_dt = 0.1"), max at 1e-16f
+  auto &A = c->async;
+  const size_t nblk = A.strength.size();
   std::vector<uint32_t> init(3 * nblk);
   const float f01 = 0.1f, fv = 1e-16f;
   uint32_t b01, bv;
   memcpy(&b01, &f01, 4); memcpy(&bv, &fv, 4);
   for (size_t b = 0; b < nblk; b++) { init[3 * b] = b01; init[3 * b + 1] = bv; init[3 * b + 2] = 0; }
   HIPCHK(c, hipMemcpyAsync(A.d_tab, init.data(), sizeof(uint32_t) * 3 * nblk, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_async_block_reduce, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, (const RecG *)c->rg,
-                     (const RecP *)c->rp, (const GroupParams *)c->d_groups, A.nb[0], A.nb[1], A.nb[2], A.d_tab, A.d_blk_of);
-  if (int rc = launch_check(c, "async_block_reduce")) return rc;
-  std::vector<uint32_t> tab(3 * nblk);
-  HIPCHK(c, hipMemcpyAsync(tab.data(), A.d_tab, sizeof(uint32_t) * 3 * nblk, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // (`init` lives on this stack frame)
+  return MPMHIP_OK;
+}
+// the block state machine of AsyncMPM<dim>::update_dt_limits (src/async/async_mpm.cpp:93-152) from the reduced table
+static int async_limits_from_table(mpmhip_ctx *c) {
+  auto &A = c->async;
+  const size_t nblk = A.strength.size();
+  if (A.h_tab_cap < 3 * nblk) {  // pinned staging (a copy into pageable memory is staged by the runtime: ~50 us more)
+    if (A.h_tab) (void)hipHostFree(A.h_tab);
+    A.h_tab = nullptr;
+    HIPCHK(c, hipHostMalloc((void **)&A.h_tab, sizeof(uint32_t) * 3 * nblk, hipHostMallocDefault));
+    A.h_tab_cap = 3 * nblk;
+  }
+  const uint32_t *tab = A.h_tab;
+  HIPCHK(c, hipMemcpyAsync(A.h_tab, A.d_tab, sizeof(uint32_t) * 3 * nblk, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const float inv_unit = 1.0f / A.cfg.unit_delta_t;
   const int64_t t = A.current_t_int;
@@ -2160,6 +2214,21 @@ int mpmhip_async_update_dt_limits(mpmhip_ctx *c) {  // AsyncMPM<dim>::update_dt_
     while (A.max_delta_t_int >= (limit << 1) && (t & ((limit << 1) - 1)) == 0) limit <<= 1;
   }
   boundary(false);
+  return MPMHIP_OK;
+}
+
+int mpmhip_async_update_dt_limits(mpmhip_ctx *c) {  // AsyncMPM<dim>::update_dt_limits, src/async/async_mpm.cpp:90-164
+  if (!c) return MPMHIP_EINVAL;
+  auto &A = c->async;
+  if (!A.enabled) return fail(c, MPMHIP_EINVAL, "mpmhip_async_enable first");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nblk = A.strength.size();
+  if (int rc = async_ensure_particle_arrays(c)) return rc;
+  if (int rc = async_reset_table(c)) return rc;
+  hipLaunchKernelGGL(k_async_block_reduce, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, (const RecG *)c->rg,
+                     (const RecP *)c->rp, (const GroupParams *)c->d_groups, A.nb[0], A.nb[1], A.nb[2], A.d_tab, A.d_blk_of);
+  if (int rc = launch_check(c, "async_block_reduce")) return rc;
+  if (int rc = async_limits_from_table(c)) return rc;
   // what the frame output shows per particle (src/async/async_visualize.cpp:17-26)
   std::vector<int32_t> lim(3 * nblk);
   for (size_t b = 0; b < nblk; b++) { lim[3 * b] = (int32_t)A.continuous[b]; lim[3 * b + 1] = (int32_t)A.strength[b]; lim[3 * b + 2] = (int32_t)A.cfl[b]; }
@@ -2216,6 +2285,8 @@ int mpmhip_async_set_time_int(mpmhip_ctx *c, int64_t t_int) {
   c->async.current_t_int = t_int;
   return MPMHIP_OK;
 }
+
+#include "async_api.h"
 
 int mpmhip_debug_allowed_dt(mpmhip_ctx *c, int32_t material, const float params[MPMHIP_NPARAM], int64_t n, const float *F,
                             const float *aux, const float *v, float dx, float *out) {

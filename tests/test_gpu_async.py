@@ -124,3 +124,96 @@ def test_async_stepping_matches_the_reference_async_stepper(tm):
     # had a dozen stiff steps to grow (the synchronous multi-step tests allow 1e-3 after 5)
     assert rel_l2(a["v"], b["v"]) <= 5e-4 and rel_l2(a["F"], b["F"]) <= 1e-4
     sim.close(); r.close()
+
+
+# ------------------------------------------------------------------------------------------ the resident stepper
+def _async_pair(tm, res, dx, states, kw, shapes, friction=0.4):
+    from oracle import refmpm as ref
+    r = ref.AsyncSim(res, dx, shapes=shapes, friction=friction, **kw)
+    sim = tm.create_simulation3("async_mpm").initialize(dict(res=(res,) * 3, delta_x=dx, **kw))
+    ls = tm.mpm.LevelSet(friction=friction)
+    for s in shapes:  # (type 0 = plane, inside_out, normal, d) as oracle/refmpm.py takes them
+        ls.add_plane(s[2:5], d=s[5])
+    sim.set_levelset(ls)
+    for s, mat in states:
+        r.add_particles(mat, s.gparams[0][0], s.gparams[0][1], s.x, s.v, s.F, s.B, s.aux)
+        sim.add_particles(dict(type=mat, positions=s.x, velocities=s.v, F=s.F, B=s.B, aux=s.aux, params=s.gparams[0]))
+    return r, sim
+
+
+def test_stepping_moves_no_particle_data_across_the_host_boundary_and_frames_hold_every_pool(tm, tmp_path):
+    """(i) AsyncMPM::step on the device-resident pools: the ctx's host<->device particle byte counter does not move while
+    stepping (the block tables and four counters are all the host sees); (ii) frame output, downloads and counts cover ALL
+    pool containers (AsyncMPM::visualize, src/async/async_visualize.cpp:86-96), not the last working set; (iii) particles added
+    between steps join their pools; (iv) many advances squeeze freed containers out of the store (compaction) without
+    changing the state."""
+    from tests.bgeo_reader import parse
+    res, dx, sa, sb = _two_stiffness_scene()
+    kw = dict(unit_delta_t=2e-6, max_units=1024)
+    sim = tm.create_simulation3("async_mpm").initialize(dict(res=(res,) * 3, delta_x=dx, frame_directory=str(tmp_path), **kw))
+    sim.set_levelset(tm.mpm.LevelSet(friction=0.4).add_plane((0, 1, 0), d=-0.2))
+    sim.add_particles(dict(type="elastic", positions=sa.x, velocities=sa.v, F=sa.F, B=sa.B, aux=sa.aux, params=sa.gparams[0]))
+    before = sim.host_particle_bytes()
+    assert before > 0  # the upload
+    for _ in range(3):
+        sim.step(2e-3)
+    assert sim.host_particle_bytes() == before
+    n_pool = sim.get_num_pool_particles()
+    assert n_pool >= len(sa.x)
+    frame = parse(open(sim.visualize(), "rb").read())["data"]
+    assert len(np.asarray(frame["index"]).reshape(-1)) == n_pool == sim.get_num_particles()
+    p = sim.get_particles()
+    assert len(p["id"]) == n_pool and set(np.unique(p["id"])) == set(range(len(sa.x)))
+    lim = np.asarray(frame["limit"]).reshape(n_pool, -1)
+    assert lim[:, 0].min() >= 1 and (lim[:, 0] & (lim[:, 0] - 1)).max() == 0  # powers of two: the pools' block limits
+    t0 = sim.get_current_time()
+    sim.add_particles(dict(type="sand", positions=sb.x, velocities=sb.v, F=sb.F, B=sb.B, aux=sb.aux, params=sb.gparams[0]))
+    assert sim.get_num_pool_particles() == n_pool + len(sb.x)  # (the view of the pools was not pooled a second time)
+    before = sim.host_particle_bytes()
+    for _ in range(6):
+        sim.step(2e-3)
+    assert sim.host_particle_bytes() == before
+    st = sim._state()
+    assert st[6] >= 1, "the store was never compacted: %r" % (st,)
+    assert sim.get_current_time() > t0 + 0.0119
+    q = sim.get_pool_particles()
+    assert set(np.unique(q["id"])) == set(range(len(sa.x) + len(sb.x)))
+    assert np.isfinite(q["x"]).all() and np.isfinite(q["v"]).all() and np.abs(q["v"]).max() < 20
+    tab = sim.block_table()
+    # (`count` = pool sizes at the last update_dt_limits, duplicates of an id included: close to, not equal to, the current number)
+    assert abs(int(tab["count"].sum()) - len(q["id"])) <= 64 and len(np.unique(tab["continuous"][tab["count"] > 0])) >= 2
+    sim.close()
+
+
+def test_a_million_particles_in_two_stiffnesses_match_the_live_reference_async_stepper(tm):
+    """128^3 grid, 2 x 0.5 M particles (soft Hencky-elastic next to stiff sand), AsyncMPM::step on the device-resident pools
+    next to the reference's own stepper on the same scene: block times, update counter, pool membership, states"""
+    from oracle import refmpm as ref
+    if not ref.available():
+        pytest.skip("oracle/_ref/libmpm_ref.so did not travel to this box")
+    ref.set_threads(min(16, os.cpu_count() or 1))
+    res = 128
+    dx = 1.0 / res
+    xa = lattice_cube(res, 30, 70, dx, jitter=0.2, seed=11)[::1]
+    xa = xa[xa[:, 0] < 50 * dx]   # 20 x 40 x 40 cells x 8 = 256 k ... two slabs side by side
+    xb = lattice_cube(res, 30, 70, dx, jitter=0.2, seed=12)
+    xb = xb[xb[:, 0] >= 50 * dx]
+    sa = make_state(xa, "elastic", dx, perturb_F=0.01, vel_scale=0.5, seed=13)
+    sb = make_state(xb, "sand", dx, perturb_F=0.01, vel_scale=0.5, seed=14)
+    assert len(xa) + len(xb) >= 500_000
+    kw = dict(unit_delta_t=2e-6, max_units=256)
+    r, sim = _async_pair(tm, res, dx, ((sa, "elastic"), (sb, "sand")), kw, shapes=[(0, 0, 0, 1, 0, -0.2)])
+    before = sim.host_particle_bytes()
+    r.step(6e-4)
+    sim.step(6e-4)
+    assert sim.host_particle_bytes() == before
+    assert sim.current_t_int == r.time_int()
+    assert sim.update_counter == r.update_counter()
+    a, b = sim.get_pool_particles(), r.download()
+    assert np.array_equal(a["id"], b["id"])
+    assert len(np.unique(b["limits"][:, 0])) >= 2, "the scene must step with at least two block step sizes"
+    assert np.array_equal(a["continuous"], b["limits"][:, 0]) and np.array_equal(a["particle_t"], b["limits"][:, 3])
+    from tests.common import rel_l2
+    assert np.abs(a["x"] - b["x"]).max() <= 1e-6
+    assert rel_l2(a["v"], b["v"]) <= 5e-4 and rel_l2(a["F"], b["F"]) <= 1e-4
+    sim.close(); r.close()
