@@ -279,7 +279,77 @@ def virtual_run(tm, cfg, args):
                       "rank0_phases_ms": per_rank[0], "migrated": [r.migrated_out for r in job.ranks]})
 
 
+class Watchdog:
+    """A multi-rank run that hangs (a collective one rank never enters, a transport that stalls on first contact) must cost
+    seconds, not the lease: a timer that prints where the run was and ends the PROCESS (os._exit: a thread stuck inside a
+    collective cannot be interrupted).  `phase(name, seconds)` re-arms it; every rank runs its own."""
+
+    def __init__(self, rank):
+        import threading
+        self.rank, self.t, self.name, self.threading = rank, None, "start", threading
+
+    def _fire(self):
+        sys.stderr.write("bench.py[rank %d]: no progress in phase '%s' within its deadline — giving up (exit 3)\n" % (self.rank, self.name))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def phase(self, name, seconds):
+        if self.t is not None:
+            self.t.cancel()
+        self.name = name
+        self.t = self.threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+        self.t.start()
+
+    def stop(self):
+        if self.t is not None:
+            self.t.cancel()
+
+
+def rccl_probe_main():
+    """`bench.py --probe-rccl` (started by every rank as a CHILD process, own rendezvous port): the two collectives the tiled
+    job uses, on device buffers over the nccl backend.  A transport that hangs or aborts takes the child down, not the job:
+    the parent waits with a timeout and falls back to staging through gloo."""
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=45))
+    dev = torch.device("cuda", local)
+    a = torch.full((world,), float(rank), device=dev)
+    b = torch.empty_like(a)
+    dist.all_to_all_single(b, a, [1] * world, [1] * world)
+    g = torch.empty(world, device=dev)
+    dist.all_gather_into_tensor(g, a[:1])
+    torch.cuda.synchronize()
+    ok = bool((b.cpu() == torch.arange(world, dtype=b.dtype)).all()) and bool((g.cpu() == torch.arange(world, dtype=g.dtype)).all())
+    dist.destroy_process_group()
+    print("RCCL_PROBE_OK" if ok else "RCCL_PROBE_WRONG_DATA", flush=True)
+    os._exit(0 if ok else 4)
+
+
+def probe_rccl_in_child(rank, world, local_rank, timeout_s=75.0):
+    """(ok, why): run rccl_probe_main in a child of this rank; the children of all ranks rendezvous among themselves"""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29511")) + 17)
+    env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank))
+    env.pop("TORCHELASTIC_RUN_ID", None)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-rccl"], env=env, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return False, "the RCCL probe did not finish within %.0f s" % timeout_s
+    if r.returncode == 0 and "RCCL_PROBE_OK" in r.stdout:
+        return True, ""
+    return False, "the RCCL probe exited with code %d: %s" % (r.returncode, (r.stderr or r.stdout).strip().splitlines()[-1:] or "")
+
+
 def main():
+    if "--probe-rccl" in sys.argv:
+        return rccl_probe_main()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -325,39 +395,39 @@ def main():
     torch.cuda.set_device(local_rank)
     force_tiled = world == 1 and os.environ.get("MPMHIP_FORCE_TILED") == "1"  # test hook: TiledJob over RCCL, 1 rank
     data_group, wire = None, None
+    dog = Watchdog(rank)
     if world > 1 or force_tiled:
+        import datetime
         # control plane (barriers, the two scalar reductions below, agreement on the transport) = gloo, the default
         # group; data plane (halo all-sum, migration) = an RCCL group over xGMI with device buffers
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dog.phase("gloo rendezvous", 180)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=150))
         wire = "gloo, staged through host memory (test hook)"
         if not staged:
-            # probe the transport with the two collectives the job uses; every rank must see it work, else all ranks
-            # stage the same buffers through gloo (slower wire, same kernels, same results) rather than abort
-            ok, why = 1, ""
-            try:
-                data_group = dist.new_group(backend="nccl")
-                dev = torch.device("cuda", local_rank)
-                a = torch.full((world,), float(rank), device=dev)
-                b = torch.empty_like(a)
-                dist.all_to_all_single(b, a, [1] * world, [1] * world, group=data_group)
-                g = torch.empty(world, device=dev)
-                dist.all_gather_into_tensor(g, a[:1], group=data_group)
-                torch.cuda.synchronize()
-                ok = int(bool((b.cpu() == torch.arange(world, dtype=b.dtype)).all())
-                         and bool((g.cpu() == torch.arange(world, dtype=g.dtype)).all()))
-                why = "" if ok else "RCCL probe returned wrong data"
-            except Exception as e:
-                ok, why = 0, repr(e)
-            flag = torch.tensor([ok])
+            # probe the transport with the two collectives the job uses, in a CHILD process per rank (a hang or an abort
+            # inside RCCL then costs the child, and a bounded wait); every rank must see it work, else all ranks stage the
+            # same buffers through gloo (slower wire, same kernels, same results) rather than abort
+            dog.phase("RCCL probe", 240)
+            ok, why = (True, "") if os.environ.get("MPMHIP_SKIP_RCCL_PROBE") == "1" else probe_rccl_in_child(rank, world, local_rank)
+            flag = torch.tensor([int(ok)])
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()):
-                wire = "RCCL (nccl backend), device buffers"
-            else:
+                dog.phase("RCCL group", 120)
+                try:
+                    data_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=90))
+                    wire = "RCCL (nccl backend), device buffers"
+                except Exception as e:
+                    ok, why = False, repr(e)
+                flag = torch.tensor([int(ok)])
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if not int(flag.item()):
+                    data_group = None
+            if data_group is None:
                 print("bench.py[rank %d]: RCCL transport unavailable (%s); staging the exchange through gloo" % (rank, why or "failed on another rank"),
                       file=sys.stderr)
-                staged, data_group = True, None
+                staged = True
                 wire = "gloo, staged through host memory (RCCL probe failed)"
 
     cfg = dict(CONFIGS[args.config])
@@ -366,6 +436,7 @@ def main():
         cfg["desc"] += " [REDUCED: cube edge %d cells]" % args.cells
     if args.virtual > 1:
         return emit(virtual_run(tm, cfg, args))
+    dog.phase("scene set-up", 900)
     if world > 1 or force_tiled:
         from taichi_mpm_amd import tiled
         comm = (tiled.StagedDistComm(dist) if staged else
@@ -374,6 +445,9 @@ def main():
     else:
         job = SingleJob(build_sim(tm, cfg, local_rank))
     n_local = job.num_particles()
+    if world > 1 or force_tiled:
+        print("bench.py[rank %d/%d]: device %d, wire: %s, %d particles on this rank" % (rank, world, local_rank, wire, n_local),
+              file=sys.stderr, flush=True)
 
     def barrier():
         if world > 1:
@@ -420,9 +494,12 @@ def main():
         return roof, both, n_per_gpu, nodes
 
     if args.state == "evolved":  # make the evolved state the one that is measured (profiling runs)
-        evolve_to_impact(job.sim, cfg)
-        job.substeps += substeps_to_impact(cfg) + EVOLVE_AFTER_IMPACT
+        dog.phase("evolving to impact", 1200)
+        job.run(substeps_to_impact(cfg) + EVOLVE_AFTER_IMPACT)  # (through the job: a tiled ctx cannot be stepped on its own)
+        job.synchronize()
+    dog.phase("measurement", 900)
     elapsed, ms, dom, prof = measure(args.warmup, args.steps)
+    dog.phase("report", 900)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -439,6 +516,7 @@ def main():
         except Exception as e:
             print("bench.py: copy bandwidth probe failed: %r" % (e,), file=sys.stderr)
     if rank != 0:
+        dog.stop()
         if world > 1:
             dist.destroy_process_group()
         return
@@ -454,7 +532,8 @@ def main():
     if args.state == "evolved":
         state_desc = "%d substeps after the block hit the floor (--state evolved)" % EVOLVE_AFTER_IMPACT
     out = {
-        "metric": "particle-steps/sec (P2G+grid+G2P), 256^3 grid 8M particles; %HBM roofline",
+        "metric": ("particle-steps/sec (P2G+grid+G2P), 256^3 grid 8M particles; %HBM roofline" if args.config == "c3" and not args.cells
+                   else "particle-steps/sec (P2G+grid+G2P), " + cfg["desc"] + "; %HBM roofline"),
         "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": job.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -470,8 +549,9 @@ def main():
     if world == 1 and not force_tiled and args.state == "lattice" and not args.no_evolved:
         # the same scene after impact, on the same ctx: the state the lattice number flatters
         try:
-            after = evolve_to_impact(job.sim, cfg)
-            job.substeps += substeps_to_impact(cfg) + after
+            after = EVOLVE_AFTER_IMPACT
+            job.run(substeps_to_impact(cfg) + after)
+            job.synchronize()
             e_el, e_ms, e_dom, e_prof = measure(5, args.steps)
             e_roof, e_both, e_n, e_nodes = roofline_of(e_ms, e_dom, e_prof, args.config + "_evolved")
             out["evolved"] = {
@@ -491,6 +571,7 @@ def main():
         except Exception as e:  # the baseline is a reported extra: never lose the GPU line because of it
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     emit(out)
+    dog.stop()
     if world > 1 or force_tiled:
         dist.destroy_process_group()
 

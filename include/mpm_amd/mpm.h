@@ -45,10 +45,10 @@ class MPM<3> {
   MPM() = default;
   MPM(const MPM &) = delete;
   MPM &operator=(const MPM &) = delete;
-  ~MPM() { if (ctx_) mpmhip_destroy(ctx_); }
+  virtual ~MPM() { if (ctx_) mpmhip_destroy(ctx_); }
 
   // --- MPM<dim>::initialize (src/mpm.cpp:26-75; config keys README.md:234-256)
-  void initialize(const Config &config) {
+  virtual void initialize(const Config &config) {
     if (config.has_key("delta_t")) throw std::runtime_error("Please use 'base_delta_t' instead of 'delta_t'");  // :41-42
     // physics-changing keys of the reference that this library does not implement: refused, not ignored
     for (const char *k : {"rigid_body_levelset_collision", "gravity_cutting", "sand_climb", "sand_crawler", "stork_nod", "energy_experiment",
@@ -75,7 +75,7 @@ class MPM<3> {
     cfg_.max_particles = (int64_t)config.get("max_particles", (double)(1 << 25));  // :773-775
     cfg_.max_blocks = (int64_t)config.get("max_blocks", 0.0);
     cfg_.device = config.get("device", 0);
-    cfg_.discard_apic_b = !config.get("keep_apic_b", false);
+    cfg_.discard_apic_b = !config.get("keep_apic_b", keep_apic_b_default());
     cfg_.generic_path = !config.get("optimized", true);  // src/mpm.cpp:508-515,546-552
     cfg_.particle_collision = config.get("particle_collision", false);  // src/mpm.cpp:566-569
     verbose_bgeo = config.get("verbose_bgeo", false);   // src/visualize.cpp:22
@@ -111,7 +111,7 @@ class MPM<3> {
   // --- MPM<dim>::add_particles (src/mpm.cpp:77-270).  Sampling: the built-in benchmark generator
   // ("benchmark" = 125 | 8000, :149-186), a lattice "cube_lo"/"cube_hi" in cells, or explicit arrays through
   // the overload below.  Returns "" (the reference returns a rigid-body id only for type "rigid").
-  std::string add_particles(const Config &config) {
+  virtual std::string add_particles(const Config &config) {
     std::vector<float> x;
     float maximum = config.get("ppc", config.get("maximum", 8.0f));
     if (config.get("benchmark", 0)) {
@@ -208,7 +208,7 @@ class MPM<3> {
     return o;
   }
 
-  std::string add_particles(const Config &config, int64_t n, const float *x, const float *v, float maximum = 0) {
+  virtual std::string add_particles(const Config &config, int64_t n, const float *x, const float *v, float maximum = 0) {
     const std::string type = config.get("type", "");
     if (type == "rigid") throw std::runtime_error("type='rigid': hand the mesh over with add_rigid_body(config, n_triangles, triangles)");
     if (maximum <= 0) maximum = config.get("ppc", config.get("maximum", 8.0f));
@@ -241,9 +241,9 @@ class MPM<3> {
   }
 
   // --- time stepping
-  void step(real dt) { check(mpmhip_step(ctx_, dt), ctx_); frame++; }  // src/mpm.cpp:428-439 (dt < 0: one substep)
+  virtual void step(real dt) { check(mpmhip_step(ctx_, dt), ctx_); frame++; }  // src/mpm.cpp:428-439 (dt < 0: one substep)
   void substep() { check(mpmhip_substep(ctx_), ctx_); }              // :452-575
-  real get_current_time() const { return (real)mpmhip_current_time(ctx_); }
+  virtual real get_current_time() const { return (real)mpmhip_current_time(ctx_); }
   void synchronize() { check(mpmhip_synchronize(ctx_), ctx_); }
 
   // --- the phases of substep(), under the reference's names
@@ -253,10 +253,12 @@ class MPM<3> {
   void apply_grid_boundary_conditions() {}  // fused into the grid kernel above (src/mpm.cpp:296-372)
   void resample_optimized() { check(mpmhip_g2p(ctx_), ctx_); }                       // src/transfer.cpp:702-970
 
-  int64_t get_num_particles() const { const int64_t n = mpmhip_num_particles(ctx_); check((int)std::min<int64_t>(n, 0), ctx_); return n; }
+  virtual int64_t get_num_particles() const { const int64_t n = mpmhip_num_particles(ctx_); check((int)std::min<int64_t>(n, 0), ctx_); return n; }
 
-  std::vector<RenderParticle> get_render_particles() const {
-    const int64_t n = get_num_particles();
+  virtual std::vector<RenderParticle> get_render_particles() const { return get_render_particles_of_records(); }
+  std::vector<RenderParticle> get_render_particles_of_records() const {
+    const int64_t n = mpmhip_num_particles(ctx_);
+    check((int)std::min<int64_t>(n, 0), ctx_);
     std::vector<float> x(3 * n), v(3 * n);
     std::vector<int32_t> id(n);
     check(mpmhip_download(ctx_, MPMHIP_F_X, x.data(), n), ctx_);
@@ -275,7 +277,7 @@ class MPM<3> {
 
   // --- frame output: visualize() -> write_bgeo() -> write_partio(file) (src/visualize.cpp:156-159, src/mpm.h:333-337,
   // src/visualize.cpp:17-100).  The Houdini .bgeo bytes equal the reference's (rows assembled on the device).
-  void write_partio(const std::string &file_name) const { check(mpmhip_write_bgeo(ctx_, file_name.c_str(), verbose_bgeo), ctx_); }
+  virtual void write_partio(const std::string &file_name) const { check(mpmhip_write_bgeo(ctx_, file_name.c_str(), verbose_bgeo), ctx_); }
   std::string write_bgeo() {
     if (frame_directory.empty()) throw std::runtime_error("write_bgeo() needs the config key 'frame_directory'");
     char name[32];
@@ -342,7 +344,7 @@ class MPM<3> {
 
   bool test() const { return true; }                          // src/mpm.cpp:577-580
   std::string get_debug_information() const { return ""; }    // :635-639
-  std::string get_name() const { return "mpm"; }              // src/mpm.h:486-488
+  virtual std::string get_name() const { return "mpm"; }      // src/mpm.h:486-488
   mpmhip_ctx *ctx() const { return ctx_; }
 
   VectorI res;
@@ -351,7 +353,8 @@ class MPM<3> {
   bool verbose_bgeo = false;
   std::string frame_directory;
 
- private:
+ protected:
+  virtual bool keep_apic_b_default() const { return false; }
   void lattice(int lower, int higher, std::vector<float> &x) const {  // src/mpm.cpp:164-180: cell centre +- 0.25 dx
     for (int i = lower; i < higher; i++)
       for (int j = lower; j < higher; j++)
@@ -373,9 +376,61 @@ class MPM<3> {
 
 using MPM3D = MPM<3>;
 
-// the factory the reference reaches through `create_instance<Simulation3D>("mpm")` (src/mpm.cpp:983-988)
+// `AsyncMPM<3>`: the reference's asynchronous stepper (src/async/async_mpm.{h,cpp}) over the C ABI's "AsyncMPM, second half"
+// (include/mpmhip.h): the block-local time stepping itself — pools, backups, gathers, the walk over the power-of-two levels —
+// runs inside the library with every particle resident on the device; this class forwards, as MPM<3> does.
+class AsyncMPM3D : public MPM3D {
+ public:
+  void initialize(const Config &config) override {  // AsyncMPM<dim>::initialize, src/async/async_mpm.cpp:13-55
+    if (config.get("left_boundary", false)) throw std::runtime_error("config key 'left_boundary' (src/async/async_mpm.cpp:43-53) is not implemented");
+    MPM3D::initialize(config);
+    mpmhip_async_config a{};
+    a.unit_delta_t = config.get("unit_delta_t", 1e-6f);  // :24-27
+    a.max_units = (int64_t)config.get("max_units", 8192.0);
+    a.cfl_dt_mul = config.get("cfl_dt_mul", 1.0f);
+    a.strength_dt_mul = config.get("strength_dt_mul", 1.0f);
+    check(mpmhip_async_begin(ctx_, &a), ctx_);
+  }
+  std::string add_particles(const Config &config) override {  // :57-75: the new particles go to their blocks' pools
+    const std::string r = MPM3D::add_particles(config);
+    check(mpmhip_async_pool_particles(ctx_), ctx_);
+    return r;
+  }
+  std::string add_particles(const Config &config, int64_t n, const float *x, const float *v, float maximum = 0) override {
+    const std::string r = MPM3D::add_particles(config, n, x, v, maximum);
+    check(mpmhip_async_pool_particles(ctx_), ctx_);
+    return r;
+  }
+  void step(real dt) override { check(mpmhip_async_step(ctx_, dt), ctx_); frame++; }  // :380-421
+  real get_current_time() const override { return (real)mpmhip_async_current_time(ctx_); }
+  // the views of "the particles" list every container of every particle pool, as AsyncMPM<dim>::visualize does
+  // (src/async/async_visualize.cpp:86-96)
+  int64_t get_num_particles() const override {
+    const int64_t n = mpmhip_async_download_pools(ctx_, 0, nullptr, nullptr);
+    check((int)std::min<int64_t>(n, 0), ctx_);
+    return n;
+  }
+  std::vector<RenderParticle> get_render_particles() const override {
+    check(mpmhip_async_load_pools(ctx_), ctx_);
+    return MPM3D::get_render_particles_of_records();
+  }
+  void write_partio(const std::string &file_name) const override {
+    check(mpmhip_async_load_pools(ctx_), ctx_);
+    MPM3D::write_partio(file_name);
+  }
+  std::string get_name() const override { return "async_mpm"; }  // src/async/async_mpm.h:251-253
+  int64_t current_t_int() const { int64_t o[8]; check(mpmhip_async_state(ctx_, o), ctx_); return o[0]; }
+  int64_t update_counter() const { int64_t o[8]; check(mpmhip_async_state(ctx_, o), ctx_); return o[1]; }
+
+ protected:
+  bool keep_apic_b_default() const override { return true; }  // (the P2G matrix is rebuilt from apic_b for every advance's dt)
+};
+
+// the factory the reference reaches through `create_instance<Simulation3D>(name)`: TC_IMPLEMENTATION(Simulation3D, MPM3D, "mpm")
+// (src/mpm.cpp:983-988) and TC_IMPLEMENTATION(Simulation3D, AsyncMPM3D, "async_mpm") (src/async/async_mpm.cpp:423-427)
 inline std::unique_ptr<MPM3D> create_simulation3(const std::string &name) {
-  if (name != "mpm") throw std::runtime_error("no Simulation3D implementation named '" + name + "' (registered: 'mpm')");
+  if (name == "async_mpm") return std::make_unique<AsyncMPM3D>();
+  if (name != "mpm") throw std::runtime_error("no Simulation3D implementation named '" + name + "' (registered: 'mpm', 'async_mpm')");
   return std::make_unique<MPM3D>();
 }
 

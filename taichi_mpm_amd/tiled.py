@@ -434,9 +434,12 @@ class TiledJob:
         _finish_migration(table, w, [r], lambda recvs, sends, cnt: self.comm.all_to_all(
             recvs[0], sends[0], cnt[:, r.rank] * MIGRATE_FLOATS, cnt[r.rank] * MIGRATE_FLOATS))
 
+    substeps = 0  # substeps run so far (bench.py reports it)
+
     def run(self, n):
         for _ in range(n):
             self.substep()
+        self.substeps += n
 
     def num_particles(self):
         return self.e.num_particles()
@@ -496,9 +499,12 @@ class VirtualTiledJob:
         _finish_migration(table, len(self.ranks), self.ranks,
                           lambda recvs, sends, cnt: self._a2a(recvs, sends, cnt * MIGRATE_FLOATS))
 
+    substeps = 0
+
     def run(self, n):
         for _ in range(n):
             self.substep()
+        self.substeps += n
 
 
 # ---------------------------------------------------------------------------------------------------- bench glue

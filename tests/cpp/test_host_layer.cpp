@@ -231,6 +231,32 @@ static void gpu_tests() {
     CHECK(std::fabs(st[12] - 3.0f) < 1e-4f && std::fabs(st[10]) < 1e-5f && std::fabs(st[11]) < 1e-5f);  // angular velocity = (0, 0, 3)
     CHECK(std::fabs(st[0] - 0.5f) < 1e-5f && std::fabs(st[1] - 0.5f) < 1e-5f);                          // the hinge holds the centre
   }
+  {  // create_simulation3("async_mpm"): AsyncMPM<3> (src/async/async_mpm.cpp) — block-local time steps, pools resident on the device
+    auto as = create_simulation3("async_mpm");
+    CHECK(as->get_name() == "async_mpm");
+    as->initialize(Config().set("res", Vector3i(32, 32, 32)).set("unit_delta_t", 2e-6).set("max_units", 1024.0).set("max_particles", 16384.0));
+    as->set_levelset(std::vector<Vector4>{Vector4(0, 1, 0, -0.2f)}, 0.4f);
+    as->add_particles(Config().set("type", "elastic").set("cube_lo", 9).set("cube_hi", 15).set("initial_velocity", Vector3(0.2f, 0, 0)));
+    as->add_particles(Config().set("type", "sand").set("cube_lo", 15).set("cube_hi", 21));
+    const int64_t n0 = as->get_num_particles();
+    CHECK(n0 == 2 * 6 * 6 * 6 * 8);
+    const int64_t bytes0 = mpmhip_host_particle_bytes(as->ctx());
+    as->step(2.5e-3f);
+    as->step(2.5e-3f);
+    CHECK(mpmhip_host_particle_bytes(as->ctx()) == bytes0);  // stepping moved no particle data across the host boundary
+    auto *a3 = dynamic_cast<AsyncMPM3D *>(as.get());
+    CHECK(a3 != nullptr && a3->current_t_int() >= 2500 && a3->update_counter() > n0);
+    CHECK(std::fabs(as->get_current_time() - 2e-6f * (float)a3->current_t_int()) < 1e-9f);
+    const auto rp = as->get_render_particles();  // every pool container (ids can repeat, as in the reference)
+    CHECK((int64_t)rp.size() == as->get_num_particles() && (int64_t)rp.size() >= n0);
+    bool finite = true;
+    int32_t max_id = -1;
+    for (auto &q : rp) { finite = finite && std::isfinite(q.position[1]) && std::isfinite(q.velocity[1]); max_id = std::max(max_id, q.id); }
+    CHECK(finite && max_id == n0 - 1);
+    bool threw = false;
+    try { as->step(-1.0f); } catch (const std::exception &) { threw = true; }
+    CHECK(threw);  // the synchronous single substep belongs to "mpm"
+  }
   // device constitutive code through the particle surface: F = I => zero force; plasticity(cdg) = F <- cdg F for jelly
   MPMParticle p;
   p.type = create_particle_type("jelly", Config(), 1.0f, 1e-6f);
