@@ -76,6 +76,24 @@ __device__ __forceinline__ void rigid_velocity_at(const RigidBodyDev &b, const f
   cross3(b.omega, r, w);
   v[0] = b.vel[0] + w[0]; v[1] = b.vel[1] + w[1]; v[2] = b.vel[2] + w[2];
 }
+// What the transfer kernels read of a body per (particle, node) pair — pose centre, velocities, friction — mirrored in LDS
+// once per workgroup: read from the body records in global memory inside the per-node loops, every iteration waited a full
+// memory round trip (k_p2g_rigid: 320 of 447 us at 8 M particles with a paddle wheel, profiles/r03_p_cpic.txt).
+struct RigidLite { float pos[3], vel[3], omega[3], fric[2], pad; };
+__device__ __forceinline__ void load_rigid_lite(RigidLite *s, const RigidBodyDev *rb, int tid, int nt) {
+  for (int t = tid; t < MAX_RIGID * 11; t += nt) {
+    const int b = t / 11, f = t - 11 * b;
+    const RigidBodyDev &B = rb[b];
+    const float v = f < 3 ? B.pos[f] : (f < 6 ? B.vel[f - 3] : (f < 9 ? B.omega[f - 6] : B.fric[f - 9]));
+    reinterpret_cast<float *>(s + b)[f] = v;
+  }
+}
+__device__ __forceinline__ void rigid_velocity_at(const RigidLite &b, const float p[3], float v[3]) {
+  const float r[3] = {p[0] - b.pos[0], p[1] - b.pos[1], p[2] - b.pos[2]};
+  float w[3];
+  cross3(b.omega, r, w);
+  v[0] = b.vel[0] + w[0]; v[1] = b.vel[1] + w[1]; v[2] = b.vel[2] + w[2];
+}
 // RigidBody::apply_tmp_impulse.  The reference adds every (particle, node) impulse to the body under a spinlock; here a
 // lane first sums its own impulses (and their torques about the body's centre) in registers, a wave then reduces the sums
 // of its lanes per body, and ONE lane issues the six float atomics: all impulses of a scene land on the same six words of
@@ -93,10 +111,12 @@ __device__ __forceinline__ void acc_flush_lane(ImpulseAcc &A, RigidBodyDev *rb) 
   }
   acc_init(A);
 }
-__device__ __forceinline__ void acc_add(ImpulseAcc &A, RigidBodyDev *rb, int body, const float imp[3], const float at[3]) {
+// (centre: the body's centre of mass — from the caller's LDS mirror where it has one)
+__device__ __forceinline__ void acc_add(ImpulseAcc &A, RigidBodyDev *rb, int body, const float imp[3], const float at[3],
+                                        const float *centre = nullptr) {
   if (A.body != body) { acc_flush_lane(A, rb); A.body = body; }
-  const RigidBodyDev &B = rb[body];
-  const float r[3] = {at[0] - B.pos[0], at[1] - B.pos[1], at[2] - B.pos[2]};
+  const float *cpos = centre ? centre : rb[body].pos;
+  const float r[3] = {at[0] - cpos[0], at[1] - cpos[1], at[2] - cpos[2]};
   float t[3];
   cross3(r, imp, t);
 #pragma unroll

@@ -40,8 +40,10 @@ __global__ __launch_bounds__(64, 2) void k_p2g_rigid(Params P, const float4 *__r
                                                   RigidXfer X) {
   __shared__ float4 tile[TN];
   __shared__ uint32_t stile[TN];
+  __shared__ RigidLite srb[MAX_RIGID];
   const uint32_t na = min(cnt->n_active, P.max_blocks);
   const int lane = threadIdx.x;
+  load_rigid_lite(srb, X.rb, lane, 64);  // (visible behind the first block's barrier)
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
   const int nbase = (cx * TS + cy) * TS + cz;
   for (uint32_t a = blockIdx.x; a < na; a += gridDim.x) {
@@ -53,99 +55,60 @@ __global__ __launch_bounds__(64, 2) void k_p2g_rigid(Params P, const float4 *__r
     __syncthreads();
     const int gx = bx * BS + cx, gy = by * BS + cy, gz = bz * BS + cz;  // base node of this lane's cell
     const uint32_t p0 = cell_start[a * BC + lane], p1 = cell_start[a * BC + lane + 1];
+    // Two walks over the cell's particles.  The first is k_p2g's scatter with the colour test (27 x 4 sums in registers); the
+    // second, after those sums have been merged into the tile and their registers are free, hands the momentum change and the
+    // stress term of the skipped nodes to the bodies — it evaluates calculate_force() (an eigen-solve, all eight materials),
+    // which in ONE loop with the 108 accumulators alive cost 43 spilled registers, their scratch reloads inside the inner
+    // loop.  Boundary particles are a minority of a rigid block's particles; their records are read a second time from L2.
     float acc[27][4];
 #pragma unroll
     for (int n = 0; n < 27; n++) acc[n][0] = acc[n][1] = acc[n][2] = acc[n][3] = 0.0f;
-    ImpulseAcc ia;
-    acc_init(ia);
-    // the records of the next particle are in flight while one is computed
-    // (F and aux are only needed for a node of the other colour: fetched then, not prefetched)
-    float4 nq0, nq1, nq2, nq3, nh3, nb0;
-    size_t icur = 0, inext = 0;
-    if (p0 < p1) {
-      inext = perm[p0];
-      nq0 = rp[inext * 4 + 0]; nq1 = rp[inext * 4 + 1]; nq2 = rp[inext * 4 + 2]; nq3 = rp[inext * 4 + 3];
-      nh3 = rg[inext * 4 + 3];
-      nb0 = reinterpret_cast<const float4 *>(X.bnd)[inext * 2];
-    }
-    for (uint32_t p = p0; p < p1; p++) {
-      const float4 q0 = nq0, q1 = nq1, q2 = nq2, q3 = nq3, h3 = nh3;
-      const float bnn[3] = {nb0.x, nb0.y, nb0.z};
-      icur = inext;
-      if (p + 1 < p1) {
-        inext = perm[p + 1];
+    bool any_other = false;
+    {
+      float4 nq0, nq1, nq2, nq3, nh3;
+      size_t inext = 0;
+      if (p0 < p1) {
+        inext = perm[p0];
         nq0 = rp[inext * 4 + 0]; nq1 = rp[inext * 4 + 1]; nq2 = rp[inext * 4 + 2]; nq3 = rp[inext * 4 + 3];
         nh3 = rg[inext * 4 + 3];
-        nb0 = reinterpret_cast<const float4 *>(X.bnd)[inext * 2];
       }
-      const uint32_t pstate = __float_as_uint(h3.w);
-      const float mass = q3.w;
-      float v[3] = {q0.w, q1.x, q1.y};
-      if (P.particle_gravity) { v[0] = fmaf(P.g[0], P.dt, v[0]); v[1] = fmaf(P.g[1], P.dt, v[1]); v[2] = fmaf(P.g[2], P.dt, v[2]); }
-      const float r0 = q0.x * P.idx - (float)gx, r1 = q0.y * P.idx - (float)gy, r2 = q0.z * P.idx - (float)gz;
-      float w0[3], w1[3], w2[3];
-      bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
-      // d/dx of the quadratic B-spline in grid units (src/kernel.h:131-132): dw = (1, -2, 1) t + (-1.5, 0, 1.5)
-      const float t0[3] = {r0, r0 - 1.0f, r0 - 2.0f}, t1[3] = {r1, r1 - 1.0f, r1 - 2.0f}, t2[3] = {r2, r2 - 1.0f, r2 - 2.0f};
-      const float dw0[3] = {t0[0] - 1.5f, -2.0f * t0[1], t0[2] + 1.5f}, dw1[3] = {t1[0] - 1.5f, -2.0f * t1[1], t1[2] + 1.5f},
-                  dw2[3] = {t2[0] - 1.5f, -2.0f * t2[1], t2[2] + 1.5f};
-      const float A00 = q1.z, A01 = q1.w, A02 = q2.x, A10 = q2.y, A11 = q2.z, A12 = q2.w, A20 = q3.x, A21 = q3.y, A22 = q3.z;
-      const float mv0 = mass * v[0], mv1 = mass * v[1], mv2 = mass * v[2];
-      // pass 1: which of the 27 nodes belong to the other side of a body for this particle
-      uint32_t other = 0u;
+      for (uint32_t p = p0; p < p1; p++) {
+        const float4 q0 = nq0, q1 = nq1, q2 = nq2, q3 = nq3, h3 = nh3;
+        if (p + 1 < p1) {  // the records of the next particle are in flight while one is computed
+          inext = perm[p + 1];
+          nq0 = rp[inext * 4 + 0]; nq1 = rp[inext * 4 + 1]; nq2 = rp[inext * 4 + 2]; nq3 = rp[inext * 4 + 3];
+          nh3 = rg[inext * 4 + 3];
+        }
+        const uint32_t pstate = __float_as_uint(h3.w);
+        const float mass = q3.w;
+        float v[3] = {q0.w, q1.x, q1.y};
+        if (P.particle_gravity) { v[0] = fmaf(P.g[0], P.dt, v[0]); v[1] = fmaf(P.g[1], P.dt, v[1]); v[2] = fmaf(P.g[2], P.dt, v[2]); }
+        const float r0 = q0.x * P.idx - (float)gx, r1 = q0.y * P.idx - (float)gy, r2 = q0.z * P.idx - (float)gz;
+        float w0[3], w1[3], w2[3];
+        bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
+        const float A00 = q1.z, A01 = q1.w, A02 = q2.x, A10 = q2.y, A11 = q2.z, A12 = q2.w, A20 = q3.x, A21 = q3.y, A22 = q3.z;
+        const float mv0 = mass * v[0], mv1 = mass * v[1], mv2 = mass * v[2];
+        // which of the 27 nodes belong to the other side of a body for this particle; the ordinary scatter skips them
+        uint32_t other = 0u;
 #pragma unroll
-      for (int n = 0; n < 27; n++) {
-        const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
-        if (cdf_incompatible(stile[nbase + (i3 * TS + j) * TS + k], pstate)) other |= 1u << n;
-      }
-      // pass 2: the ordinary scatter into the lane's registers, skipping those nodes
-#pragma unroll
-      for (int n = 0; n < 27; n++) {
-        const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
-        const float w = ((other >> n) & 1u) ? 0.0f : (w0[i3] * w1[j]) * w2[k];
-        const float d0 = r0 - (float)i3, d1 = r1 - (float)j, d2 = r2 - (float)k;
-        const float c0 = fmaf(A02, d2, fmaf(A01, d1, fmaf(A00, d0, mv0)));
-        const float c1 = fmaf(A12, d2, fmaf(A11, d1, fmaf(A10, d0, mv1)));
-        const float c2 = fmaf(A22, d2, fmaf(A21, d1, fmaf(A20, d0, mv2)));
-        acc[n][0] = fmaf(w, c0, acc[n][0]); acc[n][1] = fmaf(w, c1, acc[n][1]);
-        acc[n][2] = fmaf(w, c2, acc[n][2]); acc[n][3] = fmaf(w, mass, acc[n][3]);
-      }
-      // pass 3 (particles at a boundary only): momentum change and stress term of the skipped nodes go to the bodies
-      if (other) {
-        const float4 h0 = rg[icur * 4 + 0], h1 = rg[icur * 4 + 1], h2 = rg[icur * 4 + 2];
-        mat3 F;
-        F.m[0] = h1.x; F.m[1] = h1.y; F.m[2] = h1.z; F.m[3] = h1.w; F.m[4] = h2.x; F.m[5] = h2.y; F.m[6] = h2.z; F.m[7] = h2.w; F.m[8] = h3.x;
-        mat3 dtF = calculate_force(groups[__float_as_uint(h3.y)], F, h0.w);  // delta_t * calculate_force()
-#pragma unroll
-        for (int e = 0; e < 9; e++) dtF.m[e] *= P.dt;
-        while (other) {
-          const int n = __ffs(other) - 1;
-          other &= other - 1u;
+        for (int n = 0; n < 27; n++) {
           const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
-          const int rid = (int)(stile[nbase + (i3 * TS + j) * TS + k] >> 24) - 1;
-          if (rid < 0) continue;
-          RigidBodyDev *B = X.rb + rid;
-          // weights and their derivatives of node (i3, j, k) without indexing the per-axis arrays dynamically
-          const float wa = i3 == 0 ? w0[0] : (i3 == 1 ? w0[1] : w0[2]), wb = j == 0 ? w1[0] : (j == 1 ? w1[1] : w1[2]),
-                      wc = k == 0 ? w2[0] : (k == 1 ? w2[1] : w2[2]);
-          const float da = i3 == 0 ? dw0[0] : (i3 == 1 ? dw0[1] : dw0[2]), db = j == 0 ? dw1[0] : (j == 1 ? dw1[1] : dw1[2]),
-                      dc = k == 0 ? dw2[0] : (k == 1 ? dw2[1] : dw2[2]);
-          const float w = (wa * wb) * wc;
-          const float gp[3] = {(gx + i3) * P.dx, (gy + j) * P.dx, (gz + k) * P.dx};
-          float rv[3];
-          rigid_velocity_at(*B, gp, rv);
-          float pv[3] = {v[0], v[1], v[2]};
-          friction_project(pv, rv, bnn, B->fric[(pstate >> (2 * rid)) & 1u]);
-          const float gr[3] = {da * P.idx * wb * wc, wa * db * P.idx * wc, wa * wb * dc * P.idx};
-          float imp[3];
+          if (cdf_incompatible(stile[nbase + (i3 * TS + j) * TS + k], pstate)) other |= 1u << n;
+        }
+        any_other = any_other || other != 0u;
 #pragma unroll
-          for (int c = 0; c < 3; c++)
-            imp[c] = mass * w * (v[c] - pv[c]) + (dtF(c, 0) * gr[0] + dtF(c, 1) * gr[1] + dtF(c, 2) * gr[2]);
-          acc_add(ia, X.rb, rid, imp, gp);
+        for (int n = 0; n < 27; n++) {
+          const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
+          const float w = ((other >> n) & 1u) ? 0.0f : (w0[i3] * w1[j]) * w2[k];
+          const float d0 = r0 - (float)i3, d1 = r1 - (float)j, d2 = r2 - (float)k;
+          const float c0 = fmaf(A02, d2, fmaf(A01, d1, fmaf(A00, d0, mv0)));
+          const float c1 = fmaf(A12, d2, fmaf(A11, d1, fmaf(A10, d0, mv1)));
+          const float c2 = fmaf(A22, d2, fmaf(A21, d1, fmaf(A20, d0, mv2)));
+          acc[n][0] = fmaf(w, c0, acc[n][0]); acc[n][1] = fmaf(w, c1, acc[n][1]);
+          acc[n][2] = fmaf(w, c2, acc[n][2]); acc[n][3] = fmaf(w, mass, acc[n][3]);
         }
       }
     }
-    acc_flush_wave(ia, X.rb);  // the wave's impulses: six atomics per body
     // ordered, race-free merges into the wave's tile (see k_p2g.h)
 #pragma unroll
     for (int n = 0; n < 27; n++) {
@@ -158,6 +121,68 @@ __global__ __launch_bounds__(64, 2) void k_p2g_rigid(Params P, const float4 *__r
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
     }
+    // second walk (cells with a boundary particle only): momentum change and stress term of the skipped nodes go to the bodies
+    ImpulseAcc ia;
+    acc_init(ia);
+    if (__any(any_other)) {
+      for (uint32_t p = p0; p < p1 && any_other; p++) {
+        const size_t icur = perm[p];
+        const float4 h3 = rg[icur * 4 + 3];
+        const uint32_t pstate = __float_as_uint(h3.w);
+        uint32_t other = 0u;
+#pragma unroll
+        for (int n = 0; n < 27; n++) {
+          const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
+          if (cdf_incompatible(stile[nbase + (i3 * TS + j) * TS + k], pstate)) other |= 1u << n;
+        }
+        if (!other) continue;
+        const float4 q0 = rp[icur * 4 + 0], q1 = rp[icur * 4 + 1], q3 = rp[icur * 4 + 3];
+        const float4 nb0 = reinterpret_cast<const float4 *>(X.bnd)[icur * 2];
+        const float bnn[3] = {nb0.x, nb0.y, nb0.z};
+        const float mass = q3.w;
+        float v[3] = {q0.w, q1.x, q1.y};
+        if (P.particle_gravity) { v[0] = fmaf(P.g[0], P.dt, v[0]); v[1] = fmaf(P.g[1], P.dt, v[1]); v[2] = fmaf(P.g[2], P.dt, v[2]); }
+        const float r0 = q0.x * P.idx - (float)gx, r1 = q0.y * P.idx - (float)gy, r2 = q0.z * P.idx - (float)gz;
+        float w0[3], w1[3], w2[3];
+        bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
+        // d/dx of the quadratic B-spline in grid units (src/kernel.h:131-132): dw = (1, -2, 1) t + (-1.5, 0, 1.5)
+        const float t0[3] = {r0, r0 - 1.0f, r0 - 2.0f}, t1[3] = {r1, r1 - 1.0f, r1 - 2.0f}, t2[3] = {r2, r2 - 1.0f, r2 - 2.0f};
+        const float dw0[3] = {t0[0] - 1.5f, -2.0f * t0[1], t0[2] + 1.5f}, dw1[3] = {t1[0] - 1.5f, -2.0f * t1[1], t1[2] + 1.5f},
+                    dw2[3] = {t2[0] - 1.5f, -2.0f * t2[1], t2[2] + 1.5f};
+        const float4 h0 = rg[icur * 4 + 0], h1 = rg[icur * 4 + 1], h2 = rg[icur * 4 + 2];
+        mat3 F;
+        F.m[0] = h1.x; F.m[1] = h1.y; F.m[2] = h1.z; F.m[3] = h1.w; F.m[4] = h2.x; F.m[5] = h2.y; F.m[6] = h2.z; F.m[7] = h2.w; F.m[8] = h3.x;
+        mat3 dtF = calculate_force(groups[__float_as_uint(h3.y)], F, h0.w);  // delta_t * calculate_force()
+#pragma unroll
+        for (int e = 0; e < 9; e++) dtF.m[e] *= P.dt;
+        while (other) {
+          const int n = __ffs(other) - 1;
+          other &= other - 1u;
+          const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
+          const int rid = (int)(stile[nbase + (i3 * TS + j) * TS + k] >> 24) - 1;
+          if (rid < 0) continue;
+          const RigidLite &B = srb[rid];
+          // weights and their derivatives of node (i3, j, k) without indexing the per-axis arrays dynamically
+          const float wa = i3 == 0 ? w0[0] : (i3 == 1 ? w0[1] : w0[2]), wb = j == 0 ? w1[0] : (j == 1 ? w1[1] : w1[2]),
+                      wc = k == 0 ? w2[0] : (k == 1 ? w2[1] : w2[2]);
+          const float da = i3 == 0 ? dw0[0] : (i3 == 1 ? dw0[1] : dw0[2]), db = j == 0 ? dw1[0] : (j == 1 ? dw1[1] : dw1[2]),
+                      dc = k == 0 ? dw2[0] : (k == 1 ? dw2[1] : dw2[2]);
+          const float w = (wa * wb) * wc;
+          const float gp[3] = {(gx + i3) * P.dx, (gy + j) * P.dx, (gz + k) * P.dx};
+          float rv[3];
+          rigid_velocity_at(B, gp, rv);
+          float pv[3] = {v[0], v[1], v[2]};
+          friction_project(pv, rv, bnn, B.fric[(pstate >> (2 * rid)) & 1u]);
+          const float gr[3] = {da * P.idx * wb * wc, wa * db * P.idx * wc, wa * wb * dc * P.idx};
+          float imp[3];
+#pragma unroll
+          for (int c = 0; c < 3; c++)
+            imp[c] = mass * w * (v[c] - pv[c]) + (dtF(c, 0) * gr[0] + dtF(c, 1) * gr[1] + dtF(c, 2) * gr[2]);
+          acc_add(ia, X.rb, rid, imp, gp, B.pos);
+        }
+      }
+    }
+    acc_flush_wave(ia, X.rb);  // the wave's impulses: six atomics per body
     __syncthreads();
     for (int t = lane; t < TN; t += 64) tiles[(size_t)a * TN + t] = tile[t];
     __syncthreads();
@@ -180,8 +205,10 @@ __global__ __launch_bounds__(256, 2) void k_g2p_rigid(Params P, const float4 *__
                                                    const LevelSetDev *__restrict__ ls, RigidXfer X) {
   __shared__ float4 tile[TN];
   __shared__ uint32_t stile[TN];
+  __shared__ RigidLite srb[MAX_RIGID];
   const uint32_t na = min(cnt->n_active, P.max_blocks);
   const int tid = threadIdx.x;
+  load_rigid_lite(srb, X.rb, tid, 256);  // (visible behind the first block's barriers)
   const float scale = -4.0f * P.idx * P.dt;
   for (uint32_t a = blockIdx.x; a < na; a += gridDim.x) {
     if (!X.blk_rigid[a]) continue;
@@ -254,9 +281,9 @@ __global__ __launch_bounds__(256, 2) void k_g2p_rigid(Params P, const float4 *__
           float vg[3] = {0, 0, 0}, friction = 0.0f;
           if (rid >= 0) {
             const float gp[3] = {(bx * BS + c0 + i3) * P.dx, (by * BS + c1 + j) * P.dx, (bz * BS + c2 + k) * P.dx};
-            rigid_velocity_at(X.rb[rid], gp, vg);
+            rigid_velocity_at(srb[rid], gp, vg);
             rigid_id = rid;
-            friction = X.rb[rid].fric[(pstate >> (2 * rid)) & 1u];
+            friction = srb[rid].fric[(pstate >> (2 * rid)) & 1u];
           }
           if (bn.near) {
             friction_project(fake, vg, bn.n, friction);
@@ -306,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void k_g2p_rigid(Params P, const float4 *__
           v[0] -= dv[0]; v[1] -= dv[1]; v[2] -= dv[2];
           if (rigid_id != -1) {
             const float imp[3] = {dv[0] * g.p[0], dv[1] * g.p[0], dv[2] * g.p[0]}, at[3] = {nx0, nx1, nx2};
-            acc_add(ia, X.rb, rigid_id, imp, at);
+            acc_add(ia, X.rb, rigid_id, imp, at, srb[rigid_id].pos);
           }
         }
         if (P.clamp_pos) {
