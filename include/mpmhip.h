@@ -265,6 +265,15 @@ int mpmhip_substep_end(mpmhip_ctx *ctx);
  * that cannot touch a halo node) while it is on the wire, waits for it, and calls substep_end (the boundary part).
  * substep_interior is a no-op when the overlap is off; substep_end runs it if the caller skipped it. */
 int mpmhip_set_overlap(mpmhip_ctx *ctx, int32_t enabled);
+/* The per-substep loop of a tiled rank in native code: for each of n substeps
+ *     substep_begin;  exchange(user, MPMHIP_EXCHANGE_START);  substep_interior;  exchange(user, MPMHIP_EXCHANGE_WAIT);  substep_end
+ * — the caller supplies only the transport (START: launch the all-to-all of the halo boxes behind the work enqueued so far,
+ * e.g. on a side stream; WAIT: make the ctx's stream wait for it).  A non-zero return of the callback ends the loop and is
+ * returned (negative values are taken as they are, positive ones as MPMHIP_EINVAL).  `until_migration` > 0 stops after that
+ * many substeps even if n is larger (the caller runs its migration and calls again); returns the number of substeps run. */
+enum { MPMHIP_EXCHANGE_START = 0, MPMHIP_EXCHANGE_WAIT = 1 };
+typedef int32_t (*mpmhip_exchange_fn)(void *user, int32_t phase);
+int64_t mpmhip_tiled_run(mpmhip_ctx *ctx, int64_t n, int64_t until_migration, mpmhip_exchange_fn exchange, void *user);
 int mpmhip_substep_interior(mpmhip_ctx *ctx);
 /* counts[world]: live particles whose base cell now lies in another rank's brick.  Also raises MPMHIP_ECAPACITY
  * (sticky) if a particle is more than `margin` cells outside this rank's brick. */

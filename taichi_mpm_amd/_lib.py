@@ -47,6 +47,7 @@ class AsyncConfig(C.Structure):
 
 
 SCRIPT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_float, C.POINTER(C.c_float))  # mpmhip_script_fn
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32)  # mpmhip_exchange_fn
 
 
 class RigidConfig(C.Structure):
@@ -137,7 +138,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_las
             "mpmhip_synchronize", "mpmhip_sort", "mpmhip_p2g", "mpmhip_grid_update", "mpmhip_g2p",
             "mpmhip_download_grid", "mpmhip_upload_grid", "mpmhip_calculate_energy", "mpmhip_snapshot_size", "mpmhip_snapshot_save", "mpmhip_snapshot_load", "mpmhip_delete_particles_inside_level_set", "mpmhip_bgeo_size", "mpmhip_bgeo_encode", "mpmhip_write_bgeo", "mpmhip_set_profiling", "mpmhip_profile",
             "mpmhip_profile_reset", "mpmhip_set_partition", "mpmhip_set_halo", "mpmhip_halo_pack",
-            "mpmhip_substep_begin", "mpmhip_substep_end", "mpmhip_substep_interior", "mpmhip_set_overlap", "mpmhip_leaver_counts", "mpmhip_migration_scan", "mpmhip_export_leavers",
+            "mpmhip_substep_begin", "mpmhip_substep_end", "mpmhip_substep_interior", "mpmhip_set_overlap", "mpmhip_tiled_run", "mpmhip_leaver_counts", "mpmhip_migration_scan", "mpmhip_export_leavers",
             "mpmhip_import_particles", "mpmhip_active_bounds", "mpmhip_num_slots", "mpmhip_request_compaction", "mpmhip_reserve", "mpmhip_capacity", "mpmhip_mpm88_create", "mpmhip_mpm88_destroy", "mpmhip_mpm88_last_error", "mpmhip_mpm88_add",
             "mpmhip_mpm88_num_particles", "mpmhip_mpm88_advance", "mpmhip_mpm88_download", "mpmhip_mpm88_download_grid",
             "mpmhip_async_enable", "mpmhip_async_begin", "mpmhip_async_pool_particles", "mpmhip_async_step", "mpmhip_async_load_pools", "mpmhip_async_state", "mpmhip_async_current_time", "mpmhip_async_block_times", "mpmhip_async_download_pools", "mpmhip_async_profile", "mpmhip_host_particle_bytes", "mpmhip_async_update_dt_limits", "mpmhip_async_blocks", "mpmhip_async_set_time_int", "mpmhip_async_table", "mpmhip_clear_particles", "mpmhip_set_dt", "mpmhip_set_time", "mpmhip_get_clock", "mpmhip_set_clock", "mpmhip_debug_allowed_dt",
@@ -211,6 +212,8 @@ def load():
     L.mpmhip_import_particles.argtypes = [vp, C.c_int64, vp]
     L.mpmhip_active_bounds.argtypes = [vp, ip, ip]
     L.mpmhip_set_overlap.argtypes = [vp, C.c_int32]
+    L.mpmhip_tiled_run.argtypes = [vp, C.c_int64, C.c_int64, EXCHANGE_FN, vp]
+    L.mpmhip_tiled_run.restype = C.c_int64
     L.mpmhip_num_slots.argtypes = [vp]
     L.mpmhip_num_slots.restype = C.c_int64
     L.mpmhip_reserve.argtypes = [vp, C.c_int64]

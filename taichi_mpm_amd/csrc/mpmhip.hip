@@ -1241,6 +1241,27 @@ int mpmhip_set_overlap(mpmhip_ctx *c, int32_t enabled) {
   return MPMHIP_OK;
 }
 
+int64_t mpmhip_tiled_run(mpmhip_ctx *c, int64_t n, int64_t until_migration, mpmhip_exchange_fn exchange, void *user) {
+  if (!c || n < 0) return MPMHIP_EINVAL;
+  if (c->T.n_boxes > 0 && !exchange) return fail(c, MPMHIP_EINVAL, "this ctx has halo boxes: tiled_run needs an exchange callback");
+  if (until_migration > 0 && until_migration < n) n = until_migration;
+  for (int64_t i = 0; i < n; i++) {
+    int rc = mpmhip_substep_begin(c);
+    if (rc) return rc;
+    if (c->T.n_boxes > 0) {
+      int32_t e = exchange(user, MPMHIP_EXCHANGE_START);
+      if (!e && (rc = mpmhip_substep_interior(c))) e = rc;
+      if (!e) e = exchange(user, MPMHIP_EXCHANGE_WAIT);
+      if (e) {
+        c->in_substep = false; c->cur_ev = nullptr;  // (the substep is abandoned: the ctx can be stepped or destroyed again)
+        return e < 0 ? e : fail(c, MPMHIP_EINVAL, "tiled_run: the exchange callback returned %d", (int)e);
+      }
+    }
+    if ((rc = mpmhip_substep_end(c))) return rc;
+  }
+  return n;
+}
+
 int mpmhip_substep(mpmhip_ctx *c) {
   if (!c) return MPMHIP_EINVAL;
   if (c->T.n_boxes > 0)

@@ -219,6 +219,25 @@ class HipEngine:
         """split substeps into boundary / interior work so that the halo exchange overlaps the interior part"""
         self.sim._check(self.L.mpmhip_set_overlap(self.ctx, int(bool(on))))
 
+    def run_native(self, n, start, wait):
+        """n substeps with the loop in the library (mpmhip_tiled_run): begin / interior / end never return to Python, only
+        the transport does — start() launches the exchange of the halo boxes, wait() makes the ctx's stream wait for it.
+        Exceptions of the callbacks are re-raised here."""
+        err = []
+
+        def cb(_user, phase):
+            try:
+                (start if phase == 0 else wait)()
+                return 0
+            except BaseException as e:  # noqa: BLE001 — must not unwind through the C frames
+                err.append(e)
+                return 1
+        fn = _lib.EXCHANGE_FN(cb)
+        rc = self.L.mpmhip_tiled_run(self.ctx, int(n), 0, fn, None)
+        if err:
+            raise err[0]
+        return self.sim._check(rc)
+
     def migration_scan(self):
         """(leavers per destination rank, base-cell bounds lo, hi, fastest particle in cells per substep) — one pass,
         one synchronisation"""
@@ -437,8 +456,43 @@ class TiledJob:
     substeps = 0  # substeps run so far (bench.py reports it)
 
     def run(self, n):
-        for _ in range(n):
-            self.substep()
+        """n substeps.  With the HIP engine the loop between two migrations runs inside the library (mpmhip_tiled_run) and only
+        the exchange calls back; other engines (the CPU checker of the gloo tests) take the Python loop."""
+        left = n
+        while left > 0:
+            r, p = self.r, self.r.plan
+            m = min(left, max(int(r.next_migration - r.k), 1))
+            if hasattr(self.e, "run_native") and not getattr(self, "_python_loop", False):
+                hold = {}
+
+                def start():
+                    if not p.total:
+                        return
+                    if self.overlap:
+                        try:
+                            hold["w"] = self.comm.all_to_all_async(p.recv, p.send, p.splits, p.splits)
+                            return
+                        except Exception as exc:  # a transport without async collectives: the serial exchange from here on
+                            import sys
+                            print("tiled: async exchange unavailable (%r); continuing without overlap" % (exc,), file=sys.stderr)
+                            self.overlap, self._unsplit_after = False, True  # (the substep in flight stays split)
+                    self.comm.all_to_all(p.recv, p.send, p.splits, p.splits)
+
+                def wait():
+                    w = hold.pop("w", None)
+                    if w is not None:
+                        w.wait()
+                self.e.run_native(m, start, wait)
+                if getattr(self, "_unsplit_after", False):
+                    self._unsplit_after = False
+                    self.e.set_overlap(False)
+                r.k += m
+                if r.k >= r.next_migration:
+                    self.migrate()
+            else:
+                for _ in range(m):
+                    self.substep()
+            left -= m
         self.substeps += n
 
     def num_particles(self):
