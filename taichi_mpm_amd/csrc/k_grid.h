@@ -54,17 +54,21 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
       }
     }
     const uint32_t amask = (uint32_t)__ballot(nslot != INVALID);
-#pragma unroll
-    for (int o = 0; o < 8; o++) {
-      if (PER_CAND && o != o_mine) continue;  // wave-uniform (the loop stays unrolled: compile-time masks)
+    // One candidate: with a compile-time `o` (the unrolled loop below) all masks and neighbour indices are constants; with a
+    // run-time `o` (PER_CAND: this wave's one candidate) the body exists ONCE — the eight-fold unrolled kernel is 13 000
+    // instructions = 100 KB, more than the instruction cache holds, and a wave that handles a single candidate streams through
+    // all of it (small problems: 28 -> 21 us at 1 M particles; at 8 M, where a wave walks all eight, the unrolled form wins:
+    // 35 against 49 us — profiles/r03_q_ab_grid.txt).
+    auto candidate = [&](const int o) __attribute__((always_inline)) {
       const int ox = o >> 2, oy = (o >> 1) & 1, oz = o & 1;
       // sources of c = b + o are c - q = b + (o - q), q in {0,1}^3; owner <=> none of them active for q < o
       uint32_t lower = 0;
 #pragma unroll
-      for (int q = 0; q < o; q++) lower |= 1u << nb27(ox - (q >> 2), oy - ((q >> 1) & 1), oz - (q & 1));
-      if (amask & lower) continue;  // wave-uniform
+      for (int q = 0; q < 8; q++)
+        if (q < o) lower |= 1u << nb27(ox - (q >> 2), oy - ((q >> 1) & 1), oz - (q & 1));
+      if (amask & lower) return;  // wave-uniform
       const int cx = bx + ox, cy = by + oy, cz = bz + oz;
-      if (!in_phase(T, phase, cx * BS, cy * BS, cz * BS, BS)) continue;  // wave-uniform
+      if (!in_phase(T, phase, cx * BS, cy * BS, cz * BS, BS)) return;  // wave-uniform
       const uint32_t slot = a * 8u + (uint32_t)o;
       const int gi = cx * BS + lx, gj = cy * BS + ly, gk = cz * BS + lz;
       const bool in_grid = gi <= P.res[0] && gj <= P.res[1] && gk <= P.res[2];
@@ -72,11 +76,11 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
       if (MODE == 2) {
         gridv[(size_t)slot * BC + l] = in_grid ? dense[dense_idx] : make_float4(0, 0, 0, 0);
         if (l == 0) fat_slot[morton3(cx, cy, cz)] = slot;
-        continue;
+        return;
       }
       if (MODE == 3) {
         if (in_grid) dense[dense_idx] = gridv[(size_t)slot * BC + l];
-        continue;
+        return;
       }
       float4 acc = make_float4(0, 0, 0, 0);
 #pragma unroll
@@ -127,14 +131,14 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
       }
       if (MODE == 1) {
         if (in_grid) dense[dense_idx] = acc;
-        continue;
+        return;
       }
       if (MODE == 4) {  // grid kinetic energy sum 1/2 m |v|^2 with v = (m v)/m (calculate_energy, src/mpm.cpp:1078-1096)
         double e = (acc.w != 0.0f) ? 0.5 * ((double)acc.x * acc.x + (double)acc.y * acc.y + (double)acc.z * acc.z) / acc.w : 0.0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
         if (l == 0) atomicAdd(reinterpret_cast<double *>(dense), e);
-        continue;
+        return;
       }
       float v[3] = {acc.x, acc.y, acc.z};
       const float m = acc.w;
@@ -155,6 +159,12 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
       }
       gridv[(size_t)slot * BC + l] = make_float4(v[0], v[1], v[2], m);
       if (l == 0) fat_slot[morton3(cx, cy, cz)] = slot;
+    };
+    if constexpr (PER_CAND) {
+      candidate(o_mine);
+    } else {
+#pragma unroll
+      for (int o = 0; o < 8; o++) candidate(o);
     }
   }
 }
