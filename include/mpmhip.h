@@ -356,6 +356,12 @@ int64_t mpmhip_async_download_pools(mpmhip_ctx *ctx, int64_t capacity, float *ro
 /* host wall time spent so far, ms: {update_dt_limits, of which the neighbour lists, advance, of which the substep (meaningful
  * with sync != 0: the stream is then synchronised behind every substep), store compaction, number of advances} */
 int mpmhip_async_profile(mpmhip_ctx *ctx, int32_t sync, double out[6]);
+/* snapshots of the asynchronous stepper (the reference serialises every pool and the block table, src/async/async_mpm.h:120-172):
+ * groups, block table, clocks and every live container of the store.  Loaded into a ctx of the same grid on which
+ * mpmhip_async_begin has run with the same unit_delta_t; level set and configuration come from the scene again. */
+int64_t mpmhip_async_snapshot_size(mpmhip_ctx *ctx);
+int mpmhip_async_snapshot_save(mpmhip_ctx *ctx, void *dst, size_t capacity);
+int mpmhip_async_snapshot_load(mpmhip_ctx *ctx, const void *src, size_t size);
 /* bytes of particle data copied between host and device by this ctx so far (add_particles, download, upload, snapshots,
  * download_pools): a stepping call must leave it unchanged */
 int64_t mpmhip_host_particle_bytes(const mpmhip_ctx *ctx);

@@ -141,7 +141,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_las
             "mpmhip_substep_begin", "mpmhip_substep_end", "mpmhip_substep_interior", "mpmhip_set_overlap", "mpmhip_tiled_run", "mpmhip_leaver_counts", "mpmhip_migration_scan", "mpmhip_export_leavers",
             "mpmhip_import_particles", "mpmhip_active_bounds", "mpmhip_num_slots", "mpmhip_request_compaction", "mpmhip_reserve", "mpmhip_capacity", "mpmhip_mpm88_create", "mpmhip_mpm88_destroy", "mpmhip_mpm88_last_error", "mpmhip_mpm88_add",
             "mpmhip_mpm88_num_particles", "mpmhip_mpm88_advance", "mpmhip_mpm88_download", "mpmhip_mpm88_download_grid",
-            "mpmhip_async_enable", "mpmhip_async_begin", "mpmhip_async_pool_particles", "mpmhip_async_step", "mpmhip_async_load_pools", "mpmhip_async_state", "mpmhip_async_current_time", "mpmhip_async_block_times", "mpmhip_async_download_pools", "mpmhip_async_profile", "mpmhip_host_particle_bytes", "mpmhip_async_update_dt_limits", "mpmhip_async_blocks", "mpmhip_async_set_time_int", "mpmhip_async_table", "mpmhip_clear_particles", "mpmhip_set_dt", "mpmhip_set_time", "mpmhip_get_clock", "mpmhip_set_clock", "mpmhip_debug_allowed_dt",
+            "mpmhip_async_enable", "mpmhip_async_begin", "mpmhip_async_pool_particles", "mpmhip_async_step", "mpmhip_async_load_pools", "mpmhip_async_state", "mpmhip_async_current_time", "mpmhip_async_block_times", "mpmhip_async_download_pools", "mpmhip_async_profile", "mpmhip_async_snapshot_size", "mpmhip_async_snapshot_save", "mpmhip_async_snapshot_load", "mpmhip_host_particle_bytes", "mpmhip_async_update_dt_limits", "mpmhip_async_blocks", "mpmhip_async_set_time_int", "mpmhip_async_table", "mpmhip_clear_particles", "mpmhip_set_dt", "mpmhip_set_time", "mpmhip_get_clock", "mpmhip_set_clock", "mpmhip_debug_allowed_dt",
             "mpmhip2d_create", "mpmhip2d_destroy", "mpmhip2d_last_error", "mpmhip2d_set_levelset", "mpmhip2d_add_group", "mpmhip2d_add_particles",
             "mpmhip2d_substep", "mpmhip2d_step", "mpmhip2d_current_time", "mpmhip2d_num_particles", "mpmhip2d_download", "mpmhip2d_download_grid",
             "mpmhip2d_set_rigid_coupling", "mpmhip2d_add_articulation", "mpmhip2d_set_articulation_iterations", "mpmhip2d_add_rigid_body", "mpmhip2d_rigid_get_state", "mpmhip2d_rigid_get_samples", "mpmhip2d_cdf_phase",
@@ -258,6 +258,10 @@ def load():
     L.mpmhip_async_download_pools.argtypes = [vp, C.c_int64, fp, ip]
     L.mpmhip_async_download_pools.restype = C.c_int64
     L.mpmhip_async_profile.argtypes = [vp, C.c_int32, P(C.c_double)]
+    L.mpmhip_async_snapshot_size.argtypes = [vp]
+    L.mpmhip_async_snapshot_size.restype = C.c_int64
+    L.mpmhip_async_snapshot_save.argtypes = [vp, vp, C.c_size_t]
+    L.mpmhip_async_snapshot_load.argtypes = [vp, vp, C.c_size_t]
     L.mpmhip_host_particle_bytes.argtypes = [vp]
     L.mpmhip_host_particle_bytes.restype = C.c_int64
     L.mpmhip_async_blocks.argtypes = [vp, C.c_int64, ip, lp, lp, lp, lp, lp]

@@ -168,7 +168,25 @@ class AsyncSimulation3D(Simulation3D):
         return super().calculate_energy()
 
     def save_snapshot(self, path):
-        raise MPMError("snapshots of an asynchronous simulation are not implemented (the reference serialises every pool, "
-                       "src/async/async_mpm.h:120-172)")
+        """every pool and backup container, the block table and the clocks (include/mpmhip.h: mpmhip_async_snapshot_save; the
+        reference serialises the same: src/async/async_mpm.h:120-172)"""
+        self._ensure_ctx()
+        n = int(self._check(self._L.mpmhip_async_snapshot_size(self._ctx)))
+        buf = np.empty(n, np.uint8)
+        self._check(self._L.mpmhip_async_snapshot_save(self._ctx, buf.ctypes.data_as(C.c_void_p), n))
+        with open(path, "wb") as f:
+            f.write(np.array([self.frame], np.int64).tobytes())
+            f.write(buf.tobytes())
 
-    load_snapshot = save_snapshot
+    def load_snapshot(self, path):
+        """into a simulation initialised with the same grid and unit_delta_t; replaces all particles and groups"""
+        raw = np.fromfile(path, np.uint8)
+        self.frame = int(raw[:8].view(np.int64)[0])
+        blob = np.ascontiguousarray(raw[8:])
+        n_groups = int(blob[12:16].view(np.uint32)[0])
+        self._ensure_ctx()
+        self._check(self._L.mpmhip_async_snapshot_load(self._ctx, blob.ctypes.data_as(C.c_void_p), len(blob)))
+        off = 8 + 4 + 4 + 24 + 8 + 7 * 8 + 8 + 8  # sizeof(SnapAsync)
+        rows = blob[off:off + 80 * n_groups].view(np.float32).reshape(n_groups, 20)
+        self._groups = [(int(r[16:17].view(np.int32)[0]), r[:16].copy()) for r in rows]
+        self._n_added = max(self._n_added, self.get_num_pool_particles())

@@ -65,6 +65,7 @@ struct AsTimer {  // wall time of a host-side section, accumulated into c->async
 };
 static int as_grid(uint32_t n) { return (int)std::min<uint32_t>(std::max<uint32_t>((n + 255) / 256, 1), 4096); }
 
+static int async_compact(mpmhip_ctx *c);
 // (called right behind a read-back: S.size and S.live are exact)
 static int async_compact_if_needed(mpmhip_ctx *c, uint32_t incoming) {
   auto &S = c->async.store;
@@ -72,6 +73,11 @@ static int async_compact_if_needed(mpmhip_ctx *c, uint32_t incoming) {
   // squeeze when the freed containers outnumber the live ones (the passes over the tags then cost twice what they must), or
   // when that avoids growing the store
   if (!(dead > S.live + 65536 || (S.size + incoming > S.cap && dead > S.size / 4))) return MPMHIP_OK;
+  return async_compact(c);
+}
+static int async_compact(mpmhip_ctx *c) {
+  auto &S = c->async.store;
+  if (S.size == 0) return MPMHIP_OK;
   AsTimer whole(c->async.prof_ms[4]);
   if (!S.g2) {
     hipError_t e = hipSuccess;
@@ -484,4 +490,117 @@ int mpmhip_async_load_pools(mpmhip_ctx *c) {
     A.limits_valid = true;
   }
   return MPMHIP_OK;
+}
+
+// ---- snapshots of the asynchronous stepper (the reference serialises every pool and the block table: TC_IO of
+// particle_pool_tmp / backup_pool_tmp / blocks, src/async/async_mpm.h:120-172).  Blob: header, group table, the per-block
+// integers, the store's live containers (compacted).  Loaded into a ctx of the same grid on which mpmhip_async_begin has run
+// with the same unit_delta_t; level set and configuration come from the scene, as for the synchronous snapshots.
+struct SnapAsync {
+  char magic[8];  // "MPMASYNC"
+  uint32_t abi, n_groups;
+  int32_t res[3], nb[3];
+  float dx, unit_delta_t;
+  int64_t nblk, containers, current_t_int, min_delta_t_int, max_delta_t_int, update_counter, step_counter;
+  int32_t next_pid, pad;
+  float request_t, current_t;
+};
+static size_t async_snapshot_bytes(const mpmhip_ctx *c, size_t containers) {
+  return sizeof(SnapAsync) + sizeof(GroupParams) * c->groups.size() + sizeof(int64_t) * 6 * c->async.continuous.size() +
+         containers * (sizeof(uint32_t) + sizeof(int32_t) + 2 * 4 * sizeof(float4));
+}
+static int async_force_compaction(mpmhip_ctx *c) {  // the store holds exactly its live containers afterwards
+  if (int rc = async_settle(c)) return rc;
+  return async_compact(c);
+}
+int64_t mpmhip_async_snapshot_size(mpmhip_ctx *c) {
+  if (!c || !c->async.resident) return MPMHIP_EINVAL;
+  if (hipSetDevice(c->device) != hipSuccess) return MPMHIP_EHIP;
+  if (int rc = mpmhip_async_pool_particles(c)) return rc;
+  if (int rc = async_force_compaction(c)) return rc;
+  return (int64_t)async_snapshot_bytes(c, c->async.store.size);
+}
+int mpmhip_async_snapshot_save(mpmhip_ctx *c, void *dst, size_t cap) {
+  if (!c || !dst) return MPMHIP_EINVAL;
+  auto &A = c->async;
+  auto &S = A.store;
+  if (!A.resident) return fail(c, MPMHIP_EINVAL, "mpmhip_async_begin first");
+  const int64_t need = mpmhip_async_snapshot_size(c);
+  if (need < 0) return (int)need;
+  if (cap < (size_t)need) return fail(c, MPMHIP_ECAPACITY, "snapshot buffer too small: %zu < %lld", cap, (long long)need);
+  SnapAsync h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, "MPMASYNC", 8);
+  h.abi = MPMHIP_ABI_VERSION; h.n_groups = (uint32_t)c->groups.size();
+  for (int k = 0; k < 3; k++) { h.res[k] = c->P.res[k]; h.nb[k] = A.nb[k]; }
+  h.dx = c->P.dx; h.unit_delta_t = A.cfg.unit_delta_t;
+  h.nblk = (int64_t)A.continuous.size(); h.containers = S.size;
+  h.current_t_int = A.current_t_int; h.min_delta_t_int = A.min_delta_t_int; h.max_delta_t_int = A.max_delta_t_int;
+  h.update_counter = A.update_counter; h.step_counter = A.step_counter; h.next_pid = c->next_pid;
+  h.request_t = A.request_t; h.current_t = A.current_t;
+  char *p = (char *)dst;
+  memcpy(p, &h, sizeof h); p += sizeof h;
+  memcpy(p, c->groups.data(), sizeof(GroupParams) * c->groups.size()); p += sizeof(GroupParams) * c->groups.size();
+  const size_t nb = sizeof(int64_t) * (size_t)h.nblk;
+  for (const std::vector<int64_t> *v : {&A.continuous, &A.strength, &A.cfl, &A.particle_t, &A.backup_t, &A.local_min}) { memcpy(p, v->data(), nb); p += nb; }
+  const size_t n = S.size;
+  if (n) {
+    HIPCHK(c, hipMemcpy(p, S.tag, sizeof(uint32_t) * n, hipMemcpyDeviceToHost)); p += sizeof(uint32_t) * n;
+    HIPCHK(c, hipMemcpy(p, S.id, sizeof(int32_t) * n, hipMemcpyDeviceToHost)); p += sizeof(int32_t) * n;
+    HIPCHK(c, hipMemcpy(p, S.g, sizeof(float4) * 4 * n, hipMemcpyDeviceToHost)); p += sizeof(float4) * 4 * n;
+    HIPCHK(c, hipMemcpy(p, S.w, sizeof(float4) * 4 * n, hipMemcpyDeviceToHost));
+    c->host_particle_bytes += (int64_t)n * 136;
+  }
+  return MPMHIP_OK;
+}
+int mpmhip_async_snapshot_load(mpmhip_ctx *c, const void *src, size_t size) {
+  if (!c || !src || size < sizeof(SnapAsync)) return MPMHIP_EINVAL;
+  auto &A = c->async;
+  auto &S = A.store;
+  if (!A.resident) return fail(c, MPMHIP_EINVAL, "mpmhip_async_begin first");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  SnapAsync h;
+  memcpy(&h, src, sizeof h);
+  if (memcmp(h.magic, "MPMASYNC", 8) != 0 || h.abi != MPMHIP_ABI_VERSION) return fail(c, MPMHIP_EINVAL, "not an asynchronous-stepper snapshot of this ABI version");
+  for (int k = 0; k < 3; k++)
+    if (h.res[k] != c->P.res[k] || h.nb[k] != A.nb[k]) return fail(c, MPMHIP_EINVAL, "snapshot is of a %dx%dx%d grid", h.res[0], h.res[1], h.res[2]);
+  if (h.dx != c->P.dx || h.unit_delta_t != A.cfg.unit_delta_t) return fail(c, MPMHIP_EINVAL, "snapshot has delta_x = %g, unit_delta_t = %g", h.dx, h.unit_delta_t);
+  if ((int)h.n_groups > c->groups_cap || h.nblk != (int64_t)A.continuous.size() || h.containers < 0) return fail(c, MPMHIP_EINVAL, "snapshot header inconsistent with this ctx");
+  c->groups.resize(h.n_groups);
+  if (size != async_snapshot_bytes(c, (size_t)h.containers)) return fail(c, MPMHIP_EINVAL, "snapshot size mismatch");
+  const char *p = (const char *)src + sizeof h;
+  memcpy(c->groups.data(), p, sizeof(GroupParams) * h.n_groups); p += sizeof(GroupParams) * h.n_groups;
+  for (const GroupParams &g : c->groups)
+    if (g.type < MPMHIP_VISCO || g.type > MPMHIP_ELASTIC) return fail(c, MPMHIP_EINVAL, "snapshot holds an unknown material id %d", g.type);
+  if (h.n_groups) HIPCHK(c, hipMemcpy(c->d_groups, c->groups.data(), sizeof(GroupParams) * h.n_groups, hipMemcpyHostToDevice));
+  const size_t nb = sizeof(int64_t) * (size_t)h.nblk;
+  for (std::vector<int64_t> *v : {&A.continuous, &A.strength, &A.cfl, &A.particle_t, &A.backup_t, &A.local_min}) { memcpy(v->data(), p, nb); p += nb; }
+  const size_t n = (size_t)h.containers;
+  S.size = S.size_ub = S.live = 0;
+  if (int rc = async_store_reserve(c, (uint32_t)n + 1024)) return rc;
+  HIPCHK(c, hipMemset(S.tag, 0xFF, sizeof(uint32_t) * (size_t)S.cap));
+  if (n) {
+    HIPCHK(c, hipMemcpy(S.tag, p, sizeof(uint32_t) * n, hipMemcpyHostToDevice)); p += sizeof(uint32_t) * n;
+    HIPCHK(c, hipMemcpy(S.id, p, sizeof(int32_t) * n, hipMemcpyHostToDevice)); p += sizeof(int32_t) * n;
+    HIPCHK(c, hipMemcpy(S.g, p, sizeof(float4) * 4 * n, hipMemcpyHostToDevice)); p += sizeof(float4) * 4 * n;
+    HIPCHK(c, hipMemcpy(S.w, p, sizeof(float4) * 4 * n, hipMemcpyHostToDevice));
+    c->host_particle_bytes += (int64_t)n * 136;
+  }
+  S.size = S.size_ub = S.live = (uint32_t)n;
+  AsyncCounters z;
+  memset(&z, 0, sizeof z);
+  z.size = (uint32_t)n;
+  HIPCHK(c, hipMemcpy(S.d_cnt, &z, sizeof z, hipMemcpyHostToDevice));
+  A.pending_counters = false; A.records_are_view = false;
+  A.current_t_int = h.current_t_int; A.min_delta_t_int = h.min_delta_t_int; A.max_delta_t_int = h.max_delta_t_int;
+  A.update_counter = h.update_counter; A.step_counter = h.step_counter;
+  A.request_t = h.request_t; A.current_t = h.current_t;
+  A.limits_version++;  // (the neighbour lists are rebuilt from the loaded limits at the next update)
+  c->next_pid = h.next_pid;
+  c->n_slots = 0; c->P.n_slots = 0;
+  c->t = A.current_t;
+  c->affine_valid = false; c->b_stale = false;
+  c->keys_valid = true;
+  return invalidate_keys(c);
 }

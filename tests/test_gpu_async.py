@@ -217,3 +217,35 @@ def test_a_million_particles_in_two_stiffnesses_match_the_live_reference_async_s
     assert np.abs(a["x"] - b["x"]).max() <= 1e-6
     assert rel_l2(a["v"], b["v"]) <= 5e-4 and rel_l2(a["F"], b["F"]) <= 1e-4
     sim.close(); r.close()
+
+
+def test_async_snapshot_restart_continues_the_run(tm, tmp_path):
+    """every pool and backup container, the block table and the clocks travel in the snapshot (the reference serialises the
+    same, src/async/async_mpm.h:120-172): a fresh simulation that loads it continues like the one that wrote it (up to the
+    summation order inside a cell: working sets are gathered in order of arrival)"""
+    res, dx, sa, sb = _two_stiffness_scene()
+    kw = dict(unit_delta_t=2e-6, max_units=1024)
+
+    def scene(add):
+        sim = tm.create_simulation3("async_mpm").initialize(dict(res=(res,) * 3, delta_x=dx, **kw))
+        sim.set_levelset(tm.mpm.LevelSet(friction=0.4).add_plane((0, 1, 0), d=-0.2))
+        if add:
+            for s, mat in ((sa, "elastic"), (sb, "sand")):
+                sim.add_particles(dict(type=mat, positions=s.x, velocities=s.v, F=s.F, B=s.B, aux=s.aux, params=s.gparams[0]))
+        return sim
+    a = scene(True)
+    a.step(2.5e-3)
+    path = str(tmp_path / "async.snap")
+    a.save_snapshot(path)
+    a.step(2.5e-3)
+    b = scene(False)
+    b.load_snapshot(path)
+    assert b.current_t_int > 0 and b.get_num_pool_particles() >= len(sa.x) + len(sb.x)
+    b.step(2.5e-3)
+    assert a.current_t_int == b.current_t_int and a.update_counter == b.update_counter
+    pa, pb = a.get_pool_particles(), b.get_pool_particles()
+    assert np.array_equal(pa["id"], pb["id"]) and np.array_equal(pa["particle_t"], pb["particle_t"])
+    assert np.array_equal(pa["continuous"], pb["continuous"])
+    from tests.common import rel_l2
+    assert np.abs(pa["x"] - pb["x"]).max() <= 2e-6 and rel_l2(pa["v"], pb["v"]) <= 2e-4 and rel_l2(pa["F"], pb["F"]) <= 2e-5
+    a.close(); b.close()
