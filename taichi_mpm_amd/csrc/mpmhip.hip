@@ -927,7 +927,8 @@ static int do_sort(mpmhip_ctx *c) {
   // sort_allocator (src/mpm.cpp:752-768, every reorder_interval substeps :811-813): needed here only for records that
   // did not come out of k_g2p (fresh uploads, arrivals of a migration) — k_g2p itself leaves the records in sorted order
   // every substep, so a running simulation never pays for a separate reorder (nor for its host synchronisation)
-  if ((c->reorder_interval > 0 && !c->ordered) || c->compact_requested) {
+  // (not for the working sets of the resident asynchronous stepper: they live for ONE substep)
+  if ((c->reorder_interval > 0 && !c->ordered && !c->async.resident) || c->compact_requested) {
     c->compact_requested = false;
     return do_reorder(c);
   }
