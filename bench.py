@@ -348,6 +348,8 @@ def probe_rccl_in_child(rank, world, local_rank, timeout_s=75.0):
 
 
 def main():
+    # (multi-process GPU work on this pool needs dmabuf IPC: without it RCCL fails with hipIpcGetMemHandle: invalid argument)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if "--probe-rccl" in sys.argv:
         return rccl_probe_main()
     ap = argparse.ArgumentParser()
