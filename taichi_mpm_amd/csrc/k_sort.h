@@ -341,8 +341,7 @@ template <int CT_BLOCKS>  // blocks per chunk: 64 for large problems, 16 when th
 __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uint32_t *__restrict__ cell_cnt,
                                                     uint32_t *__restrict__ act_start,
                                                     uint32_t *__restrict__ cell_start,
-                                                    unsigned long long *__restrict__ slots, uint32_t epoch,
-                                                    uint32_t *__restrict__ chunk_blk) {
+                                                    unsigned long long *__restrict__ slots, uint32_t epoch) {
   __shared__ uint32_t lds[8];
   constexpr int CT_BPW = CT_BLOCKS / 4;  // blocks per wave
   __shared__ uint32_t blk_tot[CT_BLOCKS];
@@ -384,11 +383,6 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
     if (threadIdx.x == 0) publish(slots + chunk, epoch, total);
     if (threadIdx.x < CT_BLOCKS) blk_tot[threadIdx.x] = boff;
     const uint32_t chunk_base = sum_predecessors(slots, chunk, epoch, lds);  // its barriers also cover blk_tot
-    if (chunk_blk != nullptr && threadIdx.x < CT_BLOCKS && a0 + threadIdx.x < na) {
-      // which block holds sorted position 256 k, for the G2P that walks chunks of 256 positions across blocks (k_g2p_x.h)
-      const uint32_t s0 = chunk_base + boff, s1 = s0 + mine;
-      for (uint32_t k = (s0 + 255u) >> 8; (k << 8) < s1; k++) chunk_blk[k] = a0 + threadIdx.x;
-    }
 #pragma unroll
     for (int i = 0; i < CT_BPW; i++) {
       const uint32_t a = a0 + wave * CT_BPW + i;

@@ -83,7 +83,6 @@
 #include "k_grid.h"
 #include "k_tiling.h"
 #include "k_g2p.h"
-#include "k_g2p_x.h"
 #ifdef MPMHIP_WITH_FUSED
 #include "k_g2p2g.h"
 #else
@@ -121,9 +120,6 @@ struct mpmhip_ctx {
   uint32_t NB = 0;
   uint8_t *blk_flag = nullptr;
   uint32_t *bits = nullptr, *wprefix = nullptr, *act_blk = nullptr, *act_start = nullptr;
-  uint32_t *chunk_blk = nullptr;  // [n_slots / 256 + 2] active block holding sorted position 256 k (k_cell_table -> k_g2p_x)
-  int g2p_x_wgs = 768;
-  int g2p_x = 0;                  // G2P walks chunks across block boundaries (k_g2p_x.h); MPMHIP_G2P_X
   uint32_t *cell_cnt = nullptr, *cell_start = nullptr, *fat_slot = nullptr;
   unsigned long long *scan_slots = nullptr;  // [256] k_block_table + [ct_grid] k_cell_table: {epoch, chunk sum}
   uint32_t sort_epoch = 0, bt_slots = 0;
@@ -415,8 +411,6 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   c->device = cfg->device;
   if (const char *e = getenv("MPMHIP_G2P_MINW")) c->g2p_minw = atoi(e);
   if (const char *e = getenv("MPMHIP_G2P_WGS")) c->g2p_wgs = atoi(e) > 0 ? atoi(e) : 4096;
-  if (const char *e = getenv("MPMHIP_G2P_X")) c->g2p_x = atoi(e);
-  if (const char *e = getenv("MPMHIP_G2P_X_WGS")) c->g2p_x_wgs = atoi(e) > 0 ? atoi(e) : 768;
   if (const char *e = getenv("MPMHIP_G2P2G_WGS")) c->g2p2g_wgs = atoi(e) > 0 ? atoi(e) : 4096;
   if (const char *e = getenv("MPMHIP_P2G_SPLIT")) c->p2g_split = atoi(e);
   if (const char *e = getenv("MPMHIP_P2G_WGS")) c->p2g_wgs = atoi(e) > 0 ? atoi(e) : 16384;
@@ -486,7 +480,6 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(dmalloc(&c->fat_slot, (size_t)c->NB));
   A(dmalloc(&c->act_blk, (size_t)mb + 1));
   A(dmalloc(&c->act_start, (size_t)mb + 2));
-  A(dmalloc(&c->chunk_blk, (size_t)c->cap / 256 + 2));
   A(dmalloc(&c->cell_cnt, (size_t)mb * BC));
   A(dmalloc(&c->cell_start, (size_t)mb * BC + 1));
   c->bt_slots = (P.nbw + 255) / 256;
@@ -537,7 +530,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
     for (int k = 0; k <= PH_COUNT; k++) hipEventDestroy(ev.e[k]);
   hipFree(c->rg); hipFree(c->rp); hipFree(c->rb); hipFree(c->rg2); hipFree(c->rp2); hipFree(c->rb2);
   hipFree(c->key); hipFree(c->rank); hipFree(c->perm); hipFree(c->blk_flag); hipFree(c->bits); hipFree(c->wprefix);
-  hipFree(c->fat_slot); hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->chunk_blk); hipFree(c->cell_cnt);
+  hipFree(c->fat_slot); hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->cell_cnt);
   hipFree(c->cell_start); hipFree(c->scan_slots); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
   hipFree(c->async.d_tab); hipFree(c->async.d_blk_of); hipFree(c->async.d_blk_limits); hipFree(c->async.d_particle_limits);
   if (c->async.h_tab) hipHostFree(c->async.h_tab);
@@ -925,8 +918,7 @@ static int do_sort(mpmhip_ctx *c) {
   hipLaunchKernelGGL(k_rank, dim3(std::max(rank_wgs, 1u)), dim3(256), 0, st, P, c->key, c->rank, c->cell_cnt, c->bits, c->wprefix,
                      c->cnt);
   hipLaunchKernelGGL(small ? k_cell_table<16> : k_cell_table<64>, dim3(std::min(ct_chunks, c->scan_grid)), dim3(256), 0, st, P,
-                     c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots, epoch,
-                     c->g2p_x ? c->chunk_blk : (uint32_t *)nullptr);
+                     c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots, epoch);
   hipLaunchKernelGGL(k_perm, dim3(pg), dim3(256), 0, st, P, (const Counters *)c->cnt, c->key, c->rank, c->cell_start, c->perm);
   c->sorted = true;
   c->keys_valid = false;  // key[] now holds k_rank's packed (rank, cell index) words
@@ -1073,19 +1065,6 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0, bool fused = false) {
                        c->blk_flag, (const LevelSetDev *)c->d_LS, phase_box(c->T), phase, c->tiles8, write_p);
   } else
 #endif
-  if (c->g2p_x && phase == 0 && !rigid) {
-    auto xk = sb ? (no_visco ? k_g2p_x<MPM_G2P_MINW, true, NO_VISCO> : k_g2p_x<2, true, MAT_ALL>)
-                 : (no_visco ? k_g2p_x<MPM_G2P_MINW, false, NO_VISCO> : k_g2p_x<2, false, MAT_ALL>);
-    if (!sb) switch (mask) {
-#define MPM_ONE_MATERIAL(t) case 1u << (t): xk = k_g2p_x<MPM_G2P_MINW, false, 1u << (t)>; break;
-      MPM_ONE_MATERIAL(MPMHIP_JELLY) MPM_ONE_MATERIAL(MPMHIP_SAND)
-#undef MPM_ONE_MATERIAL
-      default: break;
-    }
-    hipLaunchKernelGGL(xk, dim3(c->g2p_x_wgs), dim3(256), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
-                       (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->chunk_blk, c->perm, c->d_groups, c->gridv, c->fat_slot,
-                       c->cnt, c->key, c->blk_flag, (const LevelSetDev *)c->d_LS);
-  } else
   hipLaunchKernelGGL(kern, dim3(c->g2p_wgs), dim3(nt), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
                      (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
                      c->blk_flag, (const LevelSetDev *)c->d_LS, phase_box(c->T), phase);
@@ -1917,7 +1896,6 @@ int mpmhip_reserve(mpmhip_ctx *c, int64_t max_particles) {
   A(regrow(&c->rg, n, cap, false)); A(regrow(&c->rp, n, cap, false)); A(regrow(&c->rb, n * BW, cap * BW, true));
   A(regrow(&c->rg2, 0, cap, false)); A(regrow(&c->rp2, 0, cap, false)); A(regrow(&c->rb2, 0, cap * BW, false));
   A(regrow(&c->key, 0, cap, false)); A(regrow(&c->rank, 0, cap, false)); A(regrow(&c->perm, 0, cap, false));
-  A(regrow(&c->chunk_blk, 0, cap / 256 + 2, false));
   if (c->rigid.d_bnd) A(regrow(&c->rigid.d_bnd, n, cap, true));
   if (c->async.d_blk_of) {  // (re-allocated at the size of the ctx by the next update_dt_limits)
     (void)hipFree(c->async.d_blk_of); (void)hipFree(c->async.d_particle_limits);
