@@ -213,7 +213,9 @@ int mpmhip_write_bgeo(mpmhip_ctx *ctx, const char *path, int32_t verbose);
 /* profiling — replaces TC_PROFILE / TC_PROFILE_TPE scoped timers (src/mpm.cpp:464-572).
  * level 0: off.  level 1: hipEvents bracket each phase of every substep on the ctx stream (six records per
  * substep; each record costs ~5 us of idle GPU).  level 2 / 3: only k_g2p / only k_p2g is bracketed (two records),
- * for timing the dominant kernel inside a throughput measurement.
+ * for timing the dominant kernel inside a throughput measurement.  level 4: the three parts of a tiled substep are
+ * bracketed — substep_begin (sort, boundary P2G, halo pack) -> "p2g", substep_interior -> "grid", substep_end -> "g2p" —
+ * with no record INSIDE a part: what one rank computes per substep when nothing is being profiled.
  * mpmhip_profile writes a JSON object: {"substeps":N,"particles":n,"active_blocks":a,"rank_mode":m,
  *   "phases":{"sort":ms,"p2g":ms,"exchange":ms,"grid":ms,"g2p":ms}}  (totals since the last reset; rank_mode = the
  *   in-cell ranking path the next sort will take: 0 per-run atomics, 1 per-batch LDS hash; "exchange" is

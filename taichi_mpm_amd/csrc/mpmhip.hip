@@ -144,7 +144,8 @@ struct mpmhip_ctx {
   float t = 0.0f, request_t = 0.0f;  // `real` accumulators, as in the reference (src/mpm.h:99, mpm.cpp:573)
   int64_t substeps = 0;
   // profiling
-  int profiling = 0;  // 0 off, 1 every phase, 2 only G2P, 3 only P2G (two events per substep instead of six)
+  int profiling = 0;  // 0 off, 1 every phase, 2 only G2P, 3 only P2G (two events per substep instead of six),
+                      // 4 the parts of a tiled substep: begin / interior / end, nothing recorded INSIDE a part
   struct Ev { hipEvent_t e[PH_COUNT + 1]; bool ov; };  // ov: the substep ran split (boundary / interior)
   std::vector<Ev> ev_pool;
   size_t ev_used = 0;
@@ -1136,6 +1137,19 @@ static int collect_events(mpmhip_ctx *c) {
   if (c->ev_used == 0) return MPMHIP_OK;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (size_t i = 0; i < c->ev_used; i++) {
+    if (c->ev_level == 4) {  // begin part -> "p2g", interior part (split substeps) -> "grid", end part -> "g2p"
+      float ms = 0;
+      HIPCHK(c, hipEventElapsedTime(&ms, c->ev_pool[i].e[0], c->ev_pool[i].e[1]));
+      c->phase_ms[PH_P2G] += ms;
+      if (c->ev_pool[i].ov) {
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev_pool[i].e[2], c->ev_pool[i].e[3]));
+        c->phase_ms[PH_GRID] += ms;
+      }
+      HIPCHK(c, hipEventElapsedTime(&ms, c->ev_pool[i].e[4], c->ev_pool[i].e[5]));
+      c->phase_ms[PH_G2P] += ms;
+      c->prof_substeps++;
+      continue;
+    }
     if (c->ev_pool[i].ov && c->ev_level >= 2) {  // split substep: the interior launch was bracketed separately
       float ms = 0;
       const int a = c->ev_level == 2 ? 0 : 3;
@@ -1180,7 +1194,7 @@ int mpmhip_substep_begin(mpmhip_ctx *c) {
     if (c->ev_used >= 4096 && (rc = collect_events(c))) return rc;
     if ((rc = get_events(c, &ev))) return rc;
     ev->ov = c->ov_active;
-    if (lvl == 1) HIPCHK(c, hipEventRecord(ev->e[0], c->stream));
+    if (lvl == 1 || lvl == 4) HIPCHK(c, hipEventRecord(ev->e[0], c->stream));
   }
   if ((rc = do_sort(c))) return rc;
   if (rigid_active(c) && (rc = do_rigid_pre(c))) return rc;  // rasterize_rigid_boundary, gather_cdf (src/mpm.cpp:466-472,506-508)
@@ -1189,6 +1203,7 @@ int mpmhip_substep_begin(mpmhip_ctx *c) {
   if (ev && lvl == 3) HIPCHK(c, hipEventRecord(ev->e[2], c->stream));
   if ((rc = do_halo_pack(c))) return rc;
   if (ev && lvl == 1) HIPCHK(c, hipEventRecord(ev->e[2], c->stream));
+  if (ev && lvl == 4) HIPCHK(c, hipEventRecord(ev->e[1], c->stream));
   c->cur_ev = ev;
   c->in_substep = true;
   return MPMHIP_OK;
@@ -1203,12 +1218,14 @@ int mpmhip_substep_interior(mpmhip_ctx *c) {
   mpmhip_ctx::Ev *ev = c->cur_ev;
   const int lvl = c->profiling;
   if (ev && lvl == 3) HIPCHK(c, hipEventRecord(ev->e[3], c->stream));
+  if (ev && lvl == 4) HIPCHK(c, hipEventRecord(ev->e[2], c->stream));
   if ((rc = do_p2g(c, 2))) return rc;
   if (ev && lvl == 3) HIPCHK(c, hipEventRecord(ev->e[4], c->stream));
   if ((rc = do_grid(c, 0, 2))) return rc;
   if (ev && lvl == 2) HIPCHK(c, hipEventRecord(ev->e[0], c->stream));
   if ((rc = do_g2p(c, 2))) return rc;
   if (ev && lvl == 2) HIPCHK(c, hipEventRecord(ev->e[1], c->stream));
+  if (ev && lvl == 4) HIPCHK(c, hipEventRecord(ev->e[3], c->stream));
   c->interior_done = true;
   return MPMHIP_OK;
 }
@@ -1224,10 +1241,11 @@ int mpmhip_substep_end(mpmhip_ctx *c) {  // grid (+ halo sum), G2P
   c->in_substep = false;
   const int lvl = c->profiling, ph = c->ov_active ? 1 : 0;
   if (ev && lvl == 1) HIPCHK(c, hipEventRecord(ev->e[3], c->stream));
+  if (ev && lvl == 4) HIPCHK(c, hipEventRecord(ev->e[4], c->stream));
   if ((rc = c->tiles8_valid ? do_grid_fused(c) : do_grid(c, 0, ph))) return rc;
   if (ev && (lvl == 1 || lvl == 2)) HIPCHK(c, hipEventRecord(ev->e[4], c->stream));
   if ((rc = do_g2p(c, ph, fused_ok(c)))) return rc;
-  if (ev && (lvl == 1 || lvl == 2)) HIPCHK(c, hipEventRecord(ev->e[5], c->stream));
+  if (ev && (lvl == 1 || lvl == 2 || lvl == 4)) HIPCHK(c, hipEventRecord(ev->e[5], c->stream));
   swap_records(c);
   if (rigid_active(c) && (rc = do_rigid_advect(c, c->P.dt))) return rc;  // src/mpm.cpp:570-572
   c->t += c->P.dt;  // src/mpm.cpp:573
@@ -1662,7 +1680,7 @@ int mpmhip_calculate_energy(mpmhip_ctx *c, double *kinetic, double *potential) {
 }
 
 int mpmhip_set_profiling(mpmhip_ctx *c, int32_t level) {
-  if (!c || level < 0 || level > 3) return MPMHIP_EINVAL;
+  if (!c || level < 0 || level > 4) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   if (c->in_substep) return fail(c, MPMHIP_EINVAL, "set_profiling inside a substep");
   int rc = collect_events(c);  // pending events belong to the old level
