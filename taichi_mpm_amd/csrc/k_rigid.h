@@ -324,8 +324,11 @@ __device__ __forceinline__ bool rigid_page_of_block(const CdfDev &C, int bx, int
 // act_start anyway, a second array there would put one more load — and with its vmcnt wait the prefetched records — on
 // the iterator's critical path (measured: +20 % on k_g2p).  Only the RIGID variants of the G2P kernels see the bit.
 constexpr uint32_t ACT_RIGID_BIT = 0x80000000u;
+// `rigid_list[0 .. *n_rigid)` = those blocks, in no particular order (the host clears *n_rigid before the launch): the
+// colour-aware kernels walk the list, so every one of their workgroups has a block to work on.
 __global__ __launch_bounds__(256) void k_blk_rigid(Params P, const Counters *__restrict__ cnt, const uint32_t *__restrict__ act_blk,
-                                                   CdfDev C, uint8_t *__restrict__ blk_rigid, uint32_t *__restrict__ act_start) {
+                                                   CdfDev C, uint8_t *__restrict__ blk_rigid, uint32_t *__restrict__ act_start,
+                                                   uint32_t *__restrict__ rigid_list, uint32_t *__restrict__ n_rigid) {
   const uint32_t na = min(cnt->n_active, P.max_blocks);
   for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < na; a += gridDim.x * blockDim.x) {
     int bx, by, bz;
@@ -334,6 +337,7 @@ __global__ __launch_bounds__(256) void k_blk_rigid(Params P, const Counters *__r
     blk_rigid[a] = r ? 1 : 0;
     const uint32_t s = act_start[a] & ~ACT_RIGID_BIT;  // (idempotent: the phase-level API may run this twice per sort)
     act_start[a] = r ? (s | ACT_RIGID_BIT) : s;
+    if (r) rigid_list[atomicAdd(n_rigid, 1u)] = a;
   }
 }
 

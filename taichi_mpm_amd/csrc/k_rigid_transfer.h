@@ -10,6 +10,13 @@
 #pragma once
 #include "k_rigid.h"
 
+#ifndef MPM_RIGID_P2G_MINW
+#define MPM_RIGID_P2G_MINW 2
+#endif
+#ifndef MPM_RIGID_G2P_MINW
+#define MPM_RIGID_G2P_MINW 2
+#endif
+
 namespace mpm {
 
 struct RigidXfer {
@@ -17,6 +24,7 @@ struct RigidXfer {
   RigidBodyDev *rb;
   const BndRec *bnd;
   const uint8_t *blk_rigid;
+  const uint32_t *rigid_list, *n_rigid;  // the flagged blocks as a list (k_blk_rigid)
   const float4 *rp_in;  // the current RecP set (G2P reads the particle's own velocity from it)
   float penalty, pushing_force;
 };
@@ -33,7 +41,9 @@ __device__ __forceinline__ void load_state_tile(const CdfDev &C, int bx, int by,
 // block_op_rigid of rasterize_optimized (src/transfer.cpp:367-463): a node of the other colour receives nothing; the
 // particle's momentum change against the body's surface velocity (friction_project with the particle's boundary
 // normal) and its stress term go to the body as an impulse at the node instead (:425-444).
-__global__ __launch_bounds__(64, 2) void k_p2g_rigid(Params P, const float4 *__restrict__ rp, const float4 *__restrict__ rg,
+constexpr int P2GR_LIST = 1024;
+template <uint32_t MATS = MAT_ALL>  // material set of the ctx (mpm_math.h): the impulse walk evaluates calculate_force()
+__global__ __launch_bounds__(64, MPM_RIGID_P2G_MINW) void k_p2g_rigid(Params P, const float4 *__restrict__ rp, const float4 *__restrict__ rg,
                                                   const Counters *__restrict__ cnt, const uint32_t *__restrict__ act_blk,
                                                   const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ perm,
                                                   const GroupParams *__restrict__ groups, float4 *__restrict__ tiles,
@@ -41,25 +51,31 @@ __global__ __launch_bounds__(64, 2) void k_p2g_rigid(Params P, const float4 *__r
   __shared__ float4 tile[TN];
   __shared__ uint32_t stile[TN];
   __shared__ RigidLite srb[MAX_RIGID];
+  __shared__ uint32_t blist[P2GR_LIST];  // the block's boundary particles: (position in the block's sorted range) << 6 | cell
+  __shared__ uint32_t bcount;
   const uint32_t na = min(cnt->n_active, P.max_blocks);
   const int lane = threadIdx.x;
   load_rigid_lite(srb, X.rb, lane, 64);  // (visible behind the first block's barrier)
   const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
   const int nbase = (cx * TS + cy) * TS + cz;
-  for (uint32_t a = blockIdx.x; a < na; a += gridDim.x) {
-    if (!X.blk_rigid[a]) continue;
+  const uint32_t nr = min(*X.n_rigid, na);
+  for (uint32_t li = blockIdx.x; li < nr; li += gridDim.x) {
+    const uint32_t a = X.rigid_list[li];
     int bx, by, bz;
     demorton3(act_blk[a], bx, by, bz);
     for (int t = lane; t < TN; t += 64) tile[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     load_state_tile(X.C, bx, by, bz, stile, lane, 64);
+    if (lane == 0) bcount = 0u;
     __syncthreads();
     const int gx = bx * BS + cx, gy = by * BS + cy, gz = bz * BS + cz;  // base node of this lane's cell
+    const uint32_t blk0 = __shfl(cell_start[a * BC + lane], 0);  // start of the block in the sorted index
     const uint32_t p0 = cell_start[a * BC + lane], p1 = cell_start[a * BC + lane + 1];
-    // Two walks over the cell's particles.  The first is k_p2g's scatter with the colour test (27 x 4 sums in registers); the
-    // second, after those sums have been merged into the tile and their registers are free, hands the momentum change and the
-    // stress term of the skipped nodes to the bodies — it evaluates calculate_force() (an eigen-solve, all eight materials),
-    // which in ONE loop with the 108 accumulators alive cost 43 spilled registers, their scratch reloads inside the inner
-    // loop.  Boundary particles are a minority of a rigid block's particles; their records are read a second time from L2.
+    // Two passes.  The first is k_p2g's scatter (lane = cell, 27 x 4 sums in registers) with the colour test; it also LISTS the
+    // particles that have a node on the other side of a body.  The second, after those sums have been merged into the tile
+    // and their registers are free, takes the list one LANE PER PARTICLE and hands the momentum change and the stress term of
+    // the skipped nodes to the bodies — it evaluates calculate_force() (an eigen-solve), which in one loop with the 108
+    // accumulators alive cost 43 spilled registers.  Boundary particles are a minority of a flagged block's particles
+    // (walking them cell by cell cost as many rounds as the fullest cell had of them); their records come from L2 again.
     float acc[27][4];
 #pragma unroll
     for (int n = 0; n < 27; n++) acc[n][0] = acc[n][1] = acc[n][2] = acc[n][3] = 0.0f;
@@ -96,6 +112,10 @@ __global__ __launch_bounds__(64, 2) void k_p2g_rigid(Params P, const float4 *__r
           if (cdf_incompatible(stile[nbase + (i3 * TS + j) * TS + k], pstate)) other |= 1u << n;
         }
         any_other = any_other || other != 0u;
+        if (other != 0u) {
+          const uint32_t slot = atomicAdd(&bcount, 1u);
+          if (slot < (uint32_t)P2GR_LIST) blist[slot] = ((p - blk0) << 6) | (uint32_t)lane;
+        }
 #pragma unroll
         for (int n = 0; n < 27; n++) {
           const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
@@ -121,65 +141,83 @@ __global__ __launch_bounds__(64, 2) void k_p2g_rigid(Params P, const float4 *__r
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
     }
-    // second walk (cells with a boundary particle only): momentum change and stress term of the skipped nodes go to the bodies
+    // second pass: the listed particles, one per lane (if the list overflowed: cell by cell, every particle re-tested)
     ImpulseAcc ia;
     acc_init(ia);
-    if (__any(any_other)) {
-      for (uint32_t p = p0; p < p1 && any_other; p++) {
-        const size_t icur = perm[p];
-        const float4 h3 = rg[icur * 4 + 3];
-        const uint32_t pstate = __float_as_uint(h3.w);
-        uint32_t other = 0u;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    const uint32_t nlist = bcount;
+    const bool listed = nlist <= (uint32_t)P2GR_LIST;
+    uint32_t lt = (uint32_t)lane, pc = p0;
+    while (true) {
+      uint32_t p = 0u, cell = (uint32_t)lane;
+      bool have;
+      if (listed) {
+        have = lt < nlist;
+        if (have) { const uint32_t e = blist[lt]; p = blk0 + (e >> 6); cell = e & 63u; }
+        lt += 64u;
+      } else {
+        have = any_other && pc < p1;
+        p = pc++;
+      }
+      if (!__any(have)) break;
+      if (!have) continue;
+      const int ccx = (int)(cell >> 4), ccy = (int)((cell >> 2) & 3u), ccz = (int)(cell & 3u);
+      const int pbase = (ccx * TS + ccy) * TS + ccz;
+      const int px = bx * BS + ccx, py = by * BS + ccy, pz = bz * BS + ccz;  // base node of the particle's cell
+      const size_t icur = perm[p];
+      const float4 h3 = rg[icur * 4 + 3];
+      const uint32_t pstate = __float_as_uint(h3.w);
+      uint32_t other = 0u;
 #pragma unroll
-        for (int n = 0; n < 27; n++) {
-          const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
-          if (cdf_incompatible(stile[nbase + (i3 * TS + j) * TS + k], pstate)) other |= 1u << n;
-        }
-        if (!other) continue;
-        const float4 q0 = rp[icur * 4 + 0], q1 = rp[icur * 4 + 1], q3 = rp[icur * 4 + 3];
-        const float4 nb0 = reinterpret_cast<const float4 *>(X.bnd)[icur * 2];
-        const float bnn[3] = {nb0.x, nb0.y, nb0.z};
-        const float mass = q3.w;
-        float v[3] = {q0.w, q1.x, q1.y};
-        if (P.particle_gravity) { v[0] = fmaf(P.g[0], P.dt, v[0]); v[1] = fmaf(P.g[1], P.dt, v[1]); v[2] = fmaf(P.g[2], P.dt, v[2]); }
-        const float r0 = q0.x * P.idx - (float)gx, r1 = q0.y * P.idx - (float)gy, r2 = q0.z * P.idx - (float)gz;
-        float w0[3], w1[3], w2[3];
-        bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
-        // d/dx of the quadratic B-spline in grid units (src/kernel.h:131-132): dw = (1, -2, 1) t + (-1.5, 0, 1.5)
-        const float t0[3] = {r0, r0 - 1.0f, r0 - 2.0f}, t1[3] = {r1, r1 - 1.0f, r1 - 2.0f}, t2[3] = {r2, r2 - 1.0f, r2 - 2.0f};
-        const float dw0[3] = {t0[0] - 1.5f, -2.0f * t0[1], t0[2] + 1.5f}, dw1[3] = {t1[0] - 1.5f, -2.0f * t1[1], t1[2] + 1.5f},
-                    dw2[3] = {t2[0] - 1.5f, -2.0f * t2[1], t2[2] + 1.5f};
-        const float4 h0 = rg[icur * 4 + 0], h1 = rg[icur * 4 + 1], h2 = rg[icur * 4 + 2];
-        mat3 F;
-        F.m[0] = h1.x; F.m[1] = h1.y; F.m[2] = h1.z; F.m[3] = h1.w; F.m[4] = h2.x; F.m[5] = h2.y; F.m[6] = h2.z; F.m[7] = h2.w; F.m[8] = h3.x;
-        mat3 dtF = calculate_force(groups[__float_as_uint(h3.y)], F, h0.w);  // delta_t * calculate_force()
+      for (int n = 0; n < 27; n++) {
+        const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
+        if (cdf_incompatible(stile[pbase + (i3 * TS + j) * TS + k], pstate)) other |= 1u << n;
+      }
+      if (!other) continue;
+      const float4 q0 = rp[icur * 4 + 0], q1 = rp[icur * 4 + 1], q3 = rp[icur * 4 + 3];
+      const float4 nb0 = reinterpret_cast<const float4 *>(X.bnd)[icur * 2];
+      const float bnn[3] = {nb0.x, nb0.y, nb0.z};
+      const float mass = q3.w;
+      float v[3] = {q0.w, q1.x, q1.y};
+      if (P.particle_gravity) { v[0] = fmaf(P.g[0], P.dt, v[0]); v[1] = fmaf(P.g[1], P.dt, v[1]); v[2] = fmaf(P.g[2], P.dt, v[2]); }
+      const float r0 = q0.x * P.idx - (float)px, r1 = q0.y * P.idx - (float)py, r2 = q0.z * P.idx - (float)pz;
+      float w0[3], w1[3], w2[3];
+      bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
+      // d/dx of the quadratic B-spline in grid units (src/kernel.h:131-132): dw = (1, -2, 1) t + (-1.5, 0, 1.5)
+      const float t0[3] = {r0, r0 - 1.0f, r0 - 2.0f}, t1[3] = {r1, r1 - 1.0f, r1 - 2.0f}, t2[3] = {r2, r2 - 1.0f, r2 - 2.0f};
+      const float dw0[3] = {t0[0] - 1.5f, -2.0f * t0[1], t0[2] + 1.5f}, dw1[3] = {t1[0] - 1.5f, -2.0f * t1[1], t1[2] + 1.5f},
+                  dw2[3] = {t2[0] - 1.5f, -2.0f * t2[1], t2[2] + 1.5f};
+      const float4 h0 = rg[icur * 4 + 0], h1 = rg[icur * 4 + 1], h2 = rg[icur * 4 + 2];
+      mat3 F;
+      F.m[0] = h1.x; F.m[1] = h1.y; F.m[2] = h1.z; F.m[3] = h1.w; F.m[4] = h2.x; F.m[5] = h2.y; F.m[6] = h2.z; F.m[7] = h2.w; F.m[8] = h3.x;
+      mat3 dtF = calculate_force<MATS>(groups[__float_as_uint(h3.y)], F, h0.w);  // delta_t * calculate_force()
 #pragma unroll
-        for (int e = 0; e < 9; e++) dtF.m[e] *= P.dt;
-        while (other) {
-          const int n = __ffs(other) - 1;
-          other &= other - 1u;
-          const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
-          const int rid = (int)(stile[nbase + (i3 * TS + j) * TS + k] >> 24) - 1;
-          if (rid < 0) continue;
-          const RigidLite &B = srb[rid];
-          // weights and their derivatives of node (i3, j, k) without indexing the per-axis arrays dynamically
-          const float wa = i3 == 0 ? w0[0] : (i3 == 1 ? w0[1] : w0[2]), wb = j == 0 ? w1[0] : (j == 1 ? w1[1] : w1[2]),
-                      wc = k == 0 ? w2[0] : (k == 1 ? w2[1] : w2[2]);
-          const float da = i3 == 0 ? dw0[0] : (i3 == 1 ? dw0[1] : dw0[2]), db = j == 0 ? dw1[0] : (j == 1 ? dw1[1] : dw1[2]),
-                      dc = k == 0 ? dw2[0] : (k == 1 ? dw2[1] : dw2[2]);
-          const float w = (wa * wb) * wc;
-          const float gp[3] = {(gx + i3) * P.dx, (gy + j) * P.dx, (gz + k) * P.dx};
-          float rv[3];
-          rigid_velocity_at(B, gp, rv);
-          float pv[3] = {v[0], v[1], v[2]};
-          friction_project(pv, rv, bnn, B.fric[(pstate >> (2 * rid)) & 1u]);
-          const float gr[3] = {da * P.idx * wb * wc, wa * db * P.idx * wc, wa * wb * dc * P.idx};
-          float imp[3];
+      for (int e = 0; e < 9; e++) dtF.m[e] *= P.dt;
+      while (other) {
+        const int n = __ffs(other) - 1;
+        other &= other - 1u;
+        const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
+        const int rid = (int)(stile[pbase + (i3 * TS + j) * TS + k] >> 24) - 1;
+        if (rid < 0) continue;
+        const RigidLite &B = srb[rid];
+        // weights and their derivatives of node (i3, j, k) without indexing the per-axis arrays dynamically
+        const float wa = i3 == 0 ? w0[0] : (i3 == 1 ? w0[1] : w0[2]), wb = j == 0 ? w1[0] : (j == 1 ? w1[1] : w1[2]),
+                    wc = k == 0 ? w2[0] : (k == 1 ? w2[1] : w2[2]);
+        const float da = i3 == 0 ? dw0[0] : (i3 == 1 ? dw0[1] : dw0[2]), db = j == 0 ? dw1[0] : (j == 1 ? dw1[1] : dw1[2]),
+                    dc = k == 0 ? dw2[0] : (k == 1 ? dw2[1] : dw2[2]);
+        const float w = (wa * wb) * wc;
+        const float gp[3] = {(px + i3) * P.dx, (py + j) * P.dx, (pz + k) * P.dx};
+        float rv[3];
+        rigid_velocity_at(B, gp, rv);
+        float pv[3] = {v[0], v[1], v[2]};
+        friction_project(pv, rv, bnn, B.fric[(pstate >> (2 * rid)) & 1u]);
+        const float gr[3] = {da * P.idx * wb * wc, wa * db * P.idx * wc, wa * wb * dc * P.idx};
+        float imp[3];
 #pragma unroll
-          for (int c = 0; c < 3; c++)
-            imp[c] = mass * w * (v[c] - pv[c]) + (dtF(c, 0) * gr[0] + dtF(c, 1) * gr[1] + dtF(c, 2) * gr[2]);
-          acc_add(ia, X.rb, rid, imp, gp, B.pos);
-        }
+        for (int c = 0; c < 3; c++)
+          imp[c] = mass * w * (v[c] - pv[c]) + (dtF(c, 0) * gr[0] + dtF(c, 1) * gr[1] + dtF(c, 2) * gr[2]);
+        acc_add(ia, X.rb, rid, imp, gp, B.pos);
       }
     }
     acc_flush_wave(ia, X.rb);  // the wave's impulses: six atomics per body
@@ -195,7 +233,8 @@ __global__ __launch_bounds__(64, 2) void k_p2g_rigid(Params P, const float4 *__r
 // body's surface motion plus a push along the boundary normal (:757-784); a particle near a boundary loses its affine
 // momentum (:800-804) and is pushed back by the penalty term when it is slightly inside (:821-832), the body receiving
 // the opposite impulse.  Everything after the gather is k_g2p's (same record layout, same key / deletion logic).
-__global__ __launch_bounds__(256, 2) void k_g2p_rigid(Params P, const float4 *__restrict__ rg, float4 *__restrict__ rg_out,
+template <uint32_t MATS = MAT_ALL>
+__global__ __launch_bounds__(256, MPM_RIGID_G2P_MINW) void k_g2p_rigid(Params P, const float4 *__restrict__ rg, float4 *__restrict__ rg_out,
                                                    float4 *__restrict__ rp_out, float4 *__restrict__ rb_out,
                                                    const Counters *__restrict__ cnt, const uint32_t *__restrict__ act_blk,
                                                    const uint32_t *__restrict__ act_start, const uint32_t *__restrict__ perm,
@@ -210,8 +249,9 @@ __global__ __launch_bounds__(256, 2) void k_g2p_rigid(Params P, const float4 *__
   const int tid = threadIdx.x;
   load_rigid_lite(srb, X.rb, tid, 256);  // (visible behind the first block's barriers)
   const float scale = -4.0f * P.idx * P.dt;
-  for (uint32_t a = blockIdx.x; a < na; a += gridDim.x) {
-    if (!X.blk_rigid[a]) continue;
+  const uint32_t nr = min(*X.n_rigid, na);
+  for (uint32_t li = blockIdx.x; li < nr; li += gridDim.x) {
+    const uint32_t a = X.rigid_list[li];
     int bx, by, bz;
     demorton3(act_blk[a], bx, by, bz);
     __syncthreads();
@@ -242,7 +282,8 @@ __global__ __launch_bounds__(256, 2) void k_g2p_rigid(Params P, const float4 *__
         if (P.particle_gravity) { pv[0] = fmaf(P.g[0], P.dt, pv[0]); pv[1] = fmaf(P.g[1], P.dt, pv[1]); pv[2] = fmaf(P.g[2], P.dt, pv[2]); }
         const float x0 = g0.x, x1 = g0.y, x2 = g0.z;
         const float X0 = x0 * P.idx - ox, X1 = x1 * P.idx - oy, X2 = x2 * P.idx - oz;
-        const int c0 = (int)(X0 - 0.5f), c1 = (int)(X1 - 0.5f), c2 = (int)(X2 - 0.5f);
+        const int c0 = min(max((int)(X0 - 0.5f), 0), BS - 1), c1 = min(max((int)(X1 - 0.5f), 0), BS - 1),
+                  c2 = min(max((int)(X2 - 0.5f), 0), BS - 1);  // (clamped: see k_p2g_rigid)
         const float r0 = X0 - (float)c0, r1 = X1 - (float)c1, r2 = X2 - (float)c2;
         float w0[3], w1[3], w2[3];
         bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
@@ -326,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_g2p_rigid(Params P, const float4 *__
         F.m[7] = g2.w; F.m[8] = g3.x;
         float aux = g0.w;
         mat3 stress;
-        plasticity_and_force(g, cdg, F, aux, stress);
+        plasticity_and_force<MATS>(g, cdg, F, aux, stress);
         float nx0 = fmaf(v[0], P.dt, x0), nx1 = fmaf(v[1], P.dt, x1), nx2 = fmaf(v[2], P.dt, x2);
         if (bn.near && bn.dist < -0.05f * P.dx && bn.dist > -P.dx * 0.3f) {  // :821-832
           const float dv[3] = {bn.dist * bn.n[0] * X.penalty, bn.dist * bn.n[1] * X.penalty, bn.dist * bn.n[2] * X.penalty};

@@ -341,13 +341,14 @@ template <int CT_BLOCKS>  // blocks per chunk: 64 for large problems, 16 when th
 __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uint32_t *__restrict__ cell_cnt,
                                                     uint32_t *__restrict__ act_start,
                                                     uint32_t *__restrict__ cell_start,
-                                                    unsigned long long *__restrict__ slots, uint32_t epoch) {
+                                                    unsigned long long *__restrict__ slots, uint32_t epoch,
+                                                    uint32_t rank_runs_mul) {
   __shared__ uint32_t lds[8];
   constexpr int CT_BPW = CT_BLOCKS / 4;  // blocks per wave
   __shared__ uint32_t blk_tot[CT_BLOCKS];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // k_rank of this sort is complete: its run statistics choose the path of the next one (see k_rank)
-    cnt->rank_mode = (cnt->run_heads * 3u > P.n_slots) ? 1u : 0u;
+    cnt->rank_mode = (cnt->run_heads * rank_runs_mul > P.n_slots) ? 1u : 0u;
     cnt->run_heads = 0u;
   }
   const uint32_t na = min(cnt->n_active, P.max_blocks);

@@ -176,15 +176,18 @@ struct GroupParams {
 };
 
 // calculate_force(): returns -vol * P(F) * F^T  (src/particles.h:134-137; bodies in src/particles.cpp)
+// MATS_: the material set the caller is compiled for (MAT_ALL below); a set of ONE material needs no type dispatch
+template <uint32_t MATS_ = 0x1FEu>
 __device__ __forceinline__ mat3 calculate_force(const GroupParams &g, const mat3 &F, float aux) {
   const float vol = g.p[1];
   mat3 out;
-  switch (g.type) {
+  const int type = ((MATS_ & (MATS_ - 1u)) == 0u) ? (int)__builtin_ctz(MATS_) : g.type;
+  switch (type) {
     case MPMHIP_VISCO:   // src/particles.cpp:72-85 (same fixed-corotated energy)
     case MPMHIP_JELLY:   // src/particles.cpp:391-411  P = 2mu(F-R) + lambda (J-1) J F^-T
     case MPMHIP_SNOW: {  // src/particles.cpp:207-220, 244-252 (mu,lambda scaled by exp(h(1-Jp)))
       float mu = g.p[2], la = g.p[3];
-      if (g.type == MPMHIP_SNOW) {
+      if (type == MPMHIP_SNOW) {
         const float e = expf(g.p[4] * (1.0f - aux));
         mu *= e; la *= e;
       }

@@ -138,6 +138,8 @@ struct mpmhip_ctx {
   int p2g_wgs = 16384;        // workgroups of k_p2g (env MPMHIP_P2G_WGS)
   int p2g_split = 11;         // tuning knob (env MPMHIP_P2G_SPLIT): 10*NS + PS, see do_p2g
   int g2p_wgs = 4096;         // workgroups of k_g2p (env MPMHIP_G2P_WGS)
+  uint32_t rank_runs_mul = 3; // k_rank takes its LDS-hash path when runs * this > slots (env MPMHIP_RANK_RUNS_MUL: tuning)
+  int ct_blocks = 0;          // blocks per chunk of k_cell_table: 0 by size, 16, 64 (env MPMHIP_CT_BLOCKS: tuning)
   int g2p2g_wgs = 4096;       // ... of its fused form (env MPMHIP_G2P2G_WGS)
   int g2p_minw = 12;          // tuning knob (env MPMHIP_G2P_MINW): 10 + __launch_bounds__ waves/SIMD of k_g2p
   int reorder_interval = 0;   // physical reorder every this many substeps (0 = never); env MPMHIP_REORDER_INTERVAL
@@ -227,6 +229,7 @@ struct mpmhip_ctx {
     CdfDev cdf{};
     BndRec *d_bnd = nullptr;
     uint8_t *d_blk_rigid = nullptr;
+    uint32_t *d_rigid_list = nullptr;  // [max_blocks + 1] the flagged blocks as a list; its length is d_counters[CDF_POOLS + 1]
     uint32_t *d_counters = nullptr;  // [0, CDF_POOLS) pages handed out per sub-pool, [CDF_POOLS] cutting_counter
     uint32_t max_pages = 0;
     uint32_t gather_epoch = 0;  // stamps the boundary records of the particles the last gather_cdf visited
@@ -412,6 +415,8 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   c->device = cfg->device;
   if (const char *e = getenv("MPMHIP_G2P_MINW")) c->g2p_minw = atoi(e);
   if (const char *e = getenv("MPMHIP_G2P_WGS")) c->g2p_wgs = atoi(e) > 0 ? atoi(e) : 4096;
+  if (const char *e = getenv("MPMHIP_RANK_RUNS_MUL")) c->rank_runs_mul = (uint32_t)atoi(e);
+  if (const char *e = getenv("MPMHIP_CT_BLOCKS")) c->ct_blocks = atoi(e);
   if (const char *e = getenv("MPMHIP_G2P2G_WGS")) c->g2p2g_wgs = atoi(e) > 0 ? atoi(e) : 4096;
   if (const char *e = getenv("MPMHIP_P2G_SPLIT")) c->p2g_split = atoi(e);
   if (const char *e = getenv("MPMHIP_P2G_WGS")) c->p2g_wgs = atoi(e) > 0 ? atoi(e) : 16384;
@@ -540,7 +545,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   hipFree(c->tiles8); hipFree(c->bits_prev); hipFree(c->wprefix_prev);
   hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_LS); hipFree(c->d_counts); hipFree(c->d_bounds); if (c->h_pinned) hipHostFree(c->h_pinned); hipFree(c->d_energy);
   { auto &R = c->rigid; hipFree(R.d_rb); hipFree(R.d_smp); hipFree(R.d_elems); hipFree(R.cdf.slot); hipFree(R.cdf.page_key); hipFree(R.cdf.mind);
-    hipFree(R.cdf.tags); hipFree(R.cdf.rpage); hipFree(R.d_bnd); hipFree(R.d_blk_rigid); hipFree(R.d_counters); hipFree(R.d_joints); }
+    hipFree(R.cdf.tags); hipFree(R.cdf.rpage); hipFree(R.d_bnd); hipFree(R.d_blk_rigid); hipFree(R.d_rigid_list); hipFree(R.d_counters); hipFree(R.d_joints); }
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -909,7 +914,7 @@ static int do_sort(mpmhip_ctx *c) {
   }
   if (!c->keys_valid)
     hipLaunchKernelGGL(k_build_keys, dim3(pg), dim3(256), 0, st, P, c->rg, c->rp, c->cnt, c->key, c->blk_flag);
-  const bool small = c->n_slots < (2 << 20);  // few blocks: finer chunks in k_cell_table
+  const bool small = c->ct_blocks ? c->ct_blocks == 16 : c->n_slots < (2 << 20);  // few blocks: finer chunks in k_cell_table
   const uint32_t bt_chunks = (P.nbw + 255) / 256, ct_chunks = (P.max_blocks + (small ? 16 : 64) - 1) / (small ? 16 : 64);
   const uint32_t epoch = ++c->sort_epoch;
   // (single-pass scans: never more workgroups than are resident at once, see k_sort.h)
@@ -919,7 +924,7 @@ static int do_sort(mpmhip_ctx *c) {
   hipLaunchKernelGGL(k_rank, dim3(std::max(rank_wgs, 1u)), dim3(256), 0, st, P, c->key, c->rank, c->cell_cnt, c->bits, c->wprefix,
                      c->cnt);
   hipLaunchKernelGGL(small ? k_cell_table<16> : k_cell_table<64>, dim3(std::min(ct_chunks, c->scan_grid)), dim3(256), 0, st, P,
-                     c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots, epoch);
+                     c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots, epoch, c->rank_runs_mul);
   hipLaunchKernelGGL(k_perm, dim3(pg), dim3(256), 0, st, P, (const Counters *)c->cnt, c->key, c->rank, c->cell_start, c->perm);
   c->sorted = true;
   c->keys_valid = false;  // key[] now holds k_rank's packed (rank, cell index) words
@@ -957,6 +962,12 @@ static int do_reorder(mpmhip_ctx *c) {
 }
 
 static RigidXfer rigid_xfer(mpmhip_ctx *c);
+// bit t set = some particle group of the ctx is of material type t
+static uint32_t material_mask(const mpmhip_ctx *c) {
+  uint32_t mask = 0;
+  for (const GroupParams &g : c->groups) mask |= 1u << (g.type & 31);
+  return mask;
+}
 static int do_rigid_apply_tmp(mpmhip_ctx *c);
 
 static int do_p2g(mpmhip_ctx *c, int phase = 0) {
@@ -985,7 +996,15 @@ static int do_p2g(mpmhip_ctx *c, int phase = 0) {
                      (const float4 *)c->rp, c->cnt, c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles, c->T, phase,
                      rigid ? (const uint8_t *)c->rigid.d_blk_rigid : (const uint8_t *)nullptr);
   if (rigid) {  // blocks near a body (block_op_rigid), then RigidBody::apply_tmp_velocity (src/transfer.cpp:578-580)
-    hipLaunchKernelGGL(k_p2g_rigid, dim3(4096), dim3(64), 0, c->stream, c->P, (const float4 *)c->rp, (const float4 *)c->rg, c->cnt,
+    auto rk = k_p2g_rigid<MAT_ALL>;
+    switch (material_mask(c)) {  // one material in the ctx: the kernel that carries only its calculate_force()
+#define MPM_ONE_MATERIAL(t) case 1u << (t): rk = k_p2g_rigid<1u << (t)>; break;
+      MPM_ONE_MATERIAL(MPMHIP_VISCO) MPM_ONE_MATERIAL(MPMHIP_SNOW) MPM_ONE_MATERIAL(MPMHIP_LINEAR) MPM_ONE_MATERIAL(MPMHIP_JELLY)
+      MPM_ONE_MATERIAL(MPMHIP_WATER) MPM_ONE_MATERIAL(MPMHIP_SAND) MPM_ONE_MATERIAL(MPMHIP_VON_MISES) MPM_ONE_MATERIAL(MPMHIP_ELASTIC)
+#undef MPM_ONE_MATERIAL
+      default: break;
+    }
+    hipLaunchKernelGGL(rk, dim3(4096), dim3(64), 0, c->stream, c->P, (const float4 *)c->rp, (const float4 *)c->rg, c->cnt,
                        c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles, rigid_xfer(c));
     if (int rc = do_rigid_apply_tmp(c)) return rc;
   }
@@ -1025,8 +1044,7 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0, bool fused = false) {
   // VGPRs against 5 552 / 180 for all eight); no visco group -> the set without it (161 VGPRs: visco, with two eigen-solves
   // and a matrix exponential, is what pushes the full kernel over the budget).
   constexpr uint32_t NO_VISCO = MAT_ALL & ~(1u << MPMHIP_VISCO);
-  uint32_t mask = 0;
-  for (const GroupParams &g : c->groups) mask |= 1u << (g.type & 31);
+  const uint32_t mask = material_mask(c);
   const bool rigid = rigid_active(c), no_visco = !(mask & (1u << MPMHIP_VISCO));
   auto kern = sb ? (no_visco ? k_g2p<256, MPM_G2P_MINW, true, true, false, NO_VISCO> : k_g2p<256, 2, true, true>)
                  : (no_visco ? k_g2p<256, MPM_G2P_MINW, true, false, false, NO_VISCO> : k_g2p<256, 2, true, false>);
@@ -1042,6 +1060,13 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0, bool fused = false) {
   if (rigid) {
     kern = sb ? (no_visco ? k_g2p<256, MPM_G2P_MINW, true, true, true, NO_VISCO> : k_g2p<256, 2, true, true, true>)
               : (no_visco ? k_g2p<256, MPM_G2P_MINW, true, false, true, NO_VISCO> : k_g2p<256, 2, true, false, true>);
+    if (!sb) switch (mask) {
+#define MPM_ONE_MATERIAL(t) case 1u << (t): kern = k_g2p<256, MPM_G2P_MINW, true, false, true, 1u << (t)>; break;
+      MPM_ONE_MATERIAL(MPMHIP_VISCO) MPM_ONE_MATERIAL(MPMHIP_SNOW) MPM_ONE_MATERIAL(MPMHIP_LINEAR) MPM_ONE_MATERIAL(MPMHIP_JELLY)
+      MPM_ONE_MATERIAL(MPMHIP_WATER) MPM_ONE_MATERIAL(MPMHIP_SAND) MPM_ONE_MATERIAL(MPMHIP_VON_MISES) MPM_ONE_MATERIAL(MPMHIP_ELASTIC)
+#undef MPM_ONE_MATERIAL
+      default: break;
+    }
   } else if (!sb) {
     switch (mask) {
 #define MPM_ONE_MATERIAL(t) case 1u << (t): kern = k_g2p<256, MPM_G2P_MINW, true, false, false, 1u << (t)>; break;
@@ -1072,7 +1097,15 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0, bool fused = false) {
   c->tiles8_valid = fused;   // (its P2G is keyed by THIS sort's block table, which the next sort keeps as bits_prev)
   c->rp_current = write_p != 0;
   if (rigid) {
-    hipLaunchKernelGGL(k_g2p_rigid, dim3(2048), dim3(256), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
+    auto rk = k_g2p_rigid<MAT_ALL>;
+    switch (mask) {
+#define MPM_ONE_MATERIAL(t) case 1u << (t): rk = k_g2p_rigid<1u << (t)>; break;
+      MPM_ONE_MATERIAL(MPMHIP_VISCO) MPM_ONE_MATERIAL(MPMHIP_SNOW) MPM_ONE_MATERIAL(MPMHIP_LINEAR) MPM_ONE_MATERIAL(MPMHIP_JELLY)
+      MPM_ONE_MATERIAL(MPMHIP_WATER) MPM_ONE_MATERIAL(MPMHIP_SAND) MPM_ONE_MATERIAL(MPMHIP_VON_MISES) MPM_ONE_MATERIAL(MPMHIP_ELASTIC)
+#undef MPM_ONE_MATERIAL
+      default: break;
+    }
+    hipLaunchKernelGGL(rk, dim3(2048), dim3(256), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
                        (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
                        c->blk_flag, (const LevelSetDev *)c->d_LS, rigid_xfer(c));
     if (int rc = do_rigid_apply_tmp(c)) return rc;
@@ -1931,7 +1964,7 @@ int mpmhip_reserve(mpmhip_ctx *c, int64_t max_particles) {
       A(regrow(&c->cell_cnt, 0, m * BC, true)); A(regrow(&c->cell_start, 0, m * BC + 1, true));
       A(regrow(&c->scan_slots, 0, c->bt_slots + (m + 15) / 16 + 1, true));  // (epoch 0 is never used)
       A(regrow(&c->tiles, 0, m * TN, false)); A(regrow(&c->gridv, 0, m * 8 * BC, false));
-      if (c->rigid.d_blk_rigid) A(regrow(&c->rigid.d_blk_rigid, 0, m + 1, true));
+      if (c->rigid.d_blk_rigid) { A(regrow(&c->rigid.d_blk_rigid, 0, m + 1, true)); A(regrow(&c->rigid.d_rigid_list, 0, m + 1, false)); }
       (void)hipFree(c->tiles8); (void)hipFree(c->bits_prev); (void)hipFree(c->wprefix_prev);  // (re-allocated on demand)
       c->tiles8 = nullptr; c->bits_prev = nullptr; c->wprefix_prev = nullptr;
       if (e != hipSuccess) return fail(c, MPMHIP_ENOMEM, "growing the block table to %lld failed: %s", (long long)mb, hipGetErrorString(e));

@@ -100,10 +100,12 @@ static int rigid_enable(mpmhip_ctx *c) {
   A(dmalloc(&R.cdf.page_key, (size_t)R.max_pages));
   A(dmalloc(&R.cdf.mind, (size_t)R.max_pages * 64));
   A(dmalloc(&R.cdf.tags, (size_t)R.max_pages * 64));
-  A(dmalloc(&R.d_counters, (size_t)CDF_POOLS + 4));  // [0, CDF_POOLS) pages handed out per sub-pool, [CDF_POOLS] cutting_counter
+  A(dmalloc(&R.d_counters, (size_t)CDF_POOLS + 4));  // [0, CDF_POOLS) pages handed out per sub-pool, [CDF_POOLS] cutting_counter,
+                                                    // [CDF_POOLS + 1] length of d_rigid_list
   A(dmalloc(&R.cdf.rpage, R.rpage_words));
   A(dmalloc(&R.d_bnd, (size_t)c->cap));
   A(dmalloc(&R.d_blk_rigid, (size_t)c->P.max_blocks + 1));
+  A(dmalloc(&R.d_rigid_list, (size_t)c->P.max_blocks + 1));
   if (e != hipSuccess) return fail(c, MPMHIP_ENOMEM, "rigid coupling: device allocation failed: %s", hipGetErrorString(e));
   R.cdf.n_pages = R.d_counters; R.cdf.error = &c->cnt->error;
   R.cdf.nb_axis = 1 << c->P.kbits;
@@ -139,6 +141,7 @@ static int rigid_enable(mpmhip_ctx *c) {
 static RigidXfer rigid_xfer(mpmhip_ctx *c) {
   RigidXfer X;
   X.C = c->rigid.cdf; X.rb = c->rigid.d_rb; X.bnd = c->rigid.d_bnd; X.blk_rigid = c->rigid.d_blk_rigid;
+  X.rigid_list = c->rigid.d_rigid_list; X.n_rigid = c->rigid.d_counters + CDF_POOLS + 1;
   X.rp_in = (const float4 *)c->rp;
   X.penalty = c->rigid.penalty; X.pushing_force = c->rigid.pushing_force;
   return X;
@@ -167,8 +170,9 @@ static int do_rigid_gather(mpmhip_ctx *c) {
 }
 static int do_rigid_block_flags(mpmhip_ctx *c) {
   auto &R = c->rigid;
+  HIPCHK(c, hipMemsetAsync(R.d_counters + CDF_POOLS + 1, 0, sizeof(uint32_t), c->stream));
   hipLaunchKernelGGL(k_blk_rigid, dim3(256), dim3(256), 0, c->stream, c->P, (const Counters *)c->cnt, (const uint32_t *)c->act_blk, R.cdf,
-                     R.d_blk_rigid, c->act_start);
+                     R.d_blk_rigid, c->act_start, R.d_rigid_list, R.d_counters + CDF_POOLS + 1);
   return launch_check(c, "rigid block flags");
 }
 static int do_rigid_apply_tmp(mpmhip_ctx *c) {
