@@ -507,6 +507,31 @@ def main():
         dog.phase("evolving to impact", 1200)
         job.run(substeps_to_impact(cfg) + EVOLVE_AFTER_IMPACT)  # (through the job: a tiled ctx cannot be stepped on its own)
         job.synchronize()
+    overlap_note = None
+    if (world > 1 or force_tiled) and os.environ.get("MPMHIP_TILE_OVERLAP", "auto") == "auto":
+        # The boundary / interior split hides the exchange behind the interior kernels but costs three more launches of
+        # latency-bound kernels per substep (1 M particles per rank: +25 us on one GPU): whether it pays depends
+        # on the wire, which only this run can measure.  Both ways are timed on a few untimed substeps (max over ranks, so
+        # every rank takes the same decision) and the faster one is kept.
+        dog.phase("overlap tuning", 600)
+        job.run(args.warmup)
+
+        def trial(flag, n=12):
+            job.set_overlap(flag)
+            barrier()
+            t0 = time.perf_counter()
+            job.run(n)
+            job.synchronize()
+            barrier()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return 1e3 * float(tt.item()) / n
+        t_on, t_off = trial(True), trial(False)
+        job.set_overlap(t_on <= t_off)
+        overlap_note = {"kept": "on" if t_on <= t_off else "off", "ms_per_step_on": t_on, "ms_per_step_off": t_off}
+        print("bench.py[rank %d]: overlap split %s (%.4f ms per substep with, %.4f without)" % (rank, overlap_note["kept"], t_on, t_off),
+              file=sys.stderr, flush=True)
     dog.phase("measurement", 900)
     elapsed, ms, dom, prof = measure(args.warmup, args.steps)
     dog.phase("report", 900)
@@ -548,6 +573,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": job.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["desc"], "particles": n_total, "dt": cfg.get("dt", 1e-4), "parallelism": job.parallelism, "wire": wire,
+                   "overlap_split": overlap_note,
                    "timed": "full substep: sort+reorder, P2G, grid normalise+boundary, G2P, boundary cleanup",
                    "state": state_desc},
         "roofline": roof,

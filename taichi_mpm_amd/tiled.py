@@ -422,6 +422,12 @@ class TiledJob:
             engine.set_overlap(True)
         self.parallelism = "%dx%dx%d bricks, one rank per GPU, halo all-sum + migration over RCCL" % part.dims
 
+    def set_overlap(self, flag):
+        """boundary / interior split of the substep (the exchange overlaps the interior part) on or off; between substeps"""
+        self.overlap = bool(flag) and hasattr(self.e, "set_overlap")
+        if hasattr(self.e, "set_overlap"):
+            self.e.set_overlap(self.overlap)
+
     def substep(self):
         r, p = self.r, self.r.plan
         r.e.begin()  # sort, P2G (only the blocks touching a halo box when overlapping), halo pack
@@ -638,6 +644,6 @@ def make_tiled_job(tm, cfg, rank, world, local_rank, margin=4, migrate_interval=
     part = scene_partition(cfg, world, margin)
     sim, _ = build_rank_sim(tm, cfg, part, rank, local_rank)
     engine = HipEngine(sim, local_rank)
-    overlap = os.environ.get("MPMHIP_TILE_OVERLAP", "1") != "0"
+    overlap = os.environ.get("MPMHIP_TILE_OVERLAP", "1") != "0"  # ("auto": bench.py times both and keeps the faster)
     comm = comm or DistComm(dist, torch.device("cuda", local_rank))
     return TiledJob(engine, part, comm, migrate_interval, overlap=overlap)

@@ -335,6 +335,8 @@ def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks, hook, co
     assert d["value"] > 0 and d["unit"] == "particle-steps/s" and d["roofline"]["kernel"] in ("k_g2p", "k_p2g")
     assert bricks + " bricks" in d["config"]["parallelism"]
     assert d["config"]["wire"].startswith("gloo") and ("probe failed" in d["config"]["wire"]) == (not hook)
+    ov = d["config"]["overlap_split"]  # both ways timed before the measurement, the faster one kept (bench.py)
+    assert ov["kept"] in ("on", "off") and ov["ms_per_step_on"] > 0 and ov["ms_per_step_off"] > 0
 
 
 def test_bench_tiled_job_over_rccl_single_rank(tm):
