@@ -10,6 +10,10 @@ Sequence:  W warm-up substeps (untimed) | a short untimed pass with every phase 
 table, picks the dominant kernel) | barrier | K timed substeps, only the dominant kernel bracketed (two event
 records per substep; bracketing all phases would add ~20 us of idle GPU per substep) | barrier.
 
+N > 1 (bricks + halo exchange): before that sequence the boundary / interior split of the substep (it hides
+the exchange behind the interior kernels at the price of three more launches) is timed on and off over a dozen untimed
+substeps, max over ranks, and the faster way is kept: config.overlap_split (MPMHIP_TILE_OVERLAP=0|1 pins it).
+
 Extra objects on the line:
   roofline      dominant kernel (the slower of k_p2g / k_g2p): algorithmic bytes per launch / its average launch
                 duration over the K timed substeps, hipEvents recorded on the ctx stream (mpmhip_set_profiling).
