@@ -382,13 +382,13 @@ using MPM3D = MPM<3>;
 class AsyncMPM3D : public MPM3D {
  public:
   void initialize(const Config &config) override {  // AsyncMPM<dim>::initialize, src/async/async_mpm.cpp:13-55
-    if (config.get("left_boundary", false)) throw std::runtime_error("config key 'left_boundary' (src/async/async_mpm.cpp:43-53) is not implemented");
     MPM3D::initialize(config);
     mpmhip_async_config a{};
     a.unit_delta_t = config.get("unit_delta_t", 1e-6f);  // :24-27
     a.max_units = (int64_t)config.get("max_units", 8192.0);
     a.cfl_dt_mul = config.get("cfl_dt_mul", 1.0f);
     a.strength_dt_mul = config.get("strength_dt_mul", 1.0f);
+    a.left_boundary = config.get("left_boundary", false) ? 1 : 0;  // :43-53
     check(mpmhip_async_begin(ctx_, &a), ctx_);
   }
   std::string add_particles(const Config &config) override {  // :57-75: the new particles go to their blocks' pools

@@ -317,6 +317,8 @@ typedef struct {
   int64_t max_units;      /* "max_units", default 8192 */
   float cfl_dt_mul;       /* "cfl_dt_mul", default 1 */
   float strength_dt_mul;  /* "strength_dt_mul", default 1 */
+  int32_t left_boundary;  /* "left_boundary", default 0: the scheduler blocks whose corner lies in x <= 0.2 of the domain follow
+                           * the SMALLEST step in use (src/async/async_mpm.cpp:43-53, 155-163) */
 } mpmhip_async_config;
 int mpmhip_async_enable(mpmhip_ctx *ctx, const mpmhip_async_config *cfg);
 int mpmhip_async_update_dt_limits(mpmhip_ctx *ctx);

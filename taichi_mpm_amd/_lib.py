@@ -43,7 +43,8 @@ MAX_SHAPES = 16
 
 class AsyncConfig(C.Structure):
     """mirror of mpmhip_async_config"""
-    _fields_ = [("unit_delta_t", C.c_float), ("max_units", C.c_int64), ("cfl_dt_mul", C.c_float), ("strength_dt_mul", C.c_float)]
+    _fields_ = [("unit_delta_t", C.c_float), ("max_units", C.c_int64), ("cfl_dt_mul", C.c_float), ("strength_dt_mul", C.c_float),
+                ("left_boundary", C.c_int32)]
 
 
 SCRIPT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_float, C.POINTER(C.c_float))  # mpmhip_script_fn

@@ -24,7 +24,7 @@ _LP = C.POINTER(C.c_int64)
 
 class AsyncSimulation3D(Simulation3D):
     """AsyncMPM<3>.  Config keys on top of MPM's: unit_delta_t (1e-6), max_units (8192), cfl_dt_mul, strength_dt_mul
-    (src/async/async_mpm.cpp:24-27)."""
+    (src/async/async_mpm.cpp:24-27), left_boundary (:43-53)."""
 
     def initialize(self, config):
         cfg = dict(config)
@@ -34,8 +34,7 @@ class AsyncSimulation3D(Simulation3D):
         self.max_units = int(cfg.get("max_units", 8192))
         self.cfl_dt_mul = float(cfg.get("cfl_dt_mul", 1.0))
         self.strength_dt_mul = float(cfg.get("strength_dt_mul", 1.0))
-        if cfg.get("left_boundary"):
-            raise MPMError("config key 'left_boundary' (src/async/async_mpm.cpp:43-53) is not implemented")
+        self.left_boundary = bool(cfg.get("left_boundary", False))  # src/async/async_mpm.cpp:43-53
         self.nb = ((self.res[0] >> 2) + 1, (self.res[1] >> 2) + 1, (self.res[2] >> 3) + 1)
         self._begun = False
         return self
@@ -43,7 +42,7 @@ class AsyncSimulation3D(Simulation3D):
     # ------------------------------------------------------------------------------------------- plumbing
     def _create(self, capacity):
         super()._create(capacity)
-        a = _lib.AsyncConfig(self.unit_delta_t, self.max_units, self.cfl_dt_mul, self.strength_dt_mul)
+        a = _lib.AsyncConfig(self.unit_delta_t, self.max_units, self.cfl_dt_mul, self.strength_dt_mul, int(self.left_boundary))
         self._check(self._L.mpmhip_async_begin(self._ctx, C.byref(a)))
         self._begun = True
 

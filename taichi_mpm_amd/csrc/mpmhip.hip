@@ -170,6 +170,7 @@ struct mpmhip_ctx {
   struct AsyncState {  // AsyncMPM block table (src/async/async_mpm.h:93-110), one entry per scheduler block of 4x4x8 nodes
     bool enabled = false, limits_valid = false;
     mpmhip_async_config cfg{};
+    std::vector<uint32_t> boundary;  // "left_boundary" blocks (src/async/async_mpm.cpp:43-53)
     int nb[3] = {0, 0, 0};
     int64_t current_t_int = 0, min_delta_t_int = 1, max_delta_t_int = 1;
     std::vector<int64_t> strength, cfl, continuous;  // strength_dt_limit, cfl_dt_limit, continuous_dt_limit
@@ -2203,6 +2204,13 @@ int mpmhip_async_enable(mpmhip_ctx *c, const mpmhip_async_config *cfg) {
   // src/async/async_mpm.cpp:32-37: strength = cfl = 2^31, continuous = 1
   A.strength.assign(nblk, 1ll << 31); A.cfl.assign(nblk, 1ll << 31); A.continuous.assign(nblk, 1);
   A.count.assign(nblk, 0);
+  A.boundary.clear();
+  if (cfg->left_boundary)  // :43-53 — blocks whose corner node lies in 0 <= x / res <= 0.2
+    for (int bx = 0; bx < A.nb[0]; bx++) {
+      if (!((float)(bx * 4) / (float)c->P.res[0] <= 0.2f)) continue;
+      for (int by = 0; by < A.nb[1]; by++)
+        for (int bz = 0; bz < A.nb[2]; bz++) A.boundary.push_back((uint32_t)((bx * A.nb[1] + by) * A.nb[2] + bz));
+    }
   A.current_t_int = 0; A.min_delta_t_int = 1; A.max_delta_t_int = 1;
   hipFree(A.d_tab); hipFree(A.d_blk_limits);
   A.d_tab = nullptr; A.d_blk_limits = nullptr;
@@ -2287,6 +2295,11 @@ static int async_limits_from_table(mpmhip_ctx *c) {
     while (A.max_delta_t_int >= (limit << 1) && (t & ((limit << 1) - 1)) == 0) limit <<= 1;
   }
   boundary(false);
+  for (uint32_t b : A.boundary)  // "left_boundary" blocks follow the smallest step in use (:155-163; min / max stay as they are)
+    if ((t & (A.continuous[b] - 1)) == 0) {
+      int64_t &limit = A.continuous[b];
+      while (A.min_delta_t_int < limit) limit >>= 1;
+    }
   return MPMHIP_OK;
 }
 

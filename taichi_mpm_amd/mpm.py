@@ -624,7 +624,7 @@ class Simulation3D:
         """config keys of AsyncMPM<dim>::initialize (src/async/async_mpm.cpp:24-27).  Builds the scheduler-block table; the
         stepping itself (AsyncMPM::advance) is not part of this build — see include/mpmhip.h."""
         self._ensure_ctx()
-        a = _lib.AsyncConfig(float(unit_delta_t), int(max_units), float(cfl_dt_mul), float(strength_dt_mul))
+        a = _lib.AsyncConfig(float(unit_delta_t), int(max_units), float(cfl_dt_mul), float(strength_dt_mul), 0)
         self._check(self._L.mpmhip_async_enable(self._ctx, C.byref(a)))
 
     def update_dt_limits(self):

@@ -92,17 +92,22 @@ def test_block_dt_limits_match_the_reference_async_stepper_on_a_two_stiffness_sc
     sim.close(); r.close()
 
 
-def test_async_stepping_matches_the_reference_async_stepper(tm):
+@pytest.mark.parametrize("left_boundary", [False, True])
+def test_async_stepping_matches_the_reference_async_stepper(tm, left_boundary):
     """create_simulation3('async_mpm').step(dt): blocks advancing with their own power-of-two multiples of unit_delta_t
     (AsyncMPM<dim>::step / advance, src/async/async_mpm.cpp:255-421) against the reference's own stepper on the
     two-stiffness scene: same pools (every container of every block, at its block's time), same number of particle
-    updates, particle states to fp32 tolerance"""
+    updates, particle states to fp32 tolerance.  left_boundary (src/async/async_mpm.cpp:43-53, 155-163): the (empty) blocks in
+    x <= 0.2 follow the SMALLEST step in use instead of the largest, so the soft blocks next to them are re-advanced with
+    the stiff level (more particle updates: the counter must agree with the reference's)"""
     from oracle import refmpm as ref
     if not ref.available():
         pytest.skip("oracle/_ref/libmpm_ref.so did not travel to this box")
     ref.set_threads(1)
     res, dx, sa, sb = _two_stiffness_scene()
     kw = dict(unit_delta_t=2e-6, max_units=1024)  # sand blocks step with 256 units, the soft elastic ones with 1024
+    if left_boundary:
+        kw["left_boundary"] = True
     r = ref.AsyncSim(res, dx, shapes=[(0, 0, 0, 1, 0, -0.2)], friction=0.4, **kw)
     sim = tm.create_simulation3("async_mpm").initialize(dict(res=(res,) * 3, delta_x=dx, **kw))
     sim.set_levelset(tm.mpm.LevelSet(friction=0.4).add_plane((0, 1, 0), d=-0.2))
