@@ -5,7 +5,7 @@
 // a particle pool at the block's own time and a backup pool at an earlier time; step() walks the power-of-two levels and
 // advance(limit) runs ONE ordinary substep, dt = unit_delta_t * limit, on the blocks of that level plus frozen copies of
 // their neighbours.  Here the block tables (a few integers per block) and the level walk are host code, as in the reference;
-// every container stays in HBM (k_async.h: the store), and an advance costs four small kernels around the substep and one
+// every container stays in HBM (k_async.h: the store), and an advance costs four small kernels around the substep and
 // two 16-byte read-backs (how many particles the working set has; how many containers were appended / freed).
 
 static inline uint32_t as_spread3(uint32_t v) {  // bits of v three apart

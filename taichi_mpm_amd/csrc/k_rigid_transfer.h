@@ -30,10 +30,38 @@ struct RigidXfer {
 };
 
 // states of the block's 6^3 tile nodes (tags | body id + 1 << 24) into LDS
-__device__ __forceinline__ void load_state_tile(const CdfDev &C, int bx, int by, int bz, uint32_t *stile, int tid, int nt) {
-  for (int t = tid; t < TN; t += nt) {
-    const int tx = t / (TS * TS), ty = (t / TS) % TS, tz = t % TS;
-    stile[t] = cdf_node_word(C, bx * BS + tx, by * BS + ty, bz * BS + tz);
+// (NT threads; a thread's nodes are looked up together — first every page slot, then every tag / distance word — so that a
+// 64-thread workgroup pays two memory round trips for its four nodes per lane, not eight)
+template <int NT>
+__device__ __forceinline__ void load_state_tile(const CdfDev &C, int bx, int by, int bz, uint32_t *stile, int tid) {
+  constexpr int R = (TN + NT - 1) / NT;
+  uint32_t pg[R], cell[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int t = tid + r * NT;
+    pg[r] = INVALID; cell[r] = 0u;
+    if (t < TN) {
+      const int i = bx * BS + t / (TS * TS), j = by * BS + (t / TS) % TS, k = bz * BS + t % TS;
+      if (!(i < 0 || j < 0 || k < 0 || (i >> 2) >= C.nb_axis || (j >> 2) >= C.nb_axis || (k >> 2) >= C.nb_axis)) {
+        pg[r] = C.slot[morton3(i >> 2, j >> 2, k >> 2)];
+        cell[r] = (uint32_t)(((i & 3) << 4) | ((j & 3) << 2) | (k & 3));
+      }
+    }
+  }
+  uint32_t tg[R];
+  unsigned long long md[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    tg[r] = 0u; md[r] = CDF_EMPTY;
+    if (pg[r] != INVALID) {
+      const size_t n = (size_t)pg[r] * 64 + cell[r];
+      tg[r] = C.tags[n]; md[r] = C.mind[n];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int t = tid + r * NT;
+    if (t < TN) stile[t] = (tg[r] & CDF_TAG_MASK) | (md[r] != CDF_EMPTY ? ((uint32_t)(md[r] & 0xFFu) << 24) : 0u);  // = cdf_node_word
   }
 }
 
@@ -64,7 +92,7 @@ __global__ __launch_bounds__(64, MPM_RIGID_P2G_MINW) void k_p2g_rigid(Params P, 
     int bx, by, bz;
     demorton3(act_blk[a], bx, by, bz);
     for (int t = lane; t < TN; t += 64) tile[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    load_state_tile(X.C, bx, by, bz, stile, lane, 64);
+    load_state_tile<64>(X.C, bx, by, bz, stile, lane);
     if (lane == 0) bcount = 0u;
     __syncthreads();
     const int gx = bx * BS + cx, gy = by * BS + cy, gz = bz * BS + cz;  // base node of this lane's cell
@@ -116,16 +144,30 @@ __global__ __launch_bounds__(64, MPM_RIGID_P2G_MINW) void k_p2g_rigid(Params P, 
           const uint32_t slot = atomicAdd(&bcount, 1u);
           if (slot < (uint32_t)P2GR_LIST) blist[slot] = ((p - blk0) << 6) | (uint32_t)lane;
         }
+        // k_p2g's scatter (k_p2g.h: the contribution stepped from node to node by the columns of the affine matrix, on packed
+        // fp32 pairs, the mass riding along) with the weight of the skipped nodes set to zero
+        const f2 a0xy = {A00, A10}, a0zw = {A20, 0.0f}, a1xy = {A01, A11}, a1zw = {A21, 0.0f}, a2xy = {A02, A12}, a2zw = {A22, 0.0f};
+        f2 cixy = {fmaf(A02, r2, fmaf(A01, r1, fmaf(A00, r0, mv0))), fmaf(A12, r2, fmaf(A11, r1, fmaf(A10, r0, mv1)))};
+        f2 cizw = {fmaf(A22, r2, fmaf(A21, r1, fmaf(A20, r0, mv2))), mass};
 #pragma unroll
-        for (int n = 0; n < 27; n++) {
-          const int i3 = n / 9, j = (n / 3) % 3, k = n % 3;
-          const float w = ((other >> n) & 1u) ? 0.0f : (w0[i3] * w1[j]) * w2[k];
-          const float d0 = r0 - (float)i3, d1 = r1 - (float)j, d2 = r2 - (float)k;
-          const float c0 = fmaf(A02, d2, fmaf(A01, d1, fmaf(A00, d0, mv0)));
-          const float c1 = fmaf(A12, d2, fmaf(A11, d1, fmaf(A10, d0, mv1)));
-          const float c2 = fmaf(A22, d2, fmaf(A21, d1, fmaf(A20, d0, mv2)));
-          acc[n][0] = fmaf(w, c0, acc[n][0]); acc[n][1] = fmaf(w, c1, acc[n][1]);
-          acc[n][2] = fmaf(w, c2, acc[n][2]); acc[n][3] = fmaf(w, mass, acc[n][3]);
+        for (int i3 = 0; i3 < 3; i3++) {
+          f2 cjxy = cixy, cjzw = cizw;
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            const float wij = w0[i3] * w1[j];
+            f2 ckxy = cjxy, ckzw = cjzw;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              const int n = (i3 * 3 + j) * 3 + k;
+              const f2 w = splat2(((other >> n) & 1u) ? 0.0f : wij * w2[k]);
+              f2 axy = {acc[n][0], acc[n][1]}, azw = {acc[n][2], acc[n][3]};
+              axy = fma2(w, ckxy, axy); azw = fma2(w, ckzw, azw);
+              acc[n][0] = axy.x; acc[n][1] = axy.y; acc[n][2] = azw.x; acc[n][3] = azw.y;
+              if (k < 2) { ckxy -= a2xy; ckzw -= a2zw; }
+            }
+            if (j < 2) { cjxy -= a1xy; cjzw -= a1zw; }
+          }
+          if (i3 < 2) { cixy -= a0xy; cizw -= a0zw; }
         }
       }
     }
@@ -260,7 +302,7 @@ __global__ __launch_bounds__(256, MPM_RIGID_G2P_MINW) void k_g2p_rigid(Params P,
       const uint32_t fs = fat_slot[morton3(bx + (tx >> 2), by + (ty >> 2), bz + (tz >> 2))];
       tile[t] = gridv[(size_t)fs * BC + (((tx & 3) << 4) | ((ty & 3) << 2) | (tz & 3))];
     }
-    load_state_tile(X.C, bx, by, bz, stile, tid, 256);
+    load_state_tile<256>(X.C, bx, by, bz, stile, tid);
     __syncthreads();
     const float ox = (float)(bx * BS), oy = (float)(by * BS), oz = (float)(bz * BS);
     const uint32_t q0 = act_start[a] & ~ACT_RIGID_BIT, q1 = act_start[a + 1] & ~ACT_RIGID_BIT;
