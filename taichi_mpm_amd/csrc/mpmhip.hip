@@ -138,6 +138,7 @@ struct mpmhip_ctx {
   int p2g_wgs = 16384;        // workgroups of k_p2g (env MPMHIP_P2G_WGS)
   int p2g_split = 11;         // tuning knob (env MPMHIP_P2G_SPLIT): 10*NS + PS, see do_p2g
   int g2p_wgs = 4096;         // workgroups of k_g2p (env MPMHIP_G2P_WGS)
+  int rigid_wgs = 2048;       // workgroups of k_p2g_rigid (one per wave slot of the device), twice those of k_g2p_rigid (env MPMHIP_RIGID_WGS: tuning)
   uint32_t rank_runs_mul = 3; // k_rank takes its LDS-hash path when runs * this > slots (env MPMHIP_RANK_RUNS_MUL: tuning)
   int ct_blocks = 0;          // blocks per chunk of k_cell_table: 0 by size, 16, 64 (env MPMHIP_CT_BLOCKS: tuning)
   int g2p2g_wgs = 4096;       // ... of its fused form (env MPMHIP_G2P2G_WGS)
@@ -416,6 +417,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   c->device = cfg->device;
   if (const char *e = getenv("MPMHIP_G2P_MINW")) c->g2p_minw = atoi(e);
   if (const char *e = getenv("MPMHIP_G2P_WGS")) c->g2p_wgs = atoi(e) > 0 ? atoi(e) : 4096;
+  if (const char *e = getenv("MPMHIP_RIGID_WGS")) c->rigid_wgs = atoi(e) > 1 ? atoi(e) : 2048;
   if (const char *e = getenv("MPMHIP_RANK_RUNS_MUL")) c->rank_runs_mul = (uint32_t)atoi(e);
   if (const char *e = getenv("MPMHIP_CT_BLOCKS")) c->ct_blocks = atoi(e);
   if (const char *e = getenv("MPMHIP_G2P2G_WGS")) c->g2p2g_wgs = atoi(e) > 0 ? atoi(e) : 4096;
@@ -1005,7 +1007,7 @@ static int do_p2g(mpmhip_ctx *c, int phase = 0) {
 #undef MPM_ONE_MATERIAL
       default: break;
     }
-    hipLaunchKernelGGL(rk, dim3(4096), dim3(64), 0, c->stream, c->P, (const float4 *)c->rp, (const float4 *)c->rg, c->cnt,
+    hipLaunchKernelGGL(rk, dim3(c->rigid_wgs), dim3(64), 0, c->stream, c->P, (const float4 *)c->rp, (const float4 *)c->rg, c->cnt,
                        c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles, rigid_xfer(c));
     if (int rc = do_rigid_apply_tmp(c)) return rc;
   }
@@ -1106,7 +1108,7 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0, bool fused = false) {
 #undef MPM_ONE_MATERIAL
       default: break;
     }
-    hipLaunchKernelGGL(rk, dim3(2048), dim3(256), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
+    hipLaunchKernelGGL(rk, dim3(c->rigid_wgs / 2), dim3(256), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
                        (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
                        c->blk_flag, (const LevelSetDev *)c->d_LS, rigid_xfer(c));
     if (int rc = do_rigid_apply_tmp(c)) return rc;
