@@ -4,8 +4,8 @@ material particles.  Round 2, one MI355X: 1.81 ms per substep (0.59 ms without b
 k_g2p (blocks away from bodies) 0.37, k_g2p_rigid 0.34, k_p2g 0.15, k_gather_cdf 0.15, k_cdf_alloc + k_cdf_rasterize 0.09 ms.
 Round 3: 1.52 ms — k_p2g_rigid 0.38 (its impulse part moved behind the scatter: 43 -> 7 spilled registers; the bodies' kinematic
 fields mirrored in LDS), k_g2p_rigid 0.32, k_g2p 0.30, k_gather_cdf 0.15, k_p2g 0.14, CDF 0.09; later in round 3 1.30-1.33 ms —
-flagged blocks as a list, per-material kernels, boundary particles listed for the impulse pass: k_p2g_rigid 0.25, k_g2p_rigid 0.25
-(profiles/r03_p_cpic.txt).
+flagged blocks as a list, per-material kernels, boundary particles listed for the impulse pass: k_p2g_rigid 0.25, k_g2p_rigid 0.25;
+then 1.17 ms with the colour-aware kernels on a second stream beside the plain ones (profiles/r03_p_cpic.txt).
     python profiles/cpic_scene_8m.py"""
 import sys, time; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np

@@ -231,6 +231,9 @@ struct mpmhip_ctx {
     CdfDev cdf{};
     BndRec *d_bnd = nullptr;
     uint8_t *d_blk_rigid = nullptr;
+    hipStream_t side = nullptr;          // the colour-aware transfer kernels run here, next to the plain ones on the ctx stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool concurrent = true;              // (env MPMHIP_RIGID_CONCURRENT=0: one stream)
     uint32_t *d_rigid_list = nullptr;  // [max_blocks + 1] the flagged blocks as a list; its length is d_counters[CDF_POOLS + 1]
     uint32_t *d_counters = nullptr;  // [0, CDF_POOLS) pages handed out per sub-pool, [CDF_POOLS] cutting_counter
     uint32_t max_pages = 0;
@@ -417,6 +420,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   c->device = cfg->device;
   if (const char *e = getenv("MPMHIP_G2P_MINW")) c->g2p_minw = atoi(e);
   if (const char *e = getenv("MPMHIP_G2P_WGS")) c->g2p_wgs = atoi(e) > 0 ? atoi(e) : 4096;
+  if (const char *e = getenv("MPMHIP_RIGID_CONCURRENT")) c->rigid.concurrent = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_RIGID_WGS")) c->rigid_wgs = atoi(e) > 1 ? atoi(e) : 2048;
   if (const char *e = getenv("MPMHIP_RANK_RUNS_MUL")) c->rank_runs_mul = (uint32_t)atoi(e);
   if (const char *e = getenv("MPMHIP_CT_BLOCKS")) c->ct_blocks = atoi(e);
@@ -548,7 +552,8 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   hipFree(c->tiles8); hipFree(c->bits_prev); hipFree(c->wprefix_prev);
   hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_LS); hipFree(c->d_counts); hipFree(c->d_bounds); if (c->h_pinned) hipHostFree(c->h_pinned); hipFree(c->d_energy);
   { auto &R = c->rigid; hipFree(R.d_rb); hipFree(R.d_smp); hipFree(R.d_elems); hipFree(R.cdf.slot); hipFree(R.cdf.page_key); hipFree(R.cdf.mind);
-    hipFree(R.cdf.tags); hipFree(R.cdf.rpage); hipFree(R.d_bnd); hipFree(R.d_blk_rigid); hipFree(R.d_rigid_list); hipFree(R.d_counters); hipFree(R.d_joints); }
+    hipFree(R.cdf.tags); hipFree(R.cdf.rpage); hipFree(R.d_bnd); if (R.side) { hipStreamSynchronize(R.side); hipStreamDestroy(R.side); } if (R.ev_fork) hipEventDestroy(R.ev_fork); if (R.ev_join) hipEventDestroy(R.ev_join);
+    hipFree(R.d_blk_rigid); hipFree(R.d_rigid_list); hipFree(R.d_counters); hipFree(R.d_joints); }
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -966,6 +971,29 @@ static int do_reorder(mpmhip_ctx *c) {
 
 static RigidXfer rigid_xfer(mpmhip_ctx *c);
 // bit t set = some particle group of the ctx is of material type t
+// The plain transfer kernel (every block away from the bodies) and the colour-aware one (the flagged blocks) touch disjoint
+// blocks and particles, and each is latency-bound at two waves per SIMD: they run side by side, the colour-aware kernel on a
+// second stream that waits for what the ctx stream has enqueued so far (fork) and is waited for before anything else (join).
+static int rigid_fork(mpmhip_ctx *c, hipStream_t *s) {
+  auto &R = c->rigid;
+  *s = c->stream;
+  if (!R.concurrent) return MPMHIP_OK;
+  if (!R.side) {
+    HIPCHK(c, hipStreamCreateWithFlags(&R.side, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&R.ev_fork, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&R.ev_join, hipEventDisableTiming));
+  }
+  HIPCHK(c, hipEventRecord(R.ev_fork, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(R.side, R.ev_fork, 0));
+  *s = R.side;
+  return MPMHIP_OK;
+}
+static int rigid_join(mpmhip_ctx *c, hipStream_t s) {
+  if (s == c->stream) return MPMHIP_OK;
+  HIPCHK(c, hipEventRecord(c->rigid.ev_join, s));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->rigid.ev_join, 0));
+  return MPMHIP_OK;
+}
 static uint32_t material_mask(const mpmhip_ctx *c) {
   uint32_t mask = 0;
   for (const GroupParams &g : c->groups) mask |= 1u << (g.type & 31);
@@ -995,6 +1023,8 @@ static int do_p2g(mpmhip_ctx *c, int phase = 0) {
 #endif
   const bool rigid = rigid_active(c);
   if (rigid) { kern = k_p2g<1, 1, 2, true>; nt = 64; }
+  hipStream_t rs = c->stream;
+  if (rigid) { if (int rc = rigid_fork(c, &rs)) return rc; }
   hipLaunchKernelGGL(kern, dim3(c->p2g_wgs), dim3(nt), 0, c->stream, c->P,
                      (const float4 *)c->rp, c->cnt, c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles, c->T, phase,
                      rigid ? (const uint8_t *)c->rigid.d_blk_rigid : (const uint8_t *)nullptr);
@@ -1007,8 +1037,9 @@ static int do_p2g(mpmhip_ctx *c, int phase = 0) {
 #undef MPM_ONE_MATERIAL
       default: break;
     }
-    hipLaunchKernelGGL(rk, dim3(c->rigid_wgs), dim3(64), 0, c->stream, c->P, (const float4 *)c->rp, (const float4 *)c->rg, c->cnt,
+    hipLaunchKernelGGL(rk, dim3(c->rigid_wgs), dim3(64), 0, rs, c->P, (const float4 *)c->rp, (const float4 *)c->rg, c->cnt,
                        c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles, rigid_xfer(c));
+    if (int rc = rigid_join(c, rs)) return rc;
     if (int rc = do_rigid_apply_tmp(c)) return rc;
   }
   return launch_check(c, "p2g");
@@ -1080,6 +1111,8 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0, bool fused = false) {
     }
   }
   const int write_p = (fused && c->defer_p) ? 0 : 1;
+  hipStream_t rs = c->stream;
+  if (rigid) { if (int rc = rigid_fork(c, &rs)) return rc; }
 #ifdef MPMHIP_WITH_FUSED
   if (fused) {  // G2P + the next substep's P2G in one kernel (k_g2p2g.h), same material-set tiers
     auto fk = no_visco ? k_g2p2g<256, MPM_G2P_MINW_FUSED, true, false, false, NO_VISCO> : k_g2p2g<256, 2, true, false, false, MAT_ALL>;
@@ -1108,9 +1141,10 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0, bool fused = false) {
 #undef MPM_ONE_MATERIAL
       default: break;
     }
-    hipLaunchKernelGGL(rk, dim3(c->rigid_wgs / 2), dim3(256), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
+    hipLaunchKernelGGL(rk, dim3(c->rigid_wgs / 2), dim3(256), 0, rs, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
                        (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
                        c->blk_flag, (const LevelSetDev *)c->d_LS, rigid_xfer(c));
+    if (int rc = rigid_join(c, rs)) return rc;
     if (int rc = do_rigid_apply_tmp(c)) return rc;
   }
   c->sorted = false;       // positions moved
@@ -1232,8 +1266,12 @@ int mpmhip_substep_begin(mpmhip_ctx *c) {
     ev->ov = c->ov_active;
     if (lvl == 1 || lvl == 4) HIPCHK(c, hipEventRecord(ev->e[0], c->stream));
   }
+  // articulate + rasterize_rigid_boundary (src/mpm.cpp:466-472) next to the sort, gather_cdf (:506-508) behind both
+  const bool bodies = rigid_active(c);
+  hipStream_t rs = c->stream;
+  if (bodies && ((rc = rigid_fork(c, &rs)) || (rc = do_rigid_pre_a(c, rs)))) return rc;
   if ((rc = do_sort(c))) return rc;
-  if (rigid_active(c) && (rc = do_rigid_pre(c))) return rc;  // rasterize_rigid_boundary, gather_cdf (src/mpm.cpp:466-472,506-508)
+  if (bodies && ((rc = rigid_join(c, rs)) || (rc = do_rigid_pre_b(c)))) return rc;
   if (ev && (lvl == 1 || lvl == 3)) HIPCHK(c, hipEventRecord(ev->e[1], c->stream));
   if (!c->tiles8_valid && (rc = do_p2g(c, c->ov_active ? 1 : 0))) return rc;  // (fused: the previous G2P already did it)
   if (ev && lvl == 3) HIPCHK(c, hipEventRecord(ev->e[2], c->stream));

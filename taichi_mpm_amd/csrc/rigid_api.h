@@ -213,11 +213,19 @@ static int do_rigid_articulate(mpmhip_ctx *c, float dt) {
                      (int)R.joints.size(), dt, R.joint_iterations);
   return launch_check(c, "articulate");
 }
-static int do_rigid_pre(mpmhip_ctx *c) {
+// In two halves: (a) the joints and the colored distance field depend on the bodies alone — substep_begin runs them on the
+// side stream NEXT TO the particle sort; (b) the particles' colours and the block flags need both the field and the sort.
+static int do_rigid_pre_a(mpmhip_ctx *c, hipStream_t on) {
+  hipStream_t keep = c->stream;
+  c->stream = on;  // (the launch helpers below enqueue on the ctx's stream)
   int rc;
-  if ((rc = do_rigid_articulate(c, c->P.dt)) || (rc = do_rigid_rasterize(c)) || (rc = do_rigid_gather(c)) ||
-      (rc = do_rigid_block_flags(c)))
-    return rc;
+  if (!(rc = do_rigid_articulate(c, c->P.dt))) rc = do_rigid_rasterize(c);
+  c->stream = keep;
+  return rc;
+}
+static int do_rigid_pre_b(mpmhip_ctx *c) {
+  int rc;
+  if ((rc = do_rigid_gather(c)) || (rc = do_rigid_block_flags(c))) return rc;
   return MPMHIP_OK;
 }
 
