@@ -3,12 +3,6 @@
 #pragma once
 #include "mpm_common.h"
 
-#ifndef MPM_FENCE_A
-#define MPM_FENCE_A
-#endif
-#ifndef MPM_FENCE_B
-#define MPM_FENCE_B
-#endif
 namespace mpm {
 
 // ------------------------------------------------------------------------------------------------ G2P
@@ -139,10 +133,6 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
     const uint32_t i_nn = lane_slot(nn);
     uint32_t bkey = INVALID, out_slot = INVALID;
     auto particle = [&](const GroupParams &g) __attribute__((always_inline)) {
-#ifdef MPM_KEEP_UNUSED
-      const size_t i = i_cur;
-      (void)i;
-#endif
       const float x0 = g0.x, x1 = g0.y, x2 = g0.z;
       const float X0 = x0 * P.idx - ox, X1 = x1 * P.idx - oy, X2 = x2 * P.idx - oz;
       const int c0 = (int)(X0 - 0.5f), c1 = (int)(X1 - 0.5f), c2 = (int)(X2 - 0.5f);
@@ -182,11 +172,9 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
         b1xy = fma2(splat2(w0i), T1xy, b1xy); b1zw = fma2(splat2(w0i), T1zw, b1zw);
         b2xy = fma2(splat2(w0i), T2xy, b2xy); b2zw = fma2(splat2(w0i), T2zw, b2zw);
       };
-      MPM_FENCE_A;
       if (!MPM_ABLATE(P, 4)) {
         plane(0, w0[0], e0[0]); plane(1, w0[1], e0[1]); plane(2, w0[2], e0[2]);
       }
-      MPM_FENCE_A;
       float v0 = vxy.x, v1 = vxy.y, v2 = vzw.x;
       mat3 b;
       b(0, 0) = b0xy.x; b(1, 0) = b0xy.y; b(2, 0) = b0zw.x;
@@ -216,10 +204,8 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
       F.m[7] = g2.w; F.m[8] = g3.x;
       float aux = g0.w;
       mat3 stress;
-      MPM_FENCE_B;
       if (!MPM_ABLATE(P, 2)) plasticity_and_force<MATS>(g, cdg, F, aux, stress);  // :950 + next substep's :509
       else stress = cdg;
-      MPM_FENCE_B;
       float nx0 = fmaf(v0, P.dt, x0), nx1 = fmaf(v1, P.dt, x1), nx2 = fmaf(v2, P.dt, x2);  // :951
       if (P.clamp_pos) {  // generic path only (optimized = false): p.pos clamped into [0, res - eps], :668-670
         nx0 = fminf(fmaxf(nx0 * P.idx, 0.0f), (float)P.res[0] - 1e-6f) * P.dx;
