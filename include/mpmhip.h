@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MPMHIP_ABI_VERSION 1
+#define MPMHIP_ABI_VERSION 2  /* 2: mpmhip_async_config gained left_boundary */
 
 enum {
   MPMHIP_OK = 0,
