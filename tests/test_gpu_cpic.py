@@ -683,3 +683,35 @@ def test_a_raising_script_surfaces_and_two_free_bodies_warn(tm):
     with pytest.warns(RuntimeWarning, match="rigid-rigid"):
         sim.add_particles(dict(type="rigid", mesh=cs.box(), codimensional=False, density=400.0, initial_position=(0.3, 0.7, 0.3)))
     sim.close()
+
+
+def test_one_stream_and_two_streams_give_the_same_run(tm, monkeypatch):
+    """The colour-aware transfer kernels run on a second stream beside the plain ones (mpmhip.hip: rigid_fork / rigid_join;
+    MPMHIP_RIGID_CONCURRENT=0 puts everything on the ctx stream): disjoint blocks and particles, so the two ways must agree up
+    to the order of the float atomics that sum the impulses on a free body."""
+    from tests.common import lattice_cube
+    res, dx = 64, 1.0 / 64
+    x = lattice_cube(res, 20, 44, dx, jitter=0.15, seed=5)
+
+    def run(flag):
+        monkeypatch.setenv("MPMHIP_RIGID_CONCURRENT", flag)  # (read when the ctx is created)
+        sim = tm.create_simulation3("mpm").initialize(dict(res=(res,) * 3, delta_x=dx, base_delta_t=1e-4, gravity=(0, -10, 0),
+                                                           max_particles=len(x) + 16))
+        wheel = int(sim.add_particles(dict(type="rigid", mesh=paddle(0.2, 0.15), codimensional=True, friction=-2,
+                                           scripted_position=lambda t: (0.5, 0.5, 0.5), scripted_rotation=lambda t: (0.0, 0.0, 720.0 * t))))
+        free = int(sim.add_particles(dict(type="rigid", mesh=cs.box() * 0.5, codimensional=False, friction=0.3, density=40.0,
+                                          initial_position=(0.5, 0.72, 0.5))))
+        sim.add_particles(dict(type="sand", positions=x))
+        sim.run_substeps(40)
+        p = sim.get_particles(sort_by_id=True)
+        st = sim.get_rigid_state(free)
+        sim.close()
+        assert wheel != free
+        return p, st
+    (a, sa), (b, sb) = run("1"), run("0")
+    assert (a["states"] != 0).sum() > 1000, "the scene must colour particles"
+    assert np.array_equal(a["id"], b["id"])
+    assert np.abs(a["x"] - b["x"]).max() <= 2e-6 and rel_l2(a["v"], b["v"]) <= 1e-4 and rel_l2(a["F"], b["F"]) <= 1e-5
+    assert (a["states"] != b["states"]).sum() <= 5
+    np.testing.assert_allclose(sa["velocity"], sb["velocity"], atol=2e-5)
+    np.testing.assert_allclose(sa["position"], sb["position"], atol=1e-6)

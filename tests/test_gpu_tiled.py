@@ -132,6 +132,44 @@ def test_k_tiles_reproduce_one_tile(tm, world, dims, overlap):
         sim.close()
 
 
+@pytest.mark.parametrize("overlap", [False, True], ids=["serial", "overlap_split"])
+def test_profiling_level_4_brackets_the_parts_of_a_tiled_substep(tm, overlap):
+    """mpmhip_set_profiling(4): begin / interior / end of a tiled substep bracketed as wholes (include/mpmhip.h) — "p2g" holds
+    the begin part, "grid" the interior part (only when the substep is split), "g2p" the end part; nothing is recorded inside
+    a part, and the run is the one an unprofiled job does."""
+    from taichi_mpm_amd import tiled
+    s = _two_material_state()
+    n, ids = s.n, np.arange(s.n)
+    part = tiled.Partition.balanced((RES,) * 3, 2, s.x, DX, margin=2)
+    owner = part.rank_of_cells(tiled.base_cells(s.x, DX))
+
+    def run(level):
+        sims = [_sim(tm, s, owner == r, ids, n + 1024) for r in range(2)]
+        job = tiled.VirtualTiledJob([tiled.HipEngine(sim, 0) for sim in sims], part, migrate_interval=2, overlap=overlap)
+        for sim in sims:
+            sim.set_profiling(level)
+            sim.profile(reset=True)
+        job.run(6)
+        profs = [sim.profile() for sim in sims]
+        got = _gather(sims)
+        for sim in sims:
+            sim.close()
+        return profs, got
+    profs, got = run(4)
+    _, plain = run(0)
+    for p in profs:
+        ph = p["phases"]
+        assert p["substeps"] == 6 and ph["sort"] == 0.0
+        assert ph["p2g"] > 0.0 and ph["g2p"] > 0.0 and (ph["grid"] > 0.0) == overlap
+    assert np.array_equal(got["id"], plain["id"]) and np.abs(got["x"] - plain["x"]).max() <= 1e-6
+    with pytest.raises(Exception):
+        s0 = _sim(tm, s, owner == 0, ids, n + 1024)
+        try:
+            s0.set_profiling(5)
+        finally:
+            s0.close()
+
+
 def test_c5_clusters_over_8_virtual_ranks_reproduce_one_ctx(tm):
     """BASELINE configs[4] on more than one GPU (reduced: 64^3 grid, 8 clusters of 12^3 cells x 8, water / Hencky-elastic
     alternating): the builders bench.py uses for `--config c5 --gpus 8` — every rank registers all 8 groups, balanced
