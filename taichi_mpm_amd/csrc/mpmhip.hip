@@ -979,7 +979,11 @@ static int rigid_fork(mpmhip_ctx *c, hipStream_t *s) {
   *s = c->stream;
   if (!R.concurrent) return MPMHIP_OK;
   if (!R.side) {
-    HIPCHK(c, hipStreamCreateWithFlags(&R.side, hipStreamNonBlocking));
+    // the highest priority: the colour-aware kernels are the longer ones of a pair and get their wave slots first
+    // (8 M scene: 1.163 -> 1.150 ms per substep against the default priority)
+    int lo = 0, hi = 0;  // (numerically lower = higher priority)
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    HIPCHK(c, hipStreamCreateWithPriority(&R.side, hipStreamNonBlocking, hi));
     HIPCHK(c, hipEventCreateWithFlags(&R.ev_fork, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&R.ev_join, hipEventDisableTiming));
   }
