@@ -233,7 +233,7 @@ struct mpmhip_ctx {
     uint8_t *d_blk_rigid = nullptr;
     hipStream_t side = nullptr;          // the colour-aware transfer kernels run here, next to the plain ones on the ctx stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool concurrent = true;              // (env MPMHIP_RIGID_CONCURRENT=0: one stream)
+    int concurrent = 7;                  // which pairs run side by side: 1 P2G, 2 G2P, 4 rasterisation | sort (env MPMHIP_RIGID_CONCURRENT; 0: one stream)
     uint32_t *d_rigid_list = nullptr;  // [max_blocks + 1] the flagged blocks as a list; its length is d_counters[CDF_POOLS + 1]
     uint32_t *d_counters = nullptr;  // [0, CDF_POOLS) pages handed out per sub-pool, [CDF_POOLS] cutting_counter
     uint32_t max_pages = 0;
@@ -420,7 +420,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   c->device = cfg->device;
   if (const char *e = getenv("MPMHIP_G2P_MINW")) c->g2p_minw = atoi(e);
   if (const char *e = getenv("MPMHIP_G2P_WGS")) c->g2p_wgs = atoi(e) > 0 ? atoi(e) : 4096;
-  if (const char *e = getenv("MPMHIP_RIGID_CONCURRENT")) c->rigid.concurrent = atoi(e) != 0;
+  if (const char *e = getenv("MPMHIP_RIGID_CONCURRENT")) c->rigid.concurrent = atoi(e);
   if (const char *e = getenv("MPMHIP_RIGID_WGS")) c->rigid_wgs = atoi(e) > 1 ? atoi(e) : 2048;
   if (const char *e = getenv("MPMHIP_RANK_RUNS_MUL")) c->rank_runs_mul = (uint32_t)atoi(e);
   if (const char *e = getenv("MPMHIP_CT_BLOCKS")) c->ct_blocks = atoi(e);
@@ -974,10 +974,10 @@ static RigidXfer rigid_xfer(mpmhip_ctx *c);
 // The plain transfer kernel (every block away from the bodies) and the colour-aware one (the flagged blocks) touch disjoint
 // blocks and particles, and each is latency-bound at two waves per SIMD: they run side by side, the colour-aware kernel on a
 // second stream that waits for what the ctx stream has enqueued so far (fork) and is waited for before anything else (join).
-static int rigid_fork(mpmhip_ctx *c, hipStream_t *s) {
+static int rigid_fork(mpmhip_ctx *c, hipStream_t *s, int which) {
   auto &R = c->rigid;
   *s = c->stream;
-  if (!R.concurrent) return MPMHIP_OK;
+  if (!(R.concurrent & which)) return MPMHIP_OK;
   if (!R.side) {
     // the highest priority: the colour-aware kernels are the longer ones of a pair and get their wave slots first
     // (8 M scene: 1.163 -> 1.150 ms per substep against the default priority)
@@ -1028,7 +1028,7 @@ static int do_p2g(mpmhip_ctx *c, int phase = 0) {
   const bool rigid = rigid_active(c);
   if (rigid) { kern = k_p2g<1, 1, 2, true>; nt = 64; }
   hipStream_t rs = c->stream;
-  if (rigid) { if (int rc = rigid_fork(c, &rs)) return rc; }
+  if (rigid) { if (int rc = rigid_fork(c, &rs, 1)) return rc; }
   hipLaunchKernelGGL(kern, dim3(c->p2g_wgs), dim3(nt), 0, c->stream, c->P,
                      (const float4 *)c->rp, c->cnt, c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles, c->T, phase,
                      rigid ? (const uint8_t *)c->rigid.d_blk_rigid : (const uint8_t *)nullptr);
@@ -1116,7 +1116,7 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0, bool fused = false) {
   }
   const int write_p = (fused && c->defer_p) ? 0 : 1;
   hipStream_t rs = c->stream;
-  if (rigid) { if (int rc = rigid_fork(c, &rs)) return rc; }
+  if (rigid) { if (int rc = rigid_fork(c, &rs, 2)) return rc; }
 #ifdef MPMHIP_WITH_FUSED
   if (fused) {  // G2P + the next substep's P2G in one kernel (k_g2p2g.h), same material-set tiers
     auto fk = no_visco ? k_g2p2g<256, MPM_G2P_MINW_FUSED, true, false, false, NO_VISCO> : k_g2p2g<256, 2, true, false, false, MAT_ALL>;
@@ -1273,7 +1273,7 @@ int mpmhip_substep_begin(mpmhip_ctx *c) {
   // articulate + rasterize_rigid_boundary (src/mpm.cpp:466-472) next to the sort, gather_cdf (:506-508) behind both
   const bool bodies = rigid_active(c);
   hipStream_t rs = c->stream;
-  if (bodies && ((rc = rigid_fork(c, &rs)) || (rc = do_rigid_pre_a(c, rs)))) return rc;
+  if (bodies && ((rc = rigid_fork(c, &rs, 4)) || (rc = do_rigid_pre_a(c, rs)))) return rc;
   if ((rc = do_sort(c))) return rc;
   if (bodies && ((rc = rigid_join(c, rs)) || (rc = do_rigid_pre_b(c)))) return rc;
   if (ev && (lvl == 1 || lvl == 3)) HIPCHK(c, hipEventRecord(ev->e[1], c->stream));

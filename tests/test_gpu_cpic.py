@@ -708,7 +708,7 @@ def test_one_stream_and_two_streams_give_the_same_run(tm, monkeypatch):
         sim.close()
         assert wheel != free
         return p, st
-    (a, sa), (b, sb) = run("1"), run("0")
+    (a, sa), (b, sb) = run("7"), run("0")
     assert (a["states"] != 0).sum() > 1000, "the scene must colour particles"
     assert np.array_equal(a["id"], b["id"])
     assert np.abs(a["x"] - b["x"]).max() <= 2e-6 and rel_l2(a["v"], b["v"]) <= 1e-4 and rel_l2(a["F"], b["F"]) <= 1e-5
