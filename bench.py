@@ -7,8 +7,9 @@ BASELINE.json's metric is quoted on: config C3 = 256^3 grid, 100^3 cells x 8 = 8
 particles, fp32, inputs resident in HBM before the timed region.
 
 Sequence:  W warm-up substeps (untimed) | a short untimed pass with every phase bracketed by hipEvents (phase
-table, picks the dominant kernel) | barrier | K timed substeps, only the dominant kernel bracketed (two event
-records per substep; bracketing all phases would add ~20 us of idle GPU per substep) | barrier.
+table, picks the dominant kernel) | barrier | K timed substeps, only the dominant kernel bracketed and only in every 4th of
+them (an event record idles the GPU for ~5 us: bracketing all phases would add ~20 us per substep, the dominant kernel in
+every substep 2 % of a C3 substep; roofline.launches_timed says how many launches the mean is over) | barrier.
 
 N > 1 (bricks + halo exchange): before that sequence the boundary / interior split of the substep (it hides
 the exchange behind the interior kernels at the price of three more launches) is timed on and off over a dozen untimed
@@ -57,6 +58,7 @@ CONFIGS = {
     "c5": dict(res=512, cells=100, material="water+elastic", cpu_material="water", clusters=(78, 334), dt=5e-5,
                desc="512^3 sparse blocked grid, 8 clusters of 100^3 cells x 8 = 64M particles, 4 water + 4 Hencky-elastic (BASELINE configs[4])"),
 }
+PROFILE_EVERY = int(os.environ.get("MPMHIP_BENCH_PROFILE_EVERY", "4"))  # the dominant kernel is timed in every 4th substep of the timed region
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -192,8 +194,8 @@ class SingleJob:
     def synchronize(self):
         self.sim.synchronize()
 
-    def set_profiling(self, level):
-        self.sim.set_profiling(level)
+    def set_profiling(self, level, every=1):
+        self.sim.set_profiling(level, every)
         self.sim.profile(reset=True)
 
     def profile(self):
@@ -480,7 +482,9 @@ def main():
         phase_prof = job.profile()
         pms = {k: v / max(phase_prof["substeps"], 1) for k, v in phase_prof["phases"].items()}
         dom = "g2p" if pms["g2p"] >= pms["p2g"] else "p2g"
-        job.set_profiling(2 if dom == "g2p" else 3)  # timed region: only the dominant kernel is bracketed
+        # timed region: only the dominant kernel is bracketed, and only in every PROFILE_EVERY-th substep (a hipEventRecord idles
+        # the GPU for ~5 us; two per substep would be 2 % of a C3 substep spent on the measurement itself)
+        job.set_profiling(2 if dom == "g2p" else 3, every=PROFILE_EVERY if steps >= 4 * PROFILE_EVERY else 1)
         barrier()
         t0 = time.perf_counter()
         job.run(steps)
@@ -503,7 +507,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": (tbytes / (ms[dom] * 1e-3) / 1e9) if tbytes else None,
                 "traffic_bytes_per_launch": tbytes, "traffic_source": tsrc,
-                "algorithmic_bytes_per_launch": per_launch[dom], "avg_launch_ms": ms[dom]}
+                "algorithmic_bytes_per_launch": per_launch[dom], "avg_launch_ms": ms[dom],
+                "launches_timed": prof["substeps"]}  # (every PROFILE_EVERY-th substep of the timed region)
         both = (per_launch["p2g"] + per_launch["g2p"]) / ((ms["p2g"] + ms["g2p"]) * 1e-3) / 1e9 / HBM_PEAK_GBS
         return roof, both, n_per_gpu, nodes
 

@@ -221,6 +221,10 @@ int mpmhip_write_bgeo(mpmhip_ctx *ctx, const char *path, int32_t verbose);
  *   in-cell ranking path the next sort will take: 0 per-run atomics, 1 per-batch LDS hash; "exchange" is
  *   the gap between substep_begin and substep_end of a tiled run; phases not bracketed at the level stay 0). */
 int mpmhip_set_profiling(mpmhip_ctx *ctx, int32_t level);
+/* levels 2 / 3: bracket the kernel only in every `every`-th substep (default 1 = all).  "substeps" of mpmhip_profile then
+ * counts the bracketed ones, so phase time / substeps stays the mean launch duration — with a quarter of the ~5 us event
+ * bubbles inside a throughput measurement at every = 4. */
+int mpmhip_set_profile_sampling(mpmhip_ctx *ctx, int32_t every);
 int mpmhip_profile(mpmhip_ctx *ctx, char *json, size_t cap);
 int mpmhip_profile_reset(mpmhip_ctx *ctx);
 

@@ -133,7 +133,7 @@ def build_variant(name, extra_flags):
 
 _lib = None
 
-_SYMBOLS = ["mpmhip_abi_version", "mpmhip_create", "mpmhip_destroy", "mpmhip_last_error", "mpmhip_set_stream", "mpmhip_set_levelset", "mpmhip_set_levelset_shapes", "mpmhip_set_levelset_keyframes",
+_SYMBOLS = ["mpmhip_abi_version", "mpmhip_set_profile_sampling", "mpmhip_create", "mpmhip_destroy", "mpmhip_last_error", "mpmhip_set_stream", "mpmhip_set_levelset", "mpmhip_set_levelset_shapes", "mpmhip_set_levelset_keyframes",
             "mpmhip_add_group", "mpmhip_add_particles", "mpmhip_num_particles", "mpmhip_download",
             "mpmhip_upload", "mpmhip_substep", "mpmhip_run_substeps", "mpmhip_step", "mpmhip_current_time",
             "mpmhip_synchronize", "mpmhip_sort", "mpmhip_p2g", "mpmhip_grid_update", "mpmhip_g2p",
@@ -303,6 +303,7 @@ def load():
     L.mpmhip_snapshot_save.argtypes = [vp, vp, C.c_size_t]
     L.mpmhip_snapshot_load.argtypes = [vp, vp, C.c_size_t]
     L.mpmhip_set_profiling.argtypes = [vp, C.c_int32]
+    L.mpmhip_set_profile_sampling.argtypes = [vp, C.c_int32]
     L.mpmhip_profile.argtypes = [vp, C.c_char_p, C.c_size_t]
     up = P(C.c_uint32)
     L.mpmhip_set_rigid_coupling.argtypes = [vp, C.c_float, C.c_float]

@@ -155,6 +155,7 @@ struct mpmhip_ctx {
   double phase_ms[PH_COUNT] = {0, 0, 0, 0, 0};
   int64_t prof_substeps = 0;
   int ev_level = 0;  // level the pooled events were recorded with
+  int prof_every = 1;  // levels 2 / 3: bracket the kernel in every prof_every-th substep only (mpmhip_set_profile_sampling)
   Ev *cur_ev = nullptr;  // events of the substep between substep_begin and substep_end
   // tiling
   LevelSetDev LS;
@@ -1261,9 +1262,10 @@ int mpmhip_substep_begin(mpmhip_ctx *c) {
   if (c->in_substep) return fail(c, MPMHIP_EINVAL, "substep_begin called twice without substep_end");
   int rc;
   mpmhip_ctx::Ev *ev = nullptr;
-  const int lvl = c->profiling;
+  int lvl = c->profiling;
   c->ov_active = c->overlap && c->T.n_boxes > 0 && lvl != 1;
   c->interior_done = false;
+  if ((lvl == 2 || lvl == 3) && c->prof_every > 1 && (c->substeps % c->prof_every) != 0) lvl = 0;  // not a sampled substep
   if (lvl) {
     if (c->ev_used >= 4096 && (rc = collect_events(c))) return rc;
     if ((rc = get_events(c, &ev))) return rc;
@@ -1765,6 +1767,11 @@ int mpmhip_set_profiling(mpmhip_ctx *c, int32_t level) {
   c->profiling = level;
   c->ev_level = level;
   return rc;
+}
+int mpmhip_set_profile_sampling(mpmhip_ctx *c, int32_t every) {
+  if (!c || every < 1) return MPMHIP_EINVAL;
+  c->prof_every = every;
+  return MPMHIP_OK;
 }
 int mpmhip_profile_reset(mpmhip_ctx *c) {
   if (!c) return MPMHIP_EINVAL;

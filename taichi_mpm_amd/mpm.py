@@ -599,9 +599,11 @@ class Simulation3D:
         self._check(self._L.mpmhip_upload(self._ctx, field, a.ctypes.data_as(C.c_void_p), len(a)))
 
     # ---------------------------------------------------------------- profiling (TC_PROFILE, src/mpm.cpp:464-572)
-    def set_profiling(self, level=1):
-        """0 off, 1 every phase, 2 only G2P, 3 only P2G (include/mpmhip.h)"""
+    def set_profiling(self, level=1, every=1):
+        """0 off, 1 every phase, 2 only G2P, 3 only P2G, 4 the parts of a tiled substep (include/mpmhip.h); every: levels 2 / 3
+        bracket the kernel in every `every`-th substep only"""
         self._ensure_ctx(); self._check(self._L.mpmhip_set_profiling(self._ctx, int(level)))
+        self._check(self._L.mpmhip_set_profile_sampling(self._ctx, int(every)))
 
     def copy_bandwidth(self, nbytes=1 << 30, iters=5):
         """GB/s (read + written) of a plain streaming copy on this GPU: the measured yardstick next to the nominal peak"""

@@ -507,8 +507,8 @@ class TiledJob:
     def synchronize(self):
         self.e.synchronize()
 
-    def set_profiling(self, level):
-        self.e.sim.set_profiling(level)
+    def set_profiling(self, level, every=1):
+        self.e.sim.set_profiling(level, every)
         self.e.sim.profile(reset=True)
 
     def profile(self):
