@@ -4,7 +4,7 @@ Two layers, as in the reference:
   * `Simulation3D` == the object `tc_core.create_simulation3('mpm')` returns (class MPM<3>, src/mpm.h:56-489):
     `initialize(config)`, `add_particles(config) -> str`, `set_levelset(ls)`, `step(dt)`,
     `get_current_time()`, `general_action(config) -> str`, `test()`, `get_debug_information()`,
-    `visualize()`, `get_mpi_world_rank()`, attribute `frame`  (scripts/async/async_mpm.py:25-32,76-287).
+    `visualize()`, `get_mpi_world_rank()`, `get_vis_resolution()`, attribute `frame`  (scripts/async/async_mpm.py:25-32,76-287).
   * `MPM` == the Python driver class scene scripts instantiate (`tc.dynamics.MPM(**kwargs)`; the twin that IS in
     the reference tree is AsyncMPM, scripts/async/async_mpm.py:17-300): kwargs config, `add_particles(**kw)`,
     `set_levelset`, `step`, `simulate`.
@@ -802,6 +802,12 @@ class Simulation3D:
 
     def get_mpi_world_rank(self):  # scripts/async/async_mpm.py:198-199
         return 0
+
+    def get_vis_resolution(self):
+        """what the reference's driver sizes its video frames with (scripts/async/async_mpm.py:79-81: `.x`, `.y`).  The
+        method lives in the absent taichi core (Simulation<dim>); here: the grid resolution in x and y."""
+        import types
+        return types.SimpleNamespace(x=int(self.res[0]), y=int(self.res[1]))
 
     def get_name(self):  # src/mpm.h:486-488
         return "mpm"

@@ -327,6 +327,10 @@ class Simulation2D:
     def get_mpi_world_rank(self):
         return 0
 
+    def get_vis_resolution(self):  # (scripts/async/async_mpm.py:79-81; see Simulation3D.get_vis_resolution)
+        import types
+        return types.SimpleNamespace(x=int(self.res[0]), y=int(self.res[1]))
+
     def add_articulation(self, cfg):
         """general_action(action='add_articulation', type='rotation', obj0=, obj1=) (src/mpm.cpp:923-933; the joint of
         scripts/mls-cpic/sand_wheel_2D.py:88): both bodies share one angular velocity.  The other joint types are 3D only."""

@@ -163,6 +163,8 @@ def test_add_particles_staging_drops_near_boundary():
     with pytest.raises(tm.MPMError):
         sim.add_particles(dict(type="jelly"))
     assert sim.test() and sim.get_name() == "mpm" and sim.get_mpi_world_rank() == 0
+    vis = sim.get_vis_resolution()  # (scripts/async/async_mpm.py:79-81 reads .x / .y)
+    assert (vis.x, vis.y) == (32, 32)
 
 
 def test_bench_and_examples_are_importable_without_a_gpu():
