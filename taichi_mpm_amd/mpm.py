@@ -18,6 +18,7 @@ rendering) is out of scope: `add_particles` takes explicit `positions=` or the b
 import ctypes as C
 import json
 import os
+import sys
 
 import numpy as np
 
@@ -849,8 +850,21 @@ class MPM:
     in-tree twin: AsyncMPM, scripts/async/async_mpm.py:17-300)."""
     simulation_name = "mpm"
 
-    def __init__(self, **kwargs):
+    def __init__(self, snapshot_interval=20, **kwargs):
         res = kwargs["res"]
+        # the reference's driver derives its output directory from task_id (tc.get_output_path, scripts/async/async_mpm.py:36-49)
+        # and injects frame_directory = <directory>/frames; here: 'output_directory' names it (default: none — nothing is written
+        # unless the script asks for it), an explicit 'frame_directory' is kept as given
+        self.snapshot_interval = snapshot_interval
+        self.task_id = kwargs.get("task_id", os.path.splitext(os.path.basename(sys.argv[0] or "mpm"))[0])
+        self.directory = kwargs.pop("output_directory", None)
+        # (snapshots every snapshot_interval frames only with an explicit output directory: a script that names just its
+        # frame_directory gets frames and nothing else)
+        self.snapshot_directory = os.path.join(self.directory, "snapshots") if self.directory is not None else None
+        if self.directory is not None:
+            kwargs.setdefault("frame_directory", os.path.join(self.directory, "frames"))
+        elif kwargs.get("frame_directory"):
+            self.directory = os.path.dirname(os.path.normpath(kwargs["frame_directory"]))
         self.frame_dt = kwargs.get("frame_dt", 0.01)
         kwargs.setdefault("frame_dt", self.frame_dt)
         self.num_frames = kwargs.get("num_frames", 1000)
@@ -908,19 +922,91 @@ class MPM:
     def visualize(self):  # scripts/async/async_mpm.py:201-202
         return self.c.visualize()
 
-    def simulate(self, num_frames=None, print_profile_info=False, frame_update=None, **_ignored):
-        """python frame loop (scripts/async/async_mpm.py:217-248): per frame step(frame_dt) [+ profile print]."""
-        if print_profile_info:
-            self.c.set_profiling(True)
+    # ---- the rest of the driver's surface (scripts/async/async_mpm.py:185-300)
+    def get_directory(self):
+        return self.directory
+
+    def make_video(self):
+        raise MPMError("make_video(): rendering is outside the scope of this build (the frames are .bgeo files)")
+
+    def test(self):
+        return self.c.test()
+
+    def get_mpi_world_rank(self):
+        return self.c.get_mpi_world_rank()
+
+    def get_debug_information(self):
+        return self.c.get_debug_information()
+
+    def clear_output_directory(self):
+        """the frames of an earlier run (.bgeo, the bodies' .obj / .poly); snapshots stay, as in the reference (:211-215)"""
+        frames = self.c.frame_directory
+        if frames and os.path.isdir(frames):
+            for f in os.listdir(frames):
+                if f.endswith((".bgeo", ".obj", ".poly")):
+                    os.remove(os.path.join(frames, f))
+
+    def delete_particles_inside_level_set(self):  # :281-284 (a dynamic level set is sampled at the current time first)
+        t = self.c.get_current_time()
+        self.update_levelset(t, t + 1)
+        self.c.general_action(dict(action="delete_particles_inside_level_set"))
+
+    def action(self, **kwargs):
+        self.c.general_action(kwargs)
+
+    def save(self, fn):
+        self.action(action="save", file_name=fn)
+
+    def load(self, fn):
+        """(scripted motions are Python callables of THIS process, re-attached by the script that adds the bodies: nothing to
+        pass along, unlike the reference's function addresses, :292-297)"""
+        self.action(action="load", file_name=fn)
+
+    def get_snapshot_file_name(self, iteration):
+        if self.snapshot_directory is None:
+            raise MPMError("snapshots need an output directory: MPM(output_directory=...)")
+        return os.path.join(self.snapshot_directory, "%04d.tcb" % iteration)
+
+    def _frames(self, num_frames, frame_update, update_frequency, print_profile_info, per_frame):
         n = self.num_frames if num_frames is None else num_frames
-        for i in range(n):
-            if frame_update:
-                frame_update(self.get_current_time(), self.frame_dt)
-            self.step(self.frame_dt)
+        done = 0
+        while done < n:
+            for _ in range(update_frequency):
+                if frame_update:
+                    frame_update(self.get_current_time(), self.frame_dt / update_frequency)
+                self.step(self.frame_dt / update_frequency)
             if self.c.frame_directory:  # one .bgeo per frame, as async_mpm.py:243
                 self.visualize()
             if print_profile_info:
                 print(json.dumps(self.c.profile(reset=True)))
+            done += 1
+            per_frame(done)
+
+    def simulate(self, num_frames=None, print_profile_info=False, frame_update=None, clear_output_directory=False,
+                 update_frequency=1, **_ignored):
+        """python frame loop (scripts/async/async_mpm.py:217-248): per frame `update_frequency` x step(frame_dt /
+        update_frequency), a frame file, [profile print], a snapshot every `snapshot_interval` frames when the driver has
+        an output directory."""
+        if print_profile_info:
+            self.c.set_profiling(True)
+        if clear_output_directory:
+            self.clear_output_directory()
+
+        def after(done):
+            if self.snapshot_directory is not None and self.snapshot_interval and done % self.snapshot_interval == 0:
+                os.makedirs(self.snapshot_directory, exist_ok=True)
+                self.save(self.get_snapshot_file_name(done))
+        self._frames(num_frames, frame_update, update_frequency, print_profile_info, after)
+
+    def simulate_with_energy(self, num_frames=None, print_profile_info=False, frame_update=None, clear_output_directory=False,
+                             update_frequency=1):
+        """the same loop, returning the total energy after every frame (:250-272)"""
+        if clear_output_directory:
+            self.clear_output_directory()
+        energy = []
+        self._frames(num_frames, frame_update, update_frequency, print_profile_info,
+                     lambda done: energy.append(float(self.general_action(action="calculate_energy"))))
+        return energy
 
 
 class AsyncMPM(MPM):

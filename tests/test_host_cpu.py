@@ -194,3 +194,33 @@ def test_unknown_articulations_are_refused_before_anything_runs():
     sim2 = tm.create_simulation2("mpm").initialize(dict(res=(32, 32)))
     with pytest.raises(tm.MPMError, match="only 'rotation'"):
         sim2.general_action(dict(action="add_articulation", type="motor", obj0=1, obj1=2))
+
+
+def test_scene_driver_surface_of_the_reference(tmp_path):
+    """the methods scene scripts call on the reference's Python driver (scripts/async/async_mpm.py:185-300) exist on ours
+    and do what they do there — everything here runs before a ctx exists (no GPU)"""
+    out = tmp_path / "run"
+    mpm = tm.MPM(res=(32, 32, 32), output_directory=str(out), snapshot_interval=5, task_id="unit")
+    assert mpm.get_directory() == str(out) and mpm.task_id == "unit" and mpm.snapshot_interval == 5
+    assert mpm.c.frame_directory == str(out / "frames")            # injected like the reference's (:49)
+    assert mpm.get_snapshot_file_name(7) == str(out / "snapshots" / "0007.tcb")
+    assert mpm.test() and mpm.get_mpi_world_rank() == 0 and mpm.get_debug_information() == ""
+    frames = out / "frames"
+    frames.mkdir(parents=True)
+    for name in ("0001.bgeo", "rigid_001_0001.obj", "notes.txt"):
+        (frames / name).write_bytes(b"x")
+    (out / "snapshots").mkdir()
+    (out / "snapshots" / "0005.tcb").write_bytes(b"x")
+    mpm.clear_output_directory()                                    # frames go, snapshots and foreign files stay (:211-215)
+    assert sorted(p.name for p in frames.iterdir()) == ["notes.txt"] and (out / "snapshots" / "0005.tcb").exists()
+    with pytest.raises(tm.MPMError):
+        mpm.make_video()
+    with pytest.raises(tm.MPMError):
+        mpm.action(action="cdf")                                    # draw_cdf: rendering, outside the scope
+    for name in ("simulate", "simulate_with_energy", "save", "load", "delete_particles_inside_level_set", "add_articulation",
+                 "general_action", "update_levelset", "set_levelset", "create_levelset", "visualize", "step", "get_current_time"):
+        assert callable(getattr(mpm, name))
+    bare = tm.MPM(res=(32, 32, 32))                                  # no output directory: nothing is written, snapshots refuse
+    assert bare.get_directory() is None and not bare.c.frame_directory
+    with pytest.raises(tm.MPMError):
+        bare.get_snapshot_file_name(1)
