@@ -39,9 +39,15 @@ class LevelSet:
     and argument order follow the calls the scene scripts make (`add_plane(normal, d)`, `add_sphere(center, radius,
     inside_out)`, `add_cuboid(lower, upper, inside_out)`, `set_friction(f)`)."""
 
-    def __init__(self, friction=-1.0):
+    def __init__(self, friction=-1.0, delta_x=None):
         self.friction = float(friction)
         self.shapes = []  # (type, inside_out, p[6]) — include/mpmhip.h: mpmhip_shape
+        self.delta_x = delta_x  # cell size of the grid the driver created it for (MPM.create_levelset)
+
+    def get_delta_x(self):  # (scripts/async/slope.py:69)
+        if self.delta_x is None:
+            raise MPMError("this LevelSet was not created through MPM.create_levelset(): it has no grid")
+        return self.delta_x
 
     def set_friction(self, f):
         self.friction = float(f)
@@ -885,7 +891,7 @@ class MPM:
         return self.c.add_particles(kwargs)
 
     def create_levelset(self):
-        return LevelSet()
+        return LevelSet(delta_x=1.0 / self.res[0])
 
     def update_levelset(self, t0, t1):  # scripts/async/async_mpm.py:119-127
         if self.levelset_generator is None:

@@ -221,6 +221,7 @@ def test_scene_driver_surface_of_the_reference(tmp_path):
                  "general_action", "update_levelset", "set_levelset", "create_levelset", "visualize", "step", "get_current_time"):
         assert callable(getattr(mpm, name))
     bare = tm.MPM(res=(32, 32, 32))                                  # no output directory: nothing is written, snapshots refuse
+    assert bare.create_levelset().get_delta_x() == 1.0 / 32           # (scripts/async/slope.py:69)
     assert bare.get_directory() is None and not bare.c.frame_directory
     with pytest.raises(tm.MPMError):
         bare.get_snapshot_file_name(1)
