@@ -40,6 +40,10 @@ BUDGET = {
     G2P % (2, 508): (168, (3000, 4200), 53 * 1024),   # every material but visco (mixed scenes, C5)
     G2P % (2, 510): (256, (4800, 6200), 80 * 1024),   # all eight
     "_ZN3mpm5k_p2gILi1ELi1ELi2ELb0EEE": (256, (900, 1450), 16 * 1024),  # the default P2G (one wave per block)
+    # the plain kernels of a ctx WITH rigid bodies (they skip the flagged blocks): same occupancy class as without —
+    # k_g2p<RIGID> runs beside k_g2p_rigid, whose 255-register workgroups only find room when this one leaves it
+    "_ZN3mpm5k_g2pILi256ELi2ELb1ELb0ELb1ELj64EEE": (168, (2400, 3300), 53 * 1024),
+    "_ZN3mpm5k_p2gILi1ELi1ELi2ELb1EEE": (256, (900, 1500), 16 * 1024),
 }
 
 
