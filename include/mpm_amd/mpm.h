@@ -18,6 +18,7 @@
 #include <functional>
 #include <memory>
 #include <stdexcept>
+#include <array>
 #include <string>
 #include <vector>
 
@@ -344,6 +345,9 @@ class MPM<3> {
 
   bool test() const { return true; }                          // src/mpm.cpp:577-580
   std::string get_debug_information() const { return ""; }    // :635-639
+  // what the reference's Python driver sizes its video frames with (scripts/async/async_mpm.py:79-81; the method itself is
+  // the absent taichi core's): the grid resolution in x and y
+  std::array<int, 2> get_vis_resolution() const { return {res[0], res[1]}; }
   virtual std::string get_name() const { return "mpm"; }      // src/mpm.h:486-488
   mpmhip_ctx *ctx() const { return ctx_; }
 

@@ -108,6 +108,7 @@ static void gpu_tests() {
   CHECK(sim->add_particles(Config().set("type", "jelly").set("benchmark", 125)) == "");
   const int64_t n = sim->get_num_particles();
   CHECK(n == 13 * 13 * 13 * 8);  // round(64*0.4)=26..39: 13^3 cells x 8 (src/mpm.cpp:149-186)
+  CHECK(sim->get_vis_resolution()[0] == 64 && sim->get_vis_resolution()[1] == 64);  // scripts/async/async_mpm.py:79-81
   {  // all-jelly scene: mechanical energy is defined (potential_energy exists for jelly, src/particles.cpp:400-407)
     const double e0 = std::stod(sim->general_action(Config().set("action", "calculate_energy")));
     CHECK(e0 >= 0 && e0 < 1e-3 && std::isfinite(e0));  // at rest, undeformed: only the first substep's gravity impulse
