@@ -946,7 +946,7 @@ class MPM:
 
     def clear_output_directory(self):
         """the frames of an earlier run (.bgeo, the bodies' .obj / .poly); snapshots stay, as in the reference (:211-215)"""
-        frames = self.c.frame_directory
+        frames = getattr(self.c, "frame_directory", None)
         if frames and os.path.isdir(frames):
             for f in os.listdir(frames):
                 if f.endswith((".bgeo", ".obj", ".poly")):
@@ -981,9 +981,9 @@ class MPM:
                 if frame_update:
                     frame_update(self.get_current_time(), self.frame_dt / update_frequency)
                 self.step(self.frame_dt / update_frequency)
-            if self.c.frame_directory:  # one .bgeo per frame, as async_mpm.py:243
+            if getattr(self.c, "frame_directory", None):  # one .bgeo per frame, as async_mpm.py:243
                 self.visualize()
-            if print_profile_info:
+            if print_profile_info and hasattr(self.c, "profile"):
                 print(json.dumps(self.c.profile(reset=True)))
             done += 1
             per_frame(done)
@@ -993,7 +993,7 @@ class MPM:
         """python frame loop (scripts/async/async_mpm.py:217-248): per frame `update_frequency` x step(frame_dt /
         update_frequency), a frame file, [profile print], a snapshot every `snapshot_interval` frames when the driver has
         an output directory."""
-        if print_profile_info:
+        if print_profile_info and hasattr(self.c, "set_profiling"):  # (the 2D simulation has no phase profile)
             self.c.set_profiling(True)
         if clear_output_directory:
             self.clear_output_directory()

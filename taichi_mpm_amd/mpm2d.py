@@ -327,6 +327,9 @@ class Simulation2D:
     def get_mpi_world_rank(self):
         return 0
 
+    def get_debug_information(self):  # src/mpm.cpp:635-639
+        return ""
+
     def get_vis_resolution(self):  # (scripts/async/async_mpm.py:79-81; see Simulation3D.get_vis_resolution)
         import types
         return types.SimpleNamespace(x=int(self.res[0]), y=int(self.res[1]))

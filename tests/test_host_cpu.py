@@ -225,3 +225,16 @@ def test_scene_driver_surface_of_the_reference(tmp_path):
     assert bare.get_directory() is None and not bare.c.frame_directory
     with pytest.raises(tm.MPMError):
         bare.get_snapshot_file_name(1)
+
+
+def test_scene_driver_over_the_2d_simulation():
+    """MPM(res=(r, r)) drives create_simulation2('mpm') through the same driver: the methods that exist only for the 3D object
+    (phase profile, frame files) are skipped, not AttributeErrors"""
+    m = tm.MPM(res=(64, 64))
+    assert type(m.c).__name__ == "Simulation2D"
+    assert m.test() and m.get_debug_information() == "" and m.get_mpi_world_rank() == 0
+    v = m.c.get_vis_resolution()
+    assert (v.x, v.y) == (64, 64)
+    m.clear_output_directory()  # nothing to clear, nothing raised
+    with pytest.raises(tm.MPMError):
+        m.action(action="calculate_energy")  # (not part of the 2D build: said so, loudly)
