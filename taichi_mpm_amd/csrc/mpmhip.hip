@@ -61,16 +61,6 @@
 #include <vector>
 
 
-// The fused G2P -> P2G transfer (k_g2p.h: FUSED, k_grid.h: k_grid_fused) is an EXPERIMENT that lost its A/B (DESIGN.md §4:
-// 0.54 ms against 0.47 ms for the two kernels at C3): it is compiled only into the variant library built with
-// -DMPMHIP_WITH_FUSED (lib/libmpmhip_fused.so, MPMHIP_LIB_VARIANT=fused), where the env MPMHIP_FUSED=1 switches it on; the
-// default library carries neither the kernels nor the switch.  Its results are valid (tests/test_gpu_fused.py).
-#ifndef MPMHIP_FUSED_DEFAULT
-#define MPMHIP_FUSED_DEFAULT 0
-#endif
-#ifndef MPM_G2P_MINW_FUSED
-#define MPM_G2P_MINW_FUSED 3
-#endif
 #ifndef MPM_G2P_MINW
 #define MPM_G2P_MINW 2  // __launch_bounds__ waves/SIMD of k_g2p.  (256, 3) states the 168-VGPR budget explicitly but was measured 3 % slower
                         // (profiles/r03_h_ab_refactor.txt: w2 against default); the budget is guarded by tests/test_kernel_budget_cpu.py instead
@@ -83,11 +73,6 @@
 #include "k_grid.h"
 #include "k_tiling.h"
 #include "k_g2p.h"
-#ifdef MPMHIP_WITH_FUSED
-#include "k_g2p2g.h"
-#else
-namespace mpm { constexpr int G2P_LDS_GROUPS_FUSED = 32, T8N = 512; }
-#endif
 #include "k_rigid_transfer.h"
 #include "k_debug.h"
 #include "k_bgeo.h"
@@ -141,7 +126,6 @@ struct mpmhip_ctx {
   int rigid_wgs = 2048;       // workgroups of k_p2g_rigid (one per wave slot of the device), twice those of k_g2p_rigid (env MPMHIP_RIGID_WGS: tuning)
   uint32_t rank_runs_mul = 3; // k_rank takes its LDS-hash path when runs * this > slots (env MPMHIP_RANK_RUNS_MUL: tuning)
   int ct_blocks = 0;          // blocks per chunk of k_cell_table: 0 by size, 16, 64 (env MPMHIP_CT_BLOCKS: tuning)
-  int g2p2g_wgs = 4096;       // ... of its fused form (env MPMHIP_G2P2G_WGS)
   int g2p_minw = 12;          // tuning knob (env MPMHIP_G2P_MINW): 10 + __launch_bounds__ waves/SIMD of k_g2p
   int reorder_interval = 0;   // physical reorder every this many substeps (0 = never); env MPMHIP_REORDER_INTERVAL
   float t = 0.0f, request_t = 0.0f;  // `real` accumulators, as in the reference (src/mpm.h:99, mpm.cpp:573)
@@ -245,13 +229,6 @@ struct mpmhip_ctx {
     JointDev *d_joints = nullptr;
     int joint_iterations = 100;      // 'articulation_iterations' (src/mpm.h:279-280)
   } rigid;
-  // fused transfer (k_g2p.h: FUSED): G2P of substep n also performs the P2G of substep n + 1 into 8^3 tiles
-  bool fused = false;          // enabled for this ctx (cfg / env MPMHIP_FUSED); used whenever fused_ok() holds
-  bool tiles8_valid = false;   // tiles8 holds the P2G of the CURRENT particle state, keyed by the block table in bits_prev
-  bool defer_p = false;        // the substep in flight is not the last of its batch: the P2G records need not be stored
-  bool rp_current = true;      // RecP matches the particle state (false only between the substeps of one batch)
-  float4 *tiles8 = nullptr;
-  uint32_t *bits_prev = nullptr, *wprefix_prev = nullptr;
   bool overlap = false;        // mpmhip_set_overlap: split tiled substeps into boundary / interior work
   bool ov_active = false, interior_done = false;  // state of the substep in flight
 };
@@ -425,15 +402,10 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   if (const char *e = getenv("MPMHIP_RIGID_WGS")) c->rigid_wgs = atoi(e) > 1 ? atoi(e) : 2048;
   if (const char *e = getenv("MPMHIP_RANK_RUNS_MUL")) c->rank_runs_mul = (uint32_t)atoi(e);
   if (const char *e = getenv("MPMHIP_CT_BLOCKS")) c->ct_blocks = atoi(e);
-  if (const char *e = getenv("MPMHIP_G2P2G_WGS")) c->g2p2g_wgs = atoi(e) > 0 ? atoi(e) : 4096;
   if (const char *e = getenv("MPMHIP_P2G_SPLIT")) c->p2g_split = atoi(e);
   if (const char *e = getenv("MPMHIP_P2G_WGS")) c->p2g_wgs = atoi(e) > 0 ? atoi(e) : 16384;
   c->reorder_interval = cfg->reorder_interval;
   if (const char *e = getenv("MPMHIP_REORDER_INTERVAL")) c->reorder_interval = atoi(e);
-#ifdef MPMHIP_WITH_FUSED
-  c->fused = MPMHIP_FUSED_DEFAULT != 0;
-  if (const char *e = getenv("MPMHIP_FUSED")) c->fused = atoi(e) != 0;
-#endif
 #ifdef MPMHIP_ABLATE_BUILD
   const int ablate = getenv("MPMHIP_ABLATE") ? atoi(getenv("MPMHIP_ABLATE")) : 0;
 #else
@@ -550,7 +522,6 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   if (c->async.h_tab) hipHostFree(c->async.h_tab);
   { auto &S = c->async.store; hipFree(S.g); hipFree(S.w); hipFree(S.g2); hipFree(S.w2); hipFree(S.tag); hipFree(S.tag2); hipFree(S.id);
     hipFree(S.id2); hipFree(S.best); hipFree(S.d_scan); hipFree(S.d_tbl); hipFree(S.d_rank); hipFree(S.d_cnt); }
-  hipFree(c->tiles8); hipFree(c->bits_prev); hipFree(c->wprefix_prev);
   hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_LS); hipFree(c->d_counts); hipFree(c->d_bounds); if (c->h_pinned) hipHostFree(c->h_pinned); hipFree(c->d_energy);
   { auto &R = c->rigid; hipFree(R.d_rb); hipFree(R.d_smp); hipFree(R.d_elems); hipFree(R.cdf.slot); hipFree(R.cdf.page_key); hipFree(R.cdf.mind);
     hipFree(R.cdf.tags); hipFree(R.cdf.rpage); hipFree(R.d_bnd); if (R.side) { hipStreamSynchronize(R.side); hipStreamDestroy(R.side); } if (R.ev_fork) hipEventDestroy(R.ev_fork); if (R.ev_join) hipEventDestroy(R.ev_join);
@@ -650,7 +621,6 @@ int mpmhip_add_group(mpmhip_ctx *c, int32_t material, const float params[MPMHIP_
 // G2P wrote for the OLD positions must not leak into the next sort — k_build_keys only ORs new flags on top, so stale
 // ones would turn into phantom active blocks (empty tiles, inflated n_active, spurious capacity errors).
 static int invalidate_keys(mpmhip_ctx *c) {
-  c->tiles8_valid = false;  // (the fused P2G result belongs to the old particle set)
   c->sorted = false;
   c->ordered = c->compact = false;
   if (c->keys_valid) {
@@ -681,9 +651,6 @@ static int read_counters(mpmhip_ctx *c, Counters &h) {
   if (h.error & 2u)
     return fail(c, MPMHIP_ECAPACITY, "a particle moved more than margin=%d cells outside this rank's brick between "
                 "two migrations: migrate more often or raise the margin", c->T.margin);
-  if (h.error & 8u)
-    return fail(c, MPMHIP_ECAPACITY, "a particle moved more than one cell in one substep (|v| dt > dx): the fused transfer "
-                "(MPMHIP_FUSED) needs the CFL condition; run with MPMHIP_FUSED=0");
   if (h.error & 4u)
     return fail(c, MPMHIP_ECAPACITY, "the colored distance field of the rigid bodies needs more than %u pages of 4^3 nodes: "
                 "recreate the ctx with a larger max_blocks", c->rigid.max_pages);
@@ -893,34 +860,10 @@ int mpmhip_upload(mpmhip_ctx *c, int32_t field, const void *src, int64_t n) {
 static int do_reorder(mpmhip_ctx *c);
 
 static inline bool rigid_active(const mpmhip_ctx *c);
-// the fused transfer covers the plain single-ctx substep in the default storage mode; everything else takes the two kernels
-static bool fused_ok(const mpmhip_ctx *c) {
-  return c->fused && !rigid_active(c) && !c->T.enabled && c->T.n_boxes == 0 && !c->async.enabled && !c->P.store_b &&
-         (int)c->groups.size() <= G2P_LDS_GROUPS_FUSED;
-}
-static int ensure_fused_buffers(mpmhip_ctx *c) {
-  if (c->tiles8) return MPMHIP_OK;
-  HIPCHK(c, dmalloc(&c->tiles8, (size_t)c->P.max_blocks * T8N));
-  HIPCHK(c, dmalloc(&c->bits_prev, (size_t)c->P.nbw));
-  HIPCHK(c, dmalloc(&c->wprefix_prev, (size_t)c->P.nbw));
-  HIPCHK(c, hipMemsetAsync(c->bits_prev, 0, sizeof(uint32_t) * c->P.nbw, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->wprefix_prev, 0, sizeof(uint32_t) * c->P.nbw, c->stream));
-  return MPMHIP_OK;
-}
-
 static int do_sort(mpmhip_ctx *c) {
   Params &P = c->P;
   hipStream_t st = c->stream;
   const int pg = particle_grid(c->n_slots);
-  // The 8^3 tiles of the last fused G2P are this substep's P2G result iff nothing touched the particles since: the keys that
-  // kernel wrote are still the valid ones (every upload / insertion / deletion / snapshot load invalidates them) and the
-  // stored affine matrices match (set_dt, uploads of F / aux / apic_b do not).
-  c->tiles8_valid = c->tiles8_valid && c->keys_valid && c->affine_valid && fused_ok(c);
-  if (fused_ok(c)) {  // the block table of the previous sort stays readable: k_grid_fused finds the tiles through it
-    if (int rc = ensure_fused_buffers(c)) return rc;
-    std::swap(c->bits, c->bits_prev);
-    std::swap(c->wprefix, c->wprefix_prev);
-  }
   if (!c->keys_valid)
     hipLaunchKernelGGL(k_build_keys, dim3(pg), dim3(256), 0, st, P, c->rg, c->rp, c->cnt, c->key, c->blk_flag);
   const bool small = c->ct_blocks ? c->ct_blocks == 16 : c->n_slots < (2 << 20);  // few blocks: finer chunks in k_cell_table
@@ -1007,7 +950,6 @@ static uint32_t material_mask(const mpmhip_ctx *c) {
 static int do_rigid_apply_tmp(mpmhip_ctx *c);
 
 static int do_p2g(mpmhip_ctx *c, int phase = 0) {
-  if (!c->rp_current) return fail(c, MPMHIP_EINVAL, "internal: the P2G records are stale (a batch of fused substeps did not finish)");
   if (!c->affine_valid) {
     hipLaunchKernelGGL(k_affine, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, c->rg, c->rp, c->rb,
                        c->d_groups);
@@ -1060,17 +1002,7 @@ static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
                      c->gridv, c->fat_slot, c->dense, c->T, (const DevBox *)c->d_boxes, c->LS, phase);
   return launch_check(c, "grid");
 }
-static int do_grid_fused(mpmhip_ctx *c) {
-#ifdef MPMHIP_WITH_FUSED
-  c->P.t = c->t;
-  hipLaunchKernelGGL(k_grid_fused, dim3(4096), dim3(256), 0, c->stream, c->P, c->cnt, c->act_blk, c->bits, c->wprefix, c->bits_prev,
-                     c->wprefix_prev, (const float4 *)c->tiles8, c->gridv, c->fat_slot, c->LS);
-  return launch_check(c, "grid (fused)");
-#else
-  return fail(c, MPMHIP_ENOTIMPL, "internal: this library was built without the fused transfer");
-#endif
-}
-static int do_g2p(mpmhip_ctx *c, int phase = 0, bool fused = false) {
+static int do_g2p(mpmhip_ctx *c, int phase = 0) {
   c->P.t = c->t;
   const bool sb = c->P.store_b != 0;
   // __launch_bounds__(256, 2) only PERMITS 256 VGPRs; what decides the speed is whether the allocation stays <= 168, i.e.
@@ -1115,28 +1047,11 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0, bool fused = false) {
       default: break;
     }
   }
-  const int write_p = (fused && c->defer_p) ? 0 : 1;
   hipStream_t rs = c->stream;
   if (rigid) { if (int rc = rigid_fork(c, &rs, 2)) return rc; }
-#ifdef MPMHIP_WITH_FUSED
-  if (fused) {  // G2P + the next substep's P2G in one kernel (k_g2p2g.h), same material-set tiers
-    auto fk = no_visco ? k_g2p2g<256, MPM_G2P_MINW_FUSED, true, false, false, NO_VISCO> : k_g2p2g<256, 2, true, false, false, MAT_ALL>;
-    switch (mask) {
-#define MPM_ONE_MATERIAL(t) case 1u << (t): fk = k_g2p2g<256, MPM_G2P_MINW_FUSED, true, false, false, 1u << (t)>; break;
-      MPM_ONE_MATERIAL(MPMHIP_JELLY) MPM_ONE_MATERIAL(MPMHIP_SAND)
-#undef MPM_ONE_MATERIAL
-      default: break;
-    }
-    hipLaunchKernelGGL(fk, dim3(c->g2p2g_wgs), dim3(256), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
-                       (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
-                       c->blk_flag, (const LevelSetDev *)c->d_LS, phase_box(c->T), phase, c->tiles8, write_p);
-  } else
-#endif
   hipLaunchKernelGGL(kern, dim3(c->g2p_wgs), dim3(nt), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
                      (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
                      c->blk_flag, (const LevelSetDev *)c->d_LS, phase_box(c->T), phase);
-  c->tiles8_valid = fused;   // (its P2G is keyed by THIS sort's block table, which the next sort keeps as bits_prev)
-  c->rp_current = write_p != 0;
   if (rigid) {
     auto rk = k_g2p_rigid<MAT_ALL>;
     switch (mask) {
@@ -1279,7 +1194,7 @@ int mpmhip_substep_begin(mpmhip_ctx *c) {
   if ((rc = do_sort(c))) return rc;
   if (bodies && ((rc = rigid_join(c, rs)) || (rc = do_rigid_pre_b(c)))) return rc;
   if (ev && (lvl == 1 || lvl == 3)) HIPCHK(c, hipEventRecord(ev->e[1], c->stream));
-  if (!c->tiles8_valid && (rc = do_p2g(c, c->ov_active ? 1 : 0))) return rc;  // (fused: the previous G2P already did it)
+  if ((rc = do_p2g(c, c->ov_active ? 1 : 0))) return rc;
   if (ev && lvl == 3) HIPCHK(c, hipEventRecord(ev->e[2], c->stream));
   if ((rc = do_halo_pack(c))) return rc;
   if (ev && lvl == 1) HIPCHK(c, hipEventRecord(ev->e[2], c->stream));
@@ -1322,9 +1237,9 @@ int mpmhip_substep_end(mpmhip_ctx *c) {  // grid (+ halo sum), G2P
   const int lvl = c->profiling, ph = c->ov_active ? 1 : 0;
   if (ev && lvl == 1) HIPCHK(c, hipEventRecord(ev->e[3], c->stream));
   if (ev && lvl == 4) HIPCHK(c, hipEventRecord(ev->e[4], c->stream));
-  if ((rc = c->tiles8_valid ? do_grid_fused(c) : do_grid(c, 0, ph))) return rc;
+  if ((rc = do_grid(c, 0, ph))) return rc;
   if (ev && (lvl == 1 || lvl == 2)) HIPCHK(c, hipEventRecord(ev->e[4], c->stream));
-  if ((rc = do_g2p(c, ph, fused_ok(c)))) return rc;
+  if ((rc = do_g2p(c, ph))) return rc;
   if (ev && (lvl == 1 || lvl == 2 || lvl == 4)) HIPCHK(c, hipEventRecord(ev->e[5], c->stream));
   swap_records(c);
   if (rigid_active(c) && (rc = do_rigid_advect(c, c->P.dt))) return rc;  // src/mpm.cpp:570-572
@@ -1369,18 +1284,9 @@ int mpmhip_substep(mpmhip_ctx *c) {
   return rc ? rc : mpmhip_substep_end(c);
 }
 
-// A batch of substeps: only the last one has to leave the P2G records (RecP) in memory — in between, the fused transfer
-// keeps them on the chip (k_g2p.h: write_p).
-static int substep_in_batch(mpmhip_ctx *c, bool last) {
-  if (!c) return MPMHIP_EINVAL;
-  c->defer_p = !last;
-  int rc = mpmhip_substep(c);
-  c->defer_p = false;
-  return rc;
-}
 int mpmhip_run_substeps(mpmhip_ctx *c, int32_t n) {
   for (int32_t i = 0; i < n; i++) {
-    int rc = substep_in_batch(c, i == n - 1);
+    int rc = mpmhip_substep(c);
     if (rc) return rc;
   }
   return MPMHIP_OK;
@@ -1395,8 +1301,7 @@ int mpmhip_step(mpmhip_ctx *c, float dt) {  // MPM<dim>::step, src/mpm.cpp:428-4
   }
   c->request_t += dt;
   while (c->t + c->P.dt < c->request_t) {
-    const float t_next = c->t + c->P.dt;  // (the clock as mpmhip_substep_end advances it)
-    int rc = substep_in_batch(c, !(t_next + c->P.dt < c->request_t));
+    int rc = mpmhip_substep(c);
     if (rc) return rc;
   }
   return MPMHIP_OK;
@@ -1790,9 +1695,9 @@ int mpmhip_profile(mpmhip_ctx *c, char *json, size_t cap) {
   if ((rc = read_counters(c, h))) return rc;
   int w = snprintf(json, cap,
                    "{\"substeps\":%lld,\"particles\":%lld,\"active_blocks\":%u,\"rank_mode\":%u,\"phases\":{\"sort\":%.6f,\"p2g\":%.6f,"
-                   "\"exchange\":%.6f,\"grid\":%.6f,\"g2p\":%.6f},\"fused\":%d}",
+                   "\"exchange\":%.6f,\"grid\":%.6f,\"g2p\":%.6f}}",
                    (long long)c->prof_substeps, (long long)(c->n_slots - h.n_dead), h.n_active, h.rank_mode, c->phase_ms[PH_SORT],
-                   c->phase_ms[PH_P2G], c->phase_ms[PH_EXCH], c->phase_ms[PH_GRID], c->phase_ms[PH_G2P], fused_ok(c) ? 1 : 0);
+                   c->phase_ms[PH_P2G], c->phase_ms[PH_EXCH], c->phase_ms[PH_GRID], c->phase_ms[PH_G2P]);
   return (w < 0 || (size_t)w >= cap) ? fail(c, MPMHIP_EINVAL, "profile buffer too small") : MPMHIP_OK;
 }
 
@@ -2017,8 +1922,6 @@ int mpmhip_reserve(mpmhip_ctx *c, int64_t max_particles) {
       A(regrow(&c->scan_slots, 0, c->bt_slots + (m + 15) / 16 + 1, true));  // (epoch 0 is never used)
       A(regrow(&c->tiles, 0, m * TN, false)); A(regrow(&c->gridv, 0, m * 8 * BC, false));
       if (c->rigid.d_blk_rigid) { A(regrow(&c->rigid.d_blk_rigid, 0, m + 1, true)); A(regrow(&c->rigid.d_rigid_list, 0, m + 1, false)); }
-      (void)hipFree(c->tiles8); (void)hipFree(c->bits_prev); (void)hipFree(c->wprefix_prev);  // (re-allocated on demand)
-      c->tiles8 = nullptr; c->bits_prev = nullptr; c->wprefix_prev = nullptr;
       if (e != hipSuccess) return fail(c, MPMHIP_ENOMEM, "growing the block table to %lld failed: %s", (long long)mb, hipGetErrorString(e));
       c->P.max_blocks = (uint32_t)mb;
       HIPCHK(c, hipMemset(c->fat_slot, 0, sizeof(uint32_t) * (size_t)c->NB));  // slots of the old grid array
