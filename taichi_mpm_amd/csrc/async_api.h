@@ -284,9 +284,17 @@ static int async_advance(mpmhip_ctx *c, int64_t limit) {
     A.has_copied[b] = 1; A.tbl[b] |= AT_BACKUP;
   }
   if (int rc = async_best_reserve(c)) return rc;
-  HIPCHK(c, hipMemcpyAsync(S.d_tbl, A.tbl.data(), nblk, hipMemcpyHostToDevice, c->stream));
-  // the working set can hold every live container: the ctx's records must have room (the caller sized the ctx for all
-  // particles; duplicates of an id are dropped by the gather)
+  // (A.tbl is pageable host memory the next lines of this function overwrite: the copy is a synchronous one)
+  HIPCHK(c, hipMemcpy(S.d_tbl, A.tbl.data(), nblk, hipMemcpyHostToDevice));
+  // the working set holds at most one container per id (duplicates are dropped by the gather), i.e. at most
+  // min(containers, ids handed out) records: the ctx's record arrays get that room BEFORE the gather writes into them — a
+  // C-ABI caller may have pooled several batches of up to `cap` particles each (mpmhip_async_pool_particles empties the slots)
+  {
+    const int64_t bound = std::min<int64_t>((int64_t)S.size_ub, (int64_t)c->next_pid);
+    if (bound > c->cap) {
+      if (int rc = mpmhip_reserve(c, bound + 1024)) return rc;
+    }
+  }
   hipLaunchKernelGGL(k_async_mark, dim3(as_grid(S.size_ub)), dim3(256), 0, c->stream, S.size_ub, (const uint32_t *)S.tag,
                      (const int32_t *)S.id, (const uint8_t *)S.d_tbl, (const uint32_t *)S.d_rank, S.best);
   hipLaunchKernelGGL(k_async_gather, dim3(as_grid(S.size_ub)), dim3(256), 0, c->stream, S.size_ub, S.tag, (const int32_t *)S.id,
@@ -300,8 +308,7 @@ static int async_advance(mpmhip_ctx *c, int64_t limit) {
   A.update_counter += n_work;
   // ONE ordinary substep of the working set with this level's dt (:327-329; step() sets base_delta_t / current_t, :405-408)
   c->n_slots = n_work; c->P.n_slots = n_work;
-  const uint32_t zero = 0;
-  HIPCHK(c, hipMemcpyAsync(&c->cnt->n_dead, &zero, sizeof zero, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(&c->cnt->n_dead, 0, sizeof(uint32_t), c->stream));
   c->P.dt = A.cfg.unit_delta_t * (float)limit;
   c->t = A.cfg.unit_delta_t * (float)t;
   c->affine_valid = false; c->b_stale = false;
@@ -325,7 +332,7 @@ static int async_advance(mpmhip_ctx *c, int64_t limit) {
       any_clear = true;
     }
   }
-  HIPCHK(c, hipMemcpyAsync(S.d_tbl, A.tbl.data(), nblk, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpy(S.d_tbl, A.tbl.data(), nblk, hipMemcpyHostToDevice));  // (pageable source, refilled by the next advance)
   if (any_clear)
     hipLaunchKernelGGL(k_async_clear, dim3(as_grid(S.size)), dim3(256), 0, c->stream, S.size, S.tag, (const uint8_t *)S.d_tbl, S.d_cnt);
   if (n_work) {
@@ -464,7 +471,7 @@ int mpmhip_async_load_pools(mpmhip_ctx *c) {
   const size_t nblk = A.continuous.size();
   if (int rc = async_ensure_particle_arrays(c)) return rc;
   std::fill(A.tbl.begin(), A.tbl.end(), (uint8_t)AT_POOL1);
-  HIPCHK(c, hipMemcpyAsync(S.d_tbl, A.tbl.data(), nblk, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpy(S.d_tbl, A.tbl.data(), nblk, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_async_load, dim3(as_grid(S.size)), dim3(256), 0, c->stream, S.size, (const uint32_t *)S.tag, (const float4 *)S.g,
                      (const float4 *)S.w, (const GroupParams *)c->d_groups, (float4 *)c->rg, (float4 *)c->rp, (float4 *)c->rb,
                      A.d_blk_of, S.d_cnt);
@@ -567,12 +574,33 @@ int mpmhip_async_snapshot_load(mpmhip_ctx *c, const void *src, size_t size) {
     if (h.res[k] != c->P.res[k] || h.nb[k] != A.nb[k]) return fail(c, MPMHIP_EINVAL, "snapshot is of a %dx%dx%d grid", h.res[0], h.res[1], h.res[2]);
   if (h.dx != c->P.dx || h.unit_delta_t != A.cfg.unit_delta_t) return fail(c, MPMHIP_EINVAL, "snapshot has delta_x = %g, unit_delta_t = %g", h.dx, h.unit_delta_t);
   if ((int)h.n_groups > c->groups_cap || h.nblk != (int64_t)A.continuous.size() || h.containers < 0) return fail(c, MPMHIP_EINVAL, "snapshot header inconsistent with this ctx");
-  c->groups.resize(h.n_groups);
-  if (size != async_snapshot_bytes(c, (size_t)h.containers)) return fail(c, MPMHIP_EINVAL, "snapshot size mismatch");
+  if (h.n_groups < 0) return fail(c, MPMHIP_EINVAL, "snapshot header inconsistent with this ctx");
+  if (size != sizeof(SnapAsync) + sizeof(GroupParams) * (size_t)h.n_groups + sizeof(int64_t) * 6 * (size_t)h.nblk +
+                  (size_t)h.containers * (sizeof(uint32_t) + sizeof(int32_t) + 2 * 4 * sizeof(float4)))
+    return fail(c, MPMHIP_EINVAL, "snapshot size mismatch");
+  {  // the container arrays index the block table (tag), the block order and the per-id bids (id) on the device: a truncated
+     // or foreign blob must not get that far
+    const size_t n = (size_t)h.containers;
+    const char *q = (const char *)src + sizeof h + sizeof(GroupParams) * h.n_groups + 6 * sizeof(int64_t) * (size_t)h.nblk;
+    const uint32_t *tags = reinterpret_cast<const uint32_t *>(q);
+    const int32_t *ids = reinterpret_cast<const int32_t *>(q + sizeof(uint32_t) * n);
+    if (h.next_pid < 0) return fail(c, MPMHIP_EINVAL, "snapshot header inconsistent with this ctx (next id %d)", h.next_pid);
+    for (size_t i = 0; i < n; i++) {
+      uint32_t tg; int32_t id;
+      memcpy(&tg, tags + i, 4); memcpy(&id, ids + i, 4);
+      if (tg == AS_FREE) continue;
+      if ((int64_t)(tg & ~AS_BACKUP) >= h.nblk) return fail(c, MPMHIP_EINVAL, "snapshot container %zu names block %u of %lld", i, tg & ~AS_BACKUP, (long long)h.nblk);
+      if (id < 0 || id >= h.next_pid) return fail(c, MPMHIP_EINVAL, "snapshot container %zu has id %d outside [0, %d)", i, id, h.next_pid);
+    }
+  }
   const char *p = (const char *)src + sizeof h;
-  memcpy(c->groups.data(), p, sizeof(GroupParams) * h.n_groups); p += sizeof(GroupParams) * h.n_groups;
-  for (const GroupParams &g : c->groups)
-    if (g.type < MPMHIP_VISCO || g.type > MPMHIP_ELASTIC) return fail(c, MPMHIP_EINVAL, "snapshot holds an unknown material id %d", g.type);
+  {  // (nothing of the ctx is touched before the whole blob has been checked)
+    std::vector<GroupParams> gs((size_t)h.n_groups);
+    memcpy(gs.data(), p, sizeof(GroupParams) * h.n_groups); p += sizeof(GroupParams) * h.n_groups;
+    for (const GroupParams &g : gs)
+      if (g.type < MPMHIP_VISCO || g.type > MPMHIP_ELASTIC) return fail(c, MPMHIP_EINVAL, "snapshot holds an unknown material id %d", g.type);
+    c->groups.swap(gs);
+  }
   if (h.n_groups) HIPCHK(c, hipMemcpy(c->d_groups, c->groups.data(), sizeof(GroupParams) * h.n_groups, hipMemcpyHostToDevice));
   const size_t nb = sizeof(int64_t) * (size_t)h.nblk;
   for (std::vector<int64_t> *v : {&A.continuous, &A.strength, &A.cfl, &A.particle_t, &A.backup_t, &A.local_min}) { memcpy(v->data(), p, nb); p += nb; }

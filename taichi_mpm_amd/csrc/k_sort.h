@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_block_table(Params P, uint8_t *__restri
     }
     if (chunk == nchunks - 1 && threadIdx.x == 255) {
       const uint32_t grand = chunk_base + total;
-      if (grand > P.max_blocks) cnt->error |= 1u;
+      if (grand > P.max_blocks) atomicOr(&cnt->error, 1u);  // (k_cdf_rasterize may set its own bit from the side stream)
       cnt->n_active = grand;
     }
   }

@@ -915,8 +915,7 @@ class MPM:
         T = time.time()
         self.c.step(step_t)
         self.c.synchronize()
-        self.simulation_total_time += time.time() - T
-        self.c.frame += 1
+        self.simulation_total_time += time.time() - T  # (the frame counter is the frame loop's, scripts/async/async_mpm.py:246)
 
     def general_action(self, **kwargs):
         return self.c.general_action(kwargs)
@@ -974,9 +973,10 @@ class MPM:
         return os.path.join(self.snapshot_directory, "%04d.tcb" % iteration)
 
     def _frames(self, num_frames, frame_update, update_frequency, print_profile_info, per_frame):
+        # the loop and the snapshot names follow the simulation object's frame counter (scripts/async/async_mpm.py:236-248:
+        # `while self.c.frame < self.num_frames`), which snapshots carry: after load() the run RESUMES at the loaded frame
         n = self.num_frames if num_frames is None else num_frames
-        done = 0
-        while done < n:
+        while self.c.frame < n:
             for _ in range(update_frequency):
                 if frame_update:
                     frame_update(self.get_current_time(), self.frame_dt / update_frequency)
@@ -985,8 +985,8 @@ class MPM:
                 self.visualize()
             if print_profile_info and hasattr(self.c, "profile"):
                 print(json.dumps(self.c.profile(reset=True)))
-            done += 1
-            per_frame(done)
+            self.c.frame += 1
+            per_frame(self.c.frame)
 
     def simulate(self, num_frames=None, print_profile_info=False, frame_update=None, clear_output_directory=False,
                  update_frequency=1, **_ignored):

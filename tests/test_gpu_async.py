@@ -254,3 +254,53 @@ def test_async_snapshot_restart_continues_the_run(tm, tmp_path):
     from tests.common import rel_l2
     assert np.abs(pa["x"] - pb["x"]).max() <= 2e-6 and rel_l2(pa["v"], pb["v"]) <= 2e-4 and rel_l2(pa["F"], pb["F"]) <= 2e-5
     a.close(); b.close()
+
+
+def test_pooling_more_batches_than_the_ctx_holds_grows_the_records_before_the_gather(tm):
+    """a C-ABI caller may pool several batches of up to `cap` particles each (mpmhip_async_pool_particles empties the
+    slots, mpmhip_add_particles only checks slots + n <= cap): the working set of an advance can then exceed the ctx's
+    record arrays — they are grown BEFORE k_async_gather writes into them (async_api.h: async_advance)"""
+    res, dx, sa, sb = _two_stiffness_scene()
+    total = len(sa.x) + len(sb.x)
+    sim = tm.create_simulation3("async_mpm").initialize(dict(res=(res,) * 3, delta_x=dx, unit_delta_t=2e-6, max_units=1024,
+                                                             max_particles=max(len(sa.x), len(sb.x)) + 64))
+    sim.set_levelset(tm.mpm.LevelSet(friction=0.4).add_plane((0, 1, 0), d=-0.2))
+    for s, mat in ((sa, "elastic"), (sb, "sand")):
+        sim.add_particles(dict(type=mat, positions=s.x, velocities=s.v, F=s.F, B=s.B, aux=s.aux, params=s.gparams[0]))
+        sim._n_added = 0  # what a C caller does: it never tells anybody how many particles it has pooled so far
+    assert int(sim._L.mpmhip_capacity(sim._ctx)) < total
+    sim.step(2.5e-3)
+    assert int(sim._L.mpmhip_capacity(sim._ctx)) >= total  # the stiff level's working set is the whole scene at t = 0
+    p = sim.get_pool_particles()
+    assert len(np.unique(p["id"])) == total and np.isfinite(p["x"]).all()
+    sim.close()
+
+
+def test_a_snapshot_with_a_container_array_out_of_range_is_refused_before_anything_is_loaded(tm, tmp_path):
+    res, dx, sa, sb = _two_stiffness_scene()
+    kw = dict(res=(res,) * 3, delta_x=dx, unit_delta_t=2e-6, max_units=1024)
+    a = tm.create_simulation3("async_mpm").initialize(dict(kw))
+    a.add_particles(dict(type="elastic", positions=sa.x, velocities=sa.v, F=sa.F, B=sa.B, aux=sa.aux, params=sa.gparams[0]))
+    a.step(1e-3)
+    path = str(tmp_path / "ok.snap")
+    a.save_snapshot(path)
+    raw = np.fromfile(path, np.uint8)
+    n_cont = a.get_num_pool_particles()
+    hdr = 8 + (8 + 4 + 4 + 24 + 8 + 7 * 8 + 8 + 8) + 80 * 1 + 6 * 8 * int(np.prod(a.nb))  # frame word, SnapAsync, one group, six block arrays
+    for what, word in (("tag", 0x7FFFFFF0), ("id", -5)):
+        bad = raw.copy()
+        if what == "tag":
+            bad[hdr:hdr + 4] = np.array([word], np.uint32).view(np.uint8)
+        else:  # ids follow the tags: find the array through the blob's own container count
+            containers = (len(raw) - hdr) // (4 + 4 + 128)
+            bad[hdr + 4 * containers:hdr + 4 * containers + 4] = np.array([word], np.int32).view(np.uint8)
+        p2 = str(tmp_path / ("bad_%s.snap" % what))
+        bad.tofile(p2)
+        b = tm.create_simulation3("async_mpm").initialize(dict(kw))
+        with pytest.raises(tm.mpm.MPMError, match="snapshot container"):
+            b.load_snapshot(p2)
+        assert b.get_num_pool_particles() == 0  # nothing of the blob got in
+        b.load_snapshot(path)                   # ... and the ctx is still usable
+        assert b.get_num_pool_particles() == n_cont
+        b.close()
+    a.close()

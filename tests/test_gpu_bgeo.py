@@ -152,3 +152,31 @@ def test_bgeo_frame_of_the_benchmark_scene_at_full_size(tm):
     assert d["n"] == 1000000 and np.array_equal(d["data"]["index"].ravel(), np.arange(1000000))
     p = sim.get_particles(sort_by_id=True)
     assert np.array_equal(d["position"], p["x"]) and np.array_equal(d["data"]["v"], p["v"])
+
+
+def test_the_frame_loop_resumes_at_the_loaded_frame(tm, tmp_path):
+    """scripts/async/async_mpm.py:236-248: `while self.c.frame < self.num_frames`, snapshots named by c.frame — after load() of
+    frame 2's snapshot, simulate() runs frames 3 and 4 (not four more) and writes 0004.tcb, and the state equals the
+    uninterrupted run's"""
+    x = tm.mpm.lattice_cube(10, 18, 1.0 / 32)
+
+    def scene(out):
+        m = tm.MPM(res=(32,) * 3, base_delta_t=2e-4, frame_dt=1e-3, num_frames=4, snapshot_interval=2, output_directory=str(out))
+        m.set_levelset(tm.mpm.LevelSet(friction=0.4).add_plane((0, 1, 0), d=-0.2))
+        return m
+    a = scene(tmp_path / "a")
+    a.add_particles(type="sand", positions=x)
+    a.simulate()
+    assert a.c.frame == 4
+    assert sorted(os.listdir(tmp_path / "a" / "snapshots")) == ["0002.tcb", "0004.tcb"]
+    assert sorted(os.listdir(tmp_path / "a" / "frames")) == ["%04d.bgeo" % k for k in (1, 2, 3, 4)]
+    b = scene(tmp_path / "b")
+    b.add_particles(type="sand", positions=x)   # (the groups come from the scene, the particles from the snapshot)
+    b.load(str(tmp_path / "a" / "snapshots" / "0002.tcb"))
+    assert b.c.frame == 2
+    b.simulate()
+    assert b.c.frame == 4 and os.listdir(tmp_path / "b" / "snapshots") == ["0004.tcb"]
+    assert len(os.listdir(tmp_path / "b" / "frames")) == 2
+    assert abs(b.get_current_time() - a.get_current_time()) < 1e-6
+    pa, pb = a.c.get_particles(), b.c.get_particles()
+    assert np.array_equal(pa["id"], pb["id"]) and np.abs(pa["x"] - pb["x"]).max() < 1e-5
