@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MPMHIP_ABI_VERSION 2  /* 2: mpmhip_async_config gained left_boundary */
+#define MPMHIP_ABI_VERSION 3  /* 2: mpmhip_async_config gained left_boundary; 3: the native data plane of tiled runs (mpmhip_tiled_*, mpmhip_comm_*) */
 
 enum {
   MPMHIP_OK = 0,
@@ -293,6 +293,68 @@ int mpmhip_migration_scan(mpmhip_ctx *ctx, int32_t world, int64_t *counts, int32
 /* packs every leaver (n_total = sum of the counts just returned) into dev_records, grouped by destination */
 int mpmhip_export_leavers(mpmhip_ctx *ctx, int32_t world, const int64_t *counts, void *dev_records);
 int mpmhip_import_particles(mpmhip_ctx *ctx, int64_t n, const void *dev_records);
+/* ---- Multi-GPU tiling, the native data plane (csrc/tiled_api.h).  With the calls above the CALLER plans the halo boxes, owns
+ * the buffers and moves them (the Python / gloo path of taichi_mpm_amd/tiled.py, kept for the CPU tests).  With the calls below
+ * the LIBRARY does all of it: it derives the halo boxes from the partition (box R∩S = intersection of the two ranks' node
+ * boxes, clipped to the occupied part of the grid — the same on both sides), owns send / receive buffers sized for the worst
+ * case (no re-allocation when the boxes follow the particles), runs the per-substep loop, the halo exchange, the migration
+ * (scan, table all-gather, record exchange, import), the re-planning and the migration schedule — nothing returns to the
+ * host language between mpmhip_tiled_advance's first and last substep.  SURVEY section 8(e) collectives (1)-(3).
+ * Wires:
+ *   MPMHIP_WIRE_RCCL   ncclGroupStart / per-neighbour ncclSend + ncclRecv / ncclGroupEnd on a side stream of the ctx (fenced to
+ *                      the ctx stream by events; on the ctx stream itself when the overlap split is off), ncclAllGather for
+ *                      the migration table, grouped ncclSend / ncclRecv for the records.  librccl is dlopen'ed (env
+ *                      MPMHIP_RCCL_LIB names it): libmpmhip does not link it.  The caller only carries the ncclUniqueId from
+ *                      rank 0 to the other ranks (mpmhip_comm_unique_id / mpmhip_comm_init).
+ *   MPMHIP_WIRE_IPC    no collective at all: every rank maps every other rank's receive arena (hipIpcGetMemHandle /
+ *                      hipIpcOpenMemHandle); k_halo_pack writes each box straight into the peer's receive buffer (double
+ *                      buffered by substep parity) and publishes the substep's epoch in the peer's flag word; the peer's
+ *                      stream polls that word (a one-wave kernel with a bounded wait: sticky error instead of a hang) before
+ *                      its grid kernel reads the box.  Migration rows and records travel the same way.  The 64-byte handles
+ *                      are all-gathered by the caller (mpmhip_tiled_ipc_handle / _connect), or through the ctx's RCCL
+ *                      communicator when it has one (_connect with handles == NULL).
+ *   MPMHIP_WIRE_LOCAL  the IPC wire between ctx of ONE process (virtual ranks on one device: tests, bench.py --virtual):
+ *                      plain pointers instead of mapped ones, driven by mpmhip_tiled_advance_group.
+ * A ctx with a native plan refuses mpmhip_set_halo / mpmhip_tiled_run with a callback, and vice versa. */
+enum { MPMHIP_WIRE_RCCL = 1, MPMHIP_WIRE_IPC = 2, MPMHIP_WIRE_LOCAL = 3 };
+#define MPMHIP_COMM_ID_BYTES 128   /* sizeof(ncclUniqueId) */
+#define MPMHIP_IPC_HANDLE_BYTES 64 /* sizeof(hipIpcMemHandle_t) */
+typedef struct {
+  int32_t rank, world;
+  int32_t dims[3];             /* bricks per axis; world = dims[0] dims[1] dims[2] */
+  int32_t margin;              /* cells a particle may sit outside its brick between two migrations */
+  int32_t clip_lo[3], clip_hi[3]; /* node box the halo boxes are clipped to (occupied part of the grid + slack); the library
+                                  * re-wraps it around the particles at every migration (slack max(8, 2 margin + 4) cells) */
+  int32_t migrate_interval;    /* > 0: a migration every that many substeps (<= margin); 0: the CFL interval (= margin)
+                                  * stretched by the measured top speed, up to migrate_cap substeps */
+  int32_t migrate_cap;         /* 0: 64 */
+  int32_t wire;                /* MPMHIP_WIRE_* */
+  int32_t overlap;             /* boundary / interior split of the substep (mpmhip_set_overlap) */
+  int64_t inbox_records;       /* capacity of the migration inbox in records (the same on every rank); 0: max(65536, capacity / 8) */
+} mpmhip_tiled_config;
+/* rank 0: a fresh ncclUniqueId; every rank: ncclCommInitRank on the ctx's device (collective over the ranks) */
+int mpmhip_comm_unique_id(uint8_t id[MPMHIP_COMM_ID_BYTES]);
+int mpmhip_comm_init(mpmhip_ctx *ctx, const uint8_t id[MPMHIP_COMM_ID_BYTES], int32_t rank, int32_t world);
+int mpmhip_comm_destroy(mpmhip_ctx *ctx);
+/* loopback check of the binding: world-sized all-gather + a grouped send / receive ring (to self when world == 1) on device
+ * buffers, verified on the host; collective over the ranks */
+int mpmhip_comm_selftest(mpmhip_ctx *ctx);
+/* partition + plan + buffers; replaces mpmhip_set_partition / mpmhip_set_halo.  Synchronises. */
+int mpmhip_tiled_setup(mpmhip_ctx *ctx, const mpmhip_tiled_config *cfg, const int32_t *cuts_x, const int32_t *cuts_y,
+                       const int32_t *cuts_z);
+int mpmhip_tiled_ipc_handle(mpmhip_ctx *ctx, uint8_t handle[MPMHIP_IPC_HANDLE_BYTES]);
+int mpmhip_tiled_ipc_connect(mpmhip_ctx *ctx, const uint8_t *handles /* [world][64], own entry ignored; NULL: via RCCL */);
+int mpmhip_tiled_connect_local(mpmhip_ctx *const *ctxs, int32_t n /* = world, ctxs[r] = rank r */);
+/* n substeps of this rank, migrations included when they are due (collective over the ranks: every rank calls it with the
+ * same n).  Returns n or a negative error code. */
+int64_t mpmhip_tiled_advance(mpmhip_ctx *ctx, int64_t n);
+/* the same for all ranks of a MPMHIP_WIRE_LOCAL job: per substep begin of every rank, [interior of every rank,] end of every rank */
+int64_t mpmhip_tiled_advance_group(mpmhip_ctx *const *ctxs, int32_t n_ctx, int64_t n);
+/* out = {substeps run, substep of the next migration, particles migrated out so far, migrations, re-plans, halo boxes,
+ *        halo nodes (float4) per exchange, wire} */
+int mpmhip_tiled_state(mpmhip_ctx *ctx, int64_t out[8]);
+/* the current plan: boxes sorted by peer (send / recv = the library's buffers); returns the number of boxes */
+int32_t mpmhip_tiled_plan(mpmhip_ctx *ctx, int32_t capacity, mpmhip_halo_box *out);
 /* cell bounding box [lo, hi) of the active 4^3-cell blocks of the last sort (lo > hi when there are none);
  * synchronises.  Lets the caller clip the halo boxes to the occupied part of the grid. */
 int mpmhip_active_bounds(mpmhip_ctx *ctx, int32_t lo[3], int32_t hi[3]);

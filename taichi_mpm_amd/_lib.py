@@ -94,9 +94,18 @@ class HaloBox(C.Structure):
                 ("send", C.c_void_p), ("recv", C.c_void_p)]
 
 
+class TiledConfig(C.Structure):
+    """mirror of mpmhip_tiled_config"""
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("dims", C.c_int32 * 3), ("margin", C.c_int32),
+                ("clip_lo", C.c_int32 * 3), ("clip_hi", C.c_int32 * 3), ("migrate_interval", C.c_int32),
+                ("migrate_cap", C.c_int32), ("wire", C.c_int32), ("overlap", C.c_int32), ("inbox_records", C.c_int64)]
+
+
 MAX_PARTS = 16
 MAX_HALO_BOXES = 64
 MIGRATE_FLOATS = 44
+WIRE_RCCL, WIRE_IPC, WIRE_LOCAL = 1, 2, 3
+COMM_ID_BYTES, IPC_HANDLE_BYTES = 128, 64
 
 
 def lib_path():
@@ -140,6 +149,8 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_set_profile_sampling", "mpmhip_create"
             "mpmhip_download_grid", "mpmhip_upload_grid", "mpmhip_calculate_energy", "mpmhip_snapshot_size", "mpmhip_snapshot_save", "mpmhip_snapshot_load", "mpmhip_delete_particles_inside_level_set", "mpmhip_bgeo_size", "mpmhip_bgeo_encode", "mpmhip_write_bgeo", "mpmhip_set_profiling", "mpmhip_profile",
             "mpmhip_profile_reset", "mpmhip_set_partition", "mpmhip_set_halo", "mpmhip_halo_pack",
             "mpmhip_substep_begin", "mpmhip_substep_end", "mpmhip_substep_interior", "mpmhip_set_overlap", "mpmhip_tiled_run", "mpmhip_leaver_counts", "mpmhip_migration_scan", "mpmhip_export_leavers",
+            "mpmhip_comm_unique_id", "mpmhip_comm_init", "mpmhip_comm_destroy", "mpmhip_comm_selftest", "mpmhip_tiled_setup", "mpmhip_tiled_ipc_handle",
+            "mpmhip_tiled_ipc_connect", "mpmhip_tiled_connect_local", "mpmhip_tiled_advance", "mpmhip_tiled_advance_group", "mpmhip_tiled_state", "mpmhip_tiled_plan",
             "mpmhip_import_particles", "mpmhip_active_bounds", "mpmhip_num_slots", "mpmhip_request_compaction", "mpmhip_reserve", "mpmhip_capacity", "mpmhip_mpm88_create", "mpmhip_mpm88_destroy", "mpmhip_mpm88_last_error", "mpmhip_mpm88_add",
             "mpmhip_mpm88_num_particles", "mpmhip_mpm88_advance", "mpmhip_mpm88_download", "mpmhip_mpm88_download_grid",
             "mpmhip_async_enable", "mpmhip_async_begin", "mpmhip_async_pool_particles", "mpmhip_async_step", "mpmhip_async_load_pools", "mpmhip_async_state", "mpmhip_async_current_time", "mpmhip_async_block_times", "mpmhip_async_download_pools", "mpmhip_async_profile", "mpmhip_async_snapshot_size", "mpmhip_async_snapshot_save", "mpmhip_async_snapshot_load", "mpmhip_host_particle_bytes", "mpmhip_async_update_dt_limits", "mpmhip_async_blocks", "mpmhip_async_set_time_int", "mpmhip_async_table", "mpmhip_clear_particles", "mpmhip_set_dt", "mpmhip_set_time", "mpmhip_get_clock", "mpmhip_set_clock", "mpmhip_debug_allowed_dt",
@@ -215,6 +226,21 @@ def load():
     L.mpmhip_set_overlap.argtypes = [vp, C.c_int32]
     L.mpmhip_tiled_run.argtypes = [vp, C.c_int64, C.c_int64, EXCHANGE_FN, vp]
     L.mpmhip_tiled_run.restype = C.c_int64
+    bp = P(C.c_uint8)
+    L.mpmhip_comm_unique_id.argtypes = [bp]
+    L.mpmhip_comm_init.argtypes = [vp, bp, C.c_int32, C.c_int32]
+    L.mpmhip_comm_destroy.argtypes = [vp]
+    L.mpmhip_comm_selftest.argtypes = [vp]
+    L.mpmhip_tiled_setup.argtypes = [vp, P(TiledConfig), ip, ip, ip]
+    L.mpmhip_tiled_ipc_handle.argtypes = [vp, bp]
+    L.mpmhip_tiled_ipc_connect.argtypes = [vp, bp]
+    L.mpmhip_tiled_connect_local.argtypes = [P(vp), C.c_int32]
+    L.mpmhip_tiled_advance.argtypes = [vp, C.c_int64]
+    L.mpmhip_tiled_advance.restype = C.c_int64
+    L.mpmhip_tiled_advance_group.argtypes = [P(vp), C.c_int32, C.c_int64]
+    L.mpmhip_tiled_advance_group.restype = C.c_int64
+    L.mpmhip_tiled_state.argtypes = [vp, P(C.c_int64)]
+    L.mpmhip_tiled_plan.argtypes = [vp, C.c_int32, P(HaloBox)]
     L.mpmhip_num_slots.argtypes = [vp]
     L.mpmhip_num_slots.restype = C.c_int64
     L.mpmhip_reserve.argtypes = [vp, C.c_int64]

@@ -8,10 +8,13 @@ namespace mpm {
 // ------------------------------------------------------------------------------------------------ tiling
 // This rank's partial (m v, m) sums on every halo box -> the box's send buffer.  One thread per box node: the
 // node's grid block c and the <= 8 active source blocks c - q whose 6^3 tiles overlap it (same sum as k_grid).
+// Peer-write wires (`done` != nullptr): B.send is the box's place in the peer's receive buffer, so the pack IS the
+// exchange; the workgroup that finishes last publishes `epoch` in every peer's flag word (release at system scope, after
+// every workgroup's stores have been fenced), which the peer's k_halo_wait polls before its k_grid reads the box.
 __global__ __launch_bounds__(256) void k_halo_pack(Params P, Tiling T, const DevBox *__restrict__ boxes,
                                                    const uint32_t *__restrict__ bits,
                                                    const uint32_t *__restrict__ wprefix,
-                                                   const float4 *__restrict__ tiles) {
+                                                   const float4 *__restrict__ tiles, uint32_t *done, uint32_t epoch) {
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T.box_nodes; t += gridDim.x * blockDim.x) {
     int b = 0;
     while (b + 1 < T.n_boxes && t >= boxes[b + 1].off) b++;
@@ -35,6 +38,69 @@ __global__ __launch_bounds__(256) void k_halo_pack(Params P, Tiling T, const Dev
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     B.send[r] = acc;
+  }
+  if (done) {
+    __threadfence_system();  // this thread's box stores are visible to the peers before the counter moves
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t prev = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (prev == gridDim.x - 1) {
+        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int b = 0; b < T.n_boxes; b++)
+          __hip_atomic_store(boxes[b].flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ peer-write wires
+// lane i < n waits until word[idx[i]] has reached `epoch` (the peers publish monotonically increasing epochs).  A bounded
+// wait: after `timeout_ticks` of the 100 MHz wall clock the sticky error bit 16 is set and the kernel returns — a peer
+// that never arrives must cost an error message, not the GPU.
+__global__ __launch_bounds__(64) void k_epoch_wait(const uint32_t *words, const int *__restrict__ idx, int n, uint32_t epoch,
+                                                   unsigned long long timeout_ticks, Counters *cnt) {
+  const int i = threadIdx.x;
+  if (i >= n) return;
+  const uint32_t *w = words + idx[i];
+  const unsigned long long t0 = wall_clock64();
+  while ((int32_t)(__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+    __builtin_amdgcn_s_sleep(16);
+    if (wall_clock64() - t0 > timeout_ticks) {
+      atomicOr(&cnt->error, 16u);
+      return;
+    }
+  }
+}
+
+// gridDim.x destinations x gridDim.y chunks: `words[d]` 4-byte words from src[d] to dst[d]; the workgroup of a destination
+// that finishes last stores epoch -> flag[d] (release, system scope).  done[d] counts the finished chunks (left at 0).
+struct PutList {
+  const uint32_t *src[MPMHIP_MAX_HALO_BOXES];
+  uint32_t *dst[MPMHIP_MAX_HALO_BOXES];
+  uint32_t *flag[MPMHIP_MAX_HALO_BOXES];
+  uint32_t words[MPMHIP_MAX_HALO_BOXES];
+};
+__global__ __launch_bounds__(256) void k_put(PutList L, uint32_t epoch, uint32_t *done) {
+  const int d = blockIdx.x;
+  const uint32_t n = L.words[d];
+  const uint32_t *__restrict__ s = L.src[d];
+  uint32_t *__restrict__ o = L.dst[d];
+  const uint32_t t = blockIdx.y * blockDim.x + threadIdx.x, stride = gridDim.y * blockDim.x;
+  if (((uintptr_t)s & 15) == 0 && ((uintptr_t)o & 15) == 0) {
+    const uint32_t n4 = n >> 2;
+    for (uint32_t i = t; i < n4; i += stride) reinterpret_cast<uint4 *>(o)[i] = reinterpret_cast<const uint4 *>(s)[i];
+    for (uint32_t i = (n4 << 2) + t; i < n; i += stride) o[i] = s[i];
+  } else {
+    for (uint32_t i = t; i < n; i += stride) o[i] = s[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t prev = __hip_atomic_fetch_add(&done[d], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == gridDim.y - 1) {
+      __hip_atomic_store(&done[d], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (L.flag[d]) __hip_atomic_store(L.flag[d], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 

@@ -129,8 +129,10 @@ struct DevBox {
   int lo[3], dim[3];
   int peer;
   uint32_t off;  // first node of this box in the concatenated (all boxes) node numbering
-  float4 *send;
-  const float4 *recv;
+  float4 *send;        // where k_halo_pack writes this rank's partial sums: a local send buffer, or — peer-write wires
+                       // (tiled_api.h) — the box's place in the PEER's receive buffer, mapped into this process
+  const float4 *recv;  // the peer's partial sums, read by k_grid
+  uint32_t *flag;      // peer-write wires: this rank's word in the peer's array of halo epochs (else nullptr)
 };
 
 // ------------------------------------------------------------------------------------------------ Morton

@@ -60,6 +60,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only (tiled_api.h): librccl is dlopen'ed, this library does not link it
+
 
 #ifndef MPM_G2P_MINW
 #define MPM_G2P_MINW 2  // __launch_bounds__ waves/SIMD of k_g2p.  (256, 3) states the 168-VGPR budget explicitly but was measured 3 % slower
@@ -231,7 +234,40 @@ struct mpmhip_ctx {
   } rigid;
   bool overlap = false;        // mpmhip_set_overlap: split tiled substeps into boundary / interior work
   bool ov_active = false, interior_done = false;  // state of the substep in flight
+  const DevBox *d_boxes_cur = nullptr;  // the box table the pack / grid kernels of the substep in flight read
+  // the native data plane of a tiled run (tiled_api.h): plan, arena, wire, migration state
+  struct TiledNative {
+    struct Box { int peer; int lo[3], hi[3]; uint64_t vol, off, peer_off; };  // off / peer_off: float4 nodes into this rank's / the peer's buffers
+    struct Peer {  // a rank's arena as THIS process addresses it
+      uint32_t *flags = nullptr, *table[2] = {nullptr, nullptr};
+      float4 *recv[2] = {nullptr, nullptr}, *inbox = nullptr;
+      void *ipc_base = nullptr;  // mapped with hipIpcOpenMemHandle (closed on destroy)
+    };
+    struct Mig { std::vector<int64_t> counts; int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; float speed = 0.0f; int64_t total = 0, n_out = 0, n_in = 0; } mig;
+    bool on = false, connected = false, exch_on_side = false;
+    int world = 1, wire = 0;
+    int clip_lo[3] = {0, 0, 0}, clip_hi[3] = {0, 0, 0};
+    std::vector<Box> boxes;
+    std::vector<int> halo_peers, all_ranks;
+    uint64_t total = 0, halo_cap = 0, inbox_cap = 0;
+    size_t arena_bytes = 0, table_bytes = 0, recv_bytes = 0, mig_send_cap = 0;
+    char *arena = nullptr;
+    uint32_t *flags = nullptr, *table[2] = {nullptr, nullptr}, *row = nullptr, *d_done = nullptr;
+    float4 *send = nullptr, *recv[2] = {nullptr, nullptr}, *inbox = nullptr, *mig_send = nullptr;
+    DevBox *d_boxes[2] = {nullptr, nullptr};
+    int *d_halo_idx = nullptr, *d_all_idx = nullptr;
+    std::vector<Peer> peers;
+    uint32_t epoch = 0, mig_epoch = 0;
+    unsigned long long timeout_ticks = 2000000000ull;  // of the 100 MHz wall clock
+    void *comm = nullptr;  // ncclComm_t
+    int comm_rank = 0, comm_world = 1;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    int64_t k = 0, next_migration = 0, migrated_out = 0, migrations = 0, replans = 0;
+    int migrate_interval = 4, adaptive_cap = 64;
+  } tn;
 };
+namespace { void tn_free(mpmhip_ctx *c); void tn_begin_substep(mpmhip_ctx *c); }
 
 static int fail(mpmhip_ctx *c, int code, const char *fmt, ...) {
   char buf[512];
@@ -526,6 +562,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   { auto &R = c->rigid; hipFree(R.d_rb); hipFree(R.d_smp); hipFree(R.d_elems); hipFree(R.cdf.slot); hipFree(R.cdf.page_key); hipFree(R.cdf.mind);
     hipFree(R.cdf.tags); hipFree(R.cdf.rpage); hipFree(R.d_bnd); if (R.side) { hipStreamSynchronize(R.side); hipStreamDestroy(R.side); } if (R.ev_fork) hipEventDestroy(R.ev_fork); if (R.ev_join) hipEventDestroy(R.ev_join);
     hipFree(R.d_blk_rigid); hipFree(R.d_rigid_list); hipFree(R.d_counters); hipFree(R.d_joints); }
+  tn_free(c);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -651,6 +688,9 @@ static int read_counters(mpmhip_ctx *c, Counters &h) {
   if (h.error & 2u)
     return fail(c, MPMHIP_ECAPACITY, "a particle moved more than margin=%d cells outside this rank's brick between "
                 "two migrations: migrate more often or raise the margin", c->T.margin);
+  if (h.error & 16u)
+    return fail(c, MPMHIP_EHIP, "tiled run: a peer rank's halo / migration epoch did not arrive within the wait limit "
+                "(MPMHIP_TILE_WAIT_S): a rank is missing, stalled or out of step");
   if (h.error & 4u)
     return fail(c, MPMHIP_ECAPACITY, "the colored distance field of the rigid bodies needs more than %u pages of 4^3 nodes: "
                 "recreate the ctx with a larger max_blocks", c->rigid.max_pages);
@@ -999,7 +1039,7 @@ static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
                                      : (mode == 2 ? k_grid<2, false> : (mode == 3 ? k_grid<3, false> : k_grid<4, false>)));
   static const int grid_wgs_small = getenv("MPMHIP_GRID_WGS") ? atoi(getenv("MPMHIP_GRID_WGS")) : 16384;
   hipLaunchKernelGGL(kern, dim3(per_cand ? grid_wgs_small : 4096), dim3(256), 0, c->stream, c->P, c->cnt, c->act_blk, c->bits, c->wprefix, c->tiles,
-                     c->gridv, c->fat_slot, c->dense, c->T, (const DevBox *)c->d_boxes, c->LS, phase);
+                     c->gridv, c->fat_slot, c->dense, c->T, c->d_boxes_cur, c->LS, phase);
   return launch_check(c, "grid");
 }
 static int do_g2p(mpmhip_ctx *c, int phase = 0) {
@@ -1162,8 +1202,9 @@ static int do_halo_pack(mpmhip_ctx *c) {
   if (c->T.n_boxes == 0) return MPMHIP_OK;
   int nb = (int)((c->T.box_nodes + 255) / 256);
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(k_halo_pack, dim3(nb), dim3(256), 0, c->stream, c->P, c->T, (const DevBox *)c->d_boxes, c->bits,
-                     c->wprefix, (const float4 *)c->tiles);
+  const bool peer_wire = c->tn.on && (c->tn.wire == MPMHIP_WIRE_IPC || c->tn.wire == MPMHIP_WIRE_LOCAL);
+  hipLaunchKernelGGL(k_halo_pack, dim3(nb), dim3(256), 0, c->stream, c->P, c->T, c->d_boxes_cur, c->bits, c->wprefix,
+                     (const float4 *)c->tiles, peer_wire ? c->tn.d_done + MPMHIP_MAX_HALO_BOXES : (uint32_t *)nullptr, c->tn.epoch);
   return launch_check(c, "halo_pack");
 }
 
@@ -1196,6 +1237,7 @@ int mpmhip_substep_begin(mpmhip_ctx *c) {
   if (ev && (lvl == 1 || lvl == 3)) HIPCHK(c, hipEventRecord(ev->e[1], c->stream));
   if ((rc = do_p2g(c, c->ov_active ? 1 : 0))) return rc;
   if (ev && lvl == 3) HIPCHK(c, hipEventRecord(ev->e[2], c->stream));
+  if (c->tn.on) tn_begin_substep(c);  // (native data plane: this substep's epoch and box table)
   if ((rc = do_halo_pack(c))) return rc;
   if (ev && lvl == 1) HIPCHK(c, hipEventRecord(ev->e[2], c->stream));
   if (ev && lvl == 4) HIPCHK(c, hipEventRecord(ev->e[1], c->stream));
@@ -1257,6 +1299,7 @@ int mpmhip_set_overlap(mpmhip_ctx *c, int32_t enabled) {
 
 int64_t mpmhip_tiled_run(mpmhip_ctx *c, int64_t n, int64_t until_migration, mpmhip_exchange_fn exchange, void *user) {
   if (!c || n < 0) return MPMHIP_EINVAL;
+  if (c->tn.on) return fail(c, MPMHIP_EINVAL, "this ctx has a native plan (mpmhip_tiled_setup): advance it with mpmhip_tiled_advance");
   if (c->T.n_boxes > 0 && !exchange) return fail(c, MPMHIP_EINVAL, "this ctx has halo boxes: tiled_run needs an exchange callback");
   if (until_migration > 0 && until_migration < n) n = until_migration;
   for (int64_t i = 0; i < n; i++) {
@@ -1732,6 +1775,7 @@ int mpmhip_set_partition(mpmhip_ctx *c, int32_t rank, const int32_t dims[3], con
 int mpmhip_set_halo(mpmhip_ctx *c, int32_t n, const mpmhip_halo_box *boxes) {
   if (!c || n < 0 || n > MPMHIP_MAX_HALO_BOXES || (n > 0 && !boxes)) return MPMHIP_EINVAL;
   if (n > 0 && !c->T.enabled) return fail(c, MPMHIP_EINVAL, "set_halo needs set_partition first");
+  if (c->tn.on) return fail(c, MPMHIP_EINVAL, "this ctx has a native plan (mpmhip_tiled_setup): its halo boxes are the library's");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   Tiling &T = c->T;
@@ -1764,13 +1808,14 @@ int mpmhip_set_halo(mpmhip_ctx *c, int32_t n, const mpmhip_halo_box *boxes) {
     }
     if (!proper) empty_interior = true;
     hb[i].peer = b.peer; hb[i].off = (uint32_t)off;
-    hb[i].send = (float4 *)b.send; hb[i].recv = (const float4 *)b.recv;
+    hb[i].send = (float4 *)b.send; hb[i].recv = (const float4 *)b.recv; hb[i].flag = nullptr;
     off += (uint64_t)hb[i].dim[0] * hb[i].dim[1] * hb[i].dim[2];
     if (off >= (1ull << 31)) return fail(c, MPMHIP_EINVAL, "halo boxes too large");
   }
   if (empty_interior) for (int a = 0; a < 3; a++) T.int_hi[a] = T.int_lo[a];
   if (!c->d_boxes) HIPCHK(c, dmalloc(&c->d_boxes, (size_t)MPMHIP_MAX_HALO_BOXES));
   HIPCHK(c, hipMemcpy(c->d_boxes, hb.data(), sizeof(DevBox) * n, hipMemcpyHostToDevice));
+  c->d_boxes_cur = c->d_boxes;
   T.n_boxes = n; T.box_nodes = (uint32_t)off;
   return MPMHIP_OK;
 }
@@ -2949,3 +2994,5 @@ int mpmhip_debug_plasticity(mpmhip_ctx *c, int32_t material, const float params[
 }
 
 }  // extern "C"
+
+#include "tiled_api.h"

@@ -1,0 +1,751 @@
+// taichi_mpm_amd/csrc/tiled_api.h — the native data plane of a tiled (multi-GPU) run: plan, buffers, wires, migration
+// and the per-substep loop (include/mpmhip.h: "Multi-GPU tiling, the native data plane").  Host code of libmpmhip,
+// included by mpmhip.hip.  The reference has no multi-process code (dead `#ifdef TC_USE_MPI`, src/mpm.cpp:6-8): the contract
+// is SURVEY section 8(e) — bricks, halo sum after P2G, particle migration after G2P, a few scalars per migration.
+//
+//   plan      box(R, S) = node_box(R) ∩ node_box(S), node_box(R) = [brick.lo - margin, brick.hi + margin + 2) clipped to the
+//             occupied part of the grid; sorted by peer.  Every rank can compute every rank's plan (the partition and the clip
+//             box are global), so a writer knows where a box lives in its reader's buffers.
+//   arena     ONE device allocation per rank: flag words, two migration tables, two receive buffers (parity of the substep),
+//             the migration inbox.  Sized for the worst case (clip = the whole grid), so it is allocated — and, for the IPC
+//             wire, mapped by the peers — exactly once.
+//   epochs    substep e: the writer stores into recv[e & 1] of the reader and then publishes e in the reader's word
+//             flag[writer]; the reader waits for flag >= e before reading.  Two buffers suffice: a writer reaches substep
+//             e + 2 only after it has seen the reader's epoch e + 1, which the reader publishes after its reads of substep e.
+//             Migrations carry their own epoch m (tables alternate by m & 1; records wait for the whole table of m, which
+//             every rank contributes to only after its import of m - 1).
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl is dlopen'ed, libmpmhip does not link it
+
+namespace {
+
+struct RcclApi {
+  void *handle = nullptr;
+  std::string error;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+RcclApi *rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return &api;
+  tried = true;
+  const char *names[] = {getenv("MPMHIP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *n : names) {
+    if (!n || !*n) continue;
+    api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (api.handle) break;
+    api.error = dlerror();
+  }
+  if (!api.handle) return &api;
+  bool ok = true;
+  auto sym = [&](const char *name) { void *p = dlsym(api.handle, name); if (!p) { ok = false; api.error = std::string("missing symbol ") + name; } return p; };
+  api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+  api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+  api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+  api.CommAbort = (decltype(api.CommAbort))sym("ncclCommAbort");
+  api.Send = (decltype(api.Send))sym("ncclSend");
+  api.Recv = (decltype(api.Recv))sym("ncclRecv");
+  api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+  api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+  api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+  api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+  if (!ok) { dlclose(api.handle); api.handle = nullptr; }
+  return &api;
+}
+
+#define NCCLCHK(c, call)                                                                                   \
+  do {                                                                                                     \
+    ncclResult_t r_ = (call);                                                                              \
+    if (r_ != ncclSuccess) return fail((c), MPMHIP_EHIP, "%s failed: %s", #call, rccl_api()->GetErrorString(r_)); \
+  } while (0)
+
+constexpr int TN_MAX_WORLD = MPMHIP_MAX_HALO_BOXES;      // every other rank can be a halo peer
+constexpr uint32_t TN_ROW = TN_MAX_WORLD + 8;            // words of a migration row: [counts(world) | lo3 | hi3 | speed], padded
+constexpr size_t TN_FLAG_BYTES = 4096;                   // halo epochs [world] | table epochs [world] | record epochs [world]
+
+int tn_wait(mpmhip_ctx *c, const uint32_t *words, const std::vector<int> &who, int *d_idx, uint32_t epoch) {
+  if (who.empty()) return MPMHIP_OK;
+  hipLaunchKernelGGL(k_epoch_wait, dim3(1), dim3(64), 0, c->stream, words, (const int *)d_idx, (int)who.size(), epoch,
+                     c->tn.timeout_ticks, c->cnt);
+  return launch_check(c, "epoch_wait");
+}
+
+// node box of `rank` under the partition (cuts of c->T) and a clip box
+void tn_node_box(const Tiling &T, const int clip_lo[3], const int clip_hi[3], int rank, int lo[3], int hi[3]) {
+  const int pc[3] = {rank / (T.dims[1] * T.dims[2]), (rank / T.dims[2]) % T.dims[1], rank % T.dims[2]};
+  for (int a = 0; a < 3; a++) {
+    lo[a] = std::max(clip_lo[a], T.cuts[a][pc[a]] - T.margin);
+    hi[a] = std::min(clip_hi[a], T.cuts[a][pc[a] + 1] + T.margin + 2);
+  }
+}
+// halo boxes of `rank`, sorted by peer, with their offsets (float4 nodes) in the rank's buffers
+std::vector<mpmhip_ctx::TiledNative::Box> tn_plan(const Tiling &T, int world, const int clip_lo[3], const int clip_hi[3], int rank,
+                                                   uint64_t *total) {
+  std::vector<mpmhip_ctx::TiledNative::Box> out;
+  int alo[3], ahi[3];
+  tn_node_box(T, clip_lo, clip_hi, rank, alo, ahi);
+  uint64_t off = 0;
+  for (int s = 0; s < world; s++) {
+    if (s == rank) continue;
+    int blo[3], bhi[3];
+    tn_node_box(T, clip_lo, clip_hi, s, blo, bhi);
+    mpmhip_ctx::TiledNative::Box b;
+    bool any = true;
+    for (int a = 0; a < 3; a++) {
+      b.lo[a] = std::max(alo[a], blo[a]);
+      b.hi[a] = std::min(ahi[a], bhi[a]);
+      any = any && b.lo[a] < b.hi[a];
+    }
+    if (!any) continue;
+    b.peer = s;
+    b.vol = (uint64_t)(b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]) * (b.hi[2] - b.lo[2]);
+    b.off = off;
+    b.peer_off = 0;
+    off += b.vol;
+    out.push_back(b);
+  }
+  if (total) *total = off;
+  return out;
+}
+
+int tn_clip_slack(const Tiling &T) { return std::max(8, 2 * T.margin + 4); }
+
+// (re)build this rank's plan for the current clip box and upload the device box tables; no allocation
+int tn_apply_plan(mpmhip_ctx *c) {
+  auto &N = c->tn;
+  Tiling &T = c->T;
+  uint64_t total = 0;
+  N.boxes = tn_plan(T, N.world, N.clip_lo, N.clip_hi, T.rank, &total);
+  if (N.boxes.size() > MPMHIP_MAX_HALO_BOXES) return fail(c, MPMHIP_EINVAL, "too many halo boxes (%zu)", N.boxes.size());
+  if (total > N.halo_cap) return fail(c, MPMHIP_ECAPACITY, "internal: halo plan of %llu nodes exceeds the arena (%llu)", (unsigned long long)total, (unsigned long long)N.halo_cap);
+  N.total = total;
+  for (auto &b : N.boxes) {  // where the box lives in the peer's buffers: the peer's own plan
+    uint64_t ptotal = 0;
+    auto pp = tn_plan(T, N.world, N.clip_lo, N.clip_hi, b.peer, &ptotal);
+    bool found = false;
+    for (auto &q : pp)
+      if (q.peer == T.rank) { b.peer_off = q.off; found = true; }
+    if (!found) return fail(c, MPMHIP_EINVAL, "internal: halo box towards rank %d has no counterpart", b.peer);
+  }
+  // the overlap-free interior of this rank's node box and the device tables (as mpmhip_set_halo)
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  T.n_boxes = 0; T.box_nodes = 0;
+  int nlo[3], nhi[3];
+  for (int a = 0; a < 3; a++) {
+    nlo[a] = std::max(0, T.lo[a] - T.margin);
+    nhi[a] = std::min(c->P.res[a] + 1, T.hi[a] + T.margin + 2);
+    T.int_lo[a] = nlo[a]; T.int_hi[a] = nhi[a];
+  }
+  const size_t n = N.boxes.size();
+  bool empty_interior = false;
+  const bool peer_wire = N.wire == MPMHIP_WIRE_IPC || N.wire == MPMHIP_WIRE_LOCAL;
+  std::vector<DevBox> hb[2] = {std::vector<DevBox>(n), std::vector<DevBox>(n)};
+  std::vector<int> idx(n);
+  for (size_t i = 0; i < n; i++) {
+    const auto &b = N.boxes[i];
+    bool proper = false;
+    for (int a = 0; a < 3; a++) {
+      if (b.lo[a] <= nlo[a] && b.hi[a] >= nhi[a]) continue;
+      proper = true;
+      if (b.lo[a] <= nlo[a]) T.int_lo[a] = std::max(T.int_lo[a], b.hi[a]);
+      else if (b.hi[a] >= nhi[a]) T.int_hi[a] = std::min(T.int_hi[a], b.lo[a]);
+      else empty_interior = true;
+    }
+    if (!proper) empty_interior = true;
+    for (int par = 0; par < 2; par++) {
+      DevBox &d = hb[par][i];
+      for (int a = 0; a < 3; a++) { d.lo[a] = b.lo[a]; d.dim[a] = b.hi[a] - b.lo[a]; }
+      d.peer = b.peer; d.off = (uint32_t)b.off;
+      if (peer_wire) {
+        const auto &P = N.peers[b.peer];
+        d.send = P.recv[par] ? P.recv[par] + b.peer_off : nullptr;  // (nullptr until the peers are connected)
+        d.recv = N.recv[par] + b.off;
+        d.flag = P.flags ? P.flags + T.rank : nullptr;
+      } else {
+        d.send = N.send + b.off;
+        d.recv = N.recv[0] + b.off;
+        d.flag = nullptr;
+      }
+    }
+    idx[i] = b.peer;
+  }
+  if (empty_interior) for (int a = 0; a < 3; a++) T.int_hi[a] = T.int_lo[a];
+  if (n) {
+    for (int par = 0; par < 2; par++) HIPCHK(c, hipMemcpy(N.d_boxes[par], hb[par].data(), sizeof(DevBox) * n, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(N.d_halo_idx, idx.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+  }
+  N.halo_peers = idx;
+  T.n_boxes = (int)n; T.box_nodes = (uint32_t)total;
+  c->d_boxes_cur = N.d_boxes[N.epoch & 1];
+  return MPMHIP_OK;
+}
+
+bool tn_connected(const mpmhip_ctx *c) {
+  const auto &N = c->tn;
+  if (N.wire == MPMHIP_WIRE_RCCL) return N.comm != nullptr;
+  return N.connected;
+}
+
+// ------------------------------------------------------------------------------------------------ the halo exchange
+// begin: which box table the pack / grid kernels of this substep use (parity of the epoch) — called by mpmhip_substep_begin
+void tn_begin_substep(mpmhip_ctx *c) {
+  auto &N = c->tn;
+  N.epoch++;
+  const bool peer_wire = N.wire == MPMHIP_WIRE_IPC || N.wire == MPMHIP_WIRE_LOCAL;
+  c->d_boxes_cur = N.d_boxes[peer_wire ? (N.epoch & 1) : 0];
+}
+
+int tn_exchange_start(mpmhip_ctx *c) {
+  auto &N = c->tn;
+  if (N.boxes.empty()) return MPMHIP_OK;
+  if (N.wire != MPMHIP_WIRE_RCCL) return MPMHIP_OK;  // peer wires: k_halo_pack wrote the boxes and published the epoch
+  RcclApi *R = rccl_api();
+  hipStream_t st = c->stream;
+  if (c->ov_active) {  // the exchange runs beside the interior kernels: side stream, fenced by events
+    HIPCHK(c, hipEventRecord(N.ev_a, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(N.side, N.ev_a, 0));
+    st = N.side;
+  }
+  NCCLCHK(c, R->GroupStart());
+  for (const auto &b : N.boxes) {
+    NCCLCHK(c, R->Send(N.send + b.off, (size_t)b.vol * 4, ncclFloat, b.peer, (ncclComm_t)N.comm, st));
+    NCCLCHK(c, R->Recv(N.recv[0] + b.off, (size_t)b.vol * 4, ncclFloat, b.peer, (ncclComm_t)N.comm, st));
+  }
+  NCCLCHK(c, R->GroupEnd());
+  if (st != c->stream) HIPCHK(c, hipEventRecord(N.ev_b, st));
+  N.exch_on_side = st != c->stream;
+  return MPMHIP_OK;
+}
+
+int tn_exchange_wait(mpmhip_ctx *c) {
+  auto &N = c->tn;
+  if (N.boxes.empty()) return MPMHIP_OK;
+  if (N.wire == MPMHIP_WIRE_RCCL) {
+    if (N.exch_on_side) HIPCHK(c, hipStreamWaitEvent(c->stream, N.ev_b, 0));
+    return MPMHIP_OK;
+  }
+  return tn_wait(c, N.flags, N.halo_peers, N.d_halo_idx, N.epoch);
+}
+
+// ------------------------------------------------------------------------------------------------ migration
+// phase A: scan (leavers per destination, bounds, top speed) and publish this rank's row of the table
+int tn_mig_a(mpmhip_ctx *c) {
+  auto &N = c->tn;
+  const int world = N.world;
+  int rc = ensure_counts(c, world);
+  if (rc) return rc;
+  N.mig_epoch++;
+  hipLaunchKernelGGL(k_scan_init, dim3((world + 7 + 255) / 256), dim3(256), 0, c->stream, c->d_counts, world);
+  int grid = particle_grid(c->n_slots);
+  if (grid > 128) grid = 128;
+  hipLaunchKernelGGL(k_leaver_count, dim3(grid), dim3(256), 0, c->stream, c->P, c->T, (const float4 *)c->rg, (const float4 *)c->rp,
+                     c->d_counts, reinterpret_cast<int *>(c->d_counts + world), c->cnt);
+  if ((rc = launch_check(c, "leaver_count"))) return rc;
+  uint32_t *table = N.table[N.mig_epoch & 1];
+  if (N.wire == MPMHIP_WIRE_RCCL) {
+    HIPCHK(c, hipMemcpyAsync(N.row, c->d_counts, sizeof(uint32_t) * (world + 7), hipMemcpyDeviceToDevice, c->stream));
+    NCCLCHK(c, rccl_api()->AllGather(N.row, table, TN_ROW, ncclUint32, (ncclComm_t)N.comm, c->stream));
+    return MPMHIP_OK;
+  }
+  PutList L;
+  memset(&L, 0, sizeof L);
+  for (int p = 0; p < world; p++) {
+    L.src[p] = c->d_counts;
+    L.dst[p] = (p == c->T.rank ? table : N.peers[p].table[N.mig_epoch & 1]) + (size_t)c->T.rank * TN_ROW;
+    L.flag[p] = (p == c->T.rank ? N.flags : N.peers[p].flags) + TN_MAX_WORLD + c->T.rank;
+    L.words[p] = (uint32_t)world + 7;
+  }
+  hipLaunchKernelGGL(k_put, dim3(world, 1), dim3(256), 0, c->stream, L, N.mig_epoch, N.d_done);
+  return launch_check(c, "put (migration row)");
+}
+
+// phase B: read the table (the ONE synchronisation of a migration), pack the leavers and send them
+int tn_mig_b(mpmhip_ctx *c) {
+  auto &N = c->tn;
+  const int world = N.world, me = c->T.rank;
+  int rc;
+  uint32_t *table = N.table[N.mig_epoch & 1];
+  if (N.wire != MPMHIP_WIRE_RCCL && (rc = tn_wait(c, N.flags + TN_MAX_WORLD, N.all_ranks, N.d_all_idx, N.mig_epoch))) return rc;
+  uint32_t *h = c->h_pinned + 2048;  // behind the counters and the cursors of mpmhip_export_leavers
+  HIPCHK(c, hipMemcpyAsync(h, table, sizeof(uint32_t) * TN_ROW * world, hipMemcpyDeviceToHost, c->stream));
+  Counters hc;
+  if ((rc = read_counters(c, hc))) return rc;  // synchronises; reports a margin violation or a wait that timed out
+  auto &M = N.mig;
+  M.counts.assign((size_t)world * world, 0);
+  int64_t total = 0;
+  int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-(1 << 30), -(1 << 30), -(1 << 30)};
+  float speed = 0.0f;
+  for (int r = 0; r < world; r++) {
+    const uint32_t *row = h + (size_t)r * TN_ROW;
+    for (int s = 0; s < world; s++) { M.counts[(size_t)r * world + s] = row[s]; total += row[s]; }
+    const int rlo[3] = {(int)row[world], (int)row[world + 1], (int)row[world + 2]};
+    const int rhi[3] = {(int)row[world + 3], (int)row[world + 4], (int)row[world + 5]};
+    if (rlo[0] <= rhi[0] && rlo[1] <= rhi[1] && rlo[2] <= rhi[2]) {  // (a rank without particles reports lo > hi)
+      for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], rlo[a]); hi[a] = std::max(hi[a], rhi[a]); }
+    }
+    float s;
+    memcpy(&s, &row[world + 6], 4);
+    if (s > speed) speed = s;
+  }
+  for (int a = 0; a < 3; a++) { M.lo[a] = lo[a]; M.hi[a] = hi[a]; }
+  M.speed = speed;
+  M.total = total;
+  M.n_out = 0; M.n_in = 0;
+  for (int s = 0; s < world; s++) { M.n_out += M.counts[(size_t)me * world + s]; M.n_in += M.counts[(size_t)s * world + me]; }
+  if (total == 0) return MPMHIP_OK;
+  // records: grouped by destination in mig_send (k_leaver_pack), then one message per destination
+  if ((size_t)M.n_out > N.mig_send_cap) {
+    if (N.mig_send) (void)hipFree(N.mig_send);
+    N.mig_send = nullptr;
+    N.mig_send_cap = (size_t)M.n_out + (size_t)M.n_out / 2 + 4096;
+    HIPCHK(c, dmalloc(&N.mig_send, N.mig_send_cap * 11));
+  }
+  if ((uint64_t)M.n_in > N.inbox_cap)
+    return fail(c, MPMHIP_ECAPACITY, "migration: %lld arriving particles exceed the inbox of %llu records (mpmhip_tiled_config.inbox_records)",
+                (long long)M.n_in, (unsigned long long)N.inbox_cap);
+  std::vector<int64_t> mine((size_t)world);
+  for (int s = 0; s < world; s++) mine[s] = M.counts[(size_t)me * world + s];
+  if (M.n_out && (rc = mpmhip_export_leavers(c, world, mine.data(), N.mig_send))) return rc;
+  N.migrated_out += M.n_out;
+  if (N.wire == MPMHIP_WIRE_RCCL) {
+    RcclApi *R = rccl_api();
+    NCCLCHK(c, R->GroupStart());
+    uint64_t soff = 0, roff = 0;
+    for (int s = 0; s < world; s++) {
+      const int64_t ns = M.counts[(size_t)me * world + s], nr = M.counts[(size_t)s * world + me];
+      if (s != me && ns) NCCLCHK(c, R->Send(N.mig_send + soff * 11, (size_t)ns * MPMHIP_MIGRATE_FLOATS, ncclFloat, s, (ncclComm_t)N.comm, c->stream));
+      if (s != me && nr) NCCLCHK(c, R->Recv(N.inbox + roff * 11, (size_t)nr * MPMHIP_MIGRATE_FLOATS, ncclFloat, s, (ncclComm_t)N.comm, c->stream));
+      soff += ns; roff += nr;
+    }
+    NCCLCHK(c, R->GroupEnd());
+    return MPMHIP_OK;
+  }
+  PutList L;
+  memset(&L, 0, sizeof L);
+  uint64_t soff = 0;
+  uint32_t most = 0;
+  for (int s = 0; s < world; s++) {
+    const int64_t ns = M.counts[(size_t)me * world + s];
+    uint64_t before = 0;  // records of lower ranks in s's inbox
+    for (int r = 0; r < me; r++) before += M.counts[(size_t)r * world + s];
+    L.src[s] = reinterpret_cast<const uint32_t *>(N.mig_send + soff * 11);
+    L.dst[s] = s == me ? nullptr : reinterpret_cast<uint32_t *>(N.peers[s].inbox + before * 11);
+    L.words[s] = s == me ? 0u : (uint32_t)(ns * MPMHIP_MIGRATE_FLOATS);
+    L.flag[s] = (s == me ? N.flags : N.peers[s].flags) + 2 * TN_MAX_WORLD + me;
+    if (s == me) { L.src[s] = nullptr; }
+    most = std::max(most, L.words[s]);
+    soff += ns;
+  }
+  const int chunks = (int)std::min<uint32_t>(64u, std::max<uint32_t>(1u, most / (256 * 16)));
+  hipLaunchKernelGGL(k_put, dim3(world, chunks), dim3(256), 0, c->stream, L, N.mig_epoch, N.d_done);
+  return launch_check(c, "put (migration records)");
+}
+
+// phase C: import the arrivals, keep the halo boxes wrapped around the particles, schedule the next migration
+int tn_mig_c(mpmhip_ctx *c) {
+  auto &N = c->tn;
+  auto &M = N.mig;
+  int rc;
+  if (M.total > 0) {
+    if (N.wire != MPMHIP_WIRE_RCCL && (rc = tn_wait(c, N.flags + 2 * TN_MAX_WORLD, N.all_ranks, N.d_all_idx, N.mig_epoch))) return rc;
+    if (M.n_in && (rc = mpmhip_import_particles(c, M.n_in, N.inbox))) return rc;
+    if (c->n_slots > (int64_t)(0.85 * (double)c->cap)) c->compact_requested = true;  // dead slots (leavers) pile up
+  }
+  N.migrations++;
+  // the clip box: does it still hold every node the particles can touch before the next check?
+  bool have = M.lo[0] <= M.hi[0] && M.lo[1] <= M.hi[1] && M.lo[2] <= M.hi[2];
+  if (have) {
+    bool covers = true;
+    for (int a = 0; a < 3; a++) {
+      covers = covers && (M.lo[a] - c->T.margin - 1 >= N.clip_lo[a] || N.clip_lo[a] == 0);
+      covers = covers && (M.hi[a] + c->T.margin + 3 <= N.clip_hi[a] || N.clip_hi[a] == c->P.res[a] + 1);
+    }
+    if (!covers) {
+      const int s = tn_clip_slack(c->T);
+      for (int a = 0; a < 3; a++) {
+        N.clip_lo[a] = std::max(0, M.lo[a] - s);
+        N.clip_hi[a] = std::min(c->P.res[a] + 1, M.hi[a] + s + 2);
+      }
+      if ((rc = tn_apply_plan(c))) return rc;
+      N.replans++;
+    }
+  }
+  // schedule: after a migration every particle is inside its brick and needs margin / speed substeps to cross the margin;
+  // half of that leaves room for the speed to double in between; never sooner than the CFL schedule, never later than the cap
+  int64_t n = N.migrate_interval;
+  if (N.adaptive_cap > n && std::isfinite(M.speed))
+    n = std::max<int64_t>(n, std::min<int64_t>(N.adaptive_cap, (int64_t)(0.5 * c->T.margin / std::max(M.speed, 1e-9f))));
+  N.next_migration = N.k + n;
+  return MPMHIP_OK;
+}
+
+int tn_check_ready(mpmhip_ctx *c, const char *who) {
+  if (!c->tn.on) return fail(c, MPMHIP_EINVAL, "%s needs mpmhip_tiled_setup first", who);
+  if (!tn_connected(c)) return fail(c, MPMHIP_EINVAL, "%s: the wire is not connected (mpmhip_comm_init / mpmhip_tiled_ipc_connect / mpmhip_tiled_connect_local)", who);
+  return MPMHIP_OK;
+}
+
+void tn_free(mpmhip_ctx *c) {
+  auto &N = c->tn;
+  for (auto &p : N.peers)
+    if (p.ipc_base) (void)hipIpcCloseMemHandle(p.ipc_base);
+  N.peers.clear();
+  if (N.arena) (void)hipFree(N.arena);
+  if (N.send) (void)hipFree(N.send);
+  if (N.mig_send) (void)hipFree(N.mig_send);
+  if (N.row) (void)hipFree(N.row);
+  for (int k = 0; k < 2; k++) if (N.d_boxes[k]) (void)hipFree(N.d_boxes[k]);
+  if (N.d_halo_idx) (void)hipFree(N.d_halo_idx);
+  if (N.d_all_idx) (void)hipFree(N.d_all_idx);
+  if (N.d_done) (void)hipFree(N.d_done);
+  if (N.side) { (void)hipStreamSynchronize(N.side); (void)hipStreamDestroy(N.side); }
+  if (N.ev_a) (void)hipEventDestroy(N.ev_a);
+  if (N.ev_b) (void)hipEventDestroy(N.ev_b);
+  if (N.comm && rccl_api()->handle) (void)rccl_api()->CommDestroy((ncclComm_t)N.comm);
+  N = mpmhip_ctx::TiledNative();
+}
+
+}  // namespace
+
+extern "C" {
+
+int mpmhip_comm_unique_id(uint8_t id[MPMHIP_COMM_ID_BYTES]) {
+  if (!id) return MPMHIP_EINVAL;
+  RcclApi *R = rccl_api();
+  if (!R->handle) return fail(nullptr, MPMHIP_EHIP, "librccl could not be loaded: %s", R->error.c_str());
+  ncclUniqueId u;
+  static_assert(sizeof u == MPMHIP_COMM_ID_BYTES, "ncclUniqueId size");
+  ncclResult_t r = R->GetUniqueId(&u);
+  if (r != ncclSuccess) return fail(nullptr, MPMHIP_EHIP, "ncclGetUniqueId failed: %s", R->GetErrorString(r));
+  memcpy(id, &u, sizeof u);
+  return MPMHIP_OK;
+}
+
+int mpmhip_comm_init(mpmhip_ctx *c, const uint8_t id[MPMHIP_COMM_ID_BYTES], int32_t rank, int32_t world) {
+  if (!c || !id) return MPMHIP_EINVAL;
+  if (world < 1 || world > TN_MAX_WORLD || rank < 0 || rank >= world) return fail(c, MPMHIP_EINVAL, "rank %d of %d (at most %d ranks)", rank, world, TN_MAX_WORLD);
+  if (c->tn.comm) return fail(c, MPMHIP_EINVAL, "this ctx already has a communicator");
+  RcclApi *R = rccl_api();
+  if (!R->handle) return fail(c, MPMHIP_EHIP, "librccl could not be loaded: %s", R->error.c_str());
+  HIPCHK(c, hipSetDevice(c->device));
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  ncclComm_t comm = nullptr;
+  NCCLCHK(c, R->CommInitRank(&comm, world, u, rank));
+  c->tn.comm = comm;
+  c->tn.comm_rank = rank; c->tn.comm_world = world;
+  return MPMHIP_OK;
+}
+
+int mpmhip_comm_destroy(mpmhip_ctx *c) {
+  if (!c) return MPMHIP_EINVAL;
+  if (!c->tn.comm) return MPMHIP_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  NCCLCHK(c, rccl_api()->CommDestroy((ncclComm_t)c->tn.comm));
+  c->tn.comm = nullptr;
+  return MPMHIP_OK;
+}
+
+int mpmhip_comm_selftest(mpmhip_ctx *c) {
+  if (!c) return MPMHIP_EINVAL;
+  auto &N = c->tn;
+  if (!N.comm) return fail(c, MPMHIP_EINVAL, "mpmhip_comm_init first");
+  RcclApi *R = rccl_api();
+  HIPCHK(c, hipSetDevice(c->device));
+  const int world = N.comm_world, me = N.comm_rank, n = 1024;
+  uint32_t *d = nullptr;
+  HIPCHK(c, dmalloc(&d, (size_t)n * (world + 3)));
+  std::vector<uint32_t> h((size_t)n * (world + 3));
+  for (int i = 0; i < n; i++) h[i] = (uint32_t)(me * 1000003 + i);
+  hipError_t e = hipMemcpy(d, h.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice);
+  auto bail = [&](int code) { (void)hipFree(d); return code; };
+  if (e != hipSuccess) return bail(fail(c, MPMHIP_EHIP, "selftest upload: %s", hipGetErrorString(e)));
+  uint32_t *gathered = d + n, *ring = d + (size_t)n * (world + 1), *ring_out = ring + n;
+  ncclResult_t r = R->AllGather(d, gathered, n, ncclUint32, (ncclComm_t)N.comm, c->stream);
+  const int next = (me + 1) % world, prev = (me + world - 1) % world;
+  if (r == ncclSuccess) r = R->GroupStart();
+  if (r == ncclSuccess) r = R->Send(d, n, ncclUint32, next, (ncclComm_t)N.comm, c->stream);
+  if (r == ncclSuccess) r = R->Recv(ring, n, ncclUint32, prev, (ncclComm_t)N.comm, c->stream);
+  if (r == ncclSuccess) r = R->GroupEnd();
+  (void)ring_out;
+  if (r != ncclSuccess) return bail(fail(c, MPMHIP_EHIP, "selftest: %s", R->GetErrorString(r)));
+  e = hipMemcpyAsync(h.data(), d, sizeof(uint32_t) * h.size(), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) return bail(fail(c, MPMHIP_EHIP, "selftest read-back: %s", hipGetErrorString(e)));
+  for (int s = 0; s < world; s++)
+    for (int i = 0; i < n; i++)
+      if (h[(size_t)n * (1 + s) + i] != (uint32_t)(s * 1000003 + i)) return bail(fail(c, MPMHIP_EHIP, "selftest: all-gather delivered wrong data (rank %d, word %d)", s, i));
+  for (int i = 0; i < n; i++)
+    if (h[(size_t)n * (world + 1) + i] != (uint32_t)(prev * 1000003 + i)) return bail(fail(c, MPMHIP_EHIP, "selftest: send / receive delivered wrong data (word %d)", i));
+  return bail(MPMHIP_OK);
+}
+
+int mpmhip_tiled_setup(mpmhip_ctx *c, const mpmhip_tiled_config *cfg, const int32_t *cuts_x, const int32_t *cuts_y, const int32_t *cuts_z) {
+  if (!c || !cfg || !cuts_x || !cuts_y || !cuts_z) return MPMHIP_EINVAL;
+  if (c->in_substep) return fail(c, MPMHIP_EINVAL, "tiled_setup inside a substep");
+  if (cfg->wire != MPMHIP_WIRE_RCCL && cfg->wire != MPMHIP_WIRE_IPC && cfg->wire != MPMHIP_WIRE_LOCAL) return fail(c, MPMHIP_EINVAL, "unknown wire %d", cfg->wire);
+  if (cfg->world != cfg->dims[0] * cfg->dims[1] * cfg->dims[2] || cfg->world > TN_MAX_WORLD) return fail(c, MPMHIP_EINVAL, "world %d does not match dims (at most %d ranks)", cfg->world, TN_MAX_WORLD);
+  if (cfg->migrate_interval < 0 || cfg->migrate_interval > cfg->margin) return fail(c, MPMHIP_EINVAL, "migrate_interval must be in [0, margin]");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int rc = mpmhip_set_partition(c, cfg->rank, cfg->dims, cuts_x, cuts_y, cuts_z, cfg->margin);
+  if (rc) return rc;
+  void *keep_comm = c->tn.comm;
+  const int keep_rank = c->tn.comm_rank, keep_world = c->tn.comm_world;
+  c->tn.comm = nullptr;
+  tn_free(c);
+  auto &N = c->tn;
+  N.comm = keep_comm; N.comm_rank = keep_rank; N.comm_world = keep_world;
+  if (N.comm && (N.comm_world != cfg->world || N.comm_rank != cfg->rank)) return fail(c, MPMHIP_EINVAL, "the communicator is rank %d of %d, the partition rank %d of %d", N.comm_rank, N.comm_world, cfg->rank, cfg->world);
+  N.world = cfg->world;
+  N.wire = cfg->wire;
+  for (int a = 0; a < 3; a++) {
+    N.clip_lo[a] = std::max(0, cfg->clip_lo[a]);
+    N.clip_hi[a] = std::min(c->P.res[a] + 1, cfg->clip_hi[a]);
+    if (N.clip_lo[a] >= N.clip_hi[a]) return fail(c, MPMHIP_EINVAL, "empty clip box on axis %d", a);
+  }
+  N.migrate_interval = cfg->migrate_interval > 0 ? cfg->migrate_interval : cfg->margin;
+  N.adaptive_cap = cfg->migrate_interval > 0 ? 0 : (cfg->migrate_cap > 0 ? cfg->migrate_cap : 64);
+  N.k = 0; N.next_migration = N.migrate_interval;
+  N.timeout_ticks = 100000000ull * (unsigned long long)std::max(1, getenv("MPMHIP_TILE_WAIT_S") ? atoi(getenv("MPMHIP_TILE_WAIT_S")) : 20);
+  // worst-case halo volume over all ranks: the clip box = the whole grid (so that every rank lays its arena out alike)
+  const int full_lo[3] = {0, 0, 0}, full_hi[3] = {c->P.res[0] + 1, c->P.res[1] + 1, c->P.res[2] + 1};
+  uint64_t cap = 0;
+  for (int r = 0; r < N.world; r++) {
+    uint64_t t = 0;
+    const auto plan = tn_plan(c->T, N.world, full_lo, full_hi, r, &t);
+    if (plan.size() > MPMHIP_MAX_HALO_BOXES) return fail(c, MPMHIP_EINVAL, "too many halo boxes");
+    cap = std::max(cap, t);
+  }
+  if (cap >= (1ull << 31)) return fail(c, MPMHIP_EINVAL, "halo boxes too large");
+  N.halo_cap = std::max<uint64_t>(cap, 1);
+  N.inbox_cap = cfg->inbox_records > 0 ? (uint64_t)cfg->inbox_records : std::max<uint64_t>(65536, (uint64_t)c->cap / 8);
+  // arena: [flags 4 KiB | table 0 | table 1 | recv 0 | recv 1 | inbox]
+  const size_t table_bytes = ((sizeof(uint32_t) * TN_ROW * TN_MAX_WORLD + 255) / 256) * 256;
+  const size_t recv_bytes = ((sizeof(float4) * N.halo_cap + 255) / 256) * 256;
+  N.arena_bytes = TN_FLAG_BYTES + 2 * table_bytes + 2 * recv_bytes + sizeof(float4) * 11 * N.inbox_cap;
+  const bool peer_wire = N.wire == MPMHIP_WIRE_IPC || N.wire == MPMHIP_WIRE_LOCAL;
+  hipError_t e;
+  if (N.wire == MPMHIP_WIRE_IPC) {
+    // written by kernels of other devices while kernels of this one poll and read it: fine-grained (coherent at system
+    // scope while kernels run); MPMHIP_TILE_COARSE=1 allocates ordinary device memory instead (single-device tests)
+    const bool coarse = getenv("MPMHIP_TILE_COARSE") && atoi(getenv("MPMHIP_TILE_COARSE")) != 0;
+    e = coarse ? hipMalloc((void **)&N.arena, N.arena_bytes) : hipExtMallocWithFlags((void **)&N.arena, N.arena_bytes, hipDeviceMallocFinegrained);
+  } else {
+    e = hipMalloc((void **)&N.arena, N.arena_bytes);
+  }
+  if (e != hipSuccess) return fail(c, MPMHIP_ENOMEM, "halo arena of %zu bytes: %s", N.arena_bytes, hipGetErrorString(e));
+  HIPCHK(c, hipMemset(N.arena, 0, N.arena_bytes));
+  auto carve = [&](mpmhip_ctx::TiledNative::Peer &P, char *base) {
+    P.flags = reinterpret_cast<uint32_t *>(base);
+    P.table[0] = reinterpret_cast<uint32_t *>(base + TN_FLAG_BYTES);
+    P.table[1] = reinterpret_cast<uint32_t *>(base + TN_FLAG_BYTES + table_bytes);
+    P.recv[0] = reinterpret_cast<float4 *>(base + TN_FLAG_BYTES + 2 * table_bytes);
+    P.recv[1] = reinterpret_cast<float4 *>(base + TN_FLAG_BYTES + 2 * table_bytes + recv_bytes);
+    P.inbox = reinterpret_cast<float4 *>(base + TN_FLAG_BYTES + 2 * table_bytes + 2 * recv_bytes);
+  };
+  mpmhip_ctx::TiledNative::Peer self;
+  carve(self, N.arena);
+  N.flags = self.flags; N.table[0] = self.table[0]; N.table[1] = self.table[1];
+  N.recv[0] = self.recv[0]; N.recv[1] = self.recv[1]; N.inbox = self.inbox;
+  N.table_bytes = table_bytes; N.recv_bytes = recv_bytes;
+  N.peers.assign((size_t)N.world, mpmhip_ctx::TiledNative::Peer());
+  N.peers[cfg->rank] = self;
+  if (!peer_wire) HIPCHK(c, dmalloc(&N.send, (size_t)N.halo_cap));
+  HIPCHK(c, dmalloc(&N.row, (size_t)TN_ROW));
+  HIPCHK(c, hipMemset(N.row, 0, sizeof(uint32_t) * TN_ROW));
+  for (int k = 0; k < 2; k++) HIPCHK(c, dmalloc(&N.d_boxes[k], (size_t)MPMHIP_MAX_HALO_BOXES));
+  HIPCHK(c, dmalloc(&N.d_halo_idx, (size_t)MPMHIP_MAX_HALO_BOXES));
+  HIPCHK(c, dmalloc(&N.d_all_idx, (size_t)TN_MAX_WORLD));
+  HIPCHK(c, dmalloc(&N.d_done, (size_t)TN_MAX_WORLD + 1));
+  HIPCHK(c, hipMemset(N.d_done, 0, sizeof(uint32_t) * (TN_MAX_WORLD + 1)));
+  N.all_ranks.resize((size_t)N.world);
+  for (int r = 0; r < N.world; r++) N.all_ranks[r] = r;
+  HIPCHK(c, hipMemcpy(N.d_all_idx, N.all_ranks.data(), sizeof(int) * N.world, hipMemcpyHostToDevice));
+  if (N.wire == MPMHIP_WIRE_RCCL) {
+    HIPCHK(c, hipStreamCreateWithFlags(&N.side, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&N.ev_a, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&N.ev_b, hipEventDisableTiming));
+  }
+  N.on = true;
+  N.connected = N.world == 1;
+  c->overlap = cfg->overlap != 0;
+  return tn_apply_plan(c);
+}
+
+int mpmhip_tiled_ipc_handle(mpmhip_ctx *c, uint8_t handle[MPMHIP_IPC_HANDLE_BYTES]) {
+  if (!c || !handle) return MPMHIP_EINVAL;
+  if (!c->tn.on || c->tn.wire != MPMHIP_WIRE_IPC) return fail(c, MPMHIP_EINVAL, "ipc_handle needs mpmhip_tiled_setup with MPMHIP_WIRE_IPC");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipIpcMemHandle_t h;
+  static_assert(sizeof h == MPMHIP_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+  HIPCHK(c, hipIpcGetMemHandle(&h, c->tn.arena));
+  memcpy(handle, &h, sizeof h);
+  return MPMHIP_OK;
+}
+
+int mpmhip_tiled_ipc_connect(mpmhip_ctx *c, const uint8_t *handles) {
+  if (!c) return MPMHIP_EINVAL;
+  auto &N = c->tn;
+  if (!N.on || N.wire != MPMHIP_WIRE_IPC) return fail(c, MPMHIP_EINVAL, "ipc_connect needs mpmhip_tiled_setup with MPMHIP_WIRE_IPC");
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<uint8_t> gathered;
+  if (!handles) {  // through the ctx's communicator
+    if (!N.comm) return fail(c, MPMHIP_EINVAL, "ipc_connect(NULL) needs mpmhip_comm_init");
+    uint8_t mine[MPMHIP_IPC_HANDLE_BYTES];
+    int rc = mpmhip_tiled_ipc_handle(c, mine);
+    if (rc) return rc;
+    uint8_t *d = nullptr;
+    HIPCHK(c, dmalloc(&d, (size_t)MPMHIP_IPC_HANDLE_BYTES * (N.world + 1)));
+    hipError_t e = hipMemcpy(d, mine, sizeof mine, hipMemcpyHostToDevice);
+    ncclResult_t r = ncclSuccess;
+    if (e == hipSuccess) r = rccl_api()->AllGather(d, d + MPMHIP_IPC_HANDLE_BYTES, MPMHIP_IPC_HANDLE_BYTES, ncclUint8, (ncclComm_t)N.comm, c->stream);
+    gathered.resize((size_t)MPMHIP_IPC_HANDLE_BYTES * N.world);
+    if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(gathered.data(), d + MPMHIP_IPC_HANDLE_BYTES, gathered.size(), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (r != ncclSuccess) return fail(c, MPMHIP_EHIP, "all-gather of the IPC handles: %s", rccl_api()->GetErrorString(r));
+    HIPCHK(c, e);
+    handles = gathered.data();
+  }
+  const size_t table_bytes = N.table_bytes, recv_bytes = N.recv_bytes;
+  for (int p = 0; p < N.world; p++) {
+    if (p == c->T.rank) continue;
+    auto &P = N.peers[p];
+    if (P.ipc_base) { (void)hipIpcCloseMemHandle(P.ipc_base); P.ipc_base = nullptr; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handles + (size_t)p * MPMHIP_IPC_HANDLE_BYTES, sizeof h);
+    void *base = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return fail(c, MPMHIP_EHIP, "hipIpcOpenMemHandle of rank %d's arena: %s", p, hipGetErrorString(e));
+    P.ipc_base = base;
+    char *b = static_cast<char *>(base);
+    P.flags = reinterpret_cast<uint32_t *>(b);
+    P.table[0] = reinterpret_cast<uint32_t *>(b + TN_FLAG_BYTES);
+    P.table[1] = reinterpret_cast<uint32_t *>(b + TN_FLAG_BYTES + table_bytes);
+    P.recv[0] = reinterpret_cast<float4 *>(b + TN_FLAG_BYTES + 2 * table_bytes);
+    P.recv[1] = reinterpret_cast<float4 *>(b + TN_FLAG_BYTES + 2 * table_bytes + recv_bytes);
+    P.inbox = reinterpret_cast<float4 *>(b + TN_FLAG_BYTES + 2 * table_bytes + 2 * recv_bytes);
+  }
+  N.connected = true;
+  return tn_apply_plan(c);
+}
+
+int mpmhip_tiled_connect_local(mpmhip_ctx *const *ctxs, int32_t n) {
+  if (!ctxs || n < 1) return MPMHIP_EINVAL;
+  for (int r = 0; r < n; r++) {
+    mpmhip_ctx *c = ctxs[r];
+    if (!c) return MPMHIP_EINVAL;
+    if (!c->tn.on || c->tn.wire != MPMHIP_WIRE_LOCAL || c->tn.world != n || c->T.rank != r)
+      return fail(c, MPMHIP_EINVAL, "connect_local: ctx %d must be set up as rank %d of %d with MPMHIP_WIRE_LOCAL", r, r, n);
+    if (c->device != ctxs[0]->device) return fail(c, MPMHIP_EINVAL, "connect_local: all ctx must live on one device");
+    if (c->tn.arena_bytes != ctxs[0]->tn.arena_bytes) return fail(c, MPMHIP_EINVAL, "connect_local: the ranks' arenas differ (inbox_records must be the same on every rank)");
+  }
+  for (int r = 0; r < n; r++) {
+    mpmhip_ctx *c = ctxs[r];
+    for (int p = 0; p < n; p++)
+      if (p != r) c->tn.peers[p] = ctxs[p]->tn.peers[p];  // (a rank's own entry describes its arena)
+    c->tn.connected = true;
+    int rc = tn_apply_plan(c);
+    if (rc) return rc;
+  }
+  return MPMHIP_OK;
+}
+
+static int tn_substep_parts(mpmhip_ctx *c, int part) {  // 0 begin (+ start of the exchange), 1 interior, 2 wait + end
+  int rc;
+  if (part == 0) {
+    if ((rc = mpmhip_substep_begin(c))) return rc;
+    return tn_exchange_start(c);
+  }
+  if (part == 1) return mpmhip_substep_interior(c);
+  if ((rc = tn_exchange_wait(c))) return rc;
+  return mpmhip_substep_end(c);
+}
+
+int64_t mpmhip_tiled_advance(mpmhip_ctx *c, int64_t n) {
+  if (!c || n < 0) return MPMHIP_EINVAL;
+  int rc = tn_check_ready(c, "tiled_advance");
+  if (rc) return rc;
+  auto &N = c->tn;
+  if (N.wire == MPMHIP_WIRE_LOCAL && N.world > 1) return fail(c, MPMHIP_EINVAL, "ranks of a local job advance together: mpmhip_tiled_advance_group");
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int64_t i = 0; i < n; i++) {
+    for (int part = 0; part < 3; part++)
+      if ((rc = tn_substep_parts(c, part))) { c->in_substep = false; c->cur_ev = nullptr; return rc; }
+    N.k++;
+    if (N.k >= N.next_migration && N.world > 1) {
+      if ((rc = tn_mig_a(c)) || (rc = tn_mig_b(c)) || (rc = tn_mig_c(c))) return rc;
+    }
+  }
+  return n;
+}
+
+int64_t mpmhip_tiled_advance_group(mpmhip_ctx *const *ctxs, int32_t n_ctx, int64_t n) {
+  if (!ctxs || n_ctx < 1 || n < 0) return MPMHIP_EINVAL;
+  for (int r = 0; r < n_ctx; r++) {
+    if (!ctxs[r]) return MPMHIP_EINVAL;
+    int rc = tn_check_ready(ctxs[r], "tiled_advance_group");
+    if (rc) return rc;
+    if (ctxs[r]->tn.wire != MPMHIP_WIRE_LOCAL || ctxs[r]->tn.world != n_ctx || ctxs[r]->T.rank != r)
+      return fail(ctxs[r], MPMHIP_EINVAL, "advance_group: ctx %d is not rank %d of a local job of %d", r, r, n_ctx);
+  }
+  for (int64_t i = 0; i < n; i++) {
+    for (int part = 0; part < 3; part++)
+      for (int r = 0; r < n_ctx; r++) {
+        int rc = tn_substep_parts(ctxs[r], part);
+        if (rc) { ctxs[r]->in_substep = false; ctxs[r]->cur_ev = nullptr; return rc; }
+      }
+    bool due = false;
+    for (int r = 0; r < n_ctx; r++) { ctxs[r]->tn.k++; due = due || ctxs[r]->tn.k >= ctxs[r]->tn.next_migration; }
+    if (due && n_ctx > 1) {
+      for (int ph = 0; ph < 3; ph++)
+        for (int r = 0; r < n_ctx; r++) {
+          mpmhip_ctx *c = ctxs[r];
+          HIPCHK(c, hipSetDevice(c->device));
+          int rc = ph == 0 ? tn_mig_a(c) : (ph == 1 ? tn_mig_b(c) : tn_mig_c(c));
+          if (rc) return rc;
+        }
+    }
+  }
+  return n;
+}
+
+int mpmhip_tiled_state(mpmhip_ctx *c, int64_t out[8]) {
+  if (!c || !out) return MPMHIP_EINVAL;
+  const auto &N = c->tn;
+  out[0] = N.k; out[1] = N.next_migration; out[2] = N.migrated_out; out[3] = N.migrations; out[4] = N.replans;
+  out[5] = (int64_t)N.boxes.size(); out[6] = (int64_t)N.total; out[7] = N.on ? N.wire : 0;
+  return MPMHIP_OK;
+}
+
+int32_t mpmhip_tiled_plan(mpmhip_ctx *c, int32_t capacity, mpmhip_halo_box *out) {
+  if (!c) return MPMHIP_EINVAL;
+  const auto &N = c->tn;
+  if (!N.on) return fail(c, MPMHIP_EINVAL, "tiled_plan needs mpmhip_tiled_setup first");
+  const int32_t n = (int32_t)N.boxes.size();
+  if (!out || capacity < n) return n;
+  const bool peer_wire = N.wire == MPMHIP_WIRE_IPC || N.wire == MPMHIP_WIRE_LOCAL;
+  for (int32_t i = 0; i < n; i++) {
+    const auto &b = N.boxes[i];
+    for (int a = 0; a < 3; a++) { out[i].lo[a] = b.lo[a]; out[i].hi[a] = b.hi[a]; }
+    out[i].peer = b.peer; out[i].reserved = (int32_t)b.peer_off;
+    out[i].send = peer_wire ? nullptr : (void *)(N.send + b.off);
+    out[i].recv = N.recv[0] + b.off;
+  }
+  return n;
+}
+
+}  // extern "C"

@@ -567,6 +567,142 @@ class VirtualTiledJob:
         self.substeps += n
 
 
+# ---------------------------------------------------------------------------------------------------- native data plane
+def native_setup(engine, part, rank, wire, migrate_interval=None, overlap=False, inbox_records=0, migrate_cap=None):
+    """mpmhip_tiled_setup: the library derives the halo boxes from the partition, owns the buffers and runs loop, exchange
+    and migration itself (include/mpmhip.h: "the native data plane").  `part` only supplies dims / cuts / margin / clip."""
+    L, sim = engine.L, engine.sim
+    cfg = _lib.TiledConfig()
+    cfg.rank, cfg.world, cfg.margin = int(rank), int(part.world), int(part.margin)
+    cfg.dims[:] = part.dims
+    cfg.clip_lo[:] = part.clip[0]
+    cfg.clip_hi[:] = part.clip[1]
+    cfg.migrate_interval = int(migrate_interval or 0)
+    cfg.migrate_cap = int(migrate_cap if migrate_cap is not None else os.environ.get("MPMHIP_TILE_MIGRATE_CAP", 64))
+    cfg.wire, cfg.overlap, cfg.inbox_records = int(wire), int(bool(overlap)), int(inbox_records)
+    ip = C.POINTER(C.c_int32)
+    arrs = [np.asarray(c, np.int32) for c in part.cuts]
+    sim._check(L.mpmhip_tiled_setup(engine.ctx, C.byref(cfg), arrs[0].ctypes.data_as(ip), arrs[1].ctypes.data_as(ip),
+                                    arrs[2].ctypes.data_as(ip)))
+    engine.world = part.world
+
+
+def native_state(engine):
+    o = (C.c_int64 * 8)()
+    engine.sim._check(engine.L.mpmhip_tiled_state(engine.ctx, o))
+    keys = ("substeps", "next_migration", "migrated_out", "migrations", "replans", "halo_boxes", "halo_nodes", "wire")
+    return dict(zip(keys, (int(v) for v in o)))
+
+
+def native_plan(engine):
+    """[(peer, lo, hi, offset of the box in the peer's buffers)] of the library's current plan"""
+    hb = (_lib.HaloBox * _lib.MAX_HALO_BOXES)()
+    n = int(engine.sim._check(engine.L.mpmhip_tiled_plan(engine.ctx, _lib.MAX_HALO_BOXES, hb)))
+    return [(int(hb[i].peer), list(hb[i].lo), list(hb[i].hi), int(hb[i].reserved)) for i in range(n)]
+
+
+class _NativeJobBase:
+    scaling = "strong"
+    substeps = 0
+
+    def set_overlap(self, flag):
+        for e in self.engines:
+            e.set_overlap(flag)
+        self.overlap = bool(flag)
+
+    def num_particles(self):
+        return sum(e.num_particles() for e in self.engines)
+
+    def synchronize(self):
+        for e in self.engines:
+            e.synchronize()
+
+    def set_profiling(self, level, every=1):
+        for e in self.engines:
+            e.sim.set_profiling(level, every)
+            e.sim.profile(reset=True)
+
+    def profile(self):
+        return self.engines[0].sim.profile()
+
+    def state(self):
+        return [native_state(e) for e in self.engines]
+
+
+class NativeTiledJob(_NativeJobBase):
+    """this process's rank of a tiled run on the library's own data plane: Python carries 128 bytes once (the ncclUniqueId,
+    or the ranks' IPC handles) over the control group `dist` (gloo) and then calls mpmhip_tiled_advance(n).
+    wire: "rccl" | "ipc" (peer writes into IPC-mapped receive buffers; with use_comm the handles travel through RCCL)."""
+
+    def __init__(self, engine, part, rank, world, wire="rccl", dist=None, migrate_interval=None, overlap=True, inbox_records=0,
+                 use_comm=None):
+        import torch
+        self.engines, self.e, self.part, self.rank, self.world, self.wire = [engine], engine, part, rank, world, wire
+        L, sim = engine.L, engine.sim
+        need_comm = wire == "rccl" or (wire == "ipc" and use_comm)
+        if need_comm:
+            ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+            if rank == 0:
+                buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+                if L.mpmhip_comm_unique_id(buf) != 0:
+                    raise RuntimeError("mpmhip_comm_unique_id: " + L.mpmhip_last_error(None).decode())
+                ident = torch.tensor(list(buf), dtype=torch.uint8)
+            if world > 1:
+                dist.broadcast(ident, src=0)
+            buf = (C.c_uint8 * _lib.COMM_ID_BYTES)(*ident.tolist())
+            sim._check(L.mpmhip_comm_init(engine.ctx, buf, rank, world))
+        native_setup(engine, part, rank, _lib.WIRE_RCCL if wire == "rccl" else _lib.WIRE_IPC, migrate_interval, overlap, inbox_records)
+        if wire == "ipc" and world > 1:
+            if use_comm:
+                sim._check(L.mpmhip_tiled_ipc_connect(engine.ctx, None))
+            else:
+                mine = (C.c_uint8 * _lib.IPC_HANDLE_BYTES)()
+                sim._check(L.mpmhip_tiled_ipc_handle(engine.ctx, mine))
+                rows = [torch.zeros(_lib.IPC_HANDLE_BYTES, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(rows, torch.tensor(list(mine), dtype=torch.uint8))
+                flat = (C.c_uint8 * (_lib.IPC_HANDLE_BYTES * world))(*[int(v) for r in rows for v in r.tolist()])
+                sim._check(L.mpmhip_tiled_ipc_connect(engine.ctx, flat))
+                dist.barrier()  # every rank has mapped every arena before anybody writes
+        self.overlap = bool(overlap)
+        self.parallelism = "%dx%dx%d bricks, one rank per GPU, halo + migration on the library's own data plane (%s)" % (
+            part.dims + ({"rccl": "ncclSend / ncclRecv groups over xGMI", "ipc": "peer writes into IPC-mapped buffers"}[wire],))
+
+    def run(self, n):
+        self.e.sim._check(self.e.L.mpmhip_tiled_advance(self.e.ctx, int(n)))
+        self.substeps += n
+
+    def num_particles(self):
+        return self.e.num_particles()
+
+
+class NativeVirtualJob(_NativeJobBase):
+    """all ranks of a partition as ctx of ONE process on one device, on the library's data plane (MPMHIP_WIRE_LOCAL: the
+    peer-write wire with plain pointers): the K-rank == 1-ctx tests and bench.py --virtual"""
+
+    def __init__(self, engines, part, migrate_interval=None, overlap=False, inbox_records=0):
+        assert len(engines) == part.world
+        self.engines, self.part = list(engines), part
+        for r, e in enumerate(engines):
+            native_setup(e, part, r, _lib.WIRE_LOCAL, migrate_interval, overlap, inbox_records)
+        self._arr = (C.c_void_p * len(engines))(*[e.ctx for e in engines])
+        L = engines[0].L
+        self._group_check(L.mpmhip_tiled_connect_local(self._arr, len(engines)), "mpmhip_tiled_connect_local")
+        self.overlap = bool(overlap)
+
+    def _group_check(self, rc, what):
+        if rc < 0:  # (the failing ctx holds the message; the others may hold older ones)
+            msgs = ["rank %d: %s" % (r, e.L.mpmhip_last_error(e.ctx).decode()) for r, e in enumerate(self.engines)
+                    if e.L.mpmhip_last_error(e.ctx)]
+            from .mpm import MPMError
+            raise MPMError("%s failed (%d): %s" % (what, rc, "; ".join(msgs)))
+        return rc
+
+    def run(self, n):
+        L = self.engines[0].L
+        self._group_check(int(L.mpmhip_tiled_advance_group(self._arr, len(self.engines), int(n))), "mpmhip_tiled_advance_group")
+        self.substeps += n
+
+
 # ---------------------------------------------------------------------------------------------------- bench glue
 def scene_groups(cfg):
     """the synthetic workload of a bench config as [(particle type, lower corner in cells (3,), cube edge in cells)]:

@@ -276,6 +276,136 @@ def test_migration_compacts_when_slots_run_out(tm):
         sim.close()
 
 
+# ------------------------------------------------------------------------------------------ the native data plane
+def test_native_plan_equals_the_python_plan(tm):
+    """mpmhip_tiled_setup derives the halo boxes from the partition itself (csrc/tiled_api.h: tn_plan); they equal the
+    boxes taichi_mpm_amd.tiled.Partition computes for the callback path, and every box knows its offset in the PEER's buffers"""
+    from taichi_mpm_amd import tiled
+    s = _two_material_state()
+    for world, dims in ((8, None), (3, (1, 3, 1)), (4, None)):
+        part = tiled.Partition.balanced((RES,) * 3, world, s.x, DX, margin=2, dims=dims)
+        owner = part.rank_of_cells(tiled.base_cells(s.x, DX))
+        sims = [_sim(tm, s, owner == r, np.arange(s.n), s.n + 1024) for r in range(world)]
+        engines = [tiled.HipEngine(sim, 0) for sim in sims]
+        job = tiled.NativeVirtualJob(engines, part, migrate_interval=2)
+        offsets = {}
+        for r in range(world):
+            off = 0
+            for peer, lo, hi in part.boxes(r):
+                offsets[(r, peer)] = off
+                off += int(np.prod([hi[a] - lo[a] for a in range(3)]))
+        for r, e in enumerate(engines):
+            got = tiled.native_plan(e)
+            want = part.boxes(r)
+            assert [(g[0], g[1], g[2]) for g in got] == [(p, list(lo), list(hi)) for p, lo, hi in want]
+            assert [g[3] for g in got] == [offsets[(p, r)] for p, _, _ in want]
+            st = tiled.native_state(e)
+            assert st["halo_boxes"] == len(want) and st["wire"] == 3 and st["halo_nodes"] == sum(
+                int(np.prod([hi[a] - lo[a] for a in range(3)])) for _, lo, hi in want)
+        del job
+        for sim in sims:
+            sim.close()
+
+
+@pytest.mark.parametrize("overlap", [False, True], ids=["serial", "overlap_split"])
+@pytest.mark.parametrize("world,dims", [(2, None), (4, None), (8, None), (3, (1, 3, 1))])
+def test_k_tiles_on_the_native_data_plane_reproduce_one_tile(tm, world, dims, overlap):
+    """the same comparison as test_k_tiles_reproduce_one_tile with NOTHING of the run in Python: plan, buffers, the
+    per-substep loop, the halo exchange (peer writes + epoch flags, MPMHIP_WIRE_LOCAL), the migration (scan, table,
+    records, import) and its schedule all run inside mpmhip_tiled_advance_group"""
+    from taichi_mpm_amd import tiled
+    s = _two_material_state()
+    n, ids = s.n, np.arange(s.n)
+    one = _sim(tm, s, np.ones(n, bool), ids, n + 1024)
+    part = tiled.Partition.balanced((RES,) * 3, world, s.x, DX, margin=2, dims=dims)
+    owner = part.rank_of_cells(tiled.base_cells(s.x, DX))
+    sims = [_sim(tm, s, owner == r, ids, n + 1024) for r in range(world)]
+    engines = [tiled.HipEngine(sim, 0) for sim in sims]
+    job = tiled.NativeVirtualJob(engines, part, migrate_interval=2, overlap=overlap)
+    steps = 12
+    job.run(5)
+    job.run(steps - 5)  # (a second call continues the schedule)
+    one.run_substeps(steps)
+    ref, got = one.get_particles(), _gather(sims)
+    st = job.state()
+    assert all(t["substeps"] == steps and t["migrations"] == steps // 2 for t in st), st
+    assert sum(t["migrated_out"] for t in st) > 0, "the scene must exercise migration"
+    assert np.array_equal(got["id"], ref["id"]) and np.array_equal(got["gid"], ref["gid"])
+    for rank, sim in enumerate(sims):
+        b = tiled.base_cells(sim.get_particles(sort_by_id=False)["x"], DX)
+        lo, hi = part.brick(rank)
+        assert (b >= np.array(lo) - part.margin).all() and (b < np.array(hi) + part.margin).all()
+    assert np.abs(got["x"] - ref["x"]).max() <= 1e-6
+    assert rel_l2(got["v"], ref["v"]) <= 1e-4 and rel_l2(got["F"], ref["F"]) <= 1e-4 and rel_l2(got["B"], ref["B"]) <= 1e-3
+    # the callback path refuses a ctx whose plan is the library's, and the other way round
+    with pytest.raises(tm.mpm.MPMError, match="native plan"):
+        engines[0].run_native(1, lambda: None, lambda: None)
+    with pytest.raises(tm.mpm.MPMError, match="advance together"):
+        sims[0]._check(sims[0]._L.mpmhip_tiled_advance(sims[0]._ctx, 1))
+    for sim in sims + [one]:
+        sim.close()
+
+
+def test_native_migration_follows_a_moving_blob(tm):
+    """the moving blob of test_migration_compacts_when_slots_run_out on the native data plane: adaptive schedule from the
+    measured top speed, re-plans when the particles leave the clip box, compaction when slots run out — all inside the library"""
+    from taichi_mpm_amd import tiled
+    x = lattice_cube(RES, 8, 20, DX, jitter=0.2, seed=31)
+    s = make_state(x, "jelly", DX, perturb_F=0.0, seed=32, vel_scale=0.0)
+    s.v[:] = (25.0, 0.0, 0.0)
+    s.B[:] = 0
+    n = s.n
+    part = tiled.Partition.balanced((RES,) * 3, 3, s.x, DX, margin=2, dims=(3, 1, 1))
+    b = tiled.base_cells(s.x, DX)
+    part.clip = (list(map(int, b.min(0) - 3)), list(map(int, b.max(0) + 6)))  # tight: the moving blob forces re-plans
+    owner = part.rank_of_cells(b)
+    own = [int((owner == r).sum()) for r in range(3)]
+    caps = [own[0] + 64, int(own[1] * 1.3), n]
+    sims = [_sim(tm, s, owner == r, np.arange(n), caps[r]) for r in range(3)]
+    for sim in sims:
+        sim.set_levelset(tm.mpm.LevelSet())
+    job = tiled.NativeVirtualJob([tiled.HipEngine(sim, 0) for sim in sims], part, inbox_records=n)
+    job.run(50)
+    st = job.state()
+    got = _gather(sims)
+    assert all(t["replans"] >= 1 for t in st), st  # the halo boxes followed the particles
+    assert 2 <= st[0]["migrations"] < 25 and len({t["next_migration"] for t in st}) == 1  # adaptive, the same on every rank
+    assert len(got["id"]) == n and np.array_equal(got["id"], np.arange(n))
+    assert st[1]["migrated_out"] > 0.5 * own[1]
+    assert int(sims[1]._L.mpmhip_num_slots(sims[1]._ctx)) <= caps[1]
+    assert np.allclose(got["v"][:, 0], 25.0, rtol=1e-3)
+    for sim in sims:
+        sim.close()
+
+
+def test_native_rccl_binding_on_one_rank(tm):
+    """librccl dlopen'ed by libmpmhip: unique id, ncclCommInitRank, the loopback self-test (all-gather + grouped send / receive
+    to self) and a tiled_advance over MPMHIP_WIRE_RCCL with the one rank a 1-GPU box allows (no halo boxes: the substeps
+    equal plain ones).  The two-rank case is test_two_ranks_over_rccl_match_one_ctx[native-*] (needs two GPUs)."""
+    import ctypes as C
+
+    from taichi_mpm_amd import _lib, tiled
+    s = _two_material_state()
+    one = _sim(tm, s, np.ones(s.n, bool), np.arange(s.n), s.n + 1024)
+    sim = _sim(tm, s, np.ones(s.n, bool), np.arange(s.n), s.n + 1024)
+    L = sim._L
+    ident = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+    assert L.mpmhip_comm_unique_id(ident) == 0, L.mpmhip_last_error(None)
+    assert any(ident)
+    sim._check(L.mpmhip_comm_init(sim._ctx, ident, 0, 1))
+    sim._check(L.mpmhip_comm_selftest(sim._ctx))
+    part = tiled.Partition.balanced((RES,) * 3, 1, s.x, DX, margin=2)
+    e = tiled.HipEngine(sim, 0)
+    tiled.native_setup(e, part, 0, _lib.WIRE_RCCL)
+    sim._check(L.mpmhip_tiled_advance(sim._ctx, 6))
+    one.run_substeps(6)
+    a, b = one.get_particles(), sim.get_particles()
+    assert np.array_equal(a["id"], b["id"]) and np.abs(a["x"] - b["x"]).max() <= 1e-6 and rel_l2(a["F"], b["F"]) <= 1e-5
+    assert tiled.native_state(e)["substeps"] == 6
+    sim._check(L.mpmhip_comm_destroy(sim._ctx))
+    sim.close(); one.close()
+
+
 # ------------------------------------------------------------------------------------------ two processes, one GPU
 def _proc_worker(rank, world, port, steps, q):
     import os

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(built):
     for sym in sorted(declared):
         assert hasattr(built, sym), "libmpmhip.so does not export %s" % sym
     assert declared == set(_lib.exported_symbols())
-    assert built.mpmhip_abi_version() == 2  # (2: mpmhip_async_config gained left_boundary)
+    assert built.mpmhip_abi_version() == 3  # (3: the native data plane of tiled runs)
 
 
 def test_config_struct_matches_header_layout():
