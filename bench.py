@@ -256,16 +256,21 @@ def pmc_traffic(config_name, kernel):
 
 
 def virtual_run(tm, cfg, args):
+    """--virtual K: the K-brick job as K ctx on ONE GPU, on the library's own data plane (MPMHIP_WIRE_LOCAL: peer writes with
+    plain pointers; loop, exchange and migration inside mpmhip_tiled_advance_group).  All ctx share one stream, so the ranks'
+    kernels run one after another and a rank's event-bracketed parts are the per-GPU compute of a K-GPU run without the wire."""
     import torch
 
     from taichi_mpm_amd import tiled
     K = args.virtual
-    part = tiled.scene_partition(cfg, K, margin=4)
+    part = tiled.scene_partition(cfg, K, margin=int(os.environ.get("MPMHIP_TILE_MARGIN", 4)))
     engines = []
     for r in range(K):
         sim, _ = tiled.build_rank_sim(tm, cfg, part, r, 0)
         engines.append(tiled.HipEngine(sim, 0))
-    job = tiled.VirtualTiledJob(engines, part, overlap=os.environ.get("MPMHIP_TILE_OVERLAP", "1") != "0")
+    overlap = os.environ.get("MPMHIP_TILE_OVERLAP", "1") != "0"
+    python_loop = os.environ.get("MPMHIP_VIRTUAL_PYTHON") == "1"  # the round-3 path: Python loop, exchanges as torch copies
+    job = tiled.VirtualTiledJob(engines, part, overlap=overlap) if python_loop else tiled.NativeVirtualJob(engines, part, overlap=overlap)
     job.run(args.warmup)
 
     def measured(level, steps):
@@ -280,17 +285,29 @@ def virtual_run(tm, cfg, args):
         profs = [e.sim.profile() for e in engines]
         return el, profs, [{k: v / max(p["substeps"], 1) for k, v in p["phases"].items()} for p in profs]
 
-    # level 4: begin / interior / end of a substep bracketed as wholes — every hipEventRecord idles the GPU for ~5 us, so the
-    # per-phase table (level 1, six records per substep, overlap split off) is a second, separate pass
-    el, profs, per_rank = measured(int(os.environ.get("MPMHIP_VIRTUAL_PROFILE", "4")), args.steps)
+    # wall time of all ranks' substeps with no event anywhere, then level 4 (begin / interior / end of a substep bracketed as
+    # wholes — every hipEventRecord idles the GPU for ~5 us), then the per-phase table (level 1, six records per substep,
+    # overlap split off)
+    el0, profs, _ = measured(0, args.steps)
+    el, _, per_rank = measured(int(os.environ.get("MPMHIP_VIRTUAL_PROFILE", "4")), args.steps)
     _, _, per_phase = measured(1, max(args.steps // 2, 4))
-    return ({"diagnostic": "virtual ranks on one GPU", "K": K, "dims": part.dims, "cuts": part.cuts,
-                      "particles_per_rank": [p["particles"] for p in profs], "active_blocks": [p["active_blocks"] for p in profs],
-                      "halo_floats_per_rank": [r.plan.total for r in job.ranks],
-                      "ms_per_step_all_ranks_serial": 1e3 * el / args.steps,
-                      "per_rank_compute_ms": [sum(v for k, v in pr.items() if k != "exchange") for pr in per_rank],
-                      "per_rank_compute_ms_per_phase_events": [sum(v for k, v in pr.items() if k != "exchange") for pr in per_phase],
-                      "rank0_phases_ms": per_phase[0], "migrated": [r.migrated_out for r in job.ranks]})
+    n_total = sum(p["particles"] for p in profs)
+    if python_loop:
+        halo, migrated = [r.plan.total // 4 for r in job.ranks], [r.migrated_out for r in job.ranks]
+    else:
+        st = job.state()
+        halo, migrated = [t["halo_nodes"] for t in st], [t["migrated_out"] for t in st]
+    return ({"diagnostic": "virtual ranks on one GPU", "K": K, "dims": part.dims, "cuts": part.cuts, "workload": cfg["desc"],
+             "loop": "python (VirtualTiledJob)" if python_loop else "native (mpmhip_tiled_advance_group, MPMHIP_WIRE_LOCAL)",
+             "overlap_split": overlap, "particles": n_total,
+             "particles_per_rank": [p["particles"] for p in profs], "active_blocks": [p["active_blocks"] for p in profs],
+             "halo_nodes_per_rank": halo, "halo_bytes_per_rank": [16 * h for h in halo],
+             "ms_per_step_all_ranks_serial_no_events": 1e3 * el0 / args.steps,
+             "per_rank_ms_serial_no_events": 1e3 * el0 / args.steps / K,
+             "ms_per_step_all_ranks_serial": 1e3 * el / args.steps,
+             "per_rank_compute_ms": [sum(v for k, v in pr.items() if k != "exchange") for pr in per_rank],
+             "per_rank_compute_ms_per_phase_events": [sum(v for k, v in pr.items() if k != "exchange") for pr in per_phase],
+             "rank0_phases_ms": per_phase[0], "migrated": migrated})
 
 
 class Watchdog:
@@ -321,28 +338,42 @@ class Watchdog:
 
 
 def rccl_probe_main():
-    """`bench.py --probe-rccl` (started by every rank as a CHILD process, own rendezvous port): the two collectives the tiled
-    job uses, on device buffers over the nccl backend.  A transport that hangs or aborts takes the child down, not the job:
-    the parent waits with a timeout and falls back to staging through gloo."""
+    """`bench.py --probe-rccl` (started by every rank as a CHILD process, own rendezvous port): exactly what the job will do with
+    the wire — the library dlopens librccl, the ncclUniqueId travels over gloo, ncclCommInitRank, then the library's loopback
+    check (an all-gather and a grouped ncclSend / ncclRecv ring on device buffers, verified on the host).  A transport that hangs
+    or aborts takes the child down, not the job: the parent waits with a timeout."""
+    import ctypes as C
     import datetime
 
     import torch
     import torch.distributed as dist
+
+    import taichi_mpm_amd as tm
+    from taichi_mpm_amd import _lib
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=45))
-    dev = torch.device("cuda", local)
-    a = torch.full((world,), float(rank), device=dev)
-    b = torch.empty_like(a)
-    dist.all_to_all_single(b, a, [1] * world, [1] * world)
-    g = torch.empty(world, device=dev)
-    dist.all_gather_into_tensor(g, a[:1])
-    torch.cuda.synchronize()
-    ok = bool((b.cpu() == torch.arange(world, dtype=b.dtype)).all()) and bool((g.cpu() == torch.arange(world, dtype=g.dtype)).all())
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=45))
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(16,) * 3, device=local, max_particles=1024))
+    sim._ensure_ctx()
+    L = sim._L
+    ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+    if rank == 0:
+        buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+        if L.mpmhip_comm_unique_id(buf) != 0:
+            print("RCCL_PROBE_FAILED " + L.mpmhip_last_error(None).decode(), flush=True)
+            os._exit(4)
+        ident = torch.tensor(list(buf), dtype=torch.uint8)
+    dist.broadcast(ident, src=0)
+    buf = (C.c_uint8 * _lib.COMM_ID_BYTES)(*ident.tolist())
+    ok = L.mpmhip_comm_init(sim._ctx, buf, rank, world) == 0 and L.mpmhip_comm_selftest(sim._ctx) == 0
+    if not ok:
+        print("RCCL_PROBE_FAILED " + L.mpmhip_last_error(sim._ctx).decode(), flush=True)
+        os._exit(4)
+    L.mpmhip_comm_destroy(sim._ctx)
+    dist.barrier()
     dist.destroy_process_group()
-    print("RCCL_PROBE_OK" if ok else "RCCL_PROBE_WRONG_DATA", flush=True)
-    os._exit(0 if ok else 4)
+    print("RCCL_PROBE_OK", flush=True)
+    os._exit(0)
 
 
 def probe_rccl_in_child(rank, world, local_rank, timeout_s=75.0):
@@ -358,7 +389,7 @@ def probe_rccl_in_child(rank, world, local_rank, timeout_s=75.0):
         return False, "the RCCL probe did not finish within %.0f s" % timeout_s
     if r.returncode == 0 and "RCCL_PROBE_OK" in r.stdout:
         return True, ""
-    return False, "the RCCL probe exited with code %d: %s" % (r.returncode, (r.stderr or r.stdout).strip().splitlines()[-1:] or "")
+    return False, "the RCCL probe exited with code %d: %s" % (r.returncode, (r.stdout or r.stderr).strip().splitlines()[-1:] or "")
 
 
 def main():
@@ -377,6 +408,13 @@ def main():
     ap.add_argument("--state", default="lattice", choices=["lattice", "evolved"],
                     help="state the main measurement is taken on: the freshly seeded lattice (the metric's configuration) or "
                          "the same scene %d substeps after the block hit the floor (for profiling runs)" % EVOLVE_AFTER_IMPACT)
+    ap.add_argument("--wire", default=os.environ.get("MPMHIP_TILE_WIRE", "rccl"), choices=["rccl", "ipc", "torch"],
+                    help="N > 1: the data plane of the halo exchange and the migration.  rccl (default): ncclSend / ncclRecv groups "
+                         "issued by libmpmhip itself; ipc: peer writes into IPC-mapped receive buffers, no collective; torch: the "
+                         "round-3 path (torch.distributed all_to_all from a Python callback per substep)")
+    ap.add_argument("--allow-staged", action="store_true",
+                    help="N > 1: if the RCCL wire cannot be brought up, stage the exchange through gloo and host memory instead of "
+                         "exiting with an error (such a line says so in config.wire and is NOT a scaling measurement)")
     ap.add_argument("--virtual", type=int, default=0, metavar="K",
                     help="diagnostic, not the metric: run the K-brick tiled job as K ctx on ONE GPU (exchanges are local "
                          "copies) and print per-rank phase times = the per-GPU compute of a K-GPU run without the wire")
@@ -406,45 +444,53 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     # test hook: MPMHIP_BENCH_BACKEND=gloo runs the N > 1 path with all ranks sharing the visible GPU(s) and the
     # device buffers staged through gloo (RCCL refuses two ranks on one GPU) — everything but the wire
-    staged = world > 1 and os.environ.get("MPMHIP_BENCH_BACKEND", "nccl") == "gloo"
+    staged = False
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     force_tiled = world == 1 and os.environ.get("MPMHIP_FORCE_TILED") == "1"  # test hook: TiledJob over RCCL, 1 rank
-    data_group, wire = None, None
+    data_group, wire, native_wire = None, None, None
+    shared = os.environ.get("MPMHIP_BENCH_BACKEND", "")  # test hooks: "gloo" / "ipc" = the ranks share the visible GPU(s)
     dog = Watchdog(rank)
     if world > 1 or force_tiled:
         import datetime
-        # control plane (barriers, the two scalar reductions below, agreement on the transport) = gloo, the default
-        # group; data plane (halo all-sum, migration) = an RCCL group over xGMI with device buffers
+        # control plane (barriers, the scalar reductions below, 64 / 128 bytes of wire set-up) = gloo, the default group;
+        # data plane (halo sums, migration) = the library's own: RCCL send / receive groups or IPC peer writes over xGMI
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dog.phase("gloo rendezvous", 180)
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=150))
-        wire = "gloo, staged through host memory (test hook)"
-        if not staged:
-            # probe the transport with the two collectives the job uses, in a CHILD process per rank (a hang or an abort
-            # inside RCCL then costs the child, and a bounded wait); every rank must see it work, else all ranks stage the
-            # same buffers through gloo (slower wire, same kernels, same results) rather than abort
-            dog.phase("RCCL probe", 240)
-            ok, why = (True, "") if os.environ.get("MPMHIP_SKIP_RCCL_PROBE") == "1" else probe_rccl_in_child(rank, world, local_rank)
-            flag = torch.tensor([int(ok)])
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()):
-                dog.phase("RCCL group", 120)
-                try:
-                    data_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=90))
-                    wire = "RCCL (nccl backend), device buffers"
-                except Exception as e:
-                    ok, why = False, repr(e)
+        if shared == "gloo":
+            staged, wire = True, "gloo, staged through host memory (test hook)"
+        elif shared == "ipc":
+            native_wire, wire = "ipc", "IPC peer writes (test hook: the ranks share the visible GPUs), handles over gloo"
+        else:
+            ok, why = True, ""
+            if args.wire in ("rccl", "torch") and os.environ.get("MPMHIP_SKIP_RCCL_PROBE") != "1":
+                # probe the transport in a CHILD process per rank (a hang or an abort inside RCCL then costs the child and a
+                # bounded wait); every rank must see it work
+                dog.phase("RCCL probe", 240)
+                ok, why = probe_rccl_in_child(rank, world, local_rank)
                 flag = torch.tensor([int(ok)])
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if not int(flag.item()):
-                    data_group = None
-            if data_group is None:
-                print("bench.py[rank %d]: RCCL transport unavailable (%s); staging the exchange through gloo" % (rank, why or "failed on another rank"),
-                      file=sys.stderr)
-                staged = True
-                wire = "gloo, staged through host memory (RCCL probe failed)"
+                ok = bool(int(flag.item()))
+            if ok and args.wire == "torch":
+                dog.phase("RCCL group", 120)
+                data_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=90))
+                wire = "RCCL through torch.distributed (all_to_all from a Python callback per substep)"
+            elif ok:
+                native_wire = args.wire
+                wire = {"rccl": "RCCL: ncclSend / ncclRecv groups issued by libmpmhip (no Python in the substep loop)",
+                        "ipc": "IPC peer writes into mapped receive buffers + epoch flags (no collective, no Python in the substep loop)"}[args.wire]
+            else:
+                msg = "bench.py[rank %d]: the RCCL wire could not be brought up (%s)" % (rank, why or "failed on another rank")
+                if not args.allow_staged:
+                    # a scaling curve measured over host-staged buffers is worthless: refuse rather than degrade silently
+                    print(msg + "; refusing to fall back to a host-staged exchange (pass --allow-staged to run anyway)", file=sys.stderr, flush=True)
+                    dog.stop()
+                    dist.destroy_process_group()
+                    sys.exit(5)
+                print(msg + "; --allow-staged: staging the exchange through gloo", file=sys.stderr, flush=True)
+                staged, wire = True, "gloo, staged through host memory (RCCL probe failed; --allow-staged)"
 
     cfg = dict(CONFIGS[args.config])
     if args.cells:  # reduced problem (tests, smoke runs): NOT the metric's configuration — the line says so
@@ -455,9 +501,12 @@ def main():
     dog.phase("scene set-up", 900)
     if world > 1 or force_tiled:
         from taichi_mpm_amd import tiled
-        comm = (tiled.StagedDistComm(dist) if staged else
-                tiled.DistComm(dist, torch.device("cuda", local_rank), data_group))
-        job = tiled.make_tiled_job(tm, cfg, rank, world, local_rank, comm=comm)
+        if native_wire:
+            job = tiled.make_native_job(tm, cfg, rank, world, local_rank, wire=native_wire, dist=dist)
+        else:
+            comm = (tiled.StagedDistComm(dist) if staged else
+                    tiled.DistComm(dist, torch.device("cuda", local_rank), data_group))
+            job = tiled.make_tiled_job(tm, cfg, rank, world, local_rank, comm=comm)
     else:
         job = SingleJob(build_sim(tm, cfg, local_rank))
     n_local = job.num_particles()

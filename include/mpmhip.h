@@ -330,7 +330,8 @@ typedef struct {
   int32_t migrate_cap;         /* 0: 64 */
   int32_t wire;                /* MPMHIP_WIRE_* */
   int32_t overlap;             /* boundary / interior split of the substep (mpmhip_set_overlap) */
-  int64_t inbox_records;       /* capacity of the migration inbox in records (the same on every rank); 0: max(65536, capacity / 8) */
+  int64_t inbox_records;       /* capacity of this rank's migration inbox in records; 0: max(65536, capacity / 8).  Every rank learns
+                                * every inbox's capacity with the migration table and all refuse together when one would overflow */
 } mpmhip_tiled_config;
 /* rank 0: a fresh ncclUniqueId; every rank: ncclCommInitRank on the ctx's device (collective over the ranks) */
 int mpmhip_comm_unique_id(uint8_t id[MPMHIP_COMM_ID_BYTES]);

@@ -1202,9 +1202,8 @@ static int do_halo_pack(mpmhip_ctx *c) {
   if (c->T.n_boxes == 0) return MPMHIP_OK;
   int nb = (int)((c->T.box_nodes + 255) / 256);
   if (nb > 4096) nb = 4096;
-  const bool peer_wire = c->tn.on && (c->tn.wire == MPMHIP_WIRE_IPC || c->tn.wire == MPMHIP_WIRE_LOCAL);
   hipLaunchKernelGGL(k_halo_pack, dim3(nb), dim3(256), 0, c->stream, c->P, c->T, c->d_boxes_cur, c->bits, c->wprefix,
-                     (const float4 *)c->tiles, peer_wire ? c->tn.d_done + MPMHIP_MAX_HALO_BOXES : (uint32_t *)nullptr, c->tn.epoch);
+                     (const float4 *)c->tiles);
   return launch_check(c, "halo_pack");
 }
 
@@ -1833,7 +1832,7 @@ static int ensure_counts(mpmhip_ctx *c, int world) {
   if (c->counts_cap < world) {
     hipFree(c->d_counts);
     c->d_counts = nullptr;
-    HIPCHK(c, dmalloc(&c->d_counts, (size_t)world + 7));  // + the 6 bounds and the speed of mpmhip_migration_scan
+    HIPCHK(c, dmalloc(&c->d_counts, (size_t)world + 8));  // + the 6 bounds and the speed of mpmhip_migration_scan + one word of the native data plane
     c->counts_cap = world;
   }
   return MPMHIP_OK;
@@ -1849,7 +1848,7 @@ int mpmhip_migration_scan(mpmhip_ctx *c, int32_t world, int64_t *counts, int32_t
   if (rc) return rc;
   if (c->in_substep) return fail(c, MPMHIP_EINVAL, "migration inside a substep");
   if ((size_t)world + 7 + sizeof(Counters) / 4 > 65536 / 4) return fail(c, MPMHIP_EINVAL, "world too large");
-  hipLaunchKernelGGL(k_scan_init, dim3((world + 7 + 255) / 256), dim3(256), 0, c->stream, c->d_counts, world);
+  hipLaunchKernelGGL(k_scan_init, dim3((world + 8 + 255) / 256), dim3(256), 0, c->stream, c->d_counts, world, 0u);
   int grid = particle_grid(c->n_slots);
   if (grid > 128) grid = 128;  // few workgroups: 6 same-address atomics each for the bounds
   hipLaunchKernelGGL(k_leaver_count, dim3(grid), dim3(256), 0, c->stream, c->P, c->T, (const float4 *)c->rg,

@@ -71,7 +71,7 @@ RcclApi *rccl_api() {
   } while (0)
 
 constexpr int TN_MAX_WORLD = MPMHIP_MAX_HALO_BOXES;      // every other rank can be a halo peer
-constexpr uint32_t TN_ROW = TN_MAX_WORLD + 8;            // words of a migration row: [counts(world) | lo3 | hi3 | speed], padded
+constexpr uint32_t TN_ROW = TN_MAX_WORLD + 8;            // words of a migration row: [counts(world) | lo3 | hi3 | speed | inbox capacity], padded
 constexpr size_t TN_FLAG_BYTES = 4096;                   // halo epochs [world] | table epochs [world] | record epochs [world]
 
 int tn_wait(mpmhip_ctx *c, const uint32_t *words, const std::vector<int> &who, int *d_idx, uint32_t epoch) {
@@ -209,7 +209,10 @@ void tn_begin_substep(mpmhip_ctx *c) {
 int tn_exchange_start(mpmhip_ctx *c) {
   auto &N = c->tn;
   if (N.boxes.empty()) return MPMHIP_OK;
-  if (N.wire != MPMHIP_WIRE_RCCL) return MPMHIP_OK;  // peer wires: k_halo_pack wrote the boxes and published the epoch
+  if (N.wire != MPMHIP_WIRE_RCCL) {  // peer wires: k_halo_pack wrote the boxes into the peers' buffers; publish the epoch
+    hipLaunchKernelGGL(k_epoch_signal, dim3(1), dim3(64), 0, c->stream, c->d_boxes_cur, (int)N.boxes.size(), N.epoch);
+    return launch_check(c, "epoch_signal");
+  }
   RcclApi *R = rccl_api();
   hipStream_t st = c->stream;
   if (c->ov_active) {  // the exchange runs beside the interior kernels: side stream, fenced by events
@@ -246,7 +249,8 @@ int tn_mig_a(mpmhip_ctx *c) {
   int rc = ensure_counts(c, world);
   if (rc) return rc;
   N.mig_epoch++;
-  hipLaunchKernelGGL(k_scan_init, dim3((world + 7 + 255) / 256), dim3(256), 0, c->stream, c->d_counts, world);
+  hipLaunchKernelGGL(k_scan_init, dim3((world + 8 + 255) / 256), dim3(256), 0, c->stream, c->d_counts, world,
+                     (uint32_t)std::min<uint64_t>(N.inbox_cap, 0xFFFFFFFFull));
   int grid = particle_grid(c->n_slots);
   if (grid > 128) grid = 128;
   hipLaunchKernelGGL(k_leaver_count, dim3(grid), dim3(256), 0, c->stream, c->P, c->T, (const float4 *)c->rg, (const float4 *)c->rp,
@@ -254,7 +258,7 @@ int tn_mig_a(mpmhip_ctx *c) {
   if ((rc = launch_check(c, "leaver_count"))) return rc;
   uint32_t *table = N.table[N.mig_epoch & 1];
   if (N.wire == MPMHIP_WIRE_RCCL) {
-    HIPCHK(c, hipMemcpyAsync(N.row, c->d_counts, sizeof(uint32_t) * (world + 7), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(N.row, c->d_counts, sizeof(uint32_t) * (world + 8), hipMemcpyDeviceToDevice, c->stream));
     NCCLCHK(c, rccl_api()->AllGather(N.row, table, TN_ROW, ncclUint32, (ncclComm_t)N.comm, c->stream));
     return MPMHIP_OK;
   }
@@ -264,7 +268,7 @@ int tn_mig_a(mpmhip_ctx *c) {
     L.src[p] = c->d_counts;
     L.dst[p] = (p == c->T.rank ? table : N.peers[p].table[N.mig_epoch & 1]) + (size_t)c->T.rank * TN_ROW;
     L.flag[p] = (p == c->T.rank ? N.flags : N.peers[p].flags) + TN_MAX_WORLD + c->T.rank;
-    L.words[p] = (uint32_t)world + 7;
+    L.words[p] = (uint32_t)world + 8;
   }
   hipLaunchKernelGGL(k_put, dim3(world, 1), dim3(256), 0, c->stream, L, N.mig_epoch, N.d_done);
   return launch_check(c, "put (migration row)");
@@ -311,9 +315,14 @@ int tn_mig_b(mpmhip_ctx *c) {
     N.mig_send_cap = (size_t)M.n_out + (size_t)M.n_out / 2 + 4096;
     HIPCHK(c, dmalloc(&N.mig_send, N.mig_send_cap * 11));
   }
-  if ((uint64_t)M.n_in > N.inbox_cap)
-    return fail(c, MPMHIP_ECAPACITY, "migration: %lld arriving particles exceed the inbox of %llu records (mpmhip_tiled_config.inbox_records)",
-                (long long)M.n_in, (unsigned long long)N.inbox_cap);
+  for (int s = 0; s < world; s++) {  // every rank sees every inbox: all refuse together, BEFORE anybody writes beyond one
+    int64_t arriving = 0;
+    for (int r = 0; r < world; r++) arriving += M.counts[(size_t)r * world + s];
+    const uint32_t room = h[(size_t)s * TN_ROW + world + 7];
+    if (arriving > (int64_t)room)
+      return fail(c, MPMHIP_ECAPACITY, "migration: %lld particles arriving at rank %d exceed its inbox of %u records (mpmhip_tiled_config.inbox_records)",
+                  (long long)arriving, s, room);
+  }
   std::vector<int64_t> mine((size_t)world);
   for (int s = 0; s < world; s++) mine[s] = M.counts[(size_t)me * world + s];
   if (M.n_out && (rc = mpmhip_export_leavers(c, world, mine.data(), N.mig_send))) return rc;
@@ -651,7 +660,7 @@ int mpmhip_tiled_connect_local(mpmhip_ctx *const *ctxs, int32_t n) {
     if (!c->tn.on || c->tn.wire != MPMHIP_WIRE_LOCAL || c->tn.world != n || c->T.rank != r)
       return fail(c, MPMHIP_EINVAL, "connect_local: ctx %d must be set up as rank %d of %d with MPMHIP_WIRE_LOCAL", r, r, n);
     if (c->device != ctxs[0]->device) return fail(c, MPMHIP_EINVAL, "connect_local: all ctx must live on one device");
-    if (c->tn.arena_bytes != ctxs[0]->tn.arena_bytes) return fail(c, MPMHIP_EINVAL, "connect_local: the ranks' arenas differ (inbox_records must be the same on every rank)");
+    if (c->tn.halo_cap != ctxs[0]->tn.halo_cap) return fail(c, MPMHIP_EINVAL, "connect_local: the ranks' arenas are laid out differently (not the same partition?)");
   }
   for (int r = 0; r < n; r++) {
     mpmhip_ctx *c = ctxs[r];
@@ -703,8 +712,13 @@ int64_t mpmhip_tiled_advance_group(mpmhip_ctx *const *ctxs, int32_t n_ctx, int64
       return fail(ctxs[r], MPMHIP_EINVAL, "advance_group: ctx %d is not rank %d of a local job of %d", r, r, n_ctx);
   }
   for (int64_t i = 0; i < n; i++) {
-    for (int part = 0; part < 3; part++)
-      for (int r = 0; r < n_ctx; r++) {
+    // begin of every rank (sort, [boundary] P2G, pack: the peers' boxes are written), then interior + end rank by rank
+    for (int r = 0; r < n_ctx; r++) {
+      int rc = tn_substep_parts(ctxs[r], 0);
+      if (rc) { ctxs[r]->in_substep = false; ctxs[r]->cur_ev = nullptr; return rc; }
+    }
+    for (int r = 0; r < n_ctx; r++)
+      for (int part = 1; part < 3; part++) {
         int rc = tn_substep_parts(ctxs[r], part);
         if (rc) { ctxs[r]->in_substep = false; ctxs[r]->cur_ev = nullptr; return rc; }
       }

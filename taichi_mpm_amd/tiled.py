@@ -783,3 +783,14 @@ def make_tiled_job(tm, cfg, rank, world, local_rank, margin=4, migrate_interval=
     overlap = os.environ.get("MPMHIP_TILE_OVERLAP", "1") != "0"  # ("auto": bench.py times both and keeps the faster)
     comm = comm or DistComm(dist, torch.device("cuda", local_rank))
     return TiledJob(engine, part, comm, migrate_interval, overlap=overlap)
+
+
+def make_native_job(tm, cfg, rank, world, local_rank, wire="rccl", dist=None, margin=4, migrate_interval=None):
+    """bench.py, N > 1 on the library's own data plane: the same scene and partition as make_tiled_job; Python hands over
+    the partition and 64 / 128 bytes of wire set-up, then only calls mpmhip_tiled_advance"""
+    margin = int(os.environ.get("MPMHIP_TILE_MARGIN", margin))
+    part = scene_partition(cfg, world, margin)
+    sim, _ = build_rank_sim(tm, cfg, part, rank, local_rank)
+    engine = HipEngine(sim, local_rank)
+    overlap = os.environ.get("MPMHIP_TILE_OVERLAP", "1") != "0"  # ("auto": bench.py times both and keeps the faster)
+    return NativeTiledJob(engine, part, rank, world, wire=wire, dist=dist, migrate_interval=migrate_interval, overlap=overlap)

@@ -467,15 +467,111 @@ def test_two_processes_on_one_gpu_match_one_ctx(tm):
     assert rel_l2(got["v"], ref["v"]) <= 1e-4 and rel_l2(got["F"], ref["F"]) <= 1e-4
 
 
-@pytest.mark.parametrize("nproc,bricks,hook,config", [(2, "2x1x1", True, "c2"), (8, "2x2x2", True, "c2"), (2, "2x1x1", False, "c2"),
-                                                       (8, "2x2x2", True, "c5")])
+def _native_worker(rank, world, port, steps, wire, overlap, device, q):
+    import os
+
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("MPMHIP_TILE_WAIT_S", "10")  # a peer that never arrives costs an error, not the box
+    torch.cuda.set_device(device)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # control plane only: 64 / 128 bytes once, barriers
+    try:
+        import taichi_mpm_amd as tm
+        from taichi_mpm_amd import tiled
+        tm.load()
+        s = _two_material_state()
+        part = tiled.Partition.balanced((RES,) * 3, world, s.x, DX, margin=2)
+        owner = part.rank_of_cells(tiled.base_cells(s.x, DX))
+        from taichi_mpm_amd.mpm import F_ID
+        sel, ids = owner == rank, np.arange(s.n)
+        sim = tm.create_simulation3("mpm")
+        sim.initialize(dict(res=(RES,) * 3, delta_x=DX, base_delta_t=DT, max_particles=s.n + 1024, reorder_interval=0, device=device))
+        ls = tm.mpm.LevelSet(friction=0.4)
+        for p in PLANES:
+            ls.add_plane(p[:3], d=p[3])
+        sim.set_levelset(ls)
+        names = {v: k for k, v in tm.MATERIAL_IDS.items()}
+        for gi in range(len(s.gtype)):
+            m = sel & (s.gid == gi)
+            sim.add_particles(dict(type=names[int(s.gtype[gi])], positions=s.x[m], velocities=s.v[m], F=s.F[m], B=s.B[m], aux=s.aux[m],
+                                   params=s.gparams[gi]))
+        order = np.concatenate([np.nonzero(sel & (s.gid == gi))[0] for gi in range(len(s.gtype))])
+        sim.upload(F_ID, ids[order].astype(np.int32))
+        job = tiled.NativeTiledJob(tiled.HipEngine(sim, device), part, rank, world, wire=wire, dist=dist, migrate_interval=2,
+                                   overlap=overlap)
+        job.run(steps)
+        job.synchronize()
+        dist.barrier()  # nobody unmaps an arena a peer may still write to
+        p = sim.get_particles(sort_by_id=False)
+        q.put((rank, job.state()[0], {k: p[k] for k in ("x", "v", "F", "id", "gid")}))
+        sim.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_native_ranks(tm, wire, overlap, devices):
+    import socket
+
+    import torch.multiprocessing as mp
+    s = _two_material_state()
+    steps, world = 12, len(devices)
+    one = _sim(tm, s, np.ones(s.n, bool), np.arange(s.n), s.n + 1024)
+    one.run_substeps(steps)
+    ref = one.get_particles()
+    one.close()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, steps, wire, overlap, devices[r], q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1]["substeps"] == steps and r[1]["migrations"] == steps // 2 for r in res), [r[1] for r in res]
+    assert sum(r[1]["migrated_out"] for r in res) > 0  # migration happened
+    got = {k: np.concatenate([r[2][k] for r in res]) for k in res[0][2]}
+    order = np.argsort(got["id"], kind="stable")
+    got = {k: v[order] for k, v in got.items()}
+    assert np.array_equal(got["id"], ref["id"]) and np.array_equal(got["gid"], ref["gid"])
+    assert np.abs(got["x"] - ref["x"]).max() <= 1e-6
+    assert rel_l2(got["v"], ref["v"]) <= 1e-4 and rel_l2(got["F"], ref["F"]) <= 1e-4
+
+
+@pytest.mark.parametrize("overlap", [False, True], ids=["serial", "overlap_split"])
+def test_two_processes_over_the_ipc_wire_match_one_ctx(tm, overlap):
+    """MPMHIP_WIRE_IPC between two PROCESSES (sharing this GPU): each maps the other's receive arena with
+    hipIpcOpenMemHandle; k_halo_pack writes the boxes straight into it and publishes the substep's epoch, the reader polls
+    it; migration rows and records travel the same way.  Python moves 64 bytes per rank once (the handles, over gloo)."""
+    _run_native_ranks(tm, "ipc", overlap, [0, 0])
+
+
+@pytest.mark.parametrize("wire", ["rccl", "ipc"])
+@pytest.mark.parametrize("overlap", [False, True], ids=["serial", "overlap_split"])
+def test_two_ranks_on_two_gpus_over_the_native_wires_match_one_ctx(tm, wire, overlap):
+    """the real wires: two processes, two GPUs — ncclSend / ncclRecv groups issued by the library, or peer writes over xGMI
+    into IPC-mapped buffers.  Needs >= 2 GPUs: skipped on the 1-GPU boxes of the development pool."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    _run_native_ranks(tm, wire, overlap, [0, 1])
+
+
+@pytest.mark.parametrize("nproc,bricks,hook,config", [(2, "2x1x1", "gloo", "c2"), (8, "2x2x2", "ipc", "c2"), (2, "2x1x1", "staged", "c2"),
+                                                       (2, "2x1x1", "refuse", "c2"), (8, "2x2x2", "ipc", "c5")])
 def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks, hook, config):
-    """`bench.py --gpus N` exactly as the driver launches it (torch.distributed.run, one process per rank), with
-    the MPMHIP_BENCH_BACKEND=gloo hook: both ranks share this GPU and the buffers are staged through gloo.  Checks
-    the ONE-JSON-line contract and the whole-job aggregation of the N > 1 path.  hook=False is the launch without
-    any hook on a box with fewer GPUs than ranks: the RCCL probe fails (two ranks on one device) on every rank and
-    the job must carry on over the staged transport instead of aborting.  config c5 = BASELINE configs[4] (512^3 grid,
-    8 clusters, two materials) tiled over 8 ranks, at a reduced cluster size (--cells 16)."""
+    """`bench.py --gpus N` exactly as the driver launches it (torch.distributed.run, one process per rank) on a box with fewer
+    GPUs than ranks.  hook "ipc" (MPMHIP_BENCH_BACKEND=ipc): the ranks share this GPU and run the library's own data plane over
+    the IPC wire — native loop, peer writes, native migration; "gloo": the round-3 Python path staged through gloo.  Without
+    a hook the RCCL probe fails (two ranks on one device): the job must EXIT NON-ZERO ("refuse") rather than silently turn a
+    scaling run into a host-staged one, unless --allow-staged is given ("staged").  Checks the ONE-JSON-line contract and the
+    whole-job aggregation of the N > 1 path.  config c5 = BASELINE configs[4] (512^3 grid, 8 clusters, two materials) tiled over 8
+    ranks, at a reduced cluster size (--cells 16)."""
     import json
     import os
     import socket
@@ -487,12 +583,17 @@ def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks, hook, co
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.pop("MPMHIP_BENCH_BACKEND", None)
-    if hook:
-        env["MPMHIP_BENCH_BACKEND"] = "gloo"
+    if hook in ("gloo", "ipc"):
+        env["MPMHIP_BENCH_BACKEND"] = hook
+    env.setdefault("MPMHIP_TILE_WAIT_S", "20")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--config", config,
-           "--steps", "8", "--warmup", "4"] + (["--cells", "16"] if config == "c5" else [])
+           "--steps", "8", "--warmup", "4"] + (["--cells", "16"] if config == "c5" else []) + (["--allow-staged"] if hook == "staged" else [])
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    if hook == "refuse":
+        assert r.returncode != 0 and "refusing to fall back" in r.stderr, r.stdout[-2000:] + r.stderr[-4000:]
+        assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+        return
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
@@ -502,7 +603,10 @@ def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks, hook, co
     assert ("REDUCED" in d["config"]["workload"]) == (config == "c5")
     assert d["value"] > 0 and d["unit"] == "particle-steps/s" and d["roofline"]["kernel"] in ("k_g2p", "k_p2g")
     assert bricks + " bricks" in d["config"]["parallelism"]
-    assert d["config"]["wire"].startswith("gloo") and ("probe failed" in d["config"]["wire"]) == (not hook)
+    if hook == "ipc":
+        assert d["config"]["wire"].startswith("IPC peer writes") and "library's own data plane" in d["config"]["parallelism"]
+    else:
+        assert d["config"]["wire"].startswith("gloo") and ("probe failed" in d["config"]["wire"]) == (hook == "staged")
     ov = d["config"]["overlap_split"]  # both ways timed before the measurement, the faster one kept (bench.py)
     assert ov["kept"] in ("on", "off") and ov["ms_per_step_on"] > 0 and ov["ms_per_step_off"] > 0
 
