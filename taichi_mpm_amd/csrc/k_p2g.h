@@ -137,7 +137,11 @@ __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const floa
                                                             const uint32_t *__restrict__ perm,
                                                             const GroupParams *__restrict__ groups,
                                                             float4 *__restrict__ tiles, Tiling T, int phase,
-                                                            const uint8_t *__restrict__ blk_rigid) {
+                                                            const uint8_t *__restrict__ blk_rigid
+#ifdef MPMHIP_TIMING_BUILD  // (variant library lib/libmpmhip_timing.so only, profiles/p2g_block_times.py: per-block wall-clock stamps)
+                                                            , unsigned long long *__restrict__ tlog
+#endif
+                                                            ) {
   constexpr int NW = NS * PS, NT = 64 * NW;
   __shared__ float4 tile[NW][TN];  // per wave: (m*vx, m*vy, m*vz, m) per node of the block's 6^3 tile
   const uint32_t na = min(cnt->n_active, P.max_blocks);
@@ -179,6 +183,9 @@ __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const floa
       cur = nxt;
       continue;
     }
+#ifdef MPMHIP_TIMING_BUILD
+    const unsigned long long t_begin = wall_clock64();
+#endif
     for (int t = threadIdx.x; t < NW * TN; t += NT) (&tile[0][0])[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();
     const float ox = (float)(bx * BS + cx), oy = (float)(by * BS + cy), oz = (float)(bz * BS + cz);
@@ -200,6 +207,17 @@ __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const floa
       tiles[(size_t)a * TN + t] = u;
     }
     __syncthreads();
+#ifdef MPMHIP_TIMING_BUILD
+    {
+      unsigned cmax = cur.c1 - cur.c0, csum = cmax;  // the fullest cell of the block and its particle count
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, off)); csum += (unsigned)__shfl_xor((int)csum, off); }
+      if (tlog && threadIdx.x == 0) {
+        tlog[3 * (size_t)a] = t_begin; tlog[3 * (size_t)a + 1] = wall_clock64();
+        tlog[3 * (size_t)a + 2] = ((unsigned long long)cmax << 32) | csum;
+      }
+    }
+#endif
     cur = nxt;
   }
 }

@@ -235,6 +235,9 @@ struct mpmhip_ctx {
   bool overlap = false;        // mpmhip_set_overlap: split tiled substeps into boundary / interior work
   bool ov_active = false, interior_done = false;  // state of the substep in flight
   const DevBox *d_boxes_cur = nullptr;  // the box table the pack / grid kernels of the substep in flight read
+#ifdef MPMHIP_TIMING_BUILD
+  unsigned long long *p2g_tlog = nullptr;  // [3 max_blocks]: begin, end (100 MHz wall clock), fullest cell << 32 | particles of the block
+#endif
   // the native data plane of a tiled run (tiled_api.h): plan, arena, wire, migration state
   struct TiledNative {
     struct Box { int peer; int lo[3], hi[3]; uint64_t vol, off, peer_off; };  // off / peer_off: float4 nodes into this rank's / the peer's buffers
@@ -1014,7 +1017,11 @@ static int do_p2g(mpmhip_ctx *c, int phase = 0) {
   if (rigid) { if (int rc = rigid_fork(c, &rs, 1)) return rc; }
   hipLaunchKernelGGL(kern, dim3(c->p2g_wgs), dim3(nt), 0, c->stream, c->P,
                      (const float4 *)c->rp, c->cnt, c->act_blk, c->cell_start, c->perm, c->d_groups, c->tiles, c->T, phase,
-                     rigid ? (const uint8_t *)c->rigid.d_blk_rigid : (const uint8_t *)nullptr);
+                     rigid ? (const uint8_t *)c->rigid.d_blk_rigid : (const uint8_t *)nullptr
+#ifdef MPMHIP_TIMING_BUILD
+                     , c->p2g_tlog
+#endif
+                     );
   if (rigid) {  // blocks near a body (block_op_rigid), then RigidBody::apply_tmp_velocity (src/transfer.cpp:578-580)
     auto rk = k_p2g_rigid<MAT_ALL>;
     switch (material_mask(c)) {  // one material in the ctx: the kernel that carries only its calculate_force()
@@ -2995,3 +3002,20 @@ int mpmhip_debug_plasticity(mpmhip_ctx *c, int32_t material, const float params[
 }  // extern "C"
 
 #include "tiled_api.h"
+
+#ifdef MPMHIP_TIMING_BUILD
+// (variant library only; not part of include/mpmhip.h) per-block stamps of the NEXT k_p2g launches (enable), or their read-back
+extern "C" int mpmhip_timing_p2g_blocks(mpmhip_ctx *c, int32_t enable, unsigned long long *out, int64_t capacity_blocks) {
+  if (!c) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (out && c->p2g_tlog) {
+    const int64_t n = std::min<int64_t>(capacity_blocks, c->P.max_blocks);
+    HIPCHK(c, hipMemcpy(out, c->p2g_tlog, sizeof(unsigned long long) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+  }
+  if (enable && !c->p2g_tlog) HIPCHK(c, dmalloc(&c->p2g_tlog, (size_t)c->P.max_blocks * 3));
+  if (enable) HIPCHK(c, hipMemset(c->p2g_tlog, 0, sizeof(unsigned long long) * 3 * (size_t)c->P.max_blocks));
+  if (!enable && c->p2g_tlog) { (void)hipFree(c->p2g_tlog); c->p2g_tlog = nullptr; }
+  return MPMHIP_OK;
+}
+#endif
