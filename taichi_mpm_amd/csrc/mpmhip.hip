@@ -125,7 +125,7 @@ struct mpmhip_ctx {
   bool compact = false;       // ... and the live ones occupy exactly [0, cnt->n_sorted): n_slots may shrink to that
   int p2g_wgs = 16384;        // workgroups of k_p2g (env MPMHIP_P2G_WGS)
   int p2g_split = 11;         // tuning knob (env MPMHIP_P2G_SPLIT): 10*NS + PS, see do_p2g
-  int g2p_wgs = 4096;         // workgroups of k_g2p (env MPMHIP_G2P_WGS)
+  int g2p_wgs = 0;            // workgroups of k_g2p; 0: by size (env MPMHIP_G2P_WGS pins it)
   int rigid_wgs = 2048;       // workgroups of k_p2g_rigid (one per wave slot of the device), twice those of k_g2p_rigid (env MPMHIP_RIGID_WGS: tuning)
   uint32_t rank_runs_mul = 3; // k_rank takes its LDS-hash path when runs * this > slots (env MPMHIP_RANK_RUNS_MUL: tuning)
   int ct_blocks = 0;          // blocks per chunk of k_cell_table: 0 by size, 16, 64 (env MPMHIP_CT_BLOCKS: tuning)
@@ -436,7 +436,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   c->cfg = *cfg;
   c->device = cfg->device;
   if (const char *e = getenv("MPMHIP_G2P_MINW")) c->g2p_minw = atoi(e);
-  if (const char *e = getenv("MPMHIP_G2P_WGS")) c->g2p_wgs = atoi(e) > 0 ? atoi(e) : 4096;
+  if (const char *e = getenv("MPMHIP_G2P_WGS")) c->g2p_wgs = atoi(e) > 0 ? atoi(e) : 0;
   if (const char *e = getenv("MPMHIP_RIGID_CONCURRENT")) c->rigid.concurrent = atoi(e);
   if (const char *e = getenv("MPMHIP_RIGID_WGS")) c->rigid_wgs = atoi(e) > 1 ? atoi(e) : 2048;
   if (const char *e = getenv("MPMHIP_RANK_RUNS_MUL")) c->rank_runs_mul = (uint32_t)atoi(e);
@@ -1096,7 +1096,11 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0) {
   }
   hipStream_t rs = c->stream;
   if (rigid) { if (int rc = rigid_fork(c, &rs, 2)) return rc; }
-  hipLaunchKernelGGL(kern, dim3(c->g2p_wgs), dim3(nt), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
+  // 4 096 workgroups at 8 M particles (2 048 / 8 192 measured no better); below ~2 M slots the device's resident set (three
+  // workgroups per CU = 768) walking ~6 chunks each WITH the record prefetch beats one chunk per workgroup: 51.9 -> 46.1 us at
+  // 1 M particles (profiles/r04_b_knobs.txt; 512 and 1 024 are slower again)
+  const int g2p_wgs = c->g2p_wgs > 0 ? c->g2p_wgs : (c->n_slots < (2 << 20) ? 768 : 4096);
+  hipLaunchKernelGGL(kern, dim3(g2p_wgs), dim3(nt), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
                      (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
                      c->blk_flag, (const LevelSetDev *)c->d_LS, phase_box(c->T), phase);
   if (rigid) {
