@@ -55,9 +55,10 @@ class MPM<3> {
     for (const char *k : {"rigid_body_levelset_collision", "gravity_cutting", "sand_climb", "sand_crawler", "stork_nod", "energy_experiment",
                           "visualize_cdf", "visualize_particle_cdf", "benchmark_rasterize", "benchmark_resample"})
       if (config.get(k, false)) throw std::runtime_error(std::string("config key '") + k + "' is not implemented by this library");
-    if (config.get("dirichlet_boundary_radius", 0.0f) > 0 || config.get("expr_leaky_levelset", 0) != 0 || config.get("remove_particles", 0) != 0 ||
+    if (config.get("expr_leaky_levelset", 0) != 0 || config.get("remove_particles", 0) != 0 ||
         config.get("coupling_iterations", 1) != 1 || config.get("cdf_expand", 0) != 0)
-      throw std::runtime_error("dirichlet_boundary_radius / expr_leaky_levelset / remove_particles / coupling_iterations / cdf_expand are not implemented");
+      throw std::runtime_error("expr_leaky_levelset / remove_particles / coupling_iterations / cdf_expand are not implemented");
+    dirichlet_ = config.get("dirichlet_boundary_radius", 0.0f) > 0;  // :541-544 -> apply_dirichlet_boundary_conditions (:401-412)
     res = config.get_vec("res", VectorI(0, 0, 0));
     if (res[0] <= 0) throw std::runtime_error("config key 'res' is required");
     delta_x = config.get("delta_x", 1.0f / res[0]);
@@ -85,6 +86,7 @@ class MPM<3> {
     // CPIC coupling constants (src/mpm.cpp:35,40)
     check(mpmhip_set_rigid_coupling(ctx_, config.get("penalty", 0.0f), config.get("pushing_force", 20000.0f)), ctx_);
     check(mpmhip_set_articulation_iterations(ctx_, config.get("articulation_iterations", 100)), ctx_);  // src/mpm.h:279-280
+    check(mpmhip_set_dirichlet(ctx_, dirichlet_ ? 1 : 0), ctx_);
     frame = 0;
     frame_count = 0;
   }
@@ -374,6 +376,7 @@ class MPM<3> {
   }
   mpmhip_ctx *ctx_ = nullptr;
   mpmhip_config cfg_{};
+  bool dirichlet_ = false;
   std::vector<ParticleType> types_;
   std::vector<std::unique_ptr<ScriptFunction>> scripts_;  // scripted motions of rigid bodies (called back by the library)
 };

@@ -135,6 +135,10 @@ typedef struct {
   float p[6];
 } mpmhip_shape;
 int mpmhip_set_levelset_shapes(mpmhip_ctx *ctx, int32_t n, const mpmhip_shape *shapes, float friction);
+/* MPM<3>::apply_dirichlet_boundary_conditions (src/mpm.cpp:401-412; runs behind the grid boundary condition when the config key
+ * dirichlet_boundary_radius is > 0, :541-544): grid nodes with y > 0.525 are held at rest (the reference's 3D form ignores the
+ * radius and hard-codes the plane) */
+int mpmhip_set_dirichlet(mpmhip_ctx *ctx, int32_t enabled);
 /* time-dependent level set — replaces DynamicLevelSet::initialize(t0, t1, levelset(t0), levelset(t1)) +
  * Simulation::set_levelset as the python driver calls them before every frame (scripts/async/async_mpm.py:119-127,
  * e.g. the shrinking container of scripts/async/balls.py:38-49): two key frames blended linearly in time; at time t
@@ -471,6 +475,11 @@ typedef struct {
 int mpmhip2d_create(const mpmhip2d_config *cfg, mpmhip2d_ctx **out);
 void mpmhip2d_destroy(mpmhip2d_ctx *ctx);
 const char *mpmhip2d_last_error(const mpmhip2d_ctx *ctx);
+/* MPM<2>::apply_dirichlet_boundary_conditions (src/mpm.cpp:374-399): grid nodes with x < distance_left move with
+ * (velocity_left, 0), nodes with x > 1 - distance_right with (velocity_right, 0) — config keys dirichlet_boundary_radius,
+ * dirichlet_distance_left / _right, dirichlet_boundary_velocity, dirichlet_boundary_left / _right */
+int mpmhip2d_set_dirichlet(mpmhip2d_ctx *ctx, int32_t enabled, float distance_left, float distance_right, float velocity_left,
+                           float velocity_right);
 int mpmhip2d_set_levelset(mpmhip2d_ctx *ctx, int32_t n0, const mpmhip_shape *shapes0, int32_t n1, const mpmhip_shape *shapes1,
                           float t0, float t1, float friction);
 int mpmhip2d_add_group(mpmhip2d_ctx *ctx, int32_t material, const float params[MPMHIP_NPARAM]);

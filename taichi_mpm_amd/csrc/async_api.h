@@ -32,6 +32,26 @@ static int async_store_reserve(mpmhip_ctx *c, uint32_t need) {  // room for `nee
   S.cap = cap;
   return MPMHIP_OK;
 }
+// the per-block action table of an advance -> S.d_tbl, ORDERED ON THE CTX STREAM behind the kernels that still read the
+// previous table (the ctx stream is non-blocking: a plain hipMemcpy would run beside them) and from pinned memory (the host
+// refills A.tbl right away): a ring of four pinned images — every advance synchronises the stream between its two uploads, so
+// an image is never rewritten while its copy is still pending
+static int async_upload_tbl(mpmhip_ctx *c) {
+  auto &A = c->async;
+  auto &S = A.store;
+  const size_t nblk = A.tbl.size();
+  if (S.pin_cap < nblk) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (S.h_tbl_pin) (void)hipHostFree(S.h_tbl_pin);
+    S.h_tbl_pin = nullptr;
+    HIPCHK(c, hipHostMalloc((void **)&S.h_tbl_pin, 4 * nblk, hipHostMallocDefault));
+    S.pin_cap = nblk;
+  }
+  uint8_t *img = S.h_tbl_pin + (size_t)(S.pin_next++ & 3) * S.pin_cap;
+  memcpy(img, A.tbl.data(), nblk);
+  HIPCHK(c, hipMemcpyAsync(S.d_tbl, img, nblk, hipMemcpyHostToDevice, c->stream));
+  return MPMHIP_OK;
+}
 static int async_best_reserve(mpmhip_ctx *c) {  // one dedup word per creation id
   auto &S = c->async.store;
   if ((int64_t)c->next_pid <= S.best_cap) return MPMHIP_OK;
@@ -284,8 +304,7 @@ static int async_advance(mpmhip_ctx *c, int64_t limit) {
     A.has_copied[b] = 1; A.tbl[b] |= AT_BACKUP;
   }
   if (int rc = async_best_reserve(c)) return rc;
-  // (A.tbl is pageable host memory the next lines of this function overwrite: the copy is a synchronous one)
-  HIPCHK(c, hipMemcpy(S.d_tbl, A.tbl.data(), nblk, hipMemcpyHostToDevice));
+  if (int rc = async_upload_tbl(c)) return rc;
   // the working set holds at most one container per id (duplicates are dropped by the gather), i.e. at most
   // min(containers, ids handed out) records: the ctx's record arrays get that room BEFORE the gather writes into them — a
   // C-ABI caller may have pooled several batches of up to `cap` particles each (mpmhip_async_pool_particles empties the slots)
@@ -332,7 +351,7 @@ static int async_advance(mpmhip_ctx *c, int64_t limit) {
       any_clear = true;
     }
   }
-  HIPCHK(c, hipMemcpy(S.d_tbl, A.tbl.data(), nblk, hipMemcpyHostToDevice));  // (pageable source, refilled by the next advance)
+  if (int rc = async_upload_tbl(c)) return rc;
   if (any_clear)
     hipLaunchKernelGGL(k_async_clear, dim3(as_grid(S.size)), dim3(256), 0, c->stream, S.size, S.tag, (const uint8_t *)S.d_tbl, S.d_cnt);
   if (n_work) {
@@ -471,7 +490,7 @@ int mpmhip_async_load_pools(mpmhip_ctx *c) {
   const size_t nblk = A.continuous.size();
   if (int rc = async_ensure_particle_arrays(c)) return rc;
   std::fill(A.tbl.begin(), A.tbl.end(), (uint8_t)AT_POOL1);
-  HIPCHK(c, hipMemcpy(S.d_tbl, A.tbl.data(), nblk, hipMemcpyHostToDevice));
+  if (int rc = async_upload_tbl(c)) return rc;
   hipLaunchKernelGGL(k_async_load, dim3(as_grid(S.size)), dim3(256), 0, c->stream, S.size, (const uint32_t *)S.tag, (const float4 *)S.g,
                      (const float4 *)S.w, (const GroupParams *)c->d_groups, (float4 *)c->rg, (float4 *)c->rp, (float4 *)c->rb,
                      A.d_blk_of, S.d_cnt);

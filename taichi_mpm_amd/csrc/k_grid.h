@@ -157,6 +157,7 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
           friction_project(v, vb, nrm, LS.friction);
         }
       }
+      if (LS.dirichlet && (float)gj * P.dx > 0.525f) { v[0] = 0.0f; v[1] = 0.0f; v[2] = 0.0f; }  // src/mpm.cpp:401-412 (behind the BC, :541-544)
       gridv[(size_t)slot * BC + l] = make_float4(v[0], v[1], v[2], m);
       if (l == 0) fat_slot[morton3(cx, cy, cz)] = slot;
     };

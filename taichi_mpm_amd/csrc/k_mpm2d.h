@@ -23,6 +23,10 @@ struct Params {
   float apic_damping, rpic_damping;
   int clean_boundary, particle_collision;
   int clamp_pos;  // generic path: positions clamped into [0, res - eps] (src/transfer.cpp:668-670)
+  // MPM<2>::apply_dirichlet_boundary_conditions (src/mpm.cpp:374-399): nodes with x < dl move with (vl, 0), nodes with
+  // x > 1 - dr with (vr, 0); off unless `dirichlet`
+  int dirichlet;
+  float dl, dr, vl, vr;
 };
 
 struct m2 {
@@ -327,6 +331,11 @@ __global__ __launch_bounds__(256) void k_grid(Params P, LevelSetDev LS, float *_
       const float vb[2] = {-dphidt * nrm[0] * P.dx, -dphidt * nrm[1] * P.dx};
       friction_project2(v, vb, nrm, LS.friction);
     }
+  }
+  if (P.dirichlet) {  // src/mpm.cpp:389-397, behind the boundary condition (:541-544); every node of the grid region
+    const float px = (float)(t / ny) * P.dx;
+    if (px < P.dl) { v[0] = P.vl; v[1] = 0.0f; }
+    else if (px > 1.0f - P.dr) { v[0] = P.vr; v[1] = 0.0f; }
   }
   g[0] = v[0]; g[1] = v[1];
 }

@@ -601,7 +601,8 @@ struct LevelSetDev {
   int particle_collision;
   int dynamic;  // 1: s1 / n1 hold the key frame at t1, s / n the one at t0
   int n1;
-  float t0, t1, pad;
+  float t0, t1;
+  int dirichlet;  // MPM<3>::apply_dirichlet_boundary_conditions (src/mpm.cpp:401-412): grid nodes above y = 0.525 are held at rest
   ShapeDev s[MPMHIP_MAX_SHAPES];
   ShapeDev s1[MPMHIP_MAX_SHAPES];
 };

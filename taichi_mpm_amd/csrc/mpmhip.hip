@@ -193,6 +193,9 @@ struct mpmhip_ctx {
       int64_t best_cap = 0;
       uint32_t scan_cap = 0, scan_epoch = 0;
       uint8_t *d_tbl = nullptr;
+      uint8_t *h_tbl_pin = nullptr;  // four pinned images of the action table (async_upload_tbl)
+      size_t pin_cap = 0;
+      uint32_t pin_next = 0;
       uint32_t *d_rank = nullptr;
       AsyncCounters *d_cnt = nullptr;
       int64_t compactions = 0;
@@ -235,6 +238,7 @@ struct mpmhip_ctx {
   bool overlap = false;        // mpmhip_set_overlap: split tiled substeps into boundary / interior work
   bool ov_active = false, interior_done = false;  // state of the substep in flight
   const DevBox *d_boxes_cur = nullptr;  // the box table the pack / grid kernels of the substep in flight read
+  bool dirichlet = false;      // mpmhip_set_dirichlet
 #ifdef MPMHIP_TIMING_BUILD
   unsigned long long *p2g_tlog = nullptr;  // [3 max_blocks]: begin, end (100 MHz wall clock), fullest cell << 32 | particles of the block
 #endif
@@ -559,6 +563,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   hipFree(c->cell_start); hipFree(c->scan_slots); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
   hipFree(c->async.d_tab); hipFree(c->async.d_blk_of); hipFree(c->async.d_blk_limits); hipFree(c->async.d_particle_limits);
   if (c->async.h_tab) hipHostFree(c->async.h_tab);
+  if (c->async.store.h_tbl_pin) hipHostFree(c->async.store.h_tbl_pin);
   { auto &S = c->async.store; hipFree(S.g); hipFree(S.w); hipFree(S.g2); hipFree(S.w2); hipFree(S.tag); hipFree(S.tag2); hipFree(S.id);
     hipFree(S.id2); hipFree(S.best); hipFree(S.d_scan); hipFree(S.d_tbl); hipFree(S.d_rank); hipFree(S.d_cnt); }
   hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_LS); hipFree(c->d_counts); hipFree(c->d_bounds); if (c->h_pinned) hipHostFree(c->h_pinned); hipFree(c->d_energy);
@@ -575,6 +580,12 @@ int mpmhip_set_stream(mpmhip_ctx *c, void *s) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->stream = s ? (hipStream_t)s : c->own_stream;
+  return MPMHIP_OK;
+}
+
+int mpmhip_set_dirichlet(mpmhip_ctx *c, int32_t enabled) {
+  if (!c) return MPMHIP_EINVAL;
+  c->dirichlet = enabled != 0;
   return MPMHIP_OK;
 }
 
@@ -1040,6 +1051,7 @@ static int do_p2g(mpmhip_ctx *c, int phase = 0) {
 }
 static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
   c->P.t = c->t;  // this->current_t of the substep in flight (src/mpm.cpp:532-533)
+  c->LS.dirichlet = c->dirichlet ? 1 : 0;
   const bool per_cand = mode == 0 && c->n_slots < (2 << 20);  // small per-GPU problem: latency-bound, see k_grid
   auto kern = mode == 0 ? (per_cand ? k_grid<0, true> : k_grid<0, false>)
                         : (mode == 1 ? k_grid<1, false>
@@ -2517,6 +2529,14 @@ int mpmhip2d_set_levelset(mpmhip2d_ctx *m, int32_t n0, const mpmhip_shape *shape
   };
   for (int i = 0; i < n0; i++) put(L.s[i], shapes0[i]);
   for (int i = 0; i < L.n1; i++) put(L.s1[i], shapes1[i]);
+  return MPMHIP_OK;
+}
+
+int mpmhip2d_set_dirichlet(mpmhip2d_ctx *m, int32_t enabled, float distance_left, float distance_right, float velocity_left,
+                           float velocity_right) {
+  if (!m) return MPMHIP_EINVAL;
+  m->P.dirichlet = enabled != 0;
+  m->P.dl = distance_left; m->P.dr = distance_right; m->P.vl = velocity_left; m->P.vr = velocity_right;
   return MPMHIP_OK;
 }
 

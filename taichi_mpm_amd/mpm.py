@@ -138,13 +138,12 @@ def load_obj_triangles(path):
 # config keys of MPM<dim>::initialize / substep that change the physics and are NOT implemented here: a scene that sets them to
 # anything but the inert default is refused instead of being simulated differently (key: inert value, where the reference reads it)
 UNSUPPORTED_KEYS = {
-    "rigid_body_levelset_collision": (False, "src/mpm.cpp:535-538"), "dirichlet_boundary_radius": (0.0, "src/mpm.cpp:541-544"),
+    "rigid_body_levelset_collision": (False, "src/mpm.cpp:535-538"),
     "expr_leaky_levelset": (0, "src/mpm.cpp:300"), "gravity_cutting": (False, "src/mpm.cpp:347"),
     "remove_particles": (0, "src/mpm.cpp:586"), "sand_climb": (False, "src/mpm.h:281"), "sand_crawler": (False, "src/mpm.h"),
     "stork_nod": (False, "src/mpm.h"), "coupling_iterations": (1, "src/mpm.cpp:467"), "cdf_expand": (0, "src/rigid_transfer.cpp:82"),
     "energy_experiment": (False, "src/mpm.cpp:68"), "visualize_cdf": (False, "src/mpm.cpp:474"),
-    "visualize_particle_cdf": (False, "src/mpm.cpp:488"), "benchmark_rasterize": (False, "src/mpm.cpp:516"),
-    "benchmark_resample": (False, "src/mpm.cpp:554"),
+    "visualize_particle_cdf": (False, "src/mpm.cpp:488"),
 }
 
 
@@ -193,6 +192,8 @@ class Simulation3D:
         self.rpic_damping = float(cfg.get("rpic_damping", 0.0))
         self.clean_boundary = bool(cfg.get("clean_boundary", True))
         self.particle_collision = bool(cfg.get("particle_collision", False))  # src/mpm.cpp:566-569
+        self.dirichlet = float(cfg.get("dirichlet_boundary_radius", 0.0)) > 0.0   # src/mpm.cpp:541-544 -> :401-412 (3D: y > 0.525 at rest)
+        self._bench_keys = tuple(k for k in ("rasterize", "resample") if cfg.get("benchmark_" + k, False))  # src/mpm.cpp:516-523, 554-561
         self.reorder_interval = int(cfg.get("reorder_interval", 1000))  # src/mpm.cpp:45
         # apic_b is only ever consumed through the P2G affine matrix A, which is stored; keeping a separate copy
         # costs 48 of the 180 bytes G2P writes per particle.  keep_apic_b=True stores it (exact downloads of B);
@@ -236,6 +237,7 @@ class Simulation3D:
         self._ctx, self._cfg, self._capacity = ctx, c, int(capacity)
         self._check(self._L.mpmhip_set_rigid_coupling(self._ctx, self.penalty, self.pushing_force))
         self._check(self._L.mpmhip_set_articulation_iterations(self._ctx, self.articulation_iterations))
+        self._check(self._L.mpmhip_set_dirichlet(self._ctx, int(self.dirichlet)))
         self._apply_levelset()
         for mat, params in self._groups:
             self._check(self._L.mpmhip_add_group(self._ctx, mat, params.ctypes.data_as(C.POINTER(C.c_float))))
@@ -530,15 +532,54 @@ class Simulation3D:
             e, self._script_error = self._script_error, None
             raise MPMError("a scripted_position / scripted_rotation callback raised %r" % (e,)) from e
 
+    # --- the reference's own performance harness (src/mpm.cpp:516-523, 554-561): with the config key benchmark_rasterize /
+    # benchmark_resample the substep never returns — `while (true) { Timer("Rasterize x 20"); base_delta_t = 0; 20 x
+    # rasterize_optimized }`.  Here ONE bounded round: the kernel launched `rounds` times on the current state with dt = 0,
+    # bracketed by device events, reported like the reference's timer plus the ns per particle its TC_PROFILE_TPE prints;
+    # the state is restored afterwards and the run goes on (config keys: before the first substep).
+    def _benchmark(self, what, rounds):
+        self._ensure_ctx()
+        n = self.get_num_particles()
+        snap = np.empty(int(self._check(self._L.mpmhip_snapshot_size(self._ctx))), np.uint8)
+        self._check(self._L.mpmhip_snapshot_save(self._ctx, snap.ctypes.data_as(C.c_void_p), len(snap)))
+        prof = self.profile()
+        self.set_profiling(3 if what == "rasterize" else 2)
+        self.profile(reset=True)
+        self._check(self._L.mpmhip_set_dt(self._ctx, C.c_float(0.0)))  # base_delta_t = 0: nothing moves
+        self._check(self._L.mpmhip_run_substeps(self._ctx, int(rounds)))
+        ms = self.profile(reset=True)["phases"]["p2g" if what == "rasterize" else "g2p"]
+        self.set_profiling(0)
+        self._check(self._L.mpmhip_set_dt(self._ctx, C.c_float(self.base_delta_t)))
+        self._check(self._L.mpmhip_snapshot_load(self._ctx, snap.ctypes.data_as(C.c_void_p), len(snap)))
+        del prof
+        out = {"name": "%s x %d" % ("Rasterize" if what == "rasterize" else "Resample", rounds), "ms": ms, "particles": n,
+               "ns_per_particle": 1e6 * ms / max(n * rounds, 1)}
+        print("%s: %.3f ms (%.3f ns per particle per launch, %d particles)" % (out["name"], ms, out["ns_per_particle"], n))
+        return out
+
+    def benchmark_rasterize(self, rounds=20):
+        return self._benchmark("rasterize", rounds)
+
+    def benchmark_resample(self, rounds=20):
+        return self._benchmark("resample", rounds)
+
+    def _pending_benchmarks(self):
+        if self._bench_keys:
+            keys, self._bench_keys = self._bench_keys, ()
+            for k in keys:
+                self._benchmark(k, 20)
+
     def step(self, dt):
         """MPM<dim>::step, src/mpm.cpp:428-439: dt<0 => exactly one substep."""
         self._ensure_ctx()
+        self._pending_benchmarks()
         rc = self._L.mpmhip_step(self._ctx, float(dt))
         self._check_script()
         self._check(rc)
 
     def substep(self):
         self._ensure_ctx()
+        self._pending_benchmarks()
         rc = self._L.mpmhip_substep(self._ctx)
         self._check_script()
         self._check(rc)

@@ -36,6 +36,9 @@ class Simulation2D:
         if "delta_t" in cfg:  # src/mpm.cpp:41-42
             raise MPMError("Please use 'base_delta_t' instead of 'delta_t'")
         check_unsupported_keys(cfg)
+        for k in ("benchmark_rasterize", "benchmark_resample"):  # (the bounded timing rounds exist for the 3D transfer kernels only)
+            if cfg.get(k, False):
+                raise MPMError("config key %r (src/mpm.cpp:516-523, 554-561) is not implemented by the 2D simulation" % k)
         res = cfg["res"]
         res = (int(res),) * 2 if np.isscalar(res) else tuple(int(r) for r in res)
         if len(res) != 2:
@@ -78,6 +81,10 @@ class Simulation2D:
         self._ctx = ctx
         self._check(self._L.mpmhip2d_set_rigid_coupling(ctx, float(cfg.get("penalty", 0.0)), float(cfg.get("pushing_force", 20000.0))))
         self._check(self._L.mpmhip2d_set_articulation_iterations(ctx, int(cfg.get("articulation_iterations", 100))))  # src/mpm.h:279-280
+        d = float(cfg.get("dirichlet_boundary_radius", 0.0))  # src/mpm.cpp:541-544 -> apply_dirichlet_boundary_conditions, :374-399
+        vel = float(cfg.get("dirichlet_boundary_velocity", 0.0))
+        self._check(self._L.mpmhip2d_set_dirichlet(ctx, int(d > 0.0), float(cfg.get("dirichlet_distance_left", d)), float(cfg.get("dirichlet_distance_right", d)),
+                                                   float(cfg.get("dirichlet_boundary_left", vel)), float(cfg.get("dirichlet_boundary_right", vel))))
         self._apply_levelset()
         for gi, (mat, params, arrs) in enumerate(self._staged):
             self._add(mat, params, *arrs)

@@ -147,3 +147,63 @@ def test_generic_path_clamps_positions_into_the_domain(tm):
     assert len(out[True]) >= 1
     zs = sorted(float(p[2]) for p in out[False])
     assert all(z <= 1.0 for z in zs)
+
+
+def test_dirichlet_boundary_2d_matches_the_live_reference(tm):
+    """MPM<2>::apply_dirichlet_boundary_conditions (src/mpm.cpp:374-399, config dirichlet_boundary_radius + the left / right
+    distances and velocities): a jelly bar clamped between a wall at rest on the left and a wall pulling to the right"""
+    from oracle import refmpm as ref
+    if not ref.available():
+        pytest.skip("oracle/_ref/libmpm_ref.so did not travel to this box")
+    ref.set_threads(1)
+    from tests.golden.make_golden import mpm2d_state
+    res = 128
+    dx, dt = 1.0 / res, 1e-4
+    x, v, F, B = mpm2d_state(res, lo=(10, 50), cells=100, seed=3)
+    keep = (x[:, 1] < 0.55)
+    x, v, F, B = x[keep], v[keep], F[keep], B[keep]
+    vol = dx * dx / 4
+    gp, _ = tm.group_params("jelly", 400.0 * vol, vol)
+    keys = dict(dirichlet_boundary_radius=0.15, dirichlet_distance_right=0.2, dirichlet_boundary_left=0.0, dirichlet_boundary_right=1.5)
+    sim = tm.create_simulation2("mpm").initialize(dict(res=(res, res), delta_x=dx, base_delta_t=dt, gravity=(0, 0), **keys))
+    sim.add_particles(dict(type="jelly", positions=x, velocities=v, F=F, B=B, params=gp))
+    r = ref.Sim(res, dx, dt, dim=2, gravity=(0, 0), **keys)
+    r.add_particles("jelly", gp[0], gp[1], x, v, F, B, np.zeros(len(x), np.float32))
+    for _ in range(5):
+        sim.substep()
+    r.substep(5)
+    a, b = sim.get_particles(), r.download()
+    sim.close(); r.close()
+    assert len(a["x"]) == len(b["x"]) == len(x)
+    left, right = x[:, 0] < 0.12, x[:, 0] > 0.83   # particles whose whole stencil lies in a clamped strip
+    assert left.sum() > 100 and right.sum() > 100
+    assert np.abs(a["v"][left]).max() < 1e-6 and np.abs(a["v"][right, 0] - 1.5).max() < 1e-5   # the walls really act
+    assert np.abs(a["x"] - b["x"]).max() <= 2e-7
+    assert rel_l2(a["v"], b["v"]) <= 5e-5 and rel_l2(a["F"], b["F"]) <= 1e-4
+
+
+def test_dirichlet_boundary_3d_matches_the_live_reference(tm):
+    """MPM<3>::apply_dirichlet_boundary_conditions (src/mpm.cpp:401-412): with dirichlet_boundary_radius > 0 every grid node
+    above y = 0.525 is held at rest (the 3D form ignores the radius) — a stirred jelly block reaching across that plane"""
+    from oracle import refmpm as ref
+    if not ref.available():
+        pytest.skip("oracle/_ref/libmpm_ref.so did not travel to this box")
+    ref.set_threads(8)
+    from tests.common import lattice_cube, make_state
+    res = 64
+    dx, dt = 1.0 / res, 1e-4
+    s = make_state(lattice_cube(res, 24, 40, dx, jitter=0.2, seed=5), "jelly", dx, perturb_F=0.02, seed=6, vel_scale=2.0)
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(res,) * 3, delta_x=dx, base_delta_t=dt, dirichlet_boundary_radius=0.1))
+    sim.add_particles(dict(type="jelly", positions=s.x, velocities=s.v, F=s.F, B=s.B, aux=s.aux, params=s.gparams[0]))
+    r = ref.Sim(res, dx, dt, dirichlet_boundary_radius=0.1)
+    r.add_particles("jelly", s.gparams[0][0], s.gparams[0][1], s.x, s.v, s.F, s.B, s.aux)
+    for _ in range(4):
+        sim.substep()
+    r.substep(4)
+    a, b = sim.get_particles(), r.download()
+    sim.close(); r.close()
+    top = s.x[:, 1] > 0.525 + 2.5 * dx   # whole stencil above the plane: grid velocity zero
+    assert top.sum() > 1000 and np.abs(a["v"][top]).max() < 1e-6
+    assert (np.abs(a["v"][s.x[:, 1] < 0.45]).max(axis=1) > 0.1).any()
+    assert np.abs(a["x"] - b["x"]).max() <= 2e-7
+    assert rel_l2(a["v"], b["v"]) <= 2e-5 and rel_l2(a["F"], b["F"]) <= 2e-5

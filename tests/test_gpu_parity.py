@@ -850,3 +850,39 @@ def test_growing_the_ctx_keeps_clocks_and_results(tm, orc):
     assert np.array_equal(small["id"], big["id"]) and np.array_equal(small["gid"], big["gid"])
     assert np.abs(small["x"] - big["x"]).max() <= 1e-7 and rel_l2(small["v"], big["v"]) <= 1e-5
     assert rel_l2(small["F"], big["F"]) <= 1e-5
+
+
+def test_benchmark_rasterize_and_resample_are_bounded_rounds_that_leave_the_state_alone(tm, capsys):
+    """the reference's performance harness (src/mpm.cpp:516-523, 554-561: with benchmark_rasterize / benchmark_resample the substep
+    loops forever over `Timer("Rasterize x 20"); base_delta_t = 0; 20 x rasterize_optimized`): here one bounded round — as a
+    method, and through the config keys before the first substep — after which the run continues from the untouched state"""
+    res, dx = 64, 1.0 / 64
+    x = lattice_cube(res, 20, 44, dx, jitter=0.2, seed=3)
+    s = make_state(x, "sand", dx, perturb_F=0.02, seed=4, vel_scale=1.0)
+
+    def scene(**cfg):
+        sim = tm.create_simulation3("mpm").initialize(dict(res=(res,) * 3, delta_x=dx, base_delta_t=1e-4, **cfg))
+        sim.add_particles(dict(type="sand", positions=s.x, velocities=s.v, F=s.F, B=s.B, aux=s.aux, params=s.gparams[0]))
+        return sim
+    a, b, c = scene(), scene(), scene(benchmark_rasterize=True, benchmark_resample=True)
+    a.run_substeps(3); b.run_substeps(3)
+    t = b.get_current_time()
+    r1, r2 = b.benchmark_rasterize(), b.benchmark_resample(rounds=10)
+    assert r1["name"] == "Rasterize x 20" and r2["name"] == "Resample x 10" and r1["particles"] == s.n
+    assert 0.001 < r1["ns_per_particle"] < 50 and 0.001 < r2["ns_per_particle"] < 50
+    assert b.get_current_time() == t
+    a.run_substeps(2); b.run_substeps(2)
+    pa, pb = a.get_particles(), b.get_particles()
+    assert np.array_equal(pa["id"], pb["id"]) and np.abs(pa["x"] - pb["x"]).max() <= 1e-7 and rel_l2(pa["F"], pb["F"]) <= 1e-6
+    capsys.readouterr()
+    c.substep()   # config keys: the two rounds run once, in front of the first substep
+    out = capsys.readouterr().out
+    assert "Rasterize x 20:" in out and "Resample x 20:" in out and "ns per particle" in out
+    c.run_substeps(4)
+    pc = c.get_particles()
+    assert np.abs(pa["x"] - pc["x"]).max() <= 1e-7
+    capsys.readouterr()
+    c.substep()
+    assert capsys.readouterr().out == ""
+    for sim in (a, b, c):
+        sim.close()
