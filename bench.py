@@ -25,6 +25,9 @@ Extra objects on the line:
                 launch duration, or null when no PMC summary matches the workload.
                 `measured_copy_GBs` = a plain float4 copy kernel of the library on this box (1 GiB, best of 5, bytes
                 read + written), run after the timed region: the practical ceiling next to the nominal `peak`.
+                `p2g_plus_g2p` (inside roofline): both transfer kernels together, the quantity the 40 % target of north_star is
+                set on — algorithmic bytes of SURVEY section 8(d) (252 B per particle-step + the touched nodes) over the sum of the
+                two kernels' launch times, and the PMC traffic of both from the same committed profile.
   evolved       the same measurement (ms_per_step, phases, roofline) on the same ctx after the seeded block has
                 fallen onto the floor and EVOLVE_AFTER_IMPACT further substeps have run: uneven cells, active
                 return map.  `value` stays the lattice the reference's benchmark seeds (config.state says so);
@@ -559,6 +562,18 @@ def main():
                 "algorithmic_bytes_per_launch": per_launch[dom], "avg_launch_ms": ms[dom],
                 "launches_timed": prof["substeps"]}  # (every PROFILE_EVERY-th substep of the timed region)
         both = (per_launch["p2g"] + per_launch["g2p"]) / ((ms["p2g"] + ms["g2p"]) * 1e-3) / 1e9 / HBM_PEAK_GBS
+        # P2G + G2P together — the quantity north_star sets its 40 % target on.  Algorithmic bytes: the 252 B per particle-step
+        # of SURVEY section 8(d) (P2G reads the 100 B state, G2P reads 52 B and writes 100 B) + 16 B per touched node written and
+        # read; what the layout actually moves (G2P hands P2G a 64-byte record with the affine matrix precomputed) is `traffic`.
+        # The kernel that is not the dominant one is timed in the untimed phase pass, not in the timed region.
+        t_other, _ = pmc_traffic(traffic_tag, "k_" + ("p2g" if dom == "g2p" else "g2p")) if world == 1 else (None, None)
+        t_both = (tbytes + t_other) if (tbytes and t_other) else None
+        dur = (ms["p2g"] + ms["g2p"]) * 1e-3
+        roof["p2g_plus_g2p"] = {"kernels": ["k_p2g", "k_g2p"], "algorithmic_bytes_per_step": per_launch["p2g"] + per_launch["g2p"],
+                                "avg_ms": ms["p2g"] + ms["g2p"], "achieved": (per_launch["p2g"] + per_launch["g2p"]) / dur / 1e9,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": both,
+                                "traffic_bytes_per_step": t_both, "traffic": (t_both / dur / 1e9) if t_both else None,
+                                "traffic_source": tsrc}
         return roof, both, n_per_gpu, nodes
 
     if args.state == "evolved":  # make the evolved state the one that is measured (profiling runs)
