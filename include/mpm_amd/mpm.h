@@ -52,7 +52,7 @@ class MPM<3> {
   virtual void initialize(const Config &config) {
     if (config.has_key("delta_t")) throw std::runtime_error("Please use 'base_delta_t' instead of 'delta_t'");  // :41-42
     // physics-changing keys of the reference that this library does not implement: refused, not ignored
-    for (const char *k : {"rigid_body_levelset_collision", "gravity_cutting", "sand_climb", "sand_crawler", "stork_nod", "energy_experiment",
+    for (const char *k : {"gravity_cutting", "sand_climb", "sand_crawler", "stork_nod", "energy_experiment",
                           "visualize_cdf", "visualize_particle_cdf", "benchmark_rasterize", "benchmark_resample"})
       if (config.get(k, false)) throw std::runtime_error(std::string("config key '") + k + "' is not implemented by this library");
     if (config.get("expr_leaky_levelset", 0) != 0 || config.get("remove_particles", 0) != 0 ||
@@ -87,6 +87,7 @@ class MPM<3> {
     check(mpmhip_set_rigid_coupling(ctx_, config.get("penalty", 0.0f), config.get("pushing_force", 20000.0f)), ctx_);
     check(mpmhip_set_articulation_iterations(ctx_, config.get("articulation_iterations", 100)), ctx_);  // src/mpm.h:279-280
     check(mpmhip_set_dirichlet(ctx_, dirichlet_ ? 1 : 0), ctx_);
+    check(mpmhip_set_rigid_levelset_collision(ctx_, config.get("rigid_body_levelset_collision", false) ? 1 : 0), ctx_);  // src/mpm.cpp:535-538
     frame = 0;
     frame_count = 0;
   }

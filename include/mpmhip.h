@@ -135,6 +135,12 @@ typedef struct {
   float p[6];
 } mpmhip_shape;
 int mpmhip_set_levelset_shapes(mpmhip_ctx *ctx, int32_t n, const mpmhip_shape *shapes, float friction);
+/* MPM<dim>::rigid_body_levelset_collision (src/mpm_rigid_body.cpp:347-387; config key rigid_body_levelset_collision, run between
+ * normalize_grid and the grid boundary condition, src/mpm.cpp:535-538): every boundary particle of a rigid body below the level
+ * set gives its body a normal impulse (restitution) and a Coulomb friction impulse (friction0) at once, so that the next boundary
+ * particle sees the changed velocity — in the order of the reference's sorted particle list, which the library keeps for the
+ * boundary particles (sort key of src/mpm.cpp:785-790, ties by the position in the previous order). */
+int mpmhip_set_rigid_levelset_collision(mpmhip_ctx *ctx, int32_t enabled);
 /* MPM<3>::apply_dirichlet_boundary_conditions (src/mpm.cpp:401-412; runs behind the grid boundary condition when the config key
  * dirichlet_boundary_radius is > 0, :541-544): grid nodes with y > 0.525 are held at rest (the reference's 3D form ignores the
  * radius and hard-codes the plane) */

@@ -142,7 +142,7 @@ def build_variant(name, extra_flags):
 
 _lib = None
 
-_SYMBOLS = ["mpmhip_abi_version", "mpmhip_set_profile_sampling", "mpmhip_create", "mpmhip_destroy", "mpmhip_last_error", "mpmhip_set_stream", "mpmhip_set_levelset", "mpmhip_set_dirichlet", "mpmhip2d_set_dirichlet", "mpmhip_set_levelset_shapes", "mpmhip_set_levelset_keyframes",
+_SYMBOLS = ["mpmhip_abi_version", "mpmhip_set_profile_sampling", "mpmhip_create", "mpmhip_destroy", "mpmhip_last_error", "mpmhip_set_stream", "mpmhip_set_levelset", "mpmhip_set_rigid_levelset_collision", "mpmhip_set_dirichlet", "mpmhip2d_set_dirichlet", "mpmhip_set_levelset_shapes", "mpmhip_set_levelset_keyframes",
             "mpmhip_add_group", "mpmhip_add_particles", "mpmhip_num_particles", "mpmhip_download",
             "mpmhip_upload", "mpmhip_substep", "mpmhip_run_substeps", "mpmhip_step", "mpmhip_current_time",
             "mpmhip_synchronize", "mpmhip_sort", "mpmhip_p2g", "mpmhip_grid_update", "mpmhip_g2p",
@@ -209,6 +209,7 @@ def load():
     L.mpmhip_set_levelset.argtypes = [vp, C.c_int32, fp, C.c_float]
     L.mpmhip_set_levelset_shapes.argtypes = [vp, C.c_int32, P(Shape), C.c_float]
     L.mpmhip_set_dirichlet.argtypes = [vp, C.c_int32]
+    L.mpmhip_set_rigid_levelset_collision.argtypes = [vp, C.c_int32]
     L.mpmhip2d_set_dirichlet.argtypes = [vp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float]
     L.mpmhip_set_levelset_keyframes.argtypes = [vp, C.c_float, C.c_float, C.c_int32, P(Shape), C.c_int32, P(Shape), C.c_float]
     L.mpmhip_add_group.argtypes = [vp, C.c_int32, fp]

@@ -521,6 +521,123 @@ __global__ __launch_bounds__(64) void k_articulate(RigidBodyDev *rb, int nb, con
   }
 }
 
+// ------------------------------------------------------------------------------------------------ rigid body <-> level set
+// MPM<dim>::rigid_body_levelset_collision (src/mpm_rigid_body.cpp:347-387; config key rigid_body_levelset_collision, called
+// between normalize_grid and the grid boundary condition, src/mpm.cpp:535-538).  The reference walks its sorted particle list
+// and every boundary particle below the level set gives its body an impulse IMMEDIATELY — the next boundary particle of that body
+// sees the changed velocity (a Gauss-Seidel chain; summing the impulses of all penetrating particles instead would multiply the
+// response by their number).  Reproduced as such: the boundary particles are kept in the reference's order — its sort key
+// (SPGrid offset of the base node, src/mpm.cpp:785-790) with the position in the previous order as the tie-break, i.e. the
+// history of stable sorts the reference's list goes through — and ONE lane applies the impulses in that order; finding the
+// penetrating particles (pose, level set) is done by the whole workgroup.
+__device__ __forceinline__ uint32_t spread_every_third(uint32_t v) {
+  uint32_t r = 0;
+#pragma unroll
+  for (int b = 0; b < 10; b++) r |= ((v >> b) & 1u) << (3 * b);
+  return r;
+}
+// SparseMask::Linear_Offset(i, j, k) >> data_bits for the reference's 4 x 4 x 8-node blocks (page bits: per level z most
+// significant, then x, then y — pinned against the reference's own header in tests/test_oracle_kernel.py)
+__device__ __forceinline__ uint32_t ref_node_key(int i, int j, int k) {
+  const uint32_t blk = (spread_every_third((uint32_t)(k >> 3)) << 2) | (spread_every_third((uint32_t)(i >> 2)) << 1) |
+                       spread_every_third((uint32_t)(j >> 2));
+  return (blk << 7) | (uint32_t)((((i & 3) << 2) | (j & 3)) << 3 | (k & 7));
+}
+__device__ __forceinline__ void sample_world(const RigidBodyDev &B, const RigidSample &s, float p[3]) {
+  rot_apply(B.R, s.off, p);
+#pragma unroll
+  for (int k = 0; k < 3; k++) p[k] += B.pos[k];
+}
+__global__ __launch_bounds__(256) void k_rigid_ls_keys(Params P, const RigidBodyDev *__restrict__ rb, const RigidSample *__restrict__ smp,
+                                                       uint32_t n, const uint32_t *__restrict__ rank, unsigned long long *__restrict__ keys,
+                                                       uint32_t *__restrict__ vals) {
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    float p[3];
+    sample_world(rb[smp[s].body], smp[s], p);
+    int b[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) b[k] = max((int)(p[k] * P.idx - 0.5f), 0);  // get_grid_base_pos (src/mpm.h:252-255)
+    keys[s] = ((unsigned long long)ref_node_key(b[0], b[1], b[2]) << 32) | rank[s];
+    vals[s] = s;
+  }
+}
+struct RigidRestitution { float e[MAX_RIGID]; };
+__global__ __launch_bounds__(1024) void k_rigid_ls_collide(Params P, const LevelSetDev *__restrict__ ls, RigidBodyDev *rb, int nb,
+                                                           const RigidSample *__restrict__ smp, const uint32_t *__restrict__ sorted,
+                                                           uint32_t n, uint32_t *__restrict__ rank, RigidRestitution rest) {
+  struct Hit { int body; float r[3], g[3]; };
+  __shared__ JointBody sb[MAX_RIGID];
+  __shared__ Hit hits[1024];
+  __shared__ int wave_n[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < nb) {
+    const RigidBodyDev &B = rb[t];
+    JointBody &J = sb[t];
+    for (int k = 0; k < 3; k++) { J.pos[k] = B.pos[k]; J.vel[k] = B.vel[k]; J.omega[k] = B.omega[k]; }
+    for (int k = 0; k < 9; k++) { J.R[k] = B.R[k]; J.inv_I[k] = B.inv_I[k]; }
+    J.inv_mass = B.inv_mass;
+    j_to_world(J.R, J.inv_I, J.Iw);
+  }
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += 1024) {
+    const uint32_t j = base + t;
+    bool hit = false;
+    Hit h;
+    h.body = 0;
+    if (j < n) {
+      const uint32_t s = sorted[j];
+      rank[s] = j;  // the position in this substep's order is the next substep's tie-break
+      const RigidSample sm = smp[s];
+      float p[3];
+      sample_world(rb[sm.body], sm, p);
+      float phi, g[3] = {0, 0, 0};
+      if (levelset_eval(*ls, P.t, p, P.idx, phi, g) && phi < 0.0f) {
+        hit = true;
+        h.body = sm.body;
+        for (int k = 0; k < 3; k++) { h.r[k] = p[k] - rb[sm.body].pos[k]; h.g[k] = g[k]; }
+      }
+    }
+    // ordered compaction of the hits of this batch
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wave_n[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0, total = 0;
+    for (int w = 0; w < 16; w++) { if (w < wave) off += wave_n[w]; total += wave_n[w]; }
+    if (hit) hits[off + __popcll(m & ((1ull << lane) - 1ull))] = h;
+    __syncthreads();
+    if (t == 0) {
+      for (int e = 0; e < total; e++) {
+        const Hit &H = hits[e];
+        JointBody &B = sb[H.body];
+        float v10[3];
+        j_velocity_at(B, H.r, v10);
+        const float v0 = j_dot(H.g, v10);
+        const float den = j_impulse_contribution(B, H.r, H.g);
+        const float J = -((1.0f + rest.e[H.body]) * v0) * (1.0f / den);
+        if (!(J >= 0.0f)) continue;  // (J < 0: separating; a body of infinite mass and inertia gives 0 / 0)
+        const float imp[3] = {J * H.g[0], J * H.g[1], J * H.g[2]};
+        j_apply_impulse(B, imp, H.r);
+        j_velocity_at(B, H.r, v10);
+        const float vn = j_dot(H.g, v10);
+        float tao[3] = {v10[0] - H.g[0] * vn, v10[1] - H.g[1] * vn, v10[2] - H.g[2] * vn};
+        if (fmaxf(fabsf(tao[0]), fmaxf(fabsf(tao[1]), fabsf(tao[2]))) > 1e-7f) {
+          const float il = 1.0f / sqrtf(j_dot(tao, tao));
+          for (int k = 0; k < 3; k++) tao[k] *= il;
+          const float fr = rb[H.body].fric[0];
+          float jj = -j_dot(v10, tao) / j_impulse_contribution(B, H.r, tao);
+          jj = fminf(fmaxf(jj, fr * -J), fr * J);
+          const float fi[3] = {jj * tao[0], jj * tao[1], jj * tao[2]};
+          j_apply_impulse(B, fi, H.r);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (t >= 1 && t < nb) {
+    for (int k = 0; k < 3; k++) { rb[t].vel[k] = sb[t].vel[k]; rb[t].omega[k] = sb[t].omega[k]; }
+  }
+}
+
 __global__ void k_rigid_apply_tmp(RigidBodyDev *rb, int nb) {
   const int b = threadIdx.x;
   if (b < 1 || b >= nb) return;

@@ -60,6 +60,7 @@
 #include <string>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>  // one plain device sort (the reference's order of the rigid boundary particles, rigid_api.h)
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only (tiled_api.h): librccl is dlopen'ed, this library does not link it
 
@@ -231,6 +232,13 @@ struct mpmhip_ctx {
     uint32_t gather_epoch = 0;  // stamps the boundary records of the particles the last gather_cdf visited
     size_t rpage_words = 0;
     float penalty = 0.0f, pushing_force = 20000.0f;  // MPM::initialize defaults, src/mpm.cpp:35,40
+    bool ls_collision = false;       // config key rigid_body_levelset_collision (src/mpm.cpp:535-538)
+    uint32_t *d_smp_rank = nullptr;  // position of every boundary particle in the reference's sorted particle list (among the boundary particles)
+    uint32_t n_ranked = 0, ls_cap = 0;
+    unsigned long long *d_ls_keys[2] = {nullptr, nullptr};
+    uint32_t *d_ls_vals[2] = {nullptr, nullptr};
+    void *d_ls_tmp = nullptr;
+    size_t ls_tmp_bytes = 0;
     std::vector<JointDev> joints;    // MPM::articulations, in the order they were added
     JointDev *d_joints = nullptr;
     int joint_iterations = 100;      // 'articulation_iterations' (src/mpm.h:279-280)
@@ -569,7 +577,8 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   hipFree(c->cnt); hipFree(c->d_groups); hipFree(c->d_boxes); hipFree(c->d_LS); hipFree(c->d_counts); hipFree(c->d_bounds); if (c->h_pinned) hipHostFree(c->h_pinned); hipFree(c->d_energy);
   { auto &R = c->rigid; hipFree(R.d_rb); hipFree(R.d_smp); hipFree(R.d_elems); hipFree(R.cdf.slot); hipFree(R.cdf.page_key); hipFree(R.cdf.mind);
     hipFree(R.cdf.tags); hipFree(R.cdf.rpage); hipFree(R.d_bnd); if (R.side) { hipStreamSynchronize(R.side); hipStreamDestroy(R.side); } if (R.ev_fork) hipEventDestroy(R.ev_fork); if (R.ev_join) hipEventDestroy(R.ev_join);
-    hipFree(R.d_blk_rigid); hipFree(R.d_rigid_list); hipFree(R.d_counters); hipFree(R.d_joints); }
+    hipFree(R.d_blk_rigid); hipFree(R.d_rigid_list); hipFree(R.d_counters); hipFree(R.d_joints);
+    hipFree(R.d_smp_rank); hipFree(R.d_ls_keys[0]); hipFree(R.d_ls_keys[1]); hipFree(R.d_ls_vals[0]); hipFree(R.d_ls_vals[1]); hipFree(R.d_ls_tmp); }
   tn_free(c);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
@@ -1299,6 +1308,7 @@ int mpmhip_substep_end(mpmhip_ctx *c) {  // grid (+ halo sum), G2P
   c->cur_ev = nullptr;
   c->in_substep = false;
   const int lvl = c->profiling, ph = c->ov_active ? 1 : 0;
+  if (rigid_active(c) && c->rigid.ls_collision && (rc = do_rigid_ls_collision(c))) return rc;  // src/mpm.cpp:535-538
   if (ev && lvl == 1) HIPCHK(c, hipEventRecord(ev->e[3], c->stream));
   if (ev && lvl == 4) HIPCHK(c, hipEventRecord(ev->e[4], c->stream));
   if ((rc = do_grid(c, 0, ph))) return rc;

@@ -179,6 +179,44 @@ static int do_rigid_apply_tmp(mpmhip_ctx *c) {
   hipLaunchKernelGGL(k_rigid_apply_tmp, dim3(1), dim3(64), 0, c->stream, c->rigid.d_rb, (int)c->rigid.bodies.size());
   return launch_check(c, "rigid apply_tmp_velocity");
 }
+// MPM<dim>::rigid_body_levelset_collision (src/mpm_rigid_body.cpp:347-387): the boundary particles in the reference's order
+// (k_rigid.h), then the sequential impulse chain
+static int do_rigid_ls_collision(mpmhip_ctx *c) {
+  auto &R = c->rigid;
+  const uint32_t n = R.n_smp;
+  if (n == 0 || c->LS.n == 0) return MPMHIP_OK;
+  if (R.ls_cap < n) {
+    for (int k = 0; k < 2; k++) { (void)hipFree(R.d_ls_keys[k]); (void)hipFree(R.d_ls_vals[k]); R.d_ls_keys[k] = nullptr; R.d_ls_vals[k] = nullptr; }
+    (void)hipFree(R.d_ls_tmp); R.d_ls_tmp = nullptr; R.ls_tmp_bytes = 0;
+    const size_t cap = (size_t)n + n / 4 + 1024;
+    for (int k = 0; k < 2; k++) { HIPCHK(c, dmalloc(&R.d_ls_keys[k], cap)); HIPCHK(c, dmalloc(&R.d_ls_vals[k], cap)); }
+    size_t bytes = 0;
+    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, R.d_ls_keys[0], R.d_ls_keys[1], R.d_ls_vals[0], R.d_ls_vals[1], (int)cap, 0, 64, c->stream));
+    HIPCHK(c, hipMalloc(&R.d_ls_tmp, bytes));
+    R.ls_tmp_bytes = bytes;
+    R.ls_cap = (uint32_t)cap;
+  }
+  if (R.n_ranked < n) {  // boundary particles added since: behind everybody else, in creation order (appended to `particles`)
+    std::vector<uint32_t> rk(n);
+    if (R.n_ranked) HIPCHK(c, hipMemcpy(rk.data(), R.d_smp_rank, sizeof(uint32_t) * R.n_ranked, hipMemcpyDeviceToHost));
+    for (uint32_t s = R.n_ranked; s < n; s++) rk[s] = s;
+    (void)hipFree(R.d_smp_rank); R.d_smp_rank = nullptr;
+    HIPCHK(c, dmalloc(&R.d_smp_rank, (size_t)n + n / 4 + 1024));
+    HIPCHK(c, hipMemcpy(R.d_smp_rank, rk.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    R.n_ranked = n;
+  }
+  c->P.t = c->t;
+  hipLaunchKernelGGL(k_rigid_ls_keys, dim3(particle_grid(n)), dim3(256), 0, c->stream, c->P, (const RigidBodyDev *)R.d_rb,
+                     (const RigidSample *)R.d_smp, n, (const uint32_t *)R.d_smp_rank, R.d_ls_keys[0], R.d_ls_vals[0]);
+  size_t bytes = R.ls_tmp_bytes;
+  HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(R.d_ls_tmp, bytes, R.d_ls_keys[0], R.d_ls_keys[1], R.d_ls_vals[0], R.d_ls_vals[1], (int)n, 0, 64, c->stream));
+  RigidRestitution rest;
+  memset(&rest, 0, sizeof rest);
+  for (size_t b = 1; b < R.bodies.size(); b++) rest.e[b] = R.bodies[b].cfg.restitution;
+  hipLaunchKernelGGL(k_rigid_ls_collide, dim3(1), dim3(1024), 0, c->stream, c->P, (const LevelSetDev *)c->d_LS, R.d_rb, (int)R.bodies.size(),
+                     (const RigidSample *)R.d_smp, (const uint32_t *)R.d_ls_vals[1], n, R.d_smp_rank, rest);
+  return launch_check(c, "rigid_body_levelset_collision");
+}
 // advect_rigid_bodies(dt) at current_t = c->t: scripts are evaluated here, on the host, for this one substep
 static int do_rigid_advect(mpmhip_ctx *c, float dt) {
   auto &R = c->rigid;
@@ -226,6 +264,12 @@ static int do_rigid_pre_a(mpmhip_ctx *c, hipStream_t on) {
 static int do_rigid_pre_b(mpmhip_ctx *c) {
   int rc;
   if ((rc = do_rigid_gather(c)) || (rc = do_rigid_block_flags(c))) return rc;
+  return MPMHIP_OK;
+}
+
+int mpmhip_set_rigid_levelset_collision(mpmhip_ctx *c, int32_t enabled) {
+  if (!c) return MPMHIP_EINVAL;
+  c->rigid.ls_collision = enabled != 0;
   return MPMHIP_OK;
 }
 

@@ -138,7 +138,7 @@ def load_obj_triangles(path):
 # config keys of MPM<dim>::initialize / substep that change the physics and are NOT implemented here: a scene that sets them to
 # anything but the inert default is refused instead of being simulated differently (key: inert value, where the reference reads it)
 UNSUPPORTED_KEYS = {
-    "rigid_body_levelset_collision": (False, "src/mpm.cpp:535-538"),
+
     "expr_leaky_levelset": (0, "src/mpm.cpp:300"), "gravity_cutting": (False, "src/mpm.cpp:347"),
     "remove_particles": (0, "src/mpm.cpp:586"), "sand_climb": (False, "src/mpm.h:281"), "sand_crawler": (False, "src/mpm.h"),
     "stork_nod": (False, "src/mpm.h"), "coupling_iterations": (1, "src/mpm.cpp:467"), "cdf_expand": (0, "src/rigid_transfer.cpp:82"),
@@ -192,6 +192,7 @@ class Simulation3D:
         self.rpic_damping = float(cfg.get("rpic_damping", 0.0))
         self.clean_boundary = bool(cfg.get("clean_boundary", True))
         self.particle_collision = bool(cfg.get("particle_collision", False))  # src/mpm.cpp:566-569
+        self.rigid_body_levelset_collision = bool(cfg.get("rigid_body_levelset_collision", False))  # src/mpm.cpp:535-538
         self.dirichlet = float(cfg.get("dirichlet_boundary_radius", 0.0)) > 0.0   # src/mpm.cpp:541-544 -> :401-412 (3D: y > 0.525 at rest)
         self._bench_keys = tuple(k for k in ("rasterize", "resample") if cfg.get("benchmark_" + k, False))  # src/mpm.cpp:516-523, 554-561
         self.reorder_interval = int(cfg.get("reorder_interval", 1000))  # src/mpm.cpp:45
@@ -238,6 +239,7 @@ class Simulation3D:
         self._check(self._L.mpmhip_set_rigid_coupling(self._ctx, self.penalty, self.pushing_force))
         self._check(self._L.mpmhip_set_articulation_iterations(self._ctx, self.articulation_iterations))
         self._check(self._L.mpmhip_set_dirichlet(self._ctx, int(self.dirichlet)))
+        self._check(self._L.mpmhip_set_rigid_levelset_collision(self._ctx, int(self.rigid_body_levelset_collision)))
         self._apply_levelset()
         for mat, params in self._groups:
             self._check(self._L.mpmhip_add_group(self._ctx, mat, params.ctypes.data_as(C.POINTER(C.c_float))))

@@ -36,9 +36,9 @@ class Simulation2D:
         if "delta_t" in cfg:  # src/mpm.cpp:41-42
             raise MPMError("Please use 'base_delta_t' instead of 'delta_t'")
         check_unsupported_keys(cfg)
-        for k in ("benchmark_rasterize", "benchmark_resample"):  # (the bounded timing rounds exist for the 3D transfer kernels only)
+        for k in ("benchmark_rasterize", "benchmark_resample", "rigid_body_levelset_collision"):  # (built for the 3D simulation only)
             if cfg.get(k, False):
-                raise MPMError("config key %r (src/mpm.cpp:516-523, 554-561) is not implemented by the 2D simulation" % k)
+                raise MPMError("config key %r (src/mpm.cpp:516-538, 554-561) is not implemented by the 2D simulation" % k)
         res = cfg["res"]
         res = (int(res),) * 2 if np.isscalar(res) else tuple(int(r) for r in res)
         if len(res) != 2:

@@ -715,3 +715,48 @@ def test_one_stream_and_two_streams_give_the_same_run(tm, monkeypatch):
     assert (a["states"] != b["states"]).sum() <= 5
     np.testing.assert_allclose(sa["velocity"], sb["velocity"], atol=2e-5)
     np.testing.assert_allclose(sa["position"], sb["position"], atol=1e-6)
+
+
+@pytest.mark.parametrize("friction,restitution", [(0.0, 0.0), (0.4, 0.5)])
+def test_rigid_body_levelset_collision_matches_the_live_reference(tm, friction, restitution):
+    """config rigid_body_levelset_collision (src/mpm.cpp:535-538 -> MPM::rigid_body_levelset_collision, src/mpm_rigid_body.cpp:347-387):
+    a tilted, spinning free box thrown at a floor plane and a side wall.  Every penetrating boundary particle hands its body an
+    impulse at once, in the order of the reference's sorted particle list — which the device keeps for the boundary particles —
+    so body state and particles follow the reference through the contact, bounce included."""
+    from oracle import refmpm
+    if not refmpm.available():
+        pytest.skip("oracle/_ref/libmpm_ref.so did not travel to this box")
+    from oracle import oracle as orc
+    refmpm.set_threads(1)
+    x, v = cs.block_of_particles(lo=12, hi=18)
+    x = x + np.float32([0.0, 0.20, 0.0])   # a small jelly block above the box (so that material particles exist)
+    gp = orc.group_params("jelly", cs.MASS, cs.VOL)[0]
+    body = dict(codimensional=False, density=300.0, friction=friction, restitution=restitution, initial_position=(0.5, 0.47, 0.5),
+                initial_rotation=(12.0, 20.0, 31.0), initial_velocity=(0.6, -1.5, 0.3), initial_angular_velocity=(2.0, -1.0, 3.0))
+    shapes = [(0, 0, 0, 1, 0, -0.3), (0, 0, -1, 0, 0, 0.66)]   # floor y = 0.3, wall x = 0.66 (phi = 0.66 - x)
+    keys = dict(rigid_body_levelset_collision=True)
+    ref = refmpm.Sim(cs.RES, cs.DX, cs.DT, gravity=(0, -10, 0), shapes=shapes, friction=0.3, **keys)
+    rid = ref.add_rigid(cs.box(), **body)
+    ref.add_particles("jelly", cs.MASS, cs.VOL, x, v)
+    sim = tm.create_simulation3("mpm").initialize(dict(res=(cs.RES,) * 3, delta_x=cs.DX, base_delta_t=cs.DT, gravity=(0, -10, 0),
+                                                       max_particles=len(x) + 16, **keys))
+    ls = tm.mpm.LevelSet(friction=0.3).add_plane((0, 1, 0), d=-0.3).add_plane((-1, 0, 0), d=0.66)
+    sim.set_levelset(ls)
+    assert int(sim.add_particles(dict(type="rigid", mesh=cs.box(), **body))) == rid
+    sim.add_particles(dict(type="jelly", positions=x, velocities=v, params=gp))
+    vy, hit = [], False
+    for k in range(12):
+        ref.substep(25)
+        sim.run_substeps(25)
+        a, b = cs.rigid_vector(ref.rigid_state(rid)), cs.rigid_vector(sim.get_rigid_state(rid))
+        vy.append(a[8])
+        np.testing.assert_allclose(b[0:7], a[0:7], rtol=0, atol=5e-5, err_msg="pose after %d substeps" % (25 * (k + 1)))
+        np.testing.assert_allclose(b[7:13], a[7:13], rtol=0, atol=2e-3 * max(np.abs(a[7:13]).max(), 1.0))
+    assert min(vy) < -1.55 and vy[-1] > min(vy) + 0.5, vy   # the box fell, hit the floor and was stopped / thrown back
+    free = refmpm.Sim(cs.RES, cs.DX, cs.DT, gravity=(0, -10, 0), shapes=shapes, friction=0.3)  # the same scene WITHOUT the key
+    rf = free.add_rigid(cs.box(), **body)
+    free.add_particles("jelly", cs.MASS, cs.VOL, x, v)
+    free.substep(300)
+    assert cs.rigid_vector(free.rigid_state(rf))[8] < a[8] - 0.3     # ... keeps falling through the floor: the key is what stops the box
+    r, h = ref.download(by_id=True), sim.get_particles(sort_by_id=True)
+    assert np.abs(h["x"] - r["x"]).max() <= 2e-5 and rel_l2(h["v"], r["v"]) <= 1e-3

@@ -77,11 +77,13 @@ def test_obj_loader_fans_polygons_and_handles_negative_indices(tmp_path):
 
 
 def test_physics_changing_keys_that_are_not_implemented_are_refused():
-    for cfg in (dict(rigid_body_levelset_collision=True), dict(coupling_iterations=2), dict(gravity_cutting=True)):
+    for cfg in (dict(coupling_iterations=2), dict(gravity_cutting=True), dict(expr_leaky_levelset=1)):
         with pytest.raises(tm.MPMError, match="not implemented"):
             tm.create_simulation3("mpm").initialize(dict(res=(32, 32, 32), **cfg))
     with pytest.raises(tm.MPMError, match="not implemented"):
         tm.create_simulation2("mpm").initialize(dict(res=(32, 32), cdf_expand=2))
+    with pytest.raises(tm.MPMError, match="not implemented by the 2D"):
+        tm.create_simulation2("mpm").initialize(dict(res=(32, 32), rigid_body_levelset_collision=True))
     tm.create_simulation3("mpm").initialize(dict(res=(32, 32, 32), rigid_body_levelset_collision=False, coupling_iterations=1))  # inert values pass
     assert tm.create_simulation3("mpm").initialize(dict(res=(32, 32, 32), dirichlet_boundary_radius=0.1)).dirichlet  # (implemented: src/mpm.cpp:401-412)
 

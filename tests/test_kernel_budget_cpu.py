@@ -59,6 +59,8 @@ def test_tuned_kernels_stay_inside_their_budget(stats, prefix):
 
 def test_no_kernel_of_the_library_uses_scratch_unnoticed(stats):
     """every kernel that spills is listed here on purpose (none of them is on the per-substep path of a scene without bodies)"""
-    allowed = ("k_p2g_rigid", "k_g2p_rigid")  # the CPIC transfers (colour test per node on top of the full kernels)
+    # the CPIC transfers (colour test per node on top of the full kernels); rocprim = the one library sort (order of the rigid boundary
+    # particles for rigid_body_levelset_collision, rigid_api.h — off the substep path of every scene that does not set that key)
+    allowed = ("k_p2g_rigid", "k_g2p_rigid", "rocprim")
     bad = [k for k, v in stats.items() if v.get("scratch_bytes", 0) > 0 and not any(a in k for a in allowed)]
     assert not bad, bad
