@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_build_keys(Params P, RecG *__restrict__
 // chunk as ONE 64-bit word {epoch, value} (agent-scope atomic: the 8 XCDs' L2s are not coherent for plain
 // accesses; the word is self-contained, so relaxed ordering suffices), sums the words of the chunks before it
 // (spinning until their epoch matches) and finishes its chunk.  A chunk publishes BEFORE it waits, and the host
-// launches no more workgroups than the device keeps resident at once (scan_grid() in mpmhip.hip, a quarter of the
+// launches no more workgroups than the device keeps resident at once (scan_grid in mpmhip.hip, three eighths of the
 // occupancy limit), so every chunk a workgroup waits for has been published or is being computed: no deadlock.
 // (Round 1 handed the chunks out through a ticket counter instead, which needs no co-residency: ~800 returning
 // atomics on ONE address per launch, 6 us of the sort at 8 M particles and 5 us at 1 M.)  The epoch changes with

@@ -112,7 +112,7 @@ struct mpmhip_ctx {
   uint32_t *cell_cnt = nullptr, *cell_start = nullptr, *fat_slot = nullptr;
   unsigned long long *scan_slots = nullptr;  // [256] k_block_table + [ct_grid] k_cell_table: {epoch, chunk sum}
   uint32_t sort_epoch = 0, bt_slots = 0;
-  uint32_t scan_grid = 256;  // workgroups of the single-pass scan kernels: a quarter of what the device keeps resident
+  uint32_t scan_grid = 256;  // workgroups of the single-pass scan kernels: three eighths of what the device keeps resident
   float4 *tiles = nullptr, *gridv = nullptr, *dense = nullptr;
   Counters *cnt = nullptr;
   std::vector<GroupParams> groups;
@@ -551,7 +551,11 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
       A(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, 0));
       lowest = std::min(lowest, per_cu);
     }
-    c->scan_grid = (uint32_t)std::max(1, cus * lowest / 4);
+    // three eighths of what the device keeps resident (a quarter until round 4): after impact C3 has 21 k active blocks = 335 chunks of
+    // k_cell_table, and with 256 workgroups 79 of them took a second chunk behind their first — sort 98 -> 88 us, 80 -> 70 us on the
+    // lattice of the same box (profiles/r04_l_scan_grid.txt); the margin is for kernels of a second stream (CPIC) beside the scans
+    c->scan_grid = (uint32_t)std::max(1, cus * lowest * 3 / 8);
+    if (const char *e = getenv("MPMHIP_SCAN_GRID")) c->scan_grid = (uint32_t)std::max(1, std::min(atoi(e), cus * lowest / 2));  // (tuning)
   }
   A(hipDeviceSynchronize());
   if (e != hipSuccess) { fail(c, MPMHIP_EHIP, "device init failed: %s", hipGetErrorString(e)); return bail(MPMHIP_EHIP); }
