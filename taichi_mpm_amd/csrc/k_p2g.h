@@ -15,7 +15,11 @@ namespace mpm {
 // written out whole; conflicts between blocks are resolved by k_grid.  p2g_cell<N0,N1> handles stencil nodes
 // N0..N1-1 of the particles [p0,p1) of the lane's cell, so a block can be one wave (default) or several waves
 // splitting the nodes and/or the particles (k_p2g<NS,PS>).
-template <int N0, int N1, class AfterParticles>
+// MC: merge chains.  The merge below is 27 read-modify-writes of the wave's tile that must stay in program order (two offsets of two
+// lanes can name the same node): 27 x (LDS read latency + add + write) = 1.3 us of a block's ~15.  With MC = 3 every x-plane of the
+// stencil merges into its OWN tile (tile + c * TN): three independent chains of nine steps whose reads, adds and writes interleave;
+// the write-out sums the three tiles.
+template <int N0, int N1, int MC, class AfterParticles>
 __device__ __forceinline__ void p2g_cell(const Params &P, const float4 *__restrict__ rp,
                                          const uint32_t *__restrict__ perm,
                                          const GroupParams *__restrict__ groups, uint32_t p0, uint32_t p1, uint32_t i0,
@@ -112,6 +116,24 @@ __device__ __forceinline__ void p2g_cell(const Params &P, const float4 *__restri
   // read-modify-write is race-free as long as the steps stay in program order: LDS operations of one wave
   // execute in order, the wave_barrier keeps the compiler from interleaving them.  (DS float atomics cost
   // ~2 LDS cycles per LANE on gfx950 even without conflicts: measured 145 cycles per ds_add_f32.)
+  if constexpr (MC == 3 && N0 == 0 && N1 == 27) {
+#pragma unroll
+    for (int s = 0; s < 9; s++) {
+      float4 t[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) t[c] = tile[c * TN + nbase + (c * TS + s / 3) * TS + s % 3];
+      if (p1 > p0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          t[c].x += acc[c * 9 + s][0]; t[c].y += acc[c * 9 + s][1]; t[c].z += acc[c * 9 + s][2]; t[c].w += acc[c * 9 + s][3];
+          tile[c * TN + nbase + (c * TS + s / 3) * TS + s % 3] = t[c];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+    }
+    return;
+  }
 #pragma unroll
   for (int n = N0; n < N1; n++) {
     const int node = nbase + ((n / 9) * TS + (n / 3) % 3) * TS + n % 3;
@@ -143,7 +165,8 @@ __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const floa
 #endif
                                                             ) {
   constexpr int NW = NS * PS, NT = 64 * NW;
-  __shared__ float4 tile[NW][TN];  // per wave: (m*vx, m*vy, m*vz, m) per node of the block's 6^3 tile
+  constexpr int MC = (NS == 1 && PS == 1) ? 3 : 1;  // merge chains (p2g_cell): three in the one-wave form; measured -2..-4 us of 166 at C3
+  __shared__ float4 tile[NW * MC][TN];  // per wave (and merge chain): (m*vx, m*vy, m*vz, m) per node of the block's 6^3 tile
   const uint32_t na = min(cnt->n_active, P.max_blocks);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int npart = wave % NS, ppart = wave / NS;
@@ -186,21 +209,21 @@ __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const floa
 #ifdef MPMHIP_TIMING_BUILD
     const unsigned long long t_begin = wall_clock64();
 #endif
-    for (int t = threadIdx.x; t < NW * TN; t += NT) (&tile[0][0])[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int t = threadIdx.x; t < NW * MC * TN; t += NT) (&tile[0][0])[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();
     const float ox = (float)(bx * BS + cx), oy = (float)(by * BS + cy), oz = (float)(bz * BS + cz);
     auto ahead = [&]() { load_indices(nxt); };
     if constexpr (NS == 1) {
-      p2g_cell<0, 27>(P, rp, perm, groups, cur.p0, cur.p1, cur.i0, cur.i1, ox, oy, oz, nbase, tile[wave], ahead);
+      p2g_cell<0, 27, MC>(P, rp, perm, groups, cur.p0, cur.p1, cur.i0, cur.i1, ox, oy, oz, nbase, tile[wave * MC], ahead);
     } else {
-      if (npart == 0) p2g_cell<0, 14>(P, rp, perm, groups, cur.p0, cur.p1, cur.i0, cur.i1, ox, oy, oz, nbase, tile[wave], ahead);
-      else p2g_cell<14, 27>(P, rp, perm, groups, cur.p0, cur.p1, cur.i0, cur.i1, ox, oy, oz, nbase, tile[wave], ahead);
+      if (npart == 0) p2g_cell<0, 14, 1>(P, rp, perm, groups, cur.p0, cur.p1, cur.i0, cur.i1, ox, oy, oz, nbase, tile[wave], ahead);
+      else p2g_cell<14, 27, 1>(P, rp, perm, groups, cur.p0, cur.p1, cur.i0, cur.i1, ox, oy, oz, nbase, tile[wave], ahead);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < TN; t += NT) {
       float4 u = tile[0][t];
 #pragma unroll
-      for (int w = 1; w < NW; w++) {
+      for (int w = 1; w < NW * MC; w++) {
         const float4 q = tile[w][t];
         u.x += q.x; u.y += q.y; u.z += q.z; u.w += q.w;
       }
