@@ -499,6 +499,35 @@ int64_t mpmhip2d_download(mpmhip2d_ctx *ctx, int64_t capacity, float *x, float *
                           int32_t *id);            /* live particles in slot order; NULL outputs are skipped; returns n */
 int mpmhip2d_download_grid(mpmhip2d_ctx *ctx, float *grid /* [(res0+1)(res1+1)][3] = (v.x, v.y, m) */);
 
+/* ---- AsyncMPM<2> — replaces create_simulation2('async_mpm') (TC_IMPLEMENTATION(Simulation2D, AsyncMPM2D, "async_mpm"),
+ * src/async/async_mpm.cpp:423-427): the asynchronous stepper of mpmhip_async_begin / _step above for the 2D simulation
+ * object.  A scheduler block is the reference's 2D SPGrid block, 8 x 16 nodes (SPGrid_Mask<5, 5, 2>); the block scheduler
+ * (limits, neighbour lists, the action table of an advance) is the same host code as in 3D (csrc/async_sched.h); the pools
+ * and backup pools are a device-resident store of 64-byte containers (csrc/k_async2d.h), and no particle data crosses the
+ * host boundary while stepping.
+ *   _begin            initialize (:13-55); not with rigid bodies.  After it mpmhip2d_step IS the asynchronous step (the
+ *                     reference's virtual Simulation::step) and mpmhip2d_substep is refused.
+ *   _pool_particles   add_particles' tail (:62-75): the particles just added with mpmhip2d_add_particles move to the pools of
+ *                     their blocks (also done by the next _step)
+ *   _step             step (:380-421): update_dt_limits, then advance(level) for every power-of-two level due
+ *   _load_pools       AsyncMPM::visualize's particle list (src/async/async_visualize.cpp:86-96): all containers of all particle
+ *                     pools become the object's particles (mpmhip2d_download / _num_particles then see the whole state, each
+ *                     particle at its block's time; an id can occur more than once, as in the reference); returns their number.
+ *                     _view_blocks: the pool block of each, in download order.
+ *   _state            {current_t_int, update_counter, min_delta_t_int, max_delta_t_int, live containers, store size,
+ *                     compactions, steps}
+ *   _table            dense block table (block b = bx nb[1] + by): limits, pool sizes, particle_t, backup_t, local_min_dt_limit;
+ *                     capacity < number of blocks returns the number only */
+int mpmhip2d_async_begin(mpmhip2d_ctx *ctx, const mpmhip_async_config *cfg);
+int mpmhip2d_async_pool_particles(mpmhip2d_ctx *ctx);
+int mpmhip2d_async_step(mpmhip2d_ctx *ctx, float dt);
+int64_t mpmhip2d_async_load_pools(mpmhip2d_ctx *ctx);
+int64_t mpmhip2d_async_view_blocks(mpmhip2d_ctx *ctx, int64_t capacity, int32_t *block);
+int mpmhip2d_async_state(mpmhip2d_ctx *ctx, int64_t out[8]);
+double mpmhip2d_async_current_time(const mpmhip2d_ctx *ctx);
+int64_t mpmhip2d_async_table(mpmhip2d_ctx *ctx, int32_t nb[2], int64_t capacity, int64_t *strength, int64_t *cfl, int64_t *continuous,
+                             int64_t *count, int64_t *particle_t, int64_t *backup_t, int64_t *local_min);
+
 /* ---- the 2D dense-grid demo (BASELINE configs[0]) — replaces advance(dt) of mls-mpm88.cpp:16-69 (annotated twin
  * mls-mpm88-explained.cpp:64-197): (n+1)^2 grid, snow model inline (E = 1e4, nu = 0.2, hardening 10, sigma clamp
  * [0.975, 1.0075], Jp in [0.6, 20]), gravity -200 on the grid, sticky side/top walls and a separating floor at 0.05.

@@ -60,6 +60,7 @@ struct Handle {
   std::unique_ptr<MPM<2>> m2;
   std::unique_ptr<MPM<3>> m3;
   AsyncMPM<3> *async3 = nullptr;  // == m3.get() when the simulation is the "async_mpm" one
+  AsyncMPM<2> *async2 = nullptr;  // == m2.get() likewise (create_simulation2('async_mpm'))
   // scripted motions of rigid bodies: the reference receives POINTERS to std::function objects through its config
   // (src/mpm_rigid_body.cpp:79-92) and copies them
   std::vector<std::unique_ptr<RigidBody<3>::PositionFunctionType>> pos_scripts;
@@ -71,6 +72,9 @@ struct Handle {
 template <int dim> MPM<dim> &sim(Handle *h);
 template <> MPM<2> &sim<2>(Handle *h) { return *h->m2; }
 template <> MPM<3> &sim<3>(Handle *h) { return *h->m3; }
+template <int dim> AsyncMPM<dim> *async_sim(Handle *h);
+template <> AsyncMPM<2> *async_sim<2>(Handle *h) { return h->async2; }
+template <> AsyncMPM<3> *async_sim<3>(Handle *h) { return h->async3; }
 
 template <int dim>
 int add_particles(Handle *h, const Config &cfg, int64_t n, const float *x, const float *v, const float *F, const float *B,
@@ -105,14 +109,14 @@ int add_particles(Handle *h, const Config &cfg, int64_t n, const float *x, const
     if (aux) if (real *a = aux_ptr<dim>(p)) *a = aux[i];
     m.particles.push_back(alloc.first);
   }
-  if (dim == 3 && h->async3) {
+  if (async_sim<dim>(h)) {
     // the tail of AsyncMPM<dim>::add_particles (src/async/async_mpm.cpp:62-75): the new particles move from the
     // flat list into the pool of the scheduler block of their base node
-    AsyncMPM<3> &a = *h->async3;
-    using Mask = typename MPM<3>::SparseMask;
+    AsyncMPM<dim> &a = *async_sim<dim>(h);
+    using Mask = typename MPM<dim>::SparseMask;
     for (auto p : a.particles) {
-      uint64 grid_offset = Mask::Linear_Offset(a.MPM<3>::get_grid_base_pos(
-          (reinterpret_cast<MPMParticle<3> *>(&a.allocator.pool[p]))->pos * a.inv_delta_x));
+      uint64 grid_offset = Mask::Linear_Offset(a.MPM<dim>::get_grid_base_pos(
+          (reinterpret_cast<MPMParticle<dim> *>(&a.allocator.pool[p]))->pos * a.inv_delta_x));
       uint64 offset = (grid_offset >> Mask::data_bits >> Mask::block_bits) & a.scheduler_mask;
       a.particle_pool[offset].push_back(a.allocator.pool[p]);
     }
@@ -240,6 +244,81 @@ using namespace taichi;
 
 #define DISPATCH(h, expr2, expr3) ((h)->dim == 2 ? (expr2) : (expr3))
 
+// ---- AsyncMPM helpers, both dimensions (the extern "C" wrappers are below) ----
+#define ASYNC_DISPATCH(h, call) ((h)->dim == 2 ? call<2>(h) : call<3>(h))
+template <int dim>
+AsyncMPM<dim> &async_ref(Handle *h) {
+  if (!async_sim<dim>(h)) TC_ERROR("not an async_mpm simulation");
+  return *async_sim<dim>(h);
+}
+template <int dim>
+int64_t async_blocks(Handle *h, int64_t cap, int32_t *coord, int64_t *strength, int64_t *cfl, int64_t *continuous, int64_t *count, int64_t *mm) {
+  AsyncMPM<dim> &a = async_ref<dim>(h);
+  using Mask = typename MPM<dim>::SparseMask;
+  int64_t n = 0;
+  for (uint64 offset = 0; offset < a.scheduler_size; ++offset) {
+    if (a.particle_pool[offset].empty()) continue;
+    if (n >= cap) TC_ERROR("block buffer too small");
+    auto c = Mask::LinearToCoord(uint64(offset) << Mask::data_bits << Mask::block_bits);
+    for (int k = 0; k < 3; k++) coord[3 * n + k] = k < dim ? c[k] : 0;
+    strength[n] = a.blocks[offset].strength_dt_limit;
+    cfl[n] = a.blocks[offset].cfl_dt_limit;
+    continuous[n] = a.blocks[offset].continuous_dt_limit;
+    count[n] = (int64_t)a.particle_pool[offset].size();
+    n++;
+  }
+  if (mm) { mm[0] = a.min_delta_t_int; mm[1] = a.max_delta_t_int; }
+  return n;
+}
+template <int dim>
+int64_t async_download(Handle *h, int64_t cap, float *x, float *v, float *F, float *B, float *aux, int32_t *id, int64_t *limits) {
+  AsyncMPM<dim> &a = async_ref<dim>(h);
+  int64_t n = 0;
+  for (uint64 offset = 0; offset < a.scheduler_size; ++offset)
+    for (auto &container : a.particle_pool[offset]) {
+      if (n >= cap) TC_ERROR("particle buffer too small");
+      MPMParticle<dim> *p = const_cast<MPMParticle<dim> *>(reinterpret_cast<const MPMParticle<dim> *>(&container));
+      auto vel = p->get_velocity();
+      for (int k = 0; k < dim; k++) { x[dim * n + k] = p->pos[k]; v[dim * n + k] = vel[k]; }
+      if (F) mat_out<dim>(p->dg_e, F + dim * dim * n);
+      if (B) mat_out<dim>(p->apic_b, B + dim * dim * n);
+      if (aux) { real *q = aux_ptr<dim>(p); aux[n] = q ? *q : 0.0f; }
+      id[n] = p->id;
+      if (limits) {
+        limits[4 * n + 0] = a.blocks[offset].continuous_dt_limit; limits[4 * n + 1] = a.blocks[offset].strength_dt_limit;
+        limits[4 * n + 2] = a.blocks[offset].cfl_dt_limit; limits[4 * n + 3] = a.blocks[offset].particle_t;
+      }
+      n++;
+    }
+  return n;
+}
+// the scheduler's geometry: per block number (= position in the order the pools are walked in) the corner node, the
+// cached_neighbours (src/async/async_mpm.h:255-301; 26 slots, -1 terminated) and whether it is a "left_boundary" block
+template <int dim>
+int64_t async_geometry(Handle *h, int64_t cap, int32_t *coord, int32_t *neighbours, int32_t *is_boundary) {
+  AsyncMPM<dim> &a = async_ref<dim>(h);
+  using Mask = typename MPM<dim>::SparseMask;
+  if ((int64_t)a.scheduler_size > cap) return (int64_t)a.scheduler_size;
+  for (uint64 offset = 0; offset < a.scheduler_size; ++offset) {
+    auto c = Mask::LinearToCoord(uint64(offset) << Mask::data_bits << Mask::block_bits);
+    for (int k = 0; k < 3; k++) coord[3 * offset + k] = k < dim ? c[k] : 0;
+    int m = 0;
+    for (auto q : a.cached_neighbours[offset]) neighbours[26 * offset + m++] = (int32_t)q;
+    for (; m < 26; m++) neighbours[26 * offset + m] = -1;
+    is_boundary[offset] = 0;
+  }
+  for (auto b : a.boundary) is_boundary[b] = 1;
+  return (int64_t)a.scheduler_size;
+}
+template <int dim> int64_t async_num(Handle *h) {
+  if (!async_sim<dim>(h)) return -1;
+  int64_t n = 0;
+  for (uint64 offset = 0; offset < async_sim<dim>(h)->scheduler_size; ++offset) n += (int64_t)async_sim<dim>(h)->particle_pool[offset].size();
+  return n;
+}
+template <int dim> int64_t async_time_int(Handle *h) { return async_sim<dim>(h) ? (int64_t)async_sim<dim>(h)->current_t_int : -1; }
+template <int dim> int64_t async_update_counter(Handle *h) { return async_sim<dim>(h) ? (int64_t)async_sim<dim>(h)->update_counter : -1; }
+
 extern "C" {
 
 const char *ref_last_error() { return g_err.c_str(); }
@@ -257,7 +336,13 @@ void *ref_create(int dim, const char *cfg) {
     h->dim = dim;
     Config c = Config::from_string(cfg);
     if (!c.has_key("num_threads")) c.set("num_threads", ShimRuntime::get().threads);
-    if (dim == 2) { h->m2 = std::make_unique<MPM<2>>(); h->m2->initialize(c); set_levelset<2>(h, 0, nullptr, -1, nullptr, 0, 1, 1.0f); }
+    if (dim == 2 && c.get("async", false)) {  // create_simulation2('async_mpm'), src/async/async_mpm.cpp:423-427
+      h->async2 = new AsyncMPM<2>();
+      h->m2.reset(h->async2);
+      h->m2->initialize(c);
+      set_levelset<2>(h, 0, nullptr, -1, nullptr, 0, 1, 1.0f);
+    }
+    else if (dim == 2) { h->m2 = std::make_unique<MPM<2>>(); h->m2->initialize(c); set_levelset<2>(h, 0, nullptr, -1, nullptr, 0, 1, 1.0f); }
     else if (dim == 3 && c.get("async", false)) {  // create_simulation3('async_mpm'), src/async/async_mpm.cpp:423-427
       h->async3 = new AsyncMPM<3>();
       h->m3.reset(h->async3);
@@ -366,10 +451,10 @@ int ref_general_action(void *hh, const char *cfg, char *out, size_t cap) {
   });
 }
 
-// ---- AsyncMPM (src/async/async_mpm.{h,cpp}) ----------------------------------------------------------------------
+// ---- AsyncMPM (src/async/async_mpm.{h,cpp}), both dimensions ------------------------------------------------------------
 int ref_async_update_dt_limits(void *hh) {
   Handle *h = (Handle *)hh;
-  return guarded([&] { if (!h->async3) TC_ERROR("not an async_mpm simulation"); h->async3->update_dt_limits(); return 0; });
+  return guarded([&] { if (h->dim == 2) async_ref<2>(h).update_dt_limits(); else async_ref<3>(h).update_dt_limits(); return 0; });
 }
 // non-empty scheduler blocks after update_dt_limits(): node coordinates of the block's corner + its three limits +
 // the number of particles in its pool.  Returns the number of blocks (-1 on error); min / max_delta_t_int in mm[2].
@@ -378,21 +463,7 @@ int64_t ref_async_blocks(void *hh, int64_t cap, int32_t *coord, int64_t *strengt
   Handle *h = (Handle *)hh;
   int64_t n = 0;
   const int rc = guarded([&] {
-    if (!h->async3) TC_ERROR("not an async_mpm simulation");
-    AsyncMPM<3> &a = *h->async3;
-    using Mask = typename MPM<3>::SparseMask;
-    for (uint64 offset = 0; offset < a.scheduler_size; ++offset) {
-      if (a.particle_pool[offset].empty()) continue;
-      if (n >= cap) TC_ERROR("block buffer too small");
-      auto c = Mask::LinearToCoord(uint64(offset) << Mask::data_bits << Mask::block_bits);
-      for (int k = 0; k < 3; k++) coord[3 * n + k] = c[k];
-      strength[n] = a.blocks[offset].strength_dt_limit;
-      cfl[n] = a.blocks[offset].cfl_dt_limit;
-      continuous[n] = a.blocks[offset].continuous_dt_limit;
-      count[n] = (int64_t)a.particle_pool[offset].size();
-      n++;
-    }
-    if (mm) { mm[0] = a.min_delta_t_int; mm[1] = a.max_delta_t_int; }
+    n = h->dim == 2 ? async_blocks<2>(h, cap, coord, strength, cfl, continuous, count, mm) : async_blocks<3>(h, cap, coord, strength, cfl, continuous, count, mm);
     return 0;
   });
   return rc ? -1 : n;
@@ -402,37 +473,23 @@ int64_t ref_async_download(void *hh, int64_t cap, float *x, float *v, float *F, 
   Handle *h = (Handle *)hh;
   int64_t n = 0;
   const int rc = guarded([&] {
-    if (!h->async3) TC_ERROR("not an async_mpm simulation");
-    AsyncMPM<3> &a = *h->async3;
-    for (uint64 offset = 0; offset < a.scheduler_size; ++offset)
-      for (auto &container : a.particle_pool[offset]) {
-        if (n >= cap) TC_ERROR("particle buffer too small");
-        MPMParticle<3> *p = const_cast<MPMParticle<3> *>(reinterpret_cast<const MPMParticle<3> *>(&container));
-        auto vel = p->get_velocity();
-        for (int k = 0; k < 3; k++) { x[3 * n + k] = p->pos[k]; v[3 * n + k] = vel[k]; }
-        if (F) mat_out<3>(p->dg_e, F + 9 * n);
-        if (B) mat_out<3>(p->apic_b, B + 9 * n);
-        if (aux) { real *q = aux_ptr<3>(p); aux[n] = q ? *q : 0.0f; }
-        id[n] = p->id;
-        if (limits) {
-          limits[4 * n + 0] = a.blocks[offset].continuous_dt_limit; limits[4 * n + 1] = a.blocks[offset].strength_dt_limit;
-          limits[4 * n + 2] = a.blocks[offset].cfl_dt_limit; limits[4 * n + 3] = a.blocks[offset].particle_t;
-        }
-        n++;
-      }
+    n = h->dim == 2 ? async_download<2>(h, cap, x, v, F, B, aux, id, limits) : async_download<3>(h, cap, x, v, F, B, aux, id, limits);
     return 0;
   });
   return rc ? -1 : n;
 }
-int64_t ref_async_num_particles(void *hh) {
+int64_t ref_async_geometry(void *hh, int64_t cap, int32_t *coord, int32_t *neighbours, int32_t *is_boundary) {
   Handle *h = (Handle *)hh;
-  if (!h->async3) return -1;
   int64_t n = 0;
-  for (uint64 offset = 0; offset < h->async3->scheduler_size; ++offset) n += (int64_t)h->async3->particle_pool[offset].size();
-  return n;
+  const int rc = guarded([&] {
+    n = h->dim == 2 ? async_geometry<2>(h, cap, coord, neighbours, is_boundary) : async_geometry<3>(h, cap, coord, neighbours, is_boundary);
+    return 0;
+  });
+  return rc ? -1 : n;
 }
-int64_t ref_async_time_int(void *hh) { Handle *h = (Handle *)hh; return h->async3 ? h->async3->current_t_int : -1; }
-int64_t ref_async_update_counter(void *hh) { Handle *h = (Handle *)hh; return h->async3 ? (int64_t)h->async3->update_counter : -1; }
+int64_t ref_async_num_particles(void *hh) { Handle *h = (Handle *)hh; return ASYNC_DISPATCH(h, async_num); }
+int64_t ref_async_time_int(void *hh) { Handle *h = (Handle *)hh; return ASYNC_DISPATCH(h, async_time_int); }
+int64_t ref_async_update_counter(void *hh) { Handle *h = (Handle *)hh; return ASYNC_DISPATCH(h, async_update_counter); }
 
 
 // ---- CPIC rigid coupling (3D) --------------------------------------------------------------------------------------

@@ -74,6 +74,8 @@ def lib():
         L.ref_async_blocks.argtypes = [C.c_void_p, C.c_int64, P_I, P_L, P_L, P_L, P_L, P_L]
         L.ref_async_download.restype = C.c_int64
         L.ref_async_download.argtypes = [C.c_void_p, C.c_int64, P_F, P_F, P_F, P_F, P_F, P_I, P_L]
+        L.ref_async_geometry.restype = C.c_int64
+        L.ref_async_geometry.argtypes = [C.c_void_p, C.c_int64, P_I, P_I, P_I]
         L.ref_async_num_particles.restype = C.c_int64
         L.ref_async_num_particles.argtypes = [C.c_void_p]
         L.ref_async_time_int.restype = C.c_int64
@@ -385,11 +387,21 @@ class Sim:
 
 
 class AsyncSim(Sim):
-    """AsyncMPM<3> of the reference (create_simulation3('async_mpm'), src/async/async_mpm.{h,cpp}): block-local time steps.
-    Config keys: unit_delta_t, max_units, cfl_dt_mul, strength_dt_mul (src/async/async_mpm.cpp:24-27)."""
+    """AsyncMPM<dim> of the reference (create_simulation3('async_mpm') / create_simulation2('async_mpm'),
+    src/async/async_mpm.{h,cpp}): block-local time steps.  Config keys: unit_delta_t, max_units, cfl_dt_mul, strength_dt_mul
+    (src/async/async_mpm.cpp:24-27), left_boundary (:43-53)."""
 
-    def __init__(self, res, dx, dt=1e-4, **cfg):
-        super().__init__(res, dx, dt, dim=3, **{"async": True, **cfg})
+    def __init__(self, res, dx, dt=1e-4, dim=3, **cfg):
+        super().__init__(res, dx, dt, dim=dim, **{"async": True, **cfg})
+
+    def geometry(self):
+        """the scheduler's block table in the order the pools are walked in: corner node (n,3), cached_neighbours (n,26;
+        -1 terminated), left_boundary flag (n)"""
+        n = int(lib().ref_async_geometry(self.h, 0, None, None, None))
+        coord, neigh, bnd = np.zeros((n, 3), np.int32), np.zeros((n, 26), np.int32), np.zeros(n, np.int32)
+        if lib().ref_async_geometry(self.h, n, coord.ctypes.data_as(P_I), neigh.ctypes.data_as(P_I), bnd.ctypes.data_as(P_I)) != n:
+            raise RuntimeError("reference: " + lib().ref_last_error().decode())
+        return coord, neigh, bnd
 
     def update_dt_limits(self):
         _chk(lib().ref_async_update_dt_limits(self.h))
@@ -412,8 +424,9 @@ class AsyncSim(Sim):
 
     def download(self, by_id=True):
         n = self.num_particles()
-        out = dict(x=np.zeros((n, 3), np.float32), v=np.zeros((n, 3), np.float32), F=np.zeros((n, 9), np.float32),
-                   B=np.zeros((n, 9), np.float32), aux=np.zeros(n, np.float32), id=np.zeros(n, np.int32), limits=np.zeros((n, 4), np.int64))
+        d = self.dim
+        out = dict(x=np.zeros((n, d), np.float32), v=np.zeros((n, d), np.float32), F=np.zeros((n, d * d), np.float32),
+                   B=np.zeros((n, d * d), np.float32), aux=np.zeros(n, np.float32), id=np.zeros(n, np.int32), limits=np.zeros((n, 4), np.int64))
         m = lib().ref_async_download(self.h, n, *(out[k].ctypes.data_as(P_F) for k in ("x", "v", "F", "B", "aux")),
                                      out["id"].ctypes.data_as(P_I), out["limits"].ctypes.data_as(C.POINTER(C.c_int64)))
         if m != n:

@@ -156,6 +156,8 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_set_profile_sampling", "mpmhip_create"
             "mpmhip_async_enable", "mpmhip_async_begin", "mpmhip_async_pool_particles", "mpmhip_async_step", "mpmhip_async_load_pools", "mpmhip_async_state", "mpmhip_async_current_time", "mpmhip_async_block_times", "mpmhip_async_download_pools", "mpmhip_async_profile", "mpmhip_async_snapshot_size", "mpmhip_async_snapshot_save", "mpmhip_async_snapshot_load", "mpmhip_host_particle_bytes", "mpmhip_async_update_dt_limits", "mpmhip_async_blocks", "mpmhip_async_set_time_int", "mpmhip_async_table", "mpmhip_clear_particles", "mpmhip_set_dt", "mpmhip_set_time", "mpmhip_get_clock", "mpmhip_set_clock", "mpmhip_debug_allowed_dt",
             "mpmhip2d_create", "mpmhip2d_destroy", "mpmhip2d_last_error", "mpmhip2d_set_levelset", "mpmhip2d_add_group", "mpmhip2d_add_particles",
             "mpmhip2d_substep", "mpmhip2d_step", "mpmhip2d_current_time", "mpmhip2d_num_particles", "mpmhip2d_download", "mpmhip2d_download_grid",
+            "mpmhip2d_async_begin", "mpmhip2d_async_pool_particles", "mpmhip2d_async_step", "mpmhip2d_async_load_pools", "mpmhip2d_async_view_blocks",
+            "mpmhip2d_async_state", "mpmhip2d_async_current_time", "mpmhip2d_async_table",
             "mpmhip2d_set_rigid_coupling", "mpmhip2d_add_articulation", "mpmhip2d_set_articulation_iterations", "mpmhip2d_add_rigid_body", "mpmhip2d_rigid_get_state", "mpmhip2d_rigid_get_samples", "mpmhip2d_cdf_phase",
             "mpmhip2d_download_cdf", "mpmhip2d_download_colours",
             "mpmhip_set_rigid_coupling", "mpmhip_add_rigid_body", "mpmhip_num_rigid_bodies", "mpmhip_rigid_get_state", "mpmhip_rigid_set_velocity",
@@ -322,6 +324,18 @@ def load():
     L.mpmhip2d_download.argtypes = [vp, C.c_int64, fp, fp, fp, fp, fp, ip, ip]
     L.mpmhip2d_download.restype = C.c_int64
     L.mpmhip2d_download_grid.argtypes = [vp, fp]
+    L.mpmhip2d_async_begin.argtypes = [vp, P(AsyncConfig)]
+    L.mpmhip2d_async_pool_particles.argtypes = [vp]
+    L.mpmhip2d_async_step.argtypes = [vp, C.c_float]
+    L.mpmhip2d_async_load_pools.argtypes = [vp]
+    L.mpmhip2d_async_load_pools.restype = C.c_int64
+    L.mpmhip2d_async_view_blocks.argtypes = [vp, C.c_int64, ip]
+    L.mpmhip2d_async_view_blocks.restype = C.c_int64
+    L.mpmhip2d_async_state.argtypes = [vp, P(C.c_int64)]
+    L.mpmhip2d_async_current_time.argtypes = [vp]
+    L.mpmhip2d_async_current_time.restype = C.c_double
+    L.mpmhip2d_async_table.argtypes = [vp, P(C.c_int32), C.c_int64] + [P(C.c_int64)] * 7
+    L.mpmhip2d_async_table.restype = C.c_int64
     L.mpmhip_debug_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int32, P(C.c_double)]
     L.mpmhip_debug_gather_bandwidth.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, P(C.c_double)]
     L.mpmhip_bgeo_size.argtypes = [vp, C.c_int32, P(C.c_size_t)]

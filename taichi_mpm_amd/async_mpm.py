@@ -1,7 +1,9 @@
-"""AsyncMPM — the reference's asynchronous (block-local time step) stepper, `create_simulation3('async_mpm')`
-(class AsyncMPM<dim>, src/async/async_mpm.{h,cpp}; TC_IMPLEMENTATION(Simulation3D, AsyncMPM3D, "async_mpm"), :423-427).
+"""AsyncMPM — the reference's asynchronous (block-local time step) stepper, `create_simulation3('async_mpm')` and
+`create_simulation2('async_mpm')` (class AsyncMPM<dim>, src/async/async_mpm.{h,cpp}; TC_IMPLEMENTATION(Simulation3D,
+AsyncMPM3D, "async_mpm") / (Simulation2D, AsyncMPM2D, "async_mpm"), :423-427).
 
-Everything of it runs inside libmpmhip (csrc/async_api.h, csrc/k_async.h; C ABI: include/mpmhip.h "AsyncMPM, second half"):
+Everything of it runs inside libmpmhip (csrc/async_sched.h: the block scheduler of both dimensions; csrc/async_api.h,
+csrc/k_async.h: 3D; csrc/async2d_api.h, csrc/k_async2d.h: 2D; C ABI: include/mpmhip.h "AsyncMPM, second half", "AsyncMPM<2>"):
 the particle pools and backup pools of every scheduler block are a device-resident store, `advance(limit)` gathers its
 working set with index kernels, runs one ordinary substep with dt = unit_delta_t * limit and files the results back; the
 block tables and the walk over the power-of-two levels are C++ host code, as in the reference.  This module is the Python
@@ -18,6 +20,7 @@ import numpy as np
 
 from . import _lib
 from .mpm import MPMError, Simulation3D
+from .mpm2d import Simulation2D
 
 _LP = C.POINTER(C.c_int64)
 
@@ -189,3 +192,129 @@ class AsyncSimulation3D(Simulation3D):
         rows = blob[off:off + 80 * n_groups].view(np.float32).reshape(n_groups, 20)
         self._groups = [(int(r[16:17].view(np.int32)[0]), r[:16].copy()) for r in rows]
         self._n_added = max(self._n_added, self.get_num_pool_particles())
+
+
+class AsyncSimulation2D(Simulation2D):
+    """AsyncMPM<2> (create_simulation2('async_mpm')).  Config keys on top of MPM<2>'s: unit_delta_t (1e-6), max_units (8192),
+    cfl_dt_mul, strength_dt_mul (src/async/async_mpm.cpp:24-27), left_boundary (:43-53).  A scheduler block is 8 x 16 nodes."""
+
+    def initialize(self, config):
+        cfg = dict(config)
+        super().initialize(cfg)
+        self.unit_delta_t = float(cfg.get("unit_delta_t", 1e-6))
+        self.max_units = int(cfg.get("max_units", 8192))
+        self.cfl_dt_mul = float(cfg.get("cfl_dt_mul", 1.0))
+        self.strength_dt_mul = float(cfg.get("strength_dt_mul", 1.0))
+        self.left_boundary = bool(cfg.get("left_boundary", False))
+        self.nb = ((self.res[0] >> 3) + 1, (self.res[1] >> 4) + 1)
+        return self
+
+    # ------------------------------------------------------------------------------------------- plumbing
+    def _resident_particles(self):
+        return 0  # (every batch moves to the pools right away: the arrays only ever hold one batch or one working set)
+
+    def _ensure_ctx(self, extra=0):
+        fresh = self._ctx is None
+        super()._ensure_ctx(extra)
+        if fresh:
+            a = _lib.AsyncConfig(self.unit_delta_t, self.max_units, self.cfl_dt_mul, self.strength_dt_mul, int(self.left_boundary))
+            self._check(self._L.mpmhip2d_async_begin(self._ctx, C.byref(a)))
+            self._capacity = 1 << 62  # (the library grows the arrays of a resident stepper: they hold one batch or one working set)
+            self._check(self._L.mpmhip2d_async_pool_particles(self._ctx))  # (particles staged before the ctx existed)
+
+    def _state(self):
+        self._ensure_ctx()
+        o = (C.c_int64 * 8)()
+        self._check(self._L.mpmhip2d_async_state(self._ctx, o))
+        return list(o)
+
+    # ------------------------------------------------------------------------------------------- the AsyncMPM interface
+    def add_particles(self, config):
+        """AsyncMPM<dim>::add_particles (src/async/async_mpm.cpp:57-75): the new particles go to their blocks' pools"""
+        if dict(config).get("type") == "rigid":
+            raise MPMError("rigid bodies cannot be combined with asynchronous stepping")
+        self._ensure_ctx()
+        ret = super().add_particles(config)
+        self._check(self._L.mpmhip2d_async_pool_particles(self._ctx))
+        return ret
+
+    def add_rigid_body(self, cfg):
+        raise MPMError("rigid bodies cannot be combined with asynchronous stepping")
+
+    def step(self, dt):
+        """AsyncMPM<dim>::step (src/async/async_mpm.cpp:380-421)"""
+        self._ensure_ctx()
+        if dt < 0:
+            raise MPMError("AsyncMPM.step(dt < 0) is the synchronous substep of the base class: use create_simulation2('mpm')")
+        self._check(self._L.mpmhip2d_async_step(self._ctx, C.c_float(dt)))
+
+    def substep(self):
+        raise MPMError("AsyncMPM steps with step(dt); the synchronous substep belongs to create_simulation2('mpm')")
+
+    run_substeps = None
+
+    @property
+    def current_t_int(self):
+        return self._state()[0]
+
+    @property
+    def update_counter(self):
+        return self._state()[1]
+
+    @property
+    def min_delta_t_int(self):
+        return self._state()[2]
+
+    @property
+    def max_delta_t_int(self):
+        return self._state()[3]
+
+    def get_current_time(self):
+        self._ensure_ctx()
+        return float(self._L.mpmhip2d_async_current_time(self._ctx))
+
+    def get_name(self):
+        return "async_mpm"
+
+    def block_table(self):
+        """dense block table (block b = bx nb[1] + by): continuous / strength / cfl limits, pool sizes, particle_t, backup_t,
+        local_min_dt_limit"""
+        self._ensure_ctx()
+        nb = (C.c_int32 * 2)()
+        n = int(self._check(self._L.mpmhip2d_async_table(self._ctx, nb, 0, *([None] * 7))))
+        keys = ("strength", "cfl", "continuous", "count", "particle_t", "backup_t", "local_min")
+        arr = {k: np.zeros(n, np.int64) for k in keys}
+        self._check(self._L.mpmhip2d_async_table(self._ctx, nb, n, *(arr[k].ctypes.data_as(_LP) for k in keys)))
+        arr["nb"] = tuple(nb)
+        return arr
+
+    def _load_pools(self):
+        self._ensure_ctx()
+        return int(self._check(self._L.mpmhip2d_async_load_pools(self._ctx)))
+
+    def get_num_pool_particles(self):
+        """containers in all particle pools (an id can sit in more than one, as in the reference)"""
+        return self._load_pools()
+
+    def get_num_particles(self):
+        if self._ctx is None:
+            return self._n_added
+        return self._load_pools()
+
+    def get_particles(self, sort_by_id=True):
+        """AsyncMPM<dim>::visualize's particle list: every container of every particle pool, each at its block's time"""
+        self._load_pools()
+        return super().get_particles(sort_by_id)
+
+    def get_pool_particles(self):
+        """every container of every particle pool + its block and that block's limits, sorted by (id, block)"""
+        n = self._load_pools()
+        out = Simulation2D.get_particles(self, sort_by_id=False)
+        blk = np.zeros(max(n, 1), np.int32)
+        got = int(self._check(self._L.mpmhip2d_async_view_blocks(self._ctx, n, blk.ctypes.data_as(C.POINTER(C.c_int32)))))
+        assert got == n == len(out["id"])
+        blk = blk[:n].astype(np.int64)
+        tab = self.block_table()
+        out.update(block=blk, continuous=tab["continuous"][blk], particle_t=tab["particle_t"][blk])
+        o = np.lexsort((out["block"], out["id"]))
+        return {k: v[o] for k, v in out.items()}

@@ -8,13 +8,6 @@
 // every container stays in HBM (k_async.h: the store), and an advance costs four small kernels around the substep and
 // two 16-byte read-backs (how many particles the working set has; how many containers were appended / freed).
 
-static inline uint32_t as_spread3(uint32_t v) {  // bits of v three apart
-  uint64_t x = v & 0x3ffu;
-  x = (x | (x << 16)) & 0x030000ffull; x = (x | (x << 8)) & 0x0300f00full;
-  x = (x | (x << 4)) & 0x030c30c3ull;  x = (x | (x << 2)) & 0x09249249ull;
-  return (uint32_t)x;
-}
-
 static int async_store_reserve(mpmhip_ctx *c, uint32_t need) {  // room for `need` containers in total
   auto &S = c->async.store;
   if (need <= S.cap) return MPMHIP_OK;
@@ -148,38 +141,8 @@ int mpmhip_async_begin(mpmhip_ctx *c, const mpmhip_async_config *cfg) {
   if (int rc = mpmhip_async_enable(c, cfg)) return rc;
   auto &A = c->async;
   auto &S = A.store;
-  const size_t nblk = A.continuous.size();
-  A.particle_t.assign(nblk, 0); A.backup_t.assign(nblk, 0); A.local_min.assign(nblk, 1);
-  A.has_copied.assign(nblk, 0); A.tbl.assign(nblk, 0);
-  A.larger.assign(64, {}); A.smaller.assign(64, {});
-  A.update_counter = 0; A.step_counter = 0; A.request_t = 0.0f; A.current_t = 0.0f;
-  // the reference's block number: the page bits of SparseMask::Linear_Offset — per level z, then x, then y
-  // (external/SPGrid/Core/SPGrid_Mask.h:29-35); pools are walked in this order
-  std::vector<std::pair<uint64_t, uint32_t>> order(nblk);
-  for (int bx = 0; bx < A.nb[0]; bx++)
-    for (int by = 0; by < A.nb[1]; by++)
-      for (int bz = 0; bz < A.nb[2]; bz++) {
-        const uint32_t b = ((uint32_t)bx * A.nb[1] + by) * A.nb[2] + bz;
-        order[b] = {((uint64_t)as_spread3(bz) << 2) | ((uint64_t)as_spread3(bx) << 1) | as_spread3(by), b};
-      }
-  std::sort(order.begin(), order.end());
-  A.rank_of.assign(nblk, 0);
-  for (size_t r = 0; r < nblk; r++) A.rank_of[order[r].second] = (uint32_t)r;
-  // cached_neighbours (src/async/async_mpm.h:248-301): the blocks around a block, 26 at most
-  A.neigh.assign(nblk * 26, -1);
-  for (int bx = 0; bx < A.nb[0]; bx++)
-    for (int by = 0; by < A.nb[1]; by++)
-      for (int bz = 0; bz < A.nb[2]; bz++) {
-        const size_t b = ((size_t)bx * A.nb[1] + by) * A.nb[2] + bz;
-        int m = 0;
-        for (int i = -1; i < 2; i++)
-          for (int j = -1; j < 2; j++)
-            for (int k = -1; k < 2; k++) {
-              const int x = bx + i, y = by + j, z = bz + k;
-              if ((i || j || k) && x >= 0 && y >= 0 && z >= 0 && x < A.nb[0] && y < A.nb[1] && z < A.nb[2])
-                A.neigh[b * 26 + m++] = (int32_t)(((size_t)x * A.nb[1] + y) * A.nb[2] + z);
-            }
-      }
+  A.sched_begin();  // block times, the reference's block order, cached_neighbours
+  const size_t nblk = A.nblk();
   HIPCHK(c, hipSetDevice(c->device));
   hipFree(S.d_tbl); hipFree(S.d_rank); hipFree(S.d_cnt);
   S.d_tbl = nullptr; S.d_rank = nullptr; S.d_cnt = nullptr;
@@ -189,7 +152,6 @@ int mpmhip_async_begin(mpmhip_ctx *c, const mpmhip_async_config *cfg) {
   HIPCHK(c, hipMemcpy(S.d_rank, A.rank_of.data(), sizeof(uint32_t) * nblk, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemset(S.d_cnt, 0, sizeof(AsyncCounters)));
   S.size = S.size_ub = S.live = 0;
-  A.limits_version = 0; A.lists_version = ~0ull;
   A.resident = true;
   return MPMHIP_OK;
 }
@@ -236,44 +198,7 @@ static int async_update_dt_limits(mpmhip_ctx *c) {
   if (int rc = async_limits_from_table(c)) return rc;  // the block state machine shared with mpmhip_async_update_dt_limits
   if (A.scratch != A.continuous) A.limits_version++;
   AsTimer lists(A.prof_ms[1]);
-  // larger / smaller neighbours per log2(limit) (:183-247), each in the reference's block order — they depend on the
-  // continuous limits alone: rebuilt only when a limit has changed
-  if (A.lists_version != A.limits_version) {
-    for (auto &v : A.larger) v.clear();
-    for (auto &v : A.smaller) v.clear();
-    auto lg = [](int64_t v) { int r = 0; while (v > 1) { v >>= 1; r++; } return r; };
-    for (size_t b = 0; b < nblk; b++) {
-      const int64_t cb = A.continuous[b];
-      for (int k = 0; k < 26; k++) {
-        const int32_t q = A.neigh[b * 26 + k];
-        if (q < 0) break;
-        if (cb < A.continuous[q]) {
-          A.larger[lg(cb)].push_back((uint32_t)q);
-          A.smaller[lg(A.continuous[q])].push_back((uint32_t)b);
-        }
-      }
-    }
-    auto tidy = [&](std::vector<uint32_t> &v) {
-      std::sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return A.rank_of[x] < A.rank_of[y]; });
-      v.erase(std::unique(v.begin(), v.end()), v.end());
-    };
-    for (auto &v : A.larger) tidy(v);
-    for (auto &v : A.smaller) tidy(v);
-    A.lists_version = A.limits_version;
-  }
-  // local_min_dt_limit (:165-182).  advance() reads it only for blocks it has copied with a LARGER limit than the level's,
-  // i.e. for members of the larger-neighbour lists: computed for those (the value of the others is never looked at)
-  for (const auto &v : A.larger)
-    for (uint32_t b : v) {
-      if (A.continuous[b] == A.min_delta_t_int) continue;
-      int64_t m = 1ll << 31;
-      for (int k = 0; k < 26; k++) {
-        const int32_t q = A.neigh[(size_t)b * 26 + k];
-        if (q < 0) break;
-        m = std::min(m, A.particle_t[q] + A.continuous[q]);
-      }
-      A.local_min[b] = m;
-    }
+  A.rebuild_lists();  // larger / smaller neighbours per level (:183-247), local_min_dt_limit (:165-182)
   return MPMHIP_OK;
 }
 
@@ -281,28 +206,10 @@ static int async_update_dt_limits(mpmhip_ctx *c) {
 static int async_advance(mpmhip_ctx *c, int64_t limit) {
   auto &A = c->async;
   auto &S = A.store;
-  const size_t nblk = A.continuous.size();
   const int64_t t = A.current_t_int;
   AsTimer whole(A.prof_ms[2]);
   A.prof_ms[5] += 1.0;  // (advances)
-  int lg = 0;
-  for (int64_t v = limit; v > 1; v >>= 1) lg++;
-  std::fill(A.has_copied.begin(), A.has_copied.end(), 0);
-  std::fill(A.tbl.begin(), A.tbl.end(), 0);
-  for (uint32_t b : A.smaller[lg]) {
-    if (A.particle_t[b] != t) return fail(c, MPMHIP_EINVAL, "async: particle_pool broken 2 (block %u at %lld, now %lld)", b, (long long)A.particle_t[b], (long long)t);
-    A.has_copied[b] = 1; A.tbl[b] |= AT_POOL0;
-  }
-  for (size_t b = 0; b < nblk; b++)
-    if (A.continuous[b] == limit) {
-      if (A.particle_t[b] != t) return fail(c, MPMHIP_EINVAL, "async: particle_pool broken 1 (block %zu)", b);
-      A.tbl[b] |= AT_POOL1 | AT_SWAP;  // (backup_current_dt_limit: same condition, :317-325)
-      A.backup_t[b] = t;
-    }
-  for (uint32_t b : A.larger[lg]) {
-    if (A.backup_t[b] != t) return fail(c, MPMHIP_EINVAL, "async: backup_pool broken (block %u at %lld, now %lld)", b, (long long)A.backup_t[b], (long long)t);
-    A.has_copied[b] = 1; A.tbl[b] |= AT_BACKUP;
-  }
+  if (!A.plan_gather(limit)) return fail(c, MPMHIP_EINVAL, "%s", A.sched_err.c_str());
   if (int rc = async_best_reserve(c)) return rc;
   if (int rc = async_upload_tbl(c)) return rc;
   // the working set holds at most one container per id (duplicates are dropped by the gather), i.e. at most
@@ -338,19 +245,7 @@ static int async_advance(mpmhip_ctx *c, int64_t limit) {
     if (int rc = mpmhip_substep(c)) return rc;
     if (A.profile_sync) HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  // update backup_t and particle_t (:331-343)
-  std::fill(A.tbl.begin(), A.tbl.end(), 0);
-  bool any_clear = false;
-  for (size_t b = 0; b < nblk; b++) {
-    if (A.continuous[b] == limit) {
-      A.particle_t[b] = t + limit;
-      A.tbl[b] = AT_DEST_POOL;
-    } else if (A.has_copied[b] && A.continuous[b] > limit && A.local_min[b] == t + limit) {
-      A.backup_t[b] = t + limit;
-      A.tbl[b] = AT_CLEAR | AT_DEST_BACKUP;
-      any_clear = true;
-    }
-  }
+  const bool any_clear = A.plan_file(limit);  // update backup_t and particle_t (:331-343), destinations of the results
   if (int rc = async_upload_tbl(c)) return rc;
   if (any_clear)
     hipLaunchKernelGGL(k_async_clear, dim3(as_grid(S.size)), dim3(256), 0, c->stream, S.size, S.tag, (const uint8_t *)S.d_tbl, S.d_cnt);
@@ -392,8 +287,7 @@ int mpmhip_async_step(mpmhip_ctx *c, float dt) {
       if (A.current_t_int % d == 0) {
         if (int rc = async_advance(c, d)) return rc;
       }
-    A.current_t_int += A.min_delta_t_int - A.current_t_int % A.min_delta_t_int;
-    A.current_t = A.cfg.unit_delta_t * (float)A.current_t_int;
+    A.finish_round();
   } while (A.current_t < A.request_t);
   if (int rc = async_settle(c)) return rc;
   c->n_slots = 0; c->P.n_slots = 0;  // the records held the last working set: the state is in the pools

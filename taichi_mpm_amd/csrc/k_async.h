@@ -13,20 +13,11 @@
 #pragma once
 #include "mpm_common.h"
 #include "k_sort.h"
+#include "async_sched.h"  // the action bits AT_* of the per-block table
 
 namespace mpm {
 
 constexpr uint32_t AS_BACKUP = 0x80000000u, AS_FREE = INVALID;
-// per-block action bits of one advance (host -> device table)
-enum : uint8_t {
-  AT_POOL0 = 1,        // gather the block's pool, first in line (a neighbour stepping with a smaller dt: ":263 Smaller neighbours")
-  AT_POOL1 = 2,        // gather the block's pool (it steps with this advance's dt: ":277 Equal neighbours")
-  AT_BACKUP = 4,       // gather the block's backup (a neighbour stepping with a larger dt: ":294 Larger neighbours")
-  AT_SWAP = 8,         // backup_current_dt_limit (:317-325): drop the block's backup, its pool becomes the backup
-  AT_CLEAR = 16,       // after the substep: drop the block's backup (:337-341)
-  AT_DEST_POOL = 32,   // after the substep: results that land in this block go to its pool (:361-364)
-  AT_DEST_BACKUP = 64  // ... to its backup (:365-371)
-};
 struct AsyncCounters {
   uint32_t n_work, n_append, n_freed, n_live;  // transient: reset by the host behind every read-back
   uint32_t size, pad[3];                       // persistent: containers in use incl. freed ones (the append cursor)

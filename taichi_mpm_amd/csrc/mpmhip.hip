@@ -82,6 +82,7 @@
 #include "k_bgeo.h"
 #include "k_mpm88.h"
 #include "k_mpm2d.h"
+#include "k_async2d.h"
 
 
 // ================================================================================================ host side
@@ -157,29 +158,14 @@ struct mpmhip_ctx {
   int counts_cap = 0;
   bool compact_requested = false;
   bool in_substep = false;
-  struct AsyncState {  // AsyncMPM block table (src/async/async_mpm.h:93-110), one entry per scheduler block of 4x4x8 nodes
+  struct AsyncState : AsyncSched {  // the block scheduler (async_sched.h) + what this ctx keeps on the device for it
     bool enabled = false, limits_valid = false;
-    mpmhip_async_config cfg{};
-    std::vector<uint32_t> boundary;  // "left_boundary" blocks (src/async/async_mpm.cpp:43-53)
-    int nb[3] = {0, 0, 0};
-    int64_t current_t_int = 0, min_delta_t_int = 1, max_delta_t_int = 1;
-    std::vector<int64_t> strength, cfl, continuous;  // strength_dt_limit, cfl_dt_limit, continuous_dt_limit
-    std::vector<uint32_t> count;
     uint32_t *d_tab = nullptr, *d_blk_of = nullptr;
     int32_t *d_blk_limits = nullptr, *d_particle_limits = nullptr;
     int64_t blk_of_cap = 0;
-    // the resident stepper (async_api.h): block times, neighbour lists, and the device store of pool / backup containers
+    // the resident stepper (async_api.h): the device store of pool / backup containers
     bool resident = false, pending_counters = false;
     bool records_are_view = false;  // the ctx's records are copies of the pools (mpmhip_async_load_pools), not new particles
-    std::vector<int64_t> particle_t, backup_t, local_min;  // BlockInfo, src/async/async_mpm.h:93-110
-    std::vector<uint8_t> has_copied, tbl;
-    std::vector<int64_t> scratch;
-    uint64_t limits_version = 0, lists_version = ~0ull;  // the neighbour lists are rebuilt only when a continuous limit changed
-    std::vector<uint32_t> rank_of;                         // position of a block in the reference's block order
-    std::vector<int32_t> neigh;                            // cached_neighbours: 26 per block, -1 terminated
-    std::vector<std::vector<uint32_t>> larger, smaller;    // larger_neighbours / smaller_neighbours by log2(limit)
-    int64_t update_counter = 0, step_counter = 0;
-    float request_t = 0.0f, current_t = 0.0f;
     double prof_ms[6] = {0, 0, 0, 0, 0, 0};
     uint32_t *h_tab = nullptr;
     size_t h_tab_cap = 0;
@@ -2233,30 +2219,14 @@ int mpmhip_async_enable(mpmhip_ctx *c, const mpmhip_async_config *cfg) {
   if (c->T.enabled) return fail(c, MPMHIP_EINVAL, "asynchronous stepping cannot be combined with the multi-GPU tiling");
   HIPCHK(c, hipSetDevice(c->device));
   auto &A = c->async;
-  A.cfg = *cfg;
-  A.nb[0] = (c->P.res[0] >> 2) + 1; A.nb[1] = (c->P.res[1] >> 2) + 1; A.nb[2] = (c->P.res[2] >> 3) + 1;
-  const size_t nblk = (size_t)A.nb[0] * A.nb[1] * A.nb[2];
-  // src/async/async_mpm.cpp:32-37: strength = cfl = 2^31, continuous = 1
-  A.strength.assign(nblk, 1ll << 31); A.cfl.assign(nblk, 1ll << 31); A.continuous.assign(nblk, 1);
-  A.count.assign(nblk, 0);
-  A.boundary.clear();
-  if (cfg->left_boundary)  // :43-53 — blocks whose corner node lies in 0 <= x / res <= 0.2
-    for (int bx = 0; bx < A.nb[0]; bx++) {
-      if (!((float)(bx * 4) / (float)c->P.res[0] <= 0.2f)) continue;
-      for (int by = 0; by < A.nb[1]; by++)
-        for (int bz = 0; bz < A.nb[2]; bz++) A.boundary.push_back((uint32_t)((bx * A.nb[1] + by) * A.nb[2] + bz));
-    }
-  A.current_t_int = 0; A.min_delta_t_int = 1; A.max_delta_t_int = 1;
+  A.sched_enable(3, c->P.res, *cfg);
+  const size_t nblk = A.nblk();
   hipFree(A.d_tab); hipFree(A.d_blk_limits);
   A.d_tab = nullptr; A.d_blk_limits = nullptr;
   HIPCHK(c, dmalloc(&A.d_tab, 3 * nblk));
   HIPCHK(c, dmalloc(&A.d_blk_limits, 3 * nblk));
   A.enabled = true; A.limits_valid = false;
   return MPMHIP_OK;
-}
-
-static inline float async_inv_sqrt(float v) {  // src/async/async_mpm.cpp:77-80: the SSE reciprocal-square-root estimate
-  return _mm_cvtss_f32(_mm_rsqrt_ss(_mm_set1_ps(v)));
 }
 
 static int async_ensure_particle_arrays(mpmhip_ctx *c) {
@@ -2283,7 +2253,7 @@ static int async_reset_table(mpmhip_ctx *c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));  // (`init` lives on this stack frame)
   return MPMHIP_OK;
 }
-// the block state machine of AsyncMPM<dim>::update_dt_limits (src/async/async_mpm.cpp:93-152) from the reduced table
+// the reduced table -> the block state machine of AsyncMPM<dim>::update_dt_limits (AsyncSched::limits_from_table)
 static int async_limits_from_table(mpmhip_ctx *c) {
   auto &A = c->async;
   const size_t nblk = A.strength.size();
@@ -2293,48 +2263,9 @@ static int async_limits_from_table(mpmhip_ctx *c) {
     HIPCHK(c, hipHostMalloc((void **)&A.h_tab, sizeof(uint32_t) * 3 * nblk, hipHostMallocDefault));
     A.h_tab_cap = 3 * nblk;
   }
-  const uint32_t *tab = A.h_tab;
   HIPCHK(c, hipMemcpyAsync(A.h_tab, A.d_tab, sizeof(uint32_t) * 3 * nblk, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  const float inv_unit = 1.0f / A.cfg.unit_delta_t;
-  const int64_t t = A.current_t_int;
-  // non-empty blocks (:93-134)
-  for (size_t b = 0; b < nblk; b++) {
-    A.count[b] = tab[3 * b + 2];
-    if (!A.count[b] || (t & (A.continuous[b] - 1)) != 0) continue;
-    float min_dt, max_v2;
-    memcpy(&min_dt, &tab[3 * b], 4); memcpy(&max_v2, &tab[3 * b + 1], 4);
-    A.strength[b] = (int64_t)(A.cfg.strength_dt_mul * min_dt * inv_unit);
-    A.cfl[b] = (int64_t)(A.cfg.cfl_dt_mul * c->P.dx * inv_unit * async_inv_sqrt(max_v2));
-    const int64_t tmp = std::min(std::min(A.cfl[b], A.strength[b]), (int64_t)A.cfg.max_units);
-    if (tmp < 1)
-      return fail(c, MPMHIP_EINVAL, "async stepping: a block's allowed time step is below unit_delta_t (particle types without a "
-                                    "sound-speed bound, e.g. linear / jelly, return 0: the reference stops here too, src/async/async_mpm.cpp:118-125)");
-    int64_t &limit = A.continuous[b];
-    while (tmp < limit) limit >>= 1;
-    while (tmp >= (limit << 1) && (t & ((limit << 1) - 1)) == 0) limit <<= 1;
-  }
-  auto boundary = [&](bool non_empty) {  // update_dt_limit_boundary, src/async/async_mpm.h:178-189
-    A.min_delta_t_int = 1ll << 31; A.max_delta_t_int = 1;
-    for (size_t b = 0; b < nblk; b++) {
-      if (non_empty && !A.count[b]) continue;
-      A.min_delta_t_int = std::min(A.min_delta_t_int, A.continuous[b]);
-      A.max_delta_t_int = std::max(A.max_delta_t_int, A.continuous[b]);
-    }
-  };
-  boundary(true);
-  for (size_t b = 0; b < nblk; b++) {  // empty blocks follow the largest step in use (:137-152)
-    if (A.count[b] || (t & (A.continuous[b] - 1)) != 0) continue;
-    int64_t &limit = A.continuous[b];
-    while (A.max_delta_t_int < limit) limit >>= 1;
-    while (A.max_delta_t_int >= (limit << 1) && (t & ((limit << 1) - 1)) == 0) limit <<= 1;
-  }
-  boundary(false);
-  for (uint32_t b : A.boundary)  // "left_boundary" blocks follow the smallest step in use (:155-163; min / max stay as they are)
-    if ((t & (A.continuous[b] - 1)) == 0) {
-      int64_t &limit = A.continuous[b];
-      while (A.min_delta_t_int < limit) limit >>= 1;
-    }
+  if (!A.limits_from_table(A.h_tab, c->P.dx)) return fail(c, MPMHIP_EINVAL, "%s", A.sched_err.c_str());
   return MPMHIP_OK;
 }
 
@@ -2461,7 +2392,35 @@ struct mpmhip2d_ctx {
   float penalty = 0.0f, pushing_force = 20000.0f;
   mpm2d::Joints2 joints{};     // MPM<2>::articulations ('rotation' joints)
   int joint_iterations = 100;  // 'articulation_iterations'
+  float base_dt = 0.0f;        // the configured "base_delta_t" (P.dt is what the next substep uses: the async stepper sets it per advance)
+  // AsyncMPM<2> (async2d_api.h): the block scheduler + the device store of pool / backup containers (k_async2d.h)
+  struct Async2 : AsyncSched {
+    bool resident = false, pending_counters = false;
+    bool view = false;  // the particle arrays are copies of the pools (mpmhip2d_async_load_pools), not new particles
+    uint32_t cap = 0, size = 0, live = 0, size_ub = 0;  // containers allocated / in use incl. freed ones / not freed / upper bound now
+    float4 *rec = nullptr, *rec2 = nullptr;
+    uint32_t *tag = nullptr, *tag2 = nullptr, *d_tab = nullptr, *d_rank = nullptr, *d_blk_of = nullptr, *h_tab = nullptr;
+    unsigned long long *best = nullptr, *d_scan = nullptr;
+    int64_t best_cap = 0, blk_of_cap = 0, compactions = 0;
+    uint32_t scan_cap = 0, scan_epoch = 0, pin_next = 0;
+    uint8_t *d_tbl = nullptr, *h_tbl_pin = nullptr;
+    AsyncCounters *d_cnt = nullptr, *h_cnt = nullptr;
+  } async;
 };
+static void a2_free(mpmhip2d_ctx *m) {
+  auto &A = m->async;
+  hipFree(A.rec); hipFree(A.rec2); hipFree(A.tag); hipFree(A.tag2); hipFree(A.d_tab); hipFree(A.d_rank); hipFree(A.d_blk_of);
+  hipFree(A.best); hipFree(A.d_scan); hipFree(A.d_tbl); hipFree(A.d_cnt);
+  if (A.h_tab) hipHostFree(A.h_tab);
+  if (A.h_tbl_pin) hipHostFree(A.h_tbl_pin);
+  if (A.h_cnt) hipHostFree(A.h_cnt);
+  A.rec = A.rec2 = nullptr; A.tag = A.tag2 = A.d_tab = A.d_rank = A.d_blk_of = A.h_tab = nullptr;
+  A.best = A.d_scan = nullptr; A.d_tbl = A.h_tbl_pin = nullptr; A.d_cnt = A.h_cnt = nullptr;
+  A.resident = false;
+}
+static int a2_drop_view(mpmhip2d_ctx *m);
+static int a2_grow_particles(mpmhip2d_ctx *m, int64_t need);
+int mpmhip2d_async_step(mpmhip2d_ctx *m, float dt);
 static thread_local std::string g_2d_create_error;
 static int fail2d(mpmhip2d_ctx *m, int code, const std::string &msg) {
   (m ? m->err : g_2d_create_error) = msg;
@@ -2491,6 +2450,7 @@ int mpmhip2d_create(const mpmhip2d_config *cfg, mpmhip2d_ctx **out) {
   mpm2d::Params &P = m->P;
   P.res[0] = cfg->res[0]; P.res[1] = cfg->res[1];
   P.dx = cfg->dx; P.idx = 1.0f / cfg->dx; P.dt = cfg->dt; P.t = 0.0f;
+  m->base_dt = cfg->dt;
   P.g[0] = cfg->gravity[0]; P.g[1] = cfg->gravity[1];
   P.particle_gravity = cfg->particle_gravity; P.apic_damping = cfg->apic_damping; P.rpic_damping = cfg->rpic_damping;
   P.clean_boundary = cfg->clean_boundary; P.particle_collision = cfg->particle_collision; P.clamp_pos = 1;
@@ -2520,6 +2480,7 @@ void mpmhip2d_destroy(mpmhip2d_ctx *m) {
   hipFree(m->x); hipFree(m->v); hipFree(m->F); hipFree(m->B); hipFree(m->aux); hipFree(m->gid); hipFree(m->pid); hipFree(m->grid);
   hipFree(m->n_dead); hipFree(m->d_groups);
   hipFree(m->d_rb); hipFree(m->d_smp); hipFree(m->d_elems); hipFree(m->d_mind); hipFree(m->d_tags); hipFree(m->d_states); hipFree(m->d_bnd);
+  a2_free(m);
   delete m;
 }
 
@@ -2575,8 +2536,12 @@ int mpmhip2d_add_particles(mpmhip2d_ctx *m, int32_t group, int64_t n, const floa
   if (!m || n < 0 || (n > 0 && !x)) return MPMHIP_EINVAL;
   if (group < 0 || group >= (int)m->groups.size()) return fail2d(m, MPMHIP_EINVAL, "unknown group");
   if (n == 0) return MPMHIP_OK;
-  if (m->n + n > m->cap) return fail2d(m, MPMHIP_ECAPACITY, "particle capacity exceeded");
   HIPCHK2D(m, hipSetDevice(m->device));
+  if (int rc = a2_drop_view(m)) return rc;  // (resident async stepper: arrays that only mirror the pools go first)
+  if (m->n + n > m->cap) {
+    if (!m->async.resident) return fail2d(m, MPMHIP_ECAPACITY, "particle capacity exceeded");
+    if (int rc = a2_grow_particles(m, m->n + n)) return rc;  // (a resident stepper's arrays hold one batch or one working set)
+  }
   HIPCHK2D(m, hipStreamSynchronize(m->stream));
   const int mat = m->groups[group].type;
   const float aux0 = (mat == MPMHIP_SNOW || mat == MPMHIP_WATER) ? 1.0f : (mat == MPMHIP_VISCO ? 1000.0f : 0.0f);
@@ -2652,8 +2617,13 @@ static int rigid2_advect(mpmhip2d_ctx *m) {
   return MPMHIP_OK;
 }
 
+static int substep2d(mpmhip2d_ctx *m);
 int mpmhip2d_substep(mpmhip2d_ctx *m) {  // MPM<2>::substep, src/mpm.cpp:452-575
   if (!m) return MPMHIP_EINVAL;
+  if (m->async.resident) return fail2d(m, MPMHIP_EINVAL, "an asynchronous stepper steps with mpmhip2d_async_step (mpmhip2d_step forwards to it)");
+  return substep2d(m);
+}
+static int substep2d(mpmhip2d_ctx *m) {
   HIPCHK2D(m, hipSetDevice(m->device));
   const size_t nodes = (size_t)(m->P.res[0] + 1) * (m->P.res[1] + 1);
   m->P.t = m->t;
@@ -2691,6 +2661,7 @@ int mpmhip2d_set_rigid_coupling(mpmhip2d_ctx *m, float penalty, float pushing_fo
 }
 int mpmhip2d_add_rigid_body(mpmhip2d_ctx *m, const mpmhip2d_rigid_config *cfg, int64_t n_segments, const float *segments) {
   if (!m || !cfg || !segments || n_segments <= 0) return MPMHIP_EINVAL;
+  if (m->async.resident) return fail2d(m, MPMHIP_EINVAL, "rigid bodies cannot be combined with asynchronous stepping");
   HIPCHK2D(m, hipSetDevice(m->device));
   HIPCHK2D(m, hipStreamSynchronize(m->stream));
   const size_t nodes = (size_t)(m->P.res[0] + 1) * (m->P.res[1] + 1);
@@ -2911,8 +2882,9 @@ int64_t mpmhip2d_download_colours(mpmhip2d_ctx *m, int64_t capacity, uint32_t *s
   return k;
 }
 
-int mpmhip2d_step(mpmhip2d_ctx *m, float dt) {  // MPM<dim>::step, src/mpm.cpp:428-439
+int mpmhip2d_step(mpmhip2d_ctx *m, float dt) {  // MPM<dim>::step, src/mpm.cpp:428-439 (virtual: AsyncMPM<2>::step when the stepper is resident)
   if (!m) return MPMHIP_EINVAL;
+  if (m->async.resident) return mpmhip2d_async_step(m, dt);
   if (dt < 0) {
     const int rc = mpmhip2d_substep(m);
     m->request_t = m->t;
@@ -2971,6 +2943,8 @@ int mpmhip2d_download_grid(mpmhip2d_ctx *m, float *grid) {  // (v.x, v.y, m) per
   HIPCHK2D(m, hipMemcpy(grid, m->grid, sizeof(float) * 3 * (size_t)(m->P.res[0] + 1) * (m->P.res[1] + 1), hipMemcpyDeviceToHost));
   return MPMHIP_OK;
 }
+
+#include "async2d_api.h"
 
 // ------------------------------------------------------------------------------------------------ debug math
 int mpmhip_debug_svd3(mpmhip_ctx *c, int64_t n, const float *F, float *U, float *S, float *V) {

@@ -866,8 +866,11 @@ class Simulation3D:
 def create_simulation2(name):
     """tc_core.create_simulation2 (scripts/async/async_mpm.py:25-32): MPM<2>
     (TC_IMPLEMENTATION(Simulation2D, MPM2D, "mpm"), src/mpm.cpp:983-986)"""
+    if name == "async_mpm":  # TC_IMPLEMENTATION(Simulation2D, AsyncMPM2D, "async_mpm"), src/async/async_mpm.cpp:423-427
+        from .async_mpm import AsyncSimulation2D
+        return AsyncSimulation2D()
     if name != "mpm":
-        raise MPMError("no Simulation2D implementation named %r (registered: 'mpm')" % (name,))
+        raise MPMError("no Simulation2D implementation named %r (registered: 'mpm', 'async_mpm')" % (name,))
     from .mpm2d import Simulation2D
     return Simulation2D()
 

@@ -59,7 +59,7 @@ class Simulation2D:
 
     def _ensure_ctx(self, extra=0):
         if self._ctx is not None:
-            if self._n_added + extra > self._capacity:
+            if self._resident_particles() + extra > self._capacity:
                 raise MPMError("2D particle capacity exceeded: pass max_particles to initialize()")
             return
         cfg = self.config
@@ -89,6 +89,10 @@ class Simulation2D:
         for gi, (mat, params, arrs) in enumerate(self._staged):
             self._add(mat, params, *arrs)
         self._staged = []
+
+    def _resident_particles(self):
+        """particles held by the object's arrays (what max_particles bounds)"""
+        return self._n_added
 
     def close(self):
         if self._ctx is not None:
