@@ -576,6 +576,9 @@ typedef struct mpmhip2d_rigid_config {
   mpmhip_script_fn scripted_rotation; void *rotation_user;
 } mpmhip2d_rigid_config;
 int mpmhip2d_set_rigid_coupling(mpmhip2d_ctx *ctx, float penalty, float pushing_force);
+/* MPM<2>::rigid_body_levelset_collision (src/mpm_rigid_body.cpp:347-387, config key rigid_body_levelset_collision): see
+ * mpmhip_set_rigid_levelset_collision */
+int mpmhip2d_set_rigid_levelset_collision(mpmhip2d_ctx *ctx, int32_t enabled);
 int mpmhip2d_add_rigid_body(mpmhip2d_ctx *ctx, const mpmhip2d_rigid_config *cfg, int64_t n_segments, const float *segments /* n x 4 */);
 /* joints in 2D: type = MPMHIP_JOINT_ROTATION only (scripts/mls-cpic/sand_wheel_2D.py:88); struct below, in the CPIC section */
 struct mpmhip_joint_config;

@@ -158,7 +158,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_set_profile_sampling", "mpmhip_create"
             "mpmhip2d_substep", "mpmhip2d_step", "mpmhip2d_current_time", "mpmhip2d_num_particles", "mpmhip2d_download", "mpmhip2d_download_grid",
             "mpmhip2d_async_begin", "mpmhip2d_async_pool_particles", "mpmhip2d_async_step", "mpmhip2d_async_load_pools", "mpmhip2d_async_view_blocks",
             "mpmhip2d_async_state", "mpmhip2d_async_current_time", "mpmhip2d_async_table",
-            "mpmhip2d_set_rigid_coupling", "mpmhip2d_add_articulation", "mpmhip2d_set_articulation_iterations", "mpmhip2d_add_rigid_body", "mpmhip2d_rigid_get_state", "mpmhip2d_rigid_get_samples", "mpmhip2d_cdf_phase",
+            "mpmhip2d_set_rigid_coupling", "mpmhip2d_set_rigid_levelset_collision", "mpmhip2d_add_articulation", "mpmhip2d_set_articulation_iterations", "mpmhip2d_add_rigid_body", "mpmhip2d_rigid_get_state", "mpmhip2d_rigid_get_samples", "mpmhip2d_cdf_phase",
             "mpmhip2d_download_cdf", "mpmhip2d_download_colours",
             "mpmhip_set_rigid_coupling", "mpmhip_add_rigid_body", "mpmhip_num_rigid_bodies", "mpmhip_rigid_get_state", "mpmhip_rigid_set_velocity",
             "mpmhip_rigid_get_samples", "mpmhip_rigid_get_mesh", "mpmhip2d_rigid_get_mesh", "mpmhip_rasterize_rigid_boundary", "mpmhip_gather_cdf", "mpmhip_advect_rigid_bodies", "mpmhip_download_cdf",
@@ -370,6 +370,7 @@ def load():
     L.mpmhip_download_boundary.argtypes = [vp, fp, C.c_int64]
     L.mpmhip_download_boundary.restype = C.c_int64
     L.mpmhip2d_set_rigid_coupling.argtypes = [vp, C.c_float, C.c_float]
+    L.mpmhip2d_set_rigid_levelset_collision.argtypes = [vp, C.c_int32]
     L.mpmhip2d_add_articulation.argtypes = [vp, P(JointConfig)]
     L.mpmhip2d_set_articulation_iterations.argtypes = [vp, C.c_int32]
     L.mpmhip2d_add_rigid_body.argtypes = [vp, P(RigidConfig2D), C.c_int64, fp]

@@ -310,6 +310,115 @@ __device__ __forceinline__ void friction_project2(float v[2], const float vb[2],
   v[1] = ts * t1 + keep * n[1] + vb[1];
 }
 
+// ---- MPM<2>::rigid_body_levelset_collision (src/mpm_rigid_body.cpp:347-387; see k_rigid_ls_keys / k_rigid_ls_collide of
+// k_rigid.h for the 3D form and why the ORDER matters: the impulses of one boundary particle change the velocity the next
+// one sees).  The order is the reference's sorted particle list: by the SPGrid key of the particle's base node
+// (sort_particles_and_populate_grid, src/mpm.cpp:785-790; SPGrid_Mask<5, 5, 2>: 8 x 16-node blocks, page bits per level y
+// above x, inside a block x above y), ties by the position in the previous order.
+__device__ __forceinline__ uint32_t spread_every_second(uint32_t v) {
+  v &= 0xFFFFu;
+  v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu;
+  v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+__device__ __forceinline__ uint32_t ref_node_key2(int i, int j) {
+  const uint32_t blk = spread_every_second((uint32_t)(i >> 3)) | (spread_every_second((uint32_t)(j >> 4)) << 1);
+  return (blk << 7) | (uint32_t)(((i & 7) << 4) | (j & 15));
+}
+__device__ __forceinline__ void sample_world2(const Rigid2 &B, const Sample2 &s, float p[2]) {
+  rot2(B.angle, s.off, p);
+  p[0] += B.pos[0]; p[1] += B.pos[1];
+}
+__global__ __launch_bounds__(256) void k2_ls_keys(float idx, const Rigid2 *__restrict__ rb, const Sample2 *__restrict__ smp, uint32_t n,
+                                                  const uint32_t *__restrict__ rank, unsigned long long *__restrict__ keys,
+                                                  uint32_t *__restrict__ vals) {
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    float p[2];
+    sample_world2(rb[smp[s].body], smp[s], p);
+    const int b0 = max((int)(p[0] * idx - 0.5f), 0), b1 = max((int)(p[1] * idx - 0.5f), 0);  // get_grid_base_pos (src/mpm.h:252-255)
+    keys[s] = ((unsigned long long)ref_node_key2(b0, b1) << 32) | rank[s];
+    vals[s] = s;
+  }
+}
+struct Restitution2 { float e[MAX_RIGID2]; };
+// one workgroup: batches of 1024 boundary particles are tested against the level set in parallel, the hits of a batch are
+// compacted IN ORDER, and one lane applies their impulses to the bodies (kept in LDS) one after the other
+__global__ __launch_bounds__(1024) void k2_ls_collide(Params P, LevelSetDev LS, Rigid2 *rb, int nb, const Sample2 *__restrict__ smp,
+                                                      const uint32_t *__restrict__ sorted, uint32_t n, uint32_t *__restrict__ rank,
+                                                      Restitution2 rest) {
+  struct Hit { int body; float r[2], g[2]; };
+  __shared__ Rigid2 sb[MAX_RIGID2];
+  __shared__ Hit hits[1024];
+  __shared__ int wave_n[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < nb) sb[t] = rb[t];
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += 1024) {
+    const uint32_t j = base + t;
+    bool hit = false;
+    Hit h;
+    h.body = 0;
+    if (j < n) {
+      const uint32_t s = sorted[j];
+      rank[s] = j;  // the position in this substep's order is the next substep's tie-break
+      const Sample2 sm = smp[s];
+      float p[2];
+      sample_world2(rb[sm.body], sm, p);
+      const float xw[3] = {p[0], p[1], 0.0f};
+      float phi, g[3] = {0, 0, 0};
+      if (mpm::levelset_eval(LS, P.t, xw, P.idx, phi, g) && phi < 0.0f) {
+        hit = true;
+        h.body = sm.body;
+        h.r[0] = p[0] - rb[sm.body].pos[0]; h.r[1] = p[1] - rb[sm.body].pos[1];
+        h.g[0] = g[0]; h.g[1] = g[1];
+      }
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wave_n[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0, total = 0;
+    for (int w = 0; w < 16; w++) { if (w < wave) off += wave_n[w]; total += wave_n[w]; }
+    if (hit) hits[off + __popcll(m & ((1ull << lane) - 1ull))] = h;
+    __syncthreads();
+    if (t == 0) {
+      for (int e = 0; e < total; e++) {
+        const Hit &H = hits[e];
+        Rigid2 &B = sb[H.body];
+        auto vel_at = [&](float v[2]) { v[0] = B.vel[0] - B.omega * H.r[1]; v[1] = B.vel[1] + B.omega * H.r[0]; };
+        auto contribution = [&](const float d[2]) {  // get_impulse_contribution: inv_mass + inv_inertia * cross(r, d)^2
+          const float c = H.r[0] * d[1] - H.r[1] * d[0];
+          return B.inv_mass + B.inv_I * c * c;
+        };
+        auto apply = [&](const float imp[2]) {
+          B.vel[0] += imp[0] * B.inv_mass; B.vel[1] += imp[1] * B.inv_mass;
+          B.omega += B.inv_I * (H.r[0] * imp[1] - H.r[1] * imp[0]);
+        };
+        float v10[2];
+        vel_at(v10);
+        const float v0 = H.g[0] * v10[0] + H.g[1] * v10[1];
+        const float J = -((1.0f + rest.e[H.body]) * v0) * (1.0f / contribution(H.g));
+        if (!(J >= 0.0f)) continue;  // (J < 0: separating; a body of infinite mass and inertia gives 0 / 0)
+        const float imp[2] = {J * H.g[0], J * H.g[1]};
+        apply(imp);
+        vel_at(v10);
+        const float vn = H.g[0] * v10[0] + H.g[1] * v10[1];
+        float tao[2] = {v10[0] - H.g[0] * vn, v10[1] - H.g[1] * vn};
+        if (fmaxf(fabsf(tao[0]), fabsf(tao[1])) > 1e-7f) {
+          const float il = 1.0f / sqrtf(tao[0] * tao[0] + tao[1] * tao[1]);
+          tao[0] *= il; tao[1] *= il;
+          const float fr = B.fric[0];
+          float jj = -(v10[0] * tao[0] + v10[1] * tao[1]) / contribution(tao);
+          jj = fminf(fmaxf(jj, fr * -J), fr * J);
+          const float fi[2] = {jj * tao[0], jj * tao[1]};
+          apply(fi);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (t >= 1 && t < nb) { rb[t].vel[0] = sb[t].vel[0]; rb[t].vel[1] = sb[t].vel[1]; rb[t].omega = sb[t].omega; }
+}
+
 // normalize_grid_and_apply_external_force + apply_grid_boundary_conditions — src/mpm.cpp:277-372
 __global__ __launch_bounds__(256) void k_grid(Params P, LevelSetDev LS, float *__restrict__ grid) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -2390,6 +2390,12 @@ struct mpmhip2d_ctx {
   uint32_t *d_tags = nullptr, *d_states = nullptr;
   mpm2d::Bnd2 *d_bnd = nullptr;
   float penalty = 0.0f, pushing_force = 20000.0f;
+  // rigid_body_levelset_collision: the boundary particles' order (see k2_ls_keys)
+  bool ls_collision = false;
+  uint32_t *d_smp_rank = nullptr, *d_ls_vals[2] = {nullptr, nullptr}, n_ranked = 0, ls_cap = 0;
+  unsigned long long *d_ls_keys[2] = {nullptr, nullptr};
+  void *d_ls_tmp = nullptr;
+  size_t ls_tmp_bytes = 0;
   mpm2d::Joints2 joints{};     // MPM<2>::articulations ('rotation' joints)
   int joint_iterations = 100;  // 'articulation_iterations'
   float base_dt = 0.0f;        // the configured "base_delta_t" (P.dt is what the next substep uses: the async stepper sets it per advance)
@@ -2481,6 +2487,8 @@ void mpmhip2d_destroy(mpmhip2d_ctx *m) {
   hipFree(m->n_dead); hipFree(m->d_groups);
   hipFree(m->d_rb); hipFree(m->d_smp); hipFree(m->d_elems); hipFree(m->d_mind); hipFree(m->d_tags); hipFree(m->d_states); hipFree(m->d_bnd);
   a2_free(m);
+  hipFree(m->d_smp_rank); hipFree(m->d_ls_tmp);
+  for (int k = 0; k < 2; k++) { hipFree(m->d_ls_keys[k]); hipFree(m->d_ls_vals[k]); }
   delete m;
 }
 
@@ -2594,6 +2602,44 @@ static int rigid2_pre(mpmhip2d_ctx *m) {
   HIPCHK2D(m, hipGetLastError());
   return MPMHIP_OK;
 }
+// rigid_body_levelset_collision(current_t, dt) (src/mpm_rigid_body.cpp:347-387), between normalize_grid and the grid boundary
+// condition (src/mpm.cpp:535-538); see do_rigid_ls_collision of rigid_api.h
+static int rigid2_ls_collision(mpmhip2d_ctx *m) {
+  const uint32_t n = (uint32_t)m->h_smp.size();
+  if (n == 0 || m->LS.n == 0) return MPMHIP_OK;
+  if (m->ls_cap < n) {
+    for (int k = 0; k < 2; k++) { (void)hipFree(m->d_ls_keys[k]); (void)hipFree(m->d_ls_vals[k]); m->d_ls_keys[k] = nullptr; m->d_ls_vals[k] = nullptr; }
+    (void)hipFree(m->d_ls_tmp); m->d_ls_tmp = nullptr; m->ls_tmp_bytes = 0;
+    const size_t cap = (size_t)n + n / 4 + 1024;
+    for (int k = 0; k < 2; k++) { HIPCHK2D(m, dmalloc(&m->d_ls_keys[k], cap)); HIPCHK2D(m, dmalloc(&m->d_ls_vals[k], cap)); }
+    size_t bytes = 0;
+    HIPCHK2D(m, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, m->d_ls_keys[0], m->d_ls_keys[1], m->d_ls_vals[0], m->d_ls_vals[1], (int)cap, 0, 64, m->stream));
+    HIPCHK2D(m, hipMalloc(&m->d_ls_tmp, bytes));
+    m->ls_tmp_bytes = bytes;
+    m->ls_cap = (uint32_t)cap;
+  }
+  if (m->n_ranked < n) {  // boundary particles added since: behind everybody else, in creation order (appended to `particles`)
+    std::vector<uint32_t> rk(n);
+    HIPCHK2D(m, hipStreamSynchronize(m->stream));
+    if (m->n_ranked) HIPCHK2D(m, hipMemcpy(rk.data(), m->d_smp_rank, sizeof(uint32_t) * m->n_ranked, hipMemcpyDeviceToHost));
+    for (uint32_t s = m->n_ranked; s < n; s++) rk[s] = s;
+    (void)hipFree(m->d_smp_rank); m->d_smp_rank = nullptr;
+    HIPCHK2D(m, dmalloc(&m->d_smp_rank, (size_t)n + n / 4 + 1024));
+    HIPCHK2D(m, hipMemcpy(m->d_smp_rank, rk.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    m->n_ranked = n;
+  }
+  hipLaunchKernelGGL(mpm2d::k2_ls_keys, dim3((n + 255) / 256), dim3(256), 0, m->stream, m->P.idx, (const mpm2d::Rigid2 *)m->d_rb,
+                     (const mpm2d::Sample2 *)m->d_smp, n, (const uint32_t *)m->d_smp_rank, m->d_ls_keys[0], m->d_ls_vals[0]);
+  size_t bytes = m->ls_tmp_bytes;
+  HIPCHK2D(m, hipcub::DeviceRadixSort::SortPairs(m->d_ls_tmp, bytes, m->d_ls_keys[0], m->d_ls_keys[1], m->d_ls_vals[0], m->d_ls_vals[1], (int)n, 0, 64, m->stream));
+  mpm2d::Restitution2 rest;
+  memset(&rest, 0, sizeof rest);
+  for (size_t b = 1; b < m->bodies.size(); b++) rest.e[b] = m->bodies[b].cfg.restitution;
+  hipLaunchKernelGGL(mpm2d::k2_ls_collide, dim3(1), dim3(1024), 0, m->stream, m->P, m->LS, m->d_rb, (int)m->bodies.size(),
+                     (const mpm2d::Sample2 *)m->d_smp, (const uint32_t *)m->d_ls_vals[1], n, m->d_smp_rank, rest);
+  HIPCHK2D(m, hipGetLastError());
+  return MPMHIP_OK;
+}
 static int rigid2_advect(mpmhip2d_ctx *m) {
   mpm2d::Steps2 st;
   memset(&st, 0, sizeof st);
@@ -2640,6 +2686,9 @@ static int substep2d(mpmhip2d_ctx *m) {
                        (const float *)m->B, (const float *)m->aux, (const int32_t *)m->gid, (const int32_t *)m->pid,
                        (const GroupParams *)m->d_groups, m->grid, R);
   if (R.enabled) hipLaunchKernelGGL(mpm2d::k2_rigid_apply_tmp, dim3(1), dim3(64), 0, m->stream, m->d_rb, (int)m->bodies.size());
+  if (R.enabled && m->ls_collision) {
+    if (int rc = rigid2_ls_collision(m)) return rc;
+  }
   hipLaunchKernelGGL(mpm2d::k_grid, gg, wg, 0, m->stream, m->P, m->LS, m->grid);
   if (m->n)
     hipLaunchKernelGGL(mpm2d::k_g2p, pg, wg, 0, m->stream, m->P, m->LS, m->n, m->x, m->v, m->F, m->B, m->aux, (const int32_t *)m->gid,
@@ -2654,6 +2703,11 @@ static int substep2d(mpmhip2d_ctx *m) {
 }
 
 // ---- CPIC rigid bodies in 2D: add_particles(type='rigid') of MPM<2> (src/mpm_rigid_body.cpp:130-252, dim = 2 branches)
+int mpmhip2d_set_rigid_levelset_collision(mpmhip2d_ctx *m, int32_t enabled) {
+  if (!m) return MPMHIP_EINVAL;
+  m->ls_collision = enabled != 0;
+  return MPMHIP_OK;
+}
 int mpmhip2d_set_rigid_coupling(mpmhip2d_ctx *m, float penalty, float pushing_force) {
   if (!m) return MPMHIP_EINVAL;
   m->penalty = penalty; m->pushing_force = pushing_force;

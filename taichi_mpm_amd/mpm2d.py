@@ -36,7 +36,7 @@ class Simulation2D:
         if "delta_t" in cfg:  # src/mpm.cpp:41-42
             raise MPMError("Please use 'base_delta_t' instead of 'delta_t'")
         check_unsupported_keys(cfg)
-        for k in ("benchmark_rasterize", "benchmark_resample", "rigid_body_levelset_collision"):  # (built for the 3D simulation only)
+        for k in ("benchmark_rasterize", "benchmark_resample"):  # (built for the 3D simulation only)
             if cfg.get(k, False):
                 raise MPMError("config key %r (src/mpm.cpp:516-538, 554-561) is not implemented by the 2D simulation" % k)
         res = cfg["res"]
@@ -81,6 +81,7 @@ class Simulation2D:
         self._ctx = ctx
         self._check(self._L.mpmhip2d_set_rigid_coupling(ctx, float(cfg.get("penalty", 0.0)), float(cfg.get("pushing_force", 20000.0))))
         self._check(self._L.mpmhip2d_set_articulation_iterations(ctx, int(cfg.get("articulation_iterations", 100))))  # src/mpm.h:279-280
+        self._check(self._L.mpmhip2d_set_rigid_levelset_collision(ctx, int(bool(cfg.get("rigid_body_levelset_collision", False)))))  # src/mpm.cpp:535-538
         d = float(cfg.get("dirichlet_boundary_radius", 0.0))  # src/mpm.cpp:541-544 -> apply_dirichlet_boundary_conditions, :374-399
         vel = float(cfg.get("dirichlet_boundary_velocity", 0.0))
         self._check(self._L.mpmhip2d_set_dirichlet(ctx, int(d > 0.0), float(cfg.get("dirichlet_distance_left", d)), float(cfg.get("dirichlet_distance_right", d)),

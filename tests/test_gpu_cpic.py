@@ -760,3 +760,46 @@ def test_rigid_body_levelset_collision_matches_the_live_reference(tm, friction, 
     assert cs.rigid_vector(free.rigid_state(rf))[8] < a[8] - 0.3     # ... keeps falling through the floor: the key is what stops the box
     r, h = ref.download(by_id=True), sim.get_particles(sort_by_id=True)
     assert np.abs(h["x"] - r["x"]).max() <= 2e-5 and rel_l2(h["v"], r["v"]) <= 1e-3
+
+
+@pytest.mark.parametrize("friction,restitution", [(0.0, 0.0), (0.4, 0.5)])
+def test_2d_rigid_body_levelset_collision_matches_the_live_reference(tm, friction, restitution):
+    """config rigid_body_levelset_collision in the 2D simulation (MPM<2>::rigid_body_levelset_collision, src/mpm_rigid_body.cpp:347-387):
+    a tilted, spinning free box thrown at a floor line and a side wall; the impulses go in the order of the reference's sorted
+    particle list (2D SPGrid key: 8 x 16-node blocks), so the body follows the reference through the contact"""
+    from oracle import refmpm
+    if not refmpm.available():
+        pytest.skip("oracle/_ref/libmpm_ref.so did not travel to this box")
+    from oracle import oracle as orc
+    refmpm.set_threads(1)
+    x, v = cs.block2(lo=24, hi=30)
+    x = x + np.float32([0.0, 0.22])   # a small jelly block above the box (so that material particles exist)
+    gp = orc.group_params("jelly", cs.MASS2, cs.VOL2)[0]
+    body = dict(codimensional=False, density=300.0, friction=friction, restitution=restitution, initial_position=(0.5, 0.385),
+                initial_rotation=17.0, initial_velocity=(0.6, -1.5), initial_angular_velocity=2.5)
+    shapes = [(0, 0, 0, 1, 0, -0.3), (0, 0, -1, 0, 0, 0.605)]   # floor y = 0.3, wall x = 0.605 (phi = 0.605 - x)
+    keys = dict(rigid_body_levelset_collision=True)
+    ref = refmpm.Sim(cs.RES2, cs.DX2, cs.DT, dim=2, gravity=(0, -10), shapes=shapes, friction=0.3, **keys)
+    rid = ref.add_rigid2(cs.box2(), **body)
+    ref.add_particles("jelly", cs.MASS2, cs.VOL2, x, v)
+    sim = tm.create_simulation2("mpm").initialize(dict(res=(cs.RES2,) * 2, delta_x=cs.DX2, base_delta_t=cs.DT, gravity=(0, -10),
+                                                       max_particles=len(x) + 16, **keys))
+    sim.set_levelset(tm.mpm.LevelSet(friction=0.3).add_plane((0, 1, 0), d=-0.3).add_plane((-1, 0, 0), d=0.605))
+    assert int(sim.add_particles(dict(type="rigid", mesh=cs.box2(), **body))) == rid
+    sim.add_particles(dict(type="jelly", positions=x, velocities=v, params=gp))
+    vy = []
+    for k in range(12):
+        ref.substep(25)
+        sim.run_substeps(25)
+        a, b = ref.rigid_state2(rid), sim.get_rigid_state(rid)
+        vy.append(float(a[4]))
+        np.testing.assert_allclose(b[0:3], a[0:3], rtol=0, atol=5e-5, err_msg="pose after %d substeps" % (25 * (k + 1)))
+        np.testing.assert_allclose(b[3:6], a[3:6], rtol=0, atol=2e-3 * max(np.abs(a[3:6]).max(), 1.0))
+    assert min(vy) < -1.55 and vy[-1] > min(vy) + 0.5, vy   # the box fell, hit the floor and was stopped / thrown back
+    free = refmpm.Sim(cs.RES2, cs.DX2, cs.DT, dim=2, gravity=(0, -10), shapes=shapes, friction=0.3)  # the same scene WITHOUT the key
+    rf = free.add_rigid2(cs.box2(), **body)
+    free.add_particles("jelly", cs.MASS2, cs.VOL2, x, v)
+    free.substep(300)
+    assert free.rigid_state2(rf)[4] < a[4] - 0.3     # ... keeps falling through the floor: the key is what stops the box
+    r, h = ref.download(by_id=True), sim.get_particles(sort_by_id=True)
+    assert np.abs(h["x"] - r["x"]).max() <= 2e-5 and rel_l2(h["v"], r["v"]) <= 1e-3

@@ -83,7 +83,9 @@ def test_physics_changing_keys_that_are_not_implemented_are_refused():
     with pytest.raises(tm.MPMError, match="not implemented"):
         tm.create_simulation2("mpm").initialize(dict(res=(32, 32), cdf_expand=2))
     with pytest.raises(tm.MPMError, match="not implemented by the 2D"):
-        tm.create_simulation2("mpm").initialize(dict(res=(32, 32), rigid_body_levelset_collision=True))
+        tm.create_simulation2("mpm").initialize(dict(res=(32, 32), benchmark_resample=True))
+    tm.create_simulation2("mpm").initialize(dict(res=(32, 32), rigid_body_levelset_collision=True))  # (implemented in both dimensions)
+    assert tm.create_simulation2("async_mpm").initialize(dict(res=(64, 64))).nb == (9, 5)  # TC_IMPLEMENTATION(Simulation2D, AsyncMPM2D, "async_mpm")
     tm.create_simulation3("mpm").initialize(dict(res=(32, 32, 32), rigid_body_levelset_collision=False, coupling_iterations=1))  # inert values pass
     assert tm.create_simulation3("mpm").initialize(dict(res=(32, 32, 32), dirichlet_boundary_radius=0.1)).dirichlet  # (implemented: src/mpm.cpp:401-412)
 
