@@ -484,6 +484,12 @@ def main():
                 native_wire = args.wire
                 wire = {"rccl": "RCCL: ncclSend / ncclRecv groups issued by libmpmhip (no Python in the substep loop)",
                         "ipc": "IPC peer writes into mapped receive buffers + epoch flags (no collective, no Python in the substep loop)"}[args.wire]
+            elif args.wire == "rccl" and os.environ.get("MPMHIP_NO_IPC_FALLBACK") != "1":
+                # still a native data plane: the library's IPC peer writes need no collective library at all (handles over gloo)
+                print("bench.py[rank %d]: the RCCL wire could not be brought up (%s); using the library's IPC wire" %
+                      (rank, why or "failed on another rank"), file=sys.stderr, flush=True)
+                native_wire = "ipc"
+                wire = "IPC peer writes into mapped receive buffers + epoch flags (no collective, no Python in the substep loop; the RCCL probe failed)"
             else:
                 msg = "bench.py[rank %d]: the RCCL wire could not be brought up (%s)" % (rank, why or "failed on another rank")
                 if not args.allow_staged:

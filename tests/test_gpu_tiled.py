@@ -563,13 +563,14 @@ def test_two_ranks_on_two_gpus_over_the_native_wires_match_one_ctx(tm, wire, ove
 
 
 @pytest.mark.parametrize("nproc,bricks,hook,config", [(2, "2x1x1", "gloo", "c2"), (8, "2x2x2", "ipc", "c2"), (2, "2x1x1", "staged", "c2"),
-                                                       (2, "2x1x1", "refuse", "c2"), (8, "2x2x2", "ipc", "c5")])
+                                                       (2, "2x1x1", "refuse", "c2"), (2, "2x1x1", "fallback", "c2"), (8, "2x2x2", "ipc", "c5")])
 def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks, hook, config):
     """`bench.py --gpus N` exactly as the driver launches it (torch.distributed.run, one process per rank) on a box with fewer
     GPUs than ranks.  hook "ipc" (MPMHIP_BENCH_BACKEND=ipc): the ranks share this GPU and run the library's own data plane over
     the IPC wire — native loop, peer writes, native migration; "gloo": the round-3 Python path staged through gloo.  Without
-    a hook the RCCL probe fails (two ranks on one device): the job must EXIT NON-ZERO ("refuse") rather than silently turn a
-    scaling run into a host-staged one, unless --allow-staged is given ("staged").  Checks the ONE-JSON-line contract and the
+    a hook the RCCL probe fails (two ranks on one device): the job then takes the library's IPC wire — still a native data plane
+    ("fallback") — and, with that ruled out too (MPMHIP_NO_IPC_FALLBACK=1), must EXIT NON-ZERO ("refuse") rather than silently
+    turn a scaling run into a host-staged one, unless --allow-staged is given ("staged").  Checks the ONE-JSON-line contract and the
     whole-job aggregation of the N > 1 path.  config c5 = BASELINE configs[4] (512^3 grid, 8 clusters, two materials) tiled over 8
     ranks, at a reduced cluster size (--cells 16)."""
     import json
@@ -586,6 +587,9 @@ def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks, hook, co
     if hook in ("gloo", "ipc"):
         env["MPMHIP_BENCH_BACKEND"] = hook
     env.setdefault("MPMHIP_TILE_WAIT_S", "20")
+    env.pop("MPMHIP_NO_IPC_FALLBACK", None)
+    if hook in ("refuse", "staged"):
+        env["MPMHIP_NO_IPC_FALLBACK"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--config", config,
            "--steps", "8", "--warmup", "4"] + (["--cells", "16"] if config == "c5" else []) + (["--allow-staged"] if hook == "staged" else [])
@@ -603,8 +607,9 @@ def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks, hook, co
     assert ("REDUCED" in d["config"]["workload"]) == (config == "c5")
     assert d["value"] > 0 and d["unit"] == "particle-steps/s" and d["roofline"]["kernel"] in ("k_g2p", "k_p2g")
     assert bricks + " bricks" in d["config"]["parallelism"]
-    if hook == "ipc":
+    if hook in ("ipc", "fallback"):
         assert d["config"]["wire"].startswith("IPC peer writes") and "library's own data plane" in d["config"]["parallelism"]
+        assert ("RCCL probe failed" in d["config"]["wire"]) == (hook == "fallback")
     else:
         assert d["config"]["wire"].startswith("gloo") and ("probe failed" in d["config"]["wire"]) == (hook == "staged")
     ov = d["config"]["overlap_split"]  # both ways timed before the measurement, the faster one kept (bench.py)
