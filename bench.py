@@ -468,7 +468,10 @@ def main():
             native_wire, wire = "ipc", "IPC peer writes (test hook: the ranks share the visible GPUs), handles over gloo"
         else:
             ok, why = True, ""
-            if args.wire in ("rccl", "torch") and os.environ.get("MPMHIP_SKIP_RCCL_PROBE") != "1":
+            if args.wire in ("rccl", "torch") and world > torch.cuda.device_count():
+                # (one node by contract: ranks then share devices, which RCCL refuses — after a long rendezvous; say so at once)
+                ok, why = False, "%d ranks on %d visible devices: RCCL does not take two ranks on one device" % (world, torch.cuda.device_count())
+            elif args.wire in ("rccl", "torch") and os.environ.get("MPMHIP_SKIP_RCCL_PROBE") != "1":
                 # probe the transport in a CHILD process per rank (a hang or an abort inside RCCL then costs the child and a
                 # bounded wait); every rank must see it work
                 dog.phase("RCCL probe", 240)
