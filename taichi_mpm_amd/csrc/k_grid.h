@@ -25,9 +25,14 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
                                               const float4 *__restrict__ tiles, float4 *__restrict__ gridv,
                                               uint32_t *__restrict__ fat_slot, float4 *__restrict__ dense, Tiling T,
                                               const DevBox *__restrict__ boxes, LevelSetDev LS, int phase) {
-  const uint32_t na = min(cnt->n_active, P.max_blocks);
+  const uint32_t na_dev = cnt->n_active;
   const int l = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  // (the first work item's block key is requested before the number of active blocks is known: act_blk has max_blocks entries)
+  const uint32_t a_first = PER_CAND ? wave >> 3 : wave;
+  uint32_t key_first = 0;
+  if (a_first < P.max_blocks) key_first = act_blk[a_first];
+  const uint32_t na = min(na_dev, P.max_blocks);
   const int lx = l >> 4, ly = (l >> 2) & 3, lz = l & 3;
   // The kernel is a chain of dependent lookups (block list -> bitmap/prefix -> tiles -> halo -> store).
   // PER_CAND = false: one wavefront per active block walks its 8 candidates (lookups shared; best when there are
@@ -39,7 +44,7 @@ __global__ __launch_bounds__(256) void k_grid(Params P, const Counters *__restri
     const uint32_t a = PER_CAND ? work >> 3 : work;
     const int o_mine = PER_CAND ? (int)(work & 7u) : -1;
     int bx, by, bz;
-    demorton3(act_blk[a], bx, by, bz);
+    demorton3(work == wave ? key_first : act_blk[a], bx, by, bz);
     // neighbour table: lane n < 27 holds (active?, slot) of block b + (n/9-1, n/3%3-1, n%3-1)
     uint32_t nslot = INVALID;
     if (l < 27) {
