@@ -11,6 +11,7 @@
 #include <random>
 
 #include "mpm_amd/mpm.h"
+#include "mpm_amd/mpm2d.h"
 #include "mpm_amd/mpm88.h"
 
 using namespace mpm_amd;
@@ -98,6 +99,65 @@ static void cpu_tests() {
       CHECK(threw);
       CHECK(msg.find("HIP") != std::string::npos);
     }
+  }
+  {  // the 2D factory: TC_IMPLEMENTATION(Simulation2D, MPM2D, "mpm") / (Simulation2D, AsyncMPM2D, "async_mpm")
+    CHECK(create_simulation2("mpm")->get_name() == "mpm" && create_simulation2("async_mpm")->get_name() == "async_mpm");
+    bool threw = false;
+    try { create_simulation2("custard"); } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw);
+    threw = false;
+    try { create_simulation2("mpm")->initialize(Config().set("res", "64,64").set("delta_t", 1e-3)); } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw);
+  }
+}
+
+static void gpu_tests_2d() {
+  {  // MPM<2>: a jelly square in free fall above a floor line
+    auto sim = create_simulation2("mpm");
+    sim->initialize(Config().set("res", "64,64").set("base_delta_t", 1e-4).set("gravity", "0,-10"));
+    mpmhip_shape floor{};
+    floor.type = 0; floor.p[1] = 1.0f; floor.p[3] = -0.2f;  // phi = y - 0.2
+    sim->set_levelset(std::vector<mpmhip_shape>{floor}, 0.4f);
+    CHECK(sim->add_particles(Config().set("type", "jelly").set("square_lo", 24).set("square_hi", 40)) == "");
+    CHECK(sim->get_num_particles() == 16 * 16 * 4);
+    sim->step(-1.0f);
+    CHECK(std::fabs(sim->get_current_time() - 1e-4f) < 1e-9f);
+    sim->step(2e-3f);
+    const auto ps = sim->get_particles();
+    CHECK((int64_t)ps.size() == 16 * 16 * 4 && ps.front().id == 0 && ps.back().id == 16 * 16 * 4 - 1);
+    double vy = 0;
+    for (auto &q : ps) vy += q.velocity[1];
+    vy /= ps.size();
+    CHECK(vy < -0.015 && vy > -0.025);  // ~20 substeps of free fall
+    bool threw = false;
+    try { sim->add_articulation(Config().set("type", "motor").set("obj0", 1)); } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw);
+  }
+  {  // AsyncMPM<2>: a stiff and a soft square side by side step with their own powers of two of unit_delta_t
+    auto as = create_simulation2("async_mpm");
+    as->initialize(Config().set("res", "128,128").set("unit_delta_t", 2e-6).set("max_units", 1024).set("gravity", "0,-10"));
+    as->add_particles(Config().set("type", "elastic").set("square_lo", 30).set("square_hi", 54));
+    as->add_particles(Config().set("type", "sand").set("square_lo", 54).set("square_hi", 78));
+    const int64_t n0 = 2 * 24 * 24 * 4;
+    CHECK(as->get_num_particles() == n0);
+    as->step(2e-3f);
+    as->step(2e-3f);
+    auto *a = dynamic_cast<AsyncMPM2D *>(as.get());
+    CHECK(a && a->current_t_int() >= 2000 && a->update_counter() > n0);
+    CHECK(as->get_current_time() >= 4e-3f);
+    const auto ps = as->get_particles();
+    CHECK((int64_t)ps.size() >= n0);  // an id can sit in more than one pool
+    bool finite = true;
+    int32_t max_id = -1;
+    for (auto &q : ps) { finite = finite && std::isfinite(q.position[1]) && std::isfinite(q.F[0]); max_id = std::max(max_id, q.id); }
+    CHECK(finite && max_id == n0 - 1);
+    bool threw = false;
+    try { as->substep(); } catch (const std::exception &) { threw = true; }
+    CHECK(threw);
+    threw = false;
+    const float seg[4] = {-0.05f, 0.0f, 0.05f, 0.0f};
+    try { as->add_rigid_body(Config().set("codimensional", true).set("initial_position", "0.5,0.8"), 1, seg); } catch (const std::exception &) { threw = true; }
+    CHECK(threw);
   }
 }
 
@@ -288,7 +348,7 @@ int main(int argc, char **argv) {
   const std::string mode = argc > 1 ? argv[1] : "cpu";
   try {
     if (mode == "cpu") cpu_tests();
-    else gpu_tests();
+    else { gpu_tests(); gpu_tests_2d(); }
   } catch (const std::exception &e) {
     std::printf("unexpected exception: %s\n", e.what());
     return 2;

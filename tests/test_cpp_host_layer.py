@@ -1,4 +1,4 @@
-"""The C++ host layer (include/mpm_amd/*.h: MPMKernel, particle registry, MPM<3>) compiled with g++ against
+"""The C++ host layer (include/mpm_amd/*.h: MPMKernel, particle registry, MPM<3>, MPM<2>, the asynchronous steppers) compiled with g++ against
 libmpmhip.so.  CPU mode: the reference's kernel known-answer tests + registry + "no GPU => throws".  GPU mode:
 MPM<3> end to end on the device."""
 import os
@@ -15,7 +15,7 @@ def _build():
     from taichi_mpm_amd import _lib
     lib = _lib.build()
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    deps = [SRC] + [os.path.join(ROOT, "include", "mpm_amd", h) for h in ("kernel.h", "particles.h", "mpm.h")] + [lib]
+    deps = [SRC] + [os.path.join(ROOT, "include", "mpm_amd", h) for h in ("kernel.h", "particles.h", "mpm.h", "mpm2d.h")] + [lib]
     if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
         libdir = os.path.dirname(lib)
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), SRC, "-o", OUT,
