@@ -65,6 +65,9 @@ class MPM<2> {
     c.particle_collision = config.get("particle_collision", false);
     c.max_particles = (int64_t)config.get("max_particles", (double)(1 << 20));
     c.device = config.get("device", 0);
+    verbose_bgeo = config.get("verbose_bgeo", false);   // src/visualize.cpp:22
+    frame_directory = config.get("frame_directory", "");  // injected by the python driver, async_mpm.py:49
+    frame_count = 0;
     check(mpmhip2d_create(&c, &ctx_), nullptr);
     check(mpmhip2d_set_rigid_coupling(ctx_, config.get("penalty", 0.0f), config.get("pushing_force", 20000.0f)), ctx_);
     check(mpmhip2d_set_articulation_iterations(ctx_, config.get("articulation_iterations", 100)), ctx_);
@@ -187,13 +190,27 @@ class MPM<2> {
     check(mpmhip2d_download_grid(ctx_, g.data()), ctx_);
     return g;
   }
+  // --- frame output: visualize() -> write_bgeo() -> write_partio(file) (src/visualize.cpp:156-159, src/mpm.h:333-337,
+  // src/visualize.cpp:17-100): the same .bgeo as the 3D simulation writes, z = 0; with the asynchronous stepper every container of
+  // every particle pool with its block's limits
+  void write_partio(const std::string &file_name) const { check(mpmhip2d_write_bgeo(ctx_, file_name.c_str(), verbose_bgeo), ctx_); }
+  std::string write_bgeo() {
+    if (frame_directory.empty()) throw std::runtime_error("write_bgeo() needs the config key 'frame_directory'");
+    char name[32];
+    std::snprintf(name, sizeof name, "/%04d.bgeo", ++frame_count);  // frames start at 1 (src/mpm.h:334-336)
+    write_partio(frame_directory + name);
+    return frame_directory + name;
+  }
+  void visualize() { write_bgeo(); }
   bool test() const { return true; }
   virtual std::string get_name() const { return "mpm"; }
   mpmhip2d_ctx *ctx() const { return ctx_; }
 
   VectorI res;
   real delta_x = 0, base_delta_t = 0;
-  int frame = 0;
+  int frame = 0, frame_count = 0;
+  bool verbose_bgeo = false;
+  std::string frame_directory;
 
  protected:
   std::vector<Particle2D> particles_of_arrays() const {

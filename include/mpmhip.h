@@ -499,6 +499,13 @@ int64_t mpmhip2d_download(mpmhip2d_ctx *ctx, int64_t capacity, float *x, float *
                           int32_t *id);            /* live particles in slot order; NULL outputs are skipped; returns n */
 int mpmhip2d_download_grid(mpmhip2d_ctx *ctx, float *grid /* [(res0+1)(res1+1)][3] = (v.x, v.y, m) */);
 
+/* frame output of the 2D simulation — replaces MPM<2>::write_partio (src/visualize.cpp:17-100): the same .bgeo as the 3D
+ * entry points above (z = 0), boundary particles of rigid bodies as rows of type 1; with a resident asynchronous stepper the rows
+ * are the containers of every particle pool with their block's limits (src/async/async_visualize.cpp:17-26,86-96) */
+int mpmhip2d_bgeo_size(mpmhip2d_ctx *ctx, int32_t verbose, size_t *bytes);
+int mpmhip2d_bgeo_encode(mpmhip2d_ctx *ctx, int32_t verbose, void *dst, size_t capacity, size_t *written);
+int mpmhip2d_write_bgeo(mpmhip2d_ctx *ctx, const char *path, int32_t verbose);
+
 /* ---- AsyncMPM<2> — replaces create_simulation2('async_mpm') (TC_IMPLEMENTATION(Simulation2D, AsyncMPM2D, "async_mpm"),
  * src/async/async_mpm.cpp:423-427): the asynchronous stepper of mpmhip_async_begin / _step above for the 2D simulation
  * object.  A scheduler block is the reference's 2D SPGrid block, 8 x 16 nodes (SPGrid_Mask<5, 5, 2>); the block scheduler

@@ -157,7 +157,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_set_profile_sampling", "mpmhip_create"
             "mpmhip2d_create", "mpmhip2d_destroy", "mpmhip2d_last_error", "mpmhip2d_set_levelset", "mpmhip2d_add_group", "mpmhip2d_add_particles",
             "mpmhip2d_substep", "mpmhip2d_step", "mpmhip2d_current_time", "mpmhip2d_num_particles", "mpmhip2d_download", "mpmhip2d_download_grid",
             "mpmhip2d_async_begin", "mpmhip2d_async_pool_particles", "mpmhip2d_async_step", "mpmhip2d_async_load_pools", "mpmhip2d_async_view_blocks",
-            "mpmhip2d_async_state", "mpmhip2d_async_current_time", "mpmhip2d_async_table",
+            "mpmhip2d_async_state", "mpmhip2d_async_current_time", "mpmhip2d_async_table", "mpmhip2d_bgeo_size", "mpmhip2d_bgeo_encode", "mpmhip2d_write_bgeo",
             "mpmhip2d_set_rigid_coupling", "mpmhip2d_set_rigid_levelset_collision", "mpmhip2d_add_articulation", "mpmhip2d_set_articulation_iterations", "mpmhip2d_add_rigid_body", "mpmhip2d_rigid_get_state", "mpmhip2d_rigid_get_samples", "mpmhip2d_cdf_phase",
             "mpmhip2d_download_cdf", "mpmhip2d_download_colours",
             "mpmhip_set_rigid_coupling", "mpmhip_add_rigid_body", "mpmhip_num_rigid_bodies", "mpmhip_rigid_get_state", "mpmhip_rigid_set_velocity",
@@ -324,6 +324,9 @@ def load():
     L.mpmhip2d_download.argtypes = [vp, C.c_int64, fp, fp, fp, fp, fp, ip, ip]
     L.mpmhip2d_download.restype = C.c_int64
     L.mpmhip2d_download_grid.argtypes = [vp, fp]
+    L.mpmhip2d_bgeo_size.argtypes = [vp, C.c_int32, P(C.c_size_t)]
+    L.mpmhip2d_bgeo_encode.argtypes = [vp, C.c_int32, vp, C.c_size_t, P(C.c_size_t)]
+    L.mpmhip2d_write_bgeo.argtypes = [vp, C.c_char_p, C.c_int32]
     L.mpmhip2d_async_begin.argtypes = [vp, P(AsyncConfig)]
     L.mpmhip2d_async_pool_particles.argtypes = [vp]
     L.mpmhip2d_async_step.argtypes = [vp, C.c_float]

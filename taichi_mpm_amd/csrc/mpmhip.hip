@@ -2382,6 +2382,7 @@ struct mpmhip2d_ctx {
   bool rigid_enabled = false;
   std::vector<HostRigid2> bodies;
   std::vector<mpm2d::Sample2> h_smp;
+  std::vector<int32_t> h_smp_id;  // creation id of every boundary particle (they share the material particles' counter)
   std::vector<float> h_elems;
   mpm2d::Rigid2 *d_rb = nullptr;
   mpm2d::Sample2 *d_smp = nullptr;
@@ -2789,7 +2790,7 @@ int mpmhip2d_add_rigid_body(mpmhip2d_ctx *m, const mpmhip2d_rigid_config *cfg, i
       s.body = body; s.elem = (int)(elem0 + e);
       const float w[2] = {(cs * s.off[0] - sn * s.off[1] + D.pos[0]) * m->P.idx, (sn * s.off[0] + cs * s.off[1] + D.pos[1]) * m->P.idx};
       const bool near_wall = w[0] < 7.0f || w[1] < 7.0f || w[0] - m->P.res[0] > -7.0f || w[1] - m->P.res[1] > -7.0f;
-      if (!near_wall) m->h_smp.push_back(s);
+      if (!near_wall) { m->h_smp.push_back(s); m->h_smp_id.push_back(m->next_pid + allocated); }
       allocated++;
     }
   }
@@ -2999,6 +3000,7 @@ int mpmhip2d_download_grid(mpmhip2d_ctx *m, float *grid) {  // (v.x, v.y, m) per
 }
 
 #include "async2d_api.h"
+#include "frame2d_api.h"
 
 // ------------------------------------------------------------------------------------------------ debug math
 int mpmhip_debug_svd3(mpmhip_ctx *c, int64_t n, const float *F, float *U, float *S, float *V) {

@@ -3,6 +3,7 @@ mpmhip2d_* entry points of the C ABI (include/mpmhip.h).  Same surface as Simula
 applies: `initialize`, `add_particles`, `set_levelset`, `step`, `get_current_time`, `get_particles`.  MPM<2> runs the
 generic transfer path (src/transfer.cpp:280-283,697-700)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -50,6 +51,9 @@ class Simulation2D:
         self.gravity = (float(g[0]), float(g[1]))
         self.config = cfg
         self.max_particles = int(cfg.get("max_particles", 0))
+        self.verbose_bgeo = bool(cfg.get("verbose_bgeo", False))  # src/visualize.cpp:22
+        self.frame_directory = cfg.get("frame_directory")  # injected by the python driver, async_mpm.py:49
+        self.frame_count = 0
         return self
 
     def _check(self, rc):
@@ -364,5 +368,32 @@ class Simulation2D:
             return self.add_articulation(config)
         raise MPMError("general_action(%r) is not part of the 2D build" % (config.get("action"),))
 
+    def write_partio(self, file_name):
+        """MPM<2>::write_partio (src/visualize.cpp:17-100): the same Houdini .bgeo as the 3D simulation writes, z = 0
+        (include/mpmhip.h: mpmhip2d_write_bgeo)"""
+        self._ensure_ctx()
+        self._check(self._L.mpmhip2d_write_bgeo(self._ctx, os.fsencode(file_name), int(self.verbose_bgeo)))
+
+    def bgeo_bytes(self, verbose=None):
+        """the .bgeo image of the current state as bytes (no file)"""
+        self._ensure_ctx()
+        verbose = int(self.verbose_bgeo if verbose is None else verbose)
+        n = C.c_size_t()
+        self._check(self._L.mpmhip2d_bgeo_size(self._ctx, verbose, C.byref(n)))
+        buf = np.empty(n.value, np.uint8)
+        w = C.c_size_t()
+        self._check(self._L.mpmhip2d_bgeo_encode(self._ctx, verbose, buf.ctypes.data_as(C.c_void_p), n.value, C.byref(w)))
+        return buf[:w.value].tobytes()
+
     def visualize(self):
-        raise MPMError("frame output is implemented for the 3D simulation")
+        """MPM<2>::visualize -> write_bgeo (src/visualize.cpp:156-159, src/mpm.h:333-343): the next `frame_directory/%04d.bgeo`
+        (frame numbers start at 1) and every rigid body's outline next to it"""
+        if not self.frame_directory:
+            raise MPMError("visualize() needs the config key 'frame_directory'")
+        self.frame_count += 1
+        os.makedirs(self.frame_directory, exist_ok=True)
+        path = os.path.join(self.frame_directory, "%04d.bgeo" % self.frame_count)
+        self.write_partio(path)
+        for rid in range(1, len(self._rigids) + 1):
+            self.write_rigid_body(rid, os.path.join(self.frame_directory, "rigid_%03d_%04d" % (rid, self.frame_count)))
+        return path

@@ -129,6 +129,17 @@ static void gpu_tests_2d() {
     for (auto &q : ps) vy += q.velocity[1];
     vy /= ps.size();
     CHECK(vy < -0.015 && vy > -0.025);  // ~20 substeps of free fall
+    {  // the frame file: "Bgeo" magic, version 5, one row per particle
+      const std::string path = "/tmp/mpm_amd_host_layer_2d.bgeo";
+      sim->write_partio(path);
+      FILE *f = std::fopen(path.c_str(), "rb");
+      unsigned char h[13] = {0};
+      CHECK(f && std::fread(h, 1, 13, f) == 13);
+      if (f) std::fclose(f);
+      CHECK(h[0] == 'B' && h[1] == 'g' && h[2] == 'e' && h[3] == 'o' && h[4] == 'V' && h[8] == 5);
+      CHECK(((h[9] << 24) | (h[10] << 16) | (h[11] << 8) | h[12]) == 16 * 16 * 4);
+      std::remove(path.c_str());
+    }
     bool threw = false;
     try { sim->add_articulation(Config().set("type", "motor").set("obj0", 1)); } catch (const std::runtime_error &) { threw = true; }
     CHECK(threw);

@@ -180,3 +180,96 @@ def test_the_frame_loop_resumes_at_the_loaded_frame(tm, tmp_path):
     assert abs(b.get_current_time() - a.get_current_time()) < 1e-6
     pa, pb = a.c.get_particles(), b.c.get_particles()
     assert np.array_equal(pa["id"], pb["id"]) and np.abs(pa["x"] - pb["x"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("verbose", [False, True])
+def test_2d_bgeo_bytes_equal_the_live_reference_partio_writer(tm, tmp_path, verbose):
+    """MPM<2>::write_partio (src/visualize.cpp:17-100; z = 0) of the 2D simulation: byte for byte against the file the reference's
+    own 2D simulation writes through its Partio for the same particle state (water + elastic: the two types with a non-trivial
+    `debug` attribute), then row by row after three substeps on both sides"""
+    from oracle import refmpm
+    if not refmpm.available():
+        pytest.skip("oracle/_ref/libmpm_ref.so did not travel to this box")
+    from tests.golden.make_golden import mpm2d_state
+    refmpm.set_threads(1)
+    res, dx, dt = 64, 1.0 / 64, 1e-4
+    vol = dx * dx / 4
+    xa, va, Fa, Ba = mpm2d_state(res, lo=(16, 24), cells=12, seed=11)
+    xb, vb, Fb, Bb = mpm2d_state(res, lo=(34, 24), cells=12, seed=12)
+    Ba = np.round(Ba * 256) / 256  # dyadic apic_b: the Frobenius norm of the verbose file is then independent of the summation order
+    Bb = np.round(Bb * 256) / 256
+    gpa, gpb = group_params("water", 400 * vol, vol)[0], group_params("elastic", 400 * vol, vol)[0]
+    ref = refmpm.Sim(res, dx, dt, dim=2, gravity=(0, -10), shapes=[(0, 0, 0, 1, 0, -0.2)], friction=0.4, verbose_bgeo=verbose)
+    sim = tm.create_simulation2("mpm").initialize(dict(res=(res, res), delta_x=dx, base_delta_t=dt, gravity=(0, -10), verbose_bgeo=verbose,
+                                                       frame_directory=str(tmp_path / "frames")))
+    sim.set_levelset(tm.mpm.LevelSet(friction=0.4).add_plane((0, 1, 0), d=-0.2))
+    aux_w = np.full(len(xa), 1.0, np.float32)
+    ref.add_particles("water", gpa[0], gpa[1], xa, va, Fa, Ba, aux_w)
+    ref.add_particles("elastic", gpb[0], gpb[1], xb, vb, Fb, Bb, None)
+    sim.add_particles(dict(type="water", positions=xa, velocities=va, F=Fa, B=Ba, aux=aux_w, params=gpa))
+    sim.add_particles(dict(type="elastic", positions=xb, velocities=vb, F=Fb, B=Bb, params=gpb))
+    path = str(tmp_path / "ref.bgeo")
+    ref.write_bgeo(path)
+    want = open(path, "rb").read()
+    got = sim.bgeo_bytes()
+    assert got == want
+    assert open(sim.visualize(), "rb").read() == want and sim.frame_count == 1  # frames start at 0001.bgeo (src/mpm.h:334-336)
+    ref.substep(3)
+    sim.run_substeps(3)
+    ref.write_bgeo(path)
+    a, b = bgeo_reader.parse(sim.bgeo_bytes()), bgeo_reader.parse(open(path, "rb").read())
+    assert a["attrs"] == b["attrs"] and np.array_equal(a["data"]["index"], b["data"]["index"])
+    assert np.abs(a["position"] - b["position"]).max() <= 5e-7 and np.all(a["position"][:, 2] == 0)
+    assert np.abs(np.asarray(a["data"]["v"]) - np.asarray(b["data"]["v"])).max() <= 2e-4
+    sim.close(); ref.close()
+
+
+def test_2d_frames_of_a_scene_with_a_rigid_body_and_of_the_async_stepper(tm, tmp_path):
+    """(i) the boundary particles of a 2D rigid body are rows of type 1 with ids from the shared creation counter, in ascending-id
+    order among the material particles' rows, as in the reference's file; (ii) a frame of the asynchronous stepper lists every
+    container of every pool with its block's limits (src/async/async_visualize.cpp:17-26,86-96)"""
+    from oracle import refmpm
+    if not refmpm.available():
+        pytest.skip("oracle/_ref/libmpm_ref.so did not travel to this box")
+    import tests.cpic_scenes as cs
+    refmpm.set_threads(1)
+    x, v = cs.block2()
+    body = dict(cs.BODIES2["box"])
+    ref = refmpm.Sim(cs.RES2, cs.DX2, cs.DT, dim=2, gravity=(0, -10))
+    sim = tm.create_simulation2("mpm").initialize(dict(res=(cs.RES2,) * 2, delta_x=cs.DX2, base_delta_t=cs.DT, gravity=(0, -10),
+                                                       max_particles=len(x) + 16, frame_directory=str(tmp_path / "f")))
+    ref.add_particles("jelly", cs.MASS2, cs.VOL2, x[:100], v[:100])   # ids 0..99, then the body's boundary particles, then the rest
+    sim.add_particles(dict(type="jelly", positions=x[:100], velocities=v[:100]))
+    kw = dict(body)
+    ref.add_rigid2(kw.pop("mesh"), **kw)
+    sim.add_particles(dict(type="rigid", **body))
+    ref.add_particles("jelly", cs.MASS2, cs.VOL2, x[100:], v[100:])
+    sim.add_particles(dict(type="jelly", positions=x[100:], velocities=v[100:]))
+    path = str(tmp_path / "ref.bgeo")
+    ref.write_bgeo(path)
+    a, b = bgeo_reader.parse(sim.bgeo_bytes()), bgeo_reader.parse(open(path, "rb").read())
+    assert np.array_equal(a["data"]["index"], b["data"]["index"]) and np.array_equal(a["data"]["type"], b["data"]["type"])
+    t = np.asarray(b["data"]["type"]).reshape(-1)
+    assert 0 < t.sum() < len(t) and t[:100].sum() == 0 and t[100] == 1
+    assert np.abs(a["position"] - b["position"]).max() <= 1e-6
+    assert np.abs(np.asarray(a["data"]["v"]) - np.asarray(b["data"]["v"])).max() <= 1e-5
+    frame = sim.visualize()
+    assert os.path.exists(frame) and os.path.exists(os.path.join(os.path.dirname(frame), "rigid_001_0001.poly"))
+    sim.close(); ref.close()
+    # (ii)
+    from tests.test_gpu_async2d import _two_stiffness_scene_2d
+    res, dx, groups = _two_stiffness_scene_2d(tm)
+    kw = dict(unit_delta_t=2e-6, max_units=1024)
+    asim = tm.create_simulation2("async_mpm").initialize(dict(res=(res, res), delta_x=dx, **kw))
+    asim.set_levelset(tm.mpm.LevelSet(friction=0.4).add_plane((0, 1, 0), d=-0.2))
+    for mat, gp, xx, vv, F, B in groups:
+        asim.add_particles(dict(type=mat, positions=xx, velocities=vv, F=F, B=B, params=gp))
+    for _ in range(2):
+        asim.step(2.5e-3)
+    d = bgeo_reader.parse(asim.bgeo_bytes())["data"]
+    p = asim.get_pool_particles()
+    lim = np.asarray(d["limit"]).reshape(-1, 3)
+    assert np.array_equal(np.asarray(d["index"]).reshape(-1), p["id"])
+    assert np.array_equal(np.sort(lim[:, 0]), np.sort(p["continuous"])) and len(np.unique(lim[:, 0])) >= 2
+    assert (lim[:, 0] & (lim[:, 0] - 1)).max() == 0 and lim[:, 1].min() >= 1
+    asim.close()
