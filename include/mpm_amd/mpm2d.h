@@ -202,6 +202,35 @@ class MPM<2> {
     return frame_directory + name;
   }
   void visualize() { write_bgeo(); }
+  // --- MPM<2>::general_action (src/mpm.cpp:920-978): add_articulation, save / load (whole-state snapshot to / from "file_name";
+  // the scene — level set, configuration, the rigid bodies — is set up again before a load, as in the reference)
+  std::string general_action(const Config &config) {
+    const std::string action = config.get("action", "");
+    if (action == "add_articulation") return add_articulation(config);
+    if (action == "save" || action == "load") {
+      const std::string fn = config.get("file_name", "");
+      if (action == "save") {
+        const int64_t n = mpmhip2d_snapshot_size(ctx_);
+        check((int)std::min<int64_t>(n, 0), ctx_);
+        std::vector<char> buf((size_t)n);
+        check(mpmhip2d_snapshot_save(ctx_, buf.data(), buf.size()), ctx_);
+        FILE *f = std::fopen(fn.c_str(), "wb");
+        if (!f || std::fwrite(buf.data(), 1, buf.size(), f) != buf.size()) throw std::runtime_error("cannot write " + fn);
+        std::fclose(f);
+      } else {
+        FILE *f = std::fopen(fn.c_str(), "rb");
+        if (!f) throw std::runtime_error("cannot read " + fn);
+        std::fseek(f, 0, SEEK_END);
+        std::vector<char> buf((size_t)std::ftell(f));
+        std::fseek(f, 0, SEEK_SET);
+        if (std::fread(buf.data(), 1, buf.size(), f) != buf.size()) throw std::runtime_error("cannot read " + fn);
+        std::fclose(f);
+        check(mpmhip2d_snapshot_load(ctx_, buf.data(), buf.size()), ctx_);
+      }
+      return "";
+    }
+    throw std::runtime_error("general_action(action='" + action + "') is outside the scope of this build");
+  }
   bool test() const { return true; }
   virtual std::string get_name() const { return "mpm"; }
   mpmhip2d_ctx *ctx() const { return ctx_; }

@@ -505,6 +505,13 @@ int mpmhip2d_download_grid(mpmhip2d_ctx *ctx, float *grid /* [(res0+1)(res1+1)][
 int mpmhip2d_bgeo_size(mpmhip2d_ctx *ctx, int32_t verbose, size_t *bytes);
 int mpmhip2d_bgeo_encode(mpmhip2d_ctx *ctx, int32_t verbose, void *dst, size_t capacity, size_t *written);
 int mpmhip2d_write_bgeo(mpmhip2d_ctx *ctx, const char *path, int32_t verbose);
+/* snapshots of the 2D simulation — replaces MPM<2>::general_action(action = 'save' | 'load') (src/mpm.cpp:940-960; AsyncMPM<2>:
+ * every pool and the block table, src/async/async_mpm.h:120-172): groups, particles, clocks, the rigid bodies' records and joints,
+ * the asynchronous stepper's block tables and containers.  Loaded into an object of the same grid whose scene (level set,
+ * configuration, the rigid bodies' outlines and scripts, mpmhip2d_async_begin) has been set up again, as for the 3D snapshots. */
+int64_t mpmhip2d_snapshot_size(mpmhip2d_ctx *ctx);
+int mpmhip2d_snapshot_save(mpmhip2d_ctx *ctx, void *dst, size_t capacity);
+int mpmhip2d_snapshot_load(mpmhip2d_ctx *ctx, const void *src, size_t size);
 
 /* ---- AsyncMPM<2> — replaces create_simulation2('async_mpm') (TC_IMPLEMENTATION(Simulation2D, AsyncMPM2D, "async_mpm"),
  * src/async/async_mpm.cpp:423-427): the asynchronous stepper of mpmhip_async_begin / _step above for the 2D simulation

@@ -80,6 +80,16 @@ class RigidConfig2D(C.Structure):
                 ("scripted_rotation", SCRIPT_FN), ("rotation_user", C.c_void_p)]
 
 
+class Snap2DHeader(C.Structure):
+    """mirror of the header of a 2D snapshot blob (csrc/frame2d_api.h: Snap2D) — only its size and the first fields are used"""
+    _fields_ = [("magic", C.c_char * 8), ("abi", C.c_uint32), ("n_groups", C.c_uint32), ("res", C.c_int32 * 2), ("next_pid", C.c_int32),
+                ("n_bodies", C.c_int32), ("n_joints", C.c_int32), ("has_async", C.c_int32), ("n", C.c_int64), ("dx", C.c_float),
+                ("base_dt", C.c_float), ("t", C.c_float), ("request_t", C.c_float), ("n_dead", C.c_uint32), ("n_ranked", C.c_uint32),
+                ("nb", C.c_int32 * 2), ("unit_delta_t", C.c_float), ("a_request_t", C.c_float), ("a_current_t", C.c_float), ("pad", C.c_float),
+                ("nblk", C.c_int64), ("containers", C.c_int64), ("current_t_int", C.c_int64), ("min_delta_t_int", C.c_int64),
+                ("max_delta_t_int", C.c_int64), ("update_counter", C.c_int64), ("step_counter", C.c_int64)]
+
+
 class Config2D(C.Structure):
     """mirror of mpmhip2d_config"""
     _fields_ = [("res", C.c_int32 * 2), ("dx", C.c_float), ("dt", C.c_float), ("gravity", C.c_float * 2),
@@ -157,7 +167,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_set_profile_sampling", "mpmhip_create"
             "mpmhip2d_create", "mpmhip2d_destroy", "mpmhip2d_last_error", "mpmhip2d_set_levelset", "mpmhip2d_add_group", "mpmhip2d_add_particles",
             "mpmhip2d_substep", "mpmhip2d_step", "mpmhip2d_current_time", "mpmhip2d_num_particles", "mpmhip2d_download", "mpmhip2d_download_grid",
             "mpmhip2d_async_begin", "mpmhip2d_async_pool_particles", "mpmhip2d_async_step", "mpmhip2d_async_load_pools", "mpmhip2d_async_view_blocks",
-            "mpmhip2d_async_state", "mpmhip2d_async_current_time", "mpmhip2d_async_table", "mpmhip2d_bgeo_size", "mpmhip2d_bgeo_encode", "mpmhip2d_write_bgeo",
+            "mpmhip2d_async_state", "mpmhip2d_async_current_time", "mpmhip2d_async_table", "mpmhip2d_bgeo_size", "mpmhip2d_bgeo_encode", "mpmhip2d_write_bgeo", "mpmhip2d_snapshot_size", "mpmhip2d_snapshot_save", "mpmhip2d_snapshot_load",
             "mpmhip2d_set_rigid_coupling", "mpmhip2d_set_rigid_levelset_collision", "mpmhip2d_add_articulation", "mpmhip2d_set_articulation_iterations", "mpmhip2d_add_rigid_body", "mpmhip2d_rigid_get_state", "mpmhip2d_rigid_get_samples", "mpmhip2d_cdf_phase",
             "mpmhip2d_download_cdf", "mpmhip2d_download_colours",
             "mpmhip_set_rigid_coupling", "mpmhip_add_rigid_body", "mpmhip_num_rigid_bodies", "mpmhip_rigid_get_state", "mpmhip_rigid_set_velocity",
@@ -327,6 +337,10 @@ def load():
     L.mpmhip2d_bgeo_size.argtypes = [vp, C.c_int32, P(C.c_size_t)]
     L.mpmhip2d_bgeo_encode.argtypes = [vp, C.c_int32, vp, C.c_size_t, P(C.c_size_t)]
     L.mpmhip2d_write_bgeo.argtypes = [vp, C.c_char_p, C.c_int32]
+    L.mpmhip2d_snapshot_size.argtypes = [vp]
+    L.mpmhip2d_snapshot_size.restype = C.c_int64
+    L.mpmhip2d_snapshot_save.argtypes = [vp, vp, C.c_size_t]
+    L.mpmhip2d_snapshot_load.argtypes = [vp, vp, C.c_size_t]
     L.mpmhip2d_async_begin.argtypes = [vp, P(AsyncConfig)]
     L.mpmhip2d_async_pool_particles.argtypes = [vp]
     L.mpmhip2d_async_step.argtypes = [vp, C.c_float]

@@ -20,6 +20,18 @@ static int a2_grow_particles(mpmhip2d_ctx *m, int64_t need) {
   m->cap = (int64_t)cap;
   return MPMHIP_OK;
 }
+// the same for any 2D object (a snapshot larger than max_particles): the per-particle arrays of the CPIC coupling grow with them
+static int a2_grow_particles_any(mpmhip2d_ctx *m, int64_t need) {
+  if (need <= m->cap) return MPMHIP_OK;
+  const size_t keep = (size_t)m->n;
+  if (int rc = a2_grow_particles(m, need)) return rc;
+  if (m->rigid_enabled) {
+    hipError_t e = regrow(&m->d_states, keep, (size_t)m->cap, true);
+    if (e == hipSuccess) e = regrow(&m->d_bnd, keep, (size_t)m->cap, true);
+    if (e != hipSuccess) return fail2d(m, MPMHIP_ENOMEM, std::string("growing the particle arrays failed: ") + hipGetErrorString(e));
+  }
+  return MPMHIP_OK;
+}
 static int a2_store_reserve(mpmhip2d_ctx *m, uint32_t need) {  // room for `need` containers in total
   auto &A = m->async;
   if (need <= A.cap) return MPMHIP_OK;

@@ -364,9 +364,43 @@ class Simulation2D:
         return ""
 
     def general_action(self, config):
-        if config.get("action") == "add_articulation":
+        """MPM<2>::general_action, src/mpm.cpp:920-978"""
+        action = config.get("action")
+        if action == "add_articulation":
             return self.add_articulation(config)
-        raise MPMError("general_action(%r) is not part of the 2D build" % (config.get("action"),))
+        if action == "save":  # src/mpm.cpp:940-949: whole-state snapshot
+            self.save_snapshot(config["file_name"])
+            return ""
+        if action == "load":  # src/mpm.cpp:950-960
+            self.load_snapshot(config["file_name"])
+            return ""
+        raise MPMError("general_action(%r) is not part of the 2D build" % (action,))
+
+    def save_snapshot(self, path):
+        """groups, particles, clocks, the rigid bodies' records and joints, an asynchronous stepper's pools and block table
+        (include/mpmhip.h: mpmhip2d_snapshot_save)"""
+        self._ensure_ctx()
+        n = int(self._check(self._L.mpmhip2d_snapshot_size(self._ctx)))
+        buf = np.empty(max(n, 1), np.uint8)
+        self._check(self._L.mpmhip2d_snapshot_save(self._ctx, buf.ctypes.data_as(C.c_void_p), n))
+        with open(path, "wb") as f:
+            f.write(np.array([self.frame, self.frame_count], np.int64).tobytes())
+            f.write(buf[:n].tobytes())
+
+    def load_snapshot(self, path):
+        """into a simulation set up with the same grid and scene (level set, configuration, the rigid bodies — added before the
+        load — come from the script, as in the reference); replaces all particles and groups"""
+        raw = np.fromfile(path, np.uint8)
+        self.frame, self.frame_count = (int(v) for v in raw[:16].view(np.int64))
+        blob = np.ascontiguousarray(raw[16:])
+        self._ensure_ctx()
+        self._check(self._L.mpmhip2d_snapshot_load(self._ctx, blob.ctypes.data_as(C.c_void_p), len(blob)))
+        n_groups = int(blob[12:16].view(np.uint32)[0])
+        off = C.sizeof(_lib.Snap2DHeader)
+        rows = blob[off:off + 80 * n_groups].view(np.float32).reshape(n_groups, 20)
+        self._groups = [(int(r[16:17].view(np.int32)[0]), r[:16].copy()) for r in rows]
+        self._staged = []
+        self._n_added = max(self._n_added, int(blob[40:48].view(np.int64)[0]))
 
     def write_partio(self, file_name):
         """MPM<2>::write_partio (src/visualize.cpp:17-100): the same Houdini .bgeo as the 3D simulation writes, z = 0

@@ -162,6 +162,16 @@ static void gpu_tests_2d() {
     int32_t max_id = -1;
     for (auto &q : ps) { finite = finite && std::isfinite(q.position[1]) && std::isfinite(q.F[0]); max_id = std::max(max_id, q.id); }
     CHECK(finite && max_id == n0 - 1);
+    {  // save / load: the pools, the block table and the clocks travel; the restarted stepper is where the saved one was
+      const std::string path = "/tmp/mpm_amd_host_layer_async2d.snap";
+      as->general_action(Config().set("action", "save").set("file_name", path.c_str()));
+      auto bs = create_simulation2("async_mpm");
+      bs->initialize(Config().set("res", "128,128").set("unit_delta_t", 2e-6).set("max_units", 1024).set("gravity", "0,-10"));
+      bs->general_action(Config().set("action", "load").set("file_name", path.c_str()));
+      auto *b2 = dynamic_cast<AsyncMPM2D *>(bs.get());
+      CHECK(b2 && b2->current_t_int() == a->current_t_int() && bs->get_num_particles() == as->get_num_particles());
+      std::remove(path.c_str());
+    }
     bool threw = false;
     try { as->substep(); } catch (const std::exception &) { threw = true; }
     CHECK(threw);

@@ -207,3 +207,84 @@ def test_dirichlet_boundary_3d_matches_the_live_reference(tm):
     assert (np.abs(a["v"][s.x[:, 1] < 0.45]).max(axis=1) > 0.1).any()
     assert np.abs(a["x"] - b["x"]).max() <= 2e-7
     assert rel_l2(a["v"], b["v"]) <= 2e-5 and rel_l2(a["F"], b["F"]) <= 2e-5
+
+
+def test_2d_snapshot_restart_continues_the_run_with_a_rigid_body(tm, tmp_path):
+    """general_action save / load (src/mpm.cpp:940-960) of the 2D simulation: particles, groups, clocks and the rigid body's record
+    come out of the blob; the scene (level set, configuration, the body's outline) is set up again before the load.  The restarted
+    run continues like the uninterrupted one (to the summation order of the 2D scatter's float atomics)."""
+    import tests.cpic_scenes as cs
+    from taichi_mpm_amd.mpm import MPMError
+    x, v = cs.block2()
+    body = dict(cs.BODIES2["box"])
+
+    def scene(with_particles):
+        sim = tm.create_simulation2("mpm").initialize(dict(res=(cs.RES2,) * 2, delta_x=cs.DX2, base_delta_t=cs.DT, gravity=(0, -10),
+                                                           max_particles=len(x) + 16, penalty=1e3))
+        sim.set_levelset(tm.mpm.LevelSet(friction=0.4).add_plane((0, 1, 0), d=-0.2))
+        sim.add_particles(dict(type="rigid", **body))
+        if with_particles:
+            sim.add_particles(dict(type="sand", positions=x, velocities=v))
+        return sim
+    a = scene(True)
+    a.run_substeps(10)
+    path = str(tmp_path / "snap2d.bin")
+    assert a.general_action(dict(action="save", file_name=path)) == ""
+    a.run_substeps(10)
+    want, wb = a.get_particles(), a.get_rigid_state(1)
+    b = scene(False)  # the body of the scene, no particles: they come out of the blob
+    assert b.general_action(dict(action="load", file_name=path)) == ""
+    assert np.isclose(b.get_current_time(), 10 * cs.DT, rtol=1e-5) and b.get_num_particles() == len(want["id"])
+    b.run_substeps(10)
+    got, gb = b.get_particles(), b.get_rigid_state(1)
+    assert np.array_equal(got["id"], want["id"]) and np.array_equal(got["gid"], want["gid"])
+    assert np.abs(got["x"] - want["x"]).max() <= 2e-6 and rel_l2(got["v"], want["v"]) <= 1e-4 and rel_l2(got["F"], want["F"]) <= 1e-5
+    np.testing.assert_allclose(gb[:6], wb[:6], atol=1e-5)
+    c = tm.create_simulation2("mpm").initialize(dict(res=(cs.RES2,) * 2, delta_x=cs.DX2, base_delta_t=cs.DT))  # a scene WITHOUT the body
+    with pytest.raises(MPMError, match="rigid bodies"):
+        c.general_action(dict(action="load", file_name=path))
+    raw = np.fromfile(path, np.uint8)
+    raw[16 + 200] ^= 0xFF
+    bad = str(tmp_path / "bad.bin")
+    raw[:len(raw) - 7].tofile(bad)  # truncated
+    with pytest.raises(MPMError, match="size mismatch"):
+        scene(False).general_action(dict(action="load", file_name=bad))
+    for s in (a, b, c):
+        s.close()
+
+
+def test_2d_async_snapshot_restart_continues_the_run(tm, tmp_path):
+    """the asynchronous stepper's snapshot carries every pool and backup container, the block table and the clocks (the reference
+    serialises the same, src/async/async_mpm.h:120-172): a restart continues the run — same clocks, same containers in every pool"""
+    from tests.test_gpu_async2d import _two_stiffness_scene_2d
+    res, dx, groups = _two_stiffness_scene_2d(tm)
+    kw = dict(unit_delta_t=2e-6, max_units=1024)
+
+    def scene(with_particles):
+        sim = tm.create_simulation2("async_mpm").initialize(dict(res=(res, res), delta_x=dx, **kw))
+        sim.set_levelset(tm.mpm.LevelSet(friction=0.4).add_plane((0, 1, 0), d=-0.2))
+        if with_particles:
+            for mat, gp, x, v, F, B in groups:
+                sim.add_particles(dict(type=mat, positions=x, velocities=v, F=F, B=B, params=gp))
+        return sim
+    a = scene(True)
+    for _ in range(2):
+        a.step(2e-3)
+    path = str(tmp_path / "async2d.bin")
+    a.save_snapshot(path)
+    for _ in range(2):
+        a.step(2e-3)
+    b = scene(False)
+    b.load_snapshot(path)
+    assert b.current_t_int > 0 and b.get_num_pool_particles() >= sum(len(g[2]) for g in groups)
+    for _ in range(2):
+        b.step(2e-3)
+    assert b.current_t_int == a.current_t_int and b.update_counter == a.update_counter
+    p, q = a.get_pool_particles(), b.get_pool_particles()
+    assert np.array_equal(p["id"], q["id"]) and np.array_equal(p["block"], q["block"]) and np.array_equal(p["particle_t"], q["particle_t"])
+    assert np.abs(p["x"] - q["x"]).max() <= 2e-6 and rel_l2(p["v"], q["v"]) <= 2e-4
+    sync = tm.create_simulation2("mpm").initialize(dict(res=(res, res), delta_x=dx))
+    with pytest.raises(tm.MPMError, match="asynchronous"):
+        sync.load_snapshot(path)
+    for s in (a, b, sync):
+        s.close()
