@@ -562,6 +562,9 @@ int mpmhip_mpm88_download_grid(mpmhip_mpm88 *m, float *grid /* [(n+1)^2][3] = (v
  * through a plain copy kernel `iters` times on the ctx stream and returns the best rate in GB/s, counting the bytes
  * read plus the bytes written.  bench.py reports it next to the nominal HBM peak.  Synchronises. */
 int mpmhip_debug_copy_bandwidth(mpmhip_ctx *ctx, size_t bytes, int32_t iters, double *gb_per_s);
+/* measurement helper: 1 when the next substep's G2P is k_g2p_packed (chunks of 256 consecutive sorted positions; large
+ * one-material problems without rigid bodies or tiling), 0 when it is k_g2p (chunks inside one block) */
+int mpmhip_debug_g2p_is_packed(const mpmhip_ctx *ctx);
 /* 64-byte record gather of KNOWN size — the access pattern of k_p2g / k_g2p (a lane fetches one whole record with four
  * 16-byte loads through an index): n (a power of two) records, index pattern 0 identity / 1 shuffled runs of 8 /
  * 2 fully shuffled.  Reads exactly (64 + 4) n bytes per launch: the yardstick rocprofv3's FETCH_SIZE is calibrated

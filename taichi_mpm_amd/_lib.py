@@ -174,7 +174,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_set_profile_sampling", "mpmhip_create"
             "mpmhip_rigid_get_samples", "mpmhip_rigid_get_mesh", "mpmhip2d_rigid_get_mesh", "mpmhip_rasterize_rigid_boundary", "mpmhip_gather_cdf", "mpmhip_advect_rigid_bodies", "mpmhip_download_cdf",
             "mpmhip_add_articulation", "mpmhip_num_articulations", "mpmhip_set_articulation_iterations", "mpmhip_articulate",
             "mpmhip_download_boundary",
-            "mpmhip_debug_copy_bandwidth", "mpmhip_debug_gather_bandwidth", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
+            "mpmhip_debug_copy_bandwidth", "mpmhip_debug_g2p_is_packed", "mpmhip_debug_gather_bandwidth", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
 
 
 def exported_symbols():

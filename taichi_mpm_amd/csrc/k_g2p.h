@@ -5,6 +5,134 @@
 
 namespace mpm {
 
+// One particle of G2P: the 27-tap gather from the LDS tile `tile` (whose node (0, 0, 0) is the grid node (ox, oy, oz)), the
+// constitutive update, the advection, the next substep's P2G matrix and sort key, and the outgoing records.  `pos` = the particle's
+// position in the sorted index (where its records go).  Shared by k_g2p and k_g2p_packed (k_g2p_packed.h).
+template <uint32_t MATS, bool STORE_B, bool RIGID>
+__device__ __forceinline__ void g2p_particle(const Params &P, const float scale, const float4 *tile, const float ox, const float oy,
+                                             const float oz, const float4 g0, const float4 g1, const float4 g2, const float4 g3,
+                                             const GroupParams &g, const LevelSetDev *__restrict__ ls, Counters *cnt_w,
+                                             uint32_t *__restrict__ key, const uint32_t pos, uint32_t &bkey, uint32_t &out_slot,
+                                             float4 &G0, float4 &G1, float4 &G2, float4 &G3, float4 &Q0, float4 &Q1, float4 &Q2,
+                                             float4 &Q3, float4 &B0, float4 &B1, float4 &B2) {
+    const float x0 = g0.x, x1 = g0.y, x2 = g0.z;
+    const float X0 = x0 * P.idx - ox, X1 = x1 * P.idx - oy, X2 = x2 * P.idx - oz;
+    const int c0 = (int)(X0 - 0.5f), c1 = (int)(X1 - 0.5f), c2 = (int)(X2 - 0.5f);
+    const float r0 = X0 - (float)c0, r1 = X1 - (float)c1, r2 = X2 - (float)c2;
+    float w0[3], w1[3], w2[3];
+    bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
+    // 27-tap gather, :888-904:  v = sum w g,  b[:, c] = sum (w d_c) g  with  w = w0[i] w1[j] w2[k],  d = r - (i, j, k).
+    // The weights factor along the axes, so the sums are taken axis by axis — 4 multiply-adds per node on the (x, y) and
+    // (z, m) register pairs of the tile's float4 (packed fp32: v_pk_fma_f32) instead of 15 scalar ones per node:
+    //   S0 = sum_k w2[k] g,  S1 = sum_k (w2 d2)[k] g;   T0 = sum_j w1[j] S0,  T1 = sum_j (w1 d1)[j] S0,  T2 = sum_j w1[j] S1;
+    //   v = sum_i w0[i] T0,  b[:,0] = sum_i (w0 d0)[i] T0,  b[:,1] = sum_i w0[i] T1,  b[:,2] = sum_i w0[i] T2
+    // (the m lanes ride along unused).  Same terms as the reference's loop, summed in a different order.
+    const float e0[3] = {w0[0] * r0, w0[1] * (r0 - 1.0f), w0[2] * (r0 - 2.0f)};
+    const float e1[3] = {w1[0] * r1, w1[1] * (r1 - 1.0f), w1[2] * (r1 - 2.0f)};
+    const float e2[3] = {w2[0] * r2, w2[1] * (r2 - 1.0f), w2[2] * (r2 - 2.0f)};
+    const f2 z2 = {0.0f, 0.0f};
+    f2 vxy = z2, vzw = z2, b0xy = z2, b0zw = z2, b1xy = z2, b1zw = z2, b2xy = z2, b2zw = z2;
+    const int nbase = (c0 * TS + c1) * TS + c2;
+    auto plane = [&](int i3, float w0i, float e0i) __attribute__((always_inline)) {
+      f2 T0xy = z2, T0zw = z2, T1xy = z2, T1zw = z2, T2xy = z2, T2zw = z2;
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        f2 S0xy = z2, S0zw = z2, S1xy = z2, S1zw = z2;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const float4 gv = tile[nbase + (i3 * TS + j) * TS + k];
+          const f2 gxy = {gv.x, gv.y}, gzw = {gv.z, gv.w};
+          S0xy = fma2(splat2(w2[k]), gxy, S0xy); S0zw = fma2(splat2(w2[k]), gzw, S0zw);
+          S1xy = fma2(splat2(e2[k]), gxy, S1xy); S1zw = fma2(splat2(e2[k]), gzw, S1zw);
+        }
+        T0xy = fma2(splat2(w1[j]), S0xy, T0xy); T0zw = fma2(splat2(w1[j]), S0zw, T0zw);
+        T1xy = fma2(splat2(e1[j]), S0xy, T1xy); T1zw = fma2(splat2(e1[j]), S0zw, T1zw);
+        T2xy = fma2(splat2(w1[j]), S1xy, T2xy); T2zw = fma2(splat2(w1[j]), S1zw, T2zw);
+      }
+      vxy = fma2(splat2(w0i), T0xy, vxy); vzw = fma2(splat2(w0i), T0zw, vzw);
+      b0xy = fma2(splat2(e0i), T0xy, b0xy); b0zw = fma2(splat2(e0i), T0zw, b0zw);
+      b1xy = fma2(splat2(w0i), T1xy, b1xy); b1zw = fma2(splat2(w0i), T1zw, b1zw);
+      b2xy = fma2(splat2(w0i), T2xy, b2xy); b2zw = fma2(splat2(w0i), T2zw, b2zw);
+    };
+    if (!MPM_ABLATE(P, 4)) {
+      plane(0, w0[0], e0[0]); plane(1, w0[1], e0[1]); plane(2, w0[2], e0[2]);
+    }
+    float v0 = vxy.x, v1 = vxy.y, v2 = vzw.x;
+    mat3 b;
+    b(0, 0) = b0xy.x; b(1, 0) = b0xy.y; b(2, 0) = b0zw.x;
+    b(0, 1) = b1xy.x; b(1, 1) = b1xy.y; b(2, 1) = b1zw.x;
+    b(0, 2) = b2xy.x; b(1, 2) = b2xy.y; b(2, 2) = b2zw.x;
+    mat3 cdg;  // :940-942  cdg = I + (-4 inv_dx dt) b   (undamped b, as in the reference)
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) cdg(r, c) = fmaf(scale, b(r, c), (r == c) ? 1.0f : 0.0f);
+    // apic_b = damp_affine_momemtum(b) (src/mpm.h:465-469); the reference's optimised path has a bug
+    // here (passes the block index, transfer.cpp:925-926) — we implement the intended damping.
+    if (P.rpic_damping != 0.0f || P.apic_damping != 0.0f) {
+      const float ks = 1.0f - P.rpic_damping, ka = 1.0f - P.apic_damping;
+      mat3 bd;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const float sym = 0.5f * (b(r, c) + b(c, r));
+          bd(r, c) = ks * sym + ka * (b(r, c) - sym);
+        }
+      b = bd;
+    }
+    mat3 F;
+    F.m[0] = g1.x; F.m[1] = g1.y; F.m[2] = g1.z; F.m[3] = g1.w; F.m[4] = g2.x; F.m[5] = g2.y; F.m[6] = g2.z;
+    F.m[7] = g2.w; F.m[8] = g3.x;
+    float aux = g0.w;
+    mat3 stress;
+    if (!MPM_ABLATE(P, 2)) plasticity_and_force<MATS>(g, cdg, F, aux, stress);  // :950 + next substep's :509
+    else stress = cdg;
+    float nx0 = fmaf(v0, P.dt, x0), nx1 = fmaf(v1, P.dt, x1), nx2 = fmaf(v2, P.dt, x2);  // :951
+    if (P.clamp_pos) {  // generic path only (optimized = false): p.pos clamped into [0, res - eps], :668-670
+      nx0 = fminf(fmaxf(nx0 * P.idx, 0.0f), (float)P.res[0] - 1e-6f) * P.dx;
+      nx1 = fminf(fmaxf(nx1 * P.idx, 0.0f), (float)P.res[1] - 1e-6f) * P.dx;
+      nx2 = fminf(fmaxf(nx2 * P.idx, 0.0f), (float)P.res[2] - 1e-6f) * P.dx;
+    }
+    if (P.particle_collision) {  // particle_collision_resolution, src/mpm.cpp:414-426 (runs after G2P, :566-569)
+      const LevelSetDev &LS = *ls;  // in device memory: by value it would sit in ~130 SGPRs for a rarely used path
+      const float xw[3] = {nx0, nx1, nx2};
+      float phi, gr[3] = {0, 0, 0};
+      if (levelset_eval(LS, P.t, xw, P.idx, phi, gr) && phi < 0.0f) {
+        const float vn = gr[0] * v0 + gr[1] * v1 + gr[2] * v2;
+        nx0 -= gr[0] * phi * P.dx; nx1 -= gr[1] * phi * P.dx; nx2 -= gr[2] * phi * P.dx;
+        v0 -= vn * gr[0]; v1 -= vn * gr[1]; v2 -= vn * gr[2];
+      }
+    }
+    const float m4 = 4.0f * g.p[0];
+    float A[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) A[k] = fmaf(stress.m[k], scale, b.m[k] * m4);  // next P2G's :521-522
+    // next substep's key; deleted particles (clear_boundary_particles) are marked for good
+    const float nxp[3] = {nx0, nx1, nx2}, nv[3] = {v0, v1, v2};
+    const uint32_t kk = particle_key(P, nxp, nv, bkey);
+    int32_t pid = __float_as_int(g3.z);
+    if (kk == INVALID) {
+      pid = -1;
+      atomicAdd(&cnt_w->n_dead, 1u);
+    }
+    key[pos] = kk;
+    G0 = make_float4(nx0, nx1, nx2, aux);
+    G1 = make_float4(F.m[0], F.m[1], F.m[2], F.m[3]);
+    G2 = make_float4(F.m[4], F.m[5], F.m[6], F.m[7]);
+    G3 = make_float4(F.m[8], g3.y, __int_as_float(pid), RIGID ? g3.w : 0.0f);  // (.w: the particle's CPIC colour word travels with it)
+    Q0 = make_float4(nx0, nx1, nx2, v0);
+    Q1 = make_float4(v1, v2, A[0], A[1]);
+    Q2 = make_float4(A[2], A[3], A[4], A[5]);
+    Q3 = make_float4(A[6], A[7], A[8], g.p[0]);
+    if constexpr (STORE_B) {
+      B0 = make_float4(b.m[0], b.m[1], b.m[2], b.m[3]);
+      B1 = make_float4(b.m[4], b.m[5], b.m[6], b.m[7]);
+      B2 = make_float4(b.m[8], 0.0f, 0.0f, 0.0f);
+    }
+    out_slot = MPM_ABLATE(P, 1) ? INVALID : pos;
+}
+
 // ------------------------------------------------------------------------------------------------ G2P
 // resample_optimized / block_op_normal (src/transfer.cpp:837-954), one workgroup per active block, one
 // particle per lane through the sorted index.  Also produces, for the NEXT substep: the affine matrix A of
@@ -133,122 +261,8 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
     const uint32_t i_nn = lane_slot(nn);
     uint32_t bkey = INVALID, out_slot = INVALID;
     auto particle = [&](const GroupParams &g) __attribute__((always_inline)) {
-      const float x0 = g0.x, x1 = g0.y, x2 = g0.z;
-      const float X0 = x0 * P.idx - ox, X1 = x1 * P.idx - oy, X2 = x2 * P.idx - oz;
-      const int c0 = (int)(X0 - 0.5f), c1 = (int)(X1 - 0.5f), c2 = (int)(X2 - 0.5f);
-      const float r0 = X0 - (float)c0, r1 = X1 - (float)c1, r2 = X2 - (float)c2;
-      float w0[3], w1[3], w2[3];
-      bspline_weights(r0, w0); bspline_weights(r1, w1); bspline_weights(r2, w2);
-      // 27-tap gather, :888-904:  v = sum w g,  b[:, c] = sum (w d_c) g  with  w = w0[i] w1[j] w2[k],  d = r - (i, j, k).
-      // The weights factor along the axes, so the sums are taken axis by axis — 4 multiply-adds per node on the (x, y) and
-      // (z, m) register pairs of the tile's float4 (packed fp32: v_pk_fma_f32) instead of 15 scalar ones per node:
-      //   S0 = sum_k w2[k] g,  S1 = sum_k (w2 d2)[k] g;   T0 = sum_j w1[j] S0,  T1 = sum_j (w1 d1)[j] S0,  T2 = sum_j w1[j] S1;
-      //   v = sum_i w0[i] T0,  b[:,0] = sum_i (w0 d0)[i] T0,  b[:,1] = sum_i w0[i] T1,  b[:,2] = sum_i w0[i] T2
-      // (the m lanes ride along unused).  Same terms as the reference's loop, summed in a different order.
-      const float e0[3] = {w0[0] * r0, w0[1] * (r0 - 1.0f), w0[2] * (r0 - 2.0f)};
-      const float e1[3] = {w1[0] * r1, w1[1] * (r1 - 1.0f), w1[2] * (r1 - 2.0f)};
-      const float e2[3] = {w2[0] * r2, w2[1] * (r2 - 1.0f), w2[2] * (r2 - 2.0f)};
-      const f2 z2 = {0.0f, 0.0f};
-      f2 vxy = z2, vzw = z2, b0xy = z2, b0zw = z2, b1xy = z2, b1zw = z2, b2xy = z2, b2zw = z2;
-      const int nbase = (c0 * TS + c1) * TS + c2;
-      auto plane = [&](int i3, float w0i, float e0i) __attribute__((always_inline)) {
-        f2 T0xy = z2, T0zw = z2, T1xy = z2, T1zw = z2, T2xy = z2, T2zw = z2;
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-          f2 S0xy = z2, S0zw = z2, S1xy = z2, S1zw = z2;
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            const float4 gv = tile[nbase + (i3 * TS + j) * TS + k];
-            const f2 gxy = {gv.x, gv.y}, gzw = {gv.z, gv.w};
-            S0xy = fma2(splat2(w2[k]), gxy, S0xy); S0zw = fma2(splat2(w2[k]), gzw, S0zw);
-            S1xy = fma2(splat2(e2[k]), gxy, S1xy); S1zw = fma2(splat2(e2[k]), gzw, S1zw);
-          }
-          T0xy = fma2(splat2(w1[j]), S0xy, T0xy); T0zw = fma2(splat2(w1[j]), S0zw, T0zw);
-          T1xy = fma2(splat2(e1[j]), S0xy, T1xy); T1zw = fma2(splat2(e1[j]), S0zw, T1zw);
-          T2xy = fma2(splat2(w1[j]), S1xy, T2xy); T2zw = fma2(splat2(w1[j]), S1zw, T2zw);
-        }
-        vxy = fma2(splat2(w0i), T0xy, vxy); vzw = fma2(splat2(w0i), T0zw, vzw);
-        b0xy = fma2(splat2(e0i), T0xy, b0xy); b0zw = fma2(splat2(e0i), T0zw, b0zw);
-        b1xy = fma2(splat2(w0i), T1xy, b1xy); b1zw = fma2(splat2(w0i), T1zw, b1zw);
-        b2xy = fma2(splat2(w0i), T2xy, b2xy); b2zw = fma2(splat2(w0i), T2zw, b2zw);
-      };
-      if (!MPM_ABLATE(P, 4)) {
-        plane(0, w0[0], e0[0]); plane(1, w0[1], e0[1]); plane(2, w0[2], e0[2]);
-      }
-      float v0 = vxy.x, v1 = vxy.y, v2 = vzw.x;
-      mat3 b;
-      b(0, 0) = b0xy.x; b(1, 0) = b0xy.y; b(2, 0) = b0zw.x;
-      b(0, 1) = b1xy.x; b(1, 1) = b1xy.y; b(2, 1) = b1zw.x;
-      b(0, 2) = b2xy.x; b(1, 2) = b2xy.y; b(2, 2) = b2zw.x;
-      mat3 cdg;  // :940-942  cdg = I + (-4 inv_dx dt) b   (undamped b, as in the reference)
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) cdg(r, c) = fmaf(scale, b(r, c), (r == c) ? 1.0f : 0.0f);
-      // apic_b = damp_affine_momemtum(b) (src/mpm.h:465-469); the reference's optimised path has a bug
-      // here (passes the block index, transfer.cpp:925-926) — we implement the intended damping.
-      if (P.rpic_damping != 0.0f || P.apic_damping != 0.0f) {
-        const float ks = 1.0f - P.rpic_damping, ka = 1.0f - P.apic_damping;
-        mat3 bd;
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-          for (int c = 0; c < 3; c++) {
-            const float sym = 0.5f * (b(r, c) + b(c, r));
-            bd(r, c) = ks * sym + ka * (b(r, c) - sym);
-          }
-        b = bd;
-      }
-      mat3 F;
-      F.m[0] = g1.x; F.m[1] = g1.y; F.m[2] = g1.z; F.m[3] = g1.w; F.m[4] = g2.x; F.m[5] = g2.y; F.m[6] = g2.z;
-      F.m[7] = g2.w; F.m[8] = g3.x;
-      float aux = g0.w;
-      mat3 stress;
-      if (!MPM_ABLATE(P, 2)) plasticity_and_force<MATS>(g, cdg, F, aux, stress);  // :950 + next substep's :509
-      else stress = cdg;
-      float nx0 = fmaf(v0, P.dt, x0), nx1 = fmaf(v1, P.dt, x1), nx2 = fmaf(v2, P.dt, x2);  // :951
-      if (P.clamp_pos) {  // generic path only (optimized = false): p.pos clamped into [0, res - eps], :668-670
-        nx0 = fminf(fmaxf(nx0 * P.idx, 0.0f), (float)P.res[0] - 1e-6f) * P.dx;
-        nx1 = fminf(fmaxf(nx1 * P.idx, 0.0f), (float)P.res[1] - 1e-6f) * P.dx;
-        nx2 = fminf(fmaxf(nx2 * P.idx, 0.0f), (float)P.res[2] - 1e-6f) * P.dx;
-      }
-      if (P.particle_collision) {  // particle_collision_resolution, src/mpm.cpp:414-426 (runs after G2P, :566-569)
-        const LevelSetDev &LS = *ls;  // in device memory: by value it would sit in ~130 SGPRs for a rarely used path
-        const float xw[3] = {nx0, nx1, nx2};
-        float phi, gr[3] = {0, 0, 0};
-        if (levelset_eval(LS, P.t, xw, P.idx, phi, gr) && phi < 0.0f) {
-          const float vn = gr[0] * v0 + gr[1] * v1 + gr[2] * v2;
-          nx0 -= gr[0] * phi * P.dx; nx1 -= gr[1] * phi * P.dx; nx2 -= gr[2] * phi * P.dx;
-          v0 -= vn * gr[0]; v1 -= vn * gr[1]; v2 -= vn * gr[2];
-        }
-      }
-      const float m4 = 4.0f * g.p[0];
-      float A[9];
-#pragma unroll
-      for (int k = 0; k < 9; k++) A[k] = fmaf(stress.m[k], scale, b.m[k] * m4);  // next P2G's :521-522
-      // next substep's key; deleted particles (clear_boundary_particles) are marked for good
-      const float nxp[3] = {nx0, nx1, nx2}, nv[3] = {v0, v1, v2};
-      const uint32_t kk = particle_key(P, nxp, nv, bkey);
-      int32_t pid = __float_as_int(g3.z);
-      if (kk == INVALID) {
-        pid = -1;
-        atomicAdd(&cnt_w->n_dead, 1u);
-      }
-      key[cur.p + tid] = kk;
-      G0 = make_float4(nx0, nx1, nx2, aux);
-      G1 = make_float4(F.m[0], F.m[1], F.m[2], F.m[3]);
-      G2 = make_float4(F.m[4], F.m[5], F.m[6], F.m[7]);
-      G3 = make_float4(F.m[8], g3.y, __int_as_float(pid), RIGID ? g3.w : 0.0f);  // (.w: the particle's CPIC colour word travels with it)
-      Q0 = make_float4(nx0, nx1, nx2, v0);
-      Q1 = make_float4(v1, v2, A[0], A[1]);
-      Q2 = make_float4(A[2], A[3], A[4], A[5]);
-      Q3 = make_float4(A[6], A[7], A[8], g.p[0]);
-      if constexpr (STORE_B) {
-        B0 = make_float4(b.m[0], b.m[1], b.m[2], b.m[3]);
-        B1 = make_float4(b.m[4], b.m[5], b.m[6], b.m[7]);
-        B2 = make_float4(b.m[8], 0.0f, 0.0f, 0.0f);
-      }
-      out_slot = MPM_ABLATE(P, 1) ? INVALID : cur.p + tid;
+      g2p_particle<MATS, STORE_B, RIGID>(P, scale, tile, ox, oy, oz, g0, g1, g2, g3, g, ls, cnt_w, key, cur.p + tid, bkey, out_slot, G0, G1,
+                                         G2, G3, Q0, Q1, Q2, Q3, B0, B1, B2);
     };
     // Group parameters are read at use (keeps ~20 VGPRs free) from the workgroup's LDS copy of the table: DS reads
     // wait on lgkmcnt, whereas vector loads in the middle of the arithmetic wait on vmcnt and with it on the

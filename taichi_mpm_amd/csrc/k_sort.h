@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
                                                     uint32_t *__restrict__ act_start,
                                                     uint32_t *__restrict__ cell_start,
                                                     unsigned long long *__restrict__ slots, uint32_t epoch,
-                                                    uint32_t rank_runs_mul) {
+                                                    uint32_t rank_runs_mul, uint32_t *__restrict__ chunk_blk) {
   __shared__ uint32_t lds[8];
   constexpr int CT_BPW = CT_BLOCKS / 4;  // blocks per wave
   __shared__ uint32_t blk_tot[CT_BLOCKS];
@@ -359,6 +359,7 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
     const uint32_t a0 = chunk * CT_BLOCKS;
     if (a0 >= na && !(na == 0 && chunk == 0)) return;
     uint32_t excl[CT_BPW];  // exclusive in-block prefix of this lane's cell, for the wave's blocks
+    uint32_t tot[CT_BPW];   // (lane 63: the block's particle count)
 #pragma unroll
     for (int i = 0; i < CT_BPW; i++) {
       const uint32_t a = a0 + wave * CT_BPW + i;
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
         if ((int)lane >= off) v += u;
       }
       excl[i] = v - c;
+      tot[i] = v;
       if (lane == 63) blk_tot[wave * CT_BPW + i] = v;
     }
     __syncthreads();
@@ -391,6 +393,9 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
         const uint32_t start = chunk_base + blk_tot[wave * CT_BPW + i];
         cell_start[(size_t)a * BC + lane] = start + excl[i];
         if (lane == 0) act_start[a] = start;
+        // k_g2p_packed walks the sorted index in chunks of 256 positions: the block holding position 256 k, for every k inside this block
+        if (chunk_blk && lane == 63)
+          for (uint32_t k = (start + 255u) >> 8; (k << 8) < start + tot[i]; k++) chunk_blk[k] = a;
       }
     }
     if (a0 + CT_BLOCKS >= na && threadIdx.x == 0) {  // last chunk: sentinels + live count

@@ -77,6 +77,7 @@
 #include "k_grid.h"
 #include "k_tiling.h"
 #include "k_g2p.h"
+#include "k_g2p_packed.h"
 #include "k_rigid_transfer.h"
 #include "k_debug.h"
 #include "k_bgeo.h"
@@ -128,6 +129,9 @@ struct mpmhip_ctx {
   int p2g_wgs = 16384;        // workgroups of k_p2g (env MPMHIP_P2G_WGS)
   int p2g_split = 11;         // tuning knob (env MPMHIP_P2G_SPLIT): 10*NS + PS, see do_p2g
   int g2p_wgs = 0;            // workgroups of k_g2p; 0: by size (env MPMHIP_G2P_WGS pins it)
+  int g2p_packed = -1;        // k_g2p_packed instead of k_g2p: -1 by size (from 2 M slots on; no rigid bodies, no tiling), 0 never, 1 wherever it
+                              // applies (env MPMHIP_G2P_PACKED)
+  uint32_t *chunk_blk = nullptr;  // per 256 positions of the sorted index: the block holding the first (k_cell_table -> k_g2p_packed)
   int rigid_wgs = 2048;       // workgroups of k_p2g_rigid (one per wave slot of the device), twice those of k_g2p_rigid (env MPMHIP_RIGID_WGS: tuning)
   uint32_t rank_runs_mul = 3; // k_rank takes its LDS-hash path when runs * this > slots (env MPMHIP_RANK_RUNS_MUL: tuning)
   int ct_blocks = 0;          // blocks per chunk of k_cell_table: 0 by size, 16, 64 (env MPMHIP_CT_BLOCKS: tuning)
@@ -440,6 +444,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   if (const char *e = getenv("MPMHIP_RANK_RUNS_MUL")) c->rank_runs_mul = (uint32_t)atoi(e);
   if (const char *e = getenv("MPMHIP_CT_BLOCKS")) c->ct_blocks = atoi(e);
   if (const char *e = getenv("MPMHIP_P2G_SPLIT")) c->p2g_split = atoi(e);
+  if (const char *e = getenv("MPMHIP_G2P_PACKED")) c->g2p_packed = atoi(e);
   if (const char *e = getenv("MPMHIP_P2G_WGS")) c->p2g_wgs = atoi(e) > 0 ? atoi(e) : 16384;
   c->reorder_interval = cfg->reorder_interval;
   if (const char *e = getenv("MPMHIP_REORDER_INTERVAL")) c->reorder_interval = atoi(e);
@@ -497,6 +502,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(dmalloc(&c->key, (size_t)c->cap));
   A(dmalloc(&c->rank, (size_t)c->cap));
   A(dmalloc(&c->perm, (size_t)c->cap));
+  A(dmalloc(&c->chunk_blk, (size_t)c->cap / 256 + 2));
   A(dmalloc(&c->bits, (size_t)P.nbw));
   A(dmalloc(&c->blk_flag, (size_t)P.nbw * 32));
   A(dmalloc(&c->wprefix, (size_t)P.nbw));
@@ -556,7 +562,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   for (auto &ev : c->ev_pool)
     for (int k = 0; k <= PH_COUNT; k++) hipEventDestroy(ev.e[k]);
   hipFree(c->rg); hipFree(c->rp); hipFree(c->rb); hipFree(c->rg2); hipFree(c->rp2); hipFree(c->rb2);
-  hipFree(c->key); hipFree(c->rank); hipFree(c->perm); hipFree(c->blk_flag); hipFree(c->bits); hipFree(c->wprefix);
+  hipFree(c->key); hipFree(c->rank); hipFree(c->perm); hipFree(c->chunk_blk); hipFree(c->blk_flag); hipFree(c->bits); hipFree(c->wprefix);
   hipFree(c->fat_slot); hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->cell_cnt);
   hipFree(c->cell_start); hipFree(c->scan_slots); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
   hipFree(c->async.d_tab); hipFree(c->async.d_blk_of); hipFree(c->async.d_blk_limits); hipFree(c->async.d_particle_limits);
@@ -929,7 +935,7 @@ static int do_sort(mpmhip_ctx *c) {
   hipLaunchKernelGGL(k_rank, dim3(std::max(rank_wgs, 1u)), dim3(256), 0, st, P, c->key, c->rank, c->cell_cnt, c->bits, c->wprefix,
                      c->cnt);
   hipLaunchKernelGGL(small ? k_cell_table<16> : k_cell_table<64>, dim3(std::min(ct_chunks, c->scan_grid)), dim3(256), 0, st, P,
-                     c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots, epoch, c->rank_runs_mul);
+                     c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots, epoch, c->rank_runs_mul, c->chunk_blk);
   hipLaunchKernelGGL(k_perm, dim3(pg), dim3(256), 0, st, P, (const Counters *)c->cnt, c->key, c->rank, c->cell_start, c->perm);
   c->sorted = true;
   c->keys_valid = false;  // key[] now holds k_rank's packed (rank, cell index) words
@@ -1060,6 +1066,13 @@ static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
                      c->gridv, c->fat_slot, c->dense, c->T, c->d_boxes_cur, c->LS, phase);
   return launch_check(c, "grid");
 }
+// which G2P kernel the plain blocks of the next substep get (bench.py names the kernel of its roofline after it)
+static bool g2p_is_packed(const mpmhip_ctx *c, int phase) {
+  const bool packed = c->g2p_packed < 0 ? c->n_slots >= (2 << 20) : c->g2p_packed != 0;
+  const uint32_t mask = material_mask(c);
+  const bool one_plain_material = mask && !(mask & (mask - 1)) && mask != (1u << MPMHIP_VISCO);
+  return packed && one_plain_material && !rigid_active(c) && !c->P.store_b && phase == 0 && !c->T.enabled && c->chunk_blk;
+}
 static int do_g2p(mpmhip_ctx *c, int phase = 0) {
   c->P.t = c->t;
   const bool sb = c->P.store_b != 0;
@@ -1104,6 +1117,27 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0) {
 #undef MPM_ONE_MATERIAL
       default: break;
     }
+  }
+  // packed chunks (k_g2p_packed.h): -3.5 us of 303 on the lattice of C3, -14 us of 373 after impact; at 1 M particles +7 us of 50
+  // (768 workgroups with a handful of chunks each: the walk's set-up is not amortised) — hence by size
+  // (one-material instantiations only: they stay below the 168 VGPRs of three workgroups per CU — 163 to 167; the kernel for
+  // mixed materials would have 177, the visco one 183: those scenes keep k_g2p)
+  decltype(&k_g2p_packed<256, MPM_G2P_MINW, false, 1u << MPMHIP_SAND>) pk = nullptr;
+  if (g2p_is_packed(c, phase)) switch (mask) {
+#define MPM_ONE_MATERIAL(t) case 1u << (t): pk = k_g2p_packed<256, MPM_G2P_MINW, false, 1u << (t)>; break;
+      MPM_ONE_MATERIAL(MPMHIP_SNOW) MPM_ONE_MATERIAL(MPMHIP_LINEAR) MPM_ONE_MATERIAL(MPMHIP_JELLY) MPM_ONE_MATERIAL(MPMHIP_WATER)
+      MPM_ONE_MATERIAL(MPMHIP_SAND) MPM_ONE_MATERIAL(MPMHIP_VON_MISES) MPM_ONE_MATERIAL(MPMHIP_ELASTIC)
+#undef MPM_ONE_MATERIAL
+      default: break;
+    }
+  if (pk) {
+    const int wgs = c->g2p_wgs > 0 ? c->g2p_wgs : (c->n_slots < (2 << 20) ? 768 : 4096);
+    hipLaunchKernelGGL(pk, dim3(wgs), dim3(256), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
+                       (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
+                       c->blk_flag, (const LevelSetDev *)c->d_LS, (const uint32_t *)c->chunk_blk);
+    c->sorted = false; c->keys_valid = true; c->affine_valid = true;
+    if (!c->P.store_b) c->b_stale = true;
+    return launch_check(c, "g2p_packed");
   }
   hipStream_t rs = c->stream;
   if (rigid) { if (int rc = rigid_fork(c, &rs, 2)) return rc; }
@@ -1970,7 +2004,7 @@ int mpmhip_reserve(mpmhip_ctx *c, int64_t max_particles) {
   auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
   A(regrow(&c->rg, n, cap, false)); A(regrow(&c->rp, n, cap, false)); A(regrow(&c->rb, n * BW, cap * BW, true));
   A(regrow(&c->rg2, 0, cap, false)); A(regrow(&c->rp2, 0, cap, false)); A(regrow(&c->rb2, 0, cap * BW, false));
-  A(regrow(&c->key, 0, cap, false)); A(regrow(&c->rank, 0, cap, false)); A(regrow(&c->perm, 0, cap, false));
+  A(regrow(&c->key, 0, cap, false)); A(regrow(&c->rank, 0, cap, false)); A(regrow(&c->perm, 0, cap, false)); A(regrow(&c->chunk_blk, 0, cap / 256 + 2, false));
   if (c->rigid.d_bnd) A(regrow(&c->rigid.d_bnd, n, cap, true));
   if (c->async.d_blk_of) {  // (re-allocated at the size of the ctx by the next update_dt_limits)
     (void)hipFree(c->async.d_blk_of); (void)hipFree(c->async.d_particle_limits);
@@ -1998,6 +2032,7 @@ int mpmhip_reserve(mpmhip_ctx *c, int64_t max_particles) {
   return invalidate_keys(c);
 }
 
+int mpmhip_debug_g2p_is_packed(const mpmhip_ctx *c) { return c ? (g2p_is_packed(c, 0) ? 1 : 0) : MPMHIP_EINVAL; }
 int mpmhip_debug_copy_bandwidth(mpmhip_ctx *c, size_t bytes, int32_t iters, double *gb_per_s) {
   if (!c || !gb_per_s || iters <= 0 || bytes < 16) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));

@@ -655,6 +655,11 @@ class Simulation3D:
         self._ensure_ctx(); self._check(self._L.mpmhip_set_profiling(self._ctx, int(level)))
         self._check(self._L.mpmhip_set_profile_sampling(self._ctx, int(every)))
 
+    def g2p_kernel(self):
+        """name of the G2P kernel the next substep's plain blocks get (measurement helper: bench.py names its roofline after it)"""
+        self._ensure_ctx()
+        return "k_g2p_packed" if self._check(self._L.mpmhip_debug_g2p_is_packed(self._ctx)) else "k_g2p"
+
     def copy_bandwidth(self, nbytes=1 << 30, iters=5):
         """GB/s (read + written) of a plain streaming copy on this GPU: the measured yardstick next to the nominal peak"""
         self._ensure_ctx()

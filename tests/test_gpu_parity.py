@@ -184,6 +184,34 @@ def test_crowded_cells_take_the_side_array_of_the_sort(tm, orc, monkeypatch):
     monkeypatch.delenv("MPMHIP_TEST_SMALL_RANK")
 
 
+def test_packed_g2p_walk_equals_the_per_block_walk(tm, monkeypatch):
+    """k_g2p_packed (chunks of 256 consecutive sorted positions, whatever blocks they belong to: csrc/k_g2p_packed.h) against k_g2p on the
+    same scene: a dense cube (chunks inside one block, tiles reused along a run), spray (a chunk touches more blocks than the
+    workgroup keeps tiles for: several passes) and particles that leave the domain (dead slots behind the live range).  The
+    library picks the packed walk by size (from 2 M slots on); the knob forces it either way."""
+    rng = np.random.default_rng(31)
+    dense = lattice_cube(RES, 8, 14, DX, jitter=0.2, seed=30)
+    spray = (rng.uniform(8.0, 24.0, (3000, 3)) * DX).astype(np.float32)   # ~6 particles per block: 256 positions span ~40 blocks
+    x = np.concatenate([dense, spray])
+    out = {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("MPMHIP_G2P_PACKED", knob)
+        s = make_state(x, "sand", DX, perturb_F=0.02, seed=32)
+        s.v[-40:] = (0.0, 0.0, 500.0)  # these leave through the wall within a few substeps: deleted, their slots drop out
+        sim = make_sim(tm, s)
+        for _ in range(5):
+            sim.substep()
+        out[knob] = sim.get_particles()
+        sim.close()
+    monkeypatch.delenv("MPMHIP_G2P_PACKED")
+    a, b = out["0"], out["1"]
+    assert np.array_equal(a["id"], b["id"]) and len(a["id"]) < len(x)
+    for f in ("x", "v", "F", "aux"):
+        # (the same per-particle arithmetic; in-cell summation orders of P2G differ from run to run: ranks are handed out by atomics)
+        # (... and the return mapping of the sand amplifies them: F gets four times the room of x and v)
+        assert np.allclose(a[f], b[f], rtol=0, atol=(2e-5 if f == "F" else 5e-6) * max(1.0, float(np.abs(a[f]).max()))), f
+
+
 # ------------------------------------------------------------------------------------------ phases
 @pytest.mark.parametrize("mat", MATS)
 def test_p2g_and_grid_update_match_oracle(tm, orc, mat):

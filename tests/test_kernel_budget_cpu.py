@@ -39,6 +39,9 @@ BUDGET = {
     G2P % (2, 16): (168, (2200, 3200), 53 * 1024),    # jelly only (C2)
     G2P % (2, 508): (168, (3000, 4200), 53 * 1024),   # every material but visco (mixed scenes, C5)
     G2P % (2, 510): (256, (4800, 6200), 80 * 1024),   # all eight
+    # k_g2p_packed (large problems without rigid bodies / tiling): the same occupancy class with four block tiles in LDS
+    "_ZN3mpm12k_g2p_packedILi256ELi2ELb0ELj64EEE": (168, (2500, 3500), 53 * 1024),   # sand
+    "_ZN3mpm12k_g2p_packedILi256ELi2ELb0ELj128EEE": (168, (2500, 3500), 53 * 1024),  # von Mises: the fullest of the seven instantiated
     "_ZN3mpm5k_p2gILi1ELi1ELi2ELb0EEE": (256, (900, 1450), 16 * 1024),  # the default P2G (one wave per block)
     # the plain kernels of a ctx WITH rigid bodies (they skip the flagged blocks): same occupancy class as without —
     # k_g2p<RIGID> runs beside k_g2p_rigid, whose 255-register workgroups only find room when this one leaves it
