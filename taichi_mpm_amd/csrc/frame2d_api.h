@@ -17,8 +17,13 @@ int mpmhip2d_bgeo_size(mpmhip2d_ctx *m, int32_t verbose, size_t *bytes) {
   *bytes = bgeo_bytes((uint32_t)n, verbose != 0);
   return MPMHIP_OK;
 }
+static int bgeo2d_encode(mpmhip2d_ctx *m, int32_t verbose, void *dst, size_t capacity, size_t *written);
 int mpmhip2d_bgeo_encode(mpmhip2d_ctx *m, int32_t verbose, void *dst, size_t capacity, size_t *written) {
   if (!m || !dst || !written) return MPMHIP_EINVAL;
+  try { return bgeo2d_encode(m, verbose, dst, capacity, written); }  // (host staging vectors: no exception leaves the C ABI)
+  catch (const std::bad_alloc &) { return fail2d(m, MPMHIP_ENOMEM, "host allocation failed while assembling the frame"); }
+}
+static int bgeo2d_encode(mpmhip2d_ctx *m, int32_t verbose, void *dst, size_t capacity, size_t *written) {
   HIPCHK2D(m, hipSetDevice(m->device));
   auto &A = m->async;
   if (A.resident) {  // (a view of all pools; also pools particles added since)
@@ -106,7 +111,8 @@ int mpmhip2d_write_bgeo(mpmhip2d_ctx *m, const char *path, int32_t verbose) {
   if (!m || !path) return MPMHIP_EINVAL;
   size_t bytes = 0, written = 0;
   if (int rc = mpmhip2d_bgeo_size(m, verbose, &bytes)) return rc;
-  std::vector<uint8_t> img(bytes);
+  std::vector<uint8_t> img;
+  try { img.resize(bytes); } catch (const std::bad_alloc &) { return fail2d(m, MPMHIP_ENOMEM, "host allocation failed while assembling the frame"); }
   if (int rc = mpmhip2d_bgeo_encode(m, verbose, img.data(), img.size(), &written)) return rc;
   FILE *f = std::fopen(path, "wb");
   if (!f) return fail2d(m, MPMHIP_EINVAL, std::string("cannot open '") + path + "' for writing: " + std::strerror(errno));
@@ -198,8 +204,13 @@ int mpmhip2d_snapshot_save(mpmhip2d_ctx *m, void *dst, size_t cap) {
   }
   return MPMHIP_OK;
 }
+static int snap2d_load(mpmhip2d_ctx *m, const void *src, size_t size);
 int mpmhip2d_snapshot_load(mpmhip2d_ctx *m, const void *src, size_t size) {
   if (!m || !src || size < sizeof(Snap2D)) return MPMHIP_EINVAL;
+  try { return snap2d_load(m, src, size); }
+  catch (const std::bad_alloc &) { return fail2d(m, MPMHIP_ENOMEM, "host allocation failed while loading the snapshot"); }
+}
+static int snap2d_load(mpmhip2d_ctx *m, const void *src, size_t size) {
   HIPCHK2D(m, hipSetDevice(m->device));
   HIPCHK2D(m, hipStreamSynchronize(m->stream));
   auto &A = m->async;
