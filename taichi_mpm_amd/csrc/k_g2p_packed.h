@@ -29,8 +29,16 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p_packed(Params P, const float4 
                                                          const GroupParams *__restrict__ groups, const float4 *__restrict__ gridv,
                                                          const uint32_t *__restrict__ fat_slot, Counters *cnt_w,
                                                          uint32_t *__restrict__ key, uint8_t *__restrict__ blk_flag,
-                                                         const LevelSetDev *__restrict__ ls, const uint32_t *__restrict__ chunk_blk) {
+                                                         const LevelSetDev *__restrict__ ls, const uint32_t *__restrict__ chunk_blk
+#ifdef MPMHIP_TIMING_BUILD  // (variant library only, profiles/g2p_tile_time.py: wall-clock time a workgroup spends making tiles resident)
+                                                         , unsigned long long *__restrict__ tlog
+#endif
+                                                         ) {
   static_assert(NT == 256, "chunk_blk is written for 256-position chunks");
+#ifdef MPMHIP_TIMING_BUILD
+  const unsigned long long t_enter = wall_clock64();
+  unsigned long long t_tile = 0, n_tile = 0, n_chunk = 0;
+#endif
   __shared__ float4 tile[G2P_PK * TN];
   __shared__ float s_org[G2P_PK][4];    // origin (grid node of the tile's node (0, 0, 0)) of the block in each slot
   __shared__ GroupParams sgroups[G2P_LDS_GROUPS];
@@ -108,6 +116,9 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p_packed(Params P, const float4 
         if (a < na && st[s] < p1 && st[s + 1] > st[s] && tag[a % G2P_PK] != a) need |= 1u << s;
       }
       if (need) {  // uniform
+#ifdef MPMHIP_TIMING_BUILD
+        const unsigned long long t0 = wall_clock64();
+#endif
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();  // everyone is done with the tiles these replace
 #pragma unroll
@@ -127,6 +138,9 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p_packed(Params P, const float4 
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
+#ifdef MPMHIP_TIMING_BUILD
+        t_tile += wall_clock64() - t0; n_tile += __popc(need);
+#endif
       }
       if (first_pass) {
         // prefetch: records of the next chunk, index and metadata of the one after — BEHIND the tile loads above: the vector-memory
@@ -189,11 +203,20 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p_packed(Params P, const float4 
       if (st[G2P_PK] >= p1 || ab + G2P_PK >= na) break;  // uniform: the window reached the end of the chunk
       ab += G2P_PK;
     }
+#ifdef MPMHIP_TIMING_BUILD
+    n_chunk++;
+#endif
     k_cur++;
     m_cur = m_nx; m_nx = m_nn;
     i_cur = i_nx; i_nx = i_nn;
     g0 = n0; g1 = n1; g2 = n2; g3 = n3;
   }
+#ifdef MPMHIP_TIMING_BUILD
+  if (tlog && tid == 0) {
+    tlog[4 * (size_t)blockIdx.x] = wall_clock64() - t_enter; tlog[4 * (size_t)blockIdx.x + 1] = t_tile;
+    tlog[4 * (size_t)blockIdx.x + 2] = n_tile; tlog[4 * (size_t)blockIdx.x + 3] = n_chunk;
+  }
+#endif
   // slots behind the live range (particles deleted by earlier substeps have dropped out): dead for every consumer
   for (uint32_t t = n_sorted + blockIdx.x * NT + tid; t < P.n_slots; t += gridDim.x * NT) {
     key[t] = INVALID;

@@ -1134,7 +1134,11 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0) {
     const int wgs = c->g2p_wgs > 0 ? c->g2p_wgs : (c->n_slots < (2 << 20) ? 768 : 4096);
     hipLaunchKernelGGL(pk, dim3(wgs), dim3(256), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
                        (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
-                       c->blk_flag, (const LevelSetDev *)c->d_LS, (const uint32_t *)c->chunk_blk);
+                       c->blk_flag, (const LevelSetDev *)c->d_LS, (const uint32_t *)c->chunk_blk
+#ifdef MPMHIP_TIMING_BUILD
+                       , c->p2g_tlog
+#endif
+                       );
     c->sorted = false; c->keys_valid = true; c->affine_valid = true;
     if (!c->P.store_b) c->b_stale = true;
     return launch_check(c, "g2p_packed");
