@@ -74,7 +74,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p_packed(Params P, const float4 
   }
   uint32_t i_nx = lane_slot(k_cur + 1);
   // chunk metadata (uniform): the block holding the chunk's first position and the starts of the G2P_PK + 1 blocks from there —
-  // two dependent loads, taken one chunk ahead like the records
+  // two dependent (scalar) loads, requested while the chunk before is computed
   struct Meta { uint32_t ab; uint32_t st[G2P_PK + 1]; };
   auto load_meta = [&](uint32_t k) {
     const uint32_t c = chunk_of(k);
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p_packed(Params P, const float4 
     }
     return m;
   };
-  Meta m_cur = load_meta(k_cur), m_nx = load_meta(k_cur + 1);
+  Meta m_cur = load_meta(k_cur);
   float4 G0, G1, G2, G3, Q0, Q1, Q2, Q3, B0, B1, B2;
   G0 = G1 = G2 = G3 = Q0 = Q1 = Q2 = Q3 = B0 = B1 = B2 = make_float4(0, 0, 0, 0);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loop is entered with nothing pending (see k_g2p)
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p_packed(Params P, const float4 
     const uint32_t p0 = chunk_of(k_cur) * NT, p1 = min(p0 + NT, n_sorted), pos = p0 + tid;
     float4 n0, n1, n2, n3;
     uint32_t i_nn = INVALID;
-    Meta m_nn;
+    Meta m_nx;
     uint32_t ab = m_cur.ab;        // the block that holds p0 (uniform)
     uint32_t st[G2P_PK + 1];       // starts of the window's blocks (uniform; behind the last block: the live count)
 #pragma unroll
@@ -143,14 +143,14 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p_packed(Params P, const float4 
 #endif
       }
       if (first_pass) {
-        // prefetch: records of the next chunk, index and metadata of the one after — BEHIND the tile loads above: the vector-memory
+        // prefetch: records and metadata of the next chunk, index of the one after — BEHIND the tile loads above: the vector-memory
         // counter is in order, a wait for the tile would otherwise wait for these as well
         if (i_nx != INVALID) {
           const size_t i = i_nx;
           n0 = rg[i * 4 + 0]; n1 = rg[i * 4 + 1]; n2 = rg[i * 4 + 2]; n3 = rg[i * 4 + 3];
         }
         i_nn = lane_slot(k_cur + 2);
-        m_nn = load_meta(k_cur + 2);
+        m_nx = load_meta(k_cur + 1);
       }
       // this lane's block: the last one of the window that starts at or before its position
       uint32_t bkey = INVALID, out_slot = INVALID;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p_packed(Params P, const float4 
     n_chunk++;
 #endif
     k_cur++;
-    m_cur = m_nx; m_nx = m_nn;
+    m_cur = m_nx;
     i_cur = i_nx; i_nx = i_nn;
     g0 = n0; g1 = n1; g2 = n2; g3 = n3;
   }
