@@ -129,6 +129,7 @@ struct mpmhip_ctx {
   int p2g_wgs = 16384;        // workgroups of k_p2g (env MPMHIP_P2G_WGS)
   int p2g_split = 11;         // tuning knob (env MPMHIP_P2G_SPLIT): 10*NS + PS, see do_p2g
   int g2p_wgs = 0;            // workgroups of k_g2p; 0: by size (env MPMHIP_G2P_WGS pins it)
+  int n_cus = 256;            // compute units of the device
   int g2p_packed = -1;        // k_g2p_packed instead of k_g2p: -1 by size (from 2 M slots on; no rigid bodies, no tiling), 0 never, 1 wherever it
                               // applies (env MPMHIP_G2P_PACKED)
   uint32_t *chunk_blk = nullptr;  // per 256 positions of the sorted index: the block holding the first (k_cell_table -> k_g2p_packed)
@@ -538,6 +539,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   {  // the single-pass scans spin on their predecessors: their grids must fit on the device all at once (k_sort.h)
     int cus = 0, per_cu = 0, lowest = 1 << 20;
     A(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    if (cus > 0) c->n_cus = cus;
     const void *scans[3] = {(const void *)k_block_table, (const void *)k_cell_table<16>, (const void *)k_cell_table<64>};
     for (const void *k : scans) {
       A(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, 0));
@@ -1131,7 +1133,10 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0) {
       default: break;
     }
   if (pk) {
-    const int wgs = c->g2p_wgs > 0 ? c->g2p_wgs : (c->n_slots < (2 << 20) ? 768 : 4096);
+    // four times the device's resident set (three workgroups per CU): with equal work items what is left of the launch's tail is
+    // the partly filled last round — 4 096 workgroups are 5.33 rounds of 768.  At C3, lattice / after impact: 3 072 -> 287 / 336 us,
+    // 4 096 -> 287 / 352, 6 144 -> 291 / 343, 2 304 -> 296 / 346, 1 536 -> 292 / 350, 768 -> 304 / 350 (profiles/r04_u_g2p_wgs.txt)
+    const int wgs = c->g2p_wgs > 0 ? c->g2p_wgs : (c->n_slots < (2 << 20) ? 768 : 12 * c->n_cus);
     hipLaunchKernelGGL(pk, dim3(wgs), dim3(256), 0, c->stream, c->P, (const float4 *)c->rg, (float4 *)c->rg2, (float4 *)c->rp2,
                        (float4 *)c->rb2, c->cnt, c->act_blk, c->act_start, c->perm, c->d_groups, c->gridv, c->fat_slot, c->cnt, c->key,
                        c->blk_flag, (const LevelSetDev *)c->d_LS, (const uint32_t *)c->chunk_blk
