@@ -159,6 +159,7 @@ struct mpmhip_ctx {
   uint32_t *d_counts = nullptr;
   int *d_bounds = nullptr;
   uint32_t *h_pinned = nullptr;  // 64 KiB of pinned host memory for small readbacks (counters, migration table)
+  static constexpr int FILL_STATS_WORD = 16368;  // word offset of the block-fill statistics in that page (do_sort, g2p_is_packed)
   double *d_energy = nullptr;
   int counts_cap = 0;
   bool compact_requested = false;
@@ -520,6 +521,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(dmalloc(&c->cnt, 1));
   A(dmalloc(&c->d_LS, 1));
   A(hipHostMalloc((void **)&c->h_pinned, 65536, hipHostMallocDefault));
+  if (e == hipSuccess && c->h_pinned) memset(c->h_pinned, 0, 65536);
   A(dmalloc(&c->d_groups, (size_t)c->groups_cap));
   if (e != hipSuccess) {
     fail(c, MPMHIP_ENOMEM, "device allocation failed: %s (max_particles=%lld, max_blocks=%lld)", hipGetErrorString(e),
@@ -939,6 +941,9 @@ static int do_sort(mpmhip_ctx *c) {
   hipLaunchKernelGGL(small ? k_cell_table<16> : k_cell_table<64>, dim3(std::min(ct_chunks, c->scan_grid)), dim3(256), 0, st, P,
                      c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots, epoch, c->rank_runs_mul, c->chunk_blk);
   hipLaunchKernelGGL(k_perm, dim3(pg), dim3(256), 0, st, P, (const Counters *)c->cnt, c->key, c->rank, c->cell_start, c->perm);
+  // every 16th sort: (live particles, active blocks) on their way to the pinned page, never waited for — the host picks the G2P
+  // walk by how full the blocks are (g2p_is_packed) and may look at numbers a few substeps old
+  if ((c->sort_epoch & 15u) == 1u) (void)hipMemcpyAsync(c->h_pinned + mpmhip_ctx::FILL_STATS_WORD, c->cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
   c->sorted = true;
   c->keys_valid = false;  // key[] now holds k_rank's packed (rank, cell index) words
   int rc = launch_check(c, "sort");
@@ -1068,9 +1073,17 @@ static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
                      c->gridv, c->fat_slot, c->dense, c->T, c->d_boxes_cur, c->LS, phase);
   return launch_check(c, "grid");
 }
-// which G2P kernel the plain blocks of the next substep get (bench.py names the kernel of its roofline after it)
+// which G2P kernel the plain blocks of the next substep get (bench.py names the kernel of its roofline after it).  By size and by
+// how full the blocks are: k_g2p's chunks stay inside a block, so with 512 particles per block (the lattice the reference's benchmark
+// seeds) they are full and it is the faster walk by a few microseconds on most boxes; with 350 per block (the same scene after the
+// impact) a third of its lanes idle and the packed walk wins by 30 us.  The numbers come from the sort, a few substeps late.
 static bool g2p_is_packed(const mpmhip_ctx *c, int phase) {
-  const bool packed = c->g2p_packed < 0 ? c->n_slots >= (2 << 20) : c->g2p_packed != 0;
+  bool packed = c->g2p_packed != 0;
+  if (c->g2p_packed < 0) {
+    const volatile uint32_t *fill = c->h_pinned + mpmhip_ctx::FILL_STATS_WORD;  // {live particles, active blocks} of a recent sort (0, 0 before the first)
+    const uint32_t n_live = fill[0], n_act = fill[1];
+    packed = c->n_slots >= (2 << 20) && n_act > 0 && (uint64_t)n_live < (uint64_t)n_act * 448u;
+  }
   const uint32_t mask = material_mask(c);
   const bool one_plain_material = mask && !(mask & (mask - 1)) && mask != (1u << MPMHIP_VISCO);
   return packed && one_plain_material && !rigid_active(c) && !c->P.store_b && phase == 0 && !c->T.enabled && c->chunk_blk;
