@@ -181,8 +181,10 @@ def test_bench_and_examples_are_importable_without_a_gpu():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     assert {"c2", "c3", "c5"} <= set(bench.CONFIGS) and bench.CONFIGS["c3"]["res"] == 256 and bench.CONFIGS["c3"]["cells"] == 100
-    tbytes, src = bench.pmc_traffic("c3", "k_g2p_packed")  # (the G2P kernel of C3 since round 4)
+    tbytes, src = bench.pmc_traffic("c3", "k_g2p")
     assert tbytes and 1.0e9 < tbytes < 3.0e9 and "rocprofv3" in src  # the committed PMC passes (profiles/traffic_c3.json)
+    tbytes, src = bench.pmc_traffic("c3_evolved", "k_g2p_packed")  # (the G2P walk of the state after impact since round 4)
+    assert tbytes and 1.0e9 < tbytes < 3.0e9 and "rocprofv3" in src
     assert bench.pmc_traffic("c2", "k_g2p") == (None, None)
     for f in ("benchmark_3d.py", "sand_column.py"):
         py_compile.compile(os.path.join(root, "examples", f), doraise=True)
