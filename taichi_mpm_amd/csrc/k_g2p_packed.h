@@ -10,7 +10,9 @@
 // block among the chunk's at most K by comparing its position with their starts (k_cell_table wrote, per chunk, the block that
 // holds the chunk's first position), and reads its tile and the tile's origin from its slot.  A chunk that touches more than K
 // blocks (K consecutive blocks with fewer than 256 particles between them: spray) is done in several passes.
-// Workgroup w takes the chunks [w cpw, (w + 1) cpw): consecutive chunks, so tiles are reused.
+// A workgroup takes runs of G2P_RUN consecutive chunks (tiles are reused along a run), the runs dealt round-robin over the launch, so
+// that the workgroups resident together work on neighbouring blocks (their tiles share grid blocks in the L2).  The host launches
+// four rounds of the device's resident set and picks this walk when the blocks are NOT full (mpmhip.hip: g2p_is_packed).
 #pragma once
 #include "k_g2p.h"
 
