@@ -488,6 +488,7 @@ int mpmhip_async_snapshot_load(mpmhip_ctx *c, const void *src, size_t size) {
   if (h.dx != c->P.dx || h.unit_delta_t != A.cfg.unit_delta_t) return fail(c, MPMHIP_EINVAL, "snapshot has delta_x = %g, unit_delta_t = %g", h.dx, h.unit_delta_t);
   if ((int)h.n_groups > c->groups_cap || h.nblk != (int64_t)A.continuous.size() || h.containers < 0) return fail(c, MPMHIP_EINVAL, "snapshot header inconsistent with this ctx");
   if (h.n_groups < 0) return fail(c, MPMHIP_EINVAL, "snapshot header inconsistent with this ctx");
+  if ((uint64_t)h.containers > size / 136) return fail(c, MPMHIP_EINVAL, "snapshot size mismatch");  // (bounded before it is multiplied)
   if (size != sizeof(SnapAsync) + sizeof(GroupParams) * (size_t)h.n_groups + sizeof(int64_t) * 6 * (size_t)h.nblk +
                   (size_t)h.containers * (sizeof(uint32_t) + sizeof(int32_t) + 2 * 4 * sizeof(float4)))
     return fail(c, MPMHIP_EINVAL, "snapshot size mismatch");

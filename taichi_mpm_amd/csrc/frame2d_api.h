@@ -226,6 +226,9 @@ static int snap2d_load(mpmhip2d_ctx *m, const void *src, size_t size) {
   if (h.has_async && (h.nb[0] != A.nb[0] || h.nb[1] != A.nb[1] || h.nblk != (int64_t)A.nblk() || h.unit_delta_t != A.cfg.unit_delta_t))
     return fail2d(m, MPMHIP_EINVAL, "snapshot is of another block table / unit_delta_t");
   if (h.n_bodies && h.n_ranked > (uint32_t)m->h_smp.size()) return fail2d(m, MPMHIP_EINVAL, "snapshot holds more boundary particles than the scene's bodies have");
+  // (counts from an untrusted header: bounded by the blob before they are multiplied)
+  if ((uint64_t)h.n > size / 60 || (uint64_t)h.containers > size / 68 || (uint64_t)h.nblk > size / 48 || h.n_ranked > size / 4)
+    return fail2d(m, MPMHIP_EINVAL, "snapshot size mismatch");
   const size_t n = (size_t)h.n;
   size_t want = sizeof(Snap2D) + sizeof(GroupParams) * h.n_groups + n * 15 * 4;
   if (h.n_bodies) want += sizeof(mpm2d::Rigid2) * (size_t)h.n_bodies + sizeof(mpm2d::Joints2) + sizeof(uint32_t) * h.n_ranked + 4 * n;
