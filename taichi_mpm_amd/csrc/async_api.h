@@ -499,10 +499,17 @@ int mpmhip_async_snapshot_load(mpmhip_ctx *c, const void *src, size_t size) {
     const uint32_t *tags = reinterpret_cast<const uint32_t *>(q);
     const int32_t *ids = reinterpret_cast<const int32_t *>(q + sizeof(uint32_t) * n);
     if (h.next_pid < 0) return fail(c, MPMHIP_EINVAL, "snapshot header inconsistent with this ctx (next id %d)", h.next_pid);
+    // the scheduler's limits (first of the six block tables): powers of two in [1, 2^31], or update_dt_limits cannot use them
+    if (!AsyncSched::limits_are_sane((const char *)src + sizeof h + sizeof(GroupParams) * h.n_groups, (size_t)h.nblk))
+      return fail(c, MPMHIP_EINVAL, "snapshot block table holds a time-step limit that is not a power of two in [1, 2^31]");
+    const char *recg = q + (sizeof(uint32_t) + sizeof(int32_t)) * n;  // RecG per container: the group id at byte 52
     for (size_t i = 0; i < n; i++) {
       uint32_t tg; int32_t id;
       memcpy(&tg, tags + i, 4); memcpy(&id, ids + i, 4);
       if (tg == AS_FREE) continue;
+      uint32_t gid;
+      memcpy(&gid, recg + 64 * i + 52, 4);
+      if (gid >= (uint32_t)h.n_groups) return fail(c, MPMHIP_EINVAL, "snapshot container %zu names group %u of %d", i, gid, h.n_groups);
       if ((int64_t)(tg & ~AS_BACKUP) >= h.nblk) return fail(c, MPMHIP_EINVAL, "snapshot container %zu names block %u of %lld", i, tg & ~AS_BACKUP, (long long)h.nblk);
       if (id < 0 || id >= h.next_pid) return fail(c, MPMHIP_EINVAL, "snapshot container %zu has id %d outside [0, %d)", i, id, h.next_pid);
     }

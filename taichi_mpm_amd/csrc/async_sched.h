@@ -124,6 +124,17 @@ struct AsyncSched {
     limits_version = 0; lists_version = ~0ull;
   }
 
+  // a block table read from a snapshot blob: every `continuous` limit must be a power of two in [1, 2^31] — limits_from_table's
+  // doubling loop never ends on 0 at t = 0, and the alignment test (t & (limit - 1)) means nothing for other values
+  static bool limits_are_sane(const char *continuous_bytes, size_t n_blocks) {
+    for (size_t b = 0; b < n_blocks; b++) {
+      int64_t v;
+      memcpy(&v, continuous_bytes + 8 * b, 8);
+      if (v < 1 || v > (1ll << 31) || (v & (v - 1)) != 0) return false;
+    }
+    return true;
+  }
+
   // the block state machine of update_dt_limits (src/async/async_mpm.cpp:93-164) from the table the device reduced:
   // tab[3 b] = {bits of the smallest get_allowed_dt, bits of the largest |v|^2, number of pool containers}.  false: sched_err.
   bool limits_from_table(const uint32_t *tab, float dx) {

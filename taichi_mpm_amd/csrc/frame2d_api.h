@@ -252,7 +252,17 @@ static int snap2d_load(mpmhip2d_ctx *m, const void *src, size_t size) {
     }
   }
   const char *q = arr + n * 15 * 4;
-  if (h.n_bodies) q += sizeof(mpm2d::Rigid2) * (size_t)h.n_bodies + sizeof(mpm2d::Joints2) + sizeof(uint32_t) * h.n_ranked + 4 * n;
+  if (h.n_bodies) {  // the joints index the body table on the device (k2_articulate)
+    mpm2d::Joints2 J;
+    memcpy(&J, q + sizeof(mpm2d::Rigid2) * (size_t)h.n_bodies, sizeof J);
+    if (J.n < 0 || J.n > mpm2d::MAX_JOINTS2) return fail2d(m, MPMHIP_EINVAL, "snapshot joint table inconsistent");
+    for (int i = 0; i < J.n; i++)
+      if (J.j[i].obj0 < 0 || J.j[i].obj0 >= h.n_bodies || J.j[i].obj1 < 0 || J.j[i].obj1 >= h.n_bodies)
+        return fail2d(m, MPMHIP_EINVAL, "snapshot joint names a body outside the scene's table");
+    q += sizeof(mpm2d::Rigid2) * (size_t)h.n_bodies + sizeof(mpm2d::Joints2) + sizeof(uint32_t) * h.n_ranked + 4 * n;
+  }
+  if (h.has_async && !AsyncSched::limits_are_sane(q, (size_t)h.nblk))
+    return fail2d(m, MPMHIP_EINVAL, "snapshot block table holds a time-step limit that is not a power of two in [1, 2^31]");
   if (h.has_async) {
     const char *tags = q + sizeof(int64_t) * 6 * (size_t)h.nblk, *recs = tags + 4 * (size_t)h.containers;
     for (size_t i = 0; i < (size_t)h.containers; i++) {

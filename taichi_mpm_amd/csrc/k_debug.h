@@ -75,14 +75,17 @@ __global__ void k_debug_force(GroupParams g, int64_t n, const float *F, const fl
   }
 }
 // plasticity alone, or (force_out != nullptr) the fused plasticity + next-step force of k_g2p
-__global__ void k_debug_plasticity(GroupParams g, int64_t n, const float *cdg, float *F, float *aux, float *force_out) {
+// (the fused form runs as k_g2p runs it: the refinement of an ill-conditioned F works in 20 floats of LDS private to the lane)
+__global__ __launch_bounds__(256) void k_debug_plasticity(GroupParams g, int64_t n, const float *cdg, float *F, float *aux,
+                                                          float *force_out) {
+  __shared__ float4 slab[256 * 5];
   for (int64_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     mat3 f, c;
     for (int k = 0; k < 9; k++) { f.m[k] = F[9 * i + k]; c.m[k] = cdg[9 * i + k]; }
     float a = aux[i];
     if (force_out) {
       mat3 st;
-      plasticity_and_force(g, c, f, a, st);
+      plasticity_and_force<MAT_ALL, true>(g, c, f, a, st, reinterpret_cast<float *>(slab + threadIdx.x * 5));
       for (int k = 0; k < 9; k++) force_out[9 * i + k] = st.m[k];
     } else {
       plasticity(g, c, f, a);

@@ -14,7 +14,9 @@ __device__ __forceinline__ void g2p_particle(const Params &P, const float scale,
                                              const GroupParams &g, const LevelSetDev *__restrict__ ls, Counters *cnt_w,
                                              uint32_t *__restrict__ key, const uint32_t pos, uint32_t &bkey, uint32_t &out_slot,
                                              float4 &G0, float4 &G1, float4 &G2, float4 &G3, float4 &Q0, float4 &Q1, float4 &Q2,
-                                             float4 &Q3, float4 &B0, float4 &B1, float4 &B2) {
+                                             float4 &Q3, float4 &B0, float4 &B1, float4 &B2, float4 *lane_lds) {
+    // (lane_lds: five float4 of LDS private to this lane — its row of the wave's store-staging slab, idle until the records
+    // are staged: scratch of the rare refinement of an ill-conditioned F, mpm_math.h: sym_eig3_refine)
     const float x0 = g0.x, x1 = g0.y, x2 = g0.z;
     const float X0 = x0 * P.idx - ox, X1 = x1 * P.idx - oy, X2 = x2 * P.idx - oz;
     const int c0 = (int)(X0 - 0.5f), c1 = (int)(X1 - 0.5f), c2 = (int)(X2 - 0.5f);
@@ -86,7 +88,7 @@ __device__ __forceinline__ void g2p_particle(const Params &P, const float scale,
     F.m[7] = g2.w; F.m[8] = g3.x;
     float aux = g0.w;
     mat3 stress;
-    if (!MPM_ABLATE(P, 2)) plasticity_and_force<MATS>(g, cdg, F, aux, stress);  // :950 + next substep's :509
+    if (!MPM_ABLATE(P, 2)) plasticity_and_force<MATS, true>(g, cdg, F, aux, stress, reinterpret_cast<float *>(lane_lds));  // :950 + next substep's :509
     else stress = cdg;
     float nx0 = fmaf(v0, P.dt, x0), nx1 = fmaf(v1, P.dt, x1), nx2 = fmaf(v2, P.dt, x2);  // :951
     if (P.clamp_pos) {  // generic path only (optimized = false): p.pos clamped into [0, res - eps], :668-670
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
     uint32_t bkey = INVALID, out_slot = INVALID;
     auto particle = [&](const GroupParams &g) __attribute__((always_inline)) {
       g2p_particle<MATS, STORE_B, RIGID>(P, scale, tile, ox, oy, oz, g0, g1, g2, g3, g, ls, cnt_w, key, cur.p + tid, bkey, out_slot, G0, G1,
-                                         G2, G3, Q0, Q1, Q2, Q3, B0, B1, B2);
+                                         G2, G3, Q0, Q1, Q2, Q3, B0, B1, B2, xp + lane * 5);
     };
     // Group parameters are read at use (keeps ~20 VGPRs free) from the workgroup's LDS copy of the table: DS reads
     // wait on lgkmcnt, whereas vector loads in the middle of the arithmetic wait on vmcnt and with it on the

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p_packed(Params P, const float4 
         const uint32_t slot = (ab + sl) % G2P_PK;
         g2p_particle<MATS, STORE_B, false>(P, scale, tile + slot * TN, s_org[slot][0], s_org[slot][1], s_org[slot][2], g0, g1, g2, g3,
                                            sgroups[__float_as_uint(g3.y) & (G2P_LDS_GROUPS - 1)], ls, cnt_w, key, pos, bkey, out_slot, G0,
-                                           G1, G2, G3, Q0, Q1, Q2, Q3, B0, B1, B2);
+                                           G1, G2, G3, Q0, Q1, Q2, Q3, B0, B1, B2, xp + lane * 5);
         done = true;
       }
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the prefetched records land before this chunk's stores go out (see k_g2p)

@@ -79,6 +79,43 @@ __device__ __forceinline__ uint32_t sum_predecessors(const unsigned long long *s
   wg_exclusive_scan_256(pre, lds, total);
   return total;
 }
+// The cell table's scan carries TWO sums in one word: particles (31 bits: n_slots < 2^31) and the chunk's owner entries of the grid
+// pass (<= 8 per block, <= 512 per chunk: 10 bits); the epoch keeps the remaining 23 bits (consecutive sorts always differ).
+__device__ __forceinline__ unsigned long long wg_exclusive_scan_256_u64(unsigned long long v, unsigned long long *lds /*>=4*/,
+                                                                        unsigned long long &total) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long u = __shfl_up(inc, off);
+    if ((int)lane >= off) inc += u;
+  }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  unsigned long long base = 0;
+  for (uint32_t w = 0; w < wave; w++) base += lds[w];
+  total = lds[0] + lds[1] + lds[2] + lds[3];
+  __syncthreads();
+  return base + inc - v;
+}
+__device__ __forceinline__ void publish2(unsigned long long *slot, uint32_t epoch, uint32_t particles, uint32_t owners) {
+  __hip_atomic_store(slot, ((unsigned long long)(epoch & 0x7FFFFFu) << 41) | ((unsigned long long)owners << 31) | particles,
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// sums over the chunks [0, chunk): (owners << 32) | particles, for every thread of the 256-thread workgroup
+__device__ __forceinline__ unsigned long long sum_predecessors2(const unsigned long long *slots, uint32_t chunk, uint32_t epoch,
+                                                                unsigned long long *lds) {
+  unsigned long long pre = 0;
+  for (uint32_t j = threadIdx.x; j < chunk; j += 256) {
+    unsigned long long w;
+    while ((uint32_t)((w = __hip_atomic_load(slots + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 41) != (epoch & 0x7FFFFFu))
+      __builtin_amdgcn_s_sleep(1);
+    pre += (((w >> 31) & 0x3FFull) << 32) | (w & 0x7FFFFFFFull);
+  }
+  unsigned long long total;
+  wg_exclusive_scan_256_u64(pre, lds, total);
+  return total;
+}
 // chunks are dealt round-robin by workgroup id: chunk = blockIdx.x + round * gridDim.x
 __device__ __forceinline__ uint32_t next_chunk(uint32_t &round) {
   __syncthreads();  // the previous chunk's LDS readers are done
@@ -232,9 +269,51 @@ __device__ __forceinline__ uint32_t run_offset(const RunInfo &R, int lane, int j
   return (uint32_t)(R.jh[j] >= 0 ? j - R.jh[j] : 4 * lane + j - R.s_in);
 }
 
+// ---- preparation of the grid pass (k_grid.h), whose work items are the touched grid blocks: the tile of active block b overlaps
+// the 8 grid blocks c = b + o, o in {0,1}^3; c is processed by its OWNER, the source block c - q with the smallest q.
+//   nbr[32 a + n]  n < 27: dense slot of b + (n/9-1, n/3%3-1, n%3-1) or INVALID; [27] Morton key of b; [28] owner mask of a
+//                  (k_rank: one active block per wave, beside its own work — bitmap and prefix are complete since k_block_table)
+//   own_list[]     one entry 8 a + o per owned candidate, compacted with the second sum of k_cell_table's scan (cnt->n_own entries)
+// so k_grid starts from a list without holes: one wave per touched grid block, one coalesced 128-byte row instead of the chain
+// block list -> bitmap -> prefix, no wave that finds out it owns nothing (at 1 M particles 85 % of the (block, candidate) pairs).
+__device__ __forceinline__ constexpr uint32_t nb27_bit(int dx, int dy, int dz) { return 1u << (((dx + 1) * 3 + (dy + 1)) * 3 + (dz + 1)); }
+__device__ __forceinline__ constexpr uint32_t lower_sources(int o) {  // neighbours that own candidate o before this block does
+  uint32_t m = 0;
+  for (int q = 0; q < o; q++) m |= nb27_bit((o >> 2) - (q >> 2), ((o >> 1) & 1) - ((q >> 1) & 1), (o & 1) - (q & 1));
+  return m;
+}
+struct FillStats { uint32_t n_live, n_active, n_own, epoch; };  // what the last sort saw, stored to a pinned host page (never waited for)
+
+// the row of active block a; all 64 lanes of a wave call it
+__device__ __forceinline__ void write_neighbour_row(const Params &P, const uint32_t a, const uint32_t key, const uint32_t lane,
+                                                    const uint32_t *__restrict__ bits, const uint32_t *__restrict__ wprefix,
+                                                    uint32_t *__restrict__ nbr) {
+  uint32_t nslot = INVALID;
+  if (lane < 27) {
+    int bx, by, bz;
+    demorton3(key, bx, by, bz);
+    const int sx = bx + (int)lane / 9 - 1, sy = by + ((int)lane / 3) % 3 - 1, sz = bz + (int)lane % 3 - 1;
+    if (sx >= 0 && sy >= 0 && sz >= 0) {
+      const uint32_t bk = morton3(sx, sy, sz);
+      if (bk < P.nbw * 32u && block_active(bits, bk)) {
+        // (a slot beyond max_blocks has no tile: the block table overflowed, the sticky capacity error is set)
+        const uint32_t ns = block_slot(bits, wprefix, bk);
+        if (ns < P.max_blocks) nslot = ns;
+      }
+    }
+  }
+  const uint32_t amask = (uint32_t)__ballot(nslot != INVALID);
+  uint32_t m = 0;
+#pragma unroll
+  for (int o = 0; o < 8; o++)
+    if (!(amask & lower_sources(o))) m |= 1u << o;
+  if (lane < 32) nbr[(size_t)a * 32 + lane] = lane < 27 ? nslot : (lane == 27 ? key : (lane == 28 ? m : 0u));
+}
+
 __global__ __launch_bounds__(256) void k_rank(Params P, uint32_t *__restrict__ key, uint32_t *__restrict__ rank,
                                                uint32_t *__restrict__ cell_cnt, const uint32_t *__restrict__ bits,
-                                               const uint32_t *__restrict__ wprefix, Counters *cnt) {
+                                               const uint32_t *__restrict__ wprefix, Counters *cnt,
+                                               const uint32_t *__restrict__ act_blk, uint32_t *__restrict__ nbr) {
   __shared__ uint32_t tkey[RANK_TAB], tcnt[RANK_TAB];
   __shared__ uint32_t s_heads;
   const uint32_t n = P.n_slots;
@@ -242,7 +321,13 @@ __global__ __launch_bounds__(256) void k_rank(Params P, uint32_t *__restrict__ k
   const uint32_t mode = cnt->rank_mode;  // uniform over the grid
   if (threadIdx.x == 0) s_heads = 0u;
   uint32_t my_heads = 0u;
-  const uint32_t cb = packed_cell_bits(P, min(cnt->n_active, P.max_blocks)), rmax = (1u << (32u - cb)) - 1u;
+  const uint32_t na = min(cnt->n_active, P.max_blocks);
+  const uint32_t cb = packed_cell_bits(P, na), rmax = (1u << (32u - cb)) - 1u;
+  // the grid pass's neighbour rows (see above): one active block per wave; the block's key is requested here, the lookups follow
+  // behind the batches (one more round trip at the end of a wave instead of two in front of its own loads)
+  const uint32_t row_a = blockIdx.x * 4u + (uint32_t)wave;
+  uint32_t row_key = 0;
+  if (row_a < na) row_key = act_blk[row_a];
   const uint32_t nbatch = (n + RANK_BATCH - 1) / RANK_BATCH;
   for (uint32_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
     const uint32_t i0 = b * RANK_BATCH + (uint32_t)wave * 256u + 4u * (uint32_t)lane;
@@ -322,6 +407,9 @@ __global__ __launch_bounds__(256) void k_rank(Params P, uint32_t *__restrict__ k
         if (i0 + j < n) key[i0 + j] = w[j];
     }
   }
+  if (row_a < na) write_neighbour_row(P, row_a, row_key, (uint32_t)lane, bits, wprefix, nbr);
+  for (uint32_t a = row_a + gridDim.x * 4u; a < na; a += gridDim.x * 4u)  // (more active blocks than waves: tiny particle counts)
+    write_neighbour_row(P, a, act_blk[a], (uint32_t)lane, bits, wprefix, nbr);
   __syncthreads();
   if ((blockIdx.x & 15u) == 0u) {
 #pragma unroll
@@ -336,16 +424,23 @@ __global__ __launch_bounds__(256) void k_rank(Params P, uint32_t *__restrict__ k
 // sentinel at [n_active]) and cell_start[a*64 + c] (sentinel at [n_active*64]): the particles of cell i are
 // perm[cell_start[i] .. cell_start[i+1]).  Zeroes the counters behind itself.  Chunk = the 64 blocks
 // [CT_BLOCKS t, CT_BLOCKS (t + 1)): each of the 4 waves takes CT_BLOCKS / 4 of them, one lane per cell.
+//
+// The same scan compacts the owner list of the grid pass (see above k_rank) from the rows' owner masks: its second sum.
 template <int CT_BLOCKS>  // blocks per chunk: 64 for large problems, 16 when there are few blocks (shorter chains,
                            // more workgroups: 35 -> 31 us of sort at 1 M particles, but 90 -> 100 us at 8 M)
 __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uint32_t *__restrict__ cell_cnt,
                                                     uint32_t *__restrict__ act_start,
                                                     uint32_t *__restrict__ cell_start,
                                                     unsigned long long *__restrict__ slots, uint32_t epoch,
-                                                    uint32_t rank_runs_mul, uint32_t *__restrict__ chunk_blk) {
-  __shared__ uint32_t lds[8];
+                                                    uint32_t rank_runs_mul, uint32_t *__restrict__ chunk_blk,
+                                                    const uint32_t *__restrict__ nbr, uint32_t *__restrict__ own_list,
+                                                    FillStats *__restrict__ stats) {
+  __shared__ unsigned long long lds[8];
   constexpr int CT_BPW = CT_BLOCKS / 4;  // blocks per wave
-  __shared__ uint32_t blk_tot[CT_BLOCKS];
+  __shared__ uint32_t blk_tot[CT_BLOCKS], blk_cnt[CT_BLOCKS], own_tot[CT_BLOCKS], own_mask[CT_BLOCKS];
+  // exclusive in-block prefix of every cell of the chunk's blocks, parked in LDS between the two halves of a chunk (in registers
+  // it costs the kernel its fifth workgroup per CU, and the host sizes the scans' grids from what stays resident)
+  __shared__ uint32_t excl_s[CT_BLOCKS][64];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // k_rank of this sort is complete: its run statistics choose the path of the next one (see k_rank)
     cnt->rank_mode = (cnt->run_heads * rank_runs_mul > P.n_slots) ? 1u : 0u;
@@ -358,8 +453,12 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
     const uint32_t chunk = next_chunk(round);
     const uint32_t a0 = chunk * CT_BLOCKS;
     if (a0 >= na && !(na == 0 && chunk == 0)) return;
-    uint32_t excl[CT_BPW];  // exclusive in-block prefix of this lane's cell, for the wave's blocks
-    uint32_t tot[CT_BPW];   // (lane 63: the block's particle count)
+    if (lane < CT_BPW) {  // owner masks of the wave's blocks (k_rank wrote the rows): one lane per block
+      const uint32_t a = a0 + wave * CT_BPW + lane;
+      const uint32_t m = a < na ? nbr[(size_t)a * 32 + 28] : 0u;
+      own_mask[wave * CT_BPW + lane] = m;
+      own_tot[wave * CT_BPW + lane] = (uint32_t)__popc(m);
+    }
 #pragma unroll
     for (int i = 0; i < CT_BPW; i++) {
       const uint32_t a = a0 + wave * CT_BPW + i;
@@ -374,35 +473,42 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
         const uint32_t u = __shfl_up(v, off);
         if ((int)lane >= off) v += u;
       }
-      excl[i] = v - c;
-      tot[i] = v;
-      if (lane == 63) blk_tot[wave * CT_BPW + i] = v;
+      excl_s[wave * CT_BPW + i][lane] = v - c;
+      if (lane == 63) { blk_tot[wave * CT_BPW + i] = v; blk_cnt[wave * CT_BPW + i] = v; }
     }
     __syncthreads();
-    // exclusive scan of the 64 block totals (threads 0..63 hold one block each; other threads contribute 0)
-    const uint32_t mine = threadIdx.x < CT_BLOCKS ? blk_tot[threadIdx.x] : 0u;
-    uint32_t total;
-    const uint32_t boff = wg_exclusive_scan_256(mine, lds, total);
-    if (threadIdx.x == 0) publish(slots + chunk, epoch, total);
-    if (threadIdx.x < CT_BLOCKS) blk_tot[threadIdx.x] = boff;
-    const uint32_t chunk_base = sum_predecessors(slots, chunk, epoch, lds);  // its barriers also cover blk_tot
+    // exclusive scan of the block totals (threads 0..CT_BLOCKS-1 hold one block each; other threads contribute 0):
+    // (owner entries << 32) | particles
+    const unsigned long long mine =
+        threadIdx.x < CT_BLOCKS ? (((unsigned long long)own_tot[threadIdx.x] << 32) | blk_tot[threadIdx.x]) : 0ull;
+    unsigned long long total;
+    const unsigned long long boff = wg_exclusive_scan_256_u64(mine, lds, total);
+    if (threadIdx.x == 0) publish2(slots + chunk, epoch, (uint32_t)total, (uint32_t)(total >> 32));
+    if (threadIdx.x < CT_BLOCKS) { blk_tot[threadIdx.x] = (uint32_t)boff; own_tot[threadIdx.x] = (uint32_t)(boff >> 32); }
+    const unsigned long long base2 = sum_predecessors2(slots, chunk, epoch, lds);  // its barriers also cover blk_tot / own_tot
+    const uint32_t chunk_base = (uint32_t)base2, own_base = (uint32_t)(base2 >> 32);
 #pragma unroll
     for (int i = 0; i < CT_BPW; i++) {
       const uint32_t a = a0 + wave * CT_BPW + i;
       if (a < na) {
         const uint32_t start = chunk_base + blk_tot[wave * CT_BPW + i];
-        cell_start[(size_t)a * BC + lane] = start + excl[i];
+        cell_start[(size_t)a * BC + lane] = start + excl_s[wave * CT_BPW + i][lane];
         if (lane == 0) act_start[a] = start;
+        const uint32_t om = own_mask[wave * CT_BPW + i];
+        if (lane < 8 && ((om >> lane) & 1u))
+          own_list[own_base + own_tot[wave * CT_BPW + i] + (uint32_t)__popc(om & ((1u << lane) - 1u))] = a * 8u + lane;
         // k_g2p_packed walks the sorted index in chunks of 256 positions: the block holding position 256 k, for every k inside this block
         if (chunk_blk && lane == 63)
-          for (uint32_t k = (start + 255u) >> 8; (k << 8) < start + tot[i]; k++) chunk_blk[k] = a;
+          for (uint32_t k = (start + 255u) >> 8, end = start + blk_cnt[wave * CT_BPW + i]; (k << 8) < end; k++) chunk_blk[k] = a;
       }
     }
     if (a0 + CT_BLOCKS >= na && threadIdx.x == 0) {  // last chunk: sentinels + live count
-      const uint32_t grand = chunk_base + total;
+      const uint32_t grand = chunk_base + (uint32_t)total, n_own = own_base + (uint32_t)(total >> 32);
       act_start[na] = grand;
       cell_start[(size_t)na * BC] = grand;
       cnt->n_sorted = grand;
+      cnt->n_own = n_own;
+      if (stats) { stats->n_live = grand; stats->n_active = na; stats->n_own = n_own; stats->epoch = epoch; }
     }
     if (na == 0) return;
   }

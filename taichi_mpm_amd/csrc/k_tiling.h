@@ -15,25 +15,36 @@ __global__ __launch_bounds__(256) void k_halo_pack(Params P, Tiling T, const Dev
                                                    const uint32_t *__restrict__ wprefix,
                                                    const float4 *__restrict__ tiles) {
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T.box_nodes; t += gridDim.x * blockDim.x) {
+    // the node's box: the offsets ascend, so its index is the number of boxes that start at or before t (independent
+    // wave-uniform loads: one round trip instead of a chain of them)
     int b = 0;
-    while (b + 1 < T.n_boxes && t >= boxes[b + 1].off) b++;
+    for (int i = 1; i < T.n_boxes; i++) b += t >= boxes[i].off ? 1 : 0;
     const DevBox &B = boxes[b];
     const uint32_t r = t - B.off;
     const int z = r % B.dim[2], y = (r / B.dim[2]) % B.dim[1], x = r / (B.dim[2] * B.dim[1]);
     const int gi = B.lo[0] + x, gj = B.lo[1] + y, gk = B.lo[2] + z;
     const int cx = gi >> 2, cy = gj >> 2, cz = gk >> 2, lx = gi & 3, ly = gj & 3, lz = gk & 3;
-    float4 acc = make_float4(0, 0, 0, 0);
+    // the <= 8 lookups first (independent: one round trip), then the tiles (one more)
+    uint32_t slot[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       const int qx = q >> 2, qy = (q >> 1) & 1, qz = q & 1;
       const int sx = cx - qx, sy = cy - qy, sz = cz - qz;
       const int tx = lx + 4 * qx, ty = ly + 4 * qy, tz = lz + 4 * qz;
+      slot[q] = INVALID;
       if (sx < 0 || sy < 0 || sz < 0 || tx >= TS || ty >= TS || tz >= TS) continue;
       const uint32_t bk = morton3(sx, sy, sz);
       if (bk >= P.nbw * 32u || !block_active(bits, bk)) continue;
-      const uint32_t slot = block_slot(bits, wprefix, bk);
-      if (slot >= P.max_blocks) continue;
-      const float4 v = tiles[(size_t)slot * TN + (tx * TS + ty) * TS + tz];
+      const uint32_t s = block_slot(bits, wprefix, bk);
+      if (s < P.max_blocks) slot[q] = s;
+    }
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int qx = q >> 2, qy = (q >> 1) & 1, qz = q & 1;
+      const int tx = lx + 4 * qx, ty = ly + 4 * qy, tz = lz + 4 * qz;
+      if (slot[q] == INVALID) continue;
+      const float4 v = tiles[(size_t)slot[q] * TN + (tx * TS + ty) * TS + tz];
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     B.send[r] = acc;

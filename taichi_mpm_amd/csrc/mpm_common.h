@@ -60,6 +60,7 @@ struct Counters {
   uint32_t error;     // bit0: active blocks exceeded max_blocks
   uint32_t run_heads;  // k_rank: runs of equal keys in adjacent slots seen by this sort (statistics for the next one)
   uint32_t rank_mode;  // k_rank path of the NEXT sort: 0 one global atomic per run, 1 LDS hash per 1024 slots
+  uint32_t n_own;      // entries of the grid pass's owner list (k_cell_table -> k_grid): touched grid blocks of this sort
 };
 
 struct Params {

@@ -96,6 +96,116 @@ __device__ __forceinline__ void jacobi_rotate(float &app, float &aqq, float &apq
   up2 = np2;
 }
 
+// Ill-conditioned F: the decomposition is finished on F itself, one-sided (Hestenes), preconditioned by the U the eigen-solve of
+// F F^T found (see sym_eig3_FFt): B = U^T F has nearly orthogonal rows sigma_k v_k^T; two cyclic sweeps of plane rotations make
+// them orthogonal, U's columns rotate along, lam_k = |b_k|^2.  One-sided Jacobi on a row-scaled well-conditioned matrix gives
+// every singular value to a relative accuracy ~ eps, whatever the condition number (Demmel & Veselic 1992); measured: 2e-6 at
+// cond 1e2, 2e-4 at cond 1e4 against 8e-4 / 5.0 of sqrt(eig(F F^T)) (profiles/r05_c_illcond_*.txt).
+// (Re-measuring |F^T u_k| with the eigenvectors as they are — no rotations — was built first and is not enough: the eigenvectors
+// of the two small singular values mix by ~ eps cond^2 / gap, and the larger of the two then leaks into the smaller.)
+// Register budget: k_g2p keeps three workgroups per CU only below 168 VGPRs, and U, B and F in registers on top of a particle's
+// other state cost it 4..14 more than it has (k_g2p_packed: 163 -> 175).  With `lds` (20 floats of LDS private to the lane: its
+// row of the wave's store-staging slab, idle while a particle is computed) U and B live THERE while the rotations run: a
+// rotation holds two rows, two columns and its own scalars, F is formed again as U B at the end (its rounding, eps |F|, is what
+// F_new = R F carries anyway) — the rare path then needs fewer registers than the common one.  Without `lds` (k_affine, the
+// colour-aware kernels, the debug entry points): the same arithmetic in registers.
+__device__ __forceinline__ void plane_rotation(const float app, const float aqq, const float apq, float &c, float &sn) {
+  // (cos, sin) that annihilate the off-diagonal of the 2x2 Gram block {app, apq; apq, aqq}: the small-angle root of jacobi_rotate
+  const float d = aqq - app, x = apq + apq;
+  const float xx = x * x;
+  const float h = fast_sqrt(fmaf(d, d, xx));
+  const float den = fabsf(d) + h;
+  const float n2 = fmaf(den, den, xx);
+  const float r = __builtin_amdgcn_rsqf(n2);
+  const bool live = n2 > 1e-30f;
+  const uint32_t sd = __float_as_uint(d) & 0x80000000u;
+  c = live ? den * r : 1.0f;
+  sn = live ? __uint_as_float(__float_as_uint(x * r) ^ sd) : 0.0f;
+}
+// (the empty asm statements end the compiler's scheduling regions: left alone it hoists the LDS loads of all six rotations to the
+// front and the kernel's allocation grows by 50 registers — __launch_bounds__(256, 2) only tells it that 256 are free)
+#define MPM_SCHED_FENCE() asm volatile("" ::: "memory")
+template <bool IN_LDS>
+__device__ __forceinline__ void sym_eig3_refine(mat3 &F, mat3 &U, float lam[3], float *lds) {
+  if constexpr (IN_LDS) {
+    // lds[3 k + r] = U(r, k) (columns), lds[9 + 3 k + c] = B(k, c) (rows)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) lds[9 + 3 * k + c] = fmaf(U(0, k), F(0, c), fmaf(U(1, k), F(1, c), U(2, k) * F(2, c)));
+#pragma unroll
+      for (int r = 0; r < 3; r++) lds[3 * k + r] = U(r, k);
+    }
+    MPM_SCHED_FENCE();
+#pragma unroll
+    for (int sweep = 0; sweep < 2; sweep++)
+#pragma unroll
+      for (int pair = 0; pair < 3; pair++) {
+        const int p = pair == 2 ? 1 : 0, q = pair == 0 ? 1 : 2;
+        float bp[3], bq[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { bp[k] = lds[9 + 3 * p + k]; bq[k] = lds[9 + 3 * q + k]; }
+        float c, sn;
+        plane_rotation(fmaf(bp[0], bp[0], fmaf(bp[1], bp[1], bp[2] * bp[2])), fmaf(bq[0], bq[0], fmaf(bq[1], bq[1], bq[2] * bq[2])),
+                       fmaf(bp[0], bq[0], fmaf(bp[1], bq[1], bp[2] * bq[2])), c, sn);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          lds[9 + 3 * p + k] = c * bp[k] - sn * bq[k];
+          lds[9 + 3 * q + k] = sn * bp[k] + c * bq[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const float up = lds[3 * p + k], uq = lds[3 * q + k];
+          lds[3 * p + k] = c * up - sn * uq;
+          lds[3 * q + k] = sn * up + c * uq;
+        }
+        MPM_SCHED_FENCE();
+      }
+    float B[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) B[k] = lds[9 + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) lam[k] = fmaf(B[3 * k], B[3 * k], fmaf(B[3 * k + 1], B[3 * k + 1], B[3 * k + 2] * B[3 * k + 2]));
+#pragma unroll
+    for (int r = 0; r < 3; r++) {  // F = U B, row by row
+      const float u0 = lds[r], u1 = lds[3 + r], u2 = lds[6 + r];
+#pragma unroll
+      for (int c = 0; c < 3; c++) F(r, c) = fmaf(u0, B[c], fmaf(u1, B[3 + c], u2 * B[6 + c]));
+    }
+    MPM_SCHED_FENCE();
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+      for (int r = 0; r < 3; r++) U(r, k) = lds[3 * k + r];
+    MPM_SCHED_FENCE();
+    return;
+  }
+  float b[3][3];  // B = U^T F
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) b[k][c] = fmaf(U(0, k), F(0, c), fmaf(U(1, k), F(1, c), U(2, k) * F(2, c)));
+#pragma unroll
+  for (int sweep = 0; sweep < 2; sweep++)
+#pragma unroll
+    for (int pair = 0; pair < 3; pair++) {
+      const int p = pair == 2 ? 1 : 0, q = pair == 0 ? 1 : 2;
+      float c, sn;
+      plane_rotation(fmaf(b[p][0], b[p][0], fmaf(b[p][1], b[p][1], b[p][2] * b[p][2])),
+                     fmaf(b[q][0], b[q][0], fmaf(b[q][1], b[q][1], b[q][2] * b[q][2])),
+                     fmaf(b[p][0], b[q][0], fmaf(b[p][1], b[q][1], b[p][2] * b[q][2])), c, sn);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const float np = c * b[p][k] - sn * b[q][k], nq = sn * b[p][k] + c * b[q][k];
+        b[p][k] = np; b[q][k] = nq;
+        const float up = c * U(k, p) - sn * U(k, q), uq = sn * U(k, p) + c * U(k, q);
+        U(k, p) = up; U(k, q) = uq;
+      }
+    }
+#pragma unroll
+  for (int k = 0; k < 3; k++) lam[k] = fmaf(b[k][0], b[k][0], fmaf(b[k][1], b[k][1], b[k][2] * b[k][2]));
+}
+
 constexpr int kJacobiSweeps = 4;
 #ifndef MPM_JACOBI_TOL
 #define MPM_JACOBI_TOL 1e-7f
@@ -106,7 +216,10 @@ constexpr int kJacobiSweeps = 4;
 // wavefront stops as soon as every lane's off-diagonal is below 1e-7 * trace (all users are isotropic functions
 // U f(lam) U^T, whose error is ~f' * |off-diagonal|, also for near-equal eigenvalues).  The test runs before every
 // sweep: material at rest or in free fall (F F^T diagonal to rounding) costs no sweep at all.
-__device__ __forceinline__ void sym_eig3_FFt(const mat3 &F, mat3 &U, float lam[3]) {
+// (F is const in effect: the refinement of an ill-conditioned F may rebuild it from its factors, equal to rounding.)
+// lds: see sym_eig3_refine.
+template <bool IN_LDS = false>
+__device__ __forceinline__ void sym_eig3_FFt(mat3 &F, mat3 &U, float lam[3], float *lds = nullptr) {
   float a00 = fmaf(F(0, 0), F(0, 0), fmaf(F(0, 1), F(0, 1), F(0, 2) * F(0, 2)));
   float a11 = fmaf(F(1, 0), F(1, 0), fmaf(F(1, 1), F(1, 1), F(1, 2) * F(1, 2)));
   float a22 = fmaf(F(2, 0), F(2, 0), fmaf(F(2, 1), F(2, 1), F(2, 2) * F(2, 2)));
@@ -127,6 +240,12 @@ __device__ __forceinline__ void sym_eig3_FFt(const mat3 &F, mat3 &U, float lam[3
   U(0, 1) = u1.x; U(1, 1) = u1.y; U(2, 1) = w1;
   U(0, 2) = u2.x; U(1, 2) = u2.y; U(2, 2) = w2;
   lam[0] = a00; lam[1] = a11; lam[2] = a22;
+  // Ill-conditioned F.  The eigenvalues of F F^T carry an ABSOLUTE error ~ eps sigma_max^2, i.e. sigma_min loses relative accuracy
+  // like eps cond(F)^2 (8e-4 at cond 1e2, nothing left at 1e3: profiles/r05_c_illcond_head.txt), while the reference takes
+  // svd(F) — and the Hencky models take log(sigma).  When some lane of the wave holds lam_min < lam_max / 64 (cond > 8: never on
+  // the benchmark states; the test is wave-uniform) the decomposition is finished on F itself (sym_eig3_refine).
+  const float lmax = fmaxf(a00, fmaxf(a11, a22)), lmin = fminf(a00, fminf(a11, a22));
+  if (__any(lmin < (1.0f / 64.0f) * lmax)) sym_eig3_refine<IN_LDS>(F, U, lam, lds);
 }
 
 // Signed singular values in U's (unsorted) column order: s_i = sqrt(lam_i); if det F < 0 the sign goes
@@ -191,8 +310,8 @@ __device__ __forceinline__ mat3 calculate_force(const GroupParams &g, const mat3
         const float e = expf(g.p[4] * (1.0f - aux));
         mu *= e; la *= e;
       }
-      mat3 U; float lam[3], s[3];
-      sym_eig3_FFt(F, U, lam);
+      mat3 U, Fm = F; float lam[3], s[3];
+      sym_eig3_FFt(Fm, U, lam);
       const float J = mat_det(F);
       signed_sigma(lam, J, s);
       // (F-R)F^T = U (S^2 - S) U^T ;  lambda (J-1) J F^-T F^T = lambda (J-1) J I
@@ -228,8 +347,8 @@ __device__ __forceinline__ mat3 calculate_force(const GroupParams &g, const mat3
     case MPMHIP_VON_MISES:  // :701-711
     case MPMHIP_ELASTIC: {  // :798-807   P F^T = U (2 mu ln S + lambda tr(ln S) I) U^T
       const float mu = g.p[2], la = g.p[3];
-      mat3 U; float lam[3], s[3];
-      sym_eig3_FFt(F, U, lam);
+      mat3 U, Fm = F; float lam[3], s[3];
+      sym_eig3_FFt(Fm, U, lam);
       signed_sigma(lam, mat_det(F), s);
       float ls[3];
 #pragma unroll
@@ -253,13 +372,14 @@ __device__ __forceinline__ mat3 calculate_force(const GroupParams &g, const mat3
 // det^-1/3)^gamma, 0.1, 10); tau += kappa gamma |P|.  Both SVDs of the reference share U and V, so one
 // eigen-solve of F_hat F_hat^T gives everything (plus one of the old F for |P|, which is rotation invariant).
 // On return F = F_hat, U/s = its left singular vectors/values, sn = the new singular values.
+template <bool IN_LDS = false>
 __device__ __forceinline__ void visco_return(const GroupParams &g, const mat3 &cdg, mat3 &F, float &aux, mat3 &U,
-                                             float s[3], float sn[3]) {
+                                             float s[3], float sn[3], float *lds = nullptr) {
   const float mu = g.p[2], la = g.p[3], vnu = g.p[4], kappa = g.p[5], dt = g.p[6];
   float pnorm;
   {
     mat3 U0; float lam0[3], s0[3];
-    sym_eig3_FFt(F, U0, lam0);
+    sym_eig3_FFt<IN_LDS>(F, U0, lam0, lds);
     const float J0 = mat_det(F);
     signed_sigma(lam0, J0, s0);
     float acc = 0.0f;
@@ -290,7 +410,7 @@ __device__ __forceinline__ void visco_return(const GroupParams &g, const mat3 &c
   for (int i = 0; i < halvings; i++) r = mat_mul(r, r);
   F = mat_mul(r, F);
   float lam[3];
-  sym_eig3_FFt(F, U, lam);
+  sym_eig3_FFt<IN_LDS>(F, U, lam, lds);
   signed_sigma(lam, mat_det(F), s);
   float gamma = 0.0f;
   if (pnorm > 1e-5f) gamma = fminf(fmaxf(dt * vnu * (pnorm - aux) / pnorm, 0.0f), 1.0f);
@@ -399,9 +519,9 @@ __device__ __forceinline__ bool mat_is(const GroupParams &g, int t) {
   if ((MATS & (MATS - 1u)) == 0u) return true;  // the only one in the set: no run-time test
   return g.type == t;
 }
-template <uint32_t MATS = MAT_ALL>
+template <uint32_t MATS = MAT_ALL, bool IN_LDS = false>
 __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const mat3 &cdg, mat3 &F, float &aux,
-                                                     mat3 &stress) {
+                                                     mat3 &stress, float *lds = nullptr) {
   const float vol = g.p[1];
   if (mat_is<MATS>(g, MPMHIP_WATER)) {  // src/particles.cpp:463-478
     float j = aux * (cdg(0, 0) + cdg(1, 1) + cdg(2, 2) - 2.0f);
@@ -415,7 +535,7 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
   }
   if (mat_is<MATS>(g, MPMHIP_VISCO)) {  // src/particles.cpp:72-134
     mat3 U; float s[3], sn[3], ratio[3], d[3];
-    visco_return(g, cdg, F, aux, U, s, sn);
+    visco_return<IN_LDS>(g, cdg, F, aux, U, s, sn, lds);
     const float Jn = sn[0] * sn[1] * sn[2];
     const float vol_l = g.p[3] * (Jn - 1.0f) * Jn;
 #pragma unroll
@@ -443,7 +563,7 @@ __device__ __forceinline__ void plasticity_and_force(const GroupParams &g, const
     return;
   }
   mat3 U; float lam[3], s[3];
-  sym_eig3_FFt(F, U, lam);
+  sym_eig3_FFt<IN_LDS>(F, U, lam, lds);
   const float detF = mat_det(F);
   signed_sigma(lam, detF, s);
   const float mu0 = g.p[2], la0 = g.p[3];

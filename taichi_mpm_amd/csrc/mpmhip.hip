@@ -112,6 +112,10 @@ struct mpmhip_ctx {
   uint8_t *blk_flag = nullptr;
   uint32_t *bits = nullptr, *wprefix = nullptr, *act_blk = nullptr, *act_start = nullptr;
   uint32_t *cell_cnt = nullptr, *cell_start = nullptr, *fat_slot = nullptr;
+  uint32_t *nbr = nullptr, *own_list = nullptr;  // k_cell_table -> k_grid: 32-word neighbour row per active block, list of owned (block, candidate) pairs
+  FillStats *d_stats = nullptr;  // device address of the pinned page's statistics words (h_pinned + FILL_STATS_WORD): k_cell_table stores there
+  int grid_walk = 2;             // walk of the substep's grid pass (k_grid.h): 2 owner list; 0 / 1 the pre-round-5 walks (env MPMHIP_GRID_WALK: A/B)
+  int grid_wgs = 0;              // workgroups of the grid pass; 0: from the last sort's owner count (env MPMHIP_GRID_WGS)
   unsigned long long *scan_slots = nullptr;  // [256] k_block_table + [ct_grid] k_cell_table: {epoch, chunk sum}
   uint32_t sort_epoch = 0, bt_slots = 0;
   uint32_t scan_grid = 256;  // workgroups of the single-pass scan kernels: three eighths of what the device keeps resident
@@ -448,6 +452,8 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   if (const char *e = getenv("MPMHIP_P2G_SPLIT")) c->p2g_split = atoi(e);
   if (const char *e = getenv("MPMHIP_G2P_PACKED")) c->g2p_packed = atoi(e);
   if (const char *e = getenv("MPMHIP_P2G_WGS")) c->p2g_wgs = atoi(e) > 0 ? atoi(e) : 16384;
+  if (const char *e = getenv("MPMHIP_GRID_WALK")) c->grid_walk = atoi(e);
+  if (const char *e = getenv("MPMHIP_GRID_WGS")) c->grid_wgs = atoi(e) > 0 ? atoi(e) : 0;
   c->reorder_interval = cfg->reorder_interval;
   if (const char *e = getenv("MPMHIP_REORDER_INTERVAL")) c->reorder_interval = atoi(e);
 #ifdef MPMHIP_ABLATE_BUILD
@@ -513,6 +519,8 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(dmalloc(&c->act_start, (size_t)mb + 2));
   A(dmalloc(&c->cell_cnt, (size_t)mb * BC));
   A(dmalloc(&c->cell_start, (size_t)mb * BC + 1));
+  A(dmalloc(&c->nbr, (size_t)mb * 32));
+  A(dmalloc(&c->own_list, (size_t)mb * 8));
   c->bt_slots = (P.nbw + 255) / 256;
   const size_t n_slots64 = c->bt_slots + ((size_t)mb + 15) / 16 + 1;  // k_cell_table chunks are >= 16 blocks
   A(dmalloc(&c->scan_slots, n_slots64));
@@ -522,6 +530,12 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(dmalloc(&c->d_LS, 1));
   A(hipHostMalloc((void **)&c->h_pinned, 65536, hipHostMallocDefault));
   if (e == hipSuccess && c->h_pinned) memset(c->h_pinned, 0, 65536);
+  if (e == hipSuccess) {
+    void *dp = nullptr;
+    A(hipHostGetDevicePointer(&dp, c->h_pinned, 0));
+    c->d_stats = reinterpret_cast<FillStats *>(reinterpret_cast<uint32_t *>(dp) + mpmhip_ctx::FILL_STATS_WORD);
+    if (getenv("MPMHIP_NO_STATS_STORE") && atoi(getenv("MPMHIP_NO_STATS_STORE"))) c->d_stats = nullptr;  // (A/B: the round-4 copy instead)
+  }
   A(dmalloc(&c->d_groups, (size_t)c->groups_cap));
   if (e != hipSuccess) {
     fail(c, MPMHIP_ENOMEM, "device allocation failed: %s (max_particles=%lld, max_blocks=%lld)", hipGetErrorString(e),
@@ -568,7 +582,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   hipFree(c->rg); hipFree(c->rp); hipFree(c->rb); hipFree(c->rg2); hipFree(c->rp2); hipFree(c->rb2);
   hipFree(c->key); hipFree(c->rank); hipFree(c->perm); hipFree(c->chunk_blk); hipFree(c->blk_flag); hipFree(c->bits); hipFree(c->wprefix);
   hipFree(c->fat_slot); hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->cell_cnt);
-  hipFree(c->cell_start); hipFree(c->scan_slots); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
+  hipFree(c->cell_start); hipFree(c->nbr); hipFree(c->own_list); hipFree(c->scan_slots); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
   hipFree(c->async.d_tab); hipFree(c->async.d_blk_of); hipFree(c->async.d_blk_limits); hipFree(c->async.d_particle_limits);
   if (c->async.h_tab) hipHostFree(c->async.h_tab);
   if (c->async.store.h_tbl_pin) hipHostFree(c->async.store.h_tbl_pin);
@@ -931,19 +945,22 @@ static int do_sort(mpmhip_ctx *c) {
     hipLaunchKernelGGL(k_build_keys, dim3(pg), dim3(256), 0, st, P, c->rg, c->rp, c->cnt, c->key, c->blk_flag);
   const bool small = c->ct_blocks ? c->ct_blocks == 16 : c->n_slots < (2 << 20);  // few blocks: finer chunks in k_cell_table
   const uint32_t bt_chunks = (P.nbw + 255) / 256, ct_chunks = (P.max_blocks + (small ? 16 : 64) - 1) / (small ? 16 : 64);
-  const uint32_t epoch = ++c->sort_epoch;
+  uint32_t epoch = ++c->sort_epoch;
+  if ((epoch & 0x7FFFFFu) == 0u) epoch = ++c->sort_epoch;  // (k_cell_table's scan words keep 23 bits of it; 0 = never published)
   // (single-pass scans: never more workgroups than are resident at once, see k_sort.h)
   hipLaunchKernelGGL(k_block_table, dim3(std::min(bt_chunks, c->scan_grid)), dim3(256), 0, st, P, c->blk_flag, c->bits,
                      c->wprefix, c->act_blk, c->cnt, c->scan_slots, epoch);
   const uint32_t rank_wgs = std::min<uint32_t>((P.n_slots + RANK_BATCH - 1) / RANK_BATCH, 8192u);
   hipLaunchKernelGGL(k_rank, dim3(std::max(rank_wgs, 1u)), dim3(256), 0, st, P, c->key, c->rank, c->cell_cnt, c->bits, c->wprefix,
-                     c->cnt);
+                     c->cnt, (const uint32_t *)c->act_blk, c->nbr);
   hipLaunchKernelGGL(small ? k_cell_table<16> : k_cell_table<64>, dim3(std::min(ct_chunks, c->scan_grid)), dim3(256), 0, st, P,
-                     c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots, epoch, c->rank_runs_mul, c->chunk_blk);
+                     c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots, epoch, c->rank_runs_mul, c->chunk_blk,
+                     (const uint32_t *)c->nbr, c->own_list, c->d_stats);
   hipLaunchKernelGGL(k_perm, dim3(pg), dim3(256), 0, st, P, (const Counters *)c->cnt, c->key, c->rank, c->cell_start, c->perm);
-  // every 16th sort: (live particles, active blocks) on their way to the pinned page, never waited for — the host picks the G2P
-  // walk by how full the blocks are (g2p_is_packed) and may look at numbers a few substeps old
-  if ((c->sort_epoch & 15u) == 1u) (void)hipMemcpyAsync(c->h_pinned + mpmhip_ctx::FILL_STATS_WORD, c->cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+  // (k_cell_table's last chunk stores (live particles, active blocks, owner entries) of this sort straight into the pinned page,
+  // never waited for: the host picks the G2P walk by how full the blocks are (g2p_is_packed) and sizes the grid pass's launch
+  // from numbers that may be a few substeps old — until round 5 a hipMemcpyAsync every 16th sort, i.e. a blit kernel in the loop)
+  if (!c->d_stats && (c->sort_epoch & 15u) == 1u) (void)hipMemcpyAsync(c->h_pinned + mpmhip_ctx::FILL_STATS_WORD, c->cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
   c->sorted = true;
   c->keys_valid = false;  // key[] now holds k_rank's packed (rank, cell index) words
   int rc = launch_check(c, "sort");
@@ -1064,13 +1081,24 @@ static int do_p2g(mpmhip_ctx *c, int phase = 0) {
 static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
   c->P.t = c->t;  // this->current_t of the substep in flight (src/mpm.cpp:532-533)
   c->LS.dirichlet = c->dirichlet ? 1 : 0;
-  const bool per_cand = mode == 0 && c->n_slots < (2 << 20);  // small per-GPU problem: latency-bound, see k_grid
-  auto kern = mode == 0 ? (per_cand ? k_grid<0, true> : k_grid<0, false>)
-                        : (mode == 1 ? k_grid<1, false>
-                                     : (mode == 2 ? k_grid<2, false> : (mode == 3 ? k_grid<3, false> : k_grid<4, false>)));
-  static const int grid_wgs_small = getenv("MPMHIP_GRID_WGS") ? atoi(getenv("MPMHIP_GRID_WGS")) : 16384;
-  hipLaunchKernelGGL(kern, dim3(per_cand ? grid_wgs_small : 4096), dim3(256), 0, c->stream, c->P, c->cnt, c->act_blk, c->bits, c->wprefix, c->tiles,
-                     c->gridv, c->fat_slot, c->dense, c->T, c->d_boxes_cur, c->LS, phase);
+  // the substep's pass (mode 0) walks the owner list of the last sort: one wave per touched grid block, launched at the size of the
+  // list as the last sort reported it (+ 12 %; the walk is a grid-stride loop, so a stale number costs time, never correctness).
+  // MPMHIP_GRID_WALK=0 / 1 (A/B): the pre-round-5 walks — per block at >= 2 M slots, per (block, candidate) below.
+  const bool per_cand = mode == 0 && c->n_slots < (2 << 20);
+  const int walk = mode != 0 ? 0 : (c->grid_walk == 2 ? 2 : (per_cand ? 1 : 0));
+  auto kern = mode == 0 ? (walk == 2 ? k_grid<0, 2> : (walk == 1 ? k_grid<0, 1> : k_grid<0, 0>))
+                        : (mode == 1 ? k_grid<1, 0> : (mode == 2 ? k_grid<2, 0> : (mode == 3 ? k_grid<3, 0> : k_grid<4, 0>)));
+  int wgs = walk == 1 ? 16384 : 4096;
+  if (walk == 2) {
+    const volatile FillStats *fs = reinterpret_cast<const volatile FillStats *>(c->h_pinned + mpmhip_ctx::FILL_STATS_WORD);
+    uint64_t n_own = fs->n_own;
+    if (n_own == 0) n_own = std::min<uint64_t>((uint64_t)c->P.max_blocks * 8u, 32768u);  // (before the first sort has reported)
+    wgs = (int)std::min<uint64_t>(8192u, std::max<uint64_t>(64u, (n_own + n_own / 8 + 3) / 4 + 8));
+  }
+  if (c->grid_wgs > 0 && mode == 0) wgs = c->grid_wgs;
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, c->stream, c->P, c->cnt, c->act_blk, c->bits, c->wprefix, (const uint32_t *)c->nbr,
+                     (const uint32_t *)c->own_list, c->tiles, c->gridv, c->fat_slot, c->dense, c->T, c->d_boxes_cur,
+                     c->LS, phase);
   return launch_check(c, "grid");
 }
 // which G2P kernel the plain blocks of the next substep get (bench.py names the kernel of its roofline after it).  By size and by
@@ -2042,6 +2070,7 @@ int mpmhip_reserve(mpmhip_ctx *c, int64_t max_particles) {
       const size_t m = (size_t)mb;
       A(regrow(&c->act_blk, 0, m + 1, false)); A(regrow(&c->act_start, 0, m + 2, true));
       A(regrow(&c->cell_cnt, 0, m * BC, true)); A(regrow(&c->cell_start, 0, m * BC + 1, true));
+      A(regrow(&c->nbr, 0, m * 32, false)); A(regrow(&c->own_list, 0, m * 8, false));
       A(regrow(&c->scan_slots, 0, c->bt_slots + (m + 15) / 16 + 1, true));  // (epoch 0 is never used)
       A(regrow(&c->tiles, 0, m * TN, false)); A(regrow(&c->gridv, 0, m * 8 * BC, false));
       if (c->rigid.d_blk_rigid) { A(regrow(&c->rigid.d_blk_rigid, 0, m + 1, true)); A(regrow(&c->rigid.d_rigid_list, 0, m + 1, false)); }
@@ -2480,6 +2509,7 @@ static void a2_free(mpmhip2d_ctx *m) {
   if (A.h_cnt) hipHostFree(A.h_cnt);
   A.rec = A.rec2 = nullptr; A.tag = A.tag2 = A.d_tab = A.d_rank = A.d_blk_of = A.h_tab = nullptr;
   A.best = A.d_scan = nullptr; A.d_tbl = A.h_tbl_pin = nullptr; A.d_cnt = A.h_cnt = nullptr;
+  A.blk_of_cap = 0;  // (d_blk_of is gone: the next load_pools must allocate it again)
   A.resident = false;
 }
 static int a2_drop_view(mpmhip2d_ctx *m);

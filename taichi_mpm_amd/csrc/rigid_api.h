@@ -198,6 +198,9 @@ static int do_rigid_ls_collision(mpmhip_ctx *c) {
   }
   if (R.n_ranked < n) {  // boundary particles added since: behind everybody else, in creation order (appended to `particles`)
     std::vector<uint32_t> rk(n);
+    // (the ctx stream does not synchronise with the blocking copies below: a collision kernel of an earlier substep may still
+    // be writing the ranks)
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     if (R.n_ranked) HIPCHK(c, hipMemcpy(rk.data(), R.d_smp_rank, sizeof(uint32_t) * R.n_ranked, hipMemcpyDeviceToHost));
     for (uint32_t s = R.n_ranked; s < n; s++) rk[s] = s;
     (void)hipFree(R.d_smp_rank); R.d_smp_rank = nullptr;

@@ -119,7 +119,9 @@ std::vector<mpmhip_ctx::TiledNative::Box> tn_plan(const Tiling &T, int world, co
   return out;
 }
 
-int tn_clip_slack(const Tiling &T) { return std::max(8, 2 * T.margin + 4); }
+// slack of a freshly cut clip box around the particles: the room the look-ahead test of tn_mig_c asks for (2 margin + 3) and as
+// much again, so that a re-plan is not followed by the next one a migration later
+int tn_clip_slack(const Tiling &T) { return std::max(8, 4 * T.margin + 4); }
 
 // (re)build this rank's plan for the current clip box and upload the device box tables; no allocation
 int tn_apply_plan(mpmhip_ctx *c) {
@@ -187,7 +189,7 @@ int tn_apply_plan(mpmhip_ctx *c) {
   }
   N.halo_peers = idx;
   T.n_boxes = (int)n; T.box_nodes = (uint32_t)total;
-  c->d_boxes_cur = N.d_boxes[N.epoch & 1];
+  c->d_boxes_cur = N.d_boxes[peer_wire ? (N.epoch & 1) : 0];
   return MPMHIP_OK;
 }
 
@@ -373,12 +375,26 @@ int tn_mig_c(mpmhip_ctx *c) {
   }
   N.migrations++;
   // the clip box: does it still hold every node the particles can touch before the next check?
+  // A particle with base cell b touches the nodes b .. b + 2; M.lo / M.hi bound the base cells of ALL ranks' live particles.
+  // (a) Looking back: the halo boxes of the substeps since the last check were cut to the clip box, so mass splatted outside it
+  //     was never exchanged.  The schedule below lets the particles travel margin cells between two checks if their top speed
+  //     at most doubles, and (b) keeps 2 margin + 1 cells of room, but a particle deep inside a brick that speeds up further
+  //     (it trips no margin test: error bit 2 only watches the brick's own faces) could have left the box unseen: that is an
+  //     error here, not a silent loss.
   bool have = M.lo[0] <= M.hi[0] && M.lo[1] <= M.hi[1] && M.lo[2] <= M.hi[2];
   if (have) {
+    for (int a = 0; a < 3; a++)
+      if (M.lo[a] < N.clip_lo[a] || M.hi[a] + 2 > N.clip_hi[a])
+        return fail(c, MPMHIP_ECAPACITY, "tiled run: particles left the clipped halo region on axis %d between two migrations (base cells "
+                    "[%d, %d), halo boxes cut to nodes [%d, %d)): their top speed more than doubled since the last check — halo sums "
+                    "of the substeps in between may be incomplete; lower mpmhip_tiled_config.migrate_cap or set migrate_interval",
+                    a, M.lo[a], M.hi[a], N.clip_lo[a], N.clip_hi[a]);
+    // (b) Looking ahead: room for a travel of 2 margin cells on every side (the schedule plans for margin)
     bool covers = true;
+    const int room = 2 * c->T.margin;
     for (int a = 0; a < 3; a++) {
-      covers = covers && (M.lo[a] - c->T.margin - 1 >= N.clip_lo[a] || N.clip_lo[a] == 0);
-      covers = covers && (M.hi[a] + c->T.margin + 3 <= N.clip_hi[a] || N.clip_hi[a] == c->P.res[a] + 1);
+      covers = covers && (M.lo[a] - room - 1 >= N.clip_lo[a] || N.clip_lo[a] == 0);
+      covers = covers && (M.hi[a] + room + 3 <= N.clip_hi[a] || N.clip_hi[a] == c->P.res[a] + 1);
     }
     if (!covers) {
       const int s = tn_clip_slack(c->T);

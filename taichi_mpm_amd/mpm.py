@@ -544,16 +544,17 @@ class Simulation3D:
         n = self.get_num_particles()
         snap = np.empty(int(self._check(self._L.mpmhip_snapshot_size(self._ctx))), np.uint8)
         self._check(self._L.mpmhip_snapshot_save(self._ctx, snap.ctypes.data_as(C.c_void_p), len(snap)))
-        prof = self.profile()
+        # the benchmark borrows the profiler: the caller's level, sampling interval and accumulated timings come back afterwards
+        level, every = getattr(self, "_prof_level", 0), getattr(self, "_prof_every", 1)
+        before = self.profile(reset=True)
         self.set_profiling(3 if what == "rasterize" else 2)
-        self.profile(reset=True)
         self._check(self._L.mpmhip_set_dt(self._ctx, C.c_float(0.0)))  # base_delta_t = 0: nothing moves
         self._check(self._L.mpmhip_run_substeps(self._ctx, int(rounds)))
         ms = self.profile(reset=True)["phases"]["p2g" if what == "rasterize" else "g2p"]
-        self.set_profiling(0)
+        self.set_profiling(level, every)
+        self._prof_carry = {"substeps": before["substeps"], "phases": dict(before["phases"])} if before["substeps"] else None
         self._check(self._L.mpmhip_set_dt(self._ctx, C.c_float(self.base_delta_t)))
         self._check(self._L.mpmhip_snapshot_load(self._ctx, snap.ctypes.data_as(C.c_void_p), len(snap)))
-        del prof
         out = {"name": "%s x %d" % ("Rasterize" if what == "rasterize" else "Resample", rounds), "ms": ms, "particles": n,
                "ns_per_particle": 1e6 * ms / max(n * rounds, 1)}
         print("%s: %.3f ms (%.3f ns per particle per launch, %d particles)" % (out["name"], ms, out["ns_per_particle"], n))
@@ -654,6 +655,7 @@ class Simulation3D:
         bracket the kernel in every `every`-th substep only"""
         self._ensure_ctx(); self._check(self._L.mpmhip_set_profiling(self._ctx, int(level)))
         self._check(self._L.mpmhip_set_profile_sampling(self._ctx, int(every)))
+        self._prof_level, self._prof_every = int(level), int(every)
 
     def g2p_kernel(self):
         """name of the G2P kernel the next substep's plain blocks get (measurement helper: bench.py names its roofline after it)"""
@@ -672,8 +674,14 @@ class Simulation3D:
         buf = C.create_string_buffer(1024)
         self._check(self._L.mpmhip_profile(self._ctx, buf, len(buf)))
         out = json.loads(buf.value.decode())
+        carry = getattr(self, "_prof_carry", None)
+        if carry:  # timings accumulated before a benchmark_rasterize / benchmark_resample run borrowed the profiler (_benchmark)
+            out["substeps"] += carry["substeps"]
+            for k, v in carry["phases"].items():
+                out["phases"][k] = out["phases"].get(k, 0.0) + v
         if reset:
             self._check(self._L.mpmhip_profile_reset(self._ctx))
+            self._prof_carry = None
         return out
 
     # ---------------------------------------------------------------- async limits (AsyncMPM, first half)

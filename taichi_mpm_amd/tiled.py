@@ -109,13 +109,20 @@ class Partition:
                 [min(self.clip[1][a], hi[a] + self.margin + 2) for a in range(3)])
 
     def clip_slack(self):
-        return max(8, 2 * self.margin + 4)
+        """slack of a freshly cut clip box: the room clip_covers asks for and as much again (csrc/tiled_api.h: tn_clip_slack)"""
+        return max(8, 4 * self.margin + 4)
 
     def clip_covers(self, cell_lo, cell_hi):
         """does the current clip box hold every node the particles (base cells in [cell_lo, cell_hi)) can touch
-        before the next check, i.e. after drifting up to `margin` cells?"""
-        return all(cell_lo[a] - self.margin - 1 >= self.clip[0][a] or self.clip[0][a] == 0 for a in range(3)) and \
-            all(cell_hi[a] + self.margin + 3 <= self.clip[1][a] or self.clip[1][a] == self.res[a] + 1 for a in range(3))
+        before the next check, with room for a travel of 2 margin cells (the schedule plans for margin)?"""
+        room = 2 * self.margin
+        return all(cell_lo[a] - room - 1 >= self.clip[0][a] or self.clip[0][a] == 0 for a in range(3)) and \
+            all(cell_hi[a] + room + 3 <= self.clip[1][a] or self.clip[1][a] == self.res[a] + 1 for a in range(3))
+
+    def clip_holds(self, cell_lo, cell_hi):
+        """did the clip box hold every node the particles touch NOW (base cell b: nodes b .. b + 2)?  If not, halo sums of the
+        substeps since the last check may have missed mass outside the clipped boxes (csrc/tiled_api.h: tn_mig_c)"""
+        return all(cell_lo[a] >= self.clip[0][a] and cell_hi[a] + 2 <= self.clip[1][a] for a in range(3))
 
     def set_clip_from_bounds(self, cell_lo, cell_hi):
         s = self.clip_slack()
@@ -399,6 +406,10 @@ def _finish_migration(table, world, ranks, exchange):
             r.mig_import()
     lo, hi = -table[:, world:world + 3].max(0), table[:, world + 3:world + 6].max(0)
     part = ranks[0].part
+    if (lo <= hi).all() and not part.clip_holds(lo, hi):
+        raise RuntimeError("tiled run: particles left the clipped halo region between two migrations (base cells %s .. %s, halo boxes "
+                           "cut to nodes %s .. %s): their top speed more than doubled since the last check; lower the migration cap "
+                           "(MPMHIP_TILE_MIGRATE_CAP) or pass migrate_interval" % (lo.tolist(), hi.tolist(), part.clip[0], part.clip[1]))
     if (lo <= hi).all() and not part.clip_covers(lo, hi):
         part.set_clip_from_bounds(lo, hi)  # (a virtual job shares ONE Partition object between its ranks)
         for r in ranks:

@@ -101,6 +101,82 @@ def materials_fixture(here):
     print("materials:", n, "states x", len(MATS), "types")
 
 
+def illcond_states(seed=77):
+    """deformation gradients F = U diag(sigma) V^T with prescribed singular values: condition numbers 1 .. 1e4 in four
+    patterns (spread / two large / two small and nearly equal / two small and exactly equal), repeated and nearly repeated
+    singular values around 1, singular values at and below sand's 1e-4 clamp (src/particles.cpp:603-604), and det F < 0
+    (one singular value negated: the convention of the reference's svd puts the sign on the smallest).  Returns
+    (F [n, 9] float32, cond [n], tag [n] (index into TAGS), negdet [n] bool); shared by the generator and the tests."""
+    rng = np.random.default_rng(seed)
+
+    def rot():
+        q, r = np.linalg.qr(rng.normal(0, 1, (3, 3)))
+        q = q * np.sign(np.diag(r))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        return q
+
+    rows = []  # (sigma triple, cond, tag, negdet)
+    for c in (1.0, 10.0, 1e2, 1e3, 1e4):
+        for tag, sig in ((0, (1.0, c ** -0.5, 1.0 / c)), (1, (1.0, 1.0, 1.0 / c)), (2, (1.0, 1.001 / c, 1.0 / c)),
+                         (3, (c ** (2 / 3), c ** (-1 / 3), c ** (-1 / 3)))):
+            for scale in (1.0, 0.8, 1.3):
+                for _ in range(2):
+                    rows.append((np.array(sig) * scale, c, tag, False))
+        for tag, sig in ((0, (1.0, c ** -0.5, 1.0 / c)), (1, (1.0, 1.0, 1.0 / c))):
+            if c <= 1e2:
+                for _ in range(3):
+                    rows.append((np.array(sig), c, tag, True))
+    for sig in ((2.0, 2.0, 1.0), (1.0, 1.0, 1.0 + 1e-6), (1.0, 1.0, 1.0), (1.0 + 1e-6, 1.0, 1.0 - 1e-6), (1.5, 1.5, 1.5)):
+        for _ in range(3):
+            rows.append((np.array(sig), max(sig) / min(sig), 4, False))
+    for sig in ((1.0, 0.5, 1e-4), (1.0, 0.5, 5e-5), (1.0, 1e-4, 1e-4), (1.0, 2e-4, 0.9e-4)):
+        for _ in range(3):
+            rows.append((np.array(sig), max(sig) / min(sig), 5, False))
+    F, cond, tag, neg = [], [], [], []
+    for sig, c, t, n in rows:
+        sg = np.array(sig, np.float64)
+        if n:
+            sg[np.argmin(sg)] *= -1.0
+        F.append((rot() @ np.diag(sg) @ rot().T).reshape(9))
+        cond.append(c); tag.append(t); neg.append(n)
+    return np.array(F, np.float32), np.array(cond), np.array(tag, np.int32), np.array(neg, bool)
+
+
+ILLCOND_TAGS = ("spread", "two_large", "two_small_close", "two_small_equal", "repeated", "sand_clamp")
+
+
+def illcond_fixture(here):
+    """calculate_force / plasticity of every particle type (src/particles.cpp:207-242,391-416,599-647,701-732,786-812) on
+    ILL-CONDITIONED deformation gradients (illcond_states): where do the device's tolerances stop holding?  The reference
+    evaluates svd(F) (here: the shim's double-precision Jacobi, rounded to float); the device takes sigma from an
+    eigen-solve of F F^T in fp32, refined on F itself when the condition number asks for it (csrc/mpm_math.h)."""
+    F, cond, tag, neg = illcond_states()
+    n = len(F)
+    rng = np.random.default_rng(78)
+    cdg = (np.eye(3) + rng.normal(0, 0.02, (n, 3, 3))).astype(np.float32).reshape(n, 9)
+    vol = DX ** 3 / 8
+    mass = 400.0 * vol
+    out = dict(F=F, cdg=cdg, cond=cond, tag=tag, negdet=neg)
+    # singular values of the float32 matrices as they are, in double precision (descending, sign on the last: det F < 0)
+    sv = np.linalg.svd(F.reshape(n, 3, 3).astype(np.float64), compute_uv=False)
+    sv[:, 2] *= np.sign(np.linalg.det(F.reshape(n, 3, 3).astype(np.float64)))
+    out["sigma"] = sv
+    for mat in MATS:
+        kw = MAT_KW.get(mat, {})
+        aux = {"snow": np.ones(n), "water": np.ones(n), "visco": np.full(n, 1000.0)}.get(mat, np.zeros(n)).astype(np.float32)
+        use = ~neg if mat in ("sand", "elastic", "von_mises") else np.ones(n, bool)  # Hencky: log of a negative sigma is NaN
+        with np.errstate(all="ignore"):
+            force = ref.calculate_force(mat, mass, vol, F, aux, **kw)
+            F2, aux2 = ref.plasticity(mat, mass, vol, cdg, F, aux, **kw)
+            force2 = ref.calculate_force(mat, mass, vol, F2, aux2, **kw)
+        gp, t = orc.group_params(mat, mass, vol, **kw)
+        out.update({mat + "_aux": aux, mat + "_use": use, mat + "_force": force, mat + "_F2": F2, mat + "_aux2": aux2,
+                    mat + "_force2": force2, mat + "_gp": gp, mat + "_type": t})
+    np.savez_compressed(os.path.join(here, "ref_illcond.npz"), mass=mass, vol=vol, dx=DX, tags=np.array(ILLCOND_TAGS), **out)
+    print("illcond:", n, "states x", len(MATS), "types; cond", sorted(set(cond.tolist()))[:3], "...", cond.max())
+
+
 def kernels_fixture(here):
     """MPMKernel<3,2>, MPMFastKernel32, MPMKernel<2,2> (src/kernel.h) and friction_project (src/mpm_fwd.h:25-57)"""
     rng = np.random.default_rng(7)
@@ -327,12 +403,14 @@ def joints_fixture(here):
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     ref.set_threads(1)  # the generic P2G of the reference is racy with more than one thread
-    what = sys.argv[1:] or (list(MATS) + ["materials", "kernels", "shapes", "mpm2d", "cpic", "cpic2d", "joints"])
+    what = sys.argv[1:] or (list(MATS) + ["materials", "illcond", "kernels", "shapes", "mpm2d", "cpic", "cpic2d", "joints"])
     for w in what:
         if w in MATS:
             substep_fixture(here, w)
         elif w == "materials":
             materials_fixture(here)
+        elif w == "illcond":
+            illcond_fixture(here)
         elif w == "kernels":
             kernels_fixture(here)
         elif w == "shapes":

@@ -206,6 +206,25 @@ def test_halo_boxes_follow_the_particles(orc):
     _compare(_collect([e.s for e in engines]), ref)
 
 
+def test_particles_outside_the_clipped_halo_region_are_an_error_not_a_silent_loss(orc):
+    """the halo boxes are cut to the clip box; a migration that finds particles whose stencils reach beyond it (their speed
+    more than doubled since the last check) must say so: the sums of the substeps in between may have missed mass
+    (the native data plane makes the same test in csrc/tiled_api.h: tn_mig_c)"""
+    s = _state()
+    part = tiled.Partition.balanced((RES,) * 3, 2, s.x, DX, margin=2)
+    b = tiled.base_cells(s.x, DX)
+    lo, hi = b.min(0), b.max(0) + 1
+    assert part.clip_holds(lo, hi) and part.clip_covers(lo, hi)  # a fresh clip box has room for 2 margin + 1 cells of travel
+    assert part.clip_holds(lo - 2 * part.margin, hi + 2 * part.margin)
+    part.clip = (list(map(int, lo + 1)), list(map(int, hi + 2)))  # one layer of particles already outside on the low side
+    assert not part.clip_holds(lo, hi)
+    owner = part.rank_of_cells(b)
+    engines = [OracleEngine(_cfg(orc), subset(s, owner == r), DX) for r in range(2)]
+    job = tiled.VirtualTiledJob(engines, part, migrate_interval=1)
+    with pytest.raises(RuntimeError, match="left the clipped halo region"):
+        job.run(2)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
