@@ -250,15 +250,48 @@ def cpu_baseline(cfg, budget_s=20.0):
             "sort_ns_per_particle": 1e9 * phases[0] / (n * steps)}
 
 
-def pmc_traffic(config_name, kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC summary of this workload (profiles/), or None"""
+_LOADED_HASHES = None
+
+
+def loaded_kernel_hashes():
+    """{kernel base name: code hash} of the library this process runs (profiles/kernel_diff.py: sha256 over the disassembly of all
+    instantiations), or a string saying why they cannot be had"""
+    global _LOADED_HASHES
+    if _LOADED_HASHES is None:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "profiles"))
+            import kernel_diff
+            from taichi_mpm_amd import _lib
+            _LOADED_HASHES = kernel_diff.kernel_hashes(_lib.lib_path())
+        except Exception as e:
+            _LOADED_HASHES = "code hash unavailable: %r" % (e,)
+    return _LOADED_HASHES
+
+
+def pmc_traffic(config_name, kernel, check=True):
+    """(HBM bytes per launch of `kernel` from the committed PMC summary of this workload (profiles/), its source text, a note).
+    The summary records the code hash of every kernel it was taken on (make_traffic.py --lib): when the loaded library's `kernel`
+    differs — a kernel edit without a new PMC pass — the bytes are withheld (None) and the note says so: a stale ratio must not
+    look measured."""
     path = os.path.join(ROOT, "profiles", "traffic_%s.json" % config_name)
     try:
         with open(path) as f:
             d = json.load(f)
-        return float(d["kernels"][kernel]["hbm_bytes_per_launch"]), d.get("source")
+        tbytes, src = float(d["kernels"][kernel]["hbm_bytes_per_launch"]), d.get("source")
     except Exception:
-        return None, None
+        return None, None, None
+    if not check:
+        return tbytes, src, None
+    want = (d.get("code") or {}).get("kernel_hashes", {}).get(kernel)
+    if want is None:
+        return None, src, "withheld: the PMC summary records no code hash for %s" % kernel
+    have = loaded_kernel_hashes()
+    if isinstance(have, str):
+        return None, src, "withheld: " + have
+    if have.get(kernel) != want:
+        return None, src, ("withheld: %s of the loaded library (code %s) is not the kernel the PMC passes ran on (code %s, commit %s): "
+                           "run profiles/run_profile.sh again" % (kernel, have.get(kernel), want, (d.get("code") or {}).get("commit")))
+    return tbytes, src, "code %s = the PMC build (commit %s)" % (want, (d.get("code") or {}).get("commit"))
 
 
 def virtual_run(tm, cfg, args):
@@ -414,9 +447,10 @@ def main():
     ap.add_argument("--state", default="lattice", choices=["lattice", "evolved"],
                     help="state the main measurement is taken on: the freshly seeded lattice (the metric's configuration) or "
                          "the same scene %d substeps after the block hit the floor (for profiling runs)" % EVOLVE_AFTER_IMPACT)
-    ap.add_argument("--wire", default=os.environ.get("MPMHIP_TILE_WIRE", "rccl"), choices=["rccl", "ipc", "torch"],
+    ap.add_argument("--wire", default=os.environ.get("MPMHIP_TILE_WIRE", "rccl"), choices=["rccl", "ipc", "both", "torch"],
                     help="N > 1: the data plane of the halo exchange and the migration.  rccl (default): ncclSend / ncclRecv groups "
-                         "issued by libmpmhip itself; ipc: peer writes into IPC-mapped receive buffers, no collective; torch: the "
+                         "issued by libmpmhip itself; ipc: peer writes into IPC-mapped receive buffers, no collective; both: the line is "
+                         "measured over rccl, then the SAME job is re-wired to ipc and measured again (`tiled.other_wire`); torch: the "
                          "round-3 path (torch.distributed all_to_all from a Python callback per substep)")
     ap.add_argument("--allow-staged", action="store_true",
                     help="N > 1: if the RCCL wire cannot be brought up, stage the exchange through gloo and host memory instead of "
@@ -471,10 +505,10 @@ def main():
             native_wire, wire = "ipc", "IPC peer writes (test hook: the ranks share the visible GPUs), handles over gloo"
         else:
             ok, why = True, ""
-            if args.wire in ("rccl", "torch") and world > torch.cuda.device_count():
+            if args.wire in ("rccl", "both", "torch") and world > torch.cuda.device_count():
                 # (one node by contract: ranks then share devices, which RCCL refuses — after a long rendezvous; say so at once)
                 ok, why = False, "%d ranks on %d visible devices: RCCL does not take two ranks on one device" % (world, torch.cuda.device_count())
-            elif args.wire in ("rccl", "torch") and os.environ.get("MPMHIP_SKIP_RCCL_PROBE") != "1":
+            elif args.wire in ("rccl", "both", "torch") and os.environ.get("MPMHIP_SKIP_RCCL_PROBE") != "1":
                 # probe the transport in a CHILD process per rank (a hang or an abort inside RCCL then costs the child and a
                 # bounded wait); every rank must see it work
                 dog.phase("RCCL probe", 240)
@@ -487,10 +521,10 @@ def main():
                 data_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=90))
                 wire = "RCCL through torch.distributed (all_to_all from a Python callback per substep)"
             elif ok:
-                native_wire = args.wire
+                native_wire = "rccl" if args.wire == "both" else args.wire
                 wire = {"rccl": "RCCL: ncclSend / ncclRecv groups issued by libmpmhip (no Python in the substep loop)",
-                        "ipc": "IPC peer writes into mapped receive buffers + epoch flags (no collective, no Python in the substep loop)"}[args.wire]
-            elif args.wire == "rccl" and os.environ.get("MPMHIP_NO_IPC_FALLBACK") != "1":
+                        "ipc": "IPC peer writes into mapped receive buffers + epoch flags (no collective, no Python in the substep loop)"}[native_wire]
+            elif args.wire in ("rccl", "both") and os.environ.get("MPMHIP_NO_IPC_FALLBACK") != "1":
                 # still a native data plane: the library's IPC peer writes need no collective library at all (handles over gloo)
                 print("bench.py[rank %d]: the RCCL wire could not be brought up (%s); using the library's IPC wire" %
                       (rank, why or "failed on another rank"), file=sys.stderr, flush=True)
@@ -567,11 +601,11 @@ def main():
         per_launch = {"p2g": n_per_gpu * 100.0 + nodes * 16.0, "g2p": n_per_gpu * 152.0 + nodes * 16.0}
         achieved = per_launch[dom] / (ms[dom] * 1e-3) / 1e9
         kname = job.kernel_name(dom) if hasattr(job, "kernel_name") else "k_" + dom  # (k_g2p_packed for large one-material problems)
-        tbytes, tsrc = pmc_traffic(traffic_tag, kname) if world == 1 else (None, None)
+        tbytes, tsrc, tnote = pmc_traffic(traffic_tag, kname) if world == 1 else (None, None, None)
         roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": (tbytes / (ms[dom] * 1e-3) / 1e9) if tbytes else None,
-                "traffic_bytes_per_launch": tbytes, "traffic_source": tsrc,
+                "traffic_bytes_per_launch": tbytes, "traffic_source": tsrc, "traffic_check": tnote,
                 "algorithmic_bytes_per_launch": per_launch[dom], "avg_launch_ms": ms[dom],
                 "launches_timed": prof["substeps"]}  # (every PROFILE_EVERY-th substep of the timed region)
         both = (per_launch["p2g"] + per_launch["g2p"]) / ((ms["p2g"] + ms["g2p"]) * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -581,7 +615,7 @@ def main():
         # The kernel that is not the dominant one is timed in the untimed phase pass, not in the timed region.
         other = "p2g" if dom == "g2p" else "g2p"
         oname = job.kernel_name(other) if hasattr(job, "kernel_name") else "k_" + other
-        t_other, _ = pmc_traffic(traffic_tag, oname) if world == 1 else (None, None)
+        t_other, _, _ = pmc_traffic(traffic_tag, oname) if world == 1 else (None, None, None)
         t_both = (tbytes + t_other) if (tbytes and t_other) else None
         dur = (ms["p2g"] + ms["g2p"]) * 1e-3
         roof["p2g_plus_g2p"] = {"kernels": sorted([kname, oname], reverse=True), "algorithmic_bytes_per_step": per_launch["p2g"] + per_launch["g2p"],
@@ -623,6 +657,52 @@ def main():
     dog.phase("measurement", 900)
     elapsed, ms, dom, prof = measure(args.warmup, args.steps)
     dog.phase("report", 900)
+    PHASES = ("sort", "p2g", "exchange", "grid", "g2p")
+
+    def rank_table(ms_here, elapsed_here):
+        """every rank's phase table (ms per substep; `exchange` = from the end of the halo pack to the arrival of the peers' sums:
+        signal + wire + wait, i.e. where a rank waits for a slower peer), its elapsed time and what its plan moves — gathered over
+        the control group, reported as max / min over the ranks and rank by rank"""
+        st = (job.state()[0] if hasattr(job, "state") else {})
+        row = [ms_here.get(k, 0.0) for k in PHASES] + [1e3 * elapsed_here / args.steps, float(n_local), float(st.get("halo_nodes", 0) * 16),
+                                                       float(st.get("halo_boxes", 0)), float(st.get("migrations", 0)), float(st.get("migrated_out", 0)),
+                                                       float(st.get("replans", 0))]
+        rows = [torch.zeros(len(row), dtype=torch.float64) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(rows, torch.tensor(row, dtype=torch.float64))
+        else:
+            rows = [torch.tensor(row, dtype=torch.float64)]
+        tab = torch.stack(rows)
+        names = list(PHASES) + ["ms_per_step", "particles", "halo_bytes_per_substep", "halo_boxes", "migrations", "migrated_out", "replans"]
+        return {"max": {k: float(tab[:, i].max()) for i, k in enumerate(names)}, "min": {k: float(tab[:, i].min()) for i, k in enumerate(names)},
+                "per_rank": [{k: float(tab[r, i]) for i, k in enumerate(names)} for r in range(world)]}
+
+    tiled_info = None
+    if world > 1 or force_tiled:
+        tiled_info = rank_table(ms, elapsed)
+        tiled_info["wire"] = native_wire or ("torch" if data_group is not None else "staged")
+        if native_wire and hasattr(job, "totals"):
+            try:  # live particles / sticky error word of the whole job, reduced inside the library (mpmhip_tiled_totals)
+                tiled_info["totals"] = job.totals()
+            except Exception as e:
+                tiled_info["totals"] = {"error": repr(e)}
+        if args.wire == "both" and native_wire in ("rccl", "ipc"):
+            # the same job, re-wired: IPC peer writes instead of send / receive groups (collective: every rank comes here).  (Where the
+            # first wire already is ipc — the RCCL probe failed, or the test hook that lets the ranks share a GPU — the job is
+            # re-planned and re-connected all the same: the second object then measures the re-wired job on the same wire.)
+            dog.phase("second wire (ipc)", 600)
+            try:
+                job.rewire("ipc")
+                e2, ms2, _, _ = measure(args.warmup, args.steps)
+                other = rank_table(ms2, e2)
+                t2 = torch.tensor([e2], dtype=torch.float64)
+                if world > 1:
+                    dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+                other.update(wire="ipc", ms_per_step=1e3 * float(t2.item()) / args.steps, overlap_split=job.overlap)
+                tiled_info["other_wire"] = other
+            except Exception as e:
+                tiled_info["other_wire"] = {"wire": "ipc", "error": repr(e)}
+            dog.phase("report", 900)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -666,6 +746,7 @@ def main():
                    "state": state_desc},
         "roofline": roof,
         "phases_ms_per_step": ms,
+        "tiled": tiled_info,
         "p2g_plus_g2p_particle_steps_per_s": n_per_gpu / ((ms["p2g"] + ms["g2p"]) * 1e-3),
         "p2g_plus_g2p_hbm_frac_algorithmic": both_frac,
         "whole_step_hbm_frac_algorithmic": whole_step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,

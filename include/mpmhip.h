@@ -197,7 +197,10 @@ int mpmhip_snapshot_load(mpmhip_ctx *ctx, const void *src, size_t size);
 /* replaces MPM<3>::calculate_energy (src/mpm.cpp:1078-1110; general_action "calculate_energy", :936-938): sorts and
  * rasterizes, then kinetic = sum over grid nodes of 1/2 m |v|^2, potential = sum of MPMParticle::potential_energy()
  * (defined for linear, jelly, elastic: src/particles.cpp:323-327,400-407,785-796).  Returns MPMHIP_ENOTIMPL (with a
- * valid *kinetic) if a live particle is of another type, as the reference aborts there.  Synchronises. */
+ * valid *kinetic) if a live particle is of another type, as the reference aborts there.  Synchronises.
+ * On a ctx of a tiled job (mpmhip_tiled_setup, wires RCCL / IPC) the call is COLLECTIVE and returns the energy of the whole job:
+ * halo exchange after the rasterization, every node's kinetic energy counted by the lowest rank that holds mass on it, the ranks'
+ * shares summed by mpmhip_tiled_reduce (MPMHIP_WIRE_LOCAL: mpmhip_calculate_energy_group). */
 int mpmhip_calculate_energy(mpmhip_ctx *ctx, double *kinetic, double *potential);
 
 /* replaces general_action "delete_particles_inside_level_set" (src/mpm.cpp:962-974): deletes every particle whose
@@ -361,6 +364,23 @@ int mpmhip_tiled_connect_local(mpmhip_ctx *const *ctxs, int32_t n /* = world, ct
 int64_t mpmhip_tiled_advance(mpmhip_ctx *ctx, int64_t n);
 /* the same for all ranks of a MPMHIP_WIRE_LOCAL job: per substep begin of every rank, [interior of every rank,] end of every rank */
 int64_t mpmhip_tiled_advance_group(mpmhip_ctx *const *ctxs, int32_t n_ctx, int64_t n);
+/* SURVEY section 8(e) collective (3) — a few scalars over all ranks of a tiled job, inside the library: in-place all-reduce of n <=
+ * MPMHIP_REDUCE_MAX_VALUES doubles (MPMHIP_WIRE_RCCL: ncclAllReduce on a device row; MPMHIP_WIRE_IPC: every rank writes its row into
+ * every rank's table, publishes an epoch, waits for the world's and reduces the table in rank order — the bit-identical result on
+ * every rank).  Collective: every rank calls it with the same n and op.  Synchronises. */
+enum { MPMHIP_REDUCE_SUM = 0, MPMHIP_REDUCE_MAX = 1, MPMHIP_REDUCE_MIN = 2 };
+#define MPMHIP_REDUCE_MAX_VALUES 16
+int mpmhip_tiled_reduce(mpmhip_ctx *ctx, double *values, int32_t n, int32_t op);
+/* the same for all ranks of a MPMHIP_WIRE_LOCAL job: values = [n_ctx][n], every row receives the result */
+int mpmhip_tiled_reduce_group(mpmhip_ctx *const *ctxs, int32_t n_ctx, double *values, int32_t n, int32_t op);
+/* MPM<dim>::calculate_energy (src/mpm.cpp:1078-1110) of the WHOLE job of a MPMHIP_WIRE_LOCAL group (on the other wires
+ * mpmhip_calculate_energy of a tiled ctx is itself the collective): sort + rasterize + halo exchange on every rank, grid kinetic
+ * energy with every node counted by the lowest rank that holds mass on it, the particles' potential energy, summed over the ranks */
+int mpmhip_calculate_energy_group(mpmhip_ctx *const *ctxs, int32_t n_ctx, double *kinetic, double *potential);
+/* out = {live particles, active blocks, sticky error word (OR over the ranks: bit 0 block table full, 1 a particle beyond the margin,
+ * 2 distance-field pages, 4 a peer's epoch timed out), particles migrated so far} of the whole job; collective; synchronises */
+int mpmhip_tiled_totals(mpmhip_ctx *ctx, int64_t out[4]);
+int mpmhip_tiled_totals_group(mpmhip_ctx *const *ctxs, int32_t n_ctx, int64_t out[4]);
 /* out = {substeps run, substep of the next migration, particles migrated out so far, migrations, re-plans, halo boxes,
  *        halo nodes (float4) per exchange, wire} */
 int mpmhip_tiled_state(mpmhip_ctx *ctx, int64_t out[8]);

@@ -59,7 +59,33 @@ def kernel_stats(lib):
     return out
 
 
+def base_name(mangled):
+    """'k_g2p' of _ZN3mpm5k_g2pILi256E...: the kernel's name without namespace and template arguments (the key of
+    profiles/traffic_*.json, where make_traffic.py cuts rocprofv3's demangled names the same way)"""
+    m = re.match(r"^_ZN3mpm(\d+)", mangled)
+    if not m:
+        return None
+    n, at = int(m.group(1)), m.end()
+    return mangled[at:at + n]
+
+
+def kernel_hashes(lib):
+    """{base name: sha256 over the instruction streams of ALL its instantiations} — the identity of a kernel's code as a PMC summary
+    or a bench line can record it: any edit that reaches one instantiation changes the hash (conservative on purpose)"""
+    import hashlib
+    acc = {}
+    for name, ins in sorted(kernels(lib).items()):
+        b = base_name(name)
+        if b:
+            acc.setdefault(b, hashlib.sha256()).update(("\n".join([name] + ins) + "\n").encode())
+    return {k: h.hexdigest()[:16] for k, h in acc.items()}
+
+
 if __name__ == "__main__":
+    if len(sys.argv) == 3 and sys.argv[1] == "--hashes":
+        import json
+        print(json.dumps(kernel_hashes(sys.argv[2]), indent=1, sort_keys=True))
+        sys.exit(0)
     if len(sys.argv) == 3 and sys.argv[1] == "--stats":
         import json
         print(json.dumps(kernel_stats(sys.argv[2]), indent=1, sort_keys=True))

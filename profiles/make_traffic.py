@@ -13,6 +13,7 @@ from collections import defaultdict
 
 LAST = None
 TAG = ""
+LIB = None  # --lib <libmpmhip.so>: the library the passes ran with; its kernels' code hashes go into the summary (bench.py checks them)
 
 
 def means(path, counter):
@@ -34,14 +35,27 @@ def main(fetch_csv, write_csv):
     for k in sorted(set(f) & set(w)):
         rd, wr = f[k] * 1024 * 2, w[k] * 1024
         out["kernels"][k] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
+    if LIB:  # identity of the code the counters were taken on: bench.py prints `traffic: null` when the loaded library's kernel differs
+        import os
+        import subprocess
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import kernel_diff
+        hashes = kernel_diff.kernel_hashes(LIB)
+        try:
+            commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
+        except Exception:
+            commit = ""
+        out["code"] = {"commit": commit or None, "kernel_hashes": {k: hashes[k] for k in out["kernels"] if k in hashes}}
     json.dump(out, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":
     args = sys.argv[1:]
-    while args and args[0] in ("--last", "--tag"):
+    while args and args[0] in ("--last", "--tag", "--lib"):
         if args[0] == "--last":  # only the last N dispatches of every kernel
             LAST = int(args[1])
+        elif args[0] == "--lib":
+            LIB = args[1]
         else:
             TAG = args[1]
         args = args[2:]

@@ -20,7 +20,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $W/pmc_write -o
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $W/pmc_sq1 -o p -- $S > $O/pmc_sq1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS --output-format csv -d $W/pmc_sq2 -o p -- $S > $O/pmc_sq2.log 2>&1
 python $R/profiles/summarize_pmc.py --last 12 $W/pmc_*/p_counter_collection.csv > $O/pmc_summary.txt 2>&1
-python $R/profiles/make_traffic.py --tag $TAG --last 12 $W/pmc_fetch/p_counter_collection.csv $W/pmc_write/p_counter_collection.csv > $O/traffic.json 2>> $O/pmc_summary.txt
+python $R/profiles/make_traffic.py --tag $TAG --last 12 --lib $R/taichi_mpm_amd/lib/libmpmhip.so $W/pmc_fetch/p_counter_collection.csv $W/pmc_write/p_counter_collection.csv > $O/traffic.json 2>> $O/pmc_summary.txt
 grep '^{' $O/trace.log | tail -1 > $O/bench_under_trace.json
 cp $W/trace/t_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
 ls $O $W/trace

@@ -161,6 +161,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_set_profile_sampling", "mpmhip_create"
             "mpmhip_substep_begin", "mpmhip_substep_end", "mpmhip_substep_interior", "mpmhip_set_overlap", "mpmhip_tiled_run", "mpmhip_leaver_counts", "mpmhip_migration_scan", "mpmhip_export_leavers",
             "mpmhip_comm_unique_id", "mpmhip_comm_init", "mpmhip_comm_destroy", "mpmhip_comm_selftest", "mpmhip_tiled_setup", "mpmhip_tiled_ipc_handle",
             "mpmhip_tiled_ipc_connect", "mpmhip_tiled_connect_local", "mpmhip_tiled_advance", "mpmhip_tiled_advance_group", "mpmhip_tiled_state", "mpmhip_tiled_plan",
+            "mpmhip_tiled_reduce", "mpmhip_tiled_reduce_group", "mpmhip_calculate_energy_group", "mpmhip_tiled_totals", "mpmhip_tiled_totals_group",
             "mpmhip_import_particles", "mpmhip_active_bounds", "mpmhip_num_slots", "mpmhip_request_compaction", "mpmhip_reserve", "mpmhip_capacity", "mpmhip_mpm88_create", "mpmhip_mpm88_destroy", "mpmhip_mpm88_last_error", "mpmhip_mpm88_add",
             "mpmhip_mpm88_num_particles", "mpmhip_mpm88_advance", "mpmhip_mpm88_download", "mpmhip_mpm88_download_grid",
             "mpmhip_async_enable", "mpmhip_async_begin", "mpmhip_async_pool_particles", "mpmhip_async_step", "mpmhip_async_load_pools", "mpmhip_async_state", "mpmhip_async_current_time", "mpmhip_async_block_times", "mpmhip_async_download_pools", "mpmhip_async_profile", "mpmhip_async_snapshot_size", "mpmhip_async_snapshot_save", "mpmhip_async_snapshot_load", "mpmhip_host_particle_bytes", "mpmhip_async_update_dt_limits", "mpmhip_async_blocks", "mpmhip_async_set_time_int", "mpmhip_async_table", "mpmhip_clear_particles", "mpmhip_set_dt", "mpmhip_set_time", "mpmhip_get_clock", "mpmhip_set_clock", "mpmhip_debug_allowed_dt",
@@ -254,6 +255,11 @@ def load():
     L.mpmhip_tiled_advance.restype = C.c_int64
     L.mpmhip_tiled_advance_group.argtypes = [P(vp), C.c_int32, C.c_int64]
     L.mpmhip_tiled_advance_group.restype = C.c_int64
+    L.mpmhip_tiled_reduce.argtypes = [vp, P(C.c_double), C.c_int32, C.c_int32]
+    L.mpmhip_tiled_reduce_group.argtypes = [P(vp), C.c_int32, P(C.c_double), C.c_int32, C.c_int32]
+    L.mpmhip_calculate_energy_group.argtypes = [P(vp), C.c_int32, P(C.c_double), P(C.c_double)]
+    L.mpmhip_tiled_totals.argtypes = [vp, P(C.c_int64)]
+    L.mpmhip_tiled_totals_group.argtypes = [P(vp), C.c_int32, P(C.c_int64)]
     L.mpmhip_tiled_state.argtypes = [vp, P(C.c_int64)]
     L.mpmhip_tiled_plan.argtypes = [vp, C.c_int32, P(HaloBox)]
     L.mpmhip_num_slots.argtypes = [vp]

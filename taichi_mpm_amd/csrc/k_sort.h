@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_rank(Params P, uint32_t *__restrict__ k
   // behind the batches (one more round trip at the end of a wave instead of two in front of its own loads)
   const uint32_t row_a = blockIdx.x * 4u + (uint32_t)wave;
   uint32_t row_key = 0;
-  if (row_a < na) row_key = act_blk[row_a];
+  if (nbr && row_a < na) row_key = act_blk[row_a];  // (nbr == nullptr: this ctx's grid pass does not use the list)
   const uint32_t nbatch = (n + RANK_BATCH - 1) / RANK_BATCH;
   for (uint32_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
     const uint32_t i0 = b * RANK_BATCH + (uint32_t)wave * 256u + 4u * (uint32_t)lane;
@@ -407,9 +407,11 @@ __global__ __launch_bounds__(256) void k_rank(Params P, uint32_t *__restrict__ k
         if (i0 + j < n) key[i0 + j] = w[j];
     }
   }
-  if (row_a < na) write_neighbour_row(P, row_a, row_key, (uint32_t)lane, bits, wprefix, nbr);
-  for (uint32_t a = row_a + gridDim.x * 4u; a < na; a += gridDim.x * 4u)  // (more active blocks than waves: tiny particle counts)
-    write_neighbour_row(P, a, act_blk[a], (uint32_t)lane, bits, wprefix, nbr);
+  if (nbr) {
+    if (row_a < na) write_neighbour_row(P, row_a, row_key, (uint32_t)lane, bits, wprefix, nbr);
+    for (uint32_t a = row_a + gridDim.x * 4u; a < na; a += gridDim.x * 4u)  // (more active blocks than waves: tiny particle counts)
+      write_neighbour_row(P, a, act_blk[a], (uint32_t)lane, bits, wprefix, nbr);
+  }
   __syncthreads();
   if ((blockIdx.x & 15u) == 0u) {
 #pragma unroll
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
     if (a0 >= na && !(na == 0 && chunk == 0)) return;
     if (lane < CT_BPW) {  // owner masks of the wave's blocks (k_rank wrote the rows): one lane per block
       const uint32_t a = a0 + wave * CT_BPW + lane;
-      const uint32_t m = a < na ? nbr[(size_t)a * 32 + 28] : 0u;
+      const uint32_t m = (nbr && a < na) ? nbr[(size_t)a * 32 + 28] : 0u;
       own_mask[wave * CT_BPW + lane] = m;
       own_tot[wave * CT_BPW + lane] = (uint32_t)__popc(m);
     }
@@ -509,6 +511,82 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
       cnt->n_sorted = grand;
       cnt->n_own = n_own;
       if (stats) { stats->n_live = grand; stats->n_active = na; stats->n_own = n_own; stats->epoch = epoch; }
+    }
+    if (na == 0) return;
+  }
+}
+
+// The cell table WITHOUT the owner list (an untiled ctx of 2 M slots and more: mpmhip.hip: do_sort), as it was until round 4: the
+// second sum of the scan, the masks and the LDS-parked prefixes cost 2 us at 8 M particles that this configuration does not get back.
+template <int CT_BLOCKS>
+__global__ __launch_bounds__(256) void k_cell_table_plain(Params P, Counters *cnt, uint32_t *__restrict__ cell_cnt,
+                                                    uint32_t *__restrict__ act_start,
+                                                    uint32_t *__restrict__ cell_start,
+                                                    unsigned long long *__restrict__ slots, uint32_t epoch,
+                                                    uint32_t rank_runs_mul, uint32_t *__restrict__ chunk_blk,
+                                                          FillStats *__restrict__ stats) {
+  __shared__ uint32_t lds[8];
+  constexpr int CT_BPW = CT_BLOCKS / 4;  // blocks per wave
+  __shared__ uint32_t blk_tot[CT_BLOCKS];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // k_rank of this sort is complete: its run statistics choose the path of the next one (see k_rank)
+    cnt->rank_mode = (cnt->run_heads * rank_runs_mul > P.n_slots) ? 1u : 0u;
+    cnt->run_heads = 0u;
+  }
+  const uint32_t na = min(cnt->n_active, P.max_blocks);
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t round = 0;
+  while (true) {
+    const uint32_t chunk = next_chunk(round);
+    const uint32_t a0 = chunk * CT_BLOCKS;
+    if (a0 >= na && !(na == 0 && chunk == 0)) return;
+    uint32_t excl[CT_BPW];  // exclusive in-block prefix of this lane's cell, for the wave's blocks
+    uint32_t tot[CT_BPW];   // (lane 63: the block's particle count)
+#pragma unroll
+    for (int i = 0; i < CT_BPW; i++) {
+      const uint32_t a = a0 + wave * CT_BPW + i;
+      uint32_t c = 0;
+      if (a < na) {
+        c = cell_cnt[(size_t)a * BC + lane];
+        cell_cnt[(size_t)a * BC + lane] = 0;
+      }
+      uint32_t v = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(v, off);
+        if ((int)lane >= off) v += u;
+      }
+      excl[i] = v - c;
+      tot[i] = v;
+      if (lane == 63) blk_tot[wave * CT_BPW + i] = v;
+    }
+    __syncthreads();
+    // exclusive scan of the 64 block totals (threads 0..63 hold one block each; other threads contribute 0)
+    const uint32_t mine = threadIdx.x < CT_BLOCKS ? blk_tot[threadIdx.x] : 0u;
+    uint32_t total;
+    const uint32_t boff = wg_exclusive_scan_256(mine, lds, total);
+    if (threadIdx.x == 0) publish(slots + chunk, epoch, total);
+    if (threadIdx.x < CT_BLOCKS) blk_tot[threadIdx.x] = boff;
+    const uint32_t chunk_base = sum_predecessors(slots, chunk, epoch, lds);  // its barriers also cover blk_tot
+#pragma unroll
+    for (int i = 0; i < CT_BPW; i++) {
+      const uint32_t a = a0 + wave * CT_BPW + i;
+      if (a < na) {
+        const uint32_t start = chunk_base + blk_tot[wave * CT_BPW + i];
+        cell_start[(size_t)a * BC + lane] = start + excl[i];
+        if (lane == 0) act_start[a] = start;
+        // k_g2p_packed walks the sorted index in chunks of 256 positions: the block holding position 256 k, for every k inside this block
+        if (chunk_blk && lane == 63)
+          for (uint32_t k = (start + 255u) >> 8; (k << 8) < start + tot[i]; k++) chunk_blk[k] = a;
+      }
+    }
+    if (a0 + CT_BLOCKS >= na && threadIdx.x == 0) {  // last chunk: sentinels + live count
+      const uint32_t grand = chunk_base + total;
+      act_start[na] = grand;
+      cell_start[(size_t)na * BC] = grand;
+      cnt->n_sorted = grand;
+      cnt->n_own = 0u;
+      if (stats) { stats->n_live = grand; stats->n_active = na; stats->n_own = 0u; stats->epoch = epoch; }
     }
     if (na == 0) return;
   }

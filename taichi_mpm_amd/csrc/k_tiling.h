@@ -64,6 +64,28 @@ __global__ __launch_bounds__(64) void k_epoch_signal(const DevBox *__restrict__ 
   if (b < n) __hip_atomic_store(boxes[b].flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// signal + wait in ONE launch (the IPC wire without the overlap split: nothing runs between the two, and a launch costs ~3.7 us of a
+// ~130 us substep at 8 bricks): lanes b < n_sig publish, then lanes i < n_wait poll.  Every rank publishes before it polls, so two
+// ranks never wait for each other's store.  NOT for ranks that share one process's hardware queues (MPMHIP_WIRE_LOCAL: the polling
+// kernel of one virtual rank could sit in front of the publishing kernel of another).
+__global__ __launch_bounds__(64) void k_epoch_signal_wait(const DevBox *__restrict__ boxes, int n_sig, const uint32_t *words,
+                                                          const int *__restrict__ idx, int n_wait, uint32_t epoch,
+                                                          unsigned long long timeout_ticks, Counters *cnt) {
+  const int i = threadIdx.x;
+  if (i == 0) __atomic_thread_fence(__ATOMIC_RELEASE);  // (system scope)
+  if (i < n_sig) __hip_atomic_store(boxes[i].flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (i >= n_wait) return;
+  const uint32_t *w = words + idx[i];
+  const unsigned long long t0 = wall_clock64();
+  while ((int32_t)(__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+    __builtin_amdgcn_s_sleep(16);
+    if (wall_clock64() - t0 > timeout_ticks) {
+      atomicOr(&cnt->error, 16u);
+      return;
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void k_epoch_wait(const uint32_t *words, const int *__restrict__ idx, int n, uint32_t epoch,
                                                    unsigned long long timeout_ticks, Counters *cnt) {
   const int i = threadIdx.x;

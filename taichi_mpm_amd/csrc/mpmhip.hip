@@ -114,10 +114,12 @@ struct mpmhip_ctx {
   uint32_t *cell_cnt = nullptr, *cell_start = nullptr, *fat_slot = nullptr;
   uint32_t *nbr = nullptr, *own_list = nullptr;  // k_cell_table -> k_grid: 32-word neighbour row per active block, list of owned (block, candidate) pairs
   FillStats *d_stats = nullptr;  // device address of the pinned page's statistics words (h_pinned + FILL_STATS_WORD): k_cell_table stores there
-  int grid_walk = 2;             // walk of the substep's grid pass (k_grid.h): 2 owner list; 0 / 1 the pre-round-5 walks (env MPMHIP_GRID_WALK: A/B)
+  int grid_walk = -1;            // walk of the substep's grid pass (k_grid.h): 2 owner list, 0 per block / per (block, candidate) as until round 4,
+                                 // -1 by size and tiling (env MPMHIP_GRID_WALK: A/B)
+  bool list_valid = false;       // the last sort built neighbour rows + owner list (do_sort -> do_grid)
   int grid_wgs = 0;              // workgroups of the grid pass; 0: from the last sort's owner count (env MPMHIP_GRID_WGS)
   unsigned long long *scan_slots = nullptr;  // [256] k_block_table + [ct_grid] k_cell_table: {epoch, chunk sum}
-  uint32_t sort_epoch = 0, bt_slots = 0;
+  uint32_t sort_epoch = 0, bt_slots = 0, ct_slots = 0;  // scan_slots: [bt_slots] k_block_table | [ct_slots] k_cell_table_plain | [ct_slots] k_cell_table
   uint32_t scan_grid = 256;  // workgroups of the single-pass scan kernels: three eighths of what the device keeps resident
   float4 *tiles = nullptr, *gridv = nullptr, *dense = nullptr;
   Counters *cnt = nullptr;
@@ -139,7 +141,7 @@ struct mpmhip_ctx {
   uint32_t *chunk_blk = nullptr;  // per 256 positions of the sorted index: the block holding the first (k_cell_table -> k_g2p_packed)
   int rigid_wgs = 2048;       // workgroups of k_p2g_rigid (one per wave slot of the device), twice those of k_g2p_rigid (env MPMHIP_RIGID_WGS: tuning)
   uint32_t rank_runs_mul = 3; // k_rank takes its LDS-hash path when runs * this > slots (env MPMHIP_RANK_RUNS_MUL: tuning)
-  int ct_blocks = 0;          // blocks per chunk of k_cell_table: 0 by size, 16, 64 (env MPMHIP_CT_BLOCKS: tuning)
+  int ct_blocks = 0;          // blocks per chunk of k_cell_table: 0 by size, 16, 32, 64 (env MPMHIP_CT_BLOCKS: tuning)
   int g2p_minw = 12;          // tuning knob (env MPMHIP_G2P_MINW): 10 + __launch_bounds__ waves/SIMD of k_g2p
   int reorder_interval = 0;   // physical reorder every this many substeps (0 = never); env MPMHIP_REORDER_INTERVAL
   float t = 0.0f, request_t = 0.0f;  // `real` accumulators, as in the reference (src/mpm.h:99, mpm.cpp:573)
@@ -252,10 +254,12 @@ struct mpmhip_ctx {
     struct Peer {  // a rank's arena as THIS process addresses it
       uint32_t *flags = nullptr, *table[2] = {nullptr, nullptr};
       float4 *recv[2] = {nullptr, nullptr}, *inbox = nullptr;
+      double *red[2] = {nullptr, nullptr};  // reduction tables (tiled_api.h: tn_reduce_*)
       void *ipc_base = nullptr;  // mapped with hipIpcOpenMemHandle (closed on destroy)
     };
     struct Mig { std::vector<int64_t> counts; int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; float speed = 0.0f; int64_t total = 0, n_out = 0, n_in = 0; } mig;
     bool on = false, connected = false, exch_on_side = false;
+    bool wait_merged = false, merge_signal_wait = true;  // IPC wire, no overlap split: signal + wait of a substep in one launch
     int world = 1, wire = 0;
     int clip_lo[3] = {0, 0, 0}, clip_hi[3] = {0, 0, 0};
     std::vector<Box> boxes;
@@ -268,7 +272,8 @@ struct mpmhip_ctx {
     DevBox *d_boxes[2] = {nullptr, nullptr};
     int *d_halo_idx = nullptr, *d_all_idx = nullptr;
     std::vector<Peer> peers;
-    uint32_t epoch = 0, mig_epoch = 0;
+    uint32_t epoch = 0, mig_epoch = 0, red_epoch = 0;
+    double *d_red = nullptr;  // this rank's row of a reduction (+ room for the all-reduced row)
     unsigned long long timeout_ticks = 2000000000ull;  // of the 100 MHz wall clock
     void *comm = nullptr;  // ncclComm_t
     int comm_rank = 0, comm_world = 1;
@@ -522,7 +527,8 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(dmalloc(&c->nbr, (size_t)mb * 32));
   A(dmalloc(&c->own_list, (size_t)mb * 8));
   c->bt_slots = (P.nbw + 255) / 256;
-  const size_t n_slots64 = c->bt_slots + ((size_t)mb + 15) / 16 + 1;  // k_cell_table chunks are >= 16 blocks
+  c->ct_slots = (uint32_t)(((size_t)mb + 15) / 16 + 1);  // k_cell_table chunks are >= 16 blocks
+  const size_t n_slots64 = c->bt_slots + 2 * (size_t)c->ct_slots;
   A(dmalloc(&c->scan_slots, n_slots64));
   A(dmalloc(&c->tiles, (size_t)mb * TN));
   A(dmalloc(&c->gridv, (size_t)mb * 8 * BC));
@@ -556,7 +562,8 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
     int cus = 0, per_cu = 0, lowest = 1 << 20;
     A(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
     if (cus > 0) c->n_cus = cus;
-    const void *scans[3] = {(const void *)k_block_table, (const void *)k_cell_table<16>, (const void *)k_cell_table<64>};
+    const void *scans[7] = {(const void *)k_block_table, (const void *)k_cell_table<16>, (const void *)k_cell_table<32>, (const void *)k_cell_table<64>,
+                            (const void *)k_cell_table_plain<16>, (const void *)k_cell_table_plain<32>, (const void *)k_cell_table_plain<64>};
     for (const void *k : scans) {
       A(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, 0));
       lowest = std::min(lowest, per_cu);
@@ -943,8 +950,18 @@ static int do_sort(mpmhip_ctx *c) {
   const int pg = particle_grid(c->n_slots);
   if (!c->keys_valid)
     hipLaunchKernelGGL(k_build_keys, dim3(pg), dim3(256), 0, st, P, c->rg, c->rp, c->cnt, c->key, c->blk_flag);
-  const bool small = c->ct_blocks ? c->ct_blocks == 16 : c->n_slots < (2 << 20);  // few blocks: finer chunks in k_cell_table
-  const uint32_t bt_chunks = (P.nbw + 255) / 256, ct_chunks = (P.max_blocks + (small ? 16 : 64) - 1) / (small ? 16 : 64);
+  // blocks per chunk of k_cell_table: few blocks -> finer chunks (shorter chains, more workgroups).  16 below 2 M slots, 64 from 6 M on
+  // (16 costs 10 us at 8 M: its 1 100 chunks no longer fit the scans' resident grid), 32 in between — a rank of a 2-brick job
+  // holds 4 M particles in 8 788 blocks: 17.4 us with 64 (as long as the whole 8 M problem takes: the kernel is a latency chain)
+  const int ct = (c->ct_blocks == 16 || c->ct_blocks == 32 || c->ct_blocks == 64) ? c->ct_blocks
+                                                                                   : (c->n_slots < (2 << 20) ? 16 : (c->n_slots < (6 << 20) ? 32 : 64));
+  const uint32_t bt_chunks = (P.nbw + 255) / 256, ct_chunks = (P.max_blocks + ct - 1) / ct;
+  // Owner list of the grid pass (k_sort.h, k_grid.h): below 2 M slots it takes the pass from 17 to 7.5 us (1 M particles) for 2..3 us
+  // in k_rank + k_cell_table; a tiled ctx always builds it (the per-block walk with the halo-box code in it thrashes the instruction
+  // cache: 31 -> 19 us at 4 M particles per rank); an untiled ctx of 2 M slots and more does not — there the pass is bound by its
+  // 180 MB of tile reads either way (30.4 against 30.5 us at 8 M) and the rows cost the sort 8 us (profiles/r05_e_*_census.txt).
+  c->list_valid = c->grid_walk == 2 || (c->grid_walk < 0 && (c->T.enabled || c->n_slots < (2 << 20)));
+  uint32_t *const nbr = c->list_valid ? c->nbr : nullptr;
   uint32_t epoch = ++c->sort_epoch;
   if ((epoch & 0x7FFFFFu) == 0u) epoch = ++c->sort_epoch;  // (k_cell_table's scan words keep 23 bits of it; 0 = never published)
   // (single-pass scans: never more workgroups than are resident at once, see k_sort.h)
@@ -952,10 +969,16 @@ static int do_sort(mpmhip_ctx *c) {
                      c->wprefix, c->act_blk, c->cnt, c->scan_slots, epoch);
   const uint32_t rank_wgs = std::min<uint32_t>((P.n_slots + RANK_BATCH - 1) / RANK_BATCH, 8192u);
   hipLaunchKernelGGL(k_rank, dim3(std::max(rank_wgs, 1u)), dim3(256), 0, st, P, c->key, c->rank, c->cell_cnt, c->bits, c->wprefix,
-                     c->cnt, (const uint32_t *)c->act_blk, c->nbr);
-  hipLaunchKernelGGL(small ? k_cell_table<16> : k_cell_table<64>, dim3(std::min(ct_chunks, c->scan_grid)), dim3(256), 0, st, P,
-                     c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots, epoch, c->rank_runs_mul, c->chunk_blk,
-                     (const uint32_t *)c->nbr, c->own_list, c->d_stats);
+                     c->cnt, (const uint32_t *)c->act_blk, nbr);
+  if (c->list_valid)  // (the two forms publish different scan words: each has its own slots)
+    hipLaunchKernelGGL(ct == 16 ? k_cell_table<16> : (ct == 32 ? k_cell_table<32> : k_cell_table<64>), dim3(std::min(ct_chunks, c->scan_grid)), dim3(256), 0, st, P,
+                       c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots + c->ct_slots, epoch, c->rank_runs_mul,
+                       c->chunk_blk, (const uint32_t *)nbr, c->own_list, c->d_stats);
+  else
+    hipLaunchKernelGGL(ct == 16 ? k_cell_table_plain<16> : (ct == 32 ? k_cell_table_plain<32> : k_cell_table_plain<64>),
+                       dim3(std::min(ct_chunks, c->scan_grid)), dim3(256), 0, st, P,
+                       c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots, epoch, c->rank_runs_mul, c->chunk_blk,
+                       c->d_stats);
   hipLaunchKernelGGL(k_perm, dim3(pg), dim3(256), 0, st, P, (const Counters *)c->cnt, c->key, c->rank, c->cell_start, c->perm);
   // (k_cell_table's last chunk stores (live particles, active blocks, owner entries) of this sort straight into the pinned page,
   // never waited for: the host picks the G2P walk by how full the blocks are (g2p_is_packed) and sizes the grid pass's launch
@@ -1081,24 +1104,29 @@ static int do_p2g(mpmhip_ctx *c, int phase = 0) {
 static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
   c->P.t = c->t;  // this->current_t of the substep in flight (src/mpm.cpp:532-533)
   c->LS.dirichlet = c->dirichlet ? 1 : 0;
-  // the substep's pass (mode 0) walks the owner list of the last sort: one wave per touched grid block, launched at the size of the
-  // list as the last sort reported it (+ 12 %; the walk is a grid-stride loop, so a stale number costs time, never correctness).
-  // MPMHIP_GRID_WALK=0 / 1 (A/B): the pre-round-5 walks — per block at >= 2 M slots, per (block, candidate) below.
-  const bool per_cand = mode == 0 && c->n_slots < (2 << 20);
-  const int walk = mode != 0 ? 0 : (c->grid_walk == 2 ? 2 : (per_cand ? 1 : 0));
-  auto kern = mode == 0 ? (walk == 2 ? k_grid<0, 2> : (walk == 1 ? k_grid<0, 1> : k_grid<0, 0>))
-                        : (mode == 1 ? k_grid<1, 0> : (mode == 2 ? k_grid<2, 0> : (mode == 3 ? k_grid<3, 0> : k_grid<4, 0>)));
-  int wgs = walk == 1 ? 16384 : 4096;
-  if (walk == 2) {
+  // mode 0 (the substep's pass) and mode 4 (energy) walk the owner list when the last sort built one (do_sort: small problems and
+  // every tiled ctx): one wave per touched grid block, launched at the size of the list as the last sort reported it (+ 12 %; the
+  // walk is a grid-stride loop, so a stale number costs time, never correctness).  Otherwise, and for the dense views: the walks
+  // of rounds 1-4 — per block at >= 2 M slots, per (block, candidate) below.
+  if ((mode == 0 || mode == 4) && c->list_valid) {
     const volatile FillStats *fs = reinterpret_cast<const volatile FillStats *>(c->h_pinned + mpmhip_ctx::FILL_STATS_WORD);
     uint64_t n_own = fs->n_own;
     if (n_own == 0) n_own = std::min<uint64_t>((uint64_t)c->P.max_blocks * 8u, 32768u);  // (before the first sort has reported)
-    wgs = (int)std::min<uint64_t>(8192u, std::max<uint64_t>(64u, (n_own + n_own / 8 + 3) / 4 + 8));
+    int wgs = (int)std::min<uint64_t>(8192u, std::max<uint64_t>(64u, (n_own + n_own / 8 + 3) / 4 + 8));
+    if (c->grid_wgs > 0) wgs = c->grid_wgs;
+    hipLaunchKernelGGL(mode == 0 ? k_grid_list<0> : k_grid_list<4>, dim3(wgs), dim3(256), 0, c->stream, c->P, c->cnt, (const uint32_t *)c->nbr,
+                       (const uint32_t *)c->own_list, c->tiles, c->gridv, c->fat_slot, reinterpret_cast<double *>(c->dense), c->T,
+                       c->d_boxes_cur, c->LS, phase);
+    return launch_check(c, "grid");
   }
+  const bool per_cand = mode == 0 && c->n_slots < (2 << 20);  // small per-GPU problem: latency-bound, see k_grid.h
+  auto kern = mode == 0 ? (per_cand ? k_grid_blocks<0, true> : k_grid_blocks<0, false>)
+                        : (mode == 1 ? k_grid_blocks<1, false>
+                                     : (mode == 2 ? k_grid_blocks<2, false> : (mode == 3 ? k_grid_blocks<3, false> : k_grid_blocks<4, false>)));
+  int wgs = per_cand ? 16384 : 4096;
   if (c->grid_wgs > 0 && mode == 0) wgs = c->grid_wgs;
-  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, c->stream, c->P, c->cnt, c->act_blk, c->bits, c->wprefix, (const uint32_t *)c->nbr,
-                     (const uint32_t *)c->own_list, c->tiles, c->gridv, c->fat_slot, c->dense, c->T, c->d_boxes_cur,
-                     c->LS, phase);
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, c->stream, c->P, c->cnt, c->act_blk, c->bits, c->wprefix, c->tiles,
+                     c->gridv, c->fat_slot, c->dense, c->T, c->d_boxes_cur, c->LS, phase);
   return launch_check(c, "grid");
 }
 // which G2P kernel the plain blocks of the next substep get (bench.py names the kernel of its roofline after it).  By size and by
@@ -1784,13 +1812,24 @@ int mpmhip_write_bgeo(mpmhip_ctx *c, const char *path, int32_t verbose) {
 
 // MPM<dim>::calculate_energy (src/mpm.cpp:1078-1110): sort + P2G, kinetic energy of the grid, potential energy
 // of the particles.  Leaves the ctx sorted with fresh P2G tiles (like the reference, which leaves its grid rasterized).
-int mpmhip_calculate_energy(mpmhip_ctx *c, double *kinetic, double *potential) {
-  if (!c || !kinetic || !potential) return MPMHIP_EINVAL;
-  HIPCHK(c, hipSetDevice(c->device));
-  if (c->T.n_boxes > 0) return fail(c, MPMHIP_ENOTIMPL, "calculate_energy on a tiled ctx (sum the ranks' shares on the caller side)");
+// calculate_energy (src/mpm.cpp:1078-1110) in two halves, so that a tiled job can put its halo exchange between them:
+//   begin  sort, rasterize (P2G) [+ halo pack and the start of the exchange]
+//   end    [the peers' sums have arrived] grid kinetic energy, particles' potential energy -> out = {kinetic, potential, particles of
+//          a type without potential_energy()}: this ctx's SHARE — on a tiled ctx a node's kinetic energy is counted by the lowest
+//          rank that holds mass on it (k_grid mode 4), so the shares add up to the one-ctx energy.
+static int energy_begin(mpmhip_ctx *c) {
   int rc;
+  c->ov_active = false;
   if ((rc = do_sort(c))) return rc;
   if ((rc = do_p2g(c))) return rc;
+  if (c->tn.on && c->T.n_boxes > 0) {
+    tn_begin_substep(c);
+    if ((rc = do_halo_pack(c))) return rc;
+  }
+  return MPMHIP_OK;
+}
+static int energy_end(mpmhip_ctx *c, double out[3]) {
+  int rc;
   if (!c->d_energy) HIPCHK(c, dmalloc(&c->d_energy, 4));
   HIPCHK(c, hipMemsetAsync(c->d_energy, 0, 4 * sizeof(double), c->stream));
   float4 *const dense_saved = c->dense;
@@ -1802,14 +1841,32 @@ int mpmhip_calculate_energy(mpmhip_ctx *c, double *kinetic, double *potential) {
   hipLaunchKernelGGL(k_potential_energy, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, (const RecG *)c->rg,
                      (const GroupParams *)c->d_groups, acc + 1);
   if ((rc = launch_check(c, "potential_energy"))) return rc;
-  double h[3];
-  HIPCHK(c, hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  double *h = reinterpret_cast<double *>(c->h_pinned + 12288);  // (pinned: behind the reductions' staging)
+  HIPCHK(c, hipMemcpyAsync(h, acc, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  *kinetic = h[0];
-  *potential = h[1];
-  if (h[2] != 0.0)
+  for (int i = 0; i < 3; i++) out[i] = h[i];
+  return MPMHIP_OK;
+}
+namespace { int tn_energy(mpmhip_ctx *c, double out[3]); }  // (tiled_api.h: exchange + reduction over the ranks)
+
+int mpmhip_calculate_energy(mpmhip_ctx *c, double *kinetic, double *potential) {
+  if (!c || !kinetic || !potential) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->in_substep) return fail(c, MPMHIP_EINVAL, "calculate_energy inside a substep");
+  double e[3];
+  int rc;
+  if (c->tn.on && c->tn.world > 1) {  // the whole job's energy: collective over the ranks
+    if ((rc = tn_energy(c, e))) return rc;
+  } else {
+    if (c->T.n_boxes > 0) return fail(c, MPMHIP_ENOTIMPL, "calculate_energy on a ctx tiled through the callback path (mpmhip_set_halo): "
+                                      "use the native data plane (mpmhip_tiled_setup), whose calculate_energy covers the whole job");
+    if ((rc = energy_begin(c)) || (rc = energy_end(c, e))) return rc;
+  }
+  *kinetic = e[0];
+  *potential = e[1];
+  if (e[2] != 0.0)
     return fail(c, MPMHIP_ENOTIMPL, "%.0f particles are of a type without potential_energy() (reference: TC_NOT_IMPLEMENTED); "
-                "kinetic energy is valid", h[2]);
+                "kinetic energy is valid", e[2]);
   return MPMHIP_OK;
 }
 
@@ -2071,7 +2128,8 @@ int mpmhip_reserve(mpmhip_ctx *c, int64_t max_particles) {
       A(regrow(&c->act_blk, 0, m + 1, false)); A(regrow(&c->act_start, 0, m + 2, true));
       A(regrow(&c->cell_cnt, 0, m * BC, true)); A(regrow(&c->cell_start, 0, m * BC + 1, true));
       A(regrow(&c->nbr, 0, m * 32, false)); A(regrow(&c->own_list, 0, m * 8, false));
-      A(regrow(&c->scan_slots, 0, c->bt_slots + (m + 15) / 16 + 1, true));  // (epoch 0 is never used)
+      c->ct_slots = (uint32_t)((m + 15) / 16 + 1);
+      A(regrow(&c->scan_slots, 0, c->bt_slots + 2 * (size_t)c->ct_slots, true));  // (epoch 0 is never used)
       A(regrow(&c->tiles, 0, m * TN, false)); A(regrow(&c->gridv, 0, m * 8 * BC, false));
       if (c->rigid.d_blk_rigid) { A(regrow(&c->rigid.d_blk_rigid, 0, m + 1, true)); A(regrow(&c->rigid.d_rigid_list, 0, m + 1, false)); }
       if (e != hipSuccess) return fail(c, MPMHIP_ENOMEM, "growing the block table to %lld failed: %s", (long long)mb, hipGetErrorString(e));

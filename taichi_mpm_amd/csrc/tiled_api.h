@@ -32,6 +32,7 @@ struct RcclApi {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
@@ -59,6 +60,7 @@ RcclApi *rccl_api() {
   api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
   api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
   api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+  api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
   api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
   if (!ok) { dlclose(api.handle); api.handle = nullptr; }
   return &api;
@@ -72,7 +74,24 @@ RcclApi *rccl_api() {
 
 constexpr int TN_MAX_WORLD = MPMHIP_MAX_HALO_BOXES;      // every other rank can be a halo peer
 constexpr uint32_t TN_ROW = TN_MAX_WORLD + 8;            // words of a migration row: [counts(world) | lo3 | hi3 | speed | inbox capacity], padded
-constexpr size_t TN_FLAG_BYTES = 4096;                   // halo epochs [world] | table epochs [world] | record epochs [world]
+constexpr size_t TN_FLAG_BYTES = 4096;                   // halo epochs [world] | table epochs [world] | record epochs [world] | reduction epochs [world]
+constexpr int TN_RED_N = MPMHIP_REDUCE_MAX_VALUES;       // doubles of one rank's row of a reduction (mpmhip_tiled_reduce)
+constexpr size_t TN_RED_BYTES = 2 * sizeof(double) * TN_RED_N * TN_MAX_WORLD;  // two tables of [world] rows (parity of the reduction)
+constexpr size_t TN_RED_PIN_WORD = 8192;                 // the staging of a reduction in the ctx's pinned page (behind the migration table)
+// a rank's arena as a process addresses it (its own allocation, or a peer's mapped one): every rank lays its arena out alike
+void tn_carve(mpmhip_ctx::TiledNative::Peer &P, char *base, size_t table_bytes, size_t recv_bytes) {
+  P.flags = reinterpret_cast<uint32_t *>(base);
+  char *p = base + TN_FLAG_BYTES;
+  P.red[0] = reinterpret_cast<double *>(p);
+  P.red[1] = P.red[0] + (size_t)TN_RED_N * TN_MAX_WORLD;
+  p += TN_RED_BYTES;
+  P.table[0] = reinterpret_cast<uint32_t *>(p);
+  P.table[1] = reinterpret_cast<uint32_t *>(p + table_bytes);
+  p += 2 * table_bytes;
+  P.recv[0] = reinterpret_cast<float4 *>(p);
+  P.recv[1] = reinterpret_cast<float4 *>(p + recv_bytes);
+  P.inbox = reinterpret_cast<float4 *>(p + 2 * recv_bytes);
+}
 
 int tn_wait(mpmhip_ctx *c, const uint32_t *words, const std::vector<int> &who, int *d_idx, uint32_t epoch) {
   if (who.empty()) return MPMHIP_OK;
@@ -212,6 +231,12 @@ int tn_exchange_start(mpmhip_ctx *c) {
   auto &N = c->tn;
   if (N.boxes.empty()) return MPMHIP_OK;
   if (N.wire != MPMHIP_WIRE_RCCL) {  // peer wires: k_halo_pack wrote the boxes into the peers' buffers; publish the epoch
+    N.wait_merged = N.wire == MPMHIP_WIRE_IPC && !c->ov_active && N.merge_signal_wait;
+    if (N.wait_merged) {  // (nothing runs between signal and wait: one launch; see k_epoch_signal_wait)
+      hipLaunchKernelGGL(k_epoch_signal_wait, dim3(1), dim3(64), 0, c->stream, c->d_boxes_cur, (int)N.boxes.size(), (const uint32_t *)N.flags,
+                         (const int *)N.d_halo_idx, (int)N.halo_peers.size(), N.epoch, N.timeout_ticks, c->cnt);
+      return launch_check(c, "epoch_signal_wait");
+    }
     hipLaunchKernelGGL(k_epoch_signal, dim3(1), dim3(64), 0, c->stream, c->d_boxes_cur, (int)N.boxes.size(), N.epoch);
     return launch_check(c, "epoch_signal");
   }
@@ -240,6 +265,7 @@ int tn_exchange_wait(mpmhip_ctx *c) {
     if (N.exch_on_side) HIPCHK(c, hipStreamWaitEvent(c->stream, N.ev_b, 0));
     return MPMHIP_OK;
   }
+  if (N.wait_merged) return MPMHIP_OK;  // (tn_exchange_start's launch has waited already)
   return tn_wait(c, N.flags, N.halo_peers, N.d_halo_idx, N.epoch);
 }
 
@@ -415,10 +441,82 @@ int tn_mig_c(mpmhip_ctx *c) {
   return MPMHIP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ reductions
+// SURVEY section 8(e) collective (3): a few scalars over all ranks (energy, live particles, the sticky error word).
+//   RCCL       ncclAllReduce on a device row, read back
+//   peer wires every rank writes its row into every rank's table (k_put: the writer of the last row piece publishes the
+//              reduction's epoch), waits for the world's epochs, reads the table back and reduces it in RANK ORDER on the host —
+//              every rank gets the bit-identical result.  Tables alternate by the parity of the reduction: a rank reaches
+//              reduction r + 2 only after it has read the table of r + 1, which every rank fills after its read of r.
+// put: this rank's share on its way (no host synchronisation); finish: wait, read back, reduce.
+int tn_reduce_put(mpmhip_ctx *c, const double *vals, int n, int op) {
+  auto &N = c->tn;
+  if (n < 1 || n > TN_RED_N) return fail(c, MPMHIP_EINVAL, "reduce: 1 .. %d values", TN_RED_N);
+  if (op != MPMHIP_REDUCE_SUM && op != MPMHIP_REDUCE_MAX && op != MPMHIP_REDUCE_MIN) return fail(c, MPMHIP_EINVAL, "reduce: unknown operation %d", op);
+  N.red_epoch++;
+  double *h = reinterpret_cast<double *>(c->h_pinned + TN_RED_PIN_WORD);
+  for (int i = 0; i < TN_RED_N; i++) h[i] = i < n ? vals[i] : 0.0;
+  HIPCHK(c, hipMemcpyAsync(N.d_red, h, sizeof(double) * TN_RED_N, hipMemcpyHostToDevice, c->stream));
+  if (N.wire == MPMHIP_WIRE_RCCL && N.comm) {  // (also with one rank: the binding is exercised on every box)
+    const ncclRedOp_t rop = op == MPMHIP_REDUCE_SUM ? ncclSum : (op == MPMHIP_REDUCE_MAX ? ncclMax : ncclMin);
+    NCCLCHK(c, rccl_api()->AllReduce(N.d_red, N.d_red, (size_t)n, ncclDouble, rop, (ncclComm_t)N.comm, c->stream));
+    return MPMHIP_OK;
+  }
+  if (N.world == 1) return MPMHIP_OK;
+  PutList L;
+  memset(&L, 0, sizeof L);
+  const int par = (int)(N.red_epoch & 1u);
+  for (int p = 0; p < N.world; p++) {
+    const auto &P = N.peers[p];
+    L.src[p] = reinterpret_cast<const uint32_t *>(N.d_red);
+    L.dst[p] = reinterpret_cast<uint32_t *>(P.red[par] + (size_t)c->T.rank * TN_RED_N);
+    L.flag[p] = P.flags + 3 * TN_MAX_WORLD + c->T.rank;
+    L.words[p] = 2u * (uint32_t)TN_RED_N;
+  }
+  hipLaunchKernelGGL(k_put, dim3(N.world, 1), dim3(256), 0, c->stream, L, N.red_epoch, N.d_done);
+  return launch_check(c, "put (reduction row)");
+}
+int tn_reduce_finish(mpmhip_ctx *c, double *vals, int n, int op) {
+  auto &N = c->tn;
+  double *h = reinterpret_cast<double *>(c->h_pinned + TN_RED_PIN_WORD);
+  if (N.world == 1 || N.wire == MPMHIP_WIRE_RCCL) {
+    HIPCHK(c, hipMemcpyAsync(h, N.d_red, sizeof(double) * TN_RED_N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++) vals[i] = h[i];
+    return MPMHIP_OK;
+  }
+  int rc = tn_wait(c, N.flags + 3 * TN_MAX_WORLD, N.all_ranks, N.d_all_idx, N.red_epoch);
+  if (rc) return rc;
+  const int par = (int)(N.red_epoch & 1u);
+  HIPCHK(c, hipMemcpyAsync(h, N.peers[c->T.rank].red[par], sizeof(double) * TN_RED_N * N.world, hipMemcpyDeviceToHost, c->stream));
+  Counters hc;
+  if ((rc = read_counters(c, hc))) return rc;  // synchronises; reports a wait that timed out
+  for (int i = 0; i < n; i++) {
+    double v = h[i];
+    for (int r = 1; r < N.world; r++) {
+      const double w = h[(size_t)r * TN_RED_N + i];
+      v = op == MPMHIP_REDUCE_SUM ? v + w : (op == MPMHIP_REDUCE_MAX ? std::max(v, w) : std::min(v, w));
+    }
+    vals[i] = v;
+  }
+  return MPMHIP_OK;
+}
+
 int tn_check_ready(mpmhip_ctx *c, const char *who) {
   if (!c->tn.on) return fail(c, MPMHIP_EINVAL, "%s needs mpmhip_tiled_setup first", who);
   if (!tn_connected(c)) return fail(c, MPMHIP_EINVAL, "%s: the wire is not connected (mpmhip_comm_init / mpmhip_tiled_ipc_connect / mpmhip_tiled_connect_local)", who);
   return MPMHIP_OK;
+}
+
+// the whole job's energy on one rank (mpmhip_calculate_energy of a tiled ctx): this rank's share with the peers' halo sums, then
+// the sum over the ranks.  out = {kinetic, potential, particles without potential_energy()}
+int tn_energy(mpmhip_ctx *c, double out[3]) {
+  int rc = tn_check_ready(c, "calculate_energy");
+  if (rc) return rc;
+  if (c->tn.wire == MPMHIP_WIRE_LOCAL) return fail(c, MPMHIP_EINVAL, "ranks of a local job compute their energy together: mpmhip_calculate_energy_group");
+  if ((rc = energy_begin(c)) || (rc = tn_exchange_start(c)) || (rc = tn_exchange_wait(c)) || (rc = energy_end(c, out))) return rc;
+  if ((rc = tn_reduce_put(c, out, 3, MPMHIP_REDUCE_SUM))) return rc;
+  return tn_reduce_finish(c, out, 3, MPMHIP_REDUCE_SUM);
 }
 
 void tn_free(mpmhip_ctx *c) {
@@ -434,6 +532,7 @@ void tn_free(mpmhip_ctx *c) {
   if (N.d_halo_idx) (void)hipFree(N.d_halo_idx);
   if (N.d_all_idx) (void)hipFree(N.d_all_idx);
   if (N.d_done) (void)hipFree(N.d_done);
+  if (N.d_red) (void)hipFree(N.d_red);
   if (N.side) { (void)hipStreamSynchronize(N.side); (void)hipStreamDestroy(N.side); }
   if (N.ev_a) (void)hipEventDestroy(N.ev_a);
   if (N.ev_b) (void)hipEventDestroy(N.ev_b);
@@ -504,7 +603,8 @@ int mpmhip_comm_selftest(mpmhip_ctx *c) {
   if (r == ncclSuccess) r = R->Send(d, n, ncclUint32, next, (ncclComm_t)N.comm, c->stream);
   if (r == ncclSuccess) r = R->Recv(ring, n, ncclUint32, prev, (ncclComm_t)N.comm, c->stream);
   if (r == ncclSuccess) r = R->GroupEnd();
-  (void)ring_out;
+  // all-reduce (sum) of the first 8 words as uint32: word i becomes sum over ranks of (rank * 1000003 + i), into ring_out
+  if (r == ncclSuccess) r = R->AllReduce(d, ring_out, 8, ncclUint32, ncclSum, (ncclComm_t)N.comm, c->stream);
   if (r != ncclSuccess) return bail(fail(c, MPMHIP_EHIP, "selftest: %s", R->GetErrorString(r)));
   e = hipMemcpyAsync(h.data(), d, sizeof(uint32_t) * h.size(), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -514,6 +614,11 @@ int mpmhip_comm_selftest(mpmhip_ctx *c) {
       if (h[(size_t)n * (1 + s) + i] != (uint32_t)(s * 1000003 + i)) return bail(fail(c, MPMHIP_EHIP, "selftest: all-gather delivered wrong data (rank %d, word %d)", s, i));
   for (int i = 0; i < n; i++)
     if (h[(size_t)n * (world + 1) + i] != (uint32_t)(prev * 1000003 + i)) return bail(fail(c, MPMHIP_EHIP, "selftest: send / receive delivered wrong data (word %d)", i));
+  for (int i = 0; i < 8; i++) {
+    uint32_t want = 0;
+    for (int s = 0; s < world; s++) want += (uint32_t)(s * 1000003 + i);
+    if (h[(size_t)n * (world + 2) + i] != want) return bail(fail(c, MPMHIP_EHIP, "selftest: all-reduce delivered wrong data (word %d)", i));
+  }
   return bail(MPMHIP_OK);
 }
 
@@ -544,6 +649,7 @@ int mpmhip_tiled_setup(mpmhip_ctx *c, const mpmhip_tiled_config *cfg, const int3
   N.migrate_interval = cfg->migrate_interval > 0 ? cfg->migrate_interval : cfg->margin;
   N.adaptive_cap = cfg->migrate_interval > 0 ? 0 : (cfg->migrate_cap > 0 ? cfg->migrate_cap : 64);
   N.k = 0; N.next_migration = N.migrate_interval;
+  N.merge_signal_wait = !(getenv("MPMHIP_TILE_MERGE_WAIT") && atoi(getenv("MPMHIP_TILE_MERGE_WAIT")) == 0);  // (A/B knob)
   N.timeout_ticks = 100000000ull * (unsigned long long)std::max(1, getenv("MPMHIP_TILE_WAIT_S") ? atoi(getenv("MPMHIP_TILE_WAIT_S")) : 20);
   // worst-case halo volume over all ranks: the clip box = the whole grid (so that every rank lays its arena out alike)
   const int full_lo[3] = {0, 0, 0}, full_hi[3] = {c->P.res[0] + 1, c->P.res[1] + 1, c->P.res[2] + 1};
@@ -557,10 +663,10 @@ int mpmhip_tiled_setup(mpmhip_ctx *c, const mpmhip_tiled_config *cfg, const int3
   if (cap >= (1ull << 31)) return fail(c, MPMHIP_EINVAL, "halo boxes too large");
   N.halo_cap = std::max<uint64_t>(cap, 1);
   N.inbox_cap = cfg->inbox_records > 0 ? (uint64_t)cfg->inbox_records : std::max<uint64_t>(65536, (uint64_t)c->cap / 8);
-  // arena: [flags 4 KiB | table 0 | table 1 | recv 0 | recv 1 | inbox]
+  // arena: [flags 4 KiB | reduction tables 16 KiB | table 0 | table 1 | recv 0 | recv 1 | inbox]
   const size_t table_bytes = ((sizeof(uint32_t) * TN_ROW * TN_MAX_WORLD + 255) / 256) * 256;
   const size_t recv_bytes = ((sizeof(float4) * N.halo_cap + 255) / 256) * 256;
-  N.arena_bytes = TN_FLAG_BYTES + 2 * table_bytes + 2 * recv_bytes + sizeof(float4) * 11 * N.inbox_cap;
+  N.arena_bytes = TN_FLAG_BYTES + TN_RED_BYTES + 2 * table_bytes + 2 * recv_bytes + sizeof(float4) * 11 * N.inbox_cap;
   const bool peer_wire = N.wire == MPMHIP_WIRE_IPC || N.wire == MPMHIP_WIRE_LOCAL;
   hipError_t e;
   if (N.wire == MPMHIP_WIRE_IPC) {
@@ -573,16 +679,8 @@ int mpmhip_tiled_setup(mpmhip_ctx *c, const mpmhip_tiled_config *cfg, const int3
   }
   if (e != hipSuccess) return fail(c, MPMHIP_ENOMEM, "halo arena of %zu bytes: %s", N.arena_bytes, hipGetErrorString(e));
   HIPCHK(c, hipMemset(N.arena, 0, N.arena_bytes));
-  auto carve = [&](mpmhip_ctx::TiledNative::Peer &P, char *base) {
-    P.flags = reinterpret_cast<uint32_t *>(base);
-    P.table[0] = reinterpret_cast<uint32_t *>(base + TN_FLAG_BYTES);
-    P.table[1] = reinterpret_cast<uint32_t *>(base + TN_FLAG_BYTES + table_bytes);
-    P.recv[0] = reinterpret_cast<float4 *>(base + TN_FLAG_BYTES + 2 * table_bytes);
-    P.recv[1] = reinterpret_cast<float4 *>(base + TN_FLAG_BYTES + 2 * table_bytes + recv_bytes);
-    P.inbox = reinterpret_cast<float4 *>(base + TN_FLAG_BYTES + 2 * table_bytes + 2 * recv_bytes);
-  };
   mpmhip_ctx::TiledNative::Peer self;
-  carve(self, N.arena);
+  tn_carve(self, N.arena, table_bytes, recv_bytes);
   N.flags = self.flags; N.table[0] = self.table[0]; N.table[1] = self.table[1];
   N.recv[0] = self.recv[0]; N.recv[1] = self.recv[1]; N.inbox = self.inbox;
   N.table_bytes = table_bytes; N.recv_bytes = recv_bytes;
@@ -594,6 +692,7 @@ int mpmhip_tiled_setup(mpmhip_ctx *c, const mpmhip_tiled_config *cfg, const int3
   for (int k = 0; k < 2; k++) HIPCHK(c, dmalloc(&N.d_boxes[k], (size_t)MPMHIP_MAX_HALO_BOXES));
   HIPCHK(c, dmalloc(&N.d_halo_idx, (size_t)MPMHIP_MAX_HALO_BOXES));
   HIPCHK(c, dmalloc(&N.d_all_idx, (size_t)TN_MAX_WORLD));
+  HIPCHK(c, dmalloc(&N.d_red, (size_t)TN_RED_N * (TN_MAX_WORLD + 1)));
   HIPCHK(c, dmalloc(&N.d_done, (size_t)TN_MAX_WORLD + 1));
   HIPCHK(c, hipMemset(N.d_done, 0, sizeof(uint32_t) * (TN_MAX_WORLD + 1)));
   N.all_ranks.resize((size_t)N.world);
@@ -656,13 +755,7 @@ int mpmhip_tiled_ipc_connect(mpmhip_ctx *c, const uint8_t *handles) {
     hipError_t e = hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess);
     if (e != hipSuccess) return fail(c, MPMHIP_EHIP, "hipIpcOpenMemHandle of rank %d's arena: %s", p, hipGetErrorString(e));
     P.ipc_base = base;
-    char *b = static_cast<char *>(base);
-    P.flags = reinterpret_cast<uint32_t *>(b);
-    P.table[0] = reinterpret_cast<uint32_t *>(b + TN_FLAG_BYTES);
-    P.table[1] = reinterpret_cast<uint32_t *>(b + TN_FLAG_BYTES + table_bytes);
-    P.recv[0] = reinterpret_cast<float4 *>(b + TN_FLAG_BYTES + 2 * table_bytes);
-    P.recv[1] = reinterpret_cast<float4 *>(b + TN_FLAG_BYTES + 2 * table_bytes + recv_bytes);
-    P.inbox = reinterpret_cast<float4 *>(b + TN_FLAG_BYTES + 2 * table_bytes + 2 * recv_bytes);
+    tn_carve(P, static_cast<char *>(base), table_bytes, recv_bytes);
   }
   N.connected = true;
   return tn_apply_plan(c);
@@ -751,6 +844,102 @@ int64_t mpmhip_tiled_advance_group(mpmhip_ctx *const *ctxs, int32_t n_ctx, int64
     }
   }
   return n;
+}
+
+int mpmhip_tiled_reduce(mpmhip_ctx *c, double *values, int32_t n, int32_t op) {
+  if (!c || !values) return MPMHIP_EINVAL;
+  int rc = tn_check_ready(c, "tiled_reduce");
+  if (rc) return rc;
+  if (c->tn.wire == MPMHIP_WIRE_LOCAL && c->tn.world > 1) return fail(c, MPMHIP_EINVAL, "ranks of a local job reduce together: mpmhip_tiled_reduce_group");
+  HIPCHK(c, hipSetDevice(c->device));
+  if ((rc = tn_reduce_put(c, values, n, op))) return rc;
+  return tn_reduce_finish(c, values, n, op);
+}
+
+static int tn_check_group(mpmhip_ctx *const *ctxs, int32_t n_ctx, const char *who) {
+  if (!ctxs || n_ctx < 1) return MPMHIP_EINVAL;
+  for (int r = 0; r < n_ctx; r++) {
+    if (!ctxs[r]) return MPMHIP_EINVAL;
+    int rc = tn_check_ready(ctxs[r], who);
+    if (rc) return rc;
+    if (ctxs[r]->tn.wire != MPMHIP_WIRE_LOCAL || ctxs[r]->tn.world != n_ctx || ctxs[r]->T.rank != r)
+      return fail(ctxs[r], MPMHIP_EINVAL, "%s: ctx %d is not rank %d of a local job of %d", who, r, r, n_ctx);
+  }
+  return MPMHIP_OK;
+}
+
+int mpmhip_tiled_reduce_group(mpmhip_ctx *const *ctxs, int32_t n_ctx, double *values, int32_t n, int32_t op) {
+  int rc = tn_check_group(ctxs, n_ctx, "tiled_reduce_group");
+  if (rc || !values) return rc ? rc : MPMHIP_EINVAL;
+  for (int r = 0; r < n_ctx; r++) {  // every rank's row on its way, then every rank reads the table
+    HIPCHK(ctxs[r], hipSetDevice(ctxs[r]->device));
+    if ((rc = tn_reduce_put(ctxs[r], values + (size_t)r * n, n, op))) return rc;
+  }
+  for (int r = 0; r < n_ctx; r++)
+    if ((rc = tn_reduce_finish(ctxs[r], values + (size_t)r * n, n, op))) return rc;
+  return MPMHIP_OK;
+}
+
+int mpmhip_calculate_energy_group(mpmhip_ctx *const *ctxs, int32_t n_ctx, double *kinetic, double *potential) {
+  int rc = tn_check_group(ctxs, n_ctx, "calculate_energy_group");
+  if (rc || !kinetic || !potential) return rc ? rc : MPMHIP_EINVAL;
+  std::vector<double> e((size_t)n_ctx * 3);
+  for (int r = 0; r < n_ctx; r++) {
+    mpmhip_ctx *c = ctxs[r];
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->in_substep) return fail(c, MPMHIP_EINVAL, "calculate_energy inside a substep");
+    if ((rc = energy_begin(c)) || (rc = tn_exchange_start(c))) return rc;
+  }
+  for (int r = 0; r < n_ctx; r++)
+    if ((rc = tn_exchange_wait(ctxs[r])) || (rc = energy_end(ctxs[r], &e[(size_t)r * 3]))) return rc;
+  if ((rc = mpmhip_tiled_reduce_group(ctxs, n_ctx, e.data(), 3, MPMHIP_REDUCE_SUM))) return rc;
+  *kinetic = e[0];
+  *potential = e[1];
+  if (e[2] != 0.0)
+    return fail(ctxs[0], MPMHIP_ENOTIMPL, "%.0f particles are of a type without potential_energy() (reference: TC_NOT_IMPLEMENTED); "
+                "kinetic energy is valid", e[2]);
+  return MPMHIP_OK;
+}
+
+// {live particles, active blocks, sticky error word (OR), particles migrated out so far} of the whole job
+static int tn_totals_local(mpmhip_ctx *c, double v[8]) {
+  Counters h;
+  HIPCHK(c, hipSetDevice(c->device));
+  // (the error word is read as it is: read_counters would turn a set bit into this rank's failure before the others have seen it)
+  Counters *pin = reinterpret_cast<Counters *>(c->h_pinned);
+  HIPCHK(c, hipMemcpyAsync(pin, c->cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  h = *pin;
+  v[0] = (double)(c->n_slots - (int64_t)h.n_dead);  // (= mpmhip_num_particles)
+  v[1] = (double)h.n_active; v[2] = (double)c->tn.migrated_out;
+  for (int b = 0; b < 5; b++) v[3 + b] = (double)((h.error >> b) & 1u);
+  return MPMHIP_OK;
+}
+static void tn_totals_out(const double v[8], int64_t out[4]) {
+  out[0] = (int64_t)v[0]; out[1] = (int64_t)v[1]; out[3] = (int64_t)v[2];
+  int64_t err = 0;
+  for (int b = 0; b < 5; b++) if (v[3 + b] > 0.0) err |= 1ll << b;
+  out[2] = err;
+}
+int mpmhip_tiled_totals(mpmhip_ctx *c, int64_t out[4]) {
+  if (!c || !out) return MPMHIP_EINVAL;
+  int rc = tn_check_ready(c, "tiled_totals");
+  if (rc) return rc;
+  if (c->tn.wire == MPMHIP_WIRE_LOCAL && c->tn.world > 1) return fail(c, MPMHIP_EINVAL, "ranks of a local job: mpmhip_tiled_totals_group");
+  double v[8];
+  if ((rc = tn_totals_local(c, v)) || (rc = tn_reduce_put(c, v, 8, MPMHIP_REDUCE_SUM)) || (rc = tn_reduce_finish(c, v, 8, MPMHIP_REDUCE_SUM))) return rc;
+  tn_totals_out(v, out);
+  return MPMHIP_OK;
+}
+int mpmhip_tiled_totals_group(mpmhip_ctx *const *ctxs, int32_t n_ctx, int64_t out[4]) {
+  int rc = tn_check_group(ctxs, n_ctx, "tiled_totals_group");
+  if (rc || !out) return rc ? rc : MPMHIP_EINVAL;
+  std::vector<double> v((size_t)n_ctx * 8);
+  for (int r = 0; r < n_ctx; r++)
+    if ((rc = tn_totals_local(ctxs[r], &v[(size_t)r * 8]))) return rc;
+  if ((rc = mpmhip_tiled_reduce_group(ctxs, n_ctx, v.data(), 8, MPMHIP_REDUCE_SUM))) return rc;
+  tn_totals_out(v.data(), out);
+  return MPMHIP_OK;
 }
 
 int mpmhip_tiled_state(mpmhip_ctx *c, int64_t out[8]) {

@@ -647,11 +647,38 @@ class NativeTiledJob(_NativeJobBase):
 
     def __init__(self, engine, part, rank, world, wire="rccl", dist=None, migrate_interval=None, overlap=True, inbox_records=0,
                  use_comm=None):
+        self.engines, self.e, self.part, self.rank, self.world = [engine], engine, part, rank, world
+        self._dist, self._setup_args, self._have_comm = dist, (migrate_interval, inbox_records), False
+        self._connect(wire, overlap, use_comm)
+
+    def rewire(self, wire, use_comm=None):
+        """the same job on the other wire (bench.py --wire both): the clip box is wrapped around the particles as they are now, plan
+        and arena are built again; particles, clocks and the RCCL communicator stay.  Collective."""
         import torch
-        self.engines, self.e, self.part, self.rank, self.world, self.wire = [engine], engine, part, rank, world, wire
+        e = self.e
+        e.synchronize()
+        if self.world > 1:
+            self._dist.barrier()  # (nobody frees or unmaps an arena a peer may still write to)
+        lo, hi = (C.c_int32 * 3)(), (C.c_int32 * 3)()
+        e.sim._check(e.L.mpmhip_sort(e.ctx))  # (the bounds are those of the last sort: make it the current positions')
+        e.sim._check(e.L.mpmhip_active_bounds(e.ctx, lo, hi))
+        t = torch.tensor([-lo[0], -lo[1], -lo[2], hi[0], hi[1], hi[2]], dtype=torch.int64)
+        if list(lo) > list(hi):  # no particles on this rank
+            t = torch.full((6,), -(1 << 30), dtype=torch.int64)
+        if self.world > 1:
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        self.part.set_clip_from_bounds([-int(t[0]), -int(t[1]), -int(t[2])], [int(t[3]), int(t[4]), int(t[5])])
+        self._connect(wire, self.overlap, use_comm)
+
+    def _connect(self, wire, overlap, use_comm):
+        import torch
+        engine, part, rank, world, dist = self.e, self.part, self.rank, self.world, self._dist
+        migrate_interval, inbox_records = self._setup_args
+        self.wire = wire
         L, sim = engine.L, engine.sim
-        need_comm = wire == "rccl" or (wire == "ipc" and use_comm)
+        need_comm = (wire == "rccl" or (wire == "ipc" and use_comm)) and not self._have_comm
         if need_comm:
+            self._have_comm = True
             ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
             if rank == 0:
                 buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
@@ -685,6 +712,23 @@ class NativeTiledJob(_NativeJobBase):
     def num_particles(self):
         return self.e.num_particles()
 
+    # --- scalars of the WHOLE job, reduced inside the library (mpmhip_tiled_reduce: ncclAllReduce, or rows + epochs over the IPC wire)
+    def reduce(self, values, op="sum"):
+        """in-place all-reduce of up to 16 doubles over the ranks (collective); returns the reduced list"""
+        v = (C.c_double * len(values))(*[float(x) for x in values])
+        self.e.sim._check(self.e.L.mpmhip_tiled_reduce(self.e.ctx, v, len(values), {"sum": 0, "max": 1, "min": 2}[op]))
+        return list(v)
+
+    def calculate_energy(self):
+        """(kinetic, potential) of the whole job (src/mpm.cpp:1078-1110): collective, every rank gets the same numbers"""
+        return self.e.sim.calculate_energy()
+
+    def totals(self):
+        """{live particles, active blocks, sticky error word, migrated particles} of the whole job (collective)"""
+        out = (C.c_int64 * 4)()
+        self.e.sim._check(self.e.L.mpmhip_tiled_totals(self.e.ctx, out))
+        return {"particles": int(out[0]), "active_blocks": int(out[1]), "error": int(out[2]), "migrated": int(out[3])}
+
 
 class NativeVirtualJob(_NativeJobBase):
     """all ranks of a partition as ctx of ONE process on one device, on the library's data plane (MPMHIP_WIRE_LOCAL: the
@@ -712,6 +756,27 @@ class NativeVirtualJob(_NativeJobBase):
         L = self.engines[0].L
         self._group_check(int(L.mpmhip_tiled_advance_group(self._arr, len(self.engines), int(n))), "mpmhip_tiled_advance_group")
         self.substeps += n
+
+    def reduce(self, rows, op="sum"):
+        """rows[r] = rank r's values (<= 16 doubles): all-reduce over the local wire; returns every rank's copy of the result"""
+        K, n = len(self.engines), len(rows[0])
+        v = (C.c_double * (K * n))(*[float(x) for row in rows for x in row])
+        L = self.engines[0].L
+        self._group_check(L.mpmhip_tiled_reduce_group(self._arr, K, v, n, {"sum": 0, "max": 1, "min": 2}[op]), "mpmhip_tiled_reduce_group")
+        return [list(v[r * n:(r + 1) * n]) for r in range(K)]
+
+    def calculate_energy(self):
+        """(kinetic, potential) of the whole job (src/mpm.cpp:1078-1110) — mpmhip_calculate_energy_group"""
+        k, p = C.c_double(), C.c_double()
+        L = self.engines[0].L
+        self._group_check(L.mpmhip_calculate_energy_group(self._arr, len(self.engines), C.byref(k), C.byref(p)), "mpmhip_calculate_energy_group")
+        return k.value, p.value
+
+    def totals(self):
+        out = (C.c_int64 * 4)()
+        L = self.engines[0].L
+        self._group_check(L.mpmhip_tiled_totals_group(self._arr, len(self.engines), out), "mpmhip_tiled_totals_group")
+        return {"particles": int(out[0]), "active_blocks": int(out[1]), "error": int(out[2]), "migrated": int(out[3])}
 
 
 # ---------------------------------------------------------------------------------------------------- bench glue

@@ -378,6 +378,46 @@ def test_native_migration_follows_a_moving_blob(tm):
         sim.close()
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_energy_and_totals_of_k_virtual_ranks_equal_the_one_ctx_numbers(tm, world):
+    """MPM<dim>::calculate_energy (src/mpm.cpp:1078-1110) of a tiled job: halo exchange after the rasterization, every node's kinetic
+    energy counted by the lowest rank that holds mass on it, the ranks' shares summed over the wire (mpmhip_tiled_reduce) — equal to
+    the one-ctx energy to 1e-6 relative; and the job's totals (live particles, error word)"""
+    from taichi_mpm_amd import tiled
+    x = lattice_cube(RES, 9, 21, DX, jitter=0.2, seed=31)
+    a = make_state(x, "jelly", DX, perturb_F=0.03, seed=32, vel_scale=8.0)
+    b = make_state(x, "elastic", DX, perturb_F=0.03, seed=33, vel_scale=8.0)
+    half = x[:, 1] < x[:, 1].mean()
+    s = a.copy()
+    s.gparams = np.concatenate([a.gparams, b.gparams]); s.gtype = np.concatenate([a.gtype, b.gtype])
+    s.gid = np.where(half, 0, 1).astype(np.int32)
+    s.F[~half] = b.F[~half]
+    one = _sim(tm, s, np.ones(s.n, bool), np.arange(s.n), s.n + 1024)
+    part = tiled.Partition.balanced((RES,) * 3, world, s.x, DX, margin=2)
+    owner = part.rank_of_cells(tiled.base_cells(s.x, DX))
+    sims = [_sim(tm, s, owner == r, np.arange(s.n), s.n + 1024) for r in range(world)]
+    job = tiled.NativeVirtualJob([tiled.HipEngine(sim, 0) for sim in sims], part, migrate_interval=2)
+    for steps in (0, 5):
+        one.run_substeps(steps)
+        job.run(steps)
+        k1, p1 = one.calculate_energy()
+        k2, p2 = job.calculate_energy()
+        assert k1 > 0 and p1 > 0
+        assert np.isclose(k2, k1, rtol=1e-6) and np.isclose(p2, p1, rtol=1e-6), (steps, k1, k2, p1, p2)
+    tot = job.totals()
+    assert tot["particles"] == one.get_num_particles() and tot["error"] == 0 and tot["active_blocks"] >= one.profile()["active_blocks"]
+    rows = job.reduce([[r + 1.0, -r] for r in range(world)], "sum")
+    assert all(row == [world * (world + 1) / 2.0, -world * (world - 1) / 2.0] for row in rows)
+    assert job.reduce([[float(r)] for r in range(world)], "max")[0] == [world - 1.0]
+    one.run_substeps(3)
+    job.run(3)  # (the energy's exchange consumed epochs on every rank alike: the run goes on)
+    got, ref = _gather(sims), one.get_particles()
+    assert np.array_equal(got["id"], ref["id"]) and np.abs(got["x"] - ref["x"]).max() <= 1e-6
+    del job
+    for sim in sims + [one]:
+        sim.close()
+
+
 def test_native_rccl_binding_on_one_rank(tm):
     """librccl dlopen'ed by libmpmhip: unique id, ncclCommInitRank, the loopback self-test (all-gather + grouped send / receive
     to self) and a tiled_advance over MPMHIP_WIRE_RCCL with the one rank a 1-GPU box allows (no halo boxes: the substeps
@@ -402,6 +442,19 @@ def test_native_rccl_binding_on_one_rank(tm):
     a, b = one.get_particles(), sim.get_particles()
     assert np.array_equal(a["id"], b["id"]) and np.abs(a["x"] - b["x"]).max() <= 1e-6 and rel_l2(a["F"], b["F"]) <= 1e-5
     assert tiled.native_state(e)["substeps"] == 6
+    # the scalars of a job travel inside the library too (SURVEY 8(e) collective 3): ncclAllReduce, here over the one rank
+    v = (C.c_double * 3)(1.5, -2.0, 7.0)
+    sim._check(L.mpmhip_tiled_reduce(sim._ctx, v, 3, 0))
+    assert list(v) == [1.5, -2.0, 7.0]
+    sim._check(L.mpmhip_tiled_reduce(sim._ctx, v, 3, 1))
+    assert list(v) == [1.5, -2.0, 7.0]
+    tot = (C.c_int64 * 4)()
+    sim._check(L.mpmhip_tiled_totals(sim._ctx, tot))
+    assert tot[0] == len(b["id"]) and tot[1] > 0 and tot[2] == 0
+    k1, p1, k2, p2 = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    assert L.mpmhip_calculate_energy(one._ctx, C.byref(k1), C.byref(p1)) in (0, -5)  # (-5: sand has no potential_energy(); kinetic valid)
+    assert L.mpmhip_calculate_energy(sim._ctx, C.byref(k2), C.byref(p2)) in (0, -5)
+    assert np.isclose(k1.value, k2.value, rtol=1e-6) and k1.value > 0
     sim._check(L.mpmhip_comm_destroy(sim._ctx))
     sim.close(); one.close()
 
@@ -503,9 +556,17 @@ def _native_worker(rank, world, port, steps, wire, overlap, device, q):
                                    overlap=overlap)
         job.run(steps)
         job.synchronize()
+        # scalars of the whole job, reduced inside the library (mpmhip_tiled_reduce: rows + epochs over the IPC wire, ncclAllReduce)
+        import ctypes as C
+        ke, pe = C.c_double(), C.c_double()
+        rc = sim._L.mpmhip_calculate_energy(sim._ctx, C.byref(ke), C.byref(pe))  # (-5: sand has no potential_energy(); kinetic valid)
+        extra = {"energy_rc": int(rc), "kinetic": ke.value, "sum": job.reduce([rank + 1.0, 10.0 * (rank + 1)], "sum"),
+                 "max": job.reduce([float(rank), -float(rank)], "max"), "min": job.reduce([float(rank)], "min"), "totals": job.totals()}
+        job.run(2)  # (the epochs of the energy's exchange are part of the protocol: the run goes on)
+        job.synchronize()
         dist.barrier()  # nobody unmaps an arena a peer may still write to
         p = sim.get_particles(sort_by_id=False)
-        q.put((rank, job.state()[0], {k: p[k] for k in ("x", "v", "F", "id", "gid")}))
+        q.put((rank, job.state()[0], {k: p[k] for k in ("x", "v", "F", "id", "gid")}, extra))
         sim.close()
     finally:
         dist.destroy_process_group()
@@ -516,9 +577,14 @@ def _run_native_ranks(tm, wire, overlap, devices):
 
     import torch.multiprocessing as mp
     s = _two_material_state()
+    import ctypes as C
     steps, world = 12, len(devices)
     one = _sim(tm, s, np.ones(s.n, bool), np.arange(s.n), s.n + 1024)
     one.run_substeps(steps)
+    ke, pe = C.c_double(), C.c_double()
+    assert one._L.mpmhip_calculate_energy(one._ctx, C.byref(ke), C.byref(pe)) in (0, -5)
+    n_live = one.get_num_particles()
+    one.run_substeps(2)
     ref = one.get_particles()
     one.close()
     with socket.socket() as sk:
@@ -533,7 +599,14 @@ def _run_native_ranks(tm, wire, overlap, devices):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert all(r[1]["substeps"] == steps and r[1]["migrations"] == steps // 2 for r in res), [r[1] for r in res]
+    assert all(r[1]["substeps"] == steps + 2 and r[1]["migrations"] == (steps + 2) // 2 for r in res), [r[1] for r in res]
+    for r in res:  # every rank holds the whole job's numbers
+        x = r[3]
+        assert x["energy_rc"] in (0, -5) and np.isclose(x["kinetic"], ke.value, rtol=1e-6), (x["kinetic"], ke.value)
+        assert x["sum"] == [sum(range(1, world + 1)), 10.0 * sum(range(1, world + 1))]
+        assert x["max"] == [world - 1.0, 0.0] and x["min"] == [0.0]
+        assert x["totals"]["particles"] == n_live and x["totals"]["error"] == 0
+    assert res[0][3]["kinetic"] == res[1][3]["kinetic"]  # reduced in rank order: bit-identical on every rank
     assert sum(r[1]["migrated_out"] for r in res) > 0  # migration happened
     got = {k: np.concatenate([r[2][k] for r in res]) for k in res[0][2]}
     order = np.argsort(got["id"], kind="stable")
@@ -563,7 +636,8 @@ def test_two_ranks_on_two_gpus_over_the_native_wires_match_one_ctx(tm, wire, ove
 
 
 @pytest.mark.parametrize("nproc,bricks,hook,config", [(2, "2x1x1", "gloo", "c2"), (8, "2x2x2", "ipc", "c2"), (2, "2x1x1", "staged", "c2"),
-                                                       (2, "2x1x1", "refuse", "c2"), (2, "2x1x1", "fallback", "c2"), (8, "2x2x2", "ipc", "c5")])
+                                                       (2, "2x1x1", "refuse", "c2"), (2, "2x1x1", "fallback", "c2"), (8, "2x2x2", "ipc", "c5"),
+                                                       (2, "2x1x1", "ipc+both", "c2")])
 def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks, hook, config):
     """`bench.py --gpus N` exactly as the driver launches it (torch.distributed.run, one process per rank) on a box with fewer
     GPUs than ranks.  hook "ipc" (MPMHIP_BENCH_BACKEND=ipc): the ranks share this GPU and run the library's own data plane over
@@ -584,6 +658,8 @@ def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks, hook, co
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.pop("MPMHIP_BENCH_BACKEND", None)
+    both = hook.endswith("+both")  # --wire both: the job is measured, re-wired (plan, arena, connection built again) and measured again
+    hook = hook.split("+")[0]
     if hook in ("gloo", "ipc"):
         env["MPMHIP_BENCH_BACKEND"] = hook
     env.setdefault("MPMHIP_TILE_WAIT_S", "20")
@@ -592,7 +668,8 @@ def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks, hook, co
         env["MPMHIP_NO_IPC_FALLBACK"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--config", config,
-           "--steps", "8", "--warmup", "4"] + (["--cells", "16"] if config == "c5" else []) + (["--allow-staged"] if hook == "staged" else [])
+           "--steps", "8", "--warmup", "4"] + (["--cells", "16"] if config == "c5" else []) + (["--allow-staged"] if hook == "staged" else []) + \
+          (["--wire", "both"] if both else [])
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
     if hook == "refuse":
         assert r.returncode != 0 and "refusing to fall back" in r.stderr, r.stdout[-2000:] + r.stderr[-4000:]
@@ -614,6 +691,21 @@ def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks, hook, co
         assert d["config"]["wire"].startswith("gloo") and ("probe failed" in d["config"]["wire"]) == (hook == "staged")
     ov = d["config"]["overlap_split"]  # both ways timed before the measurement, the faster one kept (bench.py)
     assert ov["kept"] in ("on", "off") and ov["ms_per_step_on"] > 0 and ov["ms_per_step_off"] > 0
+    # one run answers the questions of a multi-GPU run: every rank's phase table (max / min / rank by rank), where ranks wait
+    # (`exchange`), what the plan moves, migrations — and, on the native data plane, the job's totals reduced inside the library
+    t = d["tiled"]
+    assert len(t["per_rank"]) == nproc and set(t["max"]) >= {"sort", "p2g", "exchange", "grid", "g2p", "ms_per_step", "halo_bytes_per_substep"}
+    assert all(t["max"][k] >= t["min"][k] >= 0 for k in t["max"]) and t["max"]["g2p"] > 0
+    assert sum(r["particles"] for r in t["per_rank"]) == d["config"]["particles"]
+    if hook in ("ipc", "fallback"):
+        assert t["wire"] == "ipc" and t["min"]["halo_bytes_per_substep"] > 0
+        assert t["totals"]["particles"] == d["config"]["particles"] and t["totals"]["error"] == 0
+    if both:
+        o = t["other_wire"]
+        assert "error" not in o, o
+        assert o["wire"] == "ipc" and o["ms_per_step"] > 0 and len(o["per_rank"]) == nproc and o["min"]["halo_bytes_per_substep"] > 0
+    else:
+        assert "other_wire" not in t
 
 
 def test_bench_tiled_job_over_rccl_single_rank(tm):
