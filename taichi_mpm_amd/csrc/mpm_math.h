@@ -98,9 +98,10 @@ __device__ __forceinline__ void jacobi_rotate(float &app, float &aqq, float &apq
 
 // Ill-conditioned F: the decomposition is finished on F itself, one-sided (Hestenes), preconditioned by the U the eigen-solve of
 // F F^T found (see sym_eig3_FFt): B = U^T F has nearly orthogonal rows sigma_k v_k^T; two cyclic sweeps of plane rotations make
-// them orthogonal, U's columns rotate along, lam_k = |b_k|^2.  One-sided Jacobi on a row-scaled well-conditioned matrix gives
-// every singular value to a relative accuracy ~ eps, whatever the condition number (Demmel & Veselic 1992); measured: 2e-6 at
-// cond 1e2, 2e-4 at cond 1e4 against 8e-4 / 5.0 of sqrt(eig(F F^T)) (profiles/r05_c_illcond_*.txt).
+// them orthogonal, U's columns rotate along, lam_k = |b_k|^2.  One-sided Jacobi loses nothing of what its input holds (Demmel &
+// Veselic 1992), and B = U^T F formed in fp32 holds sigma_min to ~ eps cond(F) — the entries of F are of size sigma_max —
+// instead of the eps cond(F)^2 of sqrt(eig(F F^T)); measured relative error of sigma_min: 2e-6 at cond 1e2, 1e-5 at 1e3,
+// 2e-4 at 1e4, against 8e-4 / 4e-2 / 5.0 (profiles/r05_c_illcond_head.txt, r05_e_illcond_default.txt).
 // (Re-measuring |F^T u_k| with the eigenvectors as they are — no rotations — was built first and is not enough: the eigenvectors
 // of the two small singular values mix by ~ eps cond^2 / gap, and the larger of the two then leaks into the smaller.)
 // Register budget: k_g2p keeps three workgroups per CU only below 168 VGPRs, and U, B and F in registers on top of a particle's
