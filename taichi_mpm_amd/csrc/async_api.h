@@ -106,7 +106,7 @@ static int async_compact(mpmhip_ctx *c) {
     HIPCHK(c, hipMemsetAsync(S.d_scan, 0, sizeof(unsigned long long) * ((size_t)nchunks + 1024), c->stream));
     S.scan_cap = nchunks + 1024;
   }
-  hipLaunchKernelGGL(k_async_compact, dim3(std::min<uint32_t>(nchunks, c->scan_grid)), dim3(256), 0, c->stream, S.size,
+  hipLaunchKernelGGL(k_async_compact, dim3(std::min<uint32_t>(nchunks, scan_limit(c, (const void *)k_async_compact))), dim3(256), 0, c->stream, S.size,
                      (const uint32_t *)S.tag, (const int32_t *)S.id, (const float4 *)S.g, (const float4 *)S.w, S.tag2, S.id2, S.g2, S.w2,
                      S.d_scan, ++S.scan_epoch, S.d_cnt);
   if (int rc = launch_check(c, "async_compact")) return rc;

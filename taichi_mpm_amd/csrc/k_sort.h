@@ -116,24 +116,24 @@ __device__ __forceinline__ unsigned long long sum_predecessors2(const unsigned l
   wg_exclusive_scan_256_u64(pre, lds, total);
   return total;
 }
-// chunks are dealt round-robin by workgroup id: chunk = blockIdx.x + round * gridDim.x
-__device__ __forceinline__ uint32_t next_chunk(uint32_t &round) {
+// chunks are dealt round-robin by workgroup id: chunk = blockIdx.x + round * gridDim.x (bid / nwg: the workgroup's number among
+// those of its role and their count, when a launch carries two roles — k_sort_front)
+__device__ __forceinline__ uint32_t next_chunk(uint32_t &round, const uint32_t bid = blockIdx.x, const uint32_t nwg = gridDim.x) {
   __syncthreads();  // the previous chunk's LDS readers are done
-  return blockIdx.x + (round++) * gridDim.x;
+  return bid + (round++) * nwg;
 }
 
 // Active-block table, one launch: byte flags -> bitmap `bits` (bit b of word w = block with Morton key 32w+b;
 // the flags are cleared behind), per-word prefix `wprefix` (active blocks with key < 32w) = dense slot of every
 // active block, the list act_blk[slot] = key, and cnt->n_active.  Chunk = 256 bitmap words, one per thread.
-__global__ __launch_bounds__(256) void k_block_table(Params P, uint8_t *__restrict__ blk_flag,
-                                                     uint32_t *__restrict__ bits, uint32_t *__restrict__ wprefix,
-                                                     uint32_t *__restrict__ act_blk, Counters *cnt,
-                                                     unsigned long long *__restrict__ slots, uint32_t epoch) {
-  __shared__ uint32_t lds[8];
+__device__ __forceinline__ void block_table_body(const Params &P, uint8_t *__restrict__ blk_flag, uint32_t *__restrict__ bits,
+                                                 uint32_t *__restrict__ wprefix, uint32_t *__restrict__ act_blk, Counters *cnt,
+                                                 unsigned long long *__restrict__ slots, const uint32_t epoch, const uint32_t bid,
+                                                 const uint32_t nwg, uint32_t *lds /*>= 8*/) {
   const uint32_t nchunks = (P.nbw + 255) / 256;
   uint32_t round = 0;
   while (true) {
-    const uint32_t chunk = next_chunk(round);
+    const uint32_t chunk = next_chunk(round, bid, nwg);
     if (chunk >= nchunks) return;
     const uint32_t w = chunk * 256 + threadIdx.x;
     uint32_t m = 0;
@@ -171,6 +171,13 @@ __global__ __launch_bounds__(256) void k_block_table(Params P, uint8_t *__restri
     }
   }
 }
+__global__ __launch_bounds__(256) void k_block_table(Params P, uint8_t *__restrict__ blk_flag,
+                                                     uint32_t *__restrict__ bits, uint32_t *__restrict__ wprefix,
+                                                     uint32_t *__restrict__ act_blk, Counters *cnt,
+                                                     unsigned long long *__restrict__ slots, uint32_t epoch) {
+  __shared__ uint32_t lds[8];
+  block_table_body(P, blk_flag, bits, wprefix, act_blk, cnt, slots, epoch, blockIdx.x, gridDim.x, lds);
+}
 
 // rank of each particle inside its cell.  Overwrites key[i] with ONE word per slot, (rank << cb) | cidx, where
 // cidx = slot(block)*64 + cell and cb = the bits cidx needs for THIS sort's number of active blocks (packed_cell_bits):
@@ -198,6 +205,11 @@ __device__ __forceinline__ uint32_t packed_cell_bits(const Params &P, uint32_t n
   if (P.test_small_rank) return 29u;  // TEST KNOB: a 3-bit rank field, so that small scenes exercise the side array
   const uint32_t cb = 32u - (uint32_t)__clz((int)(n_active * (uint32_t)BC));
   return cb < 6u ? 6u : cb;
+}
+// bits of the KEY in the packed word of the keyed sort (rank_body<true>, k_perm_keyed): Morton block (3 kbits) << 6 | cell
+__device__ __forceinline__ uint32_t keyed_bits(const Params &P) {
+  if (P.test_small_rank) return 29u;  // TEST KNOB: a 3-bit rank field, so that small scenes exercise the side array
+  return 3u * (uint32_t)P.kbits + 6u;
 }
 struct RunInfo {
   bool head[4];   // element j starts a run of equal cidx inside the wave's tile
@@ -310,26 +322,29 @@ __device__ __forceinline__ void write_neighbour_row(const Params &P, const uint3
   if (lane < 32) nbr[(size_t)a * 32 + lane] = lane < 27 ? nslot : (lane == 27 ? key : (lane == 28 ? m : 0u));
 }
 
-__global__ __launch_bounds__(256) void k_rank(Params P, uint32_t *__restrict__ key, uint32_t *__restrict__ rank,
-                                               uint32_t *__restrict__ cell_cnt, const uint32_t *__restrict__ bits,
-                                               const uint32_t *__restrict__ wprefix, Counters *cnt,
-                                               const uint32_t *__restrict__ act_blk, uint32_t *__restrict__ nbr) {
-  __shared__ uint32_t tkey[RANK_TAB], tcnt[RANK_TAB];
-  __shared__ uint32_t s_heads;
+// KEYED (the two-launch front of the sort, k_sort_front): the cell counters are indexed by the KEY itself (Morton block << 6 | cell:
+// cell_cnt = cellcnt_key[64 NB]), so the ranks need no block table — they are handed out WHILE the block table is built, by the other
+// workgroups of the same launch; the packed word is (rank << kb) | key, kb = 3 kbits + 6, and k_perm_keyed looks the block's slot up.
+template <bool KEYED>
+__device__ __forceinline__ void rank_body(const Params &P, uint32_t *__restrict__ key, uint32_t *__restrict__ rank,
+                                          uint32_t *__restrict__ cell_cnt, const uint32_t *__restrict__ bits,
+                                          const uint32_t *__restrict__ wprefix, Counters *cnt,
+                                          const uint32_t *__restrict__ act_blk, uint32_t *__restrict__ nbr, const uint32_t bid,
+                                          const uint32_t nwg, uint32_t *tkey, uint32_t *tcnt, uint32_t &s_heads) {
   const uint32_t n = P.n_slots;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t mode = cnt->rank_mode;  // uniform over the grid
   if (threadIdx.x == 0) s_heads = 0u;
   uint32_t my_heads = 0u;
-  const uint32_t na = min(cnt->n_active, P.max_blocks);
-  const uint32_t cb = packed_cell_bits(P, na), rmax = (1u << (32u - cb)) - 1u;
+  const uint32_t na = KEYED ? 0u : min(cnt->n_active, P.max_blocks);  // (KEYED: the block table does not exist yet)
+  const uint32_t cb = KEYED ? keyed_bits(P) : packed_cell_bits(P, na), rmax = (1u << (32u - cb)) - 1u;
   // the grid pass's neighbour rows (see above): one active block per wave; the block's key is requested here, the lookups follow
   // behind the batches (one more round trip at the end of a wave instead of two in front of its own loads)
-  const uint32_t row_a = blockIdx.x * 4u + (uint32_t)wave;
+  const uint32_t row_a = bid * 4u + (uint32_t)wave;
   uint32_t row_key = 0;
-  if (nbr && row_a < na) row_key = act_blk[row_a];  // (nbr == nullptr: this ctx's grid pass does not use the list)
+  if (!KEYED && nbr && row_a < na) row_key = act_blk[row_a];  // (nbr == nullptr: this ctx's grid pass does not use the list)
   const uint32_t nbatch = (n + RANK_BATCH - 1) / RANK_BATCH;
-  for (uint32_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
+  for (uint32_t b = bid; b < nbatch; b += nwg) {
     const uint32_t i0 = b * RANK_BATCH + (uint32_t)wave * 256u + 4u * (uint32_t)lane;
     uint32_t k[4] = {INVALID, INVALID, INVALID, INVALID};
     if (i0 + 4u <= n) {
@@ -344,7 +359,9 @@ __global__ __launch_bounds__(256) void k_rank(Params P, uint32_t *__restrict__ k
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       c[j] = INVALID;
-      if (k[j] != INVALID) {
+      if (KEYED) {
+        c[j] = k[j];
+      } else if (k[j] != INVALID) {
         const uint32_t blk = k[j] >> 6;
         if (blk != last_blk) { last_slot = block_slot(bits, wprefix, blk); last_blk = blk; }
         if (last_slot < P.max_blocks) c[j] = last_slot * BC + (k[j] & 63u);
@@ -407,19 +424,46 @@ __global__ __launch_bounds__(256) void k_rank(Params P, uint32_t *__restrict__ k
         if (i0 + j < n) key[i0 + j] = w[j];
     }
   }
-  if (nbr) {
+  if (!KEYED && nbr) {
     if (row_a < na) write_neighbour_row(P, row_a, row_key, (uint32_t)lane, bits, wprefix, nbr);
-    for (uint32_t a = row_a + gridDim.x * 4u; a < na; a += gridDim.x * 4u)  // (more active blocks than waves: tiny particle counts)
+    for (uint32_t a = row_a + nwg * 4u; a < na; a += nwg * 4u)  // (more active blocks than waves: tiny particle counts)
       write_neighbour_row(P, a, act_blk[a], (uint32_t)lane, bits, wprefix, nbr);
   }
   __syncthreads();
-  if ((blockIdx.x & 15u) == 0u) {
+  if ((bid & 15u) == 0u) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) my_heads += __shfl_xor(my_heads, off);
     if (lane == 0 && my_heads) atomicAdd(&s_heads, my_heads);
     __syncthreads();
     if (threadIdx.x == 0 && s_heads) atomicAdd(&cnt->run_heads, s_heads * 16u);
   }
+}
+__global__ __launch_bounds__(256) void k_rank(Params P, uint32_t *__restrict__ key, uint32_t *__restrict__ rank,
+                                               uint32_t *__restrict__ cell_cnt, const uint32_t *__restrict__ bits,
+                                               const uint32_t *__restrict__ wprefix, Counters *cnt,
+                                               const uint32_t *__restrict__ act_blk, uint32_t *__restrict__ nbr) {
+  __shared__ uint32_t tkey[RANK_TAB], tcnt[RANK_TAB];
+  __shared__ uint32_t s_heads;
+  rank_body<false>(P, key, rank, cell_cnt, bits, wprefix, cnt, act_blk, nbr, blockIdx.x, gridDim.x, tkey, tcnt, s_heads);
+}
+
+// The front of the sort as ONE launch (a ctx with key-indexed cell counters: do_sort): the first bt_wgs workgroups build the block
+// table (they are dispatched first, so the chunks a workgroup of the chained scan waits for are resident), all others hand out the
+// in-cell ranks — two jobs that only meet in k_cell_table.  One launch (~6.5 us of latency chain at 1 M particles, 7.3 at 8 M) less,
+// and k_rank without its block-table lookups.
+__global__ __launch_bounds__(256) void k_sort_front(Params P, uint8_t *__restrict__ blk_flag, uint32_t *__restrict__ bits,
+                                                    uint32_t *__restrict__ wprefix, uint32_t *__restrict__ act_blk, Counters *cnt,
+                                                    unsigned long long *__restrict__ slots, uint32_t epoch, uint32_t bt_wgs,
+                                                    uint32_t *__restrict__ key, uint32_t *__restrict__ rank,
+                                                    uint32_t *__restrict__ cellcnt_key) {
+  __shared__ uint32_t tkey[RANK_TAB], tcnt[RANK_TAB];
+  __shared__ uint32_t s_heads;
+  if (blockIdx.x < bt_wgs) {
+    block_table_body(P, blk_flag, bits, wprefix, act_blk, cnt, slots, epoch, blockIdx.x, bt_wgs, tkey);
+    return;
+  }
+  rank_body<true>(P, key, rank, cellcnt_key, nullptr, nullptr, cnt, nullptr, nullptr, blockIdx.x - bt_wgs, gridDim.x - bt_wgs, tkey, tcnt,
+                  s_heads);
 }
 
 // Cell table, one launch: per-cell counts (k_rank) -> act_start[a] (first sorted position of active block a,
@@ -428,16 +472,21 @@ __global__ __launch_bounds__(256) void k_rank(Params P, uint32_t *__restrict__ k
 // [CT_BLOCKS t, CT_BLOCKS (t + 1)): each of the 4 waves takes CT_BLOCKS / 4 of them, one lane per cell.
 //
 // The same scan compacts the owner list of the grid pass (see above k_rank) from the rows' owner masks: its second sum.
-template <int CT_BLOCKS>  // blocks per chunk: 64 for large problems, 16 when there are few blocks (shorter chains,
-                           // more workgroups: 35 -> 31 us of sort at 1 M particles, but 90 -> 100 us at 8 M)
+// KEYED: the counters are indexed by the blocks' KEYS (k_sort_front handed the ranks out before the block table existed), and the
+// neighbour rows are written HERE (k_rank, which writes them otherwise, has no block table in that form): the 27 lookups of a wave's
+// blocks are dealt to its 64 lanes as (block, neighbour) pairs — one round trip, not one per block.
+template <int CT_BLOCKS, bool KEYED>  // blocks per chunk: 64 for large problems, 16 when there are few blocks (shorter chains,
+                                       // more workgroups: 35 -> 31 us of sort at 1 M particles, but 90 -> 100 us at 8 M)
 __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uint32_t *__restrict__ cell_cnt,
                                                     uint32_t *__restrict__ act_start,
                                                     uint32_t *__restrict__ cell_start,
                                                     unsigned long long *__restrict__ slots, uint32_t epoch,
                                                     uint32_t rank_runs_mul, uint32_t *__restrict__ chunk_blk,
-                                                    const uint32_t *__restrict__ nbr, uint32_t *__restrict__ own_list,
-                                                    FillStats *__restrict__ stats) {
+                                                    uint32_t *__restrict__ nbr, uint32_t *__restrict__ own_list,
+                                                    FillStats *__restrict__ stats, const uint32_t *__restrict__ act_blk,
+                                                    const uint32_t *__restrict__ bits, const uint32_t *__restrict__ wprefix) {
   __shared__ unsigned long long lds[8];
+  __shared__ uint32_t amask_s[CT_BLOCKS];
   constexpr int CT_BPW = CT_BLOCKS / 4;  // blocks per wave
   __shared__ uint32_t blk_tot[CT_BLOCKS], blk_cnt[CT_BLOCKS], own_tot[CT_BLOCKS], own_mask[CT_BLOCKS];
   // exclusive in-block prefix of every cell of the chunk's blocks, parked in LDS between the two halves of a chunk (in registers
@@ -455,9 +504,51 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
     const uint32_t chunk = next_chunk(round);
     const uint32_t a0 = chunk * CT_BLOCKS;
     if (a0 >= na && !(na == 0 && chunk == 0)) return;
-    if (lane < CT_BPW) {  // owner masks of the wave's blocks (k_rank wrote the rows): one lane per block
+    uint32_t mykey = 0;  // lane i < CT_BPW: the key of the wave's i-th block (KEYED)
+    if constexpr (KEYED) {
+      if (lane < CT_BPW && a0 + wave * CT_BPW + lane < na) mykey = act_blk[a0 + wave * CT_BPW + lane];
+      if (nbr) {  // neighbour rows + owner masks of the wave's blocks: (block, neighbour) pairs dealt to the lanes
+        if (lane < CT_BPW) amask_s[wave * CT_BPW + lane] = 0u;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < (27 * CT_BPW + 63) / 64; q++) {
+          const uint32_t pair = (uint32_t)q * 64u + lane, i = pair / 27u, nb = pair - 27u * i;
+          const uint32_t a = a0 + wave * CT_BPW + i;
+          const uint32_t bkey = __shfl(mykey, (int)(i < (uint32_t)CT_BPW ? i : 0u));
+          if (i < (uint32_t)CT_BPW && a < na) {
+            int bx, by, bz;
+            demorton3(bkey, bx, by, bz);
+            const int sx = bx + (int)nb / 9 - 1, sy = by + ((int)nb / 3) % 3 - 1, sz = bz + (int)nb % 3 - 1;
+            uint32_t nslot = INVALID;
+            if (sx >= 0 && sy >= 0 && sz >= 0) {
+              const uint32_t bk = morton3(sx, sy, sz);
+              if (bk < P.nbw * 32u && block_active(bits, bk)) {
+                const uint32_t ns = block_slot(bits, wprefix, bk);
+                if (ns < P.max_blocks) nslot = ns;  // (a slot beyond max_blocks has no tile: the sticky capacity error is set)
+              }
+            }
+            nbr[(size_t)a * 32 + nb] = nslot;
+            if (nslot != INVALID) atomicOr(&amask_s[wave * CT_BPW + i], 1u << nb);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (lane < CT_BPW) {  // owner masks of the wave's blocks: one lane per block
       const uint32_t a = a0 + wave * CT_BPW + lane;
-      const uint32_t m = (nbr && a < na) ? nbr[(size_t)a * 32 + 28] : 0u;
+      uint32_t m = 0u;
+      if (nbr && a < na) {
+        if constexpr (KEYED) {
+          const uint32_t amask = amask_s[wave * CT_BPW + lane];
+#pragma unroll
+          for (int o = 0; o < 8; o++)
+            if (!(amask & lower_sources(o))) m |= 1u << o;
+          nbr[(size_t)a * 32 + 27] = mykey;
+          nbr[(size_t)a * 32 + 28] = m;
+        } else {
+          m = nbr[(size_t)a * 32 + 28];  // (k_rank wrote the row)
+        }
+      }
       own_mask[wave * CT_BPW + lane] = m;
       own_tot[wave * CT_BPW + lane] = (uint32_t)__popc(m);
     }
@@ -466,8 +557,9 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
       const uint32_t a = a0 + wave * CT_BPW + i;
       uint32_t c = 0;
       if (a < na) {
-        c = cell_cnt[(size_t)a * BC + lane];
-        cell_cnt[(size_t)a * BC + lane] = 0;
+        const size_t row = KEYED ? (size_t)__shfl(mykey, i) * BC : (size_t)a * BC;
+        c = cell_cnt[row + lane];
+        cell_cnt[row + lane] = 0;
       }
       uint32_t v = c;
 #pragma unroll
@@ -518,13 +610,13 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
 
 // The cell table WITHOUT the owner list (an untiled ctx of 2 M slots and more: mpmhip.hip: do_sort), as it was until round 4: the
 // second sum of the scan, the masks and the LDS-parked prefixes cost 2 us at 8 M particles that this configuration does not get back.
-template <int CT_BLOCKS>
+template <int CT_BLOCKS, bool KEYED>
 __global__ __launch_bounds__(256) void k_cell_table_plain(Params P, Counters *cnt, uint32_t *__restrict__ cell_cnt,
                                                     uint32_t *__restrict__ act_start,
                                                     uint32_t *__restrict__ cell_start,
                                                     unsigned long long *__restrict__ slots, uint32_t epoch,
                                                     uint32_t rank_runs_mul, uint32_t *__restrict__ chunk_blk,
-                                                          FillStats *__restrict__ stats) {
+                                                          FillStats *__restrict__ stats, const uint32_t *__restrict__ act_blk) {
   __shared__ uint32_t lds[8];
   constexpr int CT_BPW = CT_BLOCKS / 4;  // blocks per wave
   __shared__ uint32_t blk_tot[CT_BLOCKS];
@@ -542,13 +634,18 @@ __global__ __launch_bounds__(256) void k_cell_table_plain(Params P, Counters *cn
     if (a0 >= na && !(na == 0 && chunk == 0)) return;
     uint32_t excl[CT_BPW];  // exclusive in-block prefix of this lane's cell, for the wave's blocks
     uint32_t tot[CT_BPW];   // (lane 63: the block's particle count)
+    uint32_t mykey = 0;     // KEYED (counters indexed by the blocks' keys, see k_cell_table): lane i < CT_BPW holds the i-th block's
+    if constexpr (KEYED) {
+      if (lane < CT_BPW && a0 + wave * CT_BPW + lane < na) mykey = act_blk[a0 + wave * CT_BPW + lane];
+    }
 #pragma unroll
     for (int i = 0; i < CT_BPW; i++) {
       const uint32_t a = a0 + wave * CT_BPW + i;
       uint32_t c = 0;
       if (a < na) {
-        c = cell_cnt[(size_t)a * BC + lane];
-        cell_cnt[(size_t)a * BC + lane] = 0;
+        const size_t row = KEYED ? (size_t)__shfl(mykey, i) * BC : (size_t)a * BC;
+        c = cell_cnt[row + lane];
+        cell_cnt[row + lane] = 0;
       }
       uint32_t v = c;
 #pragma unroll
@@ -607,6 +704,25 @@ __global__ __launch_bounds__(256) void k_perm(Params P, const Counters *__restri
     uint32_t r = w >> cb;
     if (r == rmax) r = rank[i];
     perm[cell_start[w & cmask] + r] = i;
+  }
+}
+
+// the same from the packed words of the keyed sort (k_sort_front): (rank << kb) | key, the block's slot looked up here (consecutive
+// slots nearly always share the block: the two table words come from the cache)
+__global__ __launch_bounds__(256) void k_perm_keyed(Params P, const Counters *__restrict__ cnt,
+                                                    const uint32_t *__restrict__ key, const uint32_t *__restrict__ rank,
+                                                    const uint32_t *__restrict__ cell_start, uint32_t *__restrict__ perm,
+                                                    const uint32_t *__restrict__ bits, const uint32_t *__restrict__ wprefix) {
+  const uint32_t n = P.n_slots;
+  const uint32_t kb = keyed_bits(P), rmax = (1u << (32u - kb)) - 1u, kmask = (1u << kb) - 1u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t w = key[i];
+    if (w == INVALID) continue;
+    const uint32_t k = w & kmask;
+    uint32_t r = w >> kb;
+    if (r == rmax) r = rank[i];
+    const uint32_t slot = block_slot(bits, wprefix, k >> 6);
+    if (slot < P.max_blocks) perm[cell_start[(size_t)slot * BC + (k & 63u)] + r] = i;
   }
 }
 

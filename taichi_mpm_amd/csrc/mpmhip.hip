@@ -56,6 +56,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -112,6 +113,8 @@ struct mpmhip_ctx {
   uint8_t *blk_flag = nullptr;
   uint32_t *bits = nullptr, *wprefix = nullptr, *act_blk = nullptr, *act_start = nullptr;
   uint32_t *cell_cnt = nullptr, *cell_start = nullptr, *fat_slot = nullptr;
+  bool sort_keyed = false;
+  uint32_t *cellcnt_key = nullptr;  // [64 NB] cell counters indexed by KEY (Morton block << 6 | cell): the two-launch front of the sort (do_sort); nullptr on grids beyond 2^21 blocks
   uint32_t *nbr = nullptr, *own_list = nullptr;  // k_cell_table -> k_grid: 32-word neighbour row per active block, list of owned (block, candidate) pairs
   FillStats *d_stats = nullptr;  // device address of the pinned page's statistics words (h_pinned + FILL_STATS_WORD): k_cell_table stores there
   int grid_walk = -1;            // walk of the substep's grid pass (k_grid.h): 2 owner list, 0 per block / per (block, candidate) as until round 4,
@@ -120,7 +123,10 @@ struct mpmhip_ctx {
   int grid_wgs = 0;              // workgroups of the grid pass; 0: from the last sort's owner count (env MPMHIP_GRID_WGS)
   unsigned long long *scan_slots = nullptr;  // [256] k_block_table + [ct_grid] k_cell_table: {epoch, chunk sum}
   uint32_t sort_epoch = 0, bt_slots = 0, ct_slots = 0;  // scan_slots: [bt_slots] k_block_table | [ct_slots] k_cell_table_plain | [ct_slots] k_cell_table
-  uint32_t scan_grid = 256;  // workgroups of the single-pass scan kernels: three eighths of what the device keeps resident
+  uint32_t scan_grid = 256;  // workgroups of the single-pass scan kernels: three eighths of what the device keeps resident (the lowest
+                             // of the plain kernels; scan_limit() answers per kernel)
+  std::map<const void *, uint32_t> scan_limits;  // kernel -> three eighths of its resident workgroups
+  int scan_grid_env = 0;
   float4 *tiles = nullptr, *gridv = nullptr, *dense = nullptr;
   Counters *cnt = nullptr;
   std::vector<GroupParams> groups;
@@ -524,6 +530,10 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(dmalloc(&c->act_start, (size_t)mb + 2));
   A(dmalloc(&c->cell_cnt, (size_t)mb * BC));
   A(dmalloc(&c->cell_start, (size_t)mb * BC + 1));
+  // key-indexed cell counters (256 B per block of the WHOLE block space: 67 MB at 128^3, 537 MB at 256^3..508^3): with them the ranks
+  // need no block table and share a launch with it (k_sort_front); grids of 2^24 blocks (res > 508) keep the four-launch sort
+  const int sort_v1 = getenv("MPMHIP_SORT_V1") ? atoi(getenv("MPMHIP_SORT_V1")) : 0;  // (A/B: 1 four launches, no table; 2 four launches, table allocated)
+  c->sort_keyed = c->NB <= (1u << 21) && sort_v1 == 0;  // (the table itself is allocated behind every other buffer, below)
   A(dmalloc(&c->nbr, (size_t)mb * 32));
   A(dmalloc(&c->own_list, (size_t)mb * 8));
   c->bt_slots = (P.nbw + 255) / 256;
@@ -543,6 +553,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
     if (getenv("MPMHIP_NO_STATS_STORE") && atoi(getenv("MPMHIP_NO_STATS_STORE"))) c->d_stats = nullptr;  // (A/B: the round-4 copy instead)
   }
   A(dmalloc(&c->d_groups, (size_t)c->groups_cap));
+  if (c->NB <= (1u << 21) && sort_v1 != 1) A(dmalloc(&c->cellcnt_key, (size_t)c->NB * BC));
   if (e != hipSuccess) {
     fail(c, MPMHIP_ENOMEM, "device allocation failed: %s (max_particles=%lld, max_blocks=%lld)", hipGetErrorString(e),
          (long long)c->cap, (long long)mb);
@@ -551,6 +562,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(hipMemset(c->bits, 0, sizeof(uint32_t) * P.nbw));
   A(hipMemset(c->blk_flag, 0, (size_t)P.nbw * 32));
   A(hipMemset(c->cell_cnt, 0, sizeof(uint32_t) * (size_t)mb * BC));
+  if (c->cellcnt_key) A(hipMemset(c->cellcnt_key, 0, sizeof(uint32_t) * (size_t)c->NB * BC));
   A(hipMemset(c->cell_start, 0, sizeof(uint32_t) * ((size_t)mb * BC + 1)));
   A(hipMemset(c->act_start, 0, sizeof(uint32_t) * ((size_t)mb + 2)));
   A(hipMemset(c->cnt, 0, sizeof(Counters)));
@@ -559,20 +571,10 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(hipMemset(c->fat_slot, 0, sizeof(uint32_t) * (size_t)c->NB));
   A(hipMemset(c->rb, 0, sizeof(float) * (size_t)c->cap * BW));
   {  // the single-pass scans spin on their predecessors: their grids must fit on the device all at once (k_sort.h)
-    int cus = 0, per_cu = 0, lowest = 1 << 20;
+    int cus = 0;
     A(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
     if (cus > 0) c->n_cus = cus;
-    const void *scans[7] = {(const void *)k_block_table, (const void *)k_cell_table<16>, (const void *)k_cell_table<32>, (const void *)k_cell_table<64>,
-                            (const void *)k_cell_table_plain<16>, (const void *)k_cell_table_plain<32>, (const void *)k_cell_table_plain<64>};
-    for (const void *k : scans) {
-      A(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, 0));
-      lowest = std::min(lowest, per_cu);
-    }
-    // three eighths of what the device keeps resident (a quarter until round 4): after impact C3 has 21 k active blocks = 335 chunks of
-    // k_cell_table, and with 256 workgroups 79 of them took a second chunk behind their first — sort 98 -> 88 us, 80 -> 70 us on the
-    // lattice of the same box (profiles/r04_l_scan_grid.txt); the margin is for kernels of a second stream (CPIC) beside the scans
-    c->scan_grid = (uint32_t)std::max(1, cus * lowest * 3 / 8);
-    if (const char *e = getenv("MPMHIP_SCAN_GRID")) c->scan_grid = (uint32_t)std::max(1, std::min(atoi(e), cus * lowest / 2));  // (tuning)
+    if (const char *e = getenv("MPMHIP_SCAN_GRID")) c->scan_grid_env = atoi(e);  // (tuning)
   }
   A(hipDeviceSynchronize());
   if (e != hipSuccess) { fail(c, MPMHIP_EHIP, "device init failed: %s", hipGetErrorString(e)); return bail(MPMHIP_EHIP); }
@@ -589,7 +591,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   hipFree(c->rg); hipFree(c->rp); hipFree(c->rb); hipFree(c->rg2); hipFree(c->rp2); hipFree(c->rb2);
   hipFree(c->key); hipFree(c->rank); hipFree(c->perm); hipFree(c->chunk_blk); hipFree(c->blk_flag); hipFree(c->bits); hipFree(c->wprefix);
   hipFree(c->fat_slot); hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->cell_cnt);
-  hipFree(c->cell_start); hipFree(c->nbr); hipFree(c->own_list); hipFree(c->scan_slots); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
+  hipFree(c->cell_start); hipFree(c->cellcnt_key); hipFree(c->nbr); hipFree(c->own_list); hipFree(c->scan_slots); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
   hipFree(c->async.d_tab); hipFree(c->async.d_blk_of); hipFree(c->async.d_blk_limits); hipFree(c->async.d_particle_limits);
   if (c->async.h_tab) hipHostFree(c->async.h_tab);
   if (c->async.store.h_tbl_pin) hipHostFree(c->async.store.h_tbl_pin);
@@ -944,6 +946,22 @@ int mpmhip_upload(mpmhip_ctx *c, int32_t field, const void *src, int64_t n) {
 static int do_reorder(mpmhip_ctx *c);
 
 static inline bool rigid_active(const mpmhip_ctx *c);
+// workgroups a single-pass scan kernel may be launched with: three eighths of what the device keeps resident of THAT kernel (a
+// quarter until round 4: after impact C3 has 21 k active blocks = 335 chunks of k_cell_table, and with 256 workgroups 79 of them
+// took a second chunk behind their first — sort 98 -> 88 us, profiles/r04_l_scan_grid.txt); the margin is for kernels of a second
+// stream (CPIC) beside the scans.  Per kernel since round 5: the list forms of k_cell_table hold fewer workgroups per CU than the
+// plain ones, and the lowest of all of them would cost the plain ones their grid.
+static uint32_t scan_limit(mpmhip_ctx *c, const void *kernel) {
+  const void *key = kernel;
+  auto it = c->scan_limits.find(key);
+  if (it != c->scan_limits.end()) return it->second;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  uint32_t lim = (uint32_t)std::max(1, c->n_cus * per_cu * 3 / 8);
+  if (c->scan_grid_env > 0) lim = (uint32_t)std::max(1, std::min(c->scan_grid_env, c->n_cus * per_cu / 2));
+  c->scan_limits[key] = lim;
+  return lim;
+}
 static int do_sort(mpmhip_ctx *c) {
   Params &P = c->P;
   hipStream_t st = c->stream;
@@ -965,21 +983,37 @@ static int do_sort(mpmhip_ctx *c) {
   uint32_t epoch = ++c->sort_epoch;
   if ((epoch & 0x7FFFFFu) == 0u) epoch = ++c->sort_epoch;  // (k_cell_table's scan words keep 23 bits of it; 0 = never published)
   // (single-pass scans: never more workgroups than are resident at once, see k_sort.h)
-  hipLaunchKernelGGL(k_block_table, dim3(std::min(bt_chunks, c->scan_grid)), dim3(256), 0, st, P, c->blk_flag, c->bits,
-                     c->wprefix, c->act_blk, c->cnt, c->scan_slots, epoch);
-  const uint32_t rank_wgs = std::min<uint32_t>((P.n_slots + RANK_BATCH - 1) / RANK_BATCH, 8192u);
-  hipLaunchKernelGGL(k_rank, dim3(std::max(rank_wgs, 1u)), dim3(256), 0, st, P, c->key, c->rank, c->cell_cnt, c->bits, c->wprefix,
-                     c->cnt, (const uint32_t *)c->act_blk, nbr);
+  const uint32_t rank_wgs = std::max(1u, std::min<uint32_t>((P.n_slots + RANK_BATCH - 1) / RANK_BATCH, 8192u));
+  const bool keyed = c->sort_keyed && c->cellcnt_key != nullptr;
+  const uint32_t bt_wgs = std::min(bt_chunks, keyed ? scan_limit(c, (const void *)k_sort_front) : scan_limit(c, (const void *)k_block_table));
+  if (keyed) {
+    // block table and in-cell ranks in ONE launch (k_sort_front): the ranks count into key-indexed counters and need no table
+    hipLaunchKernelGGL(k_sort_front, dim3(bt_wgs + rank_wgs), dim3(256), 0, st, P, c->blk_flag, c->bits, c->wprefix, c->act_blk, c->cnt,
+                       c->scan_slots, epoch, bt_wgs, c->key, c->rank, c->cellcnt_key);
+  } else {
+    hipLaunchKernelGGL(k_block_table, dim3(bt_wgs), dim3(256), 0, st, P, c->blk_flag, c->bits, c->wprefix, c->act_blk, c->cnt, c->scan_slots, epoch);
+    hipLaunchKernelGGL(k_rank, dim3(rank_wgs), dim3(256), 0, st, P, c->key, c->rank, c->cell_cnt, c->bits, c->wprefix,
+                       c->cnt, (const uint32_t *)c->act_blk, nbr);
+  }
+  uint32_t *const counters = keyed ? c->cellcnt_key : c->cell_cnt;
+#define MPM_CT(K, CT) (keyed ? K<CT, true> : K<CT, false>)
+  auto ct_list = ct == 16 ? MPM_CT(k_cell_table, 16) : (ct == 32 ? MPM_CT(k_cell_table, 32) : MPM_CT(k_cell_table, 64));
+  auto ct_plain = ct == 16 ? MPM_CT(k_cell_table_plain, 16) : (ct == 32 ? MPM_CT(k_cell_table_plain, 32) : MPM_CT(k_cell_table_plain, 64));
+  const uint32_t ct_wgs = std::min(ct_chunks, c->list_valid ? scan_limit(c, (const void *)ct_list) : scan_limit(c, (const void *)ct_plain));
   if (c->list_valid)  // (the two forms publish different scan words: each has its own slots)
-    hipLaunchKernelGGL(ct == 16 ? k_cell_table<16> : (ct == 32 ? k_cell_table<32> : k_cell_table<64>), dim3(std::min(ct_chunks, c->scan_grid)), dim3(256), 0, st, P,
-                       c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots + c->ct_slots, epoch, c->rank_runs_mul,
-                       c->chunk_blk, (const uint32_t *)nbr, c->own_list, c->d_stats);
+    hipLaunchKernelGGL(ct_list, dim3(ct_wgs), dim3(256), 0, st, P,
+                       c->cnt, counters, c->act_start, c->cell_start, c->scan_slots + c->bt_slots + c->ct_slots, epoch, c->rank_runs_mul,
+                       c->chunk_blk, nbr, c->own_list, c->d_stats, (const uint32_t *)c->act_blk, (const uint32_t *)c->bits, (const uint32_t *)c->wprefix);
   else
-    hipLaunchKernelGGL(ct == 16 ? k_cell_table_plain<16> : (ct == 32 ? k_cell_table_plain<32> : k_cell_table_plain<64>),
-                       dim3(std::min(ct_chunks, c->scan_grid)), dim3(256), 0, st, P,
-                       c->cnt, c->cell_cnt, c->act_start, c->cell_start, c->scan_slots + c->bt_slots, epoch, c->rank_runs_mul, c->chunk_blk,
-                       c->d_stats);
-  hipLaunchKernelGGL(k_perm, dim3(pg), dim3(256), 0, st, P, (const Counters *)c->cnt, c->key, c->rank, c->cell_start, c->perm);
+    hipLaunchKernelGGL(ct_plain, dim3(ct_wgs), dim3(256), 0, st, P,
+                       c->cnt, counters, c->act_start, c->cell_start, c->scan_slots + c->bt_slots, epoch, c->rank_runs_mul, c->chunk_blk,
+                       c->d_stats, (const uint32_t *)c->act_blk);
+#undef MPM_CT
+  if (keyed)
+    hipLaunchKernelGGL(k_perm_keyed, dim3(pg), dim3(256), 0, st, P, (const Counters *)c->cnt, c->key, c->rank, c->cell_start, c->perm,
+                       (const uint32_t *)c->bits, (const uint32_t *)c->wprefix);
+  else
+    hipLaunchKernelGGL(k_perm, dim3(pg), dim3(256), 0, st, P, (const Counters *)c->cnt, c->key, c->rank, c->cell_start, c->perm);
   // (k_cell_table's last chunk stores (live particles, active blocks, owner entries) of this sort straight into the pinned page,
   // never waited for: the host picks the G2P walk by how full the blocks are (g2p_is_packed) and sizes the grid pass's launch
   // from numbers that may be a few substeps old — until round 5 a hipMemcpyAsync every 16th sort, i.e. a blit kernel in the loop)
