@@ -1,0 +1,39 @@
+#!/bin/bash
+# round 5, step n: k_g2p hands the in-cell ranks of the next sort out (MPMHIP_G2P_RANKS=0: the sort front does, as in step l):
+# GPU suite, then A/B on C2 / C3 (both states; after impact also the packed walk forced) / 2, 4, 8 virtual ranks, census
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
+cd $R
+timeout 1800 python -m pytest tests -m gpu -q -x > $O/r05_n_pytest.log 2>&1; echo "pytest rc=$?" >> $O/r05_n_pytest.log
+tail -4 $O/r05_n_pytest.log
+line() { grep '^{' | tail -1; }
+for rep in 1 2; do
+for V in ranks front packed; do
+  case $V in ranks) E="X=1";; front) E="MPMHIP_G2P_RANKS=0";; packed) E="MPMHIP_G2P_PACKED=1";; esac
+  env $E python bench.py --config c3 --steps 30 --warmup 8 --no-cpu-baseline 2>/dev/null | line > $O/r05_n_c3_${V}_$rep.json
+  [ $V = packed ] && continue
+  env $E python bench.py --config c2 --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | line > $O/r05_n_c2_${V}_$rep.json
+  for K in 2 4 8; do
+    env $E MPMHIP_TILE_OVERLAP=0 python bench.py --virtual $K --steps 24 --warmup 8 2>/dev/null | line > $O/r05_n_v${K}_${V}_$rep.json
+  done
+done
+done
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_c3 -o t -- python $R/bench.py --config c3 --steps 20 --warmup 5 --no-cpu-baseline --no-evolved > $O/r05_n_c3_trace.log 2>&1
+python $R/profiles/loop_census.py /tmp/tr_c3/t_kernel_trace.csv 12 > $O/r05_n_c3_census.txt 2>&1
+cd $R; bash profiles/evolved_trace.sh r05_n_ev > /dev/null
+python - <<'P'
+import json, glob, os
+O = os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out"
+r = lambda p: {k: round(v * 1e3, 1) for k, v in p.items()}
+for f in sorted(glob.glob(O + "/r05_n_*_[12].json")):
+    try:
+        d = json.load(open(f))
+    except Exception as e:
+        print(os.path.basename(f), "unreadable", e); continue
+    if "K" in d:
+        print("%-26s per rank %.4f ms %s" % (os.path.basename(f), d["per_rank_ms_serial_no_events"], r(d["rank0_phases_ms"])))
+    else:
+        ev = d.get("evolved") or {}
+        print("%-26s %.4f %s | evolved %.4f %s %s" % (os.path.basename(f), d["ms_per_step"], r(d["phases_ms_per_step"]), ev.get("ms_per_step", 0), r(ev.get("phases_ms_per_step", {})), (ev.get("roofline") or {}).get("kernel")))
+P
+grep -v "^#" $O/r05_n_c3_census.txt; grep -v "stream_copy\|k_affine\|build_keys\|gather_records" $O/r05_n_ev_last_calls.txt | head -9
