@@ -722,7 +722,12 @@ __global__ __launch_bounds__(256) void k_perm_keyed(Params P, const Counters *__
     uint32_t r = w >> kb;
     if (r == rmax) r = rank[i];
     const uint32_t slot = block_slot(bits, wprefix, k >> 6);
-    if (slot < P.max_blocks) perm[cell_start[(size_t)slot * BC + (k & 63u)] + r] = i;
+    if (slot >= P.max_blocks) continue;
+    // (pos < n always holds on a healthy ctx.  After a block-table overflow — sticky error bit 1, the ctx is to be recreated — the
+    // key-indexed counters of the blocks that found no slot are never zeroed, so a caller that keeps stepping would get inflated ranks
+    // there: the bound keeps such a ctx inside its arrays)
+    const uint32_t pos = cell_start[(size_t)slot * BC + (k & 63u)] + r;
+    if (pos < n) perm[pos] = i;
   }
 }
 

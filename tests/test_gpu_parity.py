@@ -184,6 +184,42 @@ def test_crowded_cells_take_the_side_array_of_the_sort(tm, orc, monkeypatch):
     monkeypatch.delenv("MPMHIP_TEST_SMALL_RANK")
 
 
+def test_every_form_of_the_sort_gives_the_same_substep(tm, monkeypatch):
+    """The library picks the sort's launches by size and grid: k_sort_front + k_cell_table<.., keyed> + k_perm_keyed where the key-indexed
+    counters exist (res <= 508), the four launches otherwise (MPMHIP_SORT_V1=1 forces them); 16 / 32 / 64 blocks per chunk of the cell
+    table; with the owner list of the grid pass (k_cell_table + k_grid_list) or without (k_cell_table_plain + k_grid_blocks).  All twelve
+    combinations on one scene (dense runs + spray + leavers, so dead slots and short runs occur) must agree with the default."""
+    rng = np.random.default_rng(41)
+    dense = lattice_cube(RES, 8, 14, DX, jitter=0.2, seed=40)
+    spray = (rng.uniform(6.0, 26.0, (2500, 3)) * DX).astype(np.float32)
+    x = np.concatenate([dense, spray])
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = make_state(x, "jelly", DX, perturb_F=0.02, seed=42)
+        s.v[-30:] = (0.0, 0.0, 500.0)  # leave through the wall: their slots drop out of the live range
+        sim = make_sim(tm, s)
+        for _ in range(4):
+            sim.substep()
+        got = sim.get_particles()
+        sim.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return got
+
+    ref = run({})
+    assert len(ref["id"]) < len(x)
+    for v1 in ("0", "1"):
+        for walk in ("2", "0"):
+            for ct in ("16", "32", "64"):
+                got = run({"MPMHIP_SORT_V1": v1, "MPMHIP_GRID_WALK": walk, "MPMHIP_CT_BLOCKS": ct})
+                assert np.array_equal(got["id"], ref["id"]), (v1, walk, ct)
+                for f in ("x", "v", "F"):
+                    # (same sums in a different order inside a cell: ranks are handed out by atomics)
+                    assert np.allclose(got[f], ref[f], rtol=0, atol=2e-6 * max(1.0, float(np.abs(ref[f]).max()))), (v1, walk, ct, f)
+
+
 def test_packed_g2p_walk_equals_the_per_block_walk(tm, monkeypatch):
     """k_g2p_packed (chunks of 256 consecutive sorted positions, whatever blocks they belong to: csrc/k_g2p_packed.h) against k_g2p on the
     same scene: a dense cube (chunks inside one block, tiles reused along a run), spray (a chunk touches more blocks than the
@@ -529,6 +565,27 @@ def test_edge_cases_empty_single_ragged_and_capacity(tm, orc):
     assert sim2._L.mpmhip_add_group(sim2._ctx, 9, rag.gparams[0].ctypes.data_as(fp)) == -1  # unknown material id
     assert sim2._L.mpmhip_p2g(sim2._ctx) == -1  # needs a sort first
     sim2.close()
+
+
+def test_a_block_table_overflow_is_reported_and_leaves_the_ctx_inside_its_arrays(tm, monkeypatch):
+    """More active blocks than max_blocks: sticky error bit 1, reported at the next synchronising call as ECAPACITY — also when the
+    caller keeps stepping first.  In both forms of the sort: with key-indexed counters the blocks that found no slot keep their
+    counts (nobody walks their rows), which must not carry a later sort's permutation outside its array (k_perm_keyed's bound)."""
+    rng = np.random.default_rng(61)
+    x = (rng.uniform(4.0, RES - 4.0, (6000, 3)) * DX).astype(np.float32)  # ~350 blocks of the 512 the grid has
+    for v1 in ("0", "1"):
+        monkeypatch.setenv("MPMHIP_SORT_V1", v1)
+        s = make_state(x, "jelly", DX)
+        sim = tm.create_simulation3("mpm").initialize(dict(res=(RES,) * 3, delta_x=DX, base_delta_t=DT, max_particles=8192, max_blocks=64))
+        sim.add_particles(dict(type="jelly", positions=s.x, velocities=s.v, F=s.F, params=s.gparams[0]))
+        L, ctx = sim._L, sim._ctx
+        for _ in range(6):  # (asynchronous: nothing looks at the error word in between)
+            assert L.mpmhip_substep(ctx) == 0
+        rc = L.mpmhip_synchronize(ctx)
+        msg = L.mpmhip_last_error(ctx)
+        assert rc == -4 and b"exceed max_blocks" in msg, (v1, rc, msg)
+        sim.close()
+    monkeypatch.delenv("MPMHIP_SORT_V1")
 
 
 def test_particles_leaving_the_domain_are_deleted_like_the_reference(tm, orc):
