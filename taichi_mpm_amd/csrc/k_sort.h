@@ -344,9 +344,11 @@ __device__ __forceinline__ void rank_body(const Params &P, uint32_t *__restrict_
   uint32_t row_key = 0;
   if (!KEYED && nbr && row_a < na) row_key = act_blk[row_a];  // (nbr == nullptr: this ctx's grid pass does not use the list)
   const uint32_t nbatch = (n + RANK_BATCH - 1) / RANK_BATCH;
-  for (uint32_t b = bid; b < nbatch; b += nwg) {
+  // the keys of a workgroup's NEXT batch are requested before the atomics of this one are waited for (a launch with fewer workgroups
+  // than batches: do_sort)
+  auto load_keys = [&](uint32_t b, uint32_t (&k)[4]) {
     const uint32_t i0 = b * RANK_BATCH + (uint32_t)wave * 256u + 4u * (uint32_t)lane;
-    uint32_t k[4] = {INVALID, INVALID, INVALID, INVALID};
+    k[0] = INVALID; k[1] = INVALID; k[2] = INVALID; k[3] = INVALID;
     if (i0 + 4u <= n) {
       const uint4 kk = *reinterpret_cast<const uint4 *>(key + i0);
       k[0] = kk.x; k[1] = kk.y; k[2] = kk.z; k[3] = kk.w;
@@ -354,6 +356,13 @@ __device__ __forceinline__ void rank_body(const Params &P, uint32_t *__restrict_
 #pragma unroll
       for (int j = 0; j < 4; j++) if (i0 + j < n) k[j] = key[i0 + j];
     }
+  };
+  uint32_t kn[4] = {INVALID, INVALID, INVALID, INVALID};
+  if (bid < nbatch) load_keys(bid, kn);
+  for (uint32_t b = bid; b < nbatch; b += nwg) {
+    const uint32_t i0 = b * RANK_BATCH + (uint32_t)wave * 256u + 4u * (uint32_t)lane;
+    uint32_t k[4] = {kn[0], kn[1], kn[2], kn[3]};
+    if (b + nwg < nbatch) load_keys(b + nwg, kn);
     uint32_t c[4];
     uint32_t last_blk = INVALID, last_slot = INVALID;
 #pragma unroll
@@ -503,10 +512,12 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
   while (true) {
     const uint32_t chunk = next_chunk(round);
     const uint32_t a0 = chunk * CT_BLOCKS;
-    if (a0 >= na && !(na == 0 && chunk == 0)) return;
-    uint32_t mykey = 0;  // lane i < CT_BPW: the key of the wave's i-th block (KEYED)
+    uint32_t mykey = 0;  // lane i < CT_BPW: the key of the wave's i-th block (KEYED; requested before the block count is looked at)
     if constexpr (KEYED) {
-      if (lane < CT_BPW && a0 + wave * CT_BPW + lane < na) mykey = act_blk[a0 + wave * CT_BPW + lane];
+      if (lane < CT_BPW && a0 + wave * CT_BPW + lane < P.max_blocks) mykey = act_blk[a0 + wave * CT_BPW + lane];
+    }
+    if (a0 >= na && !(na == 0 && chunk == 0)) return;
+    if constexpr (KEYED) {
       if (nbr) {  // neighbour rows + owner masks of the wave's blocks: (block, neighbour) pairs dealt to the lanes
         if (lane < CT_BPW) amask_s[wave * CT_BPW + lane] = 0u;
         __builtin_amdgcn_wave_barrier();
@@ -631,13 +642,14 @@ __global__ __launch_bounds__(256) void k_cell_table_plain(Params P, Counters *cn
   while (true) {
     const uint32_t chunk = next_chunk(round);
     const uint32_t a0 = chunk * CT_BLOCKS;
+    uint32_t mykey = 0;     // KEYED (counters indexed by the blocks' keys, see k_cell_table): lane i < CT_BPW holds the i-th block's
+    if constexpr (KEYED) {  // (requested before the block count is looked at: one round trip less in front of the counters; entries
+                            // beyond the count are stale and never used)
+      if (lane < CT_BPW && a0 + wave * CT_BPW + lane < P.max_blocks) mykey = act_blk[a0 + wave * CT_BPW + lane];
+    }
     if (a0 >= na && !(na == 0 && chunk == 0)) return;
     uint32_t excl[CT_BPW];  // exclusive in-block prefix of this lane's cell, for the wave's blocks
     uint32_t tot[CT_BPW];   // (lane 63: the block's particle count)
-    uint32_t mykey = 0;     // KEYED (counters indexed by the blocks' keys, see k_cell_table): lane i < CT_BPW holds the i-th block's
-    if constexpr (KEYED) {
-      if (lane < CT_BPW && a0 + wave * CT_BPW + lane < na) mykey = act_blk[a0 + wave * CT_BPW + lane];
-    }
 #pragma unroll
     for (int i = 0; i < CT_BPW; i++) {
       const uint32_t a = a0 + wave * CT_BPW + i;
@@ -690,20 +702,34 @@ __global__ __launch_bounds__(256) void k_cell_table_plain(Params P, Counters *cn
 }
 
 // sorted position -> particle slot (the reference's sorted `particles` index vector, src/mpm.cpp:800-807) from the
-// packed words of k_rank.  (Four slots per thread as in k_rank were measured slower here: the scattered 4-byte stores
-// dominate, and one slot per lane keeps them coalesced.)
+// packed words of k_rank.  (Four CONSECUTIVE slots per thread as in k_rank were measured slower here: the scattered 4-byte stores
+// dominate, and one slot per lane and instruction keeps them coalesced.)
 __global__ __launch_bounds__(256) void k_perm(Params P, const Counters *__restrict__ cnt,
                                               const uint32_t *__restrict__ key, const uint32_t *__restrict__ rank,
                                               const uint32_t *__restrict__ cell_start, uint32_t *__restrict__ perm) {
   const uint32_t n = P.n_slots;
   const uint32_t cb = packed_cell_bits(P, min(cnt->n_active, P.max_blocks)), rmax = (1u << (32u - cb)) - 1u;
   const uint32_t cmask = (1u << cb) - 1u;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t w = key[i];
-    if (w == INVALID) continue;
-    uint32_t r = w >> cb;
-    if (r == rmax) r = rank[i];
-    perm[cell_start[w & cmask] + r] = i;
+  // (four slots of a thread one grid stride apart walk their chains side by side, as in k_perm_keyed below)
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4u * stride) {
+    uint32_t w[4], r[4], cs[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t i = i0 + (uint32_t)j * stride;
+      w[j] = i < n ? key[i] : INVALID;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      r[j] = 0u; cs[j] = 0u;
+      if (w[j] == INVALID) continue;
+      r[j] = w[j] >> cb;
+      if (r[j] == rmax) r[j] = rank[i0 + (uint32_t)j * stride];
+      cs[j] = cell_start[w[j] & cmask];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (w[j] != INVALID) perm[cs[j] + r[j]] = i0 + (uint32_t)j * stride;
   }
 }
 
@@ -715,19 +741,43 @@ __global__ __launch_bounds__(256) void k_perm_keyed(Params P, const Counters *__
                                                     const uint32_t *__restrict__ bits, const uint32_t *__restrict__ wprefix) {
   const uint32_t n = P.n_slots;
   const uint32_t kb = keyed_bits(P), rmax = (1u << (32u - kb)) - 1u, kmask = (1u << kb) - 1u;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t w = key[i];
-    if (w == INVALID) continue;
-    const uint32_t k = w & kmask;
-    uint32_t r = w >> kb;
-    if (r == rmax) r = rank[i];
-    const uint32_t slot = block_slot(bits, wprefix, k >> 6);
-    if (slot >= P.max_blocks) continue;
-    // (pos < n always holds on a healthy ctx.  After a block-table overflow — sticky error bit 1, the ctx is to be recreated — the
-    // key-indexed counters of the blocks that found no slot are never zeroed, so a caller that keeps stepping would get inflated ranks
-    // there: the bound keeps such a ctx inside its arrays)
-    const uint32_t pos = cell_start[(size_t)slot * BC + (k & 63u)] + r;
-    if (pos < n) perm[pos] = i;
+  // A slot is a chain of three dependent loads (packed word -> bitmap + prefix -> cell start) in front of one store, and the kernel has
+  // nothing else to do: four slots of a thread, one grid stride apart (every instruction stays coalesced), walk the chain side by side.
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4u * stride) {
+    uint32_t w[4], bw[4], pf[4], r[4], cs[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t i = i0 + (uint32_t)j * stride;
+      w[j] = i < n ? key[i] : INVALID;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      bw[j] = 0u; pf[j] = 0u; r[j] = 0u;
+      if (w[j] == INVALID) continue;
+      const uint32_t bk = (w[j] & kmask) >> 6;
+      bw[j] = bits[bk >> 5];
+      pf[j] = wprefix[bk >> 5];
+      r[j] = w[j] >> kb;
+      if (r[j] == rmax) r[j] = rank[i0 + (uint32_t)j * stride];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      cs[j] = INVALID;
+      if (w[j] == INVALID) continue;
+      const uint32_t k = w[j] & kmask, bk = k >> 6;
+      const uint32_t slot = pf[j] + __popc(bw[j] & ((1u << (bk & 31u)) - 1u));  // (= block_slot)
+      if (slot < P.max_blocks) cs[j] = cell_start[(size_t)slot * BC + (k & 63u)];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (cs[j] == INVALID) continue;
+      // (pos < n always holds on a healthy ctx.  After a block-table overflow — sticky error bit 1, the ctx is to be recreated — the
+      // key-indexed counters of the blocks that found no slot are never zeroed, so a caller that keeps stepping would get inflated ranks
+      // there: the bound keeps such a ctx inside its arrays)
+      const uint32_t pos = cs[j] + r[j];
+      if (pos < n) perm[pos] = i0 + (uint32_t)j * stride;
+    }
   }
 }
 

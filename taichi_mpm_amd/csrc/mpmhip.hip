@@ -127,6 +127,7 @@ struct mpmhip_ctx {
                              // of the plain kernels; scan_limit() answers per kernel)
   std::map<const void *, uint32_t> scan_limits;  // kernel -> three eighths of its resident workgroups
   int scan_grid_env = 0;
+  uint32_t rank_wgs_cap = 4096u;  // workgroups of the rank role (k_rank / k_sort_front): MPMHIP_RANK_WGS (tuning)
   float4 *tiles = nullptr, *gridv = nullptr, *dense = nullptr;
   Counters *cnt = nullptr;
   std::vector<GroupParams> groups;
@@ -575,6 +576,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
     A(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
     if (cus > 0) c->n_cus = cus;
     if (const char *e = getenv("MPMHIP_SCAN_GRID")) c->scan_grid_env = atoi(e);  // (tuning)
+    if (const char *e = getenv("MPMHIP_RANK_WGS")) c->rank_wgs_cap = (uint32_t)std::max(1, atoi(e));  // (tuning)
   }
   A(hipDeviceSynchronize());
   if (e != hipSuccess) { fail(c, MPMHIP_EHIP, "device init failed: %s", hipGetErrorString(e)); return bail(MPMHIP_EHIP); }
@@ -971,8 +973,12 @@ static int do_sort(mpmhip_ctx *c) {
   // blocks per chunk of k_cell_table: few blocks -> finer chunks (shorter chains, more workgroups).  16 below 2 M slots, 64 from 6 M on
   // (16 costs 10 us at 8 M: its 1 100 chunks no longer fit the scans' resident grid), 32 in between — a rank of a 2-brick job
   // holds 4 M particles in 8 788 blocks: 17.4 us with 64 (as long as the whole 8 M problem takes: the kernel is a latency chain)
+  // With the key-indexed counters (k_sort_front) 16 is the best or within 3 us of it at every size (profiles/r05_s_ct_blocks.txt: a rank
+  // of 4 M 47.5 -> 44 us, C3 after impact 89.6 -> 86.5, the lattice 67.3 -> 64.2 where 32 gives 61.5): the plain table of that form keeps
+  // 1 100..1 340 chunks resident in one round.
+  const bool keyed_ct = c->sort_keyed && c->cellcnt_key != nullptr;
   const int ct = (c->ct_blocks == 16 || c->ct_blocks == 32 || c->ct_blocks == 64) ? c->ct_blocks
-                                                                                   : (c->n_slots < (2 << 20) ? 16 : (c->n_slots < (6 << 20) ? 32 : 64));
+                 : (keyed_ct || c->n_slots < (2 << 20) ? 16 : (c->n_slots < (6 << 20) ? 32 : 64));
   const uint32_t bt_chunks = (P.nbw + 255) / 256, ct_chunks = (P.max_blocks + ct - 1) / ct;
   // Owner list of the grid pass (k_sort.h, k_grid.h): below 2 M slots it takes the pass from 17 to 7.5 us (1 M particles) for 2..3 us
   // in k_rank + k_cell_table; a tiled ctx always builds it (the per-block walk with the halo-box code in it thrashes the instruction
@@ -983,7 +989,7 @@ static int do_sort(mpmhip_ctx *c) {
   uint32_t epoch = ++c->sort_epoch;
   if ((epoch & 0x7FFFFFu) == 0u) epoch = ++c->sort_epoch;  // (k_cell_table's scan words keep 23 bits of it; 0 = never published)
   // (single-pass scans: never more workgroups than are resident at once, see k_sort.h)
-  const uint32_t rank_wgs = std::max(1u, std::min<uint32_t>((P.n_slots + RANK_BATCH - 1) / RANK_BATCH, 8192u));
+  const uint32_t rank_wgs = std::max(1u, std::min<uint32_t>((P.n_slots + RANK_BATCH - 1) / RANK_BATCH, c->rank_wgs_cap));
   const bool keyed = c->sort_keyed && c->cellcnt_key != nullptr;
   const uint32_t bt_wgs = std::min(bt_chunks, keyed ? scan_limit(c, (const void *)k_sort_front) : scan_limit(c, (const void *)k_block_table));
   if (keyed) {

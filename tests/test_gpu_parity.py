@@ -572,15 +572,16 @@ def test_a_block_table_overflow_is_reported_and_leaves_the_ctx_inside_its_arrays
     caller keeps stepping first.  In both forms of the sort: with key-indexed counters the blocks that found no slot keep their
     counts (nobody walks their rows), which must not carry a later sort's permutation outside its array (k_perm_keyed's bound)."""
     rng = np.random.default_rng(61)
-    x = (rng.uniform(4.0, RES - 4.0, (6000, 3)) * DX).astype(np.float32)  # ~350 blocks of the 512 the grid has
+    x = (rng.uniform(7.5, RES - 7.5, (6000, 3)) * DX).astype(np.float32)  # ~200 blocks of the 512 the grid has
     for v1 in ("0", "1"):
         monkeypatch.setenv("MPMHIP_SORT_V1", v1)
         s = make_state(x, "jelly", DX)
         sim = tm.create_simulation3("mpm").initialize(dict(res=(RES,) * 3, delta_x=DX, base_delta_t=DT, max_particles=8192, max_blocks=64))
         sim.add_particles(dict(type="jelly", positions=s.x, velocities=s.v, F=s.F, params=s.gparams[0]))
+        sim._ensure_ctx()  # (particles added before the first step are staged on the host until the ctx exists)
         L, ctx = sim._L, sim._ctx
-        for _ in range(6):  # (asynchronous: nothing looks at the error word in between)
-            assert L.mpmhip_substep(ctx) == 0
+        for _ in range(6):  # (a caller that does not look at the return codes: the substep may already report it, and keeps launching)
+            assert L.mpmhip_substep(ctx) in (0, -4)
         rc = L.mpmhip_synchronize(ctx)
         msg = L.mpmhip_last_error(ctx)
         assert rc == -4 and b"exceed max_blocks" in msg, (v1, rc, msg)
