@@ -517,6 +517,18 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
       if (lane < CT_BPW && a0 + wave * CT_BPW + lane < P.max_blocks) mykey = act_blk[a0 + wave * CT_BPW + lane];
     }
     if (a0 >= na && !(na == 0 && chunk == 0)) return;
+    // the counters of the wave's blocks, requested in front of the neighbour rows' lookups (KEYED): the two chains run side by side
+    uint32_t cc[CT_BPW];
+#pragma unroll
+    for (int i = 0; i < CT_BPW; i++) {
+      const uint32_t a = a0 + wave * CT_BPW + i;
+      cc[i] = 0u;
+      if (a < na) {
+        const size_t row = KEYED ? (size_t)__shfl(mykey, i) * BC : (size_t)a * BC;
+        cc[i] = cell_cnt[row + lane];
+        cell_cnt[row + lane] = 0;
+      }
+    }
     if constexpr (KEYED) {
       if (nbr) {  // neighbour rows + owner masks of the wave's blocks: (block, neighbour) pairs dealt to the lanes
         if (lane < CT_BPW) amask_s[wave * CT_BPW + lane] = 0u;
@@ -565,13 +577,7 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
     }
 #pragma unroll
     for (int i = 0; i < CT_BPW; i++) {
-      const uint32_t a = a0 + wave * CT_BPW + i;
-      uint32_t c = 0;
-      if (a < na) {
-        const size_t row = KEYED ? (size_t)__shfl(mykey, i) * BC : (size_t)a * BC;
-        c = cell_cnt[row + lane];
-        cell_cnt[row + lane] = 0;
-      }
+      const uint32_t c = cc[i];
       uint32_t v = c;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
