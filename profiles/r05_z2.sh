@@ -1,0 +1,24 @@
+#!/bin/bash
+# round 5, step z2: the packed G2P walk forced on at 1 M particles and on a rank of 8 bricks (the library picks it from 2 M slots on)
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
+cd $R
+line() { grep '^{' | tail -1; }
+for rep in 1 2; do
+for V in d 1; do
+  case $V in d) E="X=1";; 1) E="MPMHIP_G2P_PACKED=1";; esac
+  env $E python bench.py --config c2 --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | line > $O/r05_z2_c2_p${V}_$rep.json
+  env $E MPMHIP_TILE_OVERLAP=0 python bench.py --virtual 8 --steps 24 --warmup 8 2>/dev/null | line > $O/r05_z2_v8_p${V}_$rep.json
+done
+done
+python - <<'P'
+import json, glob, os
+O = os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out"
+r = lambda p: {k: round(v * 1e3, 1) for k, v in p.items()}
+for f in sorted(glob.glob(O + "/r05_z2_*_[12].json")):
+    d = json.load(open(f))
+    if "K" in d:
+        print("%-26s per rank %.4f ms %s" % (os.path.basename(f), d["per_rank_ms_serial_no_events"], r(d["rank0_phases_ms"])))
+    else:
+        ev = d.get("evolved") or {}
+        print("%-26s %.4f %s | evolved %.4f %s" % (os.path.basename(f), d["ms_per_step"], r(d["phases_ms_per_step"]), ev.get("ms_per_step", 0), r(ev.get("phases_ms_per_step", {}))))
+P
