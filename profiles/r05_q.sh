@@ -34,3 +34,7 @@ for f in sorted(glob.glob(O + "/r05_final_bench_*.json")) + sorted(glob.glob(O +
         ev = d.get("evolved") or {}
         print("%-28s %.4f %s frac %.3f traffic %s | evolved %.4f %s" % (os.path.basename(f), d["ms_per_step"], r(d["phases_ms_per_step"]), d["roofline"]["frac"], d["roofline"].get("traffic"), ev.get("ms_per_step", 0), r(ev.get("phases_ms_per_step", {}))))
 P
+# trace + PMC passes of the same build (profiles/run_profile.sh): the committed kernel statistics and roofline.traffic sources
+bash $R/profiles/run_profile.sh r05_q > /dev/null 2>&1
+bash $R/profiles/run_profile.sh r05_q_evolved --state evolved > /dev/null 2>&1
+head -8 $O/r05_q/kernel_stats.csv | cut -c1-60,200-400
