@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 5, step ab: threshold of the rank role's LDS-hash path (MPMHIP_RANK_RUNS_MUL; 3 = default: hash when runs x 3 > slots) on the keyed sort
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
+cd $R
+line() { grep '^{' | tail -1; }
+for rep in 1 2; do
+for G in 1 3 4 5 8 1000; do
+  MPMHIP_RANK_RUNS_MUL=$G python bench.py --config c3 --steps 30 --warmup 8 --no-cpu-baseline 2>/dev/null | line > $O/r05_ab_c3_m${G}_$rep.json
+done
+done
+python - <<'P'
+import json, glob, os
+O = os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out"
+r = lambda p: {k: round(v * 1e3, 1) for k, v in p.items()}
+for f in sorted(glob.glob(O + "/r05_ab_*_[12].json")):
+    d = json.load(open(f))
+    ev = d.get("evolved") or {}
+    print("%-26s %.4f %s | evolved %.4f %s" % (os.path.basename(f), d["ms_per_step"], r(d["phases_ms_per_step"]), ev.get("ms_per_step", 0), r(ev.get("phases_ms_per_step", {}))))
+P
