@@ -10,13 +10,16 @@
 //           clear_boundary_particles :582-633 — dead particles simply drop out of the index)
 //          [k_build_keys]  key = Morton(block) << 6 | cell-in-block per particle (normally produced by the
 //                          previous substep's k_g2p, which knows the new position)
-//          k_block_table  byte flags -> active-block bitmap + popcount prefix (dense slot of every active block)
-//                         + active-block list, one single-pass chained-scan launch
-//          k_rank         rank of each particle in its cell (one global atomic per run of equal keys, or — when the
-//                         particle order has decayed — an LDS hash per 1024 slots and one atomic per distinct cell),
-//                         four consecutive slots per thread, one packed (rank, cell) word per slot
-//          k_cell_table   per-cell counts -> start of every cell / block in the sorted index (single pass)
-//          k_perm         sorted position -> particle slot
+//          k_sort_front   ONE launch, two roles (grids up to 508 nodes per axis; do_sort):
+//            block table  byte flags -> active-block bitmap + popcount prefix (dense slot of every active block)
+//                         + active-block list, one single-pass chained scan
+//            ranks        rank of each particle in its cell on counters indexed by the KEY (one global atomic per run of equal
+//                         keys, or — when the particle order has decayed — an LDS hash per 1024 slots and one atomic per distinct
+//                         cell), four consecutive slots per thread, one packed (rank, key) word per slot
+//                         (larger grids: k_block_table, then k_rank on counters indexed by the block's dense slot)
+//          k_cell_table   per-cell counts -> start of every cell / block in the sorted index (single pass); with the owner list
+//                         of the grid pass where that pass walks it (small problems, tiled contexts)
+//          k_perm_keyed   sorted position -> particle slot (k_perm after k_rank)
 //   P2G    k_p2g   one wavefront per active 4x4x4-cell block, ONE LANE PER CELL: register accumulation of the
 //                  27x4 node contributions over the cell's particles (records prefetched two particles ahead),
 //                  ordered non-atomic float4 merge into the block's 6^3-node LDS tile, tile written out whole
