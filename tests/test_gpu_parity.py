@@ -244,8 +244,11 @@ def test_packed_g2p_walk_equals_the_per_block_walk(tm, monkeypatch):
     assert np.array_equal(a["id"], b["id"]) and len(a["id"]) < len(x)
     for f in ("x", "v", "F", "aux"):
         # (the same per-particle arithmetic; in-cell summation orders of P2G differ from run to run: ranks are handed out by atomics)
-        # (... and the return mapping of the sand amplifies them: F gets four times the room of x and v)
-        assert np.allclose(a[f], b[f], rtol=0, atol=(2e-5 if f == "F" else 5e-6) * max(1.0, float(np.abs(a[f]).max()))), f
+        # (... and the return mapping of the sand amplifies them, F and the hardening state most: one run in seven of this test on
+        # five boxes put an `aux` a few 1e-6 apart.  A chunk walked wrongly moves a particle's gather by a node: 1e-2 and more.)
+        tol = (1e-4 if f in ("F", "aux") else 2e-5) * max(1.0, float(np.abs(a[f]).max()))
+        worst = float(np.abs(a[f] - b[f]).max())
+        assert worst <= tol, (f, worst, tol)
 
 
 # ------------------------------------------------------------------------------------------ phases
