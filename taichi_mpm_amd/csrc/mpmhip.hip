@@ -557,7 +557,14 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
     if (getenv("MPMHIP_NO_STATS_STORE") && atoi(getenv("MPMHIP_NO_STATS_STORE"))) c->d_stats = nullptr;  // (A/B: the round-4 copy instead)
   }
   A(dmalloc(&c->d_groups, (size_t)c->groups_cap));
-  if (c->NB <= (1u << 21) && sort_v1 != 1) A(dmalloc(&c->cellcnt_key, (size_t)c->NB * BC));
+  if (e == hipSuccess && c->NB <= (1u << 21) && sort_v1 != 1) {
+    // (an optimisation's table, up to 537 MB: a device that cannot spare it keeps the four-launch sort instead of failing the create)
+    if (dmalloc(&c->cellcnt_key, (size_t)c->NB * BC) != hipSuccess) {
+      (void)hipGetLastError();
+      c->cellcnt_key = nullptr;
+      c->sort_keyed = false;
+    }
+  }
   if (e != hipSuccess) {
     fail(c, MPMHIP_ENOMEM, "device allocation failed: %s (max_particles=%lld, max_blocks=%lld)", hipGetErrorString(e),
          (long long)c->cap, (long long)mb);
