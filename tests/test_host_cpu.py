@@ -277,3 +277,21 @@ def test_scene_driver_over_the_2d_simulation():
     m.clear_output_directory()  # nothing to clear, nothing raised
     with pytest.raises(tm.MPMError):
         m.action(action="calculate_energy")  # (not part of the 2D build: said so, loudly)
+
+
+def test_every_environment_switch_is_in_the_readme():
+    """README.md's table of environment switches covers every MPMHIP_* name the library, the package and bench.py read"""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for f in glob.glob(os.path.join(root, "taichi_mpm_amd", "csrc", "*")) + glob.glob(os.path.join(root, "taichi_mpm_amd", "*.py")) + \
+            [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]:
+        with open(f, errors="replace") as fh:
+            t = fh.read()
+        names |= set(re.findall(r'getenv\("(MPMHIP_[A-Z0-9_]+)"\)', t))
+        names |= set(re.findall(r'environ(?:\.get)?[\(\[]\s*"(MPMHIP_[A-Z0-9_]+)"', t))
+    with open(os.path.join(root, "README.md")) as fh:
+        readme = fh.read()
+    assert len(names) > 20
+    assert not sorted(n for n in names if n not in readme)
