@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const floa
     h.p0 = h.c0 + (n * ppart + PS - 1) / PS;
     h.p1 = h.c0 + (n * (ppart + 1) + PS - 1) / PS;
     // (ablation builds only, results invalid: at most 8 / 6 particles per cell — the upper bound of what ANY balancing of the cells of a
-    // block could give k_p2g after impact, where a wave takes as long as its fullest cell: profiles/r05_m_p2g_cap.txt)
+    // block could give k_p2g after impact, where a wave takes as long as its fullest cell: profiles/r05_m_sort_front_and_p2g_cap.txt)
     if (MPM_ABLATE(P, 16)) h.p1 = min(h.p1, h.p0 + 8u);
     if (MPM_ABLATE(P, 32)) h.p1 = min(h.p1, h.p0 + 6u);
   };
