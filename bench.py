@@ -32,6 +32,13 @@ Extra objects on the line:
                 fallen onto the floor and EVOLVE_AFTER_IMPACT further substeps have run: uneven cells, active
                 return map.  `value` stays the lattice the reference's benchmark seeds (config.state says so);
                 --state evolved makes the evolved state the main measurement (profiling runs), --no-evolved skips it.
+  deterministic the same ctx with mpmhip_config.deterministic on (every cell's particles in creation-id order behind the sort: bitwise
+                reproducible runs): ms_per_step over the same K substeps and what the mode costs per substep.
+  virtual       (N = 1, default workload) the multi-GPU evidence one GPU can give, timed by whoever runs this file: the K bricks of the
+                workload as K ctx on this GPU for K = 8 (then 2 and 4 while the whole block stays below VIRTUAL_BUDGET_S), the library's
+                own loop and halo exchange over the local wire — per-rank substep (what one rank of a K-GPU job computes per substep,
+                before the wire), per-rank phase table, halo bytes, and `x_over_one_gpu` = ms_per_step of this line / per-rank substep:
+                the upper bound of the strong-scaling factor at K GPUs.  --no-virtual skips it.
   cpu_baseline  kind "reference": the reference's own solver, compiled from its sources in place
                 (oracle/_ref/libmpm_ref.so, built by `make -C oracle ref_mpm` where /root/reference exists; the
                 built library travels), timed on this box's host cores: thread sweep + threads=1 row on the
@@ -86,6 +93,7 @@ def substeps_to_impact(cfg, g=10.0, floor=0.1):
     return int(np.sqrt(2.0 * h / g) / cfg.get("dt", 1e-4))
 
 
+VIRTUAL_BUDGET_S = 60.0  # N = 1: the `virtual` block of the line takes K = 8 first, then 2 and 4 while the block stays below this
 EVOLVE_AFTER_IMPACT = 400  # substeps run after the block has touched the floor before the `evolved` state is timed
 
 
@@ -294,20 +302,21 @@ def pmc_traffic(config_name, kernel, check=True):
     return tbytes, src, "code %s = the PMC build (commit %s)" % (want, (d.get("code") or {}).get("commit"))
 
 
-def virtual_run(tm, cfg, args):
+def virtual_run(tm, cfg, args, K=None, overlap=None):
     """--virtual K: the K-brick job as K ctx on ONE GPU, on the library's own data plane (MPMHIP_WIRE_LOCAL: peer writes with
     plain pointers; loop, exchange and migration inside mpmhip_tiled_advance_group).  All ctx share one stream, so the ranks'
     kernels run one after another and a rank's event-bracketed parts are the per-GPU compute of a K-GPU run without the wire."""
     import torch
 
     from taichi_mpm_amd import tiled
-    K = args.virtual
+    K = K or args.virtual
     part = tiled.scene_partition(cfg, K, margin=int(os.environ.get("MPMHIP_TILE_MARGIN", 4)))
     engines = []
     for r in range(K):
         sim, _ = tiled.build_rank_sim(tm, cfg, part, r, 0)
         engines.append(tiled.HipEngine(sim, 0))
-    overlap = os.environ.get("MPMHIP_TILE_OVERLAP", "1") != "0"
+    if overlap is None:
+        overlap = os.environ.get("MPMHIP_TILE_OVERLAP", "1") != "0"
     python_loop = os.environ.get("MPMHIP_VIRTUAL_PYTHON") == "1"  # the round-3 path: Python loop, exchanges as torch copies
     job = tiled.VirtualTiledJob(engines, part, overlap=overlap) if python_loop else tiled.NativeVirtualJob(engines, part, overlap=overlap)
     job.run(args.warmup)
@@ -336,6 +345,8 @@ def virtual_run(tm, cfg, args):
     else:
         st = job.state()
         halo, migrated = [t["halo_nodes"] for t in st], [t["migrated_out"] for t in st]
+    for e in engines:  # (the next K of the default line's block builds its own ranks)
+        e.sim.close()
     return ({"diagnostic": "virtual ranks on one GPU", "K": K, "dims": part.dims, "cuts": part.cuts, "workload": cfg["desc"],
              "loop": "python (VirtualTiledJob)" if python_loop else "native (mpmhip_tiled_advance_group, MPMHIP_WIRE_LOCAL)",
              "overlap_split": overlap, "particles": n_total,
@@ -455,6 +466,7 @@ def main():
     ap.add_argument("--allow-staged", action="store_true",
                     help="N > 1: if the RCCL wire cannot be brought up, stage the exchange through gloo and host memory instead of "
                          "exiting with an error (such a line says so in config.wire and is NOT a scaling measurement)")
+    ap.add_argument("--no-virtual", action="store_true", help="N = 1: skip the `virtual` block of the line (K bricks as K ctx on this GPU)")
     ap.add_argument("--virtual", type=int, default=0, metavar="K",
                     help="diagnostic, not the metric: run the K-brick tiled job as K ctx on ONE GPU (exchanges are local "
                          "copies) and print per-rank phase times = the per-GPU compute of a K-GPU run without the wire")
@@ -751,6 +763,22 @@ def main():
         "p2g_plus_g2p_hbm_frac_algorithmic": both_frac,
         "whole_step_hbm_frac_algorithmic": whole_step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
     }
+    if world == 1 and not force_tiled:
+        # the same K substeps with the cells in creation-id order behind every sort (bitwise reproducible runs): what the mode costs
+        try:
+            job.sim.set_deterministic(True)
+            job.run(args.warmup)
+            barrier()
+            t0 = time.perf_counter()
+            job.run(args.steps)
+            job.synchronize()
+            d_el = time.perf_counter() - t0
+            job.sim.set_deterministic(False)
+            out["deterministic"] = {"ms_per_step": 1e3 * d_el / args.steps, "value": n_total * args.steps / d_el,
+                                    "extra_ms_per_step": 1e3 * (d_el - elapsed) / args.steps,
+                                    "what": "mpmhip_config.deterministic: k_cell_order behind every sort (in-cell order by creation id)"}
+        except Exception as e:
+            out["deterministic"] = {"error": repr(e)}
     if world == 1 and not force_tiled and args.state == "lattice" and not args.no_evolved:
         # the same scene after impact, on the same ctx: the state the lattice number flatters
         try:
@@ -769,6 +797,34 @@ def main():
                 out["evolved"]["warning"] = "%d of %d particles were deleted before the timed region" % (n_per_gpu - e_n, n_per_gpu)
         except Exception as e:
             out["evolved"] = {"error": repr(e)}
+    if world == 1 and not force_tiled and not args.no_virtual and args.config == "c3" and not args.cells and args.state == "lattice":
+        # The only multi-GPU evidence one GPU can give, on the same box and in the same process as the headline: the K bricks of the
+        # workload as K ctx on this GPU (the library's own loop, halo exchange and migration over the local wire; the ranks' kernels
+        # run one after another on one stream, so the time per rank is what one rank alone on a device computes per substep).
+        try:
+            job.sim.close()  # (the one-GPU ctx is done with: the ranks get the memory)
+            t_block = time.time()
+            vout = {"what": "K bricks of the workload as K ctx on THIS GPU (mpmhip_tiled_advance_group, MPMHIP_WIRE_LOCAL): per_rank_ms = "
+                            "all ranks' substeps back to back / K = the per-GPU compute of a K-GPU run before the wire; x_over_one_gpu = "
+                            "ms_per_step of this line / per_rank_ms = upper bound of the strong-scaling factor", "one_gpu_ms_per_step": out["ms_per_step"],
+                    "ranks": {}}
+            for K in (8, 2, 4):
+                if K != 8 and time.time() - t_block > VIRTUAL_BUDGET_S * (0.5 if K == 2 else 0.75):
+                    vout["ranks"][str(K)] = {"skipped": "time budget of the block (%.0f s) nearly spent" % VIRTUAL_BUDGET_S}
+                    continue
+                v = virtual_run(tm, cfg, args, K=K, overlap=False)
+                row = {"per_rank_ms": v["per_rank_ms_serial_no_events"], "x_over_one_gpu": out["ms_per_step"] / v["per_rank_ms_serial_no_events"],
+                       "particles_per_rank": v["particles_per_rank"], "halo_bytes_per_rank": v["halo_bytes_per_rank"],
+                       "rank0_phases_ms": v["rank0_phases_ms"], "per_rank_compute_ms": v["per_rank_compute_ms_per_phase_events"],
+                       "dims": v["dims"], "migrated": v["migrated"]}
+                if K == 8 and time.time() - t_block < VIRTUAL_BUDGET_S * 0.3:
+                    v2 = virtual_run(tm, cfg, args, K=K, overlap=True)  # (the boundary / interior split a real wire may want: three more launches)
+                    row["per_rank_ms_overlap_split"] = v2["per_rank_ms_serial_no_events"]
+                vout["ranks"][str(K)] = row
+            vout["seconds"] = time.time() - t_block
+            out["virtual"] = vout
+        except Exception as e:
+            out["virtual"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import refmpm

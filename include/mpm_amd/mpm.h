@@ -79,6 +79,7 @@ class MPM<3> {
     cfg_.device = config.get("device", 0);
     cfg_.discard_apic_b = !config.get("keep_apic_b", keep_apic_b_default());
     cfg_.generic_path = !config.get("optimized", true);  // src/mpm.cpp:508-515,546-552
+    cfg_.deterministic = config.get("deterministic", false);  // (no reference key: bitwise reproducible runs, include/mpmhip.h)
     cfg_.particle_collision = config.get("particle_collision", false);  // src/mpm.cpp:566-569
     verbose_bgeo = config.get("verbose_bgeo", false);   // src/visualize.cpp:22
     frame_directory = config.get("frame_directory", "");  // injected by the python driver, async_mpm.py:49

@@ -96,7 +96,16 @@ typedef struct {
                              * 585-687).  Same arithmetic as the optimised path here (both go through the same kernels); what
                              * differs in the reference is the position clamp into [0, res - eps] after the advection
                              * (:668-670), which this flag turns on */
-  int32_t reserved[3];
+  int32_t deterministic;    /* 1 = bitwise reproducible runs: every cell's particles are put in ascending creation id behind the sort
+                             * (the in-cell ranks of the counting sort come from atomics, so without it the summation order of P2G's
+                             * per-cell sums — and the last bits of everything downstream — differs from run to run).  Two runs of one
+                             * scene, the packed and the per-block G2P walk, the three- and the four-launch sort, and a tiled job over any
+                             * wire then give identical bits; a K-rank job differs from the one-ctx run only by how the <= 8 block tiles of
+                             * a halo node are grouped into rank partials.  Costs one more launch per sort (bench.py reports it).
+                             * Not covered: the impulse / torque sums of CPIC rigid bodies and calculate_energy (float atomics).
+                             * The reference's sort key is unique for the same purpose: (offset >> 5) << 25 | i, src/mpm.cpp:785-795.
+                             * env MPMHIP_DETERMINISTIC=0/1 overrides */
+  int32_t reserved[2];
 } mpmhip_config;
 
 typedef struct mpmhip_ctx mpmhip_ctx;
@@ -120,6 +129,8 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out);
 void mpmhip_destroy(mpmhip_ctx *ctx);
 const char *mpmhip_last_error(const mpmhip_ctx *ctx); /* ctx may be NULL: last create() failure */
 int mpmhip_set_stream(mpmhip_ctx *ctx, void *hip_stream); /* NULL = the ctx's own stream */
+/* mpmhip_config.deterministic of a live ctx (from the next sort on; no reference counterpart: its scalar path has one order) */
+int mpmhip_set_deterministic(mpmhip_ctx *ctx, int32_t enabled);
 /* replaces Simulation::set_levelset(DynamicLevelSet) (scripts/async/async_mpm.py:119-127) for analytic half-spaces */
 int mpmhip_set_levelset(mpmhip_ctx *ctx, int32_t n_planes, const float *planes /* [n][4] */, float friction);
 
@@ -585,6 +596,10 @@ int mpmhip_debug_copy_bandwidth(mpmhip_ctx *ctx, size_t bytes, int32_t iters, do
 /* measurement helper: 1 when the next substep's G2P is k_g2p_packed (chunks of 256 consecutive sorted positions; large
  * one-material problems without rigid bodies or tiling), 0 when it is k_g2p (chunks inside one block) */
 int mpmhip_debug_g2p_is_packed(const mpmhip_ctx *ctx);
+/* the launch bound of the single-pass (chained) scans of the sort as a function of the occupancy API's answer: `limit` = workgroups
+ * the host launches at most, `resident` = workgroups the device certainly keeps resident (one per CU below the API's number, at most
+ * 7).  Pure host arithmetic (no device): mpmhip_create checks limit <= resident for every such kernel; the waits are bounded besides. */
+int mpmhip_debug_scan_grid(int32_t n_cus, int32_t per_cu, int32_t env_request, uint32_t *limit, uint32_t *resident);
 /* 64-byte record gather of KNOWN size — the access pattern of k_p2g / k_g2p (a lane fetches one whole record with four
  * 16-byte loads through an index): n (a power of two) records, index pattern 0 identity / 1 shuffled runs of 8 /
  * 2 fully shuffled.  Reads exactly (64 + 4) n bytes per launch: the yardstick rocprofv3's FETCH_SIZE is calibrated

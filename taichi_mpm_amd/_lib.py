@@ -30,7 +30,7 @@ class Config(C.Structure):
                 ("clean_boundary", C.c_int32), ("n_planes", C.c_int32), ("planes", (C.c_float * 4) * 8),
                 ("friction", C.c_float), ("max_particles", C.c_int64), ("max_blocks", C.c_int64),
                 ("device", C.c_int32), ("reorder_interval", C.c_int32), ("particle_collision", C.c_int32),
-                ("discard_apic_b", C.c_int32), ("generic_path", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("discard_apic_b", C.c_int32), ("generic_path", C.c_int32), ("deterministic", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class Shape(C.Structure):
@@ -152,7 +152,7 @@ def build_variant(name, extra_flags):
 
 _lib = None
 
-_SYMBOLS = ["mpmhip_abi_version", "mpmhip_set_profile_sampling", "mpmhip_create", "mpmhip_destroy", "mpmhip_last_error", "mpmhip_set_stream", "mpmhip_set_levelset", "mpmhip_set_rigid_levelset_collision", "mpmhip_set_dirichlet", "mpmhip2d_set_dirichlet", "mpmhip_set_levelset_shapes", "mpmhip_set_levelset_keyframes",
+_SYMBOLS = ["mpmhip_abi_version", "mpmhip_set_profile_sampling", "mpmhip_create", "mpmhip_destroy", "mpmhip_last_error", "mpmhip_set_stream", "mpmhip_set_deterministic", "mpmhip_set_levelset", "mpmhip_set_rigid_levelset_collision", "mpmhip_set_dirichlet", "mpmhip2d_set_dirichlet", "mpmhip_set_levelset_shapes", "mpmhip_set_levelset_keyframes",
             "mpmhip_add_group", "mpmhip_add_particles", "mpmhip_num_particles", "mpmhip_download",
             "mpmhip_upload", "mpmhip_substep", "mpmhip_run_substeps", "mpmhip_step", "mpmhip_current_time",
             "mpmhip_synchronize", "mpmhip_sort", "mpmhip_p2g", "mpmhip_grid_update", "mpmhip_g2p",
@@ -175,7 +175,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_set_profile_sampling", "mpmhip_create"
             "mpmhip_rigid_get_samples", "mpmhip_rigid_get_mesh", "mpmhip2d_rigid_get_mesh", "mpmhip_rasterize_rigid_boundary", "mpmhip_gather_cdf", "mpmhip_advect_rigid_bodies", "mpmhip_download_cdf",
             "mpmhip_add_articulation", "mpmhip_num_articulations", "mpmhip_set_articulation_iterations", "mpmhip_articulate",
             "mpmhip_download_boundary",
-            "mpmhip_debug_copy_bandwidth", "mpmhip_debug_g2p_is_packed", "mpmhip_debug_gather_bandwidth", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
+            "mpmhip_debug_copy_bandwidth", "mpmhip_debug_g2p_is_packed", "mpmhip_debug_scan_grid", "mpmhip_debug_gather_bandwidth", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
 
 
 def exported_symbols():
@@ -222,6 +222,7 @@ def load():
     L.mpmhip_set_levelset.argtypes = [vp, C.c_int32, fp, C.c_float]
     L.mpmhip_set_levelset_shapes.argtypes = [vp, C.c_int32, P(Shape), C.c_float]
     L.mpmhip_set_dirichlet.argtypes = [vp, C.c_int32]
+    L.mpmhip_set_deterministic.argtypes = [vp, C.c_int32]
     L.mpmhip_set_rigid_levelset_collision.argtypes = [vp, C.c_int32]
     L.mpmhip2d_set_dirichlet.argtypes = [vp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float]
     L.mpmhip_set_levelset_keyframes.argtypes = [vp, C.c_float, C.c_float, C.c_int32, P(Shape), C.c_int32, P(Shape), C.c_float]
@@ -359,6 +360,7 @@ def load():
     L.mpmhip2d_async_current_time.restype = C.c_double
     L.mpmhip2d_async_table.argtypes = [vp, P(C.c_int32), C.c_int64] + [P(C.c_int64)] * 7
     L.mpmhip2d_async_table.restype = C.c_int64
+    L.mpmhip_debug_scan_grid.argtypes = [C.c_int32, C.c_int32, C.c_int32, P(C.c_uint32), P(C.c_uint32)]
     L.mpmhip_debug_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int32, P(C.c_double)]
     L.mpmhip_debug_gather_bandwidth.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, P(C.c_double)]
     L.mpmhip_bgeo_size.argtypes = [vp, C.c_int32, P(C.c_size_t)]

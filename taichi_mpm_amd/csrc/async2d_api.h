@@ -74,6 +74,8 @@ static int a2_counters(mpmhip2d_ctx *m, AsyncCounters &h) {
   HIPCHK2D(m, hipMemsetAsync(A.d_cnt, 0, 16, m->stream));
   HIPCHK2D(m, hipStreamSynchronize(m->stream));
   h = *A.h_cnt;
+  if (h.pad[0] & mpm::SCAN_ERROR_BIT)
+    return fail2d(m, MPMHIP_EHIP, "async store: a chained scan of the compaction waited in vain for a chunk that never published (k_sort.h)");
   A.live += h.n_append; A.live -= std::min(A.live, h.n_freed);
   A.size = A.size_ub = h.size;
   A.pending_counters = false;

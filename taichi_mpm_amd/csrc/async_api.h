@@ -64,6 +64,9 @@ static int async_counters(mpmhip_ctx *c, AsyncCounters &h, bool reset_after) {
   if (reset_after) HIPCHK(c, hipMemsetAsync(S.d_cnt, 0, 16, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   h = *pin;
+  if (h.pad[0] & SCAN_ERROR_BIT)
+    return fail(c, MPMHIP_EHIP, "async store: a chained scan of the compaction waited %.0f s for a chunk that never published (k_sort.h: "
+                "the launch did not fit the device's resident set?)", (double)SCAN_WAIT_TICKS / 1e8);
   if (reset_after) {
     S.live += h.n_append; S.live -= std::min(S.live, h.n_freed);
     S.size = S.size_ub = h.size;

@@ -20,7 +20,8 @@ namespace mpm {
 constexpr uint32_t AS_BACKUP = 0x80000000u, AS_FREE = INVALID;
 struct AsyncCounters {
   uint32_t n_work, n_append, n_freed, n_live;  // transient: reset by the host behind every read-back
-  uint32_t size, pad[3];                       // persistent: containers in use incl. freed ones (the append cursor)
+  uint32_t size, pad[3];                       // persistent: containers in use incl. freed ones (the append cursor); pad[0]: sticky
+                                               // error word (bit 8: a chained scan of the compaction waited in vain, k_sort.h)
 };
 
 // One 64-byte record pair per container: g = the ctx's RecG image (x3, aux, F9, gid, id, -), w = {v3, -}, {apic_b[0..3]},
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void k_async_compact(uint32_t size, const uint
     uint32_t total;
     const uint32_t excl = wg_exclusive_scan_256(live, lds, total);
     if (threadIdx.x == 0) publish(slots + chunk, epoch, total);
-    uint32_t o = sum_predecessors(slots, chunk, epoch, lds) + excl;
+    uint32_t o = sum_predecessors(slots, chunk, epoch, lds, &cnt->pad[0]) + excl;  // (a wait that expires: sticky bit in pad[0], read back by the host)
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       if (t[j] == AS_FREE) continue;

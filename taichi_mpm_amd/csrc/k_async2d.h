@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k2a_compact(uint32_t size, const uint32_t
     uint32_t total;
     const uint32_t excl = mpm::wg_exclusive_scan_256(live, lds, total);
     if (threadIdx.x == 0) mpm::publish(slots + chunk, epoch, total);
-    uint32_t o = mpm::sum_predecessors(slots, chunk, epoch, lds) + excl;
+    uint32_t o = mpm::sum_predecessors(slots, chunk, epoch, lds, &cnt->pad[0]) + excl;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       if (t[j] == AS_FREE) continue;

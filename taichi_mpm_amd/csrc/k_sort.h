@@ -65,15 +65,35 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan_256(uint32_t v, uint32_t *
 __device__ __forceinline__ void publish(unsigned long long *slot, uint32_t epoch, uint32_t value) {
   __hip_atomic_store(slot, ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// A wait on another workgroup's word is BOUNDED: the host sizes every chained scan's launch from the occupancy API so that the chunks a
+// workgroup waits for are resident (scan_limit / scan_residency_check in mpmhip.hip), but dispatch order and residency are not
+// promised by HIP (MI355X guide: "bound every spin") — another runtime, a partitioned device or a debugger must cost a sticky error
+// (Counters::error bit 8, reported by the next synchronising call), not the GPU.  A chunk that gives up counts the missing sums as
+// zero: every index derived from them is then too SMALL, i.e. still inside its array.
+constexpr unsigned long long SCAN_WAIT_TICKS = 400000000ull;  // of the 100 MHz wall clock: 4 s
+constexpr uint32_t SCAN_ERROR_BIT = 8u;
+__device__ __forceinline__ bool scan_wait_expired(unsigned long long &t0, uint32_t &polls, uint32_t *err) {
+  if ((++polls & 1023u) != 0u) return false;  // (the clock is read once per 1 024 polls)
+  const unsigned long long now = wall_clock64();
+  if (t0 == 0ull) { t0 = now; return false; }
+  if (now - t0 <= SCAN_WAIT_TICKS) return false;
+  if (err) atomicOr(err, SCAN_ERROR_BIT);
+  return true;
+}
 // sum of the published values of chunks [0, chunk): every thread of the 256-thread workgroup gets the result
 __device__ __forceinline__ uint32_t sum_predecessors(const unsigned long long *slots, uint32_t chunk, uint32_t epoch,
-                                                     uint32_t *lds) {
+                                                     uint32_t *lds, uint32_t *err) {
   uint32_t pre = 0;
+  unsigned long long t0 = 0ull;
+  uint32_t polls = 0u;
   for (uint32_t j = threadIdx.x; j < chunk; j += 256) {
     unsigned long long w;
-    while ((uint32_t)((w = __hip_atomic_load(slots + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch)
+    bool gave_up = false;
+    while ((uint32_t)((w = __hip_atomic_load(slots + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch) {
       __builtin_amdgcn_s_sleep(1);
-    pre += (uint32_t)w;
+      if (scan_wait_expired(t0, polls, err)) { gave_up = true; break; }
+    }
+    if (!gave_up) pre += (uint32_t)w;
   }
   uint32_t total;
   wg_exclusive_scan_256(pre, lds, total);
@@ -104,13 +124,18 @@ __device__ __forceinline__ void publish2(unsigned long long *slot, uint32_t epoc
 }
 // sums over the chunks [0, chunk): (owners << 32) | particles, for every thread of the 256-thread workgroup
 __device__ __forceinline__ unsigned long long sum_predecessors2(const unsigned long long *slots, uint32_t chunk, uint32_t epoch,
-                                                                unsigned long long *lds) {
+                                                                unsigned long long *lds, uint32_t *err) {
   unsigned long long pre = 0;
+  unsigned long long t0 = 0ull;
+  uint32_t polls = 0u;
   for (uint32_t j = threadIdx.x; j < chunk; j += 256) {
     unsigned long long w;
-    while ((uint32_t)((w = __hip_atomic_load(slots + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 41) != (epoch & 0x7FFFFFu))
+    bool gave_up = false;
+    while ((uint32_t)((w = __hip_atomic_load(slots + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 41) != (epoch & 0x7FFFFFu)) {
       __builtin_amdgcn_s_sleep(1);
-    pre += (((w >> 31) & 0x3FFull) << 32) | (w & 0x7FFFFFFFull);
+      if (scan_wait_expired(t0, polls, err)) { gave_up = true; break; }  // (see sum_predecessors)
+    }
+    if (!gave_up) pre += (((w >> 31) & 0x3FFull) << 32) | (w & 0x7FFFFFFFull);
   }
   unsigned long long total;
   wg_exclusive_scan_256_u64(pre, lds, total);
@@ -151,7 +176,7 @@ __device__ __forceinline__ void block_table_body(const Params &P, uint8_t *__res
     uint32_t total;
     const uint32_t excl = wg_exclusive_scan_256(__popc(m), lds, total);
     if (threadIdx.x == 0) publish(slots + chunk, epoch, total);
-    const uint32_t chunk_base = sum_predecessors(slots, chunk, epoch, lds);
+    const uint32_t chunk_base = sum_predecessors(slots, chunk, epoch, lds, &cnt->error);
     uint32_t run = chunk_base + excl;
     if (w < P.nbw) {
       bits[w] = m;
@@ -596,7 +621,7 @@ __global__ __launch_bounds__(256) void k_cell_table(Params P, Counters *cnt, uin
     const unsigned long long boff = wg_exclusive_scan_256_u64(mine, lds, total);
     if (threadIdx.x == 0) publish2(slots + chunk, epoch, (uint32_t)total, (uint32_t)(total >> 32));
     if (threadIdx.x < CT_BLOCKS) { blk_tot[threadIdx.x] = (uint32_t)boff; own_tot[threadIdx.x] = (uint32_t)(boff >> 32); }
-    const unsigned long long base2 = sum_predecessors2(slots, chunk, epoch, lds);  // its barriers also cover blk_tot / own_tot
+    const unsigned long long base2 = sum_predecessors2(slots, chunk, epoch, lds, &cnt->error);  // its barriers also cover blk_tot / own_tot
     const uint32_t chunk_base = (uint32_t)base2, own_base = (uint32_t)(base2 >> 32);
 #pragma unroll
     for (int i = 0; i < CT_BPW; i++) {
@@ -682,7 +707,7 @@ __global__ __launch_bounds__(256) void k_cell_table_plain(Params P, Counters *cn
     const uint32_t boff = wg_exclusive_scan_256(mine, lds, total);
     if (threadIdx.x == 0) publish(slots + chunk, epoch, total);
     if (threadIdx.x < CT_BLOCKS) blk_tot[threadIdx.x] = boff;
-    const uint32_t chunk_base = sum_predecessors(slots, chunk, epoch, lds);  // its barriers also cover blk_tot
+    const uint32_t chunk_base = sum_predecessors(slots, chunk, epoch, lds, &cnt->error);  // its barriers also cover blk_tot
 #pragma unroll
     for (int i = 0; i < CT_BPW; i++) {
       const uint32_t a = a0 + wave * CT_BPW + i;
@@ -783,6 +808,68 @@ __global__ __launch_bounds__(256) void k_perm_keyed(Params P, const Counters *__
       // there: the bound keeps such a ctx inside its arrays)
       const uint32_t pos = cs[j] + r[j];
       if (pos < n) perm[pos] = i0 + (uint32_t)j * stride;
+    }
+  }
+}
+
+// ---- deterministic mode (mpmhip_config.deterministic).  The in-cell ranks above come from atomics (k_rank / k_sort_front), so the
+// order of the particles INSIDE a cell of the sorted index — and with it the summation order of P2G's per-cell register sums and
+// the last bits of everything downstream — differs from run to run.  Behind k_perm this launch puts every cell's entries in
+// ascending CREATION ID (RecG.pid, unique): the one order that does not depend on where a particle happens to lie in memory
+// (slots change with every substep, with a migration, with a snapshot).  The reference's sort key is unique for the same reason:
+// (offset >> 5) << 25 | i, src/mpm.cpp:785-795.  One lane per cell: the ids of its (typically 8) particles are gathered from the
+// records — up to 16 independent loads, one round trip —, every entry's place is the number of smaller ids, the ordered entries
+// go to `out` (rank[], idle between k_perm and the next sort: do_sort swaps the two arrays).  Fuller cells count through memory,
+// a cell of more than 64 particles with its whole wave.
+__device__ __forceinline__ uint32_t pid_of(const float4 *__restrict__ rg, uint32_t slot) {
+  return __float_as_uint(rg[(size_t)slot * 4 + 3].z);  // RecG.pid (>= 0 for every entry of the sorted index)
+}
+__global__ __launch_bounds__(256) void k_cell_order(Params P, const Counters *__restrict__ cnt, const uint32_t *__restrict__ cell_start,
+                                                    const uint32_t *__restrict__ perm, const float4 *__restrict__ rg,
+                                                    uint32_t *__restrict__ out) {
+  const uint32_t ncell = min(cnt->n_active, P.max_blocks) * (uint32_t)BC;
+  const uint32_t stride = gridDim.x * blockDim.x, lane = threadIdx.x & 63;
+  const uint32_t nloop = (ncell + stride - 1) / stride;
+  for (uint32_t it = 0; it < nloop; it++) {  // uniform trip count: all lanes take part in the ballot
+    const uint32_t c = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s = 0, n = 0;
+    if (c < ncell) { s = cell_start[c]; n = cell_start[c + 1] - s; }
+    if (n == 1u) {
+      out[s] = perm[s];
+    } else if (n <= 16u) {
+      uint32_t pv[16], id[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) pv[i] = (uint32_t)i < n ? perm[s + i] : 0u;
+#pragma unroll
+      for (int i = 0; i < 16; i++) id[i] = (uint32_t)i < n ? pid_of(rg, pv[i]) : INVALID;  // (the padding is smaller than nothing)
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        if ((uint32_t)i < n) {
+          uint32_t r = 0;
+#pragma unroll
+          for (int j = 0; j < 16; j++) r += id[j] < id[i] ? 1u : 0u;
+          out[s + r] = pv[i];
+        }
+      }
+    } else if (n <= 64u) {
+      for (uint32_t i = 0; i < n; i++) {
+        const uint32_t slot = perm[s + i], pi = pid_of(rg, slot);
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < n; j++) r += pid_of(rg, perm[s + j]) < pi ? 1u : 0u;
+        out[s + r] = slot;
+      }
+    }
+    unsigned long long big = __ballot(n > 64u);
+    while (big) {
+      const int l = __ffsll((long long)big) - 1;
+      big &= big - 1;
+      const uint32_t bs = __shfl(s, l), bn = __shfl(n, l);
+      for (uint32_t i = lane; i < bn; i += 64u) {
+        const uint32_t slot = perm[bs + i], pi = pid_of(rg, slot);
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < bn; j++) r += pid_of(rg, perm[bs + j]) < pi ? 1u : 0u;
+        out[bs + r] = slot;
+      }
     }
   }
 }

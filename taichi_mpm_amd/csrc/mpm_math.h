@@ -232,10 +232,15 @@ __device__ __forceinline__ void sym_eig3_FFt(mat3 &F, mat3 &U, float lam[3], flo
   const float tol = MPM_JACOBI_TOL * (a00 + a11 + a22);
 #pragma unroll
   for (int sweep = 0; sweep < kJacobiSweeps; sweep++) {
-    if (!__any(fmaxf(fabsf(a01), fmaxf(fabsf(a02), fabsf(a12))) > tol)) break;
-    jacobi_rotate(a00, a11, a01, a02, a12, u0, w0, u1, w1);  // (p,q,r)=(0,1,2)
-    jacobi_rotate(a00, a22, a02, a01, a12, u0, w0, u2, w2);  // (0,2,1)
-    jacobi_rotate(a11, a22, a12, a01, a02, u1, w1, u2, w2);  // (1,2,0)
+    // the wave leaves when every lane has converged; a lane that HAS converged sits the sweep out, so that a particle's result
+    // does not depend on which other particles share its wave (the per-block and the packed G2P walk, two tilings of one scene)
+    const bool more = fmaxf(fabsf(a01), fmaxf(fabsf(a02), fabsf(a12))) > tol;
+    if (!__any(more)) break;
+    if (more) {
+      jacobi_rotate(a00, a11, a01, a02, a12, u0, w0, u1, w1);  // (p,q,r)=(0,1,2)
+      jacobi_rotate(a00, a22, a02, a01, a12, u0, w0, u2, w2);  // (0,2,1)
+      jacobi_rotate(a11, a22, a12, a01, a02, u1, w1, u2, w2);  // (1,2,0)
+    }
   }
   U(0, 0) = u0.x; U(1, 0) = u0.y; U(2, 0) = w0;
   U(0, 1) = u1.x; U(1, 1) = u1.y; U(2, 1) = w1;
@@ -243,10 +248,11 @@ __device__ __forceinline__ void sym_eig3_FFt(mat3 &F, mat3 &U, float lam[3], flo
   lam[0] = a00; lam[1] = a11; lam[2] = a22;
   // Ill-conditioned F.  The eigenvalues of F F^T carry an ABSOLUTE error ~ eps sigma_max^2, i.e. sigma_min loses relative accuracy
   // like eps cond(F)^2 (8e-4 at cond 1e2, nothing left at 1e3: profiles/r05_c_illcond_head.txt), while the reference takes
-  // svd(F) — and the Hencky models take log(sigma).  When some lane of the wave holds lam_min < lam_max / 64 (cond > 8: never on
-  // the benchmark states; the test is wave-uniform) the decomposition is finished on F itself (sym_eig3_refine).
+  // svd(F) — and the Hencky models take log(sigma).  A lane that holds lam_min < lam_max / 64 (cond > 8: never on the benchmark
+  // states) finishes the decomposition on F itself (sym_eig3_refine) — decided per lane, like the sweeps above: until round 5 the
+  // whole wave followed one such lane, and results depended on who shared a wave.
   const float lmax = fmaxf(a00, fmaxf(a11, a22)), lmin = fminf(a00, fminf(a11, a22));
-  if (__any(lmin < (1.0f / 64.0f) * lmax)) sym_eig3_refine<IN_LDS>(F, U, lam, lds);
+  if (lmin < (1.0f / 64.0f) * lmax) sym_eig3_refine<IN_LDS>(F, U, lam, lds);
 }
 
 // Signed singular values in U's (unsorted) column order: s_i = sqrt(lam_i); if det F < 0 the sign goes

@@ -117,6 +117,7 @@ struct mpmhip_ctx {
   uint32_t *bits = nullptr, *wprefix = nullptr, *act_blk = nullptr, *act_start = nullptr;
   uint32_t *cell_cnt = nullptr, *cell_start = nullptr, *fat_slot = nullptr;
   bool sort_keyed = false;
+  bool deterministic = false;  // mpmhip_config.deterministic (env MPMHIP_DETERMINISTIC): in-cell order by creation id behind every sort (do_sort)
   uint32_t *cellcnt_key = nullptr;  // [64 NB] cell counters indexed by KEY (Morton block << 6 | cell): the two-launch front of the sort (do_sort); nullptr on grids beyond 2^21 blocks
   uint32_t *nbr = nullptr, *own_list = nullptr;  // k_cell_table -> k_grid: 32-word neighbour row per active block, list of owned (block, candidate) pairs
   FillStats *d_stats = nullptr;  // device address of the pinned page's statistics words (h_pinned + FILL_STATS_WORD): k_cell_table stores there
@@ -125,6 +126,7 @@ struct mpmhip_ctx {
   bool list_valid = false;       // the last sort built neighbour rows + owner list (do_sort -> do_grid)
   int grid_wgs = 0;              // workgroups of the grid pass; 0: from the last sort's owner count (env MPMHIP_GRID_WGS)
   unsigned long long *scan_slots = nullptr;  // [256] k_block_table + [ct_grid] k_cell_table: {epoch, chunk sum}
+  uint32_t list_clear_epoch = 0;  // sort epoch at which the scan words of the list form of k_cell_table were last zeroed (do_sort)
   uint32_t sort_epoch = 0, bt_slots = 0, ct_slots = 0;  // scan_slots: [bt_slots] k_block_table | [ct_slots] k_cell_table_plain | [ct_slots] k_cell_table
   uint32_t scan_grid = 256;  // workgroups of the single-pass scan kernels: three eighths of what the device keeps resident (the lowest
                              // of the plain kernels; scan_limit() answers per kernel)
@@ -438,6 +440,9 @@ static int bgeo_order(mpmhip_ctx *c, std::vector<uint32_t> &order, std::vector<i
 
 extern "C" {
 
+static uint32_t scan_limit(mpmhip_ctx *c, const void *kernel);   // (defined with do_sort, below)
+static uint32_t scan_resident_set(int n_cus, int per_cu);
+
 uint32_t mpmhip_abi_version(void) { return MPMHIP_ABI_VERSION; }
 
 const char *mpmhip_last_error(const mpmhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -471,6 +476,8 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   if (const char *e = getenv("MPMHIP_GRID_WGS")) c->grid_wgs = atoi(e) > 0 ? atoi(e) : 0;
   c->reorder_interval = cfg->reorder_interval;
   if (const char *e = getenv("MPMHIP_REORDER_INTERVAL")) c->reorder_interval = atoi(e);
+  c->deterministic = cfg->deterministic != 0;
+  if (const char *e = getenv("MPMHIP_DETERMINISTIC")) c->deterministic = atoi(e) != 0;
 #ifdef MPMHIP_ABLATE_BUILD
   const int ablate = getenv("MPMHIP_ABLATE") ? atoi(getenv("MPMHIP_ABLATE")) : 0;
 #else
@@ -558,8 +565,13 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   }
   A(dmalloc(&c->d_groups, (size_t)c->groups_cap));
   if (e == hipSuccess && c->NB <= (1u << 21) && sort_v1 != 1) {
-    // (an optimisation's table, up to 537 MB: a device that cannot spare it keeps the four-launch sort instead of failing the create)
-    if (dmalloc(&c->cellcnt_key, (size_t)c->NB * BC) != hipSuccess) {
+    // (an optimisation's table, 256 B per block of the whole block space: 67 MB at 128^3, 537 MB from 256^3 to 508^3.  A device that
+    // cannot spare it keeps the four-launch sort instead of failing the create — or a later mpmhip_reserve, a tiled arena, the next
+    // rank sharing the device: the table is only taken while it is at most an eighth of what is free NOW, behind every other buffer)
+    size_t free_b = 0, total_b = 0;
+    const size_t table_b = (size_t)c->NB * BC * sizeof(uint32_t);
+    const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && table_b <= free_b / 8;
+    if (!room || dmalloc(&c->cellcnt_key, (size_t)c->NB * BC) != hipSuccess) {
       (void)hipGetLastError();
       c->cellcnt_key = nullptr;
       c->sort_keyed = false;
@@ -590,6 +602,28 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   }
   A(hipDeviceSynchronize());
   if (e != hipSuccess) { fail(c, MPMHIP_EHIP, "device init failed: %s", hipGetErrorString(e)); return bail(MPMHIP_EHIP); }
+  // every chained scan this ctx can launch (k_sort.h; the block-table role of k_sort_front included: its workgroups are the first of
+  // their launch): the grid the host will use must lie inside the set the device certainly keeps resident — asked of the occupancy
+  // API once, here, instead of being assumed at the first sort.  (The waits are bounded on top of it: k_sort.h.)
+  {
+#define MPM_CT_ALL(K) (const void *)K<16, false>, (const void *)K<32, false>, (const void *)K<64, false>, (const void *)K<16, true>, (const void *)K<32, true>, (const void *)K<64, true>
+    const void *scans[] = {(const void *)k_sort_front, (const void *)k_block_table, MPM_CT_ALL(k_cell_table), MPM_CT_ALL(k_cell_table_plain),
+                           (const void *)k_async_compact};
+#undef MPM_CT_ALL
+    for (const void *k : scans) {
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, 0) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        fail(c, MPMHIP_EHIP, "the occupancy query of a chained-scan kernel failed: its launch cannot be sized safely");
+        return bail(MPMHIP_EHIP);
+      }
+      if (scan_limit(c, k) > scan_resident_set(c->n_cus, per_cu)) {
+        fail(c, MPMHIP_EINVAL, "a chained scan would be launched with %u workgroups, the device keeps %u resident (MPMHIP_SCAN_GRID=%d?)",
+             scan_limit(c, k), scan_resident_set(c->n_cus, per_cu), c->scan_grid_env);
+        return bail(MPMHIP_EINVAL);
+      }
+    }
+  }
   *out = c;
   return MPMHIP_OK;
 }
@@ -624,6 +658,13 @@ int mpmhip_set_stream(mpmhip_ctx *c, void *s) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->stream = s ? (hipStream_t)s : c->own_stream;
+  return MPMHIP_OK;
+}
+
+int mpmhip_set_deterministic(mpmhip_ctx *c, int32_t enabled) {
+  if (!c) return MPMHIP_EINVAL;
+  if (c->in_substep) return fail(c, MPMHIP_EINVAL, "set_deterministic inside a substep");
+  c->deterministic = enabled != 0;
   return MPMHIP_OK;
 }
 
@@ -749,6 +790,10 @@ static int read_counters(mpmhip_ctx *c, Counters &h) {
   if (h.error & 16u)
     return fail(c, MPMHIP_EHIP, "tiled run: a peer rank's halo / migration epoch did not arrive within the wait limit "
                 "(MPMHIP_TILE_WAIT_S): a rank is missing, stalled or out of step");
+  if (h.error & SCAN_ERROR_BIT)
+    return fail(c, MPMHIP_EHIP, "sort: a chained scan waited %.0f s for a chunk that never published its sum (k_sort.h): the launch did not "
+                "fit the device's resident set (another runtime, a partitioned device, a debugger?) — lower MPMHIP_SCAN_GRID",
+                (double)SCAN_WAIT_TICKS / 1e8);
   if (h.error & 4u)
     return fail(c, MPMHIP_ECAPACITY, "the colored distance field of the rigid bodies needs more than %u pages of 4^3 nodes: "
                 "recreate the ctx with a larger max_blocks", c->rigid.max_pages);
@@ -963,14 +1008,25 @@ static inline bool rigid_active(const mpmhip_ctx *c);
 // took a second chunk behind their first — sort 98 -> 88 us, profiles/r04_l_scan_grid.txt); the margin is for kernels of a second
 // stream (CPIC) beside the scans.  Per kernel since round 5: the list forms of k_cell_table hold fewer workgroups per CU than the
 // plain ones, and the lowest of all of them would cost the plain ones their grid.
+// The arithmetic of that bound, host-only (tests/test_host_cpu.py drives it through mpmhip_debug_scan_grid).  `per_cu` = what the
+// occupancy API answers for the kernel at 256 threads.  That answer can be one workgroup per CU HIGH (MI355X guide: 256-thread blocks
+// are admitted up to min(API, 8, ...) per CU, one fewer than the API says at 81..112 SGPRs), so the set that is certainly resident is
+// min(per_cu, 8) - 1 per CU (at least 1).  Three eighths of the API's number lies inside it for every per_cu (3/8 p <= p - 1 from
+// p = 2 on; p = 1: a third of the CUs), a request from the environment is cut to half the API's number AND to that set.
+static uint32_t scan_resident_set(int n_cus, int per_cu) { return (uint32_t)(std::max(1, n_cus) * std::max(1, std::min(per_cu, 8) - 1)); }
+static uint32_t scan_grid_for(int n_cus, int per_cu, int env_request) {
+  per_cu = std::max(1, per_cu);
+  int lim = std::max(1, std::max(1, n_cus) * per_cu * 3 / 8);
+  if (env_request > 0) lim = std::max(1, std::min(env_request, std::max(1, n_cus) * per_cu / 2));
+  return std::min<uint32_t>((uint32_t)lim, scan_resident_set(n_cus, per_cu));
+}
 static uint32_t scan_limit(mpmhip_ctx *c, const void *kernel) {
   const void *key = kernel;
   auto it = c->scan_limits.find(key);
   if (it != c->scan_limits.end()) return it->second;
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-  uint32_t lim = (uint32_t)std::max(1, c->n_cus * per_cu * 3 / 8);
-  if (c->scan_grid_env > 0) lim = (uint32_t)std::max(1, std::min(c->scan_grid_env, c->n_cus * per_cu / 2));
+  const uint32_t lim = scan_grid_for(c->n_cus, per_cu, c->scan_grid_env);
   c->scan_limits[key] = lim;
   return lim;
 }
@@ -1016,6 +1072,13 @@ static int do_sort(mpmhip_ctx *c) {
   auto ct_list = ct == 16 ? MPM_CT(k_cell_table, 16) : (ct == 32 ? MPM_CT(k_cell_table, 32) : MPM_CT(k_cell_table, 64));
   auto ct_plain = ct == 16 ? MPM_CT(k_cell_table_plain, 16) : (ct == 32 ? MPM_CT(k_cell_table_plain, 32) : MPM_CT(k_cell_table_plain, 64));
   const uint32_t ct_wgs = std::min(ct_chunks, c->list_valid ? scan_limit(c, (const void *)ct_list) : scan_limit(c, (const void *)ct_plain));
+  if (c->list_valid && epoch - c->list_clear_epoch >= (1u << 22)) {
+    // the list form's scan words keep 23 bits of the epoch, and a word is only rewritten when that form runs with the chunk in use: one
+    // left from epoch e would match again at e + 2^23 (8.4 M sorts: reachable in a long run).  Zeroing them every 2^22 sorts keeps every
+    // surviving word younger than that; the epoch field 0 is never published.
+    HIPCHK(c, hipMemsetAsync(c->scan_slots + c->bt_slots + c->ct_slots, 0, sizeof(unsigned long long) * c->ct_slots, st));
+    c->list_clear_epoch = epoch;
+  }
   if (c->list_valid)  // (the two forms publish different scan words: each has its own slots)
     hipLaunchKernelGGL(ct_list, dim3(ct_wgs), dim3(256), 0, st, P,
                        c->cnt, counters, c->act_start, c->cell_start, c->scan_slots + c->bt_slots + c->ct_slots, epoch, c->rank_runs_mul,
@@ -1030,6 +1093,14 @@ static int do_sort(mpmhip_ctx *c) {
                        (const uint32_t *)c->bits, (const uint32_t *)c->wprefix);
   else
     hipLaunchKernelGGL(k_perm, dim3(pg), dim3(256), 0, st, P, (const Counters *)c->cnt, c->key, c->rank, c->cell_start, c->perm);
+  if (c->deterministic) {
+    // every cell's entries in ascending creation id (k_sort.h: k_cell_order); rank[] is idle until the next sort: the ordered index goes
+    // there and then IS the index
+    const int cg = (int)std::min<uint64_t>(8192u, ((uint64_t)P.max_blocks * BC + 255) / 256);
+    hipLaunchKernelGGL(k_cell_order, dim3(cg), dim3(256), 0, st, P, (const Counters *)c->cnt, (const uint32_t *)c->cell_start,
+                       (const uint32_t *)c->perm, (const float4 *)c->rg, c->rank);
+    std::swap(c->perm, c->rank);
+  }
   // (k_cell_table's last chunk stores (live particles, active blocks, owner entries) of this sort straight into the pinned page,
   // never waited for: the host picks the G2P walk by how full the blocks are (g2p_is_packed) and sizes the grid pass's launch
   // from numbers that may be a few substeps old — until round 5 a hipMemcpyAsync every 16th sort, i.e. a blit kernel in the loop)
@@ -1169,6 +1240,10 @@ static int do_grid(mpmhip_ctx *c, int mode, int phase = 0) {
                        c->d_boxes_cur, c->LS, phase);
     return launch_check(c, "grid");
   }
+  if (mode == 4 && c->T.n_boxes > 0)
+    // (only the owner-list walk knows which rank counts a halo node's kinetic energy — the lowest that holds mass on it; the per-block
+    // walk would add every halo node on every rank that holds it)
+    return fail(c, MPMHIP_EINVAL, "calculate_energy of a tiled ctx needs the owner-list walk of the grid pass: do not set MPMHIP_GRID_WALK=0");
   const bool per_cand = mode == 0 && c->n_slots < (2 << 20);  // small per-GPU problem: latency-bound, see k_grid.h
   auto kern = mode == 0 ? (per_cand ? k_grid_blocks<0, true> : k_grid_blocks<0, false>)
                         : (mode == 1 ? k_grid_blocks<1, false>
@@ -2180,6 +2255,7 @@ int mpmhip_reserve(mpmhip_ctx *c, int64_t max_particles) {
       A(regrow(&c->nbr, 0, m * 32, false)); A(regrow(&c->own_list, 0, m * 8, false));
       c->ct_slots = (uint32_t)((m + 15) / 16 + 1);
       A(regrow(&c->scan_slots, 0, c->bt_slots + 2 * (size_t)c->ct_slots, true));  // (epoch 0 is never used)
+      c->list_clear_epoch = c->sort_epoch;
       A(regrow(&c->tiles, 0, m * TN, false)); A(regrow(&c->gridv, 0, m * 8 * BC, false));
       if (c->rigid.d_blk_rigid) { A(regrow(&c->rigid.d_blk_rigid, 0, m + 1, true)); A(regrow(&c->rigid.d_rigid_list, 0, m + 1, false)); }
       if (e != hipSuccess) return fail(c, MPMHIP_ENOMEM, "growing the block table to %lld failed: %s", (long long)mb, hipGetErrorString(e));
@@ -2191,6 +2267,13 @@ int mpmhip_reserve(mpmhip_ctx *c, int64_t max_particles) {
   return invalidate_keys(c);
 }
 
+// the launch bound of the chained scans as a function of what the occupancy API answered (no device needed: scan_grid_for)
+int mpmhip_debug_scan_grid(int32_t n_cus, int32_t per_cu, int32_t env_request, uint32_t *limit, uint32_t *resident) {
+  if (!limit || !resident || n_cus < 1 || per_cu < 0) return MPMHIP_EINVAL;
+  *limit = scan_grid_for(n_cus, per_cu, env_request);
+  *resident = scan_resident_set(n_cus, per_cu);
+  return MPMHIP_OK;
+}
 int mpmhip_debug_g2p_is_packed(const mpmhip_ctx *c) { return c ? (g2p_is_packed(c, 0) ? 1 : 0) : MPMHIP_EINVAL; }
 int mpmhip_debug_copy_bandwidth(mpmhip_ctx *c, size_t bytes, int32_t iters, double *gb_per_s) {
   if (!c || !gb_per_s || iters <= 0 || bytes < 16) return MPMHIP_EINVAL;

@@ -410,7 +410,9 @@ int tn_mig_c(mpmhip_ctx *c) {
   bool have = M.lo[0] <= M.hi[0] && M.lo[1] <= M.hi[1] && M.lo[2] <= M.hi[2];
   if (have) {
     for (int a = 0; a < 3; a++)
-      if (M.lo[a] < N.clip_lo[a] || M.hi[a] + 2 > N.clip_hi[a])
+      // (a side where the clip box ends at the grid itself holds everything there is: with clean_boundary off, or on the clamped generic
+      // path, base cells reach res - 1, and no halo mass can lie beyond the last node)
+      if (M.lo[a] < N.clip_lo[a] || (M.hi[a] + 2 > N.clip_hi[a] && N.clip_hi[a] != c->P.res[a] + 1))
         return fail(c, MPMHIP_ECAPACITY, "tiled run: particles left the clipped halo region on axis %d between two migrations (base cells "
                     "[%d, %d), halo boxes cut to nodes [%d, %d)): their top speed more than doubled since the last check — halo sums "
                     "of the substeps in between may be incomplete; lower mpmhip_tiled_config.migrate_cap or set migrate_interval",

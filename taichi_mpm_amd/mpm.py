@@ -203,6 +203,8 @@ class Simulation3D:
         # optimized=False: the reference's generic transfer path (src/mpm.cpp:508-515,546-552).  Same kernels here; the
         # one arithmetic difference of that path, the position clamp of src/transfer.cpp:668-670, is switched on
         self.optimized = bool(cfg.get("optimized", True))
+        # bitwise reproducible runs (include/mpmhip.h: mpmhip_config.deterministic): in-cell order by creation id behind every sort
+        self.deterministic = bool(cfg.get("deterministic", False))
         self.max_particles = int(cfg.get("max_particles", 0))
         self.max_blocks = int(cfg.get("max_blocks", 0))
         self.device = int(cfg.get("device", 0))
@@ -231,6 +233,7 @@ class Simulation3D:
         c.reorder_interval = self.reorder_interval
         c.discard_apic_b = int(self.discard_apic_b)
         c.generic_path = int(not self.optimized)
+        c.deterministic = int(self.deterministic)
         ctx = C.c_void_p()
         rc = self._L.mpmhip_create(C.byref(c), C.byref(ctx))
         if rc != 0:
@@ -656,6 +659,12 @@ class Simulation3D:
         self._ensure_ctx(); self._check(self._L.mpmhip_set_profiling(self._ctx, int(level)))
         self._check(self._L.mpmhip_set_profile_sampling(self._ctx, int(every)))
         self._prof_level, self._prof_every = int(level), int(every)
+
+    def set_deterministic(self, on=True):
+        """config key `deterministic` of a live simulation, from the next sort on (include/mpmhip.h: mpmhip_set_deterministic)"""
+        self.deterministic = bool(on)
+        if self._ctx is not None:
+            self._check(self._L.mpmhip_set_deterministic(self._ctx, int(self.deterministic)))
 
     def g2p_kernel(self):
         """name of the G2P kernel the next substep's plain blocks get (measurement helper: bench.py names its roofline after it)"""

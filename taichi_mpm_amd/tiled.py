@@ -122,7 +122,10 @@ class Partition:
     def clip_holds(self, cell_lo, cell_hi):
         """did the clip box hold every node the particles touch NOW (base cell b: nodes b .. b + 2)?  If not, halo sums of the
         substeps since the last check may have missed mass outside the clipped boxes (csrc/tiled_api.h: tn_mig_c)"""
-        return all(cell_lo[a] >= self.clip[0][a] and cell_hi[a] + 2 <= self.clip[1][a] for a in range(3))
+        # (a side where the clip box ends at the grid itself holds everything there is: with clean_boundary off, or on the clamped
+        # generic path, base cells reach res - 1 and the stencil's last node res + 1 does not exist)
+        return all(cell_lo[a] >= self.clip[0][a] and (cell_hi[a] + 2 <= self.clip[1][a] or self.clip[1][a] == self.res[a] + 1)
+                   for a in range(3))
 
     def set_clip_from_bounds(self, cell_lo, cell_hi):
         s = self.clip_slack()
@@ -663,7 +666,7 @@ class NativeTiledJob(_NativeJobBase):
         e.sim._check(e.L.mpmhip_sort(e.ctx))  # (the bounds are those of the last sort: make it the current positions')
         e.sim._check(e.L.mpmhip_active_bounds(e.ctx, lo, hi))
         t = torch.tensor([-lo[0], -lo[1], -lo[2], hi[0], hi[1], hi[2]], dtype=torch.int64)
-        if list(lo) > list(hi):  # no particles on this rank
+        if any(l > h for l, h in zip(lo, hi)):  # no particles on this rank (mpmhip_active_bounds: lo = 2^30, hi = -1)
             t = torch.full((6,), -(1 << 30), dtype=torch.int64)
         if self.world > 1:
             self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
