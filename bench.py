@@ -28,7 +28,8 @@ Extra objects on the line:
                 `p2g_plus_g2p` (inside roofline): both transfer kernels together, the quantity the 40 % target of north_star is
                 set on — algorithmic bytes of SURVEY section 8(d) (252 B per particle-step + the touched nodes) over the sum of the
                 two kernels' launch times, and the PMC traffic of both from the same committed profile.
-  evolved       the same measurement (ms_per_step, phases, roofline) on the same ctx after the seeded block has
+  evolved       (+ `cond_F`: census of cond(F) over the evolved state's particles — max, quantiles, the share the eigen-solve refines)
+                the same measurement (ms_per_step, phases, roofline) on the same ctx after the seeded block has
                 fallen onto the floor and EVOLVE_AFTER_IMPACT further substeps have run: uneven cells, active
                 return map.  `value` stays the lattice the reference's benchmark seeds (config.state says so);
                 --state evolved makes the evolved state the main measurement (profiling runs), --no-evolved skips it.
@@ -793,6 +794,10 @@ def main():
                 "value": e_n * args.steps / e_el, "ms_per_step": 1e3 * e_el / args.steps, "phases_ms_per_step": e_ms,
                 "roofline": e_roof, "p2g_plus_g2p_hbm_frac_algorithmic": e_both,
                 "whole_step_hbm_frac_algorithmic": (e_n * 252.0 + e_nodes * 80.0) / (e_el / args.steps) / 1e9 / HBM_PEAK_GBS}
+            try:  # how ill-conditioned the state's deformation gradients are (the device's fp32 tolerances hold to cond(F) 1e2)
+                out["evolved"]["cond_F"] = job.sim.cond_census()
+            except Exception as e:
+                out["evolved"]["cond_F"] = {"error": repr(e)}
             if e_n < 0.99 * n_per_gpu:  # particles deleted on the way (left the domain / non-finite): not the workload any more
                 out["evolved"]["warning"] = "%d of %d particles were deleted before the timed region" % (n_per_gpu - e_n, n_per_gpu)
         except Exception as e:

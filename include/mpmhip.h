@@ -599,6 +599,13 @@ int mpmhip_debug_g2p_is_packed(const mpmhip_ctx *ctx);
 /* the launch bound of the single-pass (chained) scans of the sort as a function of the occupancy API's answer: `limit` = workgroups
  * the host launches at most, `resident` = workgroups the device certainly keeps resident (one per CU below the API's number, at most
  * 7).  Pure host arithmetic (no device): mpmhip_create checks limit <= resident for every such kernel; the waits are bounded besides. */
+/* measurement helper: census of cond(F) = sigma_max / sigma_min over the live particles of the ctx (the state as stored: elastic
+ * deformation gradients after the last return mapping).  out[0] live particles, [1] particles with cond > 8 — the ones the
+ * eigen-solve of the transfer kernels finishes on F itself —, [2] waves of 64 consecutive slots, [3] waves
+ * holding such a particle, [4] max cond, [8 + b] histogram over b = floor(8 log2 cond) (eighth-octave bins, clamped to 255).
+ * Synchronises.  (What decides whether the device's fp32 tolerances hold: they do to cond 1e2) */
+#define MPMHIP_COND_CENSUS_WORDS 264
+int mpmhip_debug_cond_census(mpmhip_ctx *ctx, double out[MPMHIP_COND_CENSUS_WORDS]);
 int mpmhip_debug_scan_grid(int32_t n_cus, int32_t per_cu, int32_t env_request, uint32_t *limit, uint32_t *resident);
 /* 64-byte record gather of KNOWN size — the access pattern of k_p2g / k_g2p (a lane fetches one whole record with four
  * 16-byte loads through an index): n (a power of two) records, index pattern 0 identity / 1 shuffled runs of 8 /

@@ -175,7 +175,7 @@ _SYMBOLS = ["mpmhip_abi_version", "mpmhip_set_profile_sampling", "mpmhip_create"
             "mpmhip_rigid_get_samples", "mpmhip_rigid_get_mesh", "mpmhip2d_rigid_get_mesh", "mpmhip_rasterize_rigid_boundary", "mpmhip_gather_cdf", "mpmhip_advect_rigid_bodies", "mpmhip_download_cdf",
             "mpmhip_add_articulation", "mpmhip_num_articulations", "mpmhip_set_articulation_iterations", "mpmhip_articulate",
             "mpmhip_download_boundary",
-            "mpmhip_debug_copy_bandwidth", "mpmhip_debug_g2p_is_packed", "mpmhip_debug_scan_grid", "mpmhip_debug_gather_bandwidth", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
+            "mpmhip_debug_copy_bandwidth", "mpmhip_debug_g2p_is_packed", "mpmhip_debug_scan_grid", "mpmhip_debug_cond_census", "mpmhip_debug_gather_bandwidth", "mpmhip_debug_svd3", "mpmhip_debug_force", "mpmhip_debug_plasticity"]
 
 
 def exported_symbols():
@@ -360,6 +360,7 @@ def load():
     L.mpmhip2d_async_current_time.restype = C.c_double
     L.mpmhip2d_async_table.argtypes = [vp, P(C.c_int32), C.c_int64] + [P(C.c_int64)] * 7
     L.mpmhip2d_async_table.restype = C.c_int64
+    L.mpmhip_debug_cond_census.argtypes = [vp, P(C.c_double)]
     L.mpmhip_debug_scan_grid.argtypes = [C.c_int32, C.c_int32, C.c_int32, P(C.c_uint32), P(C.c_uint32)]
     L.mpmhip_debug_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int32, P(C.c_double)]
     L.mpmhip_debug_gather_bandwidth.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, P(C.c_double)]

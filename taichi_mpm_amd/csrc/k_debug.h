@@ -96,5 +96,59 @@ __global__ __launch_bounds__(256) void k_debug_plasticity(GroupParams g, int64_t
   }
 }
 
+// ------------------------------------------------------------------------------------------------ cond(F) census
+// How ill-conditioned are the deformation gradients of the state a ctx holds?  Per live particle the eigen-solve of F F^T as the
+// transfer kernels run it (sym_eig3_FFt, refinement left out) -> cond(F) = sqrt(lam_max / lam_min); out: [0] live particles,
+// [1] particles with lam_min < lam_max / 64 — the ones sym_eig3_FFt hands to sym_eig3_refine (cond > 8) —, [2] waves of 64
+// consecutive slots, [3] waves holding at least one such particle, [4] max cond (float bits), [8 + b] histogram over
+// b = clamp(floor(8 log2 cond), 0, 255): eighth-octave bins (bench.py: `evolved.cond_F`; DESIGN.md section 2, table of the
+// ill-conditioned fixture: the device's tolerances hold to cond 1e2).
+constexpr int COND_BINS = 256;
+__global__ __launch_bounds__(256) void k_cond_census(Params P, const float4 *__restrict__ rg, unsigned long long *__restrict__ out) {
+  const uint32_t n = P.n_slots, stride = gridDim.x * blockDim.x;
+  const uint32_t nloop = (n + stride - 1) / stride;
+  for (uint32_t it = 0; it < nloop; it++) {  // uniform trip count (ballots)
+    const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = false, ill = false;
+    if (i < n) {
+      const float4 a = rg[(size_t)i * 4], b = rg[(size_t)i * 4 + 1], c = rg[(size_t)i * 4 + 2], d = rg[(size_t)i * 4 + 3];
+      live = __float_as_int(d.z) >= 0;
+      if (live) {
+        const float F[9] = {b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x};
+        // eigenvalues of the symmetric F F^T in double (closed form would do; a few Jacobi sweeps are simpler and exact enough here)
+        double A[3][3];
+        for (int r = 0; r < 3; r++)
+          for (int q = 0; q < 3; q++) A[r][q] = (double)F[3 * r] * F[3 * q] + (double)F[3 * r + 1] * F[3 * q + 1] + (double)F[3 * r + 2] * F[3 * q + 2];
+        for (int sweep = 0; sweep < 6; sweep++)
+          for (int pq = 0; pq < 3; pq++) {
+            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2, r = 3 - p - q;
+            const double apq = A[p][q];
+            if (fabs(apq) < 1e-300) continue;
+            const double th = 0.5 * (A[q][q] - A[p][p]) / apq;
+            const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+            const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+            const double app = A[p][p] - t * apq, aqq = A[q][q] + t * apq;
+            const double arp = cs * A[r][p] - sn * A[r][q], arq = sn * A[r][p] + cs * A[r][q];
+            A[p][p] = app; A[q][q] = aqq; A[p][q] = A[q][p] = 0.0;
+            A[r][p] = A[p][r] = arp; A[r][q] = A[q][r] = arq;
+          }
+        const double lmax = fmax(A[0][0], fmax(A[1][1], A[2][2])), lmin = fmin(A[0][0], fmin(A[1][1], A[2][2]));
+        ill = lmin < lmax / 64.0;
+        const float cond = lmin > 0.0 ? (float)sqrt(lmax / lmin) : 3.0e38f;
+        int bin = (int)floorf(8.0f * log2f(fmaxf(cond, 1.0f)));
+        bin = bin < 0 ? 0 : (bin >= COND_BINS ? COND_BINS - 1 : bin);
+        atomicAdd(&out[8 + bin], 1ull);
+        atomicMax(reinterpret_cast<unsigned int *>(&out[4]), __float_as_uint(cond));
+      }
+    }
+    const unsigned long long lv = __ballot(live), il = __ballot(ill);
+    if ((threadIdx.x & 63) == 0 && lv) {
+      atomicAdd(&out[0], (unsigned long long)__popcll(lv));
+      atomicAdd(&out[1], (unsigned long long)__popcll(il));
+      atomicAdd(&out[2], 1ull);
+      if (il) atomicAdd(&out[3], 1ull);
+    }
+  }
+}
 
 }  // namespace mpm

@@ -3281,6 +3281,32 @@ int mpmhip2d_download_grid(mpmhip2d_ctx *m, float *grid) {  // (v.x, v.y, m) per
 #include "frame2d_api.h"
 
 // ------------------------------------------------------------------------------------------------ debug math
+int mpmhip_debug_cond_census(mpmhip_ctx *c, double out[MPMHIP_COND_CENSUS_WORDS]) {
+  if (!c || !out) return MPMHIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->in_substep) return fail(c, MPMHIP_EINVAL, "cond_census inside a substep");
+  constexpr int W = 8 + COND_BINS;
+  static_assert(W == MPMHIP_COND_CENSUS_WORDS, "census layout");
+  unsigned long long *d = nullptr;
+  HIPCHK(c, dmalloc(&d, (size_t)W));
+  hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned long long) * W, c->stream);
+  std::vector<unsigned long long> h((size_t)W);
+  if (e == hipSuccess && c->n_slots > 0) {
+    hipLaunchKernelGGL(k_cond_census, dim3(particle_grid(c->n_slots)), dim3(256), 0, c->stream, c->P, (const float4 *)c->rg, d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d, sizeof(unsigned long long) * W, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  HIPCHK(c, e);
+  for (int i = 0; i < W; i++) out[i] = (double)h[i];
+  const uint32_t bits = (uint32_t)h[4];
+  float mx;
+  memcpy(&mx, &bits, 4);
+  out[4] = mx;
+  return MPMHIP_OK;
+}
+
 int mpmhip_debug_svd3(mpmhip_ctx *c, int64_t n, const float *F, float *U, float *S, float *V) {
   if (!c || n <= 0) return MPMHIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));

@@ -666,6 +666,21 @@ class Simulation3D:
         if self._ctx is not None:
             self._check(self._L.mpmhip_set_deterministic(self._ctx, int(self.deterministic)))
 
+    def cond_census(self):
+        """cond(F) = sigma_max / sigma_min over the live particles (include/mpmhip.h: mpmhip_debug_cond_census): max, quantiles from
+        the eighth-octave histogram (upper bin edges), the share of particles / waves the transfer kernels' eigen-solve refines"""
+        self._ensure_ctx()
+        out = (C.c_double * 264)()
+        self._check(self._L.mpmhip_debug_cond_census(self._ctx, out))
+        n, hist = out[0], np.asarray(out[8:264])
+        cum = np.cumsum(hist)
+
+        def q(p):
+            return float(2.0 ** ((int(np.searchsorted(cum, p * n)) + 1) / 8.0)) if n else None
+        return {"particles": int(n), "max": float(out[4]), "median": q(0.5), "p99": q(0.99), "p999": q(0.999), "p9999": q(0.9999),
+                "frac_particles_refined": out[1] / n if n else 0.0, "frac_waves_with_refinement": out[3] / out[2] if out[2] else 0.0,
+                "beyond_1e2": float(hist[int(8 * np.log2(100.0)):].sum() / n) if n else 0.0}
+
     def g2p_kernel(self):
         """name of the G2P kernel the next substep's plain blocks get (measurement helper: bench.py names its roofline after it)"""
         self._ensure_ctx()
