@@ -186,8 +186,9 @@ def test_c3_hundred_substeps_from_the_lattice_and_from_the_evolved_state_match_t
     census = sim.cond_census()
     st = sim.get_particles()
     n = len(st["x"])
+    print("cond(F) census of the evolved C3 state:", census)
     assert census["particles"] == n and 7_000_000 < n <= 8_000_000
-    assert 1.0 < census["median"] < census["p999"] <= census["max"] * 1.1
+    assert 1.0 < census["median"] <= census["p999"] <= census["max"] * 1.1  # (quantiles are upper bin edges of eighth-octave bins)
     # the census decides whether weak point "ill-conditioned F beyond cond 1e2" matters for this scene: it must stay a small minority
     assert census["beyond_1e2"] <= 1e-3, census
     r = ref.Sim(res, dx, 1e-4, shapes=shapes, friction=-1.0)
@@ -200,4 +201,3 @@ def test_c3_hundred_substeps_from_the_lattice_and_from_the_evolved_state_match_t
     keep = np.isin(st["id"], a["id"])  # (the reference numbered the uploaded particles 0..n-1 in the order of st)
     assert np.array_equal(np.nonzero(keep)[0], b["id"])   # the same particles were deleted at the walls on both sides
     _statistics_match(a, b, mass, n, "evolved")
-    print("cond(F) census of the evolved C3 state:", census)
