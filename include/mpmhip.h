@@ -339,8 +339,15 @@ int mpmhip_import_particles(mpmhip_ctx *ctx, int64_t n, const void *dev_records)
  *                      communicator when it has one (_connect with handles == NULL).
  *   MPMHIP_WIRE_LOCAL  the IPC wire between ctx of ONE process (virtual ranks on one device: tests, bench.py --virtual):
  *                      plain pointers instead of mapped ones, driven by mpmhip_tiled_advance_group.
+ *   MPMHIP_WIRE_LOCAL_RCCL  a LOCAL job whose HALO BOXES travel through RCCL all the same — the one-GPU pre-flight of the
+ *                      MPMHIP_WIRE_RCCL exchange: every ctx of the job has its own ONE-rank communicator
+ *                      (mpmhip_comm_init(ctx, id, 0, 1) before mpmhip_tiled_setup), every box is an ncclSend to the rank itself
+ *                      whose ncclRecv is aimed at the box's place in the PEER ctx's receive buffer: the same ncclGroupStart / Send
+ *                      + Recv per box / ncclGroupEnd, on the same side stream behind the same two event fences when the substep is
+ *                      split, with the one receive buffer of that wire — under real RCCL kernels next to the substep's own.
+ *                      Migration rows, records and reductions travel as on MPMHIP_WIRE_LOCAL.  The ranks must share one stream.
  * A ctx with a native plan refuses mpmhip_set_halo / mpmhip_tiled_run with a callback, and vice versa. */
-enum { MPMHIP_WIRE_RCCL = 1, MPMHIP_WIRE_IPC = 2, MPMHIP_WIRE_LOCAL = 3 };
+enum { MPMHIP_WIRE_RCCL = 1, MPMHIP_WIRE_IPC = 2, MPMHIP_WIRE_LOCAL = 3, MPMHIP_WIRE_LOCAL_RCCL = 4 };
 #define MPMHIP_COMM_ID_BYTES 128   /* sizeof(ncclUniqueId) */
 #define MPMHIP_IPC_HANDLE_BYTES 64 /* sizeof(hipIpcMemHandle_t) */
 typedef struct {

@@ -114,7 +114,7 @@ class TiledConfig(C.Structure):
 MAX_PARTS = 16
 MAX_HALO_BOXES = 64
 MIGRATE_FLOATS = 44
-WIRE_RCCL, WIRE_IPC, WIRE_LOCAL = 1, 2, 3
+WIRE_RCCL, WIRE_IPC, WIRE_LOCAL, WIRE_LOCAL_RCCL = 1, 2, 3, 4
 COMM_ID_BYTES, IPC_HANDLE_BYTES = 128, 64
 
 

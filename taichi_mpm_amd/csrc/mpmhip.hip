@@ -271,6 +271,8 @@ struct mpmhip_ctx {
     };
     struct Mig { std::vector<int64_t> counts; int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; float speed = 0.0f; int64_t total = 0, n_out = 0, n_in = 0; } mig;
     bool on = false, connected = false, exch_on_side = false;
+    bool loop_rccl = false;               // MPMHIP_WIRE_LOCAL_RCCL: a local job whose halo boxes travel by RCCL self-sends (tiled_api.h)
+    std::vector<mpmhip_ctx *> local_ctx;  // the ranks of a local job (mpmhip_tiled_connect_local)
     bool wait_merged = false, merge_signal_wait = true;  // IPC wire, no overlap split: signal + wait of a substep in one launch
     int world = 1, wire = 0;
     int clip_lo[3] = {0, 0, 0}, clip_hi[3] = {0, 0, 0};

@@ -170,7 +170,8 @@ int tn_apply_plan(mpmhip_ctx *c) {
   }
   const size_t n = N.boxes.size();
   bool empty_interior = false;
-  const bool peer_wire = N.wire == MPMHIP_WIRE_IPC || N.wire == MPMHIP_WIRE_LOCAL;
+  // (halo boxes by peer writes: the IPC and the local wire — unless the local job carries them by RCCL self-sends, N.loop_rccl)
+  const bool peer_wire = (N.wire == MPMHIP_WIRE_IPC || N.wire == MPMHIP_WIRE_LOCAL) && !N.loop_rccl;
   std::vector<DevBox> hb[2] = {std::vector<DevBox>(n), std::vector<DevBox>(n)};
   std::vector<int> idx(n);
   for (size_t i = 0; i < n; i++) {
@@ -223,14 +224,14 @@ bool tn_connected(const mpmhip_ctx *c) {
 void tn_begin_substep(mpmhip_ctx *c) {
   auto &N = c->tn;
   N.epoch++;
-  const bool peer_wire = N.wire == MPMHIP_WIRE_IPC || N.wire == MPMHIP_WIRE_LOCAL;
+  const bool peer_wire = (N.wire == MPMHIP_WIRE_IPC || N.wire == MPMHIP_WIRE_LOCAL) && !N.loop_rccl;
   c->d_boxes_cur = N.d_boxes[peer_wire ? (N.epoch & 1) : 0];
 }
 
 int tn_exchange_start(mpmhip_ctx *c) {
   auto &N = c->tn;
   if (N.boxes.empty()) return MPMHIP_OK;
-  if (N.wire != MPMHIP_WIRE_RCCL) {  // peer wires: k_halo_pack wrote the boxes into the peers' buffers; publish the epoch
+  if (N.wire != MPMHIP_WIRE_RCCL && !N.loop_rccl) {  // peer wires: k_halo_pack wrote the boxes into the peers' buffers; publish the epoch
     N.wait_merged = N.wire == MPMHIP_WIRE_IPC && !c->ov_active && N.merge_signal_wait;
     if (N.wait_merged) {  // (nothing runs between signal and wait: one launch; see k_epoch_signal_wait)
       hipLaunchKernelGGL(k_epoch_signal_wait, dim3(1), dim3(64), 0, c->stream, c->d_boxes_cur, (int)N.boxes.size(), (const uint32_t *)N.flags,
@@ -249,6 +250,14 @@ int tn_exchange_start(mpmhip_ctx *c) {
   }
   NCCLCHK(c, R->GroupStart());
   for (const auto &b : N.boxes) {
+    if (N.loop_rccl) {
+      // one-GPU pre-flight of this very path (MPMHIP_WIRE_LOCAL_RCCL): the rank's communicator has ONE rank, every box is a send to
+      // itself whose receive is aimed at the box's place in the peer ctx's receive buffer (same process: a plain pointer) — the same
+      // group of RCCL kernels on the same stream behind the same fences, with the peer's recv[0] as the single receive buffer
+      NCCLCHK(c, R->Send(N.send + b.off, (size_t)b.vol * 4, ncclFloat, 0, (ncclComm_t)N.comm, st));
+      NCCLCHK(c, R->Recv(N.peers[b.peer].recv[0] + b.peer_off, (size_t)b.vol * 4, ncclFloat, 0, (ncclComm_t)N.comm, st));
+      continue;
+    }
     NCCLCHK(c, R->Send(N.send + b.off, (size_t)b.vol * 4, ncclFloat, b.peer, (ncclComm_t)N.comm, st));
     NCCLCHK(c, R->Recv(N.recv[0] + b.off, (size_t)b.vol * 4, ncclFloat, b.peer, (ncclComm_t)N.comm, st));
   }
@@ -261,6 +270,17 @@ int tn_exchange_start(mpmhip_ctx *c) {
 int tn_exchange_wait(mpmhip_ctx *c) {
   auto &N = c->tn;
   if (N.boxes.empty()) return MPMHIP_OK;
+  if (N.loop_rccl) {
+    // (this rank's boxes were written by its PEERS' groups: their events; its own group read its send buffer: its own event.  The
+    // ranks of a local job share one stream and advance together — begin of every rank, then the ends —, so every event has been
+    // recorded for this substep when the first end waits)
+    if (N.exch_on_side) HIPCHK(c, hipStreamWaitEvent(c->stream, N.ev_b, 0));
+    for (int p : N.halo_peers) {
+      mpmhip_ctx *q = N.local_ctx[(size_t)p];
+      if (q->tn.exch_on_side) HIPCHK(c, hipStreamWaitEvent(c->stream, q->tn.ev_b, 0));
+    }
+    return MPMHIP_OK;
+  }
   if (N.wire == MPMHIP_WIRE_RCCL) {
     if (N.exch_on_side) HIPCHK(c, hipStreamWaitEvent(c->stream, N.ev_b, 0));
     return MPMHIP_OK;
@@ -627,7 +647,11 @@ int mpmhip_comm_selftest(mpmhip_ctx *c) {
 int mpmhip_tiled_setup(mpmhip_ctx *c, const mpmhip_tiled_config *cfg, const int32_t *cuts_x, const int32_t *cuts_y, const int32_t *cuts_z) {
   if (!c || !cfg || !cuts_x || !cuts_y || !cuts_z) return MPMHIP_EINVAL;
   if (c->in_substep) return fail(c, MPMHIP_EINVAL, "tiled_setup inside a substep");
-  if (cfg->wire != MPMHIP_WIRE_RCCL && cfg->wire != MPMHIP_WIRE_IPC && cfg->wire != MPMHIP_WIRE_LOCAL) return fail(c, MPMHIP_EINVAL, "unknown wire %d", cfg->wire);
+  if (cfg->wire != MPMHIP_WIRE_RCCL && cfg->wire != MPMHIP_WIRE_IPC && cfg->wire != MPMHIP_WIRE_LOCAL && cfg->wire != MPMHIP_WIRE_LOCAL_RCCL)
+    return fail(c, MPMHIP_EINVAL, "unknown wire %d", cfg->wire);
+  const bool loop_rccl = cfg->wire == MPMHIP_WIRE_LOCAL_RCCL;
+  if (loop_rccl && (!c->tn.comm || c->tn.comm_world != 1))
+    return fail(c, MPMHIP_EINVAL, "MPMHIP_WIRE_LOCAL_RCCL: every ctx of the job needs its own ONE-rank communicator (mpmhip_comm_init(ctx, id, 0, 1))");
   if (cfg->world != cfg->dims[0] * cfg->dims[1] * cfg->dims[2] || cfg->world > TN_MAX_WORLD) return fail(c, MPMHIP_EINVAL, "world %d does not match dims (at most %d ranks)", cfg->world, TN_MAX_WORLD);
   if (cfg->migrate_interval < 0 || cfg->migrate_interval > cfg->margin) return fail(c, MPMHIP_EINVAL, "migrate_interval must be in [0, margin]");
   HIPCHK(c, hipSetDevice(c->device));
@@ -640,9 +664,10 @@ int mpmhip_tiled_setup(mpmhip_ctx *c, const mpmhip_tiled_config *cfg, const int3
   tn_free(c);
   auto &N = c->tn;
   N.comm = keep_comm; N.comm_rank = keep_rank; N.comm_world = keep_world;
-  if (N.comm && (N.comm_world != cfg->world || N.comm_rank != cfg->rank)) return fail(c, MPMHIP_EINVAL, "the communicator is rank %d of %d, the partition rank %d of %d", N.comm_rank, N.comm_world, cfg->rank, cfg->world);
+  N.loop_rccl = loop_rccl;
+  if (N.comm && !loop_rccl && (N.comm_world != cfg->world || N.comm_rank != cfg->rank)) return fail(c, MPMHIP_EINVAL, "the communicator is rank %d of %d, the partition rank %d of %d", N.comm_rank, N.comm_world, cfg->rank, cfg->world);
   N.world = cfg->world;
-  N.wire = cfg->wire;
+  N.wire = loop_rccl ? MPMHIP_WIRE_LOCAL : cfg->wire;  // (everything but the halo boxes travels as on the local wire)
   for (int a = 0; a < 3; a++) {
     N.clip_lo[a] = std::max(0, cfg->clip_lo[a]);
     N.clip_hi[a] = std::min(c->P.res[a] + 1, cfg->clip_hi[a]);
@@ -688,7 +713,7 @@ int mpmhip_tiled_setup(mpmhip_ctx *c, const mpmhip_tiled_config *cfg, const int3
   N.table_bytes = table_bytes; N.recv_bytes = recv_bytes;
   N.peers.assign((size_t)N.world, mpmhip_ctx::TiledNative::Peer());
   N.peers[cfg->rank] = self;
-  if (!peer_wire) HIPCHK(c, dmalloc(&N.send, (size_t)N.halo_cap));
+  if (!peer_wire || N.loop_rccl) HIPCHK(c, dmalloc(&N.send, (size_t)N.halo_cap));
   HIPCHK(c, dmalloc(&N.row, (size_t)TN_ROW));
   HIPCHK(c, hipMemset(N.row, 0, sizeof(uint32_t) * TN_ROW));
   for (int k = 0; k < 2; k++) HIPCHK(c, dmalloc(&N.d_boxes[k], (size_t)MPMHIP_MAX_HALO_BOXES));
@@ -700,7 +725,7 @@ int mpmhip_tiled_setup(mpmhip_ctx *c, const mpmhip_tiled_config *cfg, const int3
   N.all_ranks.resize((size_t)N.world);
   for (int r = 0; r < N.world; r++) N.all_ranks[r] = r;
   HIPCHK(c, hipMemcpy(N.d_all_idx, N.all_ranks.data(), sizeof(int) * N.world, hipMemcpyHostToDevice));
-  if (N.wire == MPMHIP_WIRE_RCCL) {
+  if (N.wire == MPMHIP_WIRE_RCCL || N.loop_rccl) {
     HIPCHK(c, hipStreamCreateWithFlags(&N.side, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&N.ev_a, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&N.ev_b, hipEventDisableTiming));
@@ -775,8 +800,10 @@ int mpmhip_tiled_connect_local(mpmhip_ctx *const *ctxs, int32_t n) {
   }
   for (int r = 0; r < n; r++) {
     mpmhip_ctx *c = ctxs[r];
+    if (c->tn.loop_rccl != ctxs[0]->tn.loop_rccl) return fail(c, MPMHIP_EINVAL, "connect_local: the ranks were set up with different wires");
     for (int p = 0; p < n; p++)
       if (p != r) c->tn.peers[p] = ctxs[p]->tn.peers[p];  // (a rank's own entry describes its arena)
+    c->tn.local_ctx.assign(ctxs, ctxs + n);
     c->tn.connected = true;
     int rc = tn_apply_plan(c);
     if (rc) return rc;
@@ -821,6 +848,8 @@ int64_t mpmhip_tiled_advance_group(mpmhip_ctx *const *ctxs, int32_t n_ctx, int64
     if (rc) return rc;
     if (ctxs[r]->tn.wire != MPMHIP_WIRE_LOCAL || ctxs[r]->tn.world != n_ctx || ctxs[r]->T.rank != r)
       return fail(ctxs[r], MPMHIP_EINVAL, "advance_group: ctx %d is not rank %d of a local job of %d", r, r, n_ctx);
+    if (ctxs[r]->tn.loop_rccl && ctxs[r]->stream != ctxs[0]->stream)
+      return fail(ctxs[r], MPMHIP_EINVAL, "MPMHIP_WIRE_LOCAL_RCCL: the ranks of the job must share one stream (mpmhip_set_stream)");
   }
   for (int64_t i = 0; i < n; i++) {
     // begin of every rank (sort, [boundary] P2G, pack: the peers' boxes are written), then interior + end rank by rank
@@ -948,7 +977,7 @@ int mpmhip_tiled_state(mpmhip_ctx *c, int64_t out[8]) {
   if (!c || !out) return MPMHIP_EINVAL;
   const auto &N = c->tn;
   out[0] = N.k; out[1] = N.next_migration; out[2] = N.migrated_out; out[3] = N.migrations; out[4] = N.replans;
-  out[5] = (int64_t)N.boxes.size(); out[6] = (int64_t)N.total; out[7] = N.on ? N.wire : 0;
+  out[5] = (int64_t)N.boxes.size(); out[6] = (int64_t)N.total; out[7] = N.on ? (N.loop_rccl ? (int)MPMHIP_WIRE_LOCAL_RCCL : N.wire) : 0;
   return MPMHIP_OK;
 }
 
@@ -958,7 +987,7 @@ int32_t mpmhip_tiled_plan(mpmhip_ctx *c, int32_t capacity, mpmhip_halo_box *out)
   if (!N.on) return fail(c, MPMHIP_EINVAL, "tiled_plan needs mpmhip_tiled_setup first");
   const int32_t n = (int32_t)N.boxes.size();
   if (!out || capacity < n) return n;
-  const bool peer_wire = N.wire == MPMHIP_WIRE_IPC || N.wire == MPMHIP_WIRE_LOCAL;
+  const bool peer_wire = (N.wire == MPMHIP_WIRE_IPC || N.wire == MPMHIP_WIRE_LOCAL) && !N.loop_rccl;
   for (int32_t i = 0; i < n; i++) {
     const auto &b = N.boxes[i];
     for (int a = 0; a < 3; a++) { out[i].lo[a] = b.lo[a]; out[i].hi[a] = b.hi[a]; }

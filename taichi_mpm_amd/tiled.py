@@ -737,11 +737,18 @@ class NativeVirtualJob(_NativeJobBase):
     """all ranks of a partition as ctx of ONE process on one device, on the library's data plane (MPMHIP_WIRE_LOCAL: the
     peer-write wire with plain pointers): the K-rank == 1-ctx tests and bench.py --virtual"""
 
-    def __init__(self, engines, part, migrate_interval=None, overlap=False, inbox_records=0):
+    def __init__(self, engines, part, migrate_interval=None, overlap=False, inbox_records=0, halo_by_rccl=False):
+        """halo_by_rccl: MPMHIP_WIRE_LOCAL_RCCL — the one-GPU pre-flight of the RCCL exchange: every rank gets its own one-rank
+        communicator and its halo boxes travel as RCCL self-sends aimed at the peer ctx's receive buffer (include/mpmhip.h)"""
         assert len(engines) == part.world
         self.engines, self.part = list(engines), part
+        if halo_by_rccl:
+            for e in engines:
+                ident = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+                e.sim._check(e.L.mpmhip_comm_unique_id(ident))
+                e.sim._check(e.L.mpmhip_comm_init(e.ctx, ident, 0, 1))
         for r, e in enumerate(engines):
-            native_setup(e, part, r, _lib.WIRE_LOCAL, migrate_interval, overlap, inbox_records)
+            native_setup(e, part, r, _lib.WIRE_LOCAL_RCCL if halo_by_rccl else _lib.WIRE_LOCAL, migrate_interval, overlap, inbox_records)
         self._arr = (C.c_void_p * len(engines))(*[e.ctx for e in engines])
         L = engines[0].L
         self._group_check(L.mpmhip_tiled_connect_local(self._arr, len(engines)), "mpmhip_tiled_connect_local")

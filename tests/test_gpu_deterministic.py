@@ -85,16 +85,17 @@ def _det_sim(tm, s, sel, ids, cap, device=0):
     return sim
 
 
-def _virtual(tm, world, overlap, steps):
+def _virtual(tm, world, overlap, steps, halo_by_rccl=False):
     from taichi_mpm_amd import tiled
     s = _two_material_state()
     ids = np.arange(s.n)
     part = tiled.Partition.balanced((RES,) * 3, world, s.x, DX, margin=2)
     owner = part.rank_of_cells(tiled.base_cells(s.x, DX))
     sims = [_det_sim(tm, s, owner == r, ids, s.n + 1024) for r in range(world)]
-    job = tiled.NativeVirtualJob([tiled.HipEngine(sim, 0) for sim in sims], part, migrate_interval=2, overlap=overlap)
+    job = tiled.NativeVirtualJob([tiled.HipEngine(sim, 0) for sim in sims], part, migrate_interval=2, overlap=overlap, halo_by_rccl=halo_by_rccl)
     job.run(steps)
     got, st = _gather(sims), job.state()
+    assert all(t["wire"] == (4 if halo_by_rccl else 3) for t in st)
     for sim in sims:
         sim.close()
     assert sum(t["migrated_out"] for t in st) > 0, "the scene must exercise migration"
@@ -179,5 +180,21 @@ def test_two_processes_over_the_ipc_wire_give_the_bits_of_two_virtual_ranks(tm, 
     order = np.argsort(got["id"], kind="stable")
     got = {k: v[order] for k, v in got.items()}
     assert np.array_equal(got["id"], want["id"])
+    for f in FIELDS + ("B",):
+        assert np.array_equal(got[f], want[f]), (f, float(np.abs(got[f] - want[f]).max()))
+
+
+@pytest.mark.parametrize("overlap", [False, True], ids=["serial", "overlap_split"])
+@pytest.mark.parametrize("world", [2, 8])
+def test_rccl_exchange_path_preflight_on_one_gpu_gives_the_bits_of_the_local_wire(tm, world, overlap):
+    """MPMHIP_WIRE_LOCAL_RCCL: the halo boxes of a K-rank job on ONE GPU through the code of the RCCL wire — ncclGroupStart, one
+    ncclSend + ncclRecv per box, ncclGroupEnd, on the side stream fenced by two events when the substep is split, ONE receive buffer
+    (the peer-write wires have two) — as self-sends on a one-rank communicator per rank whose receives land in the peer ctx's buffer.
+    200 substeps with migrations every 2, real RCCL kernels between the substep's own: every bit must equal the local wire's.  What
+    stays untested without a second GPU is the transport under RCCL, not the ordering of the exchange against the kernels."""
+    steps = 200
+    want = _virtual(tm, world, overlap, steps)
+    got = _virtual(tm, world, overlap, steps, halo_by_rccl=True)
+    assert np.array_equal(got["id"], want["id"]) and len(got["id"]) > 1000
     for f in FIELDS + ("B",):
         assert np.array_equal(got[f], want[f]), (f, float(np.abs(got[f] - want[f]).max()))
