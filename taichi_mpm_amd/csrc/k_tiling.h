@@ -6,48 +6,53 @@
 namespace mpm {
 
 // ------------------------------------------------------------------------------------------------ tiling
-// This rank's partial (m v, m) sums on every halo box -> the box's send buffer.  One thread per box node: the
-// node's grid block c and the <= 8 active source blocks c - q whose 6^3 tiles overlap it (same sum as k_grid).
-// Peer-write wires: B.send is the box's place in the peer's receive buffer, so the pack IS the exchange; k_epoch_signal,
+// This rank's partial (m v, m) sums on every halo box -> the box's send buffer.  One WAVE per grid block (4^3 nodes) a box touches,
+// one lane per node: lanes 0..7 look the <= 8 active source blocks c - q up whose 6^3 tiles overlap the block (once per wave — until
+// round 6 every NODE did its own eight bitmap lookups: 9.9 us for the 200 k box nodes of a rank of eight bricks, as long as the grid
+// pass itself), every lane sums its node's tile values in the order q = 0..7 (the same sum as k_grid).  Lanes whose node lies outside
+// the box (blocks cut by its faces) store nothing.
+// Peer-write wires: B.send is the box's place in the PEER's receive buffer, so the pack IS the exchange; k_epoch_signal,
 // launched behind it, publishes the substep's epoch in every peer's flag word.
 __global__ __launch_bounds__(256) void k_halo_pack(Params P, Tiling T, const DevBox *__restrict__ boxes,
                                                    const uint32_t *__restrict__ bits,
                                                    const uint32_t *__restrict__ wprefix,
                                                    const float4 *__restrict__ tiles) {
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T.box_nodes; t += gridDim.x * blockDim.x) {
-    // the node's box: the offsets ascend, so its index is the number of boxes that start at or before t (independent
+  const int l = threadIdx.x & 63, lx = l >> 4, ly = (l >> 2) & 3, lz = l & 3;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t w = wave; w < T.box_blocks; w += nwaves) {
+    // the block's box: the offsets ascend, so its index is the number of boxes that start at or before w (independent
     // wave-uniform loads: one round trip instead of a chain of them)
     int b = 0;
-    for (int i = 1; i < T.n_boxes; i++) b += t >= boxes[i].off ? 1 : 0;
+    for (int i = 1; i < T.n_boxes; i++) b += w >= boxes[i].boff ? 1 : 0;
     const DevBox &B = boxes[b];
-    const uint32_t r = t - B.off;
-    const int z = r % B.dim[2], y = (r / B.dim[2]) % B.dim[1], x = r / (B.dim[2] * B.dim[1]);
-    const int gi = B.lo[0] + x, gj = B.lo[1] + y, gk = B.lo[2] + z;
-    const int cx = gi >> 2, cy = gj >> 2, cz = gk >> 2, lx = gi & 3, ly = gj & 3, lz = gk & 3;
-    // the <= 8 lookups first (independent: one round trip), then the tiles (one more)
-    uint32_t slot[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int qx = q >> 2, qy = (q >> 1) & 1, qz = q & 1;
-      const int sx = cx - qx, sy = cy - qy, sz = cz - qz;
-      const int tx = lx + 4 * qx, ty = ly + 4 * qy, tz = lz + 4 * qz;
-      slot[q] = INVALID;
-      if (sx < 0 || sy < 0 || sz < 0 || tx >= TS || ty >= TS || tz >= TS) continue;
-      const uint32_t bk = morton3(sx, sy, sz);
-      if (bk >= P.nbw * 32u || !block_active(bits, bk)) continue;
-      const uint32_t s = block_slot(bits, wprefix, bk);
-      if (s < P.max_blocks) slot[q] = s;
+    const uint32_t r = w - B.boff;
+    const int nb1 = box_blocks_axis(B.lo[1], B.dim[1]), nb2 = box_blocks_axis(B.lo[2], B.dim[2]);
+    const int cz = (B.lo[2] >> 2) + (int)(r % (uint32_t)nb2), cy = (B.lo[1] >> 2) + (int)((r / (uint32_t)nb2) % (uint32_t)nb1),
+              cx = (B.lo[0] >> 2) + (int)(r / (uint32_t)(nb2 * nb1));
+    uint32_t s = INVALID;
+    if (l < 8) {
+      const int sx = cx - (l >> 2), sy = cy - ((l >> 1) & 1), sz = cz - (l & 1);
+      if (sx >= 0 && sy >= 0 && sz >= 0) {
+        const uint32_t bk = morton3(sx, sy, sz);
+        if (bk < P.nbw * 32u && block_active(bits, bk)) {
+          const uint32_t t = block_slot(bits, wprefix, bk);
+          if (t < P.max_blocks) s = t;
+        }
+      }
     }
+    const int x = cx * BS + lx - B.lo[0], y = cy * BS + ly - B.lo[1], z = cz * BS + lz - B.lo[2];
+    const bool inbox = (unsigned)x < (unsigned)B.dim[0] && (unsigned)y < (unsigned)B.dim[1] && (unsigned)z < (unsigned)B.dim[2];
     float4 acc = make_float4(0, 0, 0, 0);
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-      const int qx = q >> 2, qy = (q >> 1) & 1, qz = q & 1;
-      const int tx = lx + 4 * qx, ty = ly + 4 * qy, tz = lz + 4 * qz;
-      if (slot[q] == INVALID) continue;
-      const float4 v = tiles[(size_t)slot[q] * TN + (tx * TS + ty) * TS + tz];
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      const uint32_t sslot = __shfl(s, q);  // wave-uniform
+      const int tx = lx + 4 * (q >> 2), ty = ly + 4 * ((q >> 1) & 1), tz = lz + 4 * (q & 1);
+      if (sslot != INVALID && inbox && tx < TS && ty < TS && tz < TS) {
+        const float4 v = tiles[(size_t)sslot * TN + (tx * TS + ty) * TS + tz];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
     }
-    B.send[r] = acc;
+    if (inbox) B.send[((size_t)x * B.dim[1] + y) * B.dim[2] + z] = acc;
   }
 }
 
@@ -62,6 +67,20 @@ __global__ __launch_bounds__(64) void k_epoch_signal(const DevBox *__restrict__ 
   const int b = threadIdx.x;
   if (b == 0) __atomic_thread_fence(__ATOMIC_RELEASE);  // (system scope)
   if (b < n) __hip_atomic_store(boxes[b].flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// the same for ALL ranks of a local job in one launch (mpmhip_tiled_advance_group: the ranks share a stream, so one kernel boundary
+// behind the last rank's k_halo_pack orders every rank's stores): workgroup r publishes rank r's epoch in its peers' flag words.  A rank
+// of a real job pays ONE launch for signal + wait (k_epoch_signal_wait); K virtual ranks paid 2 K until round 6, now K + 1.
+struct SignalGroup {
+  const DevBox *boxes[MPMHIP_MAX_HALO_BOXES];
+  int n[MPMHIP_MAX_HALO_BOXES];
+  uint32_t epoch[MPMHIP_MAX_HALO_BOXES];
+};
+__global__ __launch_bounds__(64) void k_epoch_signal_group(SignalGroup G) {
+  const int r = blockIdx.x, b = threadIdx.x;
+  if (b == 0) __atomic_thread_fence(__ATOMIC_RELEASE);  // (system scope)
+  if (b < G.n[r]) __hip_atomic_store(G.boxes[r][b].flag, G.epoch[r], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // signal + wait in ONE launch (the IPC wire without the overlap split: nothing runs between the two, and a launch costs ~3.7 us of a

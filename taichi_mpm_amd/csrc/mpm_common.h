@@ -99,6 +99,7 @@ struct Tiling {
   int margin;
   int n_boxes;
   uint32_t box_nodes;        // total nodes over all halo boxes
+  uint32_t box_blocks;       // total 4^3-node grid blocks over all halo boxes (a block cut by a box's faces counts whole): k_halo_pack's work items
   int int_lo[3], int_hi[3];  // node box that no halo box intersects (fast path of k_grid)
 };
 // Exchange/compute overlap of a tiled substep: work is split by whether it can touch a halo node.
@@ -131,11 +132,18 @@ struct DevBox {
   int lo[3], dim[3];
   int peer;
   uint32_t off;  // first node of this box in the concatenated (all boxes) node numbering
+  uint32_t boff; // first grid block of this box in the concatenated block numbering (k_halo_pack: one wave per block)
   float4 *send;        // where k_halo_pack writes this rank's partial sums: a local send buffer, or — peer-write wires
                        // (tiled_api.h) — the box's place in the PEER's receive buffer, mapped into this process
   const float4 *recv;  // the peer's partial sums, read by k_grid
   uint32_t *flag;      // peer-write wires: this rank's word in the peer's array of halo epochs (else nullptr)
 };
+
+// grid blocks (4^3 nodes) a halo box [lo, lo + dim) touches per axis, and in all
+__host__ __device__ __forceinline__ int box_blocks_axis(int lo, int dim) { return ((lo + dim - 1) >> 2) - (lo >> 2) + 1; }
+__host__ __device__ __forceinline__ uint32_t box_blocks_of(const int lo[3], const int dim[3]) {
+  return (uint32_t)box_blocks_axis(lo[0], dim[0]) * (uint32_t)box_blocks_axis(lo[1], dim[1]) * (uint32_t)box_blocks_axis(lo[2], dim[2]);
+}
 
 // ------------------------------------------------------------------------------------------------ Morton
 __host__ __device__ __forceinline__ uint32_t spread3(uint32_t v) {

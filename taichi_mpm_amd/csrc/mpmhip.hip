@@ -271,6 +271,7 @@ struct mpmhip_ctx {
     };
     struct Mig { std::vector<int64_t> counts; int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; float speed = 0.0f; int64_t total = 0, n_out = 0, n_in = 0; } mig;
     bool on = false, connected = false, exch_on_side = false;
+    bool defer_signal = false, signal_deferred = false;  // local job: the ranks' epochs are published by ONE launch of the group (tiled_api.h)
     bool loop_rccl = false;               // MPMHIP_WIRE_LOCAL_RCCL: a local job whose halo boxes travel by RCCL self-sends (tiled_api.h)
     std::vector<mpmhip_ctx *> local_ctx;  // the ranks of a local job (mpmhip_tiled_connect_local)
     bool wait_merged = false, merge_signal_wait = true;  // IPC wire, no overlap split: signal + wait of a substep in one launch
@@ -1461,7 +1462,7 @@ static int collect_events(mpmhip_ctx *c) {
 
 static int do_halo_pack(mpmhip_ctx *c) {
   if (c->T.n_boxes == 0) return MPMHIP_OK;
-  int nb = (int)((c->T.box_nodes + 255) / 256);
+  int nb = (int)((c->T.box_blocks + 3) / 4);  // one wave per grid block of a box
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(k_halo_pack, dim3(nb), dim3(256), 0, c->stream, c->P, c->T, c->d_boxes_cur, c->bits, c->wprefix,
                      (const float4 *)c->tiles);
@@ -2069,7 +2070,7 @@ int mpmhip_set_halo(mpmhip_ctx *c, int32_t n, const mpmhip_halo_box *boxes) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   Tiling &T = c->T;
-  T.n_boxes = 0; T.box_nodes = 0;
+  T.n_boxes = 0; T.box_nodes = 0; T.box_blocks = 0;
   if (n == 0) return MPMHIP_OK;
   // node box this rank's particles can touch: base cells in [lo-margin, hi+margin), stencil base..base+2
   int nlo[3], nhi[3];
@@ -2080,6 +2081,7 @@ int mpmhip_set_halo(mpmhip_ctx *c, int32_t n, const mpmhip_halo_box *boxes) {
   }
   std::vector<DevBox> hb((size_t)n);
   uint64_t off = 0;
+  uint32_t boff = 0;
   bool empty_interior = false;
   for (int i = 0; i < n; i++) {
     const mpmhip_halo_box &b = boxes[i];
@@ -2097,7 +2099,8 @@ int mpmhip_set_halo(mpmhip_ctx *c, int32_t n, const mpmhip_halo_box *boxes) {
       else empty_interior = true;
     }
     if (!proper) empty_interior = true;
-    hb[i].peer = b.peer; hb[i].off = (uint32_t)off;
+    hb[i].peer = b.peer; hb[i].off = (uint32_t)off; hb[i].boff = boff;
+    boff += box_blocks_of(hb[i].lo, hb[i].dim);
     hb[i].send = (float4 *)b.send; hb[i].recv = (const float4 *)b.recv; hb[i].flag = nullptr;
     off += (uint64_t)hb[i].dim[0] * hb[i].dim[1] * hb[i].dim[2];
     if (off >= (1ull << 31)) return fail(c, MPMHIP_EINVAL, "halo boxes too large");
@@ -2106,7 +2109,7 @@ int mpmhip_set_halo(mpmhip_ctx *c, int32_t n, const mpmhip_halo_box *boxes) {
   if (!c->d_boxes) HIPCHK(c, dmalloc(&c->d_boxes, (size_t)MPMHIP_MAX_HALO_BOXES));
   HIPCHK(c, hipMemcpy(c->d_boxes, hb.data(), sizeof(DevBox) * n, hipMemcpyHostToDevice));
   c->d_boxes_cur = c->d_boxes;
-  T.n_boxes = n; T.box_nodes = (uint32_t)off;
+  T.n_boxes = n; T.box_nodes = (uint32_t)off; T.box_blocks = boff;
   return MPMHIP_OK;
 }
 

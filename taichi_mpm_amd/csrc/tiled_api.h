@@ -161,7 +161,7 @@ int tn_apply_plan(mpmhip_ctx *c) {
   }
   // the overlap-free interior of this rank's node box and the device tables (as mpmhip_set_halo)
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  T.n_boxes = 0; T.box_nodes = 0;
+  T.n_boxes = 0; T.box_nodes = 0; T.box_blocks = 0;
   int nlo[3], nhi[3];
   for (int a = 0; a < 3; a++) {
     nlo[a] = std::max(0, T.lo[a] - T.margin);
@@ -169,6 +169,7 @@ int tn_apply_plan(mpmhip_ctx *c) {
     T.int_lo[a] = nlo[a]; T.int_hi[a] = nhi[a];
   }
   const size_t n = N.boxes.size();
+  uint32_t boff = 0;
   bool empty_interior = false;
   // (halo boxes by peer writes: the IPC and the local wire — unless the local job carries them by RCCL self-sends, N.loop_rccl)
   const bool peer_wire = (N.wire == MPMHIP_WIRE_IPC || N.wire == MPMHIP_WIRE_LOCAL) && !N.loop_rccl;
@@ -188,7 +189,7 @@ int tn_apply_plan(mpmhip_ctx *c) {
     for (int par = 0; par < 2; par++) {
       DevBox &d = hb[par][i];
       for (int a = 0; a < 3; a++) { d.lo[a] = b.lo[a]; d.dim[a] = b.hi[a] - b.lo[a]; }
-      d.peer = b.peer; d.off = (uint32_t)b.off;
+      d.peer = b.peer; d.off = (uint32_t)b.off; d.boff = boff;
       if (peer_wire) {
         const auto &P = N.peers[b.peer];
         d.send = P.recv[par] ? P.recv[par] + b.peer_off : nullptr;  // (nullptr until the peers are connected)
@@ -201,6 +202,7 @@ int tn_apply_plan(mpmhip_ctx *c) {
       }
     }
     idx[i] = b.peer;
+    boff += box_blocks_of(hb[0][i].lo, hb[0][i].dim);
   }
   if (empty_interior) for (int a = 0; a < 3; a++) T.int_hi[a] = T.int_lo[a];
   if (n) {
@@ -208,7 +210,7 @@ int tn_apply_plan(mpmhip_ctx *c) {
     HIPCHK(c, hipMemcpy(N.d_halo_idx, idx.data(), sizeof(int) * n, hipMemcpyHostToDevice));
   }
   N.halo_peers = idx;
-  T.n_boxes = (int)n; T.box_nodes = (uint32_t)total;
+  T.n_boxes = (int)n; T.box_nodes = (uint32_t)total; T.box_blocks = boff;
   c->d_boxes_cur = N.d_boxes[peer_wire ? (N.epoch & 1) : 0];
   return MPMHIP_OK;
 }
@@ -237,6 +239,10 @@ int tn_exchange_start(mpmhip_ctx *c) {
       hipLaunchKernelGGL(k_epoch_signal_wait, dim3(1), dim3(64), 0, c->stream, c->d_boxes_cur, (int)N.boxes.size(), (const uint32_t *)N.flags,
                          (const int *)N.d_halo_idx, (int)N.halo_peers.size(), N.epoch, N.timeout_ticks, c->cnt);
       return launch_check(c, "epoch_signal_wait");
+    }
+    if (N.defer_signal && !c->ov_active) {  // (mpmhip_tiled_advance_group publishes every rank's epoch with one launch)
+      N.signal_deferred = true;
+      return MPMHIP_OK;
     }
     hipLaunchKernelGGL(k_epoch_signal, dim3(1), dim3(64), 0, c->stream, c->d_boxes_cur, (int)N.boxes.size(), N.epoch);
     return launch_check(c, "epoch_signal");
@@ -851,11 +857,33 @@ int64_t mpmhip_tiled_advance_group(mpmhip_ctx *const *ctxs, int32_t n_ctx, int64
     if (ctxs[r]->tn.loop_rccl && ctxs[r]->stream != ctxs[0]->stream)
       return fail(ctxs[r], MPMHIP_EINVAL, "MPMHIP_WIRE_LOCAL_RCCL: the ranks of the job must share one stream (mpmhip_set_stream)");
   }
+  // ranks that share ONE stream publish their halo epochs with one launch behind the last rank's pack (k_epoch_signal_group)
+  bool one_stream = n_ctx > 1 && n_ctx <= MPMHIP_MAX_HALO_BOXES && !(getenv("MPMHIP_TILE_GROUP_SIGNAL") && atoi(getenv("MPMHIP_TILE_GROUP_SIGNAL")) == 0);
+  for (int r = 1; r < n_ctx; r++) one_stream = one_stream && ctxs[r]->stream == ctxs[0]->stream && ctxs[r]->device == ctxs[0]->device;
   for (int64_t i = 0; i < n; i++) {
     // begin of every rank (sort, [boundary] P2G, pack: the peers' boxes are written), then interior + end rank by rank
     for (int r = 0; r < n_ctx; r++) {
+      ctxs[r]->tn.defer_signal = one_stream && !ctxs[r]->tn.loop_rccl;  // (only inside this loop: energy / reductions signal per rank)
+      ctxs[r]->tn.signal_deferred = false;
       int rc = tn_substep_parts(ctxs[r], 0);
+      ctxs[r]->tn.defer_signal = false;
       if (rc) { ctxs[r]->in_substep = false; ctxs[r]->cur_ev = nullptr; return rc; }
+    }
+    {
+      SignalGroup G;
+      memset(&G, 0, sizeof G);
+      bool any = false;
+      for (int r = 0; r < n_ctx; r++) {
+        auto &N = ctxs[r]->tn;
+        if (!N.signal_deferred) continue;
+        N.signal_deferred = false;
+        G.boxes[r] = ctxs[r]->d_boxes_cur; G.n[r] = (int)N.boxes.size(); G.epoch[r] = N.epoch;
+        any = true;
+      }
+      if (any) {
+        hipLaunchKernelGGL(k_epoch_signal_group, dim3(n_ctx), dim3(64), 0, ctxs[0]->stream, G);
+        if (int rc = launch_check(ctxs[0], "epoch_signal_group")) return rc;
+      }
     }
     for (int r = 0; r < n_ctx; r++)
       for (int part = 1; part < 3; part++) {
