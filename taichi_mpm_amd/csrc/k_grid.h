@@ -236,6 +236,9 @@ __global__ __launch_bounds__(256) void k_grid_blocks(Params P, const Counters *_
         const int nidx = nb27(ox - qx, oy - qy, oz - qz);
         const uint32_t sslot = __shfl(nslot, nidx);
         const int tx = lx + 4 * qx, ty = ly + 4 * qy, tz = lz + 4 * qz;
+        // (ablation builds only, results invalid: 5 of the 8 overlapping tiles read — the fold union tiles of 2 x 2 x 1 quads would
+        // leave: experiments/p2g_quad_tiles/)
+        if (MPM_ABLATE(P, 128) && q >= 5) continue;
         if (((amask >> nidx) & 1u) && tx < TS && ty < TS && tz < TS) {
           const float4 t = tiles[(size_t)sslot * TN + (tx * TS + ty) * TS + tz];
           acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;

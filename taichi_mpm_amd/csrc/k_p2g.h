@@ -225,6 +225,9 @@ __global__ __launch_bounds__(64 * NS * PS, MINW) void k_p2g(Params P, const floa
     }
     __syncthreads();
     for (int t = threadIdx.x; t < TN; t += NT) {
+      // (ablation builds only, results invalid: 150 of the 216 nodes written — what a 10 x 10 x 6 union tile per 2 x 2 x 1 quad of blocks
+      // would write per block, 600 / 4: the upper bound of experiments/p2g_quad_tiles/)
+      if (MPM_ABLATE(P, 64) && t >= 150) continue;
       float4 u = tile[0][t];
 #pragma unroll
       for (int w = 1; w < NW * MC; w++) {

@@ -81,7 +81,7 @@ struct Params {
   int test_small_rank;  // TEST KNOB (env MPMHIP_TEST_SMALL_RANK, results valid): a 3-bit rank field in k_rank's packed words
   int ablate;        // only read by -DMPMHIP_ABLATE_BUILD libraries (profiles/ A/B builds; results invalid): env MPMHIP_ABLATE,
                      // 1 no G2P stores, 2 no constitutive update, 4 no 27-tap gather, 8 no P2G merge, 16 / 32 P2G capped at 8 / 6
-                     // particles per cell.  The default
+                     // particles per cell, 64 / 128 P2G writes 150 of 216 tile nodes / the grid pass reads 5 of 8 tiles (quad-tile bound).  The default
                      // library compiles every use of it away (MPM_ABLATE below is the constant false).
 };
 #ifdef MPMHIP_ABLATE_BUILD
