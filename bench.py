@@ -777,7 +777,7 @@ def main():
             job.sim.set_deterministic(False)
             out["deterministic"] = {"ms_per_step": 1e3 * d_el / args.steps, "value": n_total * args.steps / d_el,
                                     "extra_ms_per_step": 1e3 * (d_el - elapsed) / args.steps,
-                                    "what": "mpmhip_config.deterministic: k_cell_order behind every sort (in-cell order by creation id)"}
+                                    "what": "mpmhip_config.deterministic: k_cell_order_blocks behind every sort (in-cell order by creation id; the ids in a 4-byte array the key writers keep)"}
         except Exception as e:
             out["deterministic"] = {"error": repr(e)}
     if world == 1 and not force_tiled and args.state == "lattice" and not args.no_evolved:

@@ -309,6 +309,9 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p(Params P, const float4 *__rest
       }
     }
     __builtin_amdgcn_wave_barrier();
+    // deterministic mode: the creation id beside the key (mpm_common.h: Params::pidc).  Here, behind the record stores, not next to the
+    // key's store in g2p_particle: there the two address registers raised the packed kernels from 167 to 169 VGPRs (a workgroup per CU less)
+    if (P.pidc && out_slot != INVALID) P.pidc[out_slot] = __float_as_uint(G3.z);
     flag_block(blk_flag, bkey);
     cur = nx; nx = nn;
     i_cur = i_nx; i_nx = i_nn;

@@ -201,6 +201,7 @@ __global__ __launch_bounds__(NT, MINW) void k_g2p_packed(Params P, const float4 
         }
       }
       __builtin_amdgcn_wave_barrier();
+      if (P.pidc && out_slot != INVALID) P.pidc[out_slot] = __float_as_uint(G3.z);  // (deterministic mode: the id beside the key, see k_g2p)
       flag_block(blk_flag, bkey);
       if (st[G2P_PK] >= p1 || ab + G2P_PK >= na) break;  // uniform: the window reached the end of the chunk
       ab += G2P_PK;

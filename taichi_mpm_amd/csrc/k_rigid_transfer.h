@@ -446,6 +446,7 @@ __global__ __launch_bounds__(256, MPM_RIGID_G2P_MINW) void k_g2p_rigid(Params P,
           atomicAdd(&cnt_w->n_dead, 1u);
         }
         key[p] = kk;
+        if (P.pidc) P.pidc[p] = (uint32_t)pid;
         const size_t o = p;
         rg_out[o * 4 + 0] = make_float4(nx0, nx1, nx2, aux);
         rg_out[o * 4 + 1] = make_float4(F.m[0], F.m[1], F.m[2], F.m[3]);

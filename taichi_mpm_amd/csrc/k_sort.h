@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void k_build_keys(Params P, RecG *__restrict__
         }
       }
       key[i] = kk;
+      if (P.pidc) P.pidc[i] = (uint32_t)pid;  // (read AFTER a deletion above would be -1 as well: a dead slot is in no cell)
     }
     flag_block(blk_flag, bkey);
   }
@@ -821,9 +822,59 @@ __global__ __launch_bounds__(256) void k_perm_keyed(Params P, const Counters *__
 // records — up to 16 independent loads, one round trip —, every entry's place is the number of smaller ids, the ordered entries
 // go to `out` (rank[], idle between k_perm and the next sort: do_sort swaps the two arrays).  Fuller cells count through memory,
 // a cell of more than 64 particles with its whole wave.
-__device__ __forceinline__ uint32_t pid_of(const float4 *__restrict__ rg, uint32_t slot) {
-  return __float_as_uint(rg[(size_t)slot * 4 + 3].z);  // RecG.pid (>= 0 for every entry of the sorted index)
+// COMPACT = the ids come from Params::pidc (4 bytes per slot, written by whoever wrote the slot's key: the records' writers in the
+// deterministic mode) — 32 MB gathered at 8 M particles instead of one 64-byte record line per particle (512 MB);
+// otherwise from the records (a ctx whose keys were written before the mode was switched on): 147 us of gathered record lines at C3.
+template <bool COMPACT>
+__device__ __forceinline__ uint32_t pid_of(const Params &P, const float4 *__restrict__ rg, uint32_t slot) {
+  if constexpr (COMPACT) return P.pidc[slot];
+  else return __float_as_uint(rg[(size_t)slot * 4 + 3].z);  // RecG.pid (>= 0 for every entry of the sorted index)
 }
+// the 64 cells of one block, one lane per cell, straight from global memory (cells of any size; the whole wave calls it)
+template <bool COMPACT>
+__device__ __forceinline__ void cell_order_lanes(const Params &P, const uint32_t *__restrict__ perm, const float4 *__restrict__ rg,
+                                                 uint32_t *__restrict__ out, const uint32_t s, const uint32_t n, const uint32_t lane) {
+  if (n == 1u) {
+    out[s] = perm[s];
+  } else if (n > 1u && n <= 16u) {
+    uint32_t pv[16], id[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) pv[i] = (uint32_t)i < n ? perm[s + i] : 0u;
+#pragma unroll
+    for (int i = 0; i < 16; i++) id[i] = (uint32_t)i < n ? pid_of<COMPACT>(P, rg, pv[i]) : INVALID;  // (the padding is smaller than nothing)
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      if ((uint32_t)i < n) {
+        uint32_t r = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) r += id[j] < id[i] ? 1u : 0u;
+        out[s + r] = pv[i];
+      }
+    }
+  } else if (n > 16u && n <= 64u) {
+    for (uint32_t i = 0; i < n; i++) {
+      const uint32_t slot = perm[s + i], pi = pid_of<COMPACT>(P, rg, slot);
+      uint32_t r = 0;
+      for (uint32_t j = 0; j < n; j++) r += pid_of<COMPACT>(P, rg, perm[s + j]) < pi ? 1u : 0u;
+      out[s + r] = slot;
+    }
+  }
+  unsigned long long big = __ballot(n > 64u);
+  while (big) {
+    const int l = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const uint32_t bs = __shfl(s, l), bn = __shfl(n, l);
+    for (uint32_t i = lane; i < bn; i += 64u) {
+      const uint32_t slot = perm[bs + i], pi = pid_of<COMPACT>(P, rg, slot);
+      uint32_t r = 0;
+      for (uint32_t j = 0; j < bn; j++) r += pid_of<COMPACT>(P, rg, perm[bs + j]) < pi ? 1u : 0u;
+      out[bs + r] = slot;
+    }
+  }
+}
+// One lane per cell over the whole cell table (the round-6 first form; kept for A/B: MPMHIP_CELL_ORDER=0).  Adjacent lanes read
+// perm[] / write out[] at a stride of their cells' sizes: every instruction touches 64 different 32-byte sectors.
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void k_cell_order(Params P, const Counters *__restrict__ cnt, const uint32_t *__restrict__ cell_start,
                                                     const uint32_t *__restrict__ perm, const float4 *__restrict__ rg,
                                                     uint32_t *__restrict__ out) {
@@ -834,43 +885,92 @@ __global__ __launch_bounds__(256) void k_cell_order(Params P, const Counters *__
     const uint32_t c = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t s = 0, n = 0;
     if (c < ncell) { s = cell_start[c]; n = cell_start[c + 1] - s; }
-    if (n == 1u) {
-      out[s] = perm[s];
-    } else if (n <= 16u) {
-      uint32_t pv[16], id[16];
+    cell_order_lanes<COMPACT>(P, perm, rg, out, s, n, lane);
+  }
+}
+// One WAVE per active block (the default): the block's entries of perm[] and their ids are staged in LDS by coalesced loads
+// (entry e of the block by lane e mod 64), a lane orders its cell there, the ordered entries leave by coalesced stores — the global
+// traffic is perm[] once, the ids once, out[] once, all in full lines.  The ordered entries overwrite the staged ones (a lane holds
+// its cell's entries in registers by then); a cell of more than 16 particles stores straight to out[] and leaves INVALID behind (no
+// slot number: the copy-out skips it).  A block of more than CO_CAP entries takes the per-lane walk.
+// 22 KiB of LDS and 76 VGPRs per workgroup: 6 workgroups per CU — the launch is a chain of three dependent round trips per block
+// (cell row, index, ids), so waves in flight are what it runs on.  Measured on one box (profiles/r06_w_co_ab.txt; the deterministic
+// mode's extra time per C3 substep): this form 45 us; entries padded to word e + e / 8 so that cell-major accesses fall on different
+// banks: 111 VGPRs 52 us, held to 96 / 80 by the launch bounds (spills) 50 / 57 us; the next block's row and index requested ahead
+// of time: 92 VGPRs, 52 us; a separate output slab (48 KiB, 3 workgroups per CU): 53 us; one lane per cell (k_cell_order): 51 us.
+constexpr uint32_t CO_CAP = 704;
+template <bool COMPACT>
+__global__ __launch_bounds__(256, 6) void k_cell_order_blocks(Params P, const Counters *__restrict__ cnt, const uint32_t *__restrict__ cell_start,
+                                                           const uint32_t *__restrict__ perm, const float4 *__restrict__ rg,
+                                                           uint32_t *__restrict__ out) {
+  constexpr uint32_t K = CO_CAP / 64, SLAB = CO_CAP;
+  __shared__ uint32_t s_id[4][SLAB], s_pv[4][SLAB];
+  const uint32_t na = min(cnt->n_active, P.max_blocks);
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t *const ids = s_id[wave], *const pvs = s_pv[wave];
+  for (uint32_t b = blockIdx.x * 4u + wave; b < na; b += gridDim.x * 4u) {  // (wave-uniform)
+    const uint32_t cs = cell_start[(size_t)b * BC + lane], ce = cell_start[(size_t)b * BC + lane + 1];
+    const uint32_t s0 = __shfl(cs, 0), nb = __shfl(ce, 63) - s0, n = ce - cs, o = cs - s0;
+    if (nb == 0u) continue;
+    if (nb > CO_CAP) {
+      cell_order_lanes<COMPACT>(P, perm, rg, out, cs, n, lane);
+      continue;
+    }
+    {  // stage: all index loads first, then all id gathers (two round trips for the block)
+      uint32_t pv[K], id[K];
 #pragma unroll
-      for (int i = 0; i < 16; i++) pv[i] = (uint32_t)i < n ? perm[s + i] : 0u;
+      for (uint32_t k = 0; k < K; k++) pv[k] = k * 64u + lane < nb ? perm[s0 + k * 64u + lane] : 0u;
 #pragma unroll
-      for (int i = 0; i < 16; i++) id[i] = (uint32_t)i < n ? pid_of(rg, pv[i]) : INVALID;  // (the padding is smaller than nothing)
+      for (uint32_t k = 0; k < K; k++) id[k] = k * 64u + lane < nb ? pid_of<COMPACT>(P, rg, pv[k]) : INVALID;
+#pragma unroll
+      for (uint32_t k = 0; k < K; k++)
+        if (k * 64u + lane < nb) { pvs[k * 64u + lane] = pv[k]; ids[k * 64u + lane] = id[k]; }
+    }
+    __builtin_amdgcn_wave_barrier();  // (DS operations of one wave execute in program order)
+    if (n > 1u && n <= 16u) {
+      uint32_t cp[16], ci[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) { cp[i] = (uint32_t)i < n ? pvs[o + i] : 0u; ci[i] = (uint32_t)i < n ? ids[o + i] : INVALID; }
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         if ((uint32_t)i < n) {
           uint32_t r = 0;
 #pragma unroll
-          for (int j = 0; j < 16; j++) r += id[j] < id[i] ? 1u : 0u;
-          out[s + r] = pv[i];
+          for (int j = 0; j < 16; j++) r += ci[j] < ci[i] ? 1u : 0u;
+          pvs[o + r] = cp[i];
         }
       }
-    } else if (n <= 64u) {
+    } else if (n > 16u && n <= 64u) {
       for (uint32_t i = 0; i < n; i++) {
-        const uint32_t slot = perm[s + i], pi = pid_of(rg, slot);
+        const uint32_t pi = ids[o + i];
         uint32_t r = 0;
-        for (uint32_t j = 0; j < n; j++) r += pid_of(rg, perm[s + j]) < pi ? 1u : 0u;
-        out[s + r] = slot;
+        for (uint32_t j = 0; j < n; j++) r += ids[o + j] < pi ? 1u : 0u;
+        out[cs + r] = pvs[o + i];
       }
+      for (uint32_t i = 0; i < n; i++) pvs[o + i] = INVALID;
     }
     unsigned long long big = __ballot(n > 64u);
-    while (big) {
+    while (big) {  // a cell of more than 64 particles: its whole wave
       const int l = __ffsll((long long)big) - 1;
       big &= big - 1;
-      const uint32_t bs = __shfl(s, l), bn = __shfl(n, l);
+      const uint32_t bo = __shfl(o, l), bn = __shfl(n, l);
       for (uint32_t i = lane; i < bn; i += 64u) {
-        const uint32_t slot = perm[bs + i], pi = pid_of(rg, slot);
+        const uint32_t pi = ids[bo + i];
         uint32_t r = 0;
-        for (uint32_t j = 0; j < bn; j++) r += pid_of(rg, perm[bs + j]) < pi ? 1u : 0u;
-        out[bs + r] = slot;
+        for (uint32_t j = 0; j < bn; j++) r += ids[bo + j] < pi ? 1u : 0u;
+        out[s0 + bo + r] = pvs[bo + i];
       }
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t i = lane; i < bn; i += 64u) pvs[bo + i] = INVALID;
     }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (uint32_t k = 0; k < K; k++)
+      if (k * 64u + lane < nb) {
+        const uint32_t v = pvs[k * 64u + lane];
+        if (v != INVALID) out[s0 + k * 64u + lane] = v;
+      }
+    __builtin_amdgcn_wave_barrier();  // (the next block's staging overwrites the slabs)
   }
 }
 

@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256) void k_import(Params P, uint32_t n, uint32_t b
         atomicAdd(&cnt->n_dead, 1u);
       }
       key[i] = kk;
+      if (P.pidc) P.pidc[i] = (uint32_t)pid;
       rg[i * 4 + 0] = g0; rg[i * 4 + 1] = in[o + 1]; rg[i * 4 + 2] = in[o + 2];
       rg[i * 4 + 3] = make_float4(g3.x, g3.y, __int_as_float(pid), 0.0f);
       rp[i * 4 + 0] = p0; rp[i * 4 + 1] = p1; rp[i * 4 + 2] = in[o + 6]; rp[i * 4 + 3] = in[o + 7];

@@ -83,6 +83,9 @@ struct Params {
                      // 1 no G2P stores, 2 no constitutive update, 4 no 27-tap gather, 8 no P2G merge, 16 / 32 P2G capped at 8 / 6
                      // particles per cell, 64 / 128 P2G writes 150 of 216 tile nodes / the grid pass reads 5 of 8 tiles (quad-tile bound).  The default
                      // library compiles every use of it away (MPM_ABLATE below is the constant false).
+  uint32_t *pidc;    // deterministic mode only (else null): creation id per SLOT, 4 bytes beside key[] — whoever writes a slot's key writes
+                     // its id here (k_g2p / k_g2p_packed / k_g2p_rigid at the sorted position, k_build_keys, k_import), so k_cell_order
+                     // gathers 4-byte words instead of one 64-byte record line per particle (k_sort.h)
 };
 #ifdef MPMHIP_ABLATE_BUILD
 #define MPM_ABLATE(P, bit) (((P).ablate & (bit)) != 0)

@@ -140,6 +140,10 @@ struct mpmhip_ctx {
   int groups_cap = G2P_LDS_GROUPS;  // k_g2p mirrors the whole table in LDS
   bool sorted = false;        // perm / cell_start describe the current positions
   bool keys_valid = false;    // key[] + block flags describe the current positions (set by k_g2p)
+  uint32_t *pidc = nullptr;   // creation id per slot beside key[] (Params::pidc points here while the deterministic mode is on)
+  int cell_order_wgs = 24;    // env MPMHIP_CELL_ORDER_WGS: workgroups per CU of k_cell_order_blocks' launch
+  int cell_order_form = 1;    // env MPMHIP_CELL_ORDER: 1 k_cell_order_blocks (a wave per block through LDS), 0 k_cell_order (a lane per cell)
+  bool pidc_valid = false;    // ... and was written together with the current key[] (every key writer does while Params::pidc is set)
   bool affine_valid = false;  // RecP.A matches (F, aux, apic_b)
   bool b_stale = false;       // discard_apic_b: the side array is behind RecP.A (k_g2p did not write it)
   bool ordered = false;       // the records lie in the order of the last sort (k_g2p wrote them at their sorted positions)
@@ -481,6 +485,8 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   if (const char *e = getenv("MPMHIP_REORDER_INTERVAL")) c->reorder_interval = atoi(e);
   c->deterministic = cfg->deterministic != 0;
   if (const char *e = getenv("MPMHIP_DETERMINISTIC")) c->deterministic = atoi(e) != 0;
+  if (const char *e = getenv("MPMHIP_CELL_ORDER")) c->cell_order_form = atoi(e) != 0;
+  if (const char *e = getenv("MPMHIP_CELL_ORDER_WGS")) c->cell_order_wgs = std::max(1, atoi(e));
 #ifdef MPMHIP_ABLATE_BUILD
   const int ablate = getenv("MPMHIP_ABLATE") ? atoi(getenv("MPMHIP_ABLATE")) : 0;
 #else
@@ -533,6 +539,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
   A(dmalloc(&c->rp2, (size_t)c->cap));
   A(dmalloc(&c->rb2, (size_t)c->cap * BW));
   A(dmalloc(&c->key, (size_t)c->cap));
+  A(dmalloc(&c->pidc, (size_t)c->cap));
   A(dmalloc(&c->rank, (size_t)c->cap));
   A(dmalloc(&c->perm, (size_t)c->cap));
   A(dmalloc(&c->chunk_blk, (size_t)c->cap / 256 + 2));
@@ -585,6 +592,7 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
          (long long)c->cap, (long long)mb);
     return bail(MPMHIP_ENOMEM);
   }
+  P.pidc = c->deterministic ? c->pidc : nullptr;
   A(hipMemset(c->bits, 0, sizeof(uint32_t) * P.nbw));
   A(hipMemset(c->blk_flag, 0, (size_t)P.nbw * 32));
   A(hipMemset(c->cell_cnt, 0, sizeof(uint32_t) * (size_t)mb * BC));
@@ -638,7 +646,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   for (auto &ev : c->ev_pool)
     for (int k = 0; k <= PH_COUNT; k++) hipEventDestroy(ev.e[k]);
   hipFree(c->rg); hipFree(c->rp); hipFree(c->rb); hipFree(c->rg2); hipFree(c->rp2); hipFree(c->rb2);
-  hipFree(c->key); hipFree(c->rank); hipFree(c->perm); hipFree(c->chunk_blk); hipFree(c->blk_flag); hipFree(c->bits); hipFree(c->wprefix);
+  hipFree(c->key); hipFree(c->pidc); hipFree(c->rank); hipFree(c->perm); hipFree(c->chunk_blk); hipFree(c->blk_flag); hipFree(c->bits); hipFree(c->wprefix);
   hipFree(c->fat_slot); hipFree(c->act_blk); hipFree(c->act_start); hipFree(c->cell_cnt);
   hipFree(c->cell_start); hipFree(c->cellcnt_key); hipFree(c->nbr); hipFree(c->own_list); hipFree(c->scan_slots); hipFree(c->tiles); hipFree(c->gridv); hipFree(c->dense);
   hipFree(c->async.d_tab); hipFree(c->async.d_blk_of); hipFree(c->async.d_blk_limits); hipFree(c->async.d_particle_limits);
@@ -668,6 +676,8 @@ int mpmhip_set_deterministic(mpmhip_ctx *c, int32_t enabled) {
   if (!c) return MPMHIP_EINVAL;
   if (c->in_substep) return fail(c, MPMHIP_EINVAL, "set_deterministic inside a substep");
   c->deterministic = enabled != 0;
+  c->P.pidc = c->deterministic ? c->pidc : nullptr;  // (the key writers keep the ids beside the keys from now on; until a G2P has, k_cell_order reads the records)
+  c->pidc_valid = false;
   return MPMHIP_OK;
 }
 
@@ -762,6 +772,7 @@ int mpmhip_add_group(mpmhip_ctx *c, int32_t material, const float params[MPMHIP_
 static int invalidate_keys(mpmhip_ctx *c) {
   c->sorted = false;
   c->ordered = c->compact = false;
+  c->pidc_valid = false;
   if (c->keys_valid) {
     c->keys_valid = false;
     HIPCHK(c, hipMemsetAsync(c->blk_flag, 0, (size_t)c->P.nbw * 32, c->stream));
@@ -1037,8 +1048,10 @@ static int do_sort(mpmhip_ctx *c) {
   Params &P = c->P;
   hipStream_t st = c->stream;
   const int pg = particle_grid(c->n_slots);
-  if (!c->keys_valid)
+  if (!c->keys_valid) {
     hipLaunchKernelGGL(k_build_keys, dim3(pg), dim3(256), 0, st, P, c->rg, c->rp, c->cnt, c->key, c->blk_flag);
+    c->pidc_valid = P.pidc != nullptr;
+  }
   // blocks per chunk of k_cell_table: few blocks -> finer chunks (shorter chains, more workgroups).  16 below 2 M slots, 64 from 6 M on
   // (16 costs 10 us at 8 M: its 1 100 chunks no longer fit the scans' resident grid), 32 in between — a rank of a 2-brick job
   // holds 4 M particles in 8 788 blocks: 17.4 us with 64 (as long as the whole 8 M problem takes: the kernel is a latency chain)
@@ -1099,9 +1112,16 @@ static int do_sort(mpmhip_ctx *c) {
   if (c->deterministic) {
     // every cell's entries in ascending creation id (k_sort.h: k_cell_order); rank[] is idle until the next sort: the ordered index goes
     // there and then IS the index
-    const int cg = (int)std::min<uint64_t>(8192u, ((uint64_t)P.max_blocks * BC + 255) / 256);
-    hipLaunchKernelGGL(k_cell_order, dim3(cg), dim3(256), 0, st, P, (const Counters *)c->cnt, (const uint32_t *)c->cell_start,
-                       (const uint32_t *)c->perm, (const float4 *)c->rg, c->rank);
+    const bool compact = c->pidc_valid && P.pidc;
+    if (c->cell_order_form == 0) {  // (A/B: one lane per cell over the whole table)
+      const int cg = (int)std::min<uint64_t>(8192u, ((uint64_t)P.max_blocks * BC + 255) / 256);
+      hipLaunchKernelGGL((compact ? k_cell_order<true> : k_cell_order<false>), dim3(cg), dim3(256), 0, st, P, (const Counters *)c->cnt,
+                         (const uint32_t *)c->cell_start, (const uint32_t *)c->perm, (const float4 *)c->rg, c->rank);
+    } else {  // one wave per active block through LDS: 6 workgroups per CU (24 KiB each), a few blocks per wave
+      const int cg = (int)std::min<uint64_t>((uint64_t)c->n_cus * (uint64_t)c->cell_order_wgs, ((uint64_t)P.max_blocks + 3) / 4);
+      hipLaunchKernelGGL((compact ? k_cell_order_blocks<true> : k_cell_order_blocks<false>), dim3(std::max(1, cg)), dim3(256), 0, st, P,
+                         (const Counters *)c->cnt, (const uint32_t *)c->cell_start, (const uint32_t *)c->perm, (const float4 *)c->rg, c->rank);
+    }
     std::swap(c->perm, c->rank);
   }
   // (k_cell_table's last chunk stores (live particles, active blocks, owner entries) of this sort straight into the pinned page,
@@ -1110,6 +1130,7 @@ static int do_sort(mpmhip_ctx *c) {
   if (!c->d_stats && (c->sort_epoch & 15u) == 1u) (void)hipMemcpyAsync(c->h_pinned + mpmhip_ctx::FILL_STATS_WORD, c->cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
   c->sorted = true;
   c->keys_valid = false;  // key[] now holds k_rank's packed (rank, cell index) words
+  c->pidc_valid = false;
   int rc = launch_check(c, "sort");
   if (rc) return rc;
   // sort_allocator (src/mpm.cpp:752-768, every reorder_interval substeps :811-813): needed here only for records that
@@ -1342,6 +1363,7 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0) {
 #endif
                        );
     c->sorted = false; c->keys_valid = true; c->affine_valid = true;
+    c->pidc_valid = c->P.pidc != nullptr;
     if (!c->P.store_b) c->b_stale = true;
     return launch_check(c, "g2p_packed");
   }
@@ -1371,6 +1393,7 @@ static int do_g2p(mpmhip_ctx *c, int phase = 0) {
   }
   c->sorted = false;       // positions moved
   c->keys_valid = true;    // ... and their keys / block flags are ready for the next sort
+  c->pidc_valid = c->P.pidc != nullptr;
   c->affine_valid = true;  // A was produced together with F
   if (!c->P.store_b) c->b_stale = true;
   return launch_check(c, "g2p");
@@ -2241,7 +2264,7 @@ int mpmhip_reserve(mpmhip_ctx *c, int64_t max_particles) {
   auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
   A(regrow(&c->rg, n, cap, false)); A(regrow(&c->rp, n, cap, false)); A(regrow(&c->rb, n * BW, cap * BW, true));
   A(regrow(&c->rg2, 0, cap, false)); A(regrow(&c->rp2, 0, cap, false)); A(regrow(&c->rb2, 0, cap * BW, false));
-  A(regrow(&c->key, 0, cap, false)); A(regrow(&c->rank, 0, cap, false)); A(regrow(&c->perm, 0, cap, false)); A(regrow(&c->chunk_blk, 0, cap / 256 + 2, false));
+  A(regrow(&c->key, 0, cap, false)); A(regrow(&c->pidc, 0, cap, false)); A(regrow(&c->rank, 0, cap, false)); A(regrow(&c->perm, 0, cap, false)); A(regrow(&c->chunk_blk, 0, cap / 256 + 2, false));
   if (c->rigid.d_bnd) A(regrow(&c->rigid.d_bnd, n, cap, true));
   if (c->async.d_blk_of) {  // (re-allocated at the size of the ctx by the next update_dt_limits)
     (void)hipFree(c->async.d_blk_of); (void)hipFree(c->async.d_particle_limits);
@@ -2250,6 +2273,8 @@ int mpmhip_reserve(mpmhip_ctx *c, int64_t max_particles) {
   if (e != hipSuccess) return fail(c, MPMHIP_ENOMEM, "growing the particle arrays to %lld failed: %s", (long long)max_particles, hipGetErrorString(e));
   c->cap = max_particles;
   c->cfg.max_particles = max_particles;
+  c->P.pidc = c->deterministic ? c->pidc : nullptr;
+  c->pidc_valid = false;
   if (c->cfg.max_blocks <= 0) {  // auto-sized block table: same rule as mpmhip_create
     int64_t mb = c->cap / 48 + 4096;
     if (mb > (int64_t)c->NB) mb = c->NB;

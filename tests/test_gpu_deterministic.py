@@ -64,6 +64,49 @@ def test_two_runs_of_one_scene_agree_bit_for_bit(tm):
     assert np.abs(loose["x"] - runs[0]["x"]).max() <= 2e-6 and rel_l2(loose["v"], runs[0]["v"]) <= 1e-3 and rel_l2(loose["F"], runs[0]["F"]) <= 1e-3
 
 
+
+def _crowded_scene():
+    """cells of 1, <= 16, 17..64 and > 64 particles; one block of more than 704 entries (k_sort.h: CO_CAP — the per-lane walk of
+    k_cell_order_blocks); slots shuffled"""
+    rng = np.random.default_rng(71)
+    cell = lambda c, n: ((np.asarray(c, np.float32) + rng.uniform(0.05, 0.95, (n, 3))) * DX).astype(np.float32)
+    parts = [cell((12, 14, 12), 150), cell((13, 14, 12), 40), cell((12, 15, 13), 70), cell((14, 14, 14), 17)]
+    for c in np.ndindex(4, 4, 4):  # block (5, 5, 5): 64 cells x 14 = 896 entries
+        parts.append(cell((20 + c[0], 20 + c[1], 20 + c[2]), 14))
+    parts.append((rng.uniform(6.0, 26.0, (3000, 3)) * DX).astype(np.float32))  # singles and small cells
+    x = np.concatenate(parts)
+    return make_state(x[rng.permutation(len(x))], "jelly", DX, perturb_F=0.01, seed=72, vel_scale=2.0)
+
+
+def test_every_path_of_the_ordering_launch_gives_the_same_bits(tm, monkeypatch):
+    """the wave-per-block ordering launch (cells ordered in LDS; crowded cells and an over-full block on their own paths), the
+    lane-per-cell one (MPMHIP_CELL_ORDER=0), and ids gathered from the records instead of the compact array (the mode switched on
+    again in mid-run: the next sort finds keys a G2P wrote before the switch): one result, bit for bit"""
+    s = _crowded_scene()
+
+    def run(toggle=False, **cfg):
+        sim = tm.create_simulation3("mpm").initialize(dict(res=(RES,) * 3, delta_x=DX, base_delta_t=DT, deterministic=True, **cfg))
+        sim.add_particles(dict(type="jelly", positions=s.x, velocities=s.v, F=s.F, B=s.B, aux=s.aux, params=s.gparams[0]))
+        for k in range(4):
+            sim.run_substeps(3)
+            if toggle:
+                sim.set_deterministic(True)
+        out = sim.get_particles()
+        sim.close()
+        return out
+
+    ref = run()
+    assert len(ref["id"]) > 3000 and np.isfinite(ref["x"]).all()  # (spray near the walls is refused at creation, as in the reference)
+    again, toggled = run(), run(toggle=True)
+    monkeypatch.setenv("MPMHIP_CELL_ORDER", "0")
+    lanes = run()
+    monkeypatch.delenv("MPMHIP_CELL_ORDER")
+    for name, r in (("again", again), ("records' ids", toggled), ("lane per cell", lanes)):
+        assert np.array_equal(r["id"], ref["id"]), name
+        for f in FIELDS:
+            assert np.array_equal(r[f], ref[f]), (name, f, float(np.abs(r[f] - ref[f]).max()))
+
+
 def _det_sim(tm, s, sel, ids, cap, device=0):
     from taichi_mpm_amd.mpm import F_ID
     sim = tm.create_simulation3("mpm")

@@ -68,4 +68,14 @@ def test_no_kernel_of_the_library_uses_scratch_unnoticed(stats):
     # particles for rigid_body_levelset_collision, rigid_api.h — off the substep path of every scene that does not set that key)
     allowed = ("k_p2g_rigid", "k_g2p_rigid", "rocprim")
     bad = [k for k, v in stats.items() if v.get("scratch_bytes", 0) > 0 and not any(a in k for a in allowed)]
+    # k_g2p<STORE_B = true> (keep_apic_b scenes, never the benchmark's): since Params::pidc the compiler RESERVES 36 bytes of private
+    # segment for these four instantiations and never touches them — no spill counted, no scratch instruction in the code.  Held to
+    # exactly that: a reserved but unused segment costs no memory traffic.
+    from taichi_mpm_amd import _lib
+    import kernel_diff
+    code = kernel_diff.kernels(_lib.build())
+    reserved_only = [k for k in bad if k.startswith("_ZN3mpm5k_g2pILi256ELi2ELb1ELb1E") and stats[k]["vgpr_spill"] == 0
+                     and not any(i.startswith(("scratch_", "buffer_")) for i in code[k])]
+    assert len(reserved_only) <= 4
+    bad = [k for k in bad if k not in reserved_only]
     assert not bad, bad
