@@ -40,6 +40,10 @@ Extra objects on the line:
                 own loop and halo exchange over the local wire — per-rank substep (what one rank of a K-GPU job computes per substep,
                 before the wire), per-rank phase table, halo bytes, and `x_over_one_gpu` = ms_per_step of this line / per-rank substep:
                 the upper bound of the strong-scaling factor at K GPUs.  --no-virtual skips it.
+  c5            (N = 1, default workload) BASELINE configs[4] — 512^3 sparse grid, 64 M mixed particles in 8 clusters, the configuration
+                the >= 6x at 8 GPUs is claimed for — on this GPU: the whole problem in one ctx (ms_per_step, value), then as 8 ctx of one
+                cluster each over the local wire (`virtual8`: per-rank substep and x_over_one_gpu, the same proxy as `virtual`).
+                --no-c5 skips it.
   cpu_baseline  kind "reference": the reference's own solver, compiled from its sources in place
                 (oracle/_ref/libmpm_ref.so, built by `make -C oracle ref_mpm` where /root/reference exists; the
                 built library travels), timed on this box's host cores: thread sweep + threads=1 row on the
@@ -361,6 +365,50 @@ def virtual_run(tm, cfg, args, K=None, overlap=None):
              "rank0_phases_ms": per_phase[0], "migrated": migrated})
 
 
+def c5_block(tm, args, steps=10, warmup=3):
+    """BASELINE configs[4] on one GPU: the whole 64 M problem in one ctx, then its 8 clusters as 8 ctx on this GPU (tiled.scene_partition:
+    one cluster per rank) — time / 8 = what one rank of the 8-GPU job computes per substep before the wire"""
+    cfg = dict(CONFIGS["c5"])
+    t_block = time.time()
+    sim = build_sim(tm, cfg, 0)
+    job = SingleJob(sim)
+    n = job.num_particles()
+    job.run(warmup)
+    job.synchronize()
+    t0 = time.perf_counter()
+    job.run(steps)
+    job.synchronize()
+    el = time.perf_counter() - t0
+    prof_blocks = None
+    try:
+        job.set_profiling(1, 1)
+        job.run(4)
+        job.synchronize()
+        p = job.profile()
+        prof_blocks = p.get("active_blocks")
+        phases = {k: v / max(p["substeps"], 1) for k, v in p["phases"].items()}
+    except Exception:
+        phases = None
+    sim.close()
+    one = 1e3 * el / steps
+    out = {"workload": cfg["desc"], "particles": n, "dt": cfg["dt"], "steps": steps, "warmup": warmup, "ms_per_step": one,
+           "value": n * steps / el, "unit": "particle-steps/s", "active_blocks": prof_blocks, "phases_ms_per_step": phases,
+           "whole_step_hbm_frac_algorithmic": (n * 252.0 + (prof_blocks or 0) * 64 * 80.0) / (el / steps) / 1e9 / HBM_PEAK_GBS}
+    a = argparse.Namespace(**vars(args))
+    a.steps, a.warmup = steps, warmup
+    try:
+        v = virtual_run(tm, cfg, a, K=8, overlap=False)
+        out["virtual8"] = {"per_rank_ms": v["per_rank_ms_serial_no_events"], "x_over_one_gpu": one / v["per_rank_ms_serial_no_events"],
+                           "particles_per_rank": v["particles_per_rank"], "halo_bytes_per_rank": v["halo_bytes_per_rank"],
+                           "dims": v["dims"], "migrated": v["migrated"],
+                           "what": "the 8 clusters as 8 ctx on THIS GPU over the local wire: per_rank_ms = all ranks' substeps back to back / 8 = "
+                                   "the per-GPU compute of the 8-GPU job before the wire; x_over_one_gpu = upper bound of its factor over this GPU alone"}
+    except Exception as e:
+        out["virtual8"] = {"error": repr(e)}
+    out["seconds"] = time.time() - t_block
+    return out
+
+
 class Watchdog:
     """A multi-rank run that hangs (a collective one rank never enters, a transport that stalls on first contact) must cost
     seconds, not the lease: a timer that prints where the run was and ends the PROCESS (os._exit: a thread stuck inside a
@@ -468,6 +516,7 @@ def main():
                     help="N > 1: if the RCCL wire cannot be brought up, stage the exchange through gloo and host memory instead of "
                          "exiting with an error (such a line says so in config.wire and is NOT a scaling measurement)")
     ap.add_argument("--no-virtual", action="store_true", help="N = 1: skip the `virtual` block of the line (K bricks as K ctx on this GPU)")
+    ap.add_argument("--no-c5", action="store_true", help="N = 1: skip the `c5` block of the line (BASELINE configs[4] in one ctx and as 8 virtual ranks)")
     ap.add_argument("--virtual", type=int, default=0, metavar="K",
                     help="diagnostic, not the metric: run the K-brick tiled job as K ctx on ONE GPU (exchanges are local "
                          "copies) and print per-rank phase times = the per-GPU compute of a K-GPU run without the wire")
@@ -830,6 +879,17 @@ def main():
             out["virtual"] = vout
         except Exception as e:
             out["virtual"] = {"error": repr(e)}
+    if world == 1 and not force_tiled and not args.no_c5 and args.config == "c3" and not args.cells and args.state == "lattice":
+        # BASELINE configs[4] (512^3 / 64 M mixed particles: the configuration the >= 6x at 8 GPUs is claimed for) on THIS GPU in one ctx,
+        # then as 8 virtual ranks (one 8 M cluster each): the same proxy as `virtual`, driver-timed
+        try:
+            try:
+                job.sim.close()
+            except Exception:
+                pass
+            out["c5"] = c5_block(tm, args)
+        except Exception as e:
+            out["c5"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import refmpm

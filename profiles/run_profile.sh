@@ -6,7 +6,7 @@
 # timed region, the PMC passes for per-launch counters of the LAST dispatches — summarize_pmc.py --last N)
 TAG=${1:-prof}
 shift
-X="--no-evolved --no-virtual $*"
+X="--no-evolved --no-virtual --no-c5 $*"
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 W=/tmp/prof_$TAG   # raw per-dispatch CSVs stay on the box (an evolving run writes tens of MB per pass); summaries go to $O

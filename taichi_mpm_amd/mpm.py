@@ -676,7 +676,8 @@ class Simulation3D:
         cum = np.cumsum(hist)
 
         def q(p):
-            return float(2.0 ** ((int(np.searchsorted(cum, p * n)) + 1) / 8.0)) if n else None
+            # (upper edge of the eighth-octave bin the quantile falls in, never above the exact maximum)
+            return min(float(2.0 ** ((int(np.searchsorted(cum, p * n)) + 1) / 8.0)), float(out[4])) if n else None
         return {"particles": int(n), "max": float(out[4]), "median": q(0.5), "p99": q(0.99), "p999": q(0.999), "p9999": q(0.9999),
                 "frac_particles_refined": out[1] / n if n else 0.0, "frac_waves_with_refinement": out[3] / out[2] if out[2] else 0.0,
                 "beyond_1e2": float(hist[int(8 * np.log2(100.0)):].sum() / n) if n else 0.0}
