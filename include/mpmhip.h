@@ -355,7 +355,10 @@ typedef struct {
   int32_t dims[3];             /* bricks per axis; world = dims[0] dims[1] dims[2] */
   int32_t margin;              /* cells a particle may sit outside its brick between two migrations */
   int32_t clip_lo[3], clip_hi[3]; /* node box the halo boxes are clipped to (occupied part of the grid + slack); the library
-                                  * re-wraps it around the particles at every migration (slack max(8, 2 margin + 4) cells) */
+                                  * re-wraps it around the particles at every migration (slack max(8, 4 margin + 4) cells) AND, from a
+                                  * planning scan in front of the job's first substep on, cuts every rank's node box to that rank's OWN
+                                  * occupancy (every rank's particle bounds travel in the migration table): ranks whose particles cannot
+                                  * meet before the next check exchange nothing */
   int32_t migrate_interval;    /* > 0: a migration every that many substeps (<= margin); 0: the CFL interval (= margin)
                                   * stretched by the measured top speed, up to migrate_cap substeps */
   int32_t migrate_cap;         /* 0: 64 */

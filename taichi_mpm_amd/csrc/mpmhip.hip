@@ -273,7 +273,7 @@ struct mpmhip_ctx {
       double *red[2] = {nullptr, nullptr};  // reduction tables (tiled_api.h: tn_reduce_*)
       void *ipc_base = nullptr;  // mapped with hipIpcOpenMemHandle (closed on destroy)
     };
-    struct Mig { std::vector<int64_t> counts; int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; float speed = 0.0f; int64_t total = 0, n_out = 0, n_in = 0; } mig;
+    struct Mig { std::vector<int64_t> counts; std::vector<int> rank_bounds /* [world][6]: lo3, hi3 base cells, before the records moved */; int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; float speed = 0.0f; int64_t total = 0, n_out = 0, n_in = 0; } mig;
     bool on = false, connected = false, exch_on_side = false;
     bool defer_signal = false, signal_deferred = false;  // local job: the ranks' epochs are published by ONE launch of the group (tiled_api.h)
     bool loop_rccl = false;               // MPMHIP_WIRE_LOCAL_RCCL: a local job whose halo boxes travel by RCCL self-sends (tiled_api.h)
@@ -281,6 +281,8 @@ struct mpmhip_ctx {
     bool wait_merged = false, merge_signal_wait = true;  // IPC wire, no overlap split: signal + wait of a substep in one launch
     int world = 1, wire = 0;
     int clip_lo[3] = {0, 0, 0}, clip_hi[3] = {0, 0, 0};
+    std::vector<int> occ;  // [world][6]: every rank's occupancy box (lo3, hi3, nodes): node_box(r) is cut to it (tiled_api.h: plan)
+    bool occ_valid = false, initial_scan = false;  // (until the scan in front of the first substep: the global clip box only)
     std::vector<Box> boxes;
     std::vector<int> halo_peers, all_ranks;
     uint64_t total = 0, halo_cap = 0, inbox_cap = 0;

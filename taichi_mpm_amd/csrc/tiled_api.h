@@ -4,8 +4,11 @@
 // is SURVEY section 8(e) — bricks, halo sum after P2G, particle migration after G2P, a few scalars per migration.
 //
 //   plan      box(R, S) = node_box(R) ∩ node_box(S), node_box(R) = [brick.lo - margin, brick.hi + margin + 2) clipped to the
-//             occupied part of the grid; sorted by peer.  Every rank can compute every rank's plan (the partition and the clip
-//             box are global), so a writer knows where a box lives in its reader's buffers.
+//             occupied part of the grid AND to rank R's own occupancy box (the nodes R's particles can touch before the next
+//             migration check: every rank's particle bounds travel in the migration table, so all ranks hold all boxes) — R has
+//             no mass outside it to send and nothing outside it to gather, so clusters that do not meet exchange nothing
+//             (configs[4]: 8 - 39 MB per rank and substep of empty slabs around the cuts before round 6); sorted by peer.
+//             Every rank can compute every rank's plan, so a writer knows where a box lives in its reader's buffers.
 //   arena     ONE device allocation per rank: flag words, two migration tables, two receive buffers (parity of the substep),
 //             the migration inbox.  Sized for the worst case (clip = the whole grid), so it is allocated — and, for the IPC
 //             wire, mapped by the peers — exactly once.
@@ -101,24 +104,26 @@ int tn_wait(mpmhip_ctx *c, const uint32_t *words, const std::vector<int> &who, i
 }
 
 // node box of `rank` under the partition (cuts of c->T) and a clip box
-void tn_node_box(const Tiling &T, const int clip_lo[3], const int clip_hi[3], int rank, int lo[3], int hi[3]) {
+// (occ: [world][6] = lo3, hi3 of every rank's occupancy box in nodes, or nullptr: only the global clip box)
+void tn_node_box(const Tiling &T, const int clip_lo[3], const int clip_hi[3], const int *occ, int rank, int lo[3], int hi[3]) {
   const int pc[3] = {rank / (T.dims[1] * T.dims[2]), (rank / T.dims[2]) % T.dims[1], rank % T.dims[2]};
   for (int a = 0; a < 3; a++) {
     lo[a] = std::max(clip_lo[a], T.cuts[a][pc[a]] - T.margin);
     hi[a] = std::min(clip_hi[a], T.cuts[a][pc[a] + 1] + T.margin + 2);
+    if (occ) { lo[a] = std::max(lo[a], occ[rank * 6 + a]); hi[a] = std::min(hi[a], occ[rank * 6 + 3 + a]); }
   }
 }
 // halo boxes of `rank`, sorted by peer, with their offsets (float4 nodes) in the rank's buffers
-std::vector<mpmhip_ctx::TiledNative::Box> tn_plan(const Tiling &T, int world, const int clip_lo[3], const int clip_hi[3], int rank,
-                                                   uint64_t *total) {
+std::vector<mpmhip_ctx::TiledNative::Box> tn_plan(const Tiling &T, int world, const int clip_lo[3], const int clip_hi[3], const int *occ,
+                                                   int rank, uint64_t *total) {
   std::vector<mpmhip_ctx::TiledNative::Box> out;
   int alo[3], ahi[3];
-  tn_node_box(T, clip_lo, clip_hi, rank, alo, ahi);
+  tn_node_box(T, clip_lo, clip_hi, occ, rank, alo, ahi);
   uint64_t off = 0;
   for (int s = 0; s < world; s++) {
     if (s == rank) continue;
     int blo[3], bhi[3];
-    tn_node_box(T, clip_lo, clip_hi, s, blo, bhi);
+    tn_node_box(T, clip_lo, clip_hi, occ, s, blo, bhi);
     mpmhip_ctx::TiledNative::Box b;
     bool any = true;
     for (int a = 0; a < 3; a++) {
@@ -147,13 +152,14 @@ int tn_apply_plan(mpmhip_ctx *c) {
   auto &N = c->tn;
   Tiling &T = c->T;
   uint64_t total = 0;
-  N.boxes = tn_plan(T, N.world, N.clip_lo, N.clip_hi, T.rank, &total);
+  const int *occ = N.occ_valid ? N.occ.data() : nullptr;
+  N.boxes = tn_plan(T, N.world, N.clip_lo, N.clip_hi, occ, T.rank, &total);
   if (N.boxes.size() > MPMHIP_MAX_HALO_BOXES) return fail(c, MPMHIP_EINVAL, "too many halo boxes (%zu)", N.boxes.size());
   if (total > N.halo_cap) return fail(c, MPMHIP_ECAPACITY, "internal: halo plan of %llu nodes exceeds the arena (%llu)", (unsigned long long)total, (unsigned long long)N.halo_cap);
   N.total = total;
   for (auto &b : N.boxes) {  // where the box lives in the peer's buffers: the peer's own plan
     uint64_t ptotal = 0;
-    auto pp = tn_plan(T, N.world, N.clip_lo, N.clip_hi, b.peer, &ptotal);
+    auto pp = tn_plan(T, N.world, N.clip_lo, N.clip_hi, occ, b.peer, &ptotal);
     bool found = false;
     for (auto &q : pp)
       if (q.peer == T.rank) { b.peer_off = q.off; found = true; }
@@ -341,6 +347,7 @@ int tn_mig_b(mpmhip_ctx *c) {
   if ((rc = read_counters(c, hc))) return rc;  // synchronises; reports a margin violation or a wait that timed out
   auto &M = N.mig;
   M.counts.assign((size_t)world * world, 0);
+  M.rank_bounds.assign((size_t)world * 6, 0);
   int64_t total = 0;
   int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-(1 << 30), -(1 << 30), -(1 << 30)};
   float speed = 0.0f;
@@ -349,6 +356,7 @@ int tn_mig_b(mpmhip_ctx *c) {
     for (int s = 0; s < world; s++) { M.counts[(size_t)r * world + s] = row[s]; total += row[s]; }
     const int rlo[3] = {(int)row[world], (int)row[world + 1], (int)row[world + 2]};
     const int rhi[3] = {(int)row[world + 3], (int)row[world + 4], (int)row[world + 5]};
+    for (int a = 0; a < 3; a++) { M.rank_bounds[(size_t)r * 6 + a] = rlo[a]; M.rank_bounds[(size_t)r * 6 + 3 + a] = rhi[a]; }
     if (rlo[0] <= rhi[0] && rlo[1] <= rhi[1] && rlo[2] <= rhi[2]) {  // (a rank without particles reports lo > hi)
       for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], rlo[a]); hi[a] = std::max(hi[a], rhi[a]); }
     }
@@ -425,41 +433,92 @@ int tn_mig_c(mpmhip_ctx *c) {
     if (M.n_in && (rc = mpmhip_import_particles(c, M.n_in, N.inbox))) return rc;
     if (c->n_slots > (int64_t)(0.85 * (double)c->cap)) c->compact_requested = true;  // dead slots (leavers) pile up
   }
-  N.migrations++;
-  // the clip box: does it still hold every node the particles can touch before the next check?
-  // A particle with base cell b touches the nodes b .. b + 2; M.lo / M.hi bound the base cells of ALL ranks' live particles.
-  // (a) Looking back: the halo boxes of the substeps since the last check were cut to the clip box, so mass splatted outside it
-  //     was never exchanged.  The schedule below lets the particles travel margin cells between two checks if their top speed
+  if (!N.initial_scan) N.migrations++;
+  // The occupancy boxes: do they still hold every node the particles can touch before the next check?
+  // A particle with base cell b touches the nodes b .. b + 2; the table carries every rank's base-cell bounds (M.rank_bounds; M.lo / M.hi
+  // bound ALL ranks' live particles), taken BEFORE this migration's records moved: a rank's particles after it lie inside its own
+  // bounds joined with those of every rank that sent it records.
+  // (a) Looking back: the halo boxes of the substeps since the last check were cut to these boxes, so mass splatted outside a rank's
+  //     box was never exchanged.  The schedule below lets the particles travel margin cells between two checks if their top speed
   //     at most doubles, and (b) keeps 2 margin + 1 cells of room, but a particle deep inside a brick that speeds up further
   //     (it trips no margin test: error bit 2 only watches the brick's own faces) could have left the box unseen: that is an
   //     error here, not a silent loss.
+  const int world = N.world;
   bool have = M.lo[0] <= M.hi[0] && M.lo[1] <= M.hi[1] && M.lo[2] <= M.hi[2];
   if (have) {
-    for (int a = 0; a < 3; a++)
-      // (a side where the clip box ends at the grid itself holds everything there is: with clean_boundary off, or on the clamped generic
-      // path, base cells reach res - 1, and no halo mass can lie beyond the last node)
-      if (M.lo[a] < N.clip_lo[a] || (M.hi[a] + 2 > N.clip_hi[a] && N.clip_hi[a] != c->P.res[a] + 1))
-        return fail(c, MPMHIP_ECAPACITY, "tiled run: particles left the clipped halo region on axis %d between two migrations (base cells "
-                    "[%d, %d), halo boxes cut to nodes [%d, %d)): their top speed more than doubled since the last check — halo sums "
-                    "of the substeps in between may be incomplete; lower mpmhip_tiled_config.migrate_cap or set migrate_interval",
-                    a, M.lo[a], M.hi[a], N.clip_lo[a], N.clip_hi[a]);
-    // (b) Looking ahead: room for a travel of 2 margin cells on every side (the schedule plans for margin)
-    bool covers = true;
-    const int room = 2 * c->T.margin;
-    for (int a = 0; a < 3; a++) {
-      covers = covers && (M.lo[a] - room - 1 >= N.clip_lo[a] || N.clip_lo[a] == 0);
-      covers = covers && (M.hi[a] + room + 3 <= N.clip_hi[a] || N.clip_hi[a] == c->P.res[a] + 1);
-    }
-    if (!covers) {
-      const int s = tn_clip_slack(c->T);
+    auto nonempty = [](const int *b) { return b[0] <= b[3] && b[1] <= b[4] && b[2] <= b[5]; };
+    for (int r = 0; r < world; r++) {
+      const int *rb = &M.rank_bounds[(size_t)r * 6];
+      if (!nonempty(rb)) continue;
       for (int a = 0; a < 3; a++) {
-        N.clip_lo[a] = std::max(0, M.lo[a] - s);
-        N.clip_hi[a] = std::min(c->P.res[a] + 1, M.hi[a] + s + 2);
+        const int olo = N.occ_valid ? N.occ[(size_t)r * 6 + a] : N.clip_lo[a], ohi = N.occ_valid ? N.occ[(size_t)r * 6 + 3 + a] : N.clip_hi[a];
+        // (a side where the box ends at the grid itself holds everything there is: with clean_boundary off, or on the clamped generic
+        // path, base cells reach res - 1, and no halo mass can lie beyond the last node)
+        if (rb[a] < olo || (rb[3 + a] + 2 > ohi && ohi != c->P.res[a] + 1))
+          return fail(c, MPMHIP_ECAPACITY, "tiled run: particles of rank %d left the clipped halo region on axis %d between two migrations (base cells "
+                      "[%d, %d), halo boxes cut to nodes [%d, %d)): their top speed more than doubled since the last check — halo sums "
+                      "of the substeps in between may be incomplete; lower mpmhip_tiled_config.migrate_cap or set migrate_interval",
+                      r, a, rb[a], rb[3 + a], olo, ohi);
       }
+    }
+    // every rank's bounds once this migration's records have arrived
+    std::vector<int> post(M.rank_bounds);
+    for (int r = 0; r < world; r++)
+      for (int s2 = 0; s2 < world; s2++) {
+        if (s2 == r || M.counts[(size_t)s2 * world + r] == 0) continue;
+        const int *sb = &M.rank_bounds[(size_t)s2 * 6];
+        for (int a = 0; a < 3; a++) {
+          post[(size_t)r * 6 + a] = std::min(post[(size_t)r * 6 + a], sb[a]);
+          post[(size_t)r * 6 + 3 + a] = std::max(post[(size_t)r * 6 + 3 + a], sb[3 + a]);
+        }
+      }
+    // (b) Looking ahead: room for a travel of 2 margin cells on every side (the schedule plans for margin)
+    bool covers = N.occ_valid;
+    const int room = 2 * c->T.margin;
+    for (int r = 0; r < world && covers; r++) {
+      const int *pb = &post[(size_t)r * 6];
+      if (!nonempty(pb)) continue;
+      for (int a = 0; a < 3; a++) {
+        const int olo = N.occ[(size_t)r * 6 + a], ohi = N.occ[(size_t)r * 6 + 3 + a];
+        covers = covers && (pb[a] - room - 1 >= olo || olo == 0);
+        covers = covers && (pb[3 + a] + room + 3 <= ohi || ohi == c->P.res[a] + 1);
+      }
+    }
+    // fresh boxes: the bounds with tn_clip_slack cells around them (a rank without particles: an empty box — it neither sends nor gathers)
+    const int s = tn_clip_slack(c->T);
+    std::vector<int> fresh((size_t)world * 6, 0);
+    int flo[3], fhi[3];
+    for (int a = 0; a < 3; a++) { flo[a] = std::max(0, M.lo[a] - s); fhi[a] = std::min(c->P.res[a] + 1, M.hi[a] + s + 2); }
+    for (int r = 0; r < world; r++) {
+      const int *pb = &post[(size_t)r * 6];
+      if (!nonempty(pb)) continue;
+      for (int a = 0; a < 3; a++) {
+        fresh[(size_t)r * 6 + a] = std::max(0, pb[a] - s);
+        fresh[(size_t)r * 6 + 3 + a] = std::min(c->P.res[a] + 1, pb[3 + a] + s + 2);
+      }
+    }
+    // ... and a re-plan also when the boxes in use have become much too wide (clusters that have drifted apart; the first check of a
+    // job, whose boxes are the global clip box of the set-up): all ranks' plans together, which every rank computes alike
+    bool shrink = false;
+    if (covers) {
+      uint64_t now = 0, then = 0;
+      for (int r = 0; r < world; r++) {
+        uint64_t t0 = 0, t1 = 0;
+        (void)tn_plan(c->T, world, N.clip_lo, N.clip_hi, N.occ.data(), r, &t0);
+        (void)tn_plan(c->T, world, flo, fhi, fresh.data(), r, &t1);
+        now += t0; then += t1;
+      }
+      shrink = 2 * then < now;
+    }
+    if (!covers || shrink) {
+      for (int a = 0; a < 3; a++) { N.clip_lo[a] = flo[a]; N.clip_hi[a] = fhi[a]; }
+      N.occ = fresh;
+      N.occ_valid = true;
       if ((rc = tn_apply_plan(c))) return rc;
       N.replans++;
     }
   }
+  if (N.initial_scan) return MPMHIP_OK;  // (the scan in front of a job's first substep plans, it does not move the schedule)
   // schedule: after a migration every particle is inside its brick and needs margin / speed substeps to cross the margin;
   // half of that leaves room for the speed to double in between; never sooner than the CFL schedule, never later than the cap
   int64_t n = N.migrate_interval;
@@ -682,6 +741,8 @@ int mpmhip_tiled_setup(mpmhip_ctx *c, const mpmhip_tiled_config *cfg, const int3
   N.migrate_interval = cfg->migrate_interval > 0 ? cfg->migrate_interval : cfg->margin;
   N.adaptive_cap = cfg->migrate_interval > 0 ? 0 : (cfg->migrate_cap > 0 ? cfg->migrate_cap : 64);
   N.k = 0; N.next_migration = N.migrate_interval;
+  N.occ.assign((size_t)N.world * 6, 0);
+  N.occ_valid = false; N.initial_scan = false;
   N.merge_signal_wait = !(getenv("MPMHIP_TILE_MERGE_WAIT") && atoi(getenv("MPMHIP_TILE_MERGE_WAIT")) == 0);  // (A/B knob)
   N.timeout_ticks = 100000000ull * (unsigned long long)std::max(1, getenv("MPMHIP_TILE_WAIT_S") ? atoi(getenv("MPMHIP_TILE_WAIT_S")) : 20);
   // worst-case halo volume over all ranks: the clip box = the whole grid (so that every rank lays its arena out alike)
@@ -689,7 +750,7 @@ int mpmhip_tiled_setup(mpmhip_ctx *c, const mpmhip_tiled_config *cfg, const int3
   uint64_t cap = 0;
   for (int r = 0; r < N.world; r++) {
     uint64_t t = 0;
-    const auto plan = tn_plan(c->T, N.world, full_lo, full_hi, r, &t);
+    const auto plan = tn_plan(c->T, N.world, full_lo, full_hi, nullptr, r, &t);
     if (plan.size() > MPMHIP_MAX_HALO_BOXES) return fail(c, MPMHIP_EINVAL, "too many halo boxes");
     cap = std::max(cap, t);
   }
@@ -835,6 +896,16 @@ int64_t mpmhip_tiled_advance(mpmhip_ctx *c, int64_t n) {
   auto &N = c->tn;
   if (N.wire == MPMHIP_WIRE_LOCAL && N.world > 1) return fail(c, MPMHIP_EINVAL, "ranks of a local job advance together: mpmhip_tiled_advance_group");
   HIPCHK(c, hipSetDevice(c->device));
+  if (n > 0 && !N.occ_valid && N.world > 1) {
+    // in front of a job's first substep: one scan + table exchange (no particle is outside its brick yet) — every rank learns every
+    // rank's bounds and the halo boxes shrink from the set-up's global clip box to the ranks' own occupancy (tn_mig_c)
+    N.initial_scan = true;
+    rc = tn_mig_a(c);
+    if (!rc) rc = tn_mig_b(c);
+    if (!rc) rc = tn_mig_c(c);
+    N.initial_scan = false;
+    if (rc) return rc;
+  }
   for (int64_t i = 0; i < n; i++) {
     for (int part = 0; part < 3; part++)
       if ((rc = tn_substep_parts(c, part))) { c->in_substep = false; c->cur_ev = nullptr; return rc; }
@@ -860,6 +931,20 @@ int64_t mpmhip_tiled_advance_group(mpmhip_ctx *const *ctxs, int32_t n_ctx, int64
   // ranks that share ONE stream publish their halo epochs with one launch behind the last rank's pack (k_epoch_signal_group)
   bool one_stream = n_ctx > 1 && n_ctx <= MPMHIP_MAX_HALO_BOXES && !(getenv("MPMHIP_TILE_GROUP_SIGNAL") && atoi(getenv("MPMHIP_TILE_GROUP_SIGNAL")) == 0);
   for (int r = 1; r < n_ctx; r++) one_stream = one_stream && ctxs[r]->stream == ctxs[0]->stream && ctxs[r]->device == ctxs[0]->device;
+  bool scan0 = false;
+  for (int r = 0; r < n_ctx; r++) scan0 = scan0 || !ctxs[r]->tn.occ_valid;
+  if (n > 0 && scan0 && n_ctx > 1) {  // (the planning scan in front of the job's first substep: see mpmhip_tiled_advance)
+    int rc = MPMHIP_OK;
+    for (int r = 0; r < n_ctx; r++) ctxs[r]->tn.initial_scan = true;
+    for (int ph = 0; ph < 3 && !rc; ph++)
+      for (int r = 0; r < n_ctx && !rc; r++) {
+        mpmhip_ctx *c = ctxs[r];
+        if (hipSetDevice(c->device) != hipSuccess) { rc = fail(c, MPMHIP_EHIP, "hipSetDevice failed"); break; }
+        rc = ph == 0 ? tn_mig_a(c) : (ph == 1 ? tn_mig_b(c) : tn_mig_c(c));
+      }
+    for (int r = 0; r < n_ctx; r++) ctxs[r]->tn.initial_scan = false;
+    if (rc) return rc;
+  }
   for (int64_t i = 0; i < n; i++) {
     // begin of every rank (sort, [boundary] P2G, pack: the peers' boxes are written), then interior + end rank by rank
     for (int r = 0; r < n_ctx; r++) {

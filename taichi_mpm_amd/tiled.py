@@ -54,6 +54,12 @@ def balanced_cuts(cells, res, parts, hist=None):
         total = int(cum[-1])
         for k in range(1, parts):
             c = int(np.searchsorted(cum, total * k / parts, side="left")) + 1 if total else (res * k) // parts
+            if total and c < res and hist[c] == 0:
+                # the balance point lies at the edge of an EMPTY stretch (clusters that do not touch): cut in its middle, not along
+                # the face of the lower cluster — there every particle that moves up a cell would cross into the next brick
+                nz = np.nonzero(np.asarray(hist[c:]) > 0)[0]
+                if len(nz):
+                    c = c + int(nz[0]) // 2
             c = max(c, cuts[-1] + 1)
             c = min(c, res - (parts - k))
             cuts.append(c)

@@ -346,6 +346,63 @@ def test_k_tiles_on_the_native_data_plane_reproduce_one_tile(tm, world, dims, ov
         sim.close()
 
 
+def test_halo_boxes_are_cut_to_each_ranks_own_occupancy(tm):
+    """two blobs in two bricks, far apart, flying at each other: the planning scan in front of the first substep cuts every rank's node box
+    to the nodes ITS particles can reach (the migration table carries every rank's bounds), so nothing is exchanged while the blobs
+    are apart (until round 6: the slab around the cut across the job's whole bounding box, every substep); the boxes come back by
+    re-plans before the blobs meet, and the collision agrees with the one-ctx run"""
+    from taichi_mpm_amd import tiled
+    from taichi_mpm_amd.mpm import F_ID
+    res, dx = 64, 1.0 / 64
+    xa = lattice_cube(res, 29, 35, dx, jitter=0.2, seed=41)
+    xb = xa.copy()
+    xa[:, 0] -= 17 * dx  # cells 12..18 in x
+    xb[:, 0] += 17 * dx  # cells 46..52: 28 cells apart, more than the two occupancy slacks (12 cells each at margin 2)
+    s = make_state(np.concatenate([xa, xb]), "jelly", dx, perturb_F=0.0, seed=42, vel_scale=0.0)
+    s.v[:len(xa)] = (40.0, 0.0, 0.0)
+    s.v[len(xa):] = (-40.0, 0.0, 0.0)
+    s.B[:] = 0
+    n, ids = s.n, np.arange(s.n)
+    part = tiled.Partition.balanced((res,) * 3, 2, s.x, dx, margin=2, dims=(2, 1, 1))
+    owner = part.rank_of_cells(tiled.base_cells(s.x, dx))
+    assert np.array_equal(owner, (np.arange(n) >= len(xa)).astype(owner.dtype))  # one blob per brick
+
+    def make(sel):
+        sim = tm.create_simulation3("mpm")
+        sim.initialize(dict(res=(res,) * 3, delta_x=dx, base_delta_t=DT, max_particles=n + 1024, reorder_interval=0, gravity=(0, 0, 0)))
+        sim.set_levelset(tm.mpm.LevelSet())
+        sim.add_particles(dict(type="jelly", positions=s.x[sel], velocities=s.v[sel], F=s.F[sel], B=s.B[sel], aux=s.aux[sel], params=s.gparams[0]))
+        sim.upload(F_ID, ids[sel].astype(np.int32))
+        return sim
+
+    one = make(np.ones(n, bool))
+    assert one.get_num_particles() == n
+    sims = [make(owner == r) for r in range(2)]
+    job = tiled.NativeVirtualJob([tiled.HipEngine(sim, 0) for sim in sims], part)
+    assert all(t["halo_nodes"] > 0 for t in job.state())  # the set-up's plan: the job's bounding box
+    job.run(1)
+    st = job.state()
+    assert all(t["halo_nodes"] == 0 and t["halo_boxes"] == 0 and t["replans"] == 1 and t["migrations"] == 0 for t in st), st
+    seen, steps = [], 1
+    while steps < 90:
+        job.run(6)
+        steps += 6
+        seen.append(job.state()[0]["halo_nodes"])
+    one.run_substeps(steps)
+    assert seen[0] == 0 and max(seen) > 0, seen  # apart: nothing; the boxes are back before the blobs touch (and go again when they have bounced apart)
+    st = job.state()
+    assert all(t["replans"] >= 2 for t in st) and len({t["next_migration"] for t in st}) == 1, st
+    ref, got = one.get_particles(), _gather(sims)
+    assert np.array_equal(got["id"], ref["id"]) and len(ref["id"]) == n
+    va = got["v"][:len(xa), 0]
+    assert va.mean() < 20.0, float(va.mean())  # they DID collide (free flight would keep 40)
+    assert np.abs(got["x"] - ref["x"]).max() <= 1e-6
+    # (the blobs are nearly at rest by now: the velocities are compared on the scale they had, 40)
+    assert np.abs(got["v"] - ref["v"]).max() <= 40.0 * 1e-5 and rel_l2(got["F"], ref["F"]) <= 1e-4
+    for sim in sims + [one]:
+        sim.close()
+
+
 def test_native_migration_follows_a_moving_blob(tm):
     """the moving blob of test_migration_compacts_when_slots_run_out on the native data plane: adaptive schedule from the
     measured top speed, re-plans when the particles leave the clip box, compaction when slots run out — all inside the library"""
@@ -698,7 +755,9 @@ def test_bench_multi_rank_path_end_to_end_on_one_gpu(tm, nproc, bricks, hook, co
     assert all(t["max"][k] >= t["min"][k] >= 0 for k in t["max"]) and t["max"]["g2p"] > 0
     assert sum(r["particles"] for r in t["per_rank"]) == d["config"]["particles"]
     if hook in ("ipc", "fallback"):
-        assert t["wire"] == "ipc" and t["min"]["halo_bytes_per_substep"] > 0
+        # (c5: the clusters never meet — every rank's halo boxes are cut to its own occupancy, so NOTHING is exchanged; until round 6
+        # the boxes were cut to the job's bounding box only and 8 - 39 MB of empty slabs per rank travelled every substep)
+        assert t["wire"] == "ipc" and (t["min"]["halo_bytes_per_substep"] > 0) == (config != "c5") and (t["max"]["halo_bytes_per_substep"] > 0) == (config != "c5")
         assert t["totals"]["particles"] == d["config"]["particles"] and t["totals"]["error"] == 0
     if both:
         o = t["other_wire"]
