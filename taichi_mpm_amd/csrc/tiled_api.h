@@ -168,10 +168,15 @@ int tn_apply_plan(mpmhip_ctx *c) {
   // the overlap-free interior of this rank's node box and the device tables (as mpmhip_set_halo)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   T.n_boxes = 0; T.box_nodes = 0; T.box_blocks = 0;
+  // (the node box as the boxes were cut from it — clip box and occupancy included: a box that spans the CUT node box along an axis
+  // leaves the interior alone on that axis.  Until round 6 the uncut brick box stood here: a face box of a rank whose particles fill
+  // only part of its brick then "ended inside" the two tangential axes and took the whole occupied part out of the interior —
+  // at configs[3] over 8 bricks every block was boundary work and the overlap split had nothing to overlap the exchange with.
+  // Work outside the cut node box does not exist: the rank has no particle there.)
   int nlo[3], nhi[3];
+  tn_node_box(T, N.clip_lo, N.clip_hi, occ, T.rank, nlo, nhi);
   for (int a = 0; a < 3; a++) {
-    nlo[a] = std::max(0, T.lo[a] - T.margin);
-    nhi[a] = std::min(c->P.res[a] + 1, T.hi[a] + T.margin + 2);
+    if (nhi[a] < nlo[a]) nhi[a] = nlo[a];
     T.int_lo[a] = nlo[a]; T.int_hi[a] = nhi[a];
   }
   const size_t n = N.boxes.size();
