@@ -2,7 +2,7 @@
 of the last dispatch of an anchor kernel (default: the G2P kernel = one per rank and substep), with its count per anchor
 dispatch, mean duration and share of the window.  Names every runtime blit (__amd_rocclr_fillBufferAligned / copyBuffer) that a
 stepping loop issues, and what the kernels of ONE rank take at the per-rank problem size.
-usage: loop_census.py <kernel_trace.csv> [n_anchor_dispatches] [anchor substring]"""
+usage: loop_census.py <kernel_trace.csv> [n_anchor_dispatches] [anchor substring] [skip: that many anchor dispatches at the END are left out]"""
 import csv, sys, collections
 path = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
@@ -14,6 +14,9 @@ rows.sort()
 anc = [i for i, r in enumerate(rows) if anchor in r[2]]
 if not anc:
     sys.exit("no dispatch of %r" % anchor)
+skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+if skip:
+    anc = anc[:-skip]
 n = min(n, len(anc) - 1)
 # window: from the end of the anchor dispatch BEFORE the first counted one to the end of the last one = n whole substeps
 i0, i1 = anc[-n - 1] + 1, anc[-1]

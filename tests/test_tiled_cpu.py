@@ -59,6 +59,11 @@ def test_scene_partition_balances_the_c5_clusters_over_8_ranks():
         assert len(x) == 20 ** 3 * 8
         counts += np.bincount(part.rank_of_cells(tiled.base_cells(x, 1.0 / 128)), minlength=8)
     assert counts.sum() == 8 * 20 ** 3 * 8 and counts.min() == counts.max()  # one cluster per brick
+    # clusters that do not touch: the cut lies in the MIDDLE of the empty stretch between them (base cells 19..39 | 83..103 -> 61), not
+    # along the face of the lower cluster, where every particle that moves up a cell would cross into the next brick
+    assert all(part.cuts[a] == [0, 40 + (83 - 40) // 2, 128] for a in range(3)), part.cuts
+    assert tiled.balanced_cuts(None, 16, 2, hist=np.array([0, 0, 5, 5, 0, 0, 0, 0, 0, 0, 5, 5, 0, 0, 0, 0])) == [0, 7, 16]
+    assert tiled.balanced_cuts(None, 8, 2, hist=np.array([0, 3, 3, 3, 3, 3, 3, 0])) == [0, 4, 8]  # (no gap at the balance point: as before)
     # a single cube (C3) goes through the same builders
     c3 = dict(res=256, cells=100, material="sand")
     assert tiled.scene_groups(c3) == [("sand", (78, 78, 78), 100)]
