@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 for form in 1 0; do
   W=/tmp/prof_det_$form
   MPMHIP_DETERMINISTIC=1 MPMHIP_CELL_ORDER=$form rocprofv3 --kernel-trace --stats --output-format csv -d $W -o t -- \
-    python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-virtual --no-evolved > $O/r06_s_det_form$form.log 2>&1
+    python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-virtual --no-evolved --no-c5 > $O/r06_s_det_form$form.log 2>&1
   cp $W/t_kernel_stats.csv $O/r06_s_det_form${form}_kernel_stats.csv
   for st in lattice evolved; do
     MPMHIP_DETERMINISTIC=1 MPMHIP_CELL_ORDER=$form python $R/bench.py --state $st --no-cpu-baseline --no-virtual --no-evolved 2>/dev/null | grep '^{' | tail -1 > $O/r06_s_det_form${form}_$st.json
