@@ -201,3 +201,35 @@ def test_c3_hundred_substeps_from_the_lattice_and_from_the_evolved_state_match_t
     keep = np.isin(st["id"], a["id"])  # (the reference numbered the uploaded particles 0..n-1 in the order of st)
     assert np.array_equal(np.nonzero(keep)[0], b["id"])   # the same particles were deleted at the walls on both sides
     _statistics_match(a, b, mass, n, "evolved")
+
+
+def test_c3_two_runs_in_the_deterministic_mode_agree_bit_for_bit_at_full_size(tm):
+    """configs[2] at its full size (8 M sand particles, 17 576 blocks: a wave of the ordering launch takes several blocks, the ids
+    travel in the 4-byte array beside the keys) with a stirring velocity field, 12 substeps: two runs in the deterministic mode give the
+    same bits in every field; the default mode stays within the run-to-run spread of them"""
+    import hashlib
+
+    import bench
+    from taichi_mpm_amd.mpm import F_V
+    cfg = dict(bench.CONFIGS["c3"])
+
+    def run(det):
+        sim = bench.build_sim(tm, cfg, 0)
+        sim._ensure_ctx()
+        sim.set_deterministic(det)
+        x = sim.get_particles(sort_by_id=False)["x"]
+        sim.upload(F_V, _stir(x, 1.0))
+        sim.run_substeps(12)
+        p = sim.get_particles()
+        sim.close()
+        return p
+
+    a, b = run(True), run(True)
+    assert len(a["id"]) == 8000000 and np.array_equal(a["id"], b["id"])
+    for f in ("x", "v", "F", "aux"):
+        ha, hb = (hashlib.sha256(np.ascontiguousarray(q[f]).tobytes()).hexdigest() for q in (a, b))
+        assert ha == hb, (f, float(np.abs(a[f] - b[f]).max()))
+    del b
+    c = run(False)
+    assert np.array_equal(c["id"], a["id"])
+    assert np.abs(c["x"] - a["x"]).max() <= 2e-6 and rel_l2(c["v"], a["v"]) <= 1e-4 and rel_l2(c["F"], a["F"]) <= 1e-4
