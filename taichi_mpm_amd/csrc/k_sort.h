@@ -893,7 +893,7 @@ __global__ __launch_bounds__(256) void k_cell_order(Params P, const Counters *__
 // traffic is perm[] once, the ids once, out[] once, all in full lines.  The ordered entries overwrite the staged ones (a lane holds
 // its cell's entries in registers by then); a cell of more than 16 particles stores straight to out[] and leaves INVALID behind (no
 // slot number: the copy-out skips it).  A block of more than CO_CAP entries takes the per-lane walk.
-// 22 KiB of LDS and 76 VGPRs per workgroup: 6 workgroups per CU — the launch is a chain of three dependent round trips per block
+// 22 KiB of LDS and 71 VGPRs per workgroup: 7 workgroups per CU — the launch is a chain of three dependent round trips per block
 // (cell row, index, ids), so waves in flight are what it runs on.  Measured on one box (profiles/r06_w_co_ab.txt; the deterministic
 // mode's extra time per C3 substep): this form 45 us; entries padded to word e + e / 8 so that cell-major accesses fall on different
 // banks: 111 VGPRs 52 us, held to 96 / 80 by the launch bounds (spills) 50 / 57 us; the next block's row and index requested ahead

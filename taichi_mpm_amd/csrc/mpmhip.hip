@@ -1119,7 +1119,7 @@ static int do_sort(mpmhip_ctx *c) {
       const int cg = (int)std::min<uint64_t>(8192u, ((uint64_t)P.max_blocks * BC + 255) / 256);
       hipLaunchKernelGGL((compact ? k_cell_order<true> : k_cell_order<false>), dim3(cg), dim3(256), 0, st, P, (const Counters *)c->cnt,
                          (const uint32_t *)c->cell_start, (const uint32_t *)c->perm, (const float4 *)c->rg, c->rank);
-    } else {  // one wave per active block through LDS: 6 workgroups per CU (24 KiB each), a few blocks per wave
+    } else {  // one wave per active block through LDS: 7 workgroups per CU resident (22 KiB each), a few blocks per wave
       const int cg = (int)std::min<uint64_t>((uint64_t)c->n_cus * (uint64_t)c->cell_order_wgs, ((uint64_t)P.max_blocks + 3) / 4);
       hipLaunchKernelGGL((compact ? k_cell_order_blocks<true> : k_cell_order_blocks<false>), dim3(std::max(1, cg)), dim3(256), 0, st, P,
                          (const Counters *)c->cnt, (const uint32_t *)c->cell_start, (const uint32_t *)c->perm, (const float4 *)c->rg, c->rank);
